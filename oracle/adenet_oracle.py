@@ -1,0 +1,549 @@
+"""CPU oracle for the AdeNet / DeltaNet hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a NumPy restatement of the reference's training step.  It is the
+checker for the HIP path: only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it.  The product package
+(``ip_avsr_amd``) never imports anything under ``oracle/``.
+
+PARITY STATUS: *parity unpinned at the Theano/Lasagne boundary*.  The reference
+delegates all hot-path arithmetic to Theano + Lasagne (unpinned ``master.zip``,
+README.md:30-34), which are absent from /root/reference and cannot be installed
+here; no reference test pins a floating-point output of this path.
+What pins this oracle instead:
+  * finite-difference checks of every backward (tests/test_oracle.py, float64);
+  * ``torch.nn.LSTM`` on CPU as an independent second opinion for the recurrence
+    (same i,f,g,o gate order), incl. gradients;
+  * the closed-form delta operator against a literal transcription of the
+    reference's three nested scans (utils/signal.py:7-80) and the derived
+    known answers of SURVEY.md §8c;
+  * the host-side NumPy functions are pinned separately against golden vectors
+    produced by importing the reference (tests/golden/make_golden.py).
+
+Each function cites the reference file:line it restates.  Lasagne semantics
+(``[upstream]``) follow SURVEY.md Appendix A.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+GRAD_CLIP = 5.0  # grad_clipping=5. in every LSTMLayer, e.g. modelzoo/adenet_v2.py:53
+GATES = ("ingate", "forgetgate", "cell", "outgate")  # stacking order [upstream] App. A-3
+
+
+# --------------------------------------------------------------------------- #
+# nonlinearities: custom/nonlinearities.py:4-16 -> lasagne.nonlinearities
+# --------------------------------------------------------------------------- #
+def act_fwd(name, z):
+    if name in ("linear", "identity"):
+        return z
+    if name == "rectify":
+        return np.maximum(z, 0)
+    if name == "sigmoid":
+        return 1.0 / (1.0 + np.exp(-z))
+    if name == "tanh":
+        return np.tanh(z)
+    if name == "leaky_rectify":
+        return np.where(z > 0, z, z * z.dtype.type(0.01))
+    if name == "very_leaky_rectify":
+        return np.where(z > 0, z, z * z.dtype.type(1.0 / 3.0))
+    raise ValueError("unsupported nonlinearity %r" % (name,))
+
+
+def act_bwd(name, y, dy):
+    """dL/dz from the *output* y (every supported act is invertible enough).
+
+    relu'(0) is taken as 0 (Theano's 0.5*(x+|x|) form gives 0.5 at exactly 0; a
+    measure-zero divergence documented in DESIGN.md)."""
+    if name in ("linear", "identity"):
+        return dy
+    if name == "rectify":
+        return dy * (y > 0)
+    if name == "sigmoid":
+        return dy * y * (1 - y)
+    if name == "tanh":
+        return dy * (1 - y * y)
+    if name == "leaky_rectify":
+        return np.where(y > 0, dy, dy * y.dtype.type(0.01))
+    if name == "very_leaky_rectify":
+        return np.where(y > 0, dy, dy * y.dtype.type(1.0 / 3.0))
+    raise ValueError(name)
+
+
+def sigmoid(z):
+    return 1.0 / (1.0 + np.exp(-z))
+
+
+# --------------------------------------------------------------------------- #
+# Delta layer: custom/layers.py:105-121 -> utils/signal.py:59-80,26-39,7-23
+# --------------------------------------------------------------------------- #
+def delta_literal(A, theta):
+    """Literal transcription of ``delta_coeff`` (utils/signal.py:42-56) for one
+    (T,F) float32 sequence, including Theano's int32*float32 -> float64 upcast of
+    every term and the float32 cast of the accumulator after each theta
+    (utils/signal.py:19-21).  O(T*Theta*F); small cases only."""
+    A = np.asarray(A, dtype=np.float32)
+    T, F = A.shape
+    X = A.T
+    Y = np.concatenate([np.repeat(X[:, :1], theta, axis=1), X,
+                        np.repeat(X[:, -1:], theta, axis=1)], axis=1)
+    out = np.zeros((T, F), np.float32)
+    for t in range(T):
+        acc = np.zeros((F,), np.float32)
+        for th in range(1, theta + 1):
+            d = th * (Y[:, theta + t + th].astype(np.float64)
+                      - Y[:, theta + t - th].astype(np.float64)) / (2 * th * th)
+            acc = (acc.astype(np.float64) + d).astype(np.float32)
+        out[t] = acc
+    return out
+
+
+def append_delta_literal(A, theta):
+    """``append_delta_coeff`` (utils/signal.py:59-80): [A | delta(A) | delta(delta(A))]."""
+    d1 = delta_literal(A, theta)
+    d2 = delta_literal(d1, theta)
+    return np.concatenate([np.asarray(A, np.float32), d1, d2], axis=1)
+
+
+def delta_op(x, theta):
+    """Closed form of the delta operator along axis 1 of (B,T,F), any float dtype:
+    ``d[t] = sum_{k=1..theta} (x[clamp(t+k)] - x[clamp(t-k)]) / (2k)`` with indices
+    clamped to the *tensor* ends [0, T-1] (mask-blind)."""
+    B, T, F = x.shape
+    idx = np.arange(T)
+    out = np.zeros_like(x)
+    for k in range(1, theta + 1):
+        hi = np.minimum(idx + k, T - 1)
+        lo = np.maximum(idx - k, 0)
+        out = out + (x[:, hi] - x[:, lo]) * x.dtype.type(1.0 / (2 * k))
+    return out
+
+
+def delta_op_T(g, theta):
+    """Adjoint of ``delta_op`` (scatter form)."""
+    B, T, F = g.shape
+    idx = np.arange(T)
+    out = np.zeros_like(g)
+    for k in range(1, theta + 1):
+        hi = np.minimum(idx + k, T - 1)
+        lo = np.maximum(idx - k, 0)
+        w = g * g.dtype.type(1.0 / (2 * k))
+        np.add.at(out, (slice(None), hi), w)
+        np.add.at(out, (slice(None), lo), -w)
+    return out
+
+
+def delta_append(x, theta):
+    d1 = delta_op(x, theta)
+    d2 = delta_op(d1, theta)
+    return np.concatenate([x, d1, d2], axis=2)
+
+
+def delta_append_bwd(dout, theta):
+    F = dout.shape[2] // 3
+    g0, g1, g2 = dout[..., :F], dout[..., F:2 * F], dout[..., 2 * F:]
+    return g0 + delta_op_T(g1 + delta_op_T(g2, theta), theta)
+
+
+# --------------------------------------------------------------------------- #
+# LSTMLayer [upstream] as configured by custom/layers.py:10-25,55-80 and inline
+# in modelzoo/adenet_v2.py:45-63 -- semantics SURVEY App. A-3
+# --------------------------------------------------------------------------- #
+def _stack(p, prefix, kind):
+    return np.concatenate([p["%s.%s_to_%s" % (prefix, kind, g)] for g in GATES], axis=1)
+
+
+def lstm_fwd(x, mask, p, name, backwards=False, peepholes=False):
+    """x (B,T,F), mask (B,T) {0,1}.  Returns h_seq (B,T,H) and a cache."""
+    dt = x.dtype
+    B, T, F = x.shape
+    W_in = _stack(p, name, "W_in")
+    W_hid = _stack(p, name, "W_hid")
+    b = np.concatenate([p["%s.b_%s" % (name, g)] for g in GATES])
+    H = W_hid.shape[0]
+    xproj = (x.reshape(B * T, F) @ W_in + b).reshape(B, T, 4 * H)  # precompute_input=True
+    ones = np.ones((B, 1), dt)
+    h_prev = ones @ p[name + ".hid_init"]      # learn_init=True: (1,H) broadcast via dot
+    c_prev = ones @ p[name + ".cell_init"]
+    if peepholes:
+        w_ci, w_cf, w_co = (p["%s.W_cell_to_%s" % (name, g)] for g in ("ingate", "forgetgate", "outgate"))
+    hs = np.zeros((B, T, H), dt)
+    cache = dict(x=x, mask=mask, steps=[], W_in=W_in, W_hid=W_hid, H=H,
+                 backwards=backwards, peepholes=peepholes, name=name)
+    order = range(T - 1, -1, -1) if backwards else range(T)
+    for t in order:
+        gates = xproj[:, t] + h_prev @ W_hid
+        a_i, a_f, a_g, a_o = (gates[:, k * H:(k + 1) * H] for k in range(4))
+        if peepholes:
+            a_i = a_i + c_prev * w_ci
+            a_f = a_f + c_prev * w_cf
+        i, f, g = sigmoid(a_i), sigmoid(a_f), np.tanh(a_g)
+        c_new = f * c_prev + i * g
+        if peepholes:
+            a_o = a_o + c_new * w_co
+        o = sigmoid(a_o)
+        h_new = o * np.tanh(c_new)
+        m = mask[:, t].astype(bool)[:, None]
+        c = np.where(m, c_new, c_prev)
+        h = np.where(m, h_new, h_prev)
+        cache["steps"].append((t, i, f, g, o, c_new, c_prev, h_prev))
+        hs[:, t] = h
+        h_prev, c_prev = h, c
+    return hs, cache
+
+
+def lstm_bwd(dhs, cache, p, grads):
+    """BPTT with the gate-pre-activation gradient clipped to +-5 each step
+    (theano.gradient.grad_clip on ``gates`` before the peephole adds) [upstream]."""
+    name, H = cache["name"], cache["H"]
+    x, mask, W_in, W_hid = cache["x"], cache["mask"], cache["W_in"], cache["W_hid"]
+    peep = cache["peepholes"]
+    dt = x.dtype
+    B, T, F = x.shape
+    if peep:
+        w_ci, w_cf, w_co = (p["%s.W_cell_to_%s" % (name, g)] for g in ("ingate", "forgetgate", "outgate"))
+        dw_ci = np.zeros(H, dt); dw_cf = np.zeros(H, dt); dw_co = np.zeros(H, dt)
+    dxproj = np.zeros((B, T, 4 * H), dt)
+    dW_hid = np.zeros_like(W_hid)
+    dh = np.zeros((B, H), dt)
+    dc = np.zeros((B, H), dt)
+    for (t, i, f, g, o, c_new, c_prev, h_prev) in reversed(cache["steps"]):
+        dh = dh + dhs[:, t]
+        m = mask[:, t].astype(dt)[:, None]
+        dh_c, dh_p = dh * m, dh * (1 - m)
+        dc_c, dc_p = dc * m, dc * (1 - m)
+        tc = np.tanh(c_new)
+        da_o = dh_c * tc * o * (1 - o)
+        dcn = dc_c + dh_c * o * (1 - tc * tc)
+        if peep:
+            dcn = dcn + da_o * w_co
+            dw_co += (da_o * c_new).sum(0)
+        da_i = dcn * g * i * (1 - i)
+        da_f = dcn * c_prev * f * (1 - f)
+        da_g = dcn * i * (1 - g * g)
+        dc_p = dc_p + dcn * f
+        if peep:
+            dc_p = dc_p + da_i * w_ci + da_f * w_cf
+            dw_ci += (da_i * c_prev).sum(0)
+            dw_cf += (da_f * c_prev).sum(0)
+        dgates = np.clip(np.concatenate([da_i, da_f, da_g, da_o], axis=1), -GRAD_CLIP, GRAD_CLIP)
+        dxproj[:, t] = dgates
+        dW_hid += h_prev.T @ dgates
+        dh = dh_p + dgates @ W_hid.T
+        dc = dc_p
+    grads[name + ".hid_init"] = dh.sum(0, keepdims=True)
+    grads[name + ".cell_init"] = dc.sum(0, keepdims=True)
+    dxp = dxproj.reshape(B * T, 4 * H)
+    dW_in = x.reshape(B * T, F).T @ dxp
+    db = dxp.sum(0)
+    for k, gname in enumerate(GATES):
+        grads["%s.W_in_to_%s" % (name, gname)] = dW_in[:, k * H:(k + 1) * H]
+        grads["%s.W_hid_to_%s" % (name, gname)] = dW_hid[:, k * H:(k + 1) * H]
+        grads["%s.b_%s" % (name, gname)] = db[k * H:(k + 1) * H]
+    if peep:
+        grads[name + ".W_cell_to_ingate"] = dw_ci
+        grads[name + ".W_cell_to_forgetgate"] = dw_cf
+        grads[name + ".W_cell_to_outgate"] = dw_co
+    return (dxp @ W_in.T).reshape(B, T, F)
+
+
+# --------------------------------------------------------------------------- #
+# loss: custom/objectives.py:4-39 (double softmax)
+# --------------------------------------------------------------------------- #
+def softmax_rows(z):
+    e = np.exp(z - z.max(axis=-1, keepdims=True))
+    return e / e.sum(axis=-1, keepdims=True)
+
+
+def temporal_softmax_loss(x, y, mask):
+    """x (B,T,C) are *already probabilities*; they are soft-maxed again."""
+    N = x.shape[0] * x.shape[1]
+    xf = x.reshape(N, -1)
+    q = softmax_rows(xf)
+    mf = mask.reshape(N).astype(x.dtype)
+    total = mf.sum()
+    return -(mf * np.log(q[np.arange(N), y.reshape(N)])).sum() / total
+
+
+def temporal_softmax_loss_bwd(x, y, mask):
+    N = x.shape[0] * x.shape[1]
+    q = softmax_rows(x.reshape(N, -1))
+    mf = mask.reshape(N).astype(x.dtype)
+    q[np.arange(N), y.reshape(N)] -= 1
+    return (q * (mf / mf.sum())[:, None]).reshape(x.shape)
+
+
+# --------------------------------------------------------------------------- #
+# model spec + parameter order (Lasagne get_all_params order)
+# --------------------------------------------------------------------------- #
+def lstm_param_names(name, peepholes):
+    out = []
+    for g in GATES:
+        out += ["%s.W_in_to_%s" % (name, g), "%s.W_hid_to_%s" % (name, g), "%s.b_%s" % (name, g)]
+    if peepholes:
+        out += ["%s.W_cell_to_%s" % (name, g) for g in ("ingate", "forgetgate", "outgate")]
+    out += [name + ".cell_init", name + ".hid_init"]
+    return out
+
+
+def param_names(spec):
+    """spec: dict(streams=[dict(input_dim, enc_names, enc_shapes, enc_acts, delta,
+    lstm_names=[...1 or 2 (f,b)], peepholes)], fusion, fuse_name, agg_names=[f,b] or [],
+    agg_peepholes, lstm_size, classes, softmax_name)."""
+    names = []
+    for s in spec["streams"]:
+        for n in s["enc_names"]:
+            names += [n + ".W", n + ".b"]
+        for ln in s["lstm_names"]:
+            names += lstm_param_names(ln, s["peepholes"])
+    if spec["fusion"] == "adasum":
+        names += ["%s.adacoeff%d" % (spec["fuse_name"], k) for k in range(len(spec["streams"]))]
+    for ln in spec["agg_names"]:
+        names += lstm_param_names(ln, spec["agg_peepholes"])
+    names += [spec["softmax_name"] + ".W", spec["softmax_name"] + ".b"]
+    return names
+
+
+def lstm_in_dim(spec, s):
+    d = s["enc_shapes"][-1] if s["enc_shapes"] else s["input_dim"]
+    return d * 3 if s["delta"] else d
+
+
+def param_shapes(spec):
+    H, shapes = spec["lstm_size"], {}
+
+    def lstm(name, fin, peep):
+        for g in GATES:
+            shapes["%s.W_in_to_%s" % (name, g)] = (fin, H)
+            shapes["%s.W_hid_to_%s" % (name, g)] = (H, H)
+            shapes["%s.b_%s" % (name, g)] = (H,)
+        if peep:
+            for g in ("ingate", "forgetgate", "outgate"):
+                shapes["%s.W_cell_to_%s" % (name, g)] = (H,)
+        shapes[name + ".cell_init"] = (1, H)
+        shapes[name + ".hid_init"] = (1, H)
+
+    for s in spec["streams"]:
+        d = s["input_dim"]
+        for n, u in zip(s["enc_names"], s["enc_shapes"]):
+            shapes[n + ".W"] = (d, u)
+            shapes[n + ".b"] = (u,)
+            d = u
+        for ln in s["lstm_names"]:
+            lstm(ln, lstm_in_dim(spec, s), s["peepholes"])
+    S = len(spec["streams"])
+    if spec["fusion"] == "adasum":
+        for k in range(S):
+            shapes["%s.adacoeff%d" % (spec["fuse_name"], k)] = ()
+    fused = H * S if spec["fusion"] == "concat" else H
+    for ln in spec["agg_names"]:
+        lstm(ln, fused, spec["agg_peepholes"])
+    shapes[spec["softmax_name"] + ".W"] = (H, spec["classes"])
+    shapes[spec["softmax_name"] + ".b"] = (spec["classes"],)
+    return shapes
+
+
+def init_params(spec, rng, dtype=np.float32, enc_std=0.01, perturb=0.0):
+    """Synthetic parameters per SURVEY §8d: encoder N(0,enc_std) weights, LSTM /
+    softmax GlorotUniform, biases 0 (+ optional perturbation so that no parameter
+    sits at a degenerate value in gradient checks)."""
+    shapes, p = param_shapes(spec), {}
+    for n in param_names(spec):
+        shp = shapes[n]
+        leaf = n.split(".")[-1]
+        if leaf == "W" and not n.startswith(spec["softmax_name"] + "."):
+            v = rng.normal(0, enc_std, shp)
+        elif len(shp) == 2 and shp[0] > 1:
+            lim = np.sqrt(6.0 / (shp[0] + shp[1]))
+            v = rng.uniform(-lim, lim, shp)
+        elif leaf.startswith("adacoeff"):
+            v = np.ones(shp)
+        elif leaf.startswith("W_cell_to"):
+            v = rng.normal(0, 0.1, shp)      # Gate() default W_cell=Normal(0.1) [upstream] App. A-2
+        else:
+            v = np.zeros(shp)
+        if perturb:
+            v = v + rng.normal(0, perturb, shp)
+        p[n] = np.asarray(v, dtype)
+    return p
+
+
+# --------------------------------------------------------------------------- #
+# whole model: forward / loss / backward / Adam
+# --------------------------------------------------------------------------- #
+def forward(spec, p, inputs, mask, theta, want_cache=False):
+    """inputs: list of (B,T,D_s).  Returns probs (B,T,C) [, cache].
+    Graph: modelzoo/adenet_v2.py:30-92, adenet_3stream.py:166-262, adenet_4stream.py:37-157,
+    avnet.py:43-112, deltanet_majority_vote.py:31-66 (S=1, no aggregation layer)."""
+    B, T = mask.shape
+    H = spec["lstm_size"]
+    cache = dict(streams=[])
+    outs = []
+    for s, x in zip(spec["streams"], inputs):
+        sc = dict(acts=[x.reshape(B * T, -1)])
+        a = sc["acts"][0]
+        for n, act in zip(s["enc_names"], s["enc_acts"]):   # modelzoo/pretrained_encoder.py:4-9
+            a = act_fwd(act, a @ p[n + ".W"] + p[n + ".b"])
+            sc["acts"].append(a)
+        feat = a.reshape(B, T, -1)
+        sc["enc_out"] = feat
+        if s["delta"]:
+            feat = delta_append(feat, theta)
+        sc["lstm_in"] = feat
+        h = None
+        sc["lstm"] = []
+        for k, ln in enumerate(s["lstm_names"]):          # 1 = LSTM, 2 = BLSTM summed
+            hk, lc = lstm_fwd(feat, mask, p, ln, backwards=(k == 1), peepholes=s["peepholes"])
+            sc["lstm"].append(lc)
+            h = hk if h is None else h + hk
+        sc["h"] = h
+        outs.append(h)
+        cache["streams"].append(sc)
+    fusion = spec["fusion"]
+    if fusion == "concat":                                   # ConcatLayer(axis=-1)
+        fused = np.concatenate(outs, axis=2)
+    elif fusion == "sum":
+        fused = sum(outs)
+    elif fusion == "adasum":                                 # custom/layers.py:178-228
+        fused = sum(o * p["%s.adacoeff%d" % (spec["fuse_name"], k)] for k, o in enumerate(outs))
+    elif fusion == "none":
+        fused = outs[0]
+    else:
+        raise ValueError(fusion)
+    cache["fused"] = fused
+    cache["agg"] = []
+    if spec["agg_names"]:
+        hsum = None
+        for k, ln in enumerate(spec["agg_names"]):          # custom/layers.py:55-80 create_blstm
+            hk, lc = lstm_fwd(fused, mask, p, ln, backwards=(k == 1), peepholes=spec["agg_peepholes"])
+            cache["agg"].append(lc)
+            hsum = hk if hsum is None else hsum + hk
+    else:
+        hsum = fused
+    cache["hsum"] = hsum
+    sm = spec["softmax_name"]
+    probs = softmax_rows(hsum.reshape(B * T, H) @ p[sm + ".W"] + p[sm + ".b"]).reshape(B, T, -1)
+    cache["probs"] = probs
+    return (probs, cache) if want_cache else probs
+
+
+def loss_and_grads(spec, p, inputs, targets, mask, theta):
+    """targets (B,T) int (label repeated over T, runners/3stream.py:360-361)."""
+    B, T = mask.shape
+    H = spec["lstm_size"]
+    probs, cache = forward(spec, p, inputs, mask, theta, want_cache=True)
+    loss = temporal_softmax_loss(probs, targets, mask)
+    g = {}
+    dp = temporal_softmax_loss_bwd(probs, targets, mask).reshape(B * T, -1)
+    pf = probs.reshape(B * T, -1)
+    dz = pf * (dp - (dp * pf).sum(1, keepdims=True))       # through the network's own softmax
+    sm = spec["softmax_name"]
+    hs = cache["hsum"].reshape(B * T, H)
+    g[sm + ".W"] = hs.T @ dz
+    g[sm + ".b"] = dz.sum(0)
+    dhsum = (dz @ p[sm + ".W"].T).reshape(B, T, H)
+    if spec["agg_names"]:
+        dfused = 0
+        for lc in cache["agg"]:
+            dfused = dfused + lstm_bwd(dhsum, lc, p, g)
+    else:
+        dfused = dhsum
+    S = len(spec["streams"])
+    for k, (s, sc) in enumerate(zip(spec["streams"], cache["streams"])):
+        if spec["fusion"] == "concat":
+            dh = dfused[..., k * H:(k + 1) * H]
+        elif spec["fusion"] == "adasum":
+            an = "%s.adacoeff%d" % (spec["fuse_name"], k)
+            g[an] = np.asarray((dfused * sc["h"]).sum(), dtype=dfused.dtype)
+            dh = dfused * p[an]
+        else:
+            dh = dfused
+        dfeat = 0
+        for lc in sc["lstm"]:
+            dfeat = dfeat + lstm_bwd(dh, lc, p, g)
+        if s["delta"]:
+            dfeat = delta_append_bwd(dfeat, theta)
+        da = dfeat.reshape(B * T, -1)
+        for li in range(len(s["enc_names"]) - 1, -1, -1):
+            n, act = s["enc_names"][li], s["enc_acts"][li]
+            dzl = act_bwd(act, sc["acts"][li + 1], da)
+            g[n + ".W"] = sc["acts"][li].T @ dzl
+            g[n + ".b"] = dzl.sum(0)
+            da = dzl @ p[n + ".W"].T
+    return loss, g, cache
+
+
+def adam_init(p):
+    return dict(t=0, m={k: np.zeros_like(v) for k, v in p.items()},
+                v={k: np.zeros_like(v) for k, v in p.items()})
+
+
+def adam_step(p, g, state, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    """lasagne.updates.adam == custom/updates.py:73-99 with one learning rate."""
+    state["t"] += 1
+    t = state["t"]
+    for k in p:
+        dt = p[k].dtype.type
+        a_t = dt(lr) * np.sqrt(dt(1) - dt(beta2) ** dt(t)) / (dt(1) - dt(beta1) ** dt(t))
+        state["m"][k] = dt(beta1) * state["m"][k] + dt(1 - beta1) * g[k]
+        state["v"][k] = dt(beta2) * state["v"][k] + dt(1 - beta2) * g[k] * g[k]
+        p[k] = p[k] - a_t * state["m"][k] / (np.sqrt(state["v"][k]) + dt(eps))
+    return p
+
+
+def train_step(spec, p, state, inputs, targets, mask, theta, lr):
+    loss, g, _ = loss_and_grads(spec, p, inputs, targets, mask, theta)
+    adam_step(p, g, state, lr)
+    return loss
+
+
+def majority_vote(probs, mask):
+    """evaluate_model2 (runners/3stream.py:48-82): argmax over the first len_i frames,
+    vote histogram, argmax (ties -> lowest class id)."""
+    lens = mask.sum(-1).astype(int)
+    C = probs.shape[-1]
+    out = np.zeros(len(probs), int)
+    for i, eg in enumerate(probs):
+        pred = np.argmax(eg[:lens[i]], axis=-1)
+        out[i] = np.argmax(np.bincount(pred, minlength=C))
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# convenience spec builders mirroring the model zoo
+# --------------------------------------------------------------------------- #
+ENC_NAMES = ["fc1", "fc2", "fc3", "bottleneck"]
+
+
+def spec_nstream(input_dims, enc_shapes=(2000, 1000, 500, 50),
+                 enc_acts=("rectify", "rectify", "rectify", "linear"),
+                 lstm_size=250, classes=26, fusion="concat", peepholes=False,
+                 has_encoder=None, delta=None):
+    """adenet_{2,3,4}stream.create_model-shaped spec (modelzoo/adenet_3stream.py:145-262)."""
+    S = len(input_dims)
+    has_encoder = has_encoder or [True] * S
+    delta = delta or [True] * S
+    streams = []
+    for k, d in enumerate(input_dims):
+        sfx = "_s%d" % (k + 1)
+        enc = has_encoder[k]
+        streams.append(dict(input_dim=d,
+                            enc_names=[n + sfx for n in ENC_NAMES[:len(enc_shapes)]] if enc else [],
+                            enc_shapes=list(enc_shapes) if enc else [],
+                            enc_acts=list(enc_acts) if enc else [],
+                            delta=delta[k], lstm_names=["lstm" + sfx], peepholes=peepholes))
+    return dict(streams=streams, fusion=fusion, fuse_name={"adasum": "adasum1", "sum": "sum1",
+                                                           "concat": "concat"}[fusion],
+                agg_names=["f_lstm_agg", "b_lstm_agg"], agg_peepholes=False,
+                lstm_size=lstm_size, classes=classes, softmax_name="softmax")
+
+
+def spec_deltanet(input_dim, enc_shapes=(2000, 1000, 500, 50),
+                  enc_acts=("rectify", "rectify", "rectify", "linear"),
+                  lstm_size=250, classes=26, peepholes=False, use_blstm=True):
+    """deltanet_majority_vote.create_model (modelzoo/deltanet_majority_vote.py:14-66)."""
+    names = ["f_blstm1", "b_blstm1"] if use_blstm else ["lstm"]
+    return dict(streams=[dict(input_dim=input_dim, enc_names=ENC_NAMES[:len(enc_shapes)],
+                              enc_shapes=list(enc_shapes), enc_acts=list(enc_acts), delta=True,
+                              lstm_names=names, peepholes=peepholes)],
+                fusion="none", fuse_name="", agg_names=[], agg_peepholes=False,
+                lstm_size=lstm_size, classes=classes, softmax_name="softmax")
