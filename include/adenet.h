@@ -1,0 +1,176 @@
+/* adenet.h -- C ABI of libadenet_hip.so: the MI355X (gfx950) implementation of the AdeNet /
+ * DeltaNet training path of lzuwei/ip-avsr.
+ *
+ * The reference has no FFI: its boundary for this path is the Python surface its scripts use
+ *  -- a `create_model(...)` graph factory plus four compiled callables
+ * (`train`, `compute_train_cost`, `compute_test_cost`, `val_fn`) and Lasagne's parameter
+ * accessors.  Each entry point below names the reference interface it stands in for
+ * (paths relative to the reference repository).  The Python mirror of that surface lives in
+ * ip_avsr_amd/ (modelzoo/, model.py) and binds these symbols with ctypes; see INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain C types only; every function returns a status code of enum adn_status, 0 = ok, and records a message
+ *    retrievable with adn_last_error() (thread-local);
+ *  - stream inputs are float32 (B,T,D_s) C-contiguous batch-major, mask is uint8 (B,T),
+ *    targets are int32 (B,T) -- exactly what the reference's theano functions receive
+ *    (runners/3stream.py:276-281,309-320); pointers may be host or device memory
+ *    (ADN_FLAG_DEVICE_INPUTS / ADN_FLAG_DEVICE_OUTPUTS);
+ *  - all work is enqueued on the stream given to adn_set_stream (default: the null stream);
+ *    calls that return host data synchronise that stream before returning;
+ *  - a model is not thread-safe; use one model per GPU / per host thread (the reference's
+ *    caller is single-threaded).
+ */
+#ifndef ADENET_H_
+#define ADENET_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADN_MAX_STREAMS 8
+#define ADN_MAX_ENC_LAYERS 8
+#define ADN_MAX_CLASSES 64
+
+typedef enum {
+    ADN_OK = 0,
+    ADN_ERR_INVALID = 1,   /* bad argument / unsupported configuration */
+    ADN_ERR_HIP = 2,       /* a HIP runtime call failed */
+    ADN_ERR_NO_DEVICE = 3, /* no gfx950 device visible */
+    ADN_ERR_STATE = 4      /* call sequence error (e.g. apply_adam without gradients) */
+} adn_status;
+
+/* custom/nonlinearities.py:4-16 (the subset the DBN encoders use) */
+typedef enum {
+    ADN_ACT_LINEAR = 0,
+    ADN_ACT_RECTIFY = 1,
+    ADN_ACT_SIGMOID = 2,
+    ADN_ACT_TANH = 3,
+    ADN_ACT_LEAKY_RECTIFY = 4,     /* slope 0.01 */
+    ADN_ACT_VERY_LEAKY_RECTIFY = 5 /* slope 1/3  */
+} adn_act;
+
+/* fusiontype of modelzoo/adenet_v2.py:68-75 and friends */
+typedef enum { ADN_FUSE_NONE = 0, ADN_FUSE_SUM = 1, ADN_FUSE_ADASUM = 2, ADN_FUSE_CONCAT = 3 } adn_fusion;
+
+typedef enum {
+    ADN_PRECISION_F32 = 0 /* exact fp32 on the f32 MFMA pipe (parity-grade) */
+} adn_precision;
+
+enum { ADN_FLAG_DEVICE_INPUTS = 1, ADN_FLAG_DEVICE_OUTPUTS = 2 };
+
+/* which flat buffer a tensor accessor addresses */
+typedef enum { ADN_BUF_PARAM = 0, ADN_BUF_GRAD = 1, ADN_BUF_ADAM_M = 2, ADN_BUF_ADAM_V = 3 } adn_buffer;
+
+/* one input stream: [dense encoder] -> [delta layer] -> LSTM or summed BLSTM
+ * (modelzoo/pretrained_encoder.py:4-9, custom/layers.py:105-121, modelzoo/adenet_3stream.py:166-238) */
+typedef struct {
+    int32_t input_dim;
+    int32_t n_enc;                           /* 0: no encoder (e.g. a DCT stream) */
+    int32_t enc_units[ADN_MAX_ENC_LAYERS];
+    int32_t enc_act[ADN_MAX_ENC_LAYERS];     /* adn_act */
+    int32_t use_delta;                       /* DeltaLayer present */
+    int32_t bidirectional;                   /* 0: LSTMLayer, 1: forward+backward LSTMLayer summed */
+    int32_t peepholes;
+} adn_stream_config;
+
+/* the whole graph: S streams -> fusion -> aggregation (B)LSTM -> per-timestep softmax
+ * (modelzoo/adenet_v2.py:12-94, adenet_v2_2.py:40-132, adenet_2stream.py:116-210,
+ *  adenet_3stream.py:145-264, adenet_4stream.py:12-159, avnet.py:30-114,
+ *  deltanet_majority_vote.py:14-66, deltanet_v1.py:8-42, lstm_classifier_majority_vote.py:10-43) */
+typedef struct {
+    int32_t n_streams;
+    adn_stream_config streams[ADN_MAX_STREAMS];
+    int32_t fusion;          /* adn_fusion; ADN_FUSE_NONE requires n_streams == 1 */
+    int32_t agg;             /* 0: none (classifier on the stream output), 1: LSTM, 2: summed BLSTM */
+    int32_t agg_peepholes;
+    int32_t lstm_size;       /* H, all LSTMs */
+    int32_t classes;         /* C <= ADN_MAX_CLASSES */
+    int32_t precision;       /* adn_precision */
+    int32_t reserved[8];
+} adn_config;
+
+typedef struct adn_model adn_model;
+
+/* description of one trainable tensor, in Lasagne get_all_params order */
+typedef struct {
+    char name[96];      /* e.g. "stream0.enc1.W", "stream2.lstm0.W_hid_to_forgetgate", "agg1.cell_init",
+                           "fuse.adacoeff0", "softmax.b" */
+    int32_t ndim;       /* 0, 1 or 2 */
+    int64_t dims[2];
+    int64_t numel;
+} adn_param_info_t;
+
+const char* adn_version(void);
+const char* adn_last_error(void);
+/* number of visible HIP devices whose arch is gfx950 (0 if none / no driver) */
+int adn_device_count(void);
+
+/* <- modelzoo/<model>.create_model(...) : builds the graph, allocates parameters (zero-initialised:
+ * the caller injects values, like the reference injects DBN weights / Lasagne initialisers),
+ * gradients, Adam state.  Uses the current HIP device. */
+int adn_create(const adn_config* cfg, adn_model** out);
+void adn_destroy(adn_model* m);
+int adn_set_stream(adn_model* m, void* hip_stream);
+
+/* <- lasagne.layers.get_all_params / get_all_param_values / set_all_param_values
+ *    (runners/3stream.py:305,393,425; utils/io.py:40-48) */
+int adn_num_params(const adn_model* m);
+int adn_param_info(const adn_model* m, int index, adn_param_info_t* info);
+int adn_read_tensor(adn_model* m, int buffer /*adn_buffer*/, int index, float* host_dst);
+int adn_write_tensor(adn_model* m, int buffer /*adn_buffer*/, int index, const float* host_src);
+int64_t adn_total_param_count(const adn_model* m); /* logical elements (17 999 676 for 3-stream concat) */
+
+/* flat device buffers (physical layout incl. alignment padding); the gradient buffer is what a
+ * data-parallel caller all-reduces */
+int adn_flat_buffer(adn_model* m, int buffer /*adn_buffer*/, void** device_ptr, size_t* bytes);
+
+/* <- val_fn(inputs..., mask, window) -> probabilities (B,T,C)  (runners/3stream.py:320) */
+int adn_forward(adn_model* m, const void* const* inputs, const uint8_t* mask, int B, int T, int theta,
+                int flags, float* probs);
+
+/* <- compute_train_cost / compute_test_cost(inputs..., targets, mask, window) -> cost
+ *    (runners/3stream.py:311-318; identical here: no stochastic layers on this path) */
+int adn_loss(adn_model* m, const void* const* inputs, const int32_t* targets, const uint8_t* mask, int B,
+             int T, int theta, int flags, float* loss);
+
+/* forward + temporal_softmax_loss (custom/objectives.py:4-39) + back-propagation into the gradient
+ * buffer.  total_frames <= 0: normalise by this batch's valid frames (single-GPU semantics);
+ * > 0: normalise by that number (data parallel: the global count, so that the SUM of the ranks'
+ * gradients / losses equals the single-GPU result).  *loss is this call's share of the cost. */
+int adn_compute_grads(adn_model* m, const void* const* inputs, const int32_t* targets, const uint8_t* mask,
+                      int B, int T, int theta, int flags, double total_frames, float* loss);
+
+/* <- lasagne.updates.adam (runners/3stream.py:307; formula custom/updates.py:73-99): one step on
+ * the current gradient buffer; beta1=.9 beta2=.999 eps=1e-8 */
+int adn_apply_adam(adn_model* m, float learning_rate);
+int adn_adam_step_count(const adn_model* m);
+int adn_set_adam_step_count(adn_model* m, int t);
+
+/* <- train(inputs..., targets, mask, window) -> cost, parameters updated (runners/3stream.py:309-310,370) */
+int adn_train_step(adn_model* m, const void* const* inputs, const int32_t* targets, const uint8_t* mask,
+                   int B, int T, int theta, int flags, float learning_rate, float* loss);
+
+/* activations of the last forward pass, for parity checks: encoder layer `layer` (0-based) of
+ * stream `stream` as (B*T, units) batch-major rows (B,T order) */
+int adn_read_encoder_activation(adn_model* m, int stream, int layer, float* host_dst);
+
+int adn_synchronize(adn_model* m);
+
+/* ---- operator-level entry points (used by the parity tests and micro-benchmarks) -------------- */
+/* C (+)= op(A)*op(B) on device pointers; layout 0 = NN, 1 = NT (B given as [N][K]), 2 = TN (A as [K][M]) */
+int adn_op_gemm(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                int ldc, const float* bias, int act, int accumulate, void* hip_stream);
+/* utils/signal.py:59-80 on device: in (B,T,F) batch-major -> out (T,B,3F) time-major */
+int adn_op_delta_forward(const float* in, int ld_in, float* out, int ld_out, int B, int T, int F, int theta,
+                         void* hip_stream);
+int adn_op_delta_backward(const float* dout, int ld_out, float* din, int ld_in, int B, int T, int F, int theta,
+                          void* hip_stream);
+int adn_op_adam(float* p, const float* g, float* m, float* v, int64_t n, float a_t, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADENET_H_ */

@@ -1,0 +1,109 @@
+"""ctypes binding of libadenet_hip.so (the C ABI declared in include/adenet.h).
+
+The library is the ONLY compute path: if it is missing or cannot be loaded this module raises --
+there is deliberately no CPU fallback (the CPU restatement under oracle/ is test infrastructure
+and is never imported from here).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libadenet_hip.so")
+
+ADN_MAX_STREAMS = 8
+ADN_MAX_ENC_LAYERS = 8
+ADN_MAX_CLASSES = 64
+
+ADN_OK = 0
+ACT = {"linear": 0, "identity": 0, "rectify": 1, "sigmoid": 2, "tanh": 3, "leaky_rectify": 4,
+       "very_leaky_rectify": 5}
+FUSION = {"none": 0, "sum": 1, "adasum": 2, "concat": 3}
+FLAG_DEVICE_INPUTS = 1
+FLAG_DEVICE_OUTPUTS = 2
+BUF_PARAM, BUF_GRAD, BUF_ADAM_M, BUF_ADAM_V = 0, 1, 2, 3
+
+
+class StreamConfig(C.Structure):
+    _fields_ = [("input_dim", C.c_int32), ("n_enc", C.c_int32),
+                ("enc_units", C.c_int32 * ADN_MAX_ENC_LAYERS), ("enc_act", C.c_int32 * ADN_MAX_ENC_LAYERS),
+                ("use_delta", C.c_int32), ("bidirectional", C.c_int32), ("peepholes", C.c_int32)]
+
+
+class Config(C.Structure):
+    _fields_ = [("n_streams", C.c_int32), ("streams", StreamConfig * ADN_MAX_STREAMS),
+                ("fusion", C.c_int32), ("agg", C.c_int32), ("agg_peepholes", C.c_int32),
+                ("lstm_size", C.c_int32), ("classes", C.c_int32), ("precision", C.c_int32),
+                ("reserved", C.c_int32 * 8)]
+
+
+class ParamInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("ndim", C.c_int32), ("dims", C.c_int64 * 2), ("numel", C.c_int64)]
+
+
+class AdenetError(RuntimeError):
+    pass
+
+
+# every symbol include/adenet.h declares: (restype, argtypes)
+_P = C.c_void_p
+_SIGNATURES = {
+    "adn_version": (C.c_char_p, []),
+    "adn_last_error": (C.c_char_p, []),
+    "adn_device_count": (C.c_int, []),
+    "adn_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
+    "adn_destroy": (None, [_P]),
+    "adn_set_stream": (C.c_int, [_P, _P]),
+    "adn_num_params": (C.c_int, [_P]),
+    "adn_param_info": (C.c_int, [_P, C.c_int, C.POINTER(ParamInfo)]),
+    "adn_read_tensor": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "adn_write_tensor": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "adn_total_param_count": (C.c_int64, [_P]),
+    "adn_flat_buffer": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "adn_forward": (C.c_int, [_P, C.POINTER(_P), _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "adn_loss": (C.c_int, [_P, C.POINTER(_P), _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "adn_compute_grads": (C.c_int, [_P, C.POINTER(_P), _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _P]),
+    "adn_apply_adam": (C.c_int, [_P, C.c_float]),
+    "adn_adam_step_count": (C.c_int, [_P]),
+    "adn_set_adam_step_count": (C.c_int, [_P, C.c_int]),
+    "adn_train_step": (C.c_int, [_P, C.POINTER(_P), _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
+    "adn_read_encoder_activation": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "adn_synchronize": (C.c_int, [_P]),
+    "adn_op_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int, _P,
+                              C.c_int, C.c_int, _P]),
+    "adn_op_delta_forward": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "adn_op_delta_backward": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "adn_op_adam": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, _P]),
+}
+EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises AdenetError when the HIP library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AdenetError(
+            "HIP extension not built: %s is missing. Build it with `python -m ip_avsr_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the compute path." % LIB_PATH)
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise AdenetError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise AdenetError("%s does not export %s (stale build?)" % (LIB_PATH, name))
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != ADN_OK:
+        msg = load().adn_last_error()
+        raise AdenetError("libadenet_hip error %d: %s" % (status, msg.decode() if msg else "?"))

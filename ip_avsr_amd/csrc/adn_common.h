@@ -1,0 +1,130 @@
+// Internal helpers shared by the HIP sources of libadenet_hip.so (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/adenet.h"
+
+namespace adn {
+
+void set_error(const std::string& msg);
+
+#define ADN_HIP_CHECK(expr)                                                              \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            ::adn::set_error(std::string(#expr) + " failed: " + hipGetErrorString(_e) +  \
+                             " (" + __FILE__ + ":" + std::to_string(__LINE__) + ")");    \
+            return ADN_ERR_HIP;                                                          \
+        }                                                                                \
+    } while (0)
+
+#define ADN_CHECK(cond, code, msg)                                                       \
+    do {                                                                                 \
+        if (!(cond)) {                                                                   \
+            ::adn::set_error(std::string(msg) + " [" #cond "] (" + __FILE__ + ":" +      \
+                             std::to_string(__LINE__) + ")");                            \
+            return (code);                                                               \
+        }                                                                                \
+    } while (0)
+
+#define ADN_TRY(expr)                                                                    \
+    do {                                                                                 \
+        int _s = (expr);                                                                 \
+        if (_s != ADN_OK) return _s;                                                     \
+    } while (0)
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+// leading dimension (in floats) used for every matrix in HBM: rows start 32-byte aligned
+static inline int ld_of(int cols) { return (int)round_up(cols, 8); }
+
+// ---------------------------------------------------------------------------------------
+// GEMM:  C[M,N] (+)= op(A) * op(B)   fp32 in / fp32 accumulate on the f32 MFMA pipe
+// ---------------------------------------------------------------------------------------
+enum GemmLayout {
+    GEMM_NN = 0,  // A[M][K] (lda), B[K][N] (ldb)           forward:      Y  = X  * W
+    GEMM_NT = 1,  // A[M][K] (lda), B[N][K] (ldb)           input grad:   dX = dY * W^T
+    GEMM_TN = 2,  // A[K][M] (lda), B[K][N] (ldb)           weight grad:  dW = X^T * dY
+};
+
+struct GemmArgs {
+    int layout = GEMM_NN;
+    int M = 0, N = 0, K = 0;
+    const float* A = nullptr; int lda = 0;
+    const float* B = nullptr; int ldb = 0;
+    float* C = nullptr;       int ldc = 0;
+    const float* bias = nullptr;   // per output column, added before the activation
+    int act = ADN_ACT_LINEAR;      // activation applied to the result
+    int accumulate = 0;            // C += result (instead of C = result)
+    const float* Y = nullptr; int ldy = 0; int act_grad = ADN_ACT_LINEAR;
+                                   // result *= act_grad'(Y[row][col])  (back-prop through the
+                                   // activation of the layer that produced Y)
+    int precision = ADN_PRECISION_F32;
+};
+int gemm(const GemmArgs& g, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------
+// element-wise / HBM-bound kernels (elementwise.hip)
+// ---------------------------------------------------------------------------------------
+// batch-major (B,T,F) -> time-major (T,B,[F|dF|ddF]) with optional delta/delta-delta append
+int delta_forward(const float* in, int ld_in, float* out, int ld_out, int B, int T, int F, int theta,
+                  int append, hipStream_t s);
+// adjoint: time-major gradient (T,B,3F or F) -> batch-major (B,T,F)
+int delta_backward(const float* dout, int ld_out, float* din, int ld_in, int B, int T, int F, int theta,
+                   int append, hipStream_t s);
+// out[r][c] = sum_k alpha_k * in_k[r][c]  (alpha = device scalars or null for 1)
+int sum_k(int n_in, const float* const* in, const float* const* alpha, int ld_in, float* out, int ld_out,
+          int rows, int cols, hipStream_t s);
+// out[r][c] = alpha[0] * in[r][c]   (alpha device scalar)
+int scale_by(const float* in, int ld_in, const float* alpha, float* out, int ld_out, int rows, int cols,
+             hipStream_t s);
+// out[c] (+)= sum_r in[r][c]
+int col_sum(const float* in, int ld, int rows, int cols, float* out, int accumulate, hipStream_t s);
+// out[0] (+)= sum_{r,c} a[r][c]*b[r][c]
+int dot_all(const float* a, int lda, const float* b, int ldb, int rows, int cols, float* out,
+            float* scratch, hipStream_t s);
+// dz = dy * act'(y) in place on dy
+int act_backward(float* dy, int ld_dy, const float* y, int ld_y, int rows, int cols, int act, hipStream_t s);
+// mask (B,T) uint8 batch-major -> (T,B) time-major; total[0] = number of valid frames
+int mask_prepare(const uint8_t* mask_bt, uint8_t* mask_tb, int B, int T, float* total, hipStream_t s);
+// rows [0,B) of dst = vec (broadcast of a (1,H) init vector)
+int broadcast_rows(const float* vec, float* dst, int ld, int rows, int cols, hipStream_t s);
+// softmax classifier head + double-softmax temporal loss (custom/objectives.py:4-39)
+//   z (T*B rows, time-major, ldz) -> probs_bt (B,T,C) batch-major dense (may be null),
+//   row_loss[r] = -mask*log softmax(softmax(z))[y]  (if y != null), dz (may be null)
+int softmax_loss(const float* z, int ldz, int B, int T, int C, const uint8_t* mask_tb, const int32_t* y_bt,
+                 const float* total, float* probs_bt, float* row_loss, float* dz, int lddz, hipStream_t s);
+// out[0] = (sum_i v[i]) / total[0], fixed summation order
+int reduce_loss(const float* v, int n, const float* total, float* out, hipStream_t s);
+int adam_update(float* p, const float* g, float* m, float* v, int64_t n, float a_t, float beta1,
+                float beta2, float eps, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
+// LSTM recurrence (lstm.hip).  All matrices time-major; gate columns interleaved (unit, gate).
+// ---------------------------------------------------------------------------------------
+struct LstmStep {          // one LSTM instance taking part in a (possibly multi-LSTM) step launch
+    const float* W_hid;    // [H][ldg]   W_hid[k][4*u+g]
+    const float* peep;     // [3][ldh]   w_ci, w_cf, w_co  (null: no peepholes)
+    const float* xproj;    // [T*B][ldg] x*W_in + b, time-major
+    float* hbuf;           // [(T+1)*B][ldh]  see lstm.hip for the block convention
+    float* cbuf;           // [(T+1)*B][ldh]
+    float* gates;          // [T*B][ldg] post-activation i,f,g,o (saved for backward; may be null)
+    // backward only
+    float* dG;             // [T*B][ldg] clipped gradient wrt the gate pre-activations
+    const float* dhs;      // [T*B][ldh] gradient wrt the layer output
+    float* dh_carry;       // [B][ldh]
+    float* dc_state;       // [B][ldh]
+    float* dpeep_part;     // [3][ldh] accumulated peephole-weight gradients (null: none)
+    int backwards;
+};
+constexpr int kMaxLstmPerLaunch = 8;
+// runs all T steps of n (<= kMaxLstmPerLaunch) independent LSTMs of identical (B,T,H) concurrently
+int lstm_forward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
+// BPTT; on return dG holds d(gates) for every step, dh_carry / dc_state the gradient wrt the
+// initial state (per batch row)
+int lstm_backward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
+
+}  // namespace adn

@@ -1,0 +1,442 @@
+// HBM-bound kernels of the path: delta layer (+ layout change), fusion sums, bias/column reductions,
+// classifier softmax + the reference's double-softmax temporal loss, Adam.
+// Every kernel walks memory with the feature index on the lane (coalesced rows).
+#include "adn_common.h"
+#include <algorithm>
+#include <math.h>
+
+namespace adn {
+
+// =========================================================================================
+// Delta layer: custom/layers.py:105-121 -> utils/signal.py:59-80.
+//   d[t] = sum_{k=1..theta} (x[clamp(t+k)] - x[clamp(t-k)]) / (2k), clamp to [0, T-1] of the PADDED
+//   tensor (mask-blind); out = [x | d(x) | d(d(x))].
+// Input is batch-major (B,T,F) -- the order the encoder GEMMs produce -- and the output is
+// time-major (T,B,3F), the order the recurrence consumes: the layout change is free here.
+// One workgroup = one utterance x 32 features; the (T x 32) slab lives in LDS.
+// =========================================================================================
+constexpr int kDeltaFC = 32;
+
+__global__ __launch_bounds__(256) void delta_fwd_kernel(const float* __restrict__ in, int ld_in,
+                                                        float* __restrict__ out, int ld_out, int B, int T, int F,
+                                                        int theta, int append) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* xs = sm;                   // [T][32]
+    float* d1 = sm + T * kDeltaFC;    // [T][32]
+    const int b = blockIdx.x, f0 = blockIdx.y * kDeltaFC;
+    const int fl = threadIdx.x & 31, ts = threadIdx.x >> 5;
+    const int f = f0 + fl;
+    const bool fv = f < F;
+    for (int t = ts; t < T; t += 8) xs[t * kDeltaFC + fl] = fv ? in[((size_t)b * T + t) * ld_in + f] : 0.f;
+    __syncthreads();
+    if (!append) {
+        for (int t = ts; t < T; t += 8)
+            if (fv) out[((size_t)t * B + b) * ld_out + f] = xs[t * kDeltaFC + fl];
+        return;
+    }
+    for (int t = ts; t < T; t += 8) {
+        float acc = 0.f;
+        for (int k = 1; k <= theta; ++k) {
+            const int hi = min(t + k, T - 1), lo = max(t - k, 0);
+            acc += (xs[hi * kDeltaFC + fl] - xs[lo * kDeltaFC + fl]) * (0.5f / (float)k);
+        }
+        d1[t * kDeltaFC + fl] = acc;
+    }
+    __syncthreads();
+    for (int t = ts; t < T; t += 8) {
+        float acc = 0.f;
+        for (int k = 1; k <= theta; ++k) {
+            const int hi = min(t + k, T - 1), lo = max(t - k, 0);
+            acc += (d1[hi * kDeltaFC + fl] - d1[lo * kDeltaFC + fl]) * (0.5f / (float)k);
+        }
+        if (fv) {
+            float* o = out + ((size_t)t * B + b) * ld_out;
+            o[f] = xs[t * kDeltaFC + fl];
+            o[F + f] = d1[t * kDeltaFC + fl];
+            o[2 * F + f] = acc;
+        }
+    }
+}
+
+// (D^T g)[tau] for one feature column held in LDS with row stride kDeltaFC
+__device__ __forceinline__ float delta_adjoint_at(const float* g, int tau, int T, int theta) {
+    float acc = 0.f;
+    for (int k = 1; k <= theta; ++k) {
+        float plus, minus;
+        if (tau < T - 1) {
+            plus = (tau - k >= 0) ? g[(tau - k) * kDeltaFC] : 0.f;
+        } else {                       // every t with t + k >= T-1 clamps onto the last row
+            plus = 0.f;
+            for (int t = max(0, T - 1 - k); t <= T - 1; ++t) plus += g[t * kDeltaFC];
+        }
+        if (tau > 0) {
+            minus = (tau + k <= T - 1) ? g[(tau + k) * kDeltaFC] : 0.f;
+        } else {                       // every t with t - k <= 0 clamps onto row 0
+            minus = 0.f;
+            for (int t = 0; t <= min(k, T - 1); ++t) minus += g[t * kDeltaFC];
+        }
+        acc += (plus - minus) * (0.5f / (float)k);
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void delta_bwd_kernel(const float* __restrict__ dout, int ld_out,
+                                                        float* __restrict__ din, int ld_in, int B, int T, int F,
+                                                        int theta, int append) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* g2 = sm;                   // [T][32]  gradient wrt dd, later reused
+    float* r1 = sm + T * kDeltaFC;    // [T][32]  g1 + D^T g2
+    const int b = blockIdx.x, f0 = blockIdx.y * kDeltaFC;
+    const int fl = threadIdx.x & 31, ts = threadIdx.x >> 5;
+    const int f = f0 + fl;
+    const bool fv = f < F;
+    if (!append) {
+        for (int t = ts; t < T; t += 8)
+            if (fv) din[((size_t)b * T + t) * ld_in + f] = dout[((size_t)t * B + b) * ld_out + f];
+        return;
+    }
+    for (int t = ts; t < T; t += 8)
+        g2[t * kDeltaFC + fl] = fv ? dout[((size_t)t * B + b) * ld_out + 2 * F + f] : 0.f;
+    __syncthreads();
+    for (int t = ts; t < T; t += 8) {
+        const float g1 = fv ? dout[((size_t)t * B + b) * ld_out + F + f] : 0.f;
+        r1[t * kDeltaFC + fl] = g1 + delta_adjoint_at(g2 + fl, t, T, theta);
+    }
+    __syncthreads();
+    for (int t = ts; t < T; t += 8) {
+        if (fv) {
+            const float g0 = dout[((size_t)t * B + b) * ld_out + f];
+            din[((size_t)b * T + t) * ld_in + f] = g0 + delta_adjoint_at(r1 + fl, t, T, theta);
+        }
+    }
+}
+
+int delta_forward(const float* in, int ld_in, float* out, int ld_out, int B, int T, int F, int theta, int append,
+                  hipStream_t s) {
+    ADN_CHECK(T > 0 && B > 0 && F > 0, ADN_ERR_INVALID, "delta_forward: empty tensor");
+    const size_t lds = (size_t)2 * T * kDeltaFC * sizeof(float);
+    ADN_CHECK(lds <= 64 * 1024, ADN_ERR_INVALID, "delta layer: T too large (max 256 frames)");
+    hipLaunchKernelGGL(delta_fwd_kernel, dim3(B, cdiv(F, kDeltaFC)), dim3(256), lds, s, in, ld_in, out, ld_out, B, T,
+                       F, theta, append);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+int delta_backward(const float* dout, int ld_out, float* din, int ld_in, int B, int T, int F, int theta, int append,
+                   hipStream_t s) {
+    ADN_CHECK(T > 0 && B > 0 && F > 0, ADN_ERR_INVALID, "delta_backward: empty tensor");
+    const size_t lds = (size_t)2 * T * kDeltaFC * sizeof(float);
+    ADN_CHECK(lds <= 64 * 1024, ADN_ERR_INVALID, "delta layer: T too large (max 256 frames)");
+    hipLaunchKernelGGL(delta_bwd_kernel, dim3(B, cdiv(F, kDeltaFC)), dim3(256), lds, s, dout, ld_out, din, ld_in, B,
+                       T, F, theta, append);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+// =========================================================================================
+// small row-wise helpers
+// =========================================================================================
+struct SumKArgs {
+    const float* in[ADN_MAX_STREAMS];
+    const float* alpha[ADN_MAX_STREAMS];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void sum_k_kernel(SumKArgs a, int ld_in, float* __restrict__ out, int ld_out,
+                                                    int rows, int cols4) {
+    const int64_t total = (int64_t)rows * cols4;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int r = (int)(e / cols4), c = (int)(e % cols4) * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < a.n; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(a.in[k] + (size_t)r * ld_in + c);
+            const float w = a.alpha[k] ? *a.alpha[k] : 1.f;
+            acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+        }
+        *reinterpret_cast<float4*>(out + (size_t)r * ld_out + c) = acc;
+    }
+}
+
+static inline int grid_for(int64_t work_items) {
+    int64_t g = (work_items + 255) / 256;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(g, 2048));
+}
+
+// NOTE: operates on whole float4 groups up to round_up(cols,4) <= ld; pad columns of the inputs are
+// zero by construction, so the pad columns of the output stay zero.
+int sum_k(int n_in, const float* const* in, const float* const* alpha, int ld_in, float* out, int ld_out, int rows,
+          int cols, hipStream_t s) {
+    ADN_CHECK(n_in >= 1 && n_in <= ADN_MAX_STREAMS, ADN_ERR_INVALID, "sum_k: bad operand count");
+    SumKArgs a;
+    a.n = n_in;
+    for (int k = 0; k < n_in; ++k) { a.in[k] = in[k]; a.alpha[k] = alpha ? alpha[k] : nullptr; }
+    const int cols4 = cdiv(cols, 4);
+    hipLaunchKernelGGL(sum_k_kernel, dim3(grid_for((int64_t)rows * cols4)), dim3(256), 0, s, a, ld_in, out, ld_out,
+                       rows, cols4);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+int scale_by(const float* in, int ld_in, const float* alpha, float* out, int ld_out, int rows, int cols,
+             hipStream_t s) {
+    const float* ins[1] = {in};
+    const float* al[1] = {alpha};
+    return sum_k(1, ins, al, ld_in, out, ld_out, rows, cols, s);
+}
+
+// column sums: grid (col tiles of 64, row splits); 4 row-lanes per column, LDS combine, one atomic per
+// (column, split)
+__global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ in, int ld, int rows, int cols,
+                                                      float* __restrict__ out, int rows_per_split) {
+    __shared__ float part[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int r0 = blockIdx.y * rows_per_split, r1 = min(rows, r0 + rows_per_split);
+    float acc = 0.f;
+    if (c < cols)
+        for (int r = r0 + rl; r < r1; r += 4) acc += in[(size_t)r * ld + c];
+    part[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && c < cols) atomicAdd(out + c, part[0][cl] + part[1][cl] + part[2][cl] + part[3][cl]);
+}
+
+int col_sum(const float* in, int ld, int rows, int cols, float* out, int accumulate, hipStream_t s) {
+    if (!accumulate) ADN_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), s));
+    if (rows <= 0) return ADN_OK;
+    const int ctiles = cdiv(cols, 64);
+    int splits = std::max(1, std::min(cdiv(rows, 64), cdiv(1024, ctiles)));
+    const int rps = cdiv(rows, splits);
+    splits = cdiv(rows, rps);
+    hipLaunchKernelGGL(col_sum_kernel, dim3(ctiles, splits), dim3(256), 0, s, in, ld, rows, cols, out, rps);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void dot_all_kernel(const float* __restrict__ a, int lda,
+                                                      const float* __restrict__ b, int ldb, int rows, int cols,
+                                                      float* __restrict__ out) {
+    __shared__ float part[4];
+    const int64_t total = (int64_t)rows * cols;
+    float acc = 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int r = (int)(e / cols), c = (int)(e % cols);
+        acc += a[(size_t)r * lda + c] * b[(size_t)r * ldb + c];
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+int dot_all(const float* a, int lda, const float* b, int ldb, int rows, int cols, float* out, float* /*scratch*/,
+            hipStream_t s) {
+    hipLaunchKernelGGL(dot_all_kernel, dim3(grid_for((int64_t)rows * cols / 4 + 1)), dim3(256), 0, s, a, lda, b, ldb,
+                       rows, cols, out);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+__device__ __forceinline__ float act_grad_y(int act, float y) {
+    switch (act) {
+        case ADN_ACT_RECTIFY: return y > 0.f ? 1.f : 0.f;
+        case ADN_ACT_SIGMOID: return y * (1.f - y);
+        case ADN_ACT_TANH: return 1.f - y * y;
+        case ADN_ACT_LEAKY_RECTIFY: return y > 0.f ? 1.f : 0.01f;
+        case ADN_ACT_VERY_LEAKY_RECTIFY: return y > 0.f ? 1.f : (1.f / 3.f);
+        default: return 1.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(float* __restrict__ dy, int ld_dy, const float* __restrict__ y,
+                                                      int ld_y, int rows, int cols, int act) {
+    const int64_t total = (int64_t)rows * cols;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int r = (int)(e / cols), c = (int)(e % cols);
+        dy[(size_t)r * ld_dy + c] *= act_grad_y(act, y[(size_t)r * ld_y + c]);
+    }
+}
+
+int act_backward(float* dy, int ld_dy, const float* y, int ld_y, int rows, int cols, int act, hipStream_t s) {
+    if (act == ADN_ACT_LINEAR) return ADN_OK;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for((int64_t)rows * cols)), dim3(256), 0, s, dy, ld_dy, y, ld_y,
+                       rows, cols, act);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+// mask (B,T) -> (T,B); total = number of valid frames (single block: B*T is tiny)
+__global__ __launch_bounds__(256) void mask_prepare_kernel(const uint8_t* __restrict__ m_bt, uint8_t* __restrict__ m_tb,
+                                                           int B, int T, float* __restrict__ total) {
+    __shared__ int part[4];
+    int cnt = 0;
+    for (int e = threadIdx.x; e < B * T; e += 256) {
+        const int t = e / B, b = e % B;
+        const uint8_t v = m_bt[(size_t)b * T + t] ? 1 : 0;
+        m_tb[e] = v;
+        cnt += v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0 && total) *total = (float)(part[0] + part[1] + part[2] + part[3]);
+}
+
+int mask_prepare(const uint8_t* mask_bt, uint8_t* mask_tb, int B, int T, float* total, hipStream_t s) {
+    hipLaunchKernelGGL(mask_prepare_kernel, dim3(1), dim3(256), 0, s, mask_bt, mask_tb, B, T, total);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+__global__ __launch_bounds__(256) void broadcast_rows_kernel(const float* __restrict__ vec, float* __restrict__ dst,
+                                                             int ld, int rows, int cols) {
+    const int64_t total = (int64_t)rows * cols;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int r = (int)(e / cols), c = (int)(e % cols);
+        dst[(size_t)r * ld + c] = vec[c];
+    }
+}
+
+int broadcast_rows(const float* vec, float* dst, int ld, int rows, int cols, hipStream_t s) {
+    hipLaunchKernelGGL(broadcast_rows_kernel, dim3(grid_for((int64_t)rows * cols)), dim3(256), 0, s, vec, dst, ld,
+                       rows, cols);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+// =========================================================================================
+// classifier softmax (modelzoo/adenet_v2.py:89-92) + temporal_softmax_loss (custom/objectives.py:4-39)
+// The loss soft-maxes the network's probabilities a second time; kept.
+// One group of G lanes (32 or 64) per frame, class index on the lane.
+// =========================================================================================
+template <int G>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, G));
+    return v;
+}
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
+    return v;
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void softmax_loss_kernel(const float* __restrict__ z, int ldz, int B, int T, int C,
+                                                           const uint8_t* __restrict__ mask_tb,
+                                                           const int32_t* __restrict__ y_bt,
+                                                           const float* __restrict__ total,
+                                                           float* __restrict__ probs_bt, float* __restrict__ row_loss,
+                                                           float* __restrict__ dz, int lddz) {
+    const int rows = B * T;
+    const int r = (blockIdx.x * 256 + threadIdx.x) / G;
+    const int c = threadIdx.x % G;
+    if (r >= rows) return;                 // whole groups exit together (256 % G == 0)
+    const int t = r / B, b = r % B;
+    const bool cv = c < C;
+    const float zc = cv ? z[(size_t)r * ldz + c] : -INFINITY;
+    const float m1 = group_max<G>(zc);
+    const float e1 = cv ? expf(zc - m1) : 0.f;
+    const float p = e1 / group_sum<G>(e1);
+    if (probs_bt && cv) probs_bt[((size_t)b * T + t) * C + c] = p;
+    if (!y_bt) return;
+    const float m2 = group_max<G>(cv ? p : -INFINITY);
+    const float e2 = cv ? expf(p - m2) : 0.f;
+    const float s2 = group_sum<G>(e2);
+    const float q = e2 / s2;
+    const int y = y_bt[(size_t)b * T + t];
+    const float msk = mask_tb[r] ? 1.f : 0.f;
+    if (row_loss && c == y) row_loss[r] = msk * -(p - m2 - logf(s2));
+    if (dz) {
+        const float dp = cv ? (msk / total[0]) * (q - (c == y ? 1.f : 0.f)) : 0.f;
+        const float dot = group_sum<G>(dp * p);
+        if (cv) dz[(size_t)r * lddz + c] = p * (dp - dot);
+    }
+}
+
+int softmax_loss(const float* z, int ldz, int B, int T, int C, const uint8_t* mask_tb, const int32_t* y_bt,
+                 const float* total, float* probs_bt, float* row_loss, float* dz, int lddz, hipStream_t s) {
+    ADN_CHECK(C >= 1 && C <= ADN_MAX_CLASSES, ADN_ERR_INVALID, "softmax: unsupported number of classes");
+    const int rows = B * T;
+    if (C <= 32) {
+        hipLaunchKernelGGL(softmax_loss_kernel<32>, dim3(cdiv(rows, 8)), dim3(256), 0, s, z, ldz, B, T, C, mask_tb,
+                           y_bt, total, probs_bt, row_loss, dz, lddz);
+    } else {
+        hipLaunchKernelGGL(softmax_loss_kernel<64>, dim3(cdiv(rows, 4)), dim3(256), 0, s, z, ldz, B, T, C, mask_tb,
+                           y_bt, total, probs_bt, row_loss, dz, lddz);
+    }
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+// single block, fixed summation order -> reproducible loss value
+__global__ __launch_bounds__(256) void reduce_loss_kernel(const float* __restrict__ v, int n,
+                                                          const float* __restrict__ total, float* __restrict__ out) {
+    __shared__ float part[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += v[i];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = part[0] / total[0];
+}
+
+int reduce_loss(const float* v, int n, const float* total, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(256), 0, s, v, n, total, out);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+// =========================================================================================
+// Adam: lasagne.updates.adam == custom/updates.py:73-99.  a_t = lr*sqrt(1-b2^t)/(1-b1^t) from the host.
+// 7 floats of traffic per parameter (read p,g,m,v; write p,m,v): pure HBM stream, float4 per lane.
+// =========================================================================================
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n4,
+                                                   int64_t n, float a_t, float b1, float b2, float eps) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+#define ADN_ADAM1(x)                                         \
+        mm.x = b1 * mm.x + (1.f - b1) * gg.x;                \
+        vv.x = b2 * vv.x + (1.f - b2) * gg.x * gg.x;         \
+        pp.x = pp.x - a_t * mm.x / (sqrtf(vv.x) + eps);
+        ADN_ADAM1(x) ADN_ADAM1(y) ADN_ADAM1(z) ADN_ADAM1(w)
+#undef ADN_ADAM1
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) {      // tail (n not a multiple of 4)
+        const int64_t i = n4 * 4 + threadIdx.x;
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] = p[i] - a_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+int adam_update(float* p, const float* g, float* m, float* v, int64_t n, float a_t, float beta1, float beta2,
+                float eps, hipStream_t s) {
+    if (n <= 0) return ADN_OK;
+    const int64_t n4 = n / 4;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(std::max<int64_t>(n4, 1))), dim3(256), 0, s, p, g, m, v, n4, n, a_t,
+                       beta1, beta2, eps);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+}  // namespace adn

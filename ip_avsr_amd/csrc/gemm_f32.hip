@@ -1,0 +1,259 @@
+// fp32 GEMM on the gfx950 f32 MFMA pipe (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma chain).
+//
+// Used for every matmul-shaped op of the path that is not inside the recurrence:
+//   dense encoder forward      Y  = act(X W + b)            (modelzoo/pretrained_encoder.py:4-9)   NN
+//   input gradients            dX = (dY W^T) * act'(Y)                                              NT
+//   weight gradients           dW = X^T dY                  (split-K, fp32 atomics)                 TN
+//   LSTM input projections     xproj = X W_in + b           (Lasagne precompute_input [upstream])   NN
+//
+// Structure: 256 threads = 4 waves in a 2x2 arrangement over a BMxBN block tile, BK = 32 per LDS
+// stage, register prefetch of the next stage while the current one feeds the MFMAs.  Each operand
+// is staged in LDS in the orientation it has in HBM ("k-contiguous" rows read back with one
+// ds_read_b128 per four k-steps, "k-strided" rows with four conflict-free ds_read_b32), so no
+// transposing stores are needed for any of the three layouts.  The f32 MFMA issues once per 64
+// cycles per SIMD, so one LDS fragment read per MFMA keeps the kernel MFMA-bound.
+#include "adn_common.h"
+#include <algorithm>
+
+namespace adn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmParams {
+    int M, N, K;
+    const float* A; int lda;
+    const float* B; int ldb;
+    float* C;       int ldc;
+    const float* bias;
+    const float* Y; int ldy;
+    int act, act_grad, accumulate, atomic;
+    int k_chunk;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ float act_apply(int act, float v) {
+    switch (act) {
+        case ADN_ACT_RECTIFY: return v > 0.f ? v : 0.f;
+        case ADN_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        case ADN_ACT_TANH: return tanhf(v);
+        case ADN_ACT_LEAKY_RECTIFY: return v > 0.f ? v : 0.01f * v;
+        case ADN_ACT_VERY_LEAKY_RECTIFY: return v > 0.f ? v : (1.f / 3.f) * v;
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ float act_grad_from_output(int act, float y) {
+    switch (act) {
+        case ADN_ACT_RECTIFY: return y > 0.f ? 1.f : 0.f;
+        case ADN_ACT_SIGMOID: return y * (1.f - y);
+        case ADN_ACT_TANH: return 1.f - y * y;
+        case ADN_ACT_LEAKY_RECTIFY: return y > 0.f ? 1.f : 0.01f;
+        case ADN_ACT_VERY_LEAKY_RECTIFY: return y > 0.f ? 1.f : (1.f / 3.f);
+        default: return 1.f;
+    }
+}
+
+constexpr int BK = 32;
+constexpr int PAD = 4;
+
+// One operand tile.  KC (k-contiguous): global [R rows][k], LDS [R][BK+PAD].
+//                    !KC (k-strided):   global [k][R cols], LDS [BK][R+PAD].
+template <int R, bool KC>
+struct OperandTile {
+    static constexpr int kVecPerThread = R * BK / 4 / 256;   // float4 per thread per stage
+    static constexpr int kLdsFloats = KC ? R * (BK + PAD) : BK * (R + PAD);
+
+    // r0: first row (KC) / first column (!KC) of the tile, rmax: logical extent in that dimension
+    __device__ __forceinline__ static void load(float4 (&v)[kVecPerThread], const float* __restrict__ g, int ld,
+                                                int r0, int rmax, int k0, int kend, int tid) {
+#pragma unroll
+        for (int i = 0; i < kVecPerThread; ++i) {
+            const int f = tid + 256 * i;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (KC) {
+                const int row = r0 + (f >> 3);
+                const int k = k0 + ((f & 7) << 2);
+                if (row < rmax && k < kend) {
+                    x = *reinterpret_cast<const float4*>(g + (size_t)row * ld + k);
+                    if (k + 1 >= kend) x.y = 0.f;
+                    if (k + 2 >= kend) x.z = 0.f;
+                    if (k + 3 >= kend) x.w = 0.f;
+                }
+            } else {
+                constexpr int V = R / 4;       // float4 per k-row
+                const int k = k0 + f / V;
+                const int c = r0 + ((f % V) << 2);
+                if (k < kend && c < rmax) {
+                    x = *reinterpret_cast<const float4*>(g + (size_t)k * ld + c);
+                    if (c + 1 >= rmax) x.y = 0.f;
+                    if (c + 2 >= rmax) x.z = 0.f;
+                    if (c + 3 >= rmax) x.w = 0.f;
+                }
+            }
+            v[i] = x;
+        }
+    }
+
+    __device__ __forceinline__ static void store(const float4 (&v)[kVecPerThread], float* lds, int tid) {
+#pragma unroll
+        for (int i = 0; i < kVecPerThread; ++i) {
+            const int f = tid + 256 * i;
+            if (KC) {
+                *reinterpret_cast<float4*>(lds + (f >> 3) * (BK + PAD) + ((f & 7) << 2)) = v[i];
+            } else {
+                constexpr int V = R / 4;
+                *reinterpret_cast<float4*>(lds + (f / V) * (R + PAD) + ((f % V) << 2)) = v[i];
+            }
+        }
+    }
+
+    // the four k-values {8*s + 4*h + q, q=0..3} of tile row/column `r` for this lane half h
+    __device__ __forceinline__ static float4 frag(const float* lds, int r, int s, int h) {
+        if (KC) {
+            return *reinterpret_cast<const float4*>(lds + r * (BK + PAD) + 8 * s + 4 * h);
+        } else {
+            const float* p = lds + (8 * s + 4 * h) * (R + PAD) + r;
+            return make_float4(p[0], p[R + PAD], p[2 * (R + PAD)], p[3 * (R + PAD)]);
+        }
+    }
+};
+
+template <int BM, int BN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
+    using TA = OperandTile<BM, A_KC>;
+    using TB = OperandTile<BN, B_KC>;
+    constexpr int WTM = BM / 2, WTN = BN / 2;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    __shared__ __attribute__((aligned(16))) float smem[TA::kLdsFloats + TB::kLdsFloats];
+    float* As = smem;
+    float* Bs = smem + TA::kLdsFloats;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x;
+    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+    const int kbeg = blockIdx.y * p.k_chunk;
+    const int kend = min(p.K, kbeg + p.k_chunk);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    float4 ra[TA::kVecPerThread], rb[TB::kVecPerThread];
+    TA::load(ra, p.A, p.lda, m0, p.M, kbeg, kend, tid);
+    TB::load(rb, p.B, p.ldb, n0, p.N, kbeg, kend, tid);
+
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        TA::store(ra, As, tid);
+        TB::store(rb, Bs, tid);
+        __syncthreads();
+        if (k0 + BK < kend) {
+            TA::load(ra, p.A, p.lda, m0, p.M, k0 + BK, kend, tid);
+            TB::load(rb, p.B, p.ldb, n0, p.N, k0 + BK, kend, tid);
+        }
+#pragma unroll
+        for (int s = 0; s < BK / 8; ++s) {
+            float4 fa[TM], fb[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) fa[a] = TA::frag(As, wm * WTM + a * 32 + i, s, h);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) fb[b] = TB::frag(Bs, wn * WTN + b * 32 + i, s, h);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].x, fb[b].x, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].y, fb[b].y, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].z, fb[b].z, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, fb[b].w, acc[a][b], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const bool first_split = blockIdx.y == 0;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int col = n0 + wn * WTN + b * 32 + i;
+            if (col >= p.N) continue;
+            const float bias = (p.bias && first_split) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * WTM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= p.M) continue;
+                float v = acc[a][b][r] + bias;
+                float* c = p.C + (size_t)row * p.ldc + col;
+                if (p.atomic) {
+                    if (p.Y) v *= act_grad_from_output(p.act_grad, p.Y[(size_t)row * p.ldy + col]);
+                    atomicAdd(c, v);
+                } else {
+                    v = act_apply(p.act, v);
+                    if (p.Y) v *= act_grad_from_output(p.act_grad, p.Y[(size_t)row * p.ldy + col]);
+                    if (p.accumulate) v += *c;
+                    *c = v;
+                }
+            }
+        }
+}
+
+template <int BM, int BN>
+static void launch(const GemmParams& p, int layout, dim3 grid, hipStream_t s) {
+    switch (layout) {
+        case GEMM_NN: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, dim3(256), 0, s, p); break;
+        case GEMM_NT: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, dim3(256), 0, s, p); break;
+        default:      hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, dim3(256), 0, s, p); break;
+    }
+}
+
+int gemm(const GemmArgs& g, hipStream_t stream) {
+    ADN_CHECK(g.layout >= GEMM_NN && g.layout <= GEMM_TN, ADN_ERR_INVALID, "gemm: bad layout");
+    if (g.M <= 0 || g.N <= 0) return ADN_OK;
+    ADN_CHECK(g.K > 0, ADN_ERR_INVALID, "gemm: K must be positive");
+    ADN_CHECK(g.A && g.B && g.C, ADN_ERR_INVALID, "gemm: null operand");
+    ADN_CHECK(g.lda % 4 == 0 && g.ldb % 4 == 0, ADN_ERR_INVALID, "gemm: lda/ldb must be multiples of 4 floats");
+    ADN_CHECK(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0, ADN_ERR_INVALID,
+              "gemm: A and B must be 16-byte aligned");
+    ADN_CHECK(g.precision == ADN_PRECISION_F32, ADN_ERR_INVALID, "gemm: unsupported precision");
+
+    GemmParams p;
+    p.M = g.M; p.N = g.N; p.K = g.K;
+    p.A = g.A; p.lda = g.lda; p.B = g.B; p.ldb = g.ldb; p.C = g.C; p.ldc = g.ldc;
+    p.bias = g.bias; p.Y = g.Y; p.ldy = g.ldy;
+    p.act = g.act; p.act_grad = g.act_grad; p.accumulate = g.accumulate;
+
+    const int64_t t128 = (int64_t)cdiv(g.M, 128) * cdiv(g.N, 128);
+    const int64_t t64 = (int64_t)cdiv(g.M, 64) * cdiv(g.N, 64);
+    const bool big = t128 >= 384;            // >= 1.5 waves of 128x128 tiles over the 256 CUs
+    const int64_t tiles = big ? t128 : t64;
+    int split = 1;
+    if (tiles < 256 && g.K >= 512 && g.act == ADN_ACT_LINEAR) {
+        split = (int)((768 + tiles - 1) / tiles);
+        split = std::min(split, g.K / 128);
+        split = std::max(1, std::min(split, 128));
+    }
+    p.k_chunk = (int)round_up(cdiv(g.K, split), BK);
+    split = cdiv(g.K, p.k_chunk);
+    p.atomic = split > 1;
+    if (p.atomic && !g.accumulate)
+        ADN_HIP_CHECK(hipMemset2DAsync(g.C, (size_t)g.ldc * 4, 0, (size_t)g.N * 4, g.M, stream));
+    if (big) {
+        p.tiles_m = cdiv(g.M, 128); p.tiles_n = cdiv(g.N, 128);
+        launch<128, 128>(p, g.layout, dim3((unsigned)tiles, split), stream);
+    } else {
+        p.tiles_m = cdiv(g.M, 64); p.tiles_n = cdiv(g.N, 64);
+        launch<64, 64>(p, g.layout, dim3((unsigned)tiles, split), stream);
+    }
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+}  // namespace adn

@@ -1,0 +1,238 @@
+// LSTM recurrence, forward and BPTT (Lasagne LSTMLayer semantics, SURVEY.md App. A-3, as configured by
+// custom/layers.py:10-25,55-80 and modelzoo/adenet_v2.py:45-63: mask holds (c,h) on padded steps,
+// learn_init, optional peepholes, grad_clipping=5 on the gate pre-activations, backwards=True for b_*).
+//
+// Data layout (all time-major, row r = t*B + b):
+//   xproj / gates / dG : [T*B][ldg], gate columns INTERLEAVED per hidden unit: column 4*u+g holds gate
+//                        g in (i,f,g,o) of unit u, so one float4 per (row, unit) carries all four gates.
+//                        W_in, W_hid, b are stored with the same column order, which makes every GEMM
+//                        on the LSTM side (projection, dX, dW_in, dW_hid) layout-agnostic.
+//   hbuf / cbuf        : [(T+1)*B][ldh] = T+1 blocks of B rows.  Forward LSTM: block 0 = initial state,
+//                        block t+1 = state after frame t.  backwards=True: block T = initial state,
+//                        block t = state after frame t.  Either way the T output blocks and the T
+//                        "previous state" blocks are each one contiguous [T*B][ldh] matrix, so
+//                        dW_hid = H_prev^T dG is ONE GEMM after the recurrence instead of T small ones.
+//
+// v1 structure: one launch per time step covering every LSTM that is independent at that depth
+// (the S stream LSTMs, then the two aggregation LSTMs), blockIdx.z = LSTM.  Each workgroup owns a
+// (rows x hidden-units) tile, splits the K dimension of  h_prev * W_hid  over its 4 waves (one per
+// SIMD = one MFMA pipe each), reduces the four partial tiles through LDS and applies the gate math to
+// its own (row, unit) elements -- the recurrent GEMM and the gate fusion never leave the CU.
+// Operands go straight from L2 to VGPRs: with K split over the waves nothing is shared between them.
+#include "adn_common.h"
+#include <algorithm>
+
+namespace adn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct LstmLaunch {
+    LstmStep l[kMaxLstmPerLaunch];
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float clip5(float x) { return fminf(fmaxf(x, -5.f), 5.f); }
+
+// -----------------------------------------------------------------------------------------
+// forward step: tile = 32 batch rows x 8 hidden units (x 4 gates = 32 gate columns), MFMA 32x32x2 f32
+// -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_fwd_step_kernel(const LstmLaunch L, const uint8_t* __restrict__ mask_tb,
+                                                            int B, int T, int H, int ldh, int ldg, int step,
+                                                            int kc) {
+    __shared__ __attribute__((aligned(16))) float part[4][32][36];
+    const LstmStep& P = L.l[blockIdx.z];
+    const int t = P.backwards ? (T - 1 - step) : step;
+    const int prev_blk = t + (P.backwards ? 1 : 0), out_blk = t + (P.backwards ? 0 : 1);
+    const int r0 = blockIdx.x * 32, u0 = blockIdx.y * 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, hh = lane >> 5;
+
+    const float* hprev = P.hbuf + (size_t)prev_blk * B * ldh;
+    const int arow = min(r0 + i, B - 1);
+    const int bcol = u0 * 4 + i;                       // gate column owned by this lane (B operand)
+    const bool bcol_ok = (u0 + (i >> 2)) < H;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int kbeg = wave * kc;
+    for (int kk = 0; kk < kc; kk += 8) {
+        const int k = kbeg + kk + 4 * hh;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+        if (k < H) {
+            a = *reinterpret_cast<const float4*>(hprev + (size_t)arow * ldh + k);
+            if (bcol_ok) {
+                const float* w = P.W_hid + (size_t)k * ldg + bcol;
+                b0 = w[0];
+                if (k + 1 < H) b1 = w[ldg];
+                if (k + 2 < H) b2 = w[2 * (size_t)ldg];
+                if (k + 3 < H) b3 = w[3 * (size_t)ldg];
+            }
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b3, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * hh][i] = acc[r];
+    __syncthreads();
+
+    const int row = tid >> 3, ul = tid & 7;
+    const int r = r0 + row, u = u0 + ul;
+    if (r >= B || u >= H) return;
+    float4 g = *reinterpret_cast<const float4*>(&part[0][row][ul * 4]);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        const float4 x = *reinterpret_cast<const float4*>(&part[w][row][ul * 4]);
+        g.x += x.x; g.y += x.y; g.z += x.z; g.w += x.w;
+    }
+    const float4 xp = *reinterpret_cast<const float4*>(P.xproj + ((size_t)t * B + r) * ldg + u * 4);
+    float a_i = xp.x + g.x, a_f = xp.y + g.y, a_g = xp.z + g.z, a_o = xp.w + g.w;
+    const size_t prev_idx = ((size_t)prev_blk * B + r) * ldh + u;
+    const size_t out_idx = ((size_t)out_blk * B + r) * ldh + u;
+    const float c_prev = P.cbuf[prev_idx], h_prev = P.hbuf[prev_idx];
+    if (P.peep) { a_i += c_prev * P.peep[u]; a_f += c_prev * P.peep[ldh + u]; }
+    const float gi = sigmoidf_(a_i), gf = sigmoidf_(a_f), gg = tanhf(a_g);
+    const float c_new = gf * c_prev + gi * gg;
+    if (P.peep) a_o += c_new * P.peep[2 * ldh + u];
+    const float go = sigmoidf_(a_o);
+    const float h_new = go * tanhf(c_new);
+    const bool m = mask_tb[(size_t)t * B + r] != 0;
+    P.cbuf[out_idx] = m ? c_new : c_prev;
+    P.hbuf[out_idx] = m ? h_new : h_prev;
+    if (P.gates) *reinterpret_cast<float4*>(P.gates + ((size_t)t * B + r) * ldg + u * 4) = make_float4(gi, gf, gg, go);
+}
+
+int lstm_forward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s) {
+    ADN_CHECK(n >= 1 && n <= kMaxLstmPerLaunch, ADN_ERR_INVALID, "lstm_forward: bad LSTM count");
+    LstmLaunch L;
+    for (int k = 0; k < n; ++k) L.l[k] = l[k];
+    const int ldh = ld_of(H), ldg = ld_of(4 * H);
+    const int kc = (int)round_up(cdiv(H, 4), 8);
+    const dim3 grid(cdiv(B, 32), cdiv(H, 8), n);
+    for (int step = 0; step < T; ++step)
+        hipLaunchKernelGGL(lstm_fwd_step_kernel, grid, dim3(256), 0, s, L, mask_tb, B, T, H, ldh, ldg, step, kc);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+// -----------------------------------------------------------------------------------------
+// BPTT step: tile = 16 batch rows x 16 hidden units, MFMA 16x16x4 f32, K = 4H gate columns.
+//   rec   = dG[previous BPTT step] * W_hid^T                (recurrent gradient, skipped at step 0)
+//   dh    = dhs[t] + dh_carry + rec ;  dc = dc_state
+//   mask ? (gate gradients, clipped to +-5, -> dG[t];  dh_carry = 0;        dc_state = dcn*f [+peep])
+//        : (dG[t] = 0;                                   dh_carry = dh;      dc_state = dc)
+// step == T is the epilogue: dh_carry += rec only (gradient wrt the initial hidden state).
+// -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const LstmLaunch L, const uint8_t* __restrict__ mask_tb,
+                                                            int B, int T, int H, int ldh, int ldg, int step,
+                                                            int kc) {
+    __shared__ __attribute__((aligned(16))) float part[4][16][17];
+    __shared__ float pred[3][16][17];
+    const LstmStep& P = L.l[blockIdx.z];
+    // BPTT visits frames in the reverse of the forward order
+    const int t = P.backwards ? step : (T - 1 - step);
+    const int t_done = P.backwards ? (t - 1) : (t + 1);      // frame handled by the previous BPTT step
+    const int r0 = blockIdx.x * 16, u0 = blockIdx.y * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int G4 = 4 * H;
+
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (step > 0) {
+        const float* dgp = P.dG + (size_t)t_done * B * ldg;
+        const int arow = min(r0 + i, B - 1);
+        const int bunit = u0 + i;
+        const bool bok = bunit < H;
+        const int kbeg = wave * kc;
+        for (int kk = 0; kk < kc; kk += 16) {
+            const int k = kbeg + kk + 4 * kq;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < G4) {
+                a = *reinterpret_cast<const float4*>(dgp + (size_t)arow * ldg + k);
+                if (bok) b = *reinterpret_cast<const float4*>(P.W_hid + (size_t)bunit * ldg + k);
+            }
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+        }
+    }
+    // 16x16 C/D map: col = lane&15, row = 4*(lane>>4) + reg
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[wave][4 * kq + r][i] = acc[r];
+    __syncthreads();
+
+    const int row = tid >> 4, ul = tid & 15;
+    const int r = r0 + row, u = u0 + ul;
+    const bool valid = r < B && u < H;
+    const float rec = part[0][row][ul] + part[1][row][ul] + part[2][row][ul] + part[3][row][ul];
+    float pw_i = 0.f, pw_f = 0.f, pw_o = 0.f;           // peephole-weight gradient contributions
+    if (valid) {
+        const size_t sidx = (size_t)r * ldh + u;
+        if (step == T) {
+            P.dh_carry[sidx] += rec;
+        } else {
+            const size_t ridx = (size_t)t * B + r;
+            const float dh = P.dhs[ridx * ldh + u] + P.dh_carry[sidx] + rec;
+            const float dc = P.dc_state[sidx];
+            float4 dg = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (mask_tb[ridx]) {
+                const float4 gt = *reinterpret_cast<const float4*>(P.gates + ridx * ldg + u * 4);
+                const int prev_blk = t + (P.backwards ? 1 : 0), out_blk = t + (P.backwards ? 0 : 1);
+                const float c_t = P.cbuf[((size_t)out_blk * B + r) * ldh + u];
+                const float c_prev = P.cbuf[((size_t)prev_blk * B + r) * ldh + u];
+                const float tc = tanhf(c_t);
+                const float da_o = dh * tc * gt.w * (1.f - gt.w);
+                float dcn = dc + dh * gt.w * (1.f - tc * tc);
+                if (P.peep) { dcn += da_o * P.peep[2 * ldh + u]; pw_o = da_o * c_t; }
+                const float da_i = dcn * gt.z * gt.x * (1.f - gt.x);
+                const float da_f = dcn * c_prev * gt.y * (1.f - gt.y);
+                const float da_g = dcn * gt.x * (1.f - gt.z * gt.z);
+                float dcp = dcn * gt.y;
+                if (P.peep) {
+                    dcp += da_i * P.peep[u] + da_f * P.peep[ldh + u];
+                    pw_i = da_i * c_prev; pw_f = da_f * c_prev;
+                }
+                dg = make_float4(clip5(da_i), clip5(da_f), clip5(da_g), clip5(da_o));
+                P.dh_carry[sidx] = 0.f;
+                P.dc_state[sidx] = dcp;
+            } else {
+                P.dh_carry[sidx] = dh;                 // state was held: gradient passes straight through
+            }
+            *reinterpret_cast<float4*>(P.dG + ridx * ldg + u * 4) = dg;
+        }
+    }
+    if (P.dpeep_part && step < T) {                    // block-uniform branch
+        pred[0][row][ul] = pw_i; pred[1][row][ul] = pw_f; pred[2][row][ul] = pw_o;
+        __syncthreads();
+        if (tid < 48) {
+            const int which = tid >> 4, c = tid & 15;
+            float sum = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) sum += pred[which][rr][c];
+            if (u0 + c < H) atomicAdd(P.dpeep_part + (size_t)which * ldh + u0 + c, sum);
+        }
+    }
+}
+
+int lstm_backward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s) {
+    ADN_CHECK(n >= 1 && n <= kMaxLstmPerLaunch, ADN_ERR_INVALID, "lstm_backward: bad LSTM count");
+    LstmLaunch L;
+    for (int k = 0; k < n; ++k) L.l[k] = l[k];
+    const int ldh = ld_of(H), ldg = ld_of(4 * H);
+    for (int k = 0; k < n; ++k) {
+        ADN_HIP_CHECK(hipMemsetAsync(l[k].dh_carry, 0, (size_t)B * ldh * sizeof(float), s));
+        ADN_HIP_CHECK(hipMemsetAsync(l[k].dc_state, 0, (size_t)B * ldh * sizeof(float), s));
+    }
+    const int kc = (int)round_up(cdiv(4 * H, 4), 16);
+    const dim3 grid(cdiv(B, 16), cdiv(H, 16), n);
+    for (int step = 0; step <= T; ++step)
+        hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, dim3(256), 0, s, L, mask_tb, B, T, H, ldh, ldg, step, kc);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+}  // namespace adn

@@ -1,0 +1,874 @@
+// adn_model: the graph executor behind the C ABI of include/adenet.h.
+//
+// One model = the whole reference graph:
+//   x_s (B,T,D_s) -> [Dense+act]* -> DeltaLayer -> LSTM_s (or summed BLSTM)      s = 1..S
+//   fuse (sum | adasum | concat) -> aggregation LSTM / summed BLSTM -> Dense(C)+softmax per frame
+// plus temporal_softmax_loss, full back-propagation and Adam, all on one HIP stream.
+//
+// HBM layout
+//   * parameters, gradients, Adam m and v are four flat fp32 buffers with IDENTICAL layout (one Adam
+//     kernel sweeps them; the gradient buffer is what data-parallel ranks all-reduce).  Every matrix
+//     has a leading dimension rounded up to 8 floats; pad columns are zero and stay zero.
+//   * LSTM matrices are stored stacked with gate-interleaved columns (column 4u+g), see lstm.hip.
+//     The Lasagne per-gate tensors (W_in_to_ingate, ...) exposed through adn_read/write_tensor are
+//     strided views of those.
+//   * activations: encoder side batch-major (B*T rows in the caller's (b,t) order), recurrent side
+//     time-major (row t*B+b).  The delta kernel converts between the two for free.
+//   * the workspace is one slab carved per (B,T) shape and zero-filled when the shape changes.
+#include "adn_common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace adn {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+namespace {
+
+constexpr float kBeta1 = 0.9f, kBeta2 = 0.999f, kEps = 1e-8f;
+const char* const kGateNames[4] = {"ingate", "forgetgate", "cell", "outgate"};
+
+struct ParamDesc {
+    std::string name;
+    int ndim = 0;
+    int64_t dims[2] = {1, 1};
+    size_t off = 0;       // float offset of the element (0,0) inside the flat buffers
+    int ld = 0;           // physical row stride
+    int col_stride = 1;   // physical column step (4 for per-gate views of interleaved matrices)
+    int64_t numel() const { return dims[0] * dims[1]; }
+    int rows() const { return ndim == 2 ? (int)dims[0] : 1; }
+    int cols() const { return ndim == 2 ? (int)dims[1] : (ndim == 1 ? (int)dims[0] : 1); }
+};
+
+struct LstmParams {      // physical tensors (float offsets into the flat buffers)
+    int fin = 0;
+    size_t W_in = 0, W_hid = 0, b = 0, peep = 0, cell_init = 0, hid_init = 0;
+    bool peepholes = false;
+    bool backwards = false;
+};
+
+struct LstmWork {        // per-shape workspace pointers
+    float *xproj = nullptr, *gates = nullptr, *dG = nullptr, *hbuf = nullptr, *cbuf = nullptr;
+    float *dh_carry = nullptr, *dc_state = nullptr;
+    float* out(int B, int ldh, bool backwards) const { return hbuf + (backwards ? 0 : (size_t)B * ldh); }
+    float* prev(int B, int ldh, bool backwards) const { return hbuf + (backwards ? (size_t)B * ldh : 0); }
+};
+
+struct StreamState {
+    adn_stream_config cfg;
+    std::vector<size_t> encW, encb;   // offsets
+    std::vector<int> enc_in;          // input width of each encoder layer
+    int feat_dim = 0;                 // LSTM input width (3E / E / 3D / D)
+    int enc_out = 0;                  // width entering the delta layer
+    std::vector<LstmParams> lstm;     // 1 or 2
+    // workspace
+    const float* x = nullptr; int ldx = 0;     // staged input (batch-major)
+    float* xstage = nullptr;
+    std::vector<float*> act;                   // encoder activations (batch-major)
+    float* feat = nullptr;                     // time-major LSTM input
+    std::vector<LstmWork> lw;
+    float* hsum = nullptr;                     // stream output when bidirectional (else alias of lw[0].out)
+    float* dout_buf = nullptr;                 // own buffer for the gradient wrt the stream output
+    float* dout = nullptr;                     // ... the buffer actually holding it (may be a shared one)
+    float* dfeat = nullptr;
+    float* dE = nullptr;
+    float* out_ptr = nullptr;
+};
+
+}  // namespace
+}  // namespace adn
+
+using namespace adn;
+
+struct adn_model {
+    adn_config cfg;
+    hipStream_t stream = nullptr;
+    int H = 0, C = 0, ldh = 0, ldg = 0, ldc = 0, S = 0;
+
+    std::vector<ParamDesc> params;
+    size_t flat_floats = 0;
+    float* flat[4] = {nullptr, nullptr, nullptr, nullptr};   // param, grad, m, v
+    int adam_t = 0;
+    bool grads_valid = false;
+
+    std::vector<StreamState> st;
+    std::vector<LstmParams> agg;       // 0, 1 or 2
+    std::vector<LstmWork> aggw;
+    size_t adacoeff = 0;               // S scalars (one 8-float block)
+    size_t smW = 0, smb = 0;
+    int fused_dim = 0;
+
+    // workspace slab
+    char* slab = nullptr;
+    size_t slab_bytes = 0;
+    int wsB = 0, wsT = 0;
+    bool ws_host_inputs = false;
+    // shared workspace tensors
+    uint8_t *mask_bt = nullptr, *mask_tb = nullptr;
+    int32_t* y_bt = nullptr;
+    float *total = nullptr, *loss = nullptr, *row_loss = nullptr, *probs_bt = nullptr;
+    float *z = nullptr, *dz = nullptr, *cls_in = nullptr, *dcls = nullptr, *fused = nullptr, *dfused = nullptr;
+    float *pingA = nullptr, *pingB = nullptr;
+    int ping_ld = 0;
+    int lastB = 0, lastT = 0;
+
+    float* P(size_t off) const { return flat[ADN_BUF_PARAM] + off; }
+    float* G(size_t off) const { return flat[ADN_BUF_GRAD] + off; }
+};
+
+namespace adn {
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// parameter table
+// ------------------------------------------------------------------------------------------
+struct Builder {
+    adn_model* m;
+    size_t cursor = 0;
+    size_t alloc(size_t floats) { size_t o = cursor; cursor += (size_t)round_up((int64_t)floats, 8); return o; }
+    void add(const std::string& name, int ndim, int64_t d0, int64_t d1, size_t off, int ld, int col_stride = 1) {
+        ParamDesc p;
+        p.name = name; p.ndim = ndim; p.dims[0] = d0; p.dims[1] = d1; p.off = off; p.ld = ld; p.col_stride = col_stride;
+        if (ndim < 2) p.dims[1] = 1;
+        if (ndim < 1) p.dims[0] = 1;
+        m->params.push_back(p);
+    }
+    // Lasagne registration order inside an LSTMLayer
+    LstmParams add_lstm(const std::string& prefix, int fin, bool peep, bool backwards) {
+        const int H = m->H, ldg = m->ldg, ldh = m->ldh;
+        LstmParams lp;
+        lp.fin = fin; lp.peepholes = peep; lp.backwards = backwards;
+        lp.W_in = alloc((size_t)fin * ldg);
+        lp.W_hid = alloc((size_t)H * ldg);
+        lp.b = alloc(ldg);
+        if (peep) lp.peep = alloc((size_t)3 * ldh);
+        lp.cell_init = alloc(ldh);
+        lp.hid_init = alloc(ldh);
+        for (int g = 0; g < 4; ++g) {
+            add(prefix + ".W_in_to_" + kGateNames[g], 2, fin, H, lp.W_in + g, ldg, 4);
+            add(prefix + ".W_hid_to_" + kGateNames[g], 2, H, H, lp.W_hid + g, ldg, 4);
+            add(prefix + ".b_" + kGateNames[g], 1, H, 1, lp.b + g, ldg, 4);
+        }
+        if (peep) {
+            add(prefix + ".W_cell_to_ingate", 1, H, 1, lp.peep, ldh);
+            add(prefix + ".W_cell_to_forgetgate", 1, H, 1, lp.peep + ldh, ldh);
+            add(prefix + ".W_cell_to_outgate", 1, H, 1, lp.peep + 2 * (size_t)ldh, ldh);
+        }
+        add(prefix + ".cell_init", 2, 1, H, lp.cell_init, ldh);
+        add(prefix + ".hid_init", 2, 1, H, lp.hid_init, ldh);
+        return lp;
+    }
+};
+
+int validate(const adn_config& c) {
+    ADN_CHECK(c.n_streams >= 1 && c.n_streams <= ADN_MAX_STREAMS, ADN_ERR_INVALID, "n_streams out of range");
+    ADN_CHECK(c.lstm_size >= 1 && c.lstm_size <= 4096, ADN_ERR_INVALID, "lstm_size out of range");
+    ADN_CHECK(c.classes >= 1 && c.classes <= ADN_MAX_CLASSES, ADN_ERR_INVALID, "classes out of range");
+    ADN_CHECK(c.fusion >= ADN_FUSE_NONE && c.fusion <= ADN_FUSE_CONCAT, ADN_ERR_INVALID, "unknown fusion type");
+    ADN_CHECK(c.agg >= 0 && c.agg <= 2, ADN_ERR_INVALID, "agg must be 0, 1 or 2");
+    ADN_CHECK(c.precision == ADN_PRECISION_F32, ADN_ERR_INVALID, "unsupported precision");
+    if (c.fusion == ADN_FUSE_NONE) ADN_CHECK(c.n_streams == 1, ADN_ERR_INVALID, "fusion 'none' needs exactly one stream");
+    if (c.fusion == ADN_FUSE_CONCAT && c.n_streams > 1)
+        ADN_CHECK(c.agg != 0, ADN_ERR_INVALID, "concat fusion needs an aggregation LSTM");
+    int n_sub = 0;
+    for (int s = 0; s < c.n_streams; ++s) {
+        const adn_stream_config& sc = c.streams[s];
+        ADN_CHECK(sc.input_dim >= 1, ADN_ERR_INVALID, "stream input_dim must be positive");
+        ADN_CHECK(sc.n_enc >= 0 && sc.n_enc <= ADN_MAX_ENC_LAYERS, ADN_ERR_INVALID, "n_enc out of range");
+        for (int l = 0; l < sc.n_enc; ++l) {
+            ADN_CHECK(sc.enc_units[l] >= 1, ADN_ERR_INVALID, "encoder layer width must be positive");
+            ADN_CHECK(sc.enc_act[l] >= ADN_ACT_LINEAR && sc.enc_act[l] <= ADN_ACT_VERY_LEAKY_RECTIFY, ADN_ERR_INVALID,
+                      "unsupported encoder nonlinearity");
+        }
+        n_sub += sc.bidirectional ? 2 : 1;
+    }
+    ADN_CHECK(n_sub <= 2 * ADN_MAX_STREAMS, ADN_ERR_INVALID, "too many stream LSTMs");
+    return ADN_OK;
+}
+
+int build_params(adn_model* m) {
+    const adn_config& c = m->cfg;
+    Builder b{m};
+    m->st.resize(m->S);
+    for (int s = 0; s < m->S; ++s) {
+        StreamState& st = m->st[s];
+        st.cfg = c.streams[s];
+        const std::string sp = "stream" + std::to_string(s);
+        int d = st.cfg.input_dim;
+        for (int l = 0; l < st.cfg.n_enc; ++l) {
+            const int u = st.cfg.enc_units[l], ld = ld_of(u);
+            const size_t w = b.alloc((size_t)d * ld), bb = b.alloc(ld);
+            st.encW.push_back(w); st.encb.push_back(bb); st.enc_in.push_back(d);
+            b.add(sp + ".enc" + std::to_string(l) + ".W", 2, d, u, w, ld);
+            b.add(sp + ".enc" + std::to_string(l) + ".b", 1, u, 1, bb, ld);
+            d = u;
+        }
+        st.enc_out = d;
+        st.feat_dim = st.cfg.use_delta ? 3 * d : d;
+        const int ndir = st.cfg.bidirectional ? 2 : 1;
+        for (int k = 0; k < ndir; ++k)
+            st.lstm.push_back(b.add_lstm(sp + ".lstm" + std::to_string(k), st.feat_dim, st.cfg.peepholes != 0, k == 1));
+    }
+    if (c.fusion == ADN_FUSE_ADASUM) {
+        m->adacoeff = b.alloc(8);
+        for (int s = 0; s < m->S; ++s) b.add("fuse.adacoeff" + std::to_string(s), 0, 1, 1, m->adacoeff + s, 1);
+    }
+    m->fused_dim = (c.fusion == ADN_FUSE_CONCAT) ? m->S * m->H : m->H;
+    for (int k = 0; k < c.agg; ++k)
+        m->agg.push_back(b.add_lstm("agg" + std::to_string(k), m->fused_dim, c.agg_peepholes != 0, k == 1));
+    m->smW = b.alloc((size_t)m->H * m->ldc);
+    m->smb = b.alloc(m->ldc);
+    b.add("softmax.W", 2, m->H, m->C, m->smW, m->ldc);
+    b.add("softmax.b", 1, m->C, 1, m->smb, m->ldc);
+    m->flat_floats = b.cursor;
+    return ADN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// workspace
+// ------------------------------------------------------------------------------------------
+struct Carver {
+    char* base; size_t cursor = 0;
+    template <typename T> T* take(size_t count) {
+        T* p = base ? reinterpret_cast<T*>(base + cursor) : nullptr;
+        cursor += (size_t)round_up((int64_t)(count * sizeof(T)), 256);
+        return p;
+    }
+};
+
+void carve_lstm(Carver& cv, LstmWork& w, int B, int T, int ldh, int ldg) {
+    const size_t N = (size_t)B * T;
+    w.xproj = cv.take<float>(N * ldg);
+    w.gates = cv.take<float>(N * ldg);
+    w.dG = cv.take<float>(N * ldg);
+    w.hbuf = cv.take<float>((size_t)(T + 1) * B * ldh);
+    w.cbuf = cv.take<float>((size_t)(T + 1) * B * ldh);
+    w.dh_carry = cv.take<float>((size_t)B * ldh);
+    w.dc_state = cv.take<float>((size_t)B * ldh);
+}
+
+size_t carve(adn_model* m, char* base, int B, int T, bool host_inputs) {
+    Carver cv{base};
+    const size_t N = (size_t)B * T;
+    const int ldh = m->ldh, ldg = m->ldg;
+    m->mask_bt = cv.take<uint8_t>(N);
+    m->mask_tb = cv.take<uint8_t>(N);
+    m->y_bt = cv.take<int32_t>(N);
+    m->total = cv.take<float>(8);
+    m->loss = cv.take<float>(8);
+    m->row_loss = cv.take<float>(N);
+    m->probs_bt = cv.take<float>(N * m->C);
+    m->z = cv.take<float>(N * m->ldc);
+    m->dz = cv.take<float>(N * m->ldc);
+    m->cls_in = cv.take<float>(N * ldh);
+    m->dcls = cv.take<float>(N * ldh);
+    m->fused = cv.take<float>(N * ldh);
+    m->dfused = cv.take<float>(N * ldh);
+    int maxw = 8;
+    for (auto& st : m->st) {
+        // staged copy of the input: always (host inputs need one; device inputs whose width is not a
+        // multiple of 4 floats cannot feed the GEMM loader directly)
+        st.xstage = cv.take<float>(N * ld_of(st.cfg.input_dim));
+        st.act.resize(st.cfg.n_enc);
+        for (int l = 0; l < st.cfg.n_enc; ++l) {
+            st.act[l] = cv.take<float>(N * ld_of(st.cfg.enc_units[l]));
+            maxw = std::max(maxw, ld_of(st.cfg.enc_units[l]));
+        }
+        st.feat = cv.take<float>(N * ld_of(st.feat_dim));
+        st.dfeat = cv.take<float>(N * ld_of(st.feat_dim));
+        st.dE = cv.take<float>(N * ld_of(st.enc_out));
+        st.lw.resize(st.lstm.size());
+        for (auto& w : st.lw) carve_lstm(cv, w, B, T, ldh, ldg);
+        st.hsum = cv.take<float>(N * ldh);
+        st.dout_buf = cv.take<float>(N * ldh);
+        st.dout = st.dout_buf;
+    }
+    m->aggw.resize(m->agg.size());
+    for (auto& w : m->aggw) carve_lstm(cv, w, B, T, ldh, ldg);
+    m->ping_ld = maxw;
+    m->pingA = cv.take<float>(N * maxw);
+    m->pingB = cv.take<float>(N * maxw);
+    (void)host_inputs;
+    return cv.cursor;
+}
+
+int ensure_workspace(adn_model* m, int B, int T) {
+    if (B == m->wsB && T == m->wsT && m->slab) return ADN_OK;
+    const size_t need = carve(m, nullptr, B, T, true);
+    if (need > m->slab_bytes) {
+        if (m->slab) { ADN_HIP_CHECK(hipStreamSynchronize(m->stream)); ADN_HIP_CHECK(hipFree(m->slab)); m->slab = nullptr; }
+        const size_t want = need + need / 8;
+        ADN_HIP_CHECK(hipMalloc((void**)&m->slab, want));
+        m->slab_bytes = want;
+    }
+    carve(m, m->slab, B, T, true);
+    ADN_HIP_CHECK(hipMemsetAsync(m->slab, 0, need, m->stream));   // pad columns must read as zero
+    m->wsB = B; m->wsT = T;
+    return ADN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// staging of the caller's arrays
+// ------------------------------------------------------------------------------------------
+int stage_inputs(adn_model* m, const void* const* inputs, const int32_t* targets, const uint8_t* mask, int B, int T,
+                 int flags) {
+    const size_t N = (size_t)B * T;
+    const bool dev = flags & ADN_FLAG_DEVICE_INPUTS;
+    const hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    ADN_CHECK(inputs && mask, ADN_ERR_INVALID, "null inputs / mask");
+    for (int s = 0; s < m->S; ++s) {
+        StreamState& st = m->st[s];
+        ADN_CHECK(inputs[s], ADN_ERR_INVALID, "null stream input");
+        const int D = st.cfg.input_dim;
+        const bool direct = dev && (D % 4 == 0) && (((uintptr_t)inputs[s]) % 16 == 0);
+        if (direct) {
+            st.x = static_cast<const float*>(inputs[s]); st.ldx = D;
+        } else {
+            const int ld = ld_of(D);
+            ADN_HIP_CHECK(hipMemcpy2DAsync(st.xstage, (size_t)ld * 4, inputs[s], (size_t)D * 4, (size_t)D * 4, N, kind,
+                                           m->stream));
+            st.x = st.xstage; st.ldx = ld;
+        }
+    }
+    ADN_HIP_CHECK(hipMemcpyAsync(m->mask_bt, mask, N, kind, m->stream));
+    if (targets) ADN_HIP_CHECK(hipMemcpyAsync(m->y_bt, targets, N * sizeof(int32_t), kind, m->stream));
+    ADN_TRY(mask_prepare(m->mask_bt, m->mask_tb, B, T, m->total, m->stream));
+    return ADN_OK;
+}
+
+LstmStep make_step(const adn_model* m, const LstmParams& lp, const LstmWork& w, const float* dhs, bool grads) {
+    LstmStep s;
+    s.W_hid = m->P(lp.W_hid);
+    s.peep = lp.peepholes ? m->P(lp.peep) : nullptr;
+    s.xproj = w.xproj; s.hbuf = w.hbuf; s.cbuf = w.cbuf; s.gates = w.gates;
+    s.dG = w.dG; s.dhs = dhs; s.dh_carry = w.dh_carry; s.dc_state = w.dc_state;
+    s.dpeep_part = (grads && lp.peepholes) ? m->G(lp.peep) : nullptr;
+    s.backwards = lp.backwards ? 1 : 0;
+    return s;
+}
+
+int run_lstm_group(adn_model* m, std::vector<LstmStep>& steps, int B, int T, bool backward) {
+    for (size_t i = 0; i < steps.size(); i += kMaxLstmPerLaunch) {
+        const int n = (int)std::min<size_t>(kMaxLstmPerLaunch, steps.size() - i);
+        if (backward) ADN_TRY(lstm_backward(steps.data() + i, n, m->mask_tb, B, T, m->H, m->stream));
+        else ADN_TRY(lstm_forward(steps.data() + i, n, m->mask_tb, B, T, m->H, m->stream));
+    }
+    return ADN_OK;
+}
+
+// x*W_in + b for one LSTM whose input is the (virtual) concatenation of `nblk` matrices of width `blkw`
+int lstm_project(adn_model* m, const LstmParams& lp, const LstmWork& w, const float* const* in, const int* ld_in,
+                 int nblk, int blkw, int rows) {
+    for (int j = 0; j < nblk; ++j) {
+        GemmArgs g;
+        g.layout = GEMM_NN; g.M = rows; g.N = 4 * m->H; g.K = blkw;
+        g.A = in[j]; g.lda = ld_in[j];
+        g.B = m->P(lp.W_in) + (size_t)j * blkw * m->ldg; g.ldb = m->ldg;
+        g.C = w.xproj; g.ldc = m->ldg;
+        g.bias = (j == 0) ? m->P(lp.b) : nullptr;
+        g.accumulate = j > 0;
+        ADN_TRY(gemm(g, m->stream));
+    }
+    return ADN_OK;
+}
+
+int lstm_init_state(adn_model* m, const LstmParams& lp, const LstmWork& w, int B, int T) {
+    const size_t blk = lp.backwards ? (size_t)T * B * m->ldh : 0;
+    ADN_TRY(broadcast_rows(m->P(lp.hid_init), w.hbuf + blk, m->ldh, B, m->H, m->stream));
+    ADN_TRY(broadcast_rows(m->P(lp.cell_init), w.cbuf + blk, m->ldh, B, m->H, m->stream));
+    return ADN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool want_dz) {
+    const int N = B * T, H = m->H, ldh = m->ldh;
+    hipStream_t s = m->stream;
+    std::vector<LstmStep> steps;
+    for (auto& st : m->st) {
+        const float* a = st.x; int lda = st.ldx;
+        for (int l = 0; l < st.cfg.n_enc; ++l) {                 // modelzoo/pretrained_encoder.py:4-9
+            GemmArgs g;
+            g.layout = GEMM_NN; g.M = N; g.N = st.cfg.enc_units[l]; g.K = st.enc_in[l];
+            g.A = a; g.lda = lda; g.B = m->P(st.encW[l]); g.ldb = ld_of(g.N);
+            g.C = st.act[l]; g.ldc = ld_of(g.N); g.bias = m->P(st.encb[l]); g.act = st.cfg.enc_act[l];
+            ADN_TRY(gemm(g, s));
+            a = st.act[l]; lda = g.ldc;
+        }
+        ADN_TRY(delta_forward(a, lda, st.feat, ld_of(st.feat_dim), B, T, st.enc_out, theta, st.cfg.use_delta, s));
+        for (size_t k = 0; k < st.lstm.size(); ++k) {
+            const float* in[1] = {st.feat}; const int ld[1] = {ld_of(st.feat_dim)};
+            ADN_TRY(lstm_project(m, st.lstm[k], st.lw[k], in, ld, 1, st.feat_dim, N));
+            ADN_TRY(lstm_init_state(m, st.lstm[k], st.lw[k], B, T));
+            steps.push_back(make_step(m, st.lstm[k], st.lw[k], nullptr, false));
+        }
+    }
+    ADN_TRY(run_lstm_group(m, steps, B, T, false));
+    for (auto& st : m->st) {
+        if (st.lstm.size() == 2) {                               // summed BLSTM sub-stream
+            const float* in[2] = {st.lw[0].out(B, ldh, false), st.lw[1].out(B, ldh, true)};
+            ADN_TRY(sum_k(2, in, nullptr, ldh, st.hsum, ldh, N, H, s));
+            st.out_ptr = st.hsum;
+        } else {
+            st.out_ptr = st.lw[0].out(B, ldh, false);
+        }
+    }
+    // fusion (modelzoo/adenet_v2.py:68-75; custom/layers.py:178-228)
+    std::vector<const float*> fin; std::vector<int> fld;
+    const int fusion = m->cfg.fusion;
+    if (fusion == ADN_FUSE_CONCAT || fusion == ADN_FUSE_NONE || m->S == 1) {
+        if (fusion == ADN_FUSE_ADASUM) {                         // single stream, still scaled
+            ADN_TRY(scale_by(m->st[0].out_ptr, ldh, m->P(m->adacoeff), m->fused, ldh, N, H, s));
+            fin.push_back(m->fused); fld.push_back(ldh);
+        } else {
+            for (auto& st : m->st) { fin.push_back(st.out_ptr); fld.push_back(ldh); }
+        }
+    } else {
+        const float* in[ADN_MAX_STREAMS]; const float* al[ADN_MAX_STREAMS];
+        for (int k = 0; k < m->S; ++k) {
+            in[k] = m->st[k].out_ptr;
+            al[k] = fusion == ADN_FUSE_ADASUM ? m->P(m->adacoeff + k) : nullptr;
+        }
+        ADN_TRY(sum_k(m->S, in, al, ldh, m->fused, ldh, N, H, s));
+        fin.push_back(m->fused); fld.push_back(ldh);
+    }
+    const float* cls = nullptr;
+    if (!m->agg.empty()) {                                       // custom/layers.py:55-80
+        steps.clear();
+        for (size_t k = 0; k < m->agg.size(); ++k) {
+            ADN_TRY(lstm_project(m, m->agg[k], m->aggw[k], fin.data(), fld.data(), (int)fin.size(), H, N));
+            ADN_TRY(lstm_init_state(m, m->agg[k], m->aggw[k], B, T));
+            steps.push_back(make_step(m, m->agg[k], m->aggw[k], nullptr, false));
+        }
+        ADN_TRY(run_lstm_group(m, steps, B, T, false));
+        if (m->agg.size() == 2) {
+            const float* in[2] = {m->aggw[0].out(B, ldh, false), m->aggw[1].out(B, ldh, true)};
+            ADN_TRY(sum_k(2, in, nullptr, ldh, m->cls_in, ldh, N, H, s));
+            cls = m->cls_in;
+        } else {
+            cls = m->aggw[0].out(B, ldh, false);
+        }
+    } else {
+        ADN_CHECK(fin.size() == 1, ADN_ERR_INVALID, "classifier needs a single fused tensor");
+        cls = fin[0];
+    }
+    {   // Dense(C) + softmax per frame (modelzoo/adenet_v2.py:89-92)
+        GemmArgs g;
+        g.layout = GEMM_NN; g.M = N; g.N = m->C; g.K = H; g.A = cls; g.lda = ldh;
+        g.B = m->P(m->smW); g.ldb = m->ldc; g.C = m->z; g.ldc = m->ldc; g.bias = m->P(m->smb);
+        ADN_TRY(gemm(g, s));
+    }
+    ADN_TRY(softmax_loss(m->z, m->ldc, B, T, m->C, m->mask_tb, want_loss ? m->y_bt : nullptr, m->total, m->probs_bt,
+                         want_loss ? m->row_loss : nullptr, want_dz ? m->dz : nullptr, m->ldc, s));
+    if (want_loss) ADN_TRY(reduce_loss(m->row_loss, N, m->total, m->loss, s));
+    m->lastB = B; m->lastT = T;
+    return ADN_OK;
+}
+
+const float* classifier_input(const adn_model* m, int B) {
+    if (!m->agg.empty()) return m->agg.size() == 2 ? m->cls_in : m->aggw[0].out(B, m->ldh, false);
+    if (m->cfg.fusion == ADN_FUSE_ADASUM || (m->S > 1)) return m->fused;
+    return m->st[0].out_ptr;
+}
+
+// weight / bias / initial-state gradients of one LSTM after its BPTT sweep
+int lstm_param_grads(adn_model* m, const LstmParams& lp, const LstmWork& w, const float* const* in, const int* ld_in,
+                     int nblk, int blkw, int B, int T) {
+    const int N = B * T, H = m->H, ldh = m->ldh, ldg = m->ldg;
+    hipStream_t s = m->stream;
+    for (int j = 0; j < nblk; ++j) {                             // dW_in = X^T dG
+        GemmArgs g;
+        g.layout = GEMM_TN; g.M = blkw; g.N = 4 * H; g.K = N;
+        g.A = in[j]; g.lda = ld_in[j]; g.B = w.dG; g.ldb = ldg;
+        g.C = m->G(lp.W_in) + (size_t)j * blkw * ldg; g.ldc = ldg; g.accumulate = 1;
+        ADN_TRY(gemm(g, s));
+    }
+    {                                                            // dW_hid = H_prev^T dG  (one GEMM over all steps)
+        GemmArgs g;
+        g.layout = GEMM_TN; g.M = H; g.N = 4 * H; g.K = N;
+        g.A = w.prev(B, ldh, lp.backwards); g.lda = ldh; g.B = w.dG; g.ldb = ldg;
+        g.C = m->G(lp.W_hid); g.ldc = ldg; g.accumulate = 1;
+        ADN_TRY(gemm(g, s));
+    }
+    ADN_TRY(col_sum(w.dG, ldg, N, 4 * H, m->G(lp.b), 1, s));
+    ADN_TRY(col_sum(w.dh_carry, ldh, B, H, m->G(lp.hid_init), 1, s));
+    ADN_TRY(col_sum(w.dc_state, ldh, B, H, m->G(lp.cell_init), 1, s));
+    return ADN_OK;
+}
+
+// dX (+)= dG W_in^T for input block j
+int lstm_input_grad(adn_model* m, const LstmParams& lp, const LstmWork& w, int j, int blkw, float* dx, int lddx, int rows,
+                    bool accumulate) {
+    GemmArgs g;
+    g.layout = GEMM_NT; g.M = rows; g.N = blkw; g.K = 4 * m->H;
+    g.A = w.dG; g.lda = m->ldg; g.B = m->P(lp.W_in) + (size_t)j * blkw * m->ldg; g.ldb = m->ldg;
+    g.C = dx; g.ldc = lddx; g.accumulate = accumulate;
+    return gemm(g, m->stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// backward (theano.grad of the loss wrt every parameter)
+// ------------------------------------------------------------------------------------------
+int backward_pass(adn_model* m, int B, int T, int theta) {
+    const int N = B * T, H = m->H, ldh = m->ldh;
+    hipStream_t s = m->stream;
+    ADN_HIP_CHECK(hipMemsetAsync(m->flat[ADN_BUF_GRAD], 0, m->flat_floats * sizeof(float), s));
+    const float* cls = classifier_input(m, B);
+    {   // classifier
+        GemmArgs g;
+        g.layout = GEMM_TN; g.M = H; g.N = m->C; g.K = N; g.A = cls; g.lda = ldh; g.B = m->dz; g.ldb = m->ldc;
+        g.C = m->G(m->smW); g.ldc = m->ldc; g.accumulate = 1;
+        ADN_TRY(gemm(g, s));
+        ADN_TRY(col_sum(m->dz, m->ldc, N, m->C, m->G(m->smb), 1, s));
+        GemmArgs d;
+        d.layout = GEMM_NT; d.M = N; d.N = H; d.K = m->C; d.A = m->dz; d.lda = m->ldc; d.B = m->P(m->smW); d.ldb = m->ldc;
+        d.C = m->dcls; d.ldc = ldh;
+        ADN_TRY(gemm(d, s));
+    }
+    const int fusion = m->cfg.fusion;
+    const bool per_stream_fused = (fusion == ADN_FUSE_CONCAT || fusion == ADN_FUSE_NONE || m->S == 1) &&
+                                  fusion != ADN_FUSE_ADASUM;
+    std::vector<const float*> fin; std::vector<int> fld;
+    if (per_stream_fused) for (auto& st : m->st) { fin.push_back(st.out_ptr); fld.push_back(ldh); }
+    else { fin.push_back(m->fused); fld.push_back(ldh); }
+
+    // gradient wrt the fused tensor(s)
+    std::vector<float*> dfin;          // one per entry of fin
+    if (!m->agg.empty()) {
+        std::vector<LstmStep> steps;
+        for (size_t k = 0; k < m->agg.size(); ++k) steps.push_back(make_step(m, m->agg[k], m->aggw[k], m->dcls, true));
+        ADN_TRY(run_lstm_group(m, steps, B, T, true));
+        for (size_t k = 0; k < m->agg.size(); ++k)
+            ADN_TRY(lstm_param_grads(m, m->agg[k], m->aggw[k], fin.data(), fld.data(), (int)fin.size(), H, B, T));
+        for (size_t j = 0; j < fin.size(); ++j) {
+            float* dst = per_stream_fused ? m->st[j].dout_buf : m->dfused;
+            for (size_t k = 0; k < m->agg.size(); ++k)
+                ADN_TRY(lstm_input_grad(m, m->agg[k], m->aggw[k], (int)j, H, dst, ldh, N, k > 0));
+            dfin.push_back(dst);
+        }
+    } else {
+        dfin.push_back(m->dcls);
+    }
+    // un-fuse: gradient wrt each stream's output
+    for (int k = 0; k < m->S; ++k) {
+        StreamState& st = m->st[k];
+        if (per_stream_fused) {
+            st.dout = dfin[k];
+        } else if (fusion == ADN_FUSE_SUM) {
+            st.dout = dfin[0];                                   // shared, read-only from here on
+        } else {                                                 // adasum: d alpha_k = <dfused, out_k>, dout_k = alpha_k dfused
+            ADN_TRY(dot_all(dfin[0], ldh, st.out_ptr, ldh, N, H, m->G(m->adacoeff + k), nullptr, s));
+            ADN_TRY(scale_by(dfin[0], ldh, m->P(m->adacoeff + k), st.dout_buf, ldh, N, H, s));
+            st.dout = st.dout_buf;
+        }
+    }
+    // stream LSTMs
+    {
+        std::vector<LstmStep> steps;
+        for (auto& st : m->st)
+            for (size_t k = 0; k < st.lstm.size(); ++k) steps.push_back(make_step(m, st.lstm[k], st.lw[k], st.dout, true));
+        ADN_TRY(run_lstm_group(m, steps, B, T, true));
+    }
+    for (auto& st : m->st) {
+        const int ldf = ld_of(st.feat_dim);
+        const float* in[1] = {st.feat}; const int ld[1] = {ldf};
+        for (size_t k = 0; k < st.lstm.size(); ++k)
+            ADN_TRY(lstm_param_grads(m, st.lstm[k], st.lw[k], in, ld, 1, st.feat_dim, B, T));
+        if (st.cfg.n_enc == 0) continue;                         // nothing trainable below the LSTM
+        for (size_t k = 0; k < st.lstm.size(); ++k)
+            ADN_TRY(lstm_input_grad(m, st.lstm[k], st.lw[k], 0, st.feat_dim, st.dfeat, ldf, N, k > 0));
+        const int ldE = ld_of(st.enc_out);
+        ADN_TRY(delta_backward(st.dfeat, ldf, st.dE, ldE, B, T, st.enc_out, theta, st.cfg.use_delta, s));
+        // encoder: dZ_l = dA_l * act_l'(A_l);  dW_l = A_{l-1}^T dZ_l;  dA_{l-1} = dZ_l W_l^T
+        const int L = st.cfg.n_enc;
+        ADN_TRY(act_backward(st.dE, ldE, st.act[L - 1], ldE, N, st.enc_out, st.cfg.enc_act[L - 1], s));
+        float* dZ = st.dE; int lddz = ldE;
+        for (int l = L - 1; l >= 0; --l) {
+            const int out_w = st.cfg.enc_units[l], in_w = st.enc_in[l];
+            const float* a_prev = l > 0 ? st.act[l - 1] : st.x;
+            const int ld_prev = l > 0 ? ld_of(in_w) : st.ldx;
+            GemmArgs gw;
+            gw.layout = GEMM_TN; gw.M = in_w; gw.N = out_w; gw.K = N; gw.A = a_prev; gw.lda = ld_prev;
+            gw.B = dZ; gw.ldb = lddz; gw.C = m->G(st.encW[l]); gw.ldc = ld_of(out_w); gw.accumulate = 1;
+            ADN_TRY(gemm(gw, s));
+            ADN_TRY(col_sum(dZ, lddz, N, out_w, m->G(st.encb[l]), 1, s));
+            if (l > 0) {
+                float* dst = (dZ == m->pingA) ? m->pingB : m->pingA;
+                GemmArgs gx;
+                gx.layout = GEMM_NT; gx.M = N; gx.N = in_w; gx.K = out_w; gx.A = dZ; gx.lda = lddz;
+                gx.B = m->P(st.encW[l]); gx.ldb = ld_of(out_w); gx.C = dst; gx.ldc = m->ping_ld;
+                gx.Y = st.act[l - 1]; gx.ldy = ld_of(in_w); gx.act_grad = st.cfg.enc_act[l - 1];
+                ADN_TRY(gemm(gx, s));
+                dZ = dst; lddz = m->ping_ld;
+            }
+        }
+    }
+    m->grads_valid = true;
+    return ADN_OK;
+}
+
+__global__ void set_scalar_kernel(float* p, float v) { *p = v; }
+
+int check_shape(const adn_model* m, int B, int T, int theta) {
+    ADN_CHECK(m, ADN_ERR_INVALID, "null model");
+    ADN_CHECK(B >= 1 && T >= 1, ADN_ERR_INVALID, "empty batch (B and T must be >= 1)");
+    ADN_CHECK((int64_t)B * T < (1 << 30), ADN_ERR_INVALID, "batch too large");
+    ADN_CHECK(theta >= 0 && theta < 4096, ADN_ERR_INVALID, "delta window out of range");
+    return ADN_OK;
+}
+
+int fetch(adn_model* m, void* dst, const void* src, size_t bytes, bool to_device) {
+    if (to_device) {
+        ADN_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, m->stream));
+    } else {
+        ADN_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, m->stream));
+        ADN_HIP_CHECK(hipStreamSynchronize(m->stream));
+    }
+    return ADN_OK;
+}
+
+int tensor_io(adn_model* m, int buffer, int index, float* host, bool write) {
+    ADN_CHECK(m, ADN_ERR_INVALID, "null model");
+    ADN_CHECK(buffer >= 0 && buffer < 4, ADN_ERR_INVALID, "bad buffer id");
+    ADN_CHECK(index >= 0 && index < (int)m->params.size(), ADN_ERR_INVALID, "parameter index out of range");
+    ADN_CHECK(host, ADN_ERR_INVALID, "null host pointer");
+    const ParamDesc& p = m->params[index];
+    const int rows = p.rows(), cols = p.cols();
+    float* base = m->flat[buffer] + p.off;
+    ADN_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (p.col_stride == 1) {
+        if (write) ADN_HIP_CHECK(hipMemcpy2D(base, (size_t)p.ld * 4, host, (size_t)cols * 4, (size_t)cols * 4, rows,
+                                             hipMemcpyHostToDevice));
+        else ADN_HIP_CHECK(hipMemcpy2D(host, (size_t)cols * 4, base, (size_t)p.ld * 4, (size_t)cols * 4, rows,
+                                       hipMemcpyDeviceToHost));
+        return ADN_OK;
+    }
+    // strided (per-gate) view: stage the enclosing rows through the host
+    const size_t span = (size_t)(rows - 1) * p.ld + (size_t)(cols - 1) * p.col_stride + 1;
+    std::vector<float> tmp(span);
+    ADN_HIP_CHECK(hipMemcpy(tmp.data(), base, span * 4, hipMemcpyDeviceToHost));
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) {
+            float& phys = tmp[(size_t)r * p.ld + (size_t)c * p.col_stride];
+            if (write) phys = host[(size_t)r * cols + c]; else host[(size_t)r * cols + c] = phys;
+        }
+    if (write) ADN_HIP_CHECK(hipMemcpy(base, tmp.data(), span * 4, hipMemcpyHostToDevice));
+    return ADN_OK;
+}
+
+}  // namespace
+}  // namespace adn
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" {
+
+const char* adn_version(void) { return "adenet-hip 0.1.0 (gfx950)"; }
+const char* adn_last_error(void) { return g_last_error.c_str(); }
+
+int adn_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int d = 0; d < n; ++d) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+
+int adn_create(const adn_config* cfg, adn_model** out) {
+    ADN_CHECK(cfg && out, ADN_ERR_INVALID, "null argument");
+    *out = nullptr;
+    ADN_TRY(validate(*cfg));
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device visible: libadenet_hip needs an MI355X (gfx950); there is no CPU fallback");
+        return ADN_ERR_NO_DEVICE;
+    }
+    int dev = 0;
+    ADN_HIP_CHECK(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    ADN_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error(std::string("current device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+        return ADN_ERR_NO_DEVICE;
+    }
+    adn_model* m = new adn_model();
+    m->cfg = *cfg;
+    m->S = cfg->n_streams; m->H = cfg->lstm_size; m->C = cfg->classes;
+    m->ldh = ld_of(m->H); m->ldg = ld_of(4 * m->H); m->ldc = ld_of(m->C);
+    int st = build_params(m);
+    if (st != ADN_OK) { delete m; return st; }
+    for (int k = 0; k < 4; ++k) {
+        if (hipMalloc((void**)&m->flat[k], m->flat_floats * sizeof(float)) != hipSuccess ||
+            hipMemset(m->flat[k], 0, m->flat_floats * sizeof(float)) != hipSuccess) {
+            set_error("hipMalloc of the parameter buffers failed");
+            adn_destroy(m);
+            return ADN_ERR_HIP;
+        }
+    }
+    *out = m;
+    return ADN_OK;
+}
+
+void adn_destroy(adn_model* m) {
+    if (!m) return;
+    (void)hipStreamSynchronize(m->stream);
+    for (int k = 0; k < 4; ++k) if (m->flat[k]) (void)hipFree(m->flat[k]);
+    if (m->slab) (void)hipFree(m->slab);
+    delete m;
+}
+
+int adn_set_stream(adn_model* m, void* hip_stream) {
+    ADN_CHECK(m, ADN_ERR_INVALID, "null model");
+    m->stream = static_cast<hipStream_t>(hip_stream);
+    return ADN_OK;
+}
+
+int adn_num_params(const adn_model* m) { return m ? (int)m->params.size() : 0; }
+
+int adn_param_info(const adn_model* m, int index, adn_param_info_t* info) {
+    ADN_CHECK(m && info, ADN_ERR_INVALID, "null argument");
+    ADN_CHECK(index >= 0 && index < (int)m->params.size(), ADN_ERR_INVALID, "parameter index out of range");
+    const ParamDesc& p = m->params[index];
+    memset(info, 0, sizeof(*info));
+    strncpy(info->name, p.name.c_str(), sizeof(info->name) - 1);
+    info->ndim = p.ndim; info->dims[0] = p.dims[0]; info->dims[1] = p.dims[1]; info->numel = p.numel();
+    return ADN_OK;
+}
+
+int64_t adn_total_param_count(const adn_model* m) {
+    int64_t n = 0;
+    if (m) for (auto& p : m->params) n += p.numel();
+    return n;
+}
+
+int adn_read_tensor(adn_model* m, int buffer, int index, float* host_dst) { return tensor_io(m, buffer, index, host_dst, false); }
+int adn_write_tensor(adn_model* m, int buffer, int index, const float* host_src) {
+    return tensor_io(m, buffer, index, const_cast<float*>(host_src), true);
+}
+
+int adn_flat_buffer(adn_model* m, int buffer, void** device_ptr, size_t* bytes) {
+    ADN_CHECK(m && device_ptr && bytes, ADN_ERR_INVALID, "null argument");
+    ADN_CHECK(buffer >= 0 && buffer < 4, ADN_ERR_INVALID, "bad buffer id");
+    *device_ptr = m->flat[buffer];
+    *bytes = m->flat_floats * sizeof(float);
+    return ADN_OK;
+}
+
+int adn_forward(adn_model* m, const void* const* inputs, const uint8_t* mask, int B, int T, int theta, int flags,
+                float* probs) {
+    ADN_TRY(check_shape(m, B, T, theta));
+    ADN_CHECK(probs, ADN_ERR_INVALID, "null output");
+    ADN_TRY(ensure_workspace(m, B, T));
+    ADN_TRY(stage_inputs(m, inputs, nullptr, mask, B, T, flags));
+    ADN_TRY(forward_pass(m, B, T, theta, false, false));
+    return fetch(m, probs, m->probs_bt, (size_t)B * T * m->C * sizeof(float), flags & ADN_FLAG_DEVICE_OUTPUTS);
+}
+
+int adn_loss(adn_model* m, const void* const* inputs, const int32_t* targets, const uint8_t* mask, int B, int T,
+             int theta, int flags, float* loss) {
+    ADN_TRY(check_shape(m, B, T, theta));
+    ADN_CHECK(targets && loss, ADN_ERR_INVALID, "null targets / loss");
+    ADN_TRY(ensure_workspace(m, B, T));
+    ADN_TRY(stage_inputs(m, inputs, targets, mask, B, T, flags));
+    ADN_TRY(forward_pass(m, B, T, theta, true, false));
+    return fetch(m, loss, m->loss, sizeof(float), flags & ADN_FLAG_DEVICE_OUTPUTS);
+}
+
+int adn_compute_grads(adn_model* m, const void* const* inputs, const int32_t* targets, const uint8_t* mask, int B,
+                      int T, int theta, int flags, double total_frames, float* loss) {
+    ADN_TRY(check_shape(m, B, T, theta));
+    ADN_CHECK(targets, ADN_ERR_INVALID, "null targets");
+    ADN_TRY(ensure_workspace(m, B, T));
+    ADN_TRY(stage_inputs(m, inputs, targets, mask, B, T, flags));
+    if (total_frames > 0) {
+        hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, m->stream, m->total, (float)total_frames);
+        ADN_HIP_CHECK(hipGetLastError());
+    }
+    ADN_TRY(forward_pass(m, B, T, theta, true, true));
+    ADN_TRY(backward_pass(m, B, T, theta));
+    if (loss) return fetch(m, loss, m->loss, sizeof(float), flags & ADN_FLAG_DEVICE_OUTPUTS);
+    return ADN_OK;
+}
+
+int adn_apply_adam(adn_model* m, float learning_rate) {
+    ADN_CHECK(m, ADN_ERR_INVALID, "null model");
+    ADN_CHECK(m->grads_valid, ADN_ERR_STATE, "adn_apply_adam called without gradients (call adn_compute_grads first)");
+    m->adam_t += 1;
+    const float t = (float)m->adam_t;
+    const float a_t = learning_rate * sqrtf(1.f - powf(kBeta2, t)) / (1.f - powf(kBeta1, t));
+    ADN_TRY(adam_update(m->flat[ADN_BUF_PARAM], m->flat[ADN_BUF_GRAD], m->flat[ADN_BUF_ADAM_M], m->flat[ADN_BUF_ADAM_V],
+                        (int64_t)m->flat_floats, a_t, kBeta1, kBeta2, kEps, m->stream));
+    m->grads_valid = false;
+    return ADN_OK;
+}
+
+int adn_adam_step_count(const adn_model* m) { return m ? m->adam_t : 0; }
+int adn_set_adam_step_count(adn_model* m, int t) {
+    ADN_CHECK(m && t >= 0, ADN_ERR_INVALID, "bad argument");
+    m->adam_t = t;
+    return ADN_OK;
+}
+
+int adn_train_step(adn_model* m, const void* const* inputs, const int32_t* targets, const uint8_t* mask, int B, int T,
+                   int theta, int flags, float learning_rate, float* loss) {
+    // the cost is read back AFTER the update is enqueued so that the host wait overlaps nothing useful less
+    float* loss_dev_or_host = loss;
+    ADN_TRY(adn_compute_grads(m, inputs, targets, mask, B, T, theta, flags, 0.0, nullptr));
+    ADN_TRY(adn_apply_adam(m, learning_rate));
+    if (loss_dev_or_host) return fetch(m, loss_dev_or_host, m->loss, sizeof(float), flags & ADN_FLAG_DEVICE_OUTPUTS);
+    return ADN_OK;
+}
+
+int adn_read_encoder_activation(adn_model* m, int stream, int layer, float* host_dst) {
+    ADN_CHECK(m && host_dst, ADN_ERR_INVALID, "null argument");
+    ADN_CHECK(stream >= 0 && stream < m->S, ADN_ERR_INVALID, "stream index out of range");
+    StreamState& st = m->st[stream];
+    ADN_CHECK(layer >= 0 && layer < st.cfg.n_enc, ADN_ERR_INVALID, "encoder layer index out of range");
+    ADN_CHECK(m->lastB > 0, ADN_ERR_STATE, "no forward pass has been run yet");
+    const int u = st.cfg.enc_units[layer];
+    ADN_HIP_CHECK(hipStreamSynchronize(m->stream));
+    ADN_HIP_CHECK(hipMemcpy2D(host_dst, (size_t)u * 4, st.act[layer], (size_t)ld_of(u) * 4, (size_t)u * 4,
+                              (size_t)m->lastB * m->lastT, hipMemcpyDeviceToHost));
+    return ADN_OK;
+}
+
+int adn_synchronize(adn_model* m) {
+    ADN_CHECK(m, ADN_ERR_INVALID, "null model");
+    ADN_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return ADN_OK;
+}
+
+// ---- operator-level entry points ---------------------------------------------------------------
+int adn_op_gemm(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                const float* bias, int act, int accumulate, void* hip_stream) {
+    GemmArgs g;
+    g.layout = layout; g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.bias = bias; g.act = act; g.accumulate = accumulate;
+    return gemm(g, static_cast<hipStream_t>(hip_stream));
+}
+
+int adn_op_delta_forward(const float* in, int ld_in, float* out, int ld_out, int B, int T, int F, int theta,
+                         void* hip_stream) {
+    return delta_forward(in, ld_in, out, ld_out, B, T, F, theta, 1, static_cast<hipStream_t>(hip_stream));
+}
+
+int adn_op_delta_backward(const float* dout, int ld_out, float* din, int ld_in, int B, int T, int F, int theta,
+                          void* hip_stream) {
+    return delta_backward(dout, ld_out, din, ld_in, B, T, F, theta, 1, static_cast<hipStream_t>(hip_stream));
+}
+
+int adn_op_adam(float* p, const float* g, float* m, float* v, int64_t n, float a_t, void* hip_stream) {
+    return adam_update(p, g, m, v, n, a_t, kBeta1, kBeta2, kEps, static_cast<hipStream_t>(hip_stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,358 @@
+"""The network object the model zoo returns: the host-side mirror of what the reference's scripts do
+with a Lasagne output layer --
+
+    predictions / cost / updates / theano.function x4   runners/3stream.py:304-320
+    get_all_params / get_all_param_values / set_...     runners/3stream.py:305,393,425
+    save_model_params / load_model_params               utils/io.py:40-48
+
+backed by one ``adn_model`` of libadenet_hip.so.  Inputs follow the reference's conventions: NumPy
+arrays passed by reference, silently down-cast (``allow_input_downcast=True``: float64 -> float32,
+uint8 labels -> int32); outputs are fresh NumPy arrays; calls block.  ``torch`` CUDA tensors are
+accepted as well and are then used in place (no host round trip).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import AdenetError
+
+GATES = ("ingate", "forgetgate", "cell", "outgate")
+
+
+def _act_name(a):
+    if isinstance(a, str):
+        name = a
+    else:
+        name = getattr(a, "__name__", None) or type(a).__name__
+    name = {"rectify": "rectify", "relu": "rectify", "linear": "linear", "identity": "linear",
+            "sigmoid": "sigmoid", "tanh": "tanh", "leaky_rectify": "leaky_rectify",
+            "very_leaky_rectify": "very_leaky_rectify"}.get(name)
+    if name is None:
+        raise ValueError("unsupported encoder nonlinearity %r (supported: %s)" % (a, sorted(_lib.ACT)))
+    return name
+
+
+class Param(object):
+    """Handle of one trainable tensor (stands in for a Theano shared variable)."""
+
+    def __init__(self, model, index, name, shape):
+        self._model, self.index, self.name, self.shape = model, index, name, tuple(shape)
+
+    def get_value(self, borrow=False):
+        return self._model._read(_lib.BUF_PARAM, self.index)
+
+    def set_value(self, value):
+        self._model._write(_lib.BUF_PARAM, self.index, value)
+
+    def __repr__(self):
+        return "<Param %s %s>" % (self.name, self.shape)
+
+
+class AdeNetModel(object):
+    """S-stream AdeNet / DeltaNet graph on one MI355X.
+
+    ``spec`` is a plain dict::
+
+        streams      list of {input_dim, enc_names, enc_shapes, enc_acts, delta, lstm_names, peepholes}
+                     (lstm_names of length 2 = summed forward/backward pair)
+        fusion       'none' | 'sum' | 'adasum' | 'concat' ; fuse_name (layer name of the merge layer)
+        agg_names    [] | [name] | [forward_name, backward_name] ; agg_peepholes
+        lstm_size, classes, softmax_name
+    """
+
+    def __init__(self, spec, stream=None):
+        self.spec = spec
+        self._lib = _lib.load()
+        cfg = _lib.Config()
+        S = len(spec["streams"])
+        if not 1 <= S <= _lib.ADN_MAX_STREAMS:
+            raise ValueError("between 1 and %d streams are supported" % _lib.ADN_MAX_STREAMS)
+        cfg.n_streams = S
+        for k, s in enumerate(spec["streams"]):
+            sc = cfg.streams[k]
+            sc.input_dim = int(s["input_dim"])
+            sc.n_enc = len(s["enc_shapes"])
+            if sc.n_enc > _lib.ADN_MAX_ENC_LAYERS:
+                raise ValueError("at most %d encoder layers per stream" % _lib.ADN_MAX_ENC_LAYERS)
+            for l, (u, a) in enumerate(zip(s["enc_shapes"], s["enc_acts"])):
+                sc.enc_units[l] = int(u)
+                sc.enc_act[l] = _lib.ACT[_act_name(a)]
+            sc.use_delta = int(bool(s["delta"]))
+            sc.bidirectional = int(len(s["lstm_names"]) == 2)
+            sc.peepholes = int(bool(s["peepholes"]))
+        if spec["fusion"] not in _lib.FUSION:
+            # modelzoo/adenet_v2.py:75 raises for an unknown fusiontype (as a TypeError, through a
+            # bug in the raise statement itself); here it is a plain ValueError
+            raise ValueError("Unsupported Fusion Type used!")
+        cfg.fusion = _lib.FUSION[spec["fusion"]]
+        cfg.agg = len(spec["agg_names"])
+        cfg.agg_peepholes = int(bool(spec.get("agg_peepholes", False)))
+        cfg.lstm_size = int(spec["lstm_size"])
+        cfg.classes = int(spec["classes"])
+        self._handle = C.c_void_p()
+        _lib.check(self._lib.adn_create(C.byref(cfg), C.byref(self._handle)))
+        self.S, self.H, self.C = S, cfg.lstm_size, cfg.classes
+        self.input_dims = [int(s["input_dim"]) for s in spec["streams"]]
+        self._build_param_table()
+        self._torch_stream = None
+        if stream is not None:
+            self.set_stream(stream)
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            self._lib.adn_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream):
+        """``stream``: a raw hipStream_t (int) or a torch.cuda.Stream."""
+        raw = getattr(stream, "cuda_stream", stream)
+        self._torch_stream = stream if hasattr(stream, "cuda_stream") else None
+        _lib.check(self._lib.adn_set_stream(self._handle, C.c_void_p(int(raw))))
+
+    def synchronize(self):
+        _lib.check(self._lib.adn_synchronize(self._handle))
+
+    # ------------------------------------------------------------------ parameters
+    def _lasagne_name(self, cname):
+        spec = self.spec
+        head, leaf = cname.split(".", 1)
+        if head.startswith("stream"):
+            s = spec["streams"][int(head[6:])]
+            sub, leaf2 = leaf.split(".", 1)
+            if sub.startswith("enc"):
+                return "%s.%s" % (s["enc_names"][int(sub[3:])], leaf2)
+            return "%s.%s" % (s["lstm_names"][int(sub[4:])], leaf2)
+        if head == "fuse":
+            return "%s.%s" % (spec["fuse_name"], leaf)
+        if head.startswith("agg"):
+            return "%s.%s" % (spec["agg_names"][int(head[3:])], leaf)
+        return "%s.%s" % (spec["softmax_name"], leaf)
+
+    def _build_param_table(self):
+        n = self._lib.adn_num_params(self._handle)
+        self.params = []
+        self.param_index = {}
+        info = _lib.ParamInfo()
+        for i in range(n):
+            _lib.check(self._lib.adn_param_info(self._handle, i, C.byref(info)))
+            shape = tuple(int(info.dims[d]) for d in range(info.ndim))
+            name = self._lasagne_name(info.name.decode())
+            p = Param(self, i, name, shape)
+            self.params.append(p)
+            self.param_index[name] = i
+
+    def _read(self, buf, index):
+        p = self.params[index]
+        out = np.empty(p.shape, dtype=np.float32)
+        _lib.check(self._lib.adn_read_tensor(self._handle, buf, index, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def _write(self, buf, index, value):
+        p = self.params[index]
+        v = np.ascontiguousarray(np.asarray(value, dtype=np.float32))
+        if v.shape != p.shape:
+            if v.size == int(np.prod(p.shape)) and (v.ndim <= 2):
+                v = np.ascontiguousarray(v.reshape(p.shape))      # e.g. (1,H) biases from a .mat file
+            else:
+                raise ValueError("mismatch: parameter %s has shape %s, got %s" % (p.name, p.shape, v.shape))
+        _lib.check(self._lib.adn_write_tensor(self._handle, buf, index, v.ctypes.data_as(C.c_void_p)))
+
+    def get_all_params(self, trainable=True, **tags):
+        """lasagne.layers.get_all_params: every parameter on this path is trainable
+        (encoders included).  ``scaling_param=True`` selects the adasum coefficients."""
+        if tags.get("scaling_param"):
+            return [p for p in self.params if ".adacoeff" in p.name]
+        return list(self.params)
+
+    def get_all_param_values(self, **tags):
+        return [p.get_value() for p in self.get_all_params(**tags)]
+
+    def set_all_param_values(self, values, **tags):
+        params = self.get_all_params(**tags)
+        if len(values) != len(params):
+            raise ValueError("mismatch: got %d values to set %d parameters" % (len(values), len(params)))
+        for p, v in zip(params, values):
+            p.set_value(v)
+
+    def get_param(self, name):
+        return self._read(_lib.BUF_PARAM, self.param_index[name])
+
+    def set_param(self, name, value):
+        self._write(_lib.BUF_PARAM, self.param_index[name], value)
+
+    def get_params_dict(self):
+        return {p.name: p.get_value() for p in self.params}
+
+    def set_params_dict(self, d):
+        for name, v in d.items():
+            self.set_param(name, v)
+
+    def get_grads_dict(self):
+        return {p.name: self._read(_lib.BUF_GRAD, p.index) for p in self.params}
+
+    def get_adam_state(self):
+        return dict(t=self._lib.adn_adam_step_count(self._handle),
+                    m=[self._read(_lib.BUF_ADAM_M, p.index) for p in self.params],
+                    v=[self._read(_lib.BUF_ADAM_V, p.index) for p in self.params])
+
+    def set_adam_state(self, state):
+        _lib.check(self._lib.adn_set_adam_step_count(self._handle, int(state["t"])))
+        for p, m, v in zip(self.params, state["m"], state["v"]):
+            self._write(_lib.BUF_ADAM_M, p.index, m)
+            self._write(_lib.BUF_ADAM_V, p.index, v)
+
+    def count_params(self):
+        return int(self._lib.adn_total_param_count(self._handle))
+
+    def flat_buffer(self, which=_lib.BUF_GRAD):
+        """(device pointer, bytes) of a flat fp32 buffer; BUF_GRAD is what data-parallel ranks all-reduce."""
+        ptr, nbytes = C.c_void_p(), C.c_size_t()
+        _lib.check(self._lib.adn_flat_buffer(self._handle, which, C.byref(ptr), C.byref(nbytes)))
+        return ptr.value, nbytes.value
+
+    # ------------------------------------------------------------------ calls
+    @staticmethod
+    def _is_device(x):
+        return hasattr(x, "data_ptr") and getattr(x, "is_cuda", False)
+
+    def _prep(self, inputs, mask, targets=None):
+        if len(inputs) != self.S:
+            raise ValueError("expected %d input streams, got %d" % (self.S, len(inputs)))
+        dev = self._is_device(inputs[0])
+        keep = []
+        ptrs = (C.c_void_p * self.S)()
+        shape = None
+        for k, x in enumerate(inputs):
+            if self._is_device(x) != dev:
+                raise ValueError("all streams must live on the same side (host or device)")
+            if dev:
+                import torch
+                if x.dtype != torch.float32 or not x.is_contiguous():
+                    x = x.to(torch.float32).contiguous()
+                p = x.data_ptr()
+            else:
+                x = np.ascontiguousarray(x, dtype=np.float32)
+                p = x.ctypes.data
+            if x.ndim != 3 or x.shape[2] != self.input_dims[k]:
+                raise ValueError("stream %d: expected (B,T,%d), got %s" % (k, self.input_dims[k], tuple(x.shape)))
+            if shape is None:
+                shape = tuple(x.shape[:2])
+            elif tuple(x.shape[:2]) != shape:
+                raise ValueError("streams disagree on (B,T): %s vs %s" % (tuple(x.shape[:2]), shape))
+            keep.append(x)
+            ptrs[k] = p
+        B, T = shape
+
+        def small(a, np_dtype, torch_name):
+            if dev:
+                import torch
+                if not self._is_device(a):
+                    a = torch.as_tensor(np.ascontiguousarray(a, dtype=np_dtype), device=keep[0].device)
+                a = a.to(getattr(torch, torch_name)).contiguous()
+                if tuple(a.shape) != (B, T):
+                    raise ValueError("mask/targets must be (B,T)=%s, got %s" % ((B, T), tuple(a.shape)))
+                keep.append(a)
+                return a.data_ptr()
+            a = np.ascontiguousarray(a, dtype=np_dtype)
+            if a.shape != (B, T):
+                raise ValueError("mask/targets must be (B,T)=%s, got %s" % ((B, T), a.shape))
+            keep.append(a)
+            return a.ctypes.data
+
+        mp = small(mask, np.uint8, "uint8")
+        tp = small(targets, np.int32, "int32") if targets is not None else None
+        if dev and self._torch_stream is None:
+            import torch
+            raw = torch.cuda.current_stream().cuda_stream
+            _lib.check(self._lib.adn_set_stream(self._handle, C.c_void_p(int(raw))))
+        flags = _lib.FLAG_DEVICE_INPUTS if dev else 0
+        return ptrs, mp, tp, B, T, flags, keep
+
+    def predict(self, inputs, mask, window):
+        """val_fn: probabilities (B,T,C) float32."""
+        ptrs, mp, _, B, T, flags, keep = self._prep(inputs, mask)
+        out = np.empty((B, T, self.C), dtype=np.float32)
+        _lib.check(self._lib.adn_forward(self._handle, ptrs, mp, B, T, int(window), flags,
+                                         out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def loss(self, inputs, targets, mask, window):
+        """compute_train_cost / compute_test_cost (no stochastic layers on this path: identical)."""
+        ptrs, mp, tp, B, T, flags, keep = self._prep(inputs, mask, targets)
+        out = C.c_float()
+        _lib.check(self._lib.adn_loss(self._handle, ptrs, tp, mp, B, T, int(window), flags, C.byref(out)))
+        return np.float32(out.value)
+
+    def compute_grads(self, inputs, targets, mask, window, total_frames=0.0, want_loss=True):
+        ptrs, mp, tp, B, T, flags, keep = self._prep(inputs, mask, targets)
+        out = C.c_float()
+        _lib.check(self._lib.adn_compute_grads(self._handle, ptrs, tp, mp, B, T, int(window), flags,
+                                               float(total_frames), C.byref(out) if want_loss else None))
+        return np.float32(out.value) if want_loss else None
+
+    def apply_adam(self, learning_rate):
+        _lib.check(self._lib.adn_apply_adam(self._handle, float(learning_rate)))
+
+    def train_step(self, inputs, targets, mask, window, learning_rate, want_loss=True):
+        """train(...): forward + backward + Adam; returns the cost of this batch before the update."""
+        ptrs, mp, tp, B, T, flags, keep = self._prep(inputs, mask, targets)
+        out = C.c_float()
+        _lib.check(self._lib.adn_train_step(self._handle, ptrs, tp, mp, B, T, int(window), flags,
+                                            float(learning_rate), C.byref(out) if want_loss else None))
+        return np.float32(out.value) if want_loss else None
+
+    def encoder_activation(self, stream, layer, B, T):
+        u = self.spec["streams"][stream]["enc_shapes"][layer]
+        out = np.empty((B * T, u), dtype=np.float32)
+        _lib.check(self._lib.adn_read_encoder_activation(self._handle, stream, layer, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    # ------------------------------------------------------------------ the four "compiled functions"
+    def compile(self, learning_rate, order="inputs,targets,mask,window"):
+        """Returns (train, compute_train_cost, compute_test_cost, val_fn) taking positional arguments in
+        the order the reference script compiled them with:
+            3stream/4stream: 'inputs,targets,mask,window'   (runners/3stream.py:309-320)
+            2stream:         'in1,targets,mask,in2,window'  (runners/2stream.py:280-291)
+            1stream:         'inputs,targets,mask,window'   (runners/1stream.py:236-247)
+        ``val_fn`` takes the same order without ``targets``."""
+        S = self.S
+        lr = float(learning_rate)
+
+        def split(args, with_targets):
+            args = list(args)
+            if order == "in1,targets,mask,in2,window":
+                if with_targets:
+                    in1, targets, mask, in2, window = args
+                else:
+                    in1, mask, in2, window = args
+                    targets = None
+                return [in1, in2], targets, mask, window
+            ins = args[:S]
+            rest = args[S:]
+            if with_targets:
+                targets, mask, window = rest
+            else:
+                (mask, window), targets = rest, None
+            return ins, targets, mask, window
+
+        def train(*args):
+            ins, t, m, w = split(args, True)
+            return self.train_step(ins, t, m, w, lr)
+
+        def cost(*args):
+            ins, t, m, w = split(args, True)
+            return self.loss(ins, t, m, w)
+
+        def val_fn(*args):
+            ins, _, m, w = split(args, False)
+            return self.predict(ins, m, w)
+
+        return train, cost, cost, val_fn

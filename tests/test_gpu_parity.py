@@ -1,0 +1,373 @@
+"""GPU parity tests proper: the HIP path (called through the C ABI) against the CPU oracle on the same
+seeded inputs.  Tolerances are written next to each check; the north-star gates are 1e-4 on fp32
+encoder activations and identical top-1 per utterance.  Run with ``-m gpu`` on an MI355X."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import adenet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from ip_avsr_amd import _lib
+    l = _lib.load()
+    assert l.adn_device_count() >= 1, "no gfx950 device visible to libadenet_hip"
+    return l
+
+
+def dptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def ragged_mask(rng, B, T):
+    lens = rng.integers(max(2, T // 3), T + 1, size=B)
+    lens[0] = T
+    m = np.zeros((B, T), np.uint8)
+    for i, l in enumerate(lens):
+        m[i, :l] = 1
+    return m
+
+
+def relerr(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(1e-30, np.abs(b).max())
+
+
+# ============================================================================= operators
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (37, 50, 19), (64, 64, 32), (130, 250, 150), (300, 1000, 250),
+                                   (1040, 2000, 1200), (500, 50, 20800), (2600, 130, 66)])
+def test_gemm_f32(torch_cuda, lib, layout, M, N, K):
+    torch = torch_cuda
+    rng = np.random.default_rng(M * 7 + N * 3 + K + layout)
+    A = rng.normal(size=(M, K)); Bm = rng.normal(size=(K, N)); bias = rng.normal(size=(N,))
+    ref = A @ Bm
+    pad = lambda n: (n + 7) // 8 * 8
+    if layout == 0:
+        a_h, b_h = A, Bm
+    elif layout == 1:
+        a_h, b_h = A, Bm.T
+    else:
+        a_h, b_h = A.T, Bm
+
+    def dev(x):
+        buf = np.full((x.shape[0], pad(x.shape[1])), np.nan, np.float32)    # poison the padding
+        buf[:, :x.shape[1]] = x
+        return torch.tensor(buf, device="cuda")
+
+    a_d, b_d = dev(a_h), dev(b_h)
+    c_d = torch.full((M, pad(N)), 7.0, device="cuda")
+    from ip_avsr_amd._lib import check
+    check(lib.adn_op_gemm(layout, M, N, K, dptr(a_d), a_d.shape[1], dptr(b_d), b_d.shape[1], dptr(c_d), c_d.shape[1],
+                          None, 0, 0, None))
+    torch.cuda.synchronize()
+    out = c_d.cpu().numpy()
+    tol = 2e-6 * np.sqrt(K) * np.abs(A).max() * np.abs(Bm).max() + 1e-6
+    assert np.abs(out[:, :N] - ref).max() <= tol * 4
+    assert (out[:, N:] == 7.0).all(), "GEMM wrote outside its N columns"
+    # bias + relu epilogue, then accumulate on top
+    if layout == 0:
+        bias_d = torch.tensor(bias.astype(np.float32), device="cuda")
+        check(lib.adn_op_gemm(0, M, N, K, dptr(a_d), a_d.shape[1], dptr(b_d), b_d.shape[1], dptr(c_d), c_d.shape[1],
+                              dptr(bias_d), 1, 0, None))
+        check(lib.adn_op_gemm(0, M, N, K, dptr(a_d), a_d.shape[1], dptr(b_d), b_d.shape[1], dptr(c_d), c_d.shape[1],
+                              None, 0, 1, None))
+        torch.cuda.synchronize()
+        want = np.maximum(ref + bias, 0) + ref
+        assert np.abs(c_d.cpu().numpy()[:, :N] - want).max() <= tol * 8
+
+
+def test_gemm_identity_with_asymmetric_b_catches_transposes(torch_cuda, lib):
+    torch = torch_cuda
+    from ip_avsr_amd._lib import check
+    n = 96
+    eye = torch.eye(n, device="cuda")
+    Bm = torch.arange(n * n, device="cuda", dtype=torch.float32).reshape(n, n).contiguous()
+    out = torch.zeros(n, n, device="cuda")
+    check(lib.adn_op_gemm(0, n, n, n, dptr(eye), n, dptr(Bm), n, dptr(out), n, None, 0, 0, None))
+    assert torch.equal(out, Bm)
+    check(lib.adn_op_gemm(1, n, n, n, dptr(eye), n, dptr(Bm), n, dptr(out), n, None, 0, 0, None))
+    assert torch.equal(out, Bm.T)
+    check(lib.adn_op_gemm(2, n, n, n, dptr(Bm), n, dptr(eye), n, dptr(out), n, None, 0, 0, None))
+    assert torch.equal(out, Bm.T)
+
+
+@pytest.mark.parametrize("B,T,F,theta", [(1, 1, 1, 1), (3, 7, 5, 2), (5, 40, 50, 9), (4, 12, 90, 3), (2, 5, 33, 9)])
+def test_delta_layer(torch_cuda, lib, B, T, F, theta):
+    torch = torch_cuda
+    from ip_avsr_amd._lib import check
+    rng = np.random.default_rng(B + T + F + theta)
+    x = rng.normal(size=(B, T, F)).astype(np.float32)
+    ld_in, ld_out = (F + 7) // 8 * 8, (3 * F + 7) // 8 * 8
+    xin = np.zeros((B, T, ld_in), np.float32); xin[..., :F] = x
+    x_d = torch.tensor(xin, device="cuda")
+    out_d = torch.zeros(T, B, ld_out, device="cuda")
+    check(lib.adn_op_delta_forward(dptr(x_d), ld_in, dptr(out_d), ld_out, B, T, F, theta, None))
+    got = out_d.cpu().numpy()[..., :3 * F].transpose(1, 0, 2)
+    want = O.delta_append(x, theta)
+    assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
+    lit = np.stack([O.append_delta_literal(x[b], theta) for b in range(B)])   # literal scans of the reference
+    assert np.abs(got - lit).max() <= 5e-5 * max(1.0, np.abs(lit).max())
+    g = rng.normal(size=(B, T, 3 * F)).astype(np.float32)
+    gin = np.zeros((T, B, ld_out), np.float32); gin[..., :3 * F] = g.transpose(1, 0, 2)
+    g_d = torch.tensor(gin, device="cuda")
+    dx_d = torch.zeros(B, T, ld_in, device="cuda")
+    check(lib.adn_op_delta_backward(dptr(g_d), ld_out, dptr(dx_d), ld_in, B, T, F, theta, None))
+    want_dx = O.delta_append_bwd(g.astype(np.float64), theta)
+    assert np.abs(dx_d.cpu().numpy()[..., :F] - want_dx).max() <= 2e-5 * max(1.0, np.abs(want_dx).max())
+
+
+def test_adam_kernel(torch_cuda, lib):
+    torch = torch_cuda
+    from ip_avsr_amd._lib import check
+    rng = np.random.default_rng(0)
+    n = 1003
+    p = {"w": rng.normal(size=n).astype(np.float32)}
+    st = O.adam_init(p)
+    pd = torch.tensor(p["w"], device="cuda"); md = torch.zeros(n, device="cuda"); vd = torch.zeros(n, device="cuda")
+    for t in range(1, 4):
+        g = rng.normal(size=n).astype(np.float32)
+        O.adam_step(p, {"w": g}, st, lr=0.01)
+        a_t = np.float32(0.01) * np.sqrt(np.float32(1) - np.float32(0.999) ** np.float32(t)) / (
+            np.float32(1) - np.float32(0.9) ** np.float32(t))
+        check(lib.adn_op_adam(dptr(pd), dptr(torch.tensor(g, device="cuda")), dptr(md), dptr(vd), n, float(a_t), None))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(pd.cpu().numpy(), p["w"], rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(vd.cpu().numpy(), st["v"]["w"], rtol=2e-6, atol=1e-9)
+
+
+# ============================================================================= whole model
+def make_case(spec, B, T, seed, enc_std=0.3, perturb=0.1):
+    rng = np.random.default_rng(seed)
+    p = O.init_params(spec, rng, np.float32, enc_std=enc_std, perturb=perturb)
+    mask = ragged_mask(rng, B, T)
+    inputs = [(rng.normal(size=(B, T, s["input_dim"])) * mask[..., None]).astype(np.float32) for s in spec["streams"]]
+    y = np.repeat(rng.integers(0, spec["classes"], size=(B, 1)), T, axis=1).astype(np.int32)
+    return p, inputs, y, mask
+
+
+def small_specs():
+    out = {}
+    out["3stream_concat"] = O.spec_nstream([12, 9, 10], enc_shapes=(14, 6), enc_acts=("rectify", "linear"),
+                                           lstm_size=10, classes=5, fusion="concat")
+    out["2stream_sum_peep"] = O.spec_nstream([12, 9], enc_shapes=(14, 6), enc_acts=("sigmoid", "linear"),
+                                             lstm_size=7, classes=4, fusion="sum", peepholes=True)
+    out["3stream_adasum_peep"] = O.spec_nstream([8, 8, 6], enc_shapes=(9, 5), enc_acts=("tanh", "rectify"),
+                                                lstm_size=9, classes=3, fusion="adasum", peepholes=True)
+    v2 = O.spec_nstream([12, 9], enc_shapes=(14, 6), enc_acts=("rectify", "linear"), lstm_size=8, classes=6,
+                        fusion="sum", has_encoder=[True, False])                 # adenet_v2: encoder + raw DCT stream
+    out["adenet_v2_like"] = v2
+    out["deltanet_blstm"] = O.spec_deltanet(11, enc_shapes=(13, 5), enc_acts=("rectify", "linear"), lstm_size=6,
+                                            classes=4, peepholes=True, use_blstm=True)
+    out["deltanet_lstm"] = O.spec_deltanet(11, enc_shapes=(13, 5), enc_acts=("leaky_rectify", "linear"), lstm_size=6,
+                                           classes=4, use_blstm=False)
+    nd = O.spec_deltanet(10, enc_shapes=(), enc_acts=(), lstm_size=5, classes=3, use_blstm=True)
+    nd["streams"][0]["delta"] = False                                            # lstm_classifier_majority_vote
+    out["lstm_classifier"] = nd
+    return out
+
+
+@pytest.mark.parametrize("name", list(small_specs()))
+def test_forward_loss_grads_match_oracle(torch_cuda, lib, name):
+    from ip_avsr_amd.model import AdeNetModel
+    spec = small_specs()[name]
+    B, T, theta = 5, 9, 3
+    p, inputs, y, mask = make_case(spec, B, T, seed=sum(map(ord, name)))
+    m = AdeNetModel(spec)
+    assert [q.name for q in m.params] == O.param_names(spec)            # Lasagne order
+    for q in m.params:
+        assert q.shape == tuple(O.param_shapes(spec)[q.name]), q.name
+    m.set_params_dict(p)
+    back = m.get_params_dict()
+    for k in p:
+        np.testing.assert_array_equal(back[k], p[k])                       # set/get round trip is exact
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    in64 = [x.astype(np.float64) for x in inputs]
+    probs_ref = O.forward(spec, p64, in64, mask, theta)
+    probs = m.predict(inputs, mask, theta)
+    assert probs.shape == (B, T, spec["classes"]) and probs.dtype == np.float32
+    assert np.abs(probs - probs_ref).max() <= 2e-5
+    loss_ref, g_ref, cache = O.loss_and_grads(spec, p64, in64, y, mask, theta)
+    assert abs(m.loss(inputs, y, mask, theta) - loss_ref) <= 1e-5 * abs(loss_ref)
+    loss = m.compute_grads(inputs, y, mask, theta)
+    assert abs(loss - loss_ref) <= 1e-5 * abs(loss_ref)
+    grads = m.get_grads_dict()
+    gscale = max(np.abs(v).max() for v in g_ref.values())
+    for k in O.param_names(spec):
+        err = np.abs(grads[k] - g_ref[k]).max()
+        assert err <= 1e-4 * max(np.abs(g_ref[k]).max(), 1e-3 * gscale) + 1e-9, (k, err, np.abs(g_ref[k]).max())
+    # encoder activations (north-star gate: 1e-4)
+    for s, (ss, sc) in enumerate(zip(spec["streams"], cache["streams"])):
+        for l in range(len(ss["enc_shapes"])):
+            assert np.abs(m.encoder_activation(s, l, B, T) - sc["acts"][l + 1]).max() <= 1e-4
+    m.close()
+
+
+@pytest.mark.parametrize("name", ["3stream_concat", "3stream_adasum_peep", "deltanet_blstm"])
+def test_train_steps_match_oracle(torch_cuda, lib, name):
+    from ip_avsr_amd.model import AdeNetModel
+    spec = small_specs()[name]
+    B, T, theta, lr = 6, 8, 2, 1e-3
+    p, inputs, y, mask = make_case(spec, B, T, seed=11)
+    m = AdeNetModel(spec)
+    m.set_params_dict(p)
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    st = O.adam_init(p64)
+    in64 = [x.astype(np.float64) for x in inputs]
+    for step in range(4):
+        l_ref = O.train_step(spec, p64, st, in64, y, mask, theta, lr)
+        l = m.train_step(inputs, y, mask, theta, lr)
+        assert abs(l - l_ref) <= 2e-5 * abs(l_ref), (step, l, l_ref)
+    got = m.get_params_dict()
+    for k in p64:
+        # Adam's first steps move every weight by ~lr regardless of gradient scale, so compare against lr
+        assert np.abs(got[k] - p64[k]).max() <= 0.05 * lr, k
+    state = m.get_adam_state()
+    assert state["t"] == 4
+    m.close()
+
+
+def test_grad_clip_fires_like_the_oracle(torch_cuda, lib):
+    """Large weights -> saturating BPTT -> the +-5 clip on d(gates) must bind identically."""
+    from ip_avsr_amd.model import AdeNetModel
+    spec = O.spec_deltanet(6, enc_shapes=(), enc_acts=(), lstm_size=5, classes=3, use_blstm=False)
+    B, T, theta = 4, 7, 1
+    p, inputs, y, mask = make_case(spec, B, T, seed=3)
+    rng = np.random.default_rng(0)
+    p["softmax.W"] = (rng.normal(size=p["softmax.W"].shape) * 4000).astype(np.float32)
+    inputs = [x * 1 for x in inputs]
+    m = AdeNetModel(spec)
+    m.set_params_dict(p)
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    _, g_ref, cache = O.loss_and_grads(spec, p64, [x.astype(np.float64) for x in inputs], y, mask, theta)
+    m.compute_grads(inputs, y, mask, theta)
+    g = m.get_grads_dict()
+    for k in ("lstm.b_ingate", "lstm.b_outgate", "lstm.W_hid_to_cell"):
+        assert np.abs(g[k] - g_ref[k]).max() <= 2e-4 * max(1.0, np.abs(g_ref[k]).max()), k
+    m.close()
+
+
+def test_real_dimensions_encoder_1e4_and_top1(torch_cuda, lib):
+    """AVLetters-shaped 3-stream concat model (1200-2000-1000-500-50, H=250, C=26, theta=9)."""
+    from ip_avsr_amd.model import AdeNetModel
+    spec = O.spec_nstream([1200, 1200, 1200])
+    B, T, theta = 10, 14, 9
+    rng = np.random.default_rng(1234)
+    p = O.init_params(spec, rng, np.float32, enc_std=0.01)
+    for k in p:                                          # non-degenerate biases
+        if k.endswith(".b"):
+            p[k] = rng.normal(0, 0.05, p[k].shape).astype(np.float32)
+    mask = ragged_mask(rng, B, T)
+    inputs = [(rng.normal(size=(B, T, 1200)) * mask[..., None]).astype(np.float32) for _ in range(3)]
+    y = np.repeat((np.arange(B) % 26)[:, None], T, axis=1).astype(np.int32)
+    m = AdeNetModel(spec)
+    assert m.count_params() == 17999676
+    m.set_params_dict(p)
+    probs_ref, cache = O.forward(spec, p, inputs, mask, theta, want_cache=True)   # fp32 oracle, like the reference
+    probs = m.predict(inputs, mask, theta)
+    for s in range(3):
+        for l in range(4):
+            ref = cache["streams"][s]["acts"][l + 1]
+            assert np.abs(m.encoder_activation(s, l, B, T) - ref).max() <= 1e-4, (s, l)
+    assert np.abs(probs - probs_ref).max() <= 1e-4
+    np.testing.assert_array_equal(O.majority_vote(probs, mask), O.majority_vote(probs_ref, mask))
+    # one training step at full width
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    l_ref, g_ref, _ = O.loss_and_grads(spec, p64, [x.astype(np.float64) for x in inputs], y, mask, theta)
+    l = m.compute_grads(inputs, y, mask, theta)
+    assert abs(l - l_ref) <= 1e-5 * abs(l_ref)
+    g = m.get_grads_dict()
+    gscale = max(np.abs(v).max() for v in g_ref.values())
+    for k in O.param_names(spec):
+        err = np.abs(g[k] - g_ref[k]).max()
+        assert err <= 2e-4 * max(np.abs(g_ref[k]).max(), 1e-3 * gscale), (k, err)
+    m.close()
+
+
+def test_device_inputs_equal_host_inputs(torch_cuda, lib):
+    torch = torch_cuda
+    from ip_avsr_amd.model import AdeNetModel
+    spec = small_specs()["3stream_concat"]
+    p, inputs, y, mask = make_case(spec, 4, 6, seed=5)
+    m = AdeNetModel(spec)
+    m.set_params_dict(p)
+    host = m.predict(inputs, mask, 2)
+    dev = m.predict([torch.tensor(x, device="cuda") for x in inputs], torch.tensor(mask, device="cuda"), 2)
+    np.testing.assert_array_equal(host, dev)
+    l_host = m.compute_grads(inputs, y, mask, 2)
+    l_dev = m.compute_grads([torch.tensor(x, device="cuda") for x in inputs], torch.tensor(y, device="cuda"),
+                            torch.tensor(mask, device="cuda"), 2)
+    assert l_host == l_dev
+    m.close()
+
+
+def test_edge_cases_single_frame_single_utterance_and_errors(torch_cuda, lib):
+    from ip_avsr_amd.model import AdeNetModel, AdenetError
+    spec = small_specs()["3stream_concat"]
+    p, inputs, y, mask = make_case(spec, 1, 1, seed=8)
+    mask[:] = 1
+    m = AdeNetModel(spec)
+    m.set_params_dict(p)
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    ref = O.forward(spec, p64, [x.astype(np.float64) for x in inputs], mask, 9)
+    assert np.abs(m.predict(inputs, mask, 9) - ref).max() <= 2e-5        # T=1 with theta=9: all-clamped deltas
+    with pytest.raises(ValueError):
+        m.predict(inputs[:2], mask, 3)                                    # wrong stream count
+    with pytest.raises(ValueError):
+        m.predict([x[:, :, :-1] for x in inputs], mask, 3)                # wrong feature width
+    with pytest.raises(AdenetError):
+        m.apply_adam(0.1)                                                 # no gradients yet
+    with pytest.raises(ValueError):
+        m.set_all_param_values(m.get_all_param_values()[:-1])
+    m.close()
+
+
+# ============================================================================= full-size properties
+def test_full_size_properties_whole_train_batch(torch_cuda, lib):
+    """BASELINE config 2 size (B=520, T=40): properties that need no oracle run --
+    (i) utterance permutation equivariance, (ii) gradient additivity over utterance shards with a
+    common normaliser (the data-parallel identity), (iii) probabilities sum to 1."""
+    torch = torch_cuda
+    from ip_avsr_amd.model import AdeNetModel
+    spec = O.spec_nstream([1200, 1200, 1200])
+    B, T, theta = 520, 40, 9
+    rng = np.random.default_rng(7)
+    p = O.init_params(spec, rng, np.float32, enc_std=0.01)
+    m = AdeNetModel(spec)
+    m.set_params_dict(p)
+    lens = rng.integers(12, 41, size=B); lens[0] = T
+    mask = (np.arange(T)[None, :] < lens[:, None]).astype(np.uint8)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    xs = [torch.randn(B, T, 1200, device="cuda", generator=gen) * torch.tensor(mask, device="cuda")[..., None]
+          for _ in range(3)]
+    y = np.repeat((np.arange(B) % 26)[:, None], T, axis=1).astype(np.int32)
+    probs = m.predict(xs, mask, theta)
+    assert np.isfinite(probs).all() and np.abs(probs.sum(-1) - 1).max() < 1e-5
+    perm = rng.permutation(B)
+    pt = torch.tensor(perm, device="cuda")
+    probs_p = m.predict([x[pt].contiguous() for x in xs], mask[perm], theta)
+    assert np.abs(probs_p - probs[perm]).max() <= 1e-6
+    total = float(mask.sum())
+    l_full = m.compute_grads(xs, y, mask, theta)
+    g_full = m.get_grads_dict()
+    half = B // 2
+    parts, losses = [], []
+    for sl in (slice(0, half), slice(half, B)):
+        losses.append(m.compute_grads([x[sl].contiguous() for x in xs], y[sl], mask[sl], theta, total_frames=total))
+        parts.append(m.get_grads_dict())
+    assert abs(losses[0] + losses[1] - l_full) <= 1e-5 * abs(l_full)
+    for k in g_full:
+        s = parts[0][k] + parts[1][k]
+        assert np.abs(s - g_full[k]).max() <= 1e-4 * max(np.abs(g_full[k]).max(), 1e-7), k
+    m.close()
