@@ -79,6 +79,27 @@ EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same soname as /opt/rocm's).  Two HIP
+    runtimes in one process cannot both own the GPU, and whichever is loaded second sees no device.
+    Loading torch's copy first makes the dynamic loader bind libadenet_hip.so to it (soname match), so
+    this library, torch tensors and torch.distributed (RCCL) all share ONE runtime no matter which of
+    them is imported first.  Without torch installed the system runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load (once) and return the ctypes handle; raises AdenetError when the HIP library is absent."""
     global _lib
@@ -88,6 +109,7 @@ def load():
         raise AdenetError(
             "HIP extension not built: %s is missing. Build it with `python -m ip_avsr_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the compute path." % LIB_PATH)
+    _preload_torch_hip_runtime()
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:

@@ -1,0 +1,99 @@
+"""Shared builder behind the ``create_model`` factories of this package's model zoo.
+
+Every graph of the reference's per-timestep-softmax family is
+
+    S streams:  [pretrained dense encoder] -> [DeltaLayer] -> LSTM | summed BLSTM
+    fusion:     none | sum | adasum | concat
+    aggregation none | LSTM | summed BLSTM    ->  Dense(C)+softmax on every frame
+
+so each zoo module only states its layer names, defaults and argument order and calls ``build``.
+Initial values follow the reference: encoder W/b are the injected (DBN) arrays
+(modelzoo/pretrained_encoder.py:4-9); LSTM W_in/W_hid come from ``w_init_fn``, gate biases 0
+(``Gate(W_in=w_init_fn, W_hid=w_init_fn, b=Constant(0.))``, e.g. modelzoo/adenet_v2.py:20-28); peephole
+vectors keep Lasagne's Gate default Normal(0.1); cell_init/hid_init 0 (learn_init=True); the softmax
+DenseLayer uses Lasagne's defaults GlorotUniform / 0; adasum coefficients start at 1.0
+(custom/layers.py:219-220).
+"""
+import numpy as np
+
+from .. import init as _init
+from ..layers import FuseHandle
+from ..model import AdeNetModel, GATES
+
+DEFAULT_ENC_NAMES = ["fc1", "fc2", "fc3", "bottleneck", "fc5", "fc6", "fc7", "fc8"]
+
+
+def input_dim_of(shape):
+    """(None, None, D) -> D."""
+    return int(shape[-1])
+
+
+def stream(input_shape, ae=None, suffix="", delta=True, lstm_names=("lstm",), peepholes=False, enc_names=None,
+           pretrained_lstm=None, pretrained_prefixes=None):
+    """One stream description.  ``ae`` = (weights, biases, shapes, nonlinearities) like
+    ``load_decoder`` returns (runners/3stream.py:31-40) or None for an encoder-less stream."""
+    d = dict(input_dim=input_dim_of(input_shape), delta=bool(delta), lstm_names=list(lstm_names),
+             peepholes=bool(peepholes), pretrained_lstm=pretrained_lstm,
+             pretrained_prefixes=list(pretrained_prefixes or []))
+    if ae is None:
+        d.update(enc_names=[], enc_shapes=[], enc_acts=[], enc_weights=[], enc_biases=[])
+    else:
+        weights, biases, shapes, nonlins = ae
+        n = len(shapes)
+        names = list(enc_names) if enc_names else [nm + suffix for nm in DEFAULT_ENC_NAMES[:n]]
+        d.update(enc_names=names, enc_shapes=[int(s) for s in shapes], enc_acts=list(nonlins),
+                 enc_weights=list(weights[:n]), enc_biases=list(biases[:n]))
+    return d
+
+
+def _init_lstm(model, name, w_init, peepholes):
+    for g in GATES:
+        for kind in ("W_in_to_", "W_hid_to_"):
+            pname = "%s.%s%s" % (name, kind, g)
+            model.set_param(pname, w_init(model.params[model.param_index[pname]].shape))
+    if peepholes:
+        peep = _init.Normal(0.1)
+        for g in ("ingate", "forgetgate", "outgate"):
+            pname = "%s.W_cell_to_%s" % (name, g)
+            model.set_param(pname, peep(model.params[model.param_index[pname]].shape))
+
+
+def _load_pretrained_lstm(model, name, weights, prefix):
+    """custom/layers.py:28-52 create_pretrained_lstm: keys '{prefix}_w_{in,hid}_to_{gate}', '{prefix}_b_{gate}'."""
+    for g in GATES:
+        model.set_param("%s.W_in_to_%s" % (name, g), np.asarray(weights["%s_w_in_to_%s" % (prefix, g)], "float32"))
+        model.set_param("%s.W_hid_to_%s" % (name, g), np.asarray(weights["%s_w_hid_to_%s" % (prefix, g)], "float32"))
+        model.set_param("%s.b_%s" % (name, g), np.asarray(weights["%s_b_%s" % (prefix, g)], "float32").reshape(-1))
+
+
+def build(streams, lstm_size, output_classes, fusiontype, fuse_names, agg_names, agg_peepholes, w_init_fn,
+          softmax_name="softmax", return_fuse=True):
+    if fusiontype not in ("none", "sum", "adasum", "concat"):
+        # modelzoo/adenet_v2.py:74-75 (other factories fall through to a NameError)
+        raise ValueError("Unsupported Fusion Type used!")
+    spec = dict(
+        streams=[{k: s[k] for k in ("input_dim", "enc_names", "enc_shapes", "enc_acts", "delta", "lstm_names",
+                                    "peepholes")} for s in streams],
+        fusion=fusiontype, fuse_name=fuse_names.get(fusiontype, ""), agg_names=list(agg_names),
+        agg_peepholes=bool(agg_peepholes), lstm_size=int(lstm_size), classes=int(output_classes),
+        softmax_name=softmax_name)
+    model = AdeNetModel(spec)
+    w_init = _init.resolve(w_init_fn)
+    for s in streams:
+        for n, W, b in zip(s["enc_names"], s["enc_weights"], s["enc_biases"]):
+            model.set_param(n + ".W", W)
+            model.set_param(n + ".b", np.asarray(b).reshape(-1))
+        for k, ln in enumerate(s["lstm_names"]):
+            _init_lstm(model, ln, w_init, s["peepholes"])
+            if s["pretrained_lstm"] is not None:
+                _load_pretrained_lstm(model, ln, s["pretrained_lstm"], s["pretrained_prefixes"][k])
+    if fusiontype == "adasum":
+        for k in range(len(streams)):
+            model.set_param("%s.adacoeff%d" % (spec["fuse_name"], k), np.float32(1.0))
+    for ln in agg_names:
+        _init_lstm(model, ln, w_init, agg_peepholes)
+    sm_shape = model.params[model.param_index[softmax_name + ".W"]].shape
+    model.set_param(softmax_name + ".W", _init.GlorotUniform()(sm_shape))
+    if return_fuse:
+        return model, FuseHandle(model, spec["fuse_name"])
+    return model

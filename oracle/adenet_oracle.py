@@ -484,8 +484,9 @@ def adam_step(p, g, state, lr, beta1=0.9, beta2=0.999, eps=1e-8):
     for k in p:
         dt = p[k].dtype.type
         a_t = dt(lr) * np.sqrt(dt(1) - dt(beta2) ** dt(t)) / (dt(1) - dt(beta1) ** dt(t))
-        state["m"][k] = dt(beta1) * state["m"][k] + dt(1 - beta1) * g[k]
-        state["v"][k] = dt(beta2) * state["v"][k] + dt(1 - beta2) * g[k] * g[k]
+        # (one - beta) is formed in the working precision, as Theano's float32 graph does
+        state["m"][k] = dt(beta1) * state["m"][k] + (dt(1) - dt(beta1)) * g[k]
+        state["v"][k] = dt(beta2) * state["v"][k] + (dt(1) - dt(beta2)) * g[k] * g[k]
         p[k] = p[k] - a_t * state["m"][k] / (np.sqrt(state["v"][k]) + dt(eps))
     return p
 

@@ -31,7 +31,7 @@ def dptr(t):
 
 
 def ragged_mask(rng, B, T):
-    lens = rng.integers(max(2, T // 3), T + 1, size=B)
+    lens = rng.integers(min(T, max(2, T // 3)), T + 1, size=B)
     lens[0] = T
     m = np.zeros((B, T), np.uint8)
     for i, l in enumerate(lens):
