@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training throughput (sequences/s) of the AVLetters trimodal AdeNet
+(3 encoder streams 1200-2000-1000-500-50, delta window 9, three 250-unit stream LSTMs, concat fusion,
+summed 250-unit BLSTM, 26-way per-frame softmax, temporal loss, Adam) at the whole-train batch
+(B=520 utterances padded to T=40) -- BASELINE.json configs[1] -- on N MI355X GPUs of one node.
+
+One "step" = forward + back-propagation + (for N>1) one RCCL all-reduce of the flat gradient buffer + Adam
+on one batch of synthetic utterances that is already resident in HBM.  Weak scaling: every rank trains on
+its own 520-utterance shard of a 520*N global batch.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     dominant kernel class (encoder / projection GEMMs on the f32 MFMA pipe), measured live with
+               HIP events recorded on the model's stream around every launch during the timed steps
+  cpu_baseline the CPU oracle (oracle/adenet_oracle.py, NumPy fp32) timed on the host cores of this box on a
+               bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+
+# gfx950 peaks from /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+B_PER_GPU, T_MAX, THETA, H, C, D = 520, 40, 9, 250, 26, 1200
+ENC = (2000, 1000, 500, 50)
+LR = 1e-3
+
+
+def build_spec():
+    sfx = ["_s1", "_s2", "_s3"]
+    streams = [dict(input_dim=D, enc_names=[n + s for n in ("fc1", "fc2", "fc3", "bottleneck")],
+                    enc_shapes=list(ENC), enc_acts=["rectify", "rectify", "rectify", "linear"], delta=True,
+                    lstm_names=["lstm" + s], peepholes=False) for s in sfx]
+    return dict(streams=streams, fusion="concat", fuse_name="concat", agg_names=["f_lstm_agg", "b_lstm_agg"],
+                agg_peepholes=False, lstm_size=H, classes=C, softmax_name="softmax")
+
+
+def synthetic_params(model, seed=1234):
+    """encoder N(0, 0.01) weights / zero biases, GlorotUniform LSTM + softmax weights."""
+    rng = np.random.RandomState(seed)
+    for p in model.params:
+        leaf = p.name.split(".")[-1]
+        shp = p.shape
+        if leaf == "W" and not p.name.startswith("softmax."):
+            v = rng.normal(0, 0.01, shp)
+        elif len(shp) == 2 and shp[0] > 1:
+            lim = np.sqrt(6.0 / (shp[0] + shp[1]))
+            v = rng.uniform(-lim, lim, shp)
+        else:
+            v = np.zeros(shp)
+        p.set_value(v.astype(np.float32))
+
+
+def synthetic_batch(torch, rank, B, device):
+    """Lengths ~ UniformInt[12,40] (one utterance at the split maximum so that T = 40), labels i mod 26,
+    per-frame z-normalised Gaussian frames, zero beyond each utterance's length."""
+    rng = np.random.RandomState(1234 + rank)
+    lens = rng.randint(12, T_MAX + 1, size=B)
+    lens[0] = T_MAX
+    mask = (np.arange(T_MAX)[None, :] < lens[:, None]).astype(np.uint8)
+    y = np.repeat((np.arange(B) % C)[:, None], T_MAX, axis=1).astype(np.int32)
+    gen = torch.Generator(device=device).manual_seed(4321 + rank)
+    m_d = torch.tensor(mask, device=device)
+    xs = []
+    for _ in range(3):
+        x = torch.randn(B, T_MAX, D, device=device, generator=gen)
+        x = (x - x.mean(-1, keepdim=True)) / x.std(-1, unbiased=False, keepdim=True)
+        xs.append((x * m_d[..., None]).contiguous())
+    return xs, torch.tensor(y, device=device), m_d, mask
+
+
+def cpu_baseline(budget_s=20.0):
+    """The oracle's train step (fp32 NumPy, BLAS threads = all host cores) on the reference minibatch
+    (B=26, T=40) of the same model; sequences/s = 26 / median step time."""
+    from oracle import adenet_oracle as O
+    spec = O.spec_nstream([D, D, D])
+    rng = np.random.default_rng(0)
+    p = O.init_params(spec, rng, np.float32, enc_std=0.01)
+    st = O.adam_init(p)
+    Bc = 26
+    lens = rng.integers(12, T_MAX + 1, size=Bc); lens[0] = T_MAX
+    mask = (np.arange(T_MAX)[None, :] < lens[:, None]).astype(np.uint8)
+    xs = [(rng.normal(size=(Bc, T_MAX, D)) * mask[..., None]).astype(np.float32) for _ in range(3)]
+    y = np.repeat((np.arange(Bc) % C)[:, None], T_MAX, axis=1).astype(np.int32)
+    O.train_step(spec, p, st, xs, y, mask, THETA, LR)        # warm-up
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while len(times) < 2 or (time.perf_counter() < t_end and len(times) < 20):
+        t0 = time.perf_counter()
+        O.train_step(spec, p, st, xs, y, mask, THETA, LR)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return dict(value=Bc / med, unit="sequences/s", cores=os.cpu_count(), kind="port",
+                sample="%d train steps of the NumPy fp32 oracle at B=26,T=40 (reference minibatch), median %.3f s/step"
+                       % (len(times), med))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel timing")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                         % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    from ip_avsr_amd.model import AdeNetModel
+    from ip_avsr_amd.parallel import DataParallel, wrap_flat_buffer
+    model = AdeNetModel(build_spec())
+    synthetic_params(model)
+    xs, y, m_d, mask = synthetic_batch(torch, rank, B_PER_GPU, device)
+    local_frames = float(mask.sum())
+    if distributed:
+        t = torch.tensor([local_frames], device=device, dtype=torch.float64)
+        dist.all_reduce(t)                       # the loader knows every length: computed once, outside the steps
+        total_frames = float(t.item())
+        dp = DataParallel(model)
+        dp.broadcast_parameters(0)
+        step = lambda: dp.train_step(xs, y, m_d, THETA, LR, total_frames)
+    else:
+        step = lambda: model.train_step(xs, y, m_d, THETA, LR, want_loss=False)
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    profile = not args.no_profile
+    if profile:
+        model.profile(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = model.profile_read() if profile else {}
+    if profile:
+        model.profile(False)
+    if distributed:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    loss = float(model.loss(xs, y, m_d, THETA))
+    assert np.isfinite(loss), "training diverged"
+
+    if rank == 0:
+        seqs = B_PER_GPU * world * args.steps
+        out = {
+            "metric": "sequences_per_sec_train_avletters_trimodal_adenet", "value": seqs / elapsed,
+            "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "AVLetters trimodal AdeNet (3 encoder streams 1200-2000-1000-500-50, theta=9, "
+                                   "3x LSTM-250, concat, summed BLSTM-250, 26 classes), whole-train batch "
+                                   "B=520 utterances x T=40 frames per GPU, fwd+bwd+Adam",
+                       "global_batch": B_PER_GPU * world, "frames_per_utterance": T_MAX,
+                       "parallelism": "dp%d" % world, "params": model.count_params(),
+                       "epoch_time_s": elapsed / args.steps,
+                       "final_loss": loss},
+        }
+        if prof:
+            g = [prof[k] for k in ("gemm_f32_nn", "gemm_f32_nt", "gemm_f32_tn") if k in prof]
+            flops = sum(e["flops"] for e in g); ms = sum(e["ms"] for e in g); n = sum(e["launches"] for e in g)
+            ach = flops / (ms * 1e-3) / 1e12 if ms else 0.0
+            out["roofline"] = {"kernel": "gemm_f32_kernel (encoder / projection GEMMs, all three layouts)",
+                               "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                               "launches_per_step": n / args.steps, "avg_launch_ms": ms / max(n, 1),
+                               "share_of_step": ms / (1e3 * elapsed)}
+            for key, name in (("lstm_fwd_step", "roofline_lstm_fwd"), ("lstm_bwd_step", "roofline_lstm_bwd")):
+                if key in prof and prof[key]["ms"]:
+                    e = prof[key]
+                    a = e["bytes"] / (e["ms"] * 1e-3) / 1e9
+                    out[name] = {"kernel": key, "bound": "hbm", "achieved": a, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac": a / PEAK_HBM_GBS, "traffic": None,
+                                 "avg_launch_us": 1e3 * e["ms"] / e["launches"],
+                                 "share_of_step": e["ms"] / (1e3 * elapsed)}
+            out["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in prof.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -123,8 +123,10 @@ int adn_read_tensor(adn_model* m, int buffer /*adn_buffer*/, int index, float* h
 int adn_write_tensor(adn_model* m, int buffer /*adn_buffer*/, int index, const float* host_src);
 int64_t adn_total_param_count(const adn_model* m); /* logical elements (17 999 676 for 3-stream concat) */
 
-/* flat device buffers (physical layout incl. alignment padding); the gradient buffer is what a
- * data-parallel caller all-reduces */
+/* flat device buffers (physical layout incl. alignment padding, plus a tail of 8 floats); the gradient
+ * buffer is what a data-parallel caller all-reduces.  After adn_compute_grads the first
+ * tail float of the gradient buffer holds this call's share of the cost, so ONE all-reduce sums the
+ * gradients and the cost together. */
 int adn_flat_buffer(adn_model* m, int buffer /*adn_buffer*/, void** device_ptr, size_t* bytes);
 
 /* <- val_fn(inputs..., mask, window) -> probabilities (B,T,C)  (runners/3stream.py:320) */
@@ -158,6 +160,19 @@ int adn_train_step(adn_model* m, const void* const* inputs, const int32_t* targe
 int adn_read_encoder_activation(adn_model* m, int stream, int layer, float* host_dst);
 
 int adn_synchronize(adn_model* m);
+
+/* per-kernel-class timing with HIP events recorded on the model's stream around every launch of the
+ * class (bench.py's live roofline measurement).  flops / bytes are the ALGORITHMIC work of the launches
+ * (DESIGN.md "Kernels"), ms their summed durations. */
+typedef struct {
+    char name[32];
+    int64_t launches;
+    double ms;
+    double flops;
+    double bytes;
+} adn_profile_entry;
+int adn_profile_enable(adn_model* m, int on);  /* on != 0: clear the counters and start recording */
+int adn_profile_read(adn_model* m, adn_profile_entry* out, int max_entries, int* n_out); /* synchronises */
 
 /* ---- operator-level entry points (used by the parity tests and micro-benchmarks) -------------- */
 /* C (+)= op(A)*op(B) on device pointers; layout 0 = NN, 1 = NT (B given as [N][K]), 2 = TN (A as [K][M]) */

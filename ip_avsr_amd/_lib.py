@@ -40,6 +40,11 @@ class ParamInfo(C.Structure):
     _fields_ = [("name", C.c_char * 96), ("ndim", C.c_int32), ("dims", C.c_int64 * 2), ("numel", C.c_int64)]
 
 
+class ProfileEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("launches", C.c_int64), ("ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
 class AdenetError(RuntimeError):
     pass
 
@@ -68,6 +73,8 @@ _SIGNATURES = {
     "adn_train_step": (C.c_int, [_P, C.POINTER(_P), _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
     "adn_read_encoder_activation": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "adn_synchronize": (C.c_int, [_P]),
+    "adn_profile_enable": (C.c_int, [_P, C.c_int]),
+    "adn_profile_read": (C.c_int, [_P, C.POINTER(ProfileEntry), C.c_int, C.POINTER(C.c_int)]),
     "adn_op_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int, _P,
                               C.c_int, C.c_int, _P]),
     "adn_op_delta_forward": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

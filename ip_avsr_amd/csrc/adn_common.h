@@ -36,6 +36,21 @@ void set_error(const std::string& msg);
         if (_s != ADN_OK) return _s;                                                     \
     } while (0)
 
+// ---------------------------------------------------------------------------------------
+// in-stream kernel timing (HIP events on the stream the kernels are launched on); used by bench.py
+// to measure per-kernel-class durations live.  Disabled (zero cost) unless adn_profile_enable(m, 1).
+// ---------------------------------------------------------------------------------------
+enum ProfClass {
+    PROF_GEMM_NN = 0, PROF_GEMM_NT, PROF_GEMM_TN, PROF_LSTM_FWD, PROF_LSTM_BWD, PROF_DELTA_FWD, PROF_DELTA_BWD,
+    PROF_ADAM, PROF_SOFTMAX_LOSS, PROF_COUNT
+};
+struct ProfScope {
+    ProfScope(int cls, double flops, double bytes, hipStream_t s);
+    ~ProfScope();
+    int slot;
+    hipStream_t stream;
+};
+
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // leading dimension (in floats) used for every matrix in HBM: rows start 32-byte aligned

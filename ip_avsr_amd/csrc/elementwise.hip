@@ -116,6 +116,7 @@ int delta_forward(const float* in, int ld_in, float* out, int ld_out, int B, int
     ADN_CHECK(T > 0 && B > 0 && F > 0, ADN_ERR_INVALID, "delta_forward: empty tensor");
     const size_t lds = (size_t)2 * T * kDeltaFC * sizeof(float);
     ADN_CHECK(lds <= 64 * 1024, ADN_ERR_INVALID, "delta layer: T too large (max 256 frames)");
+    ProfScope prof(PROF_DELTA_FWD, 0.0, 4.0 * B * T * (double)F * (append ? 4.0 : 2.0), s);
     hipLaunchKernelGGL(delta_fwd_kernel, dim3(B, cdiv(F, kDeltaFC)), dim3(256), lds, s, in, ld_in, out, ld_out, B, T,
                        F, theta, append);
     ADN_HIP_CHECK(hipGetLastError());
@@ -127,6 +128,7 @@ int delta_backward(const float* dout, int ld_out, float* din, int ld_in, int B, 
     ADN_CHECK(T > 0 && B > 0 && F > 0, ADN_ERR_INVALID, "delta_backward: empty tensor");
     const size_t lds = (size_t)2 * T * kDeltaFC * sizeof(float);
     ADN_CHECK(lds <= 64 * 1024, ADN_ERR_INVALID, "delta layer: T too large (max 256 frames)");
+    ProfScope prof(PROF_DELTA_BWD, 0.0, 4.0 * B * T * (double)F * (append ? 4.0 : 2.0), s);
     hipLaunchKernelGGL(delta_bwd_kernel, dim3(B, cdiv(F, kDeltaFC)), dim3(256), lds, s, dout, ld_out, din, ld_in, B,
                        T, F, theta, append);
     ADN_HIP_CHECK(hipGetLastError());
@@ -365,6 +367,7 @@ int softmax_loss(const float* z, int ldz, int B, int T, int C, const uint8_t* ma
                  const float* total, float* probs_bt, float* row_loss, float* dz, int lddz, hipStream_t s) {
     ADN_CHECK(C >= 1 && C <= ADN_MAX_CLASSES, ADN_ERR_INVALID, "softmax: unsupported number of classes");
     const int rows = B * T;
+    ProfScope prof(PROF_SOFTMAX_LOSS, 0.0, 4.0 * rows * (double)C * (dz ? 3.0 : 2.0), s);
     if (C <= 32) {
         hipLaunchKernelGGL(softmax_loss_kernel<32>, dim3(cdiv(rows, 8)), dim3(256), 0, s, z, ldz, B, T, C, mask_tb,
                            y_bt, total, probs_bt, row_loss, dz, lddz);
@@ -433,6 +436,7 @@ int adam_update(float* p, const float* g, float* m, float* v, int64_t n, float a
                 float eps, hipStream_t s) {
     if (n <= 0) return ADN_OK;
     const int64_t n4 = n / 4;
+    ProfScope prof(PROF_ADAM, 0.0, 7.0 * 4.0 * (double)n, s);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(std::max<int64_t>(n4, 1))), dim3(256), 0, s, p, g, m, v, n4, n, a_t,
                        beta1, beta2, eps);
     ADN_HIP_CHECK(hipGetLastError());

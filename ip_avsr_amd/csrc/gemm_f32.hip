@@ -232,10 +232,14 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
 
     const int64_t t128 = (int64_t)cdiv(g.M, 128) * cdiv(g.N, 128);
     const int64_t t64 = (int64_t)cdiv(g.M, 64) * cdiv(g.N, 64);
-    const bool big = t128 >= 384;            // >= 1.5 waves of 128x128 tiles over the 256 CUs
+    const bool can_split = g.act == ADN_ACT_LINEAR;
+    // 128x128 tiles (4 MFMA tiles per wave, half the LDS fragment reads per MFMA of the 64x64 shape) whenever
+    // the grid can still fill 256 CUs: either by tile count alone or together with split-K (weight gradients:
+    // K = all frames of the batch)
+    const bool big = t128 >= 384 || (can_split && t128 >= 24 && g.K >= 2048);
     const int64_t tiles = big ? t128 : t64;
     int split = 1;
-    if (tiles < 256 && g.K >= 512 && g.act == ADN_ACT_LINEAR) {
+    if (tiles < 384 && g.K >= 512 && can_split) {
         split = (int)((768 + tiles - 1) / tiles);
         split = std::min(split, g.K / 128);
         split = std::max(1, std::min(split, 128));
@@ -243,6 +247,8 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
     p.k_chunk = (int)round_up(cdiv(g.K, split), BK);
     split = cdiv(g.K, p.k_chunk);
     p.atomic = split > 1;
+    ProfScope prof(PROF_GEMM_NN + g.layout, 2.0 * g.M * g.N * g.K,
+                   4.0 * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N), stream);
     if (p.atomic && !g.accumulate)
         ADN_HIP_CHECK(hipMemset2DAsync(g.C, (size_t)g.ldc * 4, 0, (size_t)g.N * 4, g.M, stream));
     if (big) {

@@ -112,8 +112,12 @@ int lstm_forward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T,
     const int ldh = ld_of(H), ldg = ld_of(4 * H);
     const int kc = (int)round_up(cdiv(H, 4), 8);
     const dim3 grid(cdiv(B, 32), cdiv(H, 8), n);
-    for (int step = 0; step < T; ++step)
+    // algorithmic work per LSTM per step: bytes = 4*(12BH + 4H^2) + B, flops = 8BH^2
+    const double bytes = n * (4.0 * (12.0 * B * H + 4.0 * H * H) + B), flops = n * 8.0 * B * H * H;
+    for (int step = 0; step < T; ++step) {
+        ProfScope prof(PROF_LSTM_FWD, flops, bytes, s);
         hipLaunchKernelGGL(lstm_fwd_step_kernel, grid, dim3(256), 0, s, L, mask_tb, B, T, H, ldh, ldg, step, kc);
+    }
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }
@@ -229,8 +233,12 @@ int lstm_backward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T
     }
     const int kc = (int)round_up(cdiv(4 * H, 4), 16);
     const dim3 grid(cdiv(B, 16), cdiv(H, 16), n);
-    for (int step = 0; step <= T; ++step)
+    // algorithmic work per LSTM per step: bytes = 4*(15BH + 4H^2), flops = 8BH^2
+    const double bytes = n * 4.0 * (15.0 * B * H + 4.0 * H * H), flops = n * 8.0 * B * H * H;
+    for (int step = 0; step <= T; ++step) {
+        ProfScope prof(PROF_LSTM_BWD, step ? flops : 0.0, step < T ? bytes : 0.0, s);
         hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, dim3(256), 0, s, L, mask_tb, B, T, H, ldh, ldg, step, kc);
+    }
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }

@@ -28,9 +28,56 @@ namespace adn {
 static thread_local std::string g_last_error;
 void set_error(const std::string& msg) { g_last_error = msg; }
 
+// ------------------------------------------------------------------------------------------
+// profiler
+// ------------------------------------------------------------------------------------------
+struct Profiler {
+    struct Rec { hipEvent_t a, b; int cls; double flops, bytes; };
+    bool enabled = false;
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    double ms[PROF_COUNT] = {0}, flops[PROF_COUNT] = {0}, bytes[PROF_COUNT] = {0};
+    int64_t launches[PROF_COUNT] = {0};
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e; (void)hipEventCreate(&e); return e;
+    }
+    void drain() {                      // caller has synchronised the stream
+        for (auto& r : recs) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) ms[r.cls] += t;
+            flops[r.cls] += r.flops; bytes[r.cls] += r.bytes; launches[r.cls] += 1;
+            pool.push_back(r.a); pool.push_back(r.b);
+        }
+        recs.clear();
+    }
+    void reset() {
+        drain();
+        for (int k = 0; k < PROF_COUNT; ++k) { ms[k] = flops[k] = bytes[k] = 0; launches[k] = 0; }
+    }
+    ~Profiler() { drain(); for (auto e : pool) (void)hipEventDestroy(e); }
+};
+static thread_local Profiler* g_prof = nullptr;
+
+ProfScope::ProfScope(int cls, double flops, double bytes, hipStream_t s) : slot(-1), stream(s) {
+    Profiler* p = g_prof;
+    if (!p || !p->enabled) return;
+    Profiler::Rec r{p->get(), p->get(), cls, flops, bytes};
+    (void)hipEventRecord(r.a, s);
+    p->recs.push_back(r);
+    slot = (int)p->recs.size() - 1;
+}
+ProfScope::~ProfScope() {
+    if (slot >= 0 && g_prof) (void)hipEventRecord(g_prof->recs[slot].b, stream);
+}
+
 namespace {
 
+const char* const kProfNames[PROF_COUNT] = {"gemm_f32_nn", "gemm_f32_nt", "gemm_f32_tn", "lstm_fwd_step",
+                                            "lstm_bwd_step", "delta_fwd", "delta_bwd", "adam", "softmax_loss"};
+
 constexpr float kBeta1 = 0.9f, kBeta2 = 0.999f, kEps = 1e-8f;
+constexpr size_t kAuxFloats = 8;   // [0] = this rank's share of the cost (summed by the DP all-reduce)
 const char* const kGateNames[4] = {"ingate", "forgetgate", "cell", "outgate"};
 
 struct ParamDesc {
@@ -116,6 +163,7 @@ struct adn_model {
     float *pingA = nullptr, *pingB = nullptr;
     int ping_ld = 0;
     int lastB = 0, lastT = 0;
+    Profiler prof;
 
     float* P(size_t off) const { return flat[ADN_BUF_PARAM] + off; }
     float* G(size_t off) const { return flat[ADN_BUF_GRAD] + off; }
@@ -518,7 +566,9 @@ int lstm_input_grad(adn_model* m, const LstmParams& lp, const LstmWork& w, int j
 int backward_pass(adn_model* m, int B, int T, int theta) {
     const int N = B * T, H = m->H, ldh = m->ldh;
     hipStream_t s = m->stream;
-    ADN_HIP_CHECK(hipMemsetAsync(m->flat[ADN_BUF_GRAD], 0, m->flat_floats * sizeof(float), s));
+    ADN_HIP_CHECK(hipMemsetAsync(m->flat[ADN_BUF_GRAD], 0, (m->flat_floats + kAuxFloats) * sizeof(float), s));
+    ADN_HIP_CHECK(hipMemcpyAsync(m->flat[ADN_BUF_GRAD] + m->flat_floats, m->loss, sizeof(float),
+                                 hipMemcpyDeviceToDevice, s));
     const float* cls = classifier_input(m, B);
     {   // classifier
         GemmArgs g;
@@ -707,9 +757,9 @@ int adn_create(const adn_config* cfg, adn_model** out) {
     m->ldh = ld_of(m->H); m->ldg = ld_of(4 * m->H); m->ldc = ld_of(m->C);
     int st = build_params(m);
     if (st != ADN_OK) { delete m; return st; }
-    for (int k = 0; k < 4; ++k) {
-        if (hipMalloc((void**)&m->flat[k], m->flat_floats * sizeof(float)) != hipSuccess ||
-            hipMemset(m->flat[k], 0, m->flat_floats * sizeof(float)) != hipSuccess) {
+    for (int k = 0; k < 4; ++k) {     // + kAuxFloats: tail slot carried through the gradient all-reduce
+        if (hipMalloc((void**)&m->flat[k], (m->flat_floats + kAuxFloats) * sizeof(float)) != hipSuccess ||
+            hipMemset(m->flat[k], 0, (m->flat_floats + kAuxFloats) * sizeof(float)) != hipSuccess) {
             set_error("hipMalloc of the parameter buffers failed");
             adn_destroy(m);
             return ADN_ERR_HIP;
@@ -722,6 +772,7 @@ int adn_create(const adn_config* cfg, adn_model** out) {
 void adn_destroy(adn_model* m) {
     if (!m) return;
     (void)hipStreamSynchronize(m->stream);
+    if (g_prof == &m->prof) g_prof = nullptr;
     for (int k = 0; k < 4; ++k) if (m->flat[k]) (void)hipFree(m->flat[k]);
     if (m->slab) (void)hipFree(m->slab);
     delete m;
@@ -760,7 +811,7 @@ int adn_flat_buffer(adn_model* m, int buffer, void** device_ptr, size_t* bytes) 
     ADN_CHECK(m && device_ptr && bytes, ADN_ERR_INVALID, "null argument");
     ADN_CHECK(buffer >= 0 && buffer < 4, ADN_ERR_INVALID, "bad buffer id");
     *device_ptr = m->flat[buffer];
-    *bytes = m->flat_floats * sizeof(float);
+    *bytes = (m->flat_floats + kAuxFloats) * sizeof(float);
     return ADN_OK;
 }
 
@@ -839,6 +890,31 @@ int adn_read_encoder_activation(adn_model* m, int stream, int layer, float* host
     ADN_HIP_CHECK(hipStreamSynchronize(m->stream));
     ADN_HIP_CHECK(hipMemcpy2D(host_dst, (size_t)u * 4, st.act[layer], (size_t)ld_of(u) * 4, (size_t)u * 4,
                               (size_t)m->lastB * m->lastT, hipMemcpyDeviceToHost));
+    return ADN_OK;
+}
+
+int adn_profile_enable(adn_model* m, int on) {
+    ADN_CHECK(m, ADN_ERR_INVALID, "null model");
+    ADN_HIP_CHECK(hipStreamSynchronize(m->stream));
+    if (on) { m->prof.reset(); m->prof.enabled = true; g_prof = &m->prof; }
+    else { m->prof.drain(); m->prof.enabled = false; if (g_prof == &m->prof) g_prof = nullptr; }
+    return ADN_OK;
+}
+
+int adn_profile_read(adn_model* m, adn_profile_entry* out, int max_entries, int* n_out) {
+    ADN_CHECK(m && out && n_out, ADN_ERR_INVALID, "null argument");
+    ADN_HIP_CHECK(hipStreamSynchronize(m->stream));
+    m->prof.drain();
+    int n = 0;
+    for (int k = 0; k < PROF_COUNT && n < max_entries; ++k) {
+        if (!m->prof.launches[k]) continue;
+        memset(&out[n], 0, sizeof(out[n]));
+        strncpy(out[n].name, kProfNames[k], sizeof(out[n].name) - 1);
+        out[n].launches = m->prof.launches[k]; out[n].ms = m->prof.ms[k];
+        out[n].flops = m->prof.flops[k]; out[n].bytes = m->prof.bytes[k];
+        ++n;
+    }
+    *n_out = n;
     return ADN_OK;
 }
 

@@ -309,6 +309,19 @@ class AdeNetModel(object):
                                             float(learning_rate), C.byref(out) if want_loss else None))
         return np.float32(out.value) if want_loss else None
 
+    def profile(self, on=True):
+        """Start (on=True, counters cleared) or stop per-kernel-class HIP-event timing."""
+        _lib.check(self._lib.adn_profile_enable(self._handle, int(bool(on))))
+
+    def profile_read(self):
+        """{class: dict(launches, ms, flops, bytes)} accumulated since profile(True); synchronises."""
+        buf = (_lib.ProfileEntry * 16)()
+        n = C.c_int()
+        _lib.check(self._lib.adn_profile_read(self._handle, buf, 16, C.byref(n)))
+        return {buf[i].name.decode(): dict(launches=int(buf[i].launches), ms=float(buf[i].ms),
+                                           flops=float(buf[i].flops), bytes=float(buf[i].bytes))
+                for i in range(n.value)}
+
     def encoder_activation(self, stream, layer, B, T):
         u = self.spec["streams"][stream]["enc_shapes"][layer]
         out = np.empty((B * T, u), dtype=np.float32)

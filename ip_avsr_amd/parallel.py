@@ -1,0 +1,89 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU, ``torch.distributed`` with the
+``nccl`` backend (= RCCL over xGMI on ROCm).  SURVEY.md §8e: utterances of a minibatch are independent
+through the whole graph, so each rank runs the full step on its shard and the only exchange is ONE
+all-reduce (sum) of the flat fp32 gradient buffer, followed by an identical local Adam step on every
+rank (Adam state replicated, step counters in lock-step).
+
+Exactness: the loss normaliser is the number of valid frames of the GLOBAL batch
+(custom/objectives.py:32,37).  Every rank can compute it without communication, because all ranks draw
+the same utterance permutation and know every utterance's length; it is passed to the library, which
+normalises BEFORE back-propagation (the +-5 gate-gradient clip inside BPTT is not scale invariant).
+The sum of the ranks' gradients then equals the single-GPU gradient.  The padded length T must be the
+split's global maximum on every rank (the delta layer is mask-blind).
+
+The reference has no distributed code at all; this module is new work.
+"""
+import numpy as np
+
+from . import _lib
+
+
+class _DeviceBuffer(object):
+    """Exposes a raw device allocation through ``__cuda_array_interface__`` so that torch can wrap it
+    without a copy."""
+
+    def __init__(self, ptr, n_floats):
+        self.__cuda_array_interface__ = {"shape": (int(n_floats),), "typestr": "<f4", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def wrap_flat_buffer(model, which=_lib.BUF_GRAD, device=None):
+    """Zero-copy torch view (1-D float32) of one of the model's flat buffers."""
+    import torch
+    ptr, nbytes = model.flat_buffer(which)
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    t = torch.as_tensor(_DeviceBuffer(ptr, nbytes // 4), device=dev)
+    if t.data_ptr() != ptr:
+        raise RuntimeError("torch copied the gradient buffer instead of wrapping it")
+    return t
+
+
+def shard_indices(batch_idxs, rank, world_size):
+    """Rank r's utterances of a global minibatch: batch_idxs[r::R]."""
+    return list(batch_idxs)[rank::world_size]
+
+
+class DataParallel(object):
+    """Wraps an ``AdeNetModel`` living on this rank's GPU.
+
+    ``backend_tensor``: for the CPU test path (gloo, no GPU) a callable returning a host tensor stands in
+    for the device gradient buffer; on a GPU box leave it None.
+    """
+
+    def __init__(self, model, process_group=None, grad_tensor=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.model = model
+        self.group = process_group
+        self.world_size = dist.get_world_size(process_group)
+        self.rank = dist.get_rank(process_group)
+        self.grad = grad_tensor if grad_tensor is not None else wrap_flat_buffer(model)
+
+    def broadcast_parameters(self, src=0):
+        """Make every replica start from rank ``src``'s parameters and Adam state."""
+        for which in (_lib.BUF_PARAM, _lib.BUF_ADAM_M, _lib.BUF_ADAM_V):
+            self.dist.broadcast(wrap_flat_buffer(self.model, which), src=src, group=self.group)
+
+    def train_step(self, inputs, targets, mask, window, learning_rate, global_total_frames, want_loss=False):
+        """One data-parallel step on this rank's shard.  ``global_total_frames`` = valid frames of the whole
+        global batch.  Returns the GLOBAL cost (a host float) when ``want_loss`` (forces a sync)."""
+        self.model.compute_grads(inputs, targets, mask, window, total_frames=float(global_total_frames),
+                                 want_loss=False)
+        if self.world_size > 1:
+            # same stream as the model's kernels (torch's current stream): ordered after the backward pass
+            self.dist.all_reduce(self.grad, op=self.dist.ReduceOp.SUM, group=self.group)
+        self.model.apply_adam(learning_rate)
+        if want_loss:
+            return float(self.grad[-8].item())
+        return None
+
+
+def reduce_and_check_equal(values, group=None):
+    """Debug helper: max |x_r - x_0| over ranks of a 1-D tensor (0 means replicas are in lock-step)."""
+    import torch
+    import torch.distributed as dist
+    ref = values.clone()
+    dist.broadcast(ref, src=0, group=group)
+    d = (values - ref).abs().max().reshape(1)
+    dist.all_reduce(d, op=dist.ReduceOp.MAX, group=group)
+    return float(d.item())
