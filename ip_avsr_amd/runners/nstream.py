@@ -1,0 +1,362 @@
+"""Dataset-agnostic N-stream trainer: the epoch driver of reference runners/{1,2,3,4}stream.py, reading the
+same ``.ini`` files (SURVEY.md App. B schema 1) and ``.mat`` inputs (App. C), driving the MI355X model.
+
+    python ip_avsr_amd/runners/3stream.py --config config/trimodal.ini [--write_results F] [--learning_rate f]
+                                          [--save_best F] [--save_plot PREFIX]
+
+Data parallel (new; the reference is single-device): launch with
+``python -m torch.distributed.run --nproc-per-node N ip_avsr_amd/runners/3stream.py --config ...``; every rank
+draws the same minibatch order (``--seed``), trains on ``batch_idxs[rank::N]`` and all-reduces gradients
+(ip_avsr_amd/parallel.py).  Rank 0 evaluates and reports.
+
+Behaviour kept from the reference: per-epoch train cost is the cost of the LAST minibatch re-evaluated after
+its update (App. E-7); GL / Pk / PQ statistics; best-parameter snapshot on validation-cost improvement;
+``early_stop2``; results line ``test_cr,best_cr,best_val``; pickled parameter list for ``--save_best``.
+"""
+from __future__ import print_function
+
+import argparse
+import configparser
+import os
+import sys
+import time
+
+import numpy as np
+import scipy.io as sio
+
+from .. import init as las_init
+from ..custom.nonlinearities import select_nonlinearity
+from ..modelzoo import (adenet_2stream, adenet_3stream, adenet_4stream, adenet_v2_2, deltanet_majority_vote)
+from ..utils.data_structures import circular_list
+from ..utils.datagen import compute_integral_len, gen_lstm_batch_random, gen_seq_batch_from_idx
+from ..utils.io import load_mat_file, read_data_split_file, save_model_params
+from ..utils.plotting_utils import plot_confusion_matrix, plot_validation_cost, print_network
+from ..utils.preprocessing import (compute_diff_images, featurewise_normalize_sequence, multistream_force_align,
+                                   normalize_input, reorder_data, sequencewise_mean_image_subtraction, split_seq_data)
+from ..utils.regularization import early_stop2
+
+
+def load_decoder(path, shapes, nonlinearities):
+    """``.mat`` with w1..wN / b1..bN -> (weights, biases, shapes, nonlinearities): the ``ae`` argument of every
+    factory (reference runners/3stream.py:31-40)."""
+    nn = sio.loadmat(path)
+    shapes = [int(s) for s in shapes.split(',')]
+    nonlins = [select_nonlinearity(n.strip()) for n in nonlinearities.split(',')]
+    weights = [nn['w{}'.format(i + 1)].astype('float32') for i in range(len(shapes))]
+    biases = [nn['b{}'.format(i + 1)][0].astype('float32') for i in range(len(shapes))]
+    return weights, biases, shapes, nonlins
+
+
+def evaluate_model2(X_vals, y_val, mask_val, window_size, eval_fn):
+    """Majority vote over each utterance's valid frames, ties to the lowest class id; returns
+    (classification rate, confusion matrix [target, prediction]) (reference runners/3stream.py:48-82).
+    ``X_vals`` is the list of stream inputs."""
+    output = eval_fn(*(list(X_vals) + [mask_val, window_size]))
+    num_classes = output.shape[-1]
+    seq_lens = np.sum(mask_val, axis=-1).astype(int)
+    frame_pred = np.argmax(output, axis=-1)                               # (N, T)
+    valid = np.arange(output.shape[1])[None, :] < seq_lens[:, None]
+    votes = np.zeros((len(output), num_classes), dtype='int')
+    for cls in range(num_classes):
+        votes[:, cls] = np.sum((frame_pred == cls) & valid, axis=1)
+    ix = np.argmax(votes, axis=1)
+    classification_rate = np.sum(ix == np.asarray(y_val)) / float(len(ix))
+    confusion_matrix = np.zeros((num_classes, num_classes), dtype='int')
+    np.add.at(confusion_matrix, (np.asarray(y_val).astype(int), ix), 1)
+    return classification_rate, confusion_matrix
+
+
+def presplit_dataprocessing(data_matrix, vidlens, config, stream_name, **kwargs):
+    """reorder -> mean removal -> diff images -> per-frame z-norm (reference runners/3stream.py:85-99)."""
+    if config.getboolean(stream_name, 'reorderdata'):
+        data_matrix = reorder_data(data_matrix, kwargs['imagesize'])
+    if config.getboolean(stream_name, 'meanremove'):
+        data_matrix = sequencewise_mean_image_subtraction(data_matrix, vidlens)
+    if config.getboolean(stream_name, 'diffimage'):
+        data_matrix = compute_diff_images(data_matrix, vidlens)
+    if config.getboolean(stream_name, 'samplewisenormalize'):
+        data_matrix = normalize_input(data_matrix)
+    return data_matrix
+
+
+def postsplit_datapreprocessing(train_X, val_X, test_X, config, stream_name):
+    """feature-wise z-norm with the TRAIN split's statistics (reference runners/3stream.py:102-108)."""
+    if config.getboolean(stream_name, 'featurewisenormalize'):
+        train_X, mean, std = featurewise_normalize_sequence(train_X)
+        val_X = (val_X - mean) / std
+        test_X = (test_X - mean) / std
+    return train_X, val_X, test_X
+
+
+def parse_options(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--config', help='[CONFIG_FILE] config file to use')
+    parser.add_argument('--write_results', help='[FILE] write results to file')
+    parser.add_argument('--learning_rate', help='[LEARNING_RATE] learning rate')
+    parser.add_argument('--save_best', help='[FILE] save the best model')
+    parser.add_argument('--save_plot', help='[FILE_PREFIX] plot the train/validation loss curve')
+    parser.add_argument('--seed', type=int, default=None, help='seed for initialisers and minibatch order '
+                                                               '(the reference never seeds; required >1 GPU)')
+    args = parser.parse_args(argv)
+    options = {'config': args.config or 'config/bimodal_meanrm_raw_diff.ini'}
+    for key in ('write_results', 'save_best', 'save_plot'):
+        if getattr(args, key):
+            options[key] = getattr(args, key)
+    if args.learning_rate:
+        options['learning_rate'] = float(args.learning_rate)
+    options['seed'] = args.seed
+    return options
+
+
+def _dist_context():
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world == 1:
+        return None, 0, 1
+    import torch
+    import torch.distributed as dist
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    return dist, dist.get_rank(), world
+
+
+def build_network(n_streams, aes, dims, lstm_weights, cfg):
+    """Picks the same factory the reference runner of that stream count picks."""
+    shapes = [(None, None, d) for d in dims]
+    ms = (None, None)
+    kw = dict(w_init_fn=cfg['weight_init_fn'], use_peepholes=cfg['use_peepholes'])
+    H, C, fuse = cfg['lstm_size'], cfg['output_classes'], cfg['fusiontype']
+    if n_streams == 1:           # runners/1stream.py:224-229
+        net = deltanet_majority_vote.create_model(aes[0], shapes[0], None, ms, None, H, None, C,
+                                                  cfg['weight_init_fn'], cfg['use_peepholes'], cfg['use_blstm'])
+        return net, None
+    if n_streams == 2:           # runners/2stream.py:256-272
+        if lstm_weights[0] is not None and lstm_weights[1] is not None:
+            return adenet_2stream.create_pretrained_model(aes[0], lstm_weights[0], aes[1], lstm_weights[1], shapes[0],
+                                                          None, shapes[1], None, ms, None, H, None, C, fuse,
+                                                          use_blstm_substream=cfg['use_blstm_substream'], **kw)
+        return adenet_v2_2.create_model(aes[0], aes[1], shapes[0], None, ms, None, shapes[1], None, H, None, C, fuse,
+                                        **kw)
+    if n_streams == 3:           # runners/3stream.py:293-299
+        return adenet_3stream.create_model(aes[0], aes[1], aes[2], shapes[0], None, shapes[1], None, shapes[2], None,
+                                           ms, None, H, None, C, fuse, **kw)
+    if n_streams == 4:           # runners/4stream.py:321-328
+        return adenet_4stream.create_model(aes[0], aes[1], aes[2], aes[3], shapes[0], None, shapes[1], None, shapes[2],
+                                           None, shapes[3], None, ms, None, H, None, C, fuse, **kw)
+    raise ValueError('1 to 4 streams are supported')
+
+
+def main(n_streams, argv=None):
+    options = parse_options(argv)
+    dist, rank, world = _dist_context()
+    if world > 1 and options['seed'] is None:
+        options['seed'] = 1234                      # ranks must agree on initial weights and minibatch order
+    if options['seed'] is not None:
+        np.random.seed(options['seed'])
+        las_init.set_rng(np.random.RandomState(options['seed']))
+    say = print if rank == 0 else (lambda *a, **k: None)
+
+    config = configparser.ConfigParser()
+    config.read(options['config'])
+    names = ['stream{}'.format(k + 1) for k in range(n_streams)]
+    say('CLI options: {}'.format(list(options.items())))
+    say('Reading Config File: {}...'.format(options['config']))
+    for sec in names + ['lstm_classifier', 'training']:
+        say(config.items(sec))
+
+    say('preprocessing dataset...')
+    data = [load_mat_file(config.get(n, 'data')) for n in names]
+    imagesizes = [tuple(int(d) for d in config.get(n, 'imagesize').split(',')) for n in names]
+    dims = [config.getint(n, 'input_dimensions') for n in names]
+    lstm_weights = [sio.loadmat(config.get(n, 'lstm_model')) if config.has_option(n, 'lstm_model') else None
+                    for n in names]
+
+    lc = 'lstm_classifier'
+    cfg = dict(
+        fusiontype=config.get(lc, 'fusiontype') if config.has_option(lc, 'fusiontype') else 'none',
+        use_peepholes=config.getboolean(lc, 'use_peepholes'),
+        lstm_size=config.getint(lc, 'lstm_size'),
+        output_classes=config.getint(lc, 'output_classes'),
+        use_blstm=config.getboolean(lc, 'use_blstm') if config.has_option(lc, 'use_blstm') else True,
+        use_blstm_substream=(config.getboolean(lc, 'use_blstm_substream')
+                             if config.has_option(lc, 'use_blstm_substream') else False))
+    cfg['weight_init_fn'] = las_init.select(config.get(lc, 'weight_init'))
+    windowsize = config.getint(lc, 'windowsize')
+    output_classnames = config.get(lc, 'output_classnames').split(',')
+    matlab_target_offset = config.getboolean(lc, 'matlab_target_offset')
+    if config.has_option(lc, 'use_dropout') and config.getboolean(lc, 'use_dropout'):
+        raise NotImplementedError('use_dropout (adenet_3stream_dropout) is not built yet: SURVEY.md §8f-1')
+
+    validation_window = config.getint('training', 'validation_window')
+    num_epoch = config.getint('training', 'num_epoch')
+    learning_rate = options.get('learning_rate', config.getfloat('training', 'learning_rate'))
+    epochsize = config.getint('training', 'epochsize')
+    batchsize = config.getint('training', 'batchsize')
+    train_ids = read_data_split_file(config.get('training', 'train_subjects_file'))
+    val_ids = read_data_split_file(config.get('training', 'val_subjects_file'))
+    test_ids = read_data_split_file(config.get('training', 'test_subjects_file'))
+
+    mats = [d['dataMatrix'].astype('float32') for d in data]
+    targets_vec = data[0]['targetsVec'].reshape((-1,)).astype('int64')
+    subjects_vec = data[0]['subjectsVec'].reshape((-1,))
+    vidlen_vec = data[0]['videoLengthVec'].reshape((-1,))
+    if matlab_target_offset:
+        targets_vec = targets_vec - 1
+
+    if n_streams == 1:
+        # runners/1stream.py:175-207: reorder, split, THEN the per-split preprocessing
+        if config.getboolean('stream1', 'reorderdata'):
+            mats[0] = reorder_data(mats[0], imagesizes[0])
+        parts = split_seq_data(mats[0], targets_vec, subjects_vec, vidlen_vec, train_ids, val_ids, test_ids)
+        split = dict(zip(('train', 'val', 'test'), ([parts[0]], [parts[4]], [parts[8]])))
+        ys = dict(train=parts[1], val=parts[5], test=parts[9])
+        lens = dict(train=parts[2], val=parts[6], test=parts[10])
+        for k in split:
+            X = split[k][0]
+            if config.getboolean('stream1', 'meanremove'):
+                X = sequencewise_mean_image_subtraction(X, lens[k])
+            if config.getboolean('stream1', 'diffimage'):
+                X = compute_diff_images(X, lens[k])
+            if config.getboolean('stream1', 'samplewisenormalize'):
+                X = normalize_input(X)
+            split[k][0] = X
+        tr, va, te = postsplit_datapreprocessing(split['train'][0], split['val'][0], split['test'][0], config, 'stream1')
+        split = dict(train=[tr], val=[va], test=[te])
+    else:
+        mats = [presplit_dataprocessing(mats[k], vidlen_vec, config, names[k], imagesize=imagesizes[k])
+                for k in range(n_streams)]
+        if config.has_option('stream1', 'force_align_data') and config.getboolean('stream1', 'force_align_data'):
+            orig = [(mats[0], targets_vec, vidlen_vec)]
+            for k in range(1, n_streams):
+                orig.append((mats[k], data[k]['targetsVec'].reshape((-1,)), data[k]['videoLengthVec'].reshape((-1,))))
+            new = multistream_force_align(orig)
+            mats[0], targets_vec, vidlen_vec = new[0]
+            for k in range(1, n_streams):
+                mats[k] = new[k][0]
+        split = dict(train=[], val=[], test=[])
+        for k in range(n_streams):
+            parts = split_seq_data(mats[k], targets_vec, subjects_vec, vidlen_vec, train_ids, val_ids, test_ids)
+            tr, va, te = postsplit_datapreprocessing(parts[0], parts[4], parts[8], config, names[k])
+            split['train'].append(tr); split['val'].append(va); split['test'].append(te)
+            if k == 0:
+                ys = dict(train=parts[1], val=parts[5], test=parts[9])
+                lens = dict(train=parts[2], val=parts[6], test=parts[10])
+
+    aes = [load_decoder(config.get(n, 'model'), config.get(n, 'shape'), config.get(n, 'nonlinearities'))
+           for n in names]
+    say('constructing end to end model...')
+    network, l_fuse = build_network(n_streams, aes, dims, lstm_weights, cfg)
+    if rank == 0:
+        print_network(network)
+    say('compiling model...')
+    order = 'in1,targets,mask,in2,window' if n_streams == 2 else 'inputs,targets,mask,window'
+    train, compute_train_cost, compute_test_cost, val_fn = network.compile(learning_rate, order)
+    dp = None
+    if world > 1:
+        from ..parallel import DataParallel, shard_indices
+        dp = DataParallel(network)
+        dp.broadcast_parameters(0)
+
+    def call(fn, Xs, *rest):                        # the 2-stream runner interleaves its arguments
+        if n_streams == 2:
+            if len(rest) == 3:
+                return fn(Xs[0], rest[0], rest[1], Xs[1], rest[2])
+            return fn(Xs[0], rest[0], Xs[1], rest[1])
+        return fn(*(list(Xs) + list(rest)))
+
+    def eval_fn(*args):                             # evaluate_model2 passes inputs..., mask, window
+        return call(val_fn, list(args[:n_streams]), *args[n_streams:])
+
+    say('begin training...')
+    cost_train, cost_val, class_rate = [], [], []
+    STRIP_SIZE = 3
+    val_window = circular_list(validation_window)
+    train_strip = np.zeros((STRIP_SIZE,))
+    best_val, best_cr, test_cr, test_conf, best_params = float('inf'), 0.0, 0.0, None, None
+
+    tr_lens = lens['train']
+    tmax_train = int(np.max(tr_lens))
+    datagen = gen_lstm_batch_random(split['train'][0], ys['train'], tr_lens, batchsize=batchsize)
+    integral_lens = compute_integral_len(tr_lens)
+
+    def whole_split(k):
+        gen = gen_lstm_batch_random(split[k][0], ys[k], lens[k], batchsize=len(lens[k]))
+        X1, y, m, idxs = next(gen)
+        il = compute_integral_len(lens[k])
+        Xs = [X1] + [gen_seq_batch_from_idx(split[k][s], idxs, lens[k], il, np.max(lens[k]))
+                     for s in range(1, n_streams)]
+        return Xs, y, m
+
+    X_val, y_val_evaluate, mask_val = whole_split('val')
+    X_test, y_test, mask_test = whole_split('test')
+    y_val = y_val_evaluate.reshape((-1, 1)).repeat(mask_val.shape[-1], axis=-1)
+
+    for epoch in range(num_epoch):
+        time_start = time.time()
+        for i in range(epochsize):
+            X1, y, m, batch_idxs = next(datagen)
+            y = y.reshape((-1, 1)).repeat(m.shape[-1], axis=-1)
+            Xs = [X1] + [gen_seq_batch_from_idx(split['train'][s], batch_idxs, tr_lens, integral_lens, tmax_train)
+                         for s in range(1, n_streams)]
+            if rank == 0:
+                print('Epoch {} batch {}/{}: {} examples using adam with learning rate = {}'.format(
+                    epoch + 1, i + 1, epochsize, len(X1), learning_rate), end='')
+                sys.stdout.flush()
+            if dp is None:
+                call(train, Xs, y, m, windowsize)
+            else:
+                mine = list(range(len(X1)))[rank::world]
+                dp.train_step([x[mine] for x in Xs], y[mine], m[mine], windowsize, learning_rate, float(m.sum()))
+            if rank == 0:
+                print('\r', end='')
+        cost = float(call(compute_train_cost, Xs, y, m, windowsize))
+        val_cost = float(call(compute_test_cost, X_val, y_val, mask_val, windowsize))
+        cost_train.append(cost)
+        cost_val.append(val_cost)
+        train_strip[epoch % STRIP_SIZE] = cost
+        val_window.push(val_cost)
+        gl = 100 * (cost_val[-1] / np.min(cost_val) - 1)
+        pk = 1000 * (np.sum(train_strip) / (STRIP_SIZE * np.min(train_strip)) - 1)
+        pq = gl / pk
+        cr, val_conf = evaluate_model2(X_val, y_val_evaluate, mask_val, windowsize, eval_fn)
+        class_rate.append(cr)
+        if val_cost < best_val:
+            best_val, best_cr = val_cost, cr
+            test_cr, test_conf = evaluate_model2(X_test, y_test, mask_test, windowsize, eval_fn)
+            say("Epoch {} train cost = {}, val cost = {}, GL loss = {:.3f}, GQ = {:.3f}, CR = {:.3f}, "
+                "Test CR= {:.3f} ({:.1f}sec)".format(epoch + 1, cost_train[-1], cost_val[-1], gl, pq, cr, test_cr,
+                                                     time.time() - time_start))
+            best_params = network.get_all_param_values()
+        else:
+            say("Epoch {} train cost = {}, val cost = {}, GL loss = {:.3f}, GQ = {:.3f}, CR = {:.3f} ({:.1f}sec)"
+                .format(epoch + 1, cost_train[-1], cost_val[-1], gl, pq, cr, time.time() - time_start))
+        if epoch >= validation_window and early_stop2(val_window, best_val, validation_window):
+            break
+
+    say('Final Model')
+    say('CR: {}, val loss: {}, Test CR: {}'.format(best_cr, best_val, test_cr))
+    if rank == 0:
+        table_str = plot_confusion_matrix(test_conf, output_classnames, fmt='pipe')
+        print('confusion matrix: ')
+        print(table_str)
+        if l_fuse is not None and cfg['fusiontype'] == 'adasum':
+            print('adascale coefficients: {}'.format(l_fuse.get_all_param_values(scaling_param=True)))
+        if 'save_plot' in options:
+            prefix = options['save_plot']
+            plot_validation_cost(cost_train, cost_val, savefilename='{}.validloss.png'.format(prefix))
+            with open('{}.confmat.txt'.format(prefix), mode='a') as f:
+                f.write(table_str + '\n\n')
+        if 'write_results' in options:
+            print('writing results to {}'.format(options['write_results']))
+            with open(options['write_results'], mode='a') as f:
+                f.write('{},{},{}\n'.format(test_cr, best_cr, best_val))
+        if 'save_best' in options:
+            print('saving best model...')
+            network.set_all_param_values(best_params)
+            save_model_params(network, options['save_best'])
+            print('best model saved to {}'.format(options['save_best']))
+    if dist is not None:
+        dist.destroy_process_group()
+    return dict(best_cr=best_cr, best_val=best_val, test_cr=test_cr, cost_train=cost_train, cost_val=cost_val,
+                class_rate=class_rate, network=network)

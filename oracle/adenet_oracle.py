@@ -254,22 +254,24 @@ def softmax_rows(z):
     return e / e.sum(axis=-1, keepdims=True)
 
 
-def temporal_softmax_loss(x, y, mask):
-    """x (B,T,C) are *already probabilities*; they are soft-maxed again."""
+def temporal_softmax_loss(x, y, mask, total_frames=None):
+    """x (B,T,C) are *already probabilities*; they are soft-maxed again.
+    ``total_frames`` overrides the normaliser (data parallel: the global batch's valid frames)."""
     N = x.shape[0] * x.shape[1]
     xf = x.reshape(N, -1)
     q = softmax_rows(xf)
     mf = mask.reshape(N).astype(x.dtype)
-    total = mf.sum()
+    total = mf.sum() if total_frames is None else x.dtype.type(total_frames)
     return -(mf * np.log(q[np.arange(N), y.reshape(N)])).sum() / total
 
 
-def temporal_softmax_loss_bwd(x, y, mask):
+def temporal_softmax_loss_bwd(x, y, mask, total_frames=None):
     N = x.shape[0] * x.shape[1]
     q = softmax_rows(x.reshape(N, -1))
     mf = mask.reshape(N).astype(x.dtype)
     q[np.arange(N), y.reshape(N)] -= 1
-    return (q * (mf / mf.sum())[:, None]).reshape(x.shape)
+    total = mf.sum() if total_frames is None else x.dtype.type(total_frames)
+    return (q * (mf / total)[:, None]).reshape(x.shape)
 
 
 # --------------------------------------------------------------------------- #
@@ -426,14 +428,14 @@ def forward(spec, p, inputs, mask, theta, want_cache=False):
     return (probs, cache) if want_cache else probs
 
 
-def loss_and_grads(spec, p, inputs, targets, mask, theta):
+def loss_and_grads(spec, p, inputs, targets, mask, theta, total_frames=None):
     """targets (B,T) int (label repeated over T, runners/3stream.py:360-361)."""
     B, T = mask.shape
     H = spec["lstm_size"]
     probs, cache = forward(spec, p, inputs, mask, theta, want_cache=True)
-    loss = temporal_softmax_loss(probs, targets, mask)
+    loss = temporal_softmax_loss(probs, targets, mask, total_frames)
     g = {}
-    dp = temporal_softmax_loss_bwd(probs, targets, mask).reshape(B * T, -1)
+    dp = temporal_softmax_loss_bwd(probs, targets, mask, total_frames).reshape(B * T, -1)
     pf = probs.reshape(B * T, -1)
     dz = pf * (dp - (dp * pf).sum(1, keepdims=True))       # through the network's own softmax
     sm = spec["softmax_name"]

@@ -1,0 +1,125 @@
+"""N>1 path on CPU: two processes, gloo backend, the package's DataParallel driving a replica whose
+compute is the oracle (the real replica needs a GPU).  Checks the data-parallel identity of SURVEY.md §8e:
+shard gradients normalised by the GLOBAL frame count and summed by one all-reduce reproduce the
+single-process step exactly, and the replicas stay in lock-step."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+class OracleReplica(object):
+    """Same call surface as AdeNetModel for what DataParallel uses, computed by the oracle in float64;
+    the flat gradient 'buffer' is a CPU tensor with the same 8-float tail (cost share in tail[0])."""
+
+    def __init__(self, spec, params):
+        from oracle import adenet_oracle as O
+        self.O, self.spec = O, spec
+        self.p = {k: v.copy() for k, v in params.items()}
+        self.names = O.param_names(spec)
+        self.sizes = [self.p[n].size for n in self.names]
+        self.grad = torch.zeros(sum(self.sizes) + 8, dtype=torch.float64)
+        self.state = O.adam_init(self.p)
+
+    def compute_grads(self, inputs, targets, mask, window, total_frames=0.0, want_loss=True):
+        loss, g, _ = self.O.loss_and_grads(self.spec, self.p, inputs, targets, mask, window,
+                                           total_frames=total_frames if total_frames > 0 else None)
+        flat = np.concatenate([np.asarray(g[n], np.float64).reshape(-1) for n in self.names] + [np.zeros(8)])
+        flat[-8] = loss
+        self.grad.copy_(torch.from_numpy(flat))
+        return loss if want_loss else None
+
+    def apply_adam(self, lr):
+        flat = self.grad.numpy()
+        g, off = {}, 0
+        for n, sz in zip(self.names, self.sizes):
+            g[n] = flat[off:off + sz].reshape(self.p[n].shape)
+            off += sz
+        self.O.adam_step(self.p, g, self.state, lr)
+
+
+def _make_problem():
+    from oracle import adenet_oracle as O
+    spec = O.spec_nstream([7, 6], enc_shapes=(6, 4), enc_acts=("rectify", "linear"), lstm_size=5, classes=4,
+                          fusion="concat", peepholes=True)
+    rng = np.random.default_rng(42)
+    p = O.init_params(spec, rng, np.float64, enc_std=0.5, perturb=0.2)
+    n_utt, T = 10, 7
+    lens = rng.integers(2, T + 1, size=n_utt); lens[3] = T
+    mask = (np.arange(T)[None, :] < lens[:, None]).astype(np.uint8)
+    xs = [rng.normal(size=(n_utt, T, s["input_dim"])) * mask[..., None] for s in spec["streams"]]
+    y = np.repeat(rng.integers(0, 4, size=(n_utt, 1)), T, axis=1)
+    return spec, p, xs, y, mask
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ip_avsr_amd.parallel import DataParallel, shard_indices
+        spec, p, xs, y, mask = _make_problem()
+        rep = OracleReplica(spec, p)
+        dp = DataParallel(rep, grad_tensor=rep.grad)
+        assert dp.world_size == world and dp.rank == rank
+        batch_idxs = list(range(len(mask)))                  # every rank sees the same global batch order
+        mine = shard_indices(batch_idxs, rank, world)
+        total = float(mask.sum())                            # known locally: all lengths are known to all ranks
+        losses = []
+        for step in range(3):
+            losses.append(dp.train_step([x[mine] for x in xs], y[mine], mask[mine], 2, 1e-2, total, want_loss=True))
+        flat = np.concatenate([rep.p[n].reshape(-1) for n in rep.names])
+        q.put((rank, losses, flat))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_matches_single_process():
+    from oracle import adenet_oracle as O
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    results.sort(key=lambda t: t[0])
+    # single-process reference on the whole batch
+    spec, p, xs, y, mask = _make_problem()
+    st = O.adam_init(p)
+    ref_losses = [O.train_step(spec, p, st, xs, y, mask, 2, 1e-2) for _ in range(3)]
+    ref_flat = np.concatenate([p[n].reshape(-1) for n in O.param_names(spec)])
+    for rank, losses, flat in results:
+        np.testing.assert_allclose(losses, ref_losses, rtol=1e-12, atol=1e-13)      # global cost via the tail slot
+        np.testing.assert_allclose(flat, ref_flat, rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(results[0][2], results[1][2])                      # replicas in lock-step
+
+
+def test_shard_indices_cover_the_batch_once():
+    from ip_avsr_amd.parallel import shard_indices
+    idx = list(np.random.default_rng(0).permutation(23))
+    for world in (1, 2, 4, 8):
+        shards = [shard_indices(idx, r, world) for r in range(world)]
+        assert sorted(sum(shards, [])) == sorted(idx)
+        assert max(map(len, shards)) - min(map(len, shards)) <= 1

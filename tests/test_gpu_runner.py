@@ -1,0 +1,103 @@
+"""End-to-end run of the N-stream driver on an MI355X: synthetic .mat datasets + DBN .mat files + an .ini in
+the reference's schema; checks the loop runs, the cost falls, the outputs (results line, pickle) appear and
+the pickle reloads into an identical model."""
+import os
+
+import numpy as np
+import pytest
+import scipy.io as sio
+
+pytestmark = pytest.mark.gpu
+
+INI = """
+[stream{k}]
+data = {root}/s{k}.mat
+imagesize = 4,6
+model = {root}/ae{k}.mat
+input_dimensions = 24
+shape = 16,12,8,5
+nonlinearities = rectify,rectify,rectify,linear
+reorderdata = {reorder}
+diffimage = {diff}
+meanremove = True
+samplewisenormalize = True
+featurewisenormalize = False
+force_align_data = False
+"""
+
+TAIL = """
+[lstm_classifier]
+fusiontype = {fusion}
+weight_init = glorot
+use_peepholes = False
+windowsize = 3
+output_classes = 4
+output_classnames = a,b,c,d
+lstm_size = 12
+matlab_target_offset = True
+use_dropout = False
+use_blstm = True
+
+[training]
+validation_window = 4
+num_epoch = 6
+learning_rate = 0.01
+epochsize = 5
+batchsize = 8
+train_subjects_file = {root}/train.txt
+val_subjects_file = {root}/val.txt
+test_subjects_file = {root}/test.txt
+"""
+
+
+def make_dataset(root, n_streams):
+    rng = np.random.RandomState(0)
+    subjects = np.repeat(np.arange(1, 9), 6)                 # 8 subjects x 6 utterances
+    n = len(subjects)
+    lens = rng.randint(5, 11, size=n)
+    labels = np.arange(n) % 4 + 1                            # 1-based (matlab_target_offset)
+    protos = rng.normal(size=(4, 24)) * 2
+    for k in range(1, n_streams + 1):
+        rows, tv = [], []
+        for u in range(n):
+            ramp = np.linspace(0, 1, lens[u])[:, None]
+            rows.append(protos[labels[u] - 1][None, :] * (0.5 + ramp) + rng.normal(size=(lens[u], 24)) * 0.3)
+            tv.append(np.full(lens[u], labels[u]))
+        sio.savemat(os.path.join(root, "s%d.mat" % k),
+                    dict(dataMatrix=np.concatenate(rows), targetsVec=np.concatenate(tv)[:, None].astype("uint8"),
+                         videoLengthVec=lens[:, None], subjectsVec=subjects[:, None]))
+        dims = [24, 16, 12, 8, 5]
+        ae = {}
+        for i in range(4):
+            ae["w%d" % (i + 1)] = rng.normal(0, 0.3, (dims[i], dims[i + 1]))
+            ae["b%d" % (i + 1)] = rng.normal(0, 0.05, (1, dims[i + 1]))
+        sio.savemat(os.path.join(root, "ae%d.mat" % k), ae)
+    open(os.path.join(root, "train.txt"), "w").write("1,2,3,4,5")
+    open(os.path.join(root, "val.txt"), "w").write("6,7")
+    open(os.path.join(root, "test.txt"), "w").write("8")
+
+
+@pytest.mark.parametrize("n_streams,fusion", [(3, "concat"), (1, "none"), (2, "adasum")])
+def test_runner_end_to_end(tmp_path, n_streams, fusion):
+    from ip_avsr_amd.runners import nstream
+    from ip_avsr_amd.utils.io import load_model
+    root = str(tmp_path)
+    make_dataset(root, n_streams)
+    ini = "".join(INI.format(k=k, root=root, reorder=(k == 1), diff=(k == 2)) for k in range(1, n_streams + 1))
+    ini += TAIL.format(root=root, fusion=fusion)
+    cfg = os.path.join(root, "cfg.ini")
+    open(cfg, "w").write(ini)
+    res_file, best_file = os.path.join(root, "results.csv"), os.path.join(root, "best.pkl")
+    out = nstream.main(n_streams, ["--config", cfg, "--write_results", res_file, "--save_best", best_file,
+                                   "--seed", "7"])
+    assert len(out["cost_val"]) >= 2 and np.isfinite(out["cost_val"]).all()
+    assert min(out["cost_val"]) < out["cost_val"][0] or out["best_cr"] >= 0.5      # it learns something
+    line = open(res_file).read().strip().split(",")
+    assert len(line) == 3 and abs(float(line[1]) - out["best_cr"]) < 1e-9
+    values = load_model(best_file)
+    net = out["network"]
+    assert isinstance(values, list) and len(values) == len(net.params)
+    for v, p in zip(values, net.params):
+        assert v.shape == p.shape and v.dtype == np.float32
+    np.testing.assert_array_equal(values[0], net.get_all_param_values()[0])       # best params were restored
+    net.close()

@@ -1,0 +1,97 @@
+"""Host-side driver pieces that need no GPU: evaluate_model2 (majority vote + confusion matrix),
+load_decoder (.mat -> ae tuple), the confusion-matrix table, initialisers, checkpoint pickles."""
+import os
+import pickle
+
+import numpy as np
+import scipy.io as sio
+
+from ip_avsr_amd import init as las_init
+from ip_avsr_amd.runners.nstream import evaluate_model2, load_decoder
+from ip_avsr_amd.utils import io as uio
+from ip_avsr_amd.utils.plotting_utils import plot_confusion_matrix
+
+
+def test_evaluate_model2_majority_vote_and_confusion():
+    # hand-made probabilities, 3 utterances, T=4, 3 classes (pin with hand-made probs)
+    probs = np.zeros((3, 4, 3))
+    for (b, t, c) in [(0, 0, 2), (0, 1, 1), (0, 2, 2), (0, 3, 1),      # tie 1 vs 2 over 4 frames -> lowest id 1
+                      (1, 0, 0), (1, 1, 2), (1, 2, 2), (1, 3, 2),      # only 2 valid frames: 0 and 2 tie -> 0
+                      (2, 0, 1), (2, 1, 1), (2, 2, 0), (2, 3, 0)]:     # 3 valid frames -> 1
+        probs[b, t, c] = 1.0
+    mask = np.array([[1, 1, 1, 1], [1, 1, 0, 0], [1, 1, 1, 0]], np.uint8)
+    y = np.array([1, 2, 1])
+    seen = {}
+
+    def eval_fn(x1, x2, m, w):
+        seen["args"] = (x1, x2, m, w)
+        return probs
+    cr, conf = evaluate_model2(["s1", "s2"], y, mask, 9, eval_fn)
+    assert seen["args"][0] == "s1" and seen["args"][3] == 9
+    assert abs(cr - 2.0 / 3.0) < 1e-12
+    want = np.zeros((3, 3), int); want[1, 1] = 2; want[2, 0] = 1
+    np.testing.assert_array_equal(conf, want)
+    from oracle import adenet_oracle as O
+    np.testing.assert_array_equal(O.majority_vote(probs, mask), [1, 0, 1])
+
+
+def test_load_decoder_roundtrip(tmp_path):
+    rng = np.random.default_rng(0)
+    dims = [12, 8, 6, 4, 3]
+    d = {}
+    for i in range(4):
+        d["w%d" % (i + 1)] = rng.normal(size=(dims[i], dims[i + 1]))
+        d["b%d" % (i + 1)] = rng.normal(size=(1, dims[i + 1]))
+    for i in range(4, 8):                                   # decoder half, ignored (App. C)
+        d["w%d" % (i + 1)] = rng.normal(size=(3, 3)); d["b%d" % (i + 1)] = rng.normal(size=(1, 3))
+    path = str(tmp_path / "ae.mat")
+    sio.savemat(path, d)
+    w, b, shapes, nonlins = load_decoder(path, "8,6,4,3", "rectify,rectify,rectify,linear")
+    assert shapes == [8, 6, 4, 3] and nonlins == ["rectify", "rectify", "rectify", "linear"]
+    assert len(w) == 4 and w[0].dtype == np.float32 and w[0].shape == (12, 8) and b[3].shape == (3,)
+    np.testing.assert_allclose(w[2], d["w3"].astype("float32"))
+    np.testing.assert_allclose(b[1], d["b2"][0].astype("float32"))
+
+
+def test_confusion_table_and_split_file(tmp_path):
+    conf = np.array([[2, 0], [1, 3]])
+    table = plot_confusion_matrix(conf, ["a", "b"], fmt="pipe")
+    assert "| a" in table and "3" in table.splitlines()[-1]
+    p = tmp_path / "subjects.txt"
+    p.write_text("1,5,9\n")
+    assert uio.read_data_split_file(str(p)) == [1, 5, 9]
+
+
+def test_param_pickle_is_a_plain_list_of_arrays(tmp_path):
+    class Net:
+        def __init__(self):
+            self.v = [np.arange(6, dtype="float32").reshape(2, 3), np.zeros(3, "float32")]
+
+        def get_all_param_values(self):
+            return [a.copy() for a in self.v]
+
+        def set_all_param_values(self, vals):
+            self.v = [np.asarray(a) for a in vals]
+    net = Net()
+    path = str(tmp_path / "best.pkl")
+    uio.save_model_params(net, path)
+    raw = pickle.load(open(path, "rb"))
+    assert isinstance(raw, list) and raw[0].shape == (2, 3)            # utils/io.py:40-42 format
+    net.v = [a * 0 for a in net.v]
+    uio.load_model_params(net, path)
+    np.testing.assert_array_equal(net.v[0], np.arange(6).reshape(2, 3))
+
+
+def test_initialisers():
+    las_init.set_rng(np.random.RandomState(0))
+    g = las_init.GlorotUniform()((150, 250))
+    assert g.dtype == np.float32 and abs(g).max() <= np.sqrt(6.0 / 400) + 1e-7
+    o = las_init.Orthogonal()((30, 50))
+    np.testing.assert_allclose(o @ o.T, np.eye(30), atol=1e-5)
+    o2 = las_init.Orthogonal()((50, 30))
+    np.testing.assert_allclose(o2.T @ o2, np.eye(30), atol=1e-5)
+    assert abs(las_init.Uniform()((1000,))).max() <= 0.01
+    assert 0.08 < las_init.Normal(0.1)((4000,)).std() < 0.12
+    assert isinstance(las_init.select("ortho"), las_init.Orthogonal)
+    assert isinstance(las_init.select("anything-else"), las_init.GlorotUniform)
+    assert isinstance(las_init.resolve(las_init.GlorotUniform), las_init.GlorotUniform)
