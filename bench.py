@@ -31,6 +31,7 @@ import numpy as np
 
 # gfx950 peaks from /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
 
 B_PER_GPU, T_MAX, THETA, H, C, D = 520, 40, 9, 250, 26, 1200
@@ -112,6 +113,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
+                    help="GEMM arithmetic: f32 = exact fp32 MFMA (parity-grade), bf16 = bf16 MFMA, fp32 accumulate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel timing")
     args = ap.parse_args()
@@ -134,6 +137,7 @@ def main():
     from ip_avsr_amd.model import AdeNetModel
     from ip_avsr_amd.parallel import DataParallel, wrap_flat_buffer
     model = AdeNetModel(build_spec())
+    model.set_precision(args.precision)
     synthetic_params(model)
     xs, y, m_d, mask = synthetic_batch(torch, rank, B_PER_GPU, device)
     local_frames = float(mask.sum())
@@ -180,7 +184,7 @@ def main():
             "metric": "sequences_per_sec_train_avletters_trimodal_adenet", "value": seqs / elapsed,
             "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "AVLetters trimodal AdeNet (3 encoder streams 1200-2000-1000-500-50, theta=9, "
                                    "3x LSTM-250, concat, summed BLSTM-250, 26 classes), whole-train batch "
                                    "B=520 utterances x T=40 frames per GPU, fwd+bwd+Adam",
@@ -193,9 +197,10 @@ def main():
             g = [prof[k] for k in ("gemm_f32_nn", "gemm_f32_nt", "gemm_f32_tn") if k in prof]
             flops = sum(e["flops"] for e in g); ms = sum(e["ms"] for e in g); n = sum(e["launches"] for e in g)
             ach = flops / (ms * 1e-3) / 1e12 if ms else 0.0
-            out["roofline"] = {"kernel": "gemm_f32_kernel (encoder / projection GEMMs, all three layouts)",
-                               "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+            peak = PEAK_BF16_MFMA_TFLOPS if args.precision == "bf16" else PEAK_F32_MFMA_TFLOPS
+            out["roofline"] = {"kernel": "gemm_%s_kernel (encoder / projection GEMMs, all three layouts)" % args.precision,
+                               "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                               "frac": ach / peak, "traffic": None,
                                "launches_per_step": n / args.steps, "avg_launch_ms": ms / max(n, 1),
                                "share_of_step": ms / (1e3 * elapsed)}
             for key, name in (("lstm_fwd_step", "roofline_lstm_fwd"), ("lstm_bwd_step", "roofline_lstm_bwd")):

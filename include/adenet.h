@@ -56,7 +56,9 @@ typedef enum {
 typedef enum { ADN_FUSE_NONE = 0, ADN_FUSE_SUM = 1, ADN_FUSE_ADASUM = 2, ADN_FUSE_CONCAT = 3 } adn_fusion;
 
 typedef enum {
-    ADN_PRECISION_F32 = 0 /* exact fp32 on the f32 MFMA pipe (parity-grade) */
+    ADN_PRECISION_F32 = 0, /* exact fp32 on the f32 MFMA pipe (parity-grade; all parity tests run in it) */
+    ADN_PRECISION_BF16 = 1 /* GEMM operands rounded to bf16 (RNE) in flight, fp32 accumulate, fp32 master
+                              weights / activations / recurrence / optimiser (BASELINE configs[1]: bf16) */
 } adn_precision;
 
 enum { ADN_FLAG_DEVICE_INPUTS = 1, ADN_FLAG_DEVICE_OUTPUTS = 2 };
@@ -114,6 +116,8 @@ int adn_device_count(void);
 int adn_create(const adn_config* cfg, adn_model** out);
 void adn_destroy(adn_model* m);
 int adn_set_stream(adn_model* m, void* hip_stream);
+/* switch the GEMM arithmetic (adn_precision) of an existing model; parameters are fp32 either way */
+int adn_set_precision(adn_model* m, int precision);
 
 /* <- lasagne.layers.get_all_params / get_all_param_values / set_all_param_values
  *    (runners/3stream.py:305,393,425; utils/io.py:40-48) */
@@ -178,6 +182,8 @@ int adn_profile_read(adn_model* m, adn_profile_entry* out, int max_entries, int*
 /* C (+)= op(A)*op(B) on device pointers; layout 0 = NN, 1 = NT (B given as [N][K]), 2 = TN (A as [K][M]) */
 int adn_op_gemm(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                 int ldc, const float* bias, int act, int accumulate, void* hip_stream);
+int adn_op_gemm_ex(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                   int ldc, const float* bias, int act, int accumulate, int precision, void* hip_stream);
 /* utils/signal.py:59-80 on device: in (B,T,F) batch-major -> out (T,B,3F) time-major */
 int adn_op_delta_forward(const float* in, int ld_in, float* out, int ld_out, int B, int T, int F, int theta,
                          void* hip_stream);

@@ -18,6 +18,7 @@ ADN_OK = 0
 ACT = {"linear": 0, "identity": 0, "rectify": 1, "sigmoid": 2, "tanh": 3, "leaky_rectify": 4,
        "very_leaky_rectify": 5}
 FUSION = {"none": 0, "sum": 1, "adasum": 2, "concat": 3}
+PRECISION = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 FLAG_DEVICE_INPUTS = 1
 FLAG_DEVICE_OUTPUTS = 2
 BUF_PARAM, BUF_GRAD, BUF_ADAM_M, BUF_ADAM_V = 0, 1, 2, 3
@@ -58,6 +59,7 @@ _SIGNATURES = {
     "adn_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
     "adn_destroy": (None, [_P]),
     "adn_set_stream": (C.c_int, [_P, _P]),
+    "adn_set_precision": (C.c_int, [_P, C.c_int]),
     "adn_num_params": (C.c_int, [_P]),
     "adn_param_info": (C.c_int, [_P, C.c_int, C.POINTER(ParamInfo)]),
     "adn_read_tensor": (C.c_int, [_P, C.c_int, C.c_int, _P]),
@@ -77,6 +79,8 @@ _SIGNATURES = {
     "adn_profile_read": (C.c_int, [_P, C.POINTER(ProfileEntry), C.c_int, C.POINTER(C.c_int)]),
     "adn_op_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int, _P,
                               C.c_int, C.c_int, _P]),
+    "adn_op_gemm_ex": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int, _P,
+                                 C.c_int, C.c_int, C.c_int, _P]),
     "adn_op_delta_forward": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "adn_op_delta_backward": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "adn_op_adam": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, _P]),

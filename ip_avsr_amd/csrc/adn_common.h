@@ -78,8 +78,14 @@ struct GemmArgs {
                                    // result *= act_grad'(Y[row][col])  (back-prop through the
                                    // activation of the layer that produced Y)
     int precision = ADN_PRECISION_F32;
+    // bf16 mode only: shadow copies of A / B (same leading dimensions and element offsets); when both are
+    // given the kernel loads bf16 directly instead of converting fp32 in flight.  C16: also store the result
+    // as bf16 (non-split-K launches only).
+    const void* A16 = nullptr; const void* B16 = nullptr; void* C16 = nullptr;
 };
 int gemm(const GemmArgs& g, hipStream_t stream);
+// dst[i] = bf16(src[i]), n a multiple of 8
+int to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
 // element-wise / HBM-bound kernels (elementwise.hip)

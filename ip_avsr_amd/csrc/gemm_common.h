@@ -1,0 +1,83 @@
+// Shared by gemm_f32.hip and gemm_bf16.hip: kernel parameter block, activation helpers and the
+// C-tile epilogue (bias, activation, act'(Y) product, accumulate / split-K atomics).
+#pragma once
+#include "adn_common.h"
+
+namespace adn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmParams {
+    int M, N, K;
+    const float* A; int lda;
+    const float* B; int ldb;
+    float* C;       int ldc;
+    const void* A16; const void* B16; void* C16;   // optional bf16 shadow copies (same ld / offsets)
+    const float* bias;
+    const float* Y; int ldy;
+    int act, act_grad, accumulate, atomic;
+    int k_chunk;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ float act_apply(int act, float v) {
+    switch (act) {
+        case ADN_ACT_RECTIFY: return v > 0.f ? v : 0.f;
+        case ADN_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        case ADN_ACT_TANH: return tanhf(v);
+        case ADN_ACT_LEAKY_RECTIFY: return v > 0.f ? v : 0.01f * v;
+        case ADN_ACT_VERY_LEAKY_RECTIFY: return v > 0.f ? v : (1.f / 3.f) * v;
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ float act_grad_from_output(int act, float y) {
+    switch (act) {
+        case ADN_ACT_RECTIFY: return y > 0.f ? 1.f : 0.f;
+        case ADN_ACT_SIGMOID: return y * (1.f - y);
+        case ADN_ACT_TANH: return 1.f - y * y;
+        case ADN_ACT_LEAKY_RECTIFY: return y > 0.f ? 1.f : 0.01f;
+        case ADN_ACT_VERY_LEAKY_RECTIFY: return y > 0.f ? 1.f : (1.f / 3.f);
+        default: return 1.f;
+    }
+}
+
+
+// XCD-aware tile order (cdna_hip_programming.md T1): workgroups are dealt round-robin over the 8 XCDs, so
+// block b and b+8 share an L2.  Give every XCD one contiguous chunk of the (m-major, n-fastest) tile list:
+// the tiles that are co-resident on an XCD then share their A row-panel and walk the same B panels.
+// Bijective for any grid size.  Speed only -- never correctness.
+__device__ __forceinline__ int xcd_tile(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
+// epilogue for one 32x32 MFMA accumulator tile whose top-left element is (row0, col0).
+// C/D map of the 32x32 MFMAs (all dtypes): col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+__device__ __forceinline__ void store_tile32(const GemmParams& p, const f32x16& acc, int row0, int col0, int lane,
+                                             bool first_split) {
+    const int col = col0 + (lane & 31);
+    if (col >= p.N) return;
+    const float bias = (p.bias && first_split) ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= p.M) continue;
+        float v = acc[r] + bias;
+        float* c = p.C + (size_t)row * p.ldc + col;
+        if (p.atomic) {
+            if (p.Y) v *= act_grad_from_output(p.act_grad, p.Y[(size_t)row * p.ldy + col]);
+            atomicAdd(c, v);
+        } else {
+            v = act_apply(p.act, v);
+            if (p.Y) v *= act_grad_from_output(p.act_grad, p.Y[(size_t)row * p.ldy + col]);
+            if (p.accumulate) v += *c;
+            *c = v;
+        }
+    }
+}
+
+// defined in gemm_bf16.hip
+void launch_gemm_bf16(const GemmParams& p, int layout, bool big, dim3 grid, hipStream_t s);
+
+}  // namespace adn

@@ -12,46 +12,10 @@
 // ds_read_b128 per four k-steps, "k-strided" rows with four conflict-free ds_read_b32), so no
 // transposing stores are needed for any of the three layouts.  The f32 MFMA issues once per 64
 // cycles per SIMD, so one LDS fragment read per MFMA keeps the kernel MFMA-bound.
-#include "adn_common.h"
+#include "gemm_common.h"
 #include <algorithm>
 
 namespace adn {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct GemmParams {
-    int M, N, K;
-    const float* A; int lda;
-    const float* B; int ldb;
-    float* C;       int ldc;
-    const float* bias;
-    const float* Y; int ldy;
-    int act, act_grad, accumulate, atomic;
-    int k_chunk;
-    int tiles_m, tiles_n;
-};
-
-__device__ __forceinline__ float act_apply(int act, float v) {
-    switch (act) {
-        case ADN_ACT_RECTIFY: return v > 0.f ? v : 0.f;
-        case ADN_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
-        case ADN_ACT_TANH: return tanhf(v);
-        case ADN_ACT_LEAKY_RECTIFY: return v > 0.f ? v : 0.01f * v;
-        case ADN_ACT_VERY_LEAKY_RECTIFY: return v > 0.f ? v : (1.f / 3.f) * v;
-        default: return v;
-    }
-}
-
-__device__ __forceinline__ float act_grad_from_output(int act, float y) {
-    switch (act) {
-        case ADN_ACT_RECTIFY: return y > 0.f ? 1.f : 0.f;
-        case ADN_ACT_SIGMOID: return y * (1.f - y);
-        case ADN_ACT_TANH: return 1.f - y * y;
-        case ADN_ACT_LEAKY_RECTIFY: return y > 0.f ? 1.f : 0.01f;
-        case ADN_ACT_VERY_LEAKY_RECTIFY: return y > 0.f ? 1.f : (1.f / 3.f);
-        default: return 1.f;
-    }
-}
 
 constexpr int BK = 32;
 constexpr int PAD = 4;
@@ -132,7 +96,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int i = lane & 31, h = lane >> 5;
-    const int tile = blockIdx.x;
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
     const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
     const int kbeg = blockIdx.y * p.k_chunk;
     const int kend = min(p.K, kbeg + p.k_chunk);
@@ -177,32 +141,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
         __syncthreads();
     }
 
-    // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const bool first_split = blockIdx.y == 0;
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            const int col = n0 + wn * WTN + b * 32 + i;
-            if (col >= p.N) continue;
-            const float bias = (p.bias && first_split) ? p.bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * WTM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row >= p.M) continue;
-                float v = acc[a][b][r] + bias;
-                float* c = p.C + (size_t)row * p.ldc + col;
-                if (p.atomic) {
-                    if (p.Y) v *= act_grad_from_output(p.act_grad, p.Y[(size_t)row * p.ldy + col]);
-                    atomicAdd(c, v);
-                } else {
-                    v = act_apply(p.act, v);
-                    if (p.Y) v *= act_grad_from_output(p.act_grad, p.Y[(size_t)row * p.ldy + col]);
-                    if (p.accumulate) v += *c;
-                    *c = v;
-                }
-            }
-        }
+        for (int b = 0; b < TN; ++b)
+            store_tile32(p, acc[a][b], m0 + wm * WTM + a * 32, n0 + wn * WTN + b * 32, lane, first_split);
 }
 
 template <int BM, int BN>
@@ -222,12 +166,14 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
     ADN_CHECK(g.lda % 4 == 0 && g.ldb % 4 == 0, ADN_ERR_INVALID, "gemm: lda/ldb must be multiples of 4 floats");
     ADN_CHECK(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0, ADN_ERR_INVALID,
               "gemm: A and B must be 16-byte aligned");
-    ADN_CHECK(g.precision == ADN_PRECISION_F32, ADN_ERR_INVALID, "gemm: unsupported precision");
+    ADN_CHECK(g.precision == ADN_PRECISION_F32 || g.precision == ADN_PRECISION_BF16, ADN_ERR_INVALID,
+              "gemm: unsupported precision");
 
     GemmParams p;
     p.M = g.M; p.N = g.N; p.K = g.K;
     p.A = g.A; p.lda = g.lda; p.B = g.B; p.ldb = g.ldb; p.C = g.C; p.ldc = g.ldc;
     p.bias = g.bias; p.Y = g.Y; p.ldy = g.ldy;
+    p.A16 = g.A16; p.B16 = g.B16; p.C16 = g.C16;
     p.act = g.act; p.act_grad = g.act_grad; p.accumulate = g.accumulate;
 
     const int64_t t128 = (int64_t)cdiv(g.M, 128) * cdiv(g.N, 128);
@@ -247,18 +193,24 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
     p.k_chunk = (int)round_up(cdiv(g.K, split), BK);
     split = cdiv(g.K, p.k_chunk);
     p.atomic = split > 1;
+    if (p.atomic) p.C16 = nullptr;            // partial sums: the bf16 copy is made after the kernel (below)
+    if (g.precision == ADN_PRECISION_BF16 && p.A16 && p.B16)
+        ADN_CHECK(g.lda % 8 == 0 && g.ldb % 8 == 0, ADN_ERR_INVALID, "gemm: bf16 shadows need lda/ldb % 8 == 0");
     ProfScope prof(PROF_GEMM_NN + g.layout, 2.0 * g.M * g.N * g.K,
                    4.0 * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N), stream);
     if (p.atomic && !g.accumulate)
         ADN_HIP_CHECK(hipMemset2DAsync(g.C, (size_t)g.ldc * 4, 0, (size_t)g.N * 4, g.M, stream));
-    if (big) {
-        p.tiles_m = cdiv(g.M, 128); p.tiles_n = cdiv(g.N, 128);
-        launch<128, 128>(p, g.layout, dim3((unsigned)tiles, split), stream);
-    } else {
-        p.tiles_m = cdiv(g.M, 64); p.tiles_n = cdiv(g.N, 64);
-        launch<64, 64>(p, g.layout, dim3((unsigned)tiles, split), stream);
-    }
+    const int tsz = big ? 128 : 64;
+    p.tiles_m = cdiv(g.M, tsz); p.tiles_n = cdiv(g.N, tsz);
+    const dim3 grid((unsigned)tiles, split);
+    if (g.precision == ADN_PRECISION_BF16) launch_gemm_bf16(p, g.layout, big, grid, stream);
+    else if (big) launch<128, 128>(p, g.layout, grid, stream);
+    else launch<64, 64>(p, g.layout, grid, stream);
     ADN_HIP_CHECK(hipGetLastError());
+    if (g.C16 && p.atomic) {                  // split-K result: refresh the bf16 shadow of whole rows
+        ADN_CHECK(g.ldc % 8 == 0, ADN_ERR_INVALID, "gemm: bf16 shadow of C needs ldc % 8 == 0");
+        ADN_TRY(to_bf16(g.C, g.C16, (size_t)g.M * g.ldc, stream));
+    }
     return ADN_OK;
 }
 

@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -164,6 +165,20 @@ struct adn_model {
     int ping_ld = 0;
     int lastB = 0, lastT = 0;
     Profiler prof;
+    // bf16 shadow copies of every GEMM operand (bf16 mode): fp32 range -> bf16 buffer with the same layout
+    struct ShadowRange { const float* base; size_t n; char* shadow; };
+    std::vector<ShadowRange> shadows;
+    char* params16 = nullptr;
+    bool params16_dirty = true;
+    bool bf16() const { return cfg.precision == ADN_PRECISION_BF16; }
+    void* shadow_of(const float* p) const {
+        if (!p) return nullptr;
+        if (p >= flat[ADN_BUF_PARAM] && p < flat[ADN_BUF_PARAM] + flat_floats)
+            return params16 ? params16 + 2 * (size_t)(p - flat[ADN_BUF_PARAM]) : nullptr;
+        for (const auto& r : shadows)
+            if (p >= r.base && p < r.base + r.n) return r.shadow + 2 * (size_t)(p - r.base);
+        return nullptr;
+    }
 
     float* P(size_t off) const { return flat[ADN_BUF_PARAM] + off; }
     float* G(size_t off) const { return flat[ADN_BUF_GRAD] + off; }
@@ -219,7 +234,8 @@ int validate(const adn_config& c) {
     ADN_CHECK(c.classes >= 1 && c.classes <= ADN_MAX_CLASSES, ADN_ERR_INVALID, "classes out of range");
     ADN_CHECK(c.fusion >= ADN_FUSE_NONE && c.fusion <= ADN_FUSE_CONCAT, ADN_ERR_INVALID, "unknown fusion type");
     ADN_CHECK(c.agg >= 0 && c.agg <= 2, ADN_ERR_INVALID, "agg must be 0, 1 or 2");
-    ADN_CHECK(c.precision == ADN_PRECISION_F32, ADN_ERR_INVALID, "unsupported precision");
+    ADN_CHECK(c.precision == ADN_PRECISION_F32 || c.precision == ADN_PRECISION_BF16, ADN_ERR_INVALID,
+              "unsupported precision");
     if (c.fusion == ADN_FUSE_NONE) ADN_CHECK(c.n_streams == 1, ADN_ERR_INVALID, "fusion 'none' needs exactly one stream");
     if (c.fusion == ADN_FUSE_CONCAT && c.n_streams > 1)
         ADN_CHECK(c.agg != 0, ADN_ERR_INVALID, "concat fusion needs an aggregation LSTM");
@@ -289,12 +305,21 @@ struct Carver {
     }
 };
 
-void carve_lstm(Carver& cv, LstmWork& w, int B, int T, int ldh, int ldg) {
+// carve an fp32 matrix that is consumed by GEMMs together with its bf16 shadow
+float* take_shadowed(adn_model* m, Carver& cv, size_t floats) {
+    floats = (size_t)round_up((int64_t)floats, 8);
+    float* p = cv.take<float>(floats);
+    char* sh = cv.take<char>(floats * 2);
+    if (p) m->shadows.push_back({p, floats, sh});
+    return p;
+}
+
+void carve_lstm(adn_model* m, Carver& cv, LstmWork& w, int B, int T, int ldh, int ldg) {
     const size_t N = (size_t)B * T;
     w.xproj = cv.take<float>(N * ldg);
     w.gates = cv.take<float>(N * ldg);
-    w.dG = cv.take<float>(N * ldg);
-    w.hbuf = cv.take<float>((size_t)(T + 1) * B * ldh);
+    w.dG = take_shadowed(m, cv, N * ldg);
+    w.hbuf = take_shadowed(m, cv, (size_t)(T + 1) * B * ldh);
     w.cbuf = cv.take<float>((size_t)(T + 1) * B * ldh);
     w.dh_carry = cv.take<float>((size_t)B * ldh);
     w.dc_state = cv.take<float>((size_t)B * ldh);
@@ -302,6 +327,7 @@ void carve_lstm(Carver& cv, LstmWork& w, int B, int T, int ldh, int ldg) {
 
 size_t carve(adn_model* m, char* base, int B, int T, bool host_inputs) {
     Carver cv{base};
+    m->shadows.clear();
     const size_t N = (size_t)B * T;
     const int ldh = m->ldh, ldg = m->ldg;
     m->mask_bt = cv.take<uint8_t>(N);
@@ -312,35 +338,35 @@ size_t carve(adn_model* m, char* base, int B, int T, bool host_inputs) {
     m->row_loss = cv.take<float>(N);
     m->probs_bt = cv.take<float>(N * m->C);
     m->z = cv.take<float>(N * m->ldc);
-    m->dz = cv.take<float>(N * m->ldc);
-    m->cls_in = cv.take<float>(N * ldh);
+    m->dz = take_shadowed(m, cv, N * m->ldc);
+    m->cls_in = take_shadowed(m, cv, N * ldh);
     m->dcls = cv.take<float>(N * ldh);
-    m->fused = cv.take<float>(N * ldh);
+    m->fused = take_shadowed(m, cv, N * ldh);
     m->dfused = cv.take<float>(N * ldh);
     int maxw = 8;
     for (auto& st : m->st) {
         // staged copy of the input: always (host inputs need one; device inputs whose width is not a
         // multiple of 4 floats cannot feed the GEMM loader directly)
-        st.xstage = cv.take<float>(N * ld_of(st.cfg.input_dim));
+        st.xstage = take_shadowed(m, cv, N * ld_of(st.cfg.input_dim));
         st.act.resize(st.cfg.n_enc);
         for (int l = 0; l < st.cfg.n_enc; ++l) {
-            st.act[l] = cv.take<float>(N * ld_of(st.cfg.enc_units[l]));
+            st.act[l] = take_shadowed(m, cv, N * ld_of(st.cfg.enc_units[l]));
             maxw = std::max(maxw, ld_of(st.cfg.enc_units[l]));
         }
-        st.feat = cv.take<float>(N * ld_of(st.feat_dim));
+        st.feat = take_shadowed(m, cv, N * ld_of(st.feat_dim));
         st.dfeat = cv.take<float>(N * ld_of(st.feat_dim));
-        st.dE = cv.take<float>(N * ld_of(st.enc_out));
+        st.dE = take_shadowed(m, cv, N * ld_of(st.enc_out));
         st.lw.resize(st.lstm.size());
-        for (auto& w : st.lw) carve_lstm(cv, w, B, T, ldh, ldg);
-        st.hsum = cv.take<float>(N * ldh);
+        for (auto& w : st.lw) carve_lstm(m, cv, w, B, T, ldh, ldg);
+        st.hsum = take_shadowed(m, cv, N * ldh);
         st.dout_buf = cv.take<float>(N * ldh);
         st.dout = st.dout_buf;
     }
     m->aggw.resize(m->agg.size());
-    for (auto& w : m->aggw) carve_lstm(cv, w, B, T, ldh, ldg);
+    for (auto& w : m->aggw) carve_lstm(m, cv, w, B, T, ldh, ldg);
     m->ping_ld = maxw;
-    m->pingA = cv.take<float>(N * maxw);
-    m->pingB = cv.take<float>(N * maxw);
+    m->pingA = take_shadowed(m, cv, N * maxw);
+    m->pingB = take_shadowed(m, cv, N * maxw);
     (void)host_inputs;
     return cv.cursor;
 }
@@ -360,6 +386,9 @@ int ensure_workspace(adn_model* m, int B, int T) {
     return ADN_OK;
 }
 
+int refresh(adn_model* m, const float* p, size_t floats);
+int refresh_params(adn_model* m);
+
 // ------------------------------------------------------------------------------------------
 // staging of the caller's arrays
 // ------------------------------------------------------------------------------------------
@@ -373,7 +402,9 @@ int stage_inputs(adn_model* m, const void* const* inputs, const int32_t* targets
         StreamState& st = m->st[s];
         ADN_CHECK(inputs[s], ADN_ERR_INVALID, "null stream input");
         const int D = st.cfg.input_dim;
-        const bool direct = dev && (D % 4 == 0) && (((uintptr_t)inputs[s]) % 16 == 0);
+        // device inputs are used in place when the GEMM loader can read them directly; in bf16 mode they
+        // are copied into the staging buffer instead, which owns a bf16 shadow
+        const bool direct = dev && !m->bf16() && (D % 4 == 0) && (((uintptr_t)inputs[s]) % 16 == 0);
         if (direct) {
             st.x = static_cast<const float*>(inputs[s]); st.ldx = D;
         } else {
@@ -383,9 +414,37 @@ int stage_inputs(adn_model* m, const void* const* inputs, const int32_t* targets
             st.x = st.xstage; st.ldx = ld;
         }
     }
+    for (auto& st : m->st) ADN_TRY(refresh(m, st.x, N * st.ldx));
+    ADN_TRY(refresh_params(m));
     ADN_HIP_CHECK(hipMemcpyAsync(m->mask_bt, mask, N, kind, m->stream));
     if (targets) ADN_HIP_CHECK(hipMemcpyAsync(m->y_bt, targets, N * sizeof(int32_t), kind, m->stream));
     ADN_TRY(mask_prepare(m->mask_bt, m->mask_tb, B, T, m->total, m->stream));
+    return ADN_OK;
+}
+
+int mgemm(adn_model* m, GemmArgs& g) {
+    g.precision = m->cfg.precision;
+    if (m->bf16() && !getenv("ADN_BF16_NO_SHADOW")) {     // env switch: convert-in-flight reference path
+        g.A16 = m->shadow_of(g.A);
+        g.B16 = m->shadow_of(g.B);
+        g.C16 = m->shadow_of(g.C);
+    }
+    return gemm(g, m->stream);
+}
+
+// bring the bf16 shadow of an fp32 matrix written by a non-GEMM kernel up to date (bf16 mode only)
+int refresh(adn_model* m, const float* p, size_t floats) {
+    if (!m->bf16()) return ADN_OK;
+    void* sh = m->shadow_of(p);
+    if (!sh) return ADN_OK;
+    return to_bf16(p, sh, (size_t)round_up((int64_t)floats, 8), m->stream);
+}
+
+int refresh_params(adn_model* m) {
+    if (!m->bf16() || !m->params16_dirty) return ADN_OK;
+    if (!m->params16) ADN_HIP_CHECK(hipMalloc((void**)&m->params16, m->flat_floats * 2));
+    ADN_TRY(to_bf16(m->flat[ADN_BUF_PARAM], m->params16, m->flat_floats, m->stream));
+    m->params16_dirty = false;
     return ADN_OK;
 }
 
@@ -420,7 +479,7 @@ int lstm_project(adn_model* m, const LstmParams& lp, const LstmWork& w, const fl
         g.C = w.xproj; g.ldc = m->ldg;
         g.bias = (j == 0) ? m->P(lp.b) : nullptr;
         g.accumulate = j > 0;
-        ADN_TRY(gemm(g, m->stream));
+        ADN_TRY(mgemm(m, g));
     }
     return ADN_OK;
 }
@@ -446,10 +505,11 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
             g.layout = GEMM_NN; g.M = N; g.N = st.cfg.enc_units[l]; g.K = st.enc_in[l];
             g.A = a; g.lda = lda; g.B = m->P(st.encW[l]); g.ldb = ld_of(g.N);
             g.C = st.act[l]; g.ldc = ld_of(g.N); g.bias = m->P(st.encb[l]); g.act = st.cfg.enc_act[l];
-            ADN_TRY(gemm(g, s));
+            ADN_TRY(mgemm(m, g));
             a = st.act[l]; lda = g.ldc;
         }
         ADN_TRY(delta_forward(a, lda, st.feat, ld_of(st.feat_dim), B, T, st.enc_out, theta, st.cfg.use_delta, s));
+        ADN_TRY(refresh(m, st.feat, (size_t)N * ld_of(st.feat_dim)));
         for (size_t k = 0; k < st.lstm.size(); ++k) {
             const float* in[1] = {st.feat}; const int ld[1] = {ld_of(st.feat_dim)};
             ADN_TRY(lstm_project(m, st.lstm[k], st.lw[k], in, ld, 1, st.feat_dim, N));
@@ -459,9 +519,11 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
     }
     ADN_TRY(run_lstm_group(m, steps, B, T, false));
     for (auto& st : m->st) {
+        for (auto& w : st.lw) ADN_TRY(refresh(m, w.hbuf, (size_t)(T + 1) * B * ldh));
         if (st.lstm.size() == 2) {                               // summed BLSTM sub-stream
             const float* in[2] = {st.lw[0].out(B, ldh, false), st.lw[1].out(B, ldh, true)};
             ADN_TRY(sum_k(2, in, nullptr, ldh, st.hsum, ldh, N, H, s));
+            ADN_TRY(refresh(m, st.hsum, (size_t)N * ldh));
             st.out_ptr = st.hsum;
         } else {
             st.out_ptr = st.lw[0].out(B, ldh, false);
@@ -473,6 +535,7 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
     if (fusion == ADN_FUSE_CONCAT || fusion == ADN_FUSE_NONE || m->S == 1) {
         if (fusion == ADN_FUSE_ADASUM) {                         // single stream, still scaled
             ADN_TRY(scale_by(m->st[0].out_ptr, ldh, m->P(m->adacoeff), m->fused, ldh, N, H, s));
+            ADN_TRY(refresh(m, m->fused, (size_t)N * ldh));
             fin.push_back(m->fused); fld.push_back(ldh);
         } else {
             for (auto& st : m->st) { fin.push_back(st.out_ptr); fld.push_back(ldh); }
@@ -484,6 +547,7 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
             al[k] = fusion == ADN_FUSE_ADASUM ? m->P(m->adacoeff + k) : nullptr;
         }
         ADN_TRY(sum_k(m->S, in, al, ldh, m->fused, ldh, N, H, s));
+        ADN_TRY(refresh(m, m->fused, (size_t)N * ldh));
         fin.push_back(m->fused); fld.push_back(ldh);
     }
     const float* cls = nullptr;
@@ -495,9 +559,11 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
             steps.push_back(make_step(m, m->agg[k], m->aggw[k], nullptr, false));
         }
         ADN_TRY(run_lstm_group(m, steps, B, T, false));
+        for (auto& w : m->aggw) ADN_TRY(refresh(m, w.hbuf, (size_t)(T + 1) * B * ldh));
         if (m->agg.size() == 2) {
             const float* in[2] = {m->aggw[0].out(B, ldh, false), m->aggw[1].out(B, ldh, true)};
             ADN_TRY(sum_k(2, in, nullptr, ldh, m->cls_in, ldh, N, H, s));
+            ADN_TRY(refresh(m, m->cls_in, (size_t)N * ldh));
             cls = m->cls_in;
         } else {
             cls = m->aggw[0].out(B, ldh, false);
@@ -510,10 +576,11 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
         GemmArgs g;
         g.layout = GEMM_NN; g.M = N; g.N = m->C; g.K = H; g.A = cls; g.lda = ldh;
         g.B = m->P(m->smW); g.ldb = m->ldc; g.C = m->z; g.ldc = m->ldc; g.bias = m->P(m->smb);
-        ADN_TRY(gemm(g, s));
+        ADN_TRY(mgemm(m, g));
     }
     ADN_TRY(softmax_loss(m->z, m->ldc, B, T, m->C, m->mask_tb, want_loss ? m->y_bt : nullptr, m->total, m->probs_bt,
                          want_loss ? m->row_loss : nullptr, want_dz ? m->dz : nullptr, m->ldc, s));
+    if (want_dz) ADN_TRY(refresh(m, m->dz, (size_t)N * m->ldc));
     if (want_loss) ADN_TRY(reduce_loss(m->row_loss, N, m->total, m->loss, s));
     m->lastB = B; m->lastT = T;
     return ADN_OK;
@@ -535,14 +602,14 @@ int lstm_param_grads(adn_model* m, const LstmParams& lp, const LstmWork& w, cons
         g.layout = GEMM_TN; g.M = blkw; g.N = 4 * H; g.K = N;
         g.A = in[j]; g.lda = ld_in[j]; g.B = w.dG; g.ldb = ldg;
         g.C = m->G(lp.W_in) + (size_t)j * blkw * ldg; g.ldc = ldg; g.accumulate = 1;
-        ADN_TRY(gemm(g, s));
+        ADN_TRY(mgemm(m, g));
     }
     {                                                            // dW_hid = H_prev^T dG  (one GEMM over all steps)
         GemmArgs g;
         g.layout = GEMM_TN; g.M = H; g.N = 4 * H; g.K = N;
         g.A = w.prev(B, ldh, lp.backwards); g.lda = ldh; g.B = w.dG; g.ldb = ldg;
         g.C = m->G(lp.W_hid); g.ldc = ldg; g.accumulate = 1;
-        ADN_TRY(gemm(g, s));
+        ADN_TRY(mgemm(m, g));
     }
     ADN_TRY(col_sum(w.dG, ldg, N, 4 * H, m->G(lp.b), 1, s));
     ADN_TRY(col_sum(w.dh_carry, ldh, B, H, m->G(lp.hid_init), 1, s));
@@ -557,7 +624,7 @@ int lstm_input_grad(adn_model* m, const LstmParams& lp, const LstmWork& w, int j
     g.layout = GEMM_NT; g.M = rows; g.N = blkw; g.K = 4 * m->H;
     g.A = w.dG; g.lda = m->ldg; g.B = m->P(lp.W_in) + (size_t)j * blkw * m->ldg; g.ldb = m->ldg;
     g.C = dx; g.ldc = lddx; g.accumulate = accumulate;
-    return gemm(g, m->stream);
+    return mgemm(m, g);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -574,12 +641,12 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         GemmArgs g;
         g.layout = GEMM_TN; g.M = H; g.N = m->C; g.K = N; g.A = cls; g.lda = ldh; g.B = m->dz; g.ldb = m->ldc;
         g.C = m->G(m->smW); g.ldc = m->ldc; g.accumulate = 1;
-        ADN_TRY(gemm(g, s));
+        ADN_TRY(mgemm(m, g));
         ADN_TRY(col_sum(m->dz, m->ldc, N, m->C, m->G(m->smb), 1, s));
         GemmArgs d;
         d.layout = GEMM_NT; d.M = N; d.N = H; d.K = m->C; d.A = m->dz; d.lda = m->ldc; d.B = m->P(m->smW); d.ldb = m->ldc;
         d.C = m->dcls; d.ldc = ldh;
-        ADN_TRY(gemm(d, s));
+        ADN_TRY(mgemm(m, d));
     }
     const int fusion = m->cfg.fusion;
     const bool per_stream_fused = (fusion == ADN_FUSE_CONCAT || fusion == ADN_FUSE_NONE || m->S == 1) &&
@@ -594,6 +661,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         std::vector<LstmStep> steps;
         for (size_t k = 0; k < m->agg.size(); ++k) steps.push_back(make_step(m, m->agg[k], m->aggw[k], m->dcls, true));
         ADN_TRY(run_lstm_group(m, steps, B, T, true));
+        for (auto& w : m->aggw) ADN_TRY(refresh(m, w.dG, (size_t)N * m->ldg));
         for (size_t k = 0; k < m->agg.size(); ++k)
             ADN_TRY(lstm_param_grads(m, m->agg[k], m->aggw[k], fin.data(), fld.data(), (int)fin.size(), H, B, T));
         for (size_t j = 0; j < fin.size(); ++j) {
@@ -626,6 +694,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         ADN_TRY(run_lstm_group(m, steps, B, T, true));
     }
     for (auto& st : m->st) {
+        for (auto& w : st.lw) ADN_TRY(refresh(m, w.dG, (size_t)N * m->ldg));
         const int ldf = ld_of(st.feat_dim);
         const float* in[1] = {st.feat}; const int ld[1] = {ldf};
         for (size_t k = 0; k < st.lstm.size(); ++k)
@@ -638,6 +707,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         // encoder: dZ_l = dA_l * act_l'(A_l);  dW_l = A_{l-1}^T dZ_l;  dA_{l-1} = dZ_l W_l^T
         const int L = st.cfg.n_enc;
         ADN_TRY(act_backward(st.dE, ldE, st.act[L - 1], ldE, N, st.enc_out, st.cfg.enc_act[L - 1], s));
+        ADN_TRY(refresh(m, st.dE, (size_t)N * ldE));
         float* dZ = st.dE; int lddz = ldE;
         for (int l = L - 1; l >= 0; --l) {
             const int out_w = st.cfg.enc_units[l], in_w = st.enc_in[l];
@@ -646,7 +716,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             GemmArgs gw;
             gw.layout = GEMM_TN; gw.M = in_w; gw.N = out_w; gw.K = N; gw.A = a_prev; gw.lda = ld_prev;
             gw.B = dZ; gw.ldb = lddz; gw.C = m->G(st.encW[l]); gw.ldc = ld_of(out_w); gw.accumulate = 1;
-            ADN_TRY(gemm(gw, s));
+            ADN_TRY(mgemm(m, gw));
             ADN_TRY(col_sum(dZ, lddz, N, out_w, m->G(st.encb[l]), 1, s));
             if (l > 0) {
                 float* dst = (dZ == m->pingA) ? m->pingB : m->pingA;
@@ -654,7 +724,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
                 gx.layout = GEMM_NT; gx.M = N; gx.N = in_w; gx.K = out_w; gx.A = dZ; gx.lda = lddz;
                 gx.B = m->P(st.encW[l]); gx.ldb = ld_of(out_w); gx.C = dst; gx.ldc = m->ping_ld;
                 gx.Y = st.act[l - 1]; gx.ldy = ld_of(in_w); gx.act_grad = st.cfg.enc_act[l - 1];
-                ADN_TRY(gemm(gx, s));
+                ADN_TRY(mgemm(m, gx));
                 dZ = dst; lddz = m->ping_ld;
             }
         }
@@ -693,8 +763,11 @@ int tensor_io(adn_model* m, int buffer, int index, float* host, bool write) {
     float* base = m->flat[buffer] + p.off;
     ADN_HIP_CHECK(hipStreamSynchronize(m->stream));
     if (p.col_stride == 1) {
-        if (write) ADN_HIP_CHECK(hipMemcpy2D(base, (size_t)p.ld * 4, host, (size_t)cols * 4, (size_t)cols * 4, rows,
-                                             hipMemcpyHostToDevice));
+        if (write) {
+            ADN_HIP_CHECK(hipMemcpy2D(base, (size_t)p.ld * 4, host, (size_t)cols * 4, (size_t)cols * 4, rows,
+                                      hipMemcpyHostToDevice));
+            if (buffer == ADN_BUF_PARAM) m->params16_dirty = true;
+        }
         else ADN_HIP_CHECK(hipMemcpy2D(host, (size_t)cols * 4, base, (size_t)p.ld * 4, (size_t)cols * 4, rows,
                                        hipMemcpyDeviceToHost));
         return ADN_OK;
@@ -709,6 +782,7 @@ int tensor_io(adn_model* m, int buffer, int index, float* host, bool write) {
             if (write) phys = host[(size_t)r * cols + c]; else host[(size_t)r * cols + c] = phys;
         }
     if (write) ADN_HIP_CHECK(hipMemcpy(base, tmp.data(), span * 4, hipMemcpyHostToDevice));
+    if (write && buffer == ADN_BUF_PARAM) m->params16_dirty = true;
     return ADN_OK;
 }
 
@@ -774,6 +848,7 @@ void adn_destroy(adn_model* m) {
     (void)hipStreamSynchronize(m->stream);
     if (g_prof == &m->prof) g_prof = nullptr;
     for (int k = 0; k < 4; ++k) if (m->flat[k]) (void)hipFree(m->flat[k]);
+    if (m->params16) (void)hipFree(m->params16);
     if (m->slab) (void)hipFree(m->slab);
     delete m;
 }
@@ -781,6 +856,16 @@ void adn_destroy(adn_model* m) {
 int adn_set_stream(adn_model* m, void* hip_stream) {
     ADN_CHECK(m, ADN_ERR_INVALID, "null model");
     m->stream = static_cast<hipStream_t>(hip_stream);
+    return ADN_OK;
+}
+
+int adn_set_precision(adn_model* m, int precision) {
+    ADN_CHECK(m, ADN_ERR_INVALID, "null model");
+    ADN_CHECK(precision == ADN_PRECISION_F32 || precision == ADN_PRECISION_BF16, ADN_ERR_INVALID,
+              "unsupported precision");
+    m->cfg.precision = precision;
+    m->params16_dirty = true;
+    m->wsB = 0;                       // input staging differs between the modes: re-carve on the next call
     return ADN_OK;
 }
 
@@ -810,6 +895,7 @@ int adn_write_tensor(adn_model* m, int buffer, int index, const float* host_src)
 int adn_flat_buffer(adn_model* m, int buffer, void** device_ptr, size_t* bytes) {
     ADN_CHECK(m && device_ptr && bytes, ADN_ERR_INVALID, "null argument");
     ADN_CHECK(buffer >= 0 && buffer < 4, ADN_ERR_INVALID, "bad buffer id");
+    if (buffer == ADN_BUF_PARAM) m->params16_dirty = true;      // the caller may write through the pointer
     *device_ptr = m->flat[buffer];
     *bytes = (m->flat_floats + kAuxFloats) * sizeof(float);
     return ADN_OK;
@@ -860,6 +946,7 @@ int adn_apply_adam(adn_model* m, float learning_rate) {
     ADN_TRY(adam_update(m->flat[ADN_BUF_PARAM], m->flat[ADN_BUF_GRAD], m->flat[ADN_BUF_ADAM_M], m->flat[ADN_BUF_ADAM_V],
                         (int64_t)m->flat_floats, a_t, kBeta1, kBeta2, kEps, m->stream));
     m->grads_valid = false;
+    m->params16_dirty = true;
     return ADN_OK;
 }
 
@@ -930,6 +1017,14 @@ int adn_op_gemm(int layout, int M, int N, int K, const float* A, int lda, const 
     GemmArgs g;
     g.layout = layout; g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.bias = bias; g.act = act; g.accumulate = accumulate;
+    return gemm(g, static_cast<hipStream_t>(hip_stream));
+}
+
+int adn_op_gemm_ex(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                   const float* bias, int act, int accumulate, int precision, void* hip_stream) {
+    GemmArgs g;
+    g.layout = layout; g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.bias = bias; g.act = act; g.accumulate = accumulate; g.precision = precision;
     return gemm(g, static_cast<hipStream_t>(hip_stream));
 }
 

@@ -90,6 +90,7 @@ class AdeNetModel(object):
         cfg.agg_peepholes = int(bool(spec.get("agg_peepholes", False)))
         cfg.lstm_size = int(spec["lstm_size"])
         cfg.classes = int(spec["classes"])
+        cfg.precision = _lib.PRECISION[spec.get("precision", "f32")]
         self._handle = C.c_void_p()
         _lib.check(self._lib.adn_create(C.byref(cfg), C.byref(self._handle)))
         self.S, self.H, self.C = S, cfg.lstm_size, cfg.classes
@@ -116,6 +117,10 @@ class AdeNetModel(object):
         raw = getattr(stream, "cuda_stream", stream)
         self._torch_stream = stream if hasattr(stream, "cuda_stream") else None
         _lib.check(self._lib.adn_set_stream(self._handle, C.c_void_p(int(raw))))
+
+    def set_precision(self, precision):
+        """'f32' (exact, parity-grade) or 'bf16' (GEMM operands rounded to bf16 in flight, fp32 accumulate)."""
+        _lib.check(self._lib.adn_set_precision(self._handle, _lib.PRECISION[precision]))
 
     def synchronize(self):
         _lib.check(self._lib.adn_synchronize(self._handle))

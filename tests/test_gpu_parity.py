@@ -371,3 +371,103 @@ def test_full_size_properties_whole_train_batch(torch_cuda, lib):
         s = parts[0][k] + parts[1][k]
         assert np.abs(s - g_full[k]).max() <= 1e-4 * max(np.abs(g_full[k]).max(), 1e-7), k
     m.close()
+
+
+# ============================================================================= bf16 GEMM mode
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(37, 50, 19), (130, 250, 150), (1040, 2000, 1200), (500, 50, 20800)])
+def test_gemm_bf16_matches_bf16_rounded_reference(torch_cuda, lib, layout, M, N, K):
+    """The bf16 kernel must equal an fp32-accumulated product of the bf16-ROUNDED operands (tight), which
+    separates rounding-of-inputs (expected) from layout / indexing mistakes (bugs)."""
+    torch = torch_cuda
+    from ip_avsr_amd import _lib as L
+    rng = np.random.default_rng(M + N + K + layout)
+    A = rng.normal(size=(M, K)).astype(np.float32); Bm = rng.normal(size=(K, N)).astype(np.float32)
+    a_d, b_d = torch.tensor(A, device="cuda"), torch.tensor(Bm, device="cuda")
+    ref = (a_d.bfloat16().double() @ b_d.bfloat16().double()).cpu().numpy()
+    pad = lambda n: (n + 7) // 8 * 8
+
+    def dev(x):
+        buf = torch.full((x.shape[0], pad(x.shape[1])), float("nan"), device="cuda")
+        buf[:, :x.shape[1]] = x
+        return buf
+    if layout == 0:
+        ah, bh = a_d, b_d
+    elif layout == 1:
+        ah, bh = a_d, b_d.T.contiguous()
+    else:
+        ah, bh = a_d.T.contiguous(), b_d
+    ap, bp = dev(ah), dev(bh)
+    c_d = torch.full((M, pad(N)), 7.0, device="cuda")
+    L.check(lib.adn_op_gemm_ex(layout, M, N, K, dptr(ap), ap.shape[1], dptr(bp), bp.shape[1], dptr(c_d), c_d.shape[1],
+                               None, 0, 0, L.PRECISION["bf16"], None))
+    torch.cuda.synchronize()
+    out = c_d.cpu().numpy()
+    assert np.abs(out[:, :N] - ref).max() <= 1e-5 * np.sqrt(K) * 16 + 1e-5
+    assert (out[:, N:] == 7.0).all()
+
+
+def test_bf16_mode_tracks_f32_mode_and_keeps_top1(torch_cuda, lib):
+    """bf16 GEMM arithmetic: same parameters, same inputs; probabilities close, majority-vote decisions
+    identical on separable data, gradients aligned (cosine) with the fp32 ones."""
+    from ip_avsr_amd.model import AdeNetModel
+    spec = O.spec_nstream([1200, 1200, 1200])
+    B, T, theta = 26, 20, 9
+    rng = np.random.default_rng(99)
+    p = O.init_params(spec, rng, np.float32, enc_std=0.01)
+    mask = ragged_mask(rng, B, T)
+    inputs = [(rng.normal(size=(B, T, 1200)) * mask[..., None]).astype(np.float32) for _ in range(3)]
+    y = np.repeat((np.arange(B) % 26)[:, None], T, axis=1).astype(np.int32)
+    m = AdeNetModel(spec)
+    m.set_params_dict(p)
+    for _ in range(30):                                   # a few fp32 steps so that the outputs are not flat
+        m.train_step(inputs, y, mask, theta, 2e-3)
+    probs32 = m.predict(inputs, mask, theta)
+    l32 = m.compute_grads(inputs, y, mask, theta)
+    g32 = m.get_grads_dict()
+    m.set_precision("bf16")
+    probs16 = m.predict(inputs, mask, theta)
+    l16 = m.compute_grads(inputs, y, mask, theta)
+    g16 = m.get_grads_dict()
+    assert np.abs(probs16 - probs32).max() < 0.05
+    assert abs(l16 - l32) < 2e-2 * abs(l32)
+    v32, v16 = O.majority_vote(probs32, mask), O.majority_vote(probs16, mask)
+    assert (v32 == v16).mean() >= 0.95
+    for k in ("fc1_s1.W", "bottleneck_s2.W", "lstm_s3.W_in_to_cell", "f_lstm_agg.W_hid_to_ingate", "softmax.W"):
+        a, b = g32[k].ravel().astype(np.float64), g16[k].ravel().astype(np.float64)
+        cos = a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)
+        assert cos > 0.98, (k, cos)
+    m.close()
+
+
+def test_bf16_shadow_copies_equal_convert_in_flight(torch_cuda, lib):
+    """bf16 mode keeps bf16 shadow copies of every GEMM operand; rounding the same fp32 value gives the same
+    bf16, so the result must be IDENTICAL to the path that converts in flight (ADN_BF16_NO_SHADOW=1).  A stale
+    or missing shadow refresh anywhere in the graph shows up here as a difference."""
+    import os
+    from ip_avsr_amd.model import AdeNetModel
+    for name in ("3stream_concat", "3stream_adasum_peep", "deltanet_blstm", "adenet_v2_like", "2stream_sum_peep"):
+        spec = dict(small_specs()[name], precision="bf16")
+        p, inputs, y, mask = make_case(spec, 6, 9, seed=21)
+        out = {}
+        for mode in ("shadow", "inflight"):
+            if mode == "inflight":
+                os.environ["ADN_BF16_NO_SHADOW"] = "1"
+            else:
+                os.environ.pop("ADN_BF16_NO_SHADOW", None)
+            try:
+                m = AdeNetModel(spec)
+                m.set_params_dict(p)
+                losses = [m.train_step(inputs, y, mask, 2, 1e-3) for _ in range(3)]
+                probs = m.predict(inputs, mask, 2)
+                m.compute_grads(inputs, y, mask, 2)
+                out[mode] = (losses, probs, m.get_grads_dict())
+                m.close()
+            finally:
+                os.environ.pop("ADN_BF16_NO_SHADOW", None)
+        assert out["shadow"][0] == out["inflight"][0], name
+        np.testing.assert_array_equal(out["shadow"][1], out["inflight"][1])
+        for k in out["shadow"][2]:
+            a, b = out["shadow"][2][k], out["inflight"][2][k]
+            # split-K weight gradients use fp32 atomics (order-dependent last bits)
+            assert np.abs(a - b).max() <= 1e-5 * max(np.abs(b).max(), 1e-6), (name, k)
