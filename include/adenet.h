@@ -184,6 +184,11 @@ int adn_op_gemm(int layout, int M, int N, int K, const float* A, int lda, const 
                 int ldc, const float* bias, int act, int accumulate, void* hip_stream);
 int adn_op_gemm_ex(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                    int ldc, const float* bias, int act, int accumulate, int precision, void* hip_stream);
+/* bf16 mode with pre-converted operands: A16/B16 (and optionally C16) are bf16 copies with the same leading
+ * dimensions as A/B/C (adn_op_to_bf16 makes them); null pointers fall back to conversion in flight */
+int adn_op_gemm_shadow(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                       int ldc, const void* A16, const void* B16, void* C16, int accumulate, void* hip_stream);
+int adn_op_to_bf16(const float* src, void* dst, int64_t n, void* hip_stream);
 /* utils/signal.py:59-80 on device: in (B,T,F) batch-major -> out (T,B,3F) time-major */
 int adn_op_delta_forward(const float* in, int ld_in, float* out, int ld_out, int B, int T, int F, int theta,
                          void* hip_stream);

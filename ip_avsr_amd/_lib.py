@@ -81,6 +81,9 @@ _SIGNATURES = {
                               C.c_int, C.c_int, _P]),
     "adn_op_gemm_ex": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int, _P,
                                  C.c_int, C.c_int, C.c_int, _P]),
+    "adn_op_gemm_shadow": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, _P,
+                                     C.c_int, _P]),
+    "adn_op_to_bf16": (C.c_int, [_P, _P, C.c_int64, _P]),
     "adn_op_delta_forward": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "adn_op_delta_backward": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "adn_op_adam": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, _P]),

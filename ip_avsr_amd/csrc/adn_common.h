@@ -45,7 +45,9 @@ enum ProfClass {
     PROF_ADAM, PROF_SOFTMAX_LOSS, PROF_COUNT
 };
 struct ProfScope {
-    ProfScope(int cls, double flops, double bytes, hipStream_t s);
+    // one scope may bracket several back-to-back launches of the class (`launches`): short kernels are timed as
+    // a sequence so that the event records do not sit between them
+    ProfScope(int cls, double flops, double bytes, hipStream_t s, int launches = 1);
     ~ProfScope();
     int slot;
     hipStream_t stream;
@@ -140,12 +142,20 @@ struct LstmStep {          // one LSTM instance taking part in a (possibly multi
     float* dc_state;       // [B][ldh]
     float* dpeep_part;     // [3][ldh] accumulated peephole-weight gradients (null: none)
     int backwards;
+    // bf16 mode (null in f32 mode): bf16 copies the step kernels read / write directly
+    const void* W_hid16T;  // [ldg][ldk] bf16: W_hid transposed (row = gate column, k contiguous, zero padded)
+    const void* W_hid16;   // [H][ldg]   bf16: W_hid as stored (row = k of the forward, contiguous gate columns)
+    void* h16;             // [(T+1)*B][ldh] bf16 shadow of hbuf
+    void* dG16;            // [T*B][ldg]     bf16 shadow of dG
 };
 constexpr int kMaxLstmPerLaunch = 8;
 // runs all T steps of n (<= kMaxLstmPerLaunch) independent LSTMs of identical (B,T,H) concurrently
-int lstm_forward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
+int lstm_forward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, int precision, hipStream_t s);
+// W [H][ldg] fp32 -> out [ldg][ldk] bf16 (ldk = round_up(H,32)), zero padded
+int lstm_pack_whid_t(const float* W, void* out, int H, hipStream_t s);
+static inline int lstm_ldk(int H) { return (int)((H + 31) / 32 * 32); }
 // BPTT; on return dG holds d(gates) for every step, dh_carry / dc_state the gradient wrt the
 // initial state (per batch row)
-int lstm_backward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
+int lstm_backward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, int precision, hipStream_t s);
 
 }  // namespace adn

@@ -43,7 +43,7 @@ struct StageKC;
 
 template <int R>
 struct StageKC<R, float> {
-    static constexpr int kStride = BKH + 8;               // bf16 per LDS row (144 B)
+    static constexpr int kStride = BKH + 16;              // bf16 per LDS row (160 B = 40 banks: conflict-free b128 fragment reads)
     static constexpr int kLds = R * kStride;
     static constexpr int kIter = R / 32;                  // row groups per thread; 2 float4 (8 k) each
     const float* ptr[kIter];
@@ -99,7 +99,7 @@ struct StageKC<R, float> {
 // ---- k-contiguous operand already in bf16 (shadow copy): one 16-byte load = 8 k ---------------------
 template <int R>
 struct StageKC<R, __bf16> {
-    static constexpr int kStride = BKH + 8;
+    static constexpr int kStride = BKH + 16;
     static constexpr int kLds = R * kStride;
     static constexpr int kIter = R / 32;
     const __bf16* ptr[kIter];
@@ -340,11 +340,72 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
     }
 
     const bool first_split = blockIdx.y == 0;
+    if (p.atomic) {                                   // split-K: fp32 atomics straight from the accumulators
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+        for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b)
-            store_tile16(p, acc[a][b], m0 + wm * WTM + a * 16, n0 + wn * WTN + b * 16, lane, first_split);
+            for (int b = 0; b < TN; ++b)
+                store_tile16(p, acc[a][b], m0 + wm * WTM + a * 16, n0 + wn * WTN + b * 16, lane, first_split);
+        return;
+    }
+    // Coalesced epilogue: the accumulators of a wave (column on the lane, 4 rows per register quad) are bounced
+    // through LDS, 32 rows at a time, so that every lane then owns 4 CONSECUTIVE columns of one row: bias /
+    // activation / act'(Y) / accumulate run on float4, C is written with 16-byte stores (256 contiguous bytes per
+    // row per wave instruction) and the bf16 shadow with 8-byte stores.  (Per-lane scalar stores of the raw MFMA
+    // layout touch 4 rows x 64 B per instruction and made the store tail as long as the main loop for N ~ K.)
+    constexpr int LW = WTN + 4;                       // floats per LDS row (16-byte aligned, bank-staggered)
+    constexpr int LPR = WTN / 4;                      // lanes per row in the read phase
+    constexpr int RPI = 64 / LPR;                     // rows per read instruction
+    float* wl = reinterpret_cast<float*>(smem) + wave * 32 * LW;
+    static_assert(4 * 32 * LW * 4 <= (SA::kLds + SB::kLds) * 2, "epilogue LDS does not fit");
+    const int i16 = lane & 15, kq4 = (lane >> 4) * 4;
+    const bool vec_ok = (p.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
+                        (!p.Y || (p.ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(p.Y) & 15) == 0));
+#pragma unroll
+    for (int pass = 0; pass < TM / 2; ++pass) {
+        __syncthreads();
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) wl[(a2 * 16 + kq4 + r) * LW + b * 16 + i16] = acc[pass * 2 + a2][b][r];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 32 / RPI; ++j) {
+            const int lr = j * RPI + lane / LPR, lc = (lane % LPR) * 4;
+            const int row = m0 + wm * WTM + pass * 32 + lr, col = n0 + wn * WTN + lc;
+            if (row >= p.M || col >= p.N) continue;
+            float4 v = *reinterpret_cast<const float4*>(wl + lr * LW + lc);
+            float* vv = reinterpret_cast<float*>(&v);
+            const size_t off = (size_t)row * p.ldc + col;
+            if (vec_ok && col + 3 < p.N) {
+                if (p.bias) { v.x += p.bias[col]; v.y += p.bias[col + 1]; v.z += p.bias[col + 2]; v.w += p.bias[col + 3]; }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vv[e] = act_apply(p.act, vv[e]);
+                if (p.Y) {
+                    const float4 y = *reinterpret_cast<const float4*>(p.Y + (size_t)row * p.ldy + col);
+                    v.x *= act_grad_from_output(p.act_grad, y.x); v.y *= act_grad_from_output(p.act_grad, y.y);
+                    v.z *= act_grad_from_output(p.act_grad, y.z); v.w *= act_grad_from_output(p.act_grad, y.w);
+                }
+                if (p.accumulate) {
+                    const float4 c = *reinterpret_cast<const float4*>(p.C + off);
+                    v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w;
+                }
+                *reinterpret_cast<float4*>(p.C + off) = v;
+                if (p.C16) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.C16) + off) = cvt4(v);
+            } else {
+                for (int e = 0; e < 4 && col + e < p.N; ++e) {
+                    float x = vv[e] + (p.bias ? p.bias[col + e] : 0.f);
+                    x = act_apply(p.act, x);
+                    if (p.Y) x *= act_grad_from_output(p.act_grad, p.Y[(size_t)row * p.ldy + col + e]);
+                    if (p.accumulate) x += p.C[off + e];
+                    p.C[off + e] = x;
+                    if (p.C16) reinterpret_cast<__bf16*>(p.C16)[off + e] = (__bf16)x;
+                }
+            }
+        }
+    }
 }
 
 template <int BM, int BN, typename T>

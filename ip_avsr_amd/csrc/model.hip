@@ -33,7 +33,7 @@ void set_error(const std::string& msg) { g_last_error = msg; }
 // profiler
 // ------------------------------------------------------------------------------------------
 struct Profiler {
-    struct Rec { hipEvent_t a, b; int cls; double flops, bytes; };
+    struct Rec { hipEvent_t a, b; int cls; double flops, bytes; int launches; };
     bool enabled = false;
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
@@ -47,7 +47,7 @@ struct Profiler {
         for (auto& r : recs) {
             float t = 0.f;
             if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) ms[r.cls] += t;
-            flops[r.cls] += r.flops; bytes[r.cls] += r.bytes; launches[r.cls] += 1;
+            flops[r.cls] += r.flops; bytes[r.cls] += r.bytes; launches[r.cls] += r.launches;
             pool.push_back(r.a); pool.push_back(r.b);
         }
         recs.clear();
@@ -60,10 +60,10 @@ struct Profiler {
 };
 static thread_local Profiler* g_prof = nullptr;
 
-ProfScope::ProfScope(int cls, double flops, double bytes, hipStream_t s) : slot(-1), stream(s) {
+ProfScope::ProfScope(int cls, double flops, double bytes, hipStream_t s, int launches) : slot(-1), stream(s) {
     Profiler* p = g_prof;
     if (!p || !p->enabled) return;
-    Profiler::Rec r{p->get(), p->get(), cls, flops, bytes};
+    Profiler::Rec r{p->get(), p->get(), cls, flops, bytes, launches};
     (void)hipEventRecord(r.a, s);
     p->recs.push_back(r);
     slot = (int)p->recs.size() - 1;
@@ -94,6 +94,7 @@ struct ParamDesc {
 };
 
 struct LstmParams {      // physical tensors (float offsets into the flat buffers)
+    char* whid16t = nullptr;   // bf16 mode: transposed bf16 copy of W_hid, refreshed with the parameter shadow
     int fin = 0;
     size_t W_in = 0, W_hid = 0, b = 0, peep = 0, cell_init = 0, hid_init = 0;
     bool peepholes = false;
@@ -444,6 +445,12 @@ int refresh_params(adn_model* m) {
     if (!m->bf16() || !m->params16_dirty) return ADN_OK;
     if (!m->params16) ADN_HIP_CHECK(hipMalloc((void**)&m->params16, m->flat_floats * 2));
     ADN_TRY(to_bf16(m->flat[ADN_BUF_PARAM], m->params16, m->flat_floats, m->stream));
+    auto pack = [&](LstmParams& lp) -> int {
+        if (!lp.whid16t) ADN_HIP_CHECK(hipMalloc((void**)&lp.whid16t, (size_t)m->ldg * lstm_ldk(m->H) * 2));
+        return lstm_pack_whid_t(m->P(lp.W_hid), lp.whid16t, m->H, m->stream);
+    };
+    for (auto& st : m->st) for (auto& lp : st.lstm) ADN_TRY(pack(lp));
+    for (auto& lp : m->agg) ADN_TRY(pack(lp));
     m->params16_dirty = false;
     return ADN_OK;
 }
@@ -456,14 +463,19 @@ LstmStep make_step(const adn_model* m, const LstmParams& lp, const LstmWork& w, 
     s.dG = w.dG; s.dhs = dhs; s.dh_carry = w.dh_carry; s.dc_state = w.dc_state;
     s.dpeep_part = (grads && lp.peepholes) ? m->G(lp.peep) : nullptr;
     s.backwards = lp.backwards ? 1 : 0;
+    const bool b16 = m->bf16();      // the step kernels maintain their own bf16 copies (h16, dG16)
+    s.W_hid16T = b16 ? lp.whid16t : nullptr;
+    s.W_hid16 = b16 ? m->shadow_of(m->P(lp.W_hid)) : nullptr;
+    s.h16 = b16 ? m->shadow_of(w.hbuf) : nullptr;
+    s.dG16 = b16 ? m->shadow_of(w.dG) : nullptr;
     return s;
 }
 
 int run_lstm_group(adn_model* m, std::vector<LstmStep>& steps, int B, int T, bool backward) {
     for (size_t i = 0; i < steps.size(); i += kMaxLstmPerLaunch) {
         const int n = (int)std::min<size_t>(kMaxLstmPerLaunch, steps.size() - i);
-        if (backward) ADN_TRY(lstm_backward(steps.data() + i, n, m->mask_tb, B, T, m->H, m->stream));
-        else ADN_TRY(lstm_forward(steps.data() + i, n, m->mask_tb, B, T, m->H, m->stream));
+        if (backward) ADN_TRY(lstm_backward(steps.data() + i, n, m->mask_tb, B, T, m->H, m->cfg.precision, m->stream));
+        else ADN_TRY(lstm_forward(steps.data() + i, n, m->mask_tb, B, T, m->H, m->cfg.precision, m->stream));
     }
     return ADN_OK;
 }
@@ -488,6 +500,7 @@ int lstm_init_state(adn_model* m, const LstmParams& lp, const LstmWork& w, int B
     const size_t blk = lp.backwards ? (size_t)T * B * m->ldh : 0;
     ADN_TRY(broadcast_rows(m->P(lp.hid_init), w.hbuf + blk, m->ldh, B, m->H, m->stream));
     ADN_TRY(broadcast_rows(m->P(lp.cell_init), w.cbuf + blk, m->ldh, B, m->H, m->stream));
+    ADN_TRY(refresh(m, w.hbuf + blk, (size_t)B * m->ldh));          // bf16 copy of the initial-state block
     return ADN_OK;
 }
 
@@ -519,7 +532,6 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
     }
     ADN_TRY(run_lstm_group(m, steps, B, T, false));
     for (auto& st : m->st) {
-        for (auto& w : st.lw) ADN_TRY(refresh(m, w.hbuf, (size_t)(T + 1) * B * ldh));
         if (st.lstm.size() == 2) {                               // summed BLSTM sub-stream
             const float* in[2] = {st.lw[0].out(B, ldh, false), st.lw[1].out(B, ldh, true)};
             ADN_TRY(sum_k(2, in, nullptr, ldh, st.hsum, ldh, N, H, s));
@@ -559,7 +571,6 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
             steps.push_back(make_step(m, m->agg[k], m->aggw[k], nullptr, false));
         }
         ADN_TRY(run_lstm_group(m, steps, B, T, false));
-        for (auto& w : m->aggw) ADN_TRY(refresh(m, w.hbuf, (size_t)(T + 1) * B * ldh));
         if (m->agg.size() == 2) {
             const float* in[2] = {m->aggw[0].out(B, ldh, false), m->aggw[1].out(B, ldh, true)};
             ADN_TRY(sum_k(2, in, nullptr, ldh, m->cls_in, ldh, N, H, s));
@@ -661,7 +672,6 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         std::vector<LstmStep> steps;
         for (size_t k = 0; k < m->agg.size(); ++k) steps.push_back(make_step(m, m->agg[k], m->aggw[k], m->dcls, true));
         ADN_TRY(run_lstm_group(m, steps, B, T, true));
-        for (auto& w : m->aggw) ADN_TRY(refresh(m, w.dG, (size_t)N * m->ldg));
         for (size_t k = 0; k < m->agg.size(); ++k)
             ADN_TRY(lstm_param_grads(m, m->agg[k], m->aggw[k], fin.data(), fld.data(), (int)fin.size(), H, B, T));
         for (size_t j = 0; j < fin.size(); ++j) {
@@ -694,7 +704,6 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         ADN_TRY(run_lstm_group(m, steps, B, T, true));
     }
     for (auto& st : m->st) {
-        for (auto& w : st.lw) ADN_TRY(refresh(m, w.dG, (size_t)N * m->ldg));
         const int ldf = ld_of(st.feat_dim);
         const float* in[1] = {st.feat}; const int ld[1] = {ldf};
         for (size_t k = 0; k < st.lstm.size(); ++k)
@@ -849,6 +858,8 @@ void adn_destroy(adn_model* m) {
     if (g_prof == &m->prof) g_prof = nullptr;
     for (int k = 0; k < 4; ++k) if (m->flat[k]) (void)hipFree(m->flat[k]);
     if (m->params16) (void)hipFree(m->params16);
+    for (auto& st : m->st) for (auto& lp : st.lstm) if (lp.whid16t) (void)hipFree(lp.whid16t);
+    for (auto& lp : m->agg) if (lp.whid16t) (void)hipFree(lp.whid16t);
     if (m->slab) (void)hipFree(m->slab);
     delete m;
 }
@@ -1026,6 +1037,18 @@ int adn_op_gemm_ex(int layout, int M, int N, int K, const float* A, int lda, con
     g.layout = layout; g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.bias = bias; g.act = act; g.accumulate = accumulate; g.precision = precision;
     return gemm(g, static_cast<hipStream_t>(hip_stream));
+}
+
+int adn_op_gemm_shadow(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                       int ldc, const void* A16, const void* B16, void* C16, int accumulate, void* hip_stream) {
+    GemmArgs g;
+    g.layout = layout; g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.accumulate = accumulate; g.precision = ADN_PRECISION_BF16; g.A16 = A16; g.B16 = B16; g.C16 = C16;
+    return gemm(g, static_cast<hipStream_t>(hip_stream));
+}
+
+int adn_op_to_bf16(const float* src, void* dst, int64_t n, void* hip_stream) {
+    return to_bf16(src, dst, (size_t)n, static_cast<hipStream_t>(hip_stream));
 }
 
 int adn_op_delta_forward(const float* in, int ld_in, float* out, int ld_out, int B, int T, int F, int theta,

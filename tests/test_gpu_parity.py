@@ -471,3 +471,31 @@ def test_bf16_shadow_copies_equal_convert_in_flight(torch_cuda, lib):
             a, b = out["shadow"][2][k], out["inflight"][2][k]
             # split-K weight gradients use fp32 atomics (order-dependent last bits)
             assert np.abs(a - b).max() <= 1e-5 * max(np.abs(b).max(), 1e-6), (name, k)
+
+
+@pytest.mark.parametrize("name", ["lstm_classifier", "deltanet_blstm", "3stream_adasum_peep"])
+def test_bf16_recurrence_close_to_oracle(torch_cuda, lib, name):
+    """bf16 mode also runs the recurrent products h*W_hid and dG*W_hid^T on bf16 MFMA (fp32 accumulate, fp32
+    cell state / gate math).  Against the fp64 oracle: probabilities within 2e-2, every gradient tensor
+    aligned (cosine > 0.99) and of the right size (norm ratio within 15 %)."""
+    from ip_avsr_amd.model import AdeNetModel
+    spec = dict(small_specs()[name], precision="bf16")
+    B, T, theta = 7, 11, 2
+    p, inputs, y, mask = make_case(spec, B, T, seed=77)
+    m = AdeNetModel(spec)
+    m.set_params_dict(p)
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    in64 = [x.astype(np.float64) for x in inputs]
+    probs_ref = O.forward(spec, p64, in64, mask, theta)
+    assert np.abs(m.predict(inputs, mask, theta) - probs_ref).max() <= 2e-2
+    l_ref, g_ref, _ = O.loss_and_grads(spec, p64, in64, y, mask, theta)
+    l = m.compute_grads(inputs, y, mask, theta)
+    assert abs(l - l_ref) <= 1e-2 * abs(l_ref)
+    g = m.get_grads_dict()
+    for k in O.param_names(spec):
+        a, b = np.asarray(g_ref[k], np.float64).ravel(), g[k].ravel().astype(np.float64)
+        if np.linalg.norm(a) < 1e-9:
+            continue
+        cos = a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)
+        assert cos > 0.99 and abs(np.linalg.norm(b) / np.linalg.norm(a) - 1) < 0.15, (k, cos)
+    m.close()
