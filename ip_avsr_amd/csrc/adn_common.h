@@ -145,6 +145,8 @@ struct LstmStep {          // one LSTM instance taking part in a (possibly multi
     // bf16 mode (null in f32 mode): bf16 copies the step kernels read / write directly
     const void* W_hid16T;  // [ldg][ldk] bf16: W_hid transposed (row = gate column, k contiguous, zero padded)
     const void* W_hid16;   // [H][ldg]   bf16: W_hid as stored (row = k of the forward, contiguous gate columns)
+    const void* W_frag_fwd;  // W_hid in MFMA-fragment order for the persistent kernels (lstm_persistent.hip)
+    const void* W_frag_bwd;
     void* h16;             // [(T+1)*B][ldh] bf16 shadow of hbuf
     void* dG16;            // [T*B][ldg]     bf16 shadow of dG
 };
@@ -153,6 +155,12 @@ constexpr int kMaxLstmPerLaunch = 8;
 int lstm_forward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, int precision, hipStream_t s);
 // W [H][ldg] fp32 -> out [ldg][ldk] bf16 (ldk = round_up(H,32)), zero padded
 int lstm_pack_whid_t(const float* W, void* out, int H, hipStream_t s);
+// persistent variants (lstm_persistent.hip): one launch for all T steps, bf16 mode, H <= 512
+bool lstm_persistent_supported(int H);
+size_t lstm_frag_elems(int H);
+int lstm_pack_frags(const float* W, void* fwd, void* bwd, int H, hipStream_t s);
+int lstm_forward_persistent(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
+int lstm_backward_persistent(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
 static inline int lstm_ldk(int H) { return (int)((H + 31) / 32 * 32); }
 // BPTT; on return dG holds d(gates) for every step, dh_carry / dc_state the gradient wrt the
 // initial state (per batch row)

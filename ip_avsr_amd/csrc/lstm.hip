@@ -318,6 +318,7 @@ int lstm_forward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T,
     bool have16 = precision == ADN_PRECISION_BF16;
     for (int k = 0; k < n; ++k) { L.l[k] = l[k]; have16 = have16 && l[k].W_hid16T && l[k].h16; }
     const int ldh = ld_of(H), ldg = ld_of(4 * H);
+    if (have16 && lstm_persistent_supported(H) && l[0].W_frag_fwd) return lstm_forward_persistent(l, n, mask_tb, B, T, H, s);
     if (have16) {
         const double bytes = n * (4.0 * (12.0 * B * H + 4.0 * H * H) + B), flops = n * 8.0 * B * H * H;
         const dim3 grid16(cdiv(B, 32), cdiv(4 * H, 64), n);
@@ -445,6 +446,7 @@ int lstm_backward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T
     bool have16 = precision == ADN_PRECISION_BF16;
     for (int k = 0; k < n; ++k) { L.l[k] = l[k]; have16 = have16 && l[k].W_hid16 && l[k].dG16; }
     const int ldh = ld_of(H), ldg = ld_of(4 * H);
+    if (have16 && lstm_persistent_supported(H) && l[0].W_frag_bwd) return lstm_backward_persistent(l, n, mask_tb, B, T, H, s);
     for (int k = 0; k < n; ++k) {
         ADN_HIP_CHECK(hipMemsetAsync(l[k].dh_carry, 0, (size_t)B * ldh * sizeof(float), s));
         ADN_HIP_CHECK(hipMemsetAsync(l[k].dc_state, 0, (size_t)B * ldh * sizeof(float), s));

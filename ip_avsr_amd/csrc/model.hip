@@ -95,6 +95,8 @@ struct ParamDesc {
 
 struct LstmParams {      // physical tensors (float offsets into the flat buffers)
     char* whid16t = nullptr;   // bf16 mode: transposed bf16 copy of W_hid, refreshed with the parameter shadow
+    char* wfrag_fwd = nullptr; // ... and the two MFMA-fragment-ordered copies the persistent kernels stream
+    char* wfrag_bwd = nullptr;
     int fin = 0;
     size_t W_in = 0, W_hid = 0, b = 0, peep = 0, cell_init = 0, hid_init = 0;
     bool peepholes = false;
@@ -446,7 +448,18 @@ int refresh_params(adn_model* m) {
     if (!m->params16) ADN_HIP_CHECK(hipMalloc((void**)&m->params16, m->flat_floats * 2));
     ADN_TRY(to_bf16(m->flat[ADN_BUF_PARAM], m->params16, m->flat_floats, m->stream));
     auto pack = [&](LstmParams& lp) -> int {
-        if (!lp.whid16t) ADN_HIP_CHECK(hipMalloc((void**)&lp.whid16t, (size_t)m->ldg * lstm_ldk(m->H) * 2));
+        if (!lp.whid16t) {           // + tail: the persistent kernel reads whole 32-k steps past a short last row
+            const size_t bytes = ((size_t)m->ldg * lstm_ldk(m->H) + 1024) * 2;
+            ADN_HIP_CHECK(hipMalloc((void**)&lp.whid16t, bytes));
+            ADN_HIP_CHECK(hipMemsetAsync(lp.whid16t, 0, bytes, m->stream));
+        }
+        if (lstm_persistent_supported(m->H)) {
+            if (!lp.wfrag_fwd) {
+                ADN_HIP_CHECK(hipMalloc((void**)&lp.wfrag_fwd, lstm_frag_elems(m->H) * 2));
+                ADN_HIP_CHECK(hipMalloc((void**)&lp.wfrag_bwd, lstm_frag_elems(m->H) * 2));
+            }
+            ADN_TRY(lstm_pack_frags(m->P(lp.W_hid), lp.wfrag_fwd, lp.wfrag_bwd, m->H, m->stream));
+        }
         return lstm_pack_whid_t(m->P(lp.W_hid), lp.whid16t, m->H, m->stream);
     };
     for (auto& st : m->st) for (auto& lp : st.lstm) ADN_TRY(pack(lp));
@@ -465,6 +478,8 @@ LstmStep make_step(const adn_model* m, const LstmParams& lp, const LstmWork& w, 
     s.backwards = lp.backwards ? 1 : 0;
     const bool b16 = m->bf16();      // the step kernels maintain their own bf16 copies (h16, dG16)
     s.W_hid16T = b16 ? lp.whid16t : nullptr;
+    s.W_frag_fwd = b16 ? lp.wfrag_fwd : nullptr;
+    s.W_frag_bwd = b16 ? lp.wfrag_bwd : nullptr;
     s.W_hid16 = b16 ? m->shadow_of(m->P(lp.W_hid)) : nullptr;
     s.h16 = b16 ? m->shadow_of(w.hbuf) : nullptr;
     s.dG16 = b16 ? m->shadow_of(w.dG) : nullptr;
@@ -858,8 +873,13 @@ void adn_destroy(adn_model* m) {
     if (g_prof == &m->prof) g_prof = nullptr;
     for (int k = 0; k < 4; ++k) if (m->flat[k]) (void)hipFree(m->flat[k]);
     if (m->params16) (void)hipFree(m->params16);
-    for (auto& st : m->st) for (auto& lp : st.lstm) if (lp.whid16t) (void)hipFree(lp.whid16t);
-    for (auto& lp : m->agg) if (lp.whid16t) (void)hipFree(lp.whid16t);
+    auto free_lp = [](LstmParams& lp) {
+        if (lp.whid16t) (void)hipFree(lp.whid16t);
+        if (lp.wfrag_fwd) (void)hipFree(lp.wfrag_fwd);
+        if (lp.wfrag_bwd) (void)hipFree(lp.wfrag_bwd);
+    };
+    for (auto& st : m->st) for (auto& lp : st.lstm) free_lp(lp);
+    for (auto& lp : m->agg) free_lp(lp);
     if (m->slab) (void)hipFree(m->slab);
     delete m;
 }

@@ -473,14 +473,19 @@ def test_bf16_shadow_copies_equal_convert_in_flight(torch_cuda, lib):
             assert np.abs(a - b).max() <= 1e-5 * max(np.abs(b).max(), 1e-6), (name, k)
 
 
-@pytest.mark.parametrize("name", ["lstm_classifier", "deltanet_blstm", "3stream_adasum_peep"])
+def wide_spec():
+    s = O.spec_deltanet(10, enc_shapes=(), enc_acts=(), lstm_size=260, classes=5, peepholes=True, use_blstm=True)
+    return s                                                  # H > 256: the 64-units-per-wave persistent kernels
+
+
+@pytest.mark.parametrize("name", ["lstm_classifier", "deltanet_blstm", "3stream_adasum_peep", "wide"])
 def test_bf16_recurrence_close_to_oracle(torch_cuda, lib, name):
     """bf16 mode also runs the recurrent products h*W_hid and dG*W_hid^T on bf16 MFMA (fp32 accumulate, fp32
     cell state / gate math).  Against the fp64 oracle: probabilities within 2e-2, every gradient tensor
     aligned (cosine > 0.99) and of the right size (norm ratio within 15 %)."""
     from ip_avsr_amd.model import AdeNetModel
-    spec = dict(small_specs()[name], precision="bf16")
-    B, T, theta = 7, 11, 2
+    spec = dict(wide_spec() if name == "wide" else small_specs()[name], precision="bf16")
+    B, T, theta = (19, 11, 2) if name == "wide" else (7, 11, 2)
     p, inputs, y, mask = make_case(spec, B, T, seed=77)
     m = AdeNetModel(spec)
     m.set_params_dict(p)
