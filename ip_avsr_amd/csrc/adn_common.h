@@ -84,6 +84,10 @@ struct GemmArgs {
     // given the kernel loads bf16 directly instead of converting fp32 in flight.  C16: also store the result
     // as bf16 (non-split-K launches only).
     const void* A16 = nullptr; const void* B16 = nullptr; void* C16 = nullptr;
+    // colsum[col] += sum over rows of the FINAL C values (bias gradients ride on the GEMM that produces dZ
+    // instead of re-reading it); honoured by the bf16 kernels' coalesced epilogue, non-split launches only --
+    // gemm() reports through *colsum_done whether it was.
+    float* colsum = nullptr; int* colsum_done = nullptr;
 };
 int gemm(const GemmArgs& g, hipStream_t stream);
 // dst[i] = bf16(src[i]), n a multiple of 8

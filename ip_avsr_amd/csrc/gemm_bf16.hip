@@ -361,6 +361,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
     const int i16 = lane & 15, kq4 = (lane >> 4) * 4;
     const bool vec_ok = (p.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
                         (!p.Y || (p.ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(p.Y) & 15) == 0));
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);    // column sums of this lane's 4 columns (p.colsum)
 #pragma unroll
     for (int pass = 0; pass < TM / 2; ++pass) {
         __syncthreads();
@@ -394,6 +395,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
                 }
                 *reinterpret_cast<float4*>(p.C + off) = v;
                 if (p.C16) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.C16) + off) = cvt4(v);
+                csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w;
             } else {
                 for (int e = 0; e < 4 && col + e < p.N; ++e) {
                     float x = vv[e] + (p.bias ? p.bias[col + e] : 0.f);
@@ -404,6 +406,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
                     if (p.C16) reinterpret_cast<__bf16*>(p.C16)[off + e] = (__bf16)x;
                 }
             }
+        }
+    }
+    if (p.colsum) {                                   // lanes that differ only in their row share the columns
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) {
+            csum.x += __shfl_xor(csum.x, o, 64); csum.y += __shfl_xor(csum.y, o, 64);
+            csum.z += __shfl_xor(csum.z, o, 64); csum.w += __shfl_xor(csum.w, o, 64);
+        }
+        const int col = n0 + wn * WTN + (lane % LPR) * 4;
+        if (lane < LPR && col + 3 < p.N) {
+            atomicAdd(p.colsum + col, csum.x); atomicAdd(p.colsum + col + 1, csum.y);
+            atomicAdd(p.colsum + col + 2, csum.z); atomicAdd(p.colsum + col + 3, csum.w);
         }
     }
 }

@@ -174,6 +174,8 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
     p.A = g.A; p.lda = g.lda; p.B = g.B; p.ldb = g.ldb; p.C = g.C; p.ldc = g.ldc;
     p.bias = g.bias; p.Y = g.Y; p.ldy = g.ldy;
     p.A16 = g.A16; p.B16 = g.B16; p.C16 = g.C16;
+    p.colsum = nullptr;
+    if (g.colsum_done) *g.colsum_done = 0;
     p.act = g.act; p.act_grad = g.act_grad; p.accumulate = g.accumulate;
 
     const int64_t t128 = (int64_t)cdiv(g.M, 128) * cdiv(g.N, 128);
@@ -200,6 +202,11 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
                    4.0 * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N), stream);
     if (p.atomic && !g.accumulate)
         ADN_HIP_CHECK(hipMemset2DAsync(g.C, (size_t)g.ldc * 4, 0, (size_t)g.N * 4, g.M, stream));
+    if (g.colsum && g.precision == ADN_PRECISION_BF16 && !p.atomic && g.ldc % 4 == 0 &&
+        ((uintptr_t)g.C % 16) == 0 && (!g.Y || (g.ldy % 4 == 0 && ((uintptr_t)g.Y % 16) == 0)) && g.N % 4 == 0) {
+        p.colsum = g.colsum;                  // the vectorised epilogue path is guaranteed for every element
+        if (g.colsum_done) *g.colsum_done = 1;
+    }
     const int tsz = big ? 128 : 64;
     p.tiles_m = cdiv(g.M, tsz); p.tiles_n = cdiv(g.N, tsz);
     const dim3 grid((unsigned)tiles, split);

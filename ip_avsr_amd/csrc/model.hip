@@ -120,6 +120,7 @@ struct StreamState {
     // workspace
     const float* x = nullptr; int ldx = 0;     // staged input (batch-major)
     float* xstage = nullptr;
+    void* x16 = nullptr;                       // bf16 copy of x when x is the caller's own device buffer
     std::vector<float*> act;                   // encoder activations (batch-major)
     float* feat = nullptr;                     // time-major LSTM input
     std::vector<LstmWork> lw;
@@ -178,6 +179,8 @@ struct adn_model {
         if (!p) return nullptr;
         if (p >= flat[ADN_BUF_PARAM] && p < flat[ADN_BUF_PARAM] + flat_floats)
             return params16 ? params16 + 2 * (size_t)(p - flat[ADN_BUF_PARAM]) : nullptr;
+        for (const auto& st_ : st)
+            if (st_.x16 && p == st_.x) return st_.x16;
         for (const auto& r : shadows)
             if (p >= r.base && p < r.base + r.n) return r.shadow + 2 * (size_t)(p - r.base);
         return nullptr;
@@ -407,9 +410,14 @@ int stage_inputs(adn_model* m, const void* const* inputs, const int32_t* targets
         const int D = st.cfg.input_dim;
         // device inputs are used in place when the GEMM loader can read them directly; in bf16 mode they
         // are copied into the staging buffer instead, which owns a bf16 shadow
-        const bool direct = dev && !m->bf16() && (D % 4 == 0) && (((uintptr_t)inputs[s]) % 16 == 0);
+        const bool direct = dev && (D % (m->bf16() ? 8 : 4) == 0) && (((uintptr_t)inputs[s]) % 16 == 0);
+        st.x16 = nullptr;
         if (direct) {
             st.x = static_cast<const float*>(inputs[s]); st.ldx = D;
+            if (m->bf16()) {                   // the staging buffer's shadow holds the bf16 copy (ld_of(D) == D)
+                st.x16 = m->shadow_of(st.xstage);
+                ADN_TRY(to_bf16(st.x, st.x16, N * (size_t)D, m->stream));
+            }
         } else {
             const int ld = ld_of(D);
             ADN_HIP_CHECK(hipMemcpy2DAsync(st.xstage, (size_t)ld * 4, inputs[s], (size_t)D * 4, (size_t)D * 4, N, kind,
@@ -417,7 +425,7 @@ int stage_inputs(adn_model* m, const void* const* inputs, const int32_t* targets
             st.x = st.xstage; st.ldx = ld;
         }
     }
-    for (auto& st : m->st) ADN_TRY(refresh(m, st.x, N * st.ldx));
+    for (auto& st : m->st) if (!st.x16) ADN_TRY(refresh(m, st.x, N * st.ldx));
     ADN_TRY(refresh_params(m));
     ADN_HIP_CHECK(hipMemcpyAsync(m->mask_bt, mask, N, kind, m->stream));
     if (targets) ADN_HIP_CHECK(hipMemcpyAsync(m->y_bt, targets, N * sizeof(int32_t), kind, m->stream));
@@ -733,6 +741,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         ADN_TRY(act_backward(st.dE, ldE, st.act[L - 1], ldE, N, st.enc_out, st.cfg.enc_act[L - 1], s));
         ADN_TRY(refresh(m, st.dE, (size_t)N * ldE));
         float* dZ = st.dE; int lddz = ldE;
+        int bias_done = 0;
         for (int l = L - 1; l >= 0; --l) {
             const int out_w = st.cfg.enc_units[l], in_w = st.enc_in[l];
             const float* a_prev = l > 0 ? st.act[l - 1] : st.x;
@@ -741,13 +750,15 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             gw.layout = GEMM_TN; gw.M = in_w; gw.N = out_w; gw.K = N; gw.A = a_prev; gw.lda = ld_prev;
             gw.B = dZ; gw.ldb = lddz; gw.C = m->G(st.encW[l]); gw.ldc = ld_of(out_w); gw.accumulate = 1;
             ADN_TRY(mgemm(m, gw));
-            ADN_TRY(col_sum(dZ, lddz, N, out_w, m->G(st.encb[l]), 1, s));
+            if (!bias_done) ADN_TRY(col_sum(dZ, lddz, N, out_w, m->G(st.encb[l]), 1, s));
+            bias_done = 0;
             if (l > 0) {
                 float* dst = (dZ == m->pingA) ? m->pingB : m->pingA;
                 GemmArgs gx;
                 gx.layout = GEMM_NT; gx.M = N; gx.N = in_w; gx.K = out_w; gx.A = dZ; gx.lda = lddz;
                 gx.B = m->P(st.encW[l]); gx.ldb = ld_of(out_w); gx.C = dst; gx.ldc = m->ping_ld;
                 gx.Y = st.act[l - 1]; gx.ldy = ld_of(in_w); gx.act_grad = st.cfg.enc_act[l - 1];
+                gx.colsum = m->G(st.encb[l - 1]); gx.colsum_done = &bias_done;     // db_{l-1} rides on this GEMM
                 ADN_TRY(mgemm(m, gx));
                 dZ = dst; lddz = m->ping_ld;
             }
