@@ -101,10 +101,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_persistent_kernel(const LstmLaun
     for (int step = 0; step < T; ++step) {
         const int t = P.backwards ? (T - 1 - step) : step;
         const int out_blk = t + (P.backwards ? 0 : 1);
-        // ---- phase 1: every load of the step (A fragments from LDS, masks, input projections)
-        bf16x8 a[KS];
-#pragma unroll
-        for (int s = 0; s < KS; ++s) a[s] = *reinterpret_cast<const bf16x8*>(&hs[cur][i][s * 32 + kq * 8]);
+        // ---- phase 1: masks and input projections of the step
         bool m[4];
         float4 xp[UT][4];
 #pragma unroll
@@ -115,19 +112,22 @@ __global__ __launch_bounds__(512) void lstm_fwd_persistent_kernel(const LstmLaun
             for (int ut = 0; ut < UT; ++ut)
                 xp[ut][r] = *reinterpret_cast<const float4*>(P.xproj + ridx * ldg + min(ubase + 16 * ut + i, H - 1) * 4);
         }
-        // ---- phase 2: recurrent product, 4 gate tiles per unit tile
+        // ---- phase 2: recurrent product; k outermost so that the 4*UT accumulator chains are independent
         f32x4 acc[UT][4];
 #pragma unroll
         for (int ut = 0; ut < UT; ++ut)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const __bf16* wrow = wt + (size_t)(ut * 4 + g) * KS * 512;
-                acc[ut][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < 4; ++g) acc[ut][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+        for (int s = 0; s < KS; ++s) {                // 2 k-steps = 16 fragment loads in flight per wave
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(&hs[cur][i][s * 32 + kq * 8]);
 #pragma unroll
-                for (int s = 0; s < KS; ++s)
+            for (int ut = 0; ut < UT; ++ut)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
                     acc[ut][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        a[s], *reinterpret_cast<const bf16x8*>(wrow + s * 512), acc[ut][g], 0, 0, 0);
-            }
+                        a, *reinterpret_cast<const bf16x8*>(wt + ((size_t)(ut * 4 + g) * KS + s) * 512), acc[ut][g], 0, 0, 0);
+        }
         // ---- phase 3: gate math and stores; lane = (unit, 4 rows)
 #pragma unroll
         for (int ut = 0; ut < UT; ++ut) {
