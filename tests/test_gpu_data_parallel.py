@@ -1,0 +1,60 @@
+"""The N>1 code path on ONE GPU: a single-rank ``nccl`` (= RCCL) process group drives DataParallel exactly as
+bench.py / the runners do for N ranks -- zero-copy torch view of the library's flat gradient buffer, all-reduce
+on it, Adam -- and must reproduce the plain single-process step bit for bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle import adenet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def test_single_rank_nccl_dataparallel_equals_plain_step():
+    import torch
+    import torch.distributed as dist
+    from ip_avsr_amd import _lib
+    from ip_avsr_amd.model import AdeNetModel
+    from ip_avsr_amd.parallel import DataParallel, wrap_flat_buffer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        spec = O.spec_nstream([12, 9, 10], enc_shapes=(14, 6), enc_acts=("rectify", "linear"), lstm_size=10, classes=5,
+                              fusion="concat")
+        rng = np.random.default_rng(5)
+        p = O.init_params(spec, rng, np.float32, enc_std=0.3, perturb=0.1)
+        B, T = 6, 9
+        lens = rng.integers(3, T + 1, size=B); lens[0] = T
+        mask = (np.arange(T)[None, :] < lens[:, None]).astype(np.uint8)
+        xs = [torch.tensor((rng.normal(size=(B, T, s["input_dim"])) * mask[..., None]).astype(np.float32), device="cuda")
+              for s in spec["streams"]]
+        y = torch.tensor(np.repeat(rng.integers(0, 5, size=(B, 1)), T, axis=1).astype(np.int32), device="cuda")
+        m_d = torch.tensor(mask, device="cuda")
+        ref, dpm = AdeNetModel(spec), AdeNetModel(spec)
+        ref.set_params_dict(p); dpm.set_params_dict(p)
+        g = wrap_flat_buffer(dpm)                                  # zero-copy view of the C library's buffer
+        ptr, nbytes = dpm.flat_buffer(_lib.BUF_GRAD)
+        assert g.data_ptr() == ptr and g.numel() * 4 == nbytes and g.dtype == torch.float32
+        dp = DataParallel(dpm)
+        dp.broadcast_parameters(0)
+        total = float(mask.sum())
+        for step in range(3):
+            l_ref = ref.train_step(xs, y, m_d, 2, 1e-3)
+            l_dp = dp.train_step(xs, y, m_d, 2, 1e-3, total, want_loss=True)
+            assert abs(l_dp - float(l_ref)) <= 1e-6 * abs(float(l_ref))
+        a, b = ref.get_all_param_values(), dpm.get_all_param_values()
+        for u, v in zip(a, b):
+            np.testing.assert_array_equal(u, v)
+        ref.close(); dpm.close()
+    finally:
+        dist.destroy_process_group()
