@@ -17,6 +17,7 @@
 // for zero-filling.  Register prefetch of stage s+1 overlaps the MFMAs of stage s.
 #include "gemm_common.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace adn {
 
@@ -25,7 +26,10 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BKH = 64;    // k per LDS stage
+#ifndef ADN_BKH
+#define ADN_BKH 64
+#endif
+constexpr int BKH = ADN_BKH;    // k per LDS stage
 
 __device__ __forceinline__ bf16x4 cvt4(const float4 v) {
     bf16x4 r;
@@ -45,16 +49,17 @@ template <int R>
 struct StageKC<R, float> {
     static constexpr int kStride = BKH + 16;              // bf16 per LDS row (160 B = 40 banks: conflict-free b128 fragment reads)
     static constexpr int kLds = R * kStride;
-    static constexpr int kIter = R / 32;                  // row groups per thread; 2 float4 (8 k) each
+    static constexpr int kCPR = BKH / 8, kRPP = 256 / kCPR; // 8-k chunks per row, rows covered per pass
+    static constexpr int kIter = R / kRPP;                // row groups per thread; 2 float4 (8 k) each
     const float* ptr[kIter];
     float4 v[kIter][2];
     int kc8;                                              // this thread's k offset inside a stage (0,8,..,56)
 
     __device__ __forceinline__ void init(const float* g, int ld, int r0, int rmax, int kbeg, int tid) {
-        kc8 = (tid & 7) * 8;
+        kc8 = (tid % kCPR) * 8;
 #pragma unroll
         for (int i = 0; i < kIter; ++i) {
-            const int row = min(r0 + (tid >> 3) + 32 * i, rmax - 1);      // clamped: feeds dropped outputs only
+            const int row = min(r0 + (tid / kCPR) + kRPP * i, rmax - 1);      // clamped: feeds dropped outputs only
             ptr[i] = g + (size_t)row * ld + kbeg + kc8;
         }
     }
@@ -86,7 +91,7 @@ struct StageKC<R, float> {
     __device__ __forceinline__ void store(__bf16* lds, int tid) const {
 #pragma unroll
         for (int i = 0; i < kIter; ++i) {
-            *reinterpret_cast<bf16x8*>(lds + ((tid >> 3) + 32 * i) * kStride + kc8) =
+            *reinterpret_cast<bf16x8*>(lds + ((tid / kCPR) + kRPP * i) * kStride + kc8) =
                 join(cvt4(v[i][0]), cvt4(v[i][1]));
         }
     }
@@ -101,16 +106,17 @@ template <int R>
 struct StageKC<R, __bf16> {
     static constexpr int kStride = BKH + 16;
     static constexpr int kLds = R * kStride;
-    static constexpr int kIter = R / 32;
+    static constexpr int kCPR = BKH / 8, kRPP = 256 / kCPR;
+    static constexpr int kIter = R / kRPP;
     const __bf16* ptr[kIter];
     bf16x8 v[kIter];
     int kc8;
 
     __device__ __forceinline__ void init(const __bf16* g, int ld, int r0, int rmax, int kbeg, int tid) {
-        kc8 = (tid & 7) * 8;
+        kc8 = (tid % kCPR) * 8;
 #pragma unroll
         for (int i = 0; i < kIter; ++i) {
-            const int row = min(r0 + (tid >> 3) + 32 * i, rmax - 1);
+            const int row = min(r0 + (tid / kCPR) + kRPP * i, rmax - 1);
             ptr[i] = g + (size_t)row * ld + kbeg + kc8;
         }
     }
@@ -140,7 +146,7 @@ struct StageKC<R, __bf16> {
     __device__ __forceinline__ void store(__bf16* lds, int tid) const {
 #pragma unroll
         for (int i = 0; i < kIter; ++i)
-            *reinterpret_cast<bf16x8*>(lds + ((tid >> 3) + 32 * i) * kStride + kc8) = v[i];
+            *reinterpret_cast<bf16x8*>(lds + ((tid / kCPR) + kRPP * i) * kStride + kc8) = v[i];
     }
     __device__ __forceinline__ static bf16x8 frag(const __bf16* lds, int row0, int s, int lane) {
         return *reinterpret_cast<const bf16x8*>(lds + (row0 + (lane & 15)) * kStride + s * 32 + (lane >> 4) * 8);
@@ -292,7 +298,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
     typedef typename StageSel<BN, B_KC, T>::type SB;
     constexpr int WTM = BM / 2, WTN = BN / 2;
     constexpr int TM = WTM / 16, TN = WTN / 16;
-    __shared__ __attribute__((aligned(16))) __bf16 smem[SA::kLds + SB::kLds];
+    constexpr int kEpiElems = 4 * 32 * (WTN + 4) * 2;        // epilogue bounce buffer, in bf16 units
+    constexpr int kSmemElems = (SA::kLds + SB::kLds) > kEpiElems ? (SA::kLds + SB::kLds) : kEpiElems;
+    __shared__ __attribute__((aligned(16))) __bf16 smem[kSmemElems];
     __bf16* As = smem;
     __bf16* Bs = smem + SA::kLds;
 
@@ -357,13 +365,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
     constexpr int LPR = WTN / 4;                      // lanes per row in the read phase
     constexpr int RPI = 64 / LPR;                     // rows per read instruction
     float* wl = reinterpret_cast<float*>(smem) + wave * 32 * LW;
-    static_assert(4 * 32 * LW * 4 <= (SA::kLds + SB::kLds) * 2, "epilogue LDS does not fit");
     const int i16 = lane & 15, kq4 = (lane >> 4) * 4;
     const bool vec_ok = (p.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
                         (!p.Y || (p.ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(p.Y) & 15) == 0));
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);    // column sums of this lane's 4 columns (p.colsum)
-#pragma unroll
-    for (int pass = 0; pass < TM / 2; ++pass) {
+    // (compile-time pass index: a run-time indexed accumulator array would be placed in scratch)
+    auto do_pass = [&](auto pass_c) {
+        constexpr int pass = decltype(pass_c)::value;
         __syncthreads();
 #pragma unroll
         for (int a2 = 0; a2 < 2; ++a2)
@@ -407,7 +415,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
                 }
             }
         }
-    }
+    };
+    do_pass(std::integral_constant<int, 0>{});
+    if constexpr (TM / 2 > 1) do_pass(std::integral_constant<int, 1>{});
+    if constexpr (TM / 2 > 2) do_pass(std::integral_constant<int, 2>{});
+    if constexpr (TM / 2 > 3) do_pass(std::integral_constant<int, 3>{});
+    static_assert(TM / 2 <= 4, "epilogue passes");
     if (p.colsum) {                                   // lanes that differ only in their row share the columns
 #pragma unroll
         for (int o = LPR; o < 64; o <<= 1) {
@@ -431,10 +444,12 @@ static void launch_bf16_t(const GemmParams& p, int layout, dim3 grid, hipStream_
     }
 }
 
-void launch_gemm_bf16(const GemmParams& p, int layout, bool big, dim3 grid, hipStream_t s) {
+void launch_gemm_bf16(const GemmParams& p, int layout, int tile_mode, dim3 grid, hipStream_t s) {
     const bool shadows = p.A16 && p.B16;      // operands already available as bf16 copies
+    const bool big = tile_mode >= 1;
     if (shadows) {
-        if (big) launch_bf16_t<128, 128, __bf16>(p, layout, grid, s);
+        if (tile_mode == 2) launch_bf16_t<256, 128, __bf16>(p, layout, grid, s);
+        else if (big) launch_bf16_t<128, 128, __bf16>(p, layout, grid, s);
         else launch_bf16_t<64, 64, __bf16>(p, layout, grid, s);
     } else {
         if (big) launch_bf16_t<128, 128, float>(p, layout, grid, s);

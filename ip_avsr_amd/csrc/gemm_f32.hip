@@ -14,6 +14,7 @@
 // cycles per SIMD, so one LDS fragment read per MFMA keeps the kernel MFMA-bound.
 #include "gemm_common.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace adn {
 
@@ -185,7 +186,13 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
     // the grid can still fill 256 CUs: either by tile count alone or together with split-K (weight gradients:
     // K = all frames of the batch)
     const bool big = t128 >= 384 || (can_split && t128 >= 24 && g.K >= 2048);
-    const int64_t tiles = big ? t128 : t64;
+    // bf16 with shadow operands: 256x128 tiles (each wave 128x64: 25 % fewer LDS fragment reads and L2 bytes
+    // per MFMA, twice the MFMA work between barriers) when even that coarse grid fills the chip
+    const int64_t t256 = (int64_t)cdiv(g.M, 256) * cdiv(g.N, 128);
+    // (measured: 2x SLOWER than 128x128 at one 4-wave workgroup per CU -- kept behind an opt-in switch)
+    const bool huge = g.precision == ADN_PRECISION_BF16 && p.A16 && p.B16 && getenv("ADN_GEMM_256") &&
+                      (t256 >= 384 || (can_split && t256 >= 24 && g.K >= 2048));
+    const int64_t tiles = huge ? t256 : (big ? t128 : t64);
     int split = 1;
     if (tiles < 384 && g.K >= 512 && can_split) {
         split = (int)((768 + tiles - 1) / tiles);
@@ -208,9 +215,9 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
         if (g.colsum_done) *g.colsum_done = 1;
     }
     const int tsz = big ? 128 : 64;
-    p.tiles_m = cdiv(g.M, tsz); p.tiles_n = cdiv(g.N, tsz);
+    p.tiles_m = cdiv(g.M, huge ? 256 : tsz); p.tiles_n = cdiv(g.N, huge ? 128 : tsz);
     const dim3 grid((unsigned)tiles, split);
-    if (g.precision == ADN_PRECISION_BF16) launch_gemm_bf16(p, g.layout, big, grid, stream);
+    if (g.precision == ADN_PRECISION_BF16) launch_gemm_bf16(p, g.layout, huge ? 2 : (big ? 1 : 0), grid, stream);
     else if (big) launch<128, 128>(p, g.layout, grid, stream);
     else launch<64, 64>(p, g.layout, grid, stream);
     ADN_HIP_CHECK(hipGetLastError());

@@ -45,6 +45,10 @@ def time_it(fn, iters=20):
     return s.elapsed_time(e) / iters
 
 
+ONLY = os.environ.get("GEMM_ONLY")          # e.g. "fwd  NN:1" -> only the 2nd shape named so, shadow variant only
+if ONLY:
+    nm, idx = ONLY.split(":")
+    SHAPES = [[s for s in SHAPES if s[0] == nm][int(idx)]]
 print("%-10s %6s %6s %6s | %9s %9s %9s   (TFLOP/s)" % ("shape", "M", "N", "K", "f32", "bf16-cvt", "bf16-shdw"))
 tot = [0.0, 0.0, 0.0]
 for name, layout, M, N, K in SHAPES:
@@ -61,6 +65,8 @@ for name, layout, M, N, K in SHAPES:
          lambda: lib.adn_op_gemm_ex(layout, M, N, K, dptr(A), ash[1], dptr(Bm), bsh[1], dptr(Cm), pad(N), None, 0, acc, 1, None),
          lambda: lib.adn_op_gemm_shadow(layout, M, N, K, dptr(A), ash[1], dptr(Bm), bsh[1], dptr(Cm), pad(N), dptr(A16),
                                         dptr(B16), dptr(C16) if layout != 2 else None, acc, None)]
+    if ONLY:
+        f = [f[2], f[2], f[2]]
     ms = [time_it(fn) for fn in f]
     fl = 2.0 * M * N * K
     for i in range(3):
