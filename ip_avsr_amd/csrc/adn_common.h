@@ -88,6 +88,9 @@ struct GemmArgs {
     // instead of re-reading it); honoured by the bf16 kernels' coalesced epilogue, non-split launches only --
     // gemm() reports through *colsum_done whether it was.
     float* colsum = nullptr; int* colsum_done = nullptr;
+    // bf16 kernels with shadows only: C may be null when C16 is given (the fp32 copy is simply not written; the
+    // launch is then never split over K), and Y16 may replace Y (bf16 copy of the activation, same ld)
+    const void* Y16 = nullptr;
 };
 int gemm(const GemmArgs& g, hipStream_t stream);
 // dst[i] = bf16(src[i]), n a multiple of 8

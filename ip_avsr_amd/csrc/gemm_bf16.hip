@@ -368,6 +368,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
     const int i16 = lane & 15, kq4 = (lane >> 4) * 4;
     const bool vec_ok = (p.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
                         (!p.Y || (p.ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(p.Y) & 15) == 0));
+    const __bf16* y16 = reinterpret_cast<const __bf16*>(p.Y16);
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);    // column sums of this lane's 4 columns (p.colsum)
     // (compile-time pass index: a run-time indexed accumulator array would be placed in scratch)
     auto do_pass = [&](auto pass_c) {
@@ -392,7 +393,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
                 if (p.bias) { v.x += p.bias[col]; v.y += p.bias[col + 1]; v.z += p.bias[col + 2]; v.w += p.bias[col + 3]; }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) vv[e] = act_apply(p.act, vv[e]);
-                if (p.Y) {
+                if (y16) {
+                    const bf16x4 y = *reinterpret_cast<const bf16x4*>(y16 + (size_t)row * p.ldy + col);
+                    v.x *= act_grad_from_output(p.act_grad, (float)y[0]); v.y *= act_grad_from_output(p.act_grad, (float)y[1]);
+                    v.z *= act_grad_from_output(p.act_grad, (float)y[2]); v.w *= act_grad_from_output(p.act_grad, (float)y[3]);
+                } else if (p.Y) {
                     const float4 y = *reinterpret_cast<const float4*>(p.Y + (size_t)row * p.ldy + col);
                     v.x *= act_grad_from_output(p.act_grad, y.x); v.y *= act_grad_from_output(p.act_grad, y.y);
                     v.z *= act_grad_from_output(p.act_grad, y.z); v.w *= act_grad_from_output(p.act_grad, y.w);
@@ -401,7 +406,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
                     const float4 c = *reinterpret_cast<const float4*>(p.C + off);
                     v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w;
                 }
-                *reinterpret_cast<float4*>(p.C + off) = v;
+                if (p.C) *reinterpret_cast<float4*>(p.C + off) = v;
                 if (p.C16) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.C16) + off) = cvt4(v);
                 csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w;
             } else {

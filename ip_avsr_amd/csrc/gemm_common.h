@@ -14,6 +14,7 @@ struct GemmParams {
     float* C;       int ldc;
     const void* A16; const void* B16; void* C16;   // optional bf16 shadow copies (same ld / offsets)
     float* colsum;                                 // optional: += column sums of the final C (bf16 kernels)
+    const void* Y16;                               // optional bf16 copy of Y (used instead of Y when set)
     const float* bias;
     const float* Y; int ldy;
     int act, act_grad, accumulate, atomic;

@@ -163,7 +163,8 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
     ADN_CHECK(g.layout >= GEMM_NN && g.layout <= GEMM_TN, ADN_ERR_INVALID, "gemm: bad layout");
     if (g.M <= 0 || g.N <= 0) return ADN_OK;
     ADN_CHECK(g.K > 0, ADN_ERR_INVALID, "gemm: K must be positive");
-    ADN_CHECK(g.A && g.B && g.C, ADN_ERR_INVALID, "gemm: null operand");
+    const bool lean_c = !g.C && g.C16 && g.precision == ADN_PRECISION_BF16 && g.A16 && g.B16 && !g.accumulate;
+    ADN_CHECK(g.A && g.B && (g.C || lean_c), ADN_ERR_INVALID, "gemm: null operand");
     ADN_CHECK(g.lda % 4 == 0 && g.ldb % 4 == 0, ADN_ERR_INVALID, "gemm: lda/ldb must be multiples of 4 floats");
     ADN_CHECK(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0, ADN_ERR_INVALID,
               "gemm: A and B must be 16-byte aligned");
@@ -176,6 +177,7 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
     p.bias = g.bias; p.Y = g.Y; p.ldy = g.ldy;
     p.A16 = g.A16; p.B16 = g.B16; p.C16 = g.C16;
     p.colsum = nullptr;
+    p.Y16 = (g.precision == ADN_PRECISION_BF16 && g.A16 && g.B16) ? g.Y16 : nullptr;
     if (g.colsum_done) *g.colsum_done = 0;
     p.act = g.act; p.act_grad = g.act_grad; p.accumulate = g.accumulate;
 
@@ -194,7 +196,7 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
                       (t256 >= 384 || (can_split && t256 >= 24 && g.K >= 2048));
     const int64_t tiles = huge ? t256 : (big ? t128 : t64);
     int split = 1;
-    if (tiles < 384 && g.K >= 512 && can_split) {
+    if (tiles < 384 && g.K >= 512 && can_split && !lean_c) {
         split = (int)((768 + tiles - 1) / tiles);
         split = std::min(split, g.K / 128);
         split = std::max(1, std::min(split, 128));
@@ -209,6 +211,8 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
                    4.0 * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N), stream);
     if (p.atomic && !g.accumulate)
         ADN_HIP_CHECK(hipMemset2DAsync(g.C, (size_t)g.ldc * 4, 0, (size_t)g.N * 4, g.M, stream));
+    if (lean_c) ADN_CHECK(g.ldc % 4 == 0 && g.N % 4 == 0 && ((uintptr_t)g.C16 % 8) == 0, ADN_ERR_INVALID,
+                          "gemm: bf16-only output needs N and ldc to be multiples of 4");
     if (g.colsum && g.precision == ADN_PRECISION_BF16 && !p.atomic && g.ldc % 4 == 0 &&
         ((uintptr_t)g.C % 16) == 0 && (!g.Y || (g.ldy % 4 == 0 && ((uintptr_t)g.Y % 16) == 0)) && g.N % 4 == 0) {
         p.colsum = g.colsum;                  // the vectorised epilogue path is guaranteed for every element

@@ -175,6 +175,7 @@ struct adn_model {
     char* params16 = nullptr;
     bool params16_dirty = true;
     bool bf16() const { return cfg.precision == ADN_PRECISION_BF16; }
+    bool keep_fp32 = false;        // debug: also write the fp32 copies that bf16 mode normally skips
     void* shadow_of(const float* p) const {
         if (!p) return nullptr;
         if (p >= flat[ADN_BUF_PARAM] && p < flat[ADN_BUF_PARAM] + flat_floats)
@@ -433,12 +434,18 @@ int stage_inputs(adn_model* m, const void* const* inputs, const int32_t* targets
     return ADN_OK;
 }
 
-int mgemm(adn_model* m, GemmArgs& g) {
+bool shadows_on(const adn_model* m) { return m->bf16() && !getenv("ADN_BF16_NO_SHADOW"); }
+
+// lean: the fp32 copy of C is not needed by anyone (bf16 mode: every consumer reads the shadow) -> skip writing it
+int mgemm(adn_model* m, GemmArgs& g, bool lean = false) {
     g.precision = m->cfg.precision;
-    if (m->bf16() && !getenv("ADN_BF16_NO_SHADOW")) {     // env switch: convert-in-flight reference path
+    if (shadows_on(m)) {                                  // env switch: convert-in-flight reference path
         g.A16 = m->shadow_of(g.A);
         g.B16 = m->shadow_of(g.B);
         g.C16 = m->shadow_of(g.C);
+        if (g.Y) g.Y16 = m->shadow_of(g.Y);
+        if (lean && g.A16 && g.B16 && g.C16 && !g.accumulate && g.N % 4 == 0 && g.ldc % 4 == 0 && !m->keep_fp32)
+            g.C = nullptr;
     }
     return gemm(g, m->stream);
 }
@@ -541,7 +548,7 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
             g.layout = GEMM_NN; g.M = N; g.N = st.cfg.enc_units[l]; g.K = st.enc_in[l];
             g.A = a; g.lda = lda; g.B = m->P(st.encW[l]); g.ldb = ld_of(g.N);
             g.C = st.act[l]; g.ldc = ld_of(g.N); g.bias = m->P(st.encb[l]); g.act = st.cfg.enc_act[l];
-            ADN_TRY(mgemm(m, g));
+            ADN_TRY(mgemm(m, g, /*lean=*/l + 1 < st.cfg.n_enc));      // the delta layer reads the last one in fp32
             a = st.act[l]; lda = g.ldc;
         }
         ADN_TRY(delta_forward(a, lda, st.feat, ld_of(st.feat_dim), B, T, st.enc_out, theta, st.cfg.use_delta, s));
@@ -759,7 +766,11 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
                 gx.B = m->P(st.encW[l]); gx.ldb = ld_of(out_w); gx.C = dst; gx.ldc = m->ping_ld;
                 gx.Y = st.act[l - 1]; gx.ldy = ld_of(in_w); gx.act_grad = st.cfg.enc_act[l - 1];
                 gx.colsum = m->G(st.encb[l - 1]); gx.colsum_done = &bias_done;     // db_{l-1} rides on this GEMM
-                ADN_TRY(mgemm(m, gx));
+                ADN_TRY(mgemm(m, gx, /*lean=*/true));
+                if (!bias_done && shadows_on(m) && !m->keep_fp32 && in_w % 4 == 0 && m->shadow_of(dst)) {
+                    // fp32 dZ was skipped but the fused column sum did not run: cannot happen for in_w % 4 == 0
+                    set_error("internal: lean dZ without fused bias gradient"); return ADN_ERR_STATE;
+                }
                 dZ = dst; lddz = m->ping_ld;
             }
         }
@@ -1017,8 +1028,20 @@ int adn_read_encoder_activation(adn_model* m, int stream, int layer, float* host
     ADN_CHECK(m->lastB > 0, ADN_ERR_STATE, "no forward pass has been run yet");
     const int u = st.cfg.enc_units[layer];
     ADN_HIP_CHECK(hipStreamSynchronize(m->stream));
-    ADN_HIP_CHECK(hipMemcpy2D(host_dst, (size_t)u * 4, st.act[layer], (size_t)ld_of(u) * 4, (size_t)u * 4,
-                              (size_t)m->lastB * m->lastT, hipMemcpyDeviceToHost));
+    const size_t rows = (size_t)m->lastB * m->lastT;
+    if (shadows_on(m) && layer + 1 < st.cfg.n_enc && m->shadow_of(st.act[layer])) {
+        // bf16 mode keeps only the bf16 copy of intermediate activations: widen it on the host
+        std::vector<uint16_t> tmp(rows * ld_of(u));
+        ADN_HIP_CHECK(hipMemcpy(tmp.data(), m->shadow_of(st.act[layer]), tmp.size() * 2, hipMemcpyDeviceToHost));
+        for (size_t r = 0; r < rows; ++r)
+            for (int c = 0; c < u; ++c) {
+                const uint32_t bits = (uint32_t)tmp[r * ld_of(u) + c] << 16;
+                memcpy(&host_dst[r * u + c], &bits, 4);
+            }
+        return ADN_OK;
+    }
+    ADN_HIP_CHECK(hipMemcpy2D(host_dst, (size_t)u * 4, st.act[layer], (size_t)ld_of(u) * 4, (size_t)u * 4, rows,
+                              hipMemcpyDeviceToHost));
     return ADN_OK;
 }
 

@@ -465,12 +465,21 @@ def test_bf16_shadow_copies_equal_convert_in_flight(torch_cuda, lib):
                 m.close()
             finally:
                 os.environ.pop("ADN_BF16_NO_SHADOW", None)
-        assert out["shadow"][0] == out["inflight"][0], name
-        np.testing.assert_array_equal(out["shadow"][1], out["inflight"][1])
+        # act'(Y) is evaluated on the bf16 copy of Y in shadow mode: exact for piecewise-linear encoders (the sign
+        # of y survives rounding), a bf16-sized difference for sigmoid / tanh ones
+        acts = {a for st in spec["streams"] for a in st["enc_acts"]}
+        exact = acts <= {"rectify", "linear", "leaky_rectify", "very_leaky_rectify"}
+        if exact:
+            assert out["shadow"][0] == out["inflight"][0], name
+            np.testing.assert_array_equal(out["shadow"][1], out["inflight"][1])
+        else:
+            np.testing.assert_allclose(out["shadow"][0], out["inflight"][0], rtol=2e-3)
+            assert np.abs(out["shadow"][1] - out["inflight"][1]).max() < 5e-3
         for k in out["shadow"][2]:
             a, b = out["shadow"][2][k], out["inflight"][2][k]
             # split-K weight gradients use fp32 atomics (order-dependent last bits)
-            assert np.abs(a - b).max() <= 1e-5 * max(np.abs(b).max(), 1e-6), (name, k)
+            tol = 1e-5 if exact else 3e-2
+            assert np.abs(a - b).max() <= tol * max(np.abs(b).max(), 1e-6), (name, k)
 
 
 def wide_spec():
