@@ -206,9 +206,14 @@ def main():
             flops = sum(e["flops"] for e in g); ms = sum(e["ms"] for e in g); n = sum(e["launches"] for e in g)
             ach = flops / (ms * 1e-3) / 1e12 if ms else 0.0
             peak = PEAK_BF16_MFMA_TFLOPS if args.precision == "bf16" else PEAK_F32_MFMA_TFLOPS
+            traffic = None                         # HBM bytes per launch from the committed PMC passes of this build
+            tfile = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_%s.json" % args.precision)
+            if os.path.exists(tfile):
+                traffic = json.load(open(tfile)).get("traffic_bytes_per_launch")
             out["roofline"] = {"kernel": "gemm_%s_kernel (encoder / projection GEMMs, all three layouts)" % args.precision,
                                "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                               "frac": ach / peak, "traffic": None,
+                               "frac": ach / peak, "traffic": traffic,
+                               "algorithmic_flops_per_launch": flops / max(n, 1),
                                "launches_per_step": n / args.steps, "avg_launch_ms": ms / max(n, 1),
                                "share_of_step": ms / (1e3 * prof_elapsed),
                                "measured": "HIP events on the model stream, second pass of %d steps "

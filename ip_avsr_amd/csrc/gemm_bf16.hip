@@ -307,8 +307,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile = xcd_tile(blockIdx.x, gridDim.x);
-    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+    int tile_m, tile_n;
+    tile_coords(p, xcd_tile(blockIdx.x, gridDim.x), tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int kbeg = blockIdx.y * p.k_chunk;
     const int kend = min(p.K, kbeg + p.k_chunk);
 

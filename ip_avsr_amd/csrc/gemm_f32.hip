@@ -14,6 +14,7 @@
 // cycles per SIMD, so one LDS fragment read per MFMA keeps the kernel MFMA-bound.
 #include "gemm_common.h"
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 namespace adn {
@@ -97,8 +98,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int i = lane & 31, h = lane >> 5;
-    const int tile = xcd_tile(blockIdx.x, gridDim.x);
-    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+    int tile_m, tile_n;
+    tile_coords(p, xcd_tile(blockIdx.x, gridDim.x), tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int kbeg = blockIdx.y * p.k_chunk;
     const int kend = min(p.K, kbeg + p.k_chunk);
 
@@ -220,6 +222,11 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
     }
     const int tsz = big ? 128 : 64;
     p.tiles_m = cdiv(g.M, huge ? 256 : tsz); p.tiles_n = cdiv(g.N, huge ? 128 : tsz);
+    {   // square-ish per-XCD tile blocks: panel width ~ sqrt(tiles per XCD)
+        const int chunk = std::max<int64_t>(1, tiles / 8);
+        int bn = (int)std::lround(std::sqrt((double)chunk));
+        p.panel_n = std::max(1, std::min(bn, p.tiles_n));
+    }
     const dim3 grid((unsigned)tiles, split);
     if (g.precision == ADN_PRECISION_BF16) launch_gemm_bf16(p, g.layout, huge ? 2 : (big ? 1 : 0), grid, stream);
     else if (big) launch<128, 128>(p, g.layout, grid, stream);
