@@ -152,6 +152,9 @@ int adn_compute_grads(adn_model* m, const void* const* inputs, const int32_t* ta
 /* <- lasagne.updates.adam (runners/3stream.py:307; formula custom/updates.py:73-99): one step on
  * the current gradient buffer; beta1=.9 beta2=.999 eps=1e-8 */
 int adn_apply_adam(adn_model* m, float learning_rate);
+/* <- custom/updates.py:35-99 adam_vlr: Adam with one learning rate per parameter tensor (index order of
+ * adn_param_info); tensors of one layer must share theirs, as generate_lr_map (custom/updates.py:10-32) gives */
+int adn_apply_adam_vlr(adn_model* m, const float* lr_by_param, int n);
 int adn_adam_step_count(const adn_model* m);
 int adn_set_adam_step_count(adn_model* m, int t);
 

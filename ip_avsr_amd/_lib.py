@@ -70,6 +70,7 @@ _SIGNATURES = {
     "adn_loss": (C.c_int, [_P, C.POINTER(_P), _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "adn_compute_grads": (C.c_int, [_P, C.POINTER(_P), _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _P]),
     "adn_apply_adam": (C.c_int, [_P, C.c_float]),
+    "adn_apply_adam_vlr": (C.c_int, [_P, C.POINTER(C.c_float), C.c_int]),
     "adn_adam_step_count": (C.c_int, [_P]),
     "adn_set_adam_step_count": (C.c_int, [_P, C.c_int]),
     "adn_train_step": (C.c_int, [_P, C.POINTER(_P), _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P]),

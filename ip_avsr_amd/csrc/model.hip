@@ -88,6 +88,7 @@ struct ParamDesc {
     size_t off = 0;       // float offset of the element (0,0) inside the flat buffers
     int ld = 0;           // physical row stride
     int col_stride = 1;   // physical column step (4 for per-gate views of interleaved matrices)
+    size_t phys_begin = 0, phys_end = 0;   // float range of the physical tensor this view lives in
     int64_t numel() const { return dims[0] * dims[1]; }
     int rows() const { return ndim == 2 ? (int)dims[0] : 1; }
     int cols() const { return ndim == 2 ? (int)dims[1] : (ndim == 1 ? (int)dims[0] : 1); }
@@ -200,10 +201,16 @@ namespace {
 struct Builder {
     adn_model* m;
     size_t cursor = 0;
-    size_t alloc(size_t floats) { size_t o = cursor; cursor += (size_t)round_up((int64_t)floats, 8); return o; }
+    std::vector<std::pair<size_t, size_t>> ranges;   // physical tensors handed out so far
+    size_t alloc(size_t floats) {
+        size_t o = cursor; cursor += (size_t)round_up((int64_t)floats, 8);
+        ranges.push_back({o, cursor});
+        return o;
+    }
     void add(const std::string& name, int ndim, int64_t d0, int64_t d1, size_t off, int ld, int col_stride = 1) {
         ParamDesc p;
         p.name = name; p.ndim = ndim; p.dims[0] = d0; p.dims[1] = d1; p.off = off; p.ld = ld; p.col_stride = col_stride;
+        for (auto& r : ranges) if (off >= r.first && off < r.second) { p.phys_begin = r.first; p.phys_end = r.second; }
         if (ndim < 2) p.dims[1] = 1;
         if (ndim < 1) p.dims[0] = 1;
         m->params.push_back(p);
@@ -998,6 +1005,38 @@ int adn_apply_adam(adn_model* m, float learning_rate) {
     const float a_t = learning_rate * sqrtf(1.f - powf(kBeta2, t)) / (1.f - powf(kBeta1, t));
     ADN_TRY(adam_update(m->flat[ADN_BUF_PARAM], m->flat[ADN_BUF_GRAD], m->flat[ADN_BUF_ADAM_M], m->flat[ADN_BUF_ADAM_V],
                         (int64_t)m->flat_floats, a_t, kBeta1, kBeta2, kEps, m->stream));
+    m->grads_valid = false;
+    m->params16_dirty = true;
+    return ADN_OK;
+}
+
+int adn_apply_adam_vlr(adn_model* m, const float* lr_by_param, int n) {
+    ADN_CHECK(m && lr_by_param, ADN_ERR_INVALID, "null argument");
+    ADN_CHECK(n == (int)m->params.size(), ADN_ERR_INVALID, "one learning rate per parameter tensor is required");
+    ADN_CHECK(m->grads_valid, ADN_ERR_STATE, "adn_apply_adam_vlr called without gradients");
+    // views that share a physical tensor (the per-gate matrices of one LSTM) must share their learning rate --
+    // generate_lr_map keys on the LAYER name (custom/updates.py:26-32), so they always do
+    std::vector<std::pair<std::pair<size_t, size_t>, float>> ranges;
+    for (int i = 0; i < n; ++i) {
+        const ParamDesc& p = m->params[i];
+        bool found = false;
+        for (auto& r : ranges)
+            if (r.first.first == p.phys_begin) {
+                ADN_CHECK(r.second == lr_by_param[i], ADN_ERR_INVALID,
+                          "parameters stored in one tensor need one learning rate: " + p.name);
+                found = true;
+            }
+        if (!found) ranges.push_back({{p.phys_begin, p.phys_end}, lr_by_param[i]});
+    }
+    m->adam_t += 1;
+    const float t = (float)m->adam_t;
+    const float scale = sqrtf(1.f - powf(kBeta2, t)) / (1.f - powf(kBeta1, t));
+    for (auto& r : ranges) {
+        const size_t b = r.first.first, e = r.first.second;
+        ADN_TRY(adam_update(m->flat[ADN_BUF_PARAM] + b, m->flat[ADN_BUF_GRAD] + b, m->flat[ADN_BUF_ADAM_M] + b,
+                            m->flat[ADN_BUF_ADAM_V] + b, (int64_t)(e - b), r.second * scale, kBeta1, kBeta2, kEps,
+                            m->stream));
+    }
     m->grads_valid = false;
     m->params16_dirty = true;
     return ADN_OK;

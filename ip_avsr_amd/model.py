@@ -306,6 +306,20 @@ class AdeNetModel(object):
     def apply_adam(self, learning_rate):
         _lib.check(self._lib.adn_apply_adam(self._handle, float(learning_rate)))
 
+    def apply_adam_vlr(self, lr_map, default=None):
+        """Adam with per-layer learning rates: ``lr_map`` maps Param handles or parameter names to rates
+        (what ``custom.updates.generate_lr_map`` returns)."""
+        rates = (C.c_float * len(self.params))()
+        by_name = {(k.name if isinstance(k, Param) else k): float(v) for k, v in lr_map.items()}
+        for i, p in enumerate(self.params):
+            if p.name in by_name:
+                rates[i] = by_name[p.name]
+            elif default is not None:
+                rates[i] = float(default)
+            else:
+                raise KeyError("no learning rate for parameter %s" % p.name)
+        _lib.check(self._lib.adn_apply_adam_vlr(self._handle, rates, len(self.params)))
+
     def train_step(self, inputs, targets, mask, window, learning_rate, want_loss=True):
         """train(...): forward + backward + Adam; returns the cost of this batch before the update."""
         ptrs, mp, tp, B, T, flags, keep = self._prep(inputs, mask, targets)

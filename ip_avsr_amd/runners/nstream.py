@@ -95,6 +95,9 @@ def parse_options(argv=None):
     parser.add_argument('--learning_rate', help='[LEARNING_RATE] learning rate')
     parser.add_argument('--save_best', help='[FILE] save the best model')
     parser.add_argument('--save_plot', help='[FILE_PREFIX] plot the train/validation loss curve')
+    parser.add_argument('--layer_lr', default=None,
+                        help='per-layer Adam learning rates "layer=rate,..." (adam_vlr, reference '
+                             'runners/1stream_variable_lr.py:235-243); other layers use --learning_rate')
     parser.add_argument('--seed', type=int, default=None, help='seed for initialisers and minibatch order '
                                                                '(the reference never seeds; required >1 GPU)')
     args = parser.parse_args(argv)
@@ -105,6 +108,8 @@ def parse_options(argv=None):
     if args.learning_rate:
         options['learning_rate'] = float(args.learning_rate)
     options['seed'] = args.seed
+    if args.layer_lr:
+        options['layer_lr'] = {kv.split('=')[0].strip(): float(kv.split('=')[1]) for kv in args.layer_lr.split(',')}
     return options
 
 
@@ -252,6 +257,10 @@ def main(n_streams, argv=None):
     say('compiling model...')
     order = 'in1,targets,mask,in2,window' if n_streams == 2 else 'inputs,targets,mask,window'
     train, compute_train_cost, compute_test_cost, val_fn = network.compile(learning_rate, order)
+    lr_map = None
+    if 'layer_lr' in options:
+        from ..custom.updates import generate_lr_map
+        lr_map = generate_lr_map(network.get_all_params(trainable=True), options['layer_lr'], learning_rate)
     dp = None
     if world > 1:
         from ..parallel import DataParallel, shard_indices
@@ -303,7 +312,10 @@ def main(n_streams, argv=None):
                 print('Epoch {} batch {}/{}: {} examples using adam with learning rate = {}'.format(
                     epoch + 1, i + 1, epochsize, len(X1), learning_rate), end='')
                 sys.stdout.flush()
-            if dp is None:
+            if lr_map is not None and dp is None:
+                network.compute_grads(Xs, y, m, windowsize, want_loss=False)
+                network.apply_adam_vlr(lr_map)
+            elif dp is None:
                 call(train, Xs, y, m, windowsize)
             else:
                 mine = list(range(len(X1)))[rank::world]

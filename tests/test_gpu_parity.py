@@ -513,3 +513,43 @@ def test_bf16_recurrence_close_to_oracle(torch_cuda, lib, name):
         cos = a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)
         assert cos > 0.99 and abs(np.linalg.norm(b) / np.linalg.norm(a) - 1) < 0.15, (k, cos)
     m.close()
+
+
+def test_adam_with_per_layer_learning_rates(torch_cuda, lib):
+    """custom/updates.py generate_lr_map + adam_vlr: per-layer rates, one step counter."""
+    from ip_avsr_amd.custom.updates import adam_vlr, generate_lr_map
+    from ip_avsr_amd.model import AdeNetModel, AdenetError
+    spec = small_specs()["3stream_adasum_peep"]
+    p, inputs, y, mask = make_case(spec, 5, 7, seed=31)
+    m = AdeNetModel(spec)
+    m.set_params_dict(p)
+    lr_config = {"fc1_s1": 1e-4, "bottleneck_s2": 5e-3, "lstm_s3": 2e-3, "softmax": 0.0}
+    lr_map = generate_lr_map(m.get_all_params(trainable=True), lr_config, 1e-3)
+    step = adam_vlr(m, lr_map)
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    st = O.adam_init(p64)
+    in64 = [x.astype(np.float64) for x in inputs]
+    for it in range(3):
+        _, g, _ = O.loss_and_grads(spec, p64, in64, y, mask, 2)
+        st["t"] += 1
+        t = st["t"]
+        for k in p64:                                           # oracle: the same formula with lr looked up per layer
+            lr = lr_config.get(k[:k.rfind(".")], 1e-3)
+            a_t = lr * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+            st["m"][k] = 0.9 * st["m"][k] + 0.1 * g[k]
+            st["v"][k] = 0.999 * st["v"][k] + 0.001 * g[k] * g[k]
+            p64[k] = p64[k] - a_t * st["m"][k] / (np.sqrt(st["v"][k]) + 1e-8)
+        m.compute_grads(inputs, y, mask, 2)
+        step()
+    got = m.get_params_dict()
+    for k in p64:
+        lr = lr_config.get(k[:k.rfind(".")], 1e-3)
+        assert np.abs(got[k] - p64[k]).max() <= 0.05 * max(lr, 1e-7) + 1e-7, k
+    np.testing.assert_array_equal(got["softmax.W"], p["softmax.W"])            # rate 0: untouched
+    # one LSTM's gates live in one tensor: they cannot get different rates
+    bad = dict(lr_map)
+    bad[[q for q in m.params if q.name == "lstm_s1.W_in_to_cell"][0]] = 0.5
+    m.compute_grads(inputs, y, mask, 2)
+    with pytest.raises(AdenetError):
+        m.apply_adam_vlr(bad)
+    m.close()
