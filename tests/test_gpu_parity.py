@@ -553,3 +553,62 @@ def test_adam_with_per_layer_learning_rates(torch_cuda, lib):
     with pytest.raises(AdenetError):
         m.apply_adam_vlr(bad)
     m.close()
+
+
+def test_four_streams_512_units_config5_shape(torch_cuda, lib):
+    """BASELINE configs[4] topology: adenet_4stream, concat fusion, 512-unit LSTMs (small encoders / batch so
+    that the fp64 oracle stays fast).  f32 mode against the oracle; bf16 mode must track it."""
+    from ip_avsr_amd.model import AdeNetModel
+    spec = O.spec_nstream([40, 36, 44, 30], enc_shapes=(48, 24, 10), enc_acts=("rectify", "rectify", "linear"),
+                          lstm_size=512, classes=10, fusion="concat")
+    B, T, theta = 6, 8, 3
+    p, inputs, y, mask = make_case(spec, B, T, seed=123, enc_std=0.2, perturb=0.02)
+    m = AdeNetModel(spec)
+    m.set_params_dict(p)
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    in64 = [x.astype(np.float64) for x in inputs]
+    probs_ref = O.forward(spec, p64, in64, mask, theta)
+    assert np.abs(m.predict(inputs, mask, theta) - probs_ref).max() <= 5e-5
+    l_ref, g_ref, _ = O.loss_and_grads(spec, p64, in64, y, mask, theta)
+    l = m.compute_grads(inputs, y, mask, theta)
+    assert abs(l - l_ref) <= 1e-5 * abs(l_ref)
+    g = m.get_grads_dict()
+    gscale = max(np.abs(v).max() for v in g_ref.values())
+    for k in O.param_names(spec):
+        assert np.abs(g[k] - g_ref[k]).max() <= 2e-4 * max(np.abs(g_ref[k]).max(), 1e-3 * gscale), k
+    m.set_precision("bf16")
+    assert np.abs(m.predict(inputs, mask, theta) - probs_ref).max() <= 3e-2
+    l16 = m.compute_grads(inputs, y, mask, theta)
+    assert abs(l16 - l_ref) <= 2e-2 * abs(l_ref)
+    m.close()
+
+
+@pytest.mark.parametrize("D,C,B", [(1500, 10, 10), (1144, 10, 10)])
+def test_cuave_oulu_input_widths(torch_cuda, lib, D, C, B):
+    """BASELINE configs[2]/[3] input geometry: CUAVE 30x50 = 1500 (not a multiple of 8), OuluVS 26x44 = 1144;
+    2-stream sum fusion, 10 classes, batch 10."""
+    from ip_avsr_amd.model import AdeNetModel
+    spec = O.spec_nstream([D, 90], fusion="sum", classes=C, has_encoder=[True, False])       # adenet_v2 topology
+    T, theta = 9, 9
+    rng = np.random.default_rng(D)
+    p = O.init_params(spec, rng, np.float32, enc_std=0.01)
+    for k in p:
+        if k.endswith(".b"):
+            p[k] = rng.normal(0, 0.05, p[k].shape).astype(np.float32)
+    mask = ragged_mask(rng, B, T)
+    inputs = [(rng.normal(size=(B, T, d)) * mask[..., None]).astype(np.float32) for d in (D, 90)]
+    y = np.repeat((np.arange(B) % C)[:, None], T, axis=1).astype(np.int32)
+    m = AdeNetModel(spec)
+    m.set_params_dict(p)
+    probs_ref, cache = O.forward(spec, p, inputs, mask, theta, want_cache=True)
+    probs = m.predict(inputs, mask, theta)
+    for l in range(4):
+        assert np.abs(m.encoder_activation(0, l, B, T) - cache["streams"][0]["acts"][l + 1]).max() <= 1e-4
+    assert np.abs(probs - probs_ref).max() <= 1e-4
+    np.testing.assert_array_equal(O.majority_vote(probs, mask), O.majority_vote(probs_ref, mask))
+    for prec in ("f32", "bf16"):                                # both staging paths (D % 8 != 0 -> padded copy)
+        m.set_precision(prec)
+        import torch
+        pd = m.predict([torch.tensor(x, device="cuda") for x in inputs], torch.tensor(mask, device="cuda"), theta)
+        assert np.abs(pd - probs_ref).max() <= (1e-4 if prec == "f32" else 3e-2)
+    m.close()
