@@ -185,6 +185,19 @@ def main():
         elapsed = float(tt.item())
     loss = float(model.loss(xs, y, m_d, THETA))
     assert np.isfinite(loss), "training diverged"
+    # epoch = one pass over the 520 training utterances + what the reference's loop does after it
+    # (runners/3stream.py:372-383): train cost of the last batch, validation cost and majority-vote evaluation on
+    # the 260-utterance held-out split
+    xe, ye, me_d, me = synthetic_batch(torch, rank + 1000, 260, device)
+    fence()
+    t2 = time.perf_counter()
+    model.loss(xs, y, m_d, THETA)
+    model.loss(xe, ye, me_d, THETA)
+    probs = model.predict(xe, me_d, THETA)
+    lens = me.sum(-1)
+    votes = np.stack([np.bincount(probs[i, :lens[i]].argmax(-1), minlength=C) for i in range(len(probs))])
+    _ = votes.argmax(-1)
+    eval_s = time.perf_counter() - t2
 
     if rank == 0:
         seqs = B_PER_GPU * world * args.steps
@@ -198,7 +211,7 @@ def main():
                                    "B=520 utterances x T=40 frames per GPU, fwd+bwd+Adam",
                        "global_batch": B_PER_GPU * world, "frames_per_utterance": T_MAX,
                        "parallelism": "dp%d" % world, "params": model.count_params(),
-                       "epoch_time_s": elapsed / args.steps,
+                       "epoch_time_s": elapsed / args.steps + eval_s, "epoch_eval_s": eval_s,
                        "final_loss": loss},
         }
         if prof:

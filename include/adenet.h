@@ -133,6 +133,15 @@ int64_t adn_total_param_count(const adn_model* m); /* logical elements (17 999 6
  * gradients and the cost together. */
 int adn_flat_buffer(adn_model* m, int buffer /*adn_buffer*/, void** device_ptr, size_t* bytes);
 
+/* Gradient buckets for overlapping the data-parallel all-reduce with back-propagation (new; the reference is
+ * single-device).  Bucket 0 = [fusion | aggregation LSTMs | classifier | cost tail], final before the stream
+ * LSTMs are back-propagated; bucket 1+s = stream s (encoder + LSTM), final when that stream's encoder backward
+ * is enqueued.  adn_compute_grads records the caller's HIP events (one per bucket, on the model's stream) at
+ * those points; a caller makes its communication stream wait on event k and reduces range k while the rest of
+ * the backward pass still runs.  Ranges are in floats inside adn_flat_buffer(ADN_BUF_GRAD). */
+int adn_grad_buckets(const adn_model* m, int max_buckets, int64_t* begin_floats, int64_t* end_floats, int* n_out);
+int adn_set_bucket_events(adn_model* m, void* const* hip_events, int n); /* n = 0 clears */
+
 /* <- val_fn(inputs..., mask, window) -> probabilities (B,T,C)  (runners/3stream.py:320) */
 int adn_forward(adn_model* m, const void* const* inputs, const uint8_t* mask, int B, int T, int theta,
                 int flags, float* probs);

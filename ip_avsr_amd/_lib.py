@@ -66,6 +66,8 @@ _SIGNATURES = {
     "adn_write_tensor": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "adn_total_param_count": (C.c_int64, [_P]),
     "adn_flat_buffer": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "adn_grad_buckets": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "adn_set_bucket_events": (C.c_int, [_P, C.POINTER(_P), C.c_int]),
     "adn_forward": (C.c_int, [_P, C.POINTER(_P), _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "adn_loss": (C.c_int, [_P, C.POINTER(_P), _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "adn_compute_grads": (C.c_int, [_P, C.POINTER(_P), _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _P]),

@@ -131,6 +131,7 @@ struct StreamState {
     float* dfeat = nullptr;
     float* dE = nullptr;
     float* out_ptr = nullptr;
+    size_t param_begin = 0;                    // this stream's parameters start here in the flat buffers
 };
 
 }  // namespace
@@ -152,6 +153,8 @@ struct adn_model {
     std::vector<StreamState> st;
     std::vector<LstmParams> agg;       // 0, 1 or 2
     std::vector<LstmWork> aggw;
+    size_t tail_begin = 0;             // first float of the [fuse | agg | softmax] parameters
+    std::vector<hipEvent_t> bucket_events;   // caller-owned; [0] = tail bucket, [1+s] = stream s (see adn_grad_buckets)
     size_t adacoeff = 0;               // S scalars (one 8-float block)
     size_t smW = 0, smb = 0;
     int fused_dim = 0;
@@ -276,6 +279,7 @@ int build_params(adn_model* m) {
     for (int s = 0; s < m->S; ++s) {
         StreamState& st = m->st[s];
         st.cfg = c.streams[s];
+        st.param_begin = b.cursor;
         const std::string sp = "stream" + std::to_string(s);
         int d = st.cfg.input_dim;
         for (int l = 0; l < st.cfg.n_enc; ++l) {
@@ -292,6 +296,7 @@ int build_params(adn_model* m) {
         for (int k = 0; k < ndir; ++k)
             st.lstm.push_back(b.add_lstm(sp + ".lstm" + std::to_string(k), st.feat_dim, st.cfg.peepholes != 0, k == 1));
     }
+    m->tail_begin = b.cursor;                 // fusion coefficients, aggregation LSTMs, classifier
     if (c.fusion == ADN_FUSE_ADASUM) {
         m->adacoeff = b.alloc(8);
         for (int s = 0; s < m->S; ++s) b.add("fuse.adacoeff" + std::to_string(s), 0, 1, 1, m->adacoeff + s, 1);
@@ -733,6 +738,11 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             st.dout = st.dout_buf;
         }
     }
+    auto bucket_ready = [&](size_t k) -> int {
+        if (k < m->bucket_events.size() && m->bucket_events[k]) ADN_HIP_CHECK(hipEventRecord(m->bucket_events[k], s));
+        return ADN_OK;
+    };
+    ADN_TRY(bucket_ready(0));                 // [fuse | agg | softmax] gradients and the cost share are final
     // stream LSTMs
     {
         std::vector<LstmStep> steps;
@@ -740,12 +750,13 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             for (size_t k = 0; k < st.lstm.size(); ++k) steps.push_back(make_step(m, st.lstm[k], st.lw[k], st.dout, true));
         ADN_TRY(run_lstm_group(m, steps, B, T, true));
     }
-    for (auto& st : m->st) {
+    for (size_t si = 0; si < m->st.size(); ++si) {
+        StreamState& st = m->st[si];
         const int ldf = ld_of(st.feat_dim);
         const float* in[1] = {st.feat}; const int ld[1] = {ldf};
         for (size_t k = 0; k < st.lstm.size(); ++k)
             ADN_TRY(lstm_param_grads(m, st.lstm[k], st.lw[k], in, ld, 1, st.feat_dim, B, T));
-        if (st.cfg.n_enc == 0) continue;                         // nothing trainable below the LSTM
+        if (st.cfg.n_enc == 0) { ADN_TRY(bucket_ready(1 + si)); continue; }   // nothing trainable below the LSTM
         for (size_t k = 0; k < st.lstm.size(); ++k)
             ADN_TRY(lstm_input_grad(m, st.lstm[k], st.lw[k], 0, st.feat_dim, st.dfeat, ldf, N, k > 0));
         const int ldE = ld_of(st.enc_out);
@@ -781,6 +792,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
                 dZ = dst; lddz = m->ping_ld;
             }
         }
+        ADN_TRY(bucket_ready(1 + si));        // every gradient of this stream is final
     }
     m->grads_valid = true;
     return ADN_OK;
@@ -958,6 +970,27 @@ int adn_flat_buffer(adn_model* m, int buffer, void** device_ptr, size_t* bytes) 
     if (buffer == ADN_BUF_PARAM) m->params16_dirty = true;      // the caller may write through the pointer
     *device_ptr = m->flat[buffer];
     *bytes = (m->flat_floats + kAuxFloats) * sizeof(float);
+    return ADN_OK;
+}
+
+int adn_grad_buckets(const adn_model* m, int max_buckets, int64_t* begin_floats, int64_t* end_floats, int* n_out) {
+    ADN_CHECK(m && begin_floats && end_floats && n_out, ADN_ERR_INVALID, "null argument");
+    const int n = 1 + m->S;
+    ADN_CHECK(max_buckets >= n, ADN_ERR_INVALID, "bucket arrays too small");
+    begin_floats[0] = (int64_t)m->tail_begin; end_floats[0] = (int64_t)(m->flat_floats + kAuxFloats);
+    for (int s = 0; s < m->S; ++s) {
+        begin_floats[1 + s] = (int64_t)m->st[s].param_begin;
+        end_floats[1 + s] = (int64_t)(s + 1 < m->S ? m->st[s + 1].param_begin : m->tail_begin);
+    }
+    *n_out = n;
+    return ADN_OK;
+}
+
+int adn_set_bucket_events(adn_model* m, void* const* hip_events, int n) {
+    ADN_CHECK(m, ADN_ERR_INVALID, "null model");
+    ADN_CHECK(n == 0 || (hip_events && n == 1 + m->S), ADN_ERR_INVALID, "expected one event per gradient bucket");
+    m->bucket_events.clear();
+    for (int k = 0; k < n; ++k) m->bucket_events.push_back(static_cast<hipEvent_t>(hip_events[k]));
     return ADN_OK;
 }
 

@@ -223,6 +223,18 @@ class AdeNetModel(object):
         _lib.check(self._lib.adn_flat_buffer(self._handle, which, C.byref(ptr), C.byref(nbytes)))
         return ptr.value, nbytes.value
 
+    def grad_buckets(self):
+        """[(begin, end)] float ranges of the flat gradient buffer in the order they become final during
+        back-propagation: [fusion | aggregation | classifier | cost tail] first, then stream 0, 1, ..."""
+        b = (C.c_int64 * 16)(); e = (C.c_int64 * 16)(); n = C.c_int()
+        _lib.check(self._lib.adn_grad_buckets(self._handle, 16, b, e, C.byref(n)))
+        return [(int(b[k]), int(e[k])) for k in range(n.value)]
+
+    def set_bucket_events(self, raw_events):
+        """Raw hipEvent_t handles (ints), one per bucket, recorded by compute_grads; [] clears."""
+        arr = (C.c_void_p * max(1, len(raw_events)))(*[C.c_void_p(int(h)) for h in raw_events])
+        _lib.check(self._lib.adn_set_bucket_events(self._handle, arr, len(raw_events)))
+
     # ------------------------------------------------------------------ calls
     @staticmethod
     def _is_device(x):

@@ -13,6 +13,8 @@ split's global maximum on every rank (the delta layer is mask-blind, SURVEY App.
 
 The reference has no distributed code at all; this module is new work.
 """
+import os
+
 import numpy as np
 
 from . import _lib
@@ -50,7 +52,7 @@ class DataParallel(object):
     for the device gradient buffer; on a GPU box leave it None.
     """
 
-    def __init__(self, model, process_group=None, grad_tensor=None):
+    def __init__(self, model, process_group=None, grad_tensor=None, overlap=None):
         import torch.distributed as dist
         self.dist = dist
         self.model = model
@@ -58,6 +60,23 @@ class DataParallel(object):
         self.world_size = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
         self.grad = grad_tensor if grad_tensor is not None else wrap_flat_buffer(model)
+        # Overlap (GPU replicas only): the library records one HIP event per gradient bucket as soon as that
+        # bucket is final; a communication stream waits on it and all-reduces the bucket while back-propagation
+        # of the remaining streams is still running.  Only the last stream's bucket is exposed.
+        if overlap is None:
+            overlap = grad_tensor is None and not os.environ.get("ADN_DP_NO_OVERLAP")
+        self.overlap = bool(overlap) and hasattr(model, "grad_buckets")
+        if self.overlap:
+            import torch
+            self._torch = torch
+            self.buckets = model.grad_buckets()
+            self.comm_stream = torch.cuda.Stream()
+            self.events = []
+            for _ in self.buckets:
+                ev = torch.cuda.Event()
+                ev.record()                       # materialises the underlying hipEvent_t
+                self.events.append(ev)
+            model.set_bucket_events([ev.cuda_event for ev in self.events])
 
     def broadcast_parameters(self, src=0):
         """Make every replica start from rank ``src``'s parameters and Adam state."""
@@ -69,7 +88,18 @@ class DataParallel(object):
         global batch.  Returns the GLOBAL cost (a host float) when ``want_loss`` (forces a sync)."""
         self.model.compute_grads(inputs, targets, mask, window, total_frames=float(global_total_frames),
                                  want_loss=False)
-        if self.world_size > 1:
+        if self.overlap:
+            torch = self._torch
+            works = []
+            with torch.cuda.stream(self.comm_stream):
+                for (b, e), ev in zip(self.buckets, self.events):
+                    self.comm_stream.wait_event(ev)      # bucket final on the compute stream
+                    works.append(self.dist.all_reduce(self.grad[b:e], op=self.dist.ReduceOp.SUM, group=self.group,
+                                                      async_op=True))
+            for w in works:
+                w.wait()                                 # the compute stream waits for the reductions
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        elif self.world_size > 1:
             # same stream as the model's kernels (torch's current stream): ordered after the backward pass
             self.dist.all_reduce(self.grad, op=self.dist.ReduceOp.SUM, group=self.group)
         self.model.apply_adam(learning_rate)
