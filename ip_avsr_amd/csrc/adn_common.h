@@ -95,6 +95,8 @@ struct GemmArgs {
 int gemm(const GemmArgs& g, hipStream_t stream);
 // dst[i] = bf16(src[i]), n a multiple of 8
 int to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
+// out[c * ldT + r] = bf16(W[r * ld + c]) for r < rows, c < cols (LDS-tiled transpose)
+int transpose_to_bf16(const float* W, int rows, int cols, int ld, void* out, int ldT, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
 // element-wise / HBM-bound kernels (elementwise.hip)

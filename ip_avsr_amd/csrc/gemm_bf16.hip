@@ -471,6 +471,31 @@ __global__ __launch_bounds__(256) void to_bf16_kernel(const float* __restrict__ 
     }
 }
 
+// bf16 transpose through a padded 32x32 LDS tile: coalesced fp32 reads along c, coalesced bf16 writes along r
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const float* __restrict__ W, int rows, int cols, int ld,
+                                                             __bf16* __restrict__ out, int ldT) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        tile[j][tx] = (r < rows && c < cols) ? W[(size_t)r * ld + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        if (c < cols && r < rows) out[(size_t)c * ldT + r] = (__bf16)tile[tx][j];
+    }
+}
+
+int transpose_to_bf16(const float* W, int rows, int cols, int ld, void* out, int ldT, hipStream_t s) {
+    if (rows <= 0 || cols <= 0) return ADN_OK;
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0, s, W, rows, cols, ld,
+                       reinterpret_cast<__bf16*>(out), ldT);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
 int to_bf16(const float* src, void* dst, size_t n, hipStream_t s) {
     ADN_CHECK(n % 8 == 0, ADN_ERR_INVALID, "to_bf16: element count must be a multiple of 8");
     if (!n) return ADN_OK;

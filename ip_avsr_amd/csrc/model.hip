@@ -178,6 +178,11 @@ struct adn_model {
     std::vector<ShadowRange> shadows;
     char* params16 = nullptr;
     bool params16_dirty = true;
+    // transposed bf16 copies of the weights that input-gradient GEMMs read as "B given [N][K]": with W^T [K][N]
+    // at hand the same product runs through the faster k-strided-B kernel (measured 1.2-1.4x)
+    struct TransW { const float* key; char* buf; int ldT; };
+    std::vector<TransW> transw;
+    char* transw_slab = nullptr;
     bool bf16() const { return cfg.precision == ADN_PRECISION_BF16; }
     bool keep_fp32 = false;        // debug: also write the fp32 copies that bf16 mode normally skips
     void* shadow_of(const float* p) const {
@@ -456,6 +461,9 @@ int mgemm(adn_model* m, GemmArgs& g, bool lean = false) {
         g.B16 = m->shadow_of(g.B);
         g.C16 = m->shadow_of(g.C);
         if (g.Y) g.Y16 = m->shadow_of(g.Y);
+        if (g.layout == GEMM_NT && g.A16 && !getenv("ADN_NO_TRANSW"))
+            for (const auto& t : m->transw)
+                if (t.key == g.B) { g.layout = GEMM_NN; g.B16 = t.buf; g.ldb = t.ldT; break; }
         if (lean && g.A16 && g.B16 && g.C16 && !g.accumulate && g.N % 4 == 0 && g.ldc % 4 == 0 && !m->keep_fp32)
             g.C = nullptr;
     }
@@ -468,6 +476,38 @@ int refresh(adn_model* m, const float* p, size_t floats) {
     void* sh = m->shadow_of(p);
     if (!sh) return ADN_OK;
     return to_bf16(p, sh, (size_t)round_up((int64_t)floats, 8), m->stream);
+}
+
+// W^T copies: encoder weights of layers >= 1, every LSTM's W_in (per input block), the classifier weights
+int refresh_transposed(adn_model* m) {
+    struct Item { const float* W; int rows, cols, ld; };
+    std::vector<Item> items;
+    for (auto& st : m->st) {
+        for (int l = 1; l < st.cfg.n_enc; ++l)
+            items.push_back({m->P(st.encW[l]), st.enc_in[l], st.cfg.enc_units[l], ld_of(st.cfg.enc_units[l])});
+        if (st.cfg.n_enc > 0)
+            for (auto& lp : st.lstm) items.push_back({m->P(lp.W_in), lp.fin, 4 * m->H, m->ldg});
+    }
+    const int nblk = (m->cfg.fusion == ADN_FUSE_CONCAT) ? m->S : 1;
+    for (auto& lp : m->agg)
+        for (int j = 0; j < nblk; ++j)
+            items.push_back({m->P(lp.W_in) + (size_t)j * m->H * m->ldg, m->H, 4 * m->H, m->ldg});
+    items.push_back({m->P(m->smW), m->H, m->C, m->ldc});
+    if (m->transw.empty()) {
+        size_t bytes = 0;
+        for (auto& it : items) bytes += (size_t)round_up((int64_t)it.cols * ld_of(it.rows) * 2, 256);
+        ADN_HIP_CHECK(hipMalloc((void**)&m->transw_slab, bytes));
+        ADN_HIP_CHECK(hipMemsetAsync(m->transw_slab, 0, bytes, m->stream));
+        size_t cur = 0;
+        for (auto& it : items) {
+            m->transw.push_back({it.W, m->transw_slab + cur, ld_of(it.rows)});
+            cur += (size_t)round_up((int64_t)it.cols * ld_of(it.rows) * 2, 256);
+        }
+    }
+    for (size_t k = 0; k < items.size(); ++k)
+        ADN_TRY(transpose_to_bf16(items[k].W, items[k].rows, items[k].cols, items[k].ld, m->transw[k].buf, m->transw[k].ldT,
+                                  m->stream));
+    return ADN_OK;
 }
 
 int refresh_params(adn_model* m) {
@@ -491,6 +531,7 @@ int refresh_params(adn_model* m) {
     };
     for (auto& st : m->st) for (auto& lp : st.lstm) ADN_TRY(pack(lp));
     for (auto& lp : m->agg) ADN_TRY(pack(lp));
+    ADN_TRY(refresh_transposed(m));
     m->params16_dirty = false;
     return ADN_OK;
 }
@@ -914,6 +955,7 @@ void adn_destroy(adn_model* m) {
     if (g_prof == &m->prof) g_prof = nullptr;
     for (int k = 0; k < 4; ++k) if (m->flat[k]) (void)hipFree(m->flat[k]);
     if (m->params16) (void)hipFree(m->params16);
+    if (m->transw_slab) (void)hipFree(m->transw_slab);
     auto free_lp = [](LstmParams& lp) {
         if (lp.whid16t) (void)hipFree(lp.whid16t);
         if (lp.wfrag_fwd) (void)hipFree(lp.wfrag_fwd);

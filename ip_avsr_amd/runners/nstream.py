@@ -329,8 +329,9 @@ def main(n_streams, argv=None):
         train_strip[epoch % STRIP_SIZE] = cost
         val_window.push(val_cost)
         gl = 100 * (cost_val[-1] / np.min(cost_val) - 1)
-        pk = 1000 * (np.sum(train_strip) / (STRIP_SIZE * np.min(train_strip)) - 1)
-        pq = gl / pk
+        with np.errstate(divide='ignore', invalid='ignore'):    # the strip holds zeros until STRIP_SIZE epochs ran
+            pk = 1000 * (np.sum(train_strip) / (STRIP_SIZE * np.min(train_strip)) - 1)
+            pq = gl / pk
         cr, val_conf = evaluate_model2(X_val, y_val_evaluate, mask_val, windowsize, eval_fn)
         class_rate.append(cr)
         if val_cost < best_val:
