@@ -433,10 +433,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
             csum.x += __shfl_xor(csum.x, o, 64); csum.y += __shfl_xor(csum.y, o, 64);
             csum.z += __shfl_xor(csum.z, o, 64); csum.w += __shfl_xor(csum.w, o, 64);
         }
-        const int col = n0 + wn * WTN + (lane % LPR) * 4;
-        if (lane < LPR && col + 3 < p.N) {
-            atomicAdd(p.colsum + col, csum.x); atomicAdd(p.colsum + col + 1, csum.y);
-            atomicAdd(p.colsum + col + 2, csum.z); atomicAdd(p.colsum + col + 3, csum.w);
+        // the two waves stacked in m combine through LDS; one plain float4 store per 4 columns and tile
+        float4* cs = reinterpret_cast<float4*>(smem);
+        __syncthreads();
+        if (wm == 1 && lane < LPR) cs[wn * LPR + lane] = csum;
+        __syncthreads();
+        const int col = n0 + wn * WTN + lane * 4;
+        if (wm == 0 && lane < LPR && col + 3 < p.N) {
+            const float4 o = cs[wn * LPR + lane];
+            csum.x += o.x; csum.y += o.y; csum.z += o.z; csum.w += o.w;
+            *reinterpret_cast<float4*>(p.colsum + (size_t)tile_m * p.colsum_ld + col) = csum;
         }
     }
 }

@@ -13,7 +13,7 @@ struct GemmParams {
     const float* B; int ldb;
     float* C;       int ldc;
     const void* A16; const void* B16; void* C16;   // optional bf16 shadow copies (same ld / offsets)
-    float* colsum;                                 // optional: += column sums of the final C (bf16 kernels)
+    float* colsum; int colsum_ld;                  // optional: per-m-tile column sums of the final C, [tiles_m][colsum_ld]
     const void* Y16;                               // optional bf16 copy of Y (used instead of Y when set)
     const float* bias;
     const float* Y; int ldy;

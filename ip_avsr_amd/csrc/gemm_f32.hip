@@ -13,6 +13,7 @@
 // transposing stores are needed for any of the three layouts.  The f32 MFMA issues once per 64
 // cycles per SIMD, so one LDS fragment read per MFMA keeps the kernel MFMA-bound.
 #include "gemm_common.h"
+#include <cstdio>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -178,7 +179,7 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
     p.A = g.A; p.lda = g.lda; p.B = g.B; p.ldb = g.ldb; p.C = g.C; p.ldc = g.ldc;
     p.bias = g.bias; p.Y = g.Y; p.ldy = g.ldy;
     p.A16 = g.A16; p.B16 = g.B16; p.C16 = g.C16;
-    p.colsum = nullptr;
+    p.colsum = nullptr; p.colsum_ld = 0;
     p.Y16 = (g.precision == ADN_PRECISION_BF16 && g.A16 && g.B16) ? g.Y16 : nullptr;
     if (g.colsum_done) *g.colsum_done = 0;
     p.act = g.act; p.act_grad = g.act_grad; p.accumulate = g.accumulate;
@@ -189,7 +190,11 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
     // 128x128 tiles (4 MFMA tiles per wave, half the LDS fragment reads per MFMA of the 64x64 shape) whenever
     // the grid can still fill 256 CUs: either by tile count alone or together with split-K (weight gradients:
     // K = all frames of the batch)
-    const bool big = t128 >= 384 || (can_split && t128 >= 24 && g.K >= 2048);
+    static const int force_tile = getenv("ADN_GEMM_TILE") ? atoi(getenv("ADN_GEMM_TILE")) : 0;   // experiments only
+    // ... and K is deep enough to amortise a 128x128 tile's prologue + epilogue latency (3 workgroups per CU
+    // cannot hide it: at K <= 512 the 64x64 shape, 8 workgroups per CU, is 1.3-2.2x faster; equal at K = 1024)
+    const bool big = force_tile ? force_tile == 128
+                                : (g.K >= 768 && (t128 >= 384 || (can_split && t128 >= 24 && g.K >= 2048)));
     // bf16 with shadow operands: 256x128 tiles (each wave 128x64: 25 % fewer LDS fragment reads and L2 bytes
     // per MFMA, twice the MFMA work between barriers) when even that coarse grid fills the chip
     const int64_t t256 = (int64_t)cdiv(g.M, 256) * cdiv(g.N, 128);
@@ -215,23 +220,31 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
         ADN_HIP_CHECK(hipMemset2DAsync(g.C, (size_t)g.ldc * 4, 0, (size_t)g.N * 4, g.M, stream));
     if (lean_c) ADN_CHECK(g.ldc % 4 == 0 && g.N % 4 == 0 && ((uintptr_t)g.C16 % 8) == 0, ADN_ERR_INVALID,
                           "gemm: bf16-only output needs N and ldc to be multiples of 4");
-    if (g.colsum && g.precision == ADN_PRECISION_BF16 && !p.atomic && g.ldc % 4 == 0 &&
-        ((uintptr_t)g.C % 16) == 0 && (!g.Y || (g.ldy % 4 == 0 && ((uintptr_t)g.Y % 16) == 0)) && g.N % 4 == 0) {
-        p.colsum = g.colsum;                  // the vectorised epilogue path is guaranteed for every element
-        if (g.colsum_done) *g.colsum_done = 1;
-    }
     const int tsz = big ? 128 : 64;
     p.tiles_m = cdiv(g.M, huge ? 256 : tsz); p.tiles_n = cdiv(g.N, huge ? 128 : tsz);
+    const int cs_ld = (int)round_up(g.N, 4);
+    if (g.colsum && g.precision == ADN_PRECISION_BF16 && !p.atomic && g.ldc % 4 == 0 &&
+        ((uintptr_t)g.C % 16) == 0 && (!g.Y || (g.ldy % 4 == 0 && ((uintptr_t)g.Y % 16) == 0)) && g.N % 4 == 0 &&
+        g.colsum_ws && ((uintptr_t)g.colsum_ws % 16) == 0 && (size_t)p.tiles_m * cs_ld <= g.colsum_ws_floats) {
+        p.colsum = g.colsum_ws; p.colsum_ld = cs_ld;   // the vectorised epilogue path is guaranteed for every element
+        if (g.colsum_done) *g.colsum_done = 1;
+    }
     {   // square-ish per-XCD tile blocks: panel width ~ sqrt(tiles per XCD)
         const int chunk = std::max<int64_t>(1, tiles / 8);
         int bn = (int)std::lround(std::sqrt((double)chunk));
         p.panel_n = std::max(1, std::min(bn, p.tiles_n));
     }
     const dim3 grid((unsigned)tiles, split);
+    static const bool trace = getenv("ADN_GEMM_TRACE") != nullptr;       // one line per launch, pairs with a kernel trace
+    if (trace)
+        fprintf(stderr, "ADN_GEMM %s M=%d N=%d K=%d tile=%d tiles=%lld split=%d shadows=%d lean=%d acc=%d\n",
+                g.layout == GEMM_NN ? "NN" : (g.layout == GEMM_NT ? "NT" : "TN"), g.M, g.N, g.K, huge ? 256 : tsz,
+                (long long)tiles, split, (int)(p.A16 && p.B16), (int)lean_c, g.accumulate);
     if (g.precision == ADN_PRECISION_BF16) launch_gemm_bf16(p, g.layout, huge ? 2 : (big ? 1 : 0), grid, stream);
     else if (big) launch<128, 128>(p, g.layout, grid, stream);
     else launch<64, 64>(p, g.layout, grid, stream);
     ADN_HIP_CHECK(hipGetLastError());
+    if (p.colsum) ADN_TRY(col_sum(p.colsum, p.colsum_ld, p.tiles_m, g.N, g.colsum, 1, stream));
     if (g.C16 && p.atomic) {                  // split-K result: refresh the bf16 shadow of whole rows
         ADN_CHECK(g.ldc % 8 == 0, ADN_ERR_INVALID, "gemm: bf16 shadow of C needs ldc % 8 == 0");
         ADN_TRY(to_bf16(g.C, g.C16, (size_t)g.M * g.ldc, stream));

@@ -171,6 +171,7 @@ struct adn_model {
     float *z = nullptr, *dz = nullptr, *cls_in = nullptr, *dcls = nullptr, *fused = nullptr, *dfused = nullptr;
     float *pingA = nullptr, *pingB = nullptr;
     int ping_ld = 0;
+    float* colsum_ws = nullptr; size_t colsum_ws_floats = 0;   // per-m-tile column sums of the fused bias gradients
     int lastB = 0, lastT = 0;
     Profiler prof;
     // bf16 shadow copies of every GEMM operand (bf16 mode): fp32 range -> bf16 buffer with the same layout
@@ -391,6 +392,8 @@ size_t carve(adn_model* m, char* base, int B, int T, bool host_inputs) {
     m->ping_ld = maxw;
     m->pingA = take_shadowed(m, cv, N * maxw);
     m->pingB = take_shadowed(m, cv, N * maxw);
+    m->colsum_ws_floats = (size_t)cdiv((int)N, 64) * maxw;
+    m->colsum_ws = cv.take<float>(m->colsum_ws_floats);
     (void)host_inputs;
     return cv.cursor;
 }
@@ -825,6 +828,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
                 gx.B = m->P(st.encW[l]); gx.ldb = ld_of(out_w); gx.C = dst; gx.ldc = m->ping_ld;
                 gx.Y = st.act[l - 1]; gx.ldy = ld_of(in_w); gx.act_grad = st.cfg.enc_act[l - 1];
                 gx.colsum = m->G(st.encb[l - 1]); gx.colsum_done = &bias_done;     // db_{l-1} rides on this GEMM
+                gx.colsum_ws = m->colsum_ws; gx.colsum_ws_floats = m->colsum_ws_floats;
                 ADN_TRY(mgemm(m, gx, /*lean=*/true));
                 if (!bias_done && shadows_on(m) && !m->keep_fp32 && in_w % 4 == 0 && m->shadow_of(dst)) {
                     // fp32 dZ was skipped but the fused column sum did not run: cannot happen for in_w % 4 == 0
