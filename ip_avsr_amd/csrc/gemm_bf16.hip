@@ -42,14 +42,14 @@ __device__ __forceinline__ bf16x8 join(const bf16x4 lo, const bf16x4 hi) {
 }
 
 // ---- k-contiguous operand: global [R][K] fp32 -------------------------------------------------------
-template <int R, typename T>
+template <int R, typename T, int NT>
 struct StageKC;
 
-template <int R>
-struct StageKC<R, float> {
+template <int R, int NT>
+struct StageKC<R, float, NT> {
     static constexpr int kStride = BKH + 16;              // bf16 per LDS row (160 B = 40 banks: conflict-free b128 fragment reads)
     static constexpr int kLds = R * kStride;
-    static constexpr int kCPR = BKH / 8, kRPP = 256 / kCPR; // 8-k chunks per row, rows covered per pass
+    static constexpr int kCPR = BKH / 8, kRPP = NT / kCPR; // 8-k chunks per row, rows covered per pass
     static constexpr int kIter = R / kRPP;                // row groups per thread; 2 float4 (8 k) each
     const float* ptr[kIter];
     float4 v[kIter][2];
@@ -102,11 +102,11 @@ struct StageKC<R, float> {
 };
 
 // ---- k-contiguous operand already in bf16 (shadow copy): one 16-byte load = 8 k ---------------------
-template <int R>
-struct StageKC<R, __bf16> {
+template <int R, int NT>
+struct StageKC<R, __bf16, NT> {
     static constexpr int kStride = BKH + 16;
     static constexpr int kLds = R * kStride;
-    static constexpr int kCPR = BKH / 8, kRPP = 256 / kCPR;
+    static constexpr int kCPR = BKH / 8, kRPP = NT / kCPR;
     static constexpr int kIter = R / kRPP;
     const __bf16* ptr[kIter];
     bf16x8 v[kIter];
@@ -169,15 +169,15 @@ __device__ __forceinline__ bf16x8 frag_tr(const __bf16* lds, int col0, int s, in
 }
 
 // ---- k-strided operand: global [K][R] fp32 ----------------------------------------------------------
-template <int R, typename T>
+template <int R, typename T, int NT>
 struct StageKS;
 
-template <int R>
-struct StageKS<R, float> {
+template <int R, int NT>
+struct StageKS<R, float, NT> {
     static constexpr int kStride = R + 16;                // bf16 per LDS k-row
     static constexpr int kLds = BKH * kStride;
     static constexpr int kVecRow = R / 4;                 // float4 per k-row
-    static constexpr int kRowsPerPass = 256 / kVecRow;    // k-rows covered by the 256 threads at once
+    static constexpr int kRowsPerPass = NT / kVecRow;     // k-rows covered by the NT threads at once
     static constexpr int kIter = BKH / kRowsPerPass;
     const float* ptr;
     size_t step;                                          // floats between this thread's consecutive k-rows
@@ -217,12 +217,12 @@ struct StageKS<R, float> {
 };
 
 // ---- k-strided operand already in bf16: one 16-byte load = 8 columns of one k-row -------------------
-template <int R>
-struct StageKS<R, __bf16> {
+template <int R, int NT>
+struct StageKS<R, __bf16, NT> {
     static constexpr int kStride = R + 16;
     static constexpr int kLds = BKH * kStride;
     static constexpr int kVecRow = R / 8;                 // 16-byte chunks per k-row
-    static constexpr int kRowsPerPass = 256 / kVecRow;
+    static constexpr int kRowsPerPass = NT / kVecRow;
     static constexpr int kIter = BKH / kRowsPerPass;
     const __bf16* ptr;
     size_t step;
@@ -264,8 +264,8 @@ struct StageKS<R, __bf16> {
     }
 };
 
-template <int R, bool KC, typename T> struct StageSel { typedef StageKC<R, T> type; };
-template <int R, typename T> struct StageSel<R, false, T> { typedef StageKS<R, T> type; };
+template <int R, bool KC, typename T, int NT> struct StageSel { typedef StageKC<R, T, NT> type; };
+template <int R, typename T, int NT> struct StageSel<R, false, T, NT> { typedef StageKS<R, T, NT> type; };
 
 // epilogue for one 16x16 accumulator tile: col = lane&15, row = 4*(lane>>4) + reg
 __device__ __forceinline__ void store_tile16(const GemmParams& p, const f32x4& acc, int row0, int col0, int lane,
@@ -292,13 +292,172 @@ __device__ __forceinline__ void store_tile16(const GemmParams& p, const f32x4& a
     }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, typename T>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
-    typedef typename StageSel<BM, A_KC, T>::type SA;
-    typedef typename StageSel<BN, B_KC, T>::type SB;
-    constexpr int WTM = BM / 2, WTN = BN / 2;
+// ---------------------------------------------------------------------------------------------------------
+// Epilogue shared by every bf16 kernel.
+//
+// A wave holds a (16 TM) x (16 TN) block of the tile in 16x16 accumulators (col = lane&15, row = 4 (lane>>4) + reg).
+// One 16-row slice at a time is bounced through a wave-PRIVATE LDS strip (no workgroup barrier in here), after which
+// a lane owns 4 consecutive columns of a row: bias / activation / act'(Y) / accumulate run on float4, C is written
+// with 16-byte stores and the bf16 shadow with 8-byte stores.  (Per-lane scalar stores of the raw MFMA layout touch
+// 4 rows x 64 B per instruction and made the store tail as long as the main loop for N ~ K.)
+//
+// The per-element work is specialised at compile time on (activation, act'(Y) form) for the combinations the
+// training step uses -- linear / rectify output, rectify gradient from the bf16 copy of Y -- and selected ONCE per
+// tile; the generic form with run-time switches stays as the fallback.  With the switches inside the element loop
+// the epilogue was ~40k instructions of mostly skipped code per kernel and cost 10-15 us per tile (instruction
+// fetch + scalar branches), more than the K-loop of a K <= 512 tile.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int EPI_RUNTIME = -1;
+
+template <int ACT, int YM>          // ACT: 0 linear, 1 rectify, -1 run-time; YM: 0 none, 1 rectify' from Y16, -1 run-time
+__device__ __forceinline__ void epi_vec4(const GemmParams& p, float4 v, const float4& bias4, int row, int col, float4& csum) {
+    const size_t off = (size_t)row * p.ldc + col;
+    v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+    if (ACT == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    else if (ACT == EPI_RUNTIME) {
+        v.x = act_apply(p.act, v.x); v.y = act_apply(p.act, v.y); v.z = act_apply(p.act, v.z); v.w = act_apply(p.act, v.w);
+    }
+    if (YM == 1) {
+        const bf16x4 y = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p.Y16) + (size_t)row * p.ldy + col);
+        v.x = (float)y[0] > 0.f ? v.x : 0.f; v.y = (float)y[1] > 0.f ? v.y : 0.f;
+        v.z = (float)y[2] > 0.f ? v.z : 0.f; v.w = (float)y[3] > 0.f ? v.w : 0.f;
+    } else if (YM == EPI_RUNTIME) {
+        if (p.Y16) {
+            const bf16x4 y = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(p.Y16) + (size_t)row * p.ldy + col);
+            v.x *= act_grad_from_output(p.act_grad, (float)y[0]); v.y *= act_grad_from_output(p.act_grad, (float)y[1]);
+            v.z *= act_grad_from_output(p.act_grad, (float)y[2]); v.w *= act_grad_from_output(p.act_grad, (float)y[3]);
+        } else if (p.Y) {
+            const float4 y = *reinterpret_cast<const float4*>(p.Y + (size_t)row * p.ldy + col);
+            v.x *= act_grad_from_output(p.act_grad, y.x); v.y *= act_grad_from_output(p.act_grad, y.y);
+            v.z *= act_grad_from_output(p.act_grad, y.z); v.w *= act_grad_from_output(p.act_grad, y.w);
+        }
+    }
+    if (p.accumulate) {
+        const float4 c = *reinterpret_cast<const float4*>(p.C + off);
+        v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w;
+    }
+    if (p.C) *reinterpret_cast<float4*>(p.C + off) = v;
+    if (p.C16) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.C16) + off) = cvt4(v);
+    csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w;
+}
+
+// element-wise fallback for rows that cannot be vectorised (unaligned C / Y, N % 4 != 0 edge)
+__device__ __forceinline__ void epi_scalar(const GemmParams& p, const float* vv, int row, int col) {
+    const size_t off = (size_t)row * p.ldc + col;
+    for (int e = 0; e < 4 && col + e < p.N; ++e) {
+        float x = vv[e] + (p.bias ? p.bias[col + e] : 0.f);
+        x = act_apply(p.act, x);
+        if (p.Y) x *= act_grad_from_output(p.act_grad, p.Y[(size_t)row * p.ldy + col + e]);
+        if (p.accumulate) x += p.C[off + e];
+        p.C[off + e] = x;
+        if (p.C16) reinterpret_cast<__bf16*>(p.C16)[off + e] = (__bf16)x;
+    }
+}
+
+// strip: 16 rows x (16 TN + 4) floats of LDS private to the calling wave; (row_base, col_base): the wave's block.
+// csum accumulates this lane's 4 column sums (fused bias gradients).
+template <int TM, int TN>
+__device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[TM][TN], float* strip, int row_base,
+                                              int col_base, int lane, float4& csum) {
+    constexpr int LW = TN * 16 + 4;                   // floats per strip row (16-byte aligned, bank-staggered)
+    constexpr int LPR = TN * 4;                       // lanes per row in the read phase (4 columns each)
+    constexpr int RPI = 64 / LPR;                     // rows per read instruction
+    const int i16 = lane & 15, kq4 = (lane >> 4) * 4;
+    const int lc = (lane % LPR) * 4, col = col_base + lc;
+    const bool vec_all = (p.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) && (p.N % 4 == 0) &&
+                         (!p.Y || (p.ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(p.Y) & 15) == 0));
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && col + 3 < p.N) bias4 = *reinterpret_cast<const float4*>(p.bias + col);   // bias rows are 16-byte aligned
+    auto run = [&](auto act_c, auto ym_c) {
+        constexpr int ACT = decltype(act_c)::value, YM = decltype(ym_c)::value;
+        auto slice = [&](auto a_c) {
+            constexpr int a = decltype(a_c)::value;
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) strip[(kq4 + r) * LW + b * 16 + i16] = acc[a][b][r];
+#pragma unroll
+            for (int j = 0; j < 16 / RPI; ++j) {
+                const int lr = j * RPI + lane / LPR;
+                const int row = row_base + a * 16 + lr;
+                if (row >= p.M || col >= p.N) continue;
+                const float4 v = *reinterpret_cast<const float4*>(strip + lr * LW + lc);
+                if (ACT != EPI_RUNTIME || (vec_all && col + 3 < p.N)) epi_vec4<ACT, YM>(p, v, bias4, row, col, csum);
+                else epi_scalar(p, reinterpret_cast<const float*>(&v), row, col);
+            }
+        };
+        slice(std::integral_constant<int, 0>{});
+        if constexpr (TM > 1) slice(std::integral_constant<int, 1>{});
+        if constexpr (TM > 2) slice(std::integral_constant<int, 2>{});
+        if constexpr (TM > 3) slice(std::integral_constant<int, 3>{});
+        if constexpr (TM > 4) slice(std::integral_constant<int, 4>{});
+        if constexpr (TM > 5) slice(std::integral_constant<int, 5>{});
+        if constexpr (TM > 6) slice(std::integral_constant<int, 6>{});
+        if constexpr (TM > 7) slice(std::integral_constant<int, 7>{});
+        static_assert(TM <= 8, "tile_epilogue: at most 8 accumulator rows");
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, EPI_RUNTIME> IR;
+    const bool y_none = (!p.Y && !p.Y16) || p.act_grad == ADN_ACT_LINEAR;
+    const bool y_relu16 = p.Y16 && p.act_grad == ADN_ACT_RECTIFY;
+    if (vec_all && p.act == ADN_ACT_LINEAR && y_none) run(I0{}, I0{});
+    else if (vec_all && p.act == ADN_ACT_RECTIFY && y_none) run(I1{}, I0{});
+    else if (vec_all && p.act == ADN_ACT_LINEAR && y_relu16) run(I0{}, I1{});
+    else run(IR{}, IR{});
+}
+
+// non-persistent kernels: WM x 2 waves; strips at the start of the (now free) LDS array; the waves stacked in m
+// combine their column sums through LDS behind the strips
+template <int WM, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[TM][TN], __bf16* smem, int m0, int n0,
+                                              int tile_m, int wave, int lane) {
+    constexpr int WTM = TM * 16, WTN = TN * 16;
+    constexpr int LPR = TN * 4;
+    constexpr int kStrip = 16 * (WTN + 4);            // floats per wave
+    const int wm = wave >> 1, wn = wave & 1;
+    if (p.atomic) {                                   // split-K: fp32 atomics straight from the accumulators
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+                store_tile16(p, acc[a][b], m0 + wm * WTM + a * 16, n0 + wn * WTN + b * 16, lane, blockIdx.y == 0);
+        return;
+    }
+    __syncthreads();                                  // every wave is done with the operand images
+    float* strips = reinterpret_cast<float*>(smem);
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    tile_epilogue<TM, TN>(p, acc, strips + wave * kStrip, m0 + wm * WTM, n0 + wn * WTN, lane, csum);
+    if (p.colsum) {                                   // lanes that differ only in their row share the columns
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) {
+            csum.x += __shfl_xor(csum.x, o, 64); csum.y += __shfl_xor(csum.y, o, 64);
+            csum.z += __shfl_xor(csum.z, o, 64); csum.w += __shfl_xor(csum.w, o, 64);
+        }
+        float4* cs = reinterpret_cast<float4*>(strips + WM * 2 * kStrip);
+        if (wm > 0 && lane < LPR) cs[((wm - 1) * 2 + wn) * LPR + lane] = csum;
+        __syncthreads();
+        const int col = n0 + wn * WTN + lane * 4;
+        if (wm == 0 && lane < LPR && col + 3 < p.N) {
+#pragma unroll
+            for (int w = 1; w < WM; ++w) {
+                const float4 o = cs[((w - 1) * 2 + wn) * LPR + lane];
+                csum.x += o.x; csum.y += o.y; csum.z += o.z; csum.w += o.w;
+            }
+            *reinterpret_cast<float4*>(p.colsum + (size_t)tile_m * p.colsum_ld + col) = csum;
+        }
+    }
+}
+
+// WM x 2 waves per workgroup, each owning a (BM/WM) x (BN/2) block of the tile
+template <int BM, int BN, int WM, bool A_KC, bool B_KC, typename T>
+__global__ __launch_bounds__(WM * 128, WM == 4 ? 4 : 1) void gemm_bf16_kernel(const GemmParams p) {
+    constexpr int NT = WM * 128;
+    typedef typename StageSel<BM, A_KC, T, NT>::type SA;
+    typedef typename StageSel<BN, B_KC, T, NT>::type SB;
+    constexpr int WTM = BM / WM, WTN = BN / 2;
     constexpr int TM = WTM / 16, TN = WTN / 16;
-    constexpr int kEpiElems = 4 * 32 * (WTN + 4) * 2;        // epilogue bounce buffer, in bf16 units
+    constexpr int kEpiElems = (WM * 2 * 16 * (WTN + 4) + (WM - 1) * 2 * WTN) * 2;   // epilogue strips + column sums, in bf16 units
     constexpr int kSmemElems = (SA::kLds + SB::kLds) > kEpiElems ? (SA::kLds + SB::kLds) : kEpiElems;
     __shared__ __attribute__((aligned(16))) __bf16 smem[kSmemElems];
     __bf16* As = smem;
@@ -348,111 +507,280 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmParams p) {
         __syncthreads();
     }
 
-    const bool first_split = blockIdx.y == 0;
-    if (p.atomic) {                                   // split-K: fp32 atomics straight from the accumulators
+    gemm_epilogue<WM, TM, TN>(p, acc, smem, m0, n0, tile_m, wave, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LDS-DMA pipelined kernel for the large GEMMs (bf16 shadow operands only).
+//
+// 256 x 128 tile, 8 waves (4 x 2, 64 x 64 each), BK = 64, ONE workgroup per CU.  Operand tiles go HBM/L2 -> LDS with
+// global_load_lds_dwordx4 (no VGPR staging, no ds_write), into a ring of kDmaStages stage buffers, two stages in
+// flight ahead of the one being multiplied, one s_barrier per K-step and counted vmcnt waits (never 0 inside the
+// loop).  A DMA wave-instruction writes 1 KiB of LDS linearly (lane l -> base + 16 l), so the stage images are
+// unpadded and bank conflicts are removed by permuting, per row, WHICH 16-byte chunk of global memory each lane
+// fetches (cdna_hip_programming.md rule 21); the fragment reads apply the same permutation:
+//   k-contiguous operand  image [R][64 k] (128-B rows):   chunk c of row r lives at slot c ^ (r & 7)
+//   k-strided operand     image [64 k][R] (2R-B rows):    chunk c of k-row kr lives at slot c ^ (2 g(kr)),
+//                         g(kr) = (kr & 3) | ((kr >> 3) & 1) << 2   (the 8 k-rows one ds_read_b64_tr_b16 lane group
+//                         touches get 8 different 32-byte slots of a 256-byte bank row)
+// Rows / columns outside the matrix are clamped in-bounds (they only feed dropped outputs); a partial last K-stage is
+// fetched from clamped addresses and its k >= K part is zeroed in LDS before use.
+// ---------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+constexpr int kDmaBM = 256, kDmaBN = 128, kDmaBK = 64, kDmaStages = 3;
+
+// One LDS-DMA wave-instruction: lane l fetches 16 bytes from its own global address into LDS byte address
+// lds_dst + 16 l (lds_dst wave-uniform, in an SGPR).  Inline asm on purpose: hipcc orders every ds_read behind a
+// pending __builtin_amdgcn_global_load_lds with s_waitcnt vmcnt(0), which would drain the two stages this kernel
+// keeps in flight; the waits are counted by hand instead (s_waitcnt vmcnt(N) + s_barrier in the K-loop).  M0 (the
+// DMA destination base) is compiler-reserved, hence saved and restored (cdna_hip_programming.md, LDS-DMA recipe).
+__device__ __forceinline__ void glds16(const __bf16* g, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
+}
+
+__device__ __forceinline__ int swz_g(int kr) { return (kr & 3) | (((kr >> 3) & 1) << 2); }
+
+// Persistent: gridDim.x workgroups (one per CU) walk the tile list with stride gridDim.x; the (tile, K-stage) pairs
+// of a workgroup form ONE stream of stages through the ring, so the first stages of the next tile are already in
+// flight while the current tile's epilogue runs, and the epilogue's stores drain under the next tile's MFMAs.
+template <bool A_KC>
+__global__ __launch_bounds__(512) void gemm_bf16_dma_kernel(const GemmParams p) {
+    constexpr int BM = kDmaBM, BN = kDmaBN, BK = kDmaBK, NS = kDmaStages;
+    constexpr int TM = 4, TN = 4;
+    constexpr int kAElems = BM * BK, kBElems = BK * BN, kStageElems = kAElems + kBElems;   // 48 KiB per stage
+    __shared__ __attribute__((aligned(1024))) __bf16 smem[NS * kStageElems];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int kbeg = blockIdx.y * p.k_chunk;
+    const int kend = min(p.K, kbeg + p.k_chunk);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    const int ktail = (kend - kbeg) - (nk - 1) * BK;          // valid k of the last stage (1..64)
+    const bool has_tail = ktail < BK;
+    const int total = my_tiles * nk;                          // stages this workgroup streams
+
+    const __bf16* A16 = reinterpret_cast<const __bf16*>(p.A16);
+    const __bf16* B16 = reinterpret_cast<const __bf16*>(p.B16);
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_void_t*)smem;
+
+    // ---- DMA side: sources of the tile being fetched ---------------------------------------------------
+    // A: 32 wave-instructions per stage, 4 per wave; B: 16 per stage, 2 per wave
+    const __bf16* srcA[4]; const __bf16* srcB[2];
+    int a_aux[4], b_row[2];  // A_KC: lane's k offset inside the stage; k-strided: lane's k-row inside the stage
 #pragma unroll
-        for (int a = 0; a < TM; ++a)
+    for (int t = 0; t < 4; ++t) a_aux[t] = A_KC ? ((lane & 7) ^ (lane >> 3)) * 8 : 2 * (wave * 4 + t) + (lane >> 5);
 #pragma unroll
-            for (int b = 0; b < TN; ++b)
-                store_tile16(p, acc[a][b], m0 + wm * WTM + a * 16, n0 + wn * WTN + b * 16, lane, first_split);
-        return;
-    }
-    // Coalesced epilogue: the accumulators of a wave (column on the lane, 4 rows per register quad) are bounced
-    // through LDS, 32 rows at a time, so that every lane then owns 4 CONSECUTIVE columns of one row: bias /
-    // activation / act'(Y) / accumulate run on float4, C is written with 16-byte stores (256 contiguous bytes per
-    // row per wave instruction) and the bf16 shadow with 8-byte stores.  (Per-lane scalar stores of the raw MFMA
-    // layout touch 4 rows x 64 B per instruction and made the store tail as long as the main loop for N ~ K.)
-    constexpr int LW = WTN + 4;                       // floats per LDS row (16-byte aligned, bank-staggered)
-    constexpr int LPR = WTN / 4;                      // lanes per row in the read phase
-    constexpr int RPI = 64 / LPR;                     // rows per read instruction
-    float* wl = reinterpret_cast<float*>(smem) + wave * 32 * LW;
-    const int i16 = lane & 15, kq4 = (lane >> 4) * 4;
-    const bool vec_ok = (p.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
-                        (!p.Y || (p.ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(p.Y) & 15) == 0));
-    const __bf16* y16 = reinterpret_cast<const __bf16*>(p.Y16);
-    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);    // column sums of this lane's 4 columns (p.colsum)
-    // (compile-time pass index: a run-time indexed accumulator array would be placed in scratch)
-    auto do_pass = [&](auto pass_c) {
-        constexpr int pass = decltype(pass_c)::value;
-        __syncthreads();
+    for (int t = 0; t < 2; ++t) b_row[t] = 4 * (wave * 2 + t) + (lane >> 4);
+    auto setup_src = [&](int idx) {                           // idx-th tile of this workgroup
+        int tm, tn;
+        tile_coords(p, xcd_tile((int)blockIdx.x + idx * (int)gridDim.x, ntiles), tm, tn);
+        const int m0 = tm * BM, n0 = tn * BN;
 #pragma unroll
-        for (int a2 = 0; a2 < 2; ++a2)
-#pragma unroll
-            for (int b = 0; b < TN; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) wl[(a2 * 16 + kq4 + r) * LW + b * 16 + i16] = acc[pass * 2 + a2][b][r];
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 32 / RPI; ++j) {
-            const int lr = j * RPI + lane / LPR, lc = (lane % LPR) * 4;
-            const int row = m0 + wm * WTM + pass * 32 + lr, col = n0 + wn * WTN + lc;
-            if (row >= p.M || col >= p.N) continue;
-            float4 v = *reinterpret_cast<const float4*>(wl + lr * LW + lc);
-            float* vv = reinterpret_cast<float*>(&v);
-            const size_t off = (size_t)row * p.ldc + col;
-            if (vec_ok && col + 3 < p.N) {
-                if (p.bias) { v.x += p.bias[col]; v.y += p.bias[col + 1]; v.z += p.bias[col + 2]; v.w += p.bias[col + 3]; }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) vv[e] = act_apply(p.act, vv[e]);
-                if (y16) {
-                    const bf16x4 y = *reinterpret_cast<const bf16x4*>(y16 + (size_t)row * p.ldy + col);
-                    v.x *= act_grad_from_output(p.act_grad, (float)y[0]); v.y *= act_grad_from_output(p.act_grad, (float)y[1]);
-                    v.z *= act_grad_from_output(p.act_grad, (float)y[2]); v.w *= act_grad_from_output(p.act_grad, (float)y[3]);
-                } else if (p.Y) {
-                    const float4 y = *reinterpret_cast<const float4*>(p.Y + (size_t)row * p.ldy + col);
-                    v.x *= act_grad_from_output(p.act_grad, y.x); v.y *= act_grad_from_output(p.act_grad, y.y);
-                    v.z *= act_grad_from_output(p.act_grad, y.z); v.w *= act_grad_from_output(p.act_grad, y.w);
-                }
-                if (p.accumulate) {
-                    const float4 c = *reinterpret_cast<const float4*>(p.C + off);
-                    v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w;
-                }
-                if (p.C) *reinterpret_cast<float4*>(p.C + off) = v;
-                if (p.C16) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.C16) + off) = cvt4(v);
-                csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w;
+        for (int t = 0; t < 4; ++t) {
+            if (A_KC) {
+                const int row = 8 * (wave * 4 + t) + (lane >> 3);
+                srcA[t] = A16 + (size_t)min(m0 + row, p.M - 1) * p.lda + kbeg + a_aux[t];
             } else {
-                for (int e = 0; e < 4 && col + e < p.N; ++e) {
-                    float x = vv[e] + (p.bias ? p.bias[col + e] : 0.f);
-                    x = act_apply(p.act, x);
-                    if (p.Y) x *= act_grad_from_output(p.act_grad, p.Y[(size_t)row * p.ldy + col + e]);
-                    if (p.accumulate) x += p.C[off + e];
-                    p.C[off + e] = x;
-                    if (p.C16) reinterpret_cast<__bf16*>(p.C16)[off + e] = (__bf16)x;
-                }
+                int col = m0 + (((lane & 31) ^ (swz_g(a_aux[t]) << 1)) * 8);
+                if (col + 8 > p.lda) col = 0;
+                srcA[t] = A16 + (size_t)(kbeg + a_aux[t]) * p.lda + col;
             }
         }
-    };
-    do_pass(std::integral_constant<int, 0>{});
-    if constexpr (TM / 2 > 1) do_pass(std::integral_constant<int, 1>{});
-    if constexpr (TM / 2 > 2) do_pass(std::integral_constant<int, 2>{});
-    if constexpr (TM / 2 > 3) do_pass(std::integral_constant<int, 3>{});
-    static_assert(TM / 2 <= 4, "epilogue passes");
-    if (p.colsum) {                                   // lanes that differ only in their row share the columns
 #pragma unroll
-        for (int o = LPR; o < 64; o <<= 1) {
-            csum.x += __shfl_xor(csum.x, o, 64); csum.y += __shfl_xor(csum.y, o, 64);
-            csum.z += __shfl_xor(csum.z, o, 64); csum.w += __shfl_xor(csum.w, o, 64);
+        for (int t = 0; t < 2; ++t) {
+            int col = n0 + (((lane & 15) ^ (swz_g(b_row[t]) << 1)) * 8);
+            if (col + 8 > p.ldb) col = 0;
+            srcB[t] = B16 + (size_t)(kbeg + b_row[t]) * p.ldb + col;
         }
-        // the two waves stacked in m combine through LDS; one plain float4 store per 4 columns and tile
-        float4* cs = reinterpret_cast<float4*>(smem);
-        __syncthreads();
-        if (wm == 1 && lane < LPR) cs[wn * LPR + lane] = csum;
-        __syncthreads();
-        const int col = n0 + wn * WTN + lane * 4;
-        if (wm == 0 && lane < LPR && col + 3 < p.N) {
-            const float4 o = cs[wn * LPR + lane];
-            csum.x += o.x; csum.y += o.y; csum.z += o.z; csum.w += o.w;
-            *reinterpret_cast<float4*>(p.colsum + (size_t)tile_m * p.colsum_ld + col) = csum;
+    };
+    const size_t a_step = A_KC ? (size_t)BK : (size_t)BK * p.lda;
+    const size_t b_step = (size_t)BK * p.ldb;
+
+    auto issue = [&](int slot, int kt, auto tail_c) {         // K-stage kt of the fetch tile -> ring slot
+        constexpr bool tail = decltype(tail_c)::value;
+        const unsigned As = lds_base + (unsigned)(slot * kStageElems * 2);
+        const unsigned Bs = As + kAElems * 2;
+        const int k0 = kbeg + kt * BK;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const __bf16* g = srcA[t];
+            if (tail) {
+                if (A_KC) { if (k0 + a_aux[t] + 8 > kend) g -= (k0 + a_aux[t] + 8 - kend); }
+                else if (k0 + a_aux[t] >= kend) g -= (size_t)(k0 + a_aux[t] - (kend - 1)) * p.lda;
+            }
+            glds16(g, __builtin_amdgcn_readfirstlane(As + (wave * 4 + t) * 1024));
+            srcA[t] += a_step;
         }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const __bf16* g = srcB[t];
+            if (tail && k0 + b_row[t] >= kend) g -= (size_t)(k0 + b_row[t] - (kend - 1)) * p.ldb;
+            glds16(g, __builtin_amdgcn_readfirstlane(Bs + (wave * 2 + t) * 1024));
+            srcB[t] += b_step;
+        }
+    };
+    int f_stage = 0, f_kt = 0, f_tile = 0, f_slot = 0;        // fetch cursor
+    auto fetch_next = [&]() {
+        if (f_stage >= total) return;
+        if (f_kt == 0) setup_src(f_tile);
+        if (has_tail && f_kt == nk - 1) issue(f_slot, f_kt, std::true_type{});
+        else issue(f_slot, f_kt, std::false_type{});
+        ++f_stage;
+        f_slot = (f_slot + 1 == NS) ? 0 : f_slot + 1;
+        if (++f_kt == nk) { f_kt = 0; ++f_tile; }
+    };
+
+    // ---- per-lane fragment addresses (bytes inside a stage) -------------------------------------------
+    const int q = (lane & 15) >> 2, pp = lane & 3, hi = lane >> 4;
+    int a_off[TM], b_off[TN];
+    const int g_lane = q | ((hi & 1) << 2);                   // swz_g of every k-row this lane reads
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        if (A_KC) a_off[a] = (wm * 64 + a * 16 + (lane & 15)) * 128 + ((hi ^ (lane & 7)) << 4);
+        else a_off[a] = (hi * 8 + q) * (BM * 2) + ((((wm * 8 + a * 2 + (pp >> 1)) ^ (g_lane << 1))) << 4) + (pp & 1) * 8;
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+        b_off[b] = (hi * 8 + q) * (BN * 2) + ((((wn * 8 + b * 2 + (pp >> 1)) ^ (g_lane << 1))) << 4) + (pp & 1) * 8;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+    fetch_next();
+    fetch_next();
+    int c_kt = 0, c_tile = 0, c_slot = 0;                     // compute cursor
+    bool landed = false;                                      // stage s already waited for (after an epilogue)
+    for (int s = 0; s < total; ++s) {
+        if (!landed) {
+            if (s + 1 < total) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        landed = false;
+        __builtin_amdgcn_s_barrier();
+        fetch_next();                                         // stage s + 2 -> the slot consumed at step s - 1
+        const char* As = reinterpret_cast<const char*>(smem + c_slot * kStageElems);
+        const char* Bs = As + kAElems * 2;
+        if (has_tail && c_kt == nk - 1) {                     // zero the k >= ktail part of both images
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (A_KC) {
+                for (int e = tid; e < BM * 8; e += 512) {     // (row, chunk)
+                    const int r = e >> 3, c = e & 7;
+                    if (c * 8 >= ktail) *reinterpret_cast<float4*>(const_cast<char*>(As) + r * 128 + ((c ^ (r & 7)) << 4)) = z;
+                }
+            } else {
+                for (int e = tid; e < BK * (BM / 8); e += 512) {
+                    const int kr = e / (BM / 8);
+                    if (kr >= ktail) *reinterpret_cast<float4*>(const_cast<char*>(As) + e * 16) = z;
+                }
+            }
+            for (int e = tid; e < BK * (BN / 8); e += 512) {
+                const int kr = e / (BN / 8);
+                if (kr >= ktail) *reinterpret_cast<float4*>(const_cast<char*>(Bs) + e * 16) = z;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                if (A_KC) {
+                    fa[a] = *reinterpret_cast<const bf16x8*>(As + (a_off[a] ^ (ks << 6)));
+                } else {
+                    const char* ad = As + a_off[a] + ks * 32 * (BM * 2);
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ad));
+                    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ad + 4 * (BM * 2)));
+                    fa[a] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const char* bd = Bs + b_off[b] + ks * 32 * (BN * 2);
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(bd));
+                const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(bd + 4 * (BN * 2)));
+                fb[b] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
+        if (++c_kt == nk) {                                   // tile finished: epilogue out of the slot just consumed
+            int tile_m, tile_n;
+            tile_coords(p, xcd_tile((int)blockIdx.x + c_tile * (int)gridDim.x, ntiles), tile_m, tile_n);
+            const int m0 = tile_m * BM, n0 = tile_n * BN;
+            // the next stage must have landed before the epilogue's own loads / stores / atomics join the (in-order)
+            // vmcnt queue behind it; the stage after it stays in flight
+            if (s + 1 < total) {
+                if (s + 2 < total) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                landed = true;
+            }
+            if (p.atomic) {                                   // split-K: fp32 atomics straight from the accumulators
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        store_tile16(p, acc[a][b], m0 + wm * 64 + a * 16, n0 + wn * 64 + b * 16, lane, blockIdx.y == 0);
+            } else {
+                __builtin_amdgcn_s_barrier();                 // every wave is done reading the slot
+                float* strip = reinterpret_cast<float*>(smem + c_slot * kStageElems) + wave * (16 * (TN * 16 + 4));
+                float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+                tile_epilogue<TM, TN>(p, acc, strip, m0 + wm * 64, n0 + wn * 64, lane, csum);
+                if (p.colsum) {                               // lanes that differ only in their row share the columns
+#pragma unroll
+                    for (int o = 16; o < 64; o <<= 1) {
+                        csum.x += __shfl_xor(csum.x, o, 64); csum.y += __shfl_xor(csum.y, o, 64);
+                        csum.z += __shfl_xor(csum.z, o, 64); csum.w += __shfl_xor(csum.w, o, 64);
+                    }
+                    // the 4 waves stacked in m combine through LDS (behind the strips); plain float4 stores
+                    float4* cs = reinterpret_cast<float4*>(reinterpret_cast<float*>(smem + c_slot * kStageElems) +
+                                                           8 * (16 * (TN * 16 + 4)));
+                    if (wm > 0 && lane < 16) cs[((wm - 1) * 2 + wn) * 16 + lane] = csum;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    const int col = n0 + wn * 64 + lane * 4;
+                    if (wm == 0 && lane < 16 && col + 3 < p.N) {
+#pragma unroll
+                        for (int w = 1; w < 4; ++w) {
+                            const float4 o = cs[((w - 1) * 2 + wn) * 16 + lane];
+                            csum.x += o.x; csum.y += o.y; csum.z += o.z; csum.w += o.w;
+                        }
+                        *reinterpret_cast<float4*>(p.colsum + (size_t)tile_m * p.colsum_ld + col) = csum;
+                    }
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            c_kt = 0; ++c_tile;
+        }
+        c_slot = (c_slot + 1 == NS) ? 0 : c_slot + 1;
     }
 }
 
-template <int BM, int BN, typename T>
+template <int BM, int BN, int WM, typename T>
 static void launch_bf16_t(const GemmParams& p, int layout, dim3 grid, hipStream_t s) {
+    const dim3 block(WM * 128);
     switch (layout) {
-        case GEMM_NN: hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, true, false, T>), grid, dim3(256), 0, s, p); break;
-        case GEMM_NT: hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, true, true, T>), grid, dim3(256), 0, s, p); break;
-        default:      hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, false, false, T>), grid, dim3(256), 0, s, p); break;
+        case GEMM_NN: hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, true, false, T>), grid, block, 0, s, p); break;
+        case GEMM_NT: hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, true, true, T>), grid, block, 0, s, p); break;
+        default:      hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, false, false, T>), grid, block, 0, s, p); break;
     }
 }
 
@@ -460,12 +788,15 @@ void launch_gemm_bf16(const GemmParams& p, int layout, int tile_mode, dim3 grid,
     const bool shadows = p.A16 && p.B16;      // operands already available as bf16 copies
     const bool big = tile_mode >= 1;
     if (shadows) {
-        if (tile_mode == 2) launch_bf16_t<256, 128, __bf16>(p, layout, grid, s);
-        else if (big) launch_bf16_t<128, 128, __bf16>(p, layout, grid, s);
-        else launch_bf16_t<64, 64, __bf16>(p, layout, grid, s);
+        if (tile_mode == 3) {                 // LDS-DMA pipelined 256x128 kernel (NN / TN)
+            if (layout == GEMM_NN) hipLaunchKernelGGL((gemm_bf16_dma_kernel<true>), grid, dim3(512), 0, s, p);
+            else hipLaunchKernelGGL((gemm_bf16_dma_kernel<false>), grid, dim3(512), 0, s, p);
+        } else if (tile_mode == 2) launch_bf16_t<256, 128, 4, __bf16>(p, layout, grid, s);   // 8 waves, 64x64 each
+        else if (big) launch_bf16_t<128, 128, 2, __bf16>(p, layout, grid, s);
+        else launch_bf16_t<64, 64, 2, __bf16>(p, layout, grid, s);
     } else {
-        if (big) launch_bf16_t<128, 128, float>(p, layout, grid, s);
-        else launch_bf16_t<64, 64, float>(p, layout, grid, s);
+        if (big) launch_bf16_t<128, 128, 2, float>(p, layout, grid, s);
+        else launch_bf16_t<64, 64, 2, float>(p, layout, grid, s);
     }
 }
 

@@ -199,8 +199,15 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
     // per MFMA, twice the MFMA work between barriers) when even that coarse grid fills the chip
     const int64_t t256 = (int64_t)cdiv(g.M, 256) * cdiv(g.N, 128);
     // (measured: 2x SLOWER than 128x128 at one 4-wave workgroup per CU -- kept behind an opt-in switch)
-    const bool huge = g.precision == ADN_PRECISION_BF16 && p.A16 && p.B16 && getenv("ADN_GEMM_256") &&
-                      (t256 >= 384 || (can_split && t256 >= 24 && g.K >= 2048));
+    const bool huge0 = g.precision == ADN_PRECISION_BF16 && p.A16 && p.B16 &&
+                      (force_tile ? force_tile == 256
+                                  : (getenv("ADN_GEMM_256") && (t256 >= 384 || (can_split && t256 >= 24 && g.K >= 2048))));
+    // LDS-DMA pipelined 256x128 kernel: shadows, NN / TN, 16-byte aligned operands, K in whole 16-byte chunks
+    const bool dma_ok = g.precision == ADN_PRECISION_BF16 && p.A16 && p.B16 && g.layout != GEMM_NT && g.K % 8 == 0 &&
+                        g.lda % 8 == 0 && g.ldb % 8 == 0 && ((uintptr_t)p.A16 % 16) == 0 && ((uintptr_t)p.B16 % 16) == 0 &&
+                        g.M >= 256 && g.N >= 128 && g.K >= 128 && (g.layout == GEMM_NN || g.lda >= 256) && g.ldb >= 128;
+    const bool dma = dma_ok && force_tile == 512;
+    const bool huge = huge0 || dma;
     const int64_t tiles = huge ? t256 : (big ? t128 : t64);
     int split = 1;
     if (tiles < 384 && g.K >= 512 && can_split && !lean_c) {
@@ -234,13 +241,15 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
         int bn = (int)std::lround(std::sqrt((double)chunk));
         p.panel_n = std::max(1, std::min(bn, p.tiles_n));
     }
-    const dim3 grid((unsigned)tiles, split);
+    // the LDS-DMA kernel is persistent: one workgroup per CU walks the tile list
+    // (workgroup count a multiple of 8 keeps a workgroup's tiles on its own XCD's chunk of the tile list)
+    const dim3 grid((unsigned)(dma ? std::min<int64_t>(tiles, std::max(8, 256 / split / 8 * 8)) : tiles), split);
     static const bool trace = getenv("ADN_GEMM_TRACE") != nullptr;       // one line per launch, pairs with a kernel trace
     if (trace)
         fprintf(stderr, "ADN_GEMM %s M=%d N=%d K=%d tile=%d tiles=%lld split=%d shadows=%d lean=%d acc=%d\n",
                 g.layout == GEMM_NN ? "NN" : (g.layout == GEMM_NT ? "NT" : "TN"), g.M, g.N, g.K, huge ? 256 : tsz,
                 (long long)tiles, split, (int)(p.A16 && p.B16), (int)lean_c, g.accumulate);
-    if (g.precision == ADN_PRECISION_BF16) launch_gemm_bf16(p, g.layout, huge ? 2 : (big ? 1 : 0), grid, stream);
+    if (g.precision == ADN_PRECISION_BF16) launch_gemm_bf16(p, g.layout, dma ? 3 : (huge ? 2 : (big ? 1 : 0)), grid, stream);
     else if (big) launch<128, 128>(p, g.layout, grid, stream);
     else launch<64, 64>(p, g.layout, grid, stream);
     ADN_HIP_CHECK(hipGetLastError());

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <vector>
 #include "adn_common.h"
 
@@ -105,6 +106,42 @@ int main(int argc, char** argv) {
         const double outb = (double)c.M * c.N * ((c.lean ? 0 : 4) + (g.C16 ? 2 : 0) + (c.ygrad ? 2 : 0) + (c.acc ? 4 : 0));
         printf("%-26s %3s %6d %6d %6d | %9.1f %9.1f %9.1f%s\n", c.name, c.layout == 0 ? "NN" : (c.layout == 1 ? "NT" : "TN"),
                c.M, c.N, c.K, us, 2.0 * c.M * c.N * c.K / us / 1e6, outb / us / 1e3, c.colsum && !done ? "  (colsum NOT fused)" : "");
+        if (getenv("LAB_VERIFY")) {                  // sampled check against a double-precision dot product of the bf16 operands
+            CK(hipMemsetAsync(C, 0, (size_t)c.M * ldc * 4, st));
+            gemm(g, st);
+            CK(hipStreamSynchronize(st));
+            std::vector<unsigned short> hA((size_t)ar * ac), hB((size_t)br * bc), hC16((size_t)c.M * ldc), hY16((size_t)c.M * ldc);
+            std::vector<float> hC((size_t)c.M * ldc), hb(ldc);
+            CK(hipMemcpy(hA.data(), A16, hA.size() * 2, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hB.data(), B16, hB.size() * 2, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hC16.data(), C16, hC16.size() * 2, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hY16.data(), Y16, hY16.size() * 2, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hb.data(), bias, ldc * 4, hipMemcpyDeviceToHost));
+            auto f = [](unsigned short h) { unsigned u = (unsigned)h << 16; float x; memcpy(&x, &u, 4); return x; };
+            double worst = 0; int bad = 0; unsigned rs = 777;
+            const int nsamp = 4000;
+            for (int sidx = 0; sidx < nsamp; ++sidx) {
+                rs = rs * 1664525u + 1013904223u; int i = (rs >> 8) % c.M;
+                rs = rs * 1664525u + 1013904223u; int j = (rs >> 8) % c.N;
+                if (sidx < 64) { i = (sidx & 1) ? c.M - 1 - (sidx >> 1) : (sidx >> 1); }          // edges
+                if (sidx >= 64 && sidx < 128) { j = (sidx & 1) ? c.N - 1 - ((sidx - 64) >> 1) : ((sidx - 64) >> 1); }
+                double acc = 0;
+                for (int k = 0; k < c.K; ++k) {
+                    const float a = c.layout == GEMM_TN ? f(hA[(size_t)k * ac + i]) : f(hA[(size_t)i * ac + k]);
+                    const float b = c.layout == GEMM_NT ? f(hB[(size_t)j * bc + k]) : f(hB[(size_t)k * bc + j]);
+                    acc += (double)a * b;
+                }
+                if (c.biasrelu) { acc += hb[j]; if (acc < 0) acc = 0; }
+                if (c.ygrad && !(f(hY16[(size_t)i * ldc + j]) > 0.f)) acc = 0;
+                const double got = c.lean ? f(hC16[(size_t)i * ldc + j]) : hC[(size_t)i * ldc + j];
+                const double tol = (c.lean ? 1.0e-2 : 2e-3) * (fabs(acc) + 1.0);
+                const double err = fabs(got - acc);
+                if (err > tol) { if (bad < 5) printf("   MISMATCH (%d,%d): got %g want %g\n", i, j, got, acc); ++bad; }
+                if (err > worst) worst = err;
+            }
+            printf("   verify: %d/%d outside tolerance, worst abs err %.3g\n", bad, nsamp, worst);
+        }
         (void)hipFree(A); (void)hipFree(B); (void)hipFree(C); (void)hipFree(Y); (void)hipFree(bias); (void)hipFree(cs); (void)hipFree(ws);
         (void)hipFree(A16); (void)hipFree(B16); (void)hipFree(C16); (void)hipFree(Y16);
     }
