@@ -407,6 +407,39 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
     else run(IR{}, IR{});
 }
 
+// split-K form: the partial tile is ADDED to C.  Float atomics execute at the memory side, one request per 64 bytes,
+// and run at full rate only for row-contiguous wave-instructions (MI355X_MICROARCH.md, Global float atomics): the
+// slice goes through the same strip and every instruction then adds 64 (TN = 4) or 2 x 32 (TN = 2) consecutive
+// floats of a row instead of the accumulator's 4 rows x 16 columns.  (Split-K launches carry no bias / activation.)
+template <int TM, int TN>
+__device__ __forceinline__ void tile_epilogue_atomic(const GemmParams& p, f32x4 (&acc)[TM][TN], float* strip, int row_base,
+                                                     int col_base, int lane) {
+    constexpr int LW = TN * 16 + 4, WTN = TN * 16, RPI = 64 / WTN;
+    const int i16 = lane & 15, kq4 = (lane >> 4) * 4;
+    const int c = lane % WTN, col = col_base + c;
+    auto slice = [&](auto a_c) {
+        constexpr int a = decltype(a_c)::value;
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) strip[(kq4 + r) * LW + b * 16 + i16] = acc[a][b][r];
+#pragma unroll
+        for (int j = 0; j < 16 / RPI; ++j) {
+            const int lr = j * RPI + lane / WTN;
+            const int row = row_base + a * 16 + lr;
+            float v = strip[lr * LW + c];
+            if (row >= p.M || col >= p.N) continue;
+            if (p.Y) v *= act_grad_from_output(p.act_grad, p.Y[(size_t)row * p.ldy + col]);
+            atomicAdd(p.C + (size_t)row * p.ldc + col, v);
+        }
+    };
+    slice(std::integral_constant<int, 0>{});
+    if constexpr (TM > 1) slice(std::integral_constant<int, 1>{});
+    if constexpr (TM > 2) slice(std::integral_constant<int, 2>{});
+    if constexpr (TM > 3) slice(std::integral_constant<int, 3>{});
+    static_assert(TM <= 4, "tile_epilogue_atomic: at most 4 accumulator rows");
+}
+
 // non-persistent kernels: WM x 2 waves; strips at the start of the (now free) LDS array; the waves stacked in m
 // combine their column sums through LDS behind the strips
 template <int WM, int TM, int TN>
@@ -416,16 +449,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     constexpr int LPR = TN * 4;
     constexpr int kStrip = 16 * (WTN + 4);            // floats per wave
     const int wm = wave >> 1, wn = wave & 1;
-    if (p.atomic) {                                   // split-K: fp32 atomics straight from the accumulators
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b)
-                store_tile16(p, acc[a][b], m0 + wm * WTM + a * 16, n0 + wn * WTN + b * 16, lane, blockIdx.y == 0);
-        return;
-    }
     __syncthreads();                                  // every wave is done with the operand images
     float* strips = reinterpret_cast<float*>(smem);
+    if (p.atomic) {                                   // split-K partial sums
+        tile_epilogue_atomic<TM, TN>(p, acc, strips + wave * kStrip, m0 + wm * WTM, n0 + wn * WTN, lane);
+        return;
+    }
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
     tile_epilogue<TM, TN>(p, acc, strips + wave * kStrip, m0 + wm * WTM, n0 + wn * WTN, lane, csum);
     if (p.colsum) {                                   // lanes that differ only in their row share the columns
