@@ -166,6 +166,7 @@ struct LstmStep {          // one LSTM instance taking part in a (possibly multi
     const void* W_frag_bwd;
     void* h16;             // [(T+1)*B][ldh] bf16 shadow of hbuf
     void* dG16;            // [T*B][ldg]     bf16 shadow of dG
+    void* xchg = nullptr;  // exchange buffer of the weight-stationary kernels (lstm_cluster.hip), lstm_cluster_xchg_bytes(B)
 };
 constexpr int kMaxLstmPerLaunch = 8;
 // runs all T steps of n (<= kMaxLstmPerLaunch) independent LSTMs of identical (B,T,H) concurrently
@@ -178,6 +179,12 @@ size_t lstm_frag_elems(int H);
 int lstm_pack_frags(const float* W, void* fwd, void* bwd, int H, hipStream_t s);
 int lstm_forward_persistent(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
 int lstm_backward_persistent(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
+// weight-stationary variants (lstm_cluster.hip): groups of 4 workgroups share a 32-utterance slice, W_hid stays in LDS
+bool lstm_cluster_supported(const LstmStep* l, int n, int B, int T, int H);
+size_t lstm_cluster_xchg_bytes(int B);
+int lstm_forward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
+int lstm_backward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
+int lstm_cluster_error_word(int** out);   // device word raised by a poll that gave up (checked at synchronisation)
 static inline int lstm_ldk(int H) { return (int)((H + 31) / 32 * 32); }
 // BPTT; on return dG holds d(gates) for every step, dh_carry / dc_state the gradient wrt the
 // initial state (per batch row)

@@ -1,0 +1,523 @@
+// Weight-stationary LSTM kernels (bf16 mode, H <= 256): W_hid never leaves LDS.
+//
+// The persistent kernels of lstm_persistent.hip give a 16-utterance slice to ONE workgroup, which must then stream
+// the whole W_hid (512 KB as bf16) from L2 every time step: 12-14 us per step, bound by what one CU can take in
+// (~40 GB/s), with only 33 workgroups per LSTM busy.  Here a group of kCWG = 4 workgroups shares a 32-utterance
+// slice; workgroup j owns hidden units [64 j, 64 j + 64): its 256 gate columns of W_hid (forward) or its 256 rows of
+// W_hid^T (backward) are 128 KB of bf16 in MFMA-fragment order and stay in LDS for all T steps.  What the four
+// workgroups must exchange each step is tiny and goes through L2 / the memory side as 8-byte tagged granules
+// {payload32, tag32}: the consumer polls the payload's own address until the tag of the step shows up (one hop,
+// no separate flag; relaxed agent-scope 64-bit atomics = sc1 stores / loads, single-copy atomic):
+//   forward   all-gather of h_t  (bf16):   granule = h of 2 rows of one unit       32 x 192 values in per workgroup
+//   backward  reduce-scatter of the partial dh_t (fp32, tag in the low mantissa bits): 2 rows of one unit per
+//             granule                                                                 3 x 32 x 64 values in
+// Two parities of the exchange buffer suffice: a workgroup can only be one step ahead of its partners.
+// Every workgroup of a launch must be resident at once (they wait for each other): the host launches at most one
+// workgroup per CU (LDS: 145 KB each) and splits larger sets of LSTMs over several launches.  Polls are bounded; a
+// poll that gives up raises the launch's error word and the host reports ADN_ERR_STATE -- never a hang.
+#include "adn_common.h"
+#include <algorithm>
+#include <cstdlib>
+
+namespace adn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+struct LstmClusterP {
+    LstmStep l[kMaxLstmPerLaunch];
+};
+
+__device__ __forceinline__ float c_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+__device__ __forceinline__ float c_tanh(float x) {
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.88539008177792681f * x));
+}
+__device__ __forceinline__ float c_clip5(float x) { return fminf(fmaxf(x, -5.f), 5.f); }
+
+constexpr int kCRows = 32;       // utterances per group
+constexpr int kCWG = 4;          // workgroups per group
+constexpr int kCUnits = 64;      // hidden units per workgroup
+constexpr int kCHP = kCWG * kCUnits;            // padded hidden size (256)
+constexpr int kCKS = kCHP / 32;                 // k-steps of the forward product
+constexpr int kCWElems = kCUnits * 4 * kCHP;    // bf16 elements of one workgroup's W slice (128 KB)
+constexpr int kCHS = kCHP + 8;                  // LDS row stride of the h / dG images (bf16)
+constexpr int kSpinLimit = 1 << 18;
+
+__device__ __forceinline__ unsigned long long granule_load(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void granule_store(unsigned long long* p, unsigned payload, unsigned tag) {
+    __hip_atomic_store(p, ((unsigned long long)tag << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Polls N granules (addresses ptr[k]) until all carry `tag`; returns false when it gave up.
+template <int N>
+__device__ __forceinline__ bool granule_wait(const unsigned long long* const (&ptr)[N], unsigned tag, unsigned (&payload)[N],
+                                             int* err) {
+    unsigned pending = (1u << N) - 1u;
+    for (int spin = 0; pending; ++spin) {
+        unsigned long long g[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            if (pending & (1u << k)) g[k] = granule_load(ptr[k]);
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            if ((pending & (1u << k)) && (unsigned)(g[k] >> 32) == tag) { payload[k] = (unsigned)g[k]; pending &= ~(1u << k); }
+        if (pending && spin >= kSpinLimit) { atomicCAS(err, 0, 1 | ((int)(tag & 1023u) << 4) | ((int)blockIdx.x << 16)); return false; }
+        if (pending && (spin & 1023) == 1023 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+    }
+    return true;
+}
+
+// =========================================================================================
+// forward
+// =========================================================================================
+// grid (kCWG * groups, n LSTMs); 512 threads: wave w -> row tile w >> 2 (16 rows), local unit tile w & 3 (16 units);
+// lane -> unit (lane & 15), rows 4 (lane >> 4) .. +3 of the row tile.
+__global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const LstmClusterP L, const uint8_t* __restrict__ mask_tb,
+                                                               int B, int T, int H, int ldh, int ldg, unsigned tag0, int* err) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
+    __bf16* wl = lds;                                 // [4 unit tiles][4 gates][8 k-steps][64 lanes][8]
+    __bf16 (*hs)[kCHS] = reinterpret_cast<__bf16 (*)[kCHS]>(lds + kCWElems);     // [32][kCHS]
+    const LstmStep& P = L.l[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int group = blockIdx.x / kCWG, j = blockIdx.x % kCWG;
+    const int r0 = group * kCRows;
+    const int rt = wave >> 2, ut = wave & 3;
+    const int u = kCUnits * j + 16 * ut + i;          // this lane's hidden unit
+    const int uc = min(u, H - 1);
+    __bf16* h16g = reinterpret_cast<__bf16*>(P.h16);
+    // exchange buffer of the group: [2 parities][16 row pairs][256 units] granules
+    unsigned long long* xb = reinterpret_cast<unsigned long long*>(P.xchg) + (size_t)group * 2 * 16 * kCHP;
+
+    // ---- resident W slice: unit tiles 4j .. 4j+3 of the fragment image are contiguous
+    {
+        const bf16x8* src = reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(P.W_frag_fwd) + (size_t)j * kCWElems);
+        for (int e = tid; e < kCWElems / 8; e += 512) reinterpret_cast<bf16x8*>(wl)[e] = src[e];
+    }
+    // ---- initial state
+    const int blk0 = P.backwards ? T : 0;
+    for (int e = tid; e < kCRows * (kCHS / 8); e += 512) {
+        const int rr = e / (kCHS / 8), cc = (e % (kCHS / 8)) * 8;
+        bf16x8 v = bf16x8{};
+        if (cc < ldh && cc < kCHP) v = *reinterpret_cast<const bf16x8*>(h16g + ((size_t)blk0 * B + min(r0 + rr, B - 1)) * ldh + cc);
+        *reinterpret_cast<bf16x8*>(&hs[rr][cc]) = v;
+    }
+    float c_st[4], h_st[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const size_t idx = ((size_t)blk0 * B + min(r0 + 16 * rt + 4 * kq + r, B - 1)) * ldh + uc;
+        c_st[r] = P.cbuf[idx];
+        h_st[r] = P.hbuf[idx];
+    }
+    __syncthreads();
+
+    // foreign granules this thread fetches every step: 3 partners x 16 row pairs x 64 units = 3072 = 6 per thread
+    int f_off[6], f_rp[6], f_u[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int id = tid + 512 * k;
+        const int fj = (j + 1 + id / 1024) & 3, rp = (id % 1024) / 64, ul = id % 64;
+        f_rp[k] = rp; f_u[k] = 64 * fj + ul;
+        f_off[k] = rp * kCHP + f_u[k];
+    }
+    const bf16x8* wfrag = reinterpret_cast<const bf16x8*>(wl) + (size_t)ut * 4 * kCKS * 64 + lane;
+    bool m[4];
+    float4 xp[4];
+    auto request_inputs = [&](int step_, bool (&mm)[4], float4 (&xx)[4]) {
+        const int t_ = P.backwards ? (T - 1 - step_) : step_;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const size_t ridx = (size_t)t_ * B + min(r0 + 16 * rt + 4 * kq + r, B - 1);
+            mm[r] = mask_tb[ridx] != 0;
+            xx[r] = *reinterpret_cast<const float4*>(P.xproj + ridx * ldg + uc * 4);
+        }
+    };
+
+    for (int step = 0; step < T; ++step) {
+        const int t = P.backwards ? (T - 1 - step) : step;
+        const int out_blk = t + (P.backwards ? 0 : 1);
+        const unsigned tag = tag0 + (unsigned)step;
+        unsigned long long* xpar = xb + (size_t)(step & 1) * 16 * kCHP;
+        // masks and input projections of the step (the round trip hides under the recurrent product)
+        request_inputs(step, m, xp);
+        // ---- recurrent product out of LDS: 4 gate tiles x 8 k-steps
+        f32x4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < kCKS; ++s) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(&hs[16 * rt + i][s * 32 + kq * 8]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wfrag[(g * kCKS + s) * 64], acc[g], 0, 0, 0);
+        }
+        __syncthreads();                              // every wave has read h_{t-1}: the image may be overwritten
+        // ---- gate math; lane = (unit, 4 rows)
+        float h_out[4];
+        float4 gts[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float a_i = xp[r].x + acc[0][r], a_f = xp[r].y + acc[1][r];
+            float a_g = xp[r].z + acc[2][r], a_o = xp[r].w + acc[3][r];
+            const float c_prev = c_st[r], h_prev = h_st[r];
+            if (P.peep) { a_i += c_prev * P.peep[uc]; a_f += c_prev * P.peep[ldh + uc]; }
+            const float gi = c_sigmoid(a_i), gf = c_sigmoid(a_f), gg = c_tanh(a_g);
+            const float c_new = gf * c_prev + gi * gg;
+            if (P.peep) a_o += c_new * P.peep[2 * ldh + uc];
+            const float go = c_sigmoid(a_o);
+            const float h_new = go * c_tanh(c_new);
+            c_st[r] = m[r] ? c_new : c_prev;
+            h_out[r] = m[r] ? h_new : h_prev;
+            h_st[r] = h_out[r];
+            gts[r] = make_float4(gi, gf, gg, go);
+        }
+        if (u >= H) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h_out[r] = 0.f;
+        }
+        // ---- publish h_t of this lane's unit first (the partners are waiting for it), 2 rows per granule
+#pragma unroll
+        for (int rp = 0; rp < 2; ++rp) {
+            bf16x2 pr; pr[0] = (__bf16)h_out[2 * rp]; pr[1] = (__bf16)h_out[2 * rp + 1];
+            granule_store(xpar + (size_t)(8 * rt + 2 * kq + rp) * kCHP + u, __builtin_bit_cast(unsigned, pr), tag);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hs[16 * rt + 4 * kq + r][u] = (__bf16)h_out[r];
+        // ---- the step's outputs
+        if (u < H) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int grow = r0 + 16 * rt + 4 * kq + r;
+                if (grow < B) {
+                    const size_t ridx = (size_t)t * B + grow;
+                    const size_t oidx = ((size_t)out_blk * B + grow) * ldh + u;
+                    P.cbuf[oidx] = c_st[r];
+                    P.hbuf[oidx] = h_out[r];
+                    h16g[oidx] = (__bf16)h_out[r];
+                    if (P.gates) *reinterpret_cast<float4*>(P.gates + ridx * ldg + u * 4) = gts[r];
+                }
+            }
+        }
+        // ---- gather the partners' h_t
+        if (step + 1 < T) {
+            const unsigned long long* ptr[6];
+            unsigned pay[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ptr[k] = xpar + f_off[k];
+            granule_wait<6>(ptr, tag, pay, err);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const bf16x2 pr = __builtin_bit_cast(bf16x2, pay[k]);
+                hs[2 * f_rp[k]][f_u[k]] = pr[0];
+                hs[2 * f_rp[k] + 1][f_u[k]] = pr[1];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// =========================================================================================
+// backward (BPTT): see lstm.hip for the per-step math
+// =========================================================================================
+// Workgroup j keeps dG_{t+1} of ITS gate columns (32 rows x 256, bf16) in LDS together with the 256 matching rows of
+// W_hid^T, multiplies them into a partial dh for ALL 256 units, keeps its own 64-unit quarter and sends the other
+// three quarters to their owners.  A partial is fp32; two of them (2 rows of one unit) travel in one 8-byte granule
+// whose tag is spread over the 4 low mantissa bits of either value (they keep 19 bits: far finer than the bf16
+// operands that produced them).  Tag 0 means "empty": owners zero their inbox slots after the last step, so every
+// launch starts from clean slots and only has to tell step s from step s - 2 of the same parity.
+constexpr int kBxPair = kCRows / 2 * kCUnits;        // granules of one (destination, source) pair: 16 row pairs x 64 units
+
+__device__ __forceinline__ unsigned long long pack_partials(float a, float b, unsigned tag8) {
+    const unsigned ua = (__builtin_bit_cast(unsigned, a) & ~15u) | (tag8 & 15u);
+    const unsigned ub = (__builtin_bit_cast(unsigned, b) & ~15u) | (tag8 >> 4);
+    return ((unsigned long long)ub << 32) | ua;
+}
+
+__global__ __launch_bounds__(512) void lstm_bwd_cluster_kernel(const LstmClusterP L, const uint8_t* __restrict__ mask_tb,
+                                                               int B, int T, int H, int ldh, int ldg, int* err) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
+    __bf16* wl = lds;                                 // [16 unit tiles][8 k-steps][64 lanes][8]: W_hid[unit][own gate columns]
+    __bf16 (*dgs)[kCHS] = reinterpret_cast<__bf16 (*)[kCHS]>(lds + kCWElems);            // [32][kCHS] own dG_{t+1}
+    float (*part)[kCUnits + 1] = reinterpret_cast<float (*)[kCUnits + 1]>(lds + kCWElems + kCRows * kCHS);   // [32][65]
+    const LstmStep& P = L.l[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int group = blockIdx.x / kCWG, j = blockIdx.x % kCWG;
+    const int r0 = group * kCRows;
+    const int rt = wave >> 2, ut = wave & 3;          // gate math: row tile, local unit tile; MFMA: row tile, destination
+    const int ul = 16 * ut + i;                       // local unit
+    const int u = kCUnits * j + ul;
+    __bf16* dg16g = reinterpret_cast<__bf16*>(P.dG16);
+    // inbox / outbox: [2 parities][4 destinations][4 sources][16 row pairs][64 units] granules, after the forward region
+    unsigned long long* xb = reinterpret_cast<unsigned long long*>(P.xchg) + (size_t)((B + kCRows - 1) / kCRows) * 2 * 16 * kCHP +
+                             (size_t)group * 2 * 16 * kBxPair;
+
+    {   // resident W slice: for every unit tile the 8 k-steps [8j, 8j+8) of the fragment image (8 KB runs)
+        const bf16x8* src = reinterpret_cast<const bf16x8*>(P.W_frag_bwd);
+        for (int e = tid; e < kCWElems / 8; e += 512) {
+            const int tile = e / (8 * 64), rest = e % (8 * 64);
+            reinterpret_cast<bf16x8*>(wl)[e] = src[(size_t)tile * (4 * kCKS) * 64 + (size_t)(8 * j) * 64 + rest];
+        }
+    }
+    for (int e = tid; e < kCRows * kCHS / 8; e += 512) reinterpret_cast<bf16x8*>(&dgs[0][0])[e] = bf16x8{};
+    float dh_c[4], dc_s[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { dh_c[r] = 0.f; dc_s[r] = 0.f; }
+    __syncthreads();
+    const bf16x8* wfrag = reinterpret_cast<const bf16x8*>(wl) + lane;
+
+    const int uc = min(u, H - 1);
+    // what the gate math of a step reads from HBM is requested at the top of the step: the round trips hide under the
+    // recurrent product and the exchange (measured: requesting a step ahead, before or after the polls, is no faster --
+    // the step is bound by the exchange hop, ~3 us of the 5-7 us)
+    float l_dhs[4], l_ct[4], l_cp[4];
+    float4 l_gt[4];
+    bool l_m[4];
+    auto request_state = [&](int step_) {
+        const int t_ = P.backwards ? step_ : (T - 1 - step_);
+        const int pb = t_ + (P.backwards ? 1 : 0), ob = t_ + (P.backwards ? 0 : 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int growc = min(r0 + 16 * rt + 4 * kq + r, B - 1);
+            const size_t ridx = (size_t)t_ * B + growc;
+            l_m[r] = mask_tb[ridx] != 0;
+            l_dhs[r] = P.dhs[ridx * ldh + uc];
+            l_gt[r] = *reinterpret_cast<const float4*>(P.gates + ridx * ldg + uc * 4);
+            l_ct[r] = P.cbuf[((size_t)ob * B + growc) * ldh + uc];
+            l_cp[r] = P.cbuf[((size_t)pb * B + growc) * ldh + uc];
+        }
+    };
+    for (int step = 0; step <= T; ++step) {
+        const int t = P.backwards ? step : (T - 1 - step);
+        if (step < T) request_state(step);
+        float rec[4] = {0.f, 0.f, 0.f, 0.f};          // recurrent part of dh for this lane's 4 (row, unit) pairs
+        if (step > 0) {
+            const unsigned tag8 = 1u + (unsigned)(step % 255);
+            unsigned long long* xpar = xb + (size_t)(step & 1) * 16 * kBxPair;
+            // ---- partial dh for destination ut (= MFMA role of this wave): 4 unit tiles x 8 k-steps
+            f32x4 acc[4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&dgs[16 * rt + i][s * 32 + kq * 8]);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wfrag[((4 * ut + ct) * 8 + s) * 64], acc[ct], 0, 0, 0);
+            }
+            // accumulator map: unit = 64 ut + 16 ct + (lane & 15), row = 16 rt + 4 kq + r
+            if (ut == j) {
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) part[16 * rt + 4 * kq + r][16 * ct + i] = acc[ct][r];
+            } else {
+                unsigned long long* box = xpar + (size_t)(ut * 4 + j) * kBxPair;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int rp = 0; rp < 2; ++rp)
+                        __hip_atomic_store(box + (size_t)(8 * rt + 2 * kq + rp) * kCUnits + 16 * ct + i,
+                                           pack_partials(acc[ct][2 * rp], acc[ct][2 * rp + 1], tag8), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();                          // own quarter is in `part`; dG_{t+1} has been consumed
+            // ---- collect the three foreign quarters of this lane's pairs
+            const unsigned long long* ptr[6];
+            unsigned long long g[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int src = (j + 1 + k / 2) & 3, rp = k & 1;
+                ptr[k] = xpar + (size_t)(j * 4 + src) * kBxPair + (size_t)(8 * rt + 2 * kq + rp) * kCUnits + ul;
+            }
+            unsigned pending = 63u;
+            for (int spin = 0; pending; ++spin) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    if (pending & (1u << k)) {
+                        g[k] = granule_load(ptr[k]);
+                        if ((((unsigned)g[k] & 15u) | (((unsigned)(g[k] >> 32) & 15u) << 4)) == tag8) pending &= ~(1u << k);
+                    }
+                if (pending && spin >= kSpinLimit) { atomicCAS(err, 0, 2 | (step << 4) | ((int)blockIdx.x << 16)); break; }
+                if (pending && (spin & 1023) == 1023 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rec[r] = part[16 * rt + 4 * kq + r][ul];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int rp = k & 1;
+                rec[2 * rp] += __builtin_bit_cast(float, (unsigned)g[k] & ~15u);
+                rec[2 * rp + 1] += __builtin_bit_cast(float, (unsigned)(g[k] >> 32) & ~15u);
+            }
+        }
+        if (step == T) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dh_c[r] += rec[r];
+            break;
+        }
+        // ---- gate math of step t for this lane's unit and 4 rows
+        float pw_i = 0.f, pw_f = 0.f, pw_o = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * rt + 4 * kq + r, grow = r0 + row;
+            const size_t ridx = (size_t)t * B + min(grow, B - 1);
+            const bool ok = grow < B && u < H;
+            float4 dg = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                const float dh = l_dhs[r] + dh_c[r] + rec[r];
+                const float dc = dc_s[r];
+                if (l_m[r]) {
+                    const float4 gt = l_gt[r];
+                    const float c_t = l_ct[r], c_prev = l_cp[r];
+                    const float tc = c_tanh(c_t);
+                    const float da_o = dh * tc * gt.w * (1.f - gt.w);
+                    float dcn = dc + dh * gt.w * (1.f - tc * tc);
+                    if (P.peep) { dcn += da_o * P.peep[2 * ldh + u]; pw_o += da_o * c_t; }
+                    const float da_i = dcn * gt.z * gt.x * (1.f - gt.x);
+                    const float da_f = dcn * c_prev * gt.y * (1.f - gt.y);
+                    const float da_g = dcn * gt.x * (1.f - gt.z * gt.z);
+                    float dcp = dcn * gt.y;
+                    if (P.peep) {
+                        dcp += da_i * P.peep[u] + da_f * P.peep[ldh + u];
+                        pw_i += da_i * c_prev; pw_f += da_f * c_prev;
+                    }
+                    dg = make_float4(c_clip5(da_i), c_clip5(da_f), c_clip5(da_g), c_clip5(da_o));
+                    dh_c[r] = 0.f;
+                    dc_s[r] = dcp;
+                } else {
+                    dh_c[r] = dh;
+                }
+                *reinterpret_cast<float4*>(P.dG + ridx * ldg + u * 4) = dg;
+            }
+            bf16x4 d16;
+            d16[0] = (__bf16)dg.x; d16[1] = (__bf16)dg.y; d16[2] = (__bf16)dg.z; d16[3] = (__bf16)dg.w;
+            if (ok) *reinterpret_cast<bf16x4*>(dg16g + ridx * ldg + u * 4) = d16;
+            *reinterpret_cast<bf16x4*>(&dgs[row][ul * 4]) = d16;
+        }
+        if (P.dpeep_part) {                          // sum this lane's 4 rows, then the 4 row groups (kq) of the wave
+            float si = pw_i, sf = pw_f, so = pw_o;
+            si += __shfl_xor(si, 16, 64); si += __shfl_xor(si, 32, 64);
+            sf += __shfl_xor(sf, 16, 64); sf += __shfl_xor(sf, 32, 64);
+            so += __shfl_xor(so, 16, 64); so += __shfl_xor(so, 32, 64);
+            if (kq == 0 && u < H) {
+                atomicAdd(P.dpeep_part + u, si);
+                atomicAdd(P.dpeep_part + ldh + u, sf);
+                atomicAdd(P.dpeep_part + 2 * (size_t)ldh + u, so);
+            }
+        }
+        __syncthreads();
+    }
+    // gradient wrt the initial state of every row of this slice (summed over rows by the caller)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int grow = r0 + 16 * rt + 4 * kq + r;
+        if (grow < B && u < H) {
+            P.dh_carry[(size_t)grow * ldh + u] = dh_c[r];
+            P.dc_state[(size_t)grow * ldh + u] = dc_s[r];
+        }
+    }
+    // leave this workgroup's inbox empty for the next launch (after EVERY lane has taken its last granules)
+    __syncthreads();
+    for (int e = tid; e < 2 * 4 * kBxPair; e += 512) {
+        const int par = e / (4 * kBxPair), rest = e % (4 * kBxPair);
+        xb[(size_t)par * 16 * kBxPair + (size_t)j * 4 * kBxPair + rest] = 0ull;
+    }
+}
+
+static unsigned g_cluster_epoch = 1;
+static int* g_cluster_err = nullptr;       // device word, lazily allocated; polled after the launch by the caller's sync
+
+bool lstm_cluster_supported(const LstmStep* l, int n, int B, int T, int H) {
+    if (H > kCHP || T >= 1024 || getenv("ADN_LSTM_NO_CLUSTER")) return false;
+    for (int k = 0; k < n; ++k)
+        if (!l[k].xchg || !l[k].W_frag_fwd || !l[k].W_frag_bwd) return false;
+    return lstm_frag_elems(H) == (size_t)4 * kCHP * kCHP;
+}
+
+size_t lstm_cluster_xchg_bytes(int B) {          // forward region (h granules) + backward region (partial-dh granules)
+    return (size_t)cdiv(B, kCRows) * (2 * 16 * kCHP + 2 * 16 * kBxPair) * 8;
+}
+
+static int cluster_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        cus = prop.multiProcessorCount;
+    }
+    return cus;
+}
+
+int lstm_cluster_error_word(int** out) {
+    if (!g_cluster_err) {
+        ADN_HIP_CHECK(hipMalloc((void**)&g_cluster_err, sizeof(int)));
+        ADN_HIP_CHECK(hipMemset(g_cluster_err, 0, sizeof(int)));
+    }
+    *out = g_cluster_err;
+    return ADN_OK;
+}
+
+int lstm_forward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s) {
+    const int groups = cdiv(B, kCRows), per = groups * kCWG, cus = cluster_cus();
+    ADN_CHECK(cus >= per, ADN_ERR_STATE, "lstm cluster kernel: one LSTM does not fit the device");
+    int* err = nullptr;
+    ADN_TRY(lstm_cluster_error_word(&err));
+    const int ldh = ld_of(H), ldg = ld_of(4 * H);
+    const size_t lds = (size_t)(kCWElems + kCRows * kCHS) * 2;
+    static bool attr = false;
+    if (!attr) {
+        ADN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_cluster_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    const double bytes = (double)n * T * (4.0 * (12.0 * B * H + 4.0 * H * H) + B), flops = (double)n * T * 8.0 * B * H * H;
+    ProfScope prof(PROF_LSTM_FWD, flops, bytes, s, T);
+    const int chunk = std::max(1, cus / per);        // LSTMs per launch: every workgroup must be resident
+    for (int k0 = 0; k0 < n; k0 += chunk) {
+        const int nn = std::min(chunk, n - k0);
+        LstmClusterP L;
+        for (int k = 0; k < nn; ++k) L.l[k] = l[k0 + k];
+        const unsigned tag0 = (g_cluster_epoch++ & 0x3fffffu) * 1024u + 1u;
+        hipLaunchKernelGGL(lstm_fwd_cluster_kernel, dim3(per, nn), dim3(512), lds, s, L, mask_tb, B, T, H, ldh, ldg, tag0, err);
+        ADN_HIP_CHECK(hipGetLastError());
+    }
+    return ADN_OK;
+}
+
+}  // namespace adn
+
+namespace adn {
+
+int lstm_backward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s) {
+    const int groups = cdiv(B, kCRows), per = groups * kCWG, cus = cluster_cus();
+    ADN_CHECK(cus >= per, ADN_ERR_STATE, "lstm cluster kernel: one LSTM does not fit the device");
+    int* err = nullptr;
+    ADN_TRY(lstm_cluster_error_word(&err));
+    const int ldh = ld_of(H), ldg = ld_of(4 * H);
+    const size_t lds = (size_t)(kCWElems + kCRows * kCHS) * 2 + (size_t)kCRows * (kCUnits + 1) * 4;
+    static bool attr = false;
+    if (!attr) {
+        ADN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_cluster_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    const double bytes = (double)n * T * 4.0 * (15.0 * B * H + 4.0 * H * H), flops = (double)n * T * 8.0 * B * H * H;
+    ProfScope prof(PROF_LSTM_BWD, flops, bytes, s, T + 1);
+    const int chunk = std::max(1, cus / per);
+    for (int k0 = 0; k0 < n; k0 += chunk) {
+        const int nn = std::min(chunk, n - k0);
+        LstmClusterP L;
+        for (int k = 0; k < nn; ++k) L.l[k] = l[k0 + k];
+        hipLaunchKernelGGL(lstm_bwd_cluster_kernel, dim3(per, nn), dim3(512), lds, s, L, mask_tb, B, T, H, ldh, ldg, err);
+        ADN_HIP_CHECK(hipGetLastError());
+    }
+    return ADN_OK;
+}
+
+}  // namespace adn

@@ -107,6 +107,7 @@ struct LstmParams {      // physical tensors (float offsets into the flat buffer
 struct LstmWork {        // per-shape workspace pointers
     float *xproj = nullptr, *gates = nullptr, *dG = nullptr, *hbuf = nullptr, *cbuf = nullptr;
     float *dh_carry = nullptr, *dc_state = nullptr;
+    void* xchg = nullptr;    // lstm_cluster.hip exchange buffer
     float* out(int B, int ldh, bool backwards) const { return hbuf + (backwards ? 0 : (size_t)B * ldh); }
     float* prev(int B, int ldh, bool backwards) const { return hbuf + (backwards ? (size_t)B * ldh : 0); }
 };
@@ -348,6 +349,7 @@ void carve_lstm(adn_model* m, Carver& cv, LstmWork& w, int B, int T, int ldh, in
     w.cbuf = cv.take<float>((size_t)(T + 1) * B * ldh);
     w.dh_carry = cv.take<float>((size_t)B * ldh);
     w.dc_state = cv.take<float>((size_t)B * ldh);
+    w.xchg = cv.take<char>(lstm_cluster_xchg_bytes(B));
 }
 
 size_t carve(adn_model* m, char* base, int B, int T, bool host_inputs) {
@@ -554,6 +556,7 @@ LstmStep make_step(const adn_model* m, const LstmParams& lp, const LstmWork& w, 
     s.W_hid16 = b16 ? m->shadow_of(m->P(lp.W_hid)) : nullptr;
     s.h16 = b16 ? m->shadow_of(w.hbuf) : nullptr;
     s.dG16 = b16 ? m->shadow_of(w.dG) : nullptr;
+    s.xchg = b16 ? w.xchg : nullptr;
     return s;
 }
 
@@ -853,12 +856,33 @@ int check_shape(const adn_model* m, int B, int T, int theta) {
     return ADN_OK;
 }
 
+// the weight-stationary LSTM kernels raise a device word when a workgroup gave up waiting for its partners
+// (lstm_cluster.hip); call after the stream has been synchronised
+int check_device_errors(adn_model* m) {
+    if (!m->bf16()) return ADN_OK;
+    int* word = nullptr;
+    ADN_TRY(lstm_cluster_error_word(&word));
+    int v = 0;
+    ADN_HIP_CHECK(hipMemcpy(&v, word, sizeof(int), hipMemcpyDeviceToHost));
+    if (v) {
+        ADN_HIP_CHECK(hipMemset(word, 0, sizeof(int)));
+        char msg[200];
+        snprintf(msg, sizeof(msg), "LSTM exchange timed out (%s kernel, step tag %d, workgroup %d): a workgroup never "
+                 "received its partners' state; results are invalid", (v & 15) == 1 ? "forward" : "backward", (v >> 4) & 4095,
+                 (v >> 16) & 1023);
+        set_error(msg);
+        return ADN_ERR_STATE;
+    }
+    return ADN_OK;
+}
+
 int fetch(adn_model* m, void* dst, const void* src, size_t bytes, bool to_device) {
     if (to_device) {
         ADN_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, m->stream));
     } else {
         ADN_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, m->stream));
         ADN_HIP_CHECK(hipStreamSynchronize(m->stream));
+        ADN_TRY(check_device_errors(m));
     }
     return ADN_OK;
 }
@@ -1191,7 +1215,7 @@ int adn_profile_read(adn_model* m, adn_profile_entry* out, int max_entries, int*
 int adn_synchronize(adn_model* m) {
     ADN_CHECK(m, ADN_ERR_INVALID, "null model");
     ADN_HIP_CHECK(hipStreamSynchronize(m->stream));
-    return ADN_OK;
+    return check_device_errors(m);
 }
 
 // ---- operator-level entry points ---------------------------------------------------------------
