@@ -1,0 +1,47 @@
+"""HBM traffic of the dominant kernel class from two rocprofv3 PMC passes (the TCC cannot hold FETCH_SIZE and
+WRITE_SIZE in one pass, MI355X_MICROARCH.md):
+
+    rocprofv3 --pmc FETCH_SIZE                         -d A -o a --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile
+    rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d B -o b --output-format csv -- python3 bench.py ... (same)
+    python3 profiles/make_traffic_json.py A/.../a_counter_collection.csv B/.../b_counter_collection.csv bf16 > profiles/r01/pmc_traffic_bf16.json
+
+FETCH_SIZE / WRITE_SIZE are reported in KiB; FETCH_SIZE is doubled per the gfx950 correction (128-byte requests
+tallied at 64 B).  bench.py reads the file named pmc_traffic_<precision>.json for `roofline.traffic`."""
+import collections
+import csv
+import json
+import sys
+
+
+def per_kernel(path, match):
+    tot, n = collections.Counter(), collections.Counter()
+    for r in csv.DictReader(open(path)):
+        if match in r["Kernel_Name"]:
+            tot[r["Counter_Name"]] += float(r["Counter_Value"])
+            n[r["Counter_Name"]] += 1
+    return tot, n
+
+
+def main():
+    fa, fb, prec = sys.argv[1:4]
+    match = "gemm_bf16" if prec == "bf16" else "gemm_f32_kernel"
+    ta, na = per_kernel(fa, match)
+    tb, nb = per_kernel(fb, match)
+    launches = na["FETCH_SIZE"]
+    fetch = 2.0 * 1024.0 * ta["FETCH_SIZE"] / max(1, launches)
+    write = 1024.0 * tb["WRITE_SIZE"] / max(1, nb["WRITE_SIZE"])
+    hit, miss = tb["TCC_HIT_sum"], tb["TCC_MISS_sum"]
+    print(json.dumps({
+        "kernel_class": "%s (all instantiations)" % match,
+        "launches": launches,
+        "fetch_bytes_per_launch": fetch,
+        "write_bytes_per_launch": write,
+        "l2_hit_rate": hit / max(1.0, hit + miss),
+        "traffic_bytes_per_launch": fetch + write,
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum (separate passes), bench.py --steps 3 "
+                  "--warmup 1 --precision %s; FETCH_SIZE doubled per the gfx950 correction" % prec,
+    }, indent=1))
+
+
+if __name__ == "__main__":
+    main()

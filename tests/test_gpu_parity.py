@@ -612,3 +612,48 @@ def test_cuave_oulu_input_widths(torch_cuda, lib, D, C, B):
         pd = m.predict([torch.tensor(x, device="cuda") for x in inputs], torch.tensor(mask, device="cuda"), theta)
         assert np.abs(pd - probs_ref).max() <= (1e-4 if prec == "f32" else 3e-2)
     m.close()
+
+
+def test_weight_stationary_lstm_equals_single_workgroup_path(torch_cuda, lib, monkeypatch):
+    """bf16 mode, H <= 256: the LSTMs run on groups of 4 workgroups that keep W_hid in LDS and exchange h / partial dh
+    through tagged granules (csrc/lstm_cluster.hip).  Same arithmetic as the one-workgroup-per-slice kernels
+    (csrc/lstm_persistent.hip, selected with ADN_LSTM_NO_CLUSTER): forward identical, gradients equal up to the 19-bit
+    partial sums of the backward exchange.  B = 70 spans three 32-utterance groups with a ragged last one; the launches
+    are repeated so that stale granules of earlier launches (tags, emptied inboxes) would be noticed; and the
+    bidirectional + peephole LSTMs exercise both directions.  The oracle check bounds both paths."""
+    from ip_avsr_amd.model import AdeNetModel
+    spec = dict(O.spec_nstream([12, 9], enc_shapes=(14, 6), enc_acts=("rectify", "linear"), lstm_size=37, classes=5,
+                               fusion="concat", peepholes=True), precision="bf16")
+    B, T, theta = 70, 13, 2
+    p, inputs, y, mask = make_case(spec, B, T, seed=4242)
+    results = {}
+    for mode in ("cluster", "single"):
+        if mode == "single":
+            monkeypatch.setenv("ADN_LSTM_NO_CLUSTER", "1")
+        else:
+            monkeypatch.delenv("ADN_LSTM_NO_CLUSTER", raising=False)
+        m = AdeNetModel(spec)
+        m.set_params_dict(p)
+        runs = []
+        for rep in range(3):                                   # same inputs again: every launch must reproduce itself
+            probs = m.predict(inputs, mask, theta)
+            loss = m.compute_grads(inputs, y, mask, theta)
+            runs.append((probs, loss, m.get_grads_dict()))
+        for probs, loss, g in runs[1:]:
+            np.testing.assert_array_equal(probs, runs[0][0])
+            assert loss == runs[0][1]
+            for k in g:
+                np.testing.assert_allclose(g[k], runs[0][2][k], rtol=0, atol=1e-6 * max(1.0, np.abs(runs[0][2][k]).max()))
+        results[mode] = runs[0]
+        m.close()
+    monkeypatch.delenv("ADN_LSTM_NO_CLUSTER", raising=False)
+    pc, lc, gc = results["cluster"]
+    ps, ls, gs = results["single"]
+    np.testing.assert_array_equal(pc, ps)                        # forward: the same products in the same order
+    assert abs(lc - ls) <= 1e-6 * abs(ls)
+    for k in gc:
+        scale = max(np.abs(gs[k]).max(), 1e-6)
+        assert np.abs(gc[k] - gs[k]).max() <= 2e-3 * scale, (k, np.abs(gc[k] - gs[k]).max(), scale)
+    probs_ref = O.forward(spec, {k: v.astype(np.float64) for k, v in p.items()}, [x.astype(np.float64) for x in inputs],
+                          mask, theta)
+    assert np.abs(pc - probs_ref).max() <= 2e-2
