@@ -105,6 +105,9 @@ int gemm(const GemmArgs& g, hipStream_t stream);
 int to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 // out[c * ldT + r] = bf16(W[r * ld + c]) for r < rows, c < cols (LDS-tiled transpose)
 int transpose_to_bf16(const float* W, int rows, int cols, int ld, void* out, int ldT, hipStream_t s);
+// the same for a table of matrices in ONE launch (items: device array; block_end[k] = running total of 32x32 tiles)
+struct TransposeItem { const float* W; void* out; int rows, cols, ld, ldT, block_end; };
+int transpose_to_bf16_batch(const TransposeItem* dev_items, int n, int total_blocks, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
 // element-wise / HBM-bound kernels (elementwise.hip)
@@ -167,6 +170,12 @@ struct LstmStep {          // one LSTM instance taking part in a (possibly multi
     void* h16;             // [(T+1)*B][ldh] bf16 shadow of hbuf
     void* dG16;            // [T*B][ldg]     bf16 shadow of dG
     void* xchg = nullptr;  // exchange buffer of the weight-stationary kernels (lstm_cluster.hip), lstm_cluster_xchg_bytes(B)
+    // optional (backward): gradients that are plain sums of what the kernel already holds in registers -- the bias
+    // (column sums of dG over all frames) and the learnt initial state (sums of dh_carry / dc_state over the batch).
+    // Kernels that add them report it through lstm_backward()'s `sums_done`; otherwise the caller runs col_sum.
+    float* dbias = nullptr;      // [ldg]  += sum_{t,b} dG
+    float* dhid_init = nullptr;  // [ldh]  += sum_b dh_carry
+    float* dcell_init = nullptr; // [ldh]  += sum_b dc_state
 };
 constexpr int kMaxLstmPerLaunch = 8;
 // runs all T steps of n (<= kMaxLstmPerLaunch) independent LSTMs of identical (B,T,H) concurrently
@@ -178,7 +187,8 @@ bool lstm_persistent_supported(int H);
 size_t lstm_frag_elems(int H);
 int lstm_pack_frags(const float* W, void* fwd, void* bwd, int H, hipStream_t s);
 int lstm_forward_persistent(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
-int lstm_backward_persistent(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
+int lstm_backward_persistent(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s,
+                             bool* sums_done = nullptr);
 // weight-stationary variants (lstm_cluster.hip): groups of 4 workgroups share a 32-utterance slice, W_hid stays in LDS
 bool lstm_cluster_supported(const LstmStep* l, int n, int B, int T, int H);
 size_t lstm_cluster_xchg_bytes(int B);
@@ -188,6 +198,7 @@ int lstm_cluster_error_word(int** out);   // device word raised by a poll that g
 static inline int lstm_ldk(int H) { return (int)((H + 31) / 32 * 32); }
 // BPTT; on return dG holds d(gates) for every step, dh_carry / dc_state the gradient wrt the
 // initial state (per batch row)
-int lstm_backward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, int precision, hipStream_t s);
+int lstm_backward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, int precision, hipStream_t s,
+                  bool* sums_done = nullptr);
 
 }  // namespace adn

@@ -862,6 +862,34 @@ int transpose_to_bf16(const float* W, int rows, int cols, int ld, void* out, int
     return ADN_OK;
 }
 
+__global__ __launch_bounds__(256) void transpose_bf16_batch_kernel(const TransposeItem* __restrict__ items, int n) {
+    __shared__ float tile[32][33];
+    int k = 0;
+    while (k + 1 < n && (int)blockIdx.x >= items[k].block_end) ++k;
+    const TransposeItem it = items[k];
+    const int local = (int)blockIdx.x - (k ? items[k - 1].block_end : 0);
+    const int ctiles = (it.cols + 31) / 32;
+    const int c0 = (local % ctiles) * 32, r0 = (local / ctiles) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        tile[j][tx] = (r < it.rows && c < it.cols) ? it.W[(size_t)r * it.ld + c] : 0.f;
+    }
+    __syncthreads();
+    __bf16* out = reinterpret_cast<__bf16*>(it.out);
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        if (c < it.cols && r < it.rows) out[(size_t)c * it.ldT + r] = (__bf16)tile[tx][j];
+    }
+}
+
+int transpose_to_bf16_batch(const TransposeItem* dev_items, int n, int total_blocks, hipStream_t s) {
+    if (n <= 0 || total_blocks <= 0) return ADN_OK;
+    hipLaunchKernelGGL(transpose_bf16_batch_kernel, dim3(total_blocks), dim3(256), 0, s, dev_items, n);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
 int to_bf16(const float* src, void* dst, size_t n, hipStream_t s) {
     ADN_CHECK(n % 8 == 0, ADN_ERR_INVALID, "to_bf16: element count must be a multiple of 8");
     if (!n) return ADN_OK;

@@ -440,13 +440,16 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const LstmLaunch L, 
     }
 }
 
-int lstm_backward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, int precision, hipStream_t s) {
+int lstm_backward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, int precision, hipStream_t s,
+                  bool* sums_done) {
     ADN_CHECK(n >= 1 && n <= kMaxLstmPerLaunch, ADN_ERR_INVALID, "lstm_backward: bad LSTM count");
+    if (sums_done) *sums_done = false;
     LstmLaunch L;
     bool have16 = precision == ADN_PRECISION_BF16;
     for (int k = 0; k < n; ++k) { L.l[k] = l[k]; have16 = have16 && l[k].W_hid16 && l[k].dG16; }
     const int ldh = ld_of(H), ldg = ld_of(4 * H);
-    if (have16 && lstm_persistent_supported(H) && l[0].W_frag_bwd) return lstm_backward_persistent(l, n, mask_tb, B, T, H, s);
+    if (have16 && lstm_persistent_supported(H) && l[0].W_frag_bwd)
+        return lstm_backward_persistent(l, n, mask_tb, B, T, H, s, sums_done);
     for (int k = 0; k < n; ++k) {
         ADN_HIP_CHECK(hipMemsetAsync(l[k].dh_carry, 0, (size_t)B * ldh * sizeof(float), s));
         ADN_HIP_CHECK(hipMemsetAsync(l[k].dc_state, 0, (size_t)B * ldh * sizeof(float), s));

@@ -269,6 +269,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_kernel(const LstmCluster
     float dh_c[4], dc_s[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { dh_c[r] = 0.f; dc_s[r] = 0.f; }
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);   // this lane's share of the bias gradient (its unit, its 4 rows, all steps)
     __syncthreads();
     const bf16x8* wfrag = reinterpret_cast<const bf16x8*>(wl) + lane;
 
@@ -394,6 +395,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_kernel(const LstmCluster
                     dh_c[r] = dh;
                 }
                 *reinterpret_cast<float4*>(P.dG + ridx * ldg + u * 4) = dg;
+                bsum.x += dg.x; bsum.y += dg.y; bsum.z += dg.z; bsum.w += dg.w;
             }
             bf16x4 d16;
             d16[0] = (__bf16)dg.x; d16[1] = (__bf16)dg.y; d16[2] = (__bf16)dg.z; d16[3] = (__bf16)dg.w;
@@ -413,13 +415,30 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_kernel(const LstmCluster
         }
         __syncthreads();
     }
-    // gradient wrt the initial state of every row of this slice (summed over rows by the caller)
+    // gradient wrt the initial state of every row of this slice
+    float sh = 0.f, sc = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int grow = r0 + 16 * rt + 4 * kq + r;
         if (grow < B && u < H) {
             P.dh_carry[(size_t)grow * ldh + u] = dh_c[r];
             P.dc_state[(size_t)grow * ldh + u] = dc_s[r];
+            sh += dh_c[r]; sc += dc_s[r];
+        }
+    }
+    // sums over this workgroup's rows: bias gradient (4 gates of the unit) and the learnt initial state; the 4 row
+    // groups of a wave combine by shuffle, then one float atomic per value (2 row tiles x 17 groups adds per address)
+    if (P.dbias) {
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {
+            bsum.x += __shfl_xor(bsum.x, o, 64); bsum.y += __shfl_xor(bsum.y, o, 64);
+            bsum.z += __shfl_xor(bsum.z, o, 64); bsum.w += __shfl_xor(bsum.w, o, 64);
+            sh += __shfl_xor(sh, o, 64); sc += __shfl_xor(sc, o, 64);
+        }
+        if (kq == 0 && u < H) {
+            atomicAdd(P.dbias + 4 * u, bsum.x); atomicAdd(P.dbias + 4 * u + 1, bsum.y);
+            atomicAdd(P.dbias + 4 * u + 2, bsum.z); atomicAdd(P.dbias + 4 * u + 3, bsum.w);
+            atomicAdd(P.dhid_init + u, sh); atomicAdd(P.dcell_init + u, sc);
         }
     }
     // leave this workgroup's inbox empty for the next launch (after EVERY lane has taken its last granules)

@@ -365,9 +365,12 @@ int lstm_forward_persistent(const LstmStep* l, int n, const uint8_t* mask_tb, in
     return ADN_OK;
 }
 
-int lstm_backward_persistent(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s) {
-    if (lstm_cluster_supported(l, n, B, T, H) && !getenv("ADN_LSTM_NO_CLUSTER_BWD"))
+int lstm_backward_persistent(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s,
+                             bool* sums_done) {
+    if (lstm_cluster_supported(l, n, B, T, H) && !getenv("ADN_LSTM_NO_CLUSTER_BWD")) {
+        if (sums_done) *sums_done = true;             // bias / initial-state gradients are added inside the kernel
         return lstm_backward_cluster(l, n, mask_tb, B, T, H, s);
+    }
     LstmLaunchP L;
     for (int k = 0; k < n; ++k) L.l[k] = l[k];
     const int ldh = ld_of(H), ldg = ld_of(4 * H);

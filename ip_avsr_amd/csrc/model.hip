@@ -185,6 +185,9 @@ struct adn_model {
     struct TransW { const float* key; char* buf; int ldT; };
     std::vector<TransW> transw;
     char* transw_slab = nullptr;
+    TransposeItem* transw_items = nullptr;      // device table for the one-launch refresh
+    int transw_blocks = 0;
+    bool packed_for_persistent = false;         // which LSTM weight images the last refresh produced
     bool bf16() const { return cfg.precision == ADN_PRECISION_BF16; }
     bool keep_fp32 = false;        // debug: also write the fp32 copies that bf16 mode normally skips
     void* shadow_of(const float* p) const {
@@ -509,14 +512,26 @@ int refresh_transposed(adn_model* m) {
             cur += (size_t)round_up((int64_t)it.cols * ld_of(it.rows) * 2, 256);
         }
     }
-    for (size_t k = 0; k < items.size(); ++k)
-        ADN_TRY(transpose_to_bf16(items[k].W, items[k].rows, items[k].cols, items[k].ld, m->transw[k].buf, m->transw[k].ldT,
-                                  m->stream));
-    return ADN_OK;
+    if (!m->transw_items) {
+        std::vector<TransposeItem> tab(items.size());
+        int total = 0;
+        for (size_t k = 0; k < items.size(); ++k) {
+            total += cdiv(items[k].rows, 32) * cdiv(items[k].cols, 32);
+            tab[k] = {items[k].W, m->transw[k].buf, items[k].rows, items[k].cols, items[k].ld, m->transw[k].ldT, total};
+        }
+        ADN_HIP_CHECK(hipMalloc((void**)&m->transw_items, tab.size() * sizeof(TransposeItem)));
+        ADN_HIP_CHECK(hipMemcpy(m->transw_items, tab.data(), tab.size() * sizeof(TransposeItem), hipMemcpyHostToDevice));
+        m->transw_blocks = total;
+    }
+    return transpose_to_bf16_batch(m->transw_items, (int)items.size(), m->transw_blocks, m->stream);
 }
 
 int refresh_params(adn_model* m) {
-    if (!m->bf16() || !m->params16_dirty) return ADN_OK;
+    if (!m->bf16()) return ADN_OK;
+    const bool persistent = lstm_persistent_supported(m->H);        // (an environment switch can flip it between calls)
+    if (persistent != m->packed_for_persistent) m->params16_dirty = true;
+    if (!m->params16_dirty) return ADN_OK;
+    m->packed_for_persistent = persistent;
     if (!m->params16) ADN_HIP_CHECK(hipMalloc((void**)&m->params16, m->flat_floats * 2));
     ADN_TRY(to_bf16(m->flat[ADN_BUF_PARAM], m->params16, m->flat_floats, m->stream));
     auto pack = [&](LstmParams& lp) -> int {
@@ -525,12 +540,12 @@ int refresh_params(adn_model* m) {
             ADN_HIP_CHECK(hipMalloc((void**)&lp.whid16t, bytes));
             ADN_HIP_CHECK(hipMemsetAsync(lp.whid16t, 0, bytes, m->stream));
         }
-        if (lstm_persistent_supported(m->H)) {
+        if (persistent) {            // the step kernels' transposed image is not read in this mode
             if (!lp.wfrag_fwd) {
                 ADN_HIP_CHECK(hipMalloc((void**)&lp.wfrag_fwd, lstm_frag_elems(m->H) * 2));
                 ADN_HIP_CHECK(hipMalloc((void**)&lp.wfrag_bwd, lstm_frag_elems(m->H) * 2));
             }
-            ADN_TRY(lstm_pack_frags(m->P(lp.W_hid), lp.wfrag_fwd, lp.wfrag_bwd, m->H, m->stream));
+            return lstm_pack_frags(m->P(lp.W_hid), lp.wfrag_fwd, lp.wfrag_bwd, m->H, m->stream);
         }
         return lstm_pack_whid_t(m->P(lp.W_hid), lp.whid16t, m->H, m->stream);
     };
@@ -557,15 +572,22 @@ LstmStep make_step(const adn_model* m, const LstmParams& lp, const LstmWork& w, 
     s.h16 = b16 ? m->shadow_of(w.hbuf) : nullptr;
     s.dG16 = b16 ? m->shadow_of(w.dG) : nullptr;
     s.xchg = b16 ? w.xchg : nullptr;
+    if (grads) { s.dbias = m->G(lp.b); s.dhid_init = m->G(lp.hid_init); s.dcell_init = m->G(lp.cell_init); }
     return s;
 }
 
-int run_lstm_group(adn_model* m, std::vector<LstmStep>& steps, int B, int T, bool backward) {
+// sums_done: the backward kernels already added the bias / initial-state gradients of every LSTM of the group
+int run_lstm_group(adn_model* m, std::vector<LstmStep>& steps, int B, int T, bool backward, bool* sums_done = nullptr) {
+    bool all = true;
     for (size_t i = 0; i < steps.size(); i += kMaxLstmPerLaunch) {
         const int n = (int)std::min<size_t>(kMaxLstmPerLaunch, steps.size() - i);
-        if (backward) ADN_TRY(lstm_backward(steps.data() + i, n, m->mask_tb, B, T, m->H, m->cfg.precision, m->stream));
+        bool done = false;
+        if (backward)
+            ADN_TRY(lstm_backward(steps.data() + i, n, m->mask_tb, B, T, m->H, m->cfg.precision, m->stream, &done));
         else ADN_TRY(lstm_forward(steps.data() + i, n, m->mask_tb, B, T, m->H, m->cfg.precision, m->stream));
+        all = all && done;
     }
+    if (sums_done) *sums_done = backward && all;
     return ADN_OK;
 }
 
@@ -694,7 +716,7 @@ const float* classifier_input(const adn_model* m, int B) {
 
 // weight / bias / initial-state gradients of one LSTM after its BPTT sweep
 int lstm_param_grads(adn_model* m, const LstmParams& lp, const LstmWork& w, const float* const* in, const int* ld_in,
-                     int nblk, int blkw, int B, int T) {
+                     int nblk, int blkw, int B, int T, bool sums_done) {
     const int N = B * T, H = m->H, ldh = m->ldh, ldg = m->ldg;
     hipStream_t s = m->stream;
     for (int j = 0; j < nblk; ++j) {                             // dW_in = X^T dG
@@ -711,9 +733,11 @@ int lstm_param_grads(adn_model* m, const LstmParams& lp, const LstmWork& w, cons
         g.C = m->G(lp.W_hid); g.ldc = ldg; g.accumulate = 1;
         ADN_TRY(mgemm(m, g));
     }
-    ADN_TRY(col_sum(w.dG, ldg, N, 4 * H, m->G(lp.b), 1, s));
-    ADN_TRY(col_sum(w.dh_carry, ldh, B, H, m->G(lp.hid_init), 1, s));
-    ADN_TRY(col_sum(w.dc_state, ldh, B, H, m->G(lp.cell_init), 1, s));
+    if (!sums_done) {
+        ADN_TRY(col_sum(w.dG, ldg, N, 4 * H, m->G(lp.b), 1, s));
+        ADN_TRY(col_sum(w.dh_carry, ldh, B, H, m->G(lp.hid_init), 1, s));
+        ADN_TRY(col_sum(w.dc_state, ldh, B, H, m->G(lp.cell_init), 1, s));
+    }
     return ADN_OK;
 }
 
@@ -760,9 +784,10 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
     if (!m->agg.empty()) {
         std::vector<LstmStep> steps;
         for (size_t k = 0; k < m->agg.size(); ++k) steps.push_back(make_step(m, m->agg[k], m->aggw[k], m->dcls, true));
-        ADN_TRY(run_lstm_group(m, steps, B, T, true));
+        bool sums_done = false;
+        ADN_TRY(run_lstm_group(m, steps, B, T, true, &sums_done));
         for (size_t k = 0; k < m->agg.size(); ++k)
-            ADN_TRY(lstm_param_grads(m, m->agg[k], m->aggw[k], fin.data(), fld.data(), (int)fin.size(), H, B, T));
+            ADN_TRY(lstm_param_grads(m, m->agg[k], m->aggw[k], fin.data(), fld.data(), (int)fin.size(), H, B, T, sums_done));
         for (size_t j = 0; j < fin.size(); ++j) {
             float* dst = per_stream_fused ? m->st[j].dout_buf : m->dfused;
             for (size_t k = 0; k < m->agg.size(); ++k)
@@ -791,18 +816,19 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
     };
     ADN_TRY(bucket_ready(0));                 // [fuse | agg | softmax] gradients and the cost share are final
     // stream LSTMs
+    bool stream_sums_done = false;
     {
         std::vector<LstmStep> steps;
         for (auto& st : m->st)
             for (size_t k = 0; k < st.lstm.size(); ++k) steps.push_back(make_step(m, st.lstm[k], st.lw[k], st.dout, true));
-        ADN_TRY(run_lstm_group(m, steps, B, T, true));
+        ADN_TRY(run_lstm_group(m, steps, B, T, true, &stream_sums_done));
     }
     for (size_t si = 0; si < m->st.size(); ++si) {
         StreamState& st = m->st[si];
         const int ldf = ld_of(st.feat_dim);
         const float* in[1] = {st.feat}; const int ld[1] = {ldf};
         for (size_t k = 0; k < st.lstm.size(); ++k)
-            ADN_TRY(lstm_param_grads(m, st.lstm[k], st.lw[k], in, ld, 1, st.feat_dim, B, T));
+            ADN_TRY(lstm_param_grads(m, st.lstm[k], st.lw[k], in, ld, 1, st.feat_dim, B, T, stream_sums_done));
         if (st.cfg.n_enc == 0) { ADN_TRY(bucket_ready(1 + si)); continue; }   // nothing trainable below the LSTM
         for (size_t k = 0; k < st.lstm.size(); ++k)
             ADN_TRY(lstm_input_grad(m, st.lstm[k], st.lw[k], 0, st.feat_dim, st.dfeat, ldf, N, k > 0));
@@ -984,6 +1010,7 @@ void adn_destroy(adn_model* m) {
     for (int k = 0; k < 4; ++k) if (m->flat[k]) (void)hipFree(m->flat[k]);
     if (m->params16) (void)hipFree(m->params16);
     if (m->transw_slab) (void)hipFree(m->transw_slab);
+    if (m->transw_items) (void)hipFree(m->transw_items);
     auto free_lp = [](LstmParams& lp) {
         if (lp.whid16t) (void)hipFree(lp.whid16t);
         if (lp.wfrag_fwd) (void)hipFree(lp.wfrag_fwd);
