@@ -124,6 +124,10 @@ int sum_k(int n_in, const float* const* in, const float* const* alpha, int ld_in
 // out[r][c] = alpha[0] * in[r][c]   (alpha device scalar)
 int scale_by(const float* in, int ld_in, const float* alpha, float* out, int ld_out, int rows, int cols,
              hipStream_t s);
+// bf16: out[r][j*cols + c] = in_j[r][c] (n <= 4 inputs with the same ld; cols % 8 == 0)
+int concat_cols_bf16(int n, const void* const* in, int ld_in, void* out, int ld_out, int rows, int cols, hipStream_t s);
+// dst[(j*rows_valid + k)*ld + c] += src[(j*rows_pad + k)*ld + c]
+int add_row_blocks(const float* src, float* dst, int ld, int nblk, int rows_valid, int rows_pad, int cols, hipStream_t s);
 // out[c] (+)= sum_r in[r][c]
 int col_sum(const float* in, int ld, int rows, int cols, float* out, int accumulate, hipStream_t s);
 // out[0] (+)= sum_{r,c} a[r][c]*b[r][c]
@@ -157,7 +161,8 @@ struct LstmStep {          // one LSTM instance taking part in a (possibly multi
     float* gates;          // [T*B][ldg] post-activation i,f,g,o (saved for backward; may be null)
     // backward only
     float* dG;             // [T*B][ldg] clipped gradient wrt the gate pre-activations
-    const float* dhs;      // [T*B][ldh] gradient wrt the layer output
+    const float* dhs;      // [T*B][ld_dhs] gradient wrt the layer output
+    int ld_dhs = 0;        // row stride of dhs (0: ldh) -- a column block of a wider matrix when the consumer was a concat
     float* dh_carry;       // [B][ldh]
     float* dc_state;       // [B][ldh]
     float* dpeep_part;     // [3][ldh] accumulated peephole-weight gradients (null: none)

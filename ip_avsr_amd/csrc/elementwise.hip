@@ -214,6 +214,56 @@ int col_sum(const float* in, int ld, int rows, int cols, float* out, int accumul
     return ADN_OK;
 }
 
+// out[r][j * cols + c] = in_j[r][c]  (bf16; cols a multiple of 8): the materialised concat of up to 4 matrices
+struct ConcatArgs { const void* in[4]; };
+__global__ __launch_bounds__(256) void concat_cols_bf16_kernel(ConcatArgs a, int n, int ld_in, uint4* __restrict__ out, int ld_out,
+                                                               int rows, int cols) {
+    const int cpr = cols / 8, per_row = n * cpr;                       // 16-byte chunks
+    const int64_t total = (int64_t)rows * per_row;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int r = (int)(e / per_row), q = (int)(e % per_row), j = q / cpr, c = q % cpr;
+        out[(size_t)r * (ld_out / 8) + q] = reinterpret_cast<const uint4*>(a.in[j])[(size_t)r * (ld_in / 8) + c];
+    }
+}
+
+int concat_cols_bf16(int n, const void* const* in, int ld_in, void* out, int ld_out, int rows, int cols, hipStream_t s) {
+    ADN_CHECK(n >= 1 && n <= 4 && cols % 8 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0, ADN_ERR_INVALID, "concat_cols_bf16: bad shape");
+    if (rows <= 0) return ADN_OK;
+    ConcatArgs a{};
+    for (int j = 0; j < n; ++j) a.in[j] = in[j];
+    const int64_t total = (int64_t)rows * n * (cols / 8);
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, 8192));
+    hipLaunchKernelGGL(concat_cols_bf16_kernel, dim3(grid), dim3(256), 0, s, a, n, ld_in, reinterpret_cast<uint4*>(out), ld_out,
+                       rows, cols);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+// dst[(j * rows_valid + k) * ld + c] += src[(j * rows_pad + k) * ld + c]   (j < nblk, k < rows_valid, c < cols; ld % 4 == 0)
+__global__ __launch_bounds__(256) void add_row_blocks_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int ld4,
+                                                             int nblk, int rows_valid, int rows_pad, int cols4) {
+    const int64_t total = (int64_t)nblk * rows_valid * cols4;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % cols4), rk = (int)(e / cols4), j = rk / rows_valid, k = rk % rows_valid;
+        const float4 a = src[(size_t)(j * rows_pad + k) * ld4 + c];
+        float4 d = dst[(size_t)(j * rows_valid + k) * ld4 + c];
+        d.x += a.x; d.y += a.y; d.z += a.z; d.w += a.w;
+        dst[(size_t)(j * rows_valid + k) * ld4 + c] = d;
+    }
+}
+
+int add_row_blocks(const float* src, float* dst, int ld, int nblk, int rows_valid, int rows_pad, int cols, hipStream_t s) {
+    ADN_CHECK(ld % 4 == 0, ADN_ERR_INVALID, "add_row_blocks: ld must be a multiple of 4");
+    const int cols4 = (cols + 3) / 4;
+    const int64_t total = (int64_t)nblk * rows_valid * cols4;
+    if (total <= 0) return ADN_OK;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, 4096));
+    hipLaunchKernelGGL(add_row_blocks_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float4*>(src),
+                       reinterpret_cast<float4*>(dst), ld / 4, nblk, rows_valid, rows_pad, cols4);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

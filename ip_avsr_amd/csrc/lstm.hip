@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_bf16_kernel(const LstmLaunc
         const size_t sidx = (size_t)r * ldh + u;
         if (step == T) { P.dh_carry[sidx] += rec; continue; }
         const size_t ridx = (size_t)t * B + r;
-        const float dh = P.dhs[ridx * ldh + u] + P.dh_carry[sidx] + rec;
+        const float dh = P.dhs[ridx * (P.ld_dhs ? P.ld_dhs : ldh) + u] + P.dh_carry[sidx] + rec;
         const float dc = P.dc_state[sidx];
         float4 dg = make_float4(0.f, 0.f, 0.f, 0.f);
         if (mask_tb[ridx]) {
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const LstmLaunch L, 
             P.dh_carry[sidx] += rec;
         } else {
             const size_t ridx = (size_t)t * B + r;
-            const float dh = P.dhs[ridx * ldh + u] + P.dh_carry[sidx] + rec;
+            const float dh = P.dhs[ridx * (P.ld_dhs ? P.ld_dhs : ldh) + u] + P.dh_carry[sidx] + rec;
             const float dc = P.dc_state[sidx];
             float4 dg = make_float4(0.f, 0.f, 0.f, 0.f);
             if (mask_tb[ridx]) {

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_kernel(const LstmCluster
             const int growc = min(r0 + 16 * rt + 4 * kq + r, B - 1);
             const size_t ridx = (size_t)t_ * B + growc;
             l_m[r] = mask_tb[ridx] != 0;
-            l_dhs[r] = P.dhs[ridx * ldh + uc];
+            l_dhs[r] = P.dhs[ridx * (P.ld_dhs ? P.ld_dhs : ldh) + uc];
             l_gt[r] = *reinterpret_cast<const float4*>(P.gates + ridx * ldg + uc * 4);
             l_ct[r] = P.cbuf[((size_t)ob * B + growc) * ldh + uc];
             l_cp[r] = P.cbuf[((size_t)pb * B + growc) * ldh + uc];

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_persistent_kernel(const LstmLaun
             for (int r = 0; r < 4; ++r) {
                 const int growc = min(r0 + 4 * kq + r, B - 1);
                 const size_t ridx = (size_t)t * B + growc;
-                l_dhs[ct][r] = P.dhs[ridx * ldh + uc];
+                l_dhs[ct][r] = P.dhs[ridx * (P.ld_dhs ? P.ld_dhs : ldh) + uc];
                 l_gt[ct][r] = *reinterpret_cast<const float4*>(P.gates + ridx * ldg + uc * 4);
                 l_ct[ct][r] = P.cbuf[((size_t)out_blk * B + growc) * ldh + uc];
                 l_cp[ct][r] = P.cbuf[((size_t)prev_blk * B + growc) * ldh + uc];

@@ -98,6 +98,7 @@ struct LstmParams {      // physical tensors (float offsets into the flat buffer
     char* whid16t = nullptr;   // bf16 mode: transposed bf16 copy of W_hid, refreshed with the parameter shadow
     char* wfrag_fwd = nullptr; // ... and the two MFMA-fragment-ordered copies the persistent kernels stream
     char* wfrag_bwd = nullptr;
+    char* wcat16 = nullptr;    // concat consumers: bf16 W_in with every input block padded to ldh rows ([S*ldh][ldg])
     int fin = 0;
     size_t W_in = 0, W_hid = 0, b = 0, peep = 0, cell_init = 0, hid_init = 0;
     bool peepholes = false;
@@ -128,6 +129,7 @@ struct StreamState {
     std::vector<LstmWork> lw;
     float* hsum = nullptr;                     // stream output when bidirectional (else alias of lw[0].out)
     float* dout_buf = nullptr;                 // own buffer for the gradient wrt the stream output
+    int dout_ld = 0;                           // row stride of `dout` (0: ldh)
     float* dout = nullptr;                     // ... the buffer actually holding it (may be a shared one)
     float* dfeat = nullptr;
     float* dE = nullptr;
@@ -173,6 +175,9 @@ struct adn_model {
     float *pingA = nullptr, *pingB = nullptr;
     int ping_ld = 0;
     float* colsum_ws = nullptr; size_t colsum_ws_floats = 0;   // per-m-tile column sums of the fused bias gradients
+    // concat fusion in bf16 mode: the aggregation LSTMs read ONE materialised [N][S*ldh] bf16 matrix, so their input
+    // projection, dW_in and the gradient wrt the concat are one GEMM each per LSTM instead of S
+    char* cat16 = nullptr; float* dcat = nullptr; float* wcat_tmp = nullptr;
     int lastB = 0, lastT = 0;
     Profiler prof;
     // bf16 shadow copies of every GEMM operand (bf16 mode): fp32 range -> bf16 buffer with the same layout
@@ -399,6 +404,11 @@ size_t carve(adn_model* m, char* base, int B, int T, bool host_inputs) {
     m->pingB = take_shadowed(m, cv, N * maxw);
     m->colsum_ws_floats = (size_t)cdiv((int)N, 64) * maxw;
     m->colsum_ws = cv.take<float>(m->colsum_ws_floats);
+    if (m->cfg.fusion == ADN_FUSE_CONCAT && m->S > 1 && !m->agg.empty()) {
+        m->cat16 = cv.take<char>(N * (size_t)m->S * ldh * 2);
+        m->dcat = cv.take<float>(N * (size_t)m->S * ldh);
+        m->wcat_tmp = cv.take<float>((size_t)m->S * ldh * ldg);
+    }
     (void)host_inputs;
     return cv.cursor;
 }
@@ -488,28 +498,31 @@ int refresh(adn_model* m, const float* p, size_t floats) {
 
 // W^T copies: encoder weights of layers >= 1, every LSTM's W_in (per input block), the classifier weights
 int refresh_transposed(adn_model* m) {
-    struct Item { const float* W; int rows, cols, ld; };
+    // ldT / col_off: an aggregation LSTM fed by a concat keeps the transposed copies of its S input blocks side by side
+    // in ONE [4H][S*ldh] matrix (block j at column j*ldh), which serves the block-wise products and the fused one alike
+    struct Item { const float* W; int rows, cols, ld, ldT, col_off; };
     std::vector<Item> items;
     for (auto& st : m->st) {
         for (int l = 1; l < st.cfg.n_enc; ++l)
-            items.push_back({m->P(st.encW[l]), st.enc_in[l], st.cfg.enc_units[l], ld_of(st.cfg.enc_units[l])});
+            items.push_back({m->P(st.encW[l]), st.enc_in[l], st.cfg.enc_units[l], ld_of(st.cfg.enc_units[l]), ld_of(st.enc_in[l]), 0});
         if (st.cfg.n_enc > 0)
-            for (auto& lp : st.lstm) items.push_back({m->P(lp.W_in), lp.fin, 4 * m->H, m->ldg});
+            for (auto& lp : st.lstm) items.push_back({m->P(lp.W_in), lp.fin, 4 * m->H, m->ldg, ld_of(lp.fin), 0});
     }
     const int nblk = (m->cfg.fusion == ADN_FUSE_CONCAT) ? m->S : 1;
     for (auto& lp : m->agg)
         for (int j = 0; j < nblk; ++j)
-            items.push_back({m->P(lp.W_in) + (size_t)j * m->H * m->ldg, m->H, 4 * m->H, m->ldg});
-    items.push_back({m->P(m->smW), m->H, m->C, m->ldc});
+            items.push_back({m->P(lp.W_in) + (size_t)j * m->H * m->ldg, m->H, 4 * m->H, m->ldg, nblk * m->ldh, j * m->ldh});
+    items.push_back({m->P(m->smW), m->H, m->C, m->ldc, ld_of(m->H), 0});
     if (m->transw.empty()) {
         size_t bytes = 0;
-        for (auto& it : items) bytes += (size_t)round_up((int64_t)it.cols * ld_of(it.rows) * 2, 256);
+        for (auto& it : items)
+            if (it.col_off == 0) bytes += (size_t)round_up((int64_t)it.cols * it.ldT * 2, 256);
         ADN_HIP_CHECK(hipMalloc((void**)&m->transw_slab, bytes));
         ADN_HIP_CHECK(hipMemsetAsync(m->transw_slab, 0, bytes, m->stream));
-        size_t cur = 0;
+        size_t cur = 0; char* base = nullptr;
         for (auto& it : items) {
-            m->transw.push_back({it.W, m->transw_slab + cur, ld_of(it.rows)});
-            cur += (size_t)round_up((int64_t)it.cols * ld_of(it.rows) * 2, 256);
+            if (it.col_off == 0) { base = m->transw_slab + cur; cur += (size_t)round_up((int64_t)it.cols * it.ldT * 2, 256); }
+            m->transw.push_back({it.W, base + (size_t)it.col_off * 2, it.ldT});
         }
     }
     if (!m->transw_items) {
@@ -551,6 +564,18 @@ int refresh_params(adn_model* m) {
     };
     for (auto& st : m->st) for (auto& lp : st.lstm) ADN_TRY(pack(lp));
     for (auto& lp : m->agg) ADN_TRY(pack(lp));
+    if (m->cfg.fusion == ADN_FUSE_CONCAT && m->S > 1) {
+        for (auto& lp : m->agg) {
+            const size_t blk = (size_t)m->ldh * m->ldg;          // elements of one padded input block
+            if (!lp.wcat16) {
+                ADN_HIP_CHECK(hipMalloc((void**)&lp.wcat16, (size_t)m->S * blk * 2));
+                ADN_HIP_CHECK(hipMemsetAsync(lp.wcat16, 0, (size_t)m->S * blk * 2, m->stream));
+            }
+            for (int j = 0; j < m->S; ++j)
+                ADN_TRY(to_bf16(m->P(lp.W_in) + (size_t)j * m->H * m->ldg, lp.wcat16 + (size_t)j * blk * 2,
+                                (size_t)m->H * m->ldg, m->stream));
+        }
+    }
     ADN_TRY(refresh_transposed(m));
     m->params16_dirty = false;
     return ADN_OK;
@@ -605,6 +630,24 @@ int lstm_project(adn_model* m, const LstmParams& lp, const LstmWork& w, const fl
         ADN_TRY(mgemm(m, g));
     }
     return ADN_OK;
+}
+
+// bf16 mode, concat fusion: the aggregation LSTMs consume one materialised [N][S*ldh] bf16 matrix
+bool cat_path(const adn_model* m) {
+    return shadows_on(m) && m->cfg.fusion == ADN_FUSE_CONCAT && m->S > 1 && m->S <= 4 && !m->agg.empty() && m->cat16 &&
+           !getenv("ADN_NO_CAT");
+}
+
+// x*W_in + b with x = the materialised concat (ONE GEMM, K = S*ldh; the pad rows of wcat16 are zero)
+int lstm_project_cat(adn_model* m, const LstmParams& lp, const LstmWork& w, int rows) {
+    GemmArgs g;
+    g.layout = GEMM_NN; g.M = rows; g.N = 4 * m->H; g.K = m->S * m->ldh;
+    g.A = reinterpret_cast<const float*>(m->cat16); g.lda = m->S * m->ldh;      // (only the bf16 operands are read)
+    g.B = m->P(lp.W_in); g.ldb = m->ldg;
+    g.A16 = m->cat16; g.B16 = lp.wcat16;
+    g.C = w.xproj; g.ldc = m->ldg; g.bias = m->P(lp.b);
+    g.precision = m->cfg.precision;
+    return gemm(g, m->stream);
 }
 
 int lstm_init_state(adn_model* m, const LstmParams& lp, const LstmWork& w, int B, int T) {
@@ -676,8 +719,15 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
     const float* cls = nullptr;
     if (!m->agg.empty()) {                                       // custom/layers.py:55-80
         steps.clear();
+        const bool cat = cat_path(m) && (int)fin.size() == m->S;
+        if (cat) {
+            const void* in16[4];
+            for (int j = 0; j < m->S; ++j) in16[j] = m->shadow_of(fin[j]);
+            ADN_TRY(concat_cols_bf16(m->S, in16, ldh, m->cat16, m->S * ldh, N, ldh, s));
+        }
         for (size_t k = 0; k < m->agg.size(); ++k) {
-            ADN_TRY(lstm_project(m, m->agg[k], m->aggw[k], fin.data(), fld.data(), (int)fin.size(), H, N));
+            if (cat) ADN_TRY(lstm_project_cat(m, m->agg[k], m->aggw[k], N));
+            else ADN_TRY(lstm_project(m, m->agg[k], m->aggw[k], fin.data(), fld.data(), (int)fin.size(), H, N));
             ADN_TRY(lstm_init_state(m, m->agg[k], m->aggw[k], B, T));
             steps.push_back(make_step(m, m->agg[k], m->aggw[k], nullptr, false));
         }
@@ -786,13 +836,39 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         for (size_t k = 0; k < m->agg.size(); ++k) steps.push_back(make_step(m, m->agg[k], m->aggw[k], m->dcls, true));
         bool sums_done = false;
         ADN_TRY(run_lstm_group(m, steps, B, T, true, &sums_done));
-        for (size_t k = 0; k < m->agg.size(); ++k)
-            ADN_TRY(lstm_param_grads(m, m->agg[k], m->aggw[k], fin.data(), fld.data(), (int)fin.size(), H, B, T, sums_done));
-        for (size_t j = 0; j < fin.size(); ++j) {
-            float* dst = per_stream_fused ? m->st[j].dout_buf : m->dfused;
+        const bool cat = cat_path(m) && (int)fin.size() == m->S && per_stream_fused;
+        for (auto& st : m->st) st.dout_ld = 0;
+        if (cat) {
+            const int ldcat = m->S * ldh;
+            for (size_t k = 0; k < m->agg.size(); ++k) {
+                const LstmParams& lp = m->agg[k]; const LstmWork& w = m->aggw[k];
+                GemmArgs g;                                   // dW_in for all S blocks: cat^T dG, pad rows dropped afterwards
+                g.layout = GEMM_TN; g.M = ldcat; g.N = 4 * H; g.K = N;
+                g.A = reinterpret_cast<const float*>(m->cat16); g.lda = ldcat; g.A16 = m->cat16;
+                g.B = w.dG; g.ldb = m->ldg; g.B16 = m->shadow_of(w.dG);
+                g.C = m->wcat_tmp; g.ldc = m->ldg; g.precision = m->cfg.precision;
+                ADN_TRY(gemm(g, s));
+                ADN_TRY(add_row_blocks(m->wcat_tmp, m->G(lp.W_in), m->ldg, m->S, H, ldh, 4 * H, s));
+                ADN_TRY(lstm_param_grads(m, lp, w, nullptr, nullptr, 0, H, B, T, sums_done));     // dW_hid (+ sums)
+                GemmArgs d;                                   // d(concat) (+)= dG W_in^T through the side-by-side W^T copies
+                d.layout = GEMM_NN; d.M = N; d.N = ldcat; d.K = 4 * H;
+                d.A = w.dG; d.lda = m->ldg; d.A16 = m->shadow_of(w.dG);
+                d.B = m->P(lp.W_in); d.ldb = ldcat;
+                for (const auto& t : m->transw) if (t.key == d.B) { d.B16 = t.buf; break; }
+                ADN_CHECK(d.B16, ADN_ERR_STATE, "internal: transposed copy of an aggregation W_in is missing");
+                d.C = m->dcat; d.ldc = ldcat; d.accumulate = k > 0; d.precision = m->cfg.precision;
+                ADN_TRY(gemm(d, s));
+            }
+            for (int j = 0; j < m->S; ++j) { dfin.push_back(m->dcat + (size_t)j * ldh); m->st[j].dout_ld = ldcat; }
+        } else {
             for (size_t k = 0; k < m->agg.size(); ++k)
-                ADN_TRY(lstm_input_grad(m, m->agg[k], m->aggw[k], (int)j, H, dst, ldh, N, k > 0));
-            dfin.push_back(dst);
+                ADN_TRY(lstm_param_grads(m, m->agg[k], m->aggw[k], fin.data(), fld.data(), (int)fin.size(), H, B, T, sums_done));
+            for (size_t j = 0; j < fin.size(); ++j) {
+                float* dst = per_stream_fused ? m->st[j].dout_buf : m->dfused;
+                for (size_t k = 0; k < m->agg.size(); ++k)
+                    ADN_TRY(lstm_input_grad(m, m->agg[k], m->aggw[k], (int)j, H, dst, ldh, N, k > 0));
+                dfin.push_back(dst);
+            }
         }
     } else {
         dfin.push_back(m->dcls);
@@ -820,7 +896,10 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
     {
         std::vector<LstmStep> steps;
         for (auto& st : m->st)
-            for (size_t k = 0; k < st.lstm.size(); ++k) steps.push_back(make_step(m, st.lstm[k], st.lw[k], st.dout, true));
+            for (size_t k = 0; k < st.lstm.size(); ++k) {
+                steps.push_back(make_step(m, st.lstm[k], st.lw[k], st.dout, true));
+                steps.back().ld_dhs = st.dout_ld;
+            }
         ADN_TRY(run_lstm_group(m, steps, B, T, true, &stream_sums_done));
     }
     for (size_t si = 0; si < m->st.size(); ++si) {
@@ -1013,6 +1092,7 @@ void adn_destroy(adn_model* m) {
     if (m->transw_items) (void)hipFree(m->transw_items);
     auto free_lp = [](LstmParams& lp) {
         if (lp.whid16t) (void)hipFree(lp.whid16t);
+        if (lp.wcat16) (void)hipFree(lp.wcat16);
         if (lp.wfrag_fwd) (void)hipFree(lp.wfrag_fwd);
         if (lp.wfrag_bwd) (void)hipFree(lp.wfrag_bwd);
     };

@@ -657,3 +657,34 @@ def test_weight_stationary_lstm_equals_single_workgroup_path(torch_cuda, lib, mo
     probs_ref = O.forward(spec, {k: v.astype(np.float64) for k, v in p.items()}, [x.astype(np.float64) for x in inputs],
                           mask, theta)
     assert np.abs(pc - probs_ref).max() <= 2e-2
+
+
+def test_concat_as_one_gemm_equals_blockwise_products(torch_cuda, lib, monkeypatch):
+    """bf16 mode, concat fusion: the aggregation BLSTM reads one materialised [N][S*ldh] bf16 matrix (input projection,
+    dW_in and d(concat) are one GEMM each per LSTM) instead of S column blocks (ADN_NO_CAT=1).  Same products, other
+    summation order: probabilities and every gradient agree to bf16-accumulation noise."""
+    from ip_avsr_amd.model import AdeNetModel
+    spec = dict(small_specs()["3stream_concat"], precision="bf16")
+    B, T, theta = 9, 10, 2
+    p, inputs, y, mask = make_case(spec, B, T, seed=99)
+    out = {}
+    for mode in ("cat", "blocks"):
+        if mode == "blocks":
+            monkeypatch.setenv("ADN_NO_CAT", "1")
+        else:
+            monkeypatch.delenv("ADN_NO_CAT", raising=False)
+        m = AdeNetModel(spec)
+        m.set_params_dict(p)
+        probs = m.predict(inputs, mask, theta)
+        loss = m.compute_grads(inputs, y, mask, theta)
+        out[mode] = (probs, loss, m.get_grads_dict())
+        m.close()
+    monkeypatch.delenv("ADN_NO_CAT", raising=False)
+    assert np.abs(out["cat"][0] - out["blocks"][0]).max() <= 2e-3
+    assert abs(out["cat"][1] - out["blocks"][1]) <= 1e-3 * abs(out["blocks"][1])
+    for k in out["cat"][2]:
+        a, b = out["cat"][2][k].ravel().astype(np.float64), out["blocks"][2][k].ravel().astype(np.float64)
+        if np.linalg.norm(b) < 1e-9:
+            continue
+        cos = a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)
+        assert cos > 0.999 and abs(np.linalg.norm(a) / np.linalg.norm(b) - 1) < 0.02, (k, cos)
