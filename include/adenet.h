@@ -208,6 +208,34 @@ int adn_op_delta_backward(const float* dout, int ld_out, float* din, int ld_in, 
                           void* hip_stream);
 int adn_op_adam(float* p, const float* g, float* m, float* v, int64_t n, float a_t, void* hip_stream);
 
+/* ---- feature front-end on the GPU (reference utils/preprocessing.py) -------------------------
+ * Device pointers, fp32 row-major frame matrices [sum of lengths][ld], work enqueued on hip_stream.  Utterance
+ * structure is passed as int32 device vectors built from the length vector: first[t] / last[t] = index of the first /
+ * last frame of the utterance frame t belongs to; starts[u] / lens[u] per utterance. */
+/* one level of linear-slope deltas along time, per utterance (utils/preprocessing.py:17-51 as used by :465-489): taps
+ * m = h..-h (h = w/2), positions before the utterance read its SECOND frame, positions after it its last frame; call
+ * twice (out of the first call as input of the second) for delta-deltas */
+int adn_prep_seq_deltas(const float* in, int ld_in, float* out, int ld_out, const int32_t* first, const int32_t* last,
+                        int n_frames, int F, int w, void* hip_stream);
+/* utils/preprocessing.py:506-517 compute_diff_images: out[t] = x[t] - x[t-1], frame 0 of an utterance = x[1] - x[0] */
+int adn_prep_diff_images(const float* in, float* out, int ld, const int32_t* first, const int32_t* last, int n_frames, int D,
+                         void* hip_stream);
+/* utils/preprocessing.py:260-277 sequencewise_mean_image_subtraction */
+int adn_prep_mean_image_subtraction(const float* in, float* out, int ld, const int32_t* starts, const int32_t* lens, int n_utt,
+                                    int D, void* hip_stream);
+/* utils/preprocessing.py:218-242 normalize_input(centralize=True): per-frame z-normalisation, population std, in place */
+int adn_prep_normalize_rows(float* x, int ld, int rows, int cols, void* hip_stream);
+/* utils/preprocessing.py:245-257 featurewise_normalize_sequence: column mean and population std of the centred data
+ * (fp64 accumulation; workspace: 2*cols doubles) ... */
+int adn_prep_column_stats(const float* x, int ld, int rows, int cols, double* workspace, float* mean, float* std,
+                          void* hip_stream);
+/* ... and their application, also to other splits (runners/3stream.py:102-108) */
+int adn_prep_apply_column_norm(const float* x, float* out, int ld, int rows, int cols, const float* mean, const float* std,
+                               void* hip_stream);
+/* out[r][j] = in[r][perm[j]]: utils/preprocessing.py:492-503 reorder_data as a pixel permutation; coefficient selection */
+int adn_prep_gather_columns(const float* in, int ld_in, float* out, int ld_out, const int32_t* perm, int rows, int cols,
+                            void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

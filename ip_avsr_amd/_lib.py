@@ -90,6 +90,13 @@ _SIGNATURES = {
     "adn_op_delta_forward": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "adn_op_delta_backward": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "adn_op_adam": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, _P]),
+    "adn_prep_seq_deltas": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "adn_prep_diff_images": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P]),
+    "adn_prep_mean_image_subtraction": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P]),
+    "adn_prep_normalize_rows": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
+    "adn_prep_column_stats": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "adn_prep_apply_column_norm": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "adn_prep_gather_columns": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, _P]),
 }
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
 

@@ -206,4 +206,18 @@ static inline int lstm_ldk(int H) { return (int)((H + 31) / 32 * 32); }
 int lstm_backward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, int precision, hipStream_t s,
                   bool* sums_done = nullptr);
 
+// ---------------------------------------------------------------------------------------
+// feature front-end on the GPU (prep.hip; reference utils/preprocessing.py)
+// ---------------------------------------------------------------------------------------
+int prep_seq_deltas(const float* in, int ld_in, float* out, int ld_out, const int* first, const int* last, int n_frames, int F,
+                    int w, hipStream_t s);
+int prep_diff_images(const float* in, float* out, int ld, const int* first, const int* last, int n_frames, int D, hipStream_t s);
+int prep_mean_image_subtraction(const float* in, float* out, int ld, const int* starts, const int* lens, int n_utt, int D,
+                                hipStream_t s);
+int prep_normalize_rows(float* x, int ld, int rows, int cols, hipStream_t s);
+int prep_column_stats(const float* x, int ld, int rows, int cols, double* ws, float* mean, float* std, hipStream_t s);
+int prep_apply_column_norm(const float* x, float* out, int ld, int rows, int cols, const float* mean, const float* std,
+                           hipStream_t s);
+int prep_gather_columns(const float* in, int ld_in, float* out, int ld_out, const int* perm, int rows, int cols, hipStream_t s);
+
 }  // namespace adn

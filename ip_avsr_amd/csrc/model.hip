@@ -1368,4 +1368,33 @@ int adn_op_adam(float* p, const float* g, float* m, float* v, int64_t n, float a
     return adam_update(p, g, m, v, n, a_t, kBeta1, kBeta2, kEps, static_cast<hipStream_t>(hip_stream));
 }
 
+// ---- feature front-end (prep.hip) ----------------------------------------------------------------
+int adn_prep_seq_deltas(const float* in, int ld_in, float* out, int ld_out, const int32_t* first, const int32_t* last,
+                        int n_frames, int F, int w, void* hip_stream) {
+    return prep_seq_deltas(in, ld_in, out, ld_out, first, last, n_frames, F, w, static_cast<hipStream_t>(hip_stream));
+}
+int adn_prep_diff_images(const float* in, float* out, int ld, const int32_t* first, const int32_t* last, int n_frames, int D,
+                         void* hip_stream) {
+    return prep_diff_images(in, out, ld, first, last, n_frames, D, static_cast<hipStream_t>(hip_stream));
+}
+int adn_prep_mean_image_subtraction(const float* in, float* out, int ld, const int32_t* starts, const int32_t* lens, int n_utt,
+                                    int D, void* hip_stream) {
+    return prep_mean_image_subtraction(in, out, ld, starts, lens, n_utt, D, static_cast<hipStream_t>(hip_stream));
+}
+int adn_prep_normalize_rows(float* x, int ld, int rows, int cols, void* hip_stream) {
+    return prep_normalize_rows(x, ld, rows, cols, static_cast<hipStream_t>(hip_stream));
+}
+int adn_prep_column_stats(const float* x, int ld, int rows, int cols, double* workspace, float* mean, float* std,
+                          void* hip_stream) {
+    return prep_column_stats(x, ld, rows, cols, workspace, mean, std, static_cast<hipStream_t>(hip_stream));
+}
+int adn_prep_apply_column_norm(const float* x, float* out, int ld, int rows, int cols, const float* mean, const float* std,
+                               void* hip_stream) {
+    return prep_apply_column_norm(x, out, ld, rows, cols, mean, std, static_cast<hipStream_t>(hip_stream));
+}
+int adn_prep_gather_columns(const float* in, int ld_in, float* out, int ld_out, const int32_t* perm, int rows, int cols,
+                            void* hip_stream) {
+    return prep_gather_columns(in, ld_in, out, ld_out, perm, rows, cols, static_cast<hipStream_t>(hip_stream));
+}
+
 }  // extern "C"

@@ -47,6 +47,11 @@ int main(int argc, char** argv) {
         {"xproj K=250 lean", GEMM_NN, R, 1000, 250, 1, 0, 0, 0, 0},
         {"fwd fc2 lean", GEMM_NN, R, 1000, 2000, 1, 0, 0, 0, 1},
         {"fwd fc3 lean", GEMM_NN, R, 500, 1000, 1, 0, 0, 0, 1},
+        {"x3 fwd fc1 bias+relu lean", GEMM_NN, 3 * R, 2000, 1200, 1, 0, 0, 0, 1},
+        {"x3 dX fc2 lean y colsum", GEMM_NN, 3 * R, 2000, 1000, 1, 0, 1, 1, 0},
+        {"x3 fwd fc2 lean", GEMM_NN, 3 * R, 1000, 2000, 1, 0, 0, 0, 1},
+        {"x3 fwd fc3 lean", GEMM_NN, 3 * R, 500, 1000, 1, 0, 0, 0, 1},
+        {"x3 dX fc3 lean y colsum", GEMM_NN, 3 * R, 1000, 500, 1, 0, 1, 1, 0},
         {"dW fc1 TN acc", GEMM_TN, 1200, 2000, R, 0, 1, 0, 0, 0},
         {"dW fc2 TN acc", GEMM_TN, 2000, 1000, R, 0, 1, 0, 0, 0},
         {"dW fc3 TN acc", GEMM_TN, 1000, 500, R, 0, 1, 0, 0, 0},
