@@ -61,7 +61,19 @@ typedef enum {
                               weights / activations / recurrence / optimiser (BASELINE configs[1]: bf16) */
 } adn_precision;
 
-enum { ADN_FLAG_DEVICE_INPUTS = 1, ADN_FLAG_DEVICE_OUTPUTS = 2 };
+enum {
+    ADN_FLAG_DEVICE_INPUTS = 1,
+    ADN_FLAG_DEVICE_OUTPUTS = 2,
+    ADN_FLAG_STOCHASTIC = 4,     /* adn_loss: dropout layers active (compute_train_cost, runners/3stream.py:372) */
+    ADN_FLAG_DETERMINISTIC = 8   /* adn_compute_grads / adn_train_step: dropout layers off (they are on by default) */
+};
+
+/* what the classifier sees and how it is trained */
+typedef enum {
+    ADN_HEAD_FRAMES = 0, /* softmax on every frame, temporal_softmax_loss, majority vote (adenet_v2.py:77-92) */
+    ADN_HEAD_LAST = 1    /* SliceLayer(-1) + softmax on the last time step, categorical cross-entropy
+                            (modelzoo/adenet_v3.py:180-186, deltanet.py:48-56, avletters/trimodal.py:327-328) */
+} adn_head;
 
 /* which flat buffer a tensor accessor addresses */
 typedef enum { ADN_BUF_PARAM = 0, ADN_BUF_GRAD = 1, ADN_BUF_ADAM_M = 2, ADN_BUF_ADAM_V = 3 } adn_buffer;
@@ -76,6 +88,7 @@ typedef struct {
     int32_t use_delta;                       /* DeltaLayer present */
     int32_t bidirectional;                   /* 0: LSTMLayer, 1: forward+backward LSTMLayer summed */
     int32_t peepholes;
+    float dropout_p;                         /* DropoutLayer ahead of the stream's LSTM (adenet_v3.py:112,123,134); 0: none */
 } adn_stream_config;
 
 /* the whole graph: S streams -> fusion -> aggregation (B)LSTM -> per-timestep softmax
@@ -91,7 +104,9 @@ typedef struct {
     int32_t lstm_size;       /* H, all LSTMs */
     int32_t classes;         /* C <= ADN_MAX_CLASSES */
     int32_t precision;       /* adn_precision */
-    int32_t reserved[8];
+    int32_t head;            /* adn_head */
+    float agg_dropout_p;     /* DropoutLayer on the fused tensor (adenet_v3.py:154); 0: none */
+    int32_t reserved[6];
 } adn_config;
 
 typedef struct adn_model adn_model;
@@ -192,6 +207,15 @@ int adn_profile_read(adn_model* m, adn_profile_entry* out, int max_entries, int*
 
 /* ---- operator-level entry points (used by the parity tests and micro-benchmarks) -------------- */
 /* C (+)= op(A)*op(B) on device pointers; layout 0 = NN, 1 = NT (B given as [N][K]), 2 = TN (A as [K][M]) */
+/* dropout masks are a counter-based hash of (seed, counter, layer, element): set both to reproduce a draw; the counter
+ * advances by one after every stochastic forward pass */
+int adn_set_dropout_state(adn_model* m, uint32_t seed, uint32_t counter);
+/* <- lasagne.updates.sgd / momentum / nesterov_momentum (avletters/bimodal.py:446-455): momentum 0 = plain sgd; the
+ * velocity lives in the ADN_BUF_ADAM_M buffer */
+int adn_apply_sgd(adn_model* m, float learning_rate, float momentum, int nesterov);
+/* <- lasagne.updates.adadelta (avletters/avletters_convae.py:230); accumulators in ADN_BUF_ADAM_M / ADN_BUF_ADAM_V */
+int adn_apply_adadelta(adn_model* m, float learning_rate, float rho, float epsilon);
+
 int adn_op_gemm(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                 int ldc, const float* bias, int act, int accumulate, void* hip_stream);
 int adn_op_gemm_ex(int layout, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,

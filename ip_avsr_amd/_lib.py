@@ -20,6 +20,9 @@ ACT = {"linear": 0, "identity": 0, "rectify": 1, "sigmoid": 2, "tanh": 3, "leaky
 FUSION = {"none": 0, "sum": 1, "adasum": 2, "concat": 3}
 PRECISION = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 FLAG_DEVICE_INPUTS = 1
+FLAG_STOCHASTIC = 4
+FLAG_DETERMINISTIC = 8
+HEAD = {"frames": 0, "last": 1}
 FLAG_DEVICE_OUTPUTS = 2
 BUF_PARAM, BUF_GRAD, BUF_ADAM_M, BUF_ADAM_V = 0, 1, 2, 3
 
@@ -27,14 +30,15 @@ BUF_PARAM, BUF_GRAD, BUF_ADAM_M, BUF_ADAM_V = 0, 1, 2, 3
 class StreamConfig(C.Structure):
     _fields_ = [("input_dim", C.c_int32), ("n_enc", C.c_int32),
                 ("enc_units", C.c_int32 * ADN_MAX_ENC_LAYERS), ("enc_act", C.c_int32 * ADN_MAX_ENC_LAYERS),
-                ("use_delta", C.c_int32), ("bidirectional", C.c_int32), ("peepholes", C.c_int32)]
+                ("use_delta", C.c_int32), ("bidirectional", C.c_int32), ("peepholes", C.c_int32),
+                ("dropout_p", C.c_float)]
 
 
 class Config(C.Structure):
     _fields_ = [("n_streams", C.c_int32), ("streams", StreamConfig * ADN_MAX_STREAMS),
                 ("fusion", C.c_int32), ("agg", C.c_int32), ("agg_peepholes", C.c_int32),
                 ("lstm_size", C.c_int32), ("classes", C.c_int32), ("precision", C.c_int32),
-                ("reserved", C.c_int32 * 8)]
+                ("head", C.c_int32), ("agg_dropout_p", C.c_float), ("reserved", C.c_int32 * 6)]
 
 
 class ParamInfo(C.Structure):
@@ -90,6 +94,9 @@ _SIGNATURES = {
     "adn_op_delta_forward": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "adn_op_delta_backward": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "adn_op_adam": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, _P]),
+    "adn_set_dropout_state": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "adn_apply_sgd": (C.c_int, [_P, C.c_float, C.c_float, C.c_int]),
+    "adn_apply_adadelta": (C.c_int, [_P, C.c_float, C.c_float, C.c_float]),
     "adn_prep_seq_deltas": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "adn_prep_diff_images": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P]),
     "adn_prep_mean_image_subtraction": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P]),

@@ -148,6 +148,16 @@ int softmax_loss(const float* z, int ldz, int B, int T, int C, const uint8_t* ma
 int reduce_loss(const float* v, int n, const float* total, float* out, hipStream_t s);
 int adam_update(float* p, const float* g, float* m, float* v, int64_t n, float a_t, float beta1,
                 float beta2, float eps, hipStream_t s);
+// lasagne.updates.sgd (momentum == 0) / momentum / nesterov_momentum; adadelta
+int sgd_update(float* p, const float* g, float* vel, int64_t n, float lr, float momentum, int nesterov, hipStream_t s);
+int adadelta_update(float* p, const float* g, float* accu, float* delta, int64_t n, float lr, float rho, float eps, hipStream_t s);
+// DropoutLayer on a time-major [T*B][ld] matrix that is the column block [off, off+cols) of a `width`-wide (B,T,width)
+// tensor; in == out allowed; the mask is a hash of (seed, counter, layer, element) shared with the oracle
+int dropout_apply(const float* in, int ld_in, float* out, int ld_out, int B, int T, int cols, int width, int off, float p,
+                  uint32_t seed, uint32_t counter, uint32_t layer, hipStream_t s);
+// last-timestep head: softmax + categorical cross-entropy over B rows (label = y_bt[b*T]); dz scaled by 1/total[0]
+int softmax_ce(const float* z, int ldz, int B, int T, int C, const int32_t* y_bt, const float* total, float* probs,
+               float* row_loss, float* dz, int lddz, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
 // LSTM recurrence (lstm.hip).  All matrices time-major; gate columns interleaved (unit, gate).

@@ -264,6 +264,147 @@ int add_row_blocks(const float* src, float* dst, int ld, int nblk, int rows_vali
     return ADN_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// DropoutLayer (lasagne, rescale=True; modelzoo/adenet_v3.py:112,123,134,154): out = x * keep / (1 - p).  The mask is
+// a counter-based hash of (seed, call counter, layer id, element index in (B,T,width) C order) -- the same function
+// as oracle/adenet_oracle.py::dropout_uniform, so both draw identical masks; backward re-derives it instead of
+// storing it.  The matrix is time-major (row t*B + b) and may be a column block [off, off + cols) of a `width`-wide
+// logical tensor (the concat of the stream outputs).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool dropout_keep(uint32_t key, uint32_t idx, float p) {
+    uint32_t x = idx * 0x9E3779B1u + key;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return (float)(x >> 8) * (1.0f / 16777216.0f) >= p;
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const float* in, int ld_in, float* out, int ld_out,     // in == out allowed
+                                                      int B, int T, int cols, int width, int off, float p, float scale, uint32_t key) {
+    const int64_t total = (int64_t)B * T * cols;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % cols), r = (int)(e / cols), t = r / B, b = r % B;
+        const uint32_t idx = (uint32_t)(((int64_t)b * T + t) * width + off + c);
+        const float v = in[(size_t)r * ld_in + c];
+        out[(size_t)r * ld_out + c] = dropout_keep(key, idx, p) ? v * scale : 0.f;
+    }
+}
+
+int dropout_apply(const float* in, int ld_in, float* out, int ld_out, int B, int T, int cols, int width, int off, float p,
+                  uint32_t seed, uint32_t counter, uint32_t layer, hipStream_t s) {
+    ADN_CHECK(p >= 0.f && p < 1.f, ADN_ERR_INVALID, "dropout probability must be in [0, 1)");
+    const int64_t total = (int64_t)B * T * cols;
+    if (total <= 0) return ADN_OK;
+    const uint32_t key = seed ^ (layer * 0x85EBCA77u) ^ (counter * 0xC2B2AE3Du);
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, 16384));
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid), dim3(256), 0, s, in, ld_in, out, ld_out, B, T, cols, width, off, p,
+                       1.f / (1.f - p), key);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// last-timestep head: softmax over C classes of B rows + categorical cross-entropy
+// (lasagne.objectives.categorical_crossentropy(...).mean(), avletters/trimodal.py:327-328):
+//   probs[b] = softmax(z[b]);  row_loss[b] = -log probs[b][y_b];  dz[b] = (probs[b] - onehot(y_b)) / total
+// one wave per row, class on the lane (C <= 64)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ z, int ldz, int B, int T, int C,
+                                                         const int32_t* __restrict__ y_bt, const float* __restrict__ total,
+                                                         float* __restrict__ probs, float* __restrict__ row_loss,
+                                                         float* __restrict__ dz, int lddz) {
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float v = lane < C ? z[(size_t)b * ldz + lane] : -INFINITY;
+    float mx = v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    const float e = lane < C ? expf(v - mx) : 0.f;
+    float sum = e;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float pr = e / sum;
+    if (lane < C && probs) probs[(size_t)b * C + lane] = pr;
+    if (y_bt) {
+        const int y = y_bt[(size_t)b * T];                      // the label is repeated over T (runners/3stream.py:360-361)
+        if (row_loss && lane == y) row_loss[b] = -logf(pr);
+        if (dz && lane < C) dz[(size_t)b * lddz + lane] = (pr - (lane == y ? 1.f : 0.f)) / total[0];
+    }
+}
+
+int softmax_ce(const float* z, int ldz, int B, int T, int C, const int32_t* y_bt, const float* total, float* probs,
+               float* row_loss, float* dz, int lddz, hipStream_t s) {
+    ADN_CHECK(C >= 1 && C <= 64, ADN_ERR_INVALID, "softmax_ce: 1..64 classes");
+    if (B <= 0) return ADN_OK;
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, z, ldz, B, T, C, y_bt, total, probs, row_loss, dz, lddz);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// lasagne.updates.sgd / momentum / nesterov_momentum / adadelta on the flat buffers
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ vel,
+                                                  int64_t n4, float lr, float mu, int nesterov) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 P = reinterpret_cast<float4*>(p)[i];
+        const float4 G = reinterpret_cast<const float4*>(g)[i];
+        float* pp = reinterpret_cast<float*>(&P);
+        const float* gg = reinterpret_cast<const float*>(&G);
+        if (mu == 0.f) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pp[e] = pp[e] - lr * gg[e];
+        } else {
+            float4 V = reinterpret_cast<float4*>(vel)[i];
+            float* vv = reinterpret_cast<float*>(&V);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                vv[e] = mu * vv[e] - lr * gg[e];
+                pp[e] = pp[e] + (nesterov ? (mu * vv[e] - lr * gg[e]) : vv[e]);
+            }
+            reinterpret_cast<float4*>(vel)[i] = V;
+        }
+        reinterpret_cast<float4*>(p)[i] = P;
+    }
+}
+
+int sgd_update(float* p, const float* g, float* vel, int64_t n, float lr, float momentum, int nesterov, hipStream_t s) {
+    ADN_CHECK(n % 4 == 0, ADN_ERR_INVALID, "sgd_update: element count must be a multiple of 4");
+    if (!n) return ADN_OK;
+    const int64_t n4 = n / 4;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n4 + 255) / 256, 8192));
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, s, p, g, vel, n4, lr, momentum, nesterov);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+__global__ __launch_bounds__(256) void adadelta_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ accu,
+                                                       float* __restrict__ delta, int64_t n4, float lr, float rho, float eps) {
+    const float omr = 1.f - rho;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 P = reinterpret_cast<float4*>(p)[i], A = reinterpret_cast<float4*>(accu)[i], D = reinterpret_cast<float4*>(delta)[i];
+        const float4 G = reinterpret_cast<const float4*>(g)[i];
+        float *pp = reinterpret_cast<float*>(&P), *aa = reinterpret_cast<float*>(&A), *dd = reinterpret_cast<float*>(&D);
+        const float* gg = reinterpret_cast<const float*>(&G);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            aa[e] = rho * aa[e] + omr * gg[e] * gg[e];
+            const float upd = gg[e] * sqrtf(dd[e] + eps) / sqrtf(aa[e] + eps);
+            pp[e] = pp[e] - lr * upd;
+            dd[e] = rho * dd[e] + omr * upd * upd;
+        }
+        reinterpret_cast<float4*>(p)[i] = P; reinterpret_cast<float4*>(accu)[i] = A; reinterpret_cast<float4*>(delta)[i] = D;
+    }
+}
+
+int adadelta_update(float* p, const float* g, float* accu, float* delta, int64_t n, float lr, float rho, float eps, hipStream_t s) {
+    ADN_CHECK(n % 4 == 0, ADN_ERR_INVALID, "adadelta_update: element count must be a multiple of 4");
+    if (!n) return ADN_OK;
+    const int64_t n4 = n / 4;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n4 + 255) / 256, 8192));
+    hipLaunchKernelGGL(adadelta_kernel, dim3(grid), dim3(256), 0, s, p, g, accu, delta, n4, lr, rho, eps);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -452,17 +452,6 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_kernel(const LstmCluster
 static unsigned g_cluster_epoch = 1;
 static int* g_cluster_err = nullptr;       // device word, lazily allocated; polled after the launch by the caller's sync
 
-bool lstm_cluster_supported(const LstmStep* l, int n, int B, int T, int H) {
-    if (H > kCHP || T >= 1024 || getenv("ADN_LSTM_NO_CLUSTER")) return false;
-    for (int k = 0; k < n; ++k)
-        if (!l[k].xchg || !l[k].W_frag_fwd || !l[k].W_frag_bwd) return false;
-    return lstm_frag_elems(H) == (size_t)4 * kCHP * kCHP;
-}
-
-size_t lstm_cluster_xchg_bytes(int B) {          // forward region (h granules) + backward region (partial-dh granules)
-    return (size_t)cdiv(B, kCRows) * (2 * 16 * kCHP + 2 * 16 * kBxPair) * 8;
-}
-
 static int cluster_cus() {
     static int cus = 0;
     if (!cus) {
@@ -471,6 +460,18 @@ static int cluster_cus() {
         cus = prop.multiProcessorCount;
     }
     return cus;
+}
+
+bool lstm_cluster_supported(const LstmStep* l, int n, int B, int T, int H) {
+    if (H > kCHP || T >= 1024 || getenv("ADN_LSTM_NO_CLUSTER")) return false;
+    for (int k = 0; k < n; ++k)
+        if (!l[k].xchg || !l[k].W_frag_fwd || !l[k].W_frag_bwd) return false;
+    if (cdiv(B, kCRows) * kCWG > cluster_cus()) return false;     // every workgroup of one LSTM must be resident at once
+    return lstm_frag_elems(H) == (size_t)4 * kCHP * kCHP;
+}
+
+size_t lstm_cluster_xchg_bytes(int B) {          // forward region (h granules) + backward region (partial-dh granules)
+    return (size_t)cdiv(B, kCRows) * (2 * 16 * kCHP + 2 * 16 * kBxPair) * 8;
 }
 
 int lstm_cluster_error_word(int** out) {

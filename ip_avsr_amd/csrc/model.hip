@@ -129,6 +129,7 @@ struct StreamState {
     std::vector<LstmWork> lw;
     float* hsum = nullptr;                     // stream output when bidirectional (else alias of lw[0].out)
     float* dout_buf = nullptr;                 // own buffer for the gradient wrt the stream output
+    float* out_drop = nullptr;                 // stream output after the fused-tensor dropout (concat / single stream)
     int dout_ld = 0;                           // row stride of `dout` (0: ldh)
     float* dout = nullptr;                     // ... the buffer actually holding it (may be a shared one)
     float* dfeat = nullptr;
@@ -152,6 +153,15 @@ struct adn_model {
     float* flat[4] = {nullptr, nullptr, nullptr, nullptr};   // param, grad, m, v
     int adam_t = 0;
     bool grads_valid = false;
+    // stochastic layers: masks are a hash of (seed, counter, layer, element); `stochastic` is set per call
+    uint32_t drop_seed = 0x5EED1234u, drop_counter = 0;
+    bool stochastic = false;
+    bool head_last() const { return cfg.head == ADN_HEAD_LAST; }
+    bool has_dropout() const {
+        if (cfg.agg_dropout_p > 0.f) return true;
+        for (int k = 0; k < cfg.n_streams; ++k) if (cfg.streams[k].dropout_p > 0.f) return true;
+        return false;
+    }
 
     std::vector<StreamState> st;
     std::vector<LstmParams> agg;       // 0, 1 or 2
@@ -183,6 +193,7 @@ struct adn_model {
     // bf16 shadow copies of every GEMM operand (bf16 mode): fp32 range -> bf16 buffer with the same layout
     struct ShadowRange { const float* base; size_t n; char* shadow; };
     std::vector<ShadowRange> shadows;
+    std::vector<const float*> fused_in;     // what the aggregation layer read in the last forward pass (after dropout)
     char* params16 = nullptr;
     bool params16_dirty = true;
     // transposed bf16 copies of the weights that input-gradient GEMMs read as "B given [N][K]": with W^T [K][N]
@@ -265,6 +276,11 @@ int validate(const adn_config& c) {
     ADN_CHECK(c.lstm_size >= 1 && c.lstm_size <= 4096, ADN_ERR_INVALID, "lstm_size out of range");
     ADN_CHECK(c.classes >= 1 && c.classes <= ADN_MAX_CLASSES, ADN_ERR_INVALID, "classes out of range");
     ADN_CHECK(c.fusion >= ADN_FUSE_NONE && c.fusion <= ADN_FUSE_CONCAT, ADN_ERR_INVALID, "unknown fusion type");
+    ADN_CHECK(c.head == ADN_HEAD_FRAMES || c.head == ADN_HEAD_LAST, ADN_ERR_INVALID, "unknown classifier head");
+    ADN_CHECK(c.agg_dropout_p >= 0.f && c.agg_dropout_p < 1.f, ADN_ERR_INVALID, "dropout probability must be in [0, 1)");
+    for (int k = 0; k < c.n_streams; ++k)
+        ADN_CHECK(c.streams[k].dropout_p >= 0.f && c.streams[k].dropout_p < 1.f, ADN_ERR_INVALID,
+                  "dropout probability must be in [0, 1)");
     ADN_CHECK(c.agg >= 0 && c.agg <= 2, ADN_ERR_INVALID, "agg must be 0, 1 or 2");
     ADN_CHECK(c.precision == ADN_PRECISION_F32 || c.precision == ADN_PRECISION_BF16, ADN_ERR_INVALID,
               "unsupported precision");
@@ -396,6 +412,7 @@ size_t carve(adn_model* m, char* base, int B, int T, bool host_inputs) {
         st.hsum = take_shadowed(m, cv, N * ldh);
         st.dout_buf = cv.take<float>(N * ldh);
         st.dout = st.dout_buf;
+        if (m->cfg.agg_dropout_p > 0.f) st.out_drop = take_shadowed(m, cv, N * ldh);
     }
     m->aggw.resize(m->agg.size());
     for (auto& w : m->aggw) carve_lstm(m, cv, w, B, T, ldh, ldg);
@@ -676,6 +693,9 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
             a = st.act[l]; lda = g.ldc;
         }
         ADN_TRY(delta_forward(a, lda, st.feat, ld_of(st.feat_dim), B, T, st.enc_out, theta, st.cfg.use_delta, s));
+        if (m->stochastic && st.cfg.dropout_p > 0.f)             // DropoutLayer ahead of the LSTM (adenet_v3.py:112,123,134)
+            ADN_TRY(dropout_apply(st.feat, ld_of(st.feat_dim), st.feat, ld_of(st.feat_dim), B, T, st.feat_dim, st.feat_dim, 0,
+                                  st.cfg.dropout_p, m->drop_seed, m->drop_counter, (uint32_t)(&st - m->st.data()), s));
         ADN_TRY(refresh(m, st.feat, (size_t)N * ld_of(st.feat_dim)));
         for (size_t k = 0; k < st.lstm.size(); ++k) {
             const float* in[1] = {st.feat}; const int ld[1] = {ld_of(st.feat_dim)};
@@ -716,6 +736,18 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
         ADN_TRY(refresh(m, m->fused, (size_t)N * ldh));
         fin.push_back(m->fused); fld.push_back(ldh);
     }
+    if (m->stochastic && m->cfg.agg_dropout_p > 0.f) {          // dropout_agg on the fused tensor (adenet_v3.py:154)
+        const int W = (int)fin.size() * H;
+        for (size_t j = 0; j < fin.size(); ++j) {
+            // a stream output is also the LSTM's own state history: the dropped copy goes to a buffer of its own
+            float* dst = (fin[j] == m->fused) ? m->fused : m->st[j].out_drop;
+            ADN_TRY(dropout_apply(fin[j], ldh, dst, ldh, B, T, H, W, (int)j * H, m->cfg.agg_dropout_p, m->drop_seed,
+                                  m->drop_counter, 100u, s));
+            ADN_TRY(refresh(m, dst, (size_t)N * ldh));
+            fin[j] = dst;
+        }
+    }
+    m->fused_in = fin;
     const float* cls = nullptr;
     if (!m->agg.empty()) {                                       // custom/layers.py:55-80
         steps.clear();
@@ -743,6 +775,20 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
     } else {
         ADN_CHECK(fin.size() == 1, ADN_ERR_INVALID, "classifier needs a single fused tensor");
         cls = fin[0];
+    }
+    if (m->head_last()) {
+        // SliceLayer(-1) + Dense(C) + softmax on the LAST row of the padded tensor (adenet_v3.py:180-186, App. E-3);
+        // time-major: block T-1 is B contiguous rows
+        GemmArgs g;
+        g.layout = GEMM_NN; g.M = B; g.N = m->C; g.K = H; g.A = cls + (size_t)(T - 1) * B * ldh; g.lda = ldh;
+        g.B = m->P(m->smW); g.ldb = m->ldc; g.C = m->z; g.ldc = m->ldc; g.bias = m->P(m->smb);
+        ADN_TRY(mgemm(m, g));
+        ADN_TRY(softmax_ce(m->z, m->ldc, B, T, m->C, want_loss ? m->y_bt : nullptr, m->total, m->probs_bt,
+                           want_loss ? m->row_loss : nullptr, want_dz ? m->dz : nullptr, m->ldc, s));
+        if (want_dz) ADN_TRY(refresh(m, m->dz, (size_t)B * m->ldc));
+        if (want_loss) ADN_TRY(reduce_loss(m->row_loss, B, m->total, m->loss, s));
+        m->lastB = B; m->lastT = T;
+        return ADN_OK;
     }
     {   // Dense(C) + softmax per frame (modelzoo/adenet_v2.py:89-92)
         GemmArgs g;
@@ -811,6 +857,20 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
     ADN_HIP_CHECK(hipMemcpyAsync(m->flat[ADN_BUF_GRAD] + m->flat_floats, m->loss, sizeof(float),
                                  hipMemcpyDeviceToDevice, s));
     const float* cls = classifier_input(m, B);
+    if (m->head_last()) {   // classifier on the last time step only: every other row of d(cls) is zero
+        const float* cl = cls + (size_t)(T - 1) * B * ldh;
+        float* dl = m->dcls + (size_t)(T - 1) * B * ldh;
+        GemmArgs g;
+        g.layout = GEMM_TN; g.M = H; g.N = m->C; g.K = B; g.A = cl; g.lda = ldh; g.B = m->dz; g.ldb = m->ldc;
+        g.C = m->G(m->smW); g.ldc = m->ldc; g.accumulate = 1;
+        ADN_TRY(mgemm(m, g));
+        ADN_TRY(col_sum(m->dz, m->ldc, B, m->C, m->G(m->smb), 1, s));
+        ADN_HIP_CHECK(hipMemsetAsync(m->dcls, 0, (size_t)N * ldh * sizeof(float), s));
+        GemmArgs d;
+        d.layout = GEMM_NT; d.M = B; d.N = H; d.K = m->C; d.A = m->dz; d.lda = m->ldc; d.B = m->P(m->smW); d.ldb = m->ldc;
+        d.C = dl; d.ldc = ldh;
+        ADN_TRY(mgemm(m, d));
+    } else
     {   // classifier
         GemmArgs g;
         g.layout = GEMM_TN; g.M = H; g.N = m->C; g.K = N; g.A = cls; g.lda = ldh; g.B = m->dz; g.ldb = m->ldc;
@@ -828,6 +888,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
     std::vector<const float*> fin; std::vector<int> fld;
     if (per_stream_fused) for (auto& st : m->st) { fin.push_back(st.out_ptr); fld.push_back(ldh); }
     else { fin.push_back(m->fused); fld.push_back(ldh); }
+    if (m->fused_in.size() == fin.size()) fin = m->fused_in;   // (after the fused-tensor dropout, when it was active)
 
     // gradient wrt the fused tensor(s)
     std::vector<float*> dfin;          // one per entry of fin
@@ -873,6 +934,14 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
     } else {
         dfin.push_back(m->dcls);
     }
+    if (m->stochastic && m->cfg.agg_dropout_p > 0.f && !m->agg.empty()) {
+        const int W = (int)dfin.size() * H;
+        for (size_t j = 0; j < dfin.size(); ++j) {
+            const int ldd = (per_stream_fused && m->st[j].dout_ld) ? m->st[j].dout_ld : ldh;
+            ADN_TRY(dropout_apply(dfin[j], ldd, dfin[j], ldd, B, T, H, W, (int)j * H, m->cfg.agg_dropout_p, m->drop_seed,
+                                  m->drop_counter, 100u, s));
+        }
+    }
     // un-fuse: gradient wrt each stream's output
     for (int k = 0; k < m->S; ++k) {
         StreamState& st = m->st[k];
@@ -911,6 +980,9 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         if (st.cfg.n_enc == 0) { ADN_TRY(bucket_ready(1 + si)); continue; }   // nothing trainable below the LSTM
         for (size_t k = 0; k < st.lstm.size(); ++k)
             ADN_TRY(lstm_input_grad(m, st.lstm[k], st.lw[k], 0, st.feat_dim, st.dfeat, ldf, N, k > 0));
+        if (m->stochastic && st.cfg.dropout_p > 0.f)
+            ADN_TRY(dropout_apply(st.dfeat, ldf, st.dfeat, ldf, B, T, st.feat_dim, st.feat_dim, 0, st.cfg.dropout_p,
+                                  m->drop_seed, m->drop_counter, (uint32_t)si, s));
         const int ldE = ld_of(st.enc_out);
         ADN_TRY(delta_backward(st.dfeat, ldf, st.dE, ldE, B, T, st.enc_out, theta, st.cfg.use_delta, s));
         // encoder: dZ_l = dA_l * act_l'(A_l);  dW_l = A_{l-1}^T dZ_l;  dA_{l-1} = dZ_l W_l^T
@@ -952,6 +1024,17 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
 }
 
 __global__ void set_scalar_kernel(float* p, float v) { *p = v; }
+
+// the loss normaliser: valid frames of the batch (already there after mask_prepare), B for the last-timestep head, or
+// the caller's global count (data parallel)
+int set_loss_normaliser(adn_model* m, int B, double override_total) {
+    const double v = override_total > 0 ? override_total : (m->head_last() ? (double)B : 0.0);
+    if (v > 0) {
+        hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, m->stream, m->total, (float)v);
+        ADN_HIP_CHECK(hipGetLastError());
+    }
+    return ADN_OK;
+}
 
 int check_shape(const adn_model* m, int B, int T, int theta) {
     ADN_CHECK(m, ADN_ERR_INVALID, "null model");
@@ -1177,8 +1260,10 @@ int adn_forward(adn_model* m, const void* const* inputs, const uint8_t* mask, in
     ADN_CHECK(probs, ADN_ERR_INVALID, "null output");
     ADN_TRY(ensure_workspace(m, B, T));
     ADN_TRY(stage_inputs(m, inputs, nullptr, mask, B, T, flags));
+    m->stochastic = false;
     ADN_TRY(forward_pass(m, B, T, theta, false, false));
-    return fetch(m, probs, m->probs_bt, (size_t)B * T * m->C * sizeof(float), flags & ADN_FLAG_DEVICE_OUTPUTS);
+    const size_t rows = m->head_last() ? (size_t)B : (size_t)B * T;
+    return fetch(m, probs, m->probs_bt, rows * m->C * sizeof(float), flags & ADN_FLAG_DEVICE_OUTPUTS);
 }
 
 int adn_loss(adn_model* m, const void* const* inputs, const int32_t* targets, const uint8_t* mask, int B, int T,
@@ -1187,7 +1272,10 @@ int adn_loss(adn_model* m, const void* const* inputs, const int32_t* targets, co
     ADN_CHECK(targets && loss, ADN_ERR_INVALID, "null targets / loss");
     ADN_TRY(ensure_workspace(m, B, T));
     ADN_TRY(stage_inputs(m, inputs, targets, mask, B, T, flags));
+    ADN_TRY(set_loss_normaliser(m, B, 0.0));
+    m->stochastic = (flags & ADN_FLAG_STOCHASTIC) && m->has_dropout();
     ADN_TRY(forward_pass(m, B, T, theta, true, false));
+    if (m->stochastic) m->drop_counter += 1;
     return fetch(m, loss, m->loss, sizeof(float), flags & ADN_FLAG_DEVICE_OUTPUTS);
 }
 
@@ -1197,12 +1285,11 @@ int adn_compute_grads(adn_model* m, const void* const* inputs, const int32_t* ta
     ADN_CHECK(targets, ADN_ERR_INVALID, "null targets");
     ADN_TRY(ensure_workspace(m, B, T));
     ADN_TRY(stage_inputs(m, inputs, targets, mask, B, T, flags));
-    if (total_frames > 0) {
-        hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, m->stream, m->total, (float)total_frames);
-        ADN_HIP_CHECK(hipGetLastError());
-    }
+    ADN_TRY(set_loss_normaliser(m, B, total_frames));
+    m->stochastic = !(flags & ADN_FLAG_DETERMINISTIC) && m->has_dropout();
     ADN_TRY(forward_pass(m, B, T, theta, true, true));
     ADN_TRY(backward_pass(m, B, T, theta));
+    if (m->stochastic) m->drop_counter += 1;
     if (loss) return fetch(m, loss, m->loss, sizeof(float), flags & ADN_FLAG_DEVICE_OUTPUTS);
     return ADN_OK;
 }
@@ -1215,6 +1302,33 @@ int adn_apply_adam(adn_model* m, float learning_rate) {
     const float a_t = learning_rate * sqrtf(1.f - powf(kBeta2, t)) / (1.f - powf(kBeta1, t));
     ADN_TRY(adam_update(m->flat[ADN_BUF_PARAM], m->flat[ADN_BUF_GRAD], m->flat[ADN_BUF_ADAM_M], m->flat[ADN_BUF_ADAM_V],
                         (int64_t)m->flat_floats, a_t, kBeta1, kBeta2, kEps, m->stream));
+    m->grads_valid = false;
+    m->params16_dirty = true;
+    return ADN_OK;
+}
+
+int adn_set_dropout_state(adn_model* m, uint32_t seed, uint32_t counter) {
+    ADN_CHECK(m, ADN_ERR_INVALID, "null model");
+    m->drop_seed = seed; m->drop_counter = counter;
+    return ADN_OK;
+}
+
+int adn_apply_sgd(adn_model* m, float learning_rate, float momentum, int nesterov) {
+    ADN_CHECK(m, ADN_ERR_INVALID, "null model");
+    ADN_CHECK(m->grads_valid, ADN_ERR_STATE, "adn_apply_sgd called without gradients (call adn_compute_grads first)");
+    ADN_CHECK(momentum >= 0.f && momentum < 1.f, ADN_ERR_INVALID, "momentum must be in [0, 1)");
+    ADN_TRY(sgd_update(m->flat[ADN_BUF_PARAM], m->flat[ADN_BUF_GRAD], m->flat[ADN_BUF_ADAM_M], (int64_t)m->flat_floats,
+                       learning_rate, momentum, nesterov, m->stream));
+    m->grads_valid = false;
+    m->params16_dirty = true;
+    return ADN_OK;
+}
+
+int adn_apply_adadelta(adn_model* m, float learning_rate, float rho, float epsilon) {
+    ADN_CHECK(m, ADN_ERR_INVALID, "null model");
+    ADN_CHECK(m->grads_valid, ADN_ERR_STATE, "adn_apply_adadelta called without gradients (call adn_compute_grads first)");
+    ADN_TRY(adadelta_update(m->flat[ADN_BUF_PARAM], m->flat[ADN_BUF_GRAD], m->flat[ADN_BUF_ADAM_M], m->flat[ADN_BUF_ADAM_V],
+                            (int64_t)m->flat_floats, learning_rate, rho, epsilon, m->stream));
     m->grads_valid = false;
     m->params16_dirty = true;
     return ADN_OK;

@@ -30,3 +30,33 @@ def adam_vlr(model, lr_map):
     def step():
         model.apply_adam_vlr(lr_map)
     return step
+
+
+# lasagne.updates.* rules the last-timestep scripts select (avletters/bimodal.py:446-455, avletters/trimodal.py:330-336,
+# avletters/avletters_convae.py:230): same names and defaults, bound to a model like ``adam`` above
+def sgd(model, learning_rate):
+    def step():
+        model.apply_sgd(learning_rate)
+    return step
+
+
+def momentum(model, learning_rate, momentum=0.9):
+    mu = momentum
+
+    def step():
+        model.apply_sgd(learning_rate, mu)
+    return step
+
+
+def nesterov_momentum(model, learning_rate, momentum=0.9):
+    mu = momentum
+
+    def step():
+        model.apply_sgd(learning_rate, mu, nesterov=True)
+    return step
+
+
+def adadelta(model, learning_rate=1.0, rho=0.95, epsilon=1e-6):
+    def step():
+        model.apply_adadelta(learning_rate, rho, epsilon)
+    return step

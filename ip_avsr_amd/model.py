@@ -54,11 +54,15 @@ class AdeNetModel(object):
 
     ``spec`` is a plain dict::
 
-        streams      list of {input_dim, enc_names, enc_shapes, enc_acts, delta, lstm_names, peepholes}
-                     (lstm_names of length 2 = summed forward/backward pair)
+        streams      list of {input_dim, enc_names, enc_shapes, enc_acts, delta, lstm_names, peepholes[, dropout]}
+                     (lstm_names of length 2 = summed forward/backward pair; dropout = p of a DropoutLayer ahead of
+                     the stream's LSTM, modelzoo/adenet_v3.py:112)
         fusion       'none' | 'sum' | 'adasum' | 'concat' ; fuse_name (layer name of the merge layer)
         agg_names    [] | [name] | [forward_name, backward_name] ; agg_peepholes
         lstm_size, classes, softmax_name
+        head         'frames' (default: softmax on every frame, temporal_softmax_loss) | 'last' (SliceLayer(-1) +
+                     softmax, categorical cross-entropy: modelzoo/adenet_v3.py:180-186, deltanet.py:48-56)
+        agg_dropout  p of the DropoutLayer on the fused tensor (adenet_v3.py:154)
     """
 
     def __init__(self, spec, stream=None):
@@ -81,6 +85,7 @@ class AdeNetModel(object):
             sc.use_delta = int(bool(s["delta"]))
             sc.bidirectional = int(len(s["lstm_names"]) == 2)
             sc.peepholes = int(bool(s["peepholes"]))
+            sc.dropout_p = float(s.get("dropout", 0.0) or 0.0)
         if spec["fusion"] not in _lib.FUSION:
             # modelzoo/adenet_v2.py:75 raises for an unknown fusiontype (as a TypeError, through a
             # bug in the raise statement itself); here it is a plain ValueError
@@ -91,6 +96,9 @@ class AdeNetModel(object):
         cfg.lstm_size = int(spec["lstm_size"])
         cfg.classes = int(spec["classes"])
         cfg.precision = _lib.PRECISION[spec.get("precision", "f32")]
+        cfg.head = _lib.HEAD[spec.get("head", "frames")]
+        cfg.agg_dropout_p = float(spec.get("agg_dropout", 0.0) or 0.0)
+        self.head = spec.get("head", "frames")
         self._handle = C.c_void_p()
         _lib.check(self._lib.adn_create(C.byref(cfg), C.byref(self._handle)))
         self.S, self.H, self.C = S, cfg.lstm_size, cfg.classes
@@ -294,22 +302,32 @@ class AdeNetModel(object):
         return ptrs, mp, tp, B, T, flags, keep
 
     def predict(self, inputs, mask, window):
-        """val_fn: probabilities (B,T,C) float32."""
+        """val_fn (deterministic): probabilities (B,T,C) float32 -- (B,C) for the last-timestep head."""
         ptrs, mp, _, B, T, flags, keep = self._prep(inputs, mask)
-        out = np.empty((B, T, self.C), dtype=np.float32)
+        out = np.empty((B, self.C) if self.head == "last" else (B, T, self.C), dtype=np.float32)
         _lib.check(self._lib.adn_forward(self._handle, ptrs, mp, B, T, int(window), flags,
                                          out.ctypes.data_as(C.c_void_p)))
         return out
 
-    def loss(self, inputs, targets, mask, window):
-        """compute_train_cost / compute_test_cost (no stochastic layers on this path: identical)."""
+    def loss(self, inputs, targets, mask, window, deterministic=True):
+        """compute_test_cost (deterministic=True) / compute_train_cost (False: dropout layers active, the
+        reference's get_output(network, deterministic=False))."""
         ptrs, mp, tp, B, T, flags, keep = self._prep(inputs, mask, targets)
+        if not deterministic:
+            flags |= _lib.FLAG_STOCHASTIC
         out = C.c_float()
         _lib.check(self._lib.adn_loss(self._handle, ptrs, tp, mp, B, T, int(window), flags, C.byref(out)))
         return np.float32(out.value)
 
-    def compute_grads(self, inputs, targets, mask, window, total_frames=0.0, want_loss=True):
+    def set_dropout_state(self, seed, counter=0):
+        """Dropout masks are a hash of (seed, counter, layer, element); the counter advances after every stochastic
+        pass.  Setting both reproduces a draw (the oracle uses the same function)."""
+        _lib.check(self._lib.adn_set_dropout_state(self._handle, int(seed) & 0xFFFFFFFF, int(counter) & 0xFFFFFFFF))
+
+    def compute_grads(self, inputs, targets, mask, window, total_frames=0.0, want_loss=True, deterministic=False):
         ptrs, mp, tp, B, T, flags, keep = self._prep(inputs, mask, targets)
+        if deterministic:
+            flags |= _lib.FLAG_DETERMINISTIC
         out = C.c_float()
         _lib.check(self._lib.adn_compute_grads(self._handle, ptrs, tp, mp, B, T, int(window), flags,
                                                float(total_frames), C.byref(out) if want_loss else None))
@@ -317,6 +335,14 @@ class AdeNetModel(object):
 
     def apply_adam(self, learning_rate):
         _lib.check(self._lib.adn_apply_adam(self._handle, float(learning_rate)))
+
+    def apply_sgd(self, learning_rate, momentum=0.0, nesterov=False):
+        """lasagne.updates.sgd / momentum / nesterov_momentum on the gradients of the last compute_grads."""
+        _lib.check(self._lib.adn_apply_sgd(self._handle, float(learning_rate), float(momentum), int(bool(nesterov))))
+
+    def apply_adadelta(self, learning_rate=1.0, rho=0.95, epsilon=1e-6):
+        """lasagne.updates.adadelta on the gradients of the last compute_grads."""
+        _lib.check(self._lib.adn_apply_adadelta(self._handle, float(learning_rate), float(rho), float(epsilon)))
 
     def apply_adam_vlr(self, lr_map, default=None):
         """Adam with per-layer learning rates: ``lr_map`` maps Param handles or parameter names to rates
@@ -360,9 +386,10 @@ class AdeNetModel(object):
         return out
 
     # ------------------------------------------------------------------ the four "compiled functions"
-    def compile(self, learning_rate, order="inputs,targets,mask,window"):
+    def compile(self, learning_rate, order="inputs,targets,mask,window", updates="adam", **update_args):
         """Returns (train, compute_train_cost, compute_test_cost, val_fn) taking positional arguments in
-        the order the reference script compiled them with:
+        the order the reference script compiled them with (``updates``: 'adam' | 'sgd' | 'momentum' |
+        'nesterov_momentum' | 'adadelta', the lasagne.updates function the script called):
             3stream/4stream: 'inputs,targets,mask,window'   (runners/3stream.py:309-320)
             2stream:         'in1,targets,mask,in2,window'  (runners/2stream.py:280-291)
             1stream:         'inputs,targets,mask,window'   (runners/1stream.py:236-247)
@@ -387,11 +414,26 @@ class AdeNetModel(object):
                 (mask, window), targets = rest, None
             return ins, targets, mask, window
 
+        if updates not in ("adam", "sgd", "momentum", "nesterov_momentum", "adadelta"):
+            raise ValueError("unknown update rule %r" % (updates,))
+
         def train(*args):
             ins, t, m, w = split(args, True)
-            return self.train_step(ins, t, m, w, lr)
+            if updates == "adam":
+                return self.train_step(ins, t, m, w, lr)
+            cost_ = self.compute_grads(ins, t, m, w)
+            if updates == "adadelta":
+                self.apply_adadelta(lr, update_args.get("rho", 0.95), update_args.get("epsilon", 1e-6))
+            else:
+                self.apply_sgd(lr, 0.0 if updates == "sgd" else update_args.get("momentum", 0.9),
+                               updates == "nesterov_momentum")
+            return cost_
 
-        def cost(*args):
+        def train_cost(*args):                       # get_output(network, deterministic=False): dropout active
+            ins, t, m, w = split(args, True)
+            return self.loss(ins, t, m, w, deterministic=False)
+
+        def test_cost(*args):
             ins, t, m, w = split(args, True)
             return self.loss(ins, t, m, w)
 
@@ -399,4 +441,4 @@ class AdeNetModel(object):
             ins, _, m, w = split(args, False)
             return self.predict(ins, m, w)
 
-        return train, cost, cost, val_fn
+        return train, train_cost, test_cost, val_fn

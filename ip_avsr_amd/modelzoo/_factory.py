@@ -28,12 +28,28 @@ def input_dim_of(shape):
     return int(shape[-1])
 
 
+def nolearn_weights(ae, shapes=(2000, 1000, 500, 50), nonlinearities=("sigmoid", "sigmoid", "sigmoid", "linear")):
+    """``extract_weights`` of the last-timestep zoo modules (modelzoo/adenet_v3.py:48-61): a nolearn network object
+    (``.get_all_layers()[1..4].W/.b``) -> the 4-tuple this package passes around.  A 4-tuple or a (weights, biases)
+    pair passes through."""
+    if isinstance(ae, (tuple, list)):
+        if len(ae) == 4:
+            return tuple(ae)
+        weights, biases = ae
+    else:
+        layers = ae.get_all_layers()
+        weights = [np.asarray(layers[i].W, "float32") for i in range(1, len(shapes) + 1)]
+        biases = [np.asarray(layers[i].b, "float32") for i in range(1, len(shapes) + 1)]
+    shapes = [int(np.asarray(w).shape[1]) for w in weights]
+    return list(weights), list(biases), shapes, list(nonlinearities)[:len(shapes) - 1] + ["linear"]
+
+
 def stream(input_shape, ae=None, suffix="", delta=True, lstm_names=("lstm",), peepholes=False, enc_names=None,
-           pretrained_lstm=None, pretrained_prefixes=None):
+           pretrained_lstm=None, pretrained_prefixes=None, dropout=0.0):
     """One stream description.  ``ae`` = (weights, biases, shapes, nonlinearities) like
     ``load_decoder`` returns (runners/3stream.py:31-40) or None for an encoder-less stream."""
     d = dict(input_dim=input_dim_of(input_shape), delta=bool(delta), lstm_names=list(lstm_names),
-             peepholes=bool(peepholes), pretrained_lstm=pretrained_lstm,
+             peepholes=bool(peepholes), dropout=float(dropout), pretrained_lstm=pretrained_lstm,
              pretrained_prefixes=list(pretrained_prefixes or []))
     if ae is None:
         d.update(enc_names=[], enc_shapes=[], enc_acts=[], enc_weights=[], enc_biases=[])
@@ -67,13 +83,14 @@ def _load_pretrained_lstm(model, name, weights, prefix):
 
 
 def build(streams, lstm_size, output_classes, fusiontype, fuse_names, agg_names, agg_peepholes, w_init_fn,
-          softmax_name="softmax", return_fuse=True):
+          softmax_name="softmax", return_fuse=True, head="frames", agg_dropout=0.0):
     if fusiontype not in ("none", "sum", "adasum", "concat"):
         # modelzoo/adenet_v2.py:74-75 (other factories fall through to a NameError)
         raise ValueError("Unsupported Fusion Type used!")
     spec = dict(
         streams=[{k: s[k] for k in ("input_dim", "enc_names", "enc_shapes", "enc_acts", "delta", "lstm_names",
-                                    "peepholes")} for s in streams],
+                                    "peepholes", "dropout")} for s in streams],
+        head=head, agg_dropout=float(agg_dropout),
         fusion=fusiontype, fuse_name=fuse_names.get(fusiontype, ""), agg_names=list(agg_names),
         agg_peepholes=bool(agg_peepholes), lstm_size=int(lstm_size), classes=int(output_classes),
         softmax_name=softmax_name)

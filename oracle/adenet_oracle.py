@@ -372,8 +372,42 @@ def init_params(spec, rng, dtype=np.float32, enc_std=0.01, perturb=0.0):
 # --------------------------------------------------------------------------- #
 # whole model: forward / loss / backward / Adam
 # --------------------------------------------------------------------------- #
-def forward(spec, p, inputs, mask, theta, want_cache=False):
-    """inputs: list of (B,T,D_s).  Returns probs (B,T,C) [, cache].
+# --------------------------------------------------------------------------- #
+# DropoutLayer [upstream lasagne.layers.DropoutLayer, rescale=True]: out = x * mask / (1 - p) with
+# mask ~ Bernoulli(1 - p) per element of the (B,T,F) tensor (modelzoo/adenet_v3.py:112,123,134,154).
+# Theano's MRG stream cannot be reproduced; the mask is DEFINED here by a counter-based integer hash of
+# (seed, call counter, layer id, element index in (B,T,F) C order) so that the HIP path and this oracle draw
+# the same mask bit for bit (csrc/elementwise.hip::dropout_keep).
+# --------------------------------------------------------------------------- #
+DROPOUT_AGG_LAYER = 100
+
+
+def dropout_uniform(seed, counter, layer, idx):
+    """uint32 hash -> uniform in [0,1) with 24 bits (idx: array of element indices)."""
+    with np.errstate(over="ignore"):
+        k = np.uint32(seed & 0xFFFFFFFF) ^ np.uint32((layer * 0x85EBCA77) & 0xFFFFFFFF) ^ \
+            np.uint32((counter * 0xC2B2AE3D) & 0xFFFFFFFF)
+        x = np.asarray(idx).astype(np.uint32) * np.uint32(0x9E3779B1) + k
+        x ^= x >> np.uint32(16)
+        x *= np.uint32(0x7FEB352D)
+        x ^= x >> np.uint32(15)
+        x *= np.uint32(0x846CA68B)
+        x ^= x >> np.uint32(16)
+    return (x >> np.uint32(8)).astype(np.float64) * (1.0 / 16777216.0)
+
+
+def dropout_scale(shape, prob, dropout, layer, dtype):
+    """mask / (1 - p) for a (B,T,F) tensor; ones when deterministic (dropout is None) or p == 0."""
+    if dropout is None or not prob:
+        return np.ones(shape, dtype)
+    idx = np.arange(int(np.prod(shape)), dtype=np.uint64).reshape(shape)
+    keep = dropout_uniform(dropout["seed"], dropout.get("counter", 0), layer, idx) >= np.float32(prob)
+    return keep.astype(dtype) * (dtype(1) / (dtype(1) - dtype(prob)))
+
+
+def forward(spec, p, inputs, mask, theta, want_cache=False, dropout=None):
+    """inputs: list of (B,T,D_s).  Returns probs (B,T,C) -- (B,C) for the last-timestep head -- [, cache].
+    dropout: None = deterministic; dict(seed=, counter=) = stochastic layers active.
     Graph: modelzoo/adenet_v2.py:30-92, adenet_3stream.py:166-262, adenet_4stream.py:37-157,
     avnet.py:43-112, deltanet_majority_vote.py:31-66 (S=1, no aggregation layer)."""
     B, T = mask.shape
@@ -390,6 +424,8 @@ def forward(spec, p, inputs, mask, theta, want_cache=False):
         sc["enc_out"] = feat
         if s["delta"]:
             feat = delta_append(feat, theta)
+        sc["drop"] = dropout_scale(feat.shape, s.get("dropout", 0.0), dropout, len(outs), feat.dtype.type)
+        feat = feat * sc["drop"]                              # DropoutLayer ahead of the stream LSTM (adenet_v3.py:112)
         sc["lstm_in"] = feat
         h = None
         sc["lstm"] = []
@@ -411,6 +447,9 @@ def forward(spec, p, inputs, mask, theta, want_cache=False):
         fused = outs[0]
     else:
         raise ValueError(fusion)
+    cache["fused_drop"] = dropout_scale(fused.shape, spec.get("agg_dropout", 0.0), dropout, DROPOUT_AGG_LAYER,
+                                        fused.dtype.type)
+    fused = fused * cache["fused_drop"]                       # dropout_agg (adenet_v3.py:154)
     cache["fused"] = fused
     cache["agg"] = []
     if spec["agg_names"]:
@@ -423,32 +462,57 @@ def forward(spec, p, inputs, mask, theta, want_cache=False):
         hsum = fused
     cache["hsum"] = hsum
     sm = spec["softmax_name"]
-    probs = softmax_rows(hsum.reshape(B * T, H) @ p[sm + ".W"] + p[sm + ".b"]).reshape(B, T, -1)
+    if spec.get("head", "frames") == "last":
+        # SliceLayer(l_sum2, -1, 1) + DenseLayer(softmax) (adenet_v3.py:180-186, deltanet.py:48-56): the LAST row of
+        # the padded tensor -- held last-valid state of the forward LSTM, first step of the backward one (App. E-3)
+        probs = softmax_rows(hsum[:, T - 1, :] @ p[sm + ".W"] + p[sm + ".b"])
+    else:
+        probs = softmax_rows(hsum.reshape(B * T, H) @ p[sm + ".W"] + p[sm + ".b"]).reshape(B, T, -1)
     cache["probs"] = probs
     return (probs, cache) if want_cache else probs
 
 
-def loss_and_grads(spec, p, inputs, targets, mask, theta, total_frames=None):
+def cross_entropy_loss(probs, y, total=None):
+    """lasagne.objectives.categorical_crossentropy(pred, targets).mean() on (B,C) probabilities
+    (avletters/trimodal.py:327-328); `total` overrides the batch size (data parallel)."""
+    B = probs.shape[0]
+    return -np.log(probs[np.arange(B), y]).sum() / (B if total is None else total)
+
+
+def loss_and_grads(spec, p, inputs, targets, mask, theta, total_frames=None, dropout=None):
     """targets (B,T) int (label repeated over T, runners/3stream.py:360-361)."""
     B, T = mask.shape
     H = spec["lstm_size"]
-    probs, cache = forward(spec, p, inputs, mask, theta, want_cache=True)
-    loss = temporal_softmax_loss(probs, targets, mask, total_frames)
+    probs, cache = forward(spec, p, inputs, mask, theta, want_cache=True, dropout=dropout)
     g = {}
-    dp = temporal_softmax_loss_bwd(probs, targets, mask, total_frames).reshape(B * T, -1)
-    pf = probs.reshape(B * T, -1)
-    dz = pf * (dp - (dp * pf).sum(1, keepdims=True))       # through the network's own softmax
     sm = spec["softmax_name"]
-    hs = cache["hsum"].reshape(B * T, H)
-    g[sm + ".W"] = hs.T @ dz
-    g[sm + ".b"] = dz.sum(0)
-    dhsum = (dz @ p[sm + ".W"].T).reshape(B, T, H)
+    if spec.get("head", "frames") == "last":
+        y = np.asarray(targets)[:, 0]
+        loss = cross_entropy_loss(probs, y, total_frames)
+        dz = probs.copy()
+        dz[np.arange(B), y] -= 1
+        dz = dz / (B if total_frames is None else total_frames)     # softmax + cross-entropy
+        hl = cache["hsum"][:, T - 1, :]
+        g[sm + ".W"] = hl.T @ dz
+        g[sm + ".b"] = dz.sum(0)
+        dhsum = np.zeros((B, T, H), dtype=dz.dtype)
+        dhsum[:, T - 1, :] = dz @ p[sm + ".W"].T
+    else:
+        loss = temporal_softmax_loss(probs, targets, mask, total_frames)
+        dp = temporal_softmax_loss_bwd(probs, targets, mask, total_frames).reshape(B * T, -1)
+        pf = probs.reshape(B * T, -1)
+        dz = pf * (dp - (dp * pf).sum(1, keepdims=True))       # through the network's own softmax
+        hs = cache["hsum"].reshape(B * T, H)
+        g[sm + ".W"] = hs.T @ dz
+        g[sm + ".b"] = dz.sum(0)
+        dhsum = (dz @ p[sm + ".W"].T).reshape(B, T, H)
     if spec["agg_names"]:
         dfused = 0
         for lc in cache["agg"]:
             dfused = dfused + lstm_bwd(dhsum, lc, p, g)
     else:
         dfused = dhsum
+    dfused = dfused * cache["fused_drop"]
     S = len(spec["streams"])
     for k, (s, sc) in enumerate(zip(spec["streams"], cache["streams"])):
         if spec["fusion"] == "concat":
@@ -462,6 +526,7 @@ def loss_and_grads(spec, p, inputs, targets, mask, theta, total_frames=None):
         dfeat = 0
         for lc in sc["lstm"]:
             dfeat = dfeat + lstm_bwd(dh, lc, p, g)
+        dfeat = dfeat * sc["drop"]
         if s["delta"]:
             dfeat = delta_append_bwd(dfeat, theta)
         da = dfeat.reshape(B * T, -1)
@@ -490,6 +555,42 @@ def adam_step(p, g, state, lr, beta1=0.9, beta2=0.999, eps=1e-8):
         state["m"][k] = dt(beta1) * state["m"][k] + (dt(1) - dt(beta1)) * g[k]
         state["v"][k] = dt(beta2) * state["v"][k] + (dt(1) - dt(beta2)) * g[k] * g[k]
         p[k] = p[k] - a_t * state["m"][k] / (np.sqrt(state["v"][k]) + dt(eps))
+    return p
+
+
+def sgd_step(p, g, lr):
+    """lasagne.updates.sgd [upstream]: p -= lr * g."""
+    for k in p:
+        p[k] = p[k] - p[k].dtype.type(lr) * g[k]
+    return p
+
+
+def momentum_init(p):
+    return {k: np.zeros_like(v) for k, v in p.items()}
+
+
+def momentum_step(p, g, vel, lr, momentum=0.9, nesterov=False):
+    """lasagne.updates.momentum / nesterov_momentum [upstream] (avletters/bimodal.py:446-455):
+    v = mu v - lr g;  p += v   (classic)      p += mu v - lr g   (Nesterov, with the NEW v)."""
+    for k in p:
+        dt = p[k].dtype.type
+        vel[k] = dt(momentum) * vel[k] - dt(lr) * g[k]
+        p[k] = p[k] + (dt(momentum) * vel[k] - dt(lr) * g[k] if nesterov else vel[k])
+    return p
+
+
+def adadelta_init(p):
+    return dict(accu={k: np.zeros_like(v) for k, v in p.items()}, delta={k: np.zeros_like(v) for k, v in p.items()})
+
+
+def adadelta_step(p, g, state, lr=1.0, rho=0.95, eps=1e-6):
+    """lasagne.updates.adadelta [upstream] (avletters/avletters_convae.py:230 uses lr 0.8, rho default)."""
+    for k in p:
+        dt = p[k].dtype.type
+        state["accu"][k] = dt(rho) * state["accu"][k] + (dt(1) - dt(rho)) * g[k] * g[k]
+        upd = g[k] * np.sqrt(state["delta"][k] + dt(eps)) / np.sqrt(state["accu"][k] + dt(eps))
+        p[k] = p[k] - dt(lr) * upd
+        state["delta"][k] = dt(rho) * state["delta"][k] + (dt(1) - dt(rho)) * upd * upd
     return p
 
 
@@ -550,3 +651,27 @@ def spec_deltanet(input_dim, enc_shapes=(2000, 1000, 500, 50),
                               lstm_names=names, peepholes=peepholes)],
                 fusion="none", fuse_name="", agg_names=[], agg_peepholes=False,
                 lstm_size=lstm_size, classes=classes, softmax_name="softmax")
+
+
+def spec_adenet_v3(raw_dim, dct_dim, diff_dim, enc_shapes=(2000, 1000, 500, 50),
+                   enc_acts=("rectify", "rectify", "rectify", "linear"), lstm_size=250, classes=26, fusion="concat"):
+    """modelzoo/adenet_v3.create_model (:64-188): raw + diff encoder streams with deltas, a raw DCT stream, dropout
+    0.5 / 0.2 / 0.5 ahead of the three LSTMs of 2*lstm_size units, dropout 0.5 on the fused tensor, summed BLSTM of
+    2*lstm_size units, LAST time step, softmax; trained with categorical cross-entropy."""
+    enc = lambda sfx: dict(enc_names=[n + sfx for n in ENC_NAMES[:len(enc_shapes)]], enc_shapes=list(enc_shapes),
+                           enc_acts=list(enc_acts), delta=True)
+    streams = [dict(input_dim=raw_dim, lstm_names=["lstm_raw"], peepholes=False, dropout=0.5, **enc("_raw")),
+               dict(input_dim=dct_dim, enc_names=[], enc_shapes=[], enc_acts=[], delta=False, lstm_names=["lstm_dct"],
+                    peepholes=False, dropout=0.2),
+               dict(input_dim=diff_dim, lstm_names=["lstm_diff"], peepholes=False, dropout=0.5, **enc("_diff"))]
+    return dict(streams=streams, fusion=fusion, fuse_name={"adasum": "adasum1", "sum": "sum1", "concat": "concat"}[fusion],
+                agg_names=["f_lstm_agg", "b_lstm_agg"], agg_peepholes=False, agg_dropout=0.5,
+                lstm_size=2 * lstm_size, classes=classes, softmax_name="output", head="last", loss="cross_entropy")
+
+
+def spec_deltanet_last(input_dim, enc_shapes=(2000, 1000, 500, 50), enc_acts=("rectify", "rectify", "rectify", "linear"),
+                       lstm_size=250, classes=26):
+    """modelzoo/deltanet.create_model (:12-56): encoder + deltas + summed BLSTM, LAST time step, softmax."""
+    s = spec_deltanet(input_dim, enc_shapes, enc_acts, lstm_size, classes, peepholes=False, use_blstm=True)
+    s.update(head="last", loss="cross_entropy", softmax_name="output")
+    return s

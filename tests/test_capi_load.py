@@ -29,7 +29,7 @@ def test_header_and_binding_agree(lib):
 
 def test_struct_sizes_match_header():
     # adn_stream_config: 3 + 8 + 8 + ... int32 fields
-    assert C.sizeof(_lib.StreamConfig) == 4 * (2 + 8 + 8 + 3)
+    assert C.sizeof(_lib.StreamConfig) == 4 * (2 + 8 + 8 + 4)
     assert C.sizeof(_lib.Config) == 4 + 8 * C.sizeof(_lib.StreamConfig) + 4 * 6 + 4 * 8
     assert C.sizeof(_lib.ParamInfo) == 96 + 4 + 4 + 16 + 8      # name, ndim, pad, dims, numel
 

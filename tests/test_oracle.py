@@ -242,3 +242,58 @@ def test_param_budget_matches_survey_appendix_d():
     spec = O.spec_nstream([1200, 1200, 1200])
     shapes = O.param_shapes(spec)
     assert sum(int(np.prod(shapes[k])) for k in O.param_names(spec)) == 17999676
+
+
+# --------------------------------------------------------------------------- SURVEY 8f-1 additions
+def test_last_timestep_head_cross_entropy_and_dropout_backward_by_finite_differences():
+    """adenet_v3-shaped graph in float64 with the stochastic layers ON (fixed hash masks): every analytic gradient of
+    oracle.loss_and_grads against central differences; and the head really reads the LAST padded row (App. E-3)."""
+    spec = O.spec_adenet_v3(11, 6, 11, enc_shapes=(8, 4), enc_acts=("sigmoid", "linear"), lstm_size=3, classes=4)
+    rng = np.random.default_rng(21)
+    p = O.init_params(spec, rng, np.float64, enc_std=0.4, perturb=0.2)
+    B, T, theta = 4, 6, 2
+    mask = np.ones((B, T), np.uint8); mask[1, 4:] = 0; mask[3, 1:] = 0
+    inputs = [rng.normal(size=(B, T, s["input_dim"])) * mask[..., None] for s in spec["streams"]]
+    y = np.repeat(rng.integers(0, 4, size=(B, 1)), T, axis=1)
+    dr = dict(seed=31337, counter=2)
+    loss, g, cache = O.loss_and_grads(spec, p, inputs, y, mask, theta, dropout=dr)
+    probs = cache["probs"]
+    assert probs.shape == (B, 4) and np.allclose(probs.sum(1), 1)
+    assert np.isclose(loss, -np.log(probs[np.arange(B), y[:, 0]]).mean())
+    for k in O.param_names(spec):
+        for _ in range(2):
+            idx = tuple(rng.integers(0, n) for n in p[k].shape)
+            q = {a: b.copy() for a, b in p.items()}
+            q[k][idx] += 1e-6
+            lp = O.loss_and_grads(spec, q, inputs, y, mask, theta, dropout=dr)[0]
+            q[k][idx] -= 2e-6
+            lm = O.loss_and_grads(spec, q, inputs, y, mask, theta, dropout=dr)[0]
+            fd = (lp - lm) / 2e-6
+            assert abs(fd - g[k][idx]) <= 1e-6 + 1e-5 * abs(fd), (k, idx, fd, g[k][idx])
+    # deterministic pass = no scaling anywhere; masks keep ~ (1 - p) of the elements and rescale by 1 / (1 - p)
+    det = O.forward(spec, p, inputs, mask, theta)
+    assert not np.allclose(det, probs)
+    sc = O.dropout_scale((64, 50, 20), 0.2, dict(seed=1, counter=0), 3, np.float32)
+    assert set(np.unique(sc)) == {np.float32(0), np.float32(1.25)} and abs((sc > 0).mean() - 0.8) < 0.01
+    assert not np.array_equal(sc, O.dropout_scale((64, 50, 20), 0.2, dict(seed=1, counter=1), 3, np.float32))
+
+
+def test_update_rules_follow_the_lasagne_formulas():
+    """Two hand-computed steps of momentum / nesterov / adadelta on a scalar."""
+    p, g = {"w": np.array([1.0])}, {"w": np.array([0.5])}
+    v = O.momentum_init(p)
+    O.momentum_step(p, g, v, 0.1, 0.9)
+    assert np.isclose(p["w"][0], 0.95) and np.isclose(v["w"][0], -0.05)
+    O.momentum_step(p, g, v, 0.1, 0.9)
+    assert np.isclose(v["w"][0], -0.095) and np.isclose(p["w"][0], 0.855)
+    p, v = {"w": np.array([1.0])}, {"w": np.array([0.0])}
+    O.momentum_step(p, g, v, 0.1, 0.9, nesterov=True)
+    assert np.isclose(p["w"][0], 1 + 0.9 * -0.05 - 0.05)
+    p, st = {"w": np.array([1.0])}, O.adadelta_init({"w": np.array([1.0])})
+    O.adadelta_step(p, g, st, 1.0, 0.95, 1e-6)
+    accu = 0.05 * 0.25
+    upd = 0.5 * np.sqrt(1e-6) / np.sqrt(accu + 1e-6)
+    assert np.isclose(p["w"][0], 1 - upd) and np.isclose(st["delta"]["w"][0], 0.05 * upd * upd)
+    p = {"w": np.array([1.0])}
+    O.sgd_step(p, g, 0.1)
+    assert np.isclose(p["w"][0], 0.95)
