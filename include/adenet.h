@@ -49,7 +49,8 @@ typedef enum {
     ADN_ACT_SIGMOID = 2,
     ADN_ACT_TANH = 3,
     ADN_ACT_LEAKY_RECTIFY = 4,     /* slope 0.01 */
-    ADN_ACT_VERY_LEAKY_RECTIFY = 5 /* slope 1/3  */
+    ADN_ACT_VERY_LEAKY_RECTIFY = 5, /* slope 1/3  */
+    ADN_ACT_SCALED_TANH = 6         /* 2.4 tanh(0.5 x): ScaledTanh(0.5, 2.4) of modelzoo/avletters_convae.py:7-26 */
 } adn_act;
 
 /* fusiontype of modelzoo/adenet_v2.py:68-75 and friends */
@@ -259,6 +260,39 @@ int adn_prep_apply_column_norm(const float* x, float* out, int ld, int rows, int
 /* out[r][j] = in[r][perm[j]]: utils/preprocessing.py:492-503 reorder_data as a pixel permutation; coefficient selection */
 int adn_prep_gather_columns(const float* in, int ld_in, float* out, int ld_out, const int32_t* perm, int rows, int cols,
                             void* hip_stream);
+
+/* ---- convolutional auto-encoder (reference modelzoo/avletters_convae.py:33-69) ---------------------
+ * conv 5x5 (100) - maxpool 2 - conv 5x5 (150) - maxpool 2 pad (1,0) - conv 3x3 (200) - dense - bottleneck, and the
+ * tied-weight decoder (transposed dense layers, Deconv2DLayer on the encoder's filters, Upscale2DLayer); ScaledTanh
+ * everywhere but the bottleneck / dense8; trained on the mean squared reconstruction error
+ * (avletters/avletters_convae.py:254-262).  Images are rows of image_h*image_w floats; parameters are read / written
+ * in Lasagne's layouts ((out, in, kh, kw) filters, (c*h*w, units) dense7) in get_all_params order. */
+typedef struct {
+    int32_t image_h, image_w;   /* 30 x 40 in the reference */
+    int32_t dense;              /* options['DENSE'] (500) */
+    int32_t bottleneck;         /* options['BOTTLENECK'] (50) */
+    int32_t precision;          /* adn_precision of the GEMMs */
+    int32_t reserved[3];
+} adn_cae_config;
+typedef struct adn_cae adn_cae;
+
+int adn_cae_create(const adn_cae_config* cfg, adn_cae** out);
+void adn_cae_destroy(adn_cae* m);
+int adn_cae_set_stream(adn_cae* m, void* hip_stream);
+int adn_cae_num_params(const adn_cae* m);
+int adn_cae_param_info(const adn_cae* m, int index, adn_param_info_t* info);   /* filters reported as (out, in*kh*kw) */
+int adn_cae_read_tensor(adn_cae* m, int buffer /*adn_buffer*/, int index, float* host_dst);
+int adn_cae_write_tensor(adn_cae* m, int buffer /*adn_buffer*/, int index, const float* host_src);
+int adn_cae_flat_buffer(adn_cae* m, int buffer /*adn_buffer*/, float** ptr, int64_t* floats);
+/* recon_fn / the encoder alone: recon (B x image_h*image_w) and / or code (B x bottleneck); either may be null (a null
+ * recon skips the decoder) */
+int adn_cae_forward(adn_cae* m, const float* x, int B, int flags, float* recon, float* code);
+/* mean((recon - target)^2); target null = x (plain auto-encoding) */
+int adn_cae_loss(adn_cae* m, const float* x, const float* target, int B, int flags, float* loss);
+int adn_cae_compute_grads(adn_cae* m, const float* x, const float* target, int B, int flags, float* loss);
+int adn_cae_apply_adadelta(adn_cae* m, float learning_rate, float rho, float epsilon);   /* lr 0.8 in the reference */
+int adn_cae_apply_adam(adn_cae* m, float learning_rate);
+int adn_cae_synchronize(adn_cae* m);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@ ADN_MAX_CLASSES = 64
 
 ADN_OK = 0
 ACT = {"linear": 0, "identity": 0, "rectify": 1, "sigmoid": 2, "tanh": 3, "leaky_rectify": 4,
-       "very_leaky_rectify": 5}
+       "very_leaky_rectify": 5, "scaled_tanh": 6}
 FUSION = {"none": 0, "sum": 1, "adasum": 2, "concat": 3}
 PRECISION = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 FLAG_DEVICE_INPUTS = 1
@@ -39,6 +39,11 @@ class Config(C.Structure):
                 ("fusion", C.c_int32), ("agg", C.c_int32), ("agg_peepholes", C.c_int32),
                 ("lstm_size", C.c_int32), ("classes", C.c_int32), ("precision", C.c_int32),
                 ("head", C.c_int32), ("agg_dropout_p", C.c_float), ("reserved", C.c_int32 * 6)]
+
+
+class CaeConfig(C.Structure):
+    _fields_ = [("image_h", C.c_int32), ("image_w", C.c_int32), ("dense", C.c_int32), ("bottleneck", C.c_int32),
+                ("precision", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class ParamInfo(C.Structure):
@@ -97,6 +102,20 @@ _SIGNATURES = {
     "adn_set_dropout_state": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "adn_apply_sgd": (C.c_int, [_P, C.c_float, C.c_float, C.c_int]),
     "adn_apply_adadelta": (C.c_int, [_P, C.c_float, C.c_float, C.c_float]),
+    "adn_cae_create": (C.c_int, [_P, _P]),
+    "adn_cae_destroy": (None, [_P]),
+    "adn_cae_set_stream": (C.c_int, [_P, _P]),
+    "adn_cae_num_params": (C.c_int, [_P]),
+    "adn_cae_param_info": (C.c_int, [_P, C.c_int, _P]),
+    "adn_cae_read_tensor": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "adn_cae_write_tensor": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "adn_cae_flat_buffer": (C.c_int, [_P, C.c_int, _P, _P]),
+    "adn_cae_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
+    "adn_cae_loss": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
+    "adn_cae_compute_grads": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
+    "adn_cae_apply_adadelta": (C.c_int, [_P, C.c_float, C.c_float, C.c_float]),
+    "adn_cae_apply_adam": (C.c_int, [_P, C.c_float]),
+    "adn_cae_synchronize": (C.c_int, [_P]),
     "adn_prep_seq_deltas": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "adn_prep_diff_images": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P]),
     "adn_prep_mean_image_subtraction": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P]),

@@ -1,0 +1,646 @@
+// Convolutional auto-encoder (reference modelzoo/avletters_convae.py:33-69 and its training step
+// avletters/avletters_convae.py:254-262): im2col + MFMA GEMM for every convolution and its adjoint.
+//
+//   (B,1,30,40) -> conv 5x5 (100) -> maxpool 2 -> conv 5x5 (150) -> maxpool 2 pad (1,0) -> conv 3x3 (200) -> 3000
+//               -> dense 500 -> bottleneck 50 (linear) -> dense8 (W_b^T) -> dense9 (W_7^T) -> (200,3,5)
+//               -> deconv (conv5.W) -> upscale 2 -> deconv (conv3.W) -> upscale 2 -> deconv crop (1,0) (conv1.W) -> 1200
+//
+// Layout: activations are NHWC fp32 ([B][H][W][C]), so a convolution's output IS the GEMM result
+// [B*OH*OW][C_out] and its patches matrix is [B*OH*OW][kh*kw*C_in] with (i, j, c) column order.  Weights are kept in
+// the matching GEMM form Wm[(i*kw + j)*C_in + c][o] = W[o][c][kh-1-i][kw-1-j] (Lasagne's W, filters flipped: true
+// convolution); dense7 rows are in (h, w, c) order.  The C ABI converts to / from Lasagne's layouts on the host, so
+// checkpoints and the oracle see (out, in, kh, kw) and (c*h*w, units).
+//   conv forward    cols = im2col(x);  y = act(cols Wm + b)                                GEMM NN
+//   conv backward   dWm += cols^T dy;  db += colsum(dy);  dx = col2im(dy Wm^T)              GEMM TN, NT
+//   deconv forward  z = act(col2im(x Wm^T) + b)       (exact adjoint of the tied convolution)  GEMM NT
+//   deconv backward cols' = im2col(dz padded by crop);  dx = cols' Wm;  dWm += cols'^T x     GEMM NN, TN
+// Every GEMM goes through gemm() (fp32 MFMA, or bf16 MFMA converting in flight with precision = bf16).
+#include "adn_common.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace adn;
+
+namespace {
+
+constexpr int kF1 = 100, kF2L = 150, kF3 = 200;     // filters per convolution (modelzoo/avletters_convae.py:34-36)
+// the GEMM loaders need row strides that are multiples of 4 floats: the 150-channel tensors carry 2 zero channels
+// (zero filters / zero bias give act(0) = 0, and nothing ever flows into or out of them)
+constexpr int kF2 = 152;
+
+// ---------------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------------
+// cols[(b, oy, ox)][(i*kw + j)*C + c] = x[b][oy + i - ph][ox + j - pw][c]  (0 outside); row stride ldc
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, float* __restrict__ cols, int B, int H, int W,
+                                                     int C, int kh, int kw, int ph, int pw, int OH, int OW, int ldc) {
+    const int K = kh * kw * C;
+    const int64_t total = (int64_t)B * OH * OW * K;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int k = (int)(e % K);
+        const int64_t r = e / K;
+        const int c = k % C, ij = k / C, j = ij % kw, i = ij / kw;
+        const int ox = (int)(r % OW), oy = (int)((r / OW) % OH), b = (int)(r / ((int64_t)OW * OH));
+        const int y = oy + i - ph, xx = ox + j - pw;
+        float v = 0.f;
+        if (y >= 0 && y < H && xx >= 0 && xx < W) v = x[(((size_t)b * H + y) * W + xx) * C + c];
+        cols[(size_t)r * ldc + k] = v;
+    }
+}
+
+// out[b][y][x][c] = sum_{i,j} dcols[(b, y + ph - i, x + pw - j)][(i*kw + j)*C + c]  over valid patch positions
+// (gather form of col2im: no atomics); optional bias[c] and activation
+__global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ dcols, int ldc, float* __restrict__ out, int B, int H,
+                                                     int W, int C, int kh, int kw, int ph, int pw, int OH, int OW,
+                                                     const float* __restrict__ bias, int act) {
+    const int64_t total = (int64_t)B * H * W * C;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const int64_t p = e / C;
+        const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((int64_t)W * H));
+        float acc = bias ? bias[c] : 0.f;
+        for (int i = 0; i < kh; ++i) {
+            const int oy = y + ph - i;
+            if (oy < 0 || oy >= OH) continue;
+            for (int j = 0; j < kw; ++j) {
+                const int ox = x + pw - j;
+                if (ox < 0 || ox >= OW) continue;
+                acc += dcols[(((size_t)b * OH + oy) * OW + ox) * ldc + (i * kw + j) * C + c];
+            }
+        }
+        if (act == ADN_ACT_SCALED_TANH) acc = 2.4f * tanhf(0.5f * acc);
+        out[e] = acc;
+    }
+}
+
+// 2x2 / stride 2 max pooling, ignore_border, `ph` rows of padding above and below that never win; code = dy*2 + dx
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ arg,
+                                                          int B, int H, int W, int C, int ph, int OH, int OW) {
+    const int64_t total = (int64_t)B * OH * OW * C;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const int64_t p = e / C;
+        const int ox = (int)(p % OW), oy = (int)((p / OW) % OH), b = (int)(p / ((int64_t)OW * OH));
+        float best = -INFINITY; int code = 0;
+        for (int dy = 0; dy < 2; ++dy) {
+            const int yy = 2 * oy + dy - ph;
+            if (yy < 0 || yy >= H) continue;
+            for (int dx = 0; dx < 2; ++dx) {
+                const int xx = 2 * ox + dx;
+                if (xx >= W) continue;
+                const float v = x[(((size_t)b * H + yy) * W + xx) * C + c];
+                if (v > best) { best = v; code = dy * 2 + dx; }
+            }
+        }
+        y[e] = best; arg[e] = (uint8_t)code;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ arg,
+                                                          float* __restrict__ dx, int B, int H, int W, int C, int ph, int OH, int OW) {
+    const int64_t total = (int64_t)B * H * W * C;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const int64_t p = e / C;
+        const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((int64_t)W * H));
+        const int oy = (y + ph) / 2, ox = x / 2;
+        float g = 0.f;
+        if (oy < OH && ox < OW) {
+            const size_t o = (((size_t)b * OH + oy) * OW + ox) * C + c;
+            if ((int)arg[o] == ((y + ph) & 1) * 2 + (x & 1)) g = dy[o];
+        }
+        dx[e] = g;
+    }
+}
+
+__global__ __launch_bounds__(256) void upscale_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C) {
+    const int64_t total = (int64_t)B * 2 * H * 2 * W * C;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const int64_t p = e / C;
+        const int xx = (int)(p % (2 * W)), yy = (int)((p / (2 * W)) % (2 * H)), b = (int)(p / ((int64_t)4 * W * H));
+        y[e] = x[(((size_t)b * H + yy / 2) * W + xx / 2) * C + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void upscale_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int H, int W, int C) {
+    const int64_t total = (int64_t)B * H * W * C;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const int64_t p = e / C;
+        const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((int64_t)W * H));
+        const size_t base = (((size_t)b * 2 * H + 2 * y) * 2 * W + 2 * x) * C + c;
+        dx[e] = dy[base] + dy[base + C] + dy[base + (size_t)2 * W * C] + dy[base + (size_t)2 * W * C + C];
+    }
+}
+
+// d = scale * (recon - target);  sq[i] = (recon - target)^2 summed into *loss_acc by the caller's dot product
+__global__ __launch_bounds__(256) void mse_grad_kernel(const float* __restrict__ r, const float* __restrict__ t, float* __restrict__ d,
+                                                       int64_t n, float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = scale * (r[i] - t[i]);
+}
+
+__global__ void scale_scalar_kernel(float* p, float s) { *p *= s; }
+
+int grid_of(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 16384)); }
+
+// one convolution (or the convolution a deconv layer is the adjoint of): input [B][H][W][C] padded by (ph, pw),
+// k x k filters, O output channels, output grid OH x OW; patches matrix [B*OH*OW][ldk]
+struct ConvGeom { int H, W, C, k, O, ph, pw, OH, OW, K, ldk; };
+
+ConvGeom conv_geom(int H, int W, int C, int k, int O, int ph = 0, int pw = 0) {
+    ConvGeom g{H, W, C, k, O, ph, pw, H + 2 * ph - k + 1, W + 2 * pw - k + 1, k * k * C, 0};
+    g.ldk = (int)round_up(g.K, 4);
+    return g;
+}
+
+// kind: 0 vector, 1 conv W (Op x Cp physical filters / channels), 2 dense7 W, 3 bottleneck W, 4 dense9 b
+struct Tensor { std::string name; int ndim; int64_t dims[4]; size_t off; size_t floats; int kind; int Op, Cp; size_t phys; };
+
+}  // namespace
+
+struct adn_cae {
+    adn_cae_config cfg;
+    hipStream_t stream = nullptr;
+    int H = 30, W = 40, D7 = 500, NB = 50, ldb = 52, precision = ADN_PRECISION_F32;
+    ConvGeom c1, c3, c5, d11, d13, d15;
+    int p2h = 0, p2w = 0, p4h = 0, p4w = 0, flat = 0;
+    std::vector<Tensor> params;
+    size_t flat_floats = 0;
+    float* buf[4] = {nullptr, nullptr, nullptr, nullptr};       // parameters, gradients, optimiser state 0 / 1
+    size_t W1 = 0, b1 = 0, W3 = 0, b3 = 0, W5 = 0, b5 = 0, W7 = 0, b7 = 0, Wb = 0, bb = 0, b8 = 0, b9 = 0, b11 = 0, b13 = 0, b15 = 0;
+    char* slab = nullptr; size_t slab_bytes = 0; int wsB = 0;
+    float *x0 = nullptr, *cols1 = nullptr, *a1 = nullptr, *p2 = nullptr, *cols3 = nullptr, *a3 = nullptr, *p4 = nullptr,
+          *cols5 = nullptr, *a5 = nullptr, *a7 = nullptr, *code = nullptr, *a8 = nullptr, *a9 = nullptr, *a11 = nullptr,
+          *u12 = nullptr, *a13 = nullptr, *u14 = nullptr, *a15 = nullptr, *target = nullptr, *scratch = nullptr,
+          *gA = nullptr, *gB = nullptr, *loss_dev = nullptr;
+    uint8_t *arg2 = nullptr, *arg4 = nullptr;
+    bool grads_valid = false;
+    int adam_t = 0;
+    float* P(size_t off) const { return buf[0] + off; }
+    float* G(size_t off) const { return buf[1] + off; }
+};
+
+namespace {
+
+size_t add_tensor(adn_cae* m, const char* name, int kind, std::initializer_list<int64_t> dims, int Op = 0, int Cp = 0) {
+    Tensor t; t.name = name; t.kind = kind; t.off = m->flat_floats; t.ndim = (int)dims.size(); t.Op = Op; t.Cp = Cp;
+    size_t n = 1; int k = 0;
+    for (auto d : dims) { t.dims[k++] = d; n *= (size_t)d; }
+    t.floats = n;                                    // logical (host) element count
+    if (kind == 1) t.phys = (size_t)t.dims[2] * t.dims[3] * Cp * Op;
+    else if (kind == 3) t.phys = (size_t)t.dims[0] * m->ldb;
+    else t.phys = (size_t)round_up((int64_t)std::max<size_t>(n, (size_t)Op), 4);      // vectors: Op = physical length
+    t.phys = (size_t)round_up((int64_t)t.phys, 4);
+    m->params.push_back(t);
+    m->flat_floats += t.phys;
+    return t.off;
+}
+
+struct Carve {
+    char* base; size_t cur = 0;
+    template <typename T> T* take(size_t n) {
+        T* p = base ? reinterpret_cast<T*>(base + cur) : nullptr;
+        cur += (size_t)round_up((int64_t)(n * sizeof(T)), 256);
+        return p;
+    }
+};
+
+size_t rows_of(const ConvGeom& g, int B) { return (size_t)B * g.OH * g.OW; }
+
+size_t carve(adn_cae* m, char* base, int B) {
+    Carve c{base};
+    const size_t N = B;
+    m->x0 = c.take<float>(N * m->H * m->W);
+    m->cols1 = c.take<float>(rows_of(m->c1, B) * m->c1.ldk);
+    m->a1 = c.take<float>(rows_of(m->c1, B) * kF1);
+    m->p2 = c.take<float>(N * m->p2h * m->p2w * kF1); m->arg2 = c.take<uint8_t>(N * m->p2h * m->p2w * kF1);
+    m->cols3 = c.take<float>(rows_of(m->c3, B) * m->c3.ldk);
+    m->a3 = c.take<float>(rows_of(m->c3, B) * kF2);
+    m->p4 = c.take<float>(N * m->p4h * m->p4w * kF2); m->arg4 = c.take<uint8_t>(N * m->p4h * m->p4w * kF2);
+    m->cols5 = c.take<float>(rows_of(m->c5, B) * m->c5.ldk);
+    m->a5 = c.take<float>(N * m->flat);
+    m->a7 = c.take<float>(N * m->D7); m->code = c.take<float>(N * m->ldb);
+    m->a8 = c.take<float>(N * m->D7); m->a9 = c.take<float>(N * m->flat);
+    m->a11 = c.take<float>(N * m->d11.H * m->d11.W * kF2);
+    m->u12 = c.take<float>(N * 4 * m->d11.H * m->d11.W * kF2);
+    m->a13 = c.take<float>(N * m->d13.H * m->d13.W * kF1);
+    m->u14 = c.take<float>(N * 4 * m->d13.H * m->d13.W * kF1);
+    m->a15 = c.take<float>(N * m->H * m->W);
+    m->target = c.take<float>(N * m->H * m->W);
+    size_t sc = 0, act = N * m->H * m->W;
+    for (const ConvGeom* g : {&m->c1, &m->c3, &m->c5, &m->d11, &m->d13, &m->d15}) {
+        sc = std::max(sc, rows_of(*g, B) * g->ldk);
+        act = std::max(act, std::max(rows_of(*g, B) * (size_t)g->O, N * g->H * g->W * (size_t)g->C));
+    }
+    m->scratch = c.take<float>(sc);
+    m->gA = c.take<float>(act); m->gB = c.take<float>(act);
+    m->loss_dev = c.take<float>(8);
+    return c.cur;
+}
+
+int ensure_ws(adn_cae* m, int B) {
+    if (B == m->wsB && m->slab) return ADN_OK;
+    const size_t need = carve(m, nullptr, B);
+    if (need > m->slab_bytes) {
+        if (m->slab) { ADN_HIP_CHECK(hipStreamSynchronize(m->stream)); ADN_HIP_CHECK(hipFree(m->slab)); m->slab = nullptr; }
+        ADN_HIP_CHECK(hipMalloc((void**)&m->slab, need));
+        m->slab_bytes = need;
+    }
+    carve(m, m->slab, B);
+    ADN_HIP_CHECK(hipMemsetAsync(m->slab, 0, need, m->stream));       // pad columns of the patches matrices read as zero
+    m->wsB = B;
+    return ADN_OK;
+}
+
+int mm(adn_cae* m, int layout, int M, int N, int K, const float* A, int lda, const float* Bm, int ldb, float* C, int ldc,
+       const float* bias = nullptr, int act = ADN_ACT_LINEAR, int accumulate = 0) {
+    GemmArgs g;
+    g.layout = layout; g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = Bm; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.bias = bias; g.act = act; g.accumulate = accumulate; g.precision = m->precision;
+    return gemm(g, m->stream);
+}
+
+int im2col(adn_cae* m, const float* x, const ConvGeom& g, int B, float* cols) {
+    const int64_t total = (int64_t)rows_of(g, B) * g.K;
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid_of(total)), dim3(256), 0, m->stream, x, cols, B, g.H, g.W, g.C, g.k, g.k, g.ph, g.pw,
+                       g.OH, g.OW, g.ldk);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+int col2im(adn_cae* m, const float* dcols, const ConvGeom& g, int B, float* out, const float* bias, int act) {
+    const int64_t total = (int64_t)B * g.H * g.W * g.C;
+    hipLaunchKernelGGL(col2im_kernel, dim3(grid_of(total)), dim3(256), 0, m->stream, dcols, g.ldk, out, B, g.H, g.W, g.C, g.k, g.k,
+                       g.ph, g.pw, g.OH, g.OW, bias, act);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+// y = act(conv(x) + b): patches kept in `cols` for the backward pass
+int conv_fwd(adn_cae* m, const float* x, const ConvGeom& g, int B, float* cols, size_t W, size_t b, float* y) {
+    ADN_TRY(im2col(m, x, g, B, cols));
+    return mm(m, GEMM_NN, (int)rows_of(g, B), g.O, g.K, cols, g.ldk, m->P(W), g.O, y, g.O, m->P(b), ADN_ACT_SCALED_TANH);
+}
+
+// dy (already multiplied by act') -> dW, db, and (optionally) dx
+int conv_bwd(adn_cae* m, const ConvGeom& g, int B, const float* cols, const float* dy, size_t W, size_t b, float* dx) {
+    const int R = (int)rows_of(g, B);
+    ADN_TRY(mm(m, GEMM_TN, g.K, g.O, R, cols, g.ldk, dy, g.O, m->G(W), g.O, nullptr, ADN_ACT_LINEAR, 1));
+    ADN_TRY(col_sum(dy, g.O, R, g.O, m->G(b), 1, m->stream));
+    if (dx) {
+        ADN_TRY(mm(m, GEMM_NT, R, g.K, g.O, dy, g.O, m->P(W), g.O, m->scratch, g.ldk));
+        ADN_TRY(col2im(m, m->scratch, g, B, dx, nullptr, ADN_ACT_LINEAR));
+    }
+    return ADN_OK;
+}
+
+// z = act(adjoint_conv(x) + b): x [B*OH*OW][O] -> z [B][H][W][C]   (g = the tied convolution, crop = its padding)
+int deconv_fwd(adn_cae* m, const float* x, const ConvGeom& g, int B, size_t W, size_t b, float* z) {
+    ADN_TRY(mm(m, GEMM_NT, (int)rows_of(g, B), g.K, g.O, x, g.O, m->P(W), g.O, m->scratch, g.ldk));
+    return col2im(m, m->scratch, g, B, z, m->P(b), ADN_ACT_SCALED_TANH);
+}
+
+// dz (already multiplied by act') -> db, dW (tied), dx
+int deconv_bwd(adn_cae* m, const ConvGeom& g, int B, const float* x, const float* dz, size_t W, size_t b, float* dx) {
+    const int R = (int)rows_of(g, B);
+    ADN_TRY(col_sum(dz, g.C, B * g.H * g.W, g.C, m->G(b), 1, m->stream));
+    ADN_TRY(im2col(m, dz, g, B, m->scratch));
+    ADN_TRY(mm(m, GEMM_NN, R, g.O, g.K, m->scratch, g.ldk, m->P(W), g.O, dx, g.O));
+    return mm(m, GEMM_TN, g.K, g.O, R, m->scratch, g.ldk, x, g.O, m->G(W), g.O, nullptr, ADN_ACT_LINEAR, 1);
+}
+
+int maxpool_fwd(adn_cae* m, const float* x, int B, int H, int W, int C, int ph, int OH, int OW, float* y, uint8_t* arg) {
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_of((int64_t)B * OH * OW * C)), dim3(256), 0, m->stream, x, y, arg, B, H, W, C, ph, OH, OW);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+int maxpool_bwd(adn_cae* m, const float* dy, const uint8_t* arg, int B, int H, int W, int C, int ph, int OH, int OW, float* dx) {
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_of((int64_t)B * H * W * C)), dim3(256), 0, m->stream, dy, arg, dx, B, H, W, C, ph, OH, OW);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+int upscale_fwd(adn_cae* m, const float* x, int B, int H, int W, int C, float* y) {
+    hipLaunchKernelGGL(upscale_fwd_kernel, dim3(grid_of((int64_t)B * 4 * H * W * C)), dim3(256), 0, m->stream, x, y, B, H, W, C);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+int upscale_bwd(adn_cae* m, const float* dy, int B, int H, int W, int C, float* dx) {
+    hipLaunchKernelGGL(upscale_bwd_kernel, dim3(grid_of((int64_t)B * H * W * C)), dim3(256), 0, m->stream, dy, dx, B, H, W, C);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+int stage(adn_cae* m, const float* x, const float* target, int B, int flags) {
+    const hipMemcpyKind kind = (flags & ADN_FLAG_DEVICE_INPUTS) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    const size_t bytes = (size_t)B * m->H * m->W * sizeof(float);
+    ADN_HIP_CHECK(hipMemcpyAsync(m->x0, x, bytes, kind, m->stream));
+    if (target) ADN_HIP_CHECK(hipMemcpyAsync(m->target, target, bytes, kind, m->stream));
+    return ADN_OK;
+}
+
+int forward(adn_cae* m, int B, bool decode) {
+    const int S = ADN_ACT_SCALED_TANH;
+    ADN_TRY(conv_fwd(m, m->x0, m->c1, B, m->cols1, m->W1, m->b1, m->a1));
+    ADN_TRY(maxpool_fwd(m, m->a1, B, m->c1.OH, m->c1.OW, kF1, 0, m->p2h, m->p2w, m->p2, m->arg2));
+    ADN_TRY(conv_fwd(m, m->p2, m->c3, B, m->cols3, m->W3, m->b3, m->a3));
+    ADN_TRY(maxpool_fwd(m, m->a3, B, m->c3.OH, m->c3.OW, kF2, 1, m->p4h, m->p4w, m->p4, m->arg4));
+    ADN_TRY(conv_fwd(m, m->p4, m->c5, B, m->cols5, m->W5, m->b5, m->a5));
+    ADN_TRY(mm(m, GEMM_NN, B, m->D7, m->flat, m->a5, m->flat, m->P(m->W7), m->D7, m->a7, m->D7, m->P(m->b7), S));
+    ADN_TRY(mm(m, GEMM_NN, B, m->NB, m->D7, m->a7, m->D7, m->P(m->Wb), m->ldb, m->code, m->ldb, m->P(m->bb)));
+    if (!decode) return ADN_OK;
+    ADN_TRY(mm(m, GEMM_NT, B, m->D7, m->NB, m->code, m->ldb, m->P(m->Wb), m->ldb, m->a8, m->D7, m->P(m->b8)));
+    ADN_TRY(mm(m, GEMM_NT, B, m->flat, m->D7, m->a8, m->D7, m->P(m->W7), m->D7, m->a9, m->flat, m->P(m->b9), S));
+    ADN_TRY(deconv_fwd(m, m->a9, m->d11, B, m->W5, m->b11, m->a11));
+    ADN_TRY(upscale_fwd(m, m->a11, B, m->d11.H, m->d11.W, kF2, m->u12));
+    ADN_TRY(deconv_fwd(m, m->u12, m->d13, B, m->W3, m->b13, m->a13));
+    ADN_TRY(upscale_fwd(m, m->a13, B, m->d13.H, m->d13.W, kF1, m->u14));
+    return deconv_fwd(m, m->u14, m->d15, B, m->W1, m->b15, m->a15);
+}
+
+// loss_dev[0] = mean((recon - target)^2); gA = d loss / d recon when want_grad
+int mse(adn_cae* m, int B, bool want_grad) {
+    const int64_t n = (int64_t)B * m->H * m->W;
+    hipLaunchKernelGGL(mse_grad_kernel, dim3(grid_of(n)), dim3(256), 0, m->stream, m->a15, m->target, m->gA, n, 1.f);
+    ADN_HIP_CHECK(hipMemsetAsync(m->loss_dev, 0, sizeof(float), m->stream));
+    ADN_TRY(dot_all(m->gA, m->W, m->gA, m->W, B * m->H, m->W, m->loss_dev, nullptr, m->stream));
+    hipLaunchKernelGGL(scale_scalar_kernel, dim3(1), dim3(1), 0, m->stream, m->loss_dev, 1.f / (float)n);
+    if (want_grad)
+        hipLaunchKernelGGL(mse_grad_kernel, dim3(grid_of(n)), dim3(256), 0, m->stream, m->a15, m->target, m->gA, n, 2.f / (float)n);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+int backward(adn_cae* m, int B) {
+    const int S = ADN_ACT_SCALED_TANH;
+    hipStream_t s = m->stream;
+    ADN_HIP_CHECK(hipMemsetAsync(m->buf[1], 0, m->flat_floats * sizeof(float), s));
+    float *gA = m->gA, *gB = m->gB;
+    // decoder
+    ADN_TRY(act_backward(gA, 1, m->a15, 1, B * m->H * m->W, 1, S, s));
+    ADN_TRY(deconv_bwd(m, m->d15, B, m->u14, gA, m->W1, m->b15, gB));                    // gB = d u14
+    ADN_TRY(upscale_bwd(m, gB, B, m->d13.H, m->d13.W, kF1, gA));                          // gA = d a13
+    ADN_TRY(act_backward(gA, kF1, m->a13, kF1, B * m->d13.H * m->d13.W, kF1, S, s));
+    ADN_TRY(deconv_bwd(m, m->d13, B, m->u12, gA, m->W3, m->b13, gB));                    // gB = d u12
+    ADN_TRY(upscale_bwd(m, gB, B, m->d11.H, m->d11.W, kF2, gA));                          // gA = d a11
+    ADN_TRY(act_backward(gA, kF2, m->a11, kF2, B * m->d11.H * m->d11.W, kF2, S, s));
+    ADN_TRY(deconv_bwd(m, m->d11, B, m->a9, gA, m->W5, m->b11, gB));                     // gB = d a9 (as [B][flat])
+    ADN_TRY(act_backward(gB, m->flat, m->a9, m->flat, B, m->flat, S, s));
+    ADN_TRY(col_sum(gB, m->flat, B, m->flat, m->G(m->b9), 1, s));
+    ADN_TRY(mm(m, GEMM_TN, m->flat, m->D7, B, gB, m->flat, m->a8, m->D7, m->G(m->W7), m->D7, nullptr, ADN_ACT_LINEAR, 1));
+    ADN_TRY(mm(m, GEMM_NN, B, m->D7, m->flat, gB, m->flat, m->P(m->W7), m->D7, gA, m->D7));          // gA = d a8
+    ADN_TRY(col_sum(gA, m->D7, B, m->D7, m->G(m->b8), 1, s));
+    ADN_TRY(mm(m, GEMM_TN, m->D7, m->NB, B, gA, m->D7, m->code, m->ldb, m->G(m->Wb), m->ldb, nullptr, ADN_ACT_LINEAR, 1));
+    ADN_TRY(mm(m, GEMM_NN, B, m->NB, m->D7, gA, m->D7, m->P(m->Wb), m->ldb, gB, m->ldb));             // gB = d code
+    // encoder
+    ADN_TRY(col_sum(gB, m->ldb, B, m->NB, m->G(m->bb), 1, s));
+    ADN_TRY(mm(m, GEMM_TN, m->D7, m->NB, B, m->a7, m->D7, gB, m->ldb, m->G(m->Wb), m->ldb, nullptr, ADN_ACT_LINEAR, 1));
+    ADN_TRY(mm(m, GEMM_NT, B, m->D7, m->NB, gB, m->ldb, m->P(m->Wb), m->ldb, gA, m->D7));             // gA = d a7
+    ADN_TRY(act_backward(gA, m->D7, m->a7, m->D7, B, m->D7, S, s));
+    ADN_TRY(col_sum(gA, m->D7, B, m->D7, m->G(m->b7), 1, s));
+    ADN_TRY(mm(m, GEMM_TN, m->flat, m->D7, B, m->a5, m->flat, gA, m->D7, m->G(m->W7), m->D7, nullptr, ADN_ACT_LINEAR, 1));
+    ADN_TRY(mm(m, GEMM_NT, B, m->flat, m->D7, gA, m->D7, m->P(m->W7), m->D7, gB, m->flat));           // gB = d a5
+    ADN_TRY(act_backward(gB, m->flat, m->a5, m->flat, B, m->flat, S, s));
+    ADN_TRY(conv_bwd(m, m->c5, B, m->cols5, gB, m->W5, m->b5, gA));                       // gA = d p4
+    ADN_TRY(maxpool_bwd(m, gA, m->arg4, B, m->c3.OH, m->c3.OW, kF2, 1, m->p4h, m->p4w, gB));            // gB = d a3
+    ADN_TRY(act_backward(gB, kF2, m->a3, kF2, (int)rows_of(m->c3, B), kF2, S, s));
+    ADN_TRY(conv_bwd(m, m->c3, B, m->cols3, gB, m->W3, m->b3, gA));                       // gA = d p2
+    ADN_TRY(maxpool_bwd(m, gA, m->arg2, B, m->c1.OH, m->c1.OW, kF1, 0, m->p2h, m->p2w, gB));            // gB = d a1
+    ADN_TRY(act_backward(gB, kF1, m->a1, kF1, (int)rows_of(m->c1, B), kF1, S, s));
+    ADN_TRY(conv_bwd(m, m->c1, B, m->cols1, gB, m->W1, m->b1, nullptr));
+    m->grads_valid = true;
+    return ADN_OK;
+}
+
+int fetch(adn_cae* m, void* dst, const void* src, size_t bytes, int flags) {
+    if (flags & ADN_FLAG_DEVICE_OUTPUTS) {
+        ADN_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, m->stream));
+    } else {
+        ADN_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, m->stream));
+        ADN_HIP_CHECK(hipStreamSynchronize(m->stream));
+    }
+    return ADN_OK;
+}
+
+// host <-> device layout conversion of one tensor (Lasagne layout on the host side)
+void to_internal(const adn_cae* m, const Tensor& t, const float* host, std::vector<float>& dev) {
+    dev.assign(t.phys, 0.f);
+    if (t.kind == 1) {                               // (O, C, kh, kw) -> [(i*kw + j)*Cp + c][o] (row stride Op), filters flipped
+        const int O = (int)t.dims[0], C = (int)t.dims[1], kh = (int)t.dims[2], kw = (int)t.dims[3];
+        for (int o = 0; o < O; ++o) for (int c = 0; c < C; ++c) for (int i = 0; i < kh; ++i) for (int j = 0; j < kw; ++j)
+            dev[((size_t)(i * kw + j) * t.Cp + c) * t.Op + o] = host[(((size_t)o * C + c) * kh + (kh - 1 - i)) * kw + (kw - 1 - j)];
+    } else if (t.kind == 2) {                        // rows (c, h, w) -> rows (h, w, c)
+        const int hh = m->c5.OH, ww = m->c5.OW, U = (int)t.dims[1];
+        for (int c = 0; c < kF3; ++c) for (int y = 0; y < hh; ++y) for (int x = 0; x < ww; ++x)
+            memcpy(&dev[((size_t)(y * ww + x) * kF3 + c) * U], &host[((size_t)(c * hh + y) * ww + x) * U], (size_t)U * 4);
+    } else if (t.kind == 3) {                        // bottleneck W: rows padded to ldb
+        const int U = (int)t.dims[1];
+        for (int r = 0; r < (int)t.dims[0]; ++r) memcpy(&dev[(size_t)r * m->ldb], &host[(size_t)r * U], (size_t)U * 4);
+    } else if (t.kind == 4) {                        // dense9.b: (c, h, w) -> (h, w, c)
+        const int hh = m->c5.OH, ww = m->c5.OW;
+        for (int c = 0; c < kF3; ++c) for (int y = 0; y < hh; ++y) for (int x = 0; x < ww; ++x)
+            dev[(size_t)(y * ww + x) * kF3 + c] = host[(size_t)(c * hh + y) * ww + x];
+    } else {
+        memcpy(dev.data(), host, t.floats * 4);
+    }
+}
+
+void to_host(const adn_cae* m, const Tensor& t, const std::vector<float>& dev, float* host) {
+    if (t.kind == 1) {
+        const int O = (int)t.dims[0], C = (int)t.dims[1], kh = (int)t.dims[2], kw = (int)t.dims[3];
+        for (int o = 0; o < O; ++o) for (int c = 0; c < C; ++c) for (int i = 0; i < kh; ++i) for (int j = 0; j < kw; ++j)
+            host[(((size_t)o * C + c) * kh + (kh - 1 - i)) * kw + (kw - 1 - j)] = dev[((size_t)(i * kw + j) * t.Cp + c) * t.Op + o];
+    } else if (t.kind == 2) {
+        const int hh = m->c5.OH, ww = m->c5.OW, U = (int)t.dims[1];
+        for (int c = 0; c < kF3; ++c) for (int y = 0; y < hh; ++y) for (int x = 0; x < ww; ++x)
+            memcpy(&host[((size_t)(c * hh + y) * ww + x) * U], &dev[((size_t)(y * ww + x) * kF3 + c) * U], (size_t)U * 4);
+    } else if (t.kind == 3) {
+        const int U = (int)t.dims[1];
+        for (int r = 0; r < (int)t.dims[0]; ++r) memcpy(&host[(size_t)r * U], &dev[(size_t)r * m->ldb], (size_t)U * 4);
+    } else if (t.kind == 4) {
+        const int hh = m->c5.OH, ww = m->c5.OW;
+        for (int c = 0; c < kF3; ++c) for (int y = 0; y < hh; ++y) for (int x = 0; x < ww; ++x)
+            host[(size_t)(c * hh + y) * ww + x] = dev[(size_t)(y * ww + x) * kF3 + c];
+    } else {
+        memcpy(host, dev.data(), t.floats * 4);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int adn_cae_create(const adn_cae_config* cfg, adn_cae** out) {
+    ADN_CHECK(cfg && out, ADN_ERR_INVALID, "null argument");
+    ADN_CHECK(cfg->image_h >= 22 && cfg->image_w >= 22 && cfg->image_h <= 512 && cfg->image_w <= 512, ADN_ERR_INVALID,
+              "image size out of range (the three valid convolutions and two poolings need at least 22 x 22)");
+    ADN_CHECK(cfg->dense >= 1 && cfg->bottleneck >= 1, ADN_ERR_INVALID, "layer widths must be positive");
+    ADN_CHECK(cfg->precision == ADN_PRECISION_F32 || cfg->precision == ADN_PRECISION_BF16, ADN_ERR_INVALID, "unknown precision");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device visible"); return ADN_ERR_NO_DEVICE; }
+    adn_cae* m = new adn_cae();
+    m->cfg = *cfg; m->H = cfg->image_h; m->W = cfg->image_w; m->D7 = cfg->dense; m->NB = cfg->bottleneck;
+    m->ldb = (int)round_up(m->NB, 4); m->precision = cfg->precision;
+    m->c1 = conv_geom(m->H, m->W, 1, 5, kF1);
+    m->p2h = (m->c1.OH - 2) / 2 + 1; m->p2w = (m->c1.OW - 2) / 2 + 1;
+    m->c3 = conv_geom(m->p2h, m->p2w, kF1, 5, kF2);
+    m->p4h = (m->c3.OH + 2 - 2) / 2 + 1; m->p4w = (m->c3.OW - 2) / 2 + 1;
+    m->c5 = conv_geom(m->p4h, m->p4w, kF2, 3, kF3);
+    if (m->c5.OH < 1 || m->c5.OW < 1) { delete m; set_error("image too small for the encoder"); return ADN_ERR_INVALID; }
+    m->flat = kF3 * m->c5.OH * m->c5.OW;
+    // deconv layers = adjoints of convolutions on their OUTPUT images (Deconv2DLayer full padding = valid conv's adjoint)
+    m->d11 = conv_geom(m->c5.OH + 2, m->c5.OW + 2, kF2, 3, kF3);
+    m->d13 = conv_geom(2 * m->d11.H + 4, 2 * m->d11.W + 4, kF1, 5, kF2);
+    m->d15 = conv_geom(2 * m->d13.H + 4 - 2, 2 * m->d13.W + 4, 1, 5, kF1, 1, 0);
+    if (m->d15.H != m->H || m->d15.W != m->W) {
+        delete m; set_error("the decoder does not reproduce this image size (use e.g. 30 x 40)"); return ADN_ERR_INVALID;
+    }
+    m->W1 = add_tensor(m, "conv2d1.W", 1, {kF1, 1, 5, 5}, kF1, 1); m->b1 = add_tensor(m, "conv2d1.b", 0, {kF1});
+    m->W3 = add_tensor(m, "conv2d3.W", 1, {kF2L, kF1, 5, 5}, kF2, kF1); m->b3 = add_tensor(m, "conv2d3.b", 0, {kF2L}, kF2);
+    m->W5 = add_tensor(m, "conv2d5.W", 1, {kF3, kF2L, 3, 3}, kF3, kF2); m->b5 = add_tensor(m, "conv2d5.b", 0, {kF3});
+    m->W7 = add_tensor(m, "dense7.W", 2, {m->flat, m->D7}); m->b7 = add_tensor(m, "dense7.b", 0, {m->D7});
+    m->Wb = add_tensor(m, "bottleneck.W", 3, {m->D7, m->NB});
+    m->bb = add_tensor(m, "bottleneck.b", 0, {m->NB});
+    m->b8 = add_tensor(m, "dense8.b", 0, {m->D7}); m->b9 = add_tensor(m, "dense9.b", 4, {m->flat});
+    m->b11 = add_tensor(m, "deconv2d11.b", 0, {kF2L}, kF2); m->b13 = add_tensor(m, "deconv2d13.b", 0, {kF1});
+    m->b15 = add_tensor(m, "deconv2d14.b", 0, {1});
+    for (int k = 0; k < 4; ++k) {
+        if (hipMalloc((void**)&m->buf[k], m->flat_floats * sizeof(float)) != hipSuccess ||
+            hipMemset(m->buf[k], 0, m->flat_floats * sizeof(float)) != hipSuccess) {
+            set_error("allocating the parameter buffers failed"); adn_cae_destroy(m); return ADN_ERR_HIP;
+        }
+    }
+    *out = m;
+    return ADN_OK;
+}
+
+void adn_cae_destroy(adn_cae* m) {
+    if (!m) return;
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    for (int k = 0; k < 4; ++k) if (m->buf[k]) (void)hipFree(m->buf[k]);
+    if (m->slab) (void)hipFree(m->slab);
+    delete m;
+}
+
+int adn_cae_set_stream(adn_cae* m, void* hip_stream) {
+    ADN_CHECK(m, ADN_ERR_INVALID, "null model");
+    m->stream = static_cast<hipStream_t>(hip_stream);
+    return ADN_OK;
+}
+
+int adn_cae_num_params(const adn_cae* m) { return m ? (int)m->params.size() : 0; }
+
+int adn_cae_param_info(const adn_cae* m, int index, adn_param_info_t* info) {
+    ADN_CHECK(m && info, ADN_ERR_INVALID, "null argument");
+    ADN_CHECK(index >= 0 && index < (int)m->params.size(), ADN_ERR_INVALID, "parameter index out of range");
+    const Tensor& t = m->params[index];
+    memset(info, 0, sizeof(*info));
+    strncpy(info->name, t.name.c_str(), sizeof(info->name) - 1);
+    info->ndim = t.ndim <= 2 ? t.ndim : 2;           // 4-d filters are reported as (out, in*kh*kw)
+    info->dims[0] = t.dims[0];
+    info->dims[1] = t.ndim == 4 ? t.dims[1] * t.dims[2] * t.dims[3] : (t.ndim >= 2 ? t.dims[1] : 1);
+    info->numel = (int64_t)t.floats;
+    return ADN_OK;
+}
+
+int adn_cae_read_tensor(adn_cae* m, int buffer, int index, float* host_dst) {
+    ADN_CHECK(m && host_dst, ADN_ERR_INVALID, "null argument");
+    ADN_CHECK(buffer >= 0 && buffer < 4 && index >= 0 && index < (int)m->params.size(), ADN_ERR_INVALID, "bad buffer / index");
+    const Tensor& t = m->params[index];
+    const size_t phys = t.phys;
+    std::vector<float> dev(phys);
+    ADN_HIP_CHECK(hipStreamSynchronize(m->stream));
+    ADN_HIP_CHECK(hipMemcpy(dev.data(), m->buf[buffer] + t.off, phys * 4, hipMemcpyDeviceToHost));
+    to_host(m, t, dev, host_dst);
+    return ADN_OK;
+}
+
+int adn_cae_write_tensor(adn_cae* m, int buffer, int index, const float* host_src) {
+    ADN_CHECK(m && host_src, ADN_ERR_INVALID, "null argument");
+    ADN_CHECK(buffer >= 0 && buffer < 4 && index >= 0 && index < (int)m->params.size(), ADN_ERR_INVALID, "bad buffer / index");
+    const Tensor& t = m->params[index];
+    std::vector<float> dev;
+    to_internal(m, t, host_src, dev);
+    ADN_HIP_CHECK(hipStreamSynchronize(m->stream));
+    ADN_HIP_CHECK(hipMemcpy(m->buf[buffer] + t.off, dev.data(), dev.size() * 4, hipMemcpyHostToDevice));
+    return ADN_OK;
+}
+
+int adn_cae_flat_buffer(adn_cae* m, int buffer, float** ptr, int64_t* floats) {
+    ADN_CHECK(m && ptr && floats, ADN_ERR_INVALID, "null argument");
+    ADN_CHECK(buffer >= 0 && buffer < 4, ADN_ERR_INVALID, "bad buffer id");
+    *ptr = m->buf[buffer]; *floats = (int64_t)m->flat_floats;
+    return ADN_OK;
+}
+
+int adn_cae_forward(adn_cae* m, const float* x, int B, int flags, float* recon, float* code) {
+    ADN_CHECK(m && x, ADN_ERR_INVALID, "null argument");
+    ADN_CHECK(B >= 1 && B <= (1 << 16), ADN_ERR_INVALID, "batch size out of range");
+    ADN_TRY(ensure_ws(m, B));
+    ADN_TRY(stage(m, x, nullptr, B, flags));
+    ADN_TRY(forward(m, B, recon != nullptr));
+    if (code) {
+        if (flags & ADN_FLAG_DEVICE_OUTPUTS) {
+            ADN_HIP_CHECK(hipMemcpy2DAsync(code, (size_t)m->NB * 4, m->code, (size_t)m->ldb * 4, (size_t)m->NB * 4, B,
+                                           hipMemcpyDeviceToDevice, m->stream));
+        } else {
+            ADN_HIP_CHECK(hipMemcpy2DAsync(code, (size_t)m->NB * 4, m->code, (size_t)m->ldb * 4, (size_t)m->NB * 4, B,
+                                           hipMemcpyDeviceToHost, m->stream));
+            ADN_HIP_CHECK(hipStreamSynchronize(m->stream));
+        }
+    }
+    if (recon) return fetch(m, recon, m->a15, (size_t)B * m->H * m->W * 4, flags);
+    return ADN_OK;
+}
+
+int adn_cae_loss(adn_cae* m, const float* x, const float* target, int B, int flags, float* loss) {
+    ADN_CHECK(m && x && loss, ADN_ERR_INVALID, "null argument");
+    ADN_CHECK(B >= 1 && B <= (1 << 16), ADN_ERR_INVALID, "batch size out of range");
+    ADN_TRY(ensure_ws(m, B));
+    ADN_TRY(stage(m, x, target ? target : x, B, flags));
+    ADN_TRY(forward(m, B, true));
+    ADN_TRY(mse(m, B, false));
+    return fetch(m, loss, m->loss_dev, sizeof(float), flags);
+}
+
+int adn_cae_compute_grads(adn_cae* m, const float* x, const float* target, int B, int flags, float* loss) {
+    ADN_CHECK(m && x, ADN_ERR_INVALID, "null argument");
+    ADN_CHECK(B >= 1 && B <= (1 << 16), ADN_ERR_INVALID, "batch size out of range");
+    ADN_TRY(ensure_ws(m, B));
+    ADN_TRY(stage(m, x, target ? target : x, B, flags));
+    ADN_TRY(forward(m, B, true));
+    ADN_TRY(mse(m, B, true));
+    ADN_TRY(backward(m, B));
+    if (loss) return fetch(m, loss, m->loss_dev, sizeof(float), flags);
+    return ADN_OK;
+}
+
+int adn_cae_apply_adadelta(adn_cae* m, float learning_rate, float rho, float epsilon) {
+    ADN_CHECK(m, ADN_ERR_INVALID, "null model");
+    ADN_CHECK(m->grads_valid, ADN_ERR_STATE, "adn_cae_apply_adadelta called without gradients");
+    ADN_TRY(adadelta_update(m->buf[0], m->buf[1], m->buf[2], m->buf[3], (int64_t)m->flat_floats, learning_rate, rho, epsilon, m->stream));
+    m->grads_valid = false;
+    return ADN_OK;
+}
+
+int adn_cae_apply_adam(adn_cae* m, float learning_rate) {
+    ADN_CHECK(m, ADN_ERR_INVALID, "null model");
+    ADN_CHECK(m->grads_valid, ADN_ERR_STATE, "adn_cae_apply_adam called without gradients");
+    m->adam_t += 1;
+    const float t = (float)m->adam_t;
+    const float a_t = learning_rate * sqrtf(1.f - powf(0.999f, t)) / (1.f - powf(0.9f, t));
+    ADN_TRY(adam_update(m->buf[0], m->buf[1], m->buf[2], m->buf[3], (int64_t)m->flat_floats, a_t, 0.9f, 0.999f, 1e-8f, m->stream));
+    m->grads_valid = false;
+    return ADN_OK;
+}
+
+int adn_cae_synchronize(adn_cae* m) {
+    ADN_CHECK(m, ADN_ERR_INVALID, "null model");
+    ADN_HIP_CHECK(hipStreamSynchronize(m->stream));
+    return ADN_OK;
+}
+
+}  // extern "C"
