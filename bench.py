@@ -103,7 +103,14 @@ def cpu_baseline(budget_s=20.0):
         O.train_step(spec, p, st, xs, y, mask, THETA, LR)
         times.append(time.perf_counter() - t0)
     med = float(np.median(times))
-    return dict(value=Bc / med, unit="sequences/s", cores=os.cpu_count(), kind="port",
+    threads = os.cpu_count()
+    try:                                             # the threads the NumPy BLAS actually ran on
+        from threadpoolctl import threadpool_info
+        blas = [i["num_threads"] for i in threadpool_info() if i.get("user_api") == "blas"]
+        threads = max(blas) if blas else threads
+    except Exception:
+        pass
+    return dict(value=Bc / med, unit="sequences/s", cores=threads, kind="port",
                 sample="%d train steps of the NumPy fp32 oracle at B=26,T=40 (reference minibatch), median %.3f s/step"
                        % (len(times), med))
 
@@ -215,7 +222,7 @@ def main():
                        "final_loss": loss},
         }
         if prof:
-            g = [prof[k] for k in ("gemm_f32_nn", "gemm_f32_nt", "gemm_f32_tn") if k in prof]
+            g = [prof[k] for k in ("gemm_nn", "gemm_nt", "gemm_tn") if k in prof]
             flops = sum(e["flops"] for e in g); ms = sum(e["ms"] for e in g); n = sum(e["launches"] for e in g)
             ach = flops / (ms * 1e-3) / 1e12 if ms else 0.0
             peak = PEAK_BF16_MFMA_TFLOPS if args.precision == "bf16" else PEAK_F32_MFMA_TFLOPS
@@ -235,7 +242,10 @@ def main():
                 if key in prof and prof[key]["ms"]:
                     e = prof[key]
                     a = e["bytes"] / (e["ms"] * 1e-3) / 1e9
-                    out[name] = {"kernel": key, "bound": "hbm", "achieved": a, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    kern = ("lstm_%s_cluster_kernel (weight-stationary, all T steps in one launch; per time step)"
+                            % key[5:8]) if args.precision == "bf16" else key + "_kernel (one launch per time step)"
+                    out[name] = {"kernel": kern, "bound": "hbm", "achieved": a, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "algorithmic_bytes": "SURVEY 8d formula: e(12BH+4H^2)+B forward, e(15BH+4H^2) backward, per LSTM and step",
                                  "frac": a / PEAK_HBM_GBS, "traffic": None,
                                  "avg_launch_us": 1e3 * e["ms"] / e["launches"],
                                  "share_of_step": e["ms"] / (1e3 * prof_elapsed)}

@@ -76,6 +76,49 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ d
     }
 }
 
+// the same two kernels for C % 4 == 0, four channels per thread (float4 both ways, a quarter of the index arithmetic)
+__global__ __launch_bounds__(256) void im2col4_kernel(const float4* __restrict__ x, float4* __restrict__ cols, int B, int H, int W,
+                                                      int C4, int kh, int kw, int ph, int pw, int OH, int OW, int ldc4) {
+    const int K4 = kh * kw * C4;
+    const int64_t total = (int64_t)B * OH * OW * K4;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int k = (int)(e % K4);
+        const int64_t r = e / K4;
+        const int c = k % C4, ij = k / C4, j = ij % kw, i = ij / kw;
+        const int ox = (int)(r % OW), oy = (int)((r / OW) % OH), b = (int)(r / ((int64_t)OW * OH));
+        const int y = oy + i - ph, xx = ox + j - pw;
+        cols[(size_t)r * ldc4 + k] = (y >= 0 && y < H && xx >= 0 && xx < W) ? x[(((size_t)b * H + y) * W + xx) * C4 + c] : z;
+    }
+}
+
+__global__ __launch_bounds__(256) void col2im4_kernel(const float4* __restrict__ dcols, int ldc4, float4* __restrict__ out, int B,
+                                                      int H, int W, int C4, int kh, int kw, int ph, int pw, int OH, int OW,
+                                                      const float4* __restrict__ bias, int act) {
+    const int64_t total = (int64_t)B * H * W * C4;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % C4);
+        const int64_t p = e / C4;
+        const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((int64_t)W * H));
+        float4 acc = bias ? bias[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < kh; ++i) {
+            const int oy = y + ph - i;
+            if (oy < 0 || oy >= OH) continue;
+            for (int j = 0; j < kw; ++j) {
+                const int ox = x + pw - j;
+                if (ox < 0 || ox >= OW) continue;
+                const float4 v = dcols[(((size_t)b * OH + oy) * OW + ox) * ldc4 + (i * kw + j) * C4 + c];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+        if (act == ADN_ACT_SCALED_TANH) {
+            acc.x = 2.4f * tanhf(0.5f * acc.x); acc.y = 2.4f * tanhf(0.5f * acc.y);
+            acc.z = 2.4f * tanhf(0.5f * acc.z); acc.w = 2.4f * tanhf(0.5f * acc.w);
+        }
+        out[e] = acc;
+    }
+}
+
 // 2x2 / stride 2 max pooling, ignore_border, `ph` rows of padding above and below that never win; code = dy*2 + dx
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ arg,
                                                           int B, int H, int W, int C, int ph, int OH, int OW) {
@@ -266,6 +309,10 @@ int mm(adn_cae* m, int layout, int M, int N, int K, const float* A, int lda, con
 
 int im2col(adn_cae* m, const float* x, const ConvGeom& g, int B, float* cols) {
     const int64_t total = (int64_t)rows_of(g, B) * g.K;
+    if (g.C % 4 == 0)
+        hipLaunchKernelGGL(im2col4_kernel, dim3(grid_of(total / 4)), dim3(256), 0, m->stream, reinterpret_cast<const float4*>(x),
+                           reinterpret_cast<float4*>(cols), B, g.H, g.W, g.C / 4, g.k, g.k, g.ph, g.pw, g.OH, g.OW, g.ldk / 4);
+    else
     hipLaunchKernelGGL(im2col_kernel, dim3(grid_of(total)), dim3(256), 0, m->stream, x, cols, B, g.H, g.W, g.C, g.k, g.k, g.ph, g.pw,
                        g.OH, g.OW, g.ldk);
     ADN_HIP_CHECK(hipGetLastError());
@@ -274,6 +321,11 @@ int im2col(adn_cae* m, const float* x, const ConvGeom& g, int B, float* cols) {
 
 int col2im(adn_cae* m, const float* dcols, const ConvGeom& g, int B, float* out, const float* bias, int act) {
     const int64_t total = (int64_t)B * g.H * g.W * g.C;
+    if (g.C % 4 == 0)
+        hipLaunchKernelGGL(col2im4_kernel, dim3(grid_of(total / 4)), dim3(256), 0, m->stream, reinterpret_cast<const float4*>(dcols),
+                           g.ldk / 4, reinterpret_cast<float4*>(out), B, g.H, g.W, g.C / 4, g.k, g.k, g.ph, g.pw, g.OH, g.OW,
+                           reinterpret_cast<const float4*>(bias), act);
+    else
     hipLaunchKernelGGL(col2im_kernel, dim3(grid_of(total)), dim3(256), 0, m->stream, dcols, g.ldk, out, B, g.H, g.W, g.C, g.k, g.k,
                        g.ph, g.pw, g.OH, g.OW, bias, act);
     ADN_HIP_CHECK(hipGetLastError());

@@ -74,7 +74,8 @@ ProfScope::~ProfScope() {
 
 namespace {
 
-const char* const kProfNames[PROF_COUNT] = {"gemm_f32_nn", "gemm_f32_nt", "gemm_f32_tn", "lstm_fwd_step",
+// (gemm_*: by the layout the caller asked for; lstm_*: one time step of one group launch, whichever kernel family ran)
+const char* const kProfNames[PROF_COUNT] = {"gemm_nn", "gemm_nt", "gemm_tn", "lstm_fwd_step",
                                             "lstm_bwd_step", "delta_fwd", "delta_bwd", "adam", "softmax_loss"};
 
 constexpr float kBeta1 = 0.9f, kBeta2 = 0.999f, kEps = 1e-8f;
