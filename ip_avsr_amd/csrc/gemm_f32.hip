@@ -193,8 +193,12 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
     static const int force_tile = getenv("ADN_GEMM_TILE") ? atoi(getenv("ADN_GEMM_TILE")) : 0;   // experiments only
     // ... and K is deep enough to amortise a 128x128 tile's prologue + epilogue latency (3 workgroups per CU
     // cannot hide it: at K <= 512 the 64x64 shape, 8 workgroups per CU, is 1.3-2.2x faster; equal at K = 1024)
+    // ... and the 128-wide tiles do not waste much more of their area on the matrix edges than 64-wide ones would
+    // (N = 152: 59 % vs 79 % useful)
+    const double fill128 = (double)g.M * g.N / ((double)t128 * 128 * 128), fill64 = (double)g.M * g.N / ((double)t64 * 64 * 64);
     const bool big = force_tile ? force_tile == 128
-                                : (g.K >= 768 && (t128 >= 384 || (can_split && t128 >= 24 && g.K >= 2048)));
+                                : (g.K >= 768 && fill128 >= 0.85 * fill64 &&
+                                   (t128 >= 384 || (can_split && t128 >= 24 && g.K >= 2048)));
     // bf16 with shadow operands: 256x128 tiles (each wave 128x64: 25 % fewer LDS fragment reads and L2 bytes
     // per MFMA, twice the MFMA work between barriers) when even that coarse grid fills the chip
     const int64_t t256 = (int64_t)cdiv(g.M, 256) * cdiv(g.N, 128);
