@@ -47,6 +47,23 @@ constexpr int kCWElems = kCUnits * 4 * kCHP;    // bf16 elements of one workgrou
 constexpr int kCHS = kCHP + 8;                  // LDS row stride of the h / dG images (bf16)
 constexpr int kSpinLimit = 1 << 18;
 
+// optional phase timing of one forward workgroup (build with -DADN_LSTM_STAMPS; read with adn_debug_lstm_stamps):
+// 100 MHz wall-clock ticks spent in [product, gate math + publish, outputs, poll, fill + barrier], summed over steps
+#ifdef ADN_LSTM_STAMPS
+__device__ unsigned long long g_stamps[8];
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+#define STAMP(k) do { if (blockIdx.x == 5 && blockIdx.y == 0 && tid == 0) { const unsigned long long now_ = stamp_now(); \
+    atomicAdd(&g_stamps[k], now_ - last_); last_ = now_; } } while (0)
+#define STAMP_INIT unsigned long long last_ = stamp_now();
+#else
+#define STAMP(k) do {} while (0)
+#define STAMP_INIT
+#endif
+
 __device__ __forceinline__ unsigned long long granule_load(const unsigned long long* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -139,12 +156,14 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const LstmCluster
         }
     };
 
+    STAMP_INIT
     for (int step = 0; step < T; ++step) {
         const int t = P.backwards ? (T - 1 - step) : step;
         const int out_blk = t + (P.backwards ? 0 : 1);
         const unsigned tag = tag0 + (unsigned)step;
         unsigned long long* xpar = xb + (size_t)(step & 1) * 16 * kCHP;
-        // masks and input projections of the step (the round trip hides under the recurrent product)
+        // masks and input projections of the step (the round trip hides under the recurrent product; requesting them a
+        // step ahead, before or after the polls, measured no faster)
         request_inputs(step, m, xp);
         // ---- recurrent product out of LDS: 4 gate tiles x 8 k-steps
         f32x4 acc[4];
@@ -158,6 +177,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const LstmCluster
                 acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wfrag[(g * kCKS + s) * 64], acc[g], 0, 0, 0);
         }
         __syncthreads();                              // every wave has read h_{t-1}: the image may be overwritten
+        STAMP(0);
         // ---- gate math; lane = (unit, 4 rows)
         float h_out[4];
         float4 gts[4];
@@ -189,6 +209,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const LstmCluster
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) hs[16 * rt + 4 * kq + r][u] = (__bf16)h_out[r];
+        STAMP(1);
         // ---- the step's outputs
         if (u < H) {
 #pragma unroll
@@ -204,6 +225,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const LstmCluster
                 }
             }
         }
+        STAMP(2);
         // ---- gather the partners' h_t
         if (step + 1 < T) {
             const unsigned long long* ptr[6];
@@ -211,6 +233,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const LstmCluster
 #pragma unroll
             for (int k = 0; k < 6; ++k) ptr[k] = xpar + f_off[k];
             granule_wait<6>(ptr, tag, pay, err);
+            STAMP(3);
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 const bf16x2 pr = __builtin_bit_cast(bf16x2, pay[k]);
@@ -219,6 +242,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const LstmCluster
             }
         }
         __syncthreads();
+        STAMP(4);
     }
 }
 
@@ -541,3 +565,11 @@ int lstm_backward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int 
 }
 
 }  // namespace adn
+
+#ifdef ADN_LSTM_STAMPS
+extern "C" int adn_debug_lstm_stamps(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(adn::g_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(adn::g_stamps), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
