@@ -13,7 +13,8 @@
 //             granule                                                                 3 x 32 x 64 values in
 // Two parities of the exchange buffer suffice: a workgroup can only be one step ahead of its partners.
 // Every workgroup of a launch must be resident at once (they wait for each other): the host launches at most one
-// workgroup per CU (LDS: 145 KB each) and splits larger sets of LSTMs over several launches.  Polls are bounded; a
+// workgroup per CU (LDS: 145 KB each) and splits larger sets of LSTMs over several launches.  Polls are bounded (10 s
+// of wall clock); a
 // poll that gives up raises the launch's error word and the host reports ADN_ERR_STATE -- never a hang.
 #include "adn_common.h"
 #include <algorithm>
@@ -45,7 +46,16 @@ constexpr int kCHP = kCWG * kCUnits;            // padded hidden size (256)
 constexpr int kCKS = kCHP / 32;                 // k-steps of the forward product
 constexpr int kCWElems = kCUnits * 4 * kCHP;    // bf16 elements of one workgroup's W slice (128 KB)
 constexpr int kCHS = kCHP + 8;                  // LDS row stride of the h / dG images (bf16)
-constexpr int kSpinLimit = 1 << 18;
+// A poll gives up after kPollTimeoutTicks of the 100 MHz wall clock (s_memrealtime), checked every 1024 spins.  Generous
+// on purpose: partners can be late for reasons that are not a deadlock -- e.g. a collective kernel of the data-parallel
+// path holding CUs until a slower rank arrives, so that not every workgroup of a launch is resident yet.
+constexpr unsigned long long kPollTimeoutTicks = 10ull * 100000000ull;   // 10 s
+
+__device__ __forceinline__ unsigned long long wall_ticks() {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
 
 // optional phase timing of one forward workgroup (build with -DADN_LSTM_STAMPS; read with adn_debug_lstm_stamps):
 // 100 MHz wall-clock ticks spent in [product, gate math + publish, outputs, poll, fill + barrier], summed over steps
@@ -84,6 +94,7 @@ template <int N>
 __device__ __forceinline__ bool granule_wait(const unsigned long long* const (&ptr)[N], unsigned tag, unsigned (&payload)[N],
                                              int* err) {
     unsigned pending = (1u << N) - 1u;
+    unsigned long long t_start = 0;
     for (int spin = 0; pending; ++spin) {
         unsigned long long g[N];
 #pragma unroll
@@ -92,8 +103,15 @@ __device__ __forceinline__ bool granule_wait(const unsigned long long* const (&p
 #pragma unroll
         for (int k = 0; k < N; ++k)
             if ((pending & (1u << k)) && (unsigned)(g[k] >> 32) == tag) { payload[k] = (unsigned)g[k]; pending &= ~(1u << k); }
-        if (pending && spin >= kSpinLimit) { atomicCAS(err, 0, 1 | ((int)(tag & 1023u) << 4) | ((int)blockIdx.x << 16)); return false; }
-        if (pending && (spin & 1023) == 1023 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+        if (pending && (spin & 1023) == 1023) {
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+            const unsigned long long now = wall_ticks();
+            if (!t_start) t_start = now;
+            else if (now - t_start > kPollTimeoutTicks) {
+                atomicCAS(err, 0, 1 | ((int)(tag & 1023u) << 4) | ((int)blockIdx.x << 16));
+                return false;
+            }
+        }
     }
     return true;
 }
@@ -373,6 +391,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_kernel(const LstmCluster
                 ptr[k] = xpar + (size_t)(j * 4 + src) * kBxPair + (size_t)(8 * rt + 2 * kq + rp) * kCUnits + ul;
             }
             unsigned pending = 63u;
+            unsigned long long t_start = 0;
             for (int spin = 0; pending; ++spin) {
                 unsigned long long v[6];
 #pragma unroll
@@ -383,8 +402,12 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_kernel(const LstmCluster
                     if ((pending & (1u << k)) && (((unsigned)v[k] & 15u) | (((unsigned)(v[k] >> 32) & 15u) << 4)) == tag8) {
                         g[k] = v[k]; pending &= ~(1u << k);
                     }
-                if (pending && spin >= kSpinLimit) { atomicCAS(err, 0, 2 | (step << 4) | ((int)blockIdx.x << 16)); break; }
-                if (pending && (spin & 1023) == 1023 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                if (pending && (spin & 1023) == 1023) {
+                    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                    const unsigned long long now = wall_ticks();
+                    if (!t_start) t_start = now;
+                    else if (now - t_start > kPollTimeoutTicks) { atomicCAS(err, 0, 2 | (step << 4) | ((int)blockIdx.x << 16)); break; }
+                }
             }
             STAMP(6);
 #pragma unroll
