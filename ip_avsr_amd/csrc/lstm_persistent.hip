@@ -50,6 +50,13 @@ __device__ __forceinline__ void quad_transpose(f32x4& a, int lane) {
     a[0] = hi ? q2 : b0; a[1] = hi ? q3 : b1; a[2] = hi ? b2 : q0; a[3] = hi ? b3 : q1;
 }
 
+// workgroup barrier that orders LDS traffic only (__syncthreads() would also wait for every outstanding global store
+// and load of the step: see lstm_cluster.hip)
+__device__ __forceinline__ void p_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
 constexpr int kPRows = 16;      // utterances per workgroup
 constexpr int kPWaves = 8;
 
@@ -102,12 +109,12 @@ __global__ __launch_bounds__(512) void lstm_fwd_persistent_kernel(const LstmLaun
         const int t = P.backwards ? (T - 1 - step) : step;
         const int out_blk = t + (P.backwards ? 0 : 1);
         // ---- phase 1: masks and input projections of the step
-        bool m[4];
+        uint8_t m[4];             // raw bytes, compared where used: the request must not wait for its own data
         float4 xp[UT][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const size_t ridx = (size_t)t * B + min(r0 + 4 * kq + r, B - 1);
-            m[r] = mask_tb[ridx] != 0;
+            m[r] = mask_tb[ridx];
 #pragma unroll
             for (int ut = 0; ut < UT; ++ut)
                 xp[ut][r] = *reinterpret_cast<const float4*>(P.xproj + ridx * ldg + min(ubase + 16 * ut + i, H - 1) * 4);
@@ -160,7 +167,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_persistent_kernel(const LstmLaun
                 }
             }
         }
-        __syncthreads();
+        p_lds_barrier();
         cur ^= 1;
     }
 }
@@ -220,10 +227,10 @@ __global__ __launch_bounds__(512) void lstm_bwd_persistent_kernel(const LstmLaun
         // every load of this step's gate math is issued before its first store (one exposed round trip)
         float l_dhs[CT][4], l_ct[CT][4], l_cp[CT][4];
         float4 l_gt[CT][4];
-        bool l_m[4];
+        uint8_t l_m[4];
         const int prev_blk = t + (P.backwards ? 1 : 0), out_blk = t + (P.backwards ? 0 : 1);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) l_m[r] = mask_tb[(size_t)t * B + min(r0 + 4 * kq + r, B - 1)] != 0;
+        for (int r = 0; r < 4; ++r) l_m[r] = mask_tb[(size_t)t * B + min(r0 + 4 * kq + r, B - 1)];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const int uc = min(ubase + 16 * ct + i, H - 1);
@@ -293,7 +300,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_persistent_kernel(const LstmLaun
                 pw_i = pw_f = pw_o = 0.f;
             }
         }
-        __syncthreads();
+        p_lds_barrier();
         cur ^= 1;
     }
     // gradient wrt the initial state of every row of this slice (summed over rows by the caller)
