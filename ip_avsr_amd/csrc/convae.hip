@@ -119,6 +119,25 @@ __global__ __launch_bounds__(256) void col2im4_kernel(const float4* __restrict__
     }
 }
 
+// im2col straight to bf16 (C % 4 == 0): the patches matrix of the bf16 GEMMs, half the bytes of the fp32 one
+typedef __bf16 cae_bf16x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void im2col4_bf16_kernel(const float4* __restrict__ x, cae_bf16x4* __restrict__ cols, int B, int H,
+                                                           int W, int C4, int kh, int kw, int ph, int pw, int OH, int OW, int ldc4) {
+    const int K4 = kh * kw * C4;
+    const int64_t total = (int64_t)B * OH * OW * K4;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int k = (int)(e % K4);
+        const int64_t r = e / K4;
+        const int c = k % C4, ij = k / C4, j = ij % kw, i = ij / kw;
+        const int ox = (int)(r % OW), oy = (int)((r / OW) % OH), b = (int)(r / ((int64_t)OW * OH));
+        const int y = oy + i - ph, xx = ox + j - pw;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (y >= 0 && y < H && xx >= 0 && xx < W) v = x[(((size_t)b * H + y) * W + xx) * C4 + c];
+        cae_bf16x4 o; o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+        cols[(size_t)r * ldc4 + k] = o;
+    }
+}
+
 // 2x2 / stride 2 max pooling, ignore_border, `ph` rows of padding above and below that never win; code = dy*2 + dx
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ arg,
                                                           int B, int H, int W, int C, int ph, int OH, int OW) {
@@ -196,7 +215,7 @@ struct ConvGeom { int H, W, C, k, O, ph, pw, OH, OW, K, ldk; };
 
 ConvGeom conv_geom(int H, int W, int C, int k, int O, int ph = 0, int pw = 0) {
     ConvGeom g{H, W, C, k, O, ph, pw, H + 2 * ph - k + 1, W + 2 * pw - k + 1, k * k * C, 0};
-    g.ldk = (int)round_up(g.K, 4);
+    g.ldk = (int)round_up(g.K, 8);      // 8: the bf16 patches matrix must keep 16-byte rows too
     return g;
 }
 
@@ -221,6 +240,9 @@ struct adn_cae {
           *u12 = nullptr, *a13 = nullptr, *u14 = nullptr, *a15 = nullptr, *target = nullptr, *scratch = nullptr,
           *gA = nullptr, *gB = nullptr, *loss_dev = nullptr;
     uint8_t *arg2 = nullptr, *arg4 = nullptr;
+    // bf16 mode: bf16 copy of the parameters (same layout), of the deconv inputs, and a scratch for gradients
+    char *p16 = nullptr, *a9_16 = nullptr, *u12_16 = nullptr, *t16 = nullptr;
+    bool p16_dirty = true;
     bool grads_valid = false;
     int adam_t = 0;
     float* P(size_t off) const { return buf[0] + off; }
@@ -282,6 +304,9 @@ size_t carve(adn_cae* m, char* base, int B) {
     m->scratch = c.take<float>(sc);
     m->gA = c.take<float>(act); m->gB = c.take<float>(act);
     m->loss_dev = c.take<float>(8);
+    m->a9_16 = c.take<char>(N * m->flat * 2);
+    m->u12_16 = c.take<char>(N * 4 * m->d11.H * m->d11.W * kF2 * 2);
+    m->t16 = c.take<char>(act * 2);
     return c.cur;
 }
 
@@ -305,6 +330,30 @@ int mm(adn_cae* m, int layout, int M, int N, int K, const float* A, int lda, con
     g.layout = layout; g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = Bm; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.bias = bias; g.act = act; g.accumulate = accumulate; g.precision = m->precision;
     return gemm(g, m->stream);
+}
+
+// the heavy layers (150 / 200 filters, K = 2500 / 1368) run on the bf16-operand GEMM kernels in bf16 mode
+bool fast16(const adn_cae* m, const ConvGeom& g) {
+    return m->precision == ADN_PRECISION_BF16 && g.O % 8 == 0 && g.C % 4 == 0;      // (row strides: ldk and O)
+}
+const void* W16(const adn_cae* m, size_t off) { return m->p16 + off * 2; }
+
+int mm16(adn_cae* m, int layout, int M, int N, int K, const void* A16, int lda, const void* B16, int ldb, float* C, int ldc,
+         const float* bias = nullptr, int act = ADN_ACT_LINEAR, int accumulate = 0) {
+    GemmArgs g;
+    g.layout = layout; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.A = reinterpret_cast<const float*>(A16); g.B = reinterpret_cast<const float*>(B16);      // (only the bf16 views are read)
+    g.A16 = A16; g.B16 = B16;
+    g.bias = bias; g.act = act; g.accumulate = accumulate; g.precision = ADN_PRECISION_BF16;
+    return gemm(g, m->stream);
+}
+
+int im2col16(adn_cae* m, const float* x, const ConvGeom& g, int B, void* cols16) {
+    const int64_t total = (int64_t)rows_of(g, B) * g.K;
+    hipLaunchKernelGGL(im2col4_bf16_kernel, dim3(grid_of(total / 4)), dim3(256), 0, m->stream, reinterpret_cast<const float4*>(x),
+                       reinterpret_cast<cae_bf16x4*>(cols16), B, g.H, g.W, g.C / 4, g.k, g.k, g.ph, g.pw, g.OH, g.OW, g.ldk / 4);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
 }
 
 int im2col(adn_cae* m, const float* x, const ConvGeom& g, int B, float* cols) {
@@ -334,6 +383,10 @@ int col2im(adn_cae* m, const float* dcols, const ConvGeom& g, int B, float* out,
 
 // y = act(conv(x) + b): patches kept in `cols` for the backward pass
 int conv_fwd(adn_cae* m, const float* x, const ConvGeom& g, int B, float* cols, size_t W, size_t b, float* y) {
+    if (fast16(m, g)) {                              // `cols` holds the bf16 patches matrix in this mode
+        ADN_TRY(im2col16(m, x, g, B, cols));
+        return mm16(m, GEMM_NN, (int)rows_of(g, B), g.O, g.K, cols, g.ldk, W16(m, W), g.O, y, g.O, m->P(b), ADN_ACT_SCALED_TANH);
+    }
     ADN_TRY(im2col(m, x, g, B, cols));
     return mm(m, GEMM_NN, (int)rows_of(g, B), g.O, g.K, cols, g.ldk, m->P(W), g.O, y, g.O, m->P(b), ADN_ACT_SCALED_TANH);
 }
@@ -341,6 +394,16 @@ int conv_fwd(adn_cae* m, const float* x, const ConvGeom& g, int B, float* cols, 
 // dy (already multiplied by act') -> dW, db, and (optionally) dx
 int conv_bwd(adn_cae* m, const ConvGeom& g, int B, const float* cols, const float* dy, size_t W, size_t b, float* dx) {
     const int R = (int)rows_of(g, B);
+    if (fast16(m, g)) {
+        ADN_TRY(to_bf16(dy, m->t16, (size_t)R * g.O, m->stream));
+        ADN_TRY(mm16(m, GEMM_TN, g.K, g.O, R, cols, g.ldk, m->t16, g.O, m->G(W), g.O, nullptr, ADN_ACT_LINEAR, 1));
+        ADN_TRY(col_sum(dy, g.O, R, g.O, m->G(b), 1, m->stream));
+        if (dx) {
+            ADN_TRY(mm16(m, GEMM_NT, R, g.K, g.O, m->t16, g.O, W16(m, W), g.O, m->scratch, g.ldk));
+            ADN_TRY(col2im(m, m->scratch, g, B, dx, nullptr, ADN_ACT_LINEAR));
+        }
+        return ADN_OK;
+    }
     ADN_TRY(mm(m, GEMM_TN, g.K, g.O, R, cols, g.ldk, dy, g.O, m->G(W), g.O, nullptr, ADN_ACT_LINEAR, 1));
     ADN_TRY(col_sum(dy, g.O, R, g.O, m->G(b), 1, m->stream));
     if (dx) {
@@ -351,15 +414,28 @@ int conv_bwd(adn_cae* m, const ConvGeom& g, int B, const float* cols, const floa
 }
 
 // z = act(adjoint_conv(x) + b): x [B*OH*OW][O] -> z [B][H][W][C]   (g = the tied convolution, crop = its padding)
-int deconv_fwd(adn_cae* m, const float* x, const ConvGeom& g, int B, size_t W, size_t b, float* z) {
+// x16: bf16 copy of x (kept for the backward pass), null = fp32 path
+int deconv_fwd(adn_cae* m, const float* x, void* x16, const ConvGeom& g, int B, size_t W, size_t b, float* z) {
+    if (x16 && fast16(m, g)) {
+        const int R = (int)rows_of(g, B);
+        ADN_TRY(to_bf16(x, x16, (size_t)R * g.O, m->stream));
+        ADN_TRY(mm16(m, GEMM_NT, R, g.K, g.O, x16, g.O, W16(m, W), g.O, m->scratch, g.ldk));
+        return col2im(m, m->scratch, g, B, z, m->P(b), ADN_ACT_SCALED_TANH);
+    }
     ADN_TRY(mm(m, GEMM_NT, (int)rows_of(g, B), g.K, g.O, x, g.O, m->P(W), g.O, m->scratch, g.ldk));
     return col2im(m, m->scratch, g, B, z, m->P(b), ADN_ACT_SCALED_TANH);
 }
 
 // dz (already multiplied by act') -> db, dW (tied), dx
-int deconv_bwd(adn_cae* m, const ConvGeom& g, int B, const float* x, const float* dz, size_t W, size_t b, float* dx) {
+int deconv_bwd(adn_cae* m, const ConvGeom& g, int B, const float* x, const void* x16, const float* dz, size_t W, size_t b,
+               float* dx) {
     const int R = (int)rows_of(g, B);
     ADN_TRY(col_sum(dz, g.C, B * g.H * g.W, g.C, m->G(b), 1, m->stream));
+    if (x16 && fast16(m, g)) {
+        ADN_TRY(im2col16(m, dz, g, B, m->scratch));
+        ADN_TRY(mm16(m, GEMM_NN, R, g.O, g.K, m->scratch, g.ldk, W16(m, W), g.O, dx, g.O));
+        return mm16(m, GEMM_TN, g.K, g.O, R, m->scratch, g.ldk, x16, g.O, m->G(W), g.O, nullptr, ADN_ACT_LINEAR, 1);
+    }
     ADN_TRY(im2col(m, dz, g, B, m->scratch));
     ADN_TRY(mm(m, GEMM_NN, R, g.O, g.K, m->scratch, g.ldk, m->P(W), g.O, dx, g.O));
     return mm(m, GEMM_TN, g.K, g.O, R, m->scratch, g.ldk, x, g.O, m->G(W), g.O, nullptr, ADN_ACT_LINEAR, 1);
@@ -396,6 +472,11 @@ int stage(adn_cae* m, const float* x, const float* target, int B, int flags) {
 
 int forward(adn_cae* m, int B, bool decode) {
     const int S = ADN_ACT_SCALED_TANH;
+    if (m->precision == ADN_PRECISION_BF16 && m->p16_dirty) {
+        if (!m->p16) ADN_HIP_CHECK(hipMalloc((void**)&m->p16, (size_t)round_up((int64_t)m->flat_floats, 8) * 2));
+        ADN_TRY(to_bf16(m->buf[0], m->p16, (size_t)(m->flat_floats / 8 * 8), m->stream));
+        m->p16_dirty = false;
+    }
     ADN_TRY(conv_fwd(m, m->x0, m->c1, B, m->cols1, m->W1, m->b1, m->a1));
     ADN_TRY(maxpool_fwd(m, m->a1, B, m->c1.OH, m->c1.OW, kF1, 0, m->p2h, m->p2w, m->p2, m->arg2));
     ADN_TRY(conv_fwd(m, m->p2, m->c3, B, m->cols3, m->W3, m->b3, m->a3));
@@ -406,11 +487,11 @@ int forward(adn_cae* m, int B, bool decode) {
     if (!decode) return ADN_OK;
     ADN_TRY(mm(m, GEMM_NT, B, m->D7, m->NB, m->code, m->ldb, m->P(m->Wb), m->ldb, m->a8, m->D7, m->P(m->b8)));
     ADN_TRY(mm(m, GEMM_NT, B, m->flat, m->D7, m->a8, m->D7, m->P(m->W7), m->D7, m->a9, m->flat, m->P(m->b9), S));
-    ADN_TRY(deconv_fwd(m, m->a9, m->d11, B, m->W5, m->b11, m->a11));
+    ADN_TRY(deconv_fwd(m, m->a9, m->a9_16, m->d11, B, m->W5, m->b11, m->a11));
     ADN_TRY(upscale_fwd(m, m->a11, B, m->d11.H, m->d11.W, kF2, m->u12));
-    ADN_TRY(deconv_fwd(m, m->u12, m->d13, B, m->W3, m->b13, m->a13));
+    ADN_TRY(deconv_fwd(m, m->u12, m->u12_16, m->d13, B, m->W3, m->b13, m->a13));
     ADN_TRY(upscale_fwd(m, m->a13, B, m->d13.H, m->d13.W, kF1, m->u14));
-    return deconv_fwd(m, m->u14, m->d15, B, m->W1, m->b15, m->a15);
+    return deconv_fwd(m, m->u14, nullptr, m->d15, B, m->W1, m->b15, m->a15);
 }
 
 // loss_dev[0] = mean((recon - target)^2); gA = d loss / d recon when want_grad
@@ -433,13 +514,13 @@ int backward(adn_cae* m, int B) {
     float *gA = m->gA, *gB = m->gB;
     // decoder
     ADN_TRY(act_backward(gA, 1, m->a15, 1, B * m->H * m->W, 1, S, s));
-    ADN_TRY(deconv_bwd(m, m->d15, B, m->u14, gA, m->W1, m->b15, gB));                    // gB = d u14
+    ADN_TRY(deconv_bwd(m, m->d15, B, m->u14, nullptr, gA, m->W1, m->b15, gB));                    // gB = d u14
     ADN_TRY(upscale_bwd(m, gB, B, m->d13.H, m->d13.W, kF1, gA));                          // gA = d a13
     ADN_TRY(act_backward(gA, kF1, m->a13, kF1, B * m->d13.H * m->d13.W, kF1, S, s));
-    ADN_TRY(deconv_bwd(m, m->d13, B, m->u12, gA, m->W3, m->b13, gB));                    // gB = d u12
+    ADN_TRY(deconv_bwd(m, m->d13, B, m->u12, m->u12_16, gA, m->W3, m->b13, gB));                    // gB = d u12
     ADN_TRY(upscale_bwd(m, gB, B, m->d11.H, m->d11.W, kF2, gA));                          // gA = d a11
     ADN_TRY(act_backward(gA, kF2, m->a11, kF2, B * m->d11.H * m->d11.W, kF2, S, s));
-    ADN_TRY(deconv_bwd(m, m->d11, B, m->a9, gA, m->W5, m->b11, gB));                     // gB = d a9 (as [B][flat])
+    ADN_TRY(deconv_bwd(m, m->d11, B, m->a9, m->a9_16, gA, m->W5, m->b11, gB));                     // gB = d a9 (as [B][flat])
     ADN_TRY(act_backward(gB, m->flat, m->a9, m->flat, B, m->flat, S, s));
     ADN_TRY(col_sum(gB, m->flat, B, m->flat, m->G(m->b9), 1, s));
     ADN_TRY(mm(m, GEMM_TN, m->flat, m->D7, B, gB, m->flat, m->a8, m->D7, m->G(m->W7), m->D7, nullptr, ADN_ACT_LINEAR, 1));
@@ -574,6 +655,7 @@ void adn_cae_destroy(adn_cae* m) {
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     for (int k = 0; k < 4; ++k) if (m->buf[k]) (void)hipFree(m->buf[k]);
     if (m->slab) (void)hipFree(m->slab);
+    if (m->p16) (void)hipFree(m->p16);
     delete m;
 }
 
@@ -618,6 +700,7 @@ int adn_cae_write_tensor(adn_cae* m, int buffer, int index, const float* host_sr
     to_internal(m, t, host_src, dev);
     ADN_HIP_CHECK(hipStreamSynchronize(m->stream));
     ADN_HIP_CHECK(hipMemcpy(m->buf[buffer] + t.off, dev.data(), dev.size() * 4, hipMemcpyHostToDevice));
+    if (buffer == ADN_BUF_PARAM) m->p16_dirty = true;
     return ADN_OK;
 }
 
@@ -675,6 +758,7 @@ int adn_cae_apply_adadelta(adn_cae* m, float learning_rate, float rho, float eps
     ADN_CHECK(m->grads_valid, ADN_ERR_STATE, "adn_cae_apply_adadelta called without gradients");
     ADN_TRY(adadelta_update(m->buf[0], m->buf[1], m->buf[2], m->buf[3], (int64_t)m->flat_floats, learning_rate, rho, epsilon, m->stream));
     m->grads_valid = false;
+    m->p16_dirty = true;
     return ADN_OK;
 }
 
@@ -686,6 +770,7 @@ int adn_cae_apply_adam(adn_cae* m, float learning_rate) {
     const float a_t = learning_rate * sqrtf(1.f - powf(0.999f, t)) / (1.f - powf(0.9f, t));
     ADN_TRY(adam_update(m->buf[0], m->buf[1], m->buf[2], m->buf[3], (int64_t)m->flat_floats, a_t, 0.9f, 0.999f, 1e-8f, m->stream));
     m->grads_valid = false;
+    m->p16_dirty = true;
     return ADN_OK;
 }
 

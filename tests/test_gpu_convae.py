@@ -98,6 +98,13 @@ def test_zoo_factory_and_bf16_mode(ConvAE):
     b16.set_all_param_values(vals)
     r32, r16 = net.recon_fn(x), b16.recon_fn(x)
     assert np.abs(r16 - r32).max() <= 5e-2 * max(1.0, np.abs(r32).max())
+    l32, l16 = net.compute_grads(x), b16.compute_grads(x)                # heavy layers on the bf16-operand GEMM kernels
+    assert abs(l16 - l32) <= 2e-2 * l32
+    g32, g16 = net.get_grads_dict(), b16.get_grads_dict()
+    for k in g32:
+        a, b = g32[k].ravel().astype(np.float64), g16[k].ravel().astype(np.float64)
+        cos = a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)
+        assert cos > 0.99 and abs(np.linalg.norm(b) / np.linalg.norm(a) - 1) < 0.1, (k, cos)
     net.close(); b16.close()
     with pytest.raises(Exception):
         ConvAE((10, 10), 8, 2)
