@@ -131,6 +131,9 @@ struct StreamState {
     float* hsum = nullptr;                     // stream output when bidirectional (else alias of lw[0].out)
     float* dout_buf = nullptr;                 // own buffer for the gradient wrt the stream output
     float* out_drop = nullptr;                 // stream output after the fused-tensor dropout (concat / single stream)
+    float *pingA = nullptr, *pingB = nullptr;  // dZ ping-pong of this stream's encoder back-propagation (own copy: the
+    int ping_ld = 0;                           // streams back-propagate concurrently on their own HIP streams)
+    float* colsum_ws = nullptr; size_t colsum_ws_floats = 0;
     int dout_ld = 0;                           // row stride of `dout` (0: ldh)
     float* dout = nullptr;                     // ... the buffer actually holding it (may be a shared one)
     float* dfeat = nullptr;
@@ -183,9 +186,11 @@ struct adn_model {
     int32_t* y_bt = nullptr;
     float *total = nullptr, *loss = nullptr, *row_loss = nullptr, *probs_bt = nullptr;
     float *z = nullptr, *dz = nullptr, *cls_in = nullptr, *dcls = nullptr, *fused = nullptr, *dfused = nullptr;
-    float *pingA = nullptr, *pingB = nullptr;
-    int ping_ld = 0;
-    float* colsum_ws = nullptr; size_t colsum_ws_floats = 0;   // per-m-tile column sums of the fused bias gradients
+    // The S input streams are independent up to the fusion (and again below it in back-propagation): optionally each
+    // runs on its own HIP stream, forked from / joined into the model's stream with events (see streams_concurrent).
+    hipStream_t side[ADN_MAX_STREAMS] = {};
+    hipEvent_t fork_ev = nullptr, join_ev[ADN_MAX_STREAMS] = {};
+    bool side_ready = false;
     // concat fusion in bf16 mode: the aggregation LSTMs read ONE materialised [N][S*ldh] bf16 matrix, so their input
     // projection, dW_in and the gradient wrt the concat are one GEMM each per LSTM instead of S
     char* cat16 = nullptr; float* dcat = nullptr; float* wcat_tmp = nullptr;
@@ -413,15 +418,22 @@ size_t carve(adn_model* m, char* base, int B, int T, bool host_inputs) {
         st.hsum = take_shadowed(m, cv, N * ldh);
         st.dout_buf = cv.take<float>(N * ldh);
         st.dout = st.dout_buf;
+        {
+            int w = 64;
+            for (int l = 0; l < st.cfg.n_enc; ++l) w = std::max(w, ld_of(st.cfg.enc_units[l]));
+            st.ping_ld = w;
+            if (st.cfg.n_enc > 1) {
+                st.pingA = take_shadowed(m, cv, N * w);
+                st.pingB = take_shadowed(m, cv, N * w);
+                st.colsum_ws_floats = (size_t)cdiv((int)N, 64) * w;
+                st.colsum_ws = cv.take<float>(st.colsum_ws_floats);
+            }
+        }
         if (m->cfg.agg_dropout_p > 0.f) st.out_drop = take_shadowed(m, cv, N * ldh);
     }
     m->aggw.resize(m->agg.size());
     for (auto& w : m->aggw) carve_lstm(m, cv, w, B, T, ldh, ldg);
-    m->ping_ld = maxw;
-    m->pingA = take_shadowed(m, cv, N * maxw);
-    m->pingB = take_shadowed(m, cv, N * maxw);
-    m->colsum_ws_floats = (size_t)cdiv((int)N, 64) * maxw;
-    m->colsum_ws = cv.take<float>(m->colsum_ws_floats);
+    (void)maxw;
     if (m->cfg.fusion == ADN_FUSE_CONCAT && m->S > 1 && !m->agg.empty()) {
         m->cat16 = cv.take<char>(N * (size_t)m->S * ldh * 2);
         m->dcat = cv.take<float>(N * (size_t)m->S * ldh);
@@ -677,13 +689,60 @@ int lstm_init_state(adn_model* m, const LstmParams& lp, const LstmWork& w, int B
 }
 
 // ------------------------------------------------------------------------------------------
+// per-input-stream concurrency: fork the model's stream into S side streams and join them again
+// ------------------------------------------------------------------------------------------
+// Opt-in (ADN_STREAMS=1): measured on the benchmark workload the kernels do overlap (9.1 ms of kernel time in a 5.1 ms
+// step, 4 hardware queues) but the step is not shorter -- the work is throughput-bound, the overlapped kernels just
+// run slower -- and per-kernel event timings lose their meaning, so the default keeps everything on one stream.
+bool streams_concurrent(const adn_model* m) { return m->S > 1 && getenv("ADN_STREAMS") != nullptr; }
+
+int ensure_side_streams(adn_model* m) {
+    if (m->side_ready) return ADN_OK;
+    ADN_HIP_CHECK(hipEventCreateWithFlags(&m->fork_ev, hipEventDisableTiming));
+    for (int k = 0; k < m->S; ++k) {
+        ADN_HIP_CHECK(hipStreamCreateWithFlags(&m->side[k], hipStreamNonBlocking));
+        ADN_HIP_CHECK(hipEventCreateWithFlags(&m->join_ev[k], hipEventDisableTiming));
+    }
+    m->side_ready = true;
+    return ADN_OK;
+}
+
+// every side stream waits for what the model's stream has enqueued so far
+int fork_streams(adn_model* m) {
+    if (!streams_concurrent(m)) return ADN_OK;
+    ADN_TRY(ensure_side_streams(m));
+    ADN_HIP_CHECK(hipEventRecord(m->fork_ev, m->stream));
+    for (int k = 0; k < m->S; ++k) ADN_HIP_CHECK(hipStreamWaitEvent(m->side[k], m->fork_ev, 0));
+    return ADN_OK;
+}
+
+// the model's stream waits for everything the side streams have enqueued
+int join_streams(adn_model* m) {
+    if (!streams_concurrent(m)) return ADN_OK;
+    for (int k = 0; k < m->S; ++k) {
+        ADN_HIP_CHECK(hipEventRecord(m->join_ev[k], m->side[k]));
+        ADN_HIP_CHECK(hipStreamWaitEvent(m->stream, m->join_ev[k], 0));
+    }
+    return ADN_OK;
+}
+
+// work enqueued while one of these is alive goes to input stream k's side stream (every helper reads m->stream)
+struct OnSideStream {
+    adn_model* m; hipStream_t saved;
+    OnSideStream(adn_model* m_, int k) : m(m_), saved(m_->stream) { if (streams_concurrent(m)) m->stream = m->side[k]; }
+    ~OnSideStream() { m->stream = saved; }
+};
+
+// ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
 int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool want_dz) {
     const int N = B * T, H = m->H, ldh = m->ldh;
     hipStream_t s = m->stream;
     std::vector<LstmStep> steps;
+    ADN_TRY(fork_streams(m));
     for (auto& st : m->st) {
+        OnSideStream on(m, (int)(&st - m->st.data()));           // encoder, delta layer, input projection of this stream
         const float* a = st.x; int lda = st.ldx;
         for (int l = 0; l < st.cfg.n_enc; ++l) {                 // modelzoo/pretrained_encoder.py:4-9
             GemmArgs g;
@@ -693,10 +752,10 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
             ADN_TRY(mgemm(m, g, /*lean=*/l + 1 < st.cfg.n_enc));      // the delta layer reads the last one in fp32
             a = st.act[l]; lda = g.ldc;
         }
-        ADN_TRY(delta_forward(a, lda, st.feat, ld_of(st.feat_dim), B, T, st.enc_out, theta, st.cfg.use_delta, s));
+        ADN_TRY(delta_forward(a, lda, st.feat, ld_of(st.feat_dim), B, T, st.enc_out, theta, st.cfg.use_delta, m->stream));
         if (m->stochastic && st.cfg.dropout_p > 0.f)             // DropoutLayer ahead of the LSTM (adenet_v3.py:112,123,134)
             ADN_TRY(dropout_apply(st.feat, ld_of(st.feat_dim), st.feat, ld_of(st.feat_dim), B, T, st.feat_dim, st.feat_dim, 0,
-                                  st.cfg.dropout_p, m->drop_seed, m->drop_counter, (uint32_t)(&st - m->st.data()), s));
+                                  st.cfg.dropout_p, m->drop_seed, m->drop_counter, (uint32_t)(&st - m->st.data()), m->stream));
         ADN_TRY(refresh(m, st.feat, (size_t)N * ld_of(st.feat_dim)));
         for (size_t k = 0; k < st.lstm.size(); ++k) {
             const float* in[1] = {st.feat}; const int ld[1] = {ld_of(st.feat_dim)};
@@ -705,6 +764,7 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
             steps.push_back(make_step(m, st.lstm[k], st.lw[k], nullptr, false));
         }
     }
+    ADN_TRY(join_streams(m));
     ADN_TRY(run_lstm_group(m, steps, B, T, false));
     for (auto& st : m->st) {
         if (st.lstm.size() == 2) {                               // summed BLSTM sub-stream
@@ -957,7 +1017,8 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         }
     }
     auto bucket_ready = [&](size_t k) -> int {
-        if (k < m->bucket_events.size() && m->bucket_events[k]) ADN_HIP_CHECK(hipEventRecord(m->bucket_events[k], s));
+        // (on the stream the bucket's last gradient was enqueued on: an input stream's side stream below the fork)
+        if (k < m->bucket_events.size() && m->bucket_events[k]) ADN_HIP_CHECK(hipEventRecord(m->bucket_events[k], m->stream));
         return ADN_OK;
     };
     ADN_TRY(bucket_ready(0));                 // [fuse | agg | softmax] gradients and the cost share are final
@@ -972,8 +1033,10 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             }
         ADN_TRY(run_lstm_group(m, steps, B, T, true, &stream_sums_done));
     }
+    ADN_TRY(fork_streams(m));                 // below the stream LSTMs the S streams back-propagate independently
     for (size_t si = 0; si < m->st.size(); ++si) {
         StreamState& st = m->st[si];
+        OnSideStream on(m, (int)si);
         const int ldf = ld_of(st.feat_dim);
         const float* in[1] = {st.feat}; const int ld[1] = {ldf};
         for (size_t k = 0; k < st.lstm.size(); ++k)
@@ -983,12 +1046,12 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             ADN_TRY(lstm_input_grad(m, st.lstm[k], st.lw[k], 0, st.feat_dim, st.dfeat, ldf, N, k > 0));
         if (m->stochastic && st.cfg.dropout_p > 0.f)
             ADN_TRY(dropout_apply(st.dfeat, ldf, st.dfeat, ldf, B, T, st.feat_dim, st.feat_dim, 0, st.cfg.dropout_p,
-                                  m->drop_seed, m->drop_counter, (uint32_t)si, s));
+                                  m->drop_seed, m->drop_counter, (uint32_t)si, m->stream));
         const int ldE = ld_of(st.enc_out);
-        ADN_TRY(delta_backward(st.dfeat, ldf, st.dE, ldE, B, T, st.enc_out, theta, st.cfg.use_delta, s));
+        ADN_TRY(delta_backward(st.dfeat, ldf, st.dE, ldE, B, T, st.enc_out, theta, st.cfg.use_delta, m->stream));
         // encoder: dZ_l = dA_l * act_l'(A_l);  dW_l = A_{l-1}^T dZ_l;  dA_{l-1} = dZ_l W_l^T
         const int L = st.cfg.n_enc;
-        ADN_TRY(act_backward(st.dE, ldE, st.act[L - 1], ldE, N, st.enc_out, st.cfg.enc_act[L - 1], s));
+        ADN_TRY(act_backward(st.dE, ldE, st.act[L - 1], ldE, N, st.enc_out, st.cfg.enc_act[L - 1], m->stream));
         ADN_TRY(refresh(m, st.dE, (size_t)N * ldE));
         float* dZ = st.dE; int lddz = ldE;
         int bias_done = 0;
@@ -1000,26 +1063,27 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             gw.layout = GEMM_TN; gw.M = in_w; gw.N = out_w; gw.K = N; gw.A = a_prev; gw.lda = ld_prev;
             gw.B = dZ; gw.ldb = lddz; gw.C = m->G(st.encW[l]); gw.ldc = ld_of(out_w); gw.accumulate = 1;
             ADN_TRY(mgemm(m, gw));
-            if (!bias_done) ADN_TRY(col_sum(dZ, lddz, N, out_w, m->G(st.encb[l]), 1, s));
+            if (!bias_done) ADN_TRY(col_sum(dZ, lddz, N, out_w, m->G(st.encb[l]), 1, m->stream));
             bias_done = 0;
             if (l > 0) {
-                float* dst = (dZ == m->pingA) ? m->pingB : m->pingA;
+                float* dst = (dZ == st.pingA) ? st.pingB : st.pingA;
                 GemmArgs gx;
                 gx.layout = GEMM_NT; gx.M = N; gx.N = in_w; gx.K = out_w; gx.A = dZ; gx.lda = lddz;
-                gx.B = m->P(st.encW[l]); gx.ldb = ld_of(out_w); gx.C = dst; gx.ldc = m->ping_ld;
+                gx.B = m->P(st.encW[l]); gx.ldb = ld_of(out_w); gx.C = dst; gx.ldc = st.ping_ld;
                 gx.Y = st.act[l - 1]; gx.ldy = ld_of(in_w); gx.act_grad = st.cfg.enc_act[l - 1];
                 gx.colsum = m->G(st.encb[l - 1]); gx.colsum_done = &bias_done;     // db_{l-1} rides on this GEMM
-                gx.colsum_ws = m->colsum_ws; gx.colsum_ws_floats = m->colsum_ws_floats;
+                gx.colsum_ws = st.colsum_ws; gx.colsum_ws_floats = st.colsum_ws_floats;
                 ADN_TRY(mgemm(m, gx, /*lean=*/true));
                 if (!bias_done && shadows_on(m) && !m->keep_fp32 && in_w % 4 == 0 && m->shadow_of(dst)) {
                     // fp32 dZ was skipped but the fused column sum did not run: cannot happen for in_w % 4 == 0
                     set_error("internal: lean dZ without fused bias gradient"); return ADN_ERR_STATE;
                 }
-                dZ = dst; lddz = m->ping_ld;
+                dZ = dst; lddz = st.ping_ld;
             }
         }
         ADN_TRY(bucket_ready(1 + si));        // every gradient of this stream is final
     }
+    ADN_TRY(join_streams(m));
     m->grads_valid = true;
     return ADN_OK;
 }
@@ -1174,6 +1238,13 @@ void adn_destroy(adn_model* m) {
     if (m->params16) (void)hipFree(m->params16);
     if (m->transw_slab) (void)hipFree(m->transw_slab);
     if (m->transw_items) (void)hipFree(m->transw_items);
+    if (m->side_ready) {
+        for (int k = 0; k < m->S; ++k) {
+            if (m->side[k]) { (void)hipStreamSynchronize(m->side[k]); (void)hipStreamDestroy(m->side[k]); }
+            if (m->join_ev[k]) (void)hipEventDestroy(m->join_ev[k]);
+        }
+        if (m->fork_ev) (void)hipEventDestroy(m->fork_ev);
+    }
     auto free_lp = [](LstmParams& lp) {
         if (lp.whid16t) (void)hipFree(lp.whid16t);
         if (lp.wcat16) (void)hipFree(lp.wcat16);
