@@ -480,7 +480,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 
 // WM x 2 waves per workgroup, each owning a (BM/WM) x (BN/2) block of the tile
 template <int BM, int BN, int WM, bool A_KC, bool B_KC, typename T>
-__global__ __launch_bounds__(WM * 128, WM == 4 ? 4 : 1) void gemm_bf16_kernel(const GemmParams p) {
+__global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams p) {
     constexpr int NT = WM * 128;
     typedef typename StageSel<BM, A_KC, T, NT>::type SA;
     typedef typename StageSel<BN, B_KC, T, NT>::type SB;
@@ -820,8 +820,7 @@ void launch_gemm_bf16(const GemmParams& p, int layout, int tile_mode, dim3 grid,
         if (tile_mode == 3) {                 // LDS-DMA pipelined 256x128 kernel (NN / TN)
             if (layout == GEMM_NN) hipLaunchKernelGGL((gemm_bf16_dma_kernel<true>), grid, dim3(512), 0, s, p);
             else hipLaunchKernelGGL((gemm_bf16_dma_kernel<false>), grid, dim3(512), 0, s, p);
-        } else if (tile_mode == 2) launch_bf16_t<256, 128, 4, __bf16>(p, layout, grid, s);   // 8 waves, 64x64 each
-        else if (big) launch_bf16_t<128, 128, 2, __bf16>(p, layout, grid, s);
+        } else if (big) launch_bf16_t<128, 128, 2, __bf16>(p, layout, grid, s);
         else launch_bf16_t<64, 64, 2, __bf16>(p, layout, grid, s);
     } else {
         if (big) launch_bf16_t<128, 128, 2, float>(p, layout, grid, s);

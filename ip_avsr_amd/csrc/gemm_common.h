@@ -95,7 +95,7 @@ __device__ __forceinline__ void store_tile32(const GemmParams& p, const f32x16& 
 }
 
 // defined in gemm_bf16.hip
-void launch_gemm_bf16(const GemmParams& p, int layout, int tile_mode /*0: 64x64, 1: 128x128, 2: 256x128*/, dim3 grid,
+void launch_gemm_bf16(const GemmParams& p, int layout, int tile_mode /*0: 64x64, 1: 128x128, 3: LDS-DMA 256x128*/, dim3 grid,
                       hipStream_t s);
 
 }  // namespace adn

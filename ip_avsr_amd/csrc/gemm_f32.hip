@@ -199,19 +199,13 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
     const bool big = force_tile ? force_tile == 128
                                 : (g.K >= 768 && fill128 >= 0.85 * fill64 &&
                                    (t128 >= 384 || (can_split && t128 >= 24 && g.K >= 2048)));
-    // bf16 with shadow operands: 256x128 tiles (each wave 128x64: 25 % fewer LDS fragment reads and L2 bytes
-    // per MFMA, twice the MFMA work between barriers) when even that coarse grid fills the chip
     const int64_t t256 = (int64_t)cdiv(g.M, 256) * cdiv(g.N, 128);
-    // (measured: 2x SLOWER than 128x128 at one 4-wave workgroup per CU -- kept behind an opt-in switch)
-    const bool huge0 = g.precision == ADN_PRECISION_BF16 && p.A16 && p.B16 &&
-                      (force_tile ? force_tile == 256
-                                  : (getenv("ADN_GEMM_256") && (t256 >= 384 || (can_split && t256 >= 24 && g.K >= 2048))));
     // LDS-DMA pipelined 256x128 kernel: shadows, NN / TN, 16-byte aligned operands, K in whole 16-byte chunks
     const bool dma_ok = g.precision == ADN_PRECISION_BF16 && p.A16 && p.B16 && g.layout != GEMM_NT && g.K % 8 == 0 &&
                         g.lda % 8 == 0 && g.ldb % 8 == 0 && ((uintptr_t)p.A16 % 16) == 0 && ((uintptr_t)p.B16 % 16) == 0 &&
                         g.M >= 256 && g.N >= 128 && g.K >= 128 && (g.layout == GEMM_NN || g.lda >= 256) && g.ldb >= 128;
     const bool dma = dma_ok && force_tile == 512;
-    const bool huge = huge0 || dma;
+    const bool huge = dma;                    // (256 x 128 tile geometry)
     const int64_t tiles = huge ? t256 : (big ? t128 : t64);
     int split = 1;
     // split-K: enough workgroups for two per CU (measured on the weight-gradient shapes: 512 beats 768 / 1024 by 0-12 %,
@@ -256,7 +250,7 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
         fprintf(stderr, "ADN_GEMM %s M=%d N=%d K=%d tile=%d tiles=%lld split=%d shadows=%d lean=%d acc=%d\n",
                 g.layout == GEMM_NN ? "NN" : (g.layout == GEMM_NT ? "NT" : "TN"), g.M, g.N, g.K, huge ? 256 : tsz,
                 (long long)tiles, split, (int)(p.A16 && p.B16), (int)lean_c, g.accumulate);
-    if (g.precision == ADN_PRECISION_BF16) launch_gemm_bf16(p, g.layout, dma ? 3 : (huge ? 2 : (big ? 1 : 0)), grid, stream);
+    if (g.precision == ADN_PRECISION_BF16) launch_gemm_bf16(p, g.layout, dma ? 3 : (big ? 1 : 0), grid, stream);
     else if (big) launch<128, 128>(p, g.layout, grid, stream);
     else launch<64, 64>(p, g.layout, grid, stream);
     ADN_HIP_CHECK(hipGetLastError());
