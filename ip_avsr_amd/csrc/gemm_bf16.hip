@@ -414,9 +414,8 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
 template <int TM, int TN>
 __device__ __forceinline__ void tile_epilogue_atomic(const GemmParams& p, f32x4 (&acc)[TM][TN], float* strip, int row_base,
                                                      int col_base, int lane) {
-    constexpr int LW = TN * 16 + 4, WTN = TN * 16, RPI = 64 / WTN;
+    constexpr int LW = TN * 16 + 4, WTN = TN * 16;
     const int i16 = lane & 15, kq4 = (lane >> 4) * 4;
-    const int c = lane % WTN, col = col_base + c;
     auto slice = [&](auto a_c) {
         constexpr int a = decltype(a_c)::value;
 #pragma unroll
@@ -424,9 +423,9 @@ __device__ __forceinline__ void tile_epilogue_atomic(const GemmParams& p, f32x4 
 #pragma unroll
             for (int r = 0; r < 4; ++r) strip[(kq4 + r) * LW + b * 16 + i16] = acc[a][b][r];
 #pragma unroll
-        for (int j = 0; j < 16 / RPI; ++j) {
-            const int lr = j * RPI + lane / WTN;
-            const int row = row_base + a * 16 + lr;
+        for (int j = 0; j < 16 * WTN / 64; ++j) {     // 64 consecutive floats of the slice per wave-instruction
+            const int e = j * 64 + lane, lr = e / WTN, c = e % WTN;
+            const int row = row_base + a * 16 + lr, col = col_base + c;
             float v = strip[lr * LW + c];
             if (row >= p.M || col >= p.N) continue;
             if (p.Y) v *= act_grad_from_output(p.act_grad, p.Y[(size_t)row * p.ldy + col]);
@@ -540,31 +539,34 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams p)
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// LDS-DMA pipelined kernel for the large GEMMs (bf16 shadow operands only).
+// LDS-DMA pipelined kernel for the large GEMMs (bf16 shadow operands only; experimental, ADN_GEMM_TILE=512).
 //
-// 256 x 128 tile, 8 waves (4 x 2, 64 x 64 each), BK = 64, ONE workgroup per CU.  Operand tiles go HBM/L2 -> LDS with
-// global_load_lds_dwordx4 (no VGPR staging, no ds_write), into a ring of kDmaStages stage buffers, two stages in
-// flight ahead of the one being multiplied, one s_barrier per K-step and counted vmcnt waits (never 0 inside the
-// loop).  A DMA wave-instruction writes 1 KiB of LDS linearly (lane l -> base + 16 l), so the stage images are
-// unpadded and bank conflicts are removed by permuting, per row, WHICH 16-byte chunk of global memory each lane
-// fetches (cdna_hip_programming.md rule 21); the fragment reads apply the same permutation:
-//   k-contiguous operand  image [R][64 k] (128-B rows):   chunk c of row r lives at slot c ^ (r & 7)
-//   k-strided operand     image [64 k][R] (2R-B rows):    chunk c of k-row kr lives at slot c ^ (2 g(kr)),
+// 256 x 256 tile (half the L2 bytes per flop of the 128 x 128 kernel, whose rate is set by what one CU takes in from L2:
+// ~44 GB/s in both register-staged shapes), 8 waves (4 x 2, each 64 x 128), BK = 32, ONE workgroup per CU walking the
+// tile list.  Operand tiles go L2 -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write) into a ring of 4
+// stage buffers, three stages in flight ahead of the one being multiplied, one s_barrier per K-step and counted vmcnt
+// waits.  A DMA wave-instruction writes 1 KiB of LDS linearly (lane l -> base + 16 l), so the stage images are unpadded
+// and bank conflicts are removed by permuting, per row, WHICH 16-byte chunk of global memory each lane fetches
+// (cdna_hip_programming.md rule 21); the fragment reads apply the same permutation:
+//   k-contiguous operand  image [R][32 k] (64-B rows):   chunk c of row r lives at slot c ^ f((r >> 2) & 3), f = {0,2,3,1}
+//                         (the 16 lanes of a ds_read_b128 group then cover all 64 banks)
+//   k-strided operand     image [32 k][R] (2R-B rows):   chunk c of k-row kr lives at slot c ^ (2 g(kr)),
 //                         g(kr) = (kr & 3) | ((kr >> 3) & 1) << 2   (the 8 k-rows one ds_read_b64_tr_b16 lane group
 //                         touches get 8 different 32-byte slots of a 256-byte bank row)
 // Rows / columns outside the matrix are clamped in-bounds (they only feed dropped outputs); a partial last K-stage is
-// fetched from clamped addresses and its k >= K part is zeroed in LDS before use.
+// fetched from clamped addresses and its k >= K part is zeroed in LDS before use.  The ring drains at the end of a
+// tile (the epilogue's strips reuse the stage buffers), so a tile pays one load latency; K >= 1000 amortises it.
 // ---------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-constexpr int kDmaBM = 256, kDmaBN = 128, kDmaBK = 64, kDmaStages = 3;
+constexpr int kDmaBM = 256, kDmaBN = 256, kDmaBK = 32, kDmaStages = 4;
 
 // One LDS-DMA wave-instruction: lane l fetches 16 bytes from its own global address into LDS byte address
 // lds_dst + 16 l (lds_dst wave-uniform, in an SGPR).  Inline asm on purpose: hipcc orders every ds_read behind a
-// pending __builtin_amdgcn_global_load_lds with s_waitcnt vmcnt(0), which would drain the two stages this kernel
-// keeps in flight; the waits are counted by hand instead (s_waitcnt vmcnt(N) + s_barrier in the K-loop).  M0 (the
-// DMA destination base) is compiler-reserved, hence saved and restored (cdna_hip_programming.md, LDS-DMA recipe).
+// pending __builtin_amdgcn_global_load_lds with s_waitcnt vmcnt(0), which would drain the stages this kernel keeps in
+// flight; the waits are counted by hand instead (s_waitcnt vmcnt(N) + s_barrier in the K-loop).  M0 (the DMA
+// destination base) is compiler-reserved, hence saved and restored (cdna_hip_programming.md, LDS-DMA recipe).
 __device__ __forceinline__ void glds16(const __bf16* g, unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -572,15 +574,28 @@ __device__ __forceinline__ void glds16(const __bf16* g, unsigned lds_dst) {
 }
 
 __device__ __forceinline__ int swz_g(int kr) { return (kr & 3) | (((kr >> 3) & 1) << 2); }
+__device__ __forceinline__ int swz_f(int q) { return (0x1320 >> (4 * q)) & 3; }     // {0, 2, 3, 1}
 
-// Persistent: gridDim.x workgroups (one per CU) walk the tile list with stride gridDim.x; the (tile, K-stage) pairs
-// of a workgroup form ONE stream of stages through the ring, so the first stages of the next tile are already in
-// flight while the current tile's epilogue runs, and the epilogue's stores drain under the next tile's MFMAs.
+#ifdef ADN_GEMM_STAMPS
+__device__ unsigned long long g_gstamps[8];
+__device__ __forceinline__ unsigned long long gstamp_now() {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+#define GSTAMP(k) do { if (blockIdx.x == 7 && blockIdx.y == 0 && (tid == 0 || tid == 256)) { const unsigned long long n_ = gstamp_now(); \
+    atomicAdd(&g_gstamps[k], n_ - gl_); gl_ = n_; } } while (0)
+#define GSTAMP_INIT unsigned long long gl_ = gstamp_now();
+#else
+#define GSTAMP(k) do {} while (0)
+#define GSTAMP_INIT
+#endif
+
 template <bool A_KC>
 __global__ __launch_bounds__(512) void gemm_bf16_dma_kernel(const GemmParams p) {
     constexpr int BM = kDmaBM, BN = kDmaBN, BK = kDmaBK, NS = kDmaStages;
-    constexpr int TM = 4, TN = 4;
-    constexpr int kAElems = BM * BK, kBElems = BK * BN, kStageElems = kAElems + kBElems;   // 48 KiB per stage
+    constexpr int TM = 4, TN = 8;                                  // per wave: 64 x 128
+    constexpr int kAElems = BM * BK, kBElems = BK * BN, kStageElems = kAElems + kBElems;   // 32 KiB per stage
     __shared__ __attribute__((aligned(1024))) __bf16 smem[NS * kStageElems];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -590,60 +605,53 @@ __global__ __launch_bounds__(512) void gemm_bf16_dma_kernel(const GemmParams p) 
     const int kbeg = blockIdx.y * p.k_chunk;
     const int kend = min(p.K, kbeg + p.k_chunk);
     const int nk = (kend - kbeg + BK - 1) / BK;
-    const int ktail = (kend - kbeg) - (nk - 1) * BK;          // valid k of the last stage (1..64)
+    const int ktail = (kend - kbeg) - (nk - 1) * BK;          // valid k of the last stage (1..32)
     const bool has_tail = ktail < BK;
-    const int total = my_tiles * nk;                          // stages this workgroup streams
 
     const __bf16* A16 = reinterpret_cast<const __bf16*>(p.A16);
     const __bf16* B16 = reinterpret_cast<const __bf16*>(p.B16);
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_void_t*)smem;
 
-    // ---- DMA side: sources of the tile being fetched ---------------------------------------------------
-    // A: 32 wave-instructions per stage, 4 per wave; B: 16 per stage, 2 per wave
-    const __bf16* srcA[4]; const __bf16* srcB[2];
-    int a_aux[4], b_row[2];  // A_KC: lane's k offset inside the stage; k-strided: lane's k-row inside the stage
+    // ---- DMA side: 16 wave-instructions per operand and stage, 2 + 2 per wave ------------------------------
+    const __bf16* srcA[2]; const __bf16* srcB[2];
+    int a_aux[2], b_row[2];  // A_KC: lane's k offset inside the stage; k-strided: lane's k-row inside the stage
 #pragma unroll
-    for (int t = 0; t < 4; ++t) a_aux[t] = A_KC ? ((lane & 7) ^ (lane >> 3)) * 8 : 2 * (wave * 4 + t) + (lane >> 5);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) b_row[t] = 4 * (wave * 2 + t) + (lane >> 4);
-    auto setup_src = [&](int idx) {                           // idx-th tile of this workgroup
-        int tm, tn;
-        tile_coords(p, xcd_tile((int)blockIdx.x + idx * (int)gridDim.x, ntiles), tm, tn);
+    for (int t = 0; t < 2; ++t) {
+        a_aux[t] = A_KC ? ((lane & 3) ^ swz_f((lane >> 4) & 3)) * 8 : 2 * (wave * 2 + t) + (lane >> 5);
+        b_row[t] = 2 * (wave * 2 + t) + (lane >> 5);
+    }
+    auto setup_src = [&](int tm, int tn) {
         const int m0 = tm * BM, n0 = tn * BN;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < 2; ++t) {
             if (A_KC) {
-                const int row = 8 * (wave * 4 + t) + (lane >> 3);
+                const int row = 16 * (wave * 2 + t) + (lane >> 2);
                 srcA[t] = A16 + (size_t)min(m0 + row, p.M - 1) * p.lda + kbeg + a_aux[t];
             } else {
                 int col = m0 + (((lane & 31) ^ (swz_g(a_aux[t]) << 1)) * 8);
                 if (col + 8 > p.lda) col = 0;
                 srcA[t] = A16 + (size_t)(kbeg + a_aux[t]) * p.lda + col;
             }
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            int col = n0 + (((lane & 15) ^ (swz_g(b_row[t]) << 1)) * 8);
+            int col = n0 + (((lane & 31) ^ (swz_g(b_row[t]) << 1)) * 8);
             if (col + 8 > p.ldb) col = 0;
             srcB[t] = B16 + (size_t)(kbeg + b_row[t]) * p.ldb + col;
         }
     };
     const size_t a_step = A_KC ? (size_t)BK : (size_t)BK * p.lda;
     const size_t b_step = (size_t)BK * p.ldb;
-
-    auto issue = [&](int slot, int kt, auto tail_c) {         // K-stage kt of the fetch tile -> ring slot
+    auto issue = [&](int slot, int kt, auto tail_c) {         // K-stage kt of the current tile -> ring slot
         constexpr bool tail = decltype(tail_c)::value;
         const unsigned As = lds_base + (unsigned)(slot * kStageElems * 2);
         const unsigned Bs = As + kAElems * 2;
         const int k0 = kbeg + kt * BK;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < 2; ++t) {
             const __bf16* g = srcA[t];
             if (tail) {
                 if (A_KC) { if (k0 + a_aux[t] + 8 > kend) g -= (k0 + a_aux[t] + 8 - kend); }
                 else if (k0 + a_aux[t] >= kend) g -= (size_t)(k0 + a_aux[t] - (kend - 1)) * p.lda;
             }
-            glds16(g, __builtin_amdgcn_readfirstlane(As + (wave * 4 + t) * 1024));
+            glds16(g, __builtin_amdgcn_readfirstlane(As + (wave * 2 + t) * 1024));
             srcA[t] += a_step;
         }
 #pragma unroll
@@ -654,92 +662,89 @@ __global__ __launch_bounds__(512) void gemm_bf16_dma_kernel(const GemmParams p) 
             srcB[t] += b_step;
         }
     };
-    int f_stage = 0, f_kt = 0, f_tile = 0, f_slot = 0;        // fetch cursor
-    auto fetch_next = [&]() {
-        if (f_stage >= total) return;
-        if (f_kt == 0) setup_src(f_tile);
-        if (has_tail && f_kt == nk - 1) issue(f_slot, f_kt, std::true_type{});
-        else issue(f_slot, f_kt, std::false_type{});
-        ++f_stage;
-        f_slot = (f_slot + 1 == NS) ? 0 : f_slot + 1;
-        if (++f_kt == nk) { f_kt = 0; ++f_tile; }
+    auto issue_any = [&](int slot, int kt) {
+        if (has_tail && kt == nk - 1) issue(slot, kt, std::true_type{});
+        else issue(slot, kt, std::false_type{});
     };
 
     // ---- per-lane fragment addresses (bytes inside a stage) -------------------------------------------
     const int q = (lane & 15) >> 2, pp = lane & 3, hi = lane >> 4;
-    int a_off[TM], b_off[TN];
     const int g_lane = q | ((hi & 1) << 2);                   // swz_g of every k-row this lane reads
+    int a_off[TM], b_off[TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
-        if (A_KC) a_off[a] = (wm * 64 + a * 16 + (lane & 15)) * 128 + ((hi ^ (lane & 7)) << 4);
+        if (A_KC) a_off[a] = (wm * 64 + a * 16 + (lane & 15)) * 64 + ((hi ^ swz_f(q)) << 4);
         else a_off[a] = (hi * 8 + q) * (BM * 2) + ((((wm * 8 + a * 2 + (pp >> 1)) ^ (g_lane << 1))) << 4) + (pp & 1) * 8;
     }
 #pragma unroll
     for (int b = 0; b < TN; ++b)
-        b_off[b] = (hi * 8 + q) * (BN * 2) + ((((wn * 8 + b * 2 + (pp >> 1)) ^ (g_lane << 1))) << 4) + (pp & 1) * 8;
-
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        b_off[b] = (hi * 8 + q) * (BN * 2) + ((((wn * 16 + b * 2 + (pp >> 1)) ^ (g_lane << 1))) << 4) + (pp & 1) * 8;
 
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     typedef short s16x8 __attribute__((ext_vector_type(8)));
+    f32x4 acc[TM][TN];
 
-    fetch_next();
-    fetch_next();
-    int c_kt = 0, c_tile = 0, c_slot = 0;                     // compute cursor
-    bool landed = false;                                      // stage s already waited for (after an epilogue)
-    for (int s = 0; s < total; ++s) {
-        if (!landed) {
-            if (s + 1 < total) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        landed = false;
-        __builtin_amdgcn_s_barrier();
-        fetch_next();                                         // stage s + 2 -> the slot consumed at step s - 1
-        const char* As = reinterpret_cast<const char*>(smem + c_slot * kStageElems);
-        const char* Bs = As + kAElems * 2;
-        if (has_tail && c_kt == nk - 1) {                     // zero the k >= ktail part of both images
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (A_KC) {
-                for (int e = tid; e < BM * 8; e += 512) {     // (row, chunk)
-                    const int r = e >> 3, c = e & 7;
-                    if (c * 8 >= ktail) *reinterpret_cast<float4*>(const_cast<char*>(As) + r * 128 + ((c ^ (r & 7)) << 4)) = z;
-                }
-            } else {
-                for (int e = tid; e < BK * (BM / 8); e += 512) {
-                    const int kr = e / (BM / 8);
-                    if (kr >= ktail) *reinterpret_cast<float4*>(const_cast<char*>(As) + e * 16) = z;
-                }
-            }
-            for (int e = tid; e < BK * (BN / 8); e += 512) {
-                const int kr = e / (BN / 8);
-                if (kr >= ktail) *reinterpret_cast<float4*>(const_cast<char*>(Bs) + e * 16) = z;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
+    for (int ti = 0; ti < my_tiles; ++ti) {
+        int tile_m, tile_n;
+        tile_coords(p, xcd_tile((int)blockIdx.x + ti * (int)gridDim.x, ntiles), tile_m, tile_n);
+        const int m0 = tile_m * BM, n0 = tile_n * BN;
 #pragma unroll
-        for (int ks = 0; ks < BK / 32; ++ks) {
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        setup_src(tile_m, tile_n);
+        __syncthreads();                                      // the previous tile's epilogue is done with the LDS
+        for (int kt = 0; kt < NS - 1 && kt < nk; ++kt) issue_any(kt, kt);
+        GSTAMP_INIT
+        for (int kt = 0; kt < nk; ++kt) {
+            // stage kt landed (this wave's part); up to NS - 2 younger stages stay in flight
+            const int younger = min(NS - 2, nk - 1 - kt);
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            GSTAMP(0);
+            __builtin_amdgcn_s_barrier();                     // everyone's part landed; slot (kt - 1) % NS is free
+            GSTAMP(1);
+            // The two waves that share a SIMD (w and w + 4) issue their DMA at different ends of the step: issuing 4
+            // pieces costs a wave ~800 cycles of front-end time (TA back-pressure), during which the other one owns
+            // the MFMA pipe.  (Both positions are behind the barrier, so the slot being refilled is no longer read.)
+            const bool issue_early = wave < 4;
+            if (issue_early && kt + NS - 1 < nk) issue_any((kt + NS - 1) % NS, kt + NS - 1);
+            GSTAMP(2);
+            const char* As = reinterpret_cast<const char*>(smem + (kt % NS) * kStageElems);
+            const char* Bs = As + kAElems * 2;
+            if (has_tail && kt == nk - 1) {                   // zero the k >= ktail part of both images
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (A_KC) {
+                    for (int e = tid; e < BM * 4; e += 512) { // (row, chunk)
+                        const int r = e >> 2, c = e & 3;
+                        if (c * 8 >= ktail)
+                            *reinterpret_cast<float4*>(const_cast<char*>(As) + r * 64 + ((c ^ swz_f((r >> 2) & 3)) << 4)) = z;
+                    }
+                } else {
+                    for (int e = tid; e < BK * (BM / 8); e += 512)
+                        if (e / (BM / 8) >= ktail) *reinterpret_cast<float4*>(const_cast<char*>(As) + e * 16) = z;
+                }
+                for (int e = tid; e < BK * (BN / 8); e += 512)
+                    if (e / (BN / 8) >= ktail) *reinterpret_cast<float4*>(const_cast<char*>(Bs) + e * 16) = z;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
             bf16x8 fa[TM], fb[TN];
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
                 if (A_KC) {
-                    fa[a] = *reinterpret_cast<const bf16x8*>(As + (a_off[a] ^ (ks << 6)));
+                    fa[a] = *reinterpret_cast<const bf16x8*>(As + a_off[a]);
                 } else {
-                    const char* ad = As + a_off[a] + ks * 32 * (BM * 2);
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ad));
-                    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ad + 4 * (BM * 2)));
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(As + a_off[a]));
+                    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(As + a_off[a] + 4 * (BM * 2)));
                     fa[a] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
                 }
             }
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
-                const char* bd = Bs + b_off[b] + ks * 32 * (BN * 2);
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(bd));
-                const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(bd + 4 * (BN * 2)));
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Bs + b_off[b]));
+                const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Bs + b_off[b] + 4 * (BN * 2)));
                 fb[b] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
             }
 #pragma unroll
@@ -747,59 +752,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_dma_kernel(const GemmParams p) 
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+            if (!issue_early && kt + NS - 1 < nk) issue_any((kt + NS - 1) % NS, kt + NS - 1);
+            GSTAMP(3);
         }
-        if (++c_kt == nk) {                                   // tile finished: epilogue out of the slot just consumed
-            int tile_m, tile_n;
-            tile_coords(p, xcd_tile((int)blockIdx.x + c_tile * (int)gridDim.x, ntiles), tile_m, tile_n);
-            const int m0 = tile_m * BM, n0 = tile_n * BN;
-            // the next stage must have landed before the epilogue's own loads / stores / atomics join the (in-order)
-            // vmcnt queue behind it; the stage after it stays in flight
-            if (s + 1 < total) {
-                if (s + 2 < total) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                landed = true;
-            }
-            if (p.atomic) {                                   // split-K: fp32 atomics straight from the accumulators
-#pragma unroll
-                for (int a = 0; a < TM; ++a)
-#pragma unroll
-                    for (int b = 0; b < TN; ++b)
-                        store_tile16(p, acc[a][b], m0 + wm * 64 + a * 16, n0 + wn * 64 + b * 16, lane, blockIdx.y == 0);
-            } else {
-                __builtin_amdgcn_s_barrier();                 // every wave is done reading the slot
-                float* strip = reinterpret_cast<float*>(smem + c_slot * kStageElems) + wave * (16 * (TN * 16 + 4));
-                float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
-                tile_epilogue<TM, TN>(p, acc, strip, m0 + wm * 64, n0 + wn * 64, lane, csum);
-                if (p.colsum) {                               // lanes that differ only in their row share the columns
-#pragma unroll
-                    for (int o = 16; o < 64; o <<= 1) {
-                        csum.x += __shfl_xor(csum.x, o, 64); csum.y += __shfl_xor(csum.y, o, 64);
-                        csum.z += __shfl_xor(csum.z, o, 64); csum.w += __shfl_xor(csum.w, o, 64);
-                    }
-                    // the 4 waves stacked in m combine through LDS (behind the strips); plain float4 stores
-                    float4* cs = reinterpret_cast<float4*>(reinterpret_cast<float*>(smem + c_slot * kStageElems) +
-                                                           8 * (16 * (TN * 16 + 4)));
-                    if (wm > 0 && lane < 16) cs[((wm - 1) * 2 + wn) * 16 + lane] = csum;
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    const int col = n0 + wn * 64 + lane * 4;
-                    if (wm == 0 && lane < 16 && col + 3 < p.N) {
-#pragma unroll
-                        for (int w = 1; w < 4; ++w) {
-                            const float4 o = cs[((w - 1) * 2 + wn) * 16 + lane];
-                            csum.x += o.x; csum.y += o.y; csum.z += o.z; csum.w += o.w;
-                        }
-                        *reinterpret_cast<float4*>(p.colsum + (size_t)tile_m * p.colsum_ld + col) = csum;
-                    }
-                }
-            }
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-            c_kt = 0; ++c_tile;
+        // ---- epilogue: nothing is in flight; the strips reuse the stage buffers
+        if (p.atomic) {
+            __syncthreads();
+            float* strip = reinterpret_cast<float*>(smem) + wave * (16 * (TN * 16 + 4));
+            tile_epilogue_atomic<TM, TN>(p, acc, strip, m0 + wm * 64, n0 + wn * 128, lane);
+        } else {
+            gemm_epilogue<4, TM, TN>(p, acc, smem, m0, n0, tile_m, wave, lane);
         }
-        c_slot = (c_slot + 1 == NS) ? 0 : c_slot + 1;
     }
 }
 
@@ -900,3 +863,11 @@ int to_bf16(const float* src, void* dst, size_t n, hipStream_t s) {
 }
 
 }  // namespace adn
+
+#ifdef ADN_GEMM_STAMPS
+extern "C" int adn_debug_gemm_stamps(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(adn::g_gstamps), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(adn::g_gstamps), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif

@@ -199,13 +199,13 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
     const bool big = force_tile ? force_tile == 128
                                 : (g.K >= 768 && fill128 >= 0.85 * fill64 &&
                                    (t128 >= 384 || (can_split && t128 >= 24 && g.K >= 2048)));
-    const int64_t t256 = (int64_t)cdiv(g.M, 256) * cdiv(g.N, 128);
-    // LDS-DMA pipelined 256x128 kernel: shadows, NN / TN, 16-byte aligned operands, K in whole 16-byte chunks
+    const int64_t t256 = (int64_t)cdiv(g.M, 256) * cdiv(g.N, 256);
+    // LDS-DMA pipelined 256x256 kernel: shadows, NN / TN, 16-byte aligned operands, K in whole 16-byte chunks
     const bool dma_ok = g.precision == ADN_PRECISION_BF16 && p.A16 && p.B16 && g.layout != GEMM_NT && g.K % 8 == 0 &&
                         g.lda % 8 == 0 && g.ldb % 8 == 0 && ((uintptr_t)p.A16 % 16) == 0 && ((uintptr_t)p.B16 % 16) == 0 &&
-                        g.M >= 256 && g.N >= 128 && g.K >= 128 && (g.layout == GEMM_NN || g.lda >= 256) && g.ldb >= 128;
+                        g.M >= 256 && g.N >= 128 && g.K >= 128 && (g.layout == GEMM_NN || g.lda >= 256) && g.ldb >= 256;
     const bool dma = dma_ok && force_tile == 512;
-    const bool huge = dma;                    // (256 x 128 tile geometry)
+    const bool huge = dma;                    // (256 x 256 tile geometry)
     const int64_t tiles = huge ? t256 : (big ? t128 : t64);
     int split = 1;
     // split-K: enough workgroups for two per CU (measured on the weight-gradient shapes: 512 beats 768 / 1024 by 0-12 %,
@@ -229,7 +229,7 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
     if (lean_c) ADN_CHECK(g.ldc % 4 == 0 && g.N % 4 == 0 && ((uintptr_t)g.C16 % 8) == 0, ADN_ERR_INVALID,
                           "gemm: bf16-only output needs N and ldc to be multiples of 4");
     const int tsz = big ? 128 : 64;
-    p.tiles_m = cdiv(g.M, huge ? 256 : tsz); p.tiles_n = cdiv(g.N, huge ? 128 : tsz);
+    p.tiles_m = cdiv(g.M, huge ? 256 : tsz); p.tiles_n = cdiv(g.N, huge ? 256 : tsz);
     const int cs_ld = (int)round_up(g.N, 4);
     if (g.colsum && g.precision == ADN_PRECISION_BF16 && !p.atomic && g.ldc % 4 == 0 &&
         ((uintptr_t)g.C % 16) == 0 && (!g.Y || (g.ldy % 4 == 0 && ((uintptr_t)g.Y % 16) == 0)) && g.N % 4 == 0 &&

@@ -12,6 +12,9 @@
 #include "adn_common.h"
 
 using namespace adn;
+#ifdef ADN_GEMM_STAMPS
+extern "C" int adn_debug_gemm_stamps(unsigned long long*, int);   // libadenet_hip.so built with -DADN_GEMM_STAMPS
+#endif
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -101,6 +104,9 @@ int main(int argc, char** argv) {
         if (c.colsum) { g.colsum = cs; g.colsum_done = &done; g.colsum_ws = ws; g.colsum_ws_floats = wsf; }
         if (c.biasrelu) { g.bias = bias; g.act = ADN_ACT_RECTIFY; }
         for (int i = 0; i < 3; ++i) if (gemm(g, st) != 0) { fprintf(stderr, "gemm failed: %s\n", c.name); return 1; }
+#ifdef ADN_GEMM_STAMPS
+        adn_debug_gemm_stamps(nullptr, 1);
+#endif
         const int iters = 20;
         CK(hipEventRecord(e0, st));
         for (int i = 0; i < iters; ++i) gemm(g, st);
@@ -108,6 +114,13 @@ int main(int argc, char** argv) {
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         const double us = ms * 1e3 / iters;
+#ifdef ADN_GEMM_STAMPS
+        { unsigned long long st8[8];
+          adn_debug_gemm_stamps(st8, 0);
+          const double nst = (double)iters * 2 * ((c.K + 31) / 32) * 3;      // 2 stamping waves, ~3 tiles per workgroup (rough)
+          printf("   stamps (us per stage, rough): wait %.3f  barrier %.3f  dma issue %.3f  reads+mfma %.3f\n", st8[0] / 100.0 / nst,
+                 st8[1] / 100.0 / nst, st8[2] / 100.0 / nst, st8[3] / 100.0 / nst); }
+#endif
         const double outb = (double)c.M * c.N * ((c.lean ? 0 : 4) + (g.C16 ? 2 : 0) + (c.ygrad ? 2 : 0) + (c.acc ? 4 : 0));
         printf("%-26s %3s %6d %6d %6d | %9.1f %9.1f %9.1f%s\n", c.name, c.layout == 0 ? "NN" : (c.layout == 1 ? "NT" : "TN"),
                c.M, c.N, c.K, us, 2.0 * c.M * c.N * c.K / us / 1e6, outb / us / 1e3, c.colsum && !done ? "  (colsum NOT fused)" : "");
