@@ -206,7 +206,7 @@ int lstm_backward_persistent(const LstmStep* l, int n, const uint8_t* mask_tb, i
                              bool* sums_done = nullptr);
 // weight-stationary variants (lstm_cluster.hip): groups of 4 workgroups share a 32-utterance slice, W_hid stays in LDS
 bool lstm_cluster_supported(const LstmStep* l, int n, int B, int T, int H);
-size_t lstm_cluster_xchg_bytes(int B);
+size_t lstm_cluster_xchg_bytes(int B, int H);
 int lstm_forward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
 int lstm_backward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
 int lstm_cluster_error_word(int** out);   // device word raised by a poll that gave up (checked at synchronisation)

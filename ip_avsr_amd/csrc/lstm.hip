@@ -21,6 +21,7 @@
 // Operands go straight from L2 to VGPRs: with K split over the waves nothing is shared between them.
 #include "adn_common.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace adn {
 
@@ -318,7 +319,10 @@ int lstm_forward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T,
     bool have16 = precision == ADN_PRECISION_BF16;
     for (int k = 0; k < n; ++k) { L.l[k] = l[k]; have16 = have16 && l[k].W_hid16T && l[k].h16; }
     const int ldh = ld_of(H), ldg = ld_of(4 * H);
-    if (have16 && lstm_persistent_supported(H) && l[0].W_frag_fwd) return lstm_forward_persistent(l, n, mask_tb, B, T, H, s);
+    // resident-weight kernels: the cluster kernels (H <= 512) or, where those cannot run, the one-workgroup persistent
+    // kernel (H <= 256 only: at H > 256 streaming 2 MB of W_hid per step into one CU is slower than the per-step launches)
+    if (have16 && lstm_persistent_supported(H) && l[0].W_frag_fwd && (H <= 256 || lstm_cluster_supported(l, n, B, T, H) || getenv("ADN_LSTM_WIDE_PERSISTENT")))
+        return lstm_forward_persistent(l, n, mask_tb, B, T, H, s);
     if (have16) {
         const double bytes = n * (4.0 * (12.0 * B * H + 4.0 * H * H) + B), flops = n * 8.0 * B * H * H;
         const dim3 grid16(cdiv(B, 32), cdiv(4 * H, 64), n);
@@ -448,7 +452,9 @@ int lstm_backward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T
     bool have16 = precision == ADN_PRECISION_BF16;
     for (int k = 0; k < n; ++k) { L.l[k] = l[k]; have16 = have16 && l[k].W_hid16 && l[k].dG16; }
     const int ldh = ld_of(H), ldg = ld_of(4 * H);
-    if (have16 && lstm_persistent_supported(H) && l[0].W_frag_bwd)
+    if (have16 && lstm_persistent_supported(H) && l[0].W_frag_bwd &&
+        (H <= 256 || (lstm_cluster_supported(l, n, B, T, H) && !getenv("ADN_LSTM_NO_CLUSTER_BWD")) ||
+         getenv("ADN_LSTM_WIDE_PERSISTENT")))
         return lstm_backward_persistent(l, n, mask_tb, B, T, H, s, sums_done);
     for (int k = 0; k < n; ++k) {
         ADN_HIP_CHECK(hipMemsetAsync(l[k].dh_carry, 0, (size_t)B * ldh * sizeof(float), s));

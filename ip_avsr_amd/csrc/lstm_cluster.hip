@@ -40,12 +40,29 @@ __device__ __forceinline__ float c_tanh(float x) {
 __device__ __forceinline__ float c_clip5(float x) { return fminf(fmaxf(x, -5.f), 5.f); }
 
 constexpr int kCRows = 32;       // utterances per group
-constexpr int kCWG = 4;          // workgroups per group
 constexpr int kCUnits = 64;      // hidden units per workgroup
-constexpr int kCHP = kCWG * kCUnits;            // padded hidden size (256)
-constexpr int kCKS = kCHP / 32;                 // k-steps of the forward product
-constexpr int kCWElems = kCUnits * 4 * kCHP;    // bf16 elements of one workgroup's W slice (128 KB)
-constexpr int kCHS = kCHP + 8;                  // LDS row stride of the h / dG images (bf16)
+// Geometry of a group of CWG workgroups (4: H <= 256, everything LDS-resident;  8: H <= 512, where a workgroup's W slice
+// is 256 KB and its k-steps are split between LDS and the waves' registers).
+template <int CWG> struct ClusterGeom {
+    static constexpr int HP = CWG * kCUnits;                // padded hidden size (256 | 512)
+    static constexpr int KS = HP / 32;                      // k-steps of the forward product (8 | 16)
+    static constexpr int KSL = CWG == 4 ? 8 : 7;            // ... of which LDS-resident; the rest sit in registers
+    static constexpr int KSR = KS - KSL;
+    static constexpr int WElems = kCUnits * 4 * HP;         // bf16 elements of one workgroup's W slice (128 | 256 KB)
+    static constexpr int WLdsFwd = 4 * 4 * KSL * 512;       // ... of which in LDS, forward  [4 unit tiles][4 gates][KSL][64][8]
+    static constexpr int HS = HP + 8;                       // LDS row stride of the h image (bf16)
+    static constexpr int NB = 2 * (CWG - 1);                // backward: foreign granules per thread and step (6 | 14)
+    // forward: with 8 workgroups a thread polls ALL 8 slots of its (row pair, unit) column, its own workgroup's included
+    // (already there): the 16 addresses are then one base plus constants, which keeps 28 registers free
+    static constexpr bool PollOwn = CWG > 4;
+    static constexpr int NF = PollOwn ? 2 * CWG : 2 * (CWG - 1);
+    static constexpr int KSLB = CWG == 4 ? 8 : 4;           // backward: LDS-resident k-steps of the 8 a workgroup owns
+    static constexpr int KSRB = 8 - KSLB;
+    static constexpr int WLdsBwd = (HP / 16) * KSLB * 512;  // [HP/16 unit tiles][KSLB][64][8]
+    static constexpr int NRT = CWG / 4;                     // backward product: row tiles per wave (4: wave = (row tile, destination);
+                                                            //   8: wave = destination, both row tiles -- no W fragment is held twice)
+};
+constexpr int kCDS = 4 * kCUnits + 8;                       // LDS row stride of the dG image: a workgroup's own 256 gate columns
 // A poll gives up after kPollTimeoutTicks of the 100 MHz wall clock (s_memrealtime), checked every 1024 spins.  Generous
 // on purpose: partners can be late for reasons that are not a deadlock -- e.g. a collective kernel of the data-parallel
 // path holding CUs until a slower rank arrives, so that not every workgroup of a launch is resident yet.
@@ -119,36 +136,46 @@ __device__ __forceinline__ bool granule_wait(const unsigned long long* const (&p
 // =========================================================================================
 // forward
 // =========================================================================================
-// grid (kCWG * groups, n LSTMs); 512 threads: wave w -> row tile w >> 2 (16 rows), local unit tile w & 3 (16 units);
+// grid (CWG * groups, n LSTMs); 512 threads: wave w -> row tile w >> 2 (16 rows), local unit tile w & 3 (16 units);
 // lane -> unit (lane & 15), rows 4 (lane >> 4) .. +3 of the row tile.
+template <int CWG>
 __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const LstmClusterP L, const uint8_t* __restrict__ mask_tb,
                                                                int B, int T, int H, int ldh, int ldg, unsigned tag0, int* err) {
+    using G = ClusterGeom<CWG>;
+    constexpr int HP = G::HP, KS = G::KS, KSL = G::KSL, KSR = G::KSR, HS = G::HS, NF = G::NF;
     extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
-    __bf16* wl = lds;                                 // [4 unit tiles][4 gates][8 k-steps][64 lanes][8]
-    __bf16 (*hs)[kCHS] = reinterpret_cast<__bf16 (*)[kCHS]>(lds + kCWElems);     // [32][kCHS]
+    __bf16* wl = lds;                                 // [4 unit tiles][4 gates][KSL k-steps][64 lanes][8]
+    __bf16 (*hs)[HS] = reinterpret_cast<__bf16 (*)[HS]>(lds + G::WLdsFwd);     // [32][HS]
     const LstmStep& P = L.l[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, kq = lane >> 4;
-    const int group = blockIdx.x / kCWG, j = blockIdx.x % kCWG;
+    const int group = blockIdx.x / CWG, j = blockIdx.x % CWG;
     const int r0 = group * kCRows;
     const int rt = wave >> 2, ut = wave & 3;
     const int u = kCUnits * j + 16 * ut + i;          // this lane's hidden unit
     const int uc = min(u, H - 1);
     __bf16* h16g = reinterpret_cast<__bf16*>(P.h16);
-    // exchange buffer of the group: [2 parities][16 row pairs][256 units] granules
-    unsigned long long* xb = reinterpret_cast<unsigned long long*>(P.xchg) + (size_t)group * 2 * 16 * kCHP;
+    // exchange buffer of the group: [2 parities][16 row pairs][HP units] granules
+    unsigned long long* xb = reinterpret_cast<unsigned long long*>(P.xchg) + (size_t)group * 2 * 16 * HP;
 
-    // ---- resident W slice: unit tiles 4j .. 4j+3 of the fragment image are contiguous
-    {
-        const bf16x8* src = reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(P.W_frag_fwd) + (size_t)j * kCWElems);
-        for (int e = tid; e < kCWElems / 8; e += 512) reinterpret_cast<bf16x8*>(wl)[e] = src[e];
+    // ---- resident W slice: unit tiles 4j .. 4j+3 of the fragment image ([tile][gate][KS][64][8]); k-steps < KSL go to
+    //      LDS, the others into this wave's registers (its own unit tile only)
+    const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(P.W_frag_fwd) + (size_t)j * G::WElems);
+    for (int e = tid; e < G::WLdsFwd / 8; e += 512) {
+        const int l64 = e & 63, s_ = (e >> 6) % KSL, tg = (e >> 6) / KSL;         // tg = 4 * unit tile + gate
+        reinterpret_cast<bf16x8*>(wl)[e] = wsrc[((size_t)tg * KS + s_) * 64 + l64];
     }
+    bf16x8 wreg[4][KSR > 0 ? KSR : 1];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int s_ = 0; s_ < KSR; ++s_) wreg[g][s_] = wsrc[((size_t)(4 * ut + g) * KS + KSL + s_) * 64 + lane];
     // ---- initial state
     const int blk0 = P.backwards ? T : 0;
-    for (int e = tid; e < kCRows * (kCHS / 8); e += 512) {
-        const int rr = e / (kCHS / 8), cc = (e % (kCHS / 8)) * 8;
+    for (int e = tid; e < kCRows * (HS / 8); e += 512) {
+        const int rr = e / (HS / 8), cc = (e % (HS / 8)) * 8;
         bf16x8 v = bf16x8{};
-        if (cc < ldh && cc < kCHP) v = *reinterpret_cast<const bf16x8*>(h16g + ((size_t)blk0 * B + min(r0 + rr, B - 1)) * ldh + cc);
+        if (cc < ldh && cc < HP) v = *reinterpret_cast<const bf16x8*>(h16g + ((size_t)blk0 * B + min(r0 + rr, B - 1)) * ldh + cc);
         *reinterpret_cast<bf16x8*>(&hs[rr][cc]) = v;
     }
     float c_st[4], h_st[4];
@@ -160,16 +187,10 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const LstmCluster
     }
     __syncthreads();
 
-    // foreign granules this thread fetches every step: 3 partners x 16 row pairs x 64 units = 3072 = 6 per thread
-    int f_off[6], f_rp[6], f_u[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const int id = tid + 512 * k;
-        const int fj = (j + 1 + id / 1024) & 3, rp = (id % 1024) / 64, ul = id % 64;
-        f_rp[k] = rp; f_u[k] = 64 * fj + ul;
-        f_off[k] = rp * kCHP + f_u[k];
-    }
-    const bf16x8* wfrag = reinterpret_cast<const bf16x8*>(wl) + (size_t)ut * 4 * kCKS * 64 + lane;
+    // foreign granules this thread fetches every step: (CWG - 1) partners x 16 row pairs x 64 units = NF per thread;
+    // granule k of the thread: id = tid + 512 k -> partner (j + 1 + id / 1024) % CWG, row pair (id % 1024) / 64, unit id % 64
+    const int f_rp0 = tid >> 6, f_ul = tid & 63;      // id % 1024 = tid + 512 (k & 1): row pair f_rp0 + 8 (k & 1)
+    const bf16x8* wfrag = reinterpret_cast<const bf16x8*>(wl) + (size_t)ut * 4 * KSL * 64 + lane;
     uint8_t m[4];           // raw mask bytes: compared where they are used, so that the request does not wait for its own data
     float4 xp[4];
     auto request_inputs = [&](int step_, uint8_t (&mm)[4], float4 (&xx)[4]) {
@@ -187,20 +208,21 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const LstmCluster
         const int t = P.backwards ? (T - 1 - step) : step;
         const int out_blk = t + (P.backwards ? 0 : 1);
         const unsigned tag = tag0 + (unsigned)step;
-        unsigned long long* xpar = xb + (size_t)(step & 1) * 16 * kCHP;
+        unsigned long long* xpar = xb + (size_t)(step & 1) * 16 * HP;
         // masks and input projections of the step (the round trip hides under the recurrent product; requesting them a
         // step ahead, before or after the polls, measured no faster)
         request_inputs(step, m, xp);
-        // ---- recurrent product out of LDS: 4 gate tiles x 8 k-steps
+        // ---- recurrent product: 4 gate tiles x KS k-steps, W fragments out of LDS (s < KSL) or registers
         f32x4 acc[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < kCKS; ++s) {
+        for (int s = 0; s < KS; ++s) {
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(&hs[16 * rt + i][s * 32 + kq * 8]);
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wfrag[(g * kCKS + s) * 64], acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, s < KSL ? wfrag[(g * KSL + s) * 64] : wreg[g][s < KSL ? 0 : s - KSL],
+                                                                 acc[g], 0, 0, 0);
         }
         lds_barrier();                                // every wave has read h_{t-1}: the image may be overwritten
         STAMP(0);
@@ -231,7 +253,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const LstmCluster
 #pragma unroll
         for (int rp = 0; rp < 2; ++rp) {
             bf16x2 pr; pr[0] = (__bf16)h_out[2 * rp]; pr[1] = (__bf16)h_out[2 * rp + 1];
-            granule_store(xpar + (size_t)(8 * rt + 2 * kq + rp) * kCHP + u, __builtin_bit_cast(unsigned, pr), tag);
+            granule_store(xpar + (size_t)(8 * rt + 2 * kq + rp) * HP + u, __builtin_bit_cast(unsigned, pr), tag);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) hs[16 * rt + 4 * kq + r][u] = (__bf16)h_out[r];
@@ -254,17 +276,21 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const LstmCluster
         STAMP(2);
         // ---- gather the partners' h_t
         if (step + 1 < T) {
-            const unsigned long long* ptr[6];
-            unsigned pay[6] = {0, 0, 0, 0, 0, 0};
+            const unsigned long long* ptr[NF];
+            unsigned pay[NF];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) ptr[k] = xpar + f_off[k];
-            granule_wait<6>(ptr, tag, pay, err);
+            for (int k = 0; k < NF; ++k) {
+                pay[k] = 0u;
+                ptr[k] = xpar + (size_t)(f_rp0 + 8 * (k & 1)) * HP + kCUnits * (G::PollOwn ? (k >> 1) : (j + 1 + (k >> 1)) % CWG) + f_ul;
+            }
+            granule_wait<NF>(ptr, tag, pay, err);
             STAMP(3);
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
+            for (int k = 0; k < NF; ++k) {
                 const bf16x2 pr = __builtin_bit_cast(bf16x2, pay[k]);
-                hs[2 * f_rp[k]][f_u[k]] = pr[0];
-                hs[2 * f_rp[k] + 1][f_u[k]] = pr[1];
+                const int fu = kCUnits * (G::PollOwn ? (k >> 1) : (j + 1 + (k >> 1)) % CWG) + f_ul, frp = f_rp0 + 8 * (k & 1);
+                hs[2 * frp][fu] = pr[0];
+                hs[2 * frp + 1][fu] = pr[1];
             }
         }
         lds_barrier();
@@ -289,33 +315,45 @@ __device__ __forceinline__ unsigned long long pack_partials(float a, float b, un
     return ((unsigned long long)ub << 32) | ua;
 }
 
+template <int CWG>
 __global__ __launch_bounds__(512) void lstm_bwd_cluster_kernel(const LstmClusterP L, const uint8_t* __restrict__ mask_tb,
                                                                int B, int T, int H, int ldh, int ldg, int* err) {
+    using G = ClusterGeom<CWG>;
+    constexpr int HP = G::HP, KSLB = G::KSLB, KSRB = G::KSRB, NRT = G::NRT, NF = G::NB;
     extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
-    __bf16* wl = lds;                                 // [16 unit tiles][8 k-steps][64 lanes][8]: W_hid[unit][own gate columns]
-    __bf16 (*dgs)[kCHS] = reinterpret_cast<__bf16 (*)[kCHS]>(lds + kCWElems);            // [32][kCHS] own dG_{t+1}
-    float (*part)[kCUnits + 1] = reinterpret_cast<float (*)[kCUnits + 1]>(lds + kCWElems + kCRows * kCHS);   // [32][65]
+    __bf16* wl = lds;                                 // [HP/16 unit tiles][KSLB k-steps][64 lanes][8]: W_hid[unit][own gate columns]
+    __bf16 (*dgs)[kCDS] = reinterpret_cast<__bf16 (*)[kCDS]>(lds + G::WLdsBwd);            // [32][kCDS] own dG_{t+1}
+    float (*part)[kCUnits + 1] = reinterpret_cast<float (*)[kCUnits + 1]>(lds + G::WLdsBwd + kCRows * kCDS);   // [32][65]
     const LstmStep& P = L.l[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, kq = lane >> 4;
-    const int group = blockIdx.x / kCWG, j = blockIdx.x % kCWG;
+    const int group = blockIdx.x / CWG, j = blockIdx.x % CWG;
     const int r0 = group * kCRows;
-    const int rt = wave >> 2, ut = wave & 3;          // gate math: row tile, local unit tile; MFMA: row tile, destination
+    const int rt = wave >> 2, ut = wave & 3;          // gate math: row tile, local unit tile
+    const int dst = CWG == 4 ? ut : wave;             // MFMA role: destination workgroup (and row tile rt when CWG == 4)
     const int ul = 16 * ut + i;                       // local unit
     const int u = kCUnits * j + ul;
     __bf16* dg16g = reinterpret_cast<__bf16*>(P.dG16);
-    // inbox / outbox: [2 parities][4 destinations][4 sources][16 row pairs][64 units] granules, after the forward region
-    unsigned long long* xb = reinterpret_cast<unsigned long long*>(P.xchg) + (size_t)((B + kCRows - 1) / kCRows) * 2 * 16 * kCHP +
-                             (size_t)group * 2 * 16 * kBxPair;
+    // inbox / outbox: [2 parities][CWG destinations][CWG slots][16 row pairs][64 units] granules, after the forward region;
+    // source src uses slot (src - dst - 1) mod CWG of destination dst, so that a receiver's addresses are base + constants
+    unsigned long long* xb = reinterpret_cast<unsigned long long*>(P.xchg) + (size_t)((B + kCRows - 1) / kCRows) * 2 * 16 * HP +
+                             (size_t)group * 2 * CWG * CWG * kBxPair;
 
-    {   // resident W slice: for every unit tile the 8 k-steps [8j, 8j+8) of the fragment image (8 KB runs)
-        const bf16x8* src = reinterpret_cast<const bf16x8*>(P.W_frag_bwd);
-        for (int e = tid; e < kCWElems / 8; e += 512) {
-            const int tile = e / (8 * 64), rest = e % (8 * 64);
-            reinterpret_cast<bf16x8*>(wl)[e] = src[(size_t)tile * (4 * kCKS) * 64 + (size_t)(8 * j) * 64 + rest];
-        }
+    // resident W slice: of every unit tile of the fragment image ([tile][4 HP / 32 k-steps][64][8]) the 8 k-steps
+    // [8j, 8j+8) = this workgroup's gate columns; the first KSLB of them in LDS, the others in the registers of the
+    // wave that multiplies them (destination dst: unit tiles 4 dst + ct)
+    const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(P.W_frag_bwd) + (size_t)(8 * j) * 64;
+    for (int e = tid; e < G::WLdsBwd / 8; e += 512) {
+        const int l64 = e & 63, s_ = (e >> 6) % KSLB, tile = (e >> 6) / KSLB;
+        reinterpret_cast<bf16x8*>(wl)[e] = wsrc[((size_t)tile * (4 * G::KS) + s_) * 64 + l64];
     }
-    for (int e = tid; e < kCRows * kCHS / 8; e += 512) reinterpret_cast<bf16x8*>(&dgs[0][0])[e] = bf16x8{};
+    bf16x8 wreg[4][KSRB > 0 ? KSRB : 1];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int s_ = 0; s_ < KSRB; ++s_)
+            wreg[ct][s_] = wsrc[((size_t)(4 * dst + ct) * (4 * G::KS) + KSLB + s_) * 64 + lane];
+    for (int e = tid; e < kCRows * kCDS / 8; e += 512) reinterpret_cast<bf16x8*>(&dgs[0][0])[e] = bf16x8{};
     float dh_c[4], dc_s[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { dh_c[r] = 0.f; dc_s[r] = 0.f; }
@@ -352,53 +390,58 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_kernel(const LstmCluster
         float rec[4] = {0.f, 0.f, 0.f, 0.f};          // recurrent part of dh for this lane's 4 (row, unit) pairs
         if (step > 0) {
             const unsigned tag8 = 1u + (unsigned)(step % 255);
-            unsigned long long* xpar = xb + (size_t)(step & 1) * 16 * kBxPair;
-            // ---- partial dh for destination ut (= MFMA role of this wave): 4 unit tiles x 8 k-steps
-            f32x4 acc[4];
+            unsigned long long* xpar = xb + (size_t)(step & 1) * CWG * CWG * kBxPair;
+            // ---- partial dh for destination dst (= MFMA role of this wave): 4 unit tiles x 8 k-steps per row tile
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < NRT; ++q) {
+                const int mr = CWG == 4 ? rt : q;
+                f32x4 acc[4];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&dgs[16 * rt + i][s * 32 + kq * 8]);
+                for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
-                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wfrag[((4 * ut + ct) * 8 + s) * 64], acc[ct], 0, 0, 0);
+                for (int s = 0; s < 8; ++s) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(&dgs[16 * mr + i][s * 32 + kq * 8]);
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+                        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            a, s < KSLB ? wfrag[((4 * dst + ct) * KSLB + s) * 64] : wreg[ct][s < KSLB ? 0 : s - KSLB], acc[ct], 0, 0, 0);
+                }
+                // accumulator map: unit = 64 dst + 16 ct + (lane & 15), row = 16 mr + 4 kq + r
+                if (dst == j) {
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) part[16 * mr + 4 * kq + r][16 * ct + i] = acc[ct][r];
+                } else {
+                    unsigned long long* box = xpar + (size_t)(dst * CWG + (j - dst - 1 + CWG) % CWG) * kBxPair;
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                        for (int rp = 0; rp < 2; ++rp)
+                            __hip_atomic_store(box + (size_t)(8 * mr + 2 * kq + rp) * kCUnits + 16 * ct + i,
+                                               pack_partials(acc[ct][2 * rp], acc[ct][2 * rp + 1], tag8), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
-            // accumulator map: unit = 64 ut + 16 ct + (lane & 15), row = 16 rt + 4 kq + r
-            if (ut == j) {
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) part[16 * rt + 4 * kq + r][16 * ct + i] = acc[ct][r];
-            } else {
-                unsigned long long* box = xpar + (size_t)(ut * 4 + j) * kBxPair;
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                    for (int rp = 0; rp < 2; ++rp)
-                        __hip_atomic_store(box + (size_t)(8 * rt + 2 * kq + rp) * kCUnits + 16 * ct + i,
-                                           pack_partials(acc[ct][2 * rp], acc[ct][2 * rp + 1], tag8), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-            }
-            lds_barrier();                            // own quarter is in `part`; dG_{t+1} has been consumed
+            lds_barrier();                            // own part is in `part`; dG_{t+1} has been consumed
             STAMP(5);
-            // ---- collect the three foreign quarters of this lane's pairs
-            const unsigned long long* ptr[6];
-            unsigned long long g[6];
+            // ---- collect the CWG - 1 foreign parts of this lane's pairs
+            const unsigned long long* ptr[NF];
+            unsigned long long g[NF];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const int src = (j + 1 + k / 2) & 3, rp = k & 1;
-                ptr[k] = xpar + (size_t)(j * 4 + src) * kBxPair + (size_t)(8 * rt + 2 * kq + rp) * kCUnits + ul;
+            for (int k = 0; k < NF; ++k) {
+                const int slot = k / 2, rp = k & 1;        // source (j + 1 + slot) mod CWG
+                ptr[k] = xpar + (size_t)(j * CWG + slot) * kBxPair + (size_t)(8 * rt + 2 * kq + rp) * kCUnits + ul;
             }
-            unsigned pending = 63u;
+            unsigned pending = (1u << NF) - 1u;
             unsigned long long t_start = 0;
             for (int spin = 0; pending; ++spin) {
-                unsigned long long v[6];
+                unsigned long long v[NF];
 #pragma unroll
-                for (int k = 0; k < 6; ++k)           // all outstanding requests first: ONE round trip per spin
+                for (int k = 0; k < NF; ++k)          // all outstanding requests first: ONE round trip per spin
                     if (pending & (1u << k)) v[k] = granule_load(ptr[k]);
 #pragma unroll
-                for (int k = 0; k < 6; ++k)
+                for (int k = 0; k < NF; ++k)
                     if ((pending & (1u << k)) && (((unsigned)v[k] & 15u) | (((unsigned)(v[k] >> 32) & 15u) << 4)) == tag8) {
                         g[k] = v[k]; pending &= ~(1u << k);
                     }
@@ -413,7 +456,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_kernel(const LstmCluster
 #pragma unroll
             for (int r = 0; r < 4; ++r) rec[r] = part[16 * rt + 4 * kq + r][ul];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
+            for (int k = 0; k < NF; ++k) {
                 const int rp = k & 1;
                 rec[2 * rp] += __builtin_bit_cast(float, (unsigned)g[k] & ~15u);
                 rec[2 * rp + 1] += __builtin_bit_cast(float, (unsigned)(g[k] >> 32) & ~15u);
@@ -506,9 +549,9 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_kernel(const LstmCluster
     }
     // leave this workgroup's inbox empty for the next launch (after EVERY lane has taken its last granules)
     __syncthreads();
-    for (int e = tid; e < 2 * 4 * kBxPair; e += 512) {
-        const int par = e / (4 * kBxPair), rest = e % (4 * kBxPair);
-        xb[(size_t)par * 16 * kBxPair + (size_t)j * 4 * kBxPair + rest] = 0ull;
+    for (int e = tid; e < 2 * CWG * kBxPair; e += 512) {
+        const int par = e / (CWG * kBxPair), rest = e % (CWG * kBxPair);
+        xb[(size_t)par * CWG * CWG * kBxPair + (size_t)j * CWG * kBxPair + rest] = 0ull;
     }
 }
 
@@ -525,16 +568,21 @@ static int cluster_cus() {
     return cus;
 }
 
+static int cluster_wgs(int H) { return H <= 256 ? 4 : 8; }      // workgroups per group: 64 hidden units each
+
 bool lstm_cluster_supported(const LstmStep* l, int n, int B, int T, int H) {
-    if (H > kCHP || T >= 1024 || getenv("ADN_LSTM_NO_CLUSTER")) return false;
+    if (H > 512 || T >= 1024 || getenv("ADN_LSTM_NO_CLUSTER")) return false;
+    if (H > 256 && getenv("ADN_LSTM_NO_WIDE_CLUSTER")) return false;
     for (int k = 0; k < n; ++k)
         if (!l[k].xchg || !l[k].W_frag_fwd || !l[k].W_frag_bwd) return false;
-    if (cdiv(B, kCRows) * kCWG > cluster_cus()) return false;     // every workgroup of one LSTM must be resident at once
-    return lstm_frag_elems(H) == (size_t)4 * kCHP * kCHP;
+    if (cdiv(B, kCRows) * cluster_wgs(H) > cluster_cus()) return false;     // every workgroup of one LSTM must be resident at once
+    const size_t hp = (size_t)cluster_wgs(H) * kCUnits;
+    return lstm_frag_elems(H) == 4 * hp * hp;
 }
 
-size_t lstm_cluster_xchg_bytes(int B) {          // forward region (h granules) + backward region (partial-dh granules)
-    return (size_t)cdiv(B, kCRows) * (2 * 16 * kCHP + 2 * 16 * kBxPair) * 8;
+size_t lstm_cluster_xchg_bytes(int B, int H) {   // forward region (h granules) + backward region (partial-dh granules)
+    const int cwg = cluster_wgs(H);
+    return (size_t)cdiv(B, kCRows) * (2 * 16 * cwg * kCUnits + 2 * cwg * cwg * kBxPair) * 8;
 }
 
 int lstm_cluster_error_word(int** out) {
@@ -546,16 +594,18 @@ int lstm_cluster_error_word(int** out) {
     return ADN_OK;
 }
 
-int lstm_forward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s) {
-    const int groups = cdiv(B, kCRows), per = groups * kCWG, cus = cluster_cus();
+template <int CWG>
+static int forward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s) {
+    using G = ClusterGeom<CWG>;
+    const int groups = cdiv(B, kCRows), per = groups * CWG, cus = cluster_cus();
     ADN_CHECK(cus >= per, ADN_ERR_STATE, "lstm cluster kernel: one LSTM does not fit the device");
     int* err = nullptr;
     ADN_TRY(lstm_cluster_error_word(&err));
     const int ldh = ld_of(H), ldg = ld_of(4 * H);
-    const size_t lds = (size_t)(kCWElems + kCRows * kCHS) * 2;
+    const size_t lds = (size_t)(G::WLdsFwd + kCRows * G::HS) * 2;
     static bool attr = false;
     if (!attr) {
-        ADN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_cluster_kernel),
+        ADN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_cluster_kernel<CWG>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
@@ -567,26 +617,28 @@ int lstm_forward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int B
         LstmClusterP L;
         for (int k = 0; k < nn; ++k) L.l[k] = l[k0 + k];
         const unsigned tag0 = (g_cluster_epoch++ & 0x3fffffu) * 1024u + 1u;
-        hipLaunchKernelGGL(lstm_fwd_cluster_kernel, dim3(per, nn), dim3(512), lds, s, L, mask_tb, B, T, H, ldh, ldg, tag0, err);
+        hipLaunchKernelGGL(lstm_fwd_cluster_kernel<CWG>, dim3(per, nn), dim3(512), lds, s, L, mask_tb, B, T, H, ldh, ldg, tag0, err);
         ADN_HIP_CHECK(hipGetLastError());
     }
     return ADN_OK;
 }
 
-}  // namespace adn
+int lstm_forward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s) {
+    return H <= 256 ? forward_cluster<4>(l, n, mask_tb, B, T, H, s) : forward_cluster<8>(l, n, mask_tb, B, T, H, s);
+}
 
-namespace adn {
-
-int lstm_backward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s) {
-    const int groups = cdiv(B, kCRows), per = groups * kCWG, cus = cluster_cus();
+template <int CWG>
+static int backward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s) {
+    using G = ClusterGeom<CWG>;
+    const int groups = cdiv(B, kCRows), per = groups * CWG, cus = cluster_cus();
     ADN_CHECK(cus >= per, ADN_ERR_STATE, "lstm cluster kernel: one LSTM does not fit the device");
     int* err = nullptr;
     ADN_TRY(lstm_cluster_error_word(&err));
     const int ldh = ld_of(H), ldg = ld_of(4 * H);
-    const size_t lds = (size_t)(kCWElems + kCRows * kCHS) * 2 + (size_t)kCRows * (kCUnits + 1) * 4;
+    const size_t lds = (size_t)(G::WLdsBwd + kCRows * kCDS) * 2 + (size_t)kCRows * (kCUnits + 1) * 4;
     static bool attr = false;
     if (!attr) {
-        ADN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_cluster_kernel),
+        ADN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_cluster_kernel<CWG>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
@@ -597,10 +649,14 @@ int lstm_backward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int 
         const int nn = std::min(chunk, n - k0);
         LstmClusterP L;
         for (int k = 0; k < nn; ++k) L.l[k] = l[k0 + k];
-        hipLaunchKernelGGL(lstm_bwd_cluster_kernel, dim3(per, nn), dim3(512), lds, s, L, mask_tb, B, T, H, ldh, ldg, err);
+        hipLaunchKernelGGL(lstm_bwd_cluster_kernel<CWG>, dim3(per, nn), dim3(512), lds, s, L, mask_tb, B, T, H, ldh, ldg, err);
         ADN_HIP_CHECK(hipGetLastError());
     }
     return ADN_OK;
+}
+
+int lstm_backward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s) {
+    return H <= 256 ? backward_cluster<4>(l, n, mask_tb, B, T, H, s) : backward_cluster<8>(l, n, mask_tb, B, T, H, s);
 }
 
 }  // namespace adn

@@ -379,7 +379,7 @@ void carve_lstm(adn_model* m, Carver& cv, LstmWork& w, int B, int T, int ldh, in
     w.cbuf = cv.take<float>((size_t)(T + 1) * B * ldh);
     w.dh_carry = cv.take<float>((size_t)B * ldh);
     w.dc_state = cv.take<float>((size_t)B * ldh);
-    w.xchg = cv.take<char>(lstm_cluster_xchg_bytes(B));
+    w.xchg = cv.take<char>(lstm_cluster_xchg_bytes(B, m->H));
 }
 
 size_t carve(adn_model* m, char* base, int B, int T, bool host_inputs) {
@@ -583,12 +583,14 @@ int refresh_params(adn_model* m) {
             ADN_HIP_CHECK(hipMalloc((void**)&lp.whid16t, bytes));
             ADN_HIP_CHECK(hipMemsetAsync(lp.whid16t, 0, bytes, m->stream));
         }
-        if (persistent) {            // the step kernels' transposed image is not read in this mode
+        if (persistent) {            // the step kernels' transposed image is not read in this mode -- except at H > 256,
+                                     // where they take over whenever a launch cannot keep a whole LSTM resident
             if (!lp.wfrag_fwd) {
                 ADN_HIP_CHECK(hipMalloc((void**)&lp.wfrag_fwd, lstm_frag_elems(m->H) * 2));
                 ADN_HIP_CHECK(hipMalloc((void**)&lp.wfrag_bwd, lstm_frag_elems(m->H) * 2));
             }
-            return lstm_pack_frags(m->P(lp.W_hid), lp.wfrag_fwd, lp.wfrag_bwd, m->H, m->stream);
+            ADN_TRY(lstm_pack_frags(m->P(lp.W_hid), lp.wfrag_fwd, lp.wfrag_bwd, m->H, m->stream));
+            if (m->H <= 256) return ADN_OK;
         }
         return lstm_pack_whid_t(m->P(lp.W_hid), lp.whid16t, m->H, m->stream);
     };
