@@ -1,20 +1,22 @@
-// Weight-stationary LSTM kernels (bf16 mode, H <= 256): W_hid never leaves LDS.
+// Weight-stationary LSTM kernels (bf16 mode, H <= 512): W_hid never leaves the CU.
 //
 // The persistent kernels of lstm_persistent.hip give a 16-utterance slice to ONE workgroup, which must then stream
-// the whole W_hid (512 KB as bf16) from L2 every time step: 12-14 us per step, bound by what one CU can take in
-// (~40 GB/s), with only 33 workgroups per LSTM busy.  Here a group of kCWG = 4 workgroups shares a 32-utterance
-// slice; workgroup j owns hidden units [64 j, 64 j + 64): its 256 gate columns of W_hid (forward) or its 256 rows of
-// W_hid^T (backward) are 128 KB of bf16 in MFMA-fragment order and stay in LDS for all T steps.  What the four
-// workgroups must exchange each step is tiny and goes through L2 / the memory side as 8-byte tagged granules
+// the whole W_hid (512 KB as bf16 at H = 250, 2 MB at H = 500) from L2 every time step: 12-14 us per step (34-70 us at
+// H = 500), bound by what one CU can take in (~40 GB/s), with only 33 workgroups per LSTM busy.  Here a group of CWG
+// workgroups shares a 32-utterance slice (CWG = 4 for H <= 256, 8 for H <= 512); workgroup j owns hidden units
+// [64 j, 64 j + 64): its 256 gate columns of W_hid (forward) or its 256 rows of W_hid^T (backward), in MFMA-fragment
+// order, stay on the CU for all T steps -- 128 KB of LDS at CWG = 4; at CWG = 8 the slice is 256 KB and its k-steps are
+// split between LDS and the registers of the waves that multiply them (see ClusterGeom).  What the workgroups
+// must exchange each step is tiny and goes through L2 / the memory side as 8-byte tagged granules
 // {payload32, tag32}: the consumer polls the payload's own address until the tag of the step shows up (one hop,
 // no separate flag; relaxed agent-scope 64-bit atomics = sc1 stores / loads, single-copy atomic):
-//   forward   all-gather of h_t  (bf16):   granule = h of 2 rows of one unit       32 x 192 values in per workgroup
+//   forward   all-gather of h_t  (bf16):   granule = h of 2 rows of one unit       32 x 64 (CWG - 1) values in per workgroup
 //   backward  reduce-scatter of the partial dh_t (fp32, tag in the low mantissa bits): 2 rows of one unit per
-//             granule                                                                 3 x 32 x 64 values in
+//             granule                                                                 (CWG - 1) x 32 x 64 values in
 // Two parities of the exchange buffer suffice: a workgroup can only be one step ahead of its partners.
 // Every workgroup of a launch must be resident at once (they wait for each other): the host launches at most one
-// workgroup per CU (LDS: 145 KB each) and splits larger sets of LSTMs over several launches.  Polls are bounded (10 s
-// of wall clock); a
+// workgroup per CU (LDS: 145-153 KB each) and splits larger sets of LSTMs over several launches; an LSTM whose groups
+// do not fit the device at all (B > 32 * CUs / CWG) runs on the other kernels.  Polls are bounded (10 s of wall clock); a
 // poll that gives up raises the launch's error word and the host reports ADN_ERR_STATE -- never a hang.
 #include "adn_common.h"
 #include <algorithm>
