@@ -260,6 +260,12 @@ int adn_prep_apply_column_norm(const float* x, float* out, int ld, int rows, int
 /* out[r][j] = in[r][perm[j]]: utils/preprocessing.py:492-503 reorder_data as a pixel permutation; coefficient selection */
 int adn_prep_gather_columns(const float* in, int ld_in, float* out, int ld_out, const int32_t* perm, int rows, int cols,
                             void* hip_stream);
+/* LeCun local contrast normalisation of n_images single-channel H x W images, [n][H][W] contiguous, device pointers
+ * (utils/lcn.py:24-61 lecun_lcn, :64-104 make_lecun_lcn): X - blur(X) divided by max(column mean of the local norm, the
+ * local norm, threshold).  filter_host: the normalised ksize x ksize filter in HOST memory (utils/lcn.py:9-21
+ * gaussian_filter), ksize odd and <= 15; H * W <= 8192. */
+int adn_prep_lcn(const float* x, float* y, int n_images, int H, int W, const float* filter_host, int ksize, float threshold,
+                 void* hip_stream);
 
 /* ---- convolutional auto-encoder (reference modelzoo/avletters_convae.py:33-69) ---------------------
  * conv 5x5 (100) - maxpool 2 - conv 5x5 (150) - maxpool 2 pad (1,0) - conv 3x3 (200) - dense - bottleneck, and the

@@ -123,6 +123,7 @@ _SIGNATURES = {
     "adn_prep_column_stats": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "adn_prep_apply_column_norm": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "adn_prep_gather_columns": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, _P]),
+    "adn_prep_lcn": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_float, _P]),
 }
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
 

@@ -229,5 +229,7 @@ int prep_column_stats(const float* x, int ld, int rows, int cols, double* ws, fl
 int prep_apply_column_norm(const float* x, float* out, int ld, int rows, int cols, const float* mean, const float* std,
                            hipStream_t s);
 int prep_gather_columns(const float* in, int ld_in, float* out, int ld_out, const int* perm, int rows, int cols, hipStream_t s);
+constexpr int kLcnMaxK = 15, kLcnMaxPerThread = 32;
+int prep_lcn(const float* x, float* y, int n_images, int H, int W, const float* filter_host, int k, float threshold, hipStream_t s);
 
 }  // namespace adn

@@ -1584,5 +1584,9 @@ int adn_prep_gather_columns(const float* in, int ld_in, float* out, int ld_out, 
                             void* hip_stream) {
     return prep_gather_columns(in, ld_in, out, ld_out, perm, rows, cols, static_cast<hipStream_t>(hip_stream));
 }
+int adn_prep_lcn(const float* x, float* y, int n_images, int H, int W, const float* filter_host, int ksize, float threshold,
+                 void* hip_stream) {
+    return prep_lcn(x, y, n_images, H, W, filter_host, ksize, threshold, static_cast<hipStream_t>(hip_stream));
+}
 
 }  // extern "C"

@@ -4,6 +4,7 @@
 // int32 index vectors built once on the host from the length vector.  Reference quirks are reproduced (cited inline).
 #include "adn_common.h"
 #include <algorithm>
+#include <cmath>
 
 namespace adn {
 
@@ -206,6 +207,134 @@ int prep_gather_columns(const float* in, int ld_in, float* out, int ld_out, cons
     const int64_t total = (int64_t)rows * cols;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, 16384));
     hipLaunchKernelGGL(gather_cols_kernel, dim3(grid), dim3(256), 0, s, in, ld_in, out, ld_out, perm, rows, cols);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LeCun local contrast normalisation of single-channel images (reference utils/lcn.py:24-61, 64-104):
+//   blur(Z)[y][x] = sum_{i,j} f[i][j] Z[y + mid - i][x + mid - j]     ('full' convolution cropped by mid = k / 2: zero
+//                                                                      outside the image; f = normalised k x k Gaussian)
+//   cen   = X - blur(X);   den = sqrt(blur(cen^2))
+//   div   = max(max(colmean[x], den), threshold)  with colmean[x] = mean over the ROWS of den[:, x]  (the reference's
+//           `denom.mean(axis=[1, 2])` of a (B, 1, H, W) tensor averages channel and rows, not the whole image)
+//   out   = cen / div
+// One workgroup per image: the image (later den), cen and a row-filtered scratch live in LDS (3 H W floats <= 96 KB), every
+// global byte is read and written once, coalesced.  A separable filter runs as 1-d row and column passes (2 k taps
+// per pixel and blur instead of k^2).
+// ---------------------------------------------------------------------------------------------------------
+struct LcnFilter { float w[kLcnMaxK * kLcnMaxK]; float row[kLcnMaxK], col[kLcnMaxK]; };
+
+// blur of the LDS image `in` at pixel (py, px): SEP = false the k x k taps; SEP = true `in` already holds the horizontal
+// pass and only the k column taps remain
+template <bool SEP>
+__device__ __forceinline__ float lcn_blur(const float* in, const LcnFilter& f, int H, int W, int k, int mid, int py, int px) {
+    float b = 0.f;
+    for (int i = 0; i < k; ++i) {
+        const int yy = py + mid - i;
+        if (yy < 0 || yy >= H) continue;
+        if (SEP) { b += f.col[i] * in[yy * W + px]; continue; }
+        for (int j = 0; j < k; ++j) {
+            const int xx = px + mid - j;
+            if (xx >= 0 && xx < W) b += f.w[i * k + j] * in[yy * W + xx];
+        }
+    }
+    return b;
+}
+
+// horizontal pass of a separable filter: out[y][x] = sum_j row[j] (SQ ? in^2 : in)[y][x + mid - j]
+template <bool SQ>
+__device__ __forceinline__ void lcn_rows(const float* in, float* out, const LcnFilter& f, int HW, int W, int k, int mid) {
+    for (int e = threadIdx.x; e < HW; e += 256) {
+        const int px = e % W, base = e - px;
+        float b = 0.f;
+        for (int j = 0; j < k; ++j) {
+            const int xx = px + mid - j;
+            if (xx >= 0 && xx < W) { const float v = in[base + xx]; b += f.row[j] * (SQ ? v * v : v); }
+        }
+        out[e] = b;
+    }
+}
+
+template <bool SEP>
+__global__ __launch_bounds__(256) void lcn_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int k,
+                                                  float threshold, const LcnFilter f) {
+    extern __shared__ float lcn_lds[];
+    float* img = lcn_lds;                 // X, later den
+    float* cen = lcn_lds + H * W;
+    float* tmp = cen + H * W;             // SEP: row-filtered image; generic: unused
+    float* colmean = tmp + (SEP ? H * W : 0);
+    const int HW = H * W, mid = k / 2;
+    const float* src = x + (size_t)blockIdx.x * HW;
+    for (int e = threadIdx.x; e < HW; e += 256) img[e] = src[e];
+    __syncthreads();
+    if (SEP) { lcn_rows<false>(img, tmp, f, HW, W, k, mid); __syncthreads(); }
+    for (int e = threadIdx.x; e < HW; e += 256)
+        cen[e] = img[e] - lcn_blur<SEP>(SEP ? tmp : img, f, H, W, k, mid, e / W, e % W);
+    __syncthreads();
+    if (SEP) {
+        lcn_rows<true>(cen, tmp, f, HW, W, k, mid);
+        __syncthreads();
+        for (int e = threadIdx.x; e < HW; e += 256) img[e] = sqrtf(fmaxf(lcn_blur<true>(tmp, f, H, W, k, mid, e / W, e % W), 0.f));
+    } else {
+        float den_r[kLcnMaxPerThread];
+        int n = 0;
+        for (int e = threadIdx.x; e < HW; e += 256, ++n) {
+            const int py = e / W, px = e % W;
+            float b = 0.f;
+            for (int i = 0; i < k; ++i) {
+                const int yy = py + mid - i;
+                if (yy < 0 || yy >= H) continue;
+                for (int j = 0; j < k; ++j) {
+                    const int xx = px + mid - j;
+                    if (xx >= 0 && xx < W) { const float c = cen[yy * W + xx]; b += f.w[i * k + j] * (c * c); }
+                }
+            }
+            den_r[n] = sqrtf(fmaxf(b, 0.f));
+        }
+        n = 0;
+        for (int e = threadIdx.x; e < HW; e += 256, ++n) img[e] = den_r[n];     // X is no longer needed
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < W; c += 256) {
+        float a = 0.f;
+        for (int r = 0; r < H; ++r) a += img[r * W + c];
+        colmean[c] = a / (float)H;
+    }
+    __syncthreads();
+    float* dst = y + (size_t)blockIdx.x * HW;
+    for (int e = threadIdx.x; e < HW; e += 256)
+        dst[e] = cen[e] / fmaxf(fmaxf(colmean[e % W], img[e]), threshold);
+}
+
+int prep_lcn(const float* x, float* y, int n_images, int H, int W, const float* filter_host, int k, float threshold, hipStream_t s) {
+    ADN_CHECK(x && y && filter_host, ADN_ERR_INVALID, "prep_lcn: null argument");
+    ADN_CHECK(k >= 1 && k <= kLcnMaxK && (k & 1), ADN_ERR_INVALID, "prep_lcn: the kernel size must be odd and <= 15");
+    ADN_CHECK(H >= 1 && W >= 1 && (int64_t)H * W <= 256 * kLcnMaxPerThread, ADN_ERR_INVALID, "prep_lcn: image larger than 8192 pixels");
+    if (n_images <= 0) return ADN_OK;
+    LcnFilter f;
+    for (int e = 0; e < k * k; ++e) f.w[e] = filter_host[e];
+    // a rank-1 filter (the reference's Gaussian is one: exp(-(a^2 + b^2) / 2 sigma^2) = g(a) g(b)) runs as two 1-d passes
+    const int mid = k / 2;
+    const float centre = filter_host[mid * k + mid];
+    bool sep = centre > 0.f;
+    if (sep) {
+        const float r = sqrtf(centre);
+        for (int i = 0; i < k; ++i) { f.col[i] = filter_host[i * k + mid] / r; f.row[i] = filter_host[mid * k + i] / r; }
+        float fmax = 0.f;
+        for (int e = 0; e < k * k; ++e) fmax = std::max(fmax, std::fabs(filter_host[e]));
+        for (int i = 0; i < k && sep; ++i)
+            for (int j = 0; j < k; ++j)
+                if (std::fabs(f.col[i] * f.row[j] - filter_host[i * k + j]) > 1e-6f * fmax) { sep = false; break; }
+    }
+    const size_t lds = ((size_t)(sep ? 3 : 2) * H * W + W) * sizeof(float);
+    if (sep) {
+        ADN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lcn_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(lcn_kernel<true>, dim3(n_images), dim3(256), lds, s, x, y, H, W, k, threshold, f);
+    } else {
+        ADN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lcn_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(lcn_kernel<false>, dim3(n_images), dim3(256), lds, s, x, y, H, W, k, threshold, f);
+    }
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }

@@ -76,6 +76,16 @@ int main(int argc, char** argv) {
             cases.push_back({names[i], GEMM_NN, R, 1000, K, 0, 0, 0, 0, 0}); ++i;
         }
     }
+    if (only && !strcmp(only, "msweep")) {          // M sweep around whole rounds of 256 workgroups: is the tail round real?
+        cases.clear(); only = nullptr;
+        static char names[64][40];
+        int i = 0;
+        for (int N : {1000, 2000})
+            for (int mt : {128, 144, 152, 160, 161, 163, 168, 176, 184, 192}) {
+                snprintf(names[i], 40, "msweep fwd N=%d mtiles=%d", N, mt);
+                cases.push_back({names[i], GEMM_NN, mt * 128, N, N == 1000 ? 2000 : 1200, 1, 0, 0, 0, 1}); ++i;
+            }
+    }
     const int padto = getenv("LAB_PAD") ? atoi(getenv("LAB_PAD")) : 8;      // leading-dimension rounding (elements)
     auto pad = [padto](int n) { return (n + padto - 1) / padto * padto; };
     hipStream_t st; CK(hipStreamCreate(&st));

@@ -14,6 +14,8 @@ import torch
 
 from ip_avsr_amd.utils import preprocessing as host
 from ip_avsr_amd.utils import preprocessing_gpu as gpu
+from ip_avsr_amd.utils import lcn as gpu_lcn
+from oracle import lcn_oracle                      # CPU leg only
 
 rng = np.random.RandomState(1234)
 lens = rng.randint(12, 41, size=780)
@@ -45,6 +47,7 @@ def cpu_ms(fn, iters=3):
     return (time.perf_counter() - t) / iters * 1e3
 
 
+LCN = gpu_lcn.make_lecun_lcn((n, 1, 30, 40), (30, 40), 9)
 cases = [
     ("compute_diff_images", lambda: gpu.compute_diff_images(Xd, lens), lambda: host.compute_diff_images(X, lens), 2 * e * n * 1200),
     ("sequencewise_mean_image_subtraction", lambda: gpu.sequencewise_mean_image_subtraction(Xd, lens),
@@ -57,9 +60,13 @@ cases = [
      lambda: host.compute_dct_features(X, (30, 40), 30), e * n * (1200 + 30)),
     ("concat_first_second_deltas F=30 w=9", lambda: gpu.concat_first_second_deltas(Fd, lens, 9),
      lambda: host.concat_first_second_deltas(F30, lens, 9), e * n * (30 + 90)),
+    ("lecun_lcn 30x40, 9x9 (utils/lcn.py)", lambda: LCN(Xd), lambda: lcn_oracle.lecun_lcn(X[:2000], (30, 40), 9, dtype=np.float32),
+     2 * e * n * 1200),
 ]
 print("frames %d x 1200 (%.1f MB fp32); host cores %d" % (n, n * 1200 * 4 / 1e6, os.cpu_count()))
 print("%-40s %10s %12s %12s %9s" % ("transform", "GPU ms", "GB/s (alg.)", "host ms", "ratio"))
 for name, g, h, nbytes in cases:
     gm, hm = gpu_ms(g), cpu_ms(h)
+    if name.startswith("lecun_lcn"):
+        hm *= n / 2000.0                                # the host leg ran on 2000 frames
     print("%-40s %10.3f %12.0f %12.1f %8.0fx" % (name, gm, nbytes / gm / 1e6, hm, hm / gm))
