@@ -82,6 +82,19 @@ def synthetic_batch(torch, rank, B, device):
     return xs, torch.tensor(y, device=device), m_d, mask
 
 
+def lstm_traffic(d, steps_per_train_step):
+    """HBM bytes per LSTM and time step from the PMC summary of the LSTM kernel class (profiles/make_traffic_json.py).
+    `steps_per_train_step` = T (or T + 1) time steps x the kernel launches of a train step; every launch of the bench model
+    holds several LSTMs (3 stream LSTMs, then the 2 directions of the BLSTM): 5 LSTMs over 2 launches."""
+    if not d or not d.get("launches"):
+        return None
+    per_launch = d["traffic_bytes_per_launch"]
+    if d.get("kernel", "").endswith("step_kernel"):                # f32 mode: one launch = one time step of 3 or 2 LSTMs
+        return per_launch / 2.5
+    t_steps = steps_per_train_step / 2.0                           # bf16: one launch = all T steps of its LSTMs; the
+    return per_launch * 2.0 / (5.0 * t_steps)                      # profiler counts T per launch, 2 launches per step
+
+
 def cpu_baseline(budget_s=20.0):
     """The oracle's train step (fp32 NumPy, BLAS threads = all host cores) on the reference minibatch
     (B=26, T=40) of the same model; sequences/s = 26 / median step time."""
@@ -226,10 +239,11 @@ def main():
             flops = sum(e["flops"] for e in g); ms = sum(e["ms"] for e in g); n = sum(e["launches"] for e in g)
             ach = flops / (ms * 1e-3) / 1e12 if ms else 0.0
             peak = PEAK_BF16_MFMA_TFLOPS if args.precision == "bf16" else PEAK_F32_MFMA_TFLOPS
-            traffic = None                         # HBM bytes per launch from the committed PMC passes of this build
+            traffic, pmc = None, {}                # HBM bytes per launch from the committed PMC passes of this build
             tfile = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_%s.json" % args.precision)
             if os.path.exists(tfile):
-                traffic = json.load(open(tfile)).get("traffic_bytes_per_launch")
+                pmc = json.load(open(tfile))
+                traffic = pmc.get("traffic_bytes_per_launch")
             out["roofline"] = {"kernel": "gemm_%s_kernel (encoder / projection GEMMs, all three layouts)" % args.precision,
                                "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                                "frac": ach / peak, "traffic": traffic,
@@ -246,7 +260,10 @@ def main():
                             % key[5:8]) if args.precision == "bf16" else key + "_kernel (one launch per time step)"
                     out[name] = {"kernel": kern, "bound": "hbm", "achieved": a, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "algorithmic_bytes": "SURVEY 8d formula: e(12BH+4H^2)+B forward, e(15BH+4H^2) backward, per LSTM and step",
-                                 "frac": a / PEAK_HBM_GBS, "traffic": None,
+                                 "frac": a / PEAK_HBM_GBS,
+                                 # PMC bytes of all kernel launches of this class in a step / the LSTM time steps they cover
+                                 # (same unit as `achieved`'s numerator: one LSTM, one time step)
+                                 "traffic": lstm_traffic(pmc.get(key[:8]), e["launches"] / args.steps),
                                  "avg_launch_us": 1e3 * e["ms"] / e["launches"],
                                  "share_of_step": e["ms"] / (1e3 * prof_elapsed)}
             out["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in prof.items()}

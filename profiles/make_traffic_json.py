@@ -22,25 +22,32 @@ def per_kernel(path, match):
     return tot, n
 
 
-def main():
-    fa, fb, prec = sys.argv[1:4]
-    match = "gemm_bf16" if prec == "bf16" else "gemm_f32_kernel"
+def summarise(fa, fb, match):
     ta, na = per_kernel(fa, match)
     tb, nb = per_kernel(fb, match)
     launches = na["FETCH_SIZE"]
     fetch = 2.0 * 1024.0 * ta["FETCH_SIZE"] / max(1, launches)
     write = 1024.0 * tb["WRITE_SIZE"] / max(1, nb["WRITE_SIZE"])
     hit, miss = tb["TCC_HIT_sum"], tb["TCC_MISS_sum"]
-    print(json.dumps({
-        "kernel_class": "%s (all instantiations)" % match,
-        "launches": launches,
-        "fetch_bytes_per_launch": fetch,
-        "write_bytes_per_launch": write,
-        "l2_hit_rate": hit / max(1.0, hit + miss),
-        "traffic_bytes_per_launch": fetch + write,
-        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum (separate passes), bench.py --steps 3 "
-                  "--warmup 1 --precision %s; FETCH_SIZE doubled per the gfx950 correction" % prec,
-    }, indent=1))
+    return {"launches": launches, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
+            "l2_hit_rate": hit / max(1.0, hit + miss), "traffic_bytes_per_launch": fetch + write}
+
+
+def main():
+    fa, fb, prec = sys.argv[1:4]
+    match = "gemm_bf16" if prec == "bf16" else "gemm_f32_kernel"
+    out = {"kernel_class": "%s (all instantiations)" % match}
+    out.update(summarise(fa, fb, match))
+    # the LSTM kernels: one launch covers all T time steps of up to 3 LSTMs (bench.py divides by what a launch covered)
+    for key, m in (("lstm_fwd", "lstm_fwd_cluster_kernel" if prec == "bf16" else "lstm_fwd_step_kernel"),
+                   ("lstm_bwd", "lstm_bwd_cluster_kernel" if prec == "bf16" else "lstm_bwd_step_kernel")):
+        d = summarise(fa, fb, m)
+        if d["launches"]:
+            d["kernel"] = m
+            out[key] = d
+    out["source"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum (separate passes), bench.py --steps 3 "
+                     "--warmup 1 --precision %s; FETCH_SIZE doubled per the gfx950 correction" % prec)
+    print(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":
