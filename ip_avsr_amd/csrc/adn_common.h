@@ -113,11 +113,12 @@ int transpose_to_bf16_batch(const TransposeItem* dev_items, int n, int total_blo
 // element-wise / HBM-bound kernels (elementwise.hip)
 // ---------------------------------------------------------------------------------------
 // batch-major (B,T,F) -> time-major (T,B,[F|dF|ddF]) with optional delta/delta-delta append
+// (out16 / din16: optional bf16 copy of the result, same leading dimension -- saves the separate conversion)
 int delta_forward(const float* in, int ld_in, float* out, int ld_out, int B, int T, int F, int theta,
-                  int append, hipStream_t s);
+                  int append, hipStream_t s, void* out16 = nullptr);
 // adjoint: time-major gradient (T,B,3F or F) -> batch-major (B,T,F)
 int delta_backward(const float* dout, int ld_out, float* din, int ld_in, int B, int T, int F, int theta,
-                   int append, hipStream_t s);
+                   int append, hipStream_t s, void* din16 = nullptr);
 // out[r][c] = sum_k alpha_k * in_k[r][c]  (alpha = device scalars or null for 1)
 int sum_k(int n_in, const float* const* in, const float* const* alpha, int ld_in, float* out, int ld_out,
           int rows, int cols, hipStream_t s);
@@ -139,6 +140,8 @@ int act_backward(float* dy, int ld_dy, const float* y, int ld_y, int rows, int c
 int mask_prepare(const uint8_t* mask_bt, uint8_t* mask_tb, int B, int T, float* total, hipStream_t s);
 // rows [0,B) of dst = vec (broadcast of a (1,H) init vector)
 int broadcast_rows(const float* vec, float* dst, int ld, int rows, int cols, hipStream_t s);
+// h[r][:] = hid, c[r][:] = cell for r < rows (pad columns 0), h16 = optional bf16 copy of h
+int lstm_init_state_rows(const float* hid, const float* cell, float* h, float* c, void* h16, int ld, int rows, int cols, hipStream_t s);
 // softmax classifier head + double-softmax temporal loss (custom/objectives.py:4-39)
 //   z (T*B rows, time-major, ldz) -> probs_bt (B,T,C) batch-major dense (may be null),
 //   row_loss[r] = -mask*log softmax(softmax(z))[y]  (if y != null), dz (may be null)

@@ -19,7 +19,7 @@ constexpr int kDeltaFC = 32;
 
 __global__ __launch_bounds__(256) void delta_fwd_kernel(const float* __restrict__ in, int ld_in,
                                                         float* __restrict__ out, int ld_out, int B, int T, int F,
-                                                        int theta, int append) {
+                                                        int theta, int append, __bf16* __restrict__ out16) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* xs = sm;                   // [T][32]
     float* d1 = sm + T * kDeltaFC;    // [T][32]
@@ -31,7 +31,10 @@ __global__ __launch_bounds__(256) void delta_fwd_kernel(const float* __restrict_
     __syncthreads();
     if (!append) {
         for (int t = ts; t < T; t += 8)
-            if (fv) out[((size_t)t * B + b) * ld_out + f] = xs[t * kDeltaFC + fl];
+            if (fv) {
+                out[((size_t)t * B + b) * ld_out + f] = xs[t * kDeltaFC + fl];
+                if (out16) out16[((size_t)t * B + b) * ld_out + f] = (__bf16)xs[t * kDeltaFC + fl];
+            }
         return;
     }
     for (int t = ts; t < T; t += 8) {
@@ -54,6 +57,12 @@ __global__ __launch_bounds__(256) void delta_fwd_kernel(const float* __restrict_
             o[f] = xs[t * kDeltaFC + fl];
             o[F + f] = d1[t * kDeltaFC + fl];
             o[2 * F + f] = acc;
+            if (out16) {                                         // the bf16 copy the projection GEMM reads
+                __bf16* o16 = out16 + ((size_t)t * B + b) * ld_out;
+                o16[f] = (__bf16)xs[t * kDeltaFC + fl];
+                o16[F + f] = (__bf16)d1[t * kDeltaFC + fl];
+                o16[2 * F + f] = (__bf16)acc;
+            }
         }
     }
 }
@@ -82,7 +91,7 @@ __device__ __forceinline__ float delta_adjoint_at(const float* g, int tau, int T
 
 __global__ __launch_bounds__(256) void delta_bwd_kernel(const float* __restrict__ dout, int ld_out,
                                                         float* __restrict__ din, int ld_in, int B, int T, int F,
-                                                        int theta, int append) {
+                                                        int theta, int append, __bf16* __restrict__ din16) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* g2 = sm;                   // [T][32]  gradient wrt dd, later reused
     float* r1 = sm + T * kDeltaFC;    // [T][32]  g1 + D^T g2
@@ -92,7 +101,11 @@ __global__ __launch_bounds__(256) void delta_bwd_kernel(const float* __restrict_
     const bool fv = f < F;
     if (!append) {
         for (int t = ts; t < T; t += 8)
-            if (fv) din[((size_t)b * T + t) * ld_in + f] = dout[((size_t)t * B + b) * ld_out + f];
+            if (fv) {
+                const float v = dout[((size_t)t * B + b) * ld_out + f];
+                din[((size_t)b * T + t) * ld_in + f] = v;
+                if (din16) din16[((size_t)b * T + t) * ld_in + f] = (__bf16)v;
+            }
         return;
     }
     for (int t = ts; t < T; t += 8)
@@ -106,31 +119,33 @@ __global__ __launch_bounds__(256) void delta_bwd_kernel(const float* __restrict_
     for (int t = ts; t < T; t += 8) {
         if (fv) {
             const float g0 = dout[((size_t)t * B + b) * ld_out + f];
-            din[((size_t)b * T + t) * ld_in + f] = g0 + delta_adjoint_at(r1 + fl, t, T, theta);
+            const float v = g0 + delta_adjoint_at(r1 + fl, t, T, theta);
+            din[((size_t)b * T + t) * ld_in + f] = v;
+            if (din16) din16[((size_t)b * T + t) * ld_in + f] = (__bf16)v;
         }
     }
 }
 
 int delta_forward(const float* in, int ld_in, float* out, int ld_out, int B, int T, int F, int theta, int append,
-                  hipStream_t s) {
+                  hipStream_t s, void* out16) {
     ADN_CHECK(T > 0 && B > 0 && F > 0, ADN_ERR_INVALID, "delta_forward: empty tensor");
     const size_t lds = (size_t)2 * T * kDeltaFC * sizeof(float);
     ADN_CHECK(lds <= 64 * 1024, ADN_ERR_INVALID, "delta layer: T too large (max 256 frames)");
     ProfScope prof(PROF_DELTA_FWD, 0.0, 4.0 * B * T * (double)F * (append ? 4.0 : 2.0), s);
     hipLaunchKernelGGL(delta_fwd_kernel, dim3(B, cdiv(F, kDeltaFC)), dim3(256), lds, s, in, ld_in, out, ld_out, B, T,
-                       F, theta, append);
+                       F, theta, append, reinterpret_cast<__bf16*>(out16));
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }
 
 int delta_backward(const float* dout, int ld_out, float* din, int ld_in, int B, int T, int F, int theta, int append,
-                   hipStream_t s) {
+                   hipStream_t s, void* din16) {
     ADN_CHECK(T > 0 && B > 0 && F > 0, ADN_ERR_INVALID, "delta_backward: empty tensor");
     const size_t lds = (size_t)2 * T * kDeltaFC * sizeof(float);
     ADN_CHECK(lds <= 64 * 1024, ADN_ERR_INVALID, "delta layer: T too large (max 256 frames)");
     ProfScope prof(PROF_DELTA_BWD, 0.0, 4.0 * B * T * (double)F * (append ? 4.0 : 2.0), s);
     hipLaunchKernelGGL(delta_bwd_kernel, dim3(B, cdiv(F, kDeltaFC)), dim3(256), lds, s, dout, ld_out, din, ld_in, B,
-                       T, F, theta, append);
+                       T, F, theta, append, reinterpret_cast<__bf16*>(din16));
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }
@@ -495,6 +510,27 @@ __global__ __launch_bounds__(256) void broadcast_rows_kernel(const float* __rest
         const int r = (int)(e / cols), c = (int)(e % cols);
         dst[(size_t)r * ld + c] = vec[c];
     }
+}
+
+// initial LSTM state of every utterance: h[r][:] = hid_init, c[r][:] = cell_init, plus the bf16 copy of h (one launch
+// instead of two broadcasts and a conversion per LSTM)
+__global__ __launch_bounds__(256) void lstm_init_state_kernel(const float* __restrict__ hid, const float* __restrict__ cell,
+                                                              float* __restrict__ h, float* __restrict__ c,
+                                                              __bf16* __restrict__ h16, int ld, int rows, int cols) {
+    const int64_t total = (int64_t)rows * ld;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int col = (int)(e % ld);
+        const float hv = col < cols ? hid[col] : 0.f, cv = col < cols ? cell[col] : 0.f;
+        h[e] = hv; c[e] = cv;
+        if (h16) h16[e] = (__bf16)hv;
+    }
+}
+
+int lstm_init_state_rows(const float* hid, const float* cell, float* h, float* c, void* h16, int ld, int rows, int cols, hipStream_t s) {
+    hipLaunchKernelGGL(lstm_init_state_kernel, dim3(grid_for((int64_t)rows * ld)), dim3(256), 0, s, hid, cell, h, c,
+                       reinterpret_cast<__bf16*>(h16), ld, rows, cols);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
 }
 
 int broadcast_rows(const float* vec, float* dst, int ld, int rows, int cols, hipStream_t s) {

@@ -684,10 +684,9 @@ int lstm_project_cat(adn_model* m, const LstmParams& lp, const LstmWork& w, int 
 
 int lstm_init_state(adn_model* m, const LstmParams& lp, const LstmWork& w, int B, int T) {
     const size_t blk = lp.backwards ? (size_t)T * B * m->ldh : 0;
-    ADN_TRY(broadcast_rows(m->P(lp.hid_init), w.hbuf + blk, m->ldh, B, m->H, m->stream));
-    ADN_TRY(broadcast_rows(m->P(lp.cell_init), w.cbuf + blk, m->ldh, B, m->H, m->stream));
-    ADN_TRY(refresh(m, w.hbuf + blk, (size_t)B * m->ldh));          // bf16 copy of the initial-state block
-    return ADN_OK;
+    char* h16 = m->bf16() ? static_cast<char*>(m->shadow_of(w.hbuf)) : nullptr;     // bf16 copy of the initial-state block
+    return lstm_init_state_rows(m->P(lp.hid_init), m->P(lp.cell_init), w.hbuf + blk, w.cbuf + blk, h16 ? h16 + blk * 2 : nullptr,
+                                m->ldh, B, m->H, m->stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -754,11 +753,13 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
             ADN_TRY(mgemm(m, g, /*lean=*/l + 1 < st.cfg.n_enc));      // the delta layer reads the last one in fp32
             a = st.act[l]; lda = g.ldc;
         }
-        ADN_TRY(delta_forward(a, lda, st.feat, ld_of(st.feat_dim), B, T, st.enc_out, theta, st.cfg.use_delta, m->stream));
-        if (m->stochastic && st.cfg.dropout_p > 0.f)             // DropoutLayer ahead of the LSTM (adenet_v3.py:112,123,134)
+        const bool drop = m->stochastic && st.cfg.dropout_p > 0.f;
+        void* feat16 = (m->bf16() && !drop) ? m->shadow_of(st.feat) : nullptr;      // written by the delta kernel itself
+        ADN_TRY(delta_forward(a, lda, st.feat, ld_of(st.feat_dim), B, T, st.enc_out, theta, st.cfg.use_delta, m->stream, feat16));
+        if (drop)                                                // DropoutLayer ahead of the LSTM (adenet_v3.py:112,123,134)
             ADN_TRY(dropout_apply(st.feat, ld_of(st.feat_dim), st.feat, ld_of(st.feat_dim), B, T, st.feat_dim, st.feat_dim, 0,
                                   st.cfg.dropout_p, m->drop_seed, m->drop_counter, (uint32_t)(&st - m->st.data()), m->stream));
-        ADN_TRY(refresh(m, st.feat, (size_t)N * ld_of(st.feat_dim)));
+        if (!feat16) ADN_TRY(refresh(m, st.feat, (size_t)N * ld_of(st.feat_dim)));
         for (size_t k = 0; k < st.lstm.size(); ++k) {
             const float* in[1] = {st.feat}; const int ld[1] = {ld_of(st.feat_dim)};
             ADN_TRY(lstm_project(m, st.lstm[k], st.lw[k], in, ld, 1, st.feat_dim, N));
@@ -1050,11 +1051,14 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             ADN_TRY(dropout_apply(st.dfeat, ldf, st.dfeat, ldf, B, T, st.feat_dim, st.feat_dim, 0, st.cfg.dropout_p,
                                   m->drop_seed, m->drop_counter, (uint32_t)si, m->stream));
         const int ldE = ld_of(st.enc_out);
-        ADN_TRY(delta_backward(st.dfeat, ldf, st.dE, ldE, B, T, st.enc_out, theta, st.cfg.use_delta, m->stream));
         // encoder: dZ_l = dA_l * act_l'(A_l);  dW_l = A_{l-1}^T dZ_l;  dA_{l-1} = dZ_l W_l^T
         const int L = st.cfg.n_enc;
-        ADN_TRY(act_backward(st.dE, ldE, st.act[L - 1], ldE, N, st.enc_out, st.cfg.enc_act[L - 1], m->stream));
-        ADN_TRY(refresh(m, st.dE, (size_t)N * ldE));
+        const bool last_linear = L > 0 && st.cfg.enc_act[L - 1] == ADN_ACT_LINEAR;
+        void* dE16 = (m->bf16() && (L == 0 || last_linear)) ? m->shadow_of(st.dE) : nullptr;   // bf16 copy straight from the kernel
+        ADN_TRY(delta_backward(st.dfeat, ldf, st.dE, ldE, B, T, st.enc_out, theta, st.cfg.use_delta, m->stream, dE16));
+        if (!last_linear)
+            ADN_TRY(act_backward(st.dE, ldE, st.act[L - 1], ldE, N, st.enc_out, st.cfg.enc_act[L - 1], m->stream));
+        if (!dE16) ADN_TRY(refresh(m, st.dE, (size_t)N * ldE));
         float* dZ = st.dE; int lddz = ldE;
         int bias_done = 0;
         for (int l = L - 1; l >= 0; --l) {
