@@ -96,6 +96,8 @@ struct GemmArgs {
     // atomics execute at the memory side and every workgroup adding into ONE row is the slow case: measured
     // 50-80 us per GEMM.)  Fusion is skipped when the workspace is missing or too small.
     float* colsum_ws = nullptr; size_t colsum_ws_floats = 0;
+    // when set and the fused path ran, the reduction of the partial rows is queued here instead of launched
+    struct ColSumBatch* colsum_batch = nullptr;
     // bf16 kernels with shadows only: C may be null when C16 is given (the fp32 copy is simply not written; the
     // launch is then never split over K), and Y16 may replace Y (bf16 copy of the activation, same ld)
     const void* Y16 = nullptr;
@@ -106,6 +108,12 @@ int to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 // out[c * ldT + r] = bf16(W[r * ld + c]) for r < rows, c < cols (LDS-tiled transpose)
 int transpose_to_bf16(const float* W, int rows, int cols, int ld, void* out, int ldT, hipStream_t s);
 // the same for a table of matrices in ONE launch (items: device array; block_end[k] = running total of 32x32 tiles)
+// several column sums in one launch (out[c] += sum_r in[r][c]); items by value in the kernel arguments
+struct ColSumItem { const float* in; float* out; int ld, rows, cols, ctiles, splits, rps, block_end; };
+struct ColSumBatch { ColSumItem it[8]; int n = 0; };
+void col_sum_batch_add(ColSumBatch& b, const float* in, int ld, int rows, int cols, float* out);
+int col_sum_batch(ColSumBatch& b, hipStream_t s);          // launches (if any item is pending) and clears the batch
+
 struct TransposeItem { const float* W; void* out; int rows, cols, ld, ldT, block_end; };
 int transpose_to_bf16_batch(const TransposeItem* dev_items, int n, int total_blocks, hipStream_t s);
 

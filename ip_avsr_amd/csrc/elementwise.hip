@@ -229,6 +229,45 @@ int col_sum(const float* in, int ld, int rows, int cols, float* out, int accumul
     return ADN_OK;
 }
 
+// the same for up to 8 matrices in one launch: block -> item through the running block_end
+__global__ __launch_bounds__(256) void col_sum_batch_kernel(const ColSumBatch b) {
+    __shared__ float part[4][64];
+    int k = 0;
+    while (k + 1 < b.n && (int)blockIdx.x >= b.it[k].block_end) ++k;
+    const ColSumItem& it = b.it[k];
+    const int local = (int)blockIdx.x - (k ? b.it[k - 1].block_end : 0);
+    const int ct = local % it.ctiles, sp = local / it.ctiles;
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = ct * 64 + cl;
+    const int r0 = sp * it.rps, r1 = min(it.rows, r0 + it.rps);
+    float acc = 0.f;
+    if (c < it.cols)
+        for (int r = r0 + rl; r < r1; r += 4) acc += it.in[(size_t)r * it.ld + c];
+    part[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && c < it.cols) atomicAdd(it.out + c, part[0][cl] + part[1][cl] + part[2][cl] + part[3][cl]);
+}
+
+void col_sum_batch_add(ColSumBatch& b, const float* in, int ld, int rows, int cols, float* out) {
+    if (rows <= 0 || cols <= 0 || b.n >= 8) return;
+    ColSumItem& it = b.it[b.n];
+    it.in = in; it.out = out; it.ld = ld; it.rows = rows; it.cols = cols;
+    it.ctiles = cdiv(cols, 64);
+    int splits = std::max(1, std::min(cdiv(rows, 64), cdiv(1024, it.ctiles)));
+    it.rps = cdiv(rows, splits);
+    it.splits = cdiv(rows, it.rps);
+    it.block_end = (b.n ? b.it[b.n - 1].block_end : 0) + it.ctiles * it.splits;
+    ++b.n;
+}
+
+int col_sum_batch(ColSumBatch& b, hipStream_t s) {
+    if (b.n <= 0) return ADN_OK;
+    hipLaunchKernelGGL(col_sum_batch_kernel, dim3(b.it[b.n - 1].block_end), dim3(256), 0, s, b);
+    b.n = 0;
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
 // out[r][j * cols + c] = in_j[r][c]  (bf16; cols a multiple of 8): the materialised concat of up to 4 matrices
 struct ConcatArgs { const void* in[4]; };
 __global__ __launch_bounds__(256) void concat_cols_bf16_kernel(ConcatArgs a, int n, int ld_in, uint4* __restrict__ out, int ld_out,

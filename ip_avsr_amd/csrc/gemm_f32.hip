@@ -254,7 +254,10 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
     else if (big) launch<128, 128>(p, g.layout, grid, stream);
     else launch<64, 64>(p, g.layout, grid, stream);
     ADN_HIP_CHECK(hipGetLastError());
-    if (p.colsum) ADN_TRY(col_sum(p.colsum, p.colsum_ld, p.tiles_m, g.N, g.colsum, 1, stream));
+    if (p.colsum) {
+        if (g.colsum_batch && g.colsum_batch->n < 8) col_sum_batch_add(*g.colsum_batch, p.colsum, p.colsum_ld, p.tiles_m, g.N, g.colsum);
+        else ADN_TRY(col_sum(p.colsum, p.colsum_ld, p.tiles_m, g.N, g.colsum, 1, stream));
+    }
     if (g.C16 && p.atomic) {                  // split-K result: refresh the bf16 shadow of whole rows
         ADN_CHECK(g.ldc % 8 == 0, ADN_ERR_INVALID, "gemm: bf16 shadow of C needs ldc % 8 == 0");
         ADN_TRY(to_bf16(g.C, g.C16, (size_t)g.M * g.ldc, stream));

@@ -425,8 +425,8 @@ size_t carve(adn_model* m, char* base, int B, int T, bool host_inputs) {
             if (st.cfg.n_enc > 1) {
                 st.pingA = take_shadowed(m, cv, N * w);
                 st.pingB = take_shadowed(m, cv, N * w);
-                st.colsum_ws_floats = (size_t)cdiv((int)N, 64) * w;
-                st.colsum_ws = cv.take<float>(st.colsum_ws_floats);
+                st.colsum_ws_floats = (size_t)cdiv((int)N, 64) * w;      // per layer: the reductions are batched
+                st.colsum_ws = cv.take<float>(st.colsum_ws_floats * st.cfg.n_enc);
             }
         }
         if (m->cfg.agg_dropout_p > 0.f) st.out_drop = take_shadowed(m, cv, N * ldh);
@@ -1061,6 +1061,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         if (!dE16) ADN_TRY(refresh(m, st.dE, (size_t)N * ldE));
         float* dZ = st.dE; int lddz = ldE;
         int bias_done = 0;
+        ColSumBatch bias_sums;                 // bf16 mode: every bias reduction of the stream in ONE launch at the end
         for (int l = L - 1; l >= 0; --l) {
             const int out_w = st.cfg.enc_units[l], in_w = st.enc_in[l];
             const float* a_prev = l > 0 ? st.act[l - 1] : st.x;
@@ -1069,7 +1070,10 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             gw.layout = GEMM_TN; gw.M = in_w; gw.N = out_w; gw.K = N; gw.A = a_prev; gw.lda = ld_prev;
             gw.B = dZ; gw.ldb = lddz; gw.C = m->G(st.encW[l]); gw.ldc = ld_of(out_w); gw.accumulate = 1;
             ADN_TRY(mgemm(m, gw));
-            if (!bias_done) ADN_TRY(col_sum(dZ, lddz, N, out_w, m->G(st.encb[l]), 1, m->stream));
+            if (!bias_done) {
+                if (m->bf16() && dZ == st.dE) col_sum_batch_add(bias_sums, dZ, lddz, (int)N, out_w, m->G(st.encb[l]));   // (dE is not reused)
+                else ADN_TRY(col_sum(dZ, lddz, N, out_w, m->G(st.encb[l]), 1, m->stream));
+            }
             bias_done = 0;
             if (l > 0) {
                 float* dst = (dZ == st.pingA) ? st.pingB : st.pingA;
@@ -1078,7 +1082,8 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
                 gx.B = m->P(st.encW[l]); gx.ldb = ld_of(out_w); gx.C = dst; gx.ldc = st.ping_ld;
                 gx.Y = st.act[l - 1]; gx.ldy = ld_of(in_w); gx.act_grad = st.cfg.enc_act[l - 1];
                 gx.colsum = m->G(st.encb[l - 1]); gx.colsum_done = &bias_done;     // db_{l-1} rides on this GEMM
-                gx.colsum_ws = st.colsum_ws; gx.colsum_ws_floats = st.colsum_ws_floats;
+                gx.colsum_ws = st.colsum_ws + (size_t)l * st.colsum_ws_floats; gx.colsum_ws_floats = st.colsum_ws_floats;
+                gx.colsum_batch = &bias_sums;
                 ADN_TRY(mgemm(m, gx, /*lean=*/true));
                 if (!bias_done && shadows_on(m) && !m->keep_fp32 && in_w % 4 == 0 && m->shadow_of(dst)) {
                     // fp32 dZ was skipped but the fused column sum did not run: cannot happen for in_w % 4 == 0
@@ -1087,6 +1092,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
                 dZ = dst; lddz = st.ping_ld;
             }
         }
+        ADN_TRY(col_sum_batch(bias_sums, m->stream));
         ADN_TRY(bucket_ready(1 + si));        // every gradient of this stream is final
     }
     ADN_TRY(join_streams(m));
