@@ -212,6 +212,9 @@ int lstm_pack_whid_t(const float* W, void* out, int H, hipStream_t s);
 bool lstm_persistent_supported(int H);
 size_t lstm_frag_elems(int H);
 int lstm_pack_frags(const float* W, void* fwd, void* bwd, int H, hipStream_t s);
+// the same for n <= 8 LSTMs in one launch
+int lstm_pack_frags_batch(int n, const float* const* W, void* const* fwd, void* const* bwd, int H, hipStream_t s);
+int repack_rows_bf16(int n, const float* const* in, void* const* out, int nblk, int rows, int rows_pad, int ld, hipStream_t s);
 int lstm_forward_persistent(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
 int lstm_backward_persistent(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s,
                              bool* sums_done = nullptr);

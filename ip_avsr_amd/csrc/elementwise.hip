@@ -268,6 +268,33 @@ int col_sum_batch(ColSumBatch& b, hipStream_t s) {
     return ADN_OK;
 }
 
+// bf16 copies of up to 4 weight matrices [nblk * rows][ld] with every block of `rows` rows re-spaced to `rows_pad` rows
+// (the K-padding of the concatenated-input GEMM); one launch, pointers by value
+struct RepackArgs { const float* in[4]; void* out[4]; };
+__global__ __launch_bounds__(256) void repack_rows_bf16_kernel(RepackArgs a, int nblk, int rows, int rows_pad, int ld) {
+    const float* in = a.in[blockIdx.y];
+    __bf16* out = reinterpret_cast<__bf16*>(a.out[blockIdx.y]);
+    const int ld4 = ld / 4;
+    const int64_t total = (int64_t)nblk * rows * ld4;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % ld4), r = (int)(e / ld4), j = r / rows, k = r % rows;
+        const float4 v = reinterpret_cast<const float4*>(in)[(size_t)r * ld4 + c];
+        __bf16 o[4] = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        *reinterpret_cast<uint2*>(out + ((size_t)(j * rows_pad + k) * ld + 4 * c)) = *reinterpret_cast<const uint2*>(o);
+    }
+}
+
+int repack_rows_bf16(int n, const float* const* in, void* const* out, int nblk, int rows, int rows_pad, int ld, hipStream_t s) {
+    ADN_CHECK(n >= 1 && n <= 4 && ld % 4 == 0 && rows_pad >= rows, ADN_ERR_INVALID, "repack_rows_bf16: bad shape");
+    RepackArgs a{};
+    for (int j = 0; j < n; ++j) { a.in[j] = in[j]; a.out[j] = out[j]; }
+    const int64_t total = (int64_t)nblk * rows * (ld / 4);
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, 2048));
+    hipLaunchKernelGGL(repack_rows_bf16_kernel, dim3(grid, n), dim3(256), 0, s, a, nblk, rows, rows_pad, ld);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
 // out[r][j * cols + c] = in_j[r][c]  (bf16; cols a multiple of 8): the materialised concat of up to 4 matrices
 struct ConcatArgs { const void* in[4]; };
 __global__ __launch_bounds__(256) void concat_cols_bf16_kernel(ConcatArgs a, int n, int ld_in, uint4* __restrict__ out, int ld_out,
@@ -650,8 +677,15 @@ int softmax_loss(const float* z, int ldz, int B, int T, int C, const uint8_t* ma
 __global__ __launch_bounds__(256) void reduce_loss_kernel(const float* __restrict__ v, int n,
                                                           const float* __restrict__ total, float* __restrict__ out) {
     __shared__ float part[256];
-    float acc = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) acc += v[i];
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // 8 independent loads in flight per lane; fixed order
+    for (int base = threadIdx.x; base < n; base += 256 * 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = base + 256 * k;
+            if (i < n) a[k] += v[i];
+        }
+    }
+    const float acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     part[threadIdx.x] = acc;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {

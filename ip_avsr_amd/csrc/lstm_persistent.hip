@@ -322,8 +322,11 @@ __global__ __launch_bounds__(512) void lstm_bwd_persistent_kernel(const LstmLaun
 //   fwd: [UW*8/16 unit tiles][4 gates][UW*8/32 k-steps][64 lanes][8]   value = W[k][4*unit + gate], unit = 16*tile + (lane&15)
 //   bwd: [UW*8/16 unit tiles][4*UW*8/32 k-steps][64 lanes][8]     value = W[unit][k], unit = 16*tile + (lane&15)
 // with k = 32*step + 8*(lane>>4) + j; zero outside the matrix.
-__global__ __launch_bounds__(256) void pack_frags_kernel(const float* __restrict__ W, __bf16* __restrict__ fwd,
-                                                         __bf16* __restrict__ bwd, int H, int ldg, int UW) {
+struct PackFragArgs { const float* W[8]; void* fwd[8]; void* bwd[8]; };
+__global__ __launch_bounds__(256) void pack_frags_kernel(const PackFragArgs a, int H, int ldg, int UW) {
+    const float* __restrict__ W = a.W[blockIdx.y];
+    __bf16* __restrict__ fwd = reinterpret_cast<__bf16*>(a.fwd[blockIdx.y]);
+    __bf16* __restrict__ bwd = reinterpret_cast<__bf16*>(a.bwd[blockIdx.y]);
     const int HP = UW * kPWaves, GP = 4 * HP;        // padded H and 4H
     const int total = GP * HP;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
@@ -345,12 +348,18 @@ __global__ __launch_bounds__(256) void pack_frags_kernel(const float* __restrict
 
 size_t lstm_frag_elems(int H) { const int UW = H <= 256 ? 32 : 64; return (size_t)4 * UW * kPWaves * UW * kPWaves; }
 
-int lstm_pack_frags(const float* W, void* fwd, void* bwd, int H, hipStream_t s) {
+int lstm_pack_frags_batch(int n, const float* const* W, void* const* fwd, void* const* bwd, int H, hipStream_t s) {
+    ADN_CHECK(n >= 1 && n <= 8, ADN_ERR_INVALID, "lstm_pack_frags_batch: 1..8 matrices per launch");
     const int UW = H <= 256 ? 32 : 64;
-    hipLaunchKernelGGL(pack_frags_kernel, dim3(1024), dim3(256), 0, s, W, reinterpret_cast<__bf16*>(fwd),
-                       reinterpret_cast<__bf16*>(bwd), H, ld_of(4 * H), UW);
+    PackFragArgs a{};
+    for (int k = 0; k < n; ++k) { a.W[k] = W[k]; a.fwd[k] = fwd[k]; a.bwd[k] = bwd[k]; }
+    hipLaunchKernelGGL(pack_frags_kernel, dim3(1024, n), dim3(256), 0, s, a, H, ld_of(4 * H), UW);
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
+}
+
+int lstm_pack_frags(const float* W, void* fwd, void* bwd, int H, hipStream_t s) {
+    return lstm_pack_frags_batch(1, &W, &fwd, &bwd, H, s);
 }
 
 bool lstm_persistent_supported(int H) { return H <= 512 && !getenv("ADN_LSTM_STEPWISE"); }

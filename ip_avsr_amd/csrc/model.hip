@@ -577,6 +577,7 @@ int refresh_params(adn_model* m) {
     m->packed_for_persistent = persistent;
     if (!m->params16) ADN_HIP_CHECK(hipMalloc((void**)&m->params16, m->flat_floats * 2));
     ADN_TRY(to_bf16(m->flat[ADN_BUF_PARAM], m->params16, m->flat_floats, m->stream));
+    std::vector<const float*> fw; std::vector<void*> ff, fb;       // fragment images to (re)build
     auto pack = [&](LstmParams& lp) -> int {
         if (!lp.whid16t) {           // + tail: the persistent kernel reads whole 32-k steps past a short last row
             const size_t bytes = ((size_t)m->ldg * lstm_ldk(m->H) + 1024) * 2;
@@ -589,24 +590,29 @@ int refresh_params(adn_model* m) {
                 ADN_HIP_CHECK(hipMalloc((void**)&lp.wfrag_fwd, lstm_frag_elems(m->H) * 2));
                 ADN_HIP_CHECK(hipMalloc((void**)&lp.wfrag_bwd, lstm_frag_elems(m->H) * 2));
             }
-            ADN_TRY(lstm_pack_frags(m->P(lp.W_hid), lp.wfrag_fwd, lp.wfrag_bwd, m->H, m->stream));
+            fw.push_back(m->P(lp.W_hid)); ff.push_back(lp.wfrag_fwd); fb.push_back(lp.wfrag_bwd);
             if (m->H <= 256) return ADN_OK;
         }
         return lstm_pack_whid_t(m->P(lp.W_hid), lp.whid16t, m->H, m->stream);
     };
     for (auto& st : m->st) for (auto& lp : st.lstm) ADN_TRY(pack(lp));
     for (auto& lp : m->agg) ADN_TRY(pack(lp));
+    for (size_t k0 = 0; k0 < fw.size(); k0 += 8)                 // every fragment image in one launch (per 8 LSTMs)
+        ADN_TRY(lstm_pack_frags_batch((int)std::min<size_t>(8, fw.size() - k0), fw.data() + k0, ff.data() + k0, fb.data() + k0,
+                                      m->H, m->stream));
     if (m->cfg.fusion == ADN_FUSE_CONCAT && m->S > 1) {
+        const size_t blk = (size_t)m->ldh * m->ldg;              // elements of one padded input block
+        std::vector<const float*> win; std::vector<void*> wout;
         for (auto& lp : m->agg) {
-            const size_t blk = (size_t)m->ldh * m->ldg;          // elements of one padded input block
             if (!lp.wcat16) {
                 ADN_HIP_CHECK(hipMalloc((void**)&lp.wcat16, (size_t)m->S * blk * 2));
                 ADN_HIP_CHECK(hipMemsetAsync(lp.wcat16, 0, (size_t)m->S * blk * 2, m->stream));
             }
-            for (int j = 0; j < m->S; ++j)
-                ADN_TRY(to_bf16(m->P(lp.W_in) + (size_t)j * m->H * m->ldg, lp.wcat16 + (size_t)j * blk * 2,
-                                (size_t)m->H * m->ldg, m->stream));
+            win.push_back(m->P(lp.W_in)); wout.push_back(lp.wcat16);
         }
+        for (size_t k0 = 0; k0 < win.size(); k0 += 4)            // W_in [S*H][ldg] -> bf16 [S][ldh][ldg], all LSTMs at once
+            ADN_TRY(repack_rows_bf16((int)std::min<size_t>(4, win.size() - k0), win.data() + k0, wout.data() + k0, m->S, m->H,
+                                     m->ldh, m->ldg, m->stream));
     }
     ADN_TRY(refresh_transposed(m));
     m->params16_dirty = false;
