@@ -107,13 +107,13 @@ int gemm(const GemmArgs& g, hipStream_t stream);
 int to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 // out[c * ldT + r] = bf16(W[r * ld + c]) for r < rows, c < cols (LDS-tiled transpose)
 int transpose_to_bf16(const float* W, int rows, int cols, int ld, void* out, int ldT, hipStream_t s);
-// the same for a table of matrices in ONE launch (items: device array; block_end[k] = running total of 32x32 tiles)
 // several column sums in one launch (out[c] += sum_r in[r][c]); items by value in the kernel arguments
 struct ColSumItem { const float* in; float* out; int ld, rows, cols, ctiles, splits, rps, block_end; };
 struct ColSumBatch { ColSumItem it[8]; int n = 0; };
 void col_sum_batch_add(ColSumBatch& b, const float* in, int ld, int rows, int cols, float* out);
 int col_sum_batch(ColSumBatch& b, hipStream_t s);          // launches (if any item is pending) and clears the batch
 
+// the same for a table of matrices in ONE launch (items: device array; block_end[k] = running total of 32x32 tiles)
 struct TransposeItem { const float* W; void* out; int rows, cols, ld, ldT, block_end; };
 int transpose_to_bf16_batch(const TransposeItem* dev_items, int n, int total_blocks, hipStream_t s);
 
@@ -157,8 +157,9 @@ int softmax_loss(const float* z, int ldz, int B, int T, int C, const uint8_t* ma
                  const float* total, float* probs_bt, float* row_loss, float* dz, int lddz, hipStream_t s);
 // out[0] = (sum_i v[i]) / total[0], fixed summation order
 int reduce_loss(const float* v, int n, const float* total, float* out, hipStream_t s);
+// p16: optional bf16 shadow of the parameters, written with the update
 int adam_update(float* p, const float* g, float* m, float* v, int64_t n, float a_t, float beta1,
-                float beta2, float eps, hipStream_t s);
+                float beta2, float eps, hipStream_t s, void* p16 = nullptr);
 // lasagne.updates.sgd (momentum == 0) / momentum / nesterov_momentum; adadelta
 int sgd_update(float* p, const float* g, float* vel, int64_t n, float lr, float momentum, int nesterov, hipStream_t s);
 int adadelta_update(float* p, const float* g, float* accu, float* delta, int64_t n, float lr, float rho, float eps, hipStream_t s);

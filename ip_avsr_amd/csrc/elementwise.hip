@@ -710,9 +710,10 @@ __global__ __launch_bounds__(256) void reduce_loss_kernel(const float* __restric
     float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // 8 independent loads in flight per lane; fixed order
     for (int base = threadIdx.x; base < n; base += 256 * 8) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 8; ++k) {                            // clamped address + select: the loads stay unconditional
             const int i = base + 256 * k;
-            if (i < n) a[k] += v[i];
+            const float x = v[min(i, n - 1)];
+            a[k] += i < n ? x : 0.f;
         }
     }
     const float acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
@@ -737,7 +738,8 @@ int reduce_loss(const float* v, int n, const float* total, float* out, hipStream
 // =========================================================================================
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n4,
-                                                   int64_t n, float a_t, float b1, float b2, float eps) {
+                                                   int64_t n, float a_t, float b1, float b2, float eps,
+                                                   __bf16* __restrict__ p16) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         float4 pp = reinterpret_cast<float4*>(p)[i];
         const float4 gg = reinterpret_cast<const float4*>(g)[i];
@@ -752,6 +754,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         reinterpret_cast<float4*>(p)[i] = pp;
         reinterpret_cast<float4*>(m)[i] = mm;
         reinterpret_cast<float4*>(v)[i] = vv;
+        if (p16) {                                               // the bf16 shadow the next step's GEMMs read
+            __bf16 o[4] = {(__bf16)pp.x, (__bf16)pp.y, (__bf16)pp.z, (__bf16)pp.w};
+            reinterpret_cast<uint2*>(p16)[i] = *reinterpret_cast<const uint2*>(o);
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) {      // tail (n not a multiple of 4)
         const int64_t i = n4 * 4 + threadIdx.x;
@@ -759,17 +765,19 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         const float mi = b1 * m[i] + (1.f - b1) * gi;
         const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
         m[i] = mi; v[i] = vi;
-        p[i] = p[i] - a_t * mi / (sqrtf(vi) + eps);
+        const float pi = p[i] - a_t * mi / (sqrtf(vi) + eps);
+        p[i] = pi;
+        if (p16) p16[i] = (__bf16)pi;
     }
 }
 
 int adam_update(float* p, const float* g, float* m, float* v, int64_t n, float a_t, float beta1, float beta2,
-                float eps, hipStream_t s) {
+                float eps, hipStream_t s, void* p16) {
     if (n <= 0) return ADN_OK;
     const int64_t n4 = n / 4;
     ProfScope prof(PROF_ADAM, 0.0, 7.0 * 4.0 * (double)n, s);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(std::max<int64_t>(n4, 1))), dim3(256), 0, s, p, g, m, v, n4, n, a_t,
-                       beta1, beta2, eps);
+                       beta1, beta2, eps, reinterpret_cast<__bf16*>(p16));
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }

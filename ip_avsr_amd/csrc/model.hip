@@ -202,6 +202,8 @@ struct adn_model {
     std::vector<const float*> fused_in;     // what the aggregation layer read in the last forward pass (after dropout)
     char* params16 = nullptr;
     bool params16_dirty = true;
+    bool params16_values_fresh = false;   // Adam wrote the bf16 parameter shadow itself; only the derived images are stale
+    void mark_params_dirty() { params16_dirty = true; params16_values_fresh = false; }
     // transposed bf16 copies of the weights that input-gradient GEMMs read as "B given [N][K]": with W^T [K][N]
     // at hand the same product runs through the faster k-strided-B kernel (measured 1.2-1.4x)
     struct TransW { const float* key; char* buf; int ldT; };
@@ -576,7 +578,8 @@ int refresh_params(adn_model* m) {
     if (!m->params16_dirty) return ADN_OK;
     m->packed_for_persistent = persistent;
     if (!m->params16) ADN_HIP_CHECK(hipMalloc((void**)&m->params16, m->flat_floats * 2));
-    ADN_TRY(to_bf16(m->flat[ADN_BUF_PARAM], m->params16, m->flat_floats, m->stream));
+    if (!m->params16_values_fresh) ADN_TRY(to_bf16(m->flat[ADN_BUF_PARAM], m->params16, m->flat_floats, m->stream));
+    m->params16_values_fresh = false;
     std::vector<const float*> fw; std::vector<void*> ff, fb;       // fragment images to (re)build
     auto pack = [&](LstmParams& lp) -> int {
         if (!lp.whid16t) {           // + tail: the persistent kernel reads whole 32-k steps past a short last row
@@ -1171,7 +1174,7 @@ int tensor_io(adn_model* m, int buffer, int index, float* host, bool write) {
         if (write) {
             ADN_HIP_CHECK(hipMemcpy2D(base, (size_t)p.ld * 4, host, (size_t)cols * 4, (size_t)cols * 4, rows,
                                       hipMemcpyHostToDevice));
-            if (buffer == ADN_BUF_PARAM) m->params16_dirty = true;
+            if (buffer == ADN_BUF_PARAM) m->mark_params_dirty();
         }
         else ADN_HIP_CHECK(hipMemcpy2D(host, (size_t)cols * 4, base, (size_t)p.ld * 4, (size_t)cols * 4, rows,
                                        hipMemcpyDeviceToHost));
@@ -1187,7 +1190,7 @@ int tensor_io(adn_model* m, int buffer, int index, float* host, bool write) {
             if (write) phys = host[(size_t)r * cols + c]; else host[(size_t)r * cols + c] = phys;
         }
     if (write) ADN_HIP_CHECK(hipMemcpy(base, tmp.data(), span * 4, hipMemcpyHostToDevice));
-    if (write && buffer == ADN_BUF_PARAM) m->params16_dirty = true;
+    if (write && buffer == ADN_BUF_PARAM) m->mark_params_dirty();
     return ADN_OK;
 }
 
@@ -1286,7 +1289,7 @@ int adn_set_precision(adn_model* m, int precision) {
     ADN_CHECK(precision == ADN_PRECISION_F32 || precision == ADN_PRECISION_BF16, ADN_ERR_INVALID,
               "unsupported precision");
     m->cfg.precision = precision;
-    m->params16_dirty = true;
+    m->mark_params_dirty();
     m->wsB = 0;                       // input staging differs between the modes: re-carve on the next call
     return ADN_OK;
 }
@@ -1317,7 +1320,7 @@ int adn_write_tensor(adn_model* m, int buffer, int index, const float* host_src)
 int adn_flat_buffer(adn_model* m, int buffer, void** device_ptr, size_t* bytes) {
     ADN_CHECK(m && device_ptr && bytes, ADN_ERR_INVALID, "null argument");
     ADN_CHECK(buffer >= 0 && buffer < 4, ADN_ERR_INVALID, "bad buffer id");
-    if (buffer == ADN_BUF_PARAM) m->params16_dirty = true;      // the caller may write through the pointer
+    if (buffer == ADN_BUF_PARAM) m->mark_params_dirty();      // the caller may write through the pointer
     *device_ptr = m->flat[buffer];
     *bytes = (m->flat_floats + kAuxFloats) * sizeof(float);
     return ADN_OK;
@@ -1390,10 +1393,12 @@ int adn_apply_adam(adn_model* m, float learning_rate) {
     m->adam_t += 1;
     const float t = (float)m->adam_t;
     const float a_t = learning_rate * sqrtf(1.f - powf(kBeta2, t)) / (1.f - powf(kBeta1, t));
+    void* p16 = shadows_on(m) ? m->params16 : nullptr;          // the update writes the bf16 shadow as well
     ADN_TRY(adam_update(m->flat[ADN_BUF_PARAM], m->flat[ADN_BUF_GRAD], m->flat[ADN_BUF_ADAM_M], m->flat[ADN_BUF_ADAM_V],
-                        (int64_t)m->flat_floats, a_t, kBeta1, kBeta2, kEps, m->stream));
+                        (int64_t)m->flat_floats, a_t, kBeta1, kBeta2, kEps, m->stream, p16));
     m->grads_valid = false;
-    m->params16_dirty = true;
+    m->mark_params_dirty();
+    m->params16_values_fresh = p16 != nullptr;
     return ADN_OK;
 }
 
@@ -1410,7 +1415,7 @@ int adn_apply_sgd(adn_model* m, float learning_rate, float momentum, int nestero
     ADN_TRY(sgd_update(m->flat[ADN_BUF_PARAM], m->flat[ADN_BUF_GRAD], m->flat[ADN_BUF_ADAM_M], (int64_t)m->flat_floats,
                        learning_rate, momentum, nesterov, m->stream));
     m->grads_valid = false;
-    m->params16_dirty = true;
+    m->mark_params_dirty();
     return ADN_OK;
 }
 
@@ -1420,7 +1425,7 @@ int adn_apply_adadelta(adn_model* m, float learning_rate, float rho, float epsil
     ADN_TRY(adadelta_update(m->flat[ADN_BUF_PARAM], m->flat[ADN_BUF_GRAD], m->flat[ADN_BUF_ADAM_M], m->flat[ADN_BUF_ADAM_V],
                             (int64_t)m->flat_floats, learning_rate, rho, epsilon, m->stream));
     m->grads_valid = false;
-    m->params16_dirty = true;
+    m->mark_params_dirty();
     return ADN_OK;
 }
 
@@ -1452,7 +1457,7 @@ int adn_apply_adam_vlr(adn_model* m, const float* lr_by_param, int n) {
                             m->stream));
     }
     m->grads_valid = false;
-    m->params16_dirty = true;
+    m->mark_params_dirty();
     return ADN_OK;
 }
 
