@@ -147,12 +147,21 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
                          % (args.gpus, args.gpus))
+    # ADN_BENCH_BACKEND=gloo: functional check of the N > 1 code path on a box with fewer GPUs than ranks (ranks share
+    # devices; not a measurement, and it needs ADN_LSTM_NO_CLUSTER=1 -- two processes' resident-workgroup LSTM launches
+    # cannot both fit one GPU)
+    backend = os.environ.get("ADN_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     distributed = world > 1
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from ip_avsr_amd.model import AdeNetModel
     from ip_avsr_amd.parallel import DataParallel, wrap_flat_buffer
