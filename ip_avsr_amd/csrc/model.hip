@@ -1033,7 +1033,11 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         if (k < m->bucket_events.size() && m->bucket_events[k]) ADN_HIP_CHECK(hipEventRecord(m->bucket_events[k], m->stream));
         return ADN_OK;
     };
-    ADN_TRY(bucket_ready(0));                 // [fuse | agg | softmax] gradients and the cost share are final
+    // [fuse | agg | softmax] gradients and the cost share are final here, but their bucket is only released BEHIND the
+    // stream LSTMs' backward launch: that launch needs (nearly) every CU resident at once, and an all-reduce kernel
+    // that starts beside it could leave both half-scheduled on several GPUs at the same time, each waiting for CUs the
+    // other holds.  Released after it, the transfer still hides under the encoders' backward GEMMs, and no
+    // resident-workgroup launch ever runs next to a collective.
     // stream LSTMs
     bool stream_sums_done = false;
     {
@@ -1044,6 +1048,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
                 steps.back().ld_dhs = st.dout_ld;
             }
         ADN_TRY(run_lstm_group(m, steps, B, T, true, &stream_sums_done));
+        ADN_TRY(bucket_ready(0));
     }
     ADN_TRY(fork_streams(m));                 // below the stream LSTMs the S streams back-propagate independently
     for (size_t si = 0; si < m->st.size(); ++si) {
