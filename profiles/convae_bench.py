@@ -17,7 +17,7 @@ import torch
 from ip_avsr_amd.convae import ConvAE
 from oracle import convae_oracle as CO
 
-B, HW = 128, (30, 40)
+HW = (30, 40)
 g = CO.geometry(HW)
 F1, F2, F3 = CO.FILTERS
 
@@ -34,34 +34,37 @@ def step_flops(B):
 
 
 rng = np.random.RandomState(0)
-x = torch.as_tensor(np.tanh(rng.normal(size=(B, HW[0] * HW[1]))).astype(np.float32), device="cuda")
-fwd_fl, step_fl = step_flops(B)
-print("batch %d frames of %dx%d; GEMM flops per step %.1f G (forward %.1f G = %.1f MFLOP/frame)" %
-      (B, HW[0], HW[1], step_fl / 1e9, fwd_fl / 1e9, fwd_fl / B / 1e6))
-for prec, peak in (("f32", 157.3), ("bf16", 2500.0)):
-    m = ConvAE(HW, 500, 50, prec)
-    m.init_params(rng)
-    for _ in range(3):
-        m.train(x, want_loss=False)
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(20):
-        m.train(x, want_loss=False)
-    b.record()
-    torch.cuda.synchronize()
-    ms = a.elapsed_time(b) / 20
-    for _ in range(3):
-        m.encode(x)
-    a.record()
-    for _ in range(20):
-        m.encode(x)
-    b.record()
-    torch.cuda.synchronize()
-    ems = a.elapsed_time(b) / 20
-    print("%-5s train step %.3f ms = %.0f frames/s, %.1f TFLOP/s (%.1f %% of the %s MFMA peak); encoder alone %.3f ms = %.0f frames/s"
-          % (prec, ms, B / ms * 1e3, step_fl / ms / 1e9, 100 * step_fl / ms / 1e9 / peak, prec, ems, B / ems * 1e3))
-    m.close()
+for B in (128, 1024, 4096):                # 128 = the reference's batch; the larger ones show where the kernels saturate
+    x = torch.as_tensor(np.tanh(rng.normal(size=(B, HW[0] * HW[1]))).astype(np.float32), device="cuda")
+    fwd_fl, step_fl = step_flops(B)
+    print("batch %d frames of %dx%d; GEMM flops per step %.1f G (forward %.1f G = %.1f MFLOP/frame)" %
+          (B, HW[0], HW[1], step_fl / 1e9, fwd_fl / 1e9, fwd_fl / B / 1e6))
+    for prec, peak in (("f32", 157.3), ("bf16", 2500.0)):
+        m = ConvAE(HW, 500, 50, prec)
+        m.init_params(rng)
+        for _ in range(3):
+            m.train(x, want_loss=False)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            m.train(x, want_loss=False)
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / 10
+        for _ in range(3):
+            m.encode(x)
+        a.record()
+        for _ in range(10):
+            m.encode(x)
+        b.record()
+        torch.cuda.synchronize()
+        ems = a.elapsed_time(b) / 10
+        print("  %-5s train step %.3f ms = %.0f frames/s, %.1f TFLOP/s (%.1f %% of the %s MFMA peak); encoder alone %.3f ms = %.0f frames/s"
+              % (prec, ms, B / ms * 1e3, step_fl / ms / 1e9, 100 * step_fl / ms / 1e9 / peak, prec, ems, B / ems * 1e3))
+        m.close()
+    del x
+x = torch.as_tensor(np.tanh(rng.normal(size=(128, HW[0] * HW[1]))).astype(np.float32), device="cuda")
 p = CO.init_params(np.random.default_rng(0), np.float32)
 xs = x.cpu().numpy()[:16]
 CO.loss_and_grads(p, xs)
