@@ -702,3 +702,27 @@ def test_concat_as_one_gemm_equals_blockwise_products(torch_cuda, lib, monkeypat
             continue
         cos = a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)
         assert cos > 0.999 and abs(np.linalg.norm(a) / np.linalg.norm(b) - 1) < 0.02, (k, cos)
+
+
+def test_bf16_parameter_shadow_written_by_adam_equals_a_fresh_conversion(torch_cuda, lib):
+    """bf16 mode: the Adam kernel writes the bf16 copy of the parameters that the next step's GEMMs read (and the
+    derived images -- transposed weights, LSTM fragments, concatenated W_in -- are rebuilt from the fp32 values).  A
+    model whose parameters are written back through the API after every update (which forces the separate conversion)
+    must follow the same trajectory."""
+    from ip_avsr_amd.model import AdeNetModel
+    spec = dict(small_specs()["3stream_concat"], precision="bf16")
+    B, T, theta = 9, 10, 2
+    p, inputs, y, mask = make_case(spec, B, T, seed=321)
+    a, b = AdeNetModel(spec), AdeNetModel(spec)
+    a.set_params_dict(p); b.set_params_dict(p)
+    la, lb = [], []
+    for step in range(4):
+        la.append(float(a.train_step(inputs, y, mask, theta, 1e-2)))
+        lb.append(float(b.train_step(inputs, y, mask, theta, 1e-2)))
+        b.set_params_dict(b.get_params_dict())                 # marks every derived copy stale, the shadow included
+    assert la[-1] < la[0]                                       # it trains
+    np.testing.assert_allclose(la, lb, rtol=2e-4)
+    pa, pb = a.get_params_dict(), b.get_params_dict()
+    for k in pa:
+        assert np.abs(pa[k] - pb[k]).max() <= 2e-3 * max(np.abs(pb[k]).max(), 1e-3), k
+    a.close(); b.close()
