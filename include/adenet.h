@@ -150,9 +150,11 @@ int64_t adn_total_param_count(const adn_model* m); /* logical elements (17 999 6
 int adn_flat_buffer(adn_model* m, int buffer /*adn_buffer*/, void** device_ptr, size_t* bytes);
 
 /* Gradient buckets for overlapping the data-parallel all-reduce with back-propagation (new; the reference is
- * single-device).  Bucket 0 = [fusion | aggregation LSTMs | classifier | cost tail], final before the stream
- * LSTMs are back-propagated; bucket 1+s = stream s (encoder + LSTM), final when that stream's encoder backward
- * is enqueued.  adn_compute_grads records the caller's HIP events (one per bucket, on the model's stream) at
+ * single-device).  Listed in the order they become final: bucket 0 = [fusion | aggregation LSTMs | classifier |
+ * cost tail] (released behind the stream LSTMs' backward launch); then for every stream s its [encoder layers >= 1 |
+ * LSTM] range, final before the stream's last weight-gradient GEMM, and its [encoder layer 0] range, final when the
+ * stream's backward is enqueued (one range per stream when it has fewer than two encoder layers).
+ * adn_compute_grads records the caller's HIP events (one per bucket, on the model's stream) at
  * those points; a caller makes its communication stream wait on event k and reduces range k while the rest of
  * the backward pass still runs.  Ranges are in floats inside adn_flat_buffer(ADN_BUF_GRAD). */
 int adn_grad_buckets(const adn_model* m, int max_buckets, int64_t* begin_floats, int64_t* end_floats, int* n_out);

@@ -1058,7 +1058,12 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         const float* in[1] = {st.feat}; const int ld[1] = {ldf};
         for (size_t k = 0; k < st.lstm.size(); ++k)
             ADN_TRY(lstm_param_grads(m, st.lstm[k], st.lw[k], in, ld, 1, st.feat_dim, B, T, stream_sums_done));
-        if (st.cfg.n_enc == 0) { ADN_TRY(bucket_ready(1 + si)); continue; }   // nothing trainable below the LSTM
+        // this stream's buckets: `b_rest` (encoder layers >= 1 + LSTM; the whole stream when it has < 2 encoder layers),
+        // then `b_first` (encoder layer 0) where it exists
+        size_t b_rest = 1;
+        for (size_t q = 0; q < si; ++q) b_rest += m->st[q].cfg.n_enc >= 2 ? 2 : 1;
+        const bool split_first = st.cfg.n_enc >= 2;
+        if (st.cfg.n_enc == 0) { ADN_TRY(bucket_ready(b_rest)); continue; }   // nothing trainable below the LSTM
         for (size_t k = 0; k < st.lstm.size(); ++k)
             ADN_TRY(lstm_input_grad(m, st.lstm[k], st.lw[k], 0, st.feat_dim, st.dfeat, ldf, N, k > 0));
         if (m->stochastic && st.cfg.dropout_p > 0.f)
@@ -1083,6 +1088,10 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             GemmArgs gw;
             gw.layout = GEMM_TN; gw.M = in_w; gw.N = out_w; gw.K = N; gw.A = a_prev; gw.lda = ld_prev;
             gw.B = dZ; gw.ldb = lddz; gw.C = m->G(st.encW[l]); gw.ldc = ld_of(out_w); gw.accumulate = 1;
+            if (l == 0 && split_first) {           // everything but layer 0's weight gradient is final: release that bucket
+                ADN_TRY(col_sum_batch(bias_sums, m->stream));                  // (all bias sums are queued by now)
+                ADN_TRY(bucket_ready(b_rest));
+            }
             ADN_TRY(mgemm(m, gw));
             if (!bias_done) {
                 if (m->bf16() && dZ == st.dE) col_sum_batch_add(bias_sums, dZ, lddz, (int)N, out_w, m->G(st.encb[l]));   // (dE is not reused)
@@ -1107,7 +1116,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             }
         }
         ADN_TRY(col_sum_batch(bias_sums, m->stream));
-        ADN_TRY(bucket_ready(1 + si));        // every gradient of this stream is final
+        ADN_TRY(bucket_ready(split_first ? b_rest + 1 : b_rest));        // every gradient of this stream is final
     }
     ADN_TRY(join_streams(m));
     m->grads_valid = true;
@@ -1331,22 +1340,39 @@ int adn_flat_buffer(adn_model* m, int buffer, void** device_ptr, size_t* bytes) 
     return ADN_OK;
 }
 
+// bucket list in the order the ranges become final (the order a communication stream should reduce them in):
+//   [tail]  then per stream  [layers >= 1 of the encoder + LSTM]  and  [encoder layer 0]  (the latter only when the
+//   stream has at least two encoder layers -- its weight gradient is the last GEMM of the stream's backward pass)
+static void bucket_ranges(const adn_model* m, std::vector<std::pair<size_t, size_t>>& out) {
+    out.clear();
+    out.emplace_back(m->tail_begin, m->flat_floats + kAuxFloats);
+    for (int s = 0; s < m->S; ++s) {
+        const StreamState& st = m->st[s];
+        const size_t begin = st.param_begin, end = s + 1 < m->S ? m->st[s + 1].param_begin : m->tail_begin;
+        if (st.cfg.n_enc >= 2) {
+            out.emplace_back(st.encW[1], end);
+            out.emplace_back(begin, st.encW[1]);
+        } else {
+            out.emplace_back(begin, end);
+        }
+    }
+}
+
 int adn_grad_buckets(const adn_model* m, int max_buckets, int64_t* begin_floats, int64_t* end_floats, int* n_out) {
     ADN_CHECK(m && begin_floats && end_floats && n_out, ADN_ERR_INVALID, "null argument");
-    const int n = 1 + m->S;
-    ADN_CHECK(max_buckets >= n, ADN_ERR_INVALID, "bucket arrays too small");
-    begin_floats[0] = (int64_t)m->tail_begin; end_floats[0] = (int64_t)(m->flat_floats + kAuxFloats);
-    for (int s = 0; s < m->S; ++s) {
-        begin_floats[1 + s] = (int64_t)m->st[s].param_begin;
-        end_floats[1 + s] = (int64_t)(s + 1 < m->S ? m->st[s + 1].param_begin : m->tail_begin);
-    }
-    *n_out = n;
+    std::vector<std::pair<size_t, size_t>> r;
+    bucket_ranges(m, r);
+    ADN_CHECK(max_buckets >= (int)r.size(), ADN_ERR_INVALID, "bucket arrays too small");
+    for (size_t k = 0; k < r.size(); ++k) { begin_floats[k] = (int64_t)r[k].first; end_floats[k] = (int64_t)r[k].second; }
+    *n_out = (int)r.size();
     return ADN_OK;
 }
 
 int adn_set_bucket_events(adn_model* m, void* const* hip_events, int n) {
     ADN_CHECK(m, ADN_ERR_INVALID, "null model");
-    ADN_CHECK(n == 0 || (hip_events && n == 1 + m->S), ADN_ERR_INVALID, "expected one event per gradient bucket");
+    std::vector<std::pair<size_t, size_t>> r;
+    bucket_ranges(m, r);
+    ADN_CHECK(n == 0 || (hip_events && n == (int)r.size()), ADN_ERR_INVALID, "expected one event per gradient bucket");
     m->bucket_events.clear();
     for (int k = 0; k < n; ++k) m->bucket_events.push_back(static_cast<hipEvent_t>(hip_events[k]));
     return ADN_OK;

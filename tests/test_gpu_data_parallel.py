@@ -46,7 +46,7 @@ def test_single_rank_nccl_dataparallel_equals_plain_step():
         ptr, nbytes = dpm.flat_buffer(_lib.BUF_GRAD)
         assert g.data_ptr() == ptr and g.numel() * 4 == nbytes and g.dtype == torch.float32
         dp = DataParallel(dpm)
-        assert dp.overlap and len(dp.buckets) == 1 + len(spec["streams"])
+        assert dp.overlap and len(dp.buckets) == 1 + sum(2 if len(s["enc_shapes"]) >= 2 else 1 for s in spec["streams"])
         # the buckets tile the whole flat buffer (incl. the cost tail) without overlap
         cover = sorted(dp.buckets)
         assert cover[0][0] == 0 and cover[-1][1] == g.numel()
