@@ -726,3 +726,38 @@ def test_bf16_parameter_shadow_written_by_adam_equals_a_fresh_conversion(torch_c
     for k in pa:
         assert np.abs(pa[k] - pb[k]).max() <= 2e-3 * max(np.abs(pb[k]).max(), 1e-3), k
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (1, 7), (33, 1), (33, 2), (64, 5)])
+def test_weight_stationary_lstm_edge_shapes(torch_cuda, lib, monkeypatch, B, T):
+    """bf16 mode, the resident-weight LSTM kernels at the edges: one utterance, one time step (the forward loop never
+    polls, the backward epilogue does), 33 utterances = two groups with one row in the second, utterances of one valid
+    frame.  Forward and gradients against the one-workgroup kernels (same arithmetic) and the oracle's probabilities."""
+    from ip_avsr_amd.model import AdeNetModel
+    spec = dict(small_specs()["2stream_sum_peep"], precision="bf16")
+    p, inputs, y, mask = make_case(spec, B, T, seed=100 * B + T)
+    mask[:, 1:] = mask[:, 1:] * (np.arange(B)[:, None] % 3 != 0)        # every third utterance has a single valid frame
+    inputs = [x * mask[..., None] for x in inputs]
+    out = {}
+    for mode in ("cluster", "single"):
+        if mode == "single":
+            monkeypatch.setenv("ADN_LSTM_NO_CLUSTER", "1")
+        else:
+            monkeypatch.delenv("ADN_LSTM_NO_CLUSTER", raising=False)
+        m = AdeNetModel(spec)
+        m.set_params_dict(p)
+        probs = m.predict(inputs, mask, 3)
+        loss = m.compute_grads(inputs, y, mask, 3)
+        out[mode] = (probs, loss, m.get_grads_dict())
+        m.close()
+    monkeypatch.delenv("ADN_LSTM_NO_CLUSTER", raising=False)
+    valid = mask[..., None].astype(bool)
+    np.testing.assert_array_equal(out["cluster"][0] * valid, out["single"][0] * valid)
+    assert abs(out["cluster"][1] - out["single"][1]) <= 1e-6 * abs(out["single"][1])
+    for k, g in out["cluster"][2].items():
+        ref = out["single"][2][k]
+        assert np.isfinite(g).all(), k
+        assert np.abs(g - ref).max() <= 5e-3 * max(np.abs(ref).max(), 1e-6), k
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    probs_ref = O.forward(spec, p64, [x.astype(np.float64) for x in inputs], mask, 3)
+    assert np.abs((out["cluster"][0] - probs_ref) * valid).max() <= 3e-2
