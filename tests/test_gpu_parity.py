@@ -761,3 +761,33 @@ def test_weight_stationary_lstm_edge_shapes(torch_cuda, lib, monkeypatch, B, T):
     p64 = {k: v.astype(np.float64) for k, v in p.items()}
     probs_ref = O.forward(spec, p64, [x.astype(np.float64) for x in inputs], mask, 3)
     assert np.abs((out["cluster"][0] - probs_ref) * valid).max() <= 3e-2
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (33, 2)])
+def test_wide_weight_stationary_lstm_edge_shapes(torch_cuda, lib, monkeypatch, B, T):
+    """The 8-workgroup kernels (256 < H <= 512) at the same edges, against the one-workgroup kernel."""
+    from ip_avsr_amd.model import AdeNetModel
+    spec = dict(O.spec_nstream([12, 9], enc_shapes=(14, 6), enc_acts=("rectify", "linear"), lstm_size=260, classes=5,
+                               fusion="sum", peepholes=True), precision="bf16")
+    p, inputs, y, mask = make_case(spec, B, T, seed=7 * B + T, perturb=0.02)
+    out = {}
+    for mode in ("cluster", "single"):
+        monkeypatch.delenv("ADN_LSTM_NO_CLUSTER", raising=False)
+        monkeypatch.delenv("ADN_LSTM_WIDE_PERSISTENT", raising=False)
+        if mode == "single":
+            monkeypatch.setenv("ADN_LSTM_NO_CLUSTER", "1")
+            monkeypatch.setenv("ADN_LSTM_WIDE_PERSISTENT", "1")
+        m = AdeNetModel(spec)
+        m.set_params_dict(p)
+        probs = m.predict(inputs, mask, 2)
+        loss = m.compute_grads(inputs, y, mask, 2)
+        out[mode] = (probs, loss, m.get_grads_dict())
+        m.close()
+    monkeypatch.delenv("ADN_LSTM_NO_CLUSTER", raising=False)
+    monkeypatch.delenv("ADN_LSTM_WIDE_PERSISTENT", raising=False)
+    valid = mask[..., None].astype(bool)
+    np.testing.assert_array_equal(out["cluster"][0] * valid, out["single"][0] * valid)
+    for k, g in out["cluster"][2].items():
+        ref = out["single"][2][k]
+        assert np.isfinite(g).all(), k
+        assert np.abs(g - ref).max() <= 5e-3 * max(np.abs(ref).max(), 1e-6), k
