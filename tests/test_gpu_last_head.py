@@ -219,3 +219,72 @@ def test_zoo_factories_of_the_last_timestep_family(model_cls):
                                                 (None, None, 30), None, (None, None), None, lstm_size=3, output_classes=4)
     assert dr.H == 6 and dr.head == "frames" and dr.predict([x(30)] * 3, mask, 2).shape == (B, T, 4)
     dr.close()
+
+
+def test_more_zoo_factories_of_the_last_timestep_family(model_cls):
+    """modelzoo/adenet_v4.py:48-147 (ONE forward aggregation LSTM), adenet_v5.py:64-186 / adenet_v6.py:64-177 (sum or
+    adaptive sum, summed BLSTM), lstm_classifier_baseline.py:56-82, baseline_end2end.py:64-116 (no deltas): positional
+    signatures, layer names, widths, head; the forward pass against the oracle for the single-LSTM aggregation."""
+    from ip_avsr_amd.modelzoo import adenet_v4, adenet_v5, adenet_v6, lstm_classifier_baseline, baseline_end2end
+
+    class Layer(object):
+        def __init__(self, W, b):
+            self.W, self.b = W, b
+
+    class Net(object):
+        def __init__(self, d, rng):
+            dims = [d, 20, 12, 8, 5]
+            self.layers = [None] + [Layer(rng.normal(0, 0.1, (a, b)).astype(np.float32), np.zeros(b, np.float32))
+                                    for a, b in zip(dims[:-1], dims[1:])]
+
+        def get_all_layers(self):
+            return self.layers
+
+    rng = np.random.RandomState(3)
+    B, T = 5, 7
+    mask = np.ones((B, T), np.uint8); mask[1, 4:] = 0; mask[3, 1:] = 0
+    x = lambda d: (rng.normal(size=(B, T, d)) * mask[..., None]).astype(np.float32)
+    y = np.repeat(rng.randint(0, 4, size=(B, 1)), T, axis=1).astype(np.int32)
+
+    v4, fuse = adenet_v4.create_model(Net(30, rng), (None, None, 30), None, (None, None), None, (None, None, 9), None,
+                                      lstm_size=3, win=None, output_classes=4)
+    names = [p.name for p in v4.params]
+    assert names[0] == "fc1.W" and "lstm_bn.W_in_to_ingate" in names and "lstm_dct.W_hid_to_cell" in names
+    assert "lstm_agg.W_in_to_ingate" in names and not any(n.startswith(("f_lstm_agg", "b_lstm_agg")) for n in names)
+    assert v4.H == 6 and v4.head == "last" and v4.spec["fusion"] == "sum" and v4.spec["agg_dropout"] == 0.5
+    ins = [x(30), x(9)]
+    probs = v4.predict(ins, mask, 2)
+    assert probs.shape == (B, 4)
+    p64 = {k: v.astype(np.float64) for k, v in v4.get_params_dict().items()}
+    ref = O.forward(v4.spec, p64, [a.astype(np.float64) for a in ins], mask, 2)
+    assert np.abs(probs - ref).max() <= 2e-5
+    l_ref, g_ref, _ = O.loss_and_grads(v4.spec, p64, [a.astype(np.float64) for a in ins], y, mask, 2)
+    l = v4.compute_grads(ins, y, mask, 2, deterministic=True)
+    assert abs(l - l_ref) <= 1e-5 * abs(l_ref)
+    check_grads(v4.get_grads_dict(), g_ref, v4.spec)
+    v4.close()
+
+    for use_adascale in (False, True):
+        v5, fuse = adenet_v5.create_model(Net(30, rng), Net(30, rng), (None, None, 30), None, (None, None), None,
+                                          (None, None, 9), None, (None, None, 30), None, 3, None, 4, use_adascale)
+        names = [p.name for p in v5.params]
+        assert v5.H == 6 and v5.head == "last" and v5.spec["fusion"] == ("adasum" if use_adascale else "sum")
+        assert ("adasum1.adacoeff0" in names) == use_adascale and "f_lstm_agg.W_in_to_ingate" in names
+        assert v5.predict([x(30), x(9), x(30)], mask, 2).shape == (B, 4)
+        v5.close()
+    v6, _ = adenet_v6.create_model(Net(30, rng), Net(30, rng), (None, None, 30), None, (None, None), None,
+                                   (None, None, 30), None, 3, None, 4)
+    assert v6.S == 2 and v6.H == 6 and [p.name for p in v6.params][0] == "fc1_raw.W"
+    assert v6.predict([x(30), x(30)], mask, 2).shape == (B, 4)
+    v6.close()
+    lb = lstm_classifier_baseline.create_model((None, None, 9), None, (None, None), None, lstm_size=5, output_classes=3)
+    names = [p.name for p in lb.params]
+    assert names[0].startswith("f_lstm.") and any(n.startswith("b_lstm.") for n in names) and names[-1] == "output.b"
+    assert lb.head == "last" and lb.predict([x(9)], mask, 2).shape == (B, 3)
+    lb.close()
+    e2e = baseline_end2end.create_model(Net(30, rng), (None, None, 30), None, (None, None), None, lstm_size=5, output_classes=3)
+    assert e2e.spec["streams"][0]["delta"] is False and "f_lstm1.W_in_to_ingate" in [p.name for p in e2e.params]
+    w_in = e2e.get_param("f_lstm1.W_in_to_ingate")
+    assert w_in.shape == (5, 5)                                             # the LSTM reads the 5 bottleneck features, no deltas
+    assert e2e.predict([x(30)], mask, 2).shape == (B, 3)
+    e2e.close()
