@@ -26,7 +26,8 @@ import scipy.io as sio
 
 from .. import init as las_init
 from ..custom.nonlinearities import select_nonlinearity
-from ..modelzoo import (adenet_2stream, adenet_3stream, adenet_4stream, adenet_v2_2, deltanet_majority_vote)
+from ..modelzoo import (adenet_2stream, adenet_3stream, adenet_3stream_dropout, adenet_4stream, adenet_v2_2,
+                        deltanet_majority_vote)
 from ..utils.data_structures import circular_list
 from ..utils.datagen import compute_integral_len, gen_lstm_batch_random, gen_seq_batch_from_idx
 from ..utils.io import load_mat_file, read_data_split_file, save_model_params
@@ -143,6 +144,9 @@ def build_network(n_streams, aes, dims, lstm_weights, cfg):
                                                           use_blstm_substream=cfg['use_blstm_substream'], **kw)
         return adenet_v2_2.create_model(aes[0], aes[1], shapes[0], None, ms, None, shapes[1], None, H, None, C, fuse,
                                         **kw)
+    if n_streams == 3 and cfg.get('use_dropout'):      # runners/3stream.py:284-291
+        return adenet_3stream_dropout.create_model(aes[0], aes[1], aes[2], shapes[0], None, shapes[1], None, shapes[2], None,
+                                                   ms, None, H, None, C, fuse, **kw)
     if n_streams == 3:           # runners/3stream.py:293-299
         return adenet_3stream.create_model(aes[0], aes[1], aes[2], shapes[0], None, shapes[1], None, shapes[2], None,
                                            ms, None, H, None, C, fuse, **kw)
@@ -190,8 +194,9 @@ def main(n_streams, argv=None):
     windowsize = config.getint(lc, 'windowsize')
     output_classnames = config.get(lc, 'output_classnames').split(',')
     matlab_target_offset = config.getboolean(lc, 'matlab_target_offset')
-    if config.has_option(lc, 'use_dropout') and config.getboolean(lc, 'use_dropout'):
-        raise NotImplementedError('use_dropout (adenet_3stream_dropout) is not built yet: SURVEY.md §8f-1')
+    cfg['use_dropout'] = config.has_option(lc, 'use_dropout') and config.getboolean(lc, 'use_dropout')
+    if cfg['use_dropout'] and n_streams != 3:
+        raise ValueError('use_dropout selects adenet_3stream_dropout: only the 3-stream runner has it (runners/3stream.py:284-291)')
 
     validation_window = config.getint('training', 'validation_window')
     num_epoch = config.getint('training', 'num_epoch')

@@ -35,7 +35,7 @@ output_classes = 4
 output_classnames = a,b,c,d
 lstm_size = 12
 matlab_target_offset = True
-use_dropout = False
+use_dropout = {dropout}
 use_blstm = True
 
 [training]
@@ -77,14 +77,15 @@ def make_dataset(root, n_streams):
     open(os.path.join(root, "test.txt"), "w").write("8")
 
 
-@pytest.mark.parametrize("n_streams,fusion", [(3, "concat"), (1, "none"), (2, "adasum")])
-def test_runner_end_to_end(tmp_path, n_streams, fusion):
+@pytest.mark.parametrize("n_streams,fusion,dropout", [(3, "concat", False), (1, "none", False), (2, "adasum", False),
+                                                      (3, "sum", True)])
+def test_runner_end_to_end(tmp_path, n_streams, fusion, dropout):
     from ip_avsr_amd.runners import nstream
     from ip_avsr_amd.utils.io import load_model
     root = str(tmp_path)
     make_dataset(root, n_streams)
     ini = "".join(INI.format(k=k, root=root, reorder=(k == 1), diff=(k == 2)) for k in range(1, n_streams + 1))
-    ini += TAIL.format(root=root, fusion=fusion)
+    ini += TAIL.format(root=root, fusion=fusion, dropout=dropout)
     cfg = os.path.join(root, "cfg.ini")
     open(cfg, "w").write(ini)
     res_file, best_file = os.path.join(root, "results.csv"), os.path.join(root, "best.pkl")
@@ -96,6 +97,8 @@ def test_runner_end_to_end(tmp_path, n_streams, fusion):
     assert len(line) == 3 and abs(float(line[1]) - out["best_cr"]) < 1e-9
     values = load_model(best_file)
     net = out["network"]
+    if dropout:                                  # use_dropout picks adenet_3stream_dropout (runners/3stream.py:284-291)
+        assert net.spec["agg_dropout"] == 0.5 and net.H == 24 and all(s["dropout"] == 0.5 for s in net.spec["streams"])
     assert isinstance(values, list) and len(values) == len(net.params)
     for v, p in zip(values, net.params):
         assert v.shape == p.shape and v.dtype == np.float32
