@@ -104,3 +104,33 @@ def test_runner_end_to_end(tmp_path, n_streams, fusion, dropout):
         assert v.shape == p.shape and v.dtype == np.float32
     np.testing.assert_array_equal(values[0], net.get_all_param_values()[0])       # best params were restored
     net.close()
+
+
+def test_extract_tools_round_trip(tmp_path):
+    """runners/extract_encoder_from_model.py / extract_lstm_from_model.py: a saved 1-stream model -> the .mat files the
+    stream loaders (load_decoder) and create_pretrained_model read."""
+    from ip_avsr_amd.modelzoo import deltanet_majority_vote
+    from ip_avsr_amd.runners import extract_encoder_from_model, extract_lstm_from_model
+    from ip_avsr_amd.runners.nstream import load_decoder
+    from ip_avsr_amd.utils.io import save_model_params
+    rng = np.random.RandomState(2)
+    dims = [24, 16, 12, 8, 5]
+    ae = ([rng.normal(0, 0.3, (a, b)).astype(np.float32) for a, b in zip(dims[:-1], dims[1:])],
+          [rng.normal(0, 0.05, (b,)).astype(np.float32) for b in dims[1:]], dims[1:], ["rectify", "rectify", "rectify", "linear"])
+    net = deltanet_majority_vote.create_model(ae, (None, None, 24), None, (None, None), None, 6, None, 4, 'glorot', False, True)
+    pkl = str(tmp_path / "model.pkl")
+    save_model_params(net, pkl)
+    common = ["--shape", "16,12,8,5", "--input_dim", "24", "--lstm_size", "6", "--output_classes", "4", "--use_blstm"]
+    enc_mat, lstm_mat = str(tmp_path / "enc.mat"), str(tmp_path / "lstm.mat")
+    d = extract_encoder_from_model.main(common + ["--output", enc_mat, pkl])
+    assert sorted(d) == ["b1", "b2", "b3", "b4", "w1", "w2", "w3", "w4"]
+    w, b, shapes, _ = load_decoder(enc_mat, "16,12,8,5", "rectify,rectify,rectify,linear")
+    for k in range(4):
+        np.testing.assert_array_equal(w[k], ae[0][k]); np.testing.assert_array_equal(b[k], ae[1][k])
+    lstm_names = [p.name.split(".")[0] for p in net.params if ".W_in_to_ingate" in p.name]
+    l = extract_lstm_from_model.main(common + ["--layer_names", ",".join(lstm_names), "--output", lstm_mat, pkl])
+    assert len(l) == 24 and "f_lstm_w_hid_to_cell" in l and "b_lstm_b_outgate" in l
+    np.testing.assert_array_equal(l["f_lstm_w_in_to_ingate"], net.get_param(lstm_names[0] + ".W_in_to_ingate"))
+    stored = sio.loadmat(lstm_mat)
+    np.testing.assert_array_equal(stored["b_lstm_w_hid_to_forgetgate"], net.get_param(lstm_names[1] + ".W_hid_to_forgetgate"))
+    net.close()
