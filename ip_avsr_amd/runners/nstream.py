@@ -99,6 +99,10 @@ def parse_options(argv=None):
     parser.add_argument('--layer_lr', default=None,
                         help='per-layer Adam learning rates "layer=rate,..." (adam_vlr, reference '
                              'runners/1stream_variable_lr.py:235-243); other layers use --learning_rate')
+    parser.add_argument('--explode_layer_lr', default=None,
+                        help='"EPOCH:RATE": after that epoch set every --layer_lr rate to RATE (the reference script '
+                             'sets fc1..fc3 to 100.0 after epoch 4 to SHOW that the per-layer rates act: the loss '
+                             'must diverge, runners/1stream_variable_lr.py:327-333)')
     parser.add_argument('--seed', type=int, default=None, help='seed for initialisers and minibatch order '
                                                                '(the reference never seeds; required >1 GPU)')
     args = parser.parse_args(argv)
@@ -111,6 +115,9 @@ def parse_options(argv=None):
     options['seed'] = args.seed
     if args.layer_lr:
         options['layer_lr'] = {kv.split('=')[0].strip(): float(kv.split('=')[1]) for kv in args.layer_lr.split(',')}
+    if args.explode_layer_lr:
+        e, r = args.explode_layer_lr.split(':')
+        options['explode_layer_lr'] = (int(e), float(r))
     return options
 
 
@@ -351,6 +358,12 @@ def main(n_streams, argv=None):
                 .format(epoch + 1, cost_train[-1], cost_val[-1], gl, pq, cr, time.time() - time_start))
         if epoch >= validation_window and early_stop2(val_window, best_val, validation_window):
             break
+        if lr_map is not None and 'explode_layer_lr' in options and epoch + 1 == options['explode_layer_lr'][0]:
+            rate = options['explode_layer_lr'][1]
+            say('explode {} learning rates to {}'.format(','.join(sorted(options['layer_lr'])), rate))
+            from ..custom.updates import generate_lr_map
+            lr_map = generate_lr_map(network.get_all_params(trainable=True), {k: rate for k in options['layer_lr']},
+                                     learning_rate)
 
     say('Final Model')
     say('CR: {}, val loss: {}, Test CR: {}'.format(best_cr, best_val, test_cr))

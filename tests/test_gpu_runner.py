@@ -134,3 +134,22 @@ def test_extract_tools_round_trip(tmp_path):
     stored = sio.loadmat(lstm_mat)
     np.testing.assert_array_equal(stored["b_lstm_w_hid_to_forgetgate"], net.get_param(lstm_names[1] + ".W_hid_to_forgetgate"))
     net.close()
+
+
+def test_variable_lr_runner_explodes_the_encoder_rates_after_epoch_4(tmp_path):
+    """runners/1stream_variable_lr.py: fc1..fc3 train at their own rate; after epoch 4 the script sets them to 100.0 and
+    the training cost must jump (that is the script's point)."""
+    import importlib
+    root = str(tmp_path)
+    make_dataset(root, 1)
+    ini = INI.format(k=1, root=root, reorder=True, diff=False) + TAIL.format(root=root, fusion="none", dropout=False)
+    ini = ini.replace("num_epoch = 6", "num_epoch = 7").replace("validation_window = 4", "validation_window = 7")
+    cfg = os.path.join(root, "cfg.ini")
+    open(cfg, "w").write(ini)
+    mod = importlib.import_module("ip_avsr_amd.runners.1stream_variable_lr")
+    out = mod.run(["--config", cfg, "--seed", "3"])
+    ct = out["cost_train"]
+    assert len(ct) >= 6 and np.isfinite(ct[:4]).all()
+    # once the rates are 100 the encoder is destroyed: the cost (bounded by log C for this loss) jumps back up
+    assert ct[3] < ct[0] and (min(ct[4:]) > ct[3] + 0.1 or not np.isfinite(ct[4:]).all())
+    out["network"].close()
