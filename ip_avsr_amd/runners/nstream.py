@@ -27,12 +27,13 @@ import scipy.io as sio
 from .. import init as las_init
 from ..custom.nonlinearities import select_nonlinearity
 from ..modelzoo import (adenet_2stream, adenet_3stream, adenet_3stream_dropout, adenet_4stream, adenet_v2_2,
-                        deltanet_majority_vote)
+                        deltanet_majority_vote, deltanet_v1, lstm_classifier_majority_vote)
 from ..utils.data_structures import circular_list
 from ..utils.datagen import compute_integral_len, gen_lstm_batch_random, gen_seq_batch_from_idx
 from ..utils.io import load_mat_file, read_data_split_file, save_model_params
 from ..utils.plotting_utils import plot_confusion_matrix, plot_validation_cost, print_network
-from ..utils.preprocessing import (compute_diff_images, featurewise_normalize_sequence, multistream_force_align,
+from ..utils.preprocessing import (compute_diff_images, concat_first_second_deltas, featurewise_normalize_sequence,
+                                   multistream_force_align,
                                    normalize_input, reorder_data, sequencewise_mean_image_subtraction, split_seq_data)
 from ..utils.regularization import early_stop2
 
@@ -163,7 +164,11 @@ def build_network(n_streams, aes, dims, lstm_weights, cfg):
     raise ValueError('1 to 4 streams are supported')
 
 
-def main(n_streams, argv=None):
+def main(n_streams, argv=None, variant=None):
+    """variant (1 stream only): None = runners/1stream.py, 'noencoder' = runners/1stream_noencoder.py (deltanet_v1 on the
+    raw features), 'dct' = runners/1stream_dct.py (host deltas of the DCT features, lstm_classifier_majority_vote)."""
+    if variant not in (None, 'noencoder', 'dct') or (variant and n_streams != 1):
+        raise ValueError('unknown runner variant %r for %d stream(s)' % (variant, n_streams))
     options = parse_options(argv)
     dist, rank, world = _dist_context()
     if world > 1 and options['seed'] is None:
@@ -221,7 +226,22 @@ def main(n_streams, argv=None):
     if matlab_target_offset:
         targets_vec = targets_vec - 1
 
-    if n_streams == 1:
+    if variant == 'dct':
+        # runners/1stream_dct.py:185-206: normalise, mean-remove, host deltas (x3 features) BEFORE the split, then the
+        # train-split featurewise normalisation
+        X = mats[0]
+        if config.getboolean('stream1', 'samplewisenormalize'):
+            X = normalize_input(X)
+        if config.getboolean('stream1', 'meanremove'):
+            X = sequencewise_mean_image_subtraction(X, vidlen_vec)
+        X = concat_first_second_deltas(X, vidlen_vec, windowsize)
+        parts = split_seq_data(X, targets_vec, subjects_vec, vidlen_vec, train_ids, val_ids, test_ids)
+        ys = dict(train=parts[1], val=parts[5], test=parts[9])
+        lens = dict(train=parts[2], val=parts[6], test=parts[10])
+        tr, va, te = postsplit_datapreprocessing(parts[0], parts[4], parts[8], config, 'stream1')
+        split = dict(train=[tr], val=[va], test=[te])
+        dims = [3 * dims[0]]
+    elif n_streams == 1:
         # runners/1stream.py:175-207: reorder, split, THEN the per-split preprocessing
         if config.getboolean('stream1', 'reorderdata'):
             mats[0] = reorder_data(mats[0], imagesizes[0])
@@ -260,10 +280,18 @@ def main(n_streams, argv=None):
                 ys = dict(train=parts[1], val=parts[5], test=parts[9])
                 lens = dict(train=parts[2], val=parts[6], test=parts[10])
 
-    aes = [load_decoder(config.get(n, 'model'), config.get(n, 'shape'), config.get(n, 'nonlinearities'))
-           for n in names]
     say('constructing end to end model...')
-    network, l_fuse = build_network(n_streams, aes, dims, lstm_weights, cfg)
+    if variant == 'noencoder':           # runners/1stream_noencoder.py:233-236
+        network, l_fuse = deltanet_v1.create_model((None, None, dims[0]), None, (None, None), None, None, cfg['lstm_size'],
+                                                   cfg['output_classes'], cfg['weight_init_fn'], cfg['use_peepholes']), None
+    elif variant == 'dct':               # runners/1stream_dct.py:220-223 (no delta layer: the window argument is unused)
+        network, l_fuse = lstm_classifier_majority_vote.create_model((None, None, dims[0]), None, (None, None), None,
+                                                                     cfg['lstm_size'], cfg['output_classes'],
+                                                                     cfg['weight_init_fn'], cfg['use_peepholes']), None
+    else:
+        aes = [load_decoder(config.get(n, 'model'), config.get(n, 'shape'), config.get(n, 'nonlinearities'))
+               for n in names]
+        network, l_fuse = build_network(n_streams, aes, dims, lstm_weights, cfg)
     if rank == 0:
         print_network(network)
     say('compiling model...')

@@ -153,3 +153,24 @@ def test_variable_lr_runner_explodes_the_encoder_rates_after_epoch_4(tmp_path):
     # once the rates are 100 the encoder is destroyed: the cost (bounded by log C for this loss) jumps back up
     assert ct[3] < ct[0] and (min(ct[4:]) > ct[3] + 0.1 or not np.isfinite(ct[4:]).all())
     out["network"].close()
+
+
+@pytest.mark.parametrize("variant", ["noencoder", "dct"])
+def test_one_stream_runner_variants(tmp_path, variant):
+    """runners/1stream_noencoder.py (deltanet_v1: delta layer + BLSTM straight on the features) and 1stream_dct.py (host
+    deltas before the split, lstm_classifier_majority_vote on 3x the features)."""
+    from ip_avsr_amd.runners import nstream
+    root = str(tmp_path)
+    make_dataset(root, 1)
+    ini = INI.format(k=1, root=root, reorder=False, diff=False) + TAIL.format(root=root, fusion="none", dropout=False)
+    cfg = os.path.join(root, "cfg.ini")
+    open(cfg, "w").write(ini)
+    out = nstream.main(1, ["--config", cfg, "--seed", "5"], variant=variant)
+    net = out["network"]
+    names = [p.name for p in net.params]
+    assert not any(n.startswith("fc") for n in names)                       # no encoder in either variant
+    w = net.get_param("f_lstm.W_in_to_ingate")
+    assert w.shape[0] == 72                                                   # 24 features x (static, delta, delta-delta)
+    assert net.spec["streams"][0]["delta"] is (variant == "noencoder")        # device delta layer vs host deltas
+    assert np.isfinite(out["cost_val"]).all() and (min(out["cost_val"]) < out["cost_val"][0] or out["best_cr"] >= 0.5)
+    net.close()
