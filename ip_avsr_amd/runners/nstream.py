@@ -27,7 +27,8 @@ import scipy.io as sio
 from .. import init as las_init
 from ..custom.nonlinearities import select_nonlinearity
 from ..modelzoo import (adenet_2stream, adenet_3stream, adenet_3stream_dropout, adenet_4stream, adenet_v2_2,
-                        deltanet_majority_vote, deltanet_v1, lstm_classifier_majority_vote)
+                        adenet_v2, adenet_v2_nodelta, deltanet_majority_vote, deltanet_v1,
+                        lstm_classifier_majority_vote)
 from ..utils.data_structures import circular_list
 from ..utils.datagen import compute_integral_len, gen_lstm_batch_random, gen_seq_batch_from_idx
 from ..utils.io import load_mat_file, read_data_split_file, save_model_params
@@ -165,9 +166,11 @@ def build_network(n_streams, aes, dims, lstm_weights, cfg):
 
 
 def main(n_streams, argv=None, variant=None):
-    """variant (1 stream only): None = runners/1stream.py, 'noencoder' = runners/1stream_noencoder.py (deltanet_v1 on the
-    raw features), 'dct' = runners/1stream_dct.py (host deltas of the DCT features, lstm_classifier_majority_vote)."""
-    if variant not in (None, 'noencoder', 'dct') or (variant and n_streams != 1):
+    """variant: None = runners/{1,2,3,4}stream.py; 1 stream: 'noencoder' = runners/1stream_noencoder.py (deltanet_v1 on
+    the raw features), 'dct' = runners/1stream_dct.py (host deltas of the DCT features, lstm_classifier_majority_vote);
+    2 streams: 'dct' = runners/2stream_dct.py (adenet_v2: encoder stream + encoder-less DCT stream), 'nodelta' =
+    runners/2stream_nodelta.py (adenet_v2_nodelta)."""
+    if (variant, n_streams) not in ((None, n_streams), ('noencoder', 1), ('dct', 1), ('dct', 2), ('nodelta', 2)):
         raise ValueError('unknown runner variant %r for %d stream(s)' % (variant, n_streams))
     options = parse_options(argv)
     dist, rank, world = _dist_context()
@@ -188,7 +191,8 @@ def main(n_streams, argv=None, variant=None):
 
     say('preprocessing dataset...')
     data = [load_mat_file(config.get(n, 'data')) for n in names]
-    imagesizes = [tuple(int(d) for d in config.get(n, 'imagesize').split(',')) for n in names]
+    imagesizes = [tuple(int(d) for d in config.get(n, 'imagesize').split(',')) if config.has_option(n, 'imagesize') else None
+                  for n in names]
     dims = [config.getint(n, 'input_dimensions') for n in names]
     lstm_weights = [sio.loadmat(config.get(n, 'lstm_model')) if config.has_option(n, 'lstm_model') else None
                     for n in names]
@@ -226,7 +230,7 @@ def main(n_streams, argv=None, variant=None):
     if matlab_target_offset:
         targets_vec = targets_vec - 1
 
-    if variant == 'dct':
+    if variant == 'dct' and n_streams == 1:
         # runners/1stream_dct.py:185-206: normalise, mean-remove, host deltas (x3 features) BEFORE the split, then the
         # train-split featurewise normalisation
         X = mats[0]
@@ -284,6 +288,17 @@ def main(n_streams, argv=None, variant=None):
     if variant == 'noencoder':           # runners/1stream_noencoder.py:233-236
         network, l_fuse = deltanet_v1.create_model((None, None, dims[0]), None, (None, None), None, None, cfg['lstm_size'],
                                                    cfg['output_classes'], cfg['weight_init_fn'], cfg['use_peepholes']), None
+    elif variant == 'dct' and n_streams == 2:           # runners/2stream_dct.py: stream 2 has no encoder
+        ae1 = load_decoder(config.get('stream1', 'model'), config.get('stream1', 'shape'), config.get('stream1', 'nonlinearities'))
+        network, l_fuse = adenet_v2.create_model(ae1, (None, None, dims[0]), None, (None, None), None, (None, None, dims[1]),
+                                                 None, cfg['lstm_size'], None, cfg['output_classes'], cfg['fusiontype'],
+                                                 w_init_fn=cfg['weight_init_fn'], use_peepholes=cfg['use_peepholes'])
+    elif variant == 'nodelta':                          # runners/2stream_nodelta.py
+        aes = [load_decoder(config.get(n, 'model'), config.get(n, 'shape'), config.get(n, 'nonlinearities')) for n in names]
+        network, l_fuse = adenet_v2_nodelta.create_model(aes[0], aes[1], (None, None, dims[0]), None, (None, None), None,
+                                                         (None, None, dims[1]), None, cfg['lstm_size'], cfg['output_classes'],
+                                                         cfg['fusiontype'], w_init_fn=cfg['weight_init_fn'],
+                                                         use_peepholes=cfg['use_peepholes'])
     elif variant == 'dct':               # runners/1stream_dct.py:220-223 (no delta layer: the window argument is unused)
         network, l_fuse = lstm_classifier_majority_vote.create_model((None, None, dims[0]), None, (None, None), None,
                                                                      cfg['lstm_size'], cfg['output_classes'],

@@ -174,3 +174,29 @@ def test_one_stream_runner_variants(tmp_path, variant):
     assert net.spec["streams"][0]["delta"] is (variant == "noencoder")        # device delta layer vs host deltas
     assert np.isfinite(out["cost_val"]).all() and (min(out["cost_val"]) < out["cost_val"][0] or out["best_cr"] >= 0.5)
     net.close()
+
+
+@pytest.mark.parametrize("variant", ["dct", "nodelta"])
+def test_two_stream_runner_variants(tmp_path, variant):
+    """runners/2stream_dct.py (adenet_v2: stream 2 is an encoder-less feature stream, its section has no model /
+    imagesize keys) and 2stream_nodelta.py (adenet_v2_nodelta: no delta layers)."""
+    from ip_avsr_amd.runners import nstream
+    root = str(tmp_path)
+    make_dataset(root, 2)
+    s1 = INI.format(k=1, root=root, reorder=True, diff=False)
+    s2 = INI.format(k=2, root=root, reorder=False, diff=True)
+    if variant == "dct":
+        s2 = "\n".join(l for l in s2.split("\n") if not l.startswith(("model", "shape", "nonlinearities", "imagesize")))
+    ini = s1 + s2 + TAIL.format(root=root, fusion="sum", dropout=False)
+    cfg = os.path.join(root, "cfg.ini")
+    open(cfg, "w").write(ini)
+    out = nstream.main(2, ["--config", cfg, "--seed", "11"], variant=variant)
+    net = out["network"]
+    if variant == "dct":
+        assert net.spec["streams"][1]["enc_shapes"] == [] and net.spec["streams"][1]["delta"] is True
+        assert net.get_param("lstm_dct.W_in_to_ingate").shape[0] == 72
+    else:
+        assert all(s["delta"] is False for s in net.spec["streams"])
+        assert net.get_param("lstm_s1.W_in_to_ingate").shape[0] == 5          # bottleneck features, no deltas
+    assert np.isfinite(out["cost_val"]).all() and (min(out["cost_val"]) < out["cost_val"][0] or out["best_cr"] >= 0.5)
+    net.close()
