@@ -79,6 +79,8 @@ struct GemmArgs {
     const float* bias = nullptr;   // per output column, added before the activation
     int act = ADN_ACT_LINEAR;      // activation applied to the result
     int accumulate = 0;            // C += result (instead of C = result)
+    int no_split = 0;              // never split K (float atomics add in arrival order: forward-pass GEMMs set this so
+                                   // that two evaluations of the same batch give the same bits)
     const float* Y = nullptr; int ldy = 0; int act_grad = ADN_ACT_LINEAR;
                                    // result *= act_grad'(Y[row][col])  (back-prop through the
                                    // activation of the layer that produced Y)

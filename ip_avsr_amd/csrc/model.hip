@@ -668,6 +668,7 @@ int lstm_project(adn_model* m, const LstmParams& lp, const LstmWork& w, const fl
         g.C = w.xproj; g.ldc = m->ldg;
         g.bias = (j == 0) ? m->P(lp.b) : nullptr;
         g.accumulate = j > 0;
+        g.no_split = 1;                                          // forward pass: reproducible bits
         ADN_TRY(mgemm(m, g));
     }
     return ADN_OK;
@@ -688,6 +689,7 @@ int lstm_project_cat(adn_model* m, const LstmParams& lp, const LstmWork& w, int 
     g.A16 = m->cat16; g.B16 = lp.wcat16;
     g.C = w.xproj; g.ldc = m->ldg; g.bias = m->P(lp.b);
     g.precision = m->cfg.precision;
+    g.no_split = 1;                                              // forward pass: reproducible bits
     return gemm(g, m->stream);
 }
 
@@ -759,6 +761,7 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
             g.layout = GEMM_NN; g.M = N; g.N = st.cfg.enc_units[l]; g.K = st.enc_in[l];
             g.A = a; g.lda = lda; g.B = m->P(st.encW[l]); g.ldb = ld_of(g.N);
             g.C = st.act[l]; g.ldc = ld_of(g.N); g.bias = m->P(st.encb[l]); g.act = st.cfg.enc_act[l];
+            g.no_split = 1;                                      // forward pass: reproducible bits
             ADN_TRY(mgemm(m, g, /*lean=*/l + 1 < st.cfg.n_enc));      // the delta layer reads the last one in fp32
             a = st.act[l]; lda = g.ldc;
         }
@@ -854,7 +857,7 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
         // time-major: block T-1 is B contiguous rows
         GemmArgs g;
         g.layout = GEMM_NN; g.M = B; g.N = m->C; g.K = H; g.A = cls + (size_t)(T - 1) * B * ldh; g.lda = ldh;
-        g.B = m->P(m->smW); g.ldb = m->ldc; g.C = m->z; g.ldc = m->ldc; g.bias = m->P(m->smb);
+        g.B = m->P(m->smW); g.ldb = m->ldc; g.C = m->z; g.ldc = m->ldc; g.bias = m->P(m->smb); g.no_split = 1;
         ADN_TRY(mgemm(m, g));
         ADN_TRY(softmax_ce(m->z, m->ldc, B, T, m->C, want_loss ? m->y_bt : nullptr, m->total, m->probs_bt,
                            want_loss ? m->row_loss : nullptr, want_dz ? m->dz : nullptr, m->ldc, s));
@@ -866,7 +869,7 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
     {   // Dense(C) + softmax per frame (modelzoo/adenet_v2.py:89-92)
         GemmArgs g;
         g.layout = GEMM_NN; g.M = N; g.N = m->C; g.K = H; g.A = cls; g.lda = ldh;
-        g.B = m->P(m->smW); g.ldb = m->ldc; g.C = m->z; g.ldc = m->ldc; g.bias = m->P(m->smb);
+        g.B = m->P(m->smW); g.ldb = m->ldc; g.C = m->z; g.ldc = m->ldc; g.bias = m->P(m->smb); g.no_split = 1;
         ADN_TRY(mgemm(m, g));
     }
     ADN_TRY(softmax_loss(m->z, m->ldc, B, T, m->C, m->mask_tb, want_loss ? m->y_bt : nullptr, m->total, m->probs_bt,

@@ -1,7 +1,6 @@
 """Randomised shapes (H 5..512, B 1..260, T 1..19, every fusion, peepholes on / off) through the resident-weight LSTM kernels
 against the one-workgroup kernels of the same arithmetic: forward identical, gradients within the 19-bit exchange noise,
-no exchange time-out.  (Forward GEMMs that split K with float atomics make two predictions differ by ~1e-7..1e-5 in BOTH
-modes; reported, not a failure of the kernels under test.)      python profiles/fuzz_lstm.py   (on an MI355X)"""
+no exchange time-out.  (Two predictions of one batch must agree bit for bit: the forward GEMMs never split K.)      python profiles/fuzz_lstm.py   (on an MI355X)"""
 import os, sys, time
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
 import numpy as np
@@ -29,12 +28,13 @@ for it in range(40):
         pr = m.predict(inputs, mask, 2); l = m.compute_grads(inputs, y, mask, 2); g = m.get_grads_dict()
         pr2 = m.predict(inputs, mask, 2)
         if not (pr == pr2).all():
+            bad += 1
             print('   NON-REPEATABLE predict: it=%d mode=%s H=%d B=%d T=%d %s peep=%d  max diff %.3e (valid %.3e)' % (it, mode, H, B, T, fusion, peep, np.abs(pr-pr2).max(), np.abs((pr-pr2)*mask[...,None]).max()))
         res[mode] = (pr, l, g); m.close()
     valid = mask[..., None].astype(bool)
     dp = np.abs((res["cluster"][0] - res["single"][0]) * valid).max()
     dg = max(np.abs(res["cluster"][2][k] - res["single"][2][k]).max() / max(np.abs(res["single"][2][k]).max(), 1e-6) for k in res["single"][2])
-    ok = dp <= 5e-5 and dg <= 5e-3 and np.isfinite(res["cluster"][1])
+    ok = dp == 0 and dg <= 5e-3 and np.isfinite(res["cluster"][1])
     bad += not ok
     print("%2d H=%3d B=%3d T=%2d %-6s peep=%d  dprobs %.1e dgrads %.1e %s" % (it, H, B, T, fusion, peep, dp, dg, "ok" if ok else "BAD"))
 print("bad:", bad, "time %.1f s" % (time.time() - t0))

@@ -791,3 +791,21 @@ def test_wide_weight_stationary_lstm_edge_shapes(torch_cuda, lib, monkeypatch, B
         ref = out["single"][2][k]
         assert np.isfinite(g).all(), k
         assert np.abs(g - ref).max() <= 5e-3 * max(np.abs(ref).max(), 1e-6), k
+
+
+@pytest.mark.parametrize("H,B,T,fusion", [(300, 33, 12, "concat"), (250, 63, 11, "concat"), (512, 100, 11, "adasum")])
+def test_evaluation_is_reproducible_bit_for_bit(torch_cuda, lib, H, B, T, fusion):
+    """bf16 mode: two evaluations of one batch give the same bits -- no forward-pass GEMM splits K (float atomics add in
+    arrival order; these shapes used to differ by 1e-7 .. 1e-5 between calls), the LSTM kernels are deterministic."""
+    from ip_avsr_amd.model import AdeNetModel
+    spec = dict(O.spec_nstream([12, 9], enc_shapes=(14, 6), enc_acts=("rectify", "linear"), lstm_size=H, classes=5,
+                               fusion=fusion, peepholes=False), precision="bf16")
+    p, inputs, y, mask = make_case(spec, B, T, seed=7, perturb=0.02)
+    m = AdeNetModel(spec)
+    m.set_params_dict(p)
+    first = m.predict(inputs, mask, 2)
+    for _ in range(4):
+        np.testing.assert_array_equal(m.predict(inputs, mask, 2), first)
+    l0 = m.loss(inputs, y, mask, 2)
+    assert all(m.loss(inputs, y, mask, 2) == l0 for _ in range(3))
+    m.close()
