@@ -1,8 +1,8 @@
 """Randomised shapes (H 5..512, B 1..260, T 1..19, every fusion, peepholes on / off) through the resident-weight LSTM kernels
 against the one-workgroup kernels of the same arithmetic: forward identical, gradients within the 19-bit exchange noise,
-no exchange time-out.  (Two predictions of one batch must agree bit for bit: the forward GEMMs never split K.)      python profiles/fuzz_lstm.py   (on an MI355X)"""
+no exchange time-out.  (Two predictions of one batch must agree bit for bit: the forward GEMMs never split K.)      python tests/fuzz_lstm.py   (on an MI355X)"""
 import os, sys, time
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 from oracle import adenet_oracle as O
 from test_gpu_parity import make_case
