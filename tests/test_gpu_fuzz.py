@@ -25,6 +25,11 @@ def test_random_graphs_match_the_oracle_in_f32():
     assert "bad: 0" in out, "\n".join(l for l in out.splitlines() if " BAD " in l or "bad:" in l)
 
 
+def test_random_graphs_track_the_oracle_in_bf16():
+    out = run("fuzz_model.py", "24", "2026", "bf16")
+    assert "bad: 0" in out, "\n".join(l for l in out.splitlines() if " BAD " in l or "bad:" in l)
+
+
 def test_random_lstm_shapes_cluster_equals_single_workgroup():
     out = run("fuzz_lstm.py")
     assert "bad: 0" in out, "\n".join(l for l in out.splitlines() if "BAD" in l or "NON-REPEATABLE" in l or "bad:" in l)
