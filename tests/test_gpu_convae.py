@@ -26,7 +26,8 @@ def make(hw, dense, nb, seed, B):
     return p, x
 
 
-@pytest.mark.parametrize("hw,dense,nb,B", [((30, 40), 500, 50, 5), ((22, 28), 24, 6, 3)])
+@pytest.mark.parametrize("hw,dense,nb,B", [((30, 40), 500, 50, 5), ((22, 28), 24, 6, 3), ((26, 44), 40, 10, 2), ((34, 28), 32, 8, 1),
+                                           ((38, 48), 20, 5, 3), ((22, 36), 16, 4, 2)])   # (H = 2 mod 4, W = 0 mod 4: the sizes the decoder reproduces)
 def test_forward_loss_and_gradients_match_the_oracle(ConvAE, hw, dense, nb, B):
     p, x = make(hw, dense, nb, 3, B)
     p64 = {k: v.astype(np.float64) for k, v in p.items()}
@@ -108,3 +109,12 @@ def test_zoo_factory_and_bf16_mode(ConvAE):
     net.close(); b16.close()
     with pytest.raises(Exception):
         ConvAE((10, 10), 8, 2)
+
+
+def test_image_sizes_the_decoder_cannot_reproduce_are_rejected(ConvAE):
+    """conv / pool / upscale / deconv only give back H x W for H = 2 (mod 4), W = 0 (mod 4); anything else must fail at
+    construction, not train on a mismatched reconstruction (the reference would fail on the shape of its MSE)."""
+    from ip_avsr_amd._lib import AdenetError
+    for hw in ((30, 50), (29, 33), (32, 40)):
+        with pytest.raises(AdenetError):
+            ConvAE(hw, 16, 4)
