@@ -5,8 +5,9 @@
 // H = 500), bound by what one CU can take in (~40 GB/s), with only 33 workgroups per LSTM busy.  Here a group of CWG
 // workgroups shares a 32-utterance slice (CWG = 4 for H <= 256, 8 for H <= 512); workgroup j owns hidden units
 // [64 j, 64 j + 64): its 256 gate columns of W_hid (forward) or its 256 rows of W_hid^T (backward), in MFMA-fragment
-// order, stay on the CU for all T steps -- 128 KB of LDS at CWG = 4; at CWG = 8 the slice is 256 KB and its k-steps are
-// split between LDS and the registers of the waves that multiply them (see ClusterGeom).  What the workgroups
+// order, stay on the CU for all T steps, split between LDS and the registers of the waves that multiply them (see
+// ClusterGeom: at CWG = 4 the 128 KB slice sits in registers in the forward kernel and half / half in the backward one; at
+// CWG = 8 the slice is 256 KB).  What the workgroups
 // must exchange each step is tiny and goes through L2 / the memory side as 8-byte tagged granules
 // {payload32, tag32}: the consumer polls the payload's own address until the tag of the step shows up (one hop,
 // no separate flag; relaxed agent-scope 64-bit atomics = sc1 stores / loads, single-copy atomic):
@@ -15,7 +16,7 @@
 //             granule                                                                 (CWG - 1) x 32 x 64 values in
 // Two parities of the exchange buffer suffice: a workgroup can only be one step ahead of its partners.
 // Every workgroup of a launch must be resident at once (they wait for each other): the host launches at most one
-// workgroup per CU (LDS: 145-153 KB each) and splits larger sets of LSTMs over several launches; an LSTM whose groups
+// workgroup per CU (registers and LDS allow no second one) and splits larger sets of LSTMs over several launches; an LSTM whose groups
 // do not fit the device at all (B > 32 * CUs / CWG) runs on the other kernels.  Polls are bounded (10 s of wall clock); a
 // poll that gives up raises the launch's error word and the host reports ADN_ERR_STATE -- never a hang.
 #include "adn_common.h"
@@ -48,7 +49,9 @@ constexpr int kCUnits = 64;      // hidden units per workgroup
 template <int CWG> struct ClusterGeom {
     static constexpr int HP = CWG * kCUnits;                // padded hidden size (256 | 512)
     static constexpr int KS = HP / 32;                      // k-steps of the forward product (8 | 16)
-    static constexpr int KSL = CWG == 4 ? 8 : 7;            // ... of which LDS-resident; the rest sit in registers
+    static constexpr int KSL = CWG == 4 ? 0 : 7;            // ... of which LDS-resident; the rest sit in registers
+                                                            // (CWG = 4: all 8 in registers, 128 VGPRs -- the product phase
+                                                            // is LDS-bandwidth bound otherwise: -0.2 us per step)
     static constexpr int KSR = KS - KSL;
     static constexpr int WElems = kCUnits * 4 * HP;         // bf16 elements of one workgroup's W slice (128 | 256 KB)
     static constexpr int WLdsFwd = 4 * 4 * KSL * 512;       // ... of which in LDS, forward  [4 unit tiles][4 gates][KSL][64][8]
@@ -58,7 +61,7 @@ template <int CWG> struct ClusterGeom {
     // (already there): the 16 addresses are then one base plus constants, which keeps 28 registers free
     static constexpr bool PollOwn = CWG > 4;
     static constexpr int NF = PollOwn ? 2 * CWG : 2 * (CWG - 1);
-    static constexpr int KSLB = CWG == 4 ? 8 : 4;           // backward: LDS-resident k-steps of the 8 a workgroup owns
+    static constexpr int KSLB = 4;                          // backward: LDS-resident k-steps of the 8 a workgroup owns
     static constexpr int KSRB = 8 - KSLB;
     static constexpr int WLdsBwd = (HP / 16) * KSLB * 512;  // [HP/16 unit tiles][KSLB][64][8]
     static constexpr int NRT = CWG / 4;                     // backward product: row tiles per wave (4: wave = (row tile, destination);
@@ -163,9 +166,11 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const LstmCluster
     // ---- resident W slice: unit tiles 4j .. 4j+3 of the fragment image ([tile][gate][KS][64][8]); k-steps < KSL go to
     //      LDS, the others into this wave's registers (its own unit tile only)
     const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(P.W_frag_fwd) + (size_t)j * G::WElems);
-    for (int e = tid; e < G::WLdsFwd / 8; e += 512) {
-        const int l64 = e & 63, s_ = (e >> 6) % KSL, tg = (e >> 6) / KSL;         // tg = 4 * unit tile + gate
-        reinterpret_cast<bf16x8*>(wl)[e] = wsrc[((size_t)tg * KS + s_) * 64 + l64];
+    if constexpr (KSL > 0) {
+        for (int e = tid; e < G::WLdsFwd / 8; e += 512) {
+            const int l64 = e & 63, s_ = (e >> 6) % KSL, tg = (e >> 6) / KSL;     // tg = 4 * unit tile + gate
+            reinterpret_cast<bf16x8*>(wl)[e] = wsrc[((size_t)tg * KS + s_) * 64 + l64];
+        }
     }
     bf16x8 wreg[4][KSR > 0 ? KSR : 1];
 #pragma unroll
