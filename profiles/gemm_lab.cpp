@@ -59,6 +59,8 @@ int main(int argc, char** argv) {
         {"dW fc2 TN acc", GEMM_TN, 2000, 1000, R, 0, 1, 0, 0, 0},
         {"dW fc3 TN acc", GEMM_TN, 1000, 500, R, 0, 1, 0, 0, 0},
         {"dW lstm TN acc", GEMM_TN, 250, 1000, R, 0, 1, 0, 0, 0},
+        {"dW lstm-in TN acc", GEMM_TN, 150, 1000, R, 0, 1, 0, 0, 0},
+        {"dW agg-cat TN", GEMM_TN, 768, 1000, R, 0, 0, 0, 0, 0},
         {"dW bn TN acc", GEMM_TN, 500, 50, R, 0, 1, 0, 0, 0},
     };
     const char* only = argc > 1 ? argv[1] : nullptr;
