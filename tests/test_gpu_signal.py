@@ -1,0 +1,43 @@
+"""ip_avsr_amd/utils/signal.py (reference utils/signal.py:42-80 on the device kernel): the known answers derived for the
+array the reference's own main() prints (utils/signal.py:95-100), and the oracle on random sequences."""
+import numpy as np
+import pytest
+
+from oracle import adenet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from ip_avsr_amd.utils import signal
+    return signal
+
+
+def test_known_answers_of_the_reference_demo_array(S):
+    A = np.array([[1, 2, 3, 4, 5], [10, 12, 13, 14, 15], [300, 1, 23, 56, 22]], dtype=np.float32)
+    out = S.append_delta_coeff(A, 1)
+    want = np.array([[1, 2, 3, 4, 5, 4.5, 5, 5, 5, 5, 72.5, -2.75, 2.5, 10.5, 1.75],
+                     [10, 12, 13, 14, 15, 149.5, -0.5, 10, 26, 8.5, 70.25, -5.25, 0, 8, -0.75],
+                     [300, 1, 23, 56, 22, 145, -5.5, 5, 21, 3.5, -2.25, -2.5, -2.5, -2.5, -2.5]], dtype=np.float32)
+    np.testing.assert_allclose(out, want, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(S.delta_coeff(A, 1), want[:, 5:10], rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape,theta", [((7, 5), 2), ((40, 50), 9), ((3, 12, 30), 3), ((1, 4), 9)])
+def test_random_sequences_match_the_oracle(S, shape, theta):
+    import torch
+    rng = np.random.default_rng(sum(shape) + theta)
+    A = rng.normal(size=shape).astype(np.float32)
+    want = O.delta_append(A[None] if A.ndim == 2 else A, theta)
+    want = want[0] if A.ndim == 2 else want
+    got = S.append_delta_coeff(A, theta)
+    assert got.shape == want.shape and np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
+    F = shape[-1]
+    np.testing.assert_array_equal(S.delta_coeff(A, theta), got[..., F:2 * F])
+    dev = S.append_delta_coeff(torch.tensor(A, device="cuda"), theta)
+    assert isinstance(dev, torch.Tensor) and dev.is_cuda
+    np.testing.assert_array_equal(dev.cpu().numpy(), got)
