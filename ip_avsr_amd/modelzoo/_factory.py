@@ -82,6 +82,39 @@ def _load_pretrained_lstm(model, name, weights, prefix):
         model.set_param("%s.b_%s" % (name, g), np.asarray(weights["%s_b_%s" % (prefix, g)], "float32").reshape(-1))
 
 
+def lstm_param_names(name, peepholes):
+    """Lasagne's registration order inside one LSTMLayer: per gate W_in, W_hid, b in the order
+    ingate, forgetgate, cell, outgate; then the peephole vectors (``peepholes=True``, Lasagne's default); then
+    cell_init, hid_init (``learn_init=True``)."""
+    out = []
+    for g in GATES:
+        out += ["%s.W_in_to_%s" % (name, g), "%s.W_hid_to_%s" % (name, g), "%s.b_%s" % (name, g)]
+    if peepholes:
+        out += ["%s.W_cell_to_%s" % (name, g) for g in ("ingate", "forgetgate", "outgate")]
+    return out + [name + ".cell_init", name + ".hid_init"]
+
+
+def param_names(spec):
+    """``[p.name for p in lasagne.layers.get_all_params(network)]`` of the graph ``spec`` describes -- the order
+    ``get_all_param_values`` / ``set_all_param_values`` and the ``.pkl`` checkpoints use (utils/io.py:40-48).  Pure
+    Python (no device): the model built from the same spec must report exactly this list."""
+    names = []
+    for s in spec["streams"]:
+        for n in s["enc_names"]:
+            names += [n + ".W", n + ".b"]
+        for ln in s["lstm_names"]:
+            names += lstm_param_names(ln, s["peepholes"])
+    if spec["fusion"] == "adasum":
+        names += ["%s.adacoeff%d" % (spec["fuse_name"], k) for k in range(len(spec["streams"]))]
+    for ln in spec["agg_names"]:
+        names += lstm_param_names(ln, spec.get("agg_peepholes", False))
+    return names + [spec["softmax_name"] + ".W", spec["softmax_name"] + ".b"]
+
+
+# set by tests that only need the graph description of a zoo module (no device, no libadenet_hip.so)
+SPEC_ONLY = False
+
+
 def build(streams, lstm_size, output_classes, fusiontype, fuse_names, agg_names, agg_peepholes, w_init_fn,
           softmax_name="softmax", return_fuse=True, head="frames", agg_dropout=0.0):
     if fusiontype not in ("none", "sum", "adasum", "concat"):
@@ -94,7 +127,10 @@ def build(streams, lstm_size, output_classes, fusiontype, fuse_names, agg_names,
         fusion=fusiontype, fuse_name=fuse_names.get(fusiontype, ""), agg_names=list(agg_names),
         agg_peepholes=bool(agg_peepholes), lstm_size=int(lstm_size), classes=int(output_classes),
         softmax_name=softmax_name)
+    if SPEC_ONLY:
+        return (spec, None) if return_fuse else spec
     model = AdeNetModel(spec)
+    assert [p.name for p in model.params] == param_names(spec)
     w_init = _init.resolve(w_init_fn)
     for s in streams:
         for n, W, b in zip(s["enc_names"], s["enc_weights"], s["enc_biases"]):

@@ -8,7 +8,7 @@ from . import _factory as F
 
 def create_model(dbn, input_shape, input_var, mask_shape, mask_var, dct_shape, dct_var, lstm_size=250, win=None,
                  output_classes=26):
-    streams = [F.stream(input_shape, F.nolearn_weights(dbn), "", lstm_names=["lstm_bn"], dropout=0.5),
-               F.stream(dct_shape, None, "_dct", delta=False, lstm_names=["lstm_dct"], dropout=0.2)]
-    return F.build(streams, 2 * int(lstm_size), output_classes, "sum", {"sum": "sum1"}, ["lstm_agg"], False, 'ortho',
+    streams = [F.stream(input_shape, F.nolearn_weights(dbn), "", lstm_names=["lstm_bn"], dropout=0.5, peepholes=True),
+               F.stream(dct_shape, None, "_dct", delta=False, lstm_names=["lstm_dct"], dropout=0.2, peepholes=True)]
+    return F.build(streams, 2 * int(lstm_size), output_classes, "sum", {"sum": "sum1"}, ["lstm_agg"], True, 'ortho',
                    softmax_name="output", head="last", agg_dropout=0.5)

@@ -657,15 +657,16 @@ def spec_adenet_v3(raw_dim, dct_dim, diff_dim, enc_shapes=(2000, 1000, 500, 50),
                    enc_acts=("rectify", "rectify", "rectify", "linear"), lstm_size=250, classes=26, fusion="concat"):
     """modelzoo/adenet_v3.create_model (:64-188): raw + diff encoder streams with deltas, a raw DCT stream, dropout
     0.5 / 0.2 / 0.5 ahead of the three LSTMs of 2*lstm_size units, dropout 0.5 on the fused tensor, summed BLSTM of
-    2*lstm_size units, LAST time step, softmax; trained with categorical cross-entropy."""
+    2*lstm_size units, LAST time step, softmax; trained with categorical cross-entropy.  No LSTMLayer of that file
+    passes ``peepholes=``, so Lasagne's default True applies to all five (:27-45, :113-143)."""
     enc = lambda sfx: dict(enc_names=[n + sfx for n in ENC_NAMES[:len(enc_shapes)]], enc_shapes=list(enc_shapes),
                            enc_acts=list(enc_acts), delta=True)
-    streams = [dict(input_dim=raw_dim, lstm_names=["lstm_raw"], peepholes=False, dropout=0.5, **enc("_raw")),
+    streams = [dict(input_dim=raw_dim, lstm_names=["lstm_raw"], peepholes=True, dropout=0.5, **enc("_raw")),
                dict(input_dim=dct_dim, enc_names=[], enc_shapes=[], enc_acts=[], delta=False, lstm_names=["lstm_dct"],
-                    peepholes=False, dropout=0.2),
-               dict(input_dim=diff_dim, lstm_names=["lstm_diff"], peepholes=False, dropout=0.5, **enc("_diff"))]
+                    peepholes=True, dropout=0.2),
+               dict(input_dim=diff_dim, lstm_names=["lstm_diff"], peepholes=True, dropout=0.5, **enc("_diff"))]
     return dict(streams=streams, fusion=fusion, fuse_name={"adasum": "adasum1", "sum": "sum1", "concat": "concat"}[fusion],
-                agg_names=["f_lstm_agg", "b_lstm_agg"], agg_peepholes=False, agg_dropout=0.5,
+                agg_names=["f_lstm_agg", "b_lstm_agg"], agg_peepholes=True, agg_dropout=0.5,
                 lstm_size=2 * lstm_size, classes=classes, softmax_name="output", head="last", loss="cross_entropy")
 
 
