@@ -1,0 +1,11 @@
+"""``python -m ip_avsr_amd.avletters.trimodal --config X.ini``: reference avletters/trimodal.py on the MI355X model
+(driver: ip_avsr_amd/runners/modal.py)."""
+from ..runners.modal import main as _main
+
+
+def main(argv=None):
+    return _main('avletters', 'trimodal', argv)
+
+
+if __name__ == "__main__":
+    main()

@@ -103,8 +103,14 @@ struct GemmArgs {
     // bf16 kernels with shadows only: C may be null when C16 is given (the fp32 copy is simply not written; the
     // launch is then never split over K), and Y16 may replace Y (bf16 copy of the activation, same ld)
     const void* Y16 = nullptr;
+    // split-K workspace of the persistent ping-pong kernel (partial tiles as plain stores + a reduce pass instead of
+    // float atomics); without it large weight-gradient GEMMs stay on the atomic split-K kernels
+    float* splitk_ws = nullptr; size_t splitk_ws_floats = 0;
 };
 int gemm(const GemmArgs& g, hipStream_t stream);
+// n problems of identical shape, layout and flags (different buffers) as ONE launch where the persistent kernel
+// applies (their tiles share one list: fuller last round); otherwise n launches
+int gemm_grouped(const GemmArgs* g, int n, hipStream_t stream);
 // dst[i] = bf16(src[i]), n a multiple of 8
 int to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 // out[c * ldT + r] = bf16(W[r * ld + c]) for r < rows, c < cols (LDS-tiled transpose)

@@ -539,34 +539,66 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams p)
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// LDS-DMA pipelined kernel for the large GEMMs (bf16 shadow operands only; experimental, ADN_GEMM_TILE=512).
+// Ping-pong LDS-DMA kernel for the large GEMMs (bf16 shadow operands; NN and TN).
 //
-// 256 x 256 tile (half the L2 bytes per flop of the 128 x 128 kernel, whose rate is set by what one CU takes in from L2:
-// ~44 GB/s in both register-staged shapes), 8 waves (4 x 2, each 64 x 128), BK = 32, ONE workgroup per CU walking the
-// tile list.  Operand tiles go L2 -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write) into a ring of 4
-// stage buffers, three stages in flight ahead of the one being multiplied, one s_barrier per K-step and counted vmcnt
-// waits.  A DMA wave-instruction writes 1 KiB of LDS linearly (lane l -> base + 16 l), so the stage images are unpadded
-// and bank conflicts are removed by permuting, per row, WHICH 16-byte chunk of global memory each lane fetches
+// Persistent: ONE 512-thread workgroup per CU walks a list of BM x BN output tiles (256 x 256, 256 x 128 or
+// 128 x 256); 8 waves as 4 (m) x 2 (n).  Operand tiles go L2 -> LDS with global_load_lds_dwordx4 (no VGPR staging, no
+// ds_write) into a ring of 4 stage buffers of BK = 32, three stages ahead of the one being multiplied, and the ring
+// keeps running across tile boundaries (the next tile's first stages land while this tile's epilogue stores).
+//
+// The two waves that share a SIMD (w and w + 4: the upper and the lower half of the tile's rows) run the same program
+// ONE BARRIER APART.  A K-step is two segments separated by s_barrier:
+//     L(s): fragment reads of stage s into registers + DMA issue for stage s + 3        (LDS / address traffic)
+//     C(s): TM x TN MFMAs on those registers (+ the tile epilogue after the last K-step)  (matrix pipe)
+//     waves 0-3:   L(0) | C(0) | L(1) | C(1) | ...
+//     waves 4-7:        | L(0) | C(0) | L(1) | ...
+// so that at any time one wave of every SIMD feeds the matrix pipe while its partner does the LDS reads and the DMA
+// issue, instead of all eight waves running wait / barrier / DMA issue / reads / MFMA in lock-step (in-kernel stamps of
+// the lock-step predecessor: 45 % of a K-step in reads + MFMA, 23 % DMA issue, 32 % waits; MFMA pipe 29 % busy).
+//
+// LDS hazards are settled by counted waits and the barrier sequence alone (barrier #n is the same event for all 8
+// waves; waves 0-3 run L(s) between #2s and #2s+1, waves 4-7 between #2s+1 and #2s+2):
+//   RAW  stage s + 1 is first read after #2s+2.  Every wave waits for ITS pieces of stage s + 1 (s_waitcnt vmcnt(N),
+//        N = pieces of the younger stages it has issued) before it arrives at #2s+2: waves 0-3 at the end of C(s),
+//        waves 4-7 at the end of L(s).
+//   WAR  stage s + 3 overwrites the slot of stage s - 1, whose last reads (waves 4-7, L(s-1)) are complete before
+//        #2s (s_waitcnt lgkmcnt(0) ends every L segment); the DMA is issued in L(s), after #2s.
+// vmcnt counts stores too and retires in order, so the epilogue's stores sit between the DMA groups of a wave's queue:
+// the first wait after an epilogue leaves only the youngest stage in flight (it also waits for the store
+// acknowledgements; once per tile).
+//
+// A DMA wave-instruction writes 1 KiB of LDS linearly (lane l -> base + 16 l), so the stage images are unpadded and
+// bank conflicts are removed by permuting, per row, WHICH 16-byte chunk of global memory each lane fetches
 // (cdna_hip_programming.md rule 21); the fragment reads apply the same permutation:
 //   k-contiguous operand  image [R][32 k] (64-B rows):   chunk c of row r lives at slot c ^ f((r >> 2) & 3), f = {0,2,3,1}
-//                         (the 16 lanes of a ds_read_b128 group then cover all 64 banks)
 //   k-strided operand     image [32 k][R] (2R-B rows):   chunk c of k-row kr lives at slot c ^ (2 g(kr)),
 //                         g(kr) = (kr & 3) | ((kr >> 3) & 1) << 2   (the 8 k-rows one ds_read_b64_tr_b16 lane group
 //                         touches get 8 different 32-byte slots of a 256-byte bank row)
-// Rows / columns outside the matrix are clamped in-bounds (they only feed dropped outputs); a partial last K-stage is
-// fetched from clamped addresses and its k >= K part is zeroed in LDS before use.  The ring drains at the end of a
-// tile (the epilogue's strips reuse the stage buffers), so a tile pays one load latency; K >= 1000 amortises it.
+// Rows / columns outside the matrix are clamped in-bounds (they only feed dropped outputs).  A partial last K-stage is
+// fetched from clamped addresses and the k >= K elements of the A fragments are masked to zero in registers (one
+// operand suffices: the other one is finite data).
+//
+// The MFMA operands are passed swapped (B fragment first), which leaves C transposed in the accumulators: a lane holds
+// FOUR CONSECUTIVE COLUMNS of one row, so the epilogue runs straight from registers with 16-byte (fp32) / 8-byte (bf16)
+// accesses -- no LDS strips, hence nothing that would collide with the running ring.
+//
+// Split-K (weight gradients: K = all frames of the batch): every (tile, K-slice) workgroup stores its partial tile
+// into a slab of its own with plain stores and splitk_reduce_kernel adds the slabs into C.  (Float atomics run at
+// ~1.3 TB/s chip-wide; a 256 x 256 tile per CU is 64 MB of them per GEMM = a 50 us tail.)
+//
+// Grouped launches: up to kMaxGemmGroups problems of identical shape and flags (the S input streams' encoder GEMMs)
+// share one tile list, which fills the last round of 256 CUs far better than each alone (656 tiles = 2.56 rounds;
+// 3 x 656 = 7.7).
 // ---------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-constexpr int kDmaBM = 256, kDmaBN = 256, kDmaBK = 32, kDmaStages = 4;
+constexpr int kPpBK = 32, kPpNS = 4, kPpD = 3;
 
 // One LDS-DMA wave-instruction: lane l fetches 16 bytes from its own global address into LDS byte address
 // lds_dst + 16 l (lds_dst wave-uniform, in an SGPR).  Inline asm on purpose: hipcc orders every ds_read behind a
 // pending __builtin_amdgcn_global_load_lds with s_waitcnt vmcnt(0), which would drain the stages this kernel keeps in
-// flight; the waits are counted by hand instead (s_waitcnt vmcnt(N) + s_barrier in the K-loop).  M0 (the DMA
-// destination base) is compiler-reserved, hence saved and restored (cdna_hip_programming.md, LDS-DMA recipe).
+// flight; the waits are counted by hand instead.  M0 (the DMA destination base) is compiler-reserved, hence saved and
+// restored (cdna_hip_programming.md, LDS-DMA recipe).
 __device__ __forceinline__ void glds16(const __bf16* g, unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -576,193 +608,319 @@ __device__ __forceinline__ void glds16(const __bf16* g, unsigned lds_dst) {
 __device__ __forceinline__ int swz_g(int kr) { return (kr & 3) | (((kr >> 3) & 1) << 2); }
 __device__ __forceinline__ int swz_f(int q) { return (0x1320 >> (4 * q)) & 3; }     // {0, 2, 3, 1}
 
-#ifdef ADN_GEMM_STAMPS
-__device__ unsigned long long g_gstamps[8];
-__device__ __forceinline__ unsigned long long gstamp_now() {
-    unsigned long long t;
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
-    return t;
+// group `g` of a grouped launch by value (explicit selects: a dynamic index into the kernel-argument block makes hipcc
+// copy the whole block to scratch, and scratch traffic would sit in the vmcnt queue this kernel counts by hand)
+__device__ __forceinline__ GemmGroup pick_group(const GemmParams& p, int g) {
+    GemmGroup r = p.grp[0];
+    if (g == 1) r = p.grp[1];
+    if (g == 2) r = p.grp[2];
+    if (g == 3) r = p.grp[3];
+    return r;
 }
-#define GSTAMP(k) do { if (blockIdx.x == 7 && blockIdx.y == 0 && (tid == 0 || tid == 256)) { const unsigned long long n_ = gstamp_now(); \
-    atomicAdd(&g_gstamps[k], n_ - gl_); gl_ = n_; } } while (0)
-#define GSTAMP_INIT unsigned long long gl_ = gstamp_now();
-#else
-#define GSTAMP(k) do {} while (0)
-#define GSTAMP_INIT
-#endif
 
-template <bool A_KC>
-__global__ __launch_bounds__(512) void gemm_bf16_dma_kernel(const GemmParams p) {
-    constexpr int BM = kDmaBM, BN = kDmaBN, BK = kDmaBK, NS = kDmaStages;
-    constexpr int TM = 4, TN = 8;                                  // per wave: 64 x 128
-    constexpr int kAElems = BM * BK, kBElems = BK * BN, kStageElems = kAElems + kBElems;   // 32 KiB per stage
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N <= 63, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+
+// one float4 of the transposed-accumulator epilogue: 4 consecutive columns of one row.  ONE body for every flag
+// combination the host routes here (linear / rectify output, optional rectify'(Y) mask from the bf16 copy of Y,
+// optional accumulate), with wave-uniform branches: compile-time variants of this fully unrolled epilogue made the
+// kernel ~50 k instructions, the K-loop then straddled that block and the kernel ran instruction-fetch bound (SQ_WAIT_INST_ANY
+// 83 % of the wave cycles, 6.7x the L2 requests: 90 TFLOP/s instead of 700).
+template <bool SPLIT>
+__device__ __forceinline__ void pp_epi4(const GemmParams& p, const GemmGroup& gp, float* Cg, f32x4 a, const float4& bias4,
+                                        int row, int col, float4& csum) {
+    const size_t off = (size_t)row * p.ldc + col;
+    float4 v = make_float4(a[0], a[1], a[2], a[3]);
+    if (SPLIT) { *reinterpret_cast<float4*>(Cg + off) = v; return; }
+    v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+    if (p.act == ADN_ACT_RECTIFY) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (gp.Y16) {                                                  // rectify'(Y): the host sends nothing else here
+        const bf16x4 y = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(gp.Y16) + (size_t)row * p.ldy + col);
+        v.x = (float)y[0] > 0.f ? v.x : 0.f; v.y = (float)y[1] > 0.f ? v.y : 0.f;
+        v.z = (float)y[2] > 0.f ? v.z : 0.f; v.w = (float)y[3] > 0.f ? v.w : 0.f;
+    }
+    if (p.accumulate) {
+        const float4 c = *reinterpret_cast<const float4*>(Cg + off);
+        v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w;
+    }
+    if (Cg) *reinterpret_cast<float4*>(Cg + off) = v;
+    if (gp.C16) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(gp.C16) + off) = cvt4(v);
+    csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w;
+}
+
+template <int BM, int BN, bool A_KC, bool SPLIT>
+__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
+    constexpr int BK = kPpBK, NS = kPpNS, D = kPpD;
+    constexpr int WTM = BM / 4, WTN = BN / 2, TM = WTM / 16, TN = WTN / 16;
+    constexpr int kAElems = BM * BK, kBElems = BK * BN, kStageElems = kAElems + kBElems;
+    constexpr int APW = BM / 128, BPW = BN / 128, PW = APW + BPW;      // 1-KiB DMA pieces per wave and stage
     __shared__ __attribute__((aligned(1024))) __bf16 smem[NS * kStageElems];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int ntiles = p.tiles_m * p.tiles_n;
-    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int kbeg = blockIdx.y * p.k_chunk;
+    const bool late = wave >= 4;                                   // the half that runs one barrier behind
+    const int per_group = p.tiles_m * p.tiles_n;
+    const int ntiles = per_group * p.ngroups;
+    const int G = (int)gridDim.x;
+    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
+    const int kbeg = (int)blockIdx.y * p.k_chunk;
     const int kend = min(p.K, kbeg + p.k_chunk);
     const int nk = (kend - kbeg + BK - 1) / BK;
-    const int ktail = (kend - kbeg) - (nk - 1) * BK;          // valid k of the last stage (1..32)
+    const int ktail = (kend - kbeg) - (nk - 1) * BK;               // valid k of the last stage (1..32)
     const bool has_tail = ktail < BK;
-
-    const __bf16* A16 = reinterpret_cast<const __bf16*>(p.A16);
-    const __bf16* B16 = reinterpret_cast<const __bf16*>(p.B16);
+    const int total = my_tiles * nk;                               // K-steps of this workgroup's whole tile list
+    if (total <= 0) return;
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_void_t*)smem;
 
-    // ---- DMA side: 16 wave-instructions per operand and stage, 2 + 2 per wave ------------------------------
-    const __bf16* srcA[2]; const __bf16* srcB[2];
-    int a_aux[2], b_row[2];  // A_KC: lane's k offset inside the stage; k-strided: lane's k-row inside the stage
+    // ---- DMA side ------------------------------------------------------------------------------------
+    // k-strided operand of width R: CPR = R / 8 chunks per k-row, one piece = 64 / CPR k-rows
+    constexpr int A_CPR = BM / 8, B_CPR = BN / 8;
+    const __bf16* srcA[APW]; const __bf16* srcB[BPW];
+    int a_aux[APW], b_row[BPW];      // A_KC: the lane's k offset inside a stage; k-strided: its k-row inside a stage
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        a_aux[t] = A_KC ? ((lane & 3) ^ swz_f((lane >> 4) & 3)) * 8 : 2 * (wave * 2 + t) + (lane >> 5);
-        b_row[t] = 2 * (wave * 2 + t) + (lane >> 5);
-    }
-    auto setup_src = [&](int tm, int tn) {
+    for (int t = 0; t < APW; ++t)
+        a_aux[t] = A_KC ? ((lane & 3) ^ swz_f((lane >> 4) & 3)) * 8 : (64 / A_CPR) * (wave * APW + t) + lane / A_CPR;
+#pragma unroll
+    for (int t = 0; t < BPW; ++t) b_row[t] = (64 / B_CPR) * (wave * BPW + t) + lane / B_CPR;
+    auto tile_of = [&](int ord, int& grp, int& tm, int& tn) {      // ord-th tile of this workgroup
+        const int q = xcd_tile((int)blockIdx.x + ord * G, ntiles);
+        grp = q / per_group;
+        tile_coords(p, q - grp * per_group, tm, tn);
+    };
+    auto setup_src = [&](int ord) {
+        int grp, tm, tn;
+        tile_of(ord, grp, tm, tn);
+        const GemmGroup sg = pick_group(p, grp);
+        const __bf16* A16 = reinterpret_cast<const __bf16*>(sg.A16);
+        const __bf16* B16 = reinterpret_cast<const __bf16*>(sg.B16);
         const int m0 = tm * BM, n0 = tn * BN;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < APW; ++t) {
             if (A_KC) {
-                const int row = 16 * (wave * 2 + t) + (lane >> 2);
+                const int row = 16 * (wave * APW + t) + (lane >> 2);
                 srcA[t] = A16 + (size_t)min(m0 + row, p.M - 1) * p.lda + kbeg + a_aux[t];
             } else {
-                int col = m0 + (((lane & 31) ^ (swz_g(a_aux[t]) << 1)) * 8);
+                int col = m0 + (((lane % A_CPR) ^ (swz_g(a_aux[t]) << 1)) * 8);
                 if (col + 8 > p.lda) col = 0;
                 srcA[t] = A16 + (size_t)(kbeg + a_aux[t]) * p.lda + col;
             }
-            int col = n0 + (((lane & 31) ^ (swz_g(b_row[t]) << 1)) * 8);
+        }
+#pragma unroll
+        for (int t = 0; t < BPW; ++t) {
+            int col = n0 + (((lane % B_CPR) ^ (swz_g(b_row[t]) << 1)) * 8);
             if (col + 8 > p.ldb) col = 0;
             srcB[t] = B16 + (size_t)(kbeg + b_row[t]) * p.ldb + col;
         }
     };
     const size_t a_step = A_KC ? (size_t)BK : (size_t)BK * p.lda;
     const size_t b_step = (size_t)BK * p.ldb;
-    auto issue = [&](int slot, int kt, auto tail_c) {         // K-stage kt of the current tile -> ring slot
+    int is_k = 0, is_ord = 0, is_step = 0;                         // next stage to issue: K-step inside its tile, tile, global step
+    auto issue_one = [&](auto tail_c) {
         constexpr bool tail = decltype(tail_c)::value;
-        const unsigned As = lds_base + (unsigned)(slot * kStageElems * 2);
+        const unsigned As = lds_base + (unsigned)((is_step & (NS - 1)) * kStageElems * 2);
         const unsigned Bs = As + kAElems * 2;
-        const int k0 = kbeg + kt * BK;
+        const int k0 = kbeg + is_k * BK;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < APW; ++t) {
             const __bf16* g = srcA[t];
             if (tail) {
-                if (A_KC) { if (k0 + a_aux[t] + 8 > kend) g -= (k0 + a_aux[t] + 8 - kend); }
+                if (A_KC) { if (k0 + a_aux[t] >= kend) g -= (k0 + a_aux[t] - (kend - 8)); }
                 else if (k0 + a_aux[t] >= kend) g -= (size_t)(k0 + a_aux[t] - (kend - 1)) * p.lda;
             }
-            glds16(g, __builtin_amdgcn_readfirstlane(As + (wave * 2 + t) * 1024));
+            glds16(g, __builtin_amdgcn_readfirstlane(As + (wave * APW + t) * 1024));
             srcA[t] += a_step;
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < BPW; ++t) {
             const __bf16* g = srcB[t];
             if (tail && k0 + b_row[t] >= kend) g -= (size_t)(k0 + b_row[t] - (kend - 1)) * p.ldb;
-            glds16(g, __builtin_amdgcn_readfirstlane(Bs + (wave * 2 + t) * 1024));
+            glds16(g, __builtin_amdgcn_readfirstlane(Bs + (wave * BPW + t) * 1024));
             srcB[t] += b_step;
         }
     };
-    auto issue_any = [&](int slot, int kt) {
-        if (has_tail && kt == nk - 1) issue(slot, kt, std::true_type{});
-        else issue(slot, kt, std::false_type{});
+    auto issue_next = [&]() {
+        if (has_tail && is_k == nk - 1) issue_one(std::true_type{});
+        else issue_one(std::false_type{});
+        ++is_step;
+        if (++is_k == nk) {
+            is_k = 0;
+            if (++is_ord < my_tiles) setup_src(is_ord);
+        }
     };
 
     // ---- per-lane fragment addresses (bytes inside a stage) -------------------------------------------
     const int q = (lane & 15) >> 2, pp = lane & 3, hi = lane >> 4;
-    const int g_lane = q | ((hi & 1) << 2);                   // swz_g of every k-row this lane reads
+    const int g_lane = q | ((hi & 1) << 2);                        // swz_g of every k-row this lane reads
     int a_off[TM], b_off[TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
-        if (A_KC) a_off[a] = (wm * 64 + a * 16 + (lane & 15)) * 64 + ((hi ^ swz_f(q)) << 4);
-        else a_off[a] = (hi * 8 + q) * (BM * 2) + ((((wm * 8 + a * 2 + (pp >> 1)) ^ (g_lane << 1))) << 4) + (pp & 1) * 8;
+        if (A_KC) a_off[a] = (wm * WTM + a * 16 + (lane & 15)) * 64 + ((hi ^ swz_f(q)) << 4);
+        else a_off[a] = (hi * 8 + q) * (BM * 2) + ((((wm * WTM + a * 16) / 8 + (pp >> 1)) ^ (g_lane << 1)) << 4) + (pp & 1) * 8;
     }
 #pragma unroll
     for (int b = 0; b < TN; ++b)
-        b_off[b] = (hi * 8 + q) * (BN * 2) + ((((wn * 16 + b * 2 + (pp >> 1)) ^ (g_lane << 1))) << 4) + (pp & 1) * 8;
+        b_off[b] = (hi * 8 + q) * (BN * 2) + ((((wn * WTN + b * 16) / 8 + (pp >> 1)) ^ (g_lane << 1)) << 4) + (pp & 1) * 8;
+    // k >= K mask of an A fragment in the last stage: element j of this lane is k = 8 hi + j
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 amask;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        amask[j] = ((8 * hi + 2 * j < ktail) ? 0x0000FFFFu : 0u) | ((8 * hi + 2 * j + 1 < ktail) ? 0xFFFF0000u : 0u);
 
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     f32x4 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int ti = 0; ti < my_tiles; ++ti) {
-        int tile_m, tile_n;
-        tile_coords(p, xcd_tile((int)blockIdx.x + ti * (int)gridDim.x, ntiles), tile_m, tile_n);
-        const int m0 = tile_m * BM, n0 = tile_n * BN;
+    // wait until this wave's pieces of stage s + 1 have landed; `fresh_epi`: an epilogue's stores are in the queue
+    auto wait_next = [&](int s, bool fresh_epi) {
+        int younger = min(D - 1, total - 2 - s);                   // younger stages this wave has issued
+        if (younger < 0) return;                                   // there is no stage s + 1
+        if (fresh_epi) younger = min(younger, 1);
+        if (younger >= 2) wait_vmcnt<2 * PW>();
+        else if (younger == 1) wait_vmcnt<PW>();
+        else wait_vmcnt<0>();
+    };
+
+    // ---- prologue: D stages in flight, stage 0 landed for everyone -----------------------------------
+    setup_src(0);
+    for (int s = 0; s < D && s < total; ++s) issue_next();
+    wait_next(-1, false);
+    __builtin_amdgcn_s_barrier();                                  // #0
+    if (late) __builtin_amdgcn_s_barrier();                        // the lower half starts one segment later
+
+    int kt = 0, ord = 0;
+    int grp, tile_m, tile_n;
+    tile_of(0, grp, tile_m, tile_n);
+    for (int s = 0; s < total; ++s) {
+        // ---------------- L(s): fragments of stage s -> registers, DMA for stage s + D
+        const char* As = reinterpret_cast<const char*>(smem + (s & (NS - 1)) * kStageElems);
+        const char* Bs = As + kAElems * 2;
+        bf16x8 fa[TM], fb[TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            if (A_KC) {
+                fa[a] = *reinterpret_cast<const bf16x8*>(As + a_off[a]);
+            } else {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(As + a_off[a]));
+                const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(As + a_off[a] + 4 * (BM * 2)));
+                fa[a] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Bs + b_off[b]));
+            const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Bs + b_off[b] + 4 * (BN * 2)));
+            fb[b] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+        if (s + D < total) issue_next();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_tail && kt == nk - 1) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a) fa[a] = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4, fa[a]) & amask);
+        }
+        if (late) wait_next(s, kt == 0 && s > 0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------------- C(s)
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        setup_src(tile_m, tile_n);
-        __syncthreads();                                      // the previous tile's epilogue is done with the LDS
-        for (int kt = 0; kt < NS - 1 && kt < nk; ++kt) issue_any(kt, kt);
-        GSTAMP_INIT
-        for (int kt = 0; kt < nk; ++kt) {
-            // stage kt landed (this wave's part); up to NS - 2 younger stages stay in flight
-            const int younger = min(NS - 2, nk - 1 - kt);
-            if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            GSTAMP(0);
-            __builtin_amdgcn_s_barrier();                     // everyone's part landed; slot (kt - 1) % NS is free
-            GSTAMP(1);
-            // The two waves that share a SIMD (w and w + 4) issue their DMA at different ends of the step: issuing 4
-            // pieces costs a wave ~800 cycles of front-end time (TA back-pressure), during which the other one owns
-            // the MFMA pipe.  (Both positions are behind the barrier, so the slot being refilled is no longer read.)
-            const bool issue_early = wave < 4;
-            if (issue_early && kt + NS - 1 < nk) issue_any((kt + NS - 1) % NS, kt + NS - 1);
-            GSTAMP(2);
-            const char* As = reinterpret_cast<const char*>(smem + (kt % NS) * kStageElems);
-            const char* Bs = As + kAElems * 2;
-            if (has_tail && kt == nk - 1) {                   // zero the k >= ktail part of both images
-                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (A_KC) {
-                    for (int e = tid; e < BM * 4; e += 512) { // (row, chunk)
-                        const int r = e >> 2, c = e & 3;
-                        if (c * 8 >= ktail)
-                            *reinterpret_cast<float4*>(const_cast<char*>(As) + r * 64 + ((c ^ swz_f((r >> 2) & 3)) << 4)) = z;
-                    }
-                } else {
-                    for (int e = tid; e < BK * (BM / 8); e += 512)
-                        if (e / (BM / 8) >= ktail) *reinterpret_cast<float4*>(const_cast<char*>(As) + e * 16) = z;
-                }
-                for (int e = tid; e < BK * (BN / 8); e += 512)
-                    if (e / (BN / 8) >= ktail) *reinterpret_cast<float4*>(const_cast<char*>(Bs) + e * 16) = z;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
-            bf16x8 fa[TM], fb[TN];
-#pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                if (A_KC) {
-                    fa[a] = *reinterpret_cast<const bf16x8*>(As + a_off[a]);
-                } else {
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(As + a_off[a]));
-                    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(As + a_off[a] + 4 * (BM * 2)));
-                    fa[a] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
-                }
-            }
-#pragma unroll
+            for (int b = 0; b < TN; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[b], fa[a], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (!late) wait_next(s, kt == 0 && s > 0);
+        if (__builtin_expect(kt == nk - 1, 0)) {
+            // ---- epilogue of tile `ord`, straight from the (transposed) accumulators: lane = row (lane & 15),
+            //      columns 4 hi .. 4 hi + 3 of every 16-column block
+            const GemmGroup gp = pick_group(p, grp);
+            float* Cg = SPLIT ? p.partial + ((size_t)(grp * (int)gridDim.y + (int)blockIdx.y) * p.M) * p.ldc : gp.C;
+            const int row0 = tile_m * BM + wm * WTM + (lane & 15), col0 = tile_n * BN + wn * WTN + 4 * hi;
+#pragma clang loop unroll(full)
             for (int b = 0; b < TN; ++b) {
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Bs + b_off[b]));
-                const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Bs + b_off[b] + 4 * (BN * 2)));
-                fb[b] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+                const int col = col0 + b * 16;
+                if (col >= p.N) continue;
+                float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), csum = bias4;
+                if (!SPLIT && gp.bias) bias4 = *reinterpret_cast<const float4*>(gp.bias + col);
+#pragma clang loop unroll(full)
+                for (int a = 0; a < TM; ++a) {
+                    const int row = row0 + a * 16;
+                    if (row < p.M) pp_epi4<SPLIT>(p, gp, Cg, acc[a][b], bias4, row, col, csum);
+                }
+                if (!SPLIT && gp.colsum) {                         // column sums over this wave's WTM rows
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) {
+                        csum.x += __shfl_xor(csum.x, o, 64); csum.y += __shfl_xor(csum.y, o, 64);
+                        csum.z += __shfl_xor(csum.z, o, 64); csum.w += __shfl_xor(csum.w, o, 64);
+                    }
+                    if ((lane & 15) == 0)
+                        *reinterpret_cast<float4*>(gp.colsum + (size_t)(tile_m * 4 + wm) * p.colsum_ld + col) = csum;
+                }
             }
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int b = 0; b < TN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
-            if (!issue_early && kt + NS - 1 < nk) issue_any((kt + NS - 1) % NS, kt + NS - 1);
-            GSTAMP(3);
-        }
-        // ---- epilogue: nothing is in flight; the strips reuse the stage buffers
-        if (p.atomic) {
-            __syncthreads();
-            float* strip = reinterpret_cast<float*>(smem) + wave * (16 * (TN * 16 + 4));
-            tile_epilogue_atomic<TM, TN>(p, acc, strip, m0 + wm * 64, n0 + wn * 128, lane);
+                for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (++ord < my_tiles) tile_of(ord, grp, tile_m, tile_n);
+            kt = 0;
         } else {
-            gemm_epilogue<4, TM, TN>(p, acc, smem, m0, n0, tile_m, wave, lane);
+            ++kt;
         }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!late) __builtin_amdgcn_s_barrier();                       // every wave executes the same number of barriers
+}
+
+// C (+)= sum of the split-K partial slabs ([group][split][M][ldc] floats); float4 per lane
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, int splits) {
+    const size_t slab4 = (size_t)p.M * p.ldc / 4;                 // float4 per slab; pad columns (>= N) are never touched
+    const int n4 = p.N / 4, ld4 = p.ldc / 4;
+    const size_t work = (size_t)p.M * n4;
+    for (int g = 0; g < p.ngroups; ++g) {
+        const float4* part = reinterpret_cast<const float4*>(p.partial) + (size_t)g * splits * slab4;
+        float4* C = reinterpret_cast<float4*>(pick_group(p, g).C);
+        for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < work; e += (size_t)gridDim.x * 256) {
+            const size_t i = (e / n4) * ld4 + (e % n4);
+            float4 v = p.accumulate ? C[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int s = 0; s < splits; ++s) {
+                const float4 w = part[(size_t)s * slab4 + i];
+                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+            }
+            C[i] = v;
+        }
+    }
+}
+
+template <int BM, int BN>
+static void launch_pp_t(const GemmParams& p, int layout, bool split, dim3 grid, hipStream_t s) {
+    if (layout == GEMM_NN) {
+        if (split) hipLaunchKernelGGL((gemm_bf16_pp_kernel<BM, BN, true, true>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((gemm_bf16_pp_kernel<BM, BN, true, false>), grid, dim3(512), 0, s, p);
+    } else {
+        if (split) hipLaunchKernelGGL((gemm_bf16_pp_kernel<BM, BN, false, true>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((gemm_bf16_pp_kernel<BM, BN, false, false>), grid, dim3(512), 0, s, p);
+    }
+}
+
+// tile_mode: 4 = 256 x 256, 5 = 256 x 128, 6 = 128 x 256
+void launch_gemm_bf16_pp(const GemmParams& p, int layout, int tile_mode, int splits, dim3 grid, hipStream_t s) {
+    const bool split = splits > 1;
+    if (tile_mode == 4) launch_pp_t<256, 256>(p, layout, split, grid, s);
+    else if (tile_mode == 5) launch_pp_t<256, 128>(p, layout, split, grid, s);
+    else launch_pp_t<128, 256>(p, layout, split, grid, s);
+    if (split) {
+        const size_t n4 = (size_t)p.M * (p.N / 4);
+        const int blocks = (int)std::min<size_t>(2048, (n4 + 255) / 256);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p, splits);
     }
 }
 
@@ -780,10 +938,7 @@ void launch_gemm_bf16(const GemmParams& p, int layout, int tile_mode, dim3 grid,
     const bool shadows = p.A16 && p.B16;      // operands already available as bf16 copies
     const bool big = tile_mode >= 1;
     if (shadows) {
-        if (tile_mode == 3) {                 // LDS-DMA pipelined 256x128 kernel (NN / TN)
-            if (layout == GEMM_NN) hipLaunchKernelGGL((gemm_bf16_dma_kernel<true>), grid, dim3(512), 0, s, p);
-            else hipLaunchKernelGGL((gemm_bf16_dma_kernel<false>), grid, dim3(512), 0, s, p);
-        } else if (big) launch_bf16_t<128, 128, 2, __bf16>(p, layout, grid, s);
+        if (big) launch_bf16_t<128, 128, 2, __bf16>(p, layout, grid, s);
         else launch_bf16_t<64, 64, 2, __bf16>(p, layout, grid, s);
     } else {
         if (big) launch_bf16_t<128, 128, 2, float>(p, layout, grid, s);
@@ -864,10 +1019,3 @@ int to_bf16(const float* src, void* dst, size_t n, hipStream_t s) {
 
 }  // namespace adn
 
-#ifdef ADN_GEMM_STAMPS
-extern "C" int adn_debug_gemm_stamps(unsigned long long* out, int reset) {
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(adn::g_gstamps), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
-    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(adn::g_gstamps), z, sizeof(z)) != hipSuccess) return 1; }
-    return 0;
-}
-#endif

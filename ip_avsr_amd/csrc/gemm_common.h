@@ -7,6 +7,16 @@ namespace adn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// one problem of a grouped launch (gemm_bf16_pp_kernel): same shape, leading dimensions and flags, own buffers
+constexpr int kMaxGemmGroups = 4;
+struct GemmGroup {
+    const void* A16; const void* B16;
+    float* C; void* C16;
+    const void* Y16; const float* Y;
+    const float* bias;
+    float* colsum;
+};
+
 struct GemmParams {
     int M, N, K;
     const float* A; int lda;
@@ -21,6 +31,10 @@ struct GemmParams {
     int k_chunk;
     int tiles_m, tiles_n;
     int panel_n;        // tiles are enumerated panel-major: panels of `panel_n` tile columns, m outer / n inner inside
+    // ping-pong kernel only
+    int ngroups;
+    float* partial;     // split-K partial slabs [group][split][M][ldc]
+    GemmGroup grp[kMaxGemmGroups];
 };
 
 __device__ __forceinline__ float act_apply(int act, float v) {
@@ -95,7 +109,8 @@ __device__ __forceinline__ void store_tile32(const GemmParams& p, const f32x16& 
 }
 
 // defined in gemm_bf16.hip
-void launch_gemm_bf16(const GemmParams& p, int layout, int tile_mode /*0: 64x64, 1: 128x128, 3: LDS-DMA 256x128*/, dim3 grid,
-                      hipStream_t s);
+void launch_gemm_bf16(const GemmParams& p, int layout, int tile_mode /*0: 64x64, 1: 128x128*/, dim3 grid, hipStream_t s);
+// persistent ping-pong LDS-DMA kernel; tile_mode 4: 256x256, 5: 256x128, 6: 128x256; splits > 1: partial slabs + reduce
+void launch_gemm_bf16_pp(const GemmParams& p, int layout, int tile_mode, int splits, dim3 grid, hipStream_t s);
 
 }  // namespace adn

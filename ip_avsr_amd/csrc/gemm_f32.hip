@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 namespace adn {
 
@@ -162,6 +163,142 @@ static void launch(const GemmParams& p, int layout, dim3 grid, hipStream_t s) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Persistent ping-pong kernel (gemm_bf16.hip): applicability, tile shape, split-K and grouping
+// ---------------------------------------------------------------------------------------------------------
+static int device_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+    }
+    return cus;
+}
+
+// Runs `n` problems of identical shape / layout / flags through the ping-pong kernel if it applies; *used says whether.
+static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used) {
+    *used = false;
+    const GemmArgs& g = gs[0];
+    static const int mode_env = getenv("ADN_GEMM_PP") ? atoi(getenv("ADN_GEMM_PP")) : -1;   // 0: off, 4/5/6: force a tile shape
+    if (mode_env == 0 || n > kMaxGemmGroups) return ADN_OK;
+    if (g.precision != ADN_PRECISION_BF16 || g.layout == GEMM_NT) return ADN_OK;
+    if (g.M < 1024 && g.N < 1024) return ADN_OK;
+    if (g.M < 256 || g.N < 256 || g.K < 256) return ADN_OK;
+    if (g.N % 4 || g.ldc % 4 || g.lda % 8 || g.ldb % 8) return ADN_OK;
+    if (g.layout == GEMM_NN && g.K % 8 && g.lda < round_up(g.K, 8)) return ADN_OK;
+    // epilogue forms of the kernel: linear / rectify output; optional rectify'(Y) from the bf16 copy of Y
+    if (g.act != ADN_ACT_LINEAR && g.act != ADN_ACT_RECTIFY) return ADN_OK;
+    if ((g.Y || g.Y16) && g.act_grad != ADN_ACT_LINEAR && (g.act_grad != ADN_ACT_RECTIFY || !g.Y16 || g.ldy % 4)) return ADN_OK;
+    for (int k = 0; k < n; ++k) {
+        const GemmArgs& q = gs[k];
+        if (!q.A16 || !q.B16 || ((uintptr_t)q.A16 % 16) || ((uintptr_t)q.B16 % 16)) return ADN_OK;
+        if (!q.C && !q.C16) return ADN_OK;
+        if ((q.C && ((uintptr_t)q.C % 16)) || (q.C16 && ((uintptr_t)q.C16 % 8))) return ADN_OK;
+        if ((q.Y && ((uintptr_t)q.Y % 16)) || (q.Y16 && ((uintptr_t)q.Y16 % 8)) || (q.bias && ((uintptr_t)q.bias % 16))) return ADN_OK;
+        if (q.M != g.M || q.N != g.N || q.K != g.K || q.lda != g.lda || q.ldb != g.ldb || q.ldc != g.ldc || q.ldy != g.ldy ||
+            q.layout != g.layout || q.act != g.act || q.act_grad != g.act_grad || q.accumulate != g.accumulate ||
+            q.no_split != g.no_split || (q.C == nullptr) != (g.C == nullptr) || (q.C16 == nullptr) != (g.C16 == nullptr) ||
+            (q.bias == nullptr) != (g.bias == nullptr) || (q.Y16 == nullptr) != (g.Y16 == nullptr) ||
+            (q.Y == nullptr) != (g.Y == nullptr) || (q.colsum == nullptr) != (g.colsum == nullptr))
+            return ADN_OK;
+    }
+    const int cus = device_cus();
+    const bool lean_c = !g.C;
+    const bool can_split = g.act == ADN_ACT_LINEAR && !lean_c && !g.no_split && !g.bias && !g.Y && !g.Y16 && !g.colsum;
+    // ---- tile shape: fewest tile-rounds weighted by the shape's relative rate; split-K only with the square tile
+    struct Cand { int mode, bm, bn; double rate; };
+    static const Cand cands[3] = {{4, 256, 256, 1.0}, {5, 256, 128, 0.80}, {6, 128, 256, 0.80}};
+    int best = -1, splits = 1; double best_cost = 0;
+    for (int c = 0; c < 3; ++c) {
+        if (mode_env >= 4 && cands[c].mode != mode_env) continue;
+        const int64_t tiles = (int64_t)cdiv(g.M, cands[c].bm) * cdiv(g.N, cands[c].bn) * n;
+        int sp = 1;
+        if (tiles * 2 <= cus && can_split && g.K >= 2048) {
+            if (cands[c].mode != 4) continue;
+            sp = (int)std::min<int64_t>(cus / tiles, g.K / 512);
+        }
+        const int64_t rounds = (tiles * sp + cus - 1) / cus;
+        const double cost = (double)rounds * cands[c].bm * cands[c].bn / sp / cands[c].rate;
+        if (best < 0 || cost < best_cost) { best = c; best_cost = cost; splits = sp; }
+    }
+    if (best < 0) return ADN_OK;
+    // useful work per CU-round vs what the register-staged kernels deliver (~0.62 of this kernel's rate at full tiles)
+    const double ideal = (double)g.M * g.N * n / cus;
+    if (mode_env < 4 && ideal / best_cost < 0.55) return ADN_OK;
+    const Cand& cd = cands[best];
+
+    GemmParams p;
+    std::memset(static_cast<void*>(&p), 0, sizeof(p));
+    p.M = g.M; p.N = g.N; p.K = g.K; p.lda = g.lda; p.ldb = g.ldb; p.ldc = g.ldc; p.ldy = g.ldy;
+    p.act = g.act; p.act_grad = g.act_grad; p.accumulate = g.accumulate;
+    p.tiles_m = cdiv(g.M, cd.bm); p.tiles_n = cdiv(g.N, cd.bn);
+    p.k_chunk = (int)round_up(cdiv(g.K, splits), 32);
+    splits = cdiv(g.K, p.k_chunk);
+    p.ngroups = n;
+    const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n * n;
+    const int cs_ld = (int)round_up(g.N, 4);
+    if (splits > 1) {
+        const size_t need = (size_t)n * splits * g.M * g.ldc;
+        if (!g.splitk_ws || need > g.splitk_ws_floats || ((uintptr_t)g.splitk_ws % 16)) return ADN_OK;
+        p.partial = g.splitk_ws;
+    }
+    bool fused_colsum = false;
+    if (g.colsum && splits == 1) {
+        fused_colsum = true;
+        for (int k = 0; k < n; ++k)
+            if (!gs[k].colsum_ws || ((uintptr_t)gs[k].colsum_ws % 16) || (size_t)p.tiles_m * 4 * cs_ld > gs[k].colsum_ws_floats) fused_colsum = false;
+    }
+    p.colsum_ld = cs_ld;
+    for (int k = 0; k < n; ++k) {
+        GemmGroup& q = p.grp[k];
+        q.A16 = gs[k].A16; q.B16 = gs[k].B16; q.C = gs[k].C; q.C16 = splits > 1 ? nullptr : gs[k].C16;
+        q.Y16 = (g.act_grad == ADN_ACT_RECTIFY) ? gs[k].Y16 : nullptr; q.Y = nullptr; q.bias = gs[k].bias;
+        q.colsum = fused_colsum ? gs[k].colsum_ws : nullptr;
+        if (gs[k].colsum_done) *gs[k].colsum_done = fused_colsum ? 1 : 0;
+    }
+    {   // square-ish per-XCD tile blocks (per group)
+        const int chunk = (int)std::max<int64_t>(1, (int64_t)p.tiles_m * p.tiles_n / 8);
+        p.panel_n = std::max(1, std::min((int)std::lround(std::sqrt((double)chunk)), p.tiles_n));
+    }
+    int gx = (int)std::min<int64_t>(tiles, cus / splits);
+    if (gx >= 8) gx = gx / 8 * 8;             // a workgroup's tiles then stay on its own XCD's chunk of the tile list
+    static const bool trace = getenv("ADN_GEMM_TRACE") != nullptr;
+    if (trace)
+        fprintf(stderr, "ADN_GEMM %s M=%d N=%d K=%d tile=%d tiles=%lld split=%d shadows=1 lean=%d acc=%d groups=%d\n",
+                g.layout == GEMM_NN ? "NN" : "TN", g.M, g.N, g.K, cd.bm * 1000 + cd.bn, (long long)tiles, splits, (int)lean_c,
+                g.accumulate, n);
+    {
+        ProfScope prof(PROF_GEMM_NN + g.layout, 2.0 * g.M * g.N * g.K * n,
+                       4.0 * n * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N), stream, n);
+        launch_gemm_bf16_pp(p, g.layout, cd.mode, splits, dim3((unsigned)gx, (unsigned)splits), stream);
+        ADN_HIP_CHECK(hipGetLastError());
+    }
+    for (int k = 0; k < n; ++k) {
+        if (fused_colsum) {
+            if (gs[k].colsum_batch && gs[k].colsum_batch->n < 8)
+                col_sum_batch_add(*gs[k].colsum_batch, gs[k].colsum_ws, cs_ld, p.tiles_m * 4, g.N, gs[k].colsum);
+            else ADN_TRY(col_sum(gs[k].colsum_ws, cs_ld, p.tiles_m * 4, g.N, gs[k].colsum, 1, stream));
+        }
+        if (gs[k].C16 && splits > 1) {            // split-K result: refresh the bf16 shadow of whole rows
+            ADN_CHECK(g.ldc % 8 == 0, ADN_ERR_INVALID, "gemm: bf16 shadow of C needs ldc % 8 == 0");
+            ADN_TRY(to_bf16(gs[k].C, gs[k].C16, (size_t)g.M * g.ldc, stream));
+        }
+    }
+    *used = true;
+    return ADN_OK;
+}
+
+int gemm_grouped(const GemmArgs* gs, int n, hipStream_t stream) {
+    if (n <= 0) return ADN_OK;
+    if (gs[0].M <= 0 || gs[0].N <= 0) return ADN_OK;
+    bool used = false;
+    if (n > 1) ADN_TRY(gemm_pp_try(gs, n, stream, &used));
+    if (used) return ADN_OK;
+    for (int k = 0; k < n; ++k) ADN_TRY(gemm(gs[k], stream));
+    return ADN_OK;
+}
+
 int gemm(const GemmArgs& g, hipStream_t stream) {
     ADN_CHECK(g.layout >= GEMM_NN && g.layout <= GEMM_TN, ADN_ERR_INVALID, "gemm: bad layout");
     if (g.M <= 0 || g.N <= 0) return ADN_OK;
@@ -174,7 +311,13 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
     ADN_CHECK(g.precision == ADN_PRECISION_F32 || g.precision == ADN_PRECISION_BF16, ADN_ERR_INVALID,
               "gemm: unsupported precision");
 
+    {
+        bool used = false;
+        ADN_TRY(gemm_pp_try(&g, 1, stream, &used));
+        if (used) return ADN_OK;
+    }
     GemmParams p;
+    std::memset(static_cast<void*>(&p), 0, sizeof(p));
     p.M = g.M; p.N = g.N; p.K = g.K;
     p.A = g.A; p.lda = g.lda; p.B = g.B; p.ldb = g.ldb; p.C = g.C; p.ldc = g.ldc;
     p.bias = g.bias; p.Y = g.Y; p.ldy = g.ldy;
@@ -199,13 +342,8 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
     const bool big = force_tile ? force_tile == 128
                                 : (g.K >= 768 && fill128 >= 0.85 * fill64 &&
                                    (t128 >= 384 || (can_split && t128 >= 24 && g.K >= 2048)));
-    const int64_t t256 = (int64_t)cdiv(g.M, 256) * cdiv(g.N, 256);
-    // LDS-DMA pipelined 256x256 kernel: shadows, NN / TN, 16-byte aligned operands, K in whole 16-byte chunks
-    const bool dma_ok = g.precision == ADN_PRECISION_BF16 && p.A16 && p.B16 && g.layout != GEMM_NT && g.K % 8 == 0 &&
-                        g.lda % 8 == 0 && g.ldb % 8 == 0 && ((uintptr_t)p.A16 % 16) == 0 && ((uintptr_t)p.B16 % 16) == 0 &&
-                        g.M >= 256 && g.N >= 128 && g.K >= 128 && (g.layout == GEMM_NN || g.lda >= 256) && g.ldb >= 256;
-    const bool dma = dma_ok && force_tile == 512;
-    const bool huge = dma;                    // (256 x 256 tile geometry)
+    const bool dma = false, huge = false;
+    const int64_t t256 = 0;
     const int64_t tiles = huge ? t256 : (big ? t128 : t64);
     int split = 1;
     // split-K: enough workgroups for two per CU (measured on the weight-gradient shapes: 512 beats 768 / 1024 by 0-12 %,

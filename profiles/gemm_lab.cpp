@@ -9,12 +9,10 @@
 #include <cstring>
 #include <cmath>
 #include <vector>
+#include <algorithm>
 #include "adn_common.h"
 
 using namespace adn;
-#ifdef ADN_GEMM_STAMPS
-extern "C" int adn_debug_gemm_stamps(unsigned long long*, int);   // libadenet_hip.so built with -DADN_GEMM_STAMPS
-#endif
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -37,6 +35,7 @@ int main(int argc, char** argv) {
         {"fwd fc1 bias+relu lean", GEMM_NN, R, 2000, 1200, 1, 0, 0, 0, 1},
         {"fwd fc1 plain C+C16", GEMM_NN, R, 2000, 1200, 0, 0, 0, 0, 0},
         {"dX fc2 lean y colsum", GEMM_NN, R, 2000, 1000, 1, 0, 1, 1, 0},
+        {"dX fc2 full y colsum", GEMM_NN, R, 2000, 1000, 0, 0, 1, 1, 0},
         {"dX fc2 lean y", GEMM_NN, R, 2000, 1000, 1, 0, 1, 0, 0},
         {"dX fc2 lean", GEMM_NN, R, 2000, 1000, 1, 0, 0, 0, 0},
         {"dX fc3 lean y colsum", GEMM_NN, R, 1000, 500, 1, 0, 1, 1, 0},
@@ -61,6 +60,10 @@ int main(int argc, char** argv) {
         {"dW lstm TN acc", GEMM_TN, 250, 1000, R, 0, 1, 0, 0, 0},
         {"dW lstm-in TN acc", GEMM_TN, 150, 1000, R, 0, 1, 0, 0, 0},
         {"dW agg-cat TN", GEMM_TN, 768, 1000, R, 0, 0, 0, 0, 0},
+        {"xproj agg-cat fp32", GEMM_NN, R, 1000, 768, 0, 0, 0, 0, 0},
+        {"dcat fp32", GEMM_NN, R, 768, 1000, 0, 0, 0, 0, 0},
+        {"odd edges fwd", GEMM_NN, 20777, 1996, 1208, 0, 0, 0, 0, 1},
+        {"odd edges dW", GEMM_TN, 1196, 2004, 20777, 0, 1, 0, 0, 0},
         {"dW bn TN acc", GEMM_TN, 500, 50, R, 0, 1, 0, 0, 0},
     };
     const char* only = argc > 1 ? argv[1] : nullptr;
@@ -93,73 +96,77 @@ int main(int argc, char** argv) {
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     printf("%-26s %3s %6s %6s %6s | %9s %9s %9s\n", "case", "lay", "M", "N", "K", "us", "TFLOP/s", "GB/s(out)");
+    const int NG = getenv("LAB_GROUPS") ? atoi(getenv("LAB_GROUPS")) : 1;      // problems per launch (gemm_grouped)
+    const size_t wsk_floats = (size_t)24 << 20;                                // split-K slabs of the ping-pong kernel (96 MB)
+    float* wsk; CK(hipMalloc((void**)&wsk, wsk_floats * 4));
     for (const auto& c : cases) {
         if (only && !strstr(c.name, only)) continue;
         const int ar = c.layout == GEMM_TN ? c.K : c.M, ac = pad(c.layout == GEMM_TN ? c.M : c.K);
         const int br = c.layout == GEMM_NT ? c.N : c.K, bc = pad(c.layout == GEMM_NT ? c.K : c.N);
         const int ldc = pad(c.N);
-        float* A = dalloc((size_t)ar * ac, true); float* B = dalloc((size_t)br * bc, true);
-        float* C = dalloc((size_t)c.M * ldc, false); float* Y = dalloc((size_t)c.M * ldc, true);
-        float* bias = dalloc(ldc, true); float* cs = dalloc(ldc, false);
-        const size_t wsf = (size_t)((c.M + 63) / 64) * ldc;
-        float* ws = dalloc(wsf, false);
-        void *A16, *B16, *C16, *Y16;
-        CK(hipMalloc(&A16, (size_t)ar * ac * 2)); CK(hipMalloc(&B16, (size_t)br * bc * 2));
-        CK(hipMalloc(&C16, (size_t)c.M * ldc * 2)); CK(hipMalloc(&Y16, (size_t)c.M * ldc * 2));
-        to_bf16(A, A16, (size_t)ar * ac, st); to_bf16(B, B16, (size_t)br * bc, st); to_bf16(Y, Y16, (size_t)c.M * ldc, st);
-        GemmArgs g;
-        g.layout = c.layout; g.M = c.M; g.N = c.N; g.K = c.K; g.A = A; g.lda = ac; g.B = B; g.ldb = bc;
-        g.C = c.lean ? nullptr : C; g.ldc = ldc; g.accumulate = c.acc; g.precision = ADN_PRECISION_BF16;
-        g.A16 = A16; g.B16 = B16; g.C16 = (c.layout == GEMM_TN) ? nullptr : C16;
-        if (c.ygrad) { g.Y = Y; g.ldy = ldc; g.Y16 = Y16; g.act_grad = ADN_ACT_RECTIFY; }
-        int done = 0;
-        if (c.colsum) { g.colsum = cs; g.colsum_done = &done; g.colsum_ws = ws; g.colsum_ws_floats = wsf; }
-        if (c.biasrelu) { g.bias = bias; g.act = ADN_ACT_RECTIFY; }
-        for (int i = 0; i < 3; ++i) if (gemm(g, st) != 0) { fprintf(stderr, "gemm failed: %s\n", c.name); return 1; }
-#ifdef ADN_GEMM_STAMPS
-        adn_debug_gemm_stamps(nullptr, 1);
-#endif
+        const size_t wsf = (size_t)((c.M + 63) / 64 + 8) * ldc;
+        float *A[4], *B[4], *C[4], *Y[4], *bias[4], *cs[4], *ws[4];
+        void *A16[4], *B16[4], *C16[4], *Y16[4];
+        GemmArgs g[4];
+        int done[4] = {0, 0, 0, 0};
+        for (int k = 0; k < NG; ++k) {
+            A[k] = dalloc((size_t)ar * ac + 64 * k, true); B[k] = dalloc((size_t)br * bc + 64 * k, true);
+            C[k] = dalloc((size_t)c.M * ldc, false); Y[k] = dalloc((size_t)c.M * ldc + 64 * k, true);
+            bias[k] = dalloc(ldc + 64 * k, true); cs[k] = dalloc(ldc, false); ws[k] = dalloc(wsf, false);
+            CK(hipMalloc(&A16[k], (size_t)ar * ac * 2 + 64)); CK(hipMalloc(&B16[k], (size_t)br * bc * 2 + 64));
+            CK(hipMalloc(&C16[k], (size_t)c.M * ldc * 2)); CK(hipMalloc(&Y16[k], (size_t)c.M * ldc * 2));
+            to_bf16(A[k], A16[k], (size_t)ar * ac, st); to_bf16(B[k], B16[k], (size_t)br * bc, st); to_bf16(Y[k], Y16[k], (size_t)c.M * ldc, st);
+            GemmArgs& q = g[k];
+            q.layout = c.layout; q.M = c.M; q.N = c.N; q.K = c.K; q.A = A[k]; q.lda = ac; q.B = B[k]; q.ldb = bc;
+            q.C = c.lean ? nullptr : C[k]; q.ldc = ldc; q.accumulate = c.acc; q.precision = ADN_PRECISION_BF16;
+            q.A16 = A16[k]; q.B16 = B16[k]; q.C16 = (c.layout == GEMM_TN) ? nullptr : C16[k];
+            if (c.ygrad) { q.Y = Y[k]; q.ldy = ldc; q.Y16 = Y16[k]; q.act_grad = ADN_ACT_RECTIFY; }
+            if (c.colsum) { q.colsum = cs[k]; q.colsum_done = &done[k]; q.colsum_ws = ws[k]; q.colsum_ws_floats = wsf; }
+            if (c.biasrelu) { q.bias = bias[k]; q.act = ADN_ACT_RECTIFY; }
+            if (c.layout != GEMM_TN) q.no_split = 1;
+            q.splitk_ws = wsk; q.splitk_ws_floats = wsk_floats;
+        }
+        for (int i = 0; i < 3; ++i) if (gemm_grouped(g, NG, st) != 0) { fprintf(stderr, "gemm failed: %s\n", c.name); return 1; }
         const int iters = 20;
         CK(hipEventRecord(e0, st));
-        for (int i = 0; i < iters; ++i) gemm(g, st);
+        for (int i = 0; i < iters; ++i) gemm_grouped(g, NG, st);
         CK(hipEventRecord(e1, st));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         const double us = ms * 1e3 / iters;
-#ifdef ADN_GEMM_STAMPS
-        { unsigned long long st8[8];
-          adn_debug_gemm_stamps(st8, 0);
-          const double nst = (double)iters * 2 * ((c.K + 31) / 32) * 3;      // 2 stamping waves, ~3 tiles per workgroup (rough)
-          printf("   stamps (us per stage, rough): wait %.3f  barrier %.3f  dma issue %.3f  reads+mfma %.3f\n", st8[0] / 100.0 / nst,
-                 st8[1] / 100.0 / nst, st8[2] / 100.0 / nst, st8[3] / 100.0 / nst); }
-#endif
-        const double outb = (double)c.M * c.N * ((c.lean ? 0 : 4) + (g.C16 ? 2 : 0) + (c.ygrad ? 2 : 0) + (c.acc ? 4 : 0));
+        const double outb = (double)NG * c.M * c.N * ((c.lean ? 0 : 4) + (g[0].C16 ? 2 : 0) + (c.ygrad ? 2 : 0) + (c.acc ? 4 : 0));
         printf("%-26s %3s %6d %6d %6d | %9.1f %9.1f %9.1f%s\n", c.name, c.layout == 0 ? "NN" : (c.layout == 1 ? "NT" : "TN"),
-               c.M, c.N, c.K, us, 2.0 * c.M * c.N * c.K / us / 1e6, outb / us / 1e3, c.colsum && !done ? "  (colsum NOT fused)" : "");
+               c.M, c.N, c.K, us, 2.0 * NG * c.M * c.N * c.K / us / 1e6, outb / us / 1e3, c.colsum && !done[0] ? "  (colsum NOT fused)" : "");
+        fflush(stdout);
         if (getenv("LAB_VERIFY")) {                  // sampled check against a double-precision dot product of the bf16 operands
-            CK(hipMemsetAsync(C, 0, (size_t)c.M * ldc * 4, st));
-            gemm(g, st);
-            CK(hipStreamSynchronize(st));
+          for (int k = 0; k < NG; ++k) {
+            CK(hipMemsetAsync(C[k], 0, (size_t)c.M * ldc * 4, st));
+            CK(hipMemsetAsync(cs[k], 0, (size_t)ldc * 4, st));
+          }
+          gemm_grouped(g, NG, st);
+          CK(hipStreamSynchronize(st));
+          for (int k = 0; k < NG; ++k) {
             std::vector<unsigned short> hA((size_t)ar * ac), hB((size_t)br * bc), hC16((size_t)c.M * ldc), hY16((size_t)c.M * ldc);
-            std::vector<float> hC((size_t)c.M * ldc), hb(ldc);
-            CK(hipMemcpy(hA.data(), A16, hA.size() * 2, hipMemcpyDeviceToHost));
-            CK(hipMemcpy(hB.data(), B16, hB.size() * 2, hipMemcpyDeviceToHost));
-            CK(hipMemcpy(hC16.data(), C16, hC16.size() * 2, hipMemcpyDeviceToHost));
-            CK(hipMemcpy(hY16.data(), Y16, hY16.size() * 2, hipMemcpyDeviceToHost));
-            CK(hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost));
-            CK(hipMemcpy(hb.data(), bias, ldc * 4, hipMemcpyDeviceToHost));
+            std::vector<float> hC((size_t)c.M * ldc), hb(ldc), hcs(ldc);
+            CK(hipMemcpy(hA.data(), A16[k], hA.size() * 2, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hB.data(), B16[k], hB.size() * 2, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hC16.data(), C16[k], hC16.size() * 2, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hY16.data(), Y16[k], hY16.size() * 2, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hC.data(), C[k], hC.size() * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hb.data(), bias[k], ldc * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hcs.data(), cs[k], ldc * 4, hipMemcpyDeviceToHost));
             auto f = [](unsigned short h) { unsigned u = (unsigned)h << 16; float x; memcpy(&x, &u, 4); return x; };
             double worst = 0; int bad = 0; unsigned rs = 777;
-            const int nsamp = 4000;
+            const int nsamp = 6000;
             for (int sidx = 0; sidx < nsamp; ++sidx) {
                 rs = rs * 1664525u + 1013904223u; int i = (rs >> 8) % c.M;
                 rs = rs * 1664525u + 1013904223u; int j = (rs >> 8) % c.N;
                 if (sidx < 64) { i = (sidx & 1) ? c.M - 1 - (sidx >> 1) : (sidx >> 1); }          // edges
                 if (sidx >= 64 && sidx < 128) { j = (sidx & 1) ? c.N - 1 - ((sidx - 64) >> 1) : ((sidx - 64) >> 1); }
                 double acc = 0;
-                for (int k = 0; k < c.K; ++k) {
-                    const float a = c.layout == GEMM_TN ? f(hA[(size_t)k * ac + i]) : f(hA[(size_t)i * ac + k]);
-                    const float b = c.layout == GEMM_NT ? f(hB[(size_t)j * bc + k]) : f(hB[(size_t)k * bc + j]);
+                for (int kk = 0; kk < c.K; ++kk) {
+                    const float a = c.layout == GEMM_TN ? f(hA[(size_t)kk * ac + i]) : f(hA[(size_t)i * ac + kk]);
+                    const float b = c.layout == GEMM_NT ? f(hB[(size_t)j * bc + kk]) : f(hB[(size_t)kk * bc + j]);
                     acc += (double)a * b;
                 }
                 if (c.biasrelu) { acc += hb[j]; if (acc < 0) acc = 0; }
@@ -167,13 +174,27 @@ int main(int argc, char** argv) {
                 const double got = c.lean ? f(hC16[(size_t)i * ldc + j]) : hC[(size_t)i * ldc + j];
                 const double tol = (c.lean ? 1.0e-2 : 2e-3) * (fabs(acc) + 1.0);
                 const double err = fabs(got - acc);
-                if (err > tol) { if (bad < 5) printf("   MISMATCH (%d,%d): got %g want %g\n", i, j, got, acc); ++bad; }
+                if (err > tol) { if (bad < 5) printf("   MISMATCH g%d (%d,%d): got %g want %g\n", k, i, j, got, acc); ++bad; }
                 if (err > worst) worst = err;
             }
-            printf("   verify: %d/%d outside tolerance, worst abs err %.3g\n", bad, nsamp, worst);
+            // pad columns of C must stay zero; the fused column sums must equal the column sums of the stored result
+            int padbad = 0;
+            if (!c.lean) for (int i = 0; i < c.M; i += 97) for (int j = c.N; j < ldc; ++j) if (hC[(size_t)i * ldc + j] != 0.f) ++padbad;
+            double csworst = 0;
+            if (c.colsum && done[k] && !c.lean) {
+                for (int j = 0; j < c.N; j += 37) {
+                    double sum = 0; for (int i = 0; i < c.M; ++i) sum += hC[(size_t)i * ldc + j];
+                    csworst = std::max(csworst, fabs(sum - hcs[j]) / (fabs(sum) + 1.0));
+                }
+            }
+            printf("   verify g%d: %d/%d outside tolerance, worst abs err %.3g, dirty pads %d, colsum rel err %.2g\n", k, bad, nsamp, worst,
+                   padbad, csworst);
+          }
         }
-        (void)hipFree(A); (void)hipFree(B); (void)hipFree(C); (void)hipFree(Y); (void)hipFree(bias); (void)hipFree(cs); (void)hipFree(ws);
-        (void)hipFree(A16); (void)hipFree(B16); (void)hipFree(C16); (void)hipFree(Y16);
+        for (int k = 0; k < NG; ++k) {
+            (void)hipFree(A[k]); (void)hipFree(B[k]); (void)hipFree(C[k]); (void)hipFree(Y[k]); (void)hipFree(bias[k]); (void)hipFree(cs[k]);
+            (void)hipFree(ws[k]); (void)hipFree(A16[k]); (void)hipFree(B16[k]); (void)hipFree(C16[k]); (void)hipFree(Y16[k]);
+        }
     }
     return 0;
 }

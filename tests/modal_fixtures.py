@@ -1,0 +1,194 @@
+"""Synthetic stand-ins for the schema-2 scripts' inputs (SURVEY.md App. B schema 2, App. C): small .mat / .ini / split files
+with the reference's keys.  Shared by the host test of the loaders and the GPU end-to-end test of the drivers."""
+import os
+import pickle
+
+import numpy as np
+import scipy.io as sio
+
+D, DCT, CLASSES = 24, 9, 4             # 4 x 6 "images", 3 DCT coefficients + deltas
+
+
+def _utterances(rng, n, dim, labels, protos):
+    lens = rng.randint(5, 11, size=n)
+    rows = [protos[labels[u]][None, :] * (0.5 + np.linspace(0, 1, lens[u])[:, None]) + rng.normal(size=(lens[u], dim)) * 0.3
+            for u in range(n)]
+    return lens, np.concatenate(rows), np.concatenate([np.full(lens[u], labels[u]) for u in range(n)])
+
+
+def _ae(rng, root, name, d_in=D, as_pickle=False):
+    dims = [d_in, 16, 12, 8, 5]
+    ws = [rng.normal(0, 0.3, (a, b)).astype(np.float32) for a, b in zip(dims[:-1], dims[1:])]
+    bs = [rng.normal(0, 0.05, (b,)).astype(np.float32) for b in dims[1:]]
+    path = os.path.join(root, name)
+    if as_pickle:
+        with open(path, "wb") as f:
+            pickle.dump((ws, bs), f)
+    else:
+        sio.savemat(path, dict([("w%d" % (i + 1), ws[i]) for i in range(4)] + [("b%d" % (i + 1), bs[i][None, :]) for i in range(4)]))
+    return path
+
+
+def make_cuave(root, seed=0):
+    """Pre-split CUAVE files (cuave/bimodal_with_val.py:211-222): targets are stored 0-based minus one (the script adds 1)."""
+    rng = np.random.RandomState(seed)
+    protos, dprotos = rng.normal(size=(CLASSES, D)) * 2, rng.normal(size=(CLASSES, DCT)) * 2
+    data, dct = {}, {}
+    for pre, n in (("tr", 32), ("val", 12), ("test", 12)):
+        labels = np.arange(n) % CLASSES
+        lens, X, tv = _utterances(rng, n, D, labels, protos)
+        feats = np.concatenate([dprotos[labels[u]][None, :] + rng.normal(size=(lens[u], DCT)) * 0.3 for u in range(n)])
+        data[pre + "Data"] = X
+        data[pre + "VideoLengthVec"] = lens[:, None].astype("float64")
+        data[pre + "TargetsVec"] = (labels - 1)[:, None].astype("float64")      # PER VIDEO (the script feeds them to the batch generator)
+        dct[pre + "DctFeatures"] = feats
+    sio.savemat(os.path.join(root, "cuave.mat"), data)
+    sio.savemat(os.path.join(root, "cuave_dct.mat"), dct)
+    ae = _ae(rng, root, "ae.mat")
+    ini = """
+[data]
+images = {root}/cuave.mat
+dct = {root}/cuave_dct.mat
+imagesize = 4,6
+
+[models]
+pretrained = {ae}
+fusiontype = adasum
+input_dimension = {D}
+no_coeff = 3
+output_classes = {C}
+lstm_size = 10
+nonlinearity = rectify
+
+[training]
+validation_window = 4
+num_epoch = 5
+weight_init = glorot
+learning_rate = 0.01
+epochsize = 4
+batchsize = 8
+use_peepholes = True
+use_blstm = True
+use_finetuning = False
+""".format(root=root, ae=ae, D=D, C=CLASSES)
+    path = os.path.join(root, "cuave.ini")
+    open(path, "w").write(ini)
+    return path
+
+
+def _frames_file(root, rng, name, with_iter):
+    subjects = np.repeat(np.arange(1, 9), 6)                  # 8 subjects x 6 utterances
+    n = len(subjects)
+    labels = np.arange(n) % CLASSES
+    protos, dprotos = rng.normal(size=(CLASSES, D)) * 2, rng.normal(size=(CLASSES, DCT)) * 2
+    lens, X, tv = _utterances(rng, n, D, labels, protos)
+    feats = np.concatenate([dprotos[labels[u]][None, :] + rng.normal(size=(lens[u], DCT)) * 0.3 for u in range(n)])
+    d = dict(dataMatrix=X, targetsVec=tv[:, None].astype("float64"), videoLengthVec=lens[:, None].astype("float64"),
+             subjectsVec=subjects[:, None].astype("float64"))
+    if with_iter:
+        d["iterVec"] = (np.arange(n) % 3 + 1)[:, None].astype("float64")        # repetitions 1, 2 -> train; 3 -> test
+    sio.savemat(os.path.join(root, name + ".mat"), d)
+    sio.savemat(os.path.join(root, name + "_dct.mat"), dict(dctFeatures=feats))
+    return X, lens
+
+
+def make_oulu(root, seed=1):
+    rng = np.random.RandomState(seed)
+    _frames_file(root, rng, "oulu", with_iter=False)
+    for k, ids in (("train", "1,2,3,4,5"), ("val", "6,7"), ("test", "8")):
+        open(os.path.join(root, k + ".txt"), "w").write(ids)
+    ae, ae_diff = _ae(rng, root, "ae_raw.pkl", as_pickle=True), _ae(rng, root, "ae_diff.mat")
+    ini = """
+[data]
+images = {root}/oulu.mat
+dct = {root}/oulu_dct.mat
+
+[models]
+pretrained = unused
+finetuned = {ae}
+finetuned_diff = {ae_diff}
+fusiontype = sum
+input_dimension = {D}
+output_classes = {C}
+lstm_size = 6
+
+[training]
+learning_rate = 1.0
+decay_rate = 0.5
+decay_start = 2
+do_finetune = False
+save_finetune = False
+load_finetune = True
+load_finetune_diff = True
+savemodel = False
+num_epoch = 4
+epochsize = 4
+batchsize = 8
+validation_window = 4
+train_subjects_file = {root}/train.txt
+val_subjects_file = {root}/val.txt
+test_subjects_file = {root}/test.txt
+""".format(root=root, ae=ae, ae_diff=ae_diff, D=D, C=CLASSES)
+    path = os.path.join(root, "oulu.ini")
+    open(path, "w").write(ini)
+    return path
+
+
+def make_avletters(root, seed=2, update_rule="sgdm"):
+    rng = np.random.RandomState(seed)
+    X, lens = _frames_file(root, rng, "avl", with_iter=True)
+    diff = np.concatenate([np.vstack([np.zeros((1, D)), np.diff(X[s:s + l], axis=0)])
+                           for s, l in zip(np.cumsum(np.r_[0, lens[:-1]]), lens)])
+    sio.savemat(os.path.join(root, "avl_diff.mat"), dict(dataMatrix=diff))
+    ae, ae_diff = _ae(rng, root, "avl_ae.mat"), _ae(rng, root, "avl_ae_diff.mat")
+    common = """
+[data]
+images = {root}/avl.mat
+dct = {root}/avl_dct.mat
+diff = {root}/avl_diff.mat
+
+[models]
+pretrained = {ae}
+finetuned = {ae}
+finetuned_diff = {ae_diff}
+fusiontype = concat
+input_dimension = {D}
+no_coeff = 3
+output_classes = {C}
+lstm_size = 6
+""".format(root=root, ae=ae, ae_diff=ae_diff, D=D, C=CLASSES)
+    tri = common + """
+[training]
+learning_rate = 1.0
+decay_rate = 0.9
+decay_start = 3
+do_finetune = False
+save_finetune = False
+load_finetune = True
+load_finetune_diff = True
+num_epoch = 4
+epochsize = 4
+batchsize = 8
+"""
+    bi = common + """
+[training]
+update_rule = {rule}
+learning_rate = 0.05
+decay_rate = 0.8
+decay_start = 3
+t1 = 1
+momentum = 0.5
+momentum_schedule = 0.7,0.9
+validation_window = 4
+num_epoch = 5
+weight_init = ortho
+use_peepholes = False
+use_blstm = True
+use_finetuning = False
+epochsize = 4
+batchsize = 8
+""".format(rule=update_rule)
+    p_tri, p_bi = os.path.join(root, "avl_tri.ini"), os.path.join(root, "avl_bi.ini")
+    open(p_tri, "w").write(tri)
+    open(p_bi, "w").write(bi)
+    return p_tri, p_bi

@@ -1,0 +1,105 @@
+"""Host logic of the schema-2 drivers (ip_avsr_amd/runners/modal.py): option precedence, the data paths of the four
+scripts on synthetic files with the reference's .mat / .ini keys (SURVEY.md App. B schema 2, App. C), the update-rule
+switch.  No device."""
+import configparser
+
+import numpy as np
+import pytest
+
+from ip_avsr_amd.runners import modal
+from tests import modal_fixtures as MF
+
+
+def _cfg(path, argv=()):
+    options = modal.parse_options(list(argv) + ["--config", path], "unused.ini")
+    config = configparser.ConfigParser()
+    assert config.read(path)
+    return modal._Cfg(config, options)
+
+
+def test_cli_overrides_training_keys_only(tmp_path):
+    _, bi = MF.make_avletters(str(tmp_path))
+    cfg = _cfg(bi, ["--learning_rate", "0.5", "--update_rule", "adam", "--t1", "7"])
+    assert cfg.get("training", "learning_rate", float) == 0.5 and cfg.get("training", "update_rule") == "adam"
+    assert cfg.get("training", "t1", int) == 7 and cfg.get("training", "decay_rate", float) == 0.8
+    assert cfg.get("models", "lstm_size", int) == 6
+    assert cfg.get("training", "absent_key", int, 12) == 12
+    with pytest.raises(configparser.NoOptionError):
+        cfg.get("training", "absent_key", int)
+
+
+def test_cuave_presplit_loader(tmp_path):
+    """cuave/bimodal_with_val.py:211-249: +1 on the stored targets, reorder, per-sequence mean removal, per-frame
+    z-normalisation; DCT features normalised with the TRAIN statistics."""
+    cfg = _cfg(MF.make_cuave(str(tmp_path)))
+    split, ys, lens = modal._load_cuave(cfg)
+    assert [len(lens[k]) for k in ("train", "val", "test")] == [32, 12, 12]
+    assert set(ys["train"]) == set(range(MF.CLASSES)) and ys["train"].shape == (32,)
+    for k in split:
+        X, dct = split[k]
+        assert X.shape == (int(lens[k].sum()), MF.D) and dct.shape == (int(lens[k].sum()), MF.DCT)
+        assert np.allclose(X.mean(1), 0, atol=1e-5) and np.allclose(X.std(1), 1, atol=1e-3)
+    assert np.allclose(split["train"][1].mean(0), 0, atol=1e-5) and np.allclose(split["train"][1].std(0), 1, atol=1e-3)
+    assert abs(split["val"][1].mean()) > 1e-4                        # (train statistics, not its own)
+
+
+def test_oulu_subject_split_loader(tmp_path):
+    """oulu/trimodal_with_val.py:274-334: streams raw / dct / diff, subjects 1-5 / 6-7 / 8."""
+    cfg = _cfg(MF.make_oulu(str(tmp_path)))
+    split, ys, lens = modal._load_subject_split(cfg)
+    assert [len(lens[k]) for k in ("train", "val", "test")] == [30, 12, 6]
+    for k in split:
+        raw, dct, diff = split[k]
+        n = int(np.sum(lens[k]))
+        assert raw.shape == (n, MF.D) and dct.shape == (n, MF.DCT) and diff.shape == (n, MF.D)
+        assert np.allclose(raw.mean(1), 0, atol=1e-5)                # per-frame z-normalisation of the raw split only
+    d = split["train"][2]
+    assert np.array_equal(d[0], d[1])                                # frame 0 carries a copy of the first difference (:514)
+
+
+def test_avletters_iter_split_loader(tmp_path):
+    tri, bi = MF.make_avletters(str(tmp_path))
+    split, ys, lens = modal._load_avletters(_cfg(tri), with_diff=True, normalise_images=False, target_offset=False)
+    assert len(lens["train"]) == 32 and len(lens["test"]) == 16 and split["val"] is split["test"]
+    assert len(split["train"]) == 3 and split["train"][2].shape == split["train"][0].shape
+    split2, ys2, _ = modal._load_avletters(_cfg(bi), with_diff=False, normalise_images=True, target_offset=True)
+    assert len(split2["train"]) == 2 and np.array_equal(ys2["train"], ys["train"] - 1)
+    assert np.allclose(split2["train"][0].mean(1), 0, atol=1e-5)
+
+
+class _FakeNet(object):
+    def __init__(self):
+        self.calls = []
+
+    def train_step(self, ins, y, m, w, lr):
+        self.calls.append(("adam", lr)); return 1.0
+
+    def compute_grads(self, ins, y, m, w):
+        self.calls.append(("grads",)); return 2.0
+
+    def apply_adadelta(self, lr):
+        self.calls.append(("adadelta", lr))
+
+    def apply_sgd(self, lr, mm, nesterov=False):
+        self.calls.append(("sgd", lr, mm, nesterov))
+
+
+def test_update_rule_switch():
+    """avletters/bimodal.py:446-455: adadelta(lr) | sgd + momentum | sgd + nesterov momentum | adam with DEFAULT parameters."""
+    for rule, want in (("adadelta", ("adadelta", 0.3)), ("sgdm", ("sgd", 0.3, 0.6, False)), ("sgdnm", ("sgd", 0.3, 0.6, True)),
+                       ("adam", ("adam", 1e-3))):
+        net = _FakeNet()
+        up = modal.Updater(net, rule, 0.3, 0.6)
+        up(None, None, None, 9)
+        assert net.calls[-1] == want, rule
+    up.lr = 0.1
+    with pytest.raises(ValueError):
+        modal.Updater(_FakeNet(), "rmsprop", 0.1)
+
+
+def test_load_ae_accepts_mat_and_pickle(tmp_path):
+    rng = np.random.RandomState(0)
+    a = modal.load_ae(MF._ae(rng, str(tmp_path), "a.mat"))
+    b = modal.load_ae(MF._ae(rng, str(tmp_path), "b.pkl", as_pickle=True))
+    for w, bias in (a, b):
+        assert [x.shape for x in w] == [(24, 16), (16, 12), (12, 8), (8, 5)] and [x.shape for x in bias] == [(16,), (12,), (8,), (5,)]
