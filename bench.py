@@ -12,11 +12,18 @@ its own 520-utterance shard of a 520*N global batch.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
   roofline     dominant kernel class (encoder / projection GEMMs on the MFMA pipe), measured live with HIP
                events recorded on the model's stream around every launch, in a second pass of the same K steps
+  roofline_lstm_{fwd,bwd}  the recurrent kernels against the HBM roofline by SURVEY 8d's byte formula; `frac` against
+               the 8 TB/s datasheet figure, `frac_of_measured` against a float4 copy kernel timed in this run
+  accurate     the same K steps in the fp32-accurate arithmetic (--accurate-precision, default f32) with its own
+               GEMM / LSTM rooflines: the mode that meets the 1e-4 / exact-top-1 parity gate
   cpu_baseline the CPU oracle (oracle/adenet_oracle.py, NumPy fp32) timed on the host cores of this box on a
                bounded sample of the same workload (rank 0, N=1 only)
+
+--scaling strong: the 520-utterance whole-train batch is SPLIT over the N ranks (520 / N utterances each) instead of
+every rank training on its own 520 (weak, the default).
 """
 import argparse
 import json
@@ -95,50 +102,143 @@ def lstm_traffic(d, steps_per_train_step):
     return per_launch * 2.0 / (5.0 * t_steps)                      # profiler counts T per launch, 2 launches per step
 
 
-def cpu_baseline(budget_s=20.0):
-    """The oracle's train step (fp32 NumPy, BLAS threads = all host cores) on the reference minibatch
-    (B=26, T=40) of the same model; sequences/s = 26 / median step time."""
+def _cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(budget_s=22.0, big_budget_s=35.0):
+    """The oracle's train step (fp32 NumPy, BLAS threads = what NumPy's BLAS reports) on the reference minibatch
+    (B=26, T=40) of the same model: 3 warm-up + >= 10 (up to 20) timed steps, sequences/s = 26 / median; plus one
+    timed step at the bench batch (B=520) when the B=26 rate predicts it fits the budget, else at the largest
+    B in {260, 130, 52} that does (said in `sample`)."""
     from oracle import adenet_oracle as O
     spec = O.spec_nstream([D, D, D])
     rng = np.random.default_rng(0)
     p = O.init_params(spec, rng, np.float32, enc_std=0.01)
     st = O.adam_init(p)
-    Bc = 26
-    lens = rng.integers(12, T_MAX + 1, size=Bc); lens[0] = T_MAX
-    mask = (np.arange(T_MAX)[None, :] < lens[:, None]).astype(np.uint8)
-    xs = [(rng.normal(size=(Bc, T_MAX, D)) * mask[..., None]).astype(np.float32) for _ in range(3)]
-    y = np.repeat((np.arange(Bc) % C)[:, None], T_MAX, axis=1).astype(np.int32)
-    O.train_step(spec, p, st, xs, y, mask, THETA, LR)        # warm-up
+
+    def batch(Bc):
+        lens = rng.integers(12, T_MAX + 1, size=Bc); lens[0] = T_MAX
+        mask = (np.arange(T_MAX)[None, :] < lens[:, None]).astype(np.uint8)
+        xs = [(rng.normal(size=(Bc, T_MAX, D)) * mask[..., None]).astype(np.float32) for _ in range(3)]
+        y = np.repeat((np.arange(Bc) % C)[:, None], T_MAX, axis=1).astype(np.int32)
+        return xs, y, mask
+
+    xs, y, mask = batch(26)
+    for _ in range(3):
+        O.train_step(spec, p, st, xs, y, mask, THETA, LR)        # warm-up
     times = []
     t_end = time.perf_counter() + budget_s
-    while len(times) < 2 or (time.perf_counter() < t_end and len(times) < 20):
+    while len(times) < 10 or (time.perf_counter() < t_end and len(times) < 20):
         t0 = time.perf_counter()
         O.train_step(spec, p, st, xs, y, mask, THETA, LR)
         times.append(time.perf_counter() - t0)
     med = float(np.median(times))
-    threads = os.cpu_count()
+    big = next((Bb for Bb in (520, 260, 130, 52) if med * Bb / 26.0 <= big_budget_s), None)
+    big_rate = None
+    if big:
+        xs, y, mask = batch(big)
+        t0 = time.perf_counter()
+        O.train_step(spec, p, st, xs, y, mask, THETA, LR)
+        big_rate = big / (time.perf_counter() - t0)
+    threads, blas = os.cpu_count(), "unknown"
     try:                                             # the threads the NumPy BLAS actually ran on
         from threadpoolctl import threadpool_info
-        blas = [i["num_threads"] for i in threadpool_info() if i.get("user_api") == "blas"]
-        threads = max(blas) if blas else threads
+        info = [i for i in threadpool_info() if i.get("user_api") == "blas"]
+        if info:
+            threads = max(i["num_threads"] for i in info)
+            blas = "%s %s" % (info[0].get("internal_api"), info[0].get("version"))
     except Exception:
         pass
-    return dict(value=Bc / med, unit="sequences/s", cores=threads, kind="port",
-                sample="%d train steps of the NumPy fp32 oracle at B=26,T=40 (reference minibatch), median %.3f s/step"
-                       % (len(times), med))
+    out = dict(value=26 / med, unit="sequences/s", cores=threads, kind="port", cpu=_cpu_model_name(), blas=blas,
+               host_cores=os.cpu_count(),
+               sample="3 warm-up + %d timed train steps of the NumPy fp32 oracle at B=26,T=40 (the reference's minibatch), "
+                      "median %.3f s/step (min %.3f, max %.3f)" % (len(times), med, min(times), max(times)))
+    if big_rate:
+        out["value_large_batch"] = big_rate
+        out["sample"] += "; one timed step at B=%d: %.1f sequences/s" % (big, big_rate)
+    return out
 
 
-def main():
+def measured_hbm_gbs(torch, device):
+    """float4 copy of 512 MiB -> 512 MiB (beyond the 256 MiB Infinity Cache), 10 launches: GB/s moved (read + write)."""
+    import ctypes as C
+    from ip_avsr_amd import _lib
+    lib = _lib.load()
+    n = 128 << 20
+    src = torch.ones(n, device=device, dtype=torch.float32)
+    dst = torch.empty_like(src)
+    ms = C.c_float()
+    stream = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.adn_op_copy_bench(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_int64(n), 10,
+                                     C.c_void_p(stream), C.byref(ms)))
+    del src, dst
+    return 10 * 2.0 * 4.0 * n / (ms.value * 1e-3) / 1e9
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--precision", default="bf16", choices=["f32", "bf16"],
                     help="GEMM arithmetic: f32 = exact fp32 MFMA (parity-grade), bf16 = bf16 MFMA, fp32 accumulate")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: 520 utterances per rank (default); strong: the 520-utterance batch split over the ranks")
+    ap.add_argument("--accurate-precision", default="f32", choices=["f32", "none"],
+                    help="also time the fp32-accurate mode (sub-object `accurate`; N=1 only); none = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel timing")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def rooflines(prof, steps, prof_elapsed, precision, hbm_measured, traffic_file):
+    """roofline objects of one precision from the per-class HIP-event profile of `steps` train steps."""
+    out = {}
+    g = [prof[k] for k in ("gemm_nn", "gemm_nt", "gemm_tn") if k in prof]
+    flops = sum(e["flops"] for e in g); ms = sum(e["ms"] for e in g); n = sum(e["launches"] for e in g)
+    ach = flops / (ms * 1e-3) / 1e12 if ms else 0.0
+    peak = PEAK_BF16_MFMA_TFLOPS if precision == "bf16" else PEAK_F32_MFMA_TFLOPS
+    traffic, pmc = None, {}                # HBM bytes per launch from the committed PMC passes (labelled with their commit)
+    if os.path.exists(traffic_file):
+        pmc = json.load(open(traffic_file))
+        traffic = pmc.get("traffic_bytes_per_launch")
+    out["roofline"] = {"kernel": "gemm_%s kernels (encoder / projection GEMMs, all layouts and tile shapes)" % precision,
+                       "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                       "frac": ach / peak, "traffic": traffic, "traffic_source": pmc.get("commit", "profiles/ (see file)") if pmc else None,
+                       "algorithmic_flops_per_launch": flops / max(n, 1),
+                       "launches_per_step": n / steps, "avg_launch_ms": ms / max(n, 1),
+                       "share_of_step": ms / (1e3 * prof_elapsed),
+                       "measured": "HIP events on the model stream, separate pass of %d steps "
+                                   "(%.2f ms/step with events on)" % (steps, 1e3 * prof_elapsed / steps)}
+    for key, name in (("lstm_fwd_step", "roofline_lstm_fwd"), ("lstm_bwd_step", "roofline_lstm_bwd")):
+        if key in prof and prof[key]["ms"]:
+            e = prof[key]
+            a = e["bytes"] / (e["ms"] * 1e-3) / 1e9
+            kern = ("lstm_%s_cluster_kernel (weight-stationary, all T steps in one launch; per time step)"
+                    % key[5:8]) if precision == "bf16" else key + "_kernel (one launch per time step)"
+            out[name] = {"kernel": kern, "bound": "hbm", "achieved": a, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "algorithmic_bytes": "SURVEY 8d formula: e(12BH+4H^2)+B forward, e(15BH+4H^2) backward, per LSTM and step",
+                         "frac": a / PEAK_HBM_GBS,
+                         "peak_measured": hbm_measured, "frac_of_measured": (a / hbm_measured) if hbm_measured else None,
+                         # PMC bytes of all kernel launches of this class in a step / the LSTM time steps they cover
+                         # (same unit as `achieved`'s numerator: one LSTM, one time step)
+                         "traffic": lstm_traffic(pmc.get(key[:8]), e["launches"] / steps),
+                         "avg_launch_us": 1e3 * e["ms"] / e["launches"],
+                         "share_of_step": e["ms"] / (1e3 * prof_elapsed)}
+    out["kernel_ms_per_step"] = {k: v["ms"] / steps for k, v in prof.items()}
+    return out
+
+
+def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
+    """The benchmark body.  `make_model` / `batch_fn` / `device` are injection points for the CPU test of the N > 1 branch
+    (tests/test_bench_distributed_gloo.py: an oracle-backed replica under gloo); on a GPU box leave them None."""
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -147,34 +247,52 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
                          % (args.gpus, args.gpus))
+    on_gpu = make_model is None
     # ADN_BENCH_BACKEND=gloo: functional check of the N > 1 code path on a box with fewer GPUs than ranks (ranks share
     # devices; not a measurement, and it needs ADN_LSTM_NO_CLUSTER=1 -- two processes' resident-workgroup LSTM launches
     # cannot both fit one GPU)
-    backend = os.environ.get("ADN_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank %= max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    backend = dist_backend or os.environ.get("ADN_BENCH_BACKEND", "nccl")
+    if on_gpu:
+        if backend != "nccl":
+            local_rank %= max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
     distributed = world > 1
-    if distributed:
+    if distributed and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
 
-    from ip_avsr_amd.model import AdeNetModel
-    from ip_avsr_amd.parallel import DataParallel, wrap_flat_buffer
-    model = AdeNetModel(build_spec())
-    model.set_precision(args.precision)
-    synthetic_params(model)
-    xs, y, m_d, mask = synthetic_batch(torch, rank, B_PER_GPU, device)
-    local_frames = float(mask.sum())
+    from ip_avsr_amd.parallel import DataParallel
+    if on_gpu:
+        from ip_avsr_amd.model import AdeNetModel
+        model = AdeNetModel(build_spec())
+        model.set_precision(args.precision)
+        synthetic_params(model)
+        batch_fn = lambda r, B: synthetic_batch(torch, r, B, device)
+        grad_tensor = None
+    else:
+        model = make_model()
+        grad_tensor = model.grad
+    # per-rank batch: weak = the whole-train batch on every rank; strong = its rank::world share
+    if args.scaling == "strong":
+        xs, y, m_d, mask = batch_fn(0, B_PER_GPU)                # every rank draws the SAME 520 utterances ...
+        mine = list(range(B_PER_GPU))[rank::world]               # ... and keeps its share
+        total_frames = float(mask.sum())
+        xs, y, m_d, mask = [x[mine] for x in xs], y[mine], m_d[mine], mask[mine]
+        global_batch = B_PER_GPU
+    else:
+        xs, y, m_d, mask = batch_fn(rank, B_PER_GPU)
+        total_frames = float(mask.sum())
+        global_batch = B_PER_GPU * world
     if distributed:
-        t = torch.tensor([local_frames], device=device, dtype=torch.float64)
-        dist.all_reduce(t)                       # the loader knows every length: computed once, outside the steps
-        total_frames = float(t.item())
-        dp = DataParallel(model)
+        if args.scaling == "weak":
+            t = torch.tensor([total_frames], device=device, dtype=torch.float64)
+            dist.all_reduce(t)                   # the loader knows every length: computed once, outside the steps
+            total_frames = float(t.item())
+        dp = DataParallel(model, grad_tensor=grad_tensor)
         dp.broadcast_parameters(0)
         step = lambda: dp.train_step(xs, y, m_d, THETA, LR, total_frames)
     else:
@@ -183,29 +301,30 @@ def main():
     def fence():
         if distributed:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
+        else:
+            model.synchronize()
+
+    def timed(k):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        fence()
+        return time.perf_counter() - t0
 
     for _ in range(args.warmup):
         step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed(args.steps)
     # per-kernel-class timing: a SECOND pass of the same K steps with HIP events recorded on the model's stream
     # around every launch (sequence of T launches for the recurrent step kernels).  Kept out of the timed region
     # above because ~700 event records per step cost ~15 % of a step.
-    profile = not args.no_profile
+    profile = on_gpu and not args.no_profile
     prof, prof_elapsed = {}, None
     if profile:
         model.profile(True)
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        prof_elapsed = time.perf_counter() - t1
+        prof_elapsed = timed(args.steps)
         prof = model.profile_read()
         model.profile(False)
     if distributed:
@@ -217,70 +336,71 @@ def main():
     # epoch = one pass over the 520 training utterances + what the reference's loop does after it
     # (runners/3stream.py:372-383): train cost of the last batch, validation cost and majority-vote evaluation on
     # the 260-utterance held-out split
-    xe, ye, me_d, me = synthetic_batch(torch, rank + 1000, 260, device)
-    fence()
-    t2 = time.perf_counter()
-    model.loss(xs, y, m_d, THETA)
-    model.loss(xe, ye, me_d, THETA)
-    probs = model.predict(xe, me_d, THETA)
-    lens = me.sum(-1)
-    votes = np.stack([np.bincount(probs[i, :lens[i]].argmax(-1), minlength=C) for i in range(len(probs))])
-    _ = votes.argmax(-1)
-    eval_s = time.perf_counter() - t2
+    eval_s = None
+    if on_gpu:
+        xe, ye, me_d, me = batch_fn(rank + 1000, 260)
+        fence()
+        t2 = time.perf_counter()
+        model.loss(xs, y, m_d, THETA)
+        model.loss(xe, ye, me_d, THETA)
+        probs = model.predict(xe, me_d, THETA)
+        lens = me.sum(-1)
+        votes = np.stack([np.bincount(probs[i, :lens[i]].argmax(-1), minlength=C) for i in range(len(probs))])
+        _ = votes.argmax(-1)
+        eval_s = time.perf_counter() - t2
 
+    out = None
     if rank == 0:
-        seqs = B_PER_GPU * world * args.steps
+        seqs = global_batch * args.steps
         out = {
             "metric": "sequences_per_sec_train_avletters_trimodal_adenet", "value": seqs / elapsed,
             "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "AVLetters trimodal AdeNet (3 encoder streams 1200-2000-1000-500-50, theta=9, "
                                    "3x LSTM-250, concat, summed BLSTM-250, 26 classes), whole-train batch "
-                                   "B=520 utterances x T=40 frames per GPU, fwd+bwd+Adam",
-                       "global_batch": B_PER_GPU * world, "frames_per_utterance": T_MAX,
+                                   "B=520 utterances x T=40 frames %s, fwd+bwd+Adam"
+                                   % ("per GPU" if args.scaling == "weak" else "split over the GPUs"),
+                       "global_batch": global_batch, "frames_per_utterance": T_MAX,
                        "parallelism": "dp%d" % world, "params": model.count_params(),
-                       "epoch_time_s": elapsed / args.steps + eval_s, "epoch_eval_s": eval_s,
-                       "final_loss": loss},
+                       "epoch_time_s": (elapsed / args.steps + eval_s) if eval_s is not None else None,
+                       "epoch_eval_s": eval_s, "final_loss": loss},
         }
+        hbm = None
+        if on_gpu and world == 1:
+            hbm = measured_hbm_gbs(torch, device)
+            out["hbm_copy_measured_GBs"] = hbm
         if prof:
-            g = [prof[k] for k in ("gemm_nn", "gemm_nt", "gemm_tn") if k in prof]
-            flops = sum(e["flops"] for e in g); ms = sum(e["ms"] for e in g); n = sum(e["launches"] for e in g)
-            ach = flops / (ms * 1e-3) / 1e12 if ms else 0.0
-            peak = PEAK_BF16_MFMA_TFLOPS if args.precision == "bf16" else PEAK_F32_MFMA_TFLOPS
-            traffic, pmc = None, {}                # HBM bytes per launch from the committed PMC passes of this build
-            tfile = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_%s.json" % args.precision)
-            if os.path.exists(tfile):
-                pmc = json.load(open(tfile))
-                traffic = pmc.get("traffic_bytes_per_launch")
-            out["roofline"] = {"kernel": "gemm_%s_kernel (encoder / projection GEMMs, all three layouts)" % args.precision,
-                               "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                               "frac": ach / peak, "traffic": traffic,
-                               "algorithmic_flops_per_launch": flops / max(n, 1),
-                               "launches_per_step": n / args.steps, "avg_launch_ms": ms / max(n, 1),
-                               "share_of_step": ms / (1e3 * prof_elapsed),
-                               "measured": "HIP events on the model stream, second pass of %d steps "
-                                           "(%.2f ms/step with events on)" % (args.steps, 1e3 * prof_elapsed / args.steps)}
-            for key, name in (("lstm_fwd_step", "roofline_lstm_fwd"), ("lstm_bwd_step", "roofline_lstm_bwd")):
-                if key in prof and prof[key]["ms"]:
-                    e = prof[key]
-                    a = e["bytes"] / (e["ms"] * 1e-3) / 1e9
-                    kern = ("lstm_%s_cluster_kernel (weight-stationary, all T steps in one launch; per time step)"
-                            % key[5:8]) if args.precision == "bf16" else key + "_kernel (one launch per time step)"
-                    out[name] = {"kernel": kern, "bound": "hbm", "achieved": a, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                 "algorithmic_bytes": "SURVEY 8d formula: e(12BH+4H^2)+B forward, e(15BH+4H^2) backward, per LSTM and step",
-                                 "frac": a / PEAK_HBM_GBS,
-                                 # PMC bytes of all kernel launches of this class in a step / the LSTM time steps they cover
-                                 # (same unit as `achieved`'s numerator: one LSTM, one time step)
-                                 "traffic": lstm_traffic(pmc.get(key[:8]), e["launches"] / args.steps),
-                                 "avg_launch_us": 1e3 * e["ms"] / e["launches"],
-                                 "share_of_step": e["ms"] / (1e3 * prof_elapsed)}
-            out["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in prof.items()}
-        if world == 1 and not args.no_cpu_baseline:
+            tfile = os.path.join(ROOT, "profiles", "r02", "pmc_traffic_%s.json" % args.precision)
+            out.update(rooflines(prof, args.steps, prof_elapsed, args.precision, hbm, tfile))
+        # ---- the fp32-accurate mode, same workload, same process (the mode the 1e-4 / exact-top-1 parity tests run in)
+        if on_gpu and world == 1 and args.accurate_precision != "none" and args.accurate_precision != args.precision:
+            prec = args.accurate_precision
+            model.set_precision(prec)
+            k = max(3, min(args.steps, 10))
+            for _ in range(2):
+                step()
+            t_acc = timed(k)
+            acc = {"dtype": prec, "steps": k, "ms_per_step": 1e3 * t_acc / k, "value": B_PER_GPU * k / t_acc, "unit": "sequences/s",
+                   "parity": "forward 1e-4 / identical votes against the fp64 oracle (tests/test_gpu_parity.py)"}
+            if profile:
+                model.profile(True)
+                pe = timed(k)
+                acc.update(rooflines(model.profile_read(), k, pe, prec, hbm,
+                                     os.path.join(ROOT, "profiles", "r02", "pmc_traffic_%s.json" % prec)))
+                model.profile(False)
+            out["accurate"] = acc
+            model.set_precision(args.precision)
+        if on_gpu and world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if distributed:
+    if distributed and dist_backend is None:
         dist.destroy_process_group()
+    return out
+
+
+def main():
+    run(parse_args())
 
 
 if __name__ == "__main__":

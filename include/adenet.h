@@ -178,6 +178,11 @@ int adn_compute_grads(adn_model* m, const void* const* inputs, const int32_t* ta
 
 /* <- lasagne.updates.adam (runners/3stream.py:307; formula custom/updates.py:73-99): one step on
  * the current gradient buffer; beta1=.9 beta2=.999 eps=1e-8 */
+/* Data parallel: a rank whose shard of a minibatch is EMPTY (fewer utterances than ranks in the short last minibatch of
+ * gen_lstm_batch_random, reference utils/datagen.py) still has to join every gradient all-reduce: this zeroes the
+ * gradient buffer (cost share included), records the bucket events of adn_set_bucket_events and marks the gradients
+ * valid, i.e. it is adn_compute_grads of nothing. */
+int adn_zero_grads(adn_model* m);
 int adn_apply_adam(adn_model* m, float learning_rate);
 /* <- custom/updates.py:35-99 adam_vlr: Adam with one learning rate per parameter tensor (index order of
  * adn_param_info); tensors of one layer must share theirs, as generate_lr_map (custom/updates.py:10-32) gives */
@@ -234,6 +239,10 @@ int adn_op_delta_forward(const float* in, int ld_in, float* out, int ld_out, int
 int adn_op_delta_backward(const float* dout, int ld_out, float* din, int ld_in, int B, int T, int F, int theta,
                           void* hip_stream);
 int adn_op_adam(float* p, const float* g, float* m, float* v, int64_t n, float a_t, void* hip_stream);
+/* dst[i] = src[i], 16 bytes per lane, `repeats` back-to-back launches; *ms = their HIP-event time on that stream.  The
+ * achievable-HBM-bandwidth yardstick of bench.py (2 n floats move per launch): MI355X_MICROARCH.md quotes 6.29 TB/s for
+ * this copy against the 8 TB/s datasheet figure. */
+int adn_op_copy_bench(const float* src, float* dst, int64_t n, int repeats, void* hip_stream, float* ms);
 
 /* ---- feature front-end on the GPU (reference utils/preprocessing.py) -------------------------
  * Device pointers, fp32 row-major frame matrices [sum of lengths][ld], work enqueued on hip_stream.  Utterance

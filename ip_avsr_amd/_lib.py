@@ -80,6 +80,7 @@ _SIGNATURES = {
     "adn_forward": (C.c_int, [_P, C.POINTER(_P), _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "adn_loss": (C.c_int, [_P, C.POINTER(_P), _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "adn_compute_grads": (C.c_int, [_P, C.POINTER(_P), _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _P]),
+    "adn_zero_grads": (C.c_int, [_P]),
     "adn_apply_adam": (C.c_int, [_P, C.c_float]),
     "adn_apply_adam_vlr": (C.c_int, [_P, C.POINTER(C.c_float), C.c_int]),
     "adn_adam_step_count": (C.c_int, [_P]),
@@ -99,6 +100,7 @@ _SIGNATURES = {
     "adn_op_delta_forward": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "adn_op_delta_backward": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "adn_op_adam": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, _P]),
+    "adn_op_copy_bench": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, C.POINTER(C.c_float)]),
     "adn_set_dropout_state": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "adn_apply_sgd": (C.c_int, [_P, C.c_float, C.c_float, C.c_int]),
     "adn_apply_adadelta": (C.c_int, [_P, C.c_float, C.c_float, C.c_float]),

@@ -108,7 +108,8 @@ struct GemmArgs {
     float* splitk_ws = nullptr; size_t splitk_ws_floats = 0;
 };
 int gemm(const GemmArgs& g, hipStream_t stream);
-// n problems of identical shape, layout and flags (different buffers) as ONE launch where the persistent kernel
+constexpr int kMaxGemmGroups = 4;
+// n <= kMaxGemmGroups problems of identical shape, layout and flags (different buffers) as ONE launch where the persistent kernel
 // applies (their tiles share one list: fuller last round); otherwise n launches
 int gemm_grouped(const GemmArgs* g, int n, hipStream_t stream);
 // dst[i] = bf16(src[i]), n a multiple of 8
@@ -166,11 +167,16 @@ int softmax_loss(const float* z, int ldz, int B, int T, int C, const uint8_t* ma
 // out[0] = (sum_i v[i]) / total[0], fixed summation order
 int reduce_loss(const float* v, int n, const float* total, float* out, hipStream_t s);
 // p16: optional bf16 shadow of the parameters, written with the update
+// poison / sticky (all three update rules): when *poison != 0 the kernel changes nothing and raises *sticky
 int adam_update(float* p, const float* g, float* m, float* v, int64_t n, float a_t, float beta1,
-                float beta2, float eps, hipStream_t s, void* p16 = nullptr);
+                float beta2, float eps, hipStream_t s, void* p16 = nullptr, const float* poison = nullptr, int* sticky = nullptr);
+int poison_tail(const int* err_word, float* tail1, hipStream_t s);
+int copy_bench(const float* src, float* dst, int64_t n, int repeats, hipStream_t s, float* ms);
 // lasagne.updates.sgd (momentum == 0) / momentum / nesterov_momentum; adadelta
-int sgd_update(float* p, const float* g, float* vel, int64_t n, float lr, float momentum, int nesterov, hipStream_t s);
-int adadelta_update(float* p, const float* g, float* accu, float* delta, int64_t n, float lr, float rho, float eps, hipStream_t s);
+int sgd_update(float* p, const float* g, float* vel, int64_t n, float lr, float momentum, int nesterov, hipStream_t s,
+               const float* poison = nullptr, int* sticky = nullptr);
+int adadelta_update(float* p, const float* g, float* accu, float* delta, int64_t n, float lr, float rho, float eps, hipStream_t s,
+                    const float* poison = nullptr, int* sticky = nullptr);
 // DropoutLayer on a time-major [T*B][ld] matrix that is the column block [off, off+cols) of a `width`-wide (B,T,width)
 // tensor; in == out allowed; the mask is a hash of (seed, counter, layer, element) shared with the oracle
 int dropout_apply(const float* in, int ld_in, float* out, int ld_out, int B, int T, int cols, int width, int off, float p,

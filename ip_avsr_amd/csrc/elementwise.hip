@@ -140,11 +140,23 @@ __global__ __launch_bounds__(256) void delta_bwd_kernel(const float* __restrict_
     }
 }
 
+// The column slab of one utterance lives in LDS: 2 (T + 2 theta) rows of 32 floats.  Up to 64 KiB that is a plain
+// launch; beyond, the kernels' dynamic-LDS limit is raised to what the request needs (gfx950: 160 KiB per workgroup =
+// 640 rows: T <= 622 at theta = 9; the reference's DeltaLayer has no limit, its longest utterances have ~ 40 frames).
+constexpr size_t kDeltaMaxLds = 160 * 1024;
+template <typename K>
+static int delta_allow_lds(K kernel, size_t lds) {
+    if (lds <= 64 * 1024) return ADN_OK;
+    ADN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDeltaMaxLds));
+    return ADN_OK;
+}
+
 int delta_forward(const float* in, int ld_in, float* out, int ld_out, int B, int T, int F, int theta, int append,
                   hipStream_t s, void* out16) {
     ADN_CHECK(T > 0 && B > 0 && F > 0 && theta >= 0, ADN_ERR_INVALID, "delta_forward: empty tensor");
     const size_t lds = (size_t)2 * (T + 2 * theta) * kDeltaFC * sizeof(float);
-    ADN_CHECK(lds <= 64 * 1024, ADN_ERR_INVALID, "delta layer: T + 2 theta too large (max 256 rows)");
+    ADN_CHECK(lds <= kDeltaMaxLds, ADN_ERR_INVALID, "delta layer: T + 2 theta too large (max 640 rows)");
+    ADN_TRY(delta_allow_lds(theta == 9 ? &delta_fwd_kernel<9> : (theta == 3 ? &delta_fwd_kernel<3> : &delta_fwd_kernel<0>), lds));
     ProfScope prof(PROF_DELTA_FWD, 0.0, 4.0 * B * T * (double)F * (append ? 4.0 : 2.0), s);
     const dim3 grid(B, cdiv(F, kDeltaFC));
     if (theta == 9)                  // the reference's windows: 9 (video streams), 3 (OuluVS audio)
@@ -164,7 +176,8 @@ int delta_backward(const float* dout, int ld_out, float* din, int ld_in, int B, 
                    hipStream_t s, void* din16) {
     ADN_CHECK(T > 0 && B > 0 && F > 0 && theta >= 0, ADN_ERR_INVALID, "delta_backward: empty tensor");
     const size_t lds = (size_t)2 * (T + 2 * theta) * kDeltaFC * sizeof(float);
-    ADN_CHECK(lds <= 64 * 1024, ADN_ERR_INVALID, "delta layer: T + 2 theta too large (max 256 rows)");
+    ADN_CHECK(lds <= kDeltaMaxLds, ADN_ERR_INVALID, "delta layer: T + 2 theta too large (max 640 rows)");
+    ADN_TRY(delta_allow_lds(theta == 9 ? &delta_bwd_kernel<9> : (theta == 3 ? &delta_bwd_kernel<3> : &delta_bwd_kernel<0>), lds));
     ProfScope prof(PROF_DELTA_BWD, 0.0, 4.0 * B * T * (double)F * (append ? 4.0 : 2.0), s);
     const dim3 grid(B, cdiv(F, kDeltaFC));
     if (theta == 9)
@@ -454,7 +467,11 @@ int softmax_ce(const float* z, int ldz, int B, int T, int C, const int32_t* y_bt
 // lasagne.updates.sgd / momentum / nesterov_momentum / adadelta on the flat buffers
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ vel,
-                                                  int64_t n4, float lr, float mu, int nesterov) {
+                                                  int64_t n4, float lr, float mu, int nesterov, const float* poison, int* sticky) {
+    if (poison && *poison != 0.f) {          // a rank's LSTM exchange timed out: the gradients are invalid on EVERY rank
+        if (sticky && blockIdx.x == 0 && threadIdx.x == 0) *sticky = 1;
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         float4 P = reinterpret_cast<float4*>(p)[i];
         const float4 G = reinterpret_cast<const float4*>(g)[i];
@@ -477,18 +494,24 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
     }
 }
 
-int sgd_update(float* p, const float* g, float* vel, int64_t n, float lr, float momentum, int nesterov, hipStream_t s) {
+int sgd_update(float* p, const float* g, float* vel, int64_t n, float lr, float momentum, int nesterov, hipStream_t s,
+               const float* poison, int* sticky) {
     ADN_CHECK(n % 4 == 0, ADN_ERR_INVALID, "sgd_update: element count must be a multiple of 4");
     if (!n) return ADN_OK;
     const int64_t n4 = n / 4;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n4 + 255) / 256, 8192));
-    hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, s, p, g, vel, n4, lr, momentum, nesterov);
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, s, p, g, vel, n4, lr, momentum, nesterov, poison, sticky);
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }
 
 __global__ __launch_bounds__(256) void adadelta_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ accu,
-                                                       float* __restrict__ delta, int64_t n4, float lr, float rho, float eps) {
+                                                       float* __restrict__ delta, int64_t n4, float lr, float rho, float eps,
+                                                       const float* poison, int* sticky) {
+    if (poison && *poison != 0.f) {          // a rank's LSTM exchange timed out: the gradients are invalid on EVERY rank
+        if (sticky && blockIdx.x == 0 && threadIdx.x == 0) *sticky = 1;
+        return;
+    }
     const float omr = 1.f - rho;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         float4 P = reinterpret_cast<float4*>(p)[i], A = reinterpret_cast<float4*>(accu)[i], D = reinterpret_cast<float4*>(delta)[i];
@@ -506,12 +529,13 @@ __global__ __launch_bounds__(256) void adadelta_kernel(float* __restrict__ p, co
     }
 }
 
-int adadelta_update(float* p, const float* g, float* accu, float* delta, int64_t n, float lr, float rho, float eps, hipStream_t s) {
+int adadelta_update(float* p, const float* g, float* accu, float* delta, int64_t n, float lr, float rho, float eps, hipStream_t s,
+                    const float* poison, int* sticky) {
     ADN_CHECK(n % 4 == 0, ADN_ERR_INVALID, "adadelta_update: element count must be a multiple of 4");
     if (!n) return ADN_OK;
     const int64_t n4 = n / 4;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n4 + 255) / 256, 8192));
-    hipLaunchKernelGGL(adadelta_kernel, dim3(grid), dim3(256), 0, s, p, g, accu, delta, n4, lr, rho, eps);
+    hipLaunchKernelGGL(adadelta_kernel, dim3(grid), dim3(256), 0, s, p, g, accu, delta, n4, lr, rho, eps, poison, sticky);
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }
@@ -739,7 +763,11 @@ int reduce_loss(const float* v, int n, const float* total, float* out, hipStream
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n4,
                                                    int64_t n, float a_t, float b1, float b2, float eps,
-                                                   __bf16* __restrict__ p16) {
+                                                   __bf16* __restrict__ p16, const float* poison, int* sticky) {
+    if (poison && *poison != 0.f) {          // a rank's LSTM exchange timed out: the gradients are invalid on EVERY rank
+        if (sticky && blockIdx.x == 0 && threadIdx.x == 0) *sticky = 1;
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         float4 pp = reinterpret_cast<float4*>(p)[i];
         const float4 gg = reinterpret_cast<const float4*>(g)[i];
@@ -771,13 +799,46 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// float4 copy (bench.py's measured-HBM yardstick)
+__global__ __launch_bounds__(256) void copy4_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+int copy_bench(const float* src, float* dst, int64_t n, int repeats, hipStream_t s, float* ms) {
+    ADN_CHECK(src && dst && ms && n >= 4 && repeats >= 1, ADN_ERR_INVALID, "copy_bench: bad argument");
+    ADN_CHECK(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, ADN_ERR_INVALID, "copy_bench: 16-byte alignment");
+    hipEvent_t a, b;
+    ADN_HIP_CHECK(hipEventCreate(&a)); ADN_HIP_CHECK(hipEventCreate(&b));
+    const int64_t n4 = n / 4;
+    const int grid = (int)std::min<int64_t>((n4 + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(copy4_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n4);
+    ADN_HIP_CHECK(hipEventRecord(a, s));
+    for (int r = 0; r < repeats; ++r)
+        hipLaunchKernelGGL(copy4_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n4);
+    ADN_HIP_CHECK(hipEventRecord(b, s));
+    ADN_HIP_CHECK(hipEventSynchronize(b));
+    ADN_HIP_CHECK(hipEventElapsedTime(ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return ADN_OK;
+}
+
+// tail[1] of the gradient buffer = 1 when this device's LSTM-exchange error word is raised (it rides through the data-parallel
+// all-reduce, so that the optimiser kernels of EVERY rank see it and skip the update together)
+__global__ void poison_tail_kernel(const int* __restrict__ err_word, float* __restrict__ tail1) {
+    *tail1 = (*err_word != 0) ? 1.f : 0.f;
+}
+int poison_tail(const int* err_word, float* tail1, hipStream_t s) {
+    hipLaunchKernelGGL(poison_tail_kernel, dim3(1), dim3(1), 0, s, err_word, tail1);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
 int adam_update(float* p, const float* g, float* m, float* v, int64_t n, float a_t, float beta1, float beta2,
-                float eps, hipStream_t s, void* p16) {
+                float eps, hipStream_t s, void* p16, const float* poison, int* sticky) {
     if (n <= 0) return ADN_OK;
     const int64_t n4 = n / 4;
     ProfScope prof(PROF_ADAM, 0.0, 7.0 * 4.0 * (double)n, s);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(std::max<int64_t>(n4, 1))), dim3(256), 0, s, p, g, m, v, n4, n, a_t,
-                       beta1, beta2, eps, reinterpret_cast<__bf16*>(p16));
+                       beta1, beta2, eps, reinterpret_cast<__bf16*>(p16), poison, sticky);
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }

@@ -8,7 +8,6 @@ namespace adn {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // one problem of a grouped launch (gemm_bf16_pp_kernel): same shape, leading dimensions and flags, own buffers
-constexpr int kMaxGemmGroups = 4;
 struct GemmGroup {
     const void* A16; const void* B16;
     float* C; void* C16;

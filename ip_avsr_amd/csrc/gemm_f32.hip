@@ -183,7 +183,6 @@ static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used
     static const int mode_env = getenv("ADN_GEMM_PP") ? atoi(getenv("ADN_GEMM_PP")) : -1;   // 0: off, 4/5/6: force a tile shape
     if (mode_env == 0 || n > kMaxGemmGroups) return ADN_OK;
     if (g.precision != ADN_PRECISION_BF16 || g.layout == GEMM_NT) return ADN_OK;
-    if (g.M < 1024 && g.N < 1024) return ADN_OK;
     if (g.M < 256 || g.N < 256 || g.K < 256) return ADN_OK;
     if (g.N % 4 || g.ldc % 4 || g.lda % 8 || g.ldb % 8) return ADN_OK;
     if (g.layout == GEMM_NN && g.K % 8 && g.lda < round_up(g.K, 8)) return ADN_OK;
@@ -206,12 +205,20 @@ static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used
     const int cus = device_cus();
     const bool lean_c = !g.C;
     const bool can_split = g.act == ADN_ACT_LINEAR && !lean_c && !g.no_split && !g.bias && !g.Y && !g.Y16 && !g.colsum;
-    // ---- tile shape: fewest tile-rounds weighted by the shape's relative rate; split-K only with the square tile
+    // ---- where it pays (profiles/r02/gemm_lab_pp.txt, MI355X, against the register-staged 128 x 128 kernel):
+    //   * split-K weight gradients with outputs of >= 1.8 M elements (dW fc1 / fc2): 144 / 114 us against 171 / 137
+    //     (692 - 750 TFLOP/s; partial slabs + reduce instead of 64 MB of float atomics)
+    //   * forward GEMMs of several input streams as ONE grouped launch, plain epilogue (bias / rectify, no act'(Y)
+    //     loads, no fused column sums): 120 against 137 us per stream for 20800 x 1000 x 2000 -- three streams fill
+    //     7.7 rounds of 256 CUs where one fills 1.3; a lone launch loses that to its last round
+    //   * NOT the input-gradient GEMMs: the transposed-accumulator epilogue reads the act'(Y) mask in 32-byte
+    //     row pieces (205 against 146 us), and not 128-wide tiles (445 TFLOP/s: B-fragment reads per flop double)
     struct Cand { int mode, bm, bn; double rate; };
-    static const Cand cands[3] = {{4, 256, 256, 1.0}, {5, 256, 128, 0.80}, {6, 128, 256, 0.80}};
+    static const Cand cands[3] = {{4, 256, 256, 1.0}, {5, 256, 128, 0.70}, {6, 128, 256, 0.70}};
     int best = -1, splits = 1; double best_cost = 0;
     for (int c = 0; c < 3; ++c) {
         if (mode_env >= 4 && cands[c].mode != mode_env) continue;
+        if (mode_env < 4 && cands[c].mode != 4) continue;
         const int64_t tiles = (int64_t)cdiv(g.M, cands[c].bm) * cdiv(g.N, cands[c].bn) * n;
         int sp = 1;
         if (tiles * 2 <= cus && can_split && g.K >= 2048) {
@@ -223,9 +230,13 @@ static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used
         if (best < 0 || cost < best_cost) { best = c; best_cost = cost; splits = sp; }
     }
     if (best < 0) return ADN_OK;
-    // useful work per CU-round vs what the register-staged kernels deliver (~0.62 of this kernel's rate at full tiles)
-    const double ideal = (double)g.M * g.N * n / cus;
-    if (mode_env < 4 && ideal / best_cost < 0.55) return ADN_OK;
+    if (mode_env < 4) {
+        const double fill = ((double)g.M * g.N * n / cus) / best_cost;       // useful share of the tile-rounds
+        const bool plain = !g.Y && !g.Y16 && !g.colsum;
+        const bool wgrad = splits > 1 && (int64_t)g.M * g.N >= 1800000;
+        const bool fwd_group = splits == 1 && n >= 2 && plain && fill >= 0.85;
+        if (!wgrad && !fwd_group) return ADN_OK;
+    }
     const Cand& cd = cands[best];
 
     GemmParams p;

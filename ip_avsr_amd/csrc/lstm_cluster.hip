@@ -562,17 +562,27 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_kernel(const LstmCluster
     }
 }
 
-static unsigned g_cluster_epoch = 1;
-static int* g_cluster_err = nullptr;       // device word, lazily allocated; polled after the launch by the caller's sync
+// per-device launcher state (one process may drive several devices: a model polls the error word of ITS device and
+// sizes its launches by ITS device's CU count)
+constexpr int kMaxDevices = 64;
+static unsigned g_cluster_epoch = 1;       // launch tag (any strictly increasing sequence works; shared on purpose)
+static int* g_cluster_err[kMaxDevices] = {};   // device words, lazily allocated; polled after the launch by the caller's sync
+static int g_cluster_cus[kMaxDevices] = {};
+
+static int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 0;
+    return dev;
+}
 
 static int cluster_cus() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-        cus = prop.multiProcessorCount;
+    const int dev = current_device();
+    if (!g_cluster_cus[dev]) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        g_cluster_cus[dev] = prop.multiProcessorCount;
     }
-    return cus;
+    return g_cluster_cus[dev];
 }
 
 static int cluster_wgs(int H) { return H <= 256 ? 4 : 8; }      // workgroups per group: 64 hidden units each
@@ -593,11 +603,12 @@ size_t lstm_cluster_xchg_bytes(int B, int H) {   // forward region (h granules) 
 }
 
 int lstm_cluster_error_word(int** out) {
-    if (!g_cluster_err) {
-        ADN_HIP_CHECK(hipMalloc((void**)&g_cluster_err, sizeof(int)));
-        ADN_HIP_CHECK(hipMemset(g_cluster_err, 0, sizeof(int)));
+    const int dev = current_device();
+    if (!g_cluster_err[dev]) {
+        ADN_HIP_CHECK(hipMalloc((void**)&g_cluster_err[dev], sizeof(int)));
+        ADN_HIP_CHECK(hipMemset(g_cluster_err[dev], 0, sizeof(int)));
     }
-    *out = g_cluster_err;
+    *out = g_cluster_err[dev];
     return ADN_OK;
 }
 
@@ -610,7 +621,8 @@ static int forward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int
     ADN_TRY(lstm_cluster_error_word(&err));
     const int ldh = ld_of(H), ldg = ld_of(4 * H);
     const size_t lds = (size_t)(G::WLdsFwd + kCRows * G::HS) * 2;
-    static bool attr = false;
+    static bool attr_set[kMaxDevices] = {};        // (a function attribute is per device)
+    bool& attr = attr_set[current_device()];
     if (!attr) {
         ADN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_cluster_kernel<CWG>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -643,7 +655,8 @@ static int backward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, in
     ADN_TRY(lstm_cluster_error_word(&err));
     const int ldh = ld_of(H), ldg = ld_of(4 * H);
     const size_t lds = (size_t)(G::WLdsBwd + kCRows * kCDS) * 2 + (size_t)kCRows * (kCUnits + 1) * 4;
-    static bool attr = false;
+    static bool attr_set[kMaxDevices] = {};        // (a function attribute is per device)
+    bool& attr = attr_set[current_device()];
     if (!attr) {
         ADN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_cluster_kernel<CWG>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

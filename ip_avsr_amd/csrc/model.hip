@@ -157,6 +157,8 @@ struct adn_model {
     float* flat[4] = {nullptr, nullptr, nullptr, nullptr};   // param, grad, m, v
     int adam_t = 0;
     bool grads_valid = false;
+    int* poison_sticky = nullptr;      // device word: an optimiser kernel skipped its update because a rank's gradients were invalid
+    float* poison_word() const { return flat[ADN_BUF_GRAD] + flat_floats + 1; }      // tail[1] of the gradient buffer
     // stochastic layers: masks are a hash of (seed, counter, layer, element); `stochastic` is set per call
     uint32_t drop_seed = 0x5EED1234u, drop_counter = 0;
     bool stochastic = false;
@@ -194,6 +196,8 @@ struct adn_model {
     // concat fusion in bf16 mode: the aggregation LSTMs read ONE materialised [N][S*ldh] bf16 matrix, so their input
     // projection, dW_in and the gradient wrt the concat are one GEMM each per LSTM instead of S
     char* cat16 = nullptr; float* dcat = nullptr; float* wcat_tmp = nullptr;
+    // partial slabs of the split-K weight-gradient GEMMs (gemm_bf16_pp_kernel): one workgroup = one 256 x 256 fp32 tile
+    float* splitk_ws = nullptr; size_t splitk_ws_floats = 0;
     int lastB = 0, lastT = 0;
     Profiler prof;
     // bf16 shadow copies of every GEMM operand (bf16 mode): fp32 range -> bf16 buffer with the same layout
@@ -503,9 +507,19 @@ int stage_inputs(adn_model* m, const void* const* inputs, const int32_t* targets
 
 bool shadows_on(const adn_model* m) { return m->bf16() && !getenv("ADN_BF16_NO_SHADOW"); }
 
+int ensure_splitk_ws(adn_model* m) {
+    if (m->splitk_ws || !m->bf16()) return ADN_OK;
+    // every (tile, K-slice) workgroup of a launch owns one slab piece: <= CUs x 256 x 256 floats, + row padding
+    m->splitk_ws_floats = (size_t)24 << 20;
+    ADN_HIP_CHECK(hipMalloc((void**)&m->splitk_ws, m->splitk_ws_floats * sizeof(float)));
+    return ADN_OK;
+}
+
+// fills in the bf16 operand copies of one GEMM of the model (bf16 mode)
 // lean: the fp32 copy of C is not needed by anyone (bf16 mode: every consumer reads the shadow) -> skip writing it
-int mgemm(adn_model* m, GemmArgs& g, bool lean = false) {
+void mgemm_prepare(adn_model* m, GemmArgs& g, bool lean) {
     g.precision = m->cfg.precision;
+    g.splitk_ws = m->splitk_ws; g.splitk_ws_floats = m->splitk_ws_floats;
     if (shadows_on(m)) {                                  // env switch: convert-in-flight reference path
         g.A16 = m->shadow_of(g.A);
         g.B16 = m->shadow_of(g.B);
@@ -517,6 +531,10 @@ int mgemm(adn_model* m, GemmArgs& g, bool lean = false) {
         if (lean && g.A16 && g.B16 && g.C16 && !g.accumulate && g.N % 4 == 0 && g.ldc % 4 == 0 && !m->keep_fp32)
             g.C = nullptr;
     }
+}
+
+int mgemm(adn_model* m, GemmArgs& g, bool lean = false) {
+    mgemm_prepare(m, g, lean);
     return gemm(g, m->stream);
 }
 
@@ -573,6 +591,7 @@ int refresh_transposed(adn_model* m) {
 
 int refresh_params(adn_model* m) {
     if (!m->bf16()) return ADN_OK;
+    ADN_TRY(ensure_splitk_ws(m));
     const bool persistent = lstm_persistent_supported(m->H);        // (an environment switch can flip it between calls)
     if (persistent != m->packed_for_persistent) m->params16_dirty = true;
     if (!m->params16_dirty) return ADN_OK;
@@ -753,17 +772,50 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
     hipStream_t s = m->stream;
     std::vector<LstmStep> steps;
     ADN_TRY(fork_streams(m));
+    auto enc_gemm = [&](StreamState& st, int l) {                // modelzoo/pretrained_encoder.py:4-9
+        GemmArgs g;
+        g.layout = GEMM_NN; g.M = N; g.N = st.cfg.enc_units[l]; g.K = st.enc_in[l];
+        g.A = l ? st.act[l - 1] : st.x; g.lda = l ? ld_of(st.enc_in[l]) : st.ldx;
+        g.B = m->P(st.encW[l]); g.ldb = ld_of(g.N);
+        g.C = st.act[l]; g.ldc = ld_of(g.N); g.bias = m->P(st.encb[l]); g.act = st.cfg.enc_act[l];
+        g.no_split = 1;                                          // forward pass: reproducible bits
+        mgemm_prepare(m, g, /*lean=*/l + 1 < st.cfg.n_enc);      // the delta layer reads the last one in fp32
+        return g;
+    };
+    // Encoders layer by layer; the streams whose layer l has the same geometry go out as ONE grouped launch (their
+    // tiles share a list: the AVLetters model's 3 x 656 tiles fill 7.7 rounds of 256 CUs, one stream alone 2.6).
+    const bool grouped = !streams_concurrent(m);
+    if (grouped) {
+        int max_enc = 0;
+        for (auto& st : m->st) max_enc = std::max(max_enc, st.cfg.n_enc);
+        for (int l = 0; l < max_enc; ++l) {
+            std::vector<char> done(m->st.size(), 0);
+            for (size_t i = 0; i < m->st.size(); ++i) {
+                if (done[i] || m->st[i].cfg.n_enc <= l) continue;
+                GemmArgs batch[kMaxGemmGroups];
+                int nb = 0;
+                batch[nb++] = enc_gemm(m->st[i], l);
+                done[i] = 1;
+                for (size_t j = i + 1; j < m->st.size() && nb < kMaxGemmGroups; ++j) {
+                    StreamState& o = m->st[j];
+                    if (done[j] || o.cfg.n_enc <= l) continue;
+                    GemmArgs c = enc_gemm(o, l);
+                    const GemmArgs& r = batch[0];
+                    if (c.N == r.N && c.K == r.K && c.lda == r.lda && c.act == r.act && (c.C == nullptr) == (r.C == nullptr) &&
+                        (c.A16 == nullptr) == (r.A16 == nullptr) && (o.cfg.n_enc == l + 1) == (m->st[i].cfg.n_enc == l + 1)) {
+                        batch[nb++] = c; done[j] = 1;
+                    }
+                }
+                ADN_TRY(gemm_grouped(batch, nb, m->stream));
+            }
+        }
+    }
     for (auto& st : m->st) {
         OnSideStream on(m, (int)(&st - m->st.data()));           // encoder, delta layer, input projection of this stream
         const float* a = st.x; int lda = st.ldx;
-        for (int l = 0; l < st.cfg.n_enc; ++l) {                 // modelzoo/pretrained_encoder.py:4-9
-            GemmArgs g;
-            g.layout = GEMM_NN; g.M = N; g.N = st.cfg.enc_units[l]; g.K = st.enc_in[l];
-            g.A = a; g.lda = lda; g.B = m->P(st.encW[l]); g.ldb = ld_of(g.N);
-            g.C = st.act[l]; g.ldc = ld_of(g.N); g.bias = m->P(st.encb[l]); g.act = st.cfg.enc_act[l];
-            g.no_split = 1;                                      // forward pass: reproducible bits
-            ADN_TRY(mgemm(m, g, /*lean=*/l + 1 < st.cfg.n_enc));      // the delta layer reads the last one in fp32
-            a = st.act[l]; lda = g.ldc;
+        for (int l = 0; l < st.cfg.n_enc; ++l) {
+            if (!grouped) { GemmArgs g = enc_gemm(st, l); ADN_TRY(gemm(g, m->stream)); }
+            a = st.act[l]; lda = ld_of(st.cfg.enc_units[l]);
         }
         const bool drop = m->stochastic && st.cfg.dropout_p > 0.f;
         void* feat16 = (m->bf16() && !drop) ? m->shadow_of(st.feat) : nullptr;      // written by the delta kernel itself
@@ -1122,6 +1174,11 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         ADN_TRY(bucket_ready(split_first ? b_rest + 1 : b_rest));        // every gradient of this stream is final
     }
     ADN_TRY(join_streams(m));
+    if (m->bf16()) {                          // this device's exchange status -> tail[1] (summed over ranks by the all-reduce)
+        int* word = nullptr;
+        ADN_TRY(lstm_cluster_error_word(&word));
+        ADN_TRY(poison_tail(word, m->poison_word(), m->stream));
+    }
     m->grads_valid = true;
     return ADN_OK;
 }
@@ -1151,6 +1208,9 @@ int check_shape(const adn_model* m, int B, int T, int theta) {
 // (lstm_cluster.hip); call after the stream has been synchronised
 int check_device_errors(adn_model* m) {
     if (!m->bf16()) return ADN_OK;
+    int sticky = 0;
+    ADN_HIP_CHECK(hipMemcpy(&sticky, m->poison_sticky, sizeof(int), hipMemcpyDeviceToHost));
+    if (sticky) ADN_HIP_CHECK(hipMemset(m->poison_sticky, 0, sizeof(int)));
     int* word = nullptr;
     ADN_TRY(lstm_cluster_error_word(&word));
     int v = 0;
@@ -1162,6 +1222,11 @@ int check_device_errors(adn_model* m) {
                  "received its partners' state; results are invalid", (v & 15) == 1 ? "forward" : "backward", (v >> 4) & 4095,
                  (v >> 16) & 1023);
         set_error(msg);
+        return ADN_ERR_STATE;
+    }
+    if (sticky) {
+        set_error("an optimiser step was skipped: the LSTM exchange of a data-parallel peer timed out and its gradients were "
+                  "invalid (the flag travels in the gradient buffer's tail, so every rank skips the same step)");
         return ADN_ERR_STATE;
     }
     return ADN_OK;
@@ -1187,6 +1252,7 @@ int tensor_io(adn_model* m, int buffer, int index, float* host, bool write) {
     const int rows = p.rows(), cols = p.cols();
     float* base = m->flat[buffer] + p.off;
     ADN_HIP_CHECK(hipStreamSynchronize(m->stream));
+    ADN_TRY(check_device_errors(m));
     if (p.col_stride == 1) {
         if (write) {
             ADN_HIP_CHECK(hipMemcpy2D(base, (size_t)p.ld * 4, host, (size_t)cols * 4, (size_t)cols * 4, rows,
@@ -1264,6 +1330,11 @@ int adn_create(const adn_config* cfg, adn_model** out) {
             return ADN_ERR_HIP;
         }
     }
+    if (hipMalloc((void**)&m->poison_sticky, sizeof(int)) != hipSuccess || hipMemset(m->poison_sticky, 0, sizeof(int)) != hipSuccess) {
+        set_error("hipMalloc of the model's status word failed");
+        adn_destroy(m);
+        return ADN_ERR_HIP;
+    }
     *out = m;
     return ADN_OK;
 }
@@ -1292,6 +1363,8 @@ void adn_destroy(adn_model* m) {
     for (auto& st : m->st) for (auto& lp : st.lstm) free_lp(lp);
     for (auto& lp : m->agg) free_lp(lp);
     if (m->slab) (void)hipFree(m->slab);
+    if (m->splitk_ws) (void)hipFree(m->splitk_ws);
+    if (m->poison_sticky) (void)hipFree(m->poison_sticky);
     delete m;
 }
 
@@ -1421,6 +1494,15 @@ int adn_compute_grads(adn_model* m, const void* const* inputs, const int32_t* ta
     return ADN_OK;
 }
 
+int adn_zero_grads(adn_model* m) {
+    ADN_CHECK(m, ADN_ERR_INVALID, "null model");
+    ADN_HIP_CHECK(hipMemsetAsync(m->flat[ADN_BUF_GRAD], 0, (m->flat_floats + kAuxFloats) * sizeof(float), m->stream));
+    for (auto ev : m->bucket_events)
+        if (ev) ADN_HIP_CHECK(hipEventRecord(ev, m->stream));
+    m->grads_valid = true;
+    return ADN_OK;
+}
+
 int adn_apply_adam(adn_model* m, float learning_rate) {
     ADN_CHECK(m, ADN_ERR_INVALID, "null model");
     ADN_CHECK(m->grads_valid, ADN_ERR_STATE, "adn_apply_adam called without gradients (call adn_compute_grads first)");
@@ -1429,7 +1511,7 @@ int adn_apply_adam(adn_model* m, float learning_rate) {
     const float a_t = learning_rate * sqrtf(1.f - powf(kBeta2, t)) / (1.f - powf(kBeta1, t));
     void* p16 = shadows_on(m) ? m->params16 : nullptr;          // the update writes the bf16 shadow as well
     ADN_TRY(adam_update(m->flat[ADN_BUF_PARAM], m->flat[ADN_BUF_GRAD], m->flat[ADN_BUF_ADAM_M], m->flat[ADN_BUF_ADAM_V],
-                        (int64_t)m->flat_floats, a_t, kBeta1, kBeta2, kEps, m->stream, p16));
+                        (int64_t)m->flat_floats, a_t, kBeta1, kBeta2, kEps, m->stream, p16, m->poison_word(), m->poison_sticky));
     m->grads_valid = false;
     m->mark_params_dirty();
     m->params16_values_fresh = p16 != nullptr;
@@ -1447,7 +1529,7 @@ int adn_apply_sgd(adn_model* m, float learning_rate, float momentum, int nestero
     ADN_CHECK(m->grads_valid, ADN_ERR_STATE, "adn_apply_sgd called without gradients (call adn_compute_grads first)");
     ADN_CHECK(momentum >= 0.f && momentum < 1.f, ADN_ERR_INVALID, "momentum must be in [0, 1)");
     ADN_TRY(sgd_update(m->flat[ADN_BUF_PARAM], m->flat[ADN_BUF_GRAD], m->flat[ADN_BUF_ADAM_M], (int64_t)m->flat_floats,
-                       learning_rate, momentum, nesterov, m->stream));
+                       learning_rate, momentum, nesterov, m->stream, m->poison_word(), m->poison_sticky));
     m->grads_valid = false;
     m->mark_params_dirty();
     return ADN_OK;
@@ -1457,7 +1539,7 @@ int adn_apply_adadelta(adn_model* m, float learning_rate, float rho, float epsil
     ADN_CHECK(m, ADN_ERR_INVALID, "null model");
     ADN_CHECK(m->grads_valid, ADN_ERR_STATE, "adn_apply_adadelta called without gradients (call adn_compute_grads first)");
     ADN_TRY(adadelta_update(m->flat[ADN_BUF_PARAM], m->flat[ADN_BUF_GRAD], m->flat[ADN_BUF_ADAM_M], m->flat[ADN_BUF_ADAM_V],
-                            (int64_t)m->flat_floats, learning_rate, rho, epsilon, m->stream));
+                            (int64_t)m->flat_floats, learning_rate, rho, epsilon, m->stream, m->poison_word(), m->poison_sticky));
     m->grads_valid = false;
     m->mark_params_dirty();
     return ADN_OK;
@@ -1488,7 +1570,7 @@ int adn_apply_adam_vlr(adn_model* m, const float* lr_by_param, int n) {
         const size_t b = r.first.first, e = r.first.second;
         ADN_TRY(adam_update(m->flat[ADN_BUF_PARAM] + b, m->flat[ADN_BUF_GRAD] + b, m->flat[ADN_BUF_ADAM_M] + b,
                             m->flat[ADN_BUF_ADAM_V] + b, (int64_t)(e - b), r.second * scale, kBeta1, kBeta2, kEps,
-                            m->stream));
+                            m->stream, nullptr, m->poison_word(), m->poison_sticky));
     }
     m->grads_valid = false;
     m->mark_params_dirty();
@@ -1609,6 +1691,10 @@ int adn_op_delta_backward(const float* dout, int ld_out, float* din, int ld_in, 
 
 int adn_op_adam(float* p, const float* g, float* m, float* v, int64_t n, float a_t, void* hip_stream) {
     return adam_update(p, g, m, v, n, a_t, kBeta1, kBeta2, kEps, static_cast<hipStream_t>(hip_stream));
+}
+
+int adn_op_copy_bench(const float* src, float* dst, int64_t n, int repeats, void* hip_stream, float* ms) {
+    return copy_bench(src, dst, n, repeats, static_cast<hipStream_t>(hip_stream), ms);
 }
 
 // ---- feature front-end (prep.hip) ----------------------------------------------------------------

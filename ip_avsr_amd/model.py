@@ -333,6 +333,17 @@ class AdeNetModel(object):
                                                float(total_frames), C.byref(out) if want_loss else None))
         return np.float32(out.value) if want_loss else None
 
+    def zero_grads(self):
+        """``compute_grads`` of an EMPTY shard (data parallel: this rank got no utterance of a short minibatch): zero
+        gradients and cost share, bucket events recorded, so that the rank still joins every all-reduce."""
+        _lib.check(self._lib.adn_zero_grads(self._handle))
+
+    def adam_step_count(self):
+        return int(self._lib.adn_adam_step_count(self._handle))
+
+    def set_adam_step_count(self, t):
+        _lib.check(self._lib.adn_set_adam_step_count(self._handle, int(t)))
+
     def apply_adam(self, learning_rate):
         _lib.check(self._lib.adn_apply_adam(self._handle, float(learning_rate)))
 

@@ -60,6 +60,9 @@ class DataParallel(object):
         self.world_size = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
         self.grad = grad_tensor if grad_tensor is not None else wrap_flat_buffer(model)
+        self._own_grad = grad_tensor           # CPU test path: the replica owns host tensors instead of device buffers
+        self._own_buffers = getattr(model, "host_buffers", None)
+        self._inflight = False
         # Overlap (GPU replicas only): the library records one HIP event per gradient bucket as soon as that
         # bucket is final; a communication stream waits on it and all-reduces the bucket while back-propagation
         # of the remaining streams is still running.  Only the last stream's first encoder layer is exposed.
@@ -79,18 +82,45 @@ class DataParallel(object):
             model.set_bucket_events([ev.cuda_event for ev in self.events])
 
     def broadcast_parameters(self, src=0):
-        """Make every replica start from rank ``src``'s parameters and Adam state."""
+        """Make every replica start from rank ``src``'s parameters, optimiser state and Adam step count."""
         for which in (_lib.BUF_PARAM, _lib.BUF_ADAM_M, _lib.BUF_ADAM_V):
-            self.dist.broadcast(wrap_flat_buffer(self.model, which), src=src, group=self.group)
+            if self._own_grad is None:
+                buf = wrap_flat_buffer(self.model, which)
+            elif self._own_buffers is not None:
+                buf = self._own_buffers[which]
+            else:
+                continue                              # a test replica without host copies of its state
+            self.dist.broadcast(buf, src=src, group=self.group)
+        if hasattr(self.model, "adam_step_count"):
+            t = self.grad.new_tensor([float(self.model.adam_step_count())])
+            self.dist.broadcast(t, src=src, group=self.group)
+            self.model.set_adam_step_count(int(t.item()))
 
-    def train_step(self, inputs, targets, mask, window, learning_rate, global_total_frames, want_loss=False):
-        """One data-parallel step on this rank's shard.  ``global_total_frames`` = valid frames of the whole
-        global batch.  Returns the GLOBAL cost (a host float) when ``want_loss`` (forces a sync)."""
-        self.model.compute_grads(inputs, targets, mask, window, total_frames=float(global_total_frames),
-                                 want_loss=False)
+    def assert_quiescent(self):
+        """The invariant of DESIGN.md 7 as a check: no bucket all-reduce of this replica may be outstanding when a step's
+        forward pass is enqueued -- the weight-stationary LSTM launches need (nearly) every CU resident at once, and a
+        collective kernel that runs beside one can leave both half-scheduled on several GPUs, each waiting for CUs the
+        other holds."""
+        if self._inflight:
+            raise RuntimeError("data parallel: a gradient all-reduce is still outstanding; the compute stream must join the "
+                               "communication stream before the next step is enqueued")
+
+    def train_step(self, inputs, targets, mask, window, learning_rate, global_total_frames, want_loss=False, update=None):
+        """One data-parallel step on this rank's shard (``inputs`` etc. may hold ZERO utterances: the rank then contributes
+        zero gradients).  ``global_total_frames`` = valid frames of the whole global batch.  ``update``: what to run on the
+        reduced gradients instead of ``apply_adam(learning_rate)`` -- a callable taking the model (per-layer learning
+        rates: ``lambda m: m.apply_adam_vlr(lr_map)``; other update rules).  Returns the GLOBAL cost (a host float) when
+        ``want_loss`` (forces a sync)."""
+        self.assert_quiescent()
+        if len(mask) == 0:
+            self.model.zero_grads()
+        else:
+            self.model.compute_grads(inputs, targets, mask, window, total_frames=float(global_total_frames),
+                                     want_loss=False)
         if self.overlap:
             torch = self._torch
             works = []
+            self._inflight = True
             with torch.cuda.stream(self.comm_stream):
                 for (b, e), ev in zip(self.buckets, self.events):
                     self.comm_stream.wait_event(ev)      # bucket final on the compute stream
@@ -99,13 +129,64 @@ class DataParallel(object):
             for w in works:
                 w.wait()                                 # the compute stream waits for the reductions
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+            self._inflight = False
         elif self.world_size > 1:
             # same stream as the model's kernels (torch's current stream): ordered after the backward pass
             self.dist.all_reduce(self.grad, op=self.dist.ReduceOp.SUM, group=self.group)
-        self.model.apply_adam(learning_rate)
+        if update is None:
+            self.model.apply_adam(learning_rate)
+        else:
+            update(self.model)
         if want_loss:
             return float(self.grad[-8].item())
         return None
+
+    # ------------------------------------------------------------------ sharded evaluation
+    def shard(self, n):
+        """Row indices of an n-row batch this rank evaluates."""
+        return list(range(n))[self.rank::self.world_size]
+
+    def gather_rows(self, local, n):
+        """Reassembles an (n, ...) array from the ranks' row shards ``local`` = full[rank::world] (any trailing shape,
+        identical on every rank).  One all-gather of equally padded shards."""
+        import torch
+        local = np.ascontiguousarray(local)
+        per = -(-n // self.world_size)
+        pad = np.zeros((per,) + local.shape[1:], dtype=local.dtype)
+        pad[:len(local)] = local
+        dev = self.grad.device
+        mine = torch.as_tensor(pad, device=dev)
+        parts = [torch.empty_like(mine) for _ in range(self.world_size)]
+        self.dist.all_gather(parts, mine, group=self.group)
+        out = np.zeros((n,) + local.shape[1:], dtype=local.dtype)
+        for r, part in enumerate(parts):
+            rows = len(range(r, n, self.world_size))
+            out[r::self.world_size] = part.cpu().numpy()[:rows]
+        return out
+
+    def predict_sharded(self, predict, inputs, mask, window):
+        """``val_fn`` on the whole batch with the utterances split over the ranks; every rank gets the full result
+        (shard the held-out utterances, gather the votes)."""
+        n = len(mask)
+        idx = self.shard(n)
+        if idx:
+            local = predict([x[idx] for x in inputs], mask[idx], window)
+        else:
+            probe = predict([x[:1] for x in inputs], mask[:1], window)       # shape / dtype of one row
+            local = probe[:0]
+        return self.gather_rows(local, n)
+
+    def loss_sharded(self, loss, inputs, targets, mask, window, weights=None):
+        """A cost that is a weighted mean over utterance shards (the temporal loss: weights = valid frames per shard;
+        the last-timestep cross-entropy: utterances per shard), evaluated shard-wise and combined over the ranks."""
+        import torch
+        n = len(mask)
+        idx = self.shard(n)
+        w = float(np.sum(mask[idx])) if weights is None else float(np.sum(np.asarray(weights)[idx]))
+        v = float(loss([x[idx] for x in inputs], targets[idx], mask[idx], window)) if idx else 0.0
+        t = torch.tensor([v * w, w], dtype=torch.float64, device=self.grad.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return float(t[0].item() / t[1].item())
 
 
 def reduce_and_check_equal(values, group=None):

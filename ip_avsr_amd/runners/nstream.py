@@ -330,7 +330,15 @@ def main(n_streams, argv=None, variant=None):
         return fn(*(list(Xs) + list(rest)))
 
     def eval_fn(*args):                             # evaluate_model2 passes inputs..., mask, window
+        if dp is not None:                          # held-out utterances split over the ranks, predictions gathered
+            return dp.predict_sharded(network.predict, list(args[:n_streams]), args[n_streams], args[n_streams + 1])
         return call(val_fn, list(args[:n_streams]), *args[n_streams:])
+
+    def heldout_cost(Xs_, y_, m_):                  # compute_test_cost of a whole split
+        if dp is not None:
+            return dp.loss_sharded(network.loss, Xs_, y_, m_, windowsize,
+                                   weights=None if network.head == "frames" else np.ones(len(m_)))
+        return float(call(compute_test_cost, Xs_, y_, m_, windowsize))
 
     say('begin training...')
     cost_train, cost_val, class_rate = [], [], []
@@ -373,12 +381,14 @@ def main(n_streams, argv=None, variant=None):
             elif dp is None:
                 call(train, Xs, y, m, windowsize)
             else:
+                # (a short last minibatch can leave high ranks without an utterance: they contribute zero gradients)
                 mine = list(range(len(X1)))[rank::world]
-                dp.train_step([x[mine] for x in Xs], y[mine], m[mine], windowsize, learning_rate, float(m.sum()))
+                upd = (lambda mdl: mdl.apply_adam_vlr(lr_map)) if lr_map is not None else None
+                dp.train_step([x[mine] for x in Xs], y[mine], m[mine], windowsize, learning_rate, float(m.sum()), update=upd)
             if rank == 0:
                 print('\r', end='')
         cost = float(call(compute_train_cost, Xs, y, m, windowsize))
-        val_cost = float(call(compute_test_cost, X_val, y_val, mask_val, windowsize))
+        val_cost = heldout_cost(X_val, y_val, mask_val)
         cost_train.append(cost)
         cost_val.append(val_cost)
         train_strip[epoch % STRIP_SIZE] = cost

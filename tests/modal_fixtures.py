@@ -40,7 +40,7 @@ def make_cuave(root, seed=0):
         feats = np.concatenate([dprotos[labels[u]][None, :] + rng.normal(size=(lens[u], DCT)) * 0.3 for u in range(n)])
         data[pre + "Data"] = X
         data[pre + "VideoLengthVec"] = lens[:, None].astype("float64")
-        data[pre + "TargetsVec"] = (labels - 1)[:, None].astype("float64")      # PER VIDEO (the script feeds them to the batch generator)
+        data[pre + "TargetsVec"] = (tv - 1)[:, None].astype("float64")          # per FRAME, 0-based minus one (the script adds 1)
         dct[pre + "DctFeatures"] = feats
     sio.savemat(os.path.join(root, "cuave.mat"), data)
     sio.savemat(os.path.join(root, "cuave_dct.mat"), dct)

@@ -23,34 +23,7 @@ def _free_port():
     return port
 
 
-class OracleReplica(object):
-    """Same call surface as AdeNetModel for what DataParallel uses, computed by the oracle in float64;
-    the flat gradient 'buffer' is a CPU tensor with the same 8-float tail (cost share in tail[0])."""
-
-    def __init__(self, spec, params):
-        from oracle import adenet_oracle as O
-        self.O, self.spec = O, spec
-        self.p = {k: v.copy() for k, v in params.items()}
-        self.names = O.param_names(spec)
-        self.sizes = [self.p[n].size for n in self.names]
-        self.grad = torch.zeros(sum(self.sizes) + 8, dtype=torch.float64)
-        self.state = O.adam_init(self.p)
-
-    def compute_grads(self, inputs, targets, mask, window, total_frames=0.0, want_loss=True):
-        loss, g, _ = self.O.loss_and_grads(self.spec, self.p, inputs, targets, mask, window,
-                                           total_frames=total_frames if total_frames > 0 else None)
-        flat = np.concatenate([np.asarray(g[n], np.float64).reshape(-1) for n in self.names] + [np.zeros(8)])
-        flat[-8] = loss
-        self.grad.copy_(torch.from_numpy(flat))
-        return loss if want_loss else None
-
-    def apply_adam(self, lr):
-        flat = self.grad.numpy()
-        g, off = {}, 0
-        for n, sz in zip(self.names, self.sizes):
-            g[n] = flat[off:off + sz].reshape(self.p[n].shape)
-            off += sz
-        self.O.adam_step(self.p, g, self.state, lr)
+from tests.oracle_replica import OracleReplica  # noqa: E402
 
 
 def _make_problem():
@@ -123,3 +96,81 @@ def test_shard_indices_cover_the_batch_once():
         shards = [shard_indices(idx, r, world) for r in range(world)]
         assert sorted(sum(shards, [])) == sorted(idx)
         assert max(map(len, shards)) - min(map(len, shards)) <= 1
+
+
+def _worker_features(rank, world, port, q):
+    """Empty shards, update callable, Adam step-count broadcast, sharded evaluation."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ip_avsr_amd.parallel import DataParallel
+        spec, p, xs, y, mask = _make_problem()
+        rep = OracleReplica(spec, p)
+        if rank == 0:
+            rep.set_adam_step_count(5)
+        dp = DataParallel(rep, grad_tensor=rep.grad)
+        dp.broadcast_parameters(0)
+        t0 = rep.adam_step_count()
+        # a 3-utterance remainder batch on 4 ranks: rank 3 has nothing
+        sub = [0, 1, 2]
+        mine = sub[rank::world]
+        calls = []
+
+        def update(model):
+            calls.append(1)
+            model.apply_adam(1e-2)
+
+        loss = dp.train_step([x[mine] for x in xs], y[mine], mask[mine], 2, 1e-2, float(mask[sub].sum()), want_loss=True,
+                             update=update)
+        probs = dp.predict_sharded(rep.predict, xs, mask, 2)
+        cost = dp.loss_sharded(rep.loss, xs, y, mask, 2)
+        flat = np.concatenate([rep.p[n].reshape(-1) for n in rep.names])
+        q.put((rank, t0, len(mine), len(calls), loss, probs, cost, flat))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_four_ranks_empty_shard_update_callable_and_sharded_evaluation():
+    """a rank whose shard of a short minibatch is empty must still join the all-reduce (it used to raise
+    'empty batch' and leave its peers hanging); per-layer update rules go through ``update=``; the Adam step count is
+    broadcast with the state; evaluation shards the held-out utterances and gathers."""
+    from oracle import adenet_oracle as O
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_features, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    results = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    spec, p, xs, y, mask = _make_problem()
+    st = O.adam_init(p); st["t"] = 5
+    sub = [0, 1, 2]
+    ref_loss = O.train_step(spec, p, st, [x[sub] for x in xs], y[sub], mask[sub], 2, 1e-2)
+    ref_flat = np.concatenate([p[n].reshape(-1) for n in O.param_names(spec)])
+    ref_probs = O.forward(spec, p, xs, mask, 2)
+    ref_cost, _, _ = O.loss_and_grads(spec, p, xs, y, mask, 2)
+    assert [r[2] for r in results] == [1, 1, 1, 0]                                   # rank 3 trained on nothing
+    for rank, t0, n_mine, n_calls, loss, probs, cost, flat in results:
+        assert t0 == 5 and n_calls == 1
+        np.testing.assert_allclose(loss, ref_loss, rtol=1e-12)
+        np.testing.assert_allclose(flat, ref_flat, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(probs, ref_probs, rtol=0, atol=1e-12)            # every rank holds the whole result
+        np.testing.assert_allclose(cost, ref_cost, rtol=1e-12)
+
+
+def test_outstanding_reduction_blocks_the_next_step():
+    """a step must not be enqueued while a bucket all-reduce of the replica is outstanding."""
+    from ip_avsr_amd.parallel import DataParallel
+    dp = DataParallel.__new__(DataParallel)
+    dp._inflight = True
+    with pytest.raises(RuntimeError, match="outstanding"):
+        dp.assert_quiescent()
+    dp._inflight = False
+    dp.assert_quiescent()

@@ -63,3 +63,52 @@ def test_single_rank_nccl_dataparallel_equals_plain_step():
         ref.close(); dpm.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_empty_shard_and_poisoned_gradients_single_rank():
+    """(1) A rank with an EMPTY shard joins the all-reduce with zero gradients (adn_zero_grads) -- with one rank the step
+    must then leave the parameters untouched apart from Adam's zero-gradient update (m = v = 0 -> no change).
+    (2) A raised exchange flag in the gradient tail makes the optimiser kernel skip the update and the next host read
+    report it (what every rank sees when a peer's weight-stationary LSTM exchange timed out)."""
+    import torch
+    import torch.distributed as dist
+    from ip_avsr_amd.model import AdeNetModel
+    from ip_avsr_amd.parallel import DataParallel, wrap_flat_buffer
+    from ip_avsr_amd._lib import AdenetError
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        spec = dict(O.spec_nstream([12, 9], enc_shapes=(14, 6), enc_acts=("rectify", "linear"), lstm_size=10, classes=5,
+                                   fusion="sum"), precision="bf16")
+        rng = np.random.default_rng(7)
+        p = O.init_params(spec, rng, np.float32, enc_std=0.3, perturb=0.1)
+        B, T = 5, 8
+        mask = np.ones((B, T), np.uint8)
+        xs = [(rng.normal(size=(B, T, s["input_dim"]))).astype(np.float32) for s in spec["streams"]]
+        y = np.repeat(rng.integers(0, 5, size=(B, 1)), T, axis=1).astype(np.int32)
+        m = AdeNetModel(spec)
+        m.set_params_dict(p)
+        dp = DataParallel(m)
+        before = m.get_all_param_values()
+        none = [x[:0] for x in xs]
+        loss = dp.train_step(none, y[:0], mask[:0], 2, 1e-2, float(mask.sum()), want_loss=True)
+        assert loss == 0.0
+        for u, v in zip(before, m.get_all_param_values()):
+            np.testing.assert_array_equal(u, v)
+        # real gradients, then raise the flag by hand and step
+        m.compute_grads(xs, y, mask, 2, want_loss=False)
+        g = wrap_flat_buffer(m)
+        g[-7] = 1.0                                            # tail[1]
+        m.apply_adam(1e-2)
+        with pytest.raises(AdenetError, match="skipped"):
+            m.get_all_param_values()                           # first host read after the skipped update reports it
+        for u, v in zip(before, m.get_all_param_values()):     # ... and nothing was updated
+            np.testing.assert_array_equal(u, v)
+        l0 = m.train_step(xs, y, mask, 2, 1e-2)               # the model keeps working afterwards
+        assert np.isfinite(l0)
+        m.close()
+    finally:
+        dist.destroy_process_group()

@@ -41,3 +41,15 @@ def test_random_sequences_match_the_oracle(S, shape, theta):
     dev = S.append_delta_coeff(torch.tensor(A, device="cuda"), theta)
     assert isinstance(dev, torch.Tensor) and dev.is_cuda
     np.testing.assert_array_equal(dev.cpu().numpy(), got)
+
+
+def test_delta_layer_long_sequences(S):
+    """the delta kernels used to refuse T + 2 theta > 256 (64 KiB of LDS); the reference's DeltaLayer has no
+    length limit (custom/layers.py:105-121).  T = 400 and T = 600 against the restatement of utils/signal.py:59-80."""
+    rng = np.random.RandomState(0)
+    for T in (400, 600):
+        x = rng.normal(size=(3, T, 17)).astype(np.float32)
+        got = S.append_delta_coeff(x, 9)
+        want = O.delta_append(x.astype(np.float64), 9)
+        assert got.shape == (3, T, 51)
+        assert np.abs(got - want).max() < 1e-4 * max(1.0, np.abs(want).max())

@@ -34,7 +34,7 @@ def test_cuave_presplit_loader(tmp_path):
     cfg = _cfg(MF.make_cuave(str(tmp_path)))
     split, ys, lens = modal._load_cuave(cfg)
     assert [len(lens[k]) for k in ("train", "val", "test")] == [32, 12, 12]
-    assert set(ys["train"]) == set(range(MF.CLASSES)) and ys["train"].shape == (32,)
+    assert set(ys["train"]) == set(range(MF.CLASSES)) and ys["train"].shape == (int(lens["train"].sum()),)   # per frame
     for k in split:
         X, dct = split[k]
         assert X.shape == (int(lens[k].sum()), MF.D) and dct.shape == (int(lens[k].sum()), MF.DCT)
