@@ -138,6 +138,15 @@ class ConvAE(object):
         _lib.check(self._lib.adn_cae_forward(self._handle, xp, B, flags, None, out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def encode_device(self, x):
+        """Bottleneck features of a torch CUDA tensor (B, H*W) as a torch CUDA tensor (B, bottleneck): no host round trip."""
+        import torch
+        xp, _, B, flags, keep = self._prep(x)
+        out = torch.empty((B, self.bottleneck), device=x.device, dtype=torch.float32)
+        _lib.check(self._lib.adn_cae_forward(self._handle, xp, B, flags | _lib.FLAG_DEVICE_OUTPUTS, None,
+                                             C.c_void_p(out.data_ptr())))
+        return out
+
     def cost(self, x, target=None):
         """train_cost_fn / eval_cost_fn: mean squared reconstruction error."""
         xp, tp, B, flags, keep = self._prep(x, target)

@@ -105,6 +105,7 @@ class AdeNetModel(object):
         self.input_dims = [int(s["input_dim"]) for s in spec["streams"]]
         self._build_param_table()
         self._torch_stream = None
+        self._front = {}                      # stream index -> (conv encoder, frame width): frozen feature extractors
         if stream is not None:
             self.set_stream(stream)
 
@@ -248,9 +249,33 @@ class AdeNetModel(object):
     def _is_device(x):
         return hasattr(x, "data_ptr") and getattr(x, "is_cuda", False)
 
+    def set_front_end(self, stream, conv_encoder, frame_dim):
+        """Stream ``stream`` receives (B, T, frame_dim) frames; ``conv_encoder.encode`` turns them into the
+        (B, T, input_dim) codes the graph consumes (a frozen convolutional feature extractor, csrc/convae.hip)."""
+        if int(conv_encoder.bottleneck) != self.input_dims[stream]:
+            raise ValueError("the encoder emits %d features, stream %d takes %d" % (conv_encoder.bottleneck, stream,
+                                                                                    self.input_dims[stream]))
+        self._front[int(stream)] = (conv_encoder, int(frame_dim))
+
+    def _apply_front_ends(self, inputs):
+        if not self._front:
+            return inputs
+        out = list(inputs)
+        for k, (conv, fd) in self._front.items():
+            x = out[k]
+            if tuple(x.shape[2:]) != (fd,):
+                raise ValueError("stream %d: expected (B,T,%d) frames, got %s" % (k, fd, tuple(x.shape)))
+            B, T = int(x.shape[0]), int(x.shape[1])
+            if self._is_device(x):
+                out[k] = conv.encode_device(x.reshape(B * T, fd)).reshape(B, T, -1)
+            else:
+                out[k] = conv.encode(np.asarray(x, np.float32).reshape(B * T, fd)).reshape(B, T, -1)
+        return out
+
     def _prep(self, inputs, mask, targets=None):
         if len(inputs) != self.S:
             raise ValueError("expected %d input streams, got %d" % (self.S, len(inputs)))
+        inputs = self._apply_front_ends(inputs)
         dev = self._is_device(inputs[0])
         keep = []
         ptrs = (C.c_void_p * self.S)()

@@ -44,13 +44,30 @@ def nolearn_weights(ae, shapes=(2000, 1000, 500, 50), nonlinearities=("sigmoid",
     return list(weights), list(biases), shapes, list(nonlinearities)[:len(shapes) - 1] + ["linear"]
 
 
+def _conv_encoder_of(ae):
+    """A convolutional auto-encoder offered as a stream's ``ae``: the ConvAE itself or the bottleneck handle that
+    ``modelzoo.avletters_convae*.create_model`` returns beside it."""
+    conv = getattr(ae, "ae", ae)
+    return conv if hasattr(conv, "encode") and hasattr(conv, "bottleneck") else None
+
+
 def stream(input_shape, ae=None, suffix="", delta=True, lstm_names=("lstm",), peepholes=False, enc_names=None,
            pretrained_lstm=None, pretrained_prefixes=None, dropout=0.0):
     """One stream description.  ``ae`` = (weights, biases, shapes, nonlinearities) like
-    ``load_decoder`` returns (runners/3stream.py:31-40) or None for an encoder-less stream."""
+    ``load_decoder`` returns (runners/3stream.py:31-40), None for an encoder-less stream, or a trained convolutional
+    auto-encoder (``ip_avsr_amd.convae.ConvAE`` / its bottleneck handle): its encoder then runs as a FROZEN feature
+    extractor in front of the stream (frames -> bottleneck code on the GPU, conv kernels of csrc/convae.hip) and the
+    stream's delta layer / LSTM consume the code.  (The reference only ever loads the conv encoder in a dead branch,
+    ``load_convae = False``, avletters/trimodal.py:278-283; training through it is outside the reference's live graph.)"""
     d = dict(input_dim=input_dim_of(input_shape), delta=bool(delta), lstm_names=list(lstm_names),
              peepholes=bool(peepholes), dropout=float(dropout), pretrained_lstm=pretrained_lstm,
              pretrained_prefixes=list(pretrained_prefixes or []))
+    conv = _conv_encoder_of(ae)
+    if conv is not None:
+        if conv.D != d["input_dim"]:
+            raise ValueError("the conv encoder takes %d-pixel frames, the stream declares %d" % (conv.D, d["input_dim"]))
+        d.update(conv_encoder=conv, frame_dim=conv.D, input_dim=int(conv.bottleneck))
+        ae = None
     if ae is None:
         d.update(enc_names=[], enc_shapes=[], enc_acts=[], enc_weights=[], enc_biases=[])
     else:
@@ -131,6 +148,9 @@ def build(streams, lstm_size, output_classes, fusiontype, fuse_names, agg_names,
         return (spec, None) if return_fuse else spec
     model = AdeNetModel(spec)
     assert [p.name for p in model.params] == param_names(spec)
+    for k, s in enumerate(streams):
+        if s.get("conv_encoder") is not None:
+            model.set_front_end(k, s["conv_encoder"], s["frame_dim"])
     w_init = _init.resolve(w_init_fn)
     for s in streams:
         for n, W, b in zip(s["enc_names"], s["enc_weights"], s["enc_biases"]):

@@ -63,3 +63,33 @@ def gen_lstm_batch_random(X, y, seqlen, batchsize=30, shuffle=True):
         else:
             start = stop
         yield Xb, yb, mask, idxs
+
+
+def batch_iterator(X, y, batchsize=128):
+    """Endless minibatch generator of the auto-encoder trainers (reference utils/datagen.py:311-342).
+
+    Kept behaviours: one permutation per pass from the global ``np.random`` stream; the last batch of a pass is the
+    remainder ZERO-PADDED to ``batchsize`` rows; and the cursor advances by ``start += end`` (not ``start = end``), so a
+    pass visits rows [0,128), [128,256), [384,512), [896,1024), ... of the permutation -- the reference's arithmetic,
+    reproduced on purpose (quirks are parity)."""
+    start = 0
+    reset = False
+    randomized = np.random.permutation(len(X))
+    while True:
+        end = start + batchsize
+        if end >= len(X):
+            reset = True
+            batch_idxs = randomized[start:]
+        else:
+            batch_idxs = randomized[start:end]
+        batch_X = np.zeros((batchsize,) + X.shape[1:], dtype=X.dtype)
+        batch_y = np.zeros((batchsize,) + y.shape[1:], dtype=y.dtype)
+        batch_X[:len(batch_idxs)] = X[batch_idxs]
+        batch_y[:len(batch_idxs)] = y[batch_idxs]
+        if reset:
+            randomized = np.random.permutation(len(X))
+            start = 0
+            reset = False
+        else:
+            start += end
+        yield batch_X, batch_y

@@ -290,3 +290,42 @@ def multistream_force_align(orig_streams, mode="fill"):
             lens[j][i] = longest
             pos[j] += l
     return [(np.array(out_x[j]), np.array(out_t[j]), lens[j]) for j in range(S)]
+
+
+def _resample_matrix(n_in, n_out):
+    """Row-stochastic (n_out, n_in) matrix of PIL's BILINEAR resampling: a triangle filter whose support grows with the
+    down-scaling factor (anti-aliasing), centres at (i + 0.5) * n_in / n_out."""
+    scale = float(n_in) / n_out
+    fscale = max(scale, 1.0)
+    support = 1.0 * fscale
+    M = np.zeros((n_out, n_in))
+    for i in range(n_out):
+        center = (i + 0.5) * scale
+        lo, hi = max(0, int(center - support + 0.5)), min(n_in, int(center + support + 0.5))
+        w = np.maximum(0.0, 1.0 - np.abs((np.arange(lo, hi) + 0.5 - center) / fscale))
+        M[i, lo:hi] = w / w.sum()
+    return M
+
+
+def resize_img(img, orig_dim=(60, 80), dim=(30, 40), reshape=True, order='F'):
+    """``scipy.misc.imresize(img, dim)`` of the reference (utils/preprocessing.py:180-192): the image is byte-scaled
+    (min -> 0, max -> 255, uint8) and resampled bilinearly the way PIL does.  scipy.misc.imresize and PIL are
+    third-party code absent from this image; this restates their documented behaviour (values may differ from the
+    original in the last unit of the 8-bit result -- there is no fixture of it in the reference)."""
+    img = np.asarray(img, dtype=np.float64)
+    if reshape:
+        img = img.reshape(orig_dim, order=order)
+    lo, hi = img.min(), img.max()
+    span = hi - lo if hi > lo else 1.0
+    b = np.clip((img - lo) * (255.0 / span) + 0.5, 0, 255).astype(np.uint8).astype(np.float64)       # bytescale
+    out = _resample_matrix(b.shape[0], dim[0]) @ b @ _resample_matrix(b.shape[1], dim[1]).T
+    return np.clip(np.floor(out + 0.5), 0, 255).astype(np.uint8)
+
+
+def resize_images(images, orig_dim=(60, 80), dim=(30, 40), reshape=True, order='F'):
+    """Resizes every row image of a data matrix; flattened results are in C order (reference :195-216)."""
+    resized = np.zeros((images.shape[0], dim[0] * dim[1])) if reshape else np.zeros((images.shape[0], dim[0], dim[1]))
+    for i, img in enumerate(images):
+        r = resize_img(img, orig_dim, dim, reshape, order)
+        resized[i] = r.reshape((dim[0] * dim[1],)) if reshape else r
+    return resized

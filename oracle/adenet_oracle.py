@@ -295,6 +295,8 @@ def param_names(spec):
     for s in spec["streams"]:
         for n in s["enc_names"]:
             names += [n + ".W", n + ".b"]
+        if s.get("batchnorm"):                       # lasagne BatchNormLayer registers beta, gamma, mean, inv_std
+            names += ["%s.%s" % (s["batchnorm"], k) for k in BN_PARAMS]
         for ln in s["lstm_names"]:
             names += lstm_param_names(ln, s["peepholes"])
     if spec["fusion"] == "adasum":
@@ -305,15 +307,24 @@ def param_names(spec):
     return names
 
 
+BN_PARAMS = ("beta", "gamma", "mean", "inv_std")
+BN_EPS, BN_ALPHA = 1e-4, 0.1                             # lasagne.layers.BatchNormLayer defaults
+
+
 def lstm_in_dim(spec, s):
+    """width of what the stream's LSTM reads: [x | dx | ddx] of the encoder output, then the stream's auxiliary input
+    (ConcatLayer([l_delta, l_dct], axis=2), modelzoo/adenet_v1.py:87)"""
     d = s["enc_shapes"][-1] if s["enc_shapes"] else s["input_dim"]
-    return d * 3 if s["delta"] else d
+    return (d * 3 if s["delta"] else d) + int(s.get("aux_dim", 0) or 0)
 
 
 def param_shapes(spec):
+    """``stream_lstm_size`` (optional): units of the STREAM LSTMs when they differ from the aggregation LSTMs'
+    ``lstm_size`` (modelzoo/adenet_v1.py:89,95: lstm_size and 2 * lstm_size)."""
     H, shapes = spec["lstm_size"], {}
+    Hs = int(spec.get("stream_lstm_size") or H)
 
-    def lstm(name, fin, peep):
+    def lstm(name, fin, peep, H=H):
         for g in GATES:
             shapes["%s.W_in_to_%s" % (name, g)] = (fin, H)
             shapes["%s.W_hid_to_%s" % (name, g)] = (H, H)
@@ -330,13 +341,16 @@ def param_shapes(spec):
             shapes[n + ".W"] = (d, u)
             shapes[n + ".b"] = (u,)
             d = u
+        if s.get("batchnorm"):
+            for k in BN_PARAMS:
+                shapes["%s.%s" % (s["batchnorm"], k)] = (d,)
         for ln in s["lstm_names"]:
-            lstm(ln, lstm_in_dim(spec, s), s["peepholes"])
+            lstm(ln, lstm_in_dim(spec, s), s["peepholes"], Hs)
     S = len(spec["streams"])
     if spec["fusion"] == "adasum":
         for k in range(S):
             shapes["%s.adacoeff%d" % (spec["fuse_name"], k)] = ()
-    fused = H * S if spec["fusion"] == "concat" else H
+    fused = Hs * S if spec["fusion"] == "concat" else Hs
     for ln in spec["agg_names"]:
         lstm(ln, fused, spec["agg_peepholes"])
     shapes[spec["softmax_name"] + ".W"] = (H, spec["classes"])
@@ -361,6 +375,10 @@ def init_params(spec, rng, dtype=np.float32, enc_std=0.01, perturb=0.0):
             v = np.ones(shp)
         elif leaf.startswith("W_cell_to"):
             v = rng.normal(0, 0.1, shp)      # Gate() default W_cell=Normal(0.1) [upstream] App. A-2
+        elif leaf in ("gamma", "inv_std"):
+            v = np.ones(shp)                 # BatchNormLayer: gamma = 1, inv_std = 1 (beta = mean = 0)
+            if perturb:
+                v = v + np.abs(rng.normal(0, perturb, shp)) - rng.normal(0, perturb, shp)
         else:
             v = np.zeros(shp)
         if perturb:
@@ -405,25 +423,42 @@ def dropout_scale(shape, prob, dropout, layer, dtype):
     return keep.astype(dtype) * (dtype(1) / (dtype(1) - dtype(prob)))
 
 
-def forward(spec, p, inputs, mask, theta, want_cache=False, dropout=None):
-    """inputs: list of (B,T,D_s).  Returns probs (B,T,C) -- (B,C) for the last-timestep head -- [, cache].
+def forward(spec, p, inputs, mask, theta, want_cache=False, dropout=None, training=None):
+    """inputs: list of (B,T,D_s), followed by the auxiliary inputs (B,T,A_s) of the streams that have one, in stream
+    order.  Returns probs (B,T,C) -- (B,C) for the last-timestep head -- [, cache].
     dropout: None = deterministic; dict(seed=, counter=) = stochastic layers active.
+    training: BatchNorm layers use batch statistics (get_output(deterministic=False)); default: dropout is not None.
     Graph: modelzoo/adenet_v2.py:30-92, adenet_3stream.py:166-262, adenet_4stream.py:37-157,
     avnet.py:43-112, deltanet_majority_vote.py:31-66 (S=1, no aggregation layer)."""
     B, T = mask.shape
     H = spec["lstm_size"]
-    cache = dict(streams=[])
+    if training is None:
+        training = dropout is not None
+    cache = dict(streams=[], training=training)
     outs = []
-    for s, x in zip(spec["streams"], inputs):
+    S_ = len(spec["streams"])
+    aux_inputs = list(inputs[S_:])
+    for s, x in zip(spec["streams"], inputs[:S_]):
         sc = dict(acts=[x.reshape(B * T, -1)])
         a = sc["acts"][0]
         for n, act in zip(s["enc_names"], s["enc_acts"]):   # modelzoo/pretrained_encoder.py:4-9
             a = act_fwd(act, a @ p[n + ".W"] + p[n + ".b"])
             sc["acts"].append(a)
+        if s.get("batchnorm"):                               # BatchNormLayer on the (B*T, E) encoder output (adenet_v1.py:82)
+            bn = s["batchnorm"]
+            if training:
+                mu = a.mean(0)
+                inv = 1.0 / np.sqrt(((a - mu) ** 2).mean(0) + a.dtype.type(BN_EPS))
+            else:
+                mu, inv = p[bn + ".mean"], p[bn + ".inv_std"]
+            sc["bn"] = dict(x=a, mean=mu, inv_std=inv, xhat=(a - mu) * inv)
+            a = sc["bn"]["xhat"] * p[bn + ".gamma"] + p[bn + ".beta"]
         feat = a.reshape(B, T, -1)
         sc["enc_out"] = feat
         if s["delta"]:
             feat = delta_append(feat, theta)
+        if s.get("aux_dim"):                                 # ConcatLayer([l_delta, l_dct], axis=2) (adenet_v1.py:87)
+            feat = np.concatenate([feat, np.asarray(aux_inputs.pop(0), feat.dtype)], axis=2)
         sc["drop"] = dropout_scale(feat.shape, s.get("dropout", 0.0), dropout, len(outs), feat.dtype.type)
         feat = feat * sc["drop"]                              # DropoutLayer ahead of the stream LSTM (adenet_v3.py:112)
         sc["lstm_in"] = feat
@@ -479,11 +514,21 @@ def cross_entropy_loss(probs, y, total=None):
     return -np.log(probs[np.arange(B), y]).sum() / (B if total is None else total)
 
 
-def loss_and_grads(spec, p, inputs, targets, mask, theta, total_frames=None, dropout=None):
+def bn_running_update(spec, p, cache):
+    """The default updates Theano applies with every non-deterministic pass: running mean / inv_std <- (1 - alpha) old +
+    alpha batch (lasagne BatchNormLayer.get_output_for, batch_norm_update_averages)."""
+    for s, sc in zip(spec["streams"], cache["streams"]):
+        if s.get("batchnorm") and cache["training"]:
+            bn, dt = s["batchnorm"], p[s["batchnorm"] + ".mean"].dtype.type
+            p[bn + ".mean"] = (dt(1) - dt(BN_ALPHA)) * p[bn + ".mean"] + dt(BN_ALPHA) * sc["bn"]["mean"].astype(dt)
+            p[bn + ".inv_std"] = (dt(1) - dt(BN_ALPHA)) * p[bn + ".inv_std"] + dt(BN_ALPHA) * sc["bn"]["inv_std"].astype(dt)
+
+
+def loss_and_grads(spec, p, inputs, targets, mask, theta, total_frames=None, dropout=None, training=None):
     """targets (B,T) int (label repeated over T, runners/3stream.py:360-361)."""
     B, T = mask.shape
     H = spec["lstm_size"]
-    probs, cache = forward(spec, p, inputs, mask, theta, want_cache=True, dropout=dropout)
+    probs, cache = forward(spec, p, inputs, mask, theta, want_cache=True, dropout=dropout, training=training)
     g = {}
     sm = spec["softmax_name"]
     if spec.get("head", "frames") == "last":
@@ -516,7 +561,8 @@ def loss_and_grads(spec, p, inputs, targets, mask, theta, total_frames=None, dro
     S = len(spec["streams"])
     for k, (s, sc) in enumerate(zip(spec["streams"], cache["streams"])):
         if spec["fusion"] == "concat":
-            dh = dfused[..., k * H:(k + 1) * H]
+            Hs = int(spec.get("stream_lstm_size") or H)
+            dh = dfused[..., k * Hs:(k + 1) * Hs]
         elif spec["fusion"] == "adasum":
             an = "%s.adacoeff%d" % (spec["fuse_name"], k)
             g[an] = np.asarray((dfused * sc["h"]).sum(), dtype=dfused.dtype)
@@ -527,9 +573,23 @@ def loss_and_grads(spec, p, inputs, targets, mask, theta, total_frames=None, dro
         for lc in sc["lstm"]:
             dfeat = dfeat + lstm_bwd(dh, lc, p, g)
         dfeat = dfeat * sc["drop"]
+        if s.get("aux_dim"):
+            dfeat = dfeat[..., :dfeat.shape[-1] - int(s["aux_dim"])]      # the auxiliary input is data
         if s["delta"]:
             dfeat = delta_append_bwd(dfeat, theta)
         da = dfeat.reshape(B * T, -1)
+        if s.get("batchnorm"):
+            bn, c = s["batchnorm"], sc["bn"]
+            g[bn + ".beta"] = da.sum(0)
+            g[bn + ".gamma"] = (da * c["xhat"]).sum(0)
+            g[bn + ".mean"] = np.zeros_like(p[bn + ".mean"])               # running averages: not trainable
+            g[bn + ".inv_std"] = np.zeros_like(p[bn + ".inv_std"])
+            gi = p[bn + ".gamma"] * c["inv_std"]
+            if cache["training"]:                                          # statistics are functions of the batch
+                n_rows = da.shape[0]
+                da = gi * (da - g[bn + ".beta"] / n_rows - c["xhat"] * g[bn + ".gamma"] / n_rows)
+            else:
+                da = gi * da
         for li in range(len(s["enc_names"]) - 1, -1, -1):
             n, act = s["enc_names"][li], s["enc_acts"][li]
             dzl = act_bwd(act, sc["acts"][li + 1], da)
@@ -594,9 +654,13 @@ def adadelta_step(p, g, state, lr=1.0, rho=0.95, eps=1e-6):
     return p
 
 
-def train_step(spec, p, state, inputs, targets, mask, theta, lr):
-    loss, g, _ = loss_and_grads(spec, p, inputs, targets, mask, theta)
+def train_step(spec, p, state, inputs, targets, mask, theta, lr, training=False):
+    """training: BatchNorm layers in batch-statistics mode incl. the running-average update (what ``train`` of the
+    reference scripts does: get_output(network, deterministic=False)); dropout stays off here (deterministic masks are
+    a separate argument of loss_and_grads)."""
+    loss, g, cache = loss_and_grads(spec, p, inputs, targets, mask, theta, training=training)
     adam_step(p, g, state, lr)
+    bn_running_update(spec, p, cache)
     return loss
 
 

@@ -76,14 +76,14 @@ use_finetuning = False
     return path
 
 
-def _frames_file(root, rng, name, with_iter):
+def _frames_file(root, rng, name, with_iter, one_based=False):
     subjects = np.repeat(np.arange(1, 9), 6)                  # 8 subjects x 6 utterances
     n = len(subjects)
     labels = np.arange(n) % CLASSES
     protos, dprotos = rng.normal(size=(CLASSES, D)) * 2, rng.normal(size=(CLASSES, DCT)) * 2
     lens, X, tv = _utterances(rng, n, D, labels, protos)
     feats = np.concatenate([dprotos[labels[u]][None, :] + rng.normal(size=(lens[u], DCT)) * 0.3 for u in range(n)])
-    d = dict(dataMatrix=X, targetsVec=tv[:, None].astype("float64"), videoLengthVec=lens[:, None].astype("float64"),
+    d = dict(dataMatrix=X, targetsVec=(tv + (1 if one_based else 0))[:, None].astype("float64"), videoLengthVec=lens[:, None].astype("float64"),
              subjectsVec=subjects[:, None].astype("float64"))
     if with_iter:
         d["iterVec"] = (np.arange(n) % 3 + 1)[:, None].astype("float64")        # repetitions 1, 2 -> train; 3 -> test
@@ -137,6 +137,8 @@ test_subjects_file = {root}/test.txt
 def make_avletters(root, seed=2, update_rule="sgdm"):
     rng = np.random.RandomState(seed)
     X, lens = _frames_file(root, rng, "avl", with_iter=True)
+    # avletters/bimodal.py subtracts 1 from the (MATLAB, 1-based) targets (:351); avletters/trimodal.py uses them as stored
+    _frames_file(root, np.random.RandomState(seed), "avl1", with_iter=True, one_based=True)
     diff = np.concatenate([np.vstack([np.zeros((1, D)), np.diff(X[s:s + l], axis=0)])
                            for s, l in zip(np.cumsum(np.r_[0, lens[:-1]]), lens)])
     sio.savemat(os.path.join(root, "avl_diff.mat"), dict(dataMatrix=diff))
@@ -170,7 +172,7 @@ num_epoch = 4
 epochsize = 4
 batchsize = 8
 """
-    bi = common + """
+    bi = common.replace("avl.mat", "avl1.mat").replace("avl_dct.mat", "avl1_dct.mat") + """
 [training]
 update_rule = {rule}
 learning_rate = 0.05

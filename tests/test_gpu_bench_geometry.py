@@ -4,7 +4,9 @@ encoder streams, H = 250, concat, summed BLSTM): the weight-stationary LSTM laun
 and nowhere else at this size -- bench.py itself only asserts a finite loss.
 
   (a) weight-stationary kernels against the one-workgroup-per-slice kernels (ADN_LSTM_NO_CLUSTER): same arithmetic
-      (bf16 operands, fp32 accumulate) in a different summation order -> probabilities equal to 1e-3, gradients to 5e-3;
+      (bf16 operands, fp32 accumulate) in a different summation order -> probabilities equal to 1e-3; gradients compared
+      as whole tensors (relative L2 distance and cosine): every layer below an LSTM re-rounds its gradient to bf16, so a
+      last-bit difference upstream flips roundings element-wise downstream (measured and printed by the test);
   (b) ping-pong GEMMs against the register-staged ones (ADN_GEMM_PP=0): the same;
   (c) against the fp64 ORACLE on a 26-utterance slice (the graph is independent per utterance, so rows 0..25 of the
       520-utterance result must be what the oracle computes for those 26 alone): probabilities and the measured
@@ -31,47 +33,73 @@ m = AdeNetModel(bench.build_spec())
 m.set_precision("bf16")
 bench.synthetic_params(m)
 xs, y, m_d, mask = bench.synthetic_batch(torch, 0, bench.B_PER_GPU, torch.device("cuda", 0))
-for _ in range(3):                                   # a few steps so that the outputs are not flat
-    m.train_step(xs, y, m_d, bench.THETA, 2e-3, want_loss=False)
+if len(sys.argv) > 2:                                # every variant evaluates the SAME parameters
+    saved = np.load(sys.argv[2])
+    for p in m.params:
+        p.set_value(saved["p_" + p.name])
+else:
+    for _ in range(3):                               # a few steps so that the outputs are not flat
+        m.train_step(xs, y, m_d, bench.THETA, 2e-3, want_loss=False)
+params = {"p_" + p.name: p.get_value() for p in m.params}
 probs = m.predict(xs, m_d, bench.THETA)
 loss = m.compute_grads(xs, y, m_d, bench.THETA)
 g = m.get_grads_dict()
 keep = ["fc1_s1.W", "fc2_s2.W", "bottleneck_s3.W", "lstm_s1.W_hid_to_cell", "lstm_s3.W_in_to_ingate", "lstm_s2.b_outgate",
         "f_lstm_agg.W_in_to_forgetgate", "b_lstm_agg.W_hid_to_outgate", "f_lstm_agg.hid_init", "softmax.W", "softmax.b"]
-np.savez(sys.argv[1], probs=probs, loss=loss, mask=mask, **{"g_" + k: g[k] for k in keep},
-         **{"p_" + p.name: p.get_value() for p in m.params}, **{"x%%d" %% k: xs[k][:26].cpu().numpy() for k in range(3)})
+np.savez(sys.argv[1], probs=probs, loss=loss, mask=mask, **{"g_" + k: g[k] for k in keep}, **params,
+         **{"x%%d" %% k: xs[k][:26].cpu().numpy() for k in range(3)})
 ''' % ROOT
 
 
-def _run(tmp_path, tag, **env):
+def _run(tmp_path, tag, params_from=None, **env):
     out = os.path.join(str(tmp_path), tag + ".npz")
     e = dict(os.environ, **env)
-    subprocess.run([sys.executable, "-c", RUN, out], check=True, env=e, cwd=ROOT, timeout=600)
+    subprocess.run([sys.executable, "-c", RUN, out] + ([params_from] if params_from else []), check=True, env=e, cwd=ROOT,
+                   timeout=600)
     return dict(np.load(out))
 
 
 @pytest.fixture(scope="module")
 def runs(tmp_path_factory):
     d = tmp_path_factory.mktemp("geom")
-    return dict(default=_run(d, "default"), nocluster=_run(d, "nocluster", ADN_LSTM_NO_CLUSTER="1"),
-                nopp=_run(d, "nopp", ADN_GEMM_PP="0"))
+    default = _run(d, "default")
+    ref = os.path.join(str(d), "default.npz")
+    return dict(default=default, nocluster=_run(d, "nocluster", ref, ADN_LSTM_NO_CLUSTER="1"),
+                nopp=_run(d, "nopp", ref, ADN_GEMM_PP="0"))
 
 
-def _close(a, b, what, p_tol=1e-3, g_tol=5e-3):
+def _close(a, b, what, p_tol=1e-3, g_tol=3e-2, cos_tol=0.9995, bit_equal_forward=False):
+    valid = a["mask"][..., None].astype(bool)
+    if bit_equal_forward:                            # the same products in the same order
+        np.testing.assert_array_equal(a["probs"] * valid, b["probs"] * valid)
     assert np.abs(a["probs"] - b["probs"]).max() <= p_tol, what
     assert abs(a["loss"] - b["loss"]) <= 1e-3 * abs(b["loss"]), what
+    worst = {}
     for k in a:
         if k.startswith("g_"):
-            scale = max(np.abs(b[k]).max(), 1e-12)
-            assert np.abs(a[k] - b[k]).max() <= g_tol * scale, (what, k, np.abs(a[k] - b[k]).max() / scale)
+            x, y = a[k].astype(np.float64).ravel(), b[k].astype(np.float64).ravel()
+            rel = np.linalg.norm(x - y) / max(np.linalg.norm(y), 1e-30)
+            cos = x @ y / max(np.linalg.norm(x) * np.linalg.norm(y), 1e-30)
+            worst[k[2:]] = (round(rel, 5), round(cos, 6))
+    print(what, "| max |dp| %.2e | (relative L2, cosine) per gradient tensor:" % np.abs(a["probs"] - b["probs"]).max(), worst)
+    for k, (rel, cos) in worst.items():
+        assert rel <= g_tol and cos >= cos_tol, (what, k, rel, cos)
 
 
 def test_weight_stationary_lstm_equals_slice_kernels_at_b520(runs):
-    _close(runs["default"], runs["nocluster"], "cluster vs one-workgroup LSTM kernels")
+    """Forward: bit-identical on the valid frames (the same bf16 products in the same order).  Backward: the exchange carries
+    the partial dh sums with 19 significant bits and every encoder layer re-rounds its gradient to bf16; measured on an
+    MI355X at this geometry: relative L2 distance 0.24 % at fc1 (the deepest tensor), 0.03 % at the LSTM inputs, cosine
+    >= 0.999997 everywhere (printed by the test)."""
+    _close(runs["default"], runs["nocluster"], "cluster vs one-workgroup LSTM kernels", g_tol=1e-2, cos_tol=0.9999,
+           bit_equal_forward=True)
 
 
 def test_pingpong_gemm_equals_register_staged_at_b520(runs):
-    _close(runs["default"], runs["nopp"], "ping-pong vs register-staged GEMM kernels")
+    """Forward GEMMs: the same k order, fp32 accumulate -> bit-identical.  Weight gradients: ordered partial slabs instead of
+    float atomics in arrival order -> fp32 summation noise only (measured: < 5e-6 relative L2)."""
+    _close(runs["default"], runs["nopp"], "ping-pong vs register-staged GEMM kernels", g_tol=1e-4, cos_tol=0.999999,
+           bit_equal_forward=True)
 
 
 def test_bf16_against_the_fp64_oracle_on_a_26_utterance_slice(runs):
@@ -90,6 +118,6 @@ def test_bf16_against_the_fp64_oracle_on_a_26_utterance_slice(runs):
     frame_agree = float(((got.argmax(-1) == ref.argmax(-1)) | (mask == 0)).mean())
     print("bf16 vs fp64 oracle at the bench geometry: max |dp| = %.2e, majority-vote agreement %.3f, per-frame top-1 %.4f"
           % (err, agree, frame_agree))
-    assert err <= 2e-2
-    assert agree >= 25.0 / 26.0                          # at most one of the 26 utterances may flip its vote
-    assert frame_agree >= 0.97
+    assert err <= 5e-3                                   # measured 3.2e-4
+    assert agree == 1.0                                  # measured: all 26 majority votes identical
+    assert frame_agree >= 0.995                          # measured: every valid frame's top-1 identical

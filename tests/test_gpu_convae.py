@@ -118,3 +118,74 @@ def test_image_sizes_the_decoder_cannot_reproduce_are_rejected(ConvAE):
     for hw in ((30, 50), (29, 33), (32, 40)):
         with pytest.raises(AdenetError):
             ConvAE(hw, 16, 4)
+
+
+def test_trainer_loop_of_the_reference_script(ConvAE, tmp_path):
+    """avletters/avletters_convae.py:202-329 on synthetic 22 x 28 'mouth' images: the loop runs, the reconstruction error
+    falls, the learning rate decays by 0.9 after every epoch past the 11th, both parameter lists are saved."""
+    from ip_avsr_amd.avletters import avletters_convae as T
+    from ip_avsr_amd.utils.io import load_model
+    rng = np.random.RandomState(0)
+    yy, xx = np.mgrid[0:22, 0:28]
+
+    def blobs(n):
+        cx, cy, s = rng.uniform(8, 20, n), rng.uniform(6, 16, n), rng.uniform(2, 5, n)
+        im = np.exp(-((xx[None] - cx[:, None, None]) ** 2 + (yy[None] - cy[:, None, None]) ** 2) / (2 * s[:, None, None] ** 2))
+        im = im.reshape(n, -1)
+        return ((im - im.mean(1, keepdims=True)) / im.std(1, keepdims=True)).reshape(n, 22, 28).astype(np.float32)
+
+    X, X_val = blobs(600), blobs(150)
+    prefix = str(tmp_path / "conv")
+    out = T.main(["--epochs", "14", "--epoch_size", "6", "--dense", "48", "--bottleneck", "12", "--image", "44,56,22,28",
+                  "--save_prefix", prefix, "--seed", "1"], data=(X, X_val))
+    assert len(out["costs"]) == 14 and np.isfinite(out["costs"]).all() and np.isfinite(out["val_costs"]).all()
+    assert out["val_costs"][-1] < 0.9 * out["val_costs"][0]
+    assert abs(out["learning_rate"] - 0.8 * 0.9 ** 3) < 1e-6                  # epochs 12, 13, 14 (index > 10) decayed it
+    enc, ae = load_model(prefix + "_encoder.dat"), load_model(prefix + "_ae.dat")
+    assert len(enc) == 10 and len(ae) == len(out["network"].param_names)
+    np.testing.assert_array_equal(ae[0], out["network"].get_param("conv2d1.W"))
+    assert out["recon"].shape == (150, 22 * 28)
+    out["network"].close()
+
+
+def test_conv_encoder_as_the_front_end_of_a_stream(ConvAE):
+    """The bottleneck of a conv auto-encoder offered as a stream's ``ae`` (modelzoo/_factory.stream): frames -> 12-d code on
+    the GPU -> delta layer -> LSTM.  Equal to feeding the codes to an encoder-less stream by hand, for host and device
+    inputs; the second stream keeps its dense encoder."""
+    import torch
+    from ip_avsr_amd.modelzoo import _factory as F, avletters_convae
+    hw = (22, 28)
+    net, bottleneck = avletters_convae.create_model((None, 1) + hw, {"DENSE": 32, "BOTTLENECK": 12})
+    rng = np.random.RandomState(5)
+    dims = [40, 16, 8]
+    dense = ([rng.normal(0, 0.3, (a, b)).astype(np.float32) for a, b in zip(dims[:-1], dims[1:])],
+             [np.zeros(b, np.float32) for b in dims[1:]], dims[1:], ["rectify", "linear"])
+    D = hw[0] * hw[1]
+    las_init = __import__("ip_avsr_amd.init", fromlist=["x"])
+    las_init.set_rng(np.random.RandomState(11))
+    streams = [F.stream((None, None, D), bottleneck, "_conv", lstm_names=["lstm_conv"]),
+               F.stream((None, None, 40), dense, "_dct", lstm_names=["lstm_dct"])]
+    model, _ = F.build(streams, 10, 4, "sum", {"sum": "sum1"}, ["f_lstm_agg", "b_lstm_agg"], False, "glorot")
+    las_init.set_rng(np.random.RandomState(11))
+    plain = [F.stream((None, None, 12), None, "_conv", lstm_names=["lstm_conv"]),
+             F.stream((None, None, 40), dense, "_dct", lstm_names=["lstm_dct"])]
+    ref, _ = F.build(plain, 10, 4, "sum", {"sum": "sum1"}, ["f_lstm_agg", "b_lstm_agg"], False, "glorot")
+    ref.set_all_param_values(model.get_all_param_values())
+    B, T = 4, 7
+    mask = np.ones((B, T), np.uint8); mask[1, 4:] = 0
+    frames = (rng.normal(size=(B, T, D)) * mask[..., None]).astype(np.float32)
+    other = (rng.normal(size=(B, T, 40)) * mask[..., None]).astype(np.float32)
+    codes = net.encode(frames.reshape(B * T, D)).reshape(B, T, 12)
+    want = ref.predict([codes, other], mask, 2)
+    got = model.predict([frames, other], mask, 2)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-6)
+    got_dev = model.predict([torch.tensor(frames, device="cuda"), torch.tensor(other, device="cuda")], mask, 2)
+    np.testing.assert_allclose(got_dev, want, rtol=0, atol=1e-6)
+    y = np.repeat(rng.randint(0, 4, size=(B, 1)), T, axis=1).astype(np.int32)
+    l0 = model.loss([frames, other], y, mask, 2)
+    for _ in range(20):
+        model.train_step([frames, other], y, mask, 2, 1e-2)
+    assert model.loss([frames, other], y, mask, 2) < l0                        # the part behind the frozen encoder learns
+    with pytest.raises(ValueError):
+        F.stream((None, None, 99), bottleneck)                                 # frame size mismatch
+    model.close(); ref.close(); net.close()

@@ -169,3 +169,29 @@ def test_circular_list(G):
     assert [3, 8, 5, 6, 7] == list(cl) and len(cl) == 5       # reference test_circular_list asserts
     assert all(item == "hello" for item in circular_list(7, "hello"))
     assert circular_list(2).pop() is None
+
+
+def test_batch_iterator_keeps_the_reference_cursor_arithmetic():
+    """utils/datagen.py:311-342: remainder batch zero-padded to the batch size; ``start += end``."""
+    from ip_avsr_amd.utils.datagen import batch_iterator
+    np.random.seed(3)
+    perm = np.random.permutation(300)
+    np.random.seed(3)
+    X = np.arange(1, 301, dtype=np.float32)[:, None]
+    it = batch_iterator(X, X * 2, 128)
+    b1, y1 = next(it); b2, _ = next(it); b3, _ = next(it)
+    assert b1.shape == (128, 1) and np.array_equal(b1[:, 0], X[perm[:128], 0]) and np.array_equal(y1, 2 * b1)
+    assert np.array_equal(b2[:, 0], X[perm[128:256], 0])
+    assert not b3.any()                                   # start = 128 + 256 = 384 >= 300: an all-zero batch, then a new pass
+    b4, _ = next(it)
+    assert b4.all()
+
+
+def test_resize_images_bytescale_and_antialiased_bilinear():
+    from ip_avsr_amd.utils.preprocessing import resize_images, _resample_matrix
+    M = _resample_matrix(80, 40)
+    assert np.allclose(M.sum(1), 1) and np.allclose(M[5, 9:13], [0.125, 0.375, 0.375, 0.125])
+    img = np.tile(np.linspace(0, 1, 80)[None, :], (60, 1))              # horizontal ramp, Fortran-flattened like the .mat rows
+    out = resize_images(img.reshape(1, -1, order="F"), (60, 80), (30, 40)).reshape(30, 40)
+    assert out.min() >= 0 and out.max() <= 255 and np.all(np.diff(out[7]) >= 0) and abs(out[7, 20] - 131) < 8
+    assert np.allclose(out, out[0][None, :], atol=1.0)          # every row of a horizontal ramp (rounding to 8 bits aside)
