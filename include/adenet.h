@@ -90,6 +90,10 @@ typedef struct {
     int32_t bidirectional;                   /* 0: LSTMLayer, 1: forward+backward LSTMLayer summed */
     int32_t peepholes;
     float dropout_p;                         /* DropoutLayer ahead of the stream's LSTM (adenet_v3.py:112,123,134); 0: none */
+    int32_t batchnorm;                       /* BatchNormLayer on the encoder output, ahead of the delta layer (adenet_v1.py:82) */
+    int32_t aux_dim;                         /* width of an auxiliary input (B,T,aux_dim) concatenated behind the delta features
+                                                (ConcatLayer([l_delta, l_dct], axis=2), adenet_v1.py:87); its array follows the
+                                                n_streams stream inputs in `inputs`, in stream order; 0: none */
 } adn_stream_config;
 
 /* the whole graph: S streams -> fusion -> aggregation (B)LSTM -> per-timestep softmax
@@ -107,7 +111,11 @@ typedef struct {
     int32_t precision;       /* adn_precision */
     int32_t head;            /* adn_head */
     float agg_dropout_p;     /* DropoutLayer on the fused tensor (adenet_v3.py:154); 0: none */
-    int32_t reserved[6];
+    int32_t stream_lstm_units; /* 0 (= lstm_size) or the smaller width of the STREAM LSTMs under wider aggregation LSTMs
+                                  (adenet_v1.py:89,95: lstm_size and 2 * lstm_size).  They run inside lstm_size-wide kernels
+                                  with the surplus units pinned at zero: zero weights give zero state and zero gradient, so
+                                  the padding never trains; parameter views have the narrow shapes.  Not with concat fusion. */
+    int32_t reserved[5];
 } adn_config;
 
 typedef struct adn_model adn_model;
@@ -122,6 +130,9 @@ typedef struct {
 } adn_param_info_t;
 
 const char* adn_version(void);
+/* sizeof(adn_stream_config), sizeof(adn_config), sizeof(adn_param_info_t), sizeof(adn_profile_entry): lets a binding
+ * check its struct declarations against the library it loaded */
+void adn_abi_sizes(int32_t out[4]);
 const char* adn_last_error(void);
 /* number of visible HIP devices whose arch is gfx950 (0 if none / no driver) */
 int adn_device_count(void);

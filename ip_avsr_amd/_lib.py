@@ -31,14 +31,15 @@ class StreamConfig(C.Structure):
     _fields_ = [("input_dim", C.c_int32), ("n_enc", C.c_int32),
                 ("enc_units", C.c_int32 * ADN_MAX_ENC_LAYERS), ("enc_act", C.c_int32 * ADN_MAX_ENC_LAYERS),
                 ("use_delta", C.c_int32), ("bidirectional", C.c_int32), ("peepholes", C.c_int32),
-                ("dropout_p", C.c_float)]
+                ("dropout_p", C.c_float), ("batchnorm", C.c_int32), ("aux_dim", C.c_int32)]
 
 
 class Config(C.Structure):
     _fields_ = [("n_streams", C.c_int32), ("streams", StreamConfig * ADN_MAX_STREAMS),
                 ("fusion", C.c_int32), ("agg", C.c_int32), ("agg_peepholes", C.c_int32),
                 ("lstm_size", C.c_int32), ("classes", C.c_int32), ("precision", C.c_int32),
-                ("head", C.c_int32), ("agg_dropout_p", C.c_float), ("reserved", C.c_int32 * 6)]
+                ("head", C.c_int32), ("agg_dropout_p", C.c_float), ("stream_lstm_units", C.c_int32),
+                ("reserved", C.c_int32 * 5)]
 
 
 class CaeConfig(C.Structure):
@@ -63,6 +64,7 @@ class AdenetError(RuntimeError):
 _P = C.c_void_p
 _SIGNATURES = {
     "adn_version": (C.c_char_p, []),
+    "adn_abi_sizes": (None, [C.POINTER(C.c_int32)]),
     "adn_last_error": (C.c_char_p, []),
     "adn_device_count": (C.c_int, []),
     "adn_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),

@@ -186,6 +186,22 @@ int softmax_ce(const float* z, int ldz, int B, int T, int C, const int32_t* y_bt
                float* row_loss, float* dz, int lddz, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
+// BatchNormLayer over the rows of a [rows][C] matrix (batchnorm.hip)
+// ---------------------------------------------------------------------------------------
+constexpr float kBnEps = 1e-4f, kBnAlpha = 0.1f;          // lasagne.layers.BatchNormLayer defaults
+size_t batchnorm_ws_bytes(int C);
+int batchnorm_forward_train(const float* x, int ldx, float* y, int ldy, int rows, int C, const float* gamma, const float* beta,
+                            float eps, float alpha, float* save_mean, float* save_inv_std, float* run_mean, float* run_inv_std,
+                            void* ws, hipStream_t s, void* y16 = nullptr);
+int batchnorm_forward_eval(const float* x, int ldx, float* y, int ldy, int rows, int C, const float* gamma, const float* beta,
+                           const float* run_mean, const float* run_inv_std, hipStream_t s, void* y16 = nullptr);
+// batch_stats: the forward pass used batch statistics (mean / inv_std = the saved ones); otherwise running averages
+// (then they are constants of the graph and the mean / variance terms of the adjoint drop out)
+int batchnorm_backward(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int rows, int C, const float* gamma,
+                       const float* mean, const float* inv_std, int batch_stats, float* dgamma, float* dbeta, void* ws,
+                       hipStream_t s, void* dx16 = nullptr);
+
+// ---------------------------------------------------------------------------------------
 // LSTM recurrence (lstm.hip).  All matrices time-major; gate columns interleaved (unit, gate).
 // ---------------------------------------------------------------------------------------
 struct LstmStep {          // one LSTM instance taking part in a (possibly multi-LSTM) step launch

@@ -81,9 +81,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            float* __restrict__ dx, int lddx, int rows, int C,
                                                            const float* __restrict__ mean, const float* __restrict__ inv_std,
                                                            const float* __restrict__ gamma, const float* __restrict__ sums,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, __bf16* __restrict__ dx16) {
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, __bf16* __restrict__ dx16,
+                                                           int batch_stats) {
     const int64_t total = (int64_t)rows * C;
-    const float inv_n = 1.f / (float)rows;
+    const float inv_n = batch_stats ? 1.f / (float)rows : 0.f;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int r = (int)(e / C), c = (int)(e % C);
         const float is = inv_std[c];
@@ -133,8 +134,8 @@ int batchnorm_forward_eval(const float* x, int ldx, float* y, int ldy, int rows,
 
 // dx may alias dy.  dgamma / dbeta are accumulated into (+=).
 int batchnorm_backward(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int rows, int C, const float* gamma,
-                       const float* save_mean, const float* save_inv_std, float* dgamma, float* dbeta, void* ws, hipStream_t s,
-                       void* dx16) {
+                       const float* save_mean, const float* save_inv_std, int batch_stats, float* dgamma, float* dbeta, void* ws,
+                       hipStream_t s, void* dx16) {
     ADN_CHECK(x && dy && dx && gamma && save_mean && save_inv_std && ws && rows > 0 && C > 0, ADN_ERR_INVALID, "batchnorm: bad argument");
     float* sums = reinterpret_cast<float*>(static_cast<double*>(ws) + 2 * (size_t)C) + C;     // behind std_tmp
     ADN_HIP_CHECK(hipMemsetAsync(sums, 0, (size_t)2 * C * sizeof(float), s));
@@ -145,7 +146,7 @@ int batchnorm_backward(const float* x, int ldx, const float* dy, int lddy, float
     hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(ctiles, splits), dim3(256), 0, s, x, ldx, dy, lddy, rows, C, save_mean, save_inv_std,
                        sums, rps);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_of((int64_t)rows * C)), dim3(256), 0, s, x, ldx, dy, lddy, dx, lddx, rows, C,
-                       save_mean, save_inv_std, gamma, sums, dgamma, dbeta, reinterpret_cast<__bf16*>(dx16));
+                       save_mean, save_inv_std, gamma, sums, dgamma, dbeta, reinterpret_cast<__bf16*>(dx16), batch_stats);
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }

@@ -630,14 +630,13 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // 83 % of the wave cycles, 6.7x the L2 requests: 90 TFLOP/s instead of 700).
 template <bool SPLIT>
 __device__ __forceinline__ void pp_epi4(const GemmParams& p, const GemmGroup& gp, float* Cg, f32x4 a, const float4& bias4,
-                                        int row, int col, float4& csum) {
+                                        const bf16x4& y, int row, int col, float4& csum) {
     const size_t off = (size_t)row * p.ldc + col;
     float4 v = make_float4(a[0], a[1], a[2], a[3]);
     if (SPLIT) { *reinterpret_cast<float4*>(Cg + off) = v; return; }
     v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
     if (p.act == ADN_ACT_RECTIFY) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    if (gp.Y16) {                                                  // rectify'(Y): the host sends nothing else here
-        const bf16x4 y = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(gp.Y16) + (size_t)row * p.ldy + col);
+    if (gp.Y16) {                                                  // rectify'(Y) from the mask values fetched ahead of the block
         v.x = (float)y[0] > 0.f ? v.x : 0.f; v.y = (float)y[1] > 0.f ? v.y : 0.f;
         v.z = (float)y[2] > 0.f ? v.z : 0.f; v.w = (float)y[3] > 0.f ? v.w : 0.f;
     }
@@ -649,6 +648,19 @@ __device__ __forceinline__ void pp_epi4(const GemmParams& p, const GemmGroup& gp
     if (gp.C16) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(gp.C16) + off) = cvt4(v);
     csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w;
 }
+
+// optional phase timing (build with -DADN_GEMM_STAMPS; read with adn_debug_gemm_stamps): shader-clock cycles that wave 0
+// (early half) and wave 4 (late half) of workgroup 3 spend in [0] fragment-read issue, [1] DMA issue, [2] lgkmcnt wait,
+// [3] vmcnt wait, [4] barrier behind L, [5] MFMAs, [6] epilogue, [7] barrier behind C; slots 8.. the same for wave 4
+#ifdef ADN_GEMM_STAMPS
+__device__ unsigned long long g_gstamps[16];
+#define GSTAMP(k) do { if (stamping) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); \
+    atomicAdd(&g_gstamps[(k) + (late ? 8 : 0)], n_ - gl_); gl_ = __builtin_amdgcn_s_memtime(); } } while (0)
+#define GSTAMP_INIT const bool stamping = blockIdx.x == 3 && blockIdx.y == 0 && (tid == 0 || tid == 256); unsigned long long gl_ = __builtin_amdgcn_s_memtime();
+#else
+#define GSTAMP(k) do {} while (0)
+#define GSTAMP_INIT
+#endif
 
 template <int BM, int BN, bool A_KC, bool SPLIT>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
@@ -664,8 +676,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
     const int per_group = p.tiles_m * p.tiles_n;
     const int ntiles = per_group * p.ngroups;
     const int G = (int)gridDim.x;
-    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
-    const int kbeg = (int)blockIdx.y * p.k_chunk;
+    // (Tried: K-slice = function of the workgroup's XCD, so that the workgroups of one XCD share one 32-row window of A and B
+    //  in its L2 -- 109.5 vs 110.5 us on the 2000 x 1000 x 20800 weight gradient: the L2 miss rate is not what bounds it.)
+    const int bid = (int)blockIdx.x, slice = (int)blockIdx.y;
+    const int my_tiles = (ntiles - bid + G - 1) / G;
+    const int kbeg = slice * p.k_chunk;
     const int kend = min(p.K, kbeg + p.k_chunk);
     const int nk = (kend - kbeg + BK - 1) / BK;
     const int ktail = (kend - kbeg) - (nk - 1) * BK;               // valid k of the last stage (1..32)
@@ -685,7 +700,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
 #pragma unroll
     for (int t = 0; t < BPW; ++t) b_row[t] = (64 / B_CPR) * (wave * BPW + t) + lane / B_CPR;
     auto tile_of = [&](int ord, int& grp, int& tm, int& tn) {      // ord-th tile of this workgroup
-        const int q = xcd_tile((int)blockIdx.x + ord * G, ntiles);
+        const int q = xcd_tile(bid + ord * G, ntiles);
         grp = q / per_group;
         tile_coords(p, q - grp * per_group, tm, tn);
     };
@@ -797,6 +812,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
     int kt = 0, ord = 0;
     int grp, tile_m, tile_n;
     tile_of(0, grp, tile_m, tile_n);
+    GSTAMP_INIT
     for (int s = 0; s < total; ++s) {
         // ---------------- L(s): fragments of stage s -> registers, DMA for stage s + D
         const char* As = reinterpret_cast<const char*>(smem + (s & (NS - 1)) * kStageElems);
@@ -818,16 +834,21 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
             const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Bs + b_off[b] + 4 * (BN * 2)));
             fb[b] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
         }
+        GSTAMP(0);
         if (s + D < total) issue_next();
+        GSTAMP(1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        GSTAMP(2);
         if (has_tail && kt == nk - 1) {
 #pragma unroll
             for (int a = 0; a < TM; ++a) fa[a] = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4, fa[a]) & amask);
         }
         if (late) wait_next(s, kt == 0 && s > 0);
+        GSTAMP(3);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        GSTAMP(4);
         // ---------------- C(s)
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -836,32 +857,52 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
             for (int b = 0; b < TN; ++b)
                 acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[b], fa[a], acc[a][b], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
+        GSTAMP(5);
         if (!late) wait_next(s, kt == 0 && s > 0);
+        GSTAMP(3);
         if (__builtin_expect(kt == nk - 1, 0)) {
             // ---- epilogue of tile `ord`, straight from the (transposed) accumulators: lane = row (lane & 15),
             //      columns 4 hi .. 4 hi + 3 of every 16-column block
             const GemmGroup gp = pick_group(p, grp);
-            float* Cg = SPLIT ? p.partial + ((size_t)(grp * (int)gridDim.y + (int)blockIdx.y) * p.M) * p.ldc : gp.C;
+            float* Cg = SPLIT ? p.partial + ((size_t)(grp * (int)gridDim.y + slice) * p.M) * p.ldc : gp.C;
             const int row0 = tile_m * BM + wm * WTM + (lane & 15), col0 = tile_n * BN + wn * WTN + 4 * hi;
+            // The act'(Y) mask of two 16-column blocks is requested in ONE burst ahead of them (2 TM eight-byte loads per
+            // lane, from addresses clamped into the matrix): issued block by block, every block paid a full memory round
+            // trip (measured 47 us on a 156 us launch: the epilogue holds up the barrier cadence of both wave halves).
+            constexpr int TNH = 2;                               // 16-column blocks per burst (TM x 2 loads in flight per lane)
 #pragma clang loop unroll(full)
-            for (int b = 0; b < TN; ++b) {
-                const int col = col0 + b * 16;
-                if (col >= p.N) continue;
-                float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), csum = bias4;
-                if (!SPLIT && gp.bias) bias4 = *reinterpret_cast<const float4*>(gp.bias + col);
+            for (int half = 0; half < TN / TNH; ++half) {
+                bf16x4 yv[TM][TNH];
+                if (!SPLIT && gp.Y16) {
 #pragma clang loop unroll(full)
-                for (int a = 0; a < TM; ++a) {
-                    const int row = row0 + a * 16;
-                    if (row < p.M) pp_epi4<SPLIT>(p, gp, Cg, acc[a][b], bias4, row, col, csum);
+                    for (int bb = 0; bb < TNH; ++bb)
+#pragma clang loop unroll(full)
+                        for (int a = 0; a < TM; ++a) {
+                            const int row = min(row0 + a * 16, p.M - 1), col = min(col0 + (half * TNH + bb) * 16, p.N - 4);
+                            yv[a][bb] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(gp.Y16) + (size_t)row * p.ldy + col);
+                        }
                 }
-                if (!SPLIT && gp.colsum) {                         // column sums over this wave's WTM rows
-#pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) {
-                        csum.x += __shfl_xor(csum.x, o, 64); csum.y += __shfl_xor(csum.y, o, 64);
-                        csum.z += __shfl_xor(csum.z, o, 64); csum.w += __shfl_xor(csum.w, o, 64);
+#pragma clang loop unroll(full)
+                for (int bb = 0; bb < TNH; ++bb) {
+                    const int b = half * TNH + bb;
+                    const int col = col0 + b * 16;
+                    if (col >= p.N) continue;
+                    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), csum = bias4;
+                    if (!SPLIT && gp.bias) bias4 = *reinterpret_cast<const float4*>(gp.bias + col);
+#pragma clang loop unroll(full)
+                    for (int a = 0; a < TM; ++a) {
+                        const int row = row0 + a * 16;
+                        if (row < p.M) pp_epi4<SPLIT>(p, gp, Cg, acc[a][b], bias4, yv[a][bb], row, col, csum);
                     }
-                    if ((lane & 15) == 0)
-                        *reinterpret_cast<float4*>(gp.colsum + (size_t)(tile_m * 4 + wm) * p.colsum_ld + col) = csum;
+                    if (!SPLIT && gp.colsum) {                     // column sums over this wave's WTM rows
+#pragma unroll
+                        for (int o = 1; o < 16; o <<= 1) {
+                            csum.x += __shfl_xor(csum.x, o, 64); csum.y += __shfl_xor(csum.y, o, 64);
+                            csum.z += __shfl_xor(csum.z, o, 64); csum.w += __shfl_xor(csum.w, o, 64);
+                        }
+                        if ((lane & 15) == 0)
+                            *reinterpret_cast<float4*>(gp.colsum + (size_t)(tile_m * 4 + wm) * p.colsum_ld + col) = csum;
+                    }
                 }
             }
 #pragma unroll
@@ -873,9 +914,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
         } else {
             ++kt;
         }
+        GSTAMP(6);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        GSTAMP(7);
     }
     if (!late) __builtin_amdgcn_s_barrier();                       // every wave executes the same number of barriers
 }
@@ -1019,3 +1062,10 @@ int to_bf16(const float* src, void* dst, size_t n, hipStream_t s) {
 
 }  // namespace adn
 
+#ifdef ADN_GEMM_STAMPS
+extern "C" int adn_debug_gemm_stamps(unsigned long long* out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(adn::g_gstamps), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(adn::g_gstamps), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif

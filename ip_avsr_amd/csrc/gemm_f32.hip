@@ -273,7 +273,8 @@ static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used
         p.panel_n = std::max(1, std::min((int)std::lround(std::sqrt((double)chunk)), p.tiles_n));
     }
     int gx = (int)std::min<int64_t>(tiles, cus / splits);
-    if (gx >= 8) gx = gx / 8 * 8;             // a workgroup's tiles then stay on its own XCD's chunk of the tile list
+    if (splits > 1) gx = (int)tiles;          // one (tile, slice) per workgroup
+    else if (gx >= 8) gx = gx / 8 * 8;      // a workgroup's tiles then stay on its own XCD's chunk of the tile list
     static const bool trace = getenv("ADN_GEMM_TRACE") != nullptr;
     if (trace)
         fprintf(stderr, "ADN_GEMM %s M=%d N=%d K=%d tile=%d tiles=%lld split=%d shadows=1 lean=%d acc=%d groups=%d\n",

@@ -118,8 +118,12 @@ struct StreamState {
     adn_stream_config cfg;
     std::vector<size_t> encW, encb;   // offsets
     std::vector<int> enc_in;          // input width of each encoder layer
-    int feat_dim = 0;                 // LSTM input width (3E / E / 3D / D)
+    int feat_dim = 0;                 // LSTM input width (3E / E / 3D / D, + aux_dim)
+    int delta_dim = 0;                // ... of which the delta layer produces the first columns
     int enc_out = 0;                  // width entering the delta layer
+    size_t bn_beta = 0, bn_gamma = 0, bn_mean = 0, bn_inv_std = 0;   // BatchNormLayer behind the encoder (cfg.batchnorm)
+    float *bn_out = nullptr, *bn_save_mean = nullptr, *bn_save_inv_std = nullptr; char* bn_ws = nullptr;
+    float* aux_stage = nullptr;       // staged auxiliary input (batch-major, ld_of(aux_dim))
     std::vector<LstmParams> lstm;     // 1 or 2
     // workspace
     const float* x = nullptr; int ldx = 0;     // staged input (batch-major)
@@ -162,6 +166,9 @@ struct adn_model {
     // stochastic layers: masks are a hash of (seed, counter, layer, element); `stochastic` is set per call
     uint32_t drop_seed = 0x5EED1234u, drop_counter = 0;
     bool stochastic = false;
+    bool training = false;            // this pass is get_output(deterministic=False): BatchNorm uses batch statistics
+    int stream_units() const { return cfg.stream_lstm_units > 0 ? cfg.stream_lstm_units : cfg.lstm_size; }
+    int n_aux() const { int n = 0; for (int k = 0; k < cfg.n_streams; ++k) n += cfg.streams[k].aux_dim > 0; return n; }
     bool head_last() const { return cfg.head == ADN_HEAD_LAST; }
     bool has_dropout() const {
         if (cfg.agg_dropout_p > 0.f) return true;
@@ -257,12 +264,17 @@ struct Builder {
         m->params.push_back(p);
     }
     // Lasagne registration order inside an LSTMLayer
-    LstmParams add_lstm(const std::string& prefix, int fin, bool peep, bool backwards) {
-        const int H = m->H, ldg = m->ldg, ldh = m->ldh;
+    // units / fin_view: logical sizes of the parameter views when they are narrower than the physical tensors
+    // (adn_config.stream_lstm_units): the surplus rows / columns are never written and stay zero
+    LstmParams add_lstm(const std::string& prefix, int fin, bool peep, bool backwards, int units = 0, int fin_view = 0) {
+        const int ldg = m->ldg, ldh = m->ldh;
+        const int H = units > 0 ? units : m->H;
+        const int fin_phys = fin;
+        if (fin_view > 0) fin = fin_view;
         LstmParams lp;
-        lp.fin = fin; lp.peepholes = peep; lp.backwards = backwards;
-        lp.W_in = alloc((size_t)fin * ldg);
-        lp.W_hid = alloc((size_t)H * ldg);
+        lp.fin = fin_phys; lp.peepholes = peep; lp.backwards = backwards;
+        lp.W_in = alloc((size_t)fin_phys * ldg);
+        lp.W_hid = alloc((size_t)m->H * ldg);
         lp.b = alloc(ldg);
         if (peep) lp.peep = alloc((size_t)3 * ldh);
         lp.cell_init = alloc(ldh);
@@ -299,10 +311,17 @@ int validate(const adn_config& c) {
     if (c.fusion == ADN_FUSE_NONE) ADN_CHECK(c.n_streams == 1, ADN_ERR_INVALID, "fusion 'none' needs exactly one stream");
     if (c.fusion == ADN_FUSE_CONCAT && c.n_streams > 1)
         ADN_CHECK(c.agg != 0, ADN_ERR_INVALID, "concat fusion needs an aggregation LSTM");
+    ADN_CHECK(c.stream_lstm_units >= 0 && c.stream_lstm_units <= c.lstm_size, ADN_ERR_INVALID,
+              "stream_lstm_units must be 0 or at most lstm_size");
+    if (c.stream_lstm_units > 0 && c.stream_lstm_units < c.lstm_size)
+        ADN_CHECK(c.fusion != ADN_FUSE_CONCAT && c.agg > 0, ADN_ERR_INVALID,
+                  "narrower stream LSTMs need an aggregation LSTM and a fusion other than concat");
     int n_sub = 0;
     for (int s = 0; s < c.n_streams; ++s) {
         const adn_stream_config& sc = c.streams[s];
         ADN_CHECK(sc.input_dim >= 1, ADN_ERR_INVALID, "stream input_dim must be positive");
+        ADN_CHECK(sc.aux_dim >= 0 && sc.aux_dim <= 65536, ADN_ERR_INVALID, "aux_dim out of range");
+        ADN_CHECK(!sc.batchnorm || sc.n_enc > 0, ADN_ERR_INVALID, "the BatchNorm layer sits behind an encoder");
         ADN_CHECK(sc.n_enc >= 0 && sc.n_enc <= ADN_MAX_ENC_LAYERS, ADN_ERR_INVALID, "n_enc out of range");
         for (int l = 0; l < sc.n_enc; ++l) {
             ADN_CHECK(sc.enc_units[l] >= 1, ADN_ERR_INVALID, "encoder layer width must be positive");
@@ -334,10 +353,20 @@ int build_params(adn_model* m) {
             d = u;
         }
         st.enc_out = d;
-        st.feat_dim = st.cfg.use_delta ? 3 * d : d;
+        if (st.cfg.batchnorm) {                   // lasagne registration order: beta, gamma, mean, inv_std
+            const int ld = ld_of(d);
+            st.bn_beta = b.alloc(ld); st.bn_gamma = b.alloc(ld); st.bn_mean = b.alloc(ld); st.bn_inv_std = b.alloc(ld);
+            b.add(sp + ".bn.beta", 1, d, 1, st.bn_beta, ld);
+            b.add(sp + ".bn.gamma", 1, d, 1, st.bn_gamma, ld);
+            b.add(sp + ".bn.mean", 1, d, 1, st.bn_mean, ld);
+            b.add(sp + ".bn.inv_std", 1, d, 1, st.bn_inv_std, ld);
+        }
+        st.delta_dim = st.cfg.use_delta ? 3 * d : d;
+        st.feat_dim = st.delta_dim + st.cfg.aux_dim;
         const int ndir = st.cfg.bidirectional ? 2 : 1;
+        const int units = m->stream_units() < m->H ? m->stream_units() : 0;
         for (int k = 0; k < ndir; ++k)
-            st.lstm.push_back(b.add_lstm(sp + ".lstm" + std::to_string(k), st.feat_dim, st.cfg.peepholes != 0, k == 1));
+            st.lstm.push_back(b.add_lstm(sp + ".lstm" + std::to_string(k), st.feat_dim, st.cfg.peepholes != 0, k == 1, units));
     }
     m->tail_begin = b.cursor;                 // fusion coefficients, aggregation LSTMs, classifier
     if (c.fusion == ADN_FUSE_ADASUM) {
@@ -345,8 +374,9 @@ int build_params(adn_model* m) {
         for (int s = 0; s < m->S; ++s) b.add("fuse.adacoeff" + std::to_string(s), 0, 1, 1, m->adacoeff + s, 1);
     }
     m->fused_dim = (c.fusion == ADN_FUSE_CONCAT) ? m->S * m->H : m->H;
-    for (int k = 0; k < c.agg; ++k)
-        m->agg.push_back(b.add_lstm("agg" + std::to_string(k), m->fused_dim, c.agg_peepholes != 0, k == 1));
+    for (int k = 0; k < c.agg; ++k)     // (narrower stream LSTMs: only the first stream_units rows of W_in are exposed)
+        m->agg.push_back(b.add_lstm("agg" + std::to_string(k), m->fused_dim, c.agg_peepholes != 0, k == 1, 0,
+                                    m->stream_units() < m->H ? m->stream_units() : 0));
     m->smW = b.alloc((size_t)m->H * m->ldc);
     m->smb = b.alloc(m->ldc);
     b.add("softmax.W", 2, m->H, m->C, m->smW, m->ldc);
@@ -416,6 +446,13 @@ size_t carve(adn_model* m, char* base, int B, int T, bool host_inputs) {
             st.act[l] = take_shadowed(m, cv, N * ld_of(st.cfg.enc_units[l]));
             maxw = std::max(maxw, ld_of(st.cfg.enc_units[l]));
         }
+        if (st.cfg.batchnorm) {
+            st.bn_out = cv.take<float>(N * ld_of(st.enc_out));
+            st.bn_save_mean = cv.take<float>(ld_of(st.enc_out));
+            st.bn_save_inv_std = cv.take<float>(ld_of(st.enc_out));
+            st.bn_ws = cv.take<char>(batchnorm_ws_bytes(st.enc_out));
+        }
+        if (st.cfg.aux_dim > 0) st.aux_stage = cv.take<float>(N * ld_of(st.cfg.aux_dim));
         st.feat = take_shadowed(m, cv, N * ld_of(st.feat_dim));
         st.dfeat = cv.take<float>(N * ld_of(st.feat_dim));
         st.dE = take_shadowed(m, cv, N * ld_of(st.enc_out));
@@ -496,6 +533,14 @@ int stage_inputs(adn_model* m, const void* const* inputs, const int32_t* targets
                                            m->stream));
             st.x = st.xstage; st.ldx = ld;
         }
+    }
+    int aux_k = 0;                               // auxiliary inputs follow the S stream inputs, in stream order
+    for (auto& st : m->st) {
+        if (st.cfg.aux_dim <= 0) continue;
+        const void* src = inputs[m->S + aux_k++];
+        ADN_CHECK(src, ADN_ERR_INVALID, "null auxiliary input");
+        ADN_HIP_CHECK(hipMemcpy2DAsync(st.aux_stage, (size_t)ld_of(st.cfg.aux_dim) * 4, src, (size_t)st.cfg.aux_dim * 4,
+                                       (size_t)st.cfg.aux_dim * 4, N, kind, m->stream));
     }
     for (auto& st : m->st) if (!st.x16) ADN_TRY(refresh(m, st.x, N * st.ldx));
     ADN_TRY(refresh_params(m));
@@ -817,9 +862,24 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
             if (!grouped) { GemmArgs g = enc_gemm(st, l); ADN_TRY(gemm(g, m->stream)); }
             a = st.act[l]; lda = ld_of(st.cfg.enc_units[l]);
         }
+        if (st.cfg.batchnorm) {                                  // BatchNormLayer on the (B*T, E) encoder output (adenet_v1.py:82)
+            const int ldE = ld_of(st.enc_out);
+            if (m->training)
+                ADN_TRY(batchnorm_forward_train(a, lda, st.bn_out, ldE, N, st.enc_out, m->P(st.bn_gamma), m->P(st.bn_beta), kBnEps,
+                                                kBnAlpha, st.bn_save_mean, st.bn_save_inv_std, m->P(st.bn_mean), m->P(st.bn_inv_std),
+                                                st.bn_ws, m->stream));
+            else
+                ADN_TRY(batchnorm_forward_eval(a, lda, st.bn_out, ldE, N, st.enc_out, m->P(st.bn_gamma), m->P(st.bn_beta),
+                                               m->P(st.bn_mean), m->P(st.bn_inv_std), m->stream));
+            a = st.bn_out; lda = ldE;
+        }
         const bool drop = m->stochastic && st.cfg.dropout_p > 0.f;
         void* feat16 = (m->bf16() && !drop) ? m->shadow_of(st.feat) : nullptr;      // written by the delta kernel itself
         ADN_TRY(delta_forward(a, lda, st.feat, ld_of(st.feat_dim), B, T, st.enc_out, theta, st.cfg.use_delta, m->stream, feat16));
+        if (st.cfg.aux_dim > 0)                                  // ConcatLayer([l_delta, l_dct], axis=2): columns behind the deltas
+            ADN_TRY(delta_forward(st.aux_stage, ld_of(st.cfg.aux_dim), st.feat + st.delta_dim, ld_of(st.feat_dim), B, T,
+                                  st.cfg.aux_dim, theta, 0, m->stream,
+                                  feat16 ? static_cast<char*>(feat16) + 2 * (size_t)st.delta_dim : nullptr));
         if (drop)                                                // DropoutLayer ahead of the LSTM (adenet_v3.py:112,123,134)
             ADN_TRY(dropout_apply(st.feat, ld_of(st.feat_dim), st.feat, ld_of(st.feat_dim), B, T, st.feat_dim, st.feat_dim, 0,
                                   st.cfg.dropout_p, m->drop_seed, m->drop_counter, (uint32_t)(&st - m->st.data()), m->stream));
@@ -1129,7 +1189,14 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         const int L = st.cfg.n_enc;
         const bool last_linear = L > 0 && st.cfg.enc_act[L - 1] == ADN_ACT_LINEAR;
         void* dE16 = (m->bf16() && (L == 0 || last_linear)) ? m->shadow_of(st.dE) : nullptr;   // bf16 copy straight from the kernel
-        ADN_TRY(delta_backward(st.dfeat, ldf, st.dE, ldE, B, T, st.enc_out, theta, st.cfg.use_delta, m->stream, dE16));
+        // (an auxiliary input sits in the columns behind the delta features: data, no gradient)
+        ADN_TRY(delta_backward(st.dfeat, ldf, st.dE, ldE, B, T, st.enc_out, theta, st.cfg.use_delta, m->stream,
+                               st.cfg.batchnorm ? nullptr : dE16));
+        if (st.cfg.batchnorm)                     // through the BatchNormLayer: d(bn_out) -> d(encoder output), dgamma, dbeta
+            ADN_TRY(batchnorm_backward(st.act[L - 1], ldE, st.dE, ldE, st.dE, ldE, N, st.enc_out, m->P(st.bn_gamma),
+                                       m->training ? st.bn_save_mean : m->P(st.bn_mean),
+                                       m->training ? st.bn_save_inv_std : m->P(st.bn_inv_std), m->training ? 1 : 0,
+                                       m->G(st.bn_gamma), m->G(st.bn_beta), st.bn_ws, m->stream, dE16));
         if (!last_linear)
             ADN_TRY(act_backward(st.dE, ldE, st.act[L - 1], ldE, N, st.enc_out, st.cfg.enc_act[L - 1], m->stream));
         if (!dE16) ADN_TRY(refresh(m, st.dE, (size_t)N * ldE));
@@ -1287,6 +1354,10 @@ extern "C" {
 
 const char* adn_version(void) { return "adenet-hip 0.1.0 (gfx950)"; }
 const char* adn_last_error(void) { return g_last_error.c_str(); }
+void adn_abi_sizes(int32_t out[4]) {
+    out[0] = (int32_t)sizeof(adn_stream_config); out[1] = (int32_t)sizeof(adn_config);
+    out[2] = (int32_t)sizeof(adn_param_info_t); out[3] = (int32_t)sizeof(adn_profile_entry);
+}
 
 int adn_device_count(void) {
     int n = 0;
@@ -1460,7 +1531,7 @@ int adn_forward(adn_model* m, const void* const* inputs, const uint8_t* mask, in
     ADN_CHECK(probs, ADN_ERR_INVALID, "null output");
     ADN_TRY(ensure_workspace(m, B, T));
     ADN_TRY(stage_inputs(m, inputs, nullptr, mask, B, T, flags));
-    m->stochastic = false;
+    m->stochastic = false; m->training = false;
     ADN_TRY(forward_pass(m, B, T, theta, false, false));
     const size_t rows = m->head_last() ? (size_t)B : (size_t)B * T;
     return fetch(m, probs, m->probs_bt, rows * m->C * sizeof(float), flags & ADN_FLAG_DEVICE_OUTPUTS);
@@ -1473,7 +1544,8 @@ int adn_loss(adn_model* m, const void* const* inputs, const int32_t* targets, co
     ADN_TRY(ensure_workspace(m, B, T));
     ADN_TRY(stage_inputs(m, inputs, targets, mask, B, T, flags));
     ADN_TRY(set_loss_normaliser(m, B, 0.0));
-    m->stochastic = (flags & ADN_FLAG_STOCHASTIC) && m->has_dropout();
+    m->training = (flags & ADN_FLAG_STOCHASTIC) != 0;          // compute_train_cost: get_output(deterministic=False)
+    m->stochastic = m->training && m->has_dropout();
     ADN_TRY(forward_pass(m, B, T, theta, true, false));
     if (m->stochastic) m->drop_counter += 1;
     return fetch(m, loss, m->loss, sizeof(float), flags & ADN_FLAG_DEVICE_OUTPUTS);
@@ -1486,7 +1558,8 @@ int adn_compute_grads(adn_model* m, const void* const* inputs, const int32_t* ta
     ADN_TRY(ensure_workspace(m, B, T));
     ADN_TRY(stage_inputs(m, inputs, targets, mask, B, T, flags));
     ADN_TRY(set_loss_normaliser(m, B, total_frames));
-    m->stochastic = !(flags & ADN_FLAG_DETERMINISTIC) && m->has_dropout();
+    m->training = !(flags & ADN_FLAG_DETERMINISTIC);
+    m->stochastic = m->training && m->has_dropout();
     ADN_TRY(forward_pass(m, B, T, theta, true, true));
     ADN_TRY(backward_pass(m, B, T, theta));
     if (m->stochastic) m->drop_counter += 1;

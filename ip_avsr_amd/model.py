@@ -54,9 +54,13 @@ class AdeNetModel(object):
 
     ``spec`` is a plain dict::
 
-        streams      list of {input_dim, enc_names, enc_shapes, enc_acts, delta, lstm_names, peepholes[, dropout]}
+        streams      list of {input_dim, enc_names, enc_shapes, enc_acts, delta, lstm_names, peepholes[, dropout]
+                     [, batchnorm, aux_dim]}
                      (lstm_names of length 2 = summed forward/backward pair; dropout = p of a DropoutLayer ahead of
-                     the stream's LSTM, modelzoo/adenet_v3.py:112)
+                     the stream's LSTM, modelzoo/adenet_v3.py:112; batchnorm = name of a BatchNormLayer on the encoder
+                     output; aux_dim = width of an auxiliary input concatenated behind the delta features, its array
+                     follows the stream inputs: modelzoo/adenet_v1.py:82-87)
+        stream_lstm_size   units of the stream LSTMs when smaller than lstm_size (adenet_v1.py:89,95)
         fusion       'none' | 'sum' | 'adasum' | 'concat' ; fuse_name (layer name of the merge layer)
         agg_names    [] | [name] | [forward_name, backward_name] ; agg_peepholes
         lstm_size, classes, softmax_name
@@ -86,6 +90,8 @@ class AdeNetModel(object):
             sc.bidirectional = int(len(s["lstm_names"]) == 2)
             sc.peepholes = int(bool(s["peepholes"]))
             sc.dropout_p = float(s.get("dropout", 0.0) or 0.0)
+            sc.batchnorm = int(bool(s.get("batchnorm")))
+            sc.aux_dim = int(s.get("aux_dim", 0) or 0)
         if spec["fusion"] not in _lib.FUSION:
             # modelzoo/adenet_v2.py:75 raises for an unknown fusiontype (as a TypeError, through a
             # bug in the raise statement itself); here it is a plain ValueError
@@ -98,11 +104,14 @@ class AdeNetModel(object):
         cfg.precision = _lib.PRECISION[spec.get("precision", "f32")]
         cfg.head = _lib.HEAD[spec.get("head", "frames")]
         cfg.agg_dropout_p = float(spec.get("agg_dropout", 0.0) or 0.0)
+        units = int(spec.get("stream_lstm_size") or 0)
+        cfg.stream_lstm_units = units if 0 < units < cfg.lstm_size else 0
         self.head = spec.get("head", "frames")
         self._handle = C.c_void_p()
         _lib.check(self._lib.adn_create(C.byref(cfg), C.byref(self._handle)))
         self.S, self.H, self.C = S, cfg.lstm_size, cfg.classes
         self.input_dims = [int(s["input_dim"]) for s in spec["streams"]]
+        self.aux_dims = [int(s["aux_dim"]) for s in spec["streams"] if s.get("aux_dim")]
         self._build_param_table()
         self._torch_stream = None
         self._front = {}                      # stream index -> (conv encoder, frame width): frozen feature extractors
@@ -143,6 +152,8 @@ class AdeNetModel(object):
             sub, leaf2 = leaf.split(".", 1)
             if sub.startswith("enc"):
                 return "%s.%s" % (s["enc_names"][int(sub[3:])], leaf2)
+            if sub == "bn":
+                return "%s.%s" % (s["batchnorm"], leaf2)
             return "%s.%s" % (s["lstm_names"][int(sub[4:])], leaf2)
         if head == "fuse":
             return "%s.%s" % (spec["fuse_name"], leaf)
@@ -179,11 +190,17 @@ class AdeNetModel(object):
                 raise ValueError("mismatch: parameter %s has shape %s, got %s" % (p.name, p.shape, v.shape))
         _lib.check(self._lib.adn_write_tensor(self._handle, buf, index, v.ctypes.data_as(C.c_void_p)))
 
-    def get_all_params(self, trainable=True, **tags):
-        """lasagne.layers.get_all_params: every parameter on this path is trainable
-        (encoders included).  ``scaling_param=True`` selects the adasum coefficients."""
+    def get_all_params(self, trainable=None, **tags):
+        """lasagne.layers.get_all_params: every parameter on this path is trainable (encoders included)
+        except a BatchNormLayer's running ``mean`` / ``inv_std``, which ``trainable=True`` filters out (they stay in the
+        plain list: ``get_all_param_values`` checkpoints carry them).  ``scaling_param=True`` selects the adasum
+        coefficients."""
         if tags.get("scaling_param"):
             return [p for p in self.params if ".adacoeff" in p.name]
+        if trainable:
+            bn = {s["batchnorm"] for s in self.spec["streams"] if s.get("batchnorm")}
+            return [p for p in self.params
+                    if not (p.name.rsplit(".", 1)[0] in bn and p.name.rsplit(".", 1)[1] in ("mean", "inv_std"))]
         return list(self.params)
 
     def get_all_param_values(self, **tags):
@@ -273,13 +290,16 @@ class AdeNetModel(object):
         return out
 
     def _prep(self, inputs, mask, targets=None):
-        if len(inputs) != self.S:
-            raise ValueError("expected %d input streams, got %d" % (self.S, len(inputs)))
+        n_in = self.S + len(self.aux_dims)
+        if len(inputs) != n_in:
+            raise ValueError("expected %d input streams%s, got %d arrays"
+                             % (self.S, " + %d auxiliary inputs" % len(self.aux_dims) if self.aux_dims else "", len(inputs)))
         inputs = self._apply_front_ends(inputs)
         dev = self._is_device(inputs[0])
         keep = []
-        ptrs = (C.c_void_p * self.S)()
+        ptrs = (C.c_void_p * n_in)()
         shape = None
+        widths = self.input_dims + self.aux_dims
         for k, x in enumerate(inputs):
             if self._is_device(x) != dev:
                 raise ValueError("all streams must live on the same side (host or device)")
@@ -291,8 +311,8 @@ class AdeNetModel(object):
             else:
                 x = np.ascontiguousarray(x, dtype=np.float32)
                 p = x.ctypes.data
-            if x.ndim != 3 or x.shape[2] != self.input_dims[k]:
-                raise ValueError("stream %d: expected (B,T,%d), got %s" % (k, self.input_dims[k], tuple(x.shape)))
+            if x.ndim != 3 or x.shape[2] != widths[k]:
+                raise ValueError("input %d: expected (B,T,%d), got %s" % (k, widths[k], tuple(x.shape)))
             if shape is None:
                 shape = tuple(x.shape[:2])
             elif tuple(x.shape[:2]) != shape:
@@ -442,8 +462,8 @@ class AdeNetModel(object):
                     in1, mask, in2, window = args
                     targets = None
                 return [in1, in2], targets, mask, window
-            ins = args[:S]
-            rest = args[S:]
+            ins = args[:S + len(self.aux_dims)]
+            rest = args[S + len(self.aux_dims):]
             if with_targets:
                 targets, mask, window = rest
             else:

@@ -52,7 +52,7 @@ def _conv_encoder_of(ae):
 
 
 def stream(input_shape, ae=None, suffix="", delta=True, lstm_names=("lstm",), peepholes=False, enc_names=None,
-           pretrained_lstm=None, pretrained_prefixes=None, dropout=0.0):
+           pretrained_lstm=None, pretrained_prefixes=None, dropout=0.0, batchnorm=None, aux_shape=None):
     """One stream description.  ``ae`` = (weights, biases, shapes, nonlinearities) like
     ``load_decoder`` returns (runners/3stream.py:31-40), None for an encoder-less stream, or a trained convolutional
     auto-encoder (``ip_avsr_amd.convae.ConvAE`` / its bottleneck handle): its encoder then runs as a FROZEN feature
@@ -61,7 +61,8 @@ def stream(input_shape, ae=None, suffix="", delta=True, lstm_names=("lstm",), pe
     ``load_convae = False``, avletters/trimodal.py:278-283; training through it is outside the reference's live graph.)"""
     d = dict(input_dim=input_dim_of(input_shape), delta=bool(delta), lstm_names=list(lstm_names),
              peepholes=bool(peepholes), dropout=float(dropout), pretrained_lstm=pretrained_lstm,
-             pretrained_prefixes=list(pretrained_prefixes or []))
+             pretrained_prefixes=list(pretrained_prefixes or []), batchnorm=batchnorm,
+             aux_dim=input_dim_of(aux_shape) if aux_shape is not None else 0)
     conv = _conv_encoder_of(ae)
     if conv is not None:
         if conv.D != d["input_dim"]:
@@ -119,6 +120,8 @@ def param_names(spec):
     for s in spec["streams"]:
         for n in s["enc_names"]:
             names += [n + ".W", n + ".b"]
+        if s.get("batchnorm"):
+            names += ["%s.%s" % (s["batchnorm"], k) for k in ("beta", "gamma", "mean", "inv_std")]
         for ln in s["lstm_names"]:
             names += lstm_param_names(ln, s["peepholes"])
     if spec["fusion"] == "adasum":
@@ -133,14 +136,14 @@ SPEC_ONLY = False
 
 
 def build(streams, lstm_size, output_classes, fusiontype, fuse_names, agg_names, agg_peepholes, w_init_fn,
-          softmax_name="softmax", return_fuse=True, head="frames", agg_dropout=0.0):
+          softmax_name="softmax", return_fuse=True, head="frames", agg_dropout=0.0, stream_lstm_size=None):
     if fusiontype not in ("none", "sum", "adasum", "concat"):
         # modelzoo/adenet_v2.py:74-75 (other factories fall through to a NameError)
         raise ValueError("Unsupported Fusion Type used!")
     spec = dict(
         streams=[{k: s[k] for k in ("input_dim", "enc_names", "enc_shapes", "enc_acts", "delta", "lstm_names",
-                                    "peepholes", "dropout")} for s in streams],
-        head=head, agg_dropout=float(agg_dropout),
+                                    "peepholes", "dropout", "batchnorm", "aux_dim")} for s in streams],
+        head=head, agg_dropout=float(agg_dropout), stream_lstm_size=int(stream_lstm_size or lstm_size),
         fusion=fusiontype, fuse_name=fuse_names.get(fusiontype, ""), agg_names=list(agg_names),
         agg_peepholes=bool(agg_peepholes), lstm_size=int(lstm_size), classes=int(output_classes),
         softmax_name=softmax_name)
@@ -156,6 +159,10 @@ def build(streams, lstm_size, output_classes, fusiontype, fuse_names, agg_names,
         for n, W, b in zip(s["enc_names"], s["enc_weights"], s["enc_biases"]):
             model.set_param(n + ".W", W)
             model.set_param(n + ".b", np.asarray(b).reshape(-1))
+        if s.get("batchnorm"):                       # lasagne.layers.BatchNormLayer: beta 0, gamma 1, mean 0, inv_std 1
+            n = model.params[model.param_index[s["batchnorm"] + ".gamma"]].shape
+            model.set_param(s["batchnorm"] + ".gamma", np.ones(n, "float32"))
+            model.set_param(s["batchnorm"] + ".inv_std", np.ones(n, "float32"))
         for k, ln in enumerate(s["lstm_names"]):
             _init_lstm(model, ln, w_init, s["peepholes"])
             if s["pretrained_lstm"] is not None:

@@ -734,6 +734,21 @@ def spec_adenet_v3(raw_dim, dct_dim, diff_dim, enc_shapes=(2000, 1000, 500, 50),
                 lstm_size=2 * lstm_size, classes=classes, softmax_name="output", head="last", loss="cross_entropy")
 
 
+def spec_adenet_v1(input_dim, dct_dim, enc_shapes=(2000, 1000, 500, 50), enc_acts=("sigmoid", "sigmoid", "sigmoid", "linear"),
+                   lstm_size=250, classes=26, v1_1=False):
+    """modelzoo/adenet_v1.create_model (:48-109) / adenet_v1_1.create_model: encoder 'fc1'..'bottleneck' -> BatchNormLayer
+    'batchnorm1' -> DeltaLayer -> ConcatLayer with the DCT input -> [v1_1: dropout 0.5] -> summed BLSTM 'f_lstm1' /
+    'b_lstm1' of lstm_size (v1_1: 2 * lstm_size) units -> [v1_1: dropout 0.5] -> summed BLSTM 'f_lstm2' / 'b_lstm2' of
+    2 * lstm_size units -> LAST time step -> softmax 'output'.  No LSTMLayer passes ``peepholes=``: Lasagne's default
+    True applies (:27-43)."""
+    stream = dict(input_dim=input_dim, enc_names=ENC_NAMES[:len(enc_shapes)], enc_shapes=list(enc_shapes), enc_acts=list(enc_acts),
+                  delta=True, batchnorm="batchnorm1", aux_dim=dct_dim, lstm_names=["f_lstm1", "b_lstm1"], peepholes=True,
+                  dropout=0.5 if v1_1 else 0.0)
+    return dict(streams=[stream], fusion="none", fuse_name="", agg_names=["f_lstm2", "b_lstm2"], agg_peepholes=True,
+                agg_dropout=0.5 if v1_1 else 0.0, lstm_size=2 * lstm_size, stream_lstm_size=(2 * lstm_size if v1_1 else lstm_size),
+                classes=classes, softmax_name="output", head="last", loss="cross_entropy")
+
+
 def spec_deltanet_last(input_dim, enc_shapes=(2000, 1000, 500, 50), enc_acts=("rectify", "rectify", "rectify", "linear"),
                        lstm_size=250, classes=26):
     """modelzoo/deltanet.create_model (:12-56): encoder + deltas + summed BLSTM, LAST time step, softmax."""

@@ -13,6 +13,9 @@
 #include "adn_common.h"
 
 using namespace adn;
+#ifdef ADN_GEMM_STAMPS
+extern "C" int adn_debug_gemm_stamps(unsigned long long*, int);   // the library built with -DADN_GEMM_STAMPS
+#endif
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -128,12 +131,26 @@ int main(int argc, char** argv) {
         }
         for (int i = 0; i < 3; ++i) if (gemm_grouped(g, NG, st) != 0) { fprintf(stderr, "gemm failed: %s\n", c.name); return 1; }
         const int iters = 20;
+#ifdef ADN_GEMM_STAMPS
+        adn_debug_gemm_stamps(nullptr, 1);
+#endif
         CK(hipEventRecord(e0, st));
         for (int i = 0; i < iters; ++i) gemm_grouped(g, NG, st);
         CK(hipEventRecord(e1, st));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         const double us = ms * 1e3 / iters;
+#ifdef ADN_GEMM_STAMPS
+        { unsigned long long s16[16];
+          adn_debug_gemm_stamps(s16, 0);
+          const char* nm[8] = {"frag reads", "DMA issue", "lgkm wait", "vmcnt wait", "barrier(L)", "MFMA", "epilogue", "barrier(C)"};
+          for (int h = 0; h < 2; ++h) {
+              double tot = 0; for (int k = 0; k < 8; ++k) tot += (double)s16[8 * h + k];
+              printf("   stamps %s half (cycles per launch %.0f):", h ? "late " : "early", tot / iters);
+              for (int k = 0; k < 8; ++k) printf("  %s %.1f%%", nm[k], 100.0 * s16[8 * h + k] / (tot > 0 ? tot : 1));
+              printf("\n");
+          } }
+#endif
         const double outb = (double)NG * c.M * c.N * ((c.lean ? 0 : 4) + (g[0].C16 ? 2 : 0) + (c.ygrad ? 2 : 0) + (c.acc ? 4 : 0));
         printf("%-26s %3s %6d %6d %6d | %9.1f %9.1f %9.1f%s\n", c.name, c.layout == 0 ? "NN" : (c.layout == 1 ? "NT" : "TN"),
                c.M, c.N, c.K, us, 2.0 * NG * c.M * c.N * c.K / us / 1e6, outb / us / 1e3, c.colsum && !done[0] ? "  (colsum NOT fused)" : "");

@@ -35,8 +35,9 @@ def summarise(fa, fb, match):
 
 def main():
     fa, fb, prec = sys.argv[1:4]
-    match = "gemm_bf16" if prec == "bf16" else "gemm_f32_kernel"
-    out = {"kernel_class": "%s (all instantiations)" % match}
+    commit = sys.argv[4] if len(sys.argv) > 4 else "unknown"
+    match = "gemm_bf16" if prec == "bf16" else "gemm_f32_kernel"      # (gemm_bf16_kernel and gemm_bf16_pp_kernel)
+    out = {"kernel_class": "%s (all instantiations)" % match, "commit": "PMC passes taken at commit %s" % commit}
     out.update(summarise(fa, fb, match))
     # the LSTM kernels: one launch covers all T time steps of up to 3 LSTMs (bench.py divides by what a launch covered)
     for key, m in (("lstm_fwd", "lstm_fwd_cluster_kernel" if prec == "bf16" else "lstm_fwd_step_kernel"),

@@ -27,11 +27,14 @@ def test_header_and_binding_agree(lib):
         assert hasattr(lib, name), name
 
 
-def test_struct_sizes_match_header():
-    # adn_stream_config: 3 + 8 + 8 + ... int32 fields
-    assert C.sizeof(_lib.StreamConfig) == 4 * (2 + 8 + 8 + 4)
-    assert C.sizeof(_lib.Config) == 4 + 8 * C.sizeof(_lib.StreamConfig) + 4 * 6 + 4 * 8
+def test_struct_sizes_match_header(lib):
+    # adn_stream_config: 2 + 8 + 8 + 4 (use_delta, bidirectional, peepholes, dropout_p) + 2 (batchnorm, aux_dim) 4-byte fields
+    assert C.sizeof(_lib.StreamConfig) == 4 * (2 + 8 + 8 + 4 + 2)
+    assert C.sizeof(_lib.Config) == 4 + 8 * C.sizeof(_lib.StreamConfig) + 4 * 14
     assert C.sizeof(_lib.ParamInfo) == 96 + 4 + 4 + 16 + 8      # name, ndim, pad, dims, numel
+    out = (C.c_int32 * 4)()
+    lib.adn_abi_sizes(out)                                       # ... and what the compiled library itself says
+    assert list(out) == [C.sizeof(_lib.StreamConfig), C.sizeof(_lib.Config), C.sizeof(_lib.ParamInfo), C.sizeof(_lib.ProfileEntry)]
 
 
 def test_version_and_error_strings(lib):

@@ -297,3 +297,53 @@ def test_update_rules_follow_the_lasagne_formulas():
     p = {"w": np.array([1.0])}
     O.sgd_step(p, g, 0.1)
     assert np.isclose(p["w"][0], 0.95)
+
+
+def test_batchnorm_auxiliary_input_and_two_lstm_widths_by_finite_differences():
+    """adenet_v1-shaped graph in float64 (modelzoo/adenet_v1.py:48-109): BatchNormLayer behind the encoder, DCT input
+    concatenated after the delta layer, stream BLSTM of lstm_size units under an aggregation BLSTM of 2 * lstm_size.
+    Every analytic gradient against central differences, in the training mode (batch statistics: the mean / variance
+    terms of the BatchNorm adjoint) and in the deterministic mode (running averages); running-average update rule."""
+    spec = O.spec_adenet_v1(9, 5, enc_shapes=(7, 4), enc_acts=("sigmoid", "linear"), lstm_size=3, classes=4)
+    shapes = O.param_shapes(spec)
+    assert shapes["f_lstm1.W_hid_to_cell"] == (3, 3) and shapes["f_lstm2.W_in_to_ingate"] == (3, 6)
+    assert shapes["f_lstm1.W_in_to_ingate"] == (3 * 4 + 5, 3) and shapes["batchnorm1.gamma"] == (4,)
+    names = O.param_names(spec)
+    i = names.index(spec["streams"][0]["enc_names"][-1] + ".b")
+    assert names[i + 1:i + 5] == ["batchnorm1.beta", "batchnorm1.gamma", "batchnorm1.mean", "batchnorm1.inv_std"]
+    assert names[i + 5] == "f_lstm1.W_in_to_ingate" and "f_lstm1.W_cell_to_ingate" in names
+    rng = np.random.default_rng(5)
+    p = O.init_params(spec, rng, np.float64, enc_std=0.4, perturb=0.2)
+    p["batchnorm1.inv_std"] = np.abs(p["batchnorm1.inv_std"]) + 0.5
+    B, T, theta = 4, 6, 2
+    mask = np.ones((B, T), np.uint8); mask[1, 4:] = 0; mask[3, 2:] = 0
+    inputs = [rng.normal(size=(B, T, 9)) * mask[..., None], rng.normal(size=(B, T, 5)) * mask[..., None]]
+    y = np.repeat(rng.integers(0, 4, size=(B, 1)), T, axis=1)
+    for training in (True, False):
+        loss, g, cache = O.loss_and_grads(spec, p, inputs, y, mask, theta, training=training)
+        for k in names:
+            if k.endswith((".mean", ".inv_std")):
+                assert not g[k].any()                          # not trainable (in deterministic mode they ARE inputs of the
+                continue                                       # graph, but the reference never differentiates them)
+            for _ in range(2):
+                idx = tuple(rng.integers(0, n) for n in p[k].shape)
+                q = {a: b.copy() for a, b in p.items()}
+                q[k][idx] += 1e-6
+                lp = O.loss_and_grads(spec, q, inputs, y, mask, theta, training=training)[0]
+                q[k][idx] -= 2e-6
+                lm = O.loss_and_grads(spec, q, inputs, y, mask, theta, training=training)[0]
+                fd = (lp - lm) / 2e-6
+                assert abs(fd - g[k][idx]) <= 1e-6 + 2e-5 * abs(fd), (training, k, idx, fd, g[k][idx])
+    loss, g, cache = O.loss_and_grads(spec, p, inputs, y, mask, theta, training=True)
+    bn = cache["streams"][0]["bn"]
+    assert np.allclose(bn["xhat"].mean(0), 0, atol=1e-12) and np.allclose((bn["xhat"] ** 2).mean(0), 1, atol=1e-2)     # (eps = 1e-4 under the root)
+    old_mean, old_inv = p["batchnorm1.mean"].copy(), p["batchnorm1.inv_std"].copy()
+    O.bn_running_update(spec, p, cache)
+    assert np.allclose(p["batchnorm1.mean"], 0.9 * old_mean + 0.1 * bn["mean"])
+    assert np.allclose(p["batchnorm1.inv_std"], 0.9 * old_inv + 0.1 * bn["inv_std"])
+    # torch's batch_norm as an independent implementation of the training-mode forward
+    import torch
+    a = torch.tensor(bn["x"])
+    ref = torch.nn.functional.batch_norm(a, None, None, torch.tensor(p["batchnorm1.gamma"]), torch.tensor(p["batchnorm1.beta"]),
+                                         training=True, eps=O.BN_EPS).numpy()
+    assert np.allclose(bn["xhat"] * p["batchnorm1.gamma"] + p["batchnorm1.beta"], ref, atol=1e-10)

@@ -84,3 +84,19 @@ def test_explicit_peepholes_false_is_still_honoured(spec_only):
     res = adenet_v2.create_model(ae, (None, None, 30), None, (None, None), None, (None, None, 9), None, 4, None, 3)
     spec = res[0] if isinstance(res, tuple) else res
     assert not any("W_cell_to" in n for n in F.param_names(spec))
+
+
+def test_adenet_v1_and_v1_1_parameter_lists(spec_only):
+    """modelzoo/adenet_v1.py:48-109: fc1 .. bottleneck, batchnorm1 (beta, gamma, mean, inv_std), the two BLSTMs with
+    Lasagne's default peepholes, 'output'.  v1: lstm_size units under 2 * lstm_size; v1_1: both 2 * lstm_size, dropout."""
+    from ip_avsr_amd.modelzoo import adenet_v1, adenet_v1_1
+    args = lambda: (_Net(30), (None, None, 30), None, (None, None), None, (None, None, 9), None)
+    spec, _ = adenet_v1.create_model(*args(), lstm_size=4, output_classes=3)
+    enc_names = [n + k for n in ("fc1", "fc2", "fc3", "bottleneck") for k in (".W", ".b")]
+    want = (enc_names + ["batchnorm1.beta", "batchnorm1.gamma", "batchnorm1.mean", "batchnorm1.inv_std"] +
+            lstm("f_lstm1") + lstm("b_lstm1") + lstm("f_lstm2") + lstm("b_lstm2") + ["output.W", "output.b"])
+    assert F.param_names(spec) == want
+    assert spec["lstm_size"] == 8 and spec["stream_lstm_size"] == 4 and spec["streams"][0]["aux_dim"] == 9
+    spec11 = adenet_v1_1.create_model(*args(), lstm_size=4, output_classes=3)
+    assert F.param_names(spec11) == want and spec11["stream_lstm_size"] == 8
+    assert spec11["streams"][0]["dropout"] == 0.5 and spec11["agg_dropout"] == 0.5
