@@ -559,8 +559,9 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams p)
 // LDS hazards are settled by counted waits and the barrier sequence alone (barrier #n is the same event for all 8
 // waves; waves 0-3 run L(s) between #2s and #2s+1, waves 4-7 between #2s+1 and #2s+2):
 //   RAW  stage s + 1 is first read after #2s+2.  Every wave waits for ITS pieces of stage s + 1 (s_waitcnt vmcnt(N),
-//        N = pieces of the younger stages it has issued) before it arrives at #2s+2: waves 0-3 at the end of C(s),
-//        waves 4-7 at the end of L(s).
+//        N = pieces of the younger stages it has issued) at the end of its L(s), i.e. before #2s+1 (waves 0-3) or
+//        #2s+2 (waves 4-7).  (One place for both halves on purpose: a wave-half test inside the K-loop is a long-lived
+//        boolean that hipcc kept in a VGPR, spilled, and reloaded behind s_waitcnt vmcnt(0) -- draining the ring.)
 //   WAR  stage s + 3 overwrites the slot of stage s - 1, whose last reads (waves 4-7, L(s-1)) are complete before
 //        #2s (s_waitcnt lgkmcnt(0) ends every L segment); the DMA is issued in L(s), after #2s.
 // vmcnt counts stores too and retires in order, so the epilogue's stores sit between the DMA groups of a wave's queue:
@@ -599,10 +600,17 @@ constexpr int kPpBK = 32, kPpNS = 4, kPpD = 3;
 // pending __builtin_amdgcn_global_load_lds with s_waitcnt vmcnt(0), which would drain the stages this kernel keeps in
 // flight; the waits are counted by hand instead.  M0 (the DMA destination base) is compiler-reserved, hence saved and
 // restored (cdna_hip_programming.md, LDS-DMA recipe).
-__device__ __forceinline__ void glds16(const __bf16* g, unsigned lds_dst) {
+__device__ __forceinline__ void glds16(const void* g, unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
+}
+// the same with the address split into a wave-uniform 64-bit base (SGPR pair) and a 32-bit per-lane byte offset: a K-step then
+// advances ONE scalar per operand instead of a 64-bit VGPR pointer per piece.  LDS destination = lds_dst + IMM.
+template <int IMM> __device__ __forceinline__ void glds16_s(unsigned off, const char* base, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %3, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(base), "s"(lds_dst), "n"(IMM) : "memory", "scc");
 }
 
 __device__ __forceinline__ int swz_g(int kr) { return (kr & 3) | (((kr >> 3) & 1) << 2); }
@@ -628,25 +636,27 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // optional accumulate), with wave-uniform branches: compile-time variants of this fully unrolled epilogue made the
 // kernel ~50 k instructions, the K-loop then straddled that block and the kernel ran instruction-fetch bound (SQ_WAIT_INST_ANY
 // 83 % of the wave cycles, 6.7x the L2 requests: 90 TFLOP/s instead of 700).
+// The final values of one float4 of the tile (bias, activation, act'(Y) mask, accumulate) and its fp32 store; the bf16 copy
+// is stored by the caller after the lane exchange (see the epilogue).  `ok`: this lane's row / columns are inside the matrix.
 template <bool SPLIT>
-__device__ __forceinline__ void pp_epi4(const GemmParams& p, const GemmGroup& gp, float* Cg, f32x4 a, const float4& bias4,
-                                        const bf16x4& y, int row, int col, float4& csum) {
+__device__ __forceinline__ float4 pp_epi4(const GemmParams& p, const GemmGroup& gp, float* Cg, f32x4 a, const float4& bias4,
+                                          const bf16x4& y, int row, int col, bool ok, float4& csum) {
     const size_t off = (size_t)row * p.ldc + col;
     float4 v = make_float4(a[0], a[1], a[2], a[3]);
-    if (SPLIT) { *reinterpret_cast<float4*>(Cg + off) = v; return; }
+    if (SPLIT) { if (ok) *reinterpret_cast<float4*>(Cg + off) = v; return v; }
     v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
     if (p.act == ADN_ACT_RECTIFY) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     if (gp.Y16) {                                                  // rectify'(Y) from the mask values fetched ahead of the block
         v.x = (float)y[0] > 0.f ? v.x : 0.f; v.y = (float)y[1] > 0.f ? v.y : 0.f;
         v.z = (float)y[2] > 0.f ? v.z : 0.f; v.w = (float)y[3] > 0.f ? v.w : 0.f;
     }
-    if (p.accumulate) {
+    if (p.accumulate && ok) {
         const float4 c = *reinterpret_cast<const float4*>(Cg + off);
         v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w;
     }
-    if (Cg) *reinterpret_cast<float4*>(Cg + off) = v;
-    if (gp.C16) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(gp.C16) + off) = cvt4(v);
-    csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w;
+    if (Cg && ok) *reinterpret_cast<float4*>(Cg + off) = v;
+    if (ok) { csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w; }
+    return v;
 }
 
 // optional phase timing (build with -DADN_GEMM_STAMPS; read with adn_debug_gemm_stamps): shader-clock cycles that wave 0
@@ -654,12 +664,15 @@ __device__ __forceinline__ void pp_epi4(const GemmParams& p, const GemmGroup& gp
 // [3] vmcnt wait, [4] barrier behind L, [5] MFMAs, [6] epilogue, [7] barrier behind C; slots 8.. the same for wave 4
 #ifdef ADN_GEMM_STAMPS
 __device__ unsigned long long g_gstamps[16];
-#define GSTAMP(k) do { if (stamping) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); \
-    atomicAdd(&g_gstamps[(k) + (late ? 8 : 0)], n_ - gl_); gl_ = __builtin_amdgcn_s_memtime(); } } while (0)
-#define GSTAMP_INIT const bool stamping = blockIdx.x == 3 && blockIdx.y == 0 && (tid == 0 || tid == 256); unsigned long long gl_ = __builtin_amdgcn_s_memtime();
+// wave-uniform accumulators (s_memtime is a scalar instruction: they live in SGPRs); written once at the end
+#define GSTAMP(k) do { if (stamping) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); gacc_[k] += n_ - gl_; gl_ = n_; } } while (0)
+#define GSTAMP_INIT const bool stamping = blockIdx.x == 3 && blockIdx.y == 0 && (wave == 0 || wave == 4); \
+    unsigned long long gacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long gl_ = __builtin_amdgcn_s_memtime();
+#define GSTAMP_FLUSH do { if (stamping && lane == 0) for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&g_gstamps[k_ + (late ? 8 : 0)], gacc_[k_]); } while (0)
 #else
 #define GSTAMP(k) do {} while (0)
 #define GSTAMP_INIT
+#define GSTAMP_FLUSH do {} while (0)
 #endif
 
 template <int BM, int BN, bool A_KC, bool SPLIT>
@@ -676,9 +689,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
     const int per_group = p.tiles_m * p.tiles_n;
     const int ntiles = per_group * p.ngroups;
     const int G = (int)gridDim.x;
-    // (Tried: K-slice = function of the workgroup's XCD, so that the workgroups of one XCD share one 32-row window of A and B
-    //  in its L2 -- 109.5 vs 110.5 us on the 2000 x 1000 x 20800 weight gradient: the L2 miss rate is not what bounds it.)
-    const int bid = (int)blockIdx.x, slice = (int)blockIdx.y;
+    // Split-K: which (tile, K-slice) this workgroup takes.  p.xcd_slices: the K-slice is a function of the workgroup's XCD
+    // (workgroups are dealt round-robin over the 8 XCDs in launch order, x fastest), so that the workgroups of one XCD run
+    // through the SAME K-slice in step and share one 32-row window of A and B in its L2.  Measured on the 2000 x 1000 x
+    // 20800 weight gradient (profiles/r02/pp_xcd_slices.txt): L2 hit rate 50 % -> 76 %, bytes fetched from beyond L2 333 MB
+    // -> 125 MB (= the operands once); the launch time does not change (not bound there), the HBM traffic does.
+    int bid = (int)blockIdx.x, slice = (int)blockIdx.y;
+    if (SPLIT && p.xcd_slices) {
+        const int S = (int)gridDim.y, lin = (int)blockIdx.y * G + (int)blockIdx.x, xcd = lin & 7, q = lin >> 3;
+        if (S >= 8) { const int m_ = S >> 3; slice = xcd * m_ + q % m_; bid = q / m_; }
+        else { const int d_ = 8 / S; slice = xcd % S; bid = q * d_ + xcd / S; }
+    }
     const int my_tiles = (ntiles - bid + G - 1) / G;
     const int kbeg = slice * p.k_chunk;
     const int kend = min(p.K, kbeg + p.k_chunk);
@@ -692,7 +713,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
     // ---- DMA side ------------------------------------------------------------------------------------
     // k-strided operand of width R: CPR = R / 8 chunks per k-row, one piece = 64 / CPR k-rows
     constexpr int A_CPR = BM / 8, B_CPR = BN / 8;
-    const __bf16* srcA[APW]; const __bf16* srcB[BPW];
+    // source of a piece = wave-uniform base (the operand at the first k of the stage being issued) + a per-lane byte offset
+    const char* baseA = nullptr; const char* baseB = nullptr;
+    unsigned offA[APW], offB[BPW];
     int a_aux[APW], b_row[BPW];      // A_KC: the lane's k offset inside a stage; k-strided: its k-row inside a stage
 #pragma unroll
     for (int t = 0; t < APW; ++t)
@@ -708,52 +731,62 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
         int grp, tm, tn;
         tile_of(ord, grp, tm, tn);
         const GemmGroup sg = pick_group(p, grp);
-        const __bf16* A16 = reinterpret_cast<const __bf16*>(sg.A16);
-        const __bf16* B16 = reinterpret_cast<const __bf16*>(sg.B16);
+        const char* A16 = reinterpret_cast<const char*>(sg.A16);
+        const char* B16 = reinterpret_cast<const char*>(sg.B16);
         const int m0 = tm * BM, n0 = tn * BN;
+        baseA = A_KC ? A16 + ((size_t)m0 * p.lda + kbeg) * 2 : A16 + (size_t)kbeg * p.lda * 2;
+        baseB = B16 + (size_t)kbeg * p.ldb * 2;
 #pragma unroll
         for (int t = 0; t < APW; ++t) {
             if (A_KC) {
-                const int row = 16 * (wave * APW + t) + (lane >> 2);
-                srcA[t] = A16 + (size_t)min(m0 + row, p.M - 1) * p.lda + kbeg + a_aux[t];
+                const int row = min(m0 + 16 * (wave * APW + t) + (lane >> 2), p.M - 1) - m0;
+                offA[t] = (unsigned)(row * p.lda + a_aux[t]) * 2u;
             } else {
                 int col = m0 + (((lane % A_CPR) ^ (swz_g(a_aux[t]) << 1)) * 8);
                 if (col + 8 > p.lda) col = 0;
-                srcA[t] = A16 + (size_t)(kbeg + a_aux[t]) * p.lda + col;
+                offA[t] = (unsigned)(a_aux[t] * p.lda + col) * 2u;
             }
         }
 #pragma unroll
         for (int t = 0; t < BPW; ++t) {
             int col = n0 + (((lane % B_CPR) ^ (swz_g(b_row[t]) << 1)) * 8);
             if (col + 8 > p.ldb) col = 0;
-            srcB[t] = B16 + (size_t)(kbeg + b_row[t]) * p.ldb + col;
+            offB[t] = (unsigned)(b_row[t] * p.ldb + col) * 2u;
         }
     };
-    const size_t a_step = A_KC ? (size_t)BK : (size_t)BK * p.lda;
-    const size_t b_step = (size_t)BK * p.ldb;
+    const size_t a_step = A_KC ? (size_t)BK * 2 : (size_t)BK * p.lda * 2;      // bytes per K-step
+    const size_t b_step = (size_t)BK * p.ldb * 2;
+    // LDS destination of this wave's first piece of a stage in ring slot 0
+    const unsigned dstA_w = __builtin_amdgcn_readfirstlane(lds_base + wave * APW * 1024);
+    const unsigned dstB_w = __builtin_amdgcn_readfirstlane(lds_base + NS * kAElems * 2 + wave * BPW * 1024);
     int is_k = 0, is_ord = 0, is_step = 0;                         // next stage to issue: K-step inside its tile, tile, global step
     auto issue_one = [&](auto tail_c) {
         constexpr bool tail = decltype(tail_c)::value;
-        const unsigned As = lds_base + (unsigned)((is_step & (NS - 1)) * kStageElems * 2);
-        const unsigned Bs = As + kAElems * 2;
+        const unsigned dA = dstA_w + (unsigned)((is_step & (NS - 1)) * kAElems * 2);
+        const unsigned dB = dstB_w + (unsigned)((is_step & (NS - 1)) * kBElems * 2);
         const int k0 = kbeg + is_k * BK;
 #pragma unroll
         for (int t = 0; t < APW; ++t) {
-            const __bf16* g = srcA[t];
-            if (tail) {
-                if (A_KC) { if (k0 + a_aux[t] >= kend) g -= (k0 + a_aux[t] - (kend - 8)); }
-                else if (k0 + a_aux[t] >= kend) g -= (size_t)(k0 + a_aux[t] - (kend - 1)) * p.lda;
+            if (tail) {                                            // k >= kend: re-read the last valid k (masked in registers)
+                const char* g = baseA + offA[t];
+                if (A_KC) { if (k0 + a_aux[t] >= kend) g -= (size_t)(k0 + a_aux[t] - (kend - 8)) * 2; }
+                else if (k0 + a_aux[t] >= kend) g -= (size_t)(k0 + a_aux[t] - (kend - 1)) * p.lda * 2;
+                glds16(g, __builtin_amdgcn_readfirstlane(dA + t * 1024));
+            } else {
+                glds16_s<0>(offA[t], baseA, __builtin_amdgcn_readfirstlane(dA + t * 1024));
             }
-            glds16(g, __builtin_amdgcn_readfirstlane(As + (wave * APW + t) * 1024));
-            srcA[t] += a_step;
         }
 #pragma unroll
         for (int t = 0; t < BPW; ++t) {
-            const __bf16* g = srcB[t];
-            if (tail && k0 + b_row[t] >= kend) g -= (size_t)(k0 + b_row[t] - (kend - 1)) * p.ldb;
-            glds16(g, __builtin_amdgcn_readfirstlane(Bs + (wave * BPW + t) * 1024));
-            srcB[t] += b_step;
+            if (tail) {
+                const char* g = baseB + offB[t];
+                if (k0 + b_row[t] >= kend) g -= (size_t)(k0 + b_row[t] - (kend - 1)) * p.ldb * 2;
+                glds16(g, __builtin_amdgcn_readfirstlane(dB + t * 1024));
+            } else {
+                glds16_s<0>(offB[t], baseB, __builtin_amdgcn_readfirstlane(dB + t * 1024));
+            }
         }
+        baseA += a_step; baseB += b_step;
     };
     auto issue_next = [&]() {
         if (has_tail && is_k == nk - 1) issue_one(std::true_type{});
@@ -765,18 +798,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
         }
     };
 
-    // ---- per-lane fragment addresses (bytes inside a stage) -------------------------------------------
+    // ---- per-lane fragment addresses (LDS byte addresses inside ring slot 0) ----------------------------
     const int q = (lane & 15) >> 2, pp = lane & 3, hi = lane >> 4;
     const int g_lane = q | ((hi & 1) << 2);                        // swz_g of every k-row this lane reads
-    int a_off[TM], b_off[TN];
+    unsigned a_off[TM], b_off[TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
-        if (A_KC) a_off[a] = (wm * WTM + a * 16 + (lane & 15)) * 64 + ((hi ^ swz_f(q)) << 4);
-        else a_off[a] = (hi * 8 + q) * (BM * 2) + ((((wm * WTM + a * 16) / 8 + (pp >> 1)) ^ (g_lane << 1)) << 4) + (pp & 1) * 8;
+        if (A_KC) a_off[a] = lds_base + (wm * WTM + a * 16 + (lane & 15)) * 64 + ((hi ^ swz_f(q)) << 4);
+        else a_off[a] = lds_base + (hi * 8 + q) * (BM * 2) + ((((wm * WTM + a * 16) / 8 + (pp >> 1)) ^ (g_lane << 1)) << 4) + (pp & 1) * 8;
     }
 #pragma unroll
-    for (int b = 0; b < TN; ++b)
-        b_off[b] = (hi * 8 + q) * (BN * 2) + ((((wn * WTN + b * 16) / 8 + (pp >> 1)) ^ (g_lane << 1)) << 4) + (pp & 1) * 8;
+    for (int b = 0; b < TN; ++b)         // (the B stages follow the NS A stages)
+        b_off[b] = lds_base + NS * kAElems * 2 + (hi * 8 + q) * (BN * 2) + ((((wn * WTN + b * 16) / 8 + (pp >> 1)) ^ (g_lane << 1)) << 4) + (pp & 1) * 8;
     // k >= K mask of an A fragment in the last stage: element j of this lane is k = 8 hi + j
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 amask;
@@ -813,27 +846,37 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
     int grp, tile_m, tile_n;
     tile_of(0, grp, tile_m, tile_n);
     GSTAMP_INIT
-    for (int s = 0; s < total; ++s) {
-        // ---------------- L(s): fragments of stage s -> registers, DMA for stage s + D
-        const char* As = reinterpret_cast<const char*>(smem + (s & (NS - 1)) * kStageElems);
-        const char* Bs = As + kAElems * 2;
-        bf16x8 fa[TM], fb[TN];
+    typedef __attribute__((address_space(3))) bf16x8 lds_bf16x8;
+    bf16x8 fa[TM], fb[TN];
+    // fragments of the stage in the ring slot at byte offsets (sa, sb) of the A / B regions -> registers
+    auto read_frags = [&](unsigned sa, unsigned sb) __attribute__((always_inline)) {
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
             if (A_KC) {
-                fa[a] = *reinterpret_cast<const bf16x8*>(As + a_off[a]);
+                fa[a] = *(lds_bf16x8*)(uintptr_t)(a_off[a] + sa);
             } else {
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(As + a_off[a]));
-                const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(As + a_off[a] + 4 * (BM * 2)));
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(a_off[a] + sa));
+                const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(a_off[a] + sa + 4 * (BM * 2)));
                 fa[a] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
             }
         }
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Bs + b_off[b]));
-            const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Bs + b_off[b] + 4 * (BN * 2)));
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(b_off[b] + sb));
+            const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(b_off[b] + sb + 4 * (BN * 2)));
             fb[b] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
         }
+    };
+    auto mfmas = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[b], fa[a], acc[a][b], 0, 0, 0);
+    };
+    for (int s = 0; s < total;) {
+        // ---------------- the general step.  L(s): fragments of stage s -> registers, DMA for stage s + D
+        read_frags((s & (NS - 1)) * (kAElems * 2), (s & (NS - 1)) * (kBElems * 2));
         GSTAMP(0);
         if (s + D < total) issue_next();
         GSTAMP(1);
@@ -844,23 +887,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
 #pragma unroll
             for (int a = 0; a < TM; ++a) fa[a] = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4, fa[a]) & amask);
         }
-        if (late) wait_next(s, kt == 0 && s > 0);
+        wait_next(s, kt == 0 && s > 0);
         GSTAMP(3);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         GSTAMP(4);
         // ---------------- C(s)
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[b], fa[a], acc[a][b], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        mfmas();
         GSTAMP(5);
-        if (!late) wait_next(s, kt == 0 && s > 0);
-        GSTAMP(3);
         if (__builtin_expect(kt == nk - 1, 0)) {
+            {
             // ---- epilogue of tile `ord`, straight from the (transposed) accumulators: lane = row (lane & 15),
             //      columns 4 hi .. 4 hi + 3 of every 16-column block
             const GemmGroup gp = pick_group(p, grp);
@@ -882,28 +918,51 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
                             yv[a][bb] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(gp.Y16) + (size_t)row * p.ldy + col);
                         }
                 }
+                // blocks b0, b0 + 1 together: after the lane exchange a lane holds EIGHT consecutive columns of one of them, so
+                // that the bf16 copy leaves in 16-byte stores covering 64 contiguous bytes of a row per instruction.  (With
+                // 8-byte stores = 32-byte row pieces the lean forward GEMMs wrote their output at 1.6 - 1.9 TB/s: 130 us of a
+                // 514 us launch; fp32 rows already go out in 64-byte pieces.)
+                const int b0 = half * TNH;
+                const int colA = col0 + b0 * 16, colB = colA + 16;
+                float4 biasA = make_float4(0.f, 0.f, 0.f, 0.f), biasB = biasA, csumA = biasA, csumB = biasA;
+                if (!SPLIT && gp.bias) {
+                    biasA = *reinterpret_cast<const float4*>(gp.bias + min(colA, p.N - 4));
+                    biasB = *reinterpret_cast<const float4*>(gp.bias + min(colB, p.N - 4));
+                }
+                const bool odd = hi & 1;
 #pragma clang loop unroll(full)
-                for (int bb = 0; bb < TNH; ++bb) {
-                    const int b = half * TNH + bb;
-                    const int col = col0 + b * 16;
-                    if (col >= p.N) continue;
-                    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), csum = bias4;
-                    if (!SPLIT && gp.bias) bias4 = *reinterpret_cast<const float4*>(gp.bias + col);
-#pragma clang loop unroll(full)
-                    for (int a = 0; a < TM; ++a) {
-                        const int row = row0 + a * 16;
-                        if (row < p.M) pp_epi4<SPLIT>(p, gp, Cg, acc[a][b], bias4, yv[a][bb], row, col, csum);
-                    }
-                    if (!SPLIT && gp.colsum) {                     // column sums over this wave's WTM rows
-#pragma unroll
-                        for (int o = 1; o < 16; o <<= 1) {
-                            csum.x += __shfl_xor(csum.x, o, 64); csum.y += __shfl_xor(csum.y, o, 64);
-                            csum.z += __shfl_xor(csum.z, o, 64); csum.w += __shfl_xor(csum.w, o, 64);
-                        }
-                        if ((lane & 15) == 0)
-                            *reinterpret_cast<float4*>(gp.colsum + (size_t)(tile_m * 4 + wm) * p.colsum_ld + col) = csum;
+                for (int a = 0; a < TM; ++a) {
+                    const int row = row0 + a * 16;
+                    const bool rok = row < p.M;
+                    const float4 vA = pp_epi4<SPLIT>(p, gp, Cg, acc[a][b0], biasA, yv[a][0], row, colA, rok && colA < p.N, csumA);
+                    const float4 vB = pp_epi4<SPLIT>(p, gp, Cg, acc[a][b0 + 1], biasB, yv[a][1], row, colB, rok && colB < p.N, csumB);
+                    if (!SPLIT && gp.C16) {
+                        const uint2 pA = __builtin_bit_cast(uint2, cvt4(vA)), pB = __builtin_bit_cast(uint2, cvt4(vB));
+                        const uint2 give = odd ? pA : pB;            // even hi keeps block A and takes the partner's half of it
+                        uint2 take;
+                        take.x = __shfl_xor(give.x, 16, 64); take.y = __shfl_xor(give.y, 16, 64);
+                        const uint4 out = odd ? make_uint4(take.x, take.y, pB.x, pB.y) : make_uint4(pA.x, pA.y, take.x, take.y);
+                        const int cs = odd ? colB - 4 : colA;        // first of the 8 columns this lane now holds
+                        __bf16* dst = reinterpret_cast<__bf16*>(gp.C16) + (size_t)row * p.ldc + cs;
+                        if (rok && cs + 8 <= p.N) *reinterpret_cast<uint4*>(dst) = out;
+                        else if (rok && cs + 4 <= p.N) *reinterpret_cast<uint2*>(dst) = make_uint2(out.x, out.y);
                     }
                 }
+                if (!SPLIT && gp.colsum) {                         // column sums over this wave's WTM rows
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) {
+                        csumA.x += __shfl_xor(csumA.x, o, 64); csumA.y += __shfl_xor(csumA.y, o, 64);
+                        csumA.z += __shfl_xor(csumA.z, o, 64); csumA.w += __shfl_xor(csumA.w, o, 64);
+                        csumB.x += __shfl_xor(csumB.x, o, 64); csumB.y += __shfl_xor(csumB.y, o, 64);
+                        csumB.z += __shfl_xor(csumB.z, o, 64); csumB.w += __shfl_xor(csumB.w, o, 64);
+                    }
+                    if ((lane & 15) == 0) {
+                        float* cs_row = gp.colsum + (size_t)(tile_m * 4 + wm) * p.colsum_ld;
+                        if (colA < p.N) *reinterpret_cast<float4*>(cs_row + colA) = csumA;
+                        if (colB < p.N) *reinterpret_cast<float4*>(cs_row + colB) = csumB;
+                    }
+                }
+            }
             }
 #pragma unroll
             for (int a = 0; a < TM; ++a)
@@ -919,7 +978,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         GSTAMP(7);
+        ++s;
     }
+    GSTAMP_FLUSH;
     if (!late) __builtin_amdgcn_s_barrier();                       // every wave executes the same number of barriers
 }
 

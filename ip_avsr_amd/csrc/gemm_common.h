@@ -32,6 +32,7 @@ struct GemmParams {
     int panel_n;        // tiles are enumerated panel-major: panels of `panel_n` tile columns, m outer / n inner inside
     // ping-pong kernel only
     int ngroups;
+    int xcd_slices;     // split-K: K-slice = function of the workgroup's XCD (see the kernel)
     float* partial;     // split-K partial slabs [group][split][M][ldc]
     GemmGroup grp[kMaxGemmGroups];
 };

@@ -193,7 +193,7 @@ static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used
         const GemmArgs& q = gs[k];
         if (!q.A16 || !q.B16 || ((uintptr_t)q.A16 % 16) || ((uintptr_t)q.B16 % 16)) return ADN_OK;
         if (!q.C && !q.C16) return ADN_OK;
-        if ((q.C && ((uintptr_t)q.C % 16)) || (q.C16 && ((uintptr_t)q.C16 % 8))) return ADN_OK;
+        if ((q.C && ((uintptr_t)q.C % 16)) || (q.C16 && (((uintptr_t)q.C16 % 16) || g.ldc % 8))) return ADN_OK;
         if ((q.Y && ((uintptr_t)q.Y % 16)) || (q.Y16 && ((uintptr_t)q.Y16 % 8)) || (q.bias && ((uintptr_t)q.bias % 16))) return ADN_OK;
         if (q.M != g.M || q.N != g.N || q.K != g.K || q.lda != g.lda || q.ldb != g.ldb || q.ldc != g.ldc || q.ldy != g.ldy ||
             q.layout != g.layout || q.act != g.act || q.act_grad != g.act_grad || q.accumulate != g.accumulate ||
@@ -208,9 +208,10 @@ static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used
     // ---- where it pays (profiles/r02/gemm_lab_pp.txt, MI355X, against the register-staged 128 x 128 kernel):
     //   * split-K weight gradients with outputs of >= 1.8 M elements (dW fc1 / fc2): 144 / 114 us against 171 / 137
     //     (692 - 750 TFLOP/s; partial slabs + reduce instead of 64 MB of float atomics)
-    //   * forward GEMMs of several input streams as ONE grouped launch, plain epilogue (bias / rectify, no act'(Y)
-    //     loads, no fused column sums): 120 against 137 us per stream for 20800 x 1000 x 2000 -- three streams fill
-    //     7.7 rounds of 256 CUs where one fills 1.3; a lone launch loses that to its last round
+    //   * forward GEMMs with a plain epilogue (bias / rectify, no act'(Y) loads, no fused column sums) whose tiles fill
+    //     >= 85 % of their rounds of 256 CUs -- in practice the input streams' encoder layers as ONE grouped launch:
+    //     114 against 134 us per stream for 20800 x 1000 x 2000 (three streams fill 3.8 rounds where one fills 1.3 and
+    //     loses the difference to its last round), 145 against 161 us for 20800 x 2000 x 1200
     //   * NOT the input-gradient GEMMs: the transposed-accumulator epilogue reads the act'(Y) mask in 32-byte
     //     row pieces (205 against 146 us), and not 128-wide tiles (445 TFLOP/s: B-fragment reads per flop double)
     struct Cand { int mode, bm, bn; double rate; };
@@ -234,7 +235,7 @@ static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used
         const double fill = ((double)g.M * g.N * n / cus) / best_cost;       // useful share of the tile-rounds
         const bool plain = !g.Y && !g.Y16 && !g.colsum;
         const bool wgrad = splits > 1 && (int64_t)g.M * g.N >= 1800000;
-        const bool fwd_group = splits == 1 && n >= 2 && plain && fill >= 0.85;
+        const bool fwd_group = splits == 1 && plain && fill >= 0.85;
         if (!wgrad && !fwd_group) return ADN_OK;
     }
     const Cand& cd = cands[best];
@@ -273,8 +274,11 @@ static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used
         p.panel_n = std::max(1, std::min((int)std::lround(std::sqrt((double)chunk)), p.tiles_n));
     }
     int gx = (int)std::min<int64_t>(tiles, cus / splits);
-    if (splits > 1) gx = (int)tiles;          // one (tile, slice) per workgroup
-    else if (gx >= 8) gx = gx / 8 * 8;      // a workgroup's tiles then stay on its own XCD's chunk of the tile list
+    if (splits > 1) {
+        gx = (int)tiles;                      // one (tile, slice) per workgroup
+        static const bool no_xcd = getenv("ADN_GEMM_NO_XCD_SLICES") != nullptr;
+        p.xcd_slices = !no_xcd && (splits % 8 == 0 || 8 % splits == 0) && ((int64_t)gx * splits) % 8 == 0;
+    } else if (gx >= 8) gx = gx / 8 * 8;      // a workgroup's tiles then stay on its own XCD's chunk of the tile list
     static const bool trace = getenv("ADN_GEMM_TRACE") != nullptr;
     if (trace)
         fprintf(stderr, "ADN_GEMM %s M=%d N=%d K=%d tile=%d tiles=%lld split=%d shadows=1 lean=%d acc=%d groups=%d\n",

@@ -1,5 +1,5 @@
 set -u
-ROOT=$(pwd); OUT=$ROOT/gpurun_out/r02b; mkdir -p $OUT
+ROOT=$(pwd); OUT=$ROOT/gpurun_out/r02c; mkdir -p $OUT
 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest.log
 tail -15 $OUT/pytest.log
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_bf16.json 2> $OUT/bench_bf16.err; tail -c 1500 $OUT/bench_bf16.json
