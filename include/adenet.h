@@ -50,7 +50,8 @@ typedef enum {
     ADN_ACT_TANH = 3,
     ADN_ACT_LEAKY_RECTIFY = 4,     /* slope 0.01 */
     ADN_ACT_VERY_LEAKY_RECTIFY = 5, /* slope 1/3  */
-    ADN_ACT_SCALED_TANH = 6         /* 2.4 tanh(0.5 x): ScaledTanh(0.5, 2.4) of modelzoo/avletters_convae.py:7-26 */
+    ADN_ACT_SCALED_TANH = 6,        /* 2.4 tanh(0.5 x): ScaledTanh(0.5, 2.4) of modelzoo/avletters_convae.py:7-26 */
+    ADN_ACT_SCALED_TANH_LECUN = 7   /* 1.7159 tanh(2/3 x): ScaledTanh(2./3, 1.7159) of modelzoo/avletters_convae_bndrop.py:8 */
 } adn_act;
 
 /* fusiontype of modelzoo/adenet_v2.py:68-75 and friends */
@@ -294,13 +295,26 @@ int adn_prep_lcn(const float* x, float* y, int n_images, int H, int W, const flo
  * tied-weight decoder (transposed dense layers, Deconv2DLayer on the encoder's filters, Upscale2DLayer); ScaledTanh
  * everywhere but the bottleneck / dense8; trained on the mean squared reconstruction error
  * (avletters/avletters_convae.py:254-262).  Images are rows of image_h*image_w floats; parameters are read / written
- * in Lasagne's layouts ((out, in, kh, kw) filters, (c*h*w, units) dense7) in get_all_params order. */
+ * in Lasagne's layouts ((out, in, kh, kw) filters, (c*h*w, units) dense7) in get_all_params order.
+ * `variant` selects the --model of avletters/avletters_convae.py:245-252:
+ *   ADN_CAE_BATCHNORM  modelzoo/avletters_convae_bn.py:33-74     BatchNormLayers behind both poolings, on the flattened
+ *                      conv output (per feature) and behind the dense layer; layer names conv2d4 / conv2d7 / dense10 ...
+ *   ADN_CAE_DROPOUT    modelzoo/avletters_convae_drop.py:33-75   DropoutLayers (0.2 on the input, 0.5 behind the poolings,
+ *                      the flatten and the dense layer); 125 / 300 / 400 filters; `dense` / `bottleneck` are the widths AS
+ *                      BUILT (the reference doubles options['DENSE'] / ['BOTTLENECK'] -- the caller does)
+ *   ADN_CAE_BNDROP     modelzoo/avletters_convae_bndrop.py:33-77 both; BatchNorm behind every convolution's nonlinearity
+ *                      (per channel) and the dense layer; ScaledTanh(2/3, 1.7159)
+ * BatchNorm / dropout follow the model's conventions: non-deterministic passes (adn_cae_compute_grads, adn_cae_loss with
+ * ADN_FLAG_STOCHASTIC) use batch statistics, update the running averages and draw masks; deterministic passes
+ * (adn_cae_forward, adn_cae_loss, adn_cae_compute_grads with ADN_FLAG_DETERMINISTIC) use the running averages, no masks. */
+typedef enum { ADN_CAE_NORMAL = 0, ADN_CAE_BATCHNORM = 1, ADN_CAE_DROPOUT = 2, ADN_CAE_BNDROP = 3 } adn_cae_variant;
 typedef struct {
     int32_t image_h, image_w;   /* 30 x 40 in the reference */
-    int32_t dense;              /* options['DENSE'] (500) */
-    int32_t bottleneck;         /* options['BOTTLENECK'] (50) */
+    int32_t dense;              /* width of the dense layer (options['DENSE'] = 500) */
+    int32_t bottleneck;         /* width of the code (options['BOTTLENECK'] = 50) */
     int32_t precision;          /* adn_precision of the GEMMs */
-    int32_t reserved[3];
+    int32_t variant;            /* adn_cae_variant */
+    int32_t reserved[2];
 } adn_cae_config;
 typedef struct adn_cae adn_cae;
 
@@ -321,6 +335,9 @@ int adn_cae_compute_grads(adn_cae* m, const float* x, const float* target, int B
 int adn_cae_apply_adadelta(adn_cae* m, float learning_rate, float rho, float epsilon);   /* lr 0.8 in the reference */
 int adn_cae_apply_adam(adn_cae* m, float learning_rate);
 int adn_cae_synchronize(adn_cae* m);
+/* masks of the DropoutLayers = hash(seed, counter, layer 0..4, element index in the layer's (B, C, H, W) tensor); the counter
+ * advances by one after every non-deterministic pass (same convention as adn_set_dropout_state) */
+int adn_cae_set_dropout_state(adn_cae* m, uint32_t seed, uint32_t counter);
 
 #ifdef __cplusplus
 }

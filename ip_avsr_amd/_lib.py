@@ -16,7 +16,7 @@ ADN_MAX_CLASSES = 64
 
 ADN_OK = 0
 ACT = {"linear": 0, "identity": 0, "rectify": 1, "sigmoid": 2, "tanh": 3, "leaky_rectify": 4,
-       "very_leaky_rectify": 5, "scaled_tanh": 6}
+       "very_leaky_rectify": 5, "scaled_tanh": 6, "scaled_tanh_lecun": 7}
 FUSION = {"none": 0, "sum": 1, "adasum": 2, "concat": 3}
 PRECISION = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 FLAG_DEVICE_INPUTS = 1
@@ -44,7 +44,7 @@ class Config(C.Structure):
 
 class CaeConfig(C.Structure):
     _fields_ = [("image_h", C.c_int32), ("image_w", C.c_int32), ("dense", C.c_int32), ("bottleneck", C.c_int32),
-                ("precision", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("precision", C.c_int32), ("variant", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class ParamInfo(C.Structure):
@@ -120,6 +120,7 @@ _SIGNATURES = {
     "adn_cae_apply_adadelta": (C.c_int, [_P, C.c_float, C.c_float, C.c_float]),
     "adn_cae_apply_adam": (C.c_int, [_P, C.c_float]),
     "adn_cae_synchronize": (C.c_int, [_P]),
+    "adn_cae_set_dropout_state": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "adn_prep_seq_deltas": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "adn_prep_diff_images": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P]),
     "adn_prep_mean_image_subtraction": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P]),

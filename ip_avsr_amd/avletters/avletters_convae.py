@@ -23,7 +23,7 @@ import time
 
 import numpy as np
 
-from ..modelzoo import avletters_convae
+from ..modelzoo import avletters_convae, avletters_convae_bn, avletters_convae_bndrop, avletters_convae_drop
 from ..utils.datagen import batch_iterator
 from ..utils.io import load_mat_file, save_model
 from ..utils.plotting_utils import plot_validation_cost
@@ -67,7 +67,7 @@ def parse_options(argv=None):
     parser.add_argument('--epochs', help='number of epochs to run')
     parser.add_argument('--bottleneck', help='bottleneck size')
     parser.add_argument('--dense', help='dense layer size')
-    parser.add_argument('--model', help='model to run [normal]  (the reference also has batchnorm / dropout / bn+dropout variants)')
+    parser.add_argument('--model', help='model to run: normal | batchnorm | dropout | bn+dropout')
     parser.add_argument('--data', default='data/allData_mouthROIs.mat', help='.mat with dataMatrix / videoLengthVec / iterVec')
     parser.add_argument('--epoch_size', help='minibatches per epoch (reference: 96)')
     parser.add_argument('--save_prefix', default='models/conv', help="writes <prefix>_encoder.dat and <prefix>_ae.dat")
@@ -90,7 +90,9 @@ def parse_options(argv=None):
     return options
 
 
-FACTORIES = {'normal': avletters_convae}
+# --model values of avletters/avletters_convae.py:245-252
+FACTORIES = {'normal': avletters_convae, 'batchnorm': avletters_convae_bn, 'dropout': avletters_convae_drop,
+             'bn+dropout': avletters_convae_bndrop}
 
 
 def main(argv=None, data=None):
@@ -124,12 +126,16 @@ def main(argv=None, data=None):
         raise ValueError('--model must be one of %s' % sorted(FACTORIES))
     network, encoder = FACTORIES[options['MODEL']].create_model((None, 1, h, w), options)
     print('AE Network architecture: {}'.format(options['MODEL']))
+    if options.get('SEED') is not None:
+        network.set_dropout_state(options['SEED'])
     lr, lr_decay = np.float32(0.8), np.float32(0.9)
 
     def train(bx, by):
         return network.train(bx.reshape((len(bx), -1)), by, learning_rate=float(lr), want_loss=False)
 
-    train_cost_fn = lambda bx, by: network.cost(bx.reshape((len(bx), -1)), by)      # (no stochastic layer in this model)
+    # get_output(network, deterministic=False) for the training cost, deterministic=True for evaluation and reconstruction
+    # (avletters/avletters_convae.py:254-268)
+    train_cost_fn = lambda bx, by: network.cost(bx.reshape((len(bx), -1)), by, deterministic=False)
     eval_cost_fn = lambda bx, by: network.cost(bx.reshape((len(bx), -1)), by)
     recon_fn = lambda bx: network.recon_fn(bx.reshape((len(bx), -1)))
 

@@ -12,22 +12,33 @@ import numpy as np
 from . import _lib
 
 PARAM, GRAD, STATE0, STATE1 = 0, 1, 2, 3
+# --model of avletters/avletters_convae.py:245-252 -> adn_cae_variant, filters per convolution, names of the three
+# convolutions in that model-zoo file
+VARIANTS = {"normal": (0, (100, 150, 200), ("conv2d1", "conv2d3", "conv2d5")),
+            "batchnorm": (1, (100, 150, 200), ("conv2d1", "conv2d4", "conv2d7")),
+            "dropout": (2, (125, 300, 400), ("conv2d1", "conv2d3", "conv2d5")),
+            "bn+dropout": (3, (100, 150, 200), ("conv2d1", "conv2d3", "conv2d5"))}
 
 
 class ConvAE(object):
-    def __init__(self, image_shape=(30, 40), dense=500, bottleneck=50, precision="f32"):
+    def __init__(self, image_shape=(30, 40), dense=500, bottleneck=50, precision="f32", variant="normal"):
+        """``dense`` / ``bottleneck``: the layer widths as built (modelzoo.avletters_convae_drop doubles the options)."""
         self._lib = _lib.load()
         cfg = _lib.CaeConfig()
         cfg.image_h, cfg.image_w = int(image_shape[0]), int(image_shape[1])
         cfg.dense, cfg.bottleneck = int(dense), int(bottleneck)
         cfg.precision = _lib.PRECISION[precision]
+        cfg.variant, (f1, f2, f3), (n1, n3, n5) = VARIANTS[variant]
+        self.variant = variant
+        self.stochastic = variant in ("dropout", "bn+dropout")
+        self.has_batchnorm = variant in ("batchnorm", "bn+dropout")
         self._handle = C.c_void_p()
         _lib.check(self._lib.adn_cae_create(C.byref(cfg), C.byref(self._handle)))
         self.image_shape = (cfg.image_h, cfg.image_w)
         self.D = cfg.image_h * cfg.image_w
         self.bottleneck = cfg.bottleneck
-        g = _geometry(self.image_shape)
-        shapes = {"conv2d1.W": (100, 1, 5, 5), "conv2d3.W": (150, 100, 5, 5), "conv2d5.W": (200, 150, 3, 3)}
+        g = _geometry(self.image_shape, f3)
+        shapes = {n1 + ".W": (f1, 1, 5, 5), n3 + ".W": (f2, f1, 5, 5), n5 + ".W": (f3, f2, 3, 3)}
         self.param_names, self.param_shapes = [], {}
         info = _lib.ParamInfo()
         for i in range(self._lib.adn_cae_num_params(self._handle)):
@@ -94,6 +105,8 @@ class ConvAE(object):
                 fan_in, fan_out = (shp[1] * shp[2] * shp[3], shp[0] * shp[2] * shp[3]) if len(shp) == 4 else shp
                 lim = np.sqrt(6.0 / (fan_in + fan_out))
                 self.set_param(n, rng.uniform(-lim, lim, shp))
+            elif n.endswith((".gamma", ".inv_std")):         # BatchNormLayer: beta 0, gamma 1, mean 0, inv_std 1
+                self.set_param(n, np.ones(shp))
             else:
                 self.set_param(n, np.zeros(shp))
 
@@ -147,15 +160,25 @@ class ConvAE(object):
                                              C.c_void_p(out.data_ptr())))
         return out
 
-    def cost(self, x, target=None):
-        """train_cost_fn / eval_cost_fn: mean squared reconstruction error."""
+    def cost(self, x, target=None, deterministic=True):
+        """eval_cost_fn (deterministic) / train_cost_fn (``deterministic=False``: dropout masks drawn, BatchNorm on batch
+        statistics incl. the running-average update, as get_output(network, deterministic=False) does): mean squared
+        reconstruction error."""
         xp, tp, B, flags, keep = self._prep(x, target)
+        if not deterministic:
+            flags |= _lib.FLAG_STOCHASTIC
         out = C.c_float()
         _lib.check(self._lib.adn_cae_loss(self._handle, xp, tp, B, flags, C.byref(out)))
         return np.float32(out.value)
 
-    def compute_grads(self, x, target=None, want_loss=True):
+    def set_dropout_state(self, seed, counter=0):
+        """Masks are a hash of (seed, counter, layer, element); the counter advances with every non-deterministic pass."""
+        _lib.check(self._lib.adn_cae_set_dropout_state(self._handle, int(seed) & 0xFFFFFFFF, int(counter) & 0xFFFFFFFF))
+
+    def compute_grads(self, x, target=None, want_loss=True, deterministic=False):
         xp, tp, B, flags, keep = self._prep(x, target)
+        if deterministic:
+            flags |= _lib.FLAG_DETERMINISTIC
         out = C.c_float()
         _lib.check(self._lib.adn_cae_compute_grads(self._handle, xp, tp, B, flags, C.byref(out) if want_loss else None))
         return np.float32(out.value) if want_loss else None
@@ -176,11 +199,11 @@ class ConvAE(object):
         _lib.check(self._lib.adn_cae_synchronize(self._handle))
 
 
-def _geometry(hw):
+def _geometry(hw, f3=200):
     h, w = hw
     c1 = (h - 4, w - 4)
     p2 = ((c1[0] - 2) // 2 + 1, (c1[1] - 2) // 2 + 1)
     c3 = (p2[0] - 4, p2[1] - 4)
     p4 = (c3[0] // 2 + 1, (c3[1] - 2) // 2 + 1)
     c5 = (p4[0] - 2, p4[1] - 2)
-    return 200 * c5[0] * c5[1]
+    return f3 * c5[0] * c5[1]

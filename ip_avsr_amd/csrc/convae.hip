@@ -1,5 +1,7 @@
-// Convolutional auto-encoder (reference modelzoo/avletters_convae.py:33-69 and its training step
-// avletters/avletters_convae.py:254-262): im2col + MFMA GEMM for every convolution and its adjoint.
+// Convolutional auto-encoder (reference modelzoo/avletters_convae.py:33-69, its BatchNorm / dropout
+// variants avletters_convae_{bn,drop,bndrop}.py and the training step avletters/avletters_convae.py:254-262): im2col + MFMA
+// GEMM for every convolution and its adjoint; BatchNorm through csrc/batchnorm.hip (NHWC: a channel is a column), dropout
+// masks from the model's counter-based hash.
 //
 //   (B,1,30,40) -> conv 5x5 (100) -> maxpool 2 -> conv 5x5 (150) -> maxpool 2 pad (1,0) -> conv 3x3 (200) -> 3000
 //               -> dense 500 -> bottleneck 50 (linear) -> dense8 (W_b^T) -> dense9 (W_7^T) -> (200,3,5)
@@ -26,10 +28,22 @@ using namespace adn;
 
 namespace {
 
-constexpr int kF1 = 100, kF2L = 150, kF3 = 200;     // filters per convolution (modelzoo/avletters_convae.py:34-36)
-// the GEMM loaders need row strides that are multiples of 4 floats: the 150-channel tensors carry 2 zero channels
-// (zero filters / zero bias give act(0) = 0, and nothing ever flows into or out of them)
-constexpr int kF2 = 152;
+// Filters per convolution: 100 / 150 / 200 (modelzoo/avletters_convae.py:34-36), 125 / 300 / 400 in the dropout variant
+// (avletters_convae_drop.py:36-38).  The GEMM loaders need row strides that are multiples of 4 floats (8 for the bf16
+// operands): channel counts that are not multiples of 4 are padded to the next multiple of 8 with zero channels (zero
+// filters / zero bias / zero BatchNorm beta and gamma give 0, and nothing ever flows into or out of them).
+int pad_channels(int f, bool first) { return (first && f % 4 == 0) ? f : (int)round_up(f, 8); }   // (the first layer's C_in is 1: f32 path)
+
+__device__ __forceinline__ float cae_act(int act, float v) {
+    if (act == ADN_ACT_SCALED_TANH) return 2.4f * tanhf(0.5f * v);
+    if (act == ADN_ACT_SCALED_TANH_LECUN) return 1.7159f * tanhf((2.f / 3.f) * v);
+    return v;
+}
+__device__ __forceinline__ bool cae_keep(uint32_t key, uint32_t idx, float p) {       // = elementwise.hip::dropout_keep
+    uint32_t x = idx * 0x9E3779B1u + key;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return (float)(x >> 8) * (1.0f / 16777216.0f) >= p;
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // kernels
@@ -71,8 +85,7 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ d
                 acc += dcols[(((size_t)b * OH + oy) * OW + ox) * ldc + (i * kw + j) * C + c];
             }
         }
-        if (act == ADN_ACT_SCALED_TANH) acc = 2.4f * tanhf(0.5f * acc);
-        out[e] = acc;
+        out[e] = cae_act(act, acc);
     }
 }
 
@@ -111,10 +124,7 @@ __global__ __launch_bounds__(256) void col2im4_kernel(const float4* __restrict__
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
         }
-        if (act == ADN_ACT_SCALED_TANH) {
-            acc.x = 2.4f * tanhf(0.5f * acc.x); acc.y = 2.4f * tanhf(0.5f * acc.y);
-            acc.z = 2.4f * tanhf(0.5f * acc.z); acc.w = 2.4f * tanhf(0.5f * acc.w);
-        }
+        acc.x = cae_act(act, acc.x); acc.y = cae_act(act, acc.y); acc.z = cae_act(act, acc.z); acc.w = cae_act(act, acc.w);
         out[e] = acc;
     }
 }
@@ -207,6 +217,21 @@ __global__ __launch_bounds__(256) void mse_grad_kernel(const float* __restrict__
 
 __global__ void scale_scalar_kernel(float* p, float s) { *p *= s; }
 
+// DropoutLayer (rescale) in place on an NHWC tensor [rows = B*HW][Cp] with C logical channels: the mask is indexed by the
+// element's position in the reference's (B, C, H, W) tensor (for the flattened tensor that IS the (c, h, w) feature index),
+// so that it does not depend on this file's layout; forward and backward apply the same kernel.
+__global__ __launch_bounds__(256) void cae_dropout_kernel(float* __restrict__ x, int64_t rows, int HW, int C, int Cp, float p,
+                                                          float scale, uint32_t key) {
+    const int64_t total = rows * Cp;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % Cp);
+        if (c >= C) continue;
+        const int64_t r = e / Cp;
+        const uint32_t idx = (uint32_t)(((r / HW) * C + c) * HW + r % HW);
+        x[e] = cae_keep(key, idx, p) ? x[e] * scale : 0.f;
+    }
+}
+
 int grid_of(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 16384)); }
 
 // one convolution (or the convolution a deconv layer is the adjoint of): input [B][H][W][C] padded by (ph, pw),
@@ -224,10 +249,25 @@ struct Tensor { std::string name; int ndim; int64_t dims[4]; size_t off; size_t 
 
 }  // namespace
 
+struct BnSlot {              // one BatchNormLayer: parameter offsets, width (physical / logical), what it normalises
+    bool on = false;
+    size_t beta = 0, gamma = 0, mean = 0, inv_std = 0;
+    int C = 0;
+    float *out = nullptr, *save_mean = nullptr, *save_inv = nullptr;
+    void* ws = nullptr;
+};
+
 struct adn_cae {
     adn_cae_config cfg;
     hipStream_t stream = nullptr;
     int H = 30, W = 40, D7 = 500, NB = 50, ldb = 52, precision = ADN_PRECISION_F32;
+    int variant = ADN_CAE_NORMAL, S = ADN_ACT_SCALED_TANH;
+    int F1 = 100, F2 = 152, F3 = 200, F1L = 100, F2L = 150, F3L = 200;       // physical (padded) and logical filter counts
+    int bn_mode = 0;                      // 0 none, 1 behind the poolings / flatten / dense, 2 behind the convolutions / dense
+    bool drop = false;
+    bool training = false;                // this pass: batch statistics + running-average update + dropout masks
+    uint32_t drop_seed = 0x5EED1234u, drop_counter = 0;
+    BnSlot bn[4];
     ConvGeom c1, c3, c5, d11, d13, d15;
     int p2h = 0, p2w = 0, p4h = 0, p4w = 0, flat = 0;
     std::vector<Tensor> params;
@@ -238,7 +278,9 @@ struct adn_cae {
     float *x0 = nullptr, *cols1 = nullptr, *a1 = nullptr, *p2 = nullptr, *cols3 = nullptr, *a3 = nullptr, *p4 = nullptr,
           *cols5 = nullptr, *a5 = nullptr, *a7 = nullptr, *code = nullptr, *a8 = nullptr, *a9 = nullptr, *a11 = nullptr,
           *u12 = nullptr, *a13 = nullptr, *u14 = nullptr, *a15 = nullptr, *target = nullptr, *scratch = nullptr,
-          *gA = nullptr, *gB = nullptr, *loss_dev = nullptr;
+          *gA = nullptr, *gB = nullptr, *loss_dev = nullptr, *f6d = nullptr, *a7d = nullptr;
+    // what each layer actually read in the last forward pass (the BatchNorm output where one sits in front of it)
+    const float *in3 = nullptr, *in5 = nullptr, *in7 = nullptr, *inb = nullptr;
     uint8_t *arg2 = nullptr, *arg4 = nullptr;
     // bf16 mode: bf16 copy of the parameters (same layout), of the deconv inputs, and a scratch for gradients
     char *p16 = nullptr, *a9_16 = nullptr, *u12_16 = nullptr, *t16 = nullptr;
@@ -281,19 +323,19 @@ size_t carve(adn_cae* m, char* base, int B) {
     const size_t N = B;
     m->x0 = c.take<float>(N * m->H * m->W);
     m->cols1 = c.take<float>(rows_of(m->c1, B) * m->c1.ldk);
-    m->a1 = c.take<float>(rows_of(m->c1, B) * kF1);
-    m->p2 = c.take<float>(N * m->p2h * m->p2w * kF1); m->arg2 = c.take<uint8_t>(N * m->p2h * m->p2w * kF1);
+    m->a1 = c.take<float>(rows_of(m->c1, B) * m->F1);
+    m->p2 = c.take<float>(N * m->p2h * m->p2w * m->F1); m->arg2 = c.take<uint8_t>(N * m->p2h * m->p2w * m->F1);
     m->cols3 = c.take<float>(rows_of(m->c3, B) * m->c3.ldk);
-    m->a3 = c.take<float>(rows_of(m->c3, B) * kF2);
-    m->p4 = c.take<float>(N * m->p4h * m->p4w * kF2); m->arg4 = c.take<uint8_t>(N * m->p4h * m->p4w * kF2);
+    m->a3 = c.take<float>(rows_of(m->c3, B) * m->F2);
+    m->p4 = c.take<float>(N * m->p4h * m->p4w * m->F2); m->arg4 = c.take<uint8_t>(N * m->p4h * m->p4w * m->F2);
     m->cols5 = c.take<float>(rows_of(m->c5, B) * m->c5.ldk);
     m->a5 = c.take<float>(N * m->flat);
     m->a7 = c.take<float>(N * m->D7); m->code = c.take<float>(N * m->ldb);
     m->a8 = c.take<float>(N * m->D7); m->a9 = c.take<float>(N * m->flat);
-    m->a11 = c.take<float>(N * m->d11.H * m->d11.W * kF2);
-    m->u12 = c.take<float>(N * 4 * m->d11.H * m->d11.W * kF2);
-    m->a13 = c.take<float>(N * m->d13.H * m->d13.W * kF1);
-    m->u14 = c.take<float>(N * 4 * m->d13.H * m->d13.W * kF1);
+    m->a11 = c.take<float>(N * m->d11.H * m->d11.W * m->F2);
+    m->u12 = c.take<float>(N * 4 * m->d11.H * m->d11.W * m->F2);
+    m->a13 = c.take<float>(N * m->d13.H * m->d13.W * m->F1);
+    m->u14 = c.take<float>(N * 4 * m->d13.H * m->d13.W * m->F1);
     m->a15 = c.take<float>(N * m->H * m->W);
     m->target = c.take<float>(N * m->H * m->W);
     size_t sc = 0, act = N * m->H * m->W;
@@ -305,8 +347,19 @@ size_t carve(adn_cae* m, char* base, int B) {
     m->gA = c.take<float>(act); m->gB = c.take<float>(act);
     m->loss_dev = c.take<float>(8);
     m->a9_16 = c.take<char>(N * m->flat * 2);
-    m->u12_16 = c.take<char>(N * 4 * m->d11.H * m->d11.W * kF2 * 2);
+    m->u12_16 = c.take<char>(N * 4 * m->d11.H * m->d11.W * m->F2 * 2);
     m->t16 = c.take<char>(act * 2);
+    if (m->drop && m->bn_mode == 0) { m->f6d = c.take<float>(N * m->flat); m->a7d = c.take<float>(N * m->D7); }   // dropped copies of a5 / a7
+    if (m->bn_mode) {                                 // BatchNorm outputs, batch statistics, workspaces
+        const size_t rows[4] = {m->bn_mode == 1 ? N * m->p2h * m->p2w : rows_of(m->c1, B), m->bn_mode == 1 ? N * m->p4h * m->p4w : rows_of(m->c3, B),
+                                m->bn_mode == 1 ? N : rows_of(m->c5, B), N};
+        for (int k = 0; k < 4; ++k) {
+            BnSlot& q = m->bn[k];
+            q.out = c.take<float>(rows[k] * q.C);
+            q.save_mean = c.take<float>(q.C); q.save_inv = c.take<float>(q.C);
+            q.ws = c.take<char>(batchnorm_ws_bytes(q.C));
+        }
+    }
     return c.cur;
 }
 
@@ -385,10 +438,10 @@ int col2im(adn_cae* m, const float* dcols, const ConvGeom& g, int B, float* out,
 int conv_fwd(adn_cae* m, const float* x, const ConvGeom& g, int B, float* cols, size_t W, size_t b, float* y) {
     if (fast16(m, g)) {                              // `cols` holds the bf16 patches matrix in this mode
         ADN_TRY(im2col16(m, x, g, B, cols));
-        return mm16(m, GEMM_NN, (int)rows_of(g, B), g.O, g.K, cols, g.ldk, W16(m, W), g.O, y, g.O, m->P(b), ADN_ACT_SCALED_TANH);
+        return mm16(m, GEMM_NN, (int)rows_of(g, B), g.O, g.K, cols, g.ldk, W16(m, W), g.O, y, g.O, m->P(b), m->S);
     }
     ADN_TRY(im2col(m, x, g, B, cols));
-    return mm(m, GEMM_NN, (int)rows_of(g, B), g.O, g.K, cols, g.ldk, m->P(W), g.O, y, g.O, m->P(b), ADN_ACT_SCALED_TANH);
+    return mm(m, GEMM_NN, (int)rows_of(g, B), g.O, g.K, cols, g.ldk, m->P(W), g.O, y, g.O, m->P(b), m->S);
 }
 
 // dy (already multiplied by act') -> dW, db, and (optionally) dx
@@ -420,10 +473,10 @@ int deconv_fwd(adn_cae* m, const float* x, void* x16, const ConvGeom& g, int B, 
         const int R = (int)rows_of(g, B);
         ADN_TRY(to_bf16(x, x16, (size_t)R * g.O, m->stream));
         ADN_TRY(mm16(m, GEMM_NT, R, g.K, g.O, x16, g.O, W16(m, W), g.O, m->scratch, g.ldk));
-        return col2im(m, m->scratch, g, B, z, m->P(b), ADN_ACT_SCALED_TANH);
+        return col2im(m, m->scratch, g, B, z, m->P(b), m->S);
     }
     ADN_TRY(mm(m, GEMM_NT, (int)rows_of(g, B), g.K, g.O, x, g.O, m->P(W), g.O, m->scratch, g.ldk));
-    return col2im(m, m->scratch, g, B, z, m->P(b), ADN_ACT_SCALED_TANH);
+    return col2im(m, m->scratch, g, B, z, m->P(b), m->S);
 }
 
 // dz (already multiplied by act') -> db, dW (tied), dx
@@ -470,27 +523,86 @@ int stage(adn_cae* m, const float* x, const float* target, int B, int flags) {
     return ADN_OK;
 }
 
+// DropoutLayer k (0..4) in place on [rows][Cp] (no-op in deterministic passes and in the variants without dropout)
+int dropout_inplace(adn_cae* m, int layer, float* x, int64_t rows, int HW, int C, int Cp) {
+    if (!m->drop || !m->training) return ADN_OK;
+    const float p = layer == 0 ? 0.2f : 0.5f;                    // avletters_convae_drop.py:46 (p=0.2), DropoutLayer's default
+    const uint32_t key = m->drop_seed ^ ((uint32_t)layer * 0x85EBCA77u) ^ (m->drop_counter * 0xC2B2AE3Du);
+    hipLaunchKernelGGL(cae_dropout_kernel, dim3(grid_of(rows * Cp)), dim3(256), 0, m->stream, x, rows, HW, C, Cp, p, 1.f / (1.f - p), key);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+// BatchNormLayer k on x [rows][C]: -> q.out (training: batch statistics kept for backward, running averages updated)
+int bn_fwd(adn_cae* m, int k, const float* x, int rows) {
+    BnSlot& q = m->bn[k];
+    if (m->training)
+        return batchnorm_forward_train(x, q.C, q.out, q.C, rows, q.C, m->P(q.gamma), m->P(q.beta), kBnEps, kBnAlpha, q.save_mean,
+                                       q.save_inv, m->P(q.mean), m->P(q.inv_std), q.ws, m->stream);
+    return batchnorm_forward_eval(x, q.C, q.out, q.C, rows, q.C, m->P(q.gamma), m->P(q.beta), m->P(q.mean), m->P(q.inv_std), m->stream);
+}
+// d(out) -> d(x) in place, dgamma / dbeta accumulated
+int bn_bwd(adn_cae* m, int k, const float* x, float* d, int rows) {
+    BnSlot& q = m->bn[k];
+    return batchnorm_backward(x, q.C, d, q.C, d, q.C, rows, q.C, m->P(q.gamma), m->training ? q.save_mean : m->P(q.mean),
+                              m->training ? q.save_inv : m->P(q.inv_std), m->training ? 1 : 0, m->G(q.gamma), m->G(q.beta), q.ws, m->stream);
+}
+
 int forward(adn_cae* m, int B, bool decode) {
-    const int S = ADN_ACT_SCALED_TANH;
+    const int S = m->S;
     if (m->precision == ADN_PRECISION_BF16 && m->p16_dirty) {
         if (!m->p16) ADN_HIP_CHECK(hipMalloc((void**)&m->p16, (size_t)round_up((int64_t)m->flat_floats, 8) * 2));
         ADN_TRY(to_bf16(m->buf[0], m->p16, (size_t)(m->flat_floats / 8 * 8), m->stream));
         m->p16_dirty = false;
     }
+    const int R1 = (int)rows_of(m->c1, B), R3 = (int)rows_of(m->c3, B), R5 = (int)rows_of(m->c5, B);
+    const int P2 = B * m->p2h * m->p2w, P4 = B * m->p4h * m->p4w;
+    // (a dropout layer works in place on the tensor the next layer reads: a BatchNorm output, a pooling output -- whose
+    //  backward needs only the argmax codes -- or the staged input)
+    ADN_TRY(dropout_inplace(m, 0, m->x0, (int64_t)B * m->H * m->W, m->H * m->W, 1, 1));
     ADN_TRY(conv_fwd(m, m->x0, m->c1, B, m->cols1, m->W1, m->b1, m->a1));
-    ADN_TRY(maxpool_fwd(m, m->a1, B, m->c1.OH, m->c1.OW, kF1, 0, m->p2h, m->p2w, m->p2, m->arg2));
-    ADN_TRY(conv_fwd(m, m->p2, m->c3, B, m->cols3, m->W3, m->b3, m->a3));
-    ADN_TRY(maxpool_fwd(m, m->a3, B, m->c3.OH, m->c3.OW, kF2, 1, m->p4h, m->p4w, m->p4, m->arg4));
-    ADN_TRY(conv_fwd(m, m->p4, m->c5, B, m->cols5, m->W5, m->b5, m->a5));
-    ADN_TRY(mm(m, GEMM_NN, B, m->D7, m->flat, m->a5, m->flat, m->P(m->W7), m->D7, m->a7, m->D7, m->P(m->b7), S));
-    ADN_TRY(mm(m, GEMM_NN, B, m->NB, m->D7, m->a7, m->D7, m->P(m->Wb), m->ldb, m->code, m->ldb, m->P(m->bb)));
+    const float* t = m->a1;
+    if (m->bn_mode == 2) { ADN_TRY(bn_fwd(m, 0, t, R1)); t = m->bn[0].out; }
+    ADN_TRY(maxpool_fwd(m, t, B, m->c1.OH, m->c1.OW, m->F1, 0, m->p2h, m->p2w, m->p2, m->arg2));
+    float* u = m->p2;
+    if (m->bn_mode == 1) { ADN_TRY(bn_fwd(m, 0, u, P2)); u = m->bn[0].out; }
+    ADN_TRY(dropout_inplace(m, 1, u, P2, m->p2h * m->p2w, m->F1L, m->F1));
+    m->in3 = u;
+    ADN_TRY(conv_fwd(m, u, m->c3, B, m->cols3, m->W3, m->b3, m->a3));
+    t = m->a3;
+    if (m->bn_mode == 2) { ADN_TRY(bn_fwd(m, 1, t, R3)); t = m->bn[1].out; }
+    ADN_TRY(maxpool_fwd(m, t, B, m->c3.OH, m->c3.OW, m->F2, 1, m->p4h, m->p4w, m->p4, m->arg4));
+    u = m->p4;
+    if (m->bn_mode == 1) { ADN_TRY(bn_fwd(m, 1, u, P4)); u = m->bn[1].out; }
+    ADN_TRY(dropout_inplace(m, 2, u, P4, m->p4h * m->p4w, m->F2L, m->F2));
+    m->in5 = u;
+    ADN_TRY(conv_fwd(m, u, m->c5, B, m->cols5, m->W5, m->b5, m->a5));
+    u = m->a5;
+    if (m->bn_mode == 2) { ADN_TRY(bn_fwd(m, 2, u, R5)); u = m->bn[2].out; }             // per channel
+    if (m->bn_mode == 1) { ADN_TRY(bn_fwd(m, 2, u, B)); u = m->bn[2].out; }              // per flattened feature
+    if (m->drop && m->training && u == m->a5) {       // (dropout3 must not overwrite a5: its nonlinearity's backward reads it)
+        ADN_HIP_CHECK(hipMemcpyAsync(m->f6d, m->a5, (size_t)B * m->flat * 4, hipMemcpyDeviceToDevice, m->stream));
+        u = m->f6d;
+    }
+    ADN_TRY(dropout_inplace(m, 3, u, (int64_t)B * m->c5.OH * m->c5.OW, m->c5.OH * m->c5.OW, m->F3L, m->F3));
+    m->in7 = u;
+    ADN_TRY(mm(m, GEMM_NN, B, m->D7, m->flat, u, m->flat, m->P(m->W7), m->D7, m->a7, m->D7, m->P(m->b7), S));
+    u = m->a7;
+    if (m->bn_mode) { ADN_TRY(bn_fwd(m, 3, u, B)); u = m->bn[3].out; }
+    if (m->drop && m->training && u == m->a7) {
+        ADN_HIP_CHECK(hipMemcpyAsync(m->a7d, m->a7, (size_t)B * m->D7 * 4, hipMemcpyDeviceToDevice, m->stream));
+        u = m->a7d;
+    }
+    ADN_TRY(dropout_inplace(m, 4, u, B, 1, m->D7, m->D7));
+    m->inb = u;
+    ADN_TRY(mm(m, GEMM_NN, B, m->NB, m->D7, u, m->D7, m->P(m->Wb), m->ldb, m->code, m->ldb, m->P(m->bb)));
     if (!decode) return ADN_OK;
     ADN_TRY(mm(m, GEMM_NT, B, m->D7, m->NB, m->code, m->ldb, m->P(m->Wb), m->ldb, m->a8, m->D7, m->P(m->b8)));
     ADN_TRY(mm(m, GEMM_NT, B, m->flat, m->D7, m->a8, m->D7, m->P(m->W7), m->D7, m->a9, m->flat, m->P(m->b9), S));
     ADN_TRY(deconv_fwd(m, m->a9, m->a9_16, m->d11, B, m->W5, m->b11, m->a11));
-    ADN_TRY(upscale_fwd(m, m->a11, B, m->d11.H, m->d11.W, kF2, m->u12));
+    ADN_TRY(upscale_fwd(m, m->a11, B, m->d11.H, m->d11.W, m->F2, m->u12));
     ADN_TRY(deconv_fwd(m, m->u12, m->u12_16, m->d13, B, m->W3, m->b13, m->a13));
-    ADN_TRY(upscale_fwd(m, m->a13, B, m->d13.H, m->d13.W, kF1, m->u14));
+    ADN_TRY(upscale_fwd(m, m->a13, B, m->d13.H, m->d13.W, m->F1, m->u14));
     return deconv_fwd(m, m->u14, nullptr, m->d15, B, m->W1, m->b15, m->a15);
 }
 
@@ -508,18 +620,21 @@ int mse(adn_cae* m, int B, bool want_grad) {
 }
 
 int backward(adn_cae* m, int B) {
-    const int S = ADN_ACT_SCALED_TANH;
+    const int S = m->S;
     hipStream_t s = m->stream;
     ADN_HIP_CHECK(hipMemsetAsync(m->buf[1], 0, m->flat_floats * sizeof(float), s));
     float *gA = m->gA, *gB = m->gB;
+    const int F1 = m->F1, F2 = m->F2;
+    const int R1 = (int)rows_of(m->c1, B), R3 = (int)rows_of(m->c3, B), R5 = (int)rows_of(m->c5, B);
+    const int P2 = B * m->p2h * m->p2w, P4 = B * m->p4h * m->p4w;
     // decoder
     ADN_TRY(act_backward(gA, 1, m->a15, 1, B * m->H * m->W, 1, S, s));
     ADN_TRY(deconv_bwd(m, m->d15, B, m->u14, nullptr, gA, m->W1, m->b15, gB));                    // gB = d u14
-    ADN_TRY(upscale_bwd(m, gB, B, m->d13.H, m->d13.W, kF1, gA));                          // gA = d a13
-    ADN_TRY(act_backward(gA, kF1, m->a13, kF1, B * m->d13.H * m->d13.W, kF1, S, s));
+    ADN_TRY(upscale_bwd(m, gB, B, m->d13.H, m->d13.W, F1, gA));                           // gA = d a13
+    ADN_TRY(act_backward(gA, F1, m->a13, F1, B * m->d13.H * m->d13.W, F1, S, s));
     ADN_TRY(deconv_bwd(m, m->d13, B, m->u12, m->u12_16, gA, m->W3, m->b13, gB));                    // gB = d u12
-    ADN_TRY(upscale_bwd(m, gB, B, m->d11.H, m->d11.W, kF2, gA));                          // gA = d a11
-    ADN_TRY(act_backward(gA, kF2, m->a11, kF2, B * m->d11.H * m->d11.W, kF2, S, s));
+    ADN_TRY(upscale_bwd(m, gB, B, m->d11.H, m->d11.W, F2, gA));                           // gA = d a11
+    ADN_TRY(act_backward(gA, F2, m->a11, F2, B * m->d11.H * m->d11.W, F2, S, s));
     ADN_TRY(deconv_bwd(m, m->d11, B, m->a9, m->a9_16, gA, m->W5, m->b11, gB));                     // gB = d a9 (as [B][flat])
     ADN_TRY(act_backward(gB, m->flat, m->a9, m->flat, B, m->flat, S, s));
     ADN_TRY(col_sum(gB, m->flat, B, m->flat, m->G(m->b9), 1, s));
@@ -528,21 +643,32 @@ int backward(adn_cae* m, int B) {
     ADN_TRY(col_sum(gA, m->D7, B, m->D7, m->G(m->b8), 1, s));
     ADN_TRY(mm(m, GEMM_TN, m->D7, m->NB, B, gA, m->D7, m->code, m->ldb, m->G(m->Wb), m->ldb, nullptr, ADN_ACT_LINEAR, 1));
     ADN_TRY(mm(m, GEMM_NN, B, m->NB, m->D7, gA, m->D7, m->P(m->Wb), m->ldb, gB, m->ldb));             // gB = d code
-    // encoder
+    // encoder: every optional layer is undone where the forward pass applied it (dropout: the same mask on the gradient)
     ADN_TRY(col_sum(gB, m->ldb, B, m->NB, m->G(m->bb), 1, s));
-    ADN_TRY(mm(m, GEMM_TN, m->D7, m->NB, B, m->a7, m->D7, gB, m->ldb, m->G(m->Wb), m->ldb, nullptr, ADN_ACT_LINEAR, 1));
-    ADN_TRY(mm(m, GEMM_NT, B, m->D7, m->NB, gB, m->ldb, m->P(m->Wb), m->ldb, gA, m->D7));             // gA = d a7
+    ADN_TRY(mm(m, GEMM_TN, m->D7, m->NB, B, m->inb, m->D7, gB, m->ldb, m->G(m->Wb), m->ldb, nullptr, ADN_ACT_LINEAR, 1));
+    ADN_TRY(mm(m, GEMM_NT, B, m->D7, m->NB, gB, m->ldb, m->P(m->Wb), m->ldb, gA, m->D7));             // gA = d (bottleneck input)
+    ADN_TRY(dropout_inplace(m, 4, gA, B, 1, m->D7, m->D7));
+    if (m->bn_mode) ADN_TRY(bn_bwd(m, 3, m->a7, gA, B));                                   // gA = d a7
     ADN_TRY(act_backward(gA, m->D7, m->a7, m->D7, B, m->D7, S, s));
     ADN_TRY(col_sum(gA, m->D7, B, m->D7, m->G(m->b7), 1, s));
-    ADN_TRY(mm(m, GEMM_TN, m->flat, m->D7, B, m->a5, m->flat, gA, m->D7, m->G(m->W7), m->D7, nullptr, ADN_ACT_LINEAR, 1));
-    ADN_TRY(mm(m, GEMM_NT, B, m->flat, m->D7, gA, m->D7, m->P(m->W7), m->D7, gB, m->flat));           // gB = d a5
+    ADN_TRY(mm(m, GEMM_TN, m->flat, m->D7, B, m->in7, m->flat, gA, m->D7, m->G(m->W7), m->D7, nullptr, ADN_ACT_LINEAR, 1));
+    ADN_TRY(mm(m, GEMM_NT, B, m->flat, m->D7, gA, m->D7, m->P(m->W7), m->D7, gB, m->flat));           // gB = d (dense input)
+    ADN_TRY(dropout_inplace(m, 3, gB, (int64_t)B * m->c5.OH * m->c5.OW, m->c5.OH * m->c5.OW, m->F3L, m->F3));
+    if (m->bn_mode == 1) ADN_TRY(bn_bwd(m, 2, m->a5, gB, B));
+    if (m->bn_mode == 2) ADN_TRY(bn_bwd(m, 2, m->a5, gB, R5));                             // gB = d a5
     ADN_TRY(act_backward(gB, m->flat, m->a5, m->flat, B, m->flat, S, s));
-    ADN_TRY(conv_bwd(m, m->c5, B, m->cols5, gB, m->W5, m->b5, gA));                       // gA = d p4
-    ADN_TRY(maxpool_bwd(m, gA, m->arg4, B, m->c3.OH, m->c3.OW, kF2, 1, m->p4h, m->p4w, gB));            // gB = d a3
-    ADN_TRY(act_backward(gB, kF2, m->a3, kF2, (int)rows_of(m->c3, B), kF2, S, s));
-    ADN_TRY(conv_bwd(m, m->c3, B, m->cols3, gB, m->W3, m->b3, gA));                       // gA = d p2
-    ADN_TRY(maxpool_bwd(m, gA, m->arg2, B, m->c1.OH, m->c1.OW, kF1, 0, m->p2h, m->p2w, gB));            // gB = d a1
-    ADN_TRY(act_backward(gB, kF1, m->a1, kF1, (int)rows_of(m->c1, B), kF1, S, s));
+    ADN_TRY(conv_bwd(m, m->c5, B, m->cols5, gB, m->W5, m->b5, gA));                       // gA = d (conv5 input)
+    ADN_TRY(dropout_inplace(m, 2, gA, P4, m->p4h * m->p4w, m->F2L, F2));
+    if (m->bn_mode == 1) ADN_TRY(bn_bwd(m, 1, m->p4, gA, P4));                             // gA = d p4
+    ADN_TRY(maxpool_bwd(m, gA, m->arg4, B, m->c3.OH, m->c3.OW, F2, 1, m->p4h, m->p4w, gB));           // gB = d (pool input)
+    if (m->bn_mode == 2) ADN_TRY(bn_bwd(m, 1, m->a3, gB, R3));                             // gB = d a3
+    ADN_TRY(act_backward(gB, F2, m->a3, F2, R3, F2, S, s));
+    ADN_TRY(conv_bwd(m, m->c3, B, m->cols3, gB, m->W3, m->b3, gA));                       // gA = d (conv3 input)
+    ADN_TRY(dropout_inplace(m, 1, gA, P2, m->p2h * m->p2w, m->F1L, F1));
+    if (m->bn_mode == 1) ADN_TRY(bn_bwd(m, 0, m->p2, gA, P2));                             // gA = d p2
+    ADN_TRY(maxpool_bwd(m, gA, m->arg2, B, m->c1.OH, m->c1.OW, F1, 0, m->p2h, m->p2w, gB));           // gB = d (pool input)
+    if (m->bn_mode == 2) ADN_TRY(bn_bwd(m, 0, m->a1, gB, R1));                             // gB = d a1
+    ADN_TRY(act_backward(gB, F1, m->a1, F1, R1, F1, S, s));
     ADN_TRY(conv_bwd(m, m->c1, B, m->cols1, gB, m->W1, m->b1, nullptr));
     m->grads_valid = true;
     return ADN_OK;
@@ -567,15 +693,15 @@ void to_internal(const adn_cae* m, const Tensor& t, const float* host, std::vect
             dev[((size_t)(i * kw + j) * t.Cp + c) * t.Op + o] = host[(((size_t)o * C + c) * kh + (kh - 1 - i)) * kw + (kw - 1 - j)];
     } else if (t.kind == 2) {                        // rows (c, h, w) -> rows (h, w, c)
         const int hh = m->c5.OH, ww = m->c5.OW, U = (int)t.dims[1];
-        for (int c = 0; c < kF3; ++c) for (int y = 0; y < hh; ++y) for (int x = 0; x < ww; ++x)
-            memcpy(&dev[((size_t)(y * ww + x) * kF3 + c) * U], &host[((size_t)(c * hh + y) * ww + x) * U], (size_t)U * 4);
+        for (int c = 0; c < m->F3; ++c) for (int y = 0; y < hh; ++y) for (int x = 0; x < ww; ++x)
+            memcpy(&dev[((size_t)(y * ww + x) * m->F3 + c) * U], &host[((size_t)(c * hh + y) * ww + x) * U], (size_t)U * 4);
     } else if (t.kind == 3) {                        // bottleneck W: rows padded to ldb
         const int U = (int)t.dims[1];
         for (int r = 0; r < (int)t.dims[0]; ++r) memcpy(&dev[(size_t)r * m->ldb], &host[(size_t)r * U], (size_t)U * 4);
     } else if (t.kind == 4) {                        // dense9.b: (c, h, w) -> (h, w, c)
         const int hh = m->c5.OH, ww = m->c5.OW;
-        for (int c = 0; c < kF3; ++c) for (int y = 0; y < hh; ++y) for (int x = 0; x < ww; ++x)
-            dev[(size_t)(y * ww + x) * kF3 + c] = host[(size_t)(c * hh + y) * ww + x];
+        for (int c = 0; c < m->F3; ++c) for (int y = 0; y < hh; ++y) for (int x = 0; x < ww; ++x)
+            dev[(size_t)(y * ww + x) * m->F3 + c] = host[(size_t)(c * hh + y) * ww + x];
     } else {
         memcpy(dev.data(), host, t.floats * 4);
     }
@@ -588,23 +714,41 @@ void to_host(const adn_cae* m, const Tensor& t, const std::vector<float>& dev, f
             host[(((size_t)o * C + c) * kh + (kh - 1 - i)) * kw + (kw - 1 - j)] = dev[((size_t)(i * kw + j) * t.Cp + c) * t.Op + o];
     } else if (t.kind == 2) {
         const int hh = m->c5.OH, ww = m->c5.OW, U = (int)t.dims[1];
-        for (int c = 0; c < kF3; ++c) for (int y = 0; y < hh; ++y) for (int x = 0; x < ww; ++x)
-            memcpy(&host[((size_t)(c * hh + y) * ww + x) * U], &dev[((size_t)(y * ww + x) * kF3 + c) * U], (size_t)U * 4);
+        for (int c = 0; c < m->F3; ++c) for (int y = 0; y < hh; ++y) for (int x = 0; x < ww; ++x)
+            memcpy(&host[((size_t)(c * hh + y) * ww + x) * U], &dev[((size_t)(y * ww + x) * m->F3 + c) * U], (size_t)U * 4);
     } else if (t.kind == 3) {
         const int U = (int)t.dims[1];
         for (int r = 0; r < (int)t.dims[0]; ++r) memcpy(&host[(size_t)r * U], &dev[(size_t)r * m->ldb], (size_t)U * 4);
     } else if (t.kind == 4) {
         const int hh = m->c5.OH, ww = m->c5.OW;
-        for (int c = 0; c < kF3; ++c) for (int y = 0; y < hh; ++y) for (int x = 0; x < ww; ++x)
-            host[(size_t)(c * hh + y) * ww + x] = dev[(size_t)(y * ww + x) * kF3 + c];
+        for (int c = 0; c < m->F3; ++c) for (int y = 0; y < hh; ++y) for (int x = 0; x < ww; ++x)
+            host[(size_t)(c * hh + y) * ww + x] = dev[(size_t)(y * ww + x) * m->F3 + c];
     } else {
         memcpy(host, dev.data(), t.floats * 4);
     }
 }
 
+// get_output(..., deterministic=...): training passes are adn_cae_compute_grads unless ADN_FLAG_DETERMINISTIC, and
+// adn_cae_loss / adn_cae_forward only with ADN_FLAG_STOCHASTIC (avletters/avletters_convae.py:254-268: train and
+// train_cost_fn are non-deterministic, eval_cost_fn and recon_fn deterministic)
+void begin_pass(adn_cae* m, int flags, bool training_default) {
+    m->training = (flags & ADN_FLAG_STOCHASTIC) ? true : (flags & ADN_FLAG_DETERMINISTIC) ? false : training_default;
+    if (m->training && m->bn_mode) m->p16_dirty = true;          // the running averages live in the parameter buffer
+}
+void end_pass(adn_cae* m) {
+    if (m->training && m->drop) m->drop_counter += 1;
+    m->training = false;
+}
+
 }  // namespace
 
 extern "C" {
+
+int adn_cae_set_dropout_state(adn_cae* m, uint32_t seed, uint32_t counter) {
+    ADN_CHECK(m, ADN_ERR_INVALID, "null model");
+    m->drop_seed = seed; m->drop_counter = counter;
+    return ADN_OK;
+}
 
 int adn_cae_create(const adn_cae_config* cfg, adn_cae** out) {
     ADN_CHECK(cfg && out, ADN_ERR_INVALID, "null argument");
@@ -614,31 +758,67 @@ int adn_cae_create(const adn_cae_config* cfg, adn_cae** out) {
     ADN_CHECK(cfg->precision == ADN_PRECISION_F32 || cfg->precision == ADN_PRECISION_BF16, ADN_ERR_INVALID, "unknown precision");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device visible"); return ADN_ERR_NO_DEVICE; }
+    ADN_CHECK(cfg->variant >= ADN_CAE_NORMAL && cfg->variant <= ADN_CAE_BNDROP, ADN_ERR_INVALID, "unknown conv auto-encoder variant");
     adn_cae* m = new adn_cae();
     m->cfg = *cfg; m->H = cfg->image_h; m->W = cfg->image_w; m->D7 = cfg->dense; m->NB = cfg->bottleneck;
     m->ldb = (int)round_up(m->NB, 4); m->precision = cfg->precision;
-    m->c1 = conv_geom(m->H, m->W, 1, 5, kF1);
+    m->variant = cfg->variant;
+    m->drop = m->variant == ADN_CAE_DROPOUT || m->variant == ADN_CAE_BNDROP;
+    m->bn_mode = m->variant == ADN_CAE_BATCHNORM ? 1 : m->variant == ADN_CAE_BNDROP ? 2 : 0;
+    m->S = m->variant == ADN_CAE_BNDROP ? ADN_ACT_SCALED_TANH_LECUN : ADN_ACT_SCALED_TANH;     // avletters_convae_bndrop.py:8
+    if (m->variant == ADN_CAE_DROPOUT) { m->F1L = 125; m->F2L = 300; m->F3L = 400; }           // avletters_convae_drop.py:36-38
+    m->F1 = pad_channels(m->F1L, true); m->F2 = pad_channels(m->F2L, false); m->F3 = pad_channels(m->F3L, false);
+    if (m->F3 != m->F3L || (m->bn_mode && m->D7 % 4)) {
+        delete m; set_error("layer widths: the last filter count and (with BatchNorm) the dense width must be multiples of 4");
+        return ADN_ERR_INVALID;
+    }
+    const int F1 = m->F1, F2 = m->F2, F3 = m->F3, F1L = m->F1L, F2L = m->F2L, F3L = m->F3L;
+    m->c1 = conv_geom(m->H, m->W, 1, 5, F1);
     m->p2h = (m->c1.OH - 2) / 2 + 1; m->p2w = (m->c1.OW - 2) / 2 + 1;
-    m->c3 = conv_geom(m->p2h, m->p2w, kF1, 5, kF2);
+    m->c3 = conv_geom(m->p2h, m->p2w, F1, 5, F2);
     m->p4h = (m->c3.OH + 2 - 2) / 2 + 1; m->p4w = (m->c3.OW - 2) / 2 + 1;
-    m->c5 = conv_geom(m->p4h, m->p4w, kF2, 3, kF3);
+    m->c5 = conv_geom(m->p4h, m->p4w, F2, 3, F3);
     if (m->c5.OH < 1 || m->c5.OW < 1) { delete m; set_error("image too small for the encoder"); return ADN_ERR_INVALID; }
-    m->flat = kF3 * m->c5.OH * m->c5.OW;
+    m->flat = F3 * m->c5.OH * m->c5.OW;
     // deconv layers = adjoints of convolutions on their OUTPUT images (Deconv2DLayer full padding = valid conv's adjoint)
-    m->d11 = conv_geom(m->c5.OH + 2, m->c5.OW + 2, kF2, 3, kF3);
-    m->d13 = conv_geom(2 * m->d11.H + 4, 2 * m->d11.W + 4, kF1, 5, kF2);
-    m->d15 = conv_geom(2 * m->d13.H + 4 - 2, 2 * m->d13.W + 4, 1, 5, kF1, 1, 0);
+    m->d11 = conv_geom(m->c5.OH + 2, m->c5.OW + 2, F2, 3, F3);
+    m->d13 = conv_geom(2 * m->d11.H + 4, 2 * m->d11.W + 4, F1, 5, F2);
+    m->d15 = conv_geom(2 * m->d13.H + 4 - 2, 2 * m->d13.W + 4, 1, 5, F1, 1, 0);
     if (m->d15.H != m->H || m->d15.W != m->W) {
         delete m; set_error("the decoder does not reproduce this image size (use e.g. 30 x 40)"); return ADN_ERR_INVALID;
     }
-    m->W1 = add_tensor(m, "conv2d1.W", 1, {kF1, 1, 5, 5}, kF1, 1); m->b1 = add_tensor(m, "conv2d1.b", 0, {kF1});
-    m->W3 = add_tensor(m, "conv2d3.W", 1, {kF2L, kF1, 5, 5}, kF2, kF1); m->b3 = add_tensor(m, "conv2d3.b", 0, {kF2L}, kF2);
-    m->W5 = add_tensor(m, "conv2d5.W", 1, {kF3, kF2L, 3, 3}, kF3, kF2); m->b5 = add_tensor(m, "conv2d5.b", 0, {kF3});
-    m->W7 = add_tensor(m, "dense7.W", 2, {m->flat, m->D7}); m->b7 = add_tensor(m, "dense7.b", 0, {m->D7});
+    // layer names of the variant's model-zoo file (the BatchNorm file numbers its layers differently); parameters in
+    // lasagne.layers.get_all_params order
+    const bool bnfile = m->variant == ADN_CAE_BATCHNORM;
+    const char* n_c1 = "conv2d1"; const char* n_c3 = bnfile ? "conv2d4" : "conv2d3"; const char* n_c5 = bnfile ? "conv2d7" : "conv2d5";
+    const char* n_d7 = bnfile ? "dense10" : "dense7"; const char* n_d8 = bnfile ? "dense12" : "dense8"; const char* n_d9 = bnfile ? "dense13" : "dense9";
+    const char* n_dc11 = bnfile ? "deconv2d19" : "deconv2d11"; const char* n_dc13 = bnfile ? "deconv2d17" : "deconv2d13";
+    const char* bn_names[4] = {bnfile ? "batchnorm2" : "batchnorm1", bnfile ? "batchnorm3" : "batchnorm2",
+                               bnfile ? "batchnorm8" : "batchnorm3", bnfile ? "batchnorm11" : "batchnorm4"};
+    auto nm = [](const char* layer, const char* p) { return std::string(layer) + "." + p; };
+    auto add_bn = [&](int k, int logical, int physical, bool flat_order) {
+        if (!m->bn_mode) return;
+        BnSlot& q = m->bn[k];
+        q.on = true; q.C = physical;
+        const int kind = flat_order ? 4 : 0;
+        q.beta = add_tensor(m, nm(bn_names[k], "beta").c_str(), kind, {logical}, physical);
+        q.gamma = add_tensor(m, nm(bn_names[k], "gamma").c_str(), kind, {logical}, physical);
+        q.mean = add_tensor(m, nm(bn_names[k], "mean").c_str(), kind, {logical}, physical);
+        q.inv_std = add_tensor(m, nm(bn_names[k], "inv_std").c_str(), kind, {logical}, physical);
+    };
+    m->W1 = add_tensor(m, nm(n_c1, "W").c_str(), 1, {F1L, 1, 5, 5}, F1, 1); m->b1 = add_tensor(m, nm(n_c1, "b").c_str(), 0, {F1L}, F1);
+    add_bn(0, F1L, F1, false);
+    m->W3 = add_tensor(m, nm(n_c3, "W").c_str(), 1, {F2L, F1L, 5, 5}, F2, F1); m->b3 = add_tensor(m, nm(n_c3, "b").c_str(), 0, {F2L}, F2);
+    add_bn(1, F2L, F2, false);
+    m->W5 = add_tensor(m, nm(n_c5, "W").c_str(), 1, {F3L, F2L, 3, 3}, F3, F2); m->b5 = add_tensor(m, nm(n_c5, "b").c_str(), 0, {F3L}, F3);
+    if (m->bn_mode == 1) add_bn(2, m->flat, m->flat, true);      // per flattened feature, (c, h, w) order on the host
+    else add_bn(2, F3L, F3, false);                              // per channel
+    m->W7 = add_tensor(m, nm(n_d7, "W").c_str(), 2, {m->flat, m->D7}); m->b7 = add_tensor(m, nm(n_d7, "b").c_str(), 0, {m->D7});
+    add_bn(3, m->D7, m->D7, false);
     m->Wb = add_tensor(m, "bottleneck.W", 3, {m->D7, m->NB});
     m->bb = add_tensor(m, "bottleneck.b", 0, {m->NB});
-    m->b8 = add_tensor(m, "dense8.b", 0, {m->D7}); m->b9 = add_tensor(m, "dense9.b", 4, {m->flat});
-    m->b11 = add_tensor(m, "deconv2d11.b", 0, {kF2L}, kF2); m->b13 = add_tensor(m, "deconv2d13.b", 0, {kF1});
+    m->b8 = add_tensor(m, nm(n_d8, "b").c_str(), 0, {m->D7}); m->b9 = add_tensor(m, nm(n_d9, "b").c_str(), 4, {m->flat});
+    m->b11 = add_tensor(m, nm(n_dc11, "b").c_str(), 0, {F2L}, F2); m->b13 = add_tensor(m, nm(n_dc13, "b").c_str(), 0, {F1L}, F1);
     m->b15 = add_tensor(m, "deconv2d14.b", 0, {1});
     for (int k = 0; k < 4; ++k) {
         if (hipMalloc((void**)&m->buf[k], m->flat_floats * sizeof(float)) != hipSuccess ||
@@ -716,7 +896,9 @@ int adn_cae_forward(adn_cae* m, const float* x, int B, int flags, float* recon, 
     ADN_CHECK(B >= 1 && B <= (1 << 16), ADN_ERR_INVALID, "batch size out of range");
     ADN_TRY(ensure_ws(m, B));
     ADN_TRY(stage(m, x, nullptr, B, flags));
+    begin_pass(m, flags, false);
     ADN_TRY(forward(m, B, recon != nullptr));
+    end_pass(m);
     if (code) {
         if (flags & ADN_FLAG_DEVICE_OUTPUTS) {
             ADN_HIP_CHECK(hipMemcpy2DAsync(code, (size_t)m->NB * 4, m->code, (size_t)m->ldb * 4, (size_t)m->NB * 4, B,
@@ -736,7 +918,9 @@ int adn_cae_loss(adn_cae* m, const float* x, const float* target, int B, int fla
     ADN_CHECK(B >= 1 && B <= (1 << 16), ADN_ERR_INVALID, "batch size out of range");
     ADN_TRY(ensure_ws(m, B));
     ADN_TRY(stage(m, x, target ? target : x, B, flags));
+    begin_pass(m, flags, false);
     ADN_TRY(forward(m, B, true));
+    end_pass(m);
     ADN_TRY(mse(m, B, false));
     return fetch(m, loss, m->loss_dev, sizeof(float), flags);
 }
@@ -746,9 +930,11 @@ int adn_cae_compute_grads(adn_cae* m, const float* x, const float* target, int B
     ADN_CHECK(B >= 1 && B <= (1 << 16), ADN_ERR_INVALID, "batch size out of range");
     ADN_TRY(ensure_ws(m, B));
     ADN_TRY(stage(m, x, target ? target : x, B, flags));
+    begin_pass(m, flags, true);
     ADN_TRY(forward(m, B, true));
     ADN_TRY(mse(m, B, true));
     ADN_TRY(backward(m, B));
+    end_pass(m);
     if (loss) return fetch(m, loss, m->loss_dev, sizeof(float), flags);
     return ADN_OK;
 }

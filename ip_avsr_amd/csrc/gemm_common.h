@@ -45,6 +45,7 @@ __device__ __forceinline__ float act_apply(int act, float v) {
         case ADN_ACT_LEAKY_RECTIFY: return v > 0.f ? v : 0.01f * v;
         case ADN_ACT_VERY_LEAKY_RECTIFY: return v > 0.f ? v : (1.f / 3.f) * v;
         case ADN_ACT_SCALED_TANH: return 2.4f * tanhf(0.5f * v);
+        case ADN_ACT_SCALED_TANH_LECUN: return 1.7159f * tanhf((2.f / 3.f) * v);
         default: return v;
     }
 }
@@ -57,6 +58,7 @@ __device__ __forceinline__ float act_grad_from_output(int act, float y) {
         case ADN_ACT_LEAKY_RECTIFY: return y > 0.f ? 1.f : 0.01f;
         case ADN_ACT_VERY_LEAKY_RECTIFY: return y > 0.f ? 1.f : (1.f / 3.f);
         case ADN_ACT_SCALED_TANH: { const float t = y * (1.f / 2.4f); return 1.2f * (1.f - t * t); }
+        case ADN_ACT_SCALED_TANH_LECUN: { const float t = y * (1.f / 1.7159f); return (2.f / 3.f) * 1.7159f * (1.f - t * t); }
         default: return 1.f;
     }
 }

@@ -325,7 +325,7 @@ int validate(const adn_config& c) {
         ADN_CHECK(sc.n_enc >= 0 && sc.n_enc <= ADN_MAX_ENC_LAYERS, ADN_ERR_INVALID, "n_enc out of range");
         for (int l = 0; l < sc.n_enc; ++l) {
             ADN_CHECK(sc.enc_units[l] >= 1, ADN_ERR_INVALID, "encoder layer width must be positive");
-            ADN_CHECK(sc.enc_act[l] >= ADN_ACT_LINEAR && sc.enc_act[l] <= ADN_ACT_SCALED_TANH, ADN_ERR_INVALID,
+            ADN_CHECK(sc.enc_act[l] >= ADN_ACT_LINEAR && sc.enc_act[l] <= ADN_ACT_SCALED_TANH_LECUN, ADN_ERR_INVALID,
                       "unsupported encoder nonlinearity");
         }
         n_sub += sc.bidirectional ? 2 : 1;

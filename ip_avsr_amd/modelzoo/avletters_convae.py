@@ -14,8 +14,8 @@ class _Encoder(object):
         return self.ae.encode(x)
 
     def get_all_param_values(self):
-        names = ["conv2d1.W", "conv2d1.b", "conv2d3.W", "conv2d3.b", "conv2d5.W", "conv2d5.b", "dense7.W", "dense7.b",
-                 "bottleneck.W", "bottleneck.b"]
+        # get_all_param_values(bottleneck): every layer up to the bottleneck, BatchNorm parameters included
+        names = self.ae.param_names[:self.ae.param_names.index("bottleneck.b") + 1]
         return [self.ae.get_param(n) for n in names]
 
 

@@ -189,3 +189,83 @@ def test_conv_encoder_as_the_front_end_of_a_stream(ConvAE):
     with pytest.raises(ValueError):
         F.stream((None, None, 99), bottleneck)                                 # frame size mismatch
     model.close(); ref.close(); net.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BatchNorm / dropout variants (modelzoo/avletters_convae_{bn,drop,bndrop}.py)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant,hw,dense,nb,B", [("batchnorm", (30, 40), 500, 50, 6), ("batchnorm", (22, 28), 24, 8, 5),
+                                                   ("dropout", (30, 40), 1000, 100, 4), ("dropout", (22, 28), 24, 6, 3),
+                                                   ("bn+dropout", (30, 40), 500, 50, 6), ("bn+dropout", (26, 44), 40, 12, 4)])
+def test_variants_match_the_oracle(ConvAE, variant, hw, dense, nb, B):
+    """Deterministic passes (running averages, no masks) and non-deterministic ones (batch statistics + running-average
+    update, the oracle's own masks) against the fp64 oracle: reconstruction / code 1e-4, every gradient 1e-4 of scale."""
+    rng = np.random.default_rng(21)
+    p = CO.init_params(rng, np.float32, dense=dense, bottleneck=nb, image_hw=hw, bias_noise=0.05, variant=variant)
+    x = rng.normal(size=(B, hw[0] * hw[1])).astype(np.float32)
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    x64 = x.astype(np.float64)
+    m = ConvAE(hw, dense, nb, variant=variant)
+    assert m.param_names == CO.param_names(variant)
+    m.set_params_dict(p)
+    for k in p:
+        np.testing.assert_array_equal(m.get_param(k), p[k])
+    # deterministic: recon_fn / eval_cost_fn
+    recon_ref, code_ref = CO.forward(p64, x64, hw, variant=variant)
+    assert np.abs(m.recon_fn(x) - recon_ref).max() <= 1e-4
+    assert np.abs(m.encode(x) - code_ref).max() <= 1e-4
+    loss_ref, g_ref, _ = CO.loss_and_grads(p64, x64, image_hw=hw, variant=variant, training=False)
+    assert abs(m.cost(x) - loss_ref) <= 1e-5 * loss_ref
+    assert abs(m.compute_grads(x, deterministic=True) - loss_ref) <= 1e-5 * loss_ref
+    _check_grads(m, g_ref, variant)
+    for k in p:                                       # a deterministic pass leaves the running averages alone
+        np.testing.assert_array_equal(m.get_param(k), p[k])
+    # non-deterministic: train / train_cost_fn
+    drop = dict(seed=4242, counter=7)
+    m.set_dropout_state(drop["seed"], drop["counter"])
+    loss_ref, g_ref, c = CO.loss_and_grads(p64, x64, image_hw=hw, variant=variant, dropout=drop, training=True)
+    loss = m.compute_grads(x)
+    assert abs(loss - loss_ref) <= 2e-5 * loss_ref, (loss, loss_ref)
+    _check_grads(m, g_ref, variant)
+    CO.bn_running_update(p64, c, variant)             # ... and it moved the running averages like Lasagne's default updates
+    for k in p:
+        assert np.abs(m.get_param(k) - p64[k]).max() <= 1e-5 * max(1.0, np.abs(p64[k]).max()), k
+    if CO.VARIANTS[variant]["drop"]:                  # the counter advanced: the next stochastic cost draws other masks
+        l_next = m.cost(x, deterministic=False)
+        ref_next = CO.loss_and_grads(p64, x64, image_hw=hw, variant=variant, dropout=dict(seed=4242, counter=8), training=True)[0]
+        assert abs(l_next - ref_next) <= 2e-5 * ref_next and abs(l_next - loss) > 1e-6 * loss
+    m.close()
+
+
+def _check_grads(m, g_ref, variant):
+    g = m.get_grads_dict()
+    gscale = max(np.abs(v).max() for v in g_ref.values())
+    for k in CO.param_names(variant):
+        err = np.abs(g[k] - g_ref[k]).max()
+        assert err <= 1e-4 * max(np.abs(g_ref[k]).max(), 1e-3 * gscale) + 1e-10, (k, err, np.abs(g_ref[k]).max())
+
+
+def test_variant_zoo_factories_and_trainer(ConvAE, tmp_path):
+    from ip_avsr_amd.modelzoo import avletters_convae_bn, avletters_convae_bndrop, avletters_convae_drop
+    x = np.random.default_rng(0).normal(size=(4, 1200)).astype(np.float32)
+    opts = {"BOTTLENECK": 50, "DENSE": 500}
+    net, enc = avletters_convae_bn.create_model((None, 1, 30, 40), opts)
+    assert "batchnorm8.inv_std" in net.param_names and net.param_shapes["batchnorm8.mean"] == (3000,)
+    assert net.param_names[:6] == ["conv2d1.W", "conv2d1.b", "batchnorm2.beta", "batchnorm2.gamma", "batchnorm2.mean", "batchnorm2.inv_std"]
+    assert enc(x).shape == (4, 50) and len(enc.get_all_param_values()) == 10 + 16
+    net, enc = avletters_convae_drop.create_model((None, 1, 30, 40), opts)
+    assert net.param_shapes["conv2d3.W"] == (300, 125, 5, 5) and enc(x).shape == (4, 100)     # widths / keep probability
+    assert net.param_shapes["dense7.W"] == (400 * 3 * 5, 1000)
+    net, enc = avletters_convae_bndrop.create_model((None, 1, 30, 40), opts)
+    assert net.param_names[2] == "batchnorm1.beta" and net.recon_fn(x).shape == (4, 1200)
+    # the trainer with --model bn+dropout on a few synthetic frames: runs, saves, the training cost is stochastic
+    from ip_avsr_amd.avletters import avletters_convae as trainer
+    rng = np.random.default_rng(3)
+    X = rng.uniform(-1, 1, size=(40, 1200)).astype(np.float32)
+    prefix = str(tmp_path / "cae")
+    out = trainer.main(["--model", "bn+dropout", "--epochs", "1", "--epoch_size", "2", "--save_prefix", prefix, "--seed", "5",
+                        "--bottleneck", "8", "--dense", "32"], data=(X[:32], X[32:]))
+    import os
+    assert os.path.exists(prefix + "_ae.dat") and os.path.exists(prefix + "_encoder.dat")
+    assert np.isfinite(out["costs"]).all() and np.isfinite(out["val_costs"]).all()
+    out["network"].close()
