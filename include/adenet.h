@@ -59,8 +59,12 @@ typedef enum { ADN_FUSE_NONE = 0, ADN_FUSE_SUM = 1, ADN_FUSE_ADASUM = 2, ADN_FUS
 
 typedef enum {
     ADN_PRECISION_F32 = 0, /* exact fp32 on the f32 MFMA pipe (parity-grade; all parity tests run in it) */
-    ADN_PRECISION_BF16 = 1 /* GEMM operands rounded to bf16 (RNE) in flight, fp32 accumulate, fp32 master
+    ADN_PRECISION_BF16 = 1, /* GEMM operands rounded to bf16 (RNE) in flight, fp32 accumulate, fp32 master
                               weights / activations / recurrence / optimiser (BASELINE configs[1]: bf16) */
+    ADN_PRECISION_BF16X3 = 2 /* fp32 everywhere like ADN_PRECISION_F32, but every large GEMM runs as three bf16 MFMA
+                              products of the operands' bf16 hi / lo parts (a_hi b_hi + a_hi b_lo + a_lo b_hi, fp32
+                              accumulate: ~4e-6 relative, inside the 1e-4 parity gate) at the bf16 matrix rate; the
+                              recurrent kernels are the fp32 ones */
 } adn_precision;
 
 enum {

@@ -18,7 +18,7 @@ ADN_OK = 0
 ACT = {"linear": 0, "identity": 0, "rectify": 1, "sigmoid": 2, "tanh": 3, "leaky_rectify": 4,
        "very_leaky_rectify": 5, "scaled_tanh": 6, "scaled_tanh_lecun": 7}
 FUSION = {"none": 0, "sum": 1, "adasum": 2, "concat": 3}
-PRECISION = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
+PRECISION = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "bf16x3": 2}
 FLAG_DEVICE_INPUTS = 1
 FLAG_STOCHASTIC = 4
 FLAG_DETERMINISTIC = 8

@@ -1121,6 +1121,82 @@ int to_bf16(const float* src, void* dst, size_t n, hipStream_t s) {
     return ADN_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// bf16x3: fp32-grade products at the bf16 MFMA rate.  x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (|x - hi - lo| <=
+// 2^-18 |x|); a b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi (the dropped lo lo term is 2^-18 relative too), every product exact
+// in the fp32 accumulator.  The three products are ONE GEMM over a three times deeper K: A' = [A_hi | A_hi | A_lo],
+// B' = [B_hi ; B_lo ; B_hi] along k, each segment padded to Kp = round_up(K, 8) with zeros.  These kernels write the
+// split images; the GEMM kernels above then run unchanged on them.
+//   lo_mask: bit s set = segment s holds the lo part (A: 0b100, B: 0b010)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split4(const float4& v, bf16x4& hi, bf16x4& lo) {
+    hi = cvt4(v);
+    const float4 r = make_float4(v.x - (float)hi[0], v.y - (float)hi[1], v.z - (float)hi[2], v.w - (float)hi[3]);
+    lo = cvt4(r);
+}
+
+// k along the COLUMNS of src [rows][ld_src]: dst [rows][3 Kp], dst[r][s Kp + k]
+__global__ __launch_bounds__(256) void split3_cols_kernel(const float* __restrict__ src, int ld_src, int rows, int K, int Kp,
+                                                          __bf16* __restrict__ dst, int lo_mask) {
+    const int q = Kp / 4;
+    const int64_t total = (int64_t)rows * q;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int k = (int)(e % q) * 4;
+        const int64_t r = e / q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k + 4 <= K) v = *reinterpret_cast<const float4*>(src + (size_t)r * ld_src + k);
+        else if (k < K) {
+            const float* p = src + (size_t)r * ld_src + k;
+            v.x = p[0]; if (k + 1 < K) v.y = p[1]; if (k + 2 < K) v.z = p[2];
+        }
+        bf16x4 hi, lo;
+        split4(v, hi, lo);
+        __bf16* d = dst + (size_t)r * 3 * Kp + k;
+#pragma unroll
+        for (int sgm = 0; sgm < 3; ++sgm) *reinterpret_cast<bf16x4*>(d + (size_t)sgm * Kp) = ((lo_mask >> sgm) & 1) ? lo : hi;
+    }
+}
+
+// k along the ROWS of src [K][ld_src] (cols valid columns): dst [3 Kp][ld_dst], dst[s Kp + k][c]; pad rows / columns zero
+__global__ __launch_bounds__(256) void split3_rows_kernel(const float* __restrict__ src, int ld_src, int K, int Kp, int cols,
+                                                          __bf16* __restrict__ dst, int ld_dst, int lo_mask) {
+    const int q = ld_dst / 4;
+    const int64_t total = (int64_t)Kp * q;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % q) * 4;
+        const int k = (int)(e / q);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < K) {
+            if (c + 4 <= cols) v = *reinterpret_cast<const float4*>(src + (size_t)k * ld_src + c);
+            else if (c < cols) {
+                const float* p = src + (size_t)k * ld_src + c;
+                v.x = p[0]; if (c + 1 < cols) v.y = p[1]; if (c + 2 < cols) v.z = p[2];
+            }
+        }
+        bf16x4 hi, lo;
+        split4(v, hi, lo);
+#pragma unroll
+        for (int sgm = 0; sgm < 3; ++sgm)
+            *reinterpret_cast<bf16x4*>(dst + ((size_t)sgm * Kp + k) * ld_dst + c) = ((lo_mask >> sgm) & 1) ? lo : hi;
+    }
+}
+
+int split3_cols(const float* src, int ld_src, int rows, int K, int Kp, void* dst, int lo_mask, hipStream_t s) {
+    const int64_t total = (int64_t)rows * (Kp / 4);
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, 16384));
+    hipLaunchKernelGGL(split3_cols_kernel, dim3(grid), dim3(256), 0, s, src, ld_src, rows, K, Kp, reinterpret_cast<__bf16*>(dst), lo_mask);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+int split3_rows(const float* src, int ld_src, int K, int Kp, int cols, void* dst, int ld_dst, int lo_mask, hipStream_t s) {
+    const int64_t total = (int64_t)Kp * (ld_dst / 4);
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, 16384));
+    hipLaunchKernelGGL(split3_rows_kernel, dim3(grid), dim3(256), 0, s, src, ld_src, K, Kp, cols, reinterpret_cast<__bf16*>(dst), ld_dst, lo_mask);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
 }  // namespace adn
 
 #ifdef ADN_GEMM_STAMPS

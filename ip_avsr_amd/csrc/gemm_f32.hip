@@ -18,6 +18,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace adn {
 
@@ -315,10 +318,66 @@ int gemm_grouped(const GemmArgs* gs, int n, hipStream_t stream) {
     return ADN_OK;
 }
 
+// ---- bf16x3 (ADN_PRECISION_BF16X3): split both operands into [hi | hi | lo] / [hi ; lo ; hi] images along k (gemm_bf16.hip)
+// and run the bf16 kernels on a three times deeper K.  The images live in a workspace that belongs to the STREAM the GEMM is
+// enqueued on (consecutive GEMMs of a stream reuse it in order; two streams never share one); it grows on demand and is
+// kept for the life of the process.
+namespace {
+struct X3Workspace { void* ptr = nullptr; size_t bytes = 0; };
+std::mutex g_x3_mutex;
+std::map<std::pair<int, hipStream_t>, X3Workspace> g_x3_ws;
+
+int x3_workspace(hipStream_t stream, size_t bytes, void** out) {
+    int dev = 0;
+    ADN_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_x3_mutex);
+    X3Workspace& w = g_x3_ws[std::make_pair(dev, stream)];
+    if (w.bytes < bytes) {
+        if (w.ptr) { ADN_HIP_CHECK(hipStreamSynchronize(stream)); ADN_HIP_CHECK(hipFree(w.ptr)); w.ptr = nullptr; w.bytes = 0; }
+        const size_t want = std::max(bytes + bytes / 8, (size_t)64 << 20);
+        ADN_HIP_CHECK(hipMalloc(&w.ptr, want));
+        w.bytes = want;
+    }
+    *out = w.ptr;
+    return ADN_OK;
+}
+}  // namespace
+
+static int gemm_bf16x3(const GemmArgs& g, hipStream_t stream) {
+    const int Kp = (int)round_up(g.K, 8);
+    const bool a_rows = g.layout == GEMM_TN;                     // A given as [K][M]: k along its rows
+    const bool b_cols = g.layout == GEMM_NT;                     // B given as [N][K]: k along its columns
+    const int lda3 = a_rows ? (int)round_up(g.M, 64) : 3 * Kp, ldb3 = b_cols ? 3 * Kp : (int)round_up(g.N, 64);
+    const size_t a_elems = a_rows ? (size_t)3 * Kp * lda3 : (size_t)g.M * lda3;
+    const size_t b_elems = b_cols ? (size_t)g.N * ldb3 : (size_t)3 * Kp * ldb3;
+    const size_t a_bytes = (size_t)round_up((int64_t)a_elems * 2, 256);
+    void* ws = nullptr;
+    ADN_TRY(x3_workspace(stream, a_bytes + b_elems * 2 + 256, &ws));
+    void* A3 = ws; void* B3 = static_cast<char*>(ws) + a_bytes;
+    if (a_rows) ADN_TRY(split3_rows(g.A, g.lda, g.K, Kp, g.M, A3, lda3, 0b100, stream));
+    else ADN_TRY(split3_cols(g.A, g.lda, g.M, g.K, Kp, A3, 0b100, stream));
+    if (b_cols) ADN_TRY(split3_cols(g.B, g.ldb, g.N, g.K, Kp, B3, 0b010, stream));
+    else ADN_TRY(split3_rows(g.B, g.ldb, g.K, Kp, g.N, B3, ldb3, 0b010, stream));
+    GemmArgs h = g;
+    h.precision = ADN_PRECISION_BF16;
+    h.A16 = A3; h.B16 = B3; h.lda = lda3; h.ldb = ldb3; h.K = 3 * Kp;
+    h.C16 = nullptr; h.Y16 = nullptr;                           // fp32 outputs and masks, as in fp32 mode
+    return gemm(h, stream);
+}
+
 int gemm(const GemmArgs& g, hipStream_t stream) {
     ADN_CHECK(g.layout >= GEMM_NN && g.layout <= GEMM_TN, ADN_ERR_INVALID, "gemm: bad layout");
     if (g.M <= 0 || g.N <= 0) return ADN_OK;
     ADN_CHECK(g.K > 0, ADN_ERR_INVALID, "gemm: K must be positive");
+    if (g.precision == ADN_PRECISION_BF16X3) {
+        // small problems (launch-bound; the split passes would cost more than they save) stay on the fp32 MFMA kernels
+        if ((double)g.M * g.N * g.K >= 6.4e7 && g.K >= 32 && g.A && g.B && g.C && g.lda % 4 == 0 && g.ldb % 4 == 0 &&
+            ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0)
+            return gemm_bf16x3(g, stream);
+        GemmArgs h = g;
+        h.precision = ADN_PRECISION_F32;
+        return gemm(h, stream);
+    }
     const bool lean_c = !g.C && g.C16 && g.precision == ADN_PRECISION_BF16 && g.A16 && g.B16 && !g.accumulate;
     ADN_CHECK(g.A && g.B && (g.C || lean_c), ADN_ERR_INVALID, "gemm: null operand");
     ADN_CHECK(g.lda % 4 == 0 && g.ldb % 4 == 0, ADN_ERR_INVALID, "gemm: lda/ldb must be multiples of 4 floats");
@@ -345,7 +404,8 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
 
     const int64_t t128 = (int64_t)cdiv(g.M, 128) * cdiv(g.N, 128);
     const int64_t t64 = (int64_t)cdiv(g.M, 64) * cdiv(g.N, 64);
-    const bool can_split = g.act == ADN_ACT_LINEAR;
+    // (the split-K epilogue adds bare partial sums: no bias, no act'(Y) mask)
+    const bool can_split = g.act == ADN_ACT_LINEAR && !g.bias && !g.Y && !g.Y16;
     // 128x128 tiles (4 MFMA tiles per wave, half the LDS fragment reads per MFMA of the 64x64 shape) whenever
     // the grid can still fill 256 CUs: either by tile count alone or together with split-K (weight gradients:
     // K = all frames of the batch)

@@ -224,6 +224,8 @@ struct adn_model {
     int transw_blocks = 0;
     bool packed_for_persistent = false;         // which LSTM weight images the last refresh produced
     bool bf16() const { return cfg.precision == ADN_PRECISION_BF16; }
+    // bf16x3 mode is fp32 mode everywhere but inside gemm(): fp32 activations, no shadows, the fp32 recurrent kernels
+    int lstm_precision() const { return bf16() ? ADN_PRECISION_BF16 : ADN_PRECISION_F32; }
     bool keep_fp32 = false;        // debug: also write the fp32 copies that bf16 mode normally skips
     void* shadow_of(const float* p) const {
         if (!p) return nullptr;
@@ -306,7 +308,7 @@ int validate(const adn_config& c) {
         ADN_CHECK(c.streams[k].dropout_p >= 0.f && c.streams[k].dropout_p < 1.f, ADN_ERR_INVALID,
                   "dropout probability must be in [0, 1)");
     ADN_CHECK(c.agg >= 0 && c.agg <= 2, ADN_ERR_INVALID, "agg must be 0, 1 or 2");
-    ADN_CHECK(c.precision == ADN_PRECISION_F32 || c.precision == ADN_PRECISION_BF16, ADN_ERR_INVALID,
+    ADN_CHECK(c.precision >= ADN_PRECISION_F32 && c.precision <= ADN_PRECISION_BF16X3, ADN_ERR_INVALID,
               "unsupported precision");
     if (c.fusion == ADN_FUSE_NONE) ADN_CHECK(c.n_streams == 1, ADN_ERR_INVALID, "fusion 'none' needs exactly one stream");
     if (c.fusion == ADN_FUSE_CONCAT && c.n_streams > 1)
@@ -553,7 +555,7 @@ int stage_inputs(adn_model* m, const void* const* inputs, const int32_t* targets
 bool shadows_on(const adn_model* m) { return m->bf16() && !getenv("ADN_BF16_NO_SHADOW"); }
 
 int ensure_splitk_ws(adn_model* m) {
-    if (m->splitk_ws || !m->bf16()) return ADN_OK;
+    if (m->splitk_ws || m->cfg.precision == ADN_PRECISION_F32) return ADN_OK;
     // every (tile, K-slice) workgroup of a launch owns one slab piece: <= CUs x 256 x 256 floats, + row padding
     m->splitk_ws_floats = (size_t)24 << 20;
     ADN_HIP_CHECK(hipMalloc((void**)&m->splitk_ws, m->splitk_ws_floats * sizeof(float)));
@@ -713,8 +715,8 @@ int run_lstm_group(adn_model* m, std::vector<LstmStep>& steps, int B, int T, boo
         const int n = (int)std::min<size_t>(kMaxLstmPerLaunch, steps.size() - i);
         bool done = false;
         if (backward)
-            ADN_TRY(lstm_backward(steps.data() + i, n, m->mask_tb, B, T, m->H, m->cfg.precision, m->stream, &done));
-        else ADN_TRY(lstm_forward(steps.data() + i, n, m->mask_tb, B, T, m->H, m->cfg.precision, m->stream));
+            ADN_TRY(lstm_backward(steps.data() + i, n, m->mask_tb, B, T, m->H, m->lstm_precision(), m->stream, &done));
+        else ADN_TRY(lstm_forward(steps.data() + i, n, m->mask_tb, B, T, m->H, m->lstm_precision(), m->stream));
         all = all && done;
     }
     if (sums_done) *sums_done = backward && all;
@@ -816,6 +818,7 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
     const int N = B * T, H = m->H, ldh = m->ldh;
     hipStream_t s = m->stream;
     std::vector<LstmStep> steps;
+    ADN_TRY(ensure_splitk_ws(m));                                // (bf16x3 mode: the weight gradients' partial slabs)
     ADN_TRY(fork_streams(m));
     auto enc_gemm = [&](StreamState& st, int l) {                // modelzoo/pretrained_encoder.py:4-9
         GemmArgs g;
@@ -1447,7 +1450,7 @@ int adn_set_stream(adn_model* m, void* hip_stream) {
 
 int adn_set_precision(adn_model* m, int precision) {
     ADN_CHECK(m, ADN_ERR_INVALID, "null model");
-    ADN_CHECK(precision == ADN_PRECISION_F32 || precision == ADN_PRECISION_BF16, ADN_ERR_INVALID,
+    ADN_CHECK(precision >= ADN_PRECISION_F32 && precision <= ADN_PRECISION_BF16X3, ADN_ERR_INVALID,
               "unsupported precision");
     m->cfg.precision = precision;
     m->mark_params_dirty();
