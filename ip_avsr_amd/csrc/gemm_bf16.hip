@@ -1181,6 +1181,35 @@ __global__ __launch_bounds__(256) void split3_rows_kernel(const float* __restric
     }
 }
 
+// src [R][ld_src] with k along its COLUMNS, written TRANSPOSED: dst [3 Kp][ld_dst], dst[s Kp + k][r] (an NT operand turned
+// into the k-strided form the faster NN kernels read); 32 x 32 tiles through LDS, pad rows / columns zero
+__global__ __launch_bounds__(256) void split3_transpose_kernel(const float* __restrict__ src, int ld_src, int R, int K, int Kp,
+                                                               __bf16* __restrict__ dst, int ld_dst, int lo_mask) {
+    __shared__ float tile[32][33];
+    const int k0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, k = k0 + tx;
+        tile[j][tx] = (r < R && k < K) ? src[(size_t)r * ld_src + k] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int k = k0 + j, r = r0 + tx;
+        if (k >= Kp || r >= ld_dst) continue;
+        const float v = tile[tx][j];
+        const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
+#pragma unroll
+        for (int sgm = 0; sgm < 3; ++sgm) dst[((size_t)sgm * Kp + k) * ld_dst + r] = ((lo_mask >> sgm) & 1) ? lo : hi;
+    }
+}
+
+int split3_transpose(const float* src, int ld_src, int R, int K, int Kp, void* dst, int ld_dst, int lo_mask, hipStream_t s) {
+    hipLaunchKernelGGL(split3_transpose_kernel, dim3(cdiv(Kp, 32), cdiv(ld_dst, 32)), dim3(256), 0, s, src, ld_src, R, K, Kp,
+                       reinterpret_cast<__bf16*>(dst), ld_dst, lo_mask);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
 int split3_cols(const float* src, int ld_src, int rows, int K, int Kp, void* dst, int lo_mask, hipStream_t s) {
     const int64_t total = (int64_t)rows * (Kp / 4);
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, 16384));

@@ -114,6 +114,7 @@ __device__ __forceinline__ void store_tile32(const GemmParams& p, const f32x16& 
 void launch_gemm_bf16(const GemmParams& p, int layout, int tile_mode /*0: 64x64, 1: 128x128*/, dim3 grid, hipStream_t s);
 // persistent ping-pong LDS-DMA kernel; tile_mode 4: 256x256, 5: 256x128, 6: 128x256; splits > 1: partial slabs + reduce
 int split3_cols(const float* src, int ld_src, int rows, int K, int Kp, void* dst, int lo_mask, hipStream_t s);
+int split3_transpose(const float* src, int ld_src, int R, int K, int Kp, void* dst, int ld_dst, int lo_mask, hipStream_t s);
 int split3_rows(const float* src, int ld_src, int K, int Kp, int cols, void* dst, int ld_dst, int lo_mask, hipStream_t s);
 void launch_gemm_bf16_pp(const GemmParams& p, int layout, int tile_mode, int splits, dim3 grid, hipStream_t s);
 
