@@ -1038,9 +1038,15 @@ static void launch_bf16_t(const GemmParams& p, int layout, dim3 grid, hipStream_
     }
 }
 
+// tile_mode: 0 = 64 x 64, 1 = 128 x 128, 2 = 256 x 64 (tall: narrow outputs under many rows)
 void launch_gemm_bf16(const GemmParams& p, int layout, int tile_mode, dim3 grid, hipStream_t s) {
     const bool shadows = p.A16 && p.B16;      // operands already available as bf16 copies
-    const bool big = tile_mode >= 1;
+    const bool big = tile_mode == 1;
+    if (tile_mode == 2) {
+        if (shadows) launch_bf16_t<256, 64, 4, __bf16>(p, layout, grid, s);
+        else launch_bf16_t<256, 64, 4, float>(p, layout, grid, s);
+        return;
+    }
     if (shadows) {
         if (big) launch_bf16_t<128, 128, 2, __bf16>(p, layout, grid, s);
         else launch_bf16_t<64, 64, 2, __bf16>(p, layout, grid, s);

@@ -422,9 +422,14 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
     const bool big = force_tile ? force_tile == 128
                                 : (g.K >= 768 && fill128 >= 0.85 * fill64 &&
                                    (t128 >= 384 || (can_split && t128 >= 24 && g.K >= 2048)));
-    const bool dma = false, huge = false;
-    const int64_t t256 = 0;
-    const int64_t tiles = huge ? t256 : (big ? t128 : t64);
+    // 256 x 64 tiles (bf16 kernels): a narrow output under many rows -- the B panel is re-read once per 256 rows
+    // instead of once per 64, at the per-wave tile of the 128 x 128 shape
+    const int64_t t_tall = (int64_t)cdiv(g.M, 256) * cdiv(g.N, 64);
+    // (measured, profiles/r02/gemm_lab_tall.txt: 129024 x 152 x 2504 -- the conv auto-encoder's second convolution at batch
+    //  1024 -- 266 us against 331 (64 x 64) / 293 (128 x 128); N = 104 / 150 / 200 and the 20800-row shapes: no gain)
+    const bool tall = g.precision == ADN_PRECISION_BF16 &&
+                      (force_tile ? force_tile == 256 : (!big && g.N > 128 && g.N <= 192 && g.M >= 65536 && g.K >= 1024));
+    const int64_t tiles = tall ? t_tall : (big ? t128 : t64);
     int split = 1;
     // split-K: enough workgroups for two per CU (measured on the weight-gradient shapes: 512 beats 768 / 1024 by 0-12 %,
     // fewer partial sums to add atomically; 256 leaves CUs idle on the large ones)
@@ -447,7 +452,7 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
     if (lean_c) ADN_CHECK(g.ldc % 4 == 0 && g.N % 4 == 0 && ((uintptr_t)g.C16 % 8) == 0, ADN_ERR_INVALID,
                           "gemm: bf16-only output needs N and ldc to be multiples of 4");
     const int tsz = big ? 128 : 64;
-    p.tiles_m = cdiv(g.M, huge ? 256 : tsz); p.tiles_n = cdiv(g.N, huge ? 256 : tsz);
+    p.tiles_m = cdiv(g.M, tall ? 256 : tsz); p.tiles_n = cdiv(g.N, tsz);
     const int cs_ld = (int)round_up(g.N, 4);
     if (g.colsum && g.precision == ADN_PRECISION_BF16 && !p.atomic && g.ldc % 4 == 0 &&
         ((uintptr_t)g.C % 16) == 0 && (!g.Y || (g.ldy % 4 == 0 && ((uintptr_t)g.Y % 16) == 0)) && g.N % 4 == 0 &&
@@ -460,15 +465,13 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
         int bn = (int)std::lround(std::sqrt((double)chunk));
         p.panel_n = std::max(1, std::min(bn, p.tiles_n));
     }
-    // the LDS-DMA kernel is persistent: one workgroup per CU walks the tile list
-    // (workgroup count a multiple of 8 keeps a workgroup's tiles on its own XCD's chunk of the tile list)
-    const dim3 grid((unsigned)(dma ? std::min<int64_t>(tiles, std::max(8, 256 / split / 8 * 8)) : tiles), split);
+    const dim3 grid((unsigned)tiles, split);
     static const bool trace = getenv("ADN_GEMM_TRACE") != nullptr;       // one line per launch, pairs with a kernel trace
     if (trace)
         fprintf(stderr, "ADN_GEMM %s M=%d N=%d K=%d tile=%d tiles=%lld split=%d shadows=%d lean=%d acc=%d\n",
-                g.layout == GEMM_NN ? "NN" : (g.layout == GEMM_NT ? "NT" : "TN"), g.M, g.N, g.K, huge ? 256 : tsz,
+                g.layout == GEMM_NN ? "NN" : (g.layout == GEMM_NT ? "NT" : "TN"), g.M, g.N, g.K, tall ? 25664 : tsz,
                 (long long)tiles, split, (int)(p.A16 && p.B16), (int)lean_c, g.accumulate);
-    if (g.precision == ADN_PRECISION_BF16) launch_gemm_bf16(p, g.layout, dma ? 3 : (big ? 1 : 0), grid, stream);
+    if (g.precision == ADN_PRECISION_BF16) launch_gemm_bf16(p, g.layout, tall ? 2 : (big ? 1 : 0), grid, stream);
     else if (big) launch<128, 128>(p, g.layout, grid, stream);
     else launch<64, 64>(p, g.layout, grid, stream);
     ADN_HIP_CHECK(hipGetLastError());

@@ -68,6 +68,13 @@ int main(int argc, char** argv) {
         {"odd edges fwd", GEMM_NN, 20777, 1996, 1208, 0, 0, 0, 0, 1},
         {"odd edges dW", GEMM_TN, 1196, 2004, 20777, 0, 1, 0, 0, 0},
         {"dW bn TN acc", GEMM_TN, 500, 50, R, 0, 1, 0, 0, 0},
+        // narrow outputs under many rows: the LSTM input gradient, the bottleneck, the conv auto-encoder's convolutions
+        // as GEMMs at batch 1024 (rows = B x OH x OW; N = filters; K = kh kw C_in)
+        {"narrow dfeat N=150", GEMM_NN, R, 150, 1000, 0, 0, 0, 0, 0},
+        {"narrow fwd bn N=50", GEMM_NN, R, 50, 500, 0, 0, 0, 0, 1},
+        {"narrow cae conv3 N=152", GEMM_NN, 129024, 152, 2504, 0, 0, 0, 0, 1},
+        {"narrow cae conv5 N=200", GEMM_NN, 15360, 200, 1368, 0, 0, 0, 0, 1},
+        {"narrow cae deconv13 N=104", GEMM_NN, 338 * 1024, 104, 3800, 0, 0, 0, 0, 0},
     };
     const char* only = argc > 1 ? argv[1] : nullptr;
     if (only && !strcmp(only, "sweep")) {           // K sweep of one output shape: fixed cost vs per-stage cost
