@@ -343,6 +343,34 @@ int adn_cae_synchronize(adn_cae* m);
  * advances by one after every non-deterministic pass (same convention as adn_set_dropout_state) */
 int adn_cae_set_dropout_state(adn_cae* m, uint32_t seed, uint32_t counter);
 
+/* ---- RBM / DBN pre-trainer (optional; reference dbn/trainRBM.m, RBMup.m, RBMdown.m, computeStates.m) ----
+ * Contrastive divergence CD-1 on one restricted Boltzmann machine: the offline producer of the w1..wN / b1..bN files the
+ * encoders start from, without MATLAB.  Layer types are adn_act codes: ADN_ACT_SIGMOID ('sigm'), ADN_ACT_LINEAR ('linear'),
+ * ADN_ACT_RECTIFY ('ReLu'), ADN_ACT_TANH, ADN_ACT_LEAKY_RECTIFY (visible layer only: dbn/computeStates.m samples sigm, linear
+ * and ReLu units).  The caller picks the learning rates (dbn/trainRBM.m:47-51: the *_linear set as soon as a linear or ReLu
+ * layer is involved) and the momentum of each minibatch (0.5, then 0.9 after rbmParams.momentumEpochThres epochs). */
+typedef struct {
+    int32_t num_vis, num_hid;
+    int32_t vis_type, hid_type;   /* adn_act */
+    int32_t cd_type;              /* rbmParams.type: 1 = probabilities in the statistics (Hinton's guide), 2 = sampled states */
+    int32_t batchsize;            /* rbmParams.batchsize: the statistics are divided by it, also for a short last batch */
+    float lr_w, lr_vb, lr_hb;     /* rbmParams.lrW / lrVb / lrHb (or their _linear versions) */
+    float weight_penalty;         /* rbmParams.weightPenaltyL2 */
+    int32_t reserved[2];
+} adn_rbm_config;
+typedef struct adn_rbm adn_rbm;
+int adn_rbm_create(const adn_rbm_config* cfg, adn_rbm** out);          /* weights and biases start at zero: write W */
+void adn_rbm_destroy(adn_rbm* m);
+int adn_rbm_set_stream(adn_rbm* m, void* hip_stream);
+/* which: 0 = W (num_vis x num_hid, row-major), 1 = hidbiases, 2 = visbiases, 3..5 = their momentum terms */
+int adn_rbm_read(adn_rbm* m, int which, float* host_dst);
+int adn_rbm_write(adn_rbm* m, int which, const float* host_src);
+/* RBMup's activations of n rows (dbn/trainDBN.m:46-47: the next layer's training data) */
+int adn_rbm_up(adn_rbm* m, const float* data, int n, int flags, float* probs);
+/* one minibatch of dbn/trainRBM.m:98-160; noise = hash(seed, counter, stream, element) as in oracle/rbm_oracle.py; err (may be
+ * null) receives sum((data - reconstruction)^2) */
+int adn_rbm_train_batch(adn_rbm* m, const float* data, int n, int flags, float momentum, uint32_t seed, uint32_t counter, float* err);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,12 @@ class CaeConfig(C.Structure):
                 ("precision", C.c_int32), ("variant", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
+class RbmConfig(C.Structure):
+    _fields_ = [("num_vis", C.c_int32), ("num_hid", C.c_int32), ("vis_type", C.c_int32), ("hid_type", C.c_int32),
+                ("cd_type", C.c_int32), ("batchsize", C.c_int32), ("lr_w", C.c_float), ("lr_vb", C.c_float), ("lr_hb", C.c_float),
+                ("weight_penalty", C.c_float), ("reserved", C.c_int32 * 2)]
+
+
 class ParamInfo(C.Structure):
     _fields_ = [("name", C.c_char * 96), ("ndim", C.c_int32), ("dims", C.c_int64 * 2), ("numel", C.c_int64)]
 
@@ -121,6 +127,13 @@ _SIGNATURES = {
     "adn_cae_apply_adam": (C.c_int, [_P, C.c_float]),
     "adn_cae_synchronize": (C.c_int, [_P]),
     "adn_cae_set_dropout_state": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "adn_rbm_create": (C.c_int, [_P, _P]),
+    "adn_rbm_destroy": (None, [_P]),
+    "adn_rbm_set_stream": (C.c_int, [_P, _P]),
+    "adn_rbm_read": (C.c_int, [_P, C.c_int, _P]),
+    "adn_rbm_write": (C.c_int, [_P, C.c_int, _P]),
+    "adn_rbm_up": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "adn_rbm_train_batch": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, C.c_uint32, C.c_uint32, _P]),
     "adn_prep_seq_deltas": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "adn_prep_diff_images": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P]),
     "adn_prep_mean_image_subtraction": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P]),
