@@ -11,7 +11,8 @@ OUT=$ROOT/gpurun_out/collect
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B="$ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --accurate-precision none"
-for prec in bf16 f32; do
+# (kernel-stats passes: one per arithmetic mode, the mode under test as --precision)
+for prec in bf16 f32 bf16x3; do
   timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/ks_$prec -o ks --output-format csv -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --accurate-precision none --precision $prec > $OUT/ks_$prec.log 2>&1
   cp $(find $OUT/ks_$prec -name "ks_kernel_stats.csv" | head -1) $OUT/final_${prec}_kernel_stats.csv
 done
@@ -39,8 +40,10 @@ cd $ROOT
   echo "=== ping-pong forced, 256 x 256 tiles (ADN_GEMM_PP=4)"; ADN_GEMM_PP=4 timeout 200 profiles/gemm_lab
   echo "=== three problems per launch (LAB_GROUPS=3), selection as shipped"; LAB_GROUPS=3 timeout 200 profiles/gemm_lab
   echo "=== three problems per launch, ping-pong forced"; LAB_GROUPS=3 ADN_GEMM_PP=4 timeout 200 profiles/gemm_lab ) > $OUT/gemm_lab_pp.txt 2>&1
+timeout 200 python3 profiles/hipblaslt_calibration.py > $OUT/hipblaslt_calibration.txt 2>/dev/null
+timeout 300 python3 profiles/convae_bench.py > $OUT/convae_bench.txt 2>/dev/null
 # the bench lines last, so that roofline.traffic comes from the PMC passes of THIS build
 mkdir -p profiles/$ROUND && cp $OUT/pmc_traffic_bf16.json profiles/$ROUND/pmc_traffic_bf16.json
 timeout 400 python3 bench.py --precision bf16 2>/dev/null | tail -1 > $OUT/final_bf16_bench.json
-rm -rf $OUT/ks_bf16 $OUT/ks_f32 $OUT/pmcA $OUT/pmcB $OUT/pmcM $OUT/pmcC $OUT/bd
+rm -rf $OUT/ks_bf16 $OUT/ks_f32 $OUT/ks_bf16x3 $OUT/pmcA $OUT/pmcB $OUT/pmcM $OUT/pmcC $OUT/bd
 ls -la $OUT
