@@ -375,7 +375,9 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
     ADN_CHECK(g.K > 0, ADN_ERR_INVALID, "gemm: K must be positive");
     if (g.precision == ADN_PRECISION_BF16X3) {
         // small problems (launch-bound; the split passes would cost more than they save) stay on the fp32 MFMA kernels
-        if ((double)g.M * g.N * g.K >= 6.4e7 && g.K >= 32 && g.A && g.B && g.C && g.lda % 4 == 0 && g.ldb % 4 == 0 &&
+        // (ADN_X3_MIN_WORK: test hook -- 0 sends every shape through the split path)
+        static const double min_work = getenv("ADN_X3_MIN_WORK") ? atof(getenv("ADN_X3_MIN_WORK")) : 6.4e7;
+        if ((double)g.M * g.N * g.K >= min_work && (g.K >= 32 || min_work == 0) && g.A && g.B && g.C && g.lda % 4 == 0 && g.ldb % 4 == 0 &&
             ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0)
             return gemm_bf16x3(g, stream);
         GemmArgs h = g;

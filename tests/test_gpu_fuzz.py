@@ -30,6 +30,12 @@ def test_random_graphs_track_the_oracle_in_bf16():
     assert "bad: 0" in out, "\n".join(l for l in out.splitlines() if " BAD " in l or "bad:" in l)
 
 
+def test_random_graphs_match_the_oracle_in_bf16x3():
+    """Every GEMM of the random graphs -- K from 2 up, ragged M and N -- through the hi / lo split path."""
+    out = run("fuzz_model.py", "24", "2027", "bf16x3")
+    assert "bad: 0" in out, "\n".join(l for l in out.splitlines() if " BAD " in l or "bad:" in l)
+
+
 def test_random_lstm_shapes_cluster_equals_single_workgroup():
     out = run("fuzz_lstm.py")
     assert "bad: 0" in out, "\n".join(l for l in out.splitlines() if "BAD" in l or "NON-REPEATABLE" in l or "bad:" in l)
