@@ -547,23 +547,27 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams p)
 // keeps running across tile boundaries (the next tile's first stages land while this tile's epilogue stores).
 //
 // The two waves that share a SIMD (w and w + 4: the upper and the lower half of the tile's rows) run the same program
-// ONE BARRIER APART.  A K-step is two segments separated by s_barrier:
+// HALF A K-STEP APART.  A K-step is two segments:
 //     L(s): fragment reads of stage s into registers + DMA issue for stage s + 3        (LDS / address traffic)
 //     C(s): TM x TN MFMAs on those registers (+ the tile epilogue after the last K-step)  (matrix pipe)
-//     waves 0-3:   L(0) | C(0) | L(1) | C(1) | ...
-//     waves 4-7:        | L(0) | C(0) | L(1) | ...
-// so that at any time one wave of every SIMD feeds the matrix pipe while its partner does the LDS reads and the DMA
-// issue, instead of all eight waves running wait / barrier / DMA issue / reads / MFMA in lock-step (in-kernel stamps of
-// the lock-step predecessor: 45 % of a K-step in reads + MFMA, 23 % DMA issue, 32 % waits; MFMA pipe 29 % busy).
+// and ONE s_barrier per K-step, placed behind C by waves 0-3 and behind L by waves 4-7:
+//     waves 0-3:   L(0) C(0) | L(1) C(1) | L(2) C(2) | ...
+//     waves 4-7:   L(0)      | C(0) L(1) | C(1) L(2) | ...          ( | = the barrier, the same event for all 8 waves)
+// so that inside every interval one wave of a SIMD feeds the matrix pipe while its partner does the LDS reads and the DMA
+// issue, and they swap in the middle -- instead of all eight waves running wait / barrier / DMA issue / reads / MFMA in
+// lock-step (in-kernel stamps of the lock-step predecessor: 45 % of a K-step in reads + MFMA, 23 % DMA issue, 32 % waits;
+// MFMA pipe 29 % busy).  (Round 2's first version separated L and C by a barrier each -- waves 0-3: L | C | L | C, waves 4-7
+// one barrier behind: a K-step then costs 2 max(L, C) + two barriers, and L is the longer segment; with one barrier it is
+// L + C + one barrier: 7 - 16 % faster on every shape, profiles/r02/pp_one_barrier.txt; ADN_GEMM_PP_BARRIERS=2 selects the
+// old schedule.)
 //
-// LDS hazards are settled by counted waits and the barrier sequence alone (barrier #n is the same event for all 8
-// waves; waves 0-3 run L(s) between #2s and #2s+1, waves 4-7 between #2s+1 and #2s+2):
-//   RAW  stage s + 1 is first read after #2s+2.  Every wave waits for ITS pieces of stage s + 1 (s_waitcnt vmcnt(N),
-//        N = pieces of the younger stages it has issued) at the end of its L(s), i.e. before #2s+1 (waves 0-3) or
-//        #2s+2 (waves 4-7).  (One place for both halves on purpose: a wave-half test inside the K-loop is a long-lived
-//        boolean that hipcc kept in a VGPR, spilled, and reloaded behind s_waitcnt vmcnt(0) -- draining the ring.)
-//   WAR  stage s + 3 overwrites the slot of stage s - 1, whose last reads (waves 4-7, L(s-1)) are complete before
-//        #2s (s_waitcnt lgkmcnt(0) ends every L segment); the DMA is issued in L(s), after #2s.
+// LDS hazards are settled by counted waits and the barrier sequence alone (interval s = between barrier #s-1 and #s):
+//   RAW  stage s + 1 is first read in interval s + 1.  Every wave waits for ITS pieces of stage s + 1 (s_waitcnt vmcnt(N),
+//        N = pieces of the younger stages it has issued) at the end of its L(s), which lies in interval s for both halves.
+//        (One place for both halves on purpose: a wave-half test around the wait is a long-lived boolean that hipcc kept
+//        in a VGPR, spilled, and reloaded behind s_waitcnt vmcnt(0) -- draining the ring.)
+//   WAR  stage s + 3 overwrites the slot of stage s - 1 and is issued in L(s), i.e. in interval s; the last reads of that
+//        slot are the L(s - 1) segments, both in interval s - 1 and each closed by s_waitcnt lgkmcnt(0) before barrier #s-1.
 // vmcnt counts stores too and retires in order, so the epilogue's stores sit between the DMA groups of a wave's queue:
 // the first wait after an epilogue leaves only the youngest stage in flight (it also waits for the store
 // acknowledgements; once per tile).
@@ -840,7 +844,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
     for (int s = 0; s < D && s < total; ++s) issue_next();
     wait_next(-1, false);
     __builtin_amdgcn_s_barrier();                                  // #0
-    if (late) __builtin_amdgcn_s_barrier();                        // the lower half starts one segment later
+    const bool one = p.one_barrier != 0;
+    if (late && !one) __builtin_amdgcn_s_barrier();                // the lower half starts one segment later
 
     int kt = 0, ord = 0;
     int grp, tile_m, tile_n;
@@ -889,7 +894,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
         }
         wait_next(s, kt == 0 && s > 0);
         GSTAMP(3);
-        __builtin_amdgcn_s_barrier();
+        if (!one || late) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         GSTAMP(4);
         // ---------------- C(s)
@@ -975,13 +980,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
         }
         GSTAMP(6);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        if (!one || !late) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         GSTAMP(7);
         ++s;
     }
     GSTAMP_FLUSH;
-    if (!late) __builtin_amdgcn_s_barrier();                       // every wave executes the same number of barriers
+    if (!late && !one) __builtin_amdgcn_s_barrier();               // every wave executes the same number of barriers
 }
 
 // C (+)= sum of the split-K partial slabs ([group][split][M][ldc] floats); float4 per lane

@@ -33,6 +33,7 @@ struct GemmParams {
     // ping-pong kernel only
     int ngroups;
     int xcd_slices;     // split-K: K-slice = function of the workgroup's XCD (see the kernel)
+    int one_barrier;    // ping-pong kernel: one s_barrier per K-step (halves offset inside the interval) instead of two
     float* partial;     // split-K partial slabs [group][split][M][ldc]
     GemmGroup grp[kMaxGemmGroups];
 };

@@ -209,12 +209,13 @@ static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used
     const bool lean_c = !g.C;
     const bool can_split = g.act == ADN_ACT_LINEAR && !lean_c && !g.no_split && !g.bias && !g.Y && !g.Y16 && !g.colsum;
     // ---- where it pays (profiles/r02/gemm_lab_pp.txt, MI355X, against the register-staged 128 x 128 kernel):
-    //   * split-K weight gradients with outputs of >= 1.8 M elements (dW fc1 / fc2): 144 / 114 us against 171 / 137
-    //     (692 - 750 TFLOP/s; partial slabs + reduce instead of 64 MB of float atomics)
+    //   * split-K weight gradients with outputs of >= 0.4 M elements: dW fc1 / fc2 125 / 102 us against 178 / 139 (800 - 818
+    //     TFLOP/s; partial slabs + reduce instead of 64 MB of float atomics), 768 x 1000 (the aggregation LSTMs' input
+    //     weights) 55 against 81, 1000 x 500 50 against 54
     //   * forward GEMMs with a plain epilogue (bias / rectify, no act'(Y) loads, no fused column sums) whose tiles fill
-    //     >= 85 % of their rounds of 256 CUs -- in practice the input streams' encoder layers as ONE grouped launch:
-    //     114 against 134 us per stream for 20800 x 1000 x 2000 (three streams fill 3.8 rounds where one fills 1.3 and
-    //     loses the difference to its last round), 145 against 161 us for 20800 x 2000 x 1200
+    //     >= 80 % of their rounds of 256 CUs -- in practice the input streams' encoder layers as ONE grouped launch:
+    //     110 against 134 us per stream for 20800 x 1000 x 2000 (three streams fill 3.8 rounds where one fills 1.3 and
+    //     loses the difference to its last round), 142 against 161 us for 20800 x 2000 x 1200
     //   * NOT the input-gradient GEMMs: the transposed-accumulator epilogue reads the act'(Y) mask in 32-byte
     //     row pieces (205 against 146 us), and not 128-wide tiles (445 TFLOP/s: B-fragment reads per flop double)
     struct Cand { int mode, bm, bn; double rate; };
@@ -237,8 +238,8 @@ static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used
     if (mode_env < 4) {
         const double fill = ((double)g.M * g.N * n / cus) / best_cost;       // useful share of the tile-rounds
         const bool plain = !g.Y && !g.Y16 && !g.colsum;
-        const bool wgrad = splits > 1 && (int64_t)g.M * g.N >= 1800000;
-        const bool fwd_group = splits == 1 && plain && fill >= 0.85;
+        const bool wgrad = splits > 1 && (int64_t)g.M * g.N >= 400000;
+        const bool fwd_group = splits == 1 && plain && fill >= 0.80;
         if (!wgrad && !fwd_group) return ADN_OK;
     }
     const Cand& cd = cands[best];
@@ -247,6 +248,8 @@ static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used
     std::memset(static_cast<void*>(&p), 0, sizeof(p));
     p.M = g.M; p.N = g.N; p.K = g.K; p.lda = g.lda; p.ldb = g.ldb; p.ldc = g.ldc; p.ldy = g.ldy;
     p.act = g.act; p.act_grad = g.act_grad; p.accumulate = g.accumulate;
+    static const int barriers_env = getenv("ADN_GEMM_PP_BARRIERS") ? atoi(getenv("ADN_GEMM_PP_BARRIERS")) : 1;   // 2: the two-barrier schedule
+    p.one_barrier = barriers_env != 2;
     p.tiles_m = cdiv(g.M, cd.bm); p.tiles_n = cdiv(g.N, cd.bn);
     p.k_chunk = (int)round_up(cdiv(g.K, splits), 32);
     splits = cdiv(g.K, p.k_chunk);
