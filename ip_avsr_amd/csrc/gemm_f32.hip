@@ -238,9 +238,15 @@ static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used
     if (mode_env < 4) {
         const double fill = ((double)g.M * g.N * n / cus) / best_cost;       // useful share of the tile-rounds
         const bool plain = !g.Y && !g.Y16 && !g.colsum;
-        const bool wgrad = splits > 1 && (int64_t)g.M * g.N >= 400000;
+        // (several weight gradients in one launch only when each alone has too few tiles to split well: three 1000 x 500
+        //  162 -> 89 us, but three 2000 x 1000 332 against 3 x 97)
+        const int64_t per_group_tiles = (int64_t)cdiv(g.M, cands[best].bm) * cdiv(g.N, cands[best].bn);
+        const bool wgrad = splits > 1 && (int64_t)g.M * g.N >= 400000 && (n == 1 || per_group_tiles <= 16);
         const bool fwd_group = splits == 1 && plain && fill >= 0.80;
-        if (!wgrad && !fwd_group) return ADN_OK;
+        // input-gradient GEMMs of several streams (act'(Y) mask from the bf16 copy, fused column sums): 445 against 3 x 153 us
+        // for 20800 x 2000 x 1000, 178 against 3 x 59 for 20800 x 1000 x 500; one alone is no faster than the 128 x 128 kernel
+        const bool bwd_group = splits == 1 && n >= 2 && g.Y16 && fill >= 0.85;
+        if (!wgrad && !fwd_group && !bwd_group) return ADN_OK;
     }
     const Cand& cd = cands[best];
 

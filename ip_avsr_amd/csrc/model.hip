@@ -1169,19 +1169,28 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         ADN_TRY(bucket_ready(0));
     }
     ADN_TRY(fork_streams(m));                 // below the stream LSTMs the S streams back-propagate independently
-    for (size_t si = 0; si < m->st.size(); ++si) {
+    // Per-stream walk state of the encoder's back-propagation.
+    struct Walk {
+        float* dZ = nullptr; int lddz = 0; int bias_done = 0; int L = 0;
+        size_t b_rest = 0; bool split_first = false, active = false;
+        ColSumBatch bias_sums;                 // bf16 mode: every bias reduction of the stream in ONE launch at the end
+    };
+    std::vector<Walk> walk(m->st.size());
+    // everything of stream si above its encoder: LSTM parameter / input gradients, dropout, delta layer, BatchNorm, act'
+    auto stream_head = [&](size_t si) -> int {
         StreamState& st = m->st[si];
-        OnSideStream on(m, (int)si);
+        Walk& w = walk[si];
         const int ldf = ld_of(st.feat_dim);
         const float* in[1] = {st.feat}; const int ld[1] = {ldf};
         for (size_t k = 0; k < st.lstm.size(); ++k)
             ADN_TRY(lstm_param_grads(m, st.lstm[k], st.lw[k], in, ld, 1, st.feat_dim, B, T, stream_sums_done));
         // this stream's buckets: `b_rest` (encoder layers >= 1 + LSTM; the whole stream when it has < 2 encoder layers),
         // then `b_first` (encoder layer 0) where it exists
-        size_t b_rest = 1;
-        for (size_t q = 0; q < si; ++q) b_rest += m->st[q].cfg.n_enc >= 2 ? 2 : 1;
-        const bool split_first = st.cfg.n_enc >= 2;
-        if (st.cfg.n_enc == 0) { ADN_TRY(bucket_ready(b_rest)); continue; }   // nothing trainable below the LSTM
+        w.b_rest = 1;
+        for (size_t q = 0; q < si; ++q) w.b_rest += m->st[q].cfg.n_enc >= 2 ? 2 : 1;
+        w.split_first = st.cfg.n_enc >= 2;
+        w.L = st.cfg.n_enc;
+        if (st.cfg.n_enc == 0) { ADN_TRY(bucket_ready(w.b_rest)); return ADN_OK; }   // nothing trainable below the LSTM
         for (size_t k = 0; k < st.lstm.size(); ++k)
             ADN_TRY(lstm_input_grad(m, st.lstm[k], st.lw[k], 0, st.feat_dim, st.dfeat, ldf, N, k > 0));
         if (m->stochastic && st.cfg.dropout_p > 0.f)
@@ -1203,45 +1212,104 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         if (!last_linear)
             ADN_TRY(act_backward(st.dE, ldE, st.act[L - 1], ldE, N, st.enc_out, st.cfg.enc_act[L - 1], m->stream));
         if (!dE16) ADN_TRY(refresh(m, st.dE, (size_t)N * ldE));
-        float* dZ = st.dE; int lddz = ldE;
-        int bias_done = 0;
-        ColSumBatch bias_sums;                 // bf16 mode: every bias reduction of the stream in ONE launch at the end
-        for (int l = L - 1; l >= 0; --l) {
+        w.dZ = st.dE; w.lddz = ldE; w.bias_done = 0; w.active = true;
+        return ADN_OK;
+    };
+    // encoder layer L - 1 - depth of the streams `sis` (same geometry when more than one): weight gradients, bias
+    // gradients, input gradients -- each kind as ONE grouped launch where the ping-pong kernel takes it
+    auto layer_step = [&](const std::vector<size_t>& sis, int depth) -> int {
+        const int n = (int)sis.size();
+        GemmArgs gws[kMaxGemmGroups], gxs[kMaxGemmGroups];
+        for (int q = 0; q < n; ++q) {
+            StreamState& st = m->st[sis[q]]; Walk& w = walk[sis[q]];
+            const int l = w.L - 1 - depth;
             const int out_w = st.cfg.enc_units[l], in_w = st.enc_in[l];
-            const float* a_prev = l > 0 ? st.act[l - 1] : st.x;
-            const int ld_prev = l > 0 ? ld_of(in_w) : st.ldx;
-            GemmArgs gw;
-            gw.layout = GEMM_TN; gw.M = in_w; gw.N = out_w; gw.K = N; gw.A = a_prev; gw.lda = ld_prev;
-            gw.B = dZ; gw.ldb = lddz; gw.C = m->G(st.encW[l]); gw.ldc = ld_of(out_w); gw.accumulate = 1;
-            if (l == 0 && split_first) {           // everything but layer 0's weight gradient is final: release that bucket
-                ADN_TRY(col_sum_batch(bias_sums, m->stream));                  // (all bias sums are queued by now)
-                ADN_TRY(bucket_ready(b_rest));
+            GemmArgs& gw = gws[q];
+            gw.layout = GEMM_TN; gw.M = in_w; gw.N = out_w; gw.K = N; gw.A = l > 0 ? st.act[l - 1] : st.x;
+            gw.lda = l > 0 ? ld_of(in_w) : st.ldx;
+            gw.B = w.dZ; gw.ldb = w.lddz; gw.C = m->G(st.encW[l]); gw.ldc = ld_of(out_w); gw.accumulate = 1;
+            if (l == 0 && w.split_first) {         // everything but layer 0's weight gradient is final: release that bucket
+                ADN_TRY(col_sum_batch(w.bias_sums, m->stream));                // (all bias sums are queued by now)
+                ADN_TRY(bucket_ready(w.b_rest));
             }
-            ADN_TRY(mgemm(m, gw));
-            if (!bias_done) {
-                if (m->bf16() && dZ == st.dE) col_sum_batch_add(bias_sums, dZ, lddz, (int)N, out_w, m->G(st.encb[l]));   // (dE is not reused)
-                else ADN_TRY(col_sum(dZ, lddz, N, out_w, m->G(st.encb[l]), 1, m->stream));
+            mgemm_prepare(m, gw, false);
+        }
+        ADN_TRY(gemm_grouped(gws, n, m->stream));
+        bool any_dx = false;
+        for (int q = 0; q < n; ++q) {
+            StreamState& st = m->st[sis[q]]; Walk& w = walk[sis[q]];
+            const int l = w.L - 1 - depth;
+            const int out_w = st.cfg.enc_units[l], in_w = st.enc_in[l];
+            if (!w.bias_done) {
+                if (m->bf16() && w.dZ == st.dE) col_sum_batch_add(w.bias_sums, w.dZ, w.lddz, (int)N, out_w, m->G(st.encb[l]));   // (dE is not reused)
+                else ADN_TRY(col_sum(w.dZ, w.lddz, N, out_w, m->G(st.encb[l]), 1, m->stream));
             }
-            bias_done = 0;
-            if (l > 0) {
-                float* dst = (dZ == st.pingA) ? st.pingB : st.pingA;
-                GemmArgs gx;
-                gx.layout = GEMM_NT; gx.M = N; gx.N = in_w; gx.K = out_w; gx.A = dZ; gx.lda = lddz;
-                gx.B = m->P(st.encW[l]); gx.ldb = ld_of(out_w); gx.C = dst; gx.ldc = st.ping_ld;
-                gx.Y = st.act[l - 1]; gx.ldy = ld_of(in_w); gx.act_grad = st.cfg.enc_act[l - 1];
-                gx.colsum = m->G(st.encb[l - 1]); gx.colsum_done = &bias_done;     // db_{l-1} rides on this GEMM
-                gx.colsum_ws = st.colsum_ws + (size_t)l * st.colsum_ws_floats; gx.colsum_ws_floats = st.colsum_ws_floats;
-                gx.colsum_batch = &bias_sums;
-                ADN_TRY(mgemm(m, gx, /*lean=*/true));
-                if (!bias_done && shadows_on(m) && !m->keep_fp32 && in_w % 4 == 0 && m->shadow_of(dst)) {
-                    // fp32 dZ was skipped but the fused column sum did not run: cannot happen for in_w % 4 == 0
-                    set_error("internal: lean dZ without fused bias gradient"); return ADN_ERR_STATE;
+            w.bias_done = 0;
+            if (l == 0) continue;
+            any_dx = true;
+            float* dst = (w.dZ == st.pingA) ? st.pingB : st.pingA;
+            GemmArgs& gx = gxs[q];
+            gx.layout = GEMM_NT; gx.M = N; gx.N = in_w; gx.K = out_w; gx.A = w.dZ; gx.lda = w.lddz;
+            gx.B = m->P(st.encW[l]); gx.ldb = ld_of(out_w); gx.C = dst; gx.ldc = st.ping_ld;
+            gx.Y = st.act[l - 1]; gx.ldy = ld_of(in_w); gx.act_grad = st.cfg.enc_act[l - 1];
+            gx.colsum = m->G(st.encb[l - 1]); gx.colsum_done = &w.bias_done;     // db_{l-1} rides on this GEMM
+            gx.colsum_ws = st.colsum_ws + (size_t)l * st.colsum_ws_floats; gx.colsum_ws_floats = st.colsum_ws_floats;
+            gx.colsum_batch = &w.bias_sums;
+            mgemm_prepare(m, gx, /*lean=*/true);
+        }
+        if (!any_dx) return ADN_OK;                 // (streams of one group share l == 0)
+        ADN_TRY(gemm_grouped(gxs, n, m->stream));
+        for (int q = 0; q < n; ++q) {
+            StreamState& st = m->st[sis[q]]; Walk& w = walk[sis[q]];
+            const int l = w.L - 1 - depth, in_w = st.enc_in[l];
+            float* dst = (w.dZ == st.pingA) ? st.pingB : st.pingA;
+            if (!w.bias_done && shadows_on(m) && !m->keep_fp32 && in_w % 4 == 0 && m->shadow_of(dst)) {
+                // fp32 dZ was skipped but the fused column sum did not run: cannot happen for in_w % 4 == 0
+                set_error("internal: lean dZ without fused bias gradient"); return ADN_ERR_STATE;
+            }
+            w.dZ = dst; w.lddz = st.ping_ld;
+        }
+        return ADN_OK;
+    };
+    auto stream_tail = [&](size_t si) -> int {
+        Walk& w = walk[si];
+        ADN_TRY(col_sum_batch(w.bias_sums, m->stream));
+        return bucket_ready(w.split_first ? w.b_rest + 1 : w.b_rest);        // every gradient of this stream is final
+    };
+    // Layer-major with grouped launches (the streams' layers of equal geometry share tile lists, like the forward pass) on
+    // a single GPU; stream-major when gradient buckets are released to an all-reduce as they complete (data parallel: a
+    // stream's transfer hides under the next stream's GEMMs) or when the streams run on forked HIP streams.
+    const bool layer_major = m->bucket_events.empty() && !streams_concurrent(m) && !getenv("ADN_NO_GROUPED_BACKWARD");
+    if (layer_major) {
+        int max_depth = 0;
+        for (size_t si = 0; si < m->st.size(); ++si) { ADN_TRY(stream_head(si)); max_depth = std::max(max_depth, walk[si].active ? walk[si].L : 0); }
+        for (int d = 0; d < max_depth; ++d) {
+            std::vector<char> done(m->st.size(), 0);
+            for (size_t i = 0; i < m->st.size(); ++i) {
+                if (done[i] || !walk[i].active || d >= walk[i].L) continue;
+                std::vector<size_t> sis{i};
+                done[i] = 1;
+                const StreamState& a = m->st[i];
+                const int la = walk[i].L - 1 - d;
+                for (size_t j = i + 1; j < m->st.size() && sis.size() < (size_t)kMaxGemmGroups; ++j) {
+                    if (done[j] || !walk[j].active || d >= walk[j].L) continue;
+                    const StreamState& o = m->st[j];
+                    const int lo = walk[j].L - 1 - d;
+                    if (o.cfg.enc_units[lo] == a.cfg.enc_units[la] && o.enc_in[lo] == a.enc_in[la] && (lo == 0) == (la == 0) &&
+                        (lo == 0 || o.cfg.enc_act[lo - 1] == a.cfg.enc_act[la - 1])) { sis.push_back(j); done[j] = 1; }
                 }
-                dZ = dst; lddz = st.ping_ld;
+                ADN_TRY(layer_step(sis, d));
             }
         }
-        ADN_TRY(col_sum_batch(bias_sums, m->stream));
-        ADN_TRY(bucket_ready(split_first ? b_rest + 1 : b_rest));        // every gradient of this stream is final
+        for (size_t si = 0; si < m->st.size(); ++si) if (walk[si].active) ADN_TRY(stream_tail(si));
+    } else {
+        for (size_t si = 0; si < m->st.size(); ++si) {
+            OnSideStream on(m, (int)si);
+            ADN_TRY(stream_head(si));
+            if (!walk[si].active) continue;
+            for (int d = 0; d < walk[si].L; ++d) ADN_TRY(layer_step(std::vector<size_t>{si}, d));
+            ADN_TRY(stream_tail(si));
+        }
     }
     ADN_TRY(join_streams(m));
     if (m->bf16()) {                          // this device's exchange status -> tail[1] (summed over ranks by the all-reduce)
