@@ -186,7 +186,9 @@ static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used
     static const int mode_env = getenv("ADN_GEMM_PP") ? atoi(getenv("ADN_GEMM_PP")) : -1;   // 0: off, 4/5/6: force a tile shape
     if (mode_env == 0 || n > kMaxGemmGroups) return ADN_OK;
     if (g.precision != ADN_PRECISION_BF16 || g.layout == GEMM_NT) return ADN_OK;
-    if (g.M < 256 || g.N < 256 || g.K < 256) return ADN_OK;
+    // (one output of < 256 rows wastes too much of its 256-row tiles; several of them in one launch still win: three
+    //  250 x 1000 x 20800 weight gradients 66 against 3 x 33 us, three 150 x 1000 62 against 3 x 30)
+    if (g.M < (n >= 2 ? 128 : 256) || g.N < 256 || g.K < 256) return ADN_OK;
     if (g.N % 4 || g.ldc % 4 || g.lda % 8 || g.ldb % 8) return ADN_OK;
     if (g.layout == GEMM_NN && g.K % 8 && g.lda < round_up(g.K, 8)) return ADN_OK;
     // epilogue forms of the kernel: linear / rectify output; optional rectify'(Y) from the bf16 copy of Y
@@ -241,8 +243,8 @@ static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used
         // (several weight gradients in one launch only when each alone has too few tiles to split well: three 1000 x 500
         //  162 -> 89 us, but three 2000 x 1000 332 against 3 x 97)
         const int64_t per_group_tiles = (int64_t)cdiv(g.M, cands[best].bm) * cdiv(g.N, cands[best].bn);
-        const bool wgrad = splits > 1 && (int64_t)g.M * g.N >= 400000 && (n == 1 || per_group_tiles <= 16);
-        const bool fwd_group = splits == 1 && plain && fill >= 0.80;
+        const bool wgrad = splits > 1 && (int64_t)g.M * g.N * n >= 400000 && (n == 1 || per_group_tiles <= 16);
+        const bool fwd_group = splits == 1 && plain && !g.accumulate && fill >= 0.80;      // (accumulate: the epilogue would read C back)
         // input-gradient GEMMs of several streams (act'(Y) mask from the bf16 copy, fused column sums): 445 against 3 x 153 us
         // for 20800 x 2000 x 1000, 178 against 3 x 59 for 20800 x 1000 x 500; one alone is no faster than the 128 x 128 kernel
         const bool bwd_group = splits == 1 && n >= 2 && g.Y16 && fill >= 0.85;

@@ -1028,6 +1028,39 @@ int lstm_param_grads(adn_model* m, const LstmParams& lp, const LstmWork& w, cons
     return ADN_OK;
 }
 
+// the same for several LSTMs with ONE input block each: their dW_in GEMMs and their dW_hid GEMMs go out as grouped launches
+// (equal shapes share a tile list in the ping-pong kernel; anything else falls back to one launch each)
+struct LstmGradJob { const LstmParams* lp; const LstmWork* w; const float* in; int ld_in; int blkw; };
+int lstm_param_grads_grouped(adn_model* m, const std::vector<LstmGradJob>& jobs, int B, int T, bool sums_done) {
+    const int N = B * T, H = m->H, ldh = m->ldh, ldg = m->ldg;
+    for (int pass = 0; pass < 2; ++pass) {                       // 0: dW_in = X^T dG, 1: dW_hid = H_prev^T dG
+        size_t i = 0;
+        while (i < jobs.size()) {
+            GemmArgs gs[kMaxGemmGroups];
+            int n = 0;
+            const size_t first = i;
+            for (; i < jobs.size() && n < kMaxGemmGroups; ++i) {
+                const LstmGradJob& jb = jobs[i];
+                if (pass == 0 && !jb.in) continue;               // (a concat-fused aggregation LSTM: its dW_in is made elsewhere)
+                if (n && pass == 0 && (jb.blkw != jobs[first].blkw || jb.ld_in != jobs[first].ld_in)) break;
+                GemmArgs& g = gs[n++];
+                g.layout = GEMM_TN; g.N = 4 * H; g.K = N; g.B = jb.w->dG; g.ldb = ldg; g.ldc = ldg; g.accumulate = 1;
+                if (pass == 0) { g.M = jb.blkw; g.A = jb.in; g.lda = jb.ld_in; g.C = m->G(jb.lp->W_in); }
+                else { g.M = H; g.A = jb.w->prev(B, ldh, jb.lp->backwards); g.lda = ldh; g.C = m->G(jb.lp->W_hid); }
+                mgemm_prepare(m, g, false);
+            }
+            if (n) ADN_TRY(gemm_grouped(gs, n, m->stream));
+        }
+    }
+    if (!sums_done)
+        for (const LstmGradJob& jb : jobs) {
+            ADN_TRY(col_sum(jb.w->dG, ldg, N, 4 * H, m->G(jb.lp->b), 1, m->stream));
+            ADN_TRY(col_sum(jb.w->dh_carry, ldh, B, H, m->G(jb.lp->hid_init), 1, m->stream));
+            ADN_TRY(col_sum(jb.w->dc_state, ldh, B, H, m->G(jb.lp->cell_init), 1, m->stream));
+        }
+    return ADN_OK;
+}
+
 // dX (+)= dG W_in^T for input block j
 int lstm_input_grad(adn_model* m, const LstmParams& lp, const LstmWork& w, int j, int blkw, float* dx, int lddx, int rows,
                     bool accumulate) {
@@ -1099,9 +1132,9 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
                 g.A = reinterpret_cast<const float*>(m->cat16); g.lda = ldcat; g.A16 = m->cat16;
                 g.B = w.dG; g.ldb = m->ldg; g.B16 = m->shadow_of(w.dG);
                 g.C = m->wcat_tmp; g.ldc = m->ldg; g.precision = m->cfg.precision;
+                g.splitk_ws = m->splitk_ws; g.splitk_ws_floats = m->splitk_ws_floats;
                 ADN_TRY(gemm(g, s));
                 ADN_TRY(add_row_blocks(m->wcat_tmp, m->G(lp.W_in), m->ldg, m->S, H, ldh, 4 * H, s));
-                ADN_TRY(lstm_param_grads(m, lp, w, nullptr, nullptr, 0, H, B, T, sums_done));     // dW_hid (+ sums)
                 GemmArgs d;                                   // d(concat) (+)= dG W_in^T through the side-by-side W^T copies
                 d.layout = GEMM_NN; d.M = N; d.N = ldcat; d.K = 4 * H;
                 d.A = w.dG; d.lda = m->ldg; d.A16 = m->shadow_of(w.dG);
@@ -1110,6 +1143,11 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
                 ADN_CHECK(d.B16, ADN_ERR_STATE, "internal: transposed copy of an aggregation W_in is missing");
                 d.C = m->dcat; d.ldc = ldcat; d.accumulate = k > 0; d.precision = m->cfg.precision;
                 ADN_TRY(gemm(d, s));
+            }
+            {                                                 // dW_hid (+ sums) of the aggregation LSTMs: one grouped launch
+                std::vector<LstmGradJob> jobs;
+                for (size_t k = 0; k < m->agg.size(); ++k) jobs.push_back(LstmGradJob{&m->agg[k], &m->aggw[k], nullptr, 0, 0});
+                ADN_TRY(lstm_param_grads_grouped(m, jobs, B, T, sums_done));
             }
             for (int j = 0; j < m->S; ++j) { dfin.push_back(m->dcat + (size_t)j * ldh); m->st[j].dout_ld = ldcat; }
         } else {
@@ -1177,12 +1215,12 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
     };
     std::vector<Walk> walk(m->st.size());
     // everything of stream si above its encoder: LSTM parameter / input gradients, dropout, delta layer, BatchNorm, act'
-    auto stream_head = [&](size_t si) -> int {
+    auto stream_head = [&](size_t si, bool lstm_grads_done) -> int {
         StreamState& st = m->st[si];
         Walk& w = walk[si];
         const int ldf = ld_of(st.feat_dim);
         const float* in[1] = {st.feat}; const int ld[1] = {ldf};
-        for (size_t k = 0; k < st.lstm.size(); ++k)
+        for (size_t k = 0; k < st.lstm.size() && !lstm_grads_done; ++k)
             ADN_TRY(lstm_param_grads(m, st.lstm[k], st.lw[k], in, ld, 1, st.feat_dim, B, T, stream_sums_done));
         // this stream's buckets: `b_rest` (encoder layers >= 1 + LSTM; the whole stream when it has < 2 encoder layers),
         // then `b_first` (encoder layer 0) where it exists
@@ -1282,7 +1320,14 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
     const bool layer_major = m->bucket_events.empty() && !streams_concurrent(m) && !getenv("ADN_NO_GROUPED_BACKWARD");
     if (layer_major) {
         int max_depth = 0;
-        for (size_t si = 0; si < m->st.size(); ++si) { ADN_TRY(stream_head(si)); max_depth = std::max(max_depth, walk[si].active ? walk[si].L : 0); }
+        {                                      // parameter gradients of all stream LSTMs: grouped launches
+            std::vector<LstmGradJob> jobs;
+            for (auto& st : m->st)
+                for (size_t k = 0; k < st.lstm.size(); ++k)
+                    jobs.push_back(LstmGradJob{&st.lstm[k], &st.lw[k], st.feat, ld_of(st.feat_dim), st.feat_dim});
+            ADN_TRY(lstm_param_grads_grouped(m, jobs, B, T, stream_sums_done));
+        }
+        for (size_t si = 0; si < m->st.size(); ++si) { ADN_TRY(stream_head(si, true)); max_depth = std::max(max_depth, walk[si].active ? walk[si].L : 0); }
         for (int d = 0; d < max_depth; ++d) {
             std::vector<char> done(m->st.size(), 0);
             for (size_t i = 0; i < m->st.size(); ++i) {
@@ -1305,7 +1350,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
     } else {
         for (size_t si = 0; si < m->st.size(); ++si) {
             OnSideStream on(m, (int)si);
-            ADN_TRY(stream_head(si));
+            ADN_TRY(stream_head(si, false));
             if (!walk[si].active) continue;
             for (int d = 0; d < walk[si].L; ++d) ADN_TRY(layer_step(std::vector<size_t>{si}, d));
             ADN_TRY(stream_tail(si));
