@@ -597,7 +597,12 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams p)
 // ---------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-constexpr int kPpBK = 32, kPpNS = 4, kPpD = 3;
+// ring depth: 4 stages (128 KB of LDS), three in flight.  -DADN_PP_NS=5 (all 160 KB, four in flight) measured no faster on any
+// shape of profiles/gemm_lab: the K-step is not bound by the DMA latency
+#ifndef ADN_PP_NS
+#define ADN_PP_NS 4
+#endif
+constexpr int kPpBK = 32, kPpNS = ADN_PP_NS, kPpD = ADN_PP_NS - 1;
 
 // One LDS-DMA wave-instruction: lane l fetches 16 bytes from its own global address into LDS byte address
 // lds_dst + 16 l (lds_dst wave-uniform, in an SGPR).  Inline asm on purpose: hipcc orders every ds_read behind a
@@ -763,11 +768,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
     // LDS destination of this wave's first piece of a stage in ring slot 0
     const unsigned dstA_w = __builtin_amdgcn_readfirstlane(lds_base + wave * APW * 1024);
     const unsigned dstB_w = __builtin_amdgcn_readfirstlane(lds_base + NS * kAElems * 2 + wave * BPW * 1024);
-    int is_k = 0, is_ord = 0, is_step = 0;                         // next stage to issue: K-step inside its tile, tile, global step
+    int is_k = 0, is_ord = 0, is_slot = 0;                         // next stage to issue: K-step inside its tile, tile, ring slot
     auto issue_one = [&](auto tail_c) {
         constexpr bool tail = decltype(tail_c)::value;
-        const unsigned dA = dstA_w + (unsigned)((is_step & (NS - 1)) * kAElems * 2);
-        const unsigned dB = dstB_w + (unsigned)((is_step & (NS - 1)) * kBElems * 2);
+        const unsigned dA = dstA_w + (unsigned)(is_slot * kAElems * 2);
+        const unsigned dB = dstB_w + (unsigned)(is_slot * kBElems * 2);
         const int k0 = kbeg + is_k * BK;
 #pragma unroll
         for (int t = 0; t < APW; ++t) {
@@ -795,7 +800,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
     auto issue_next = [&]() {
         if (has_tail && is_k == nk - 1) issue_one(std::true_type{});
         else issue_one(std::false_type{});
-        ++is_step;
+        if (++is_slot == NS) is_slot = 0;
         if (++is_k == nk) {
             is_k = 0;
             if (++is_ord < my_tiles) setup_src(is_ord);
@@ -834,7 +839,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
         int younger = min(D - 1, total - 2 - s);                   // younger stages this wave has issued
         if (younger < 0) return;                                   // there is no stage s + 1
         if (fresh_epi) younger = min(younger, 1);
-        if (younger >= 2) wait_vmcnt<2 * PW>();
+        if (D >= 4 && younger >= 3) wait_vmcnt<(D >= 4 ? 3 : 2) * PW>();
+        else if (younger >= 2) wait_vmcnt<2 * PW>();
         else if (younger == 1) wait_vmcnt<PW>();
         else wait_vmcnt<0>();
     };
@@ -879,9 +885,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
             for (int b = 0; b < TN; ++b)
                 acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[b], fa[a], acc[a][b], 0, 0, 0);
     };
+    int rd_slot = 0;
     for (int s = 0; s < total;) {
         // ---------------- the general step.  L(s): fragments of stage s -> registers, DMA for stage s + D
-        read_frags((s & (NS - 1)) * (kAElems * 2), (s & (NS - 1)) * (kBElems * 2));
+        read_frags(rd_slot * (kAElems * 2), rd_slot * (kBElems * 2));
+        if (++rd_slot == NS) rd_slot = 0;
         GSTAMP(0);
         if (s + D < total) issue_next();
         GSTAMP(1);
