@@ -243,7 +243,10 @@ static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used
         // (several weight gradients in one launch only when each alone has too few tiles to split well: three 1000 x 500
         //  162 -> 89 us, but three 2000 x 1000 332 against 3 x 97)
         const int64_t per_group_tiles = (int64_t)cdiv(g.M, cands[best].bm) * cdiv(g.N, cands[best].bn);
-        const bool wgrad = splits > 1 && (int64_t)g.M * g.N * n >= 400000 && (n == 1 || per_group_tiles <= 16);
+        // (... or when the joint launch still fills the device: three 1200 x 2000 take 359 us grouped with 2 slabs each
+        //  against 3 x 120 with 6 slabs each -- the same GEMM time and a third of the reduce traffic)
+        const bool wgrad = splits > 1 && (int64_t)g.M * g.N * n >= 400000 &&
+                           (n == 1 || per_group_tiles <= 16 || per_group_tiles * n * splits * 10 >= (int64_t)cus * 9);
         const bool fwd_group = splits == 1 && plain && !g.accumulate && fill >= 0.80;      // (accumulate: the epilogue would read C back)
         // input-gradient GEMMs of several streams (act'(Y) mask from the bf16 copy, fused column sums): 445 against 3 x 153 us
         // for 20800 x 2000 x 1000, 178 against 3 x 59 for 20800 x 1000 x 500; one alone is no faster than the 128 x 128 kernel
