@@ -562,11 +562,16 @@ int ensure_splitk_ws(adn_model* m) {
     return ADN_OK;
 }
 
+bool streams_concurrent(const adn_model* m);
+
 // fills in the bf16 operand copies of one GEMM of the model (bf16 mode)
 // lean: the fp32 copy of C is not needed by anyone (bf16 mode: every consumer reads the shadow) -> skip writing it
 void mgemm_prepare(adn_model* m, GemmArgs& g, bool lean) {
     g.precision = m->cfg.precision;
-    g.splitk_ws = m->splitk_ws; g.splitk_ws_floats = m->splitk_ws_floats;
+    // (the slab workspace is ONE buffer: with the streams on forked HIP streams their split-K GEMMs would share it
+    //  concurrently -- those runs keep the atomic split-K of the register-staged kernel)
+    const bool shared_ws_ok = !streams_concurrent(m);
+    g.splitk_ws = shared_ws_ok ? m->splitk_ws : nullptr; g.splitk_ws_floats = shared_ws_ok ? m->splitk_ws_floats : 0;
     if (shadows_on(m)) {                                  // env switch: convert-in-flight reference path
         g.A16 = m->shadow_of(g.A);
         g.B16 = m->shadow_of(g.B);
@@ -1132,7 +1137,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
                 g.A = reinterpret_cast<const float*>(m->cat16); g.lda = ldcat; g.A16 = m->cat16;
                 g.B = w.dG; g.ldb = m->ldg; g.B16 = m->shadow_of(w.dG);
                 g.C = m->wcat_tmp; g.ldc = m->ldg; g.precision = m->cfg.precision;
-                g.splitk_ws = m->splitk_ws; g.splitk_ws_floats = m->splitk_ws_floats;
+                g.splitk_ws = m->splitk_ws; g.splitk_ws_floats = m->splitk_ws_floats;      // (main stream: before the fork)
                 ADN_TRY(gemm(g, s));
                 ADN_TRY(add_row_blocks(m->wcat_tmp, m->G(lp.W_in), m->ldg, m->S, H, ldh, 4 * H, s));
                 GemmArgs d;                                   // d(concat) (+)= dG W_in^T through the side-by-side W^T copies

@@ -65,7 +65,8 @@ def runs(tmp_path_factory):
     default = _run(d, "default")
     ref = os.path.join(str(d), "default.npz")
     return dict(default=default, nocluster=_run(d, "nocluster", ref, ADN_LSTM_NO_CLUSTER="1"),
-                nopp=_run(d, "nopp", ref, ADN_GEMM_PP="0"))
+                nopp=_run(d, "nopp", ref, ADN_GEMM_PP="0"), streams=_run(d, "streams", ref, ADN_STREAMS="1"),
+                streammajor=_run(d, "streammajor", ref, ADN_NO_GROUPED_BACKWARD="1"))
 
 
 def _close(a, b, what, p_tol=1e-3, g_tol=3e-2, cos_tol=0.9995, bit_equal_forward=False):
@@ -100,6 +101,15 @@ def test_pingpong_gemm_equals_register_staged_at_b520(runs):
     float atomics in arrival order -> fp32 summation noise only (measured: < 5e-6 relative L2)."""
     _close(runs["default"], runs["nopp"], "ping-pong vs register-staged GEMM kernels", g_tol=1e-4, cos_tol=0.999999,
            bit_equal_forward=True)
+
+
+def test_schedules_of_the_backward_pass_agree_at_b520(runs):
+    """Layer-major back-propagation with grouped launches (the single-GPU default) against the stream-major order (what data
+    parallel runs use) and against the streams on forked HIP streams (ADN_STREAMS=1: no shared split-K workspace there -- a
+    shared one was a race this test caught).  The same products; the weight gradients are summed in a different order."""
+    _close(runs["default"], runs["streammajor"], "layer-major vs stream-major backward", g_tol=1e-4, cos_tol=0.999999,
+           bit_equal_forward=True)
+    _close(runs["default"], runs["streams"], "default vs forked HIP streams", g_tol=1e-4, cos_tol=0.999999, bit_equal_forward=True)
 
 
 def test_bf16_against_the_fp64_oracle_on_a_26_utterance_slice(runs):
