@@ -242,7 +242,10 @@ def _check_grads(m, g_ref, variant):
     gscale = max(np.abs(v).max() for v in g_ref.values())
     for k in CO.param_names(variant):
         err = np.abs(g[k] - g_ref[k]).max()
-        assert err <= 1e-4 * max(np.abs(g_ref[k]).max(), 1e-3 * gscale) + 1e-10, (k, err, np.abs(g_ref[k]).max())
+        # (+ 3e-7 of the largest gradient: a bias in front of a BatchNorm has an almost-zero gradient -- a difference of
+        #  large sums -- whose fp32 float-atomic statistics carry ~1e-7 of arrival-order noise; 1 run in 12 missed 1e-4 of
+        #  1e-3 gscale by 6 %)
+        assert err <= 1e-4 * max(np.abs(g_ref[k]).max(), 1e-3 * gscale) + 3e-7 * gscale, (k, err, np.abs(g_ref[k]).max())
 
 
 def test_variant_zoo_factories_and_trainer(ConvAE, tmp_path):
