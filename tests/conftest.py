@@ -17,3 +17,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _seed_global_numpy_rng(request):
+    """The model-zoo factories draw their initial weights from NumPy's global generator, as Lasagne's initialisers do (the
+    reference never seeds it).  A test must not depend on the draw: every test starts from a seed derived from its own id."""
+    import zlib
+    import numpy as np
+    np.random.seed(zlib.crc32(request.node.nodeid.encode()) & 0xFFFFFFFF)
+    yield
