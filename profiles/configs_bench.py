@@ -62,8 +62,8 @@ for name, dims, classes, batches, make in CONFIGS:
         for precision in ("f32", "bf16"):
             m = unwrap(make())
             m.set_precision(precision)
-            for _ in range(3):
-                m.train_step(x, y, mask, THETA, 1e-4, want_loss=False)
+            for _ in range(20):                      # (the GPU idles while the host builds the model: at the small batches the
+                m.train_step(x, y, mask, THETA, 1e-4, want_loss=False)      #  first ~10 steps can run 3x slower until the clocks are back)
             m.synchronize()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             steps = 10
