@@ -49,8 +49,10 @@ __device__ __forceinline__ bool cae_keep(uint32_t key, uint32_t idx, float p) { 
 // kernels
 // ---------------------------------------------------------------------------------------------------------
 // cols[(b, oy, ox)][(i*kw + j)*C + c] = x[b][oy + i - ph][ox + j - pw][c]  (0 outside); row stride ldc
+// `up` = 1: the patch rows belong to a 2x upscaled grid and are wanted SUMMED over every 2 x 2 block of it (OH, OW = the
+// compact grid): row (b, oy, ox) = sum over dy, dx in {0, 1} of the patch at (2 oy + dy, 2 ox + dx) -- see deconv_bwd
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, float* __restrict__ cols, int B, int H, int W,
-                                                     int C, int kh, int kw, int ph, int pw, int OH, int OW, int ldc) {
+                                                     int C, int kh, int kw, int ph, int pw, int OH, int OW, int ldc, int up) {
     const int K = kh * kw * C;
     const int64_t total = (int64_t)B * OH * OW * K;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
@@ -58,18 +60,23 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x
         const int64_t r = e / K;
         const int c = k % C, ij = k / C, j = ij % kw, i = ij / kw;
         const int ox = (int)(r % OW), oy = (int)((r / OW) % OH), b = (int)(r / ((int64_t)OW * OH));
-        const int y = oy + i - ph, xx = ox + j - pw;
         float v = 0.f;
-        if (y >= 0 && y < H && xx >= 0 && xx < W) v = x[(((size_t)b * H + y) * W + xx) * C + c];
+        for (int dy = 0; dy <= up; ++dy)
+            for (int dx = 0; dx <= up; ++dx) {
+                const int y = (up ? 2 * oy + dy : oy) + i - ph, xx = (up ? 2 * ox + dx : ox) + j - pw;
+                if (y >= 0 && y < H && xx >= 0 && xx < W) v += x[(((size_t)b * H + y) * W + xx) * C + c];
+            }
         cols[(size_t)r * ldc + k] = v;
     }
 }
 
 // out[b][y][x][c] = sum_{i,j} dcols[(b, y + ph - i, x + pw - j)][(i*kw + j)*C + c]  over valid patch positions
 // (gather form of col2im: no atomics); optional bias[c] and activation
+// `up` = 1: the patch rows exist for the compact (OH / 2) x (OW / 2) grid only and every row stands for the 2 x 2 block of the
+// upscaled grid it was repeated into (Upscale2DLayer folded into the gather: x_up W^T = repeat(x W^T))
 __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ dcols, int ldc, float* __restrict__ out, int B, int H,
                                                      int W, int C, int kh, int kw, int ph, int pw, int OH, int OW,
-                                                     const float* __restrict__ bias, int act) {
+                                                     const float* __restrict__ bias, int act, int up) {
     const int64_t total = (int64_t)B * H * W * C;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int c = (int)(e % C);
@@ -82,7 +89,7 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ d
             for (int j = 0; j < kw; ++j) {
                 const int ox = x + pw - j;
                 if (ox < 0 || ox >= OW) continue;
-                acc += dcols[(((size_t)b * OH + oy) * OW + ox) * ldc + (i * kw + j) * C + c];
+                acc += dcols[(up ? ((size_t)b * (OH / 2) + oy / 2) * (OW / 2) + ox / 2 : ((size_t)b * OH + oy) * OW + ox) * ldc + (i * kw + j) * C + c];
             }
         }
         out[e] = cae_act(act, acc);
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ d
 
 // the same two kernels for C % 4 == 0, four channels per thread (float4 both ways, a quarter of the index arithmetic)
 __global__ __launch_bounds__(256) void im2col4_kernel(const float4* __restrict__ x, float4* __restrict__ cols, int B, int H, int W,
-                                                      int C4, int kh, int kw, int ph, int pw, int OH, int OW, int ldc4) {
+                                                      int C4, int kh, int kw, int ph, int pw, int OH, int OW, int ldc4, int up) {
     const int K4 = kh * kw * C4;
     const int64_t total = (int64_t)B * OH * OW * K4;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -100,14 +107,22 @@ __global__ __launch_bounds__(256) void im2col4_kernel(const float4* __restrict__
         const int64_t r = e / K4;
         const int c = k % C4, ij = k / C4, j = ij % kw, i = ij / kw;
         const int ox = (int)(r % OW), oy = (int)((r / OW) % OH), b = (int)(r / ((int64_t)OW * OH));
-        const int y = oy + i - ph, xx = ox + j - pw;
-        cols[(size_t)r * ldc4 + k] = (y >= 0 && y < H && xx >= 0 && xx < W) ? x[(((size_t)b * H + y) * W + xx) * C4 + c] : z;
+        float4 v = z;
+        for (int dy = 0; dy <= up; ++dy)
+            for (int dx = 0; dx <= up; ++dx) {
+                const int y = (up ? 2 * oy + dy : oy) + i - ph, xx = (up ? 2 * ox + dx : ox) + j - pw;
+                if (y >= 0 && y < H && xx >= 0 && xx < W) {
+                    const float4 t = x[(((size_t)b * H + y) * W + xx) * C4 + c];
+                    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+                }
+            }
+        cols[(size_t)r * ldc4 + k] = v;
     }
 }
 
 __global__ __launch_bounds__(256) void col2im4_kernel(const float4* __restrict__ dcols, int ldc4, float4* __restrict__ out, int B,
                                                       int H, int W, int C4, int kh, int kw, int ph, int pw, int OH, int OW,
-                                                      const float4* __restrict__ bias, int act) {
+                                                      const float4* __restrict__ bias, int act, int up) {
     const int64_t total = (int64_t)B * H * W * C4;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int c = (int)(e % C4);
@@ -120,7 +135,7 @@ __global__ __launch_bounds__(256) void col2im4_kernel(const float4* __restrict__
             for (int j = 0; j < kw; ++j) {
                 const int ox = x + pw - j;
                 if (ox < 0 || ox >= OW) continue;
-                const float4 v = dcols[(((size_t)b * OH + oy) * OW + ox) * ldc4 + (i * kw + j) * C4 + c];
+                const float4 v = dcols[(up ? ((size_t)b * (OH / 2) + oy / 2) * (OW / 2) + ox / 2 : ((size_t)b * OH + oy) * OW + ox) * ldc4 + (i * kw + j) * C4 + c];
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
         }
@@ -132,7 +147,7 @@ __global__ __launch_bounds__(256) void col2im4_kernel(const float4* __restrict__
 // im2col straight to bf16 (C % 4 == 0): the patches matrix of the bf16 GEMMs, half the bytes of the fp32 one
 typedef __bf16 cae_bf16x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void im2col4_bf16_kernel(const float4* __restrict__ x, cae_bf16x4* __restrict__ cols, int B, int H,
-                                                           int W, int C4, int kh, int kw, int ph, int pw, int OH, int OW, int ldc4) {
+                                                           int W, int C4, int kh, int kw, int ph, int pw, int OH, int OW, int ldc4, int up) {
     const int K4 = kh * kw * C4;
     const int64_t total = (int64_t)B * OH * OW * K4;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
@@ -140,9 +155,15 @@ __global__ __launch_bounds__(256) void im2col4_bf16_kernel(const float4* __restr
         const int64_t r = e / K4;
         const int c = k % C4, ij = k / C4, j = ij % kw, i = ij / kw;
         const int ox = (int)(r % OW), oy = (int)((r / OW) % OH), b = (int)(r / ((int64_t)OW * OH));
-        const int y = oy + i - ph, xx = ox + j - pw;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (y >= 0 && y < H && xx >= 0 && xx < W) v = x[(((size_t)b * H + y) * W + xx) * C4 + c];
+        for (int dy = 0; dy <= up; ++dy)
+            for (int dx = 0; dx <= up; ++dx) {
+                const int y = (up ? 2 * oy + dy : oy) + i - ph, xx = (up ? 2 * ox + dx : ox) + j - pw;
+                if (y >= 0 && y < H && xx >= 0 && xx < W) {
+                    const float4 t = x[(((size_t)b * H + y) * W + xx) * C4 + c];
+                    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+                }
+            }
         cae_bf16x4 o; o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
         cols[(size_t)r * ldc4 + k] = o;
     }
@@ -401,35 +422,39 @@ int mm16(adn_cae* m, int layout, int M, int N, int K, const void* A16, int lda, 
     return gemm(g, m->stream);
 }
 
-int im2col16(adn_cae* m, const float* x, const ConvGeom& g, int B, void* cols16) {
-    const int64_t total = (int64_t)rows_of(g, B) * g.K;
+// `up`: the rows are wanted for the compact (OH / 2) x (OW / 2) grid, each the sum of the 2 x 2 block of the upscaled grid
+int im2col16(adn_cae* m, const float* x, const ConvGeom& g, int B, void* cols16, int up = 0) {
+    const int oh = up ? g.OH / 2 : g.OH, ow = up ? g.OW / 2 : g.OW;
+    const int64_t total = (int64_t)B * oh * ow * g.K;
     hipLaunchKernelGGL(im2col4_bf16_kernel, dim3(grid_of(total / 4)), dim3(256), 0, m->stream, reinterpret_cast<const float4*>(x),
-                       reinterpret_cast<cae_bf16x4*>(cols16), B, g.H, g.W, g.C / 4, g.k, g.k, g.ph, g.pw, g.OH, g.OW, g.ldk / 4);
+                       reinterpret_cast<cae_bf16x4*>(cols16), B, g.H, g.W, g.C / 4, g.k, g.k, g.ph, g.pw, oh, ow, g.ldk / 4, up);
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }
 
-int im2col(adn_cae* m, const float* x, const ConvGeom& g, int B, float* cols) {
-    const int64_t total = (int64_t)rows_of(g, B) * g.K;
+int im2col(adn_cae* m, const float* x, const ConvGeom& g, int B, float* cols, int up = 0) {
+    const int oh = up ? g.OH / 2 : g.OH, ow = up ? g.OW / 2 : g.OW;
+    const int64_t total = (int64_t)B * oh * ow * g.K;
     if (g.C % 4 == 0)
         hipLaunchKernelGGL(im2col4_kernel, dim3(grid_of(total / 4)), dim3(256), 0, m->stream, reinterpret_cast<const float4*>(x),
-                           reinterpret_cast<float4*>(cols), B, g.H, g.W, g.C / 4, g.k, g.k, g.ph, g.pw, g.OH, g.OW, g.ldk / 4);
+                           reinterpret_cast<float4*>(cols), B, g.H, g.W, g.C / 4, g.k, g.k, g.ph, g.pw, oh, ow, g.ldk / 4, up);
     else
     hipLaunchKernelGGL(im2col_kernel, dim3(grid_of(total)), dim3(256), 0, m->stream, x, cols, B, g.H, g.W, g.C, g.k, g.k, g.ph, g.pw,
-                       g.OH, g.OW, g.ldk);
+                       oh, ow, g.ldk, up);
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }
 
-int col2im(adn_cae* m, const float* dcols, const ConvGeom& g, int B, float* out, const float* bias, int act) {
+// `up`: dcols holds the rows of the compact grid; every row stands for a 2 x 2 block of the (OH x OW) grid
+int col2im(adn_cae* m, const float* dcols, const ConvGeom& g, int B, float* out, const float* bias, int act, int up = 0) {
     const int64_t total = (int64_t)B * g.H * g.W * g.C;
     if (g.C % 4 == 0)
         hipLaunchKernelGGL(col2im4_kernel, dim3(grid_of(total / 4)), dim3(256), 0, m->stream, reinterpret_cast<const float4*>(dcols),
                            g.ldk / 4, reinterpret_cast<float4*>(out), B, g.H, g.W, g.C / 4, g.k, g.k, g.ph, g.pw, g.OH, g.OW,
-                           reinterpret_cast<const float4*>(bias), act);
+                           reinterpret_cast<const float4*>(bias), act, up);
     else
     hipLaunchKernelGGL(col2im_kernel, dim3(grid_of(total)), dim3(256), 0, m->stream, dcols, g.ldk, out, B, g.H, g.W, g.C, g.k, g.k,
-                       g.ph, g.pw, g.OH, g.OW, bias, act);
+                       g.ph, g.pw, g.OH, g.OW, bias, act, up);
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }
@@ -467,29 +492,35 @@ int conv_bwd(adn_cae* m, const ConvGeom& g, int B, const float* cols, const floa
 }
 
 // z = act(adjoint_conv(x) + b): x [B*OH*OW][O] -> z [B][H][W][C]   (g = the tied convolution, crop = its padding)
-// x16: bf16 copy of x (kept for the backward pass), null = fp32 path
-int deconv_fwd(adn_cae* m, const float* x, void* x16, const ConvGeom& g, int B, size_t W, size_t b, float* z) {
+// x16: bf16 copy of x (kept for the backward pass), null = fp32 path.
+// up = 1: the layer's input is Upscale2DLayer(x), x on the compact (OH / 2) x (OW / 2) grid.  The upscaled tensor is never
+// built: repeat(x) W^T = repeat(x W^T), so the GEMM runs on a quarter of the rows and the gather reads row (oy / 2, ox / 2)
+// (modelzoo/avletters_convae.py:62-66: upscale2d12 / upscale2d14 in front of deconv2d13 / deconv2d14; deconv2d13 was 106 of
+// the forward pass's 231 MFLOP per frame)
+int deconv_fwd(adn_cae* m, const float* x, void* x16, const ConvGeom& g, int B, size_t W, size_t b, float* z, int up = 0) {
+    const int R = (int)rows_of(g, B) / (up ? 4 : 1);
     if (x16 && fast16(m, g)) {
-        const int R = (int)rows_of(g, B);
         ADN_TRY(to_bf16(x, x16, (size_t)R * g.O, m->stream));
         ADN_TRY(mm16(m, GEMM_NT, R, g.K, g.O, x16, g.O, W16(m, W), g.O, m->scratch, g.ldk));
-        return col2im(m, m->scratch, g, B, z, m->P(b), m->S);
+        return col2im(m, m->scratch, g, B, z, m->P(b), m->S, up);
     }
-    ADN_TRY(mm(m, GEMM_NT, (int)rows_of(g, B), g.K, g.O, x, g.O, m->P(W), g.O, m->scratch, g.ldk));
-    return col2im(m, m->scratch, g, B, z, m->P(b), m->S);
+    ADN_TRY(mm(m, GEMM_NT, R, g.K, g.O, x, g.O, m->P(W), g.O, m->scratch, g.ldk));
+    return col2im(m, m->scratch, g, B, z, m->P(b), m->S, up);
 }
 
-// dz (already multiplied by act') -> db, dW (tied), dx
+// dz (already multiplied by act') -> db, dW (tied), dx.  up = 1: x and dx live on the compact grid; the adjoint of the 2 x 2
+// repetition is a sum, and it commutes with the products: dx = (sum4 cols') Wm, dW += (sum4 cols')^T x -- the patches are
+// summed while they are gathered (im2col `up`), both GEMMs run on a quarter of the rows
 int deconv_bwd(adn_cae* m, const ConvGeom& g, int B, const float* x, const void* x16, const float* dz, size_t W, size_t b,
-               float* dx) {
-    const int R = (int)rows_of(g, B);
+               float* dx, int up = 0) {
+    const int R = (int)rows_of(g, B) / (up ? 4 : 1);
     ADN_TRY(col_sum(dz, g.C, B * g.H * g.W, g.C, m->G(b), 1, m->stream));
     if (x16 && fast16(m, g)) {
-        ADN_TRY(im2col16(m, dz, g, B, m->scratch));
+        ADN_TRY(im2col16(m, dz, g, B, m->scratch, up));
         ADN_TRY(mm16(m, GEMM_NN, R, g.O, g.K, m->scratch, g.ldk, W16(m, W), g.O, dx, g.O));
         return mm16(m, GEMM_TN, g.K, g.O, R, m->scratch, g.ldk, x16, g.O, m->G(W), g.O, nullptr, ADN_ACT_LINEAR, 1);
     }
-    ADN_TRY(im2col(m, dz, g, B, m->scratch));
+    ADN_TRY(im2col(m, dz, g, B, m->scratch, up));
     ADN_TRY(mm(m, GEMM_NN, R, g.O, g.K, m->scratch, g.ldk, m->P(W), g.O, dx, g.O));
     return mm(m, GEMM_TN, g.K, g.O, R, m->scratch, g.ldk, x, g.O, m->G(W), g.O, nullptr, ADN_ACT_LINEAR, 1);
 }
@@ -600,10 +631,9 @@ int forward(adn_cae* m, int B, bool decode) {
     ADN_TRY(mm(m, GEMM_NT, B, m->D7, m->NB, m->code, m->ldb, m->P(m->Wb), m->ldb, m->a8, m->D7, m->P(m->b8)));
     ADN_TRY(mm(m, GEMM_NT, B, m->flat, m->D7, m->a8, m->D7, m->P(m->W7), m->D7, m->a9, m->flat, m->P(m->b9), S));
     ADN_TRY(deconv_fwd(m, m->a9, m->a9_16, m->d11, B, m->W5, m->b11, m->a11));
-    ADN_TRY(upscale_fwd(m, m->a11, B, m->d11.H, m->d11.W, m->F2, m->u12));
-    ADN_TRY(deconv_fwd(m, m->u12, m->u12_16, m->d13, B, m->W3, m->b13, m->a13));
-    ADN_TRY(upscale_fwd(m, m->a13, B, m->d13.H, m->d13.W, m->F1, m->u14));
-    return deconv_fwd(m, m->u14, nullptr, m->d15, B, m->W1, m->b15, m->a15);
+    // (upscale2d12 / upscale2d14 are folded into the deconvolutions behind them)
+    ADN_TRY(deconv_fwd(m, m->a11, m->u12_16, m->d13, B, m->W3, m->b13, m->a13, 1));
+    return deconv_fwd(m, m->a13, nullptr, m->d15, B, m->W1, m->b15, m->a15, 1);
 }
 
 // loss_dev[0] = mean((recon - target)^2); gA = d loss / d recon when want_grad
@@ -629,11 +659,9 @@ int backward(adn_cae* m, int B) {
     const int P2 = B * m->p2h * m->p2w, P4 = B * m->p4h * m->p4w;
     // decoder
     ADN_TRY(act_backward(gA, 1, m->a15, 1, B * m->H * m->W, 1, S, s));
-    ADN_TRY(deconv_bwd(m, m->d15, B, m->u14, nullptr, gA, m->W1, m->b15, gB));                    // gB = d u14
-    ADN_TRY(upscale_bwd(m, gB, B, m->d13.H, m->d13.W, F1, gA));                           // gA = d a13
-    ADN_TRY(act_backward(gA, F1, m->a13, F1, B * m->d13.H * m->d13.W, F1, S, s));
-    ADN_TRY(deconv_bwd(m, m->d13, B, m->u12, m->u12_16, gA, m->W3, m->b13, gB));                    // gB = d u12
-    ADN_TRY(upscale_bwd(m, gB, B, m->d11.H, m->d11.W, F2, gA));                           // gA = d a11
+    ADN_TRY(deconv_bwd(m, m->d15, B, m->a13, nullptr, gA, m->W1, m->b15, gB, 1));                  // gB = d a13 (through upscale2d14)
+    ADN_TRY(act_backward(gB, F1, m->a13, F1, B * m->d13.H * m->d13.W, F1, S, s));
+    ADN_TRY(deconv_bwd(m, m->d13, B, m->a11, m->u12_16, gB, m->W3, m->b13, gA, 1));                // gA = d a11 (through upscale2d12)
     ADN_TRY(act_backward(gA, F2, m->a11, F2, B * m->d11.H * m->d11.W, F2, S, s));
     ADN_TRY(deconv_bwd(m, m->d11, B, m->a9, m->a9_16, gA, m->W5, m->b11, gB));                     // gB = d a9 (as [B][flat])
     ADN_TRY(act_backward(gB, m->flat, m->a9, m->flat, B, m->flat, S, s));

@@ -1,8 +1,10 @@
 """Conv auto-encoder training-step throughput and MFMA utilisation, beside the NumPy oracle on the host.
 
 One step = forward + mean-squared error + backward + adadelta on a batch of 128 frames of 30x40 (the reference's batch,
-avletters/avletters_convae.py:276) resident in HBM.  FLOPs counted = 2 M N K of every GEMM the step launches (im2col /
-col2im data movement is not arithmetic).
+avletters/avletters_convae.py:276) resident in HBM.  FLOPs counted = 2 M N K of every GEMM of the layer-by-layer formulation (im2col /
+col2im data movement is not arithmetic; since round 2 the two Upscale2DLayers are folded into the deconvolutions behind them,
+which runs those layers' three GEMMs on a quarter of the rows -- the count stays the reference formulation's, so the TFLOP/s
+figure is an effective one).
 
     python profiles/convae_bench.py        (on an MI355X)
 """
