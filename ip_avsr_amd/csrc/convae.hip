@@ -192,8 +192,16 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
     }
 }
 
+// (act_y != null: the pooled tensor was act(z); the gradient is multiplied by act'(z) from the activation's output in the same
+//  pass -- one sweep over the full-resolution tensor instead of two)
+__device__ __forceinline__ float cae_act_grad(int act, float y) {
+    if (act == ADN_ACT_SCALED_TANH) { const float t = y * (1.f / 2.4f); return 1.2f * (1.f - t * t); }
+    if (act == ADN_ACT_SCALED_TANH_LECUN) { const float t = y * (1.f / 1.7159f); return (2.f / 3.f) * 1.7159f * (1.f - t * t); }
+    return 1.f;
+}
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ arg,
-                                                          float* __restrict__ dx, int B, int H, int W, int C, int ph, int OH, int OW) {
+                                                          float* __restrict__ dx, int B, int H, int W, int C, int ph, int OH, int OW,
+                                                          const float* __restrict__ act_y, int act) {
     const int64_t total = (int64_t)B * H * W * C;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int c = (int)(e % C);
@@ -205,6 +213,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
             const size_t o = (((size_t)b * OH + oy) * OW + ox) * C + c;
             if ((int)arg[o] == ((y + ph) & 1) * 2 + (x & 1)) g = dy[o];
         }
+        if (act_y && g != 0.f) g *= cae_act_grad(act, act_y[e]);
         dx[e] = g;
     }
 }
@@ -530,8 +539,10 @@ int maxpool_fwd(adn_cae* m, const float* x, int B, int H, int W, int C, int ph, 
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }
-int maxpool_bwd(adn_cae* m, const float* dy, const uint8_t* arg, int B, int H, int W, int C, int ph, int OH, int OW, float* dx) {
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_of((int64_t)B * H * W * C)), dim3(256), 0, m->stream, dy, arg, dx, B, H, W, C, ph, OH, OW);
+int maxpool_bwd(adn_cae* m, const float* dy, const uint8_t* arg, int B, int H, int W, int C, int ph, int OH, int OW, float* dx,
+                const float* act_y = nullptr) {
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_of((int64_t)B * H * W * C)), dim3(256), 0, m->stream, dy, arg, dx, B, H, W, C, ph, OH, OW,
+                       act_y, m->S);
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }
@@ -688,15 +699,20 @@ int backward(adn_cae* m, int B) {
     ADN_TRY(conv_bwd(m, m->c5, B, m->cols5, gB, m->W5, m->b5, gA));                       // gA = d (conv5 input)
     ADN_TRY(dropout_inplace(m, 2, gA, P4, m->p4h * m->p4w, m->F2L, F2));
     if (m->bn_mode == 1) ADN_TRY(bn_bwd(m, 1, m->p4, gA, P4));                             // gA = d p4
-    ADN_TRY(maxpool_bwd(m, gA, m->arg4, B, m->c3.OH, m->c3.OW, F2, 1, m->p4h, m->p4w, gB));           // gB = d (pool input)
-    if (m->bn_mode == 2) ADN_TRY(bn_bwd(m, 1, m->a3, gB, R3));                             // gB = d a3
-    ADN_TRY(act_backward(gB, F2, m->a3, F2, R3, F2, S, s));
+    // (the pooling's input is the activation itself unless a BatchNorm sits between them: act' rides on the pooling's backward)
+    ADN_TRY(maxpool_bwd(m, gA, m->arg4, B, m->c3.OH, m->c3.OW, F2, 1, m->p4h, m->p4w, gB, m->bn_mode == 2 ? nullptr : m->a3));   // gB = d (pool input)
+    if (m->bn_mode == 2) {
+        ADN_TRY(bn_bwd(m, 1, m->a3, gB, R3));                                             // gB = d a3
+        ADN_TRY(act_backward(gB, F2, m->a3, F2, R3, F2, S, s));
+    }
     ADN_TRY(conv_bwd(m, m->c3, B, m->cols3, gB, m->W3, m->b3, gA));                       // gA = d (conv3 input)
     ADN_TRY(dropout_inplace(m, 1, gA, P2, m->p2h * m->p2w, m->F1L, F1));
     if (m->bn_mode == 1) ADN_TRY(bn_bwd(m, 0, m->p2, gA, P2));                             // gA = d p2
-    ADN_TRY(maxpool_bwd(m, gA, m->arg2, B, m->c1.OH, m->c1.OW, F1, 0, m->p2h, m->p2w, gB));           // gB = d (pool input)
-    if (m->bn_mode == 2) ADN_TRY(bn_bwd(m, 0, m->a1, gB, R1));                             // gB = d a1
-    ADN_TRY(act_backward(gB, F1, m->a1, F1, R1, F1, S, s));
+    ADN_TRY(maxpool_bwd(m, gA, m->arg2, B, m->c1.OH, m->c1.OW, F1, 0, m->p2h, m->p2w, gB, m->bn_mode == 2 ? nullptr : m->a1));   // gB = d (pool input)
+    if (m->bn_mode == 2) {
+        ADN_TRY(bn_bwd(m, 0, m->a1, gB, R1));                                             // gB = d a1
+        ADN_TRY(act_backward(gB, F1, m->a1, F1, R1, F1, S, s));
+    }
     ADN_TRY(conv_bwd(m, m->c1, B, m->cols1, gB, m->W1, m->b1, nullptr));
     m->grads_valid = true;
     return ADN_OK;
