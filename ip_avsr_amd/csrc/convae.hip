@@ -218,27 +218,6 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void upscale_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C) {
-    const int64_t total = (int64_t)B * 2 * H * 2 * W * C;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int c = (int)(e % C);
-        const int64_t p = e / C;
-        const int xx = (int)(p % (2 * W)), yy = (int)((p / (2 * W)) % (2 * H)), b = (int)(p / ((int64_t)4 * W * H));
-        y[e] = x[(((size_t)b * H + yy / 2) * W + xx / 2) * C + c];
-    }
-}
-
-__global__ __launch_bounds__(256) void upscale_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int H, int W, int C) {
-    const int64_t total = (int64_t)B * H * W * C;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int c = (int)(e % C);
-        const int64_t p = e / C;
-        const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((int64_t)W * H));
-        const size_t base = (((size_t)b * 2 * H + 2 * y) * 2 * W + 2 * x) * C + c;
-        dx[e] = dy[base] + dy[base + C] + dy[base + (size_t)2 * W * C] + dy[base + (size_t)2 * W * C + C];
-    }
-}
-
 // d = scale * (recon - target);  sq[i] = (recon - target)^2 summed into *loss_acc by the caller's dot product
 __global__ __launch_bounds__(256) void mse_grad_kernel(const float* __restrict__ r, const float* __restrict__ t, float* __restrict__ d,
                                                        int64_t n, float scale) {
@@ -307,7 +286,7 @@ struct adn_cae {
     char* slab = nullptr; size_t slab_bytes = 0; int wsB = 0;
     float *x0 = nullptr, *cols1 = nullptr, *a1 = nullptr, *p2 = nullptr, *cols3 = nullptr, *a3 = nullptr, *p4 = nullptr,
           *cols5 = nullptr, *a5 = nullptr, *a7 = nullptr, *code = nullptr, *a8 = nullptr, *a9 = nullptr, *a11 = nullptr,
-          *u12 = nullptr, *a13 = nullptr, *u14 = nullptr, *a15 = nullptr, *target = nullptr, *scratch = nullptr,
+          *a13 = nullptr, *a15 = nullptr, *target = nullptr, *scratch = nullptr,
           *gA = nullptr, *gB = nullptr, *loss_dev = nullptr, *f6d = nullptr, *a7d = nullptr;
     // what each layer actually read in the last forward pass (the BatchNorm output where one sits in front of it)
     const float *in3 = nullptr, *in5 = nullptr, *in7 = nullptr, *inb = nullptr;
@@ -363,9 +342,7 @@ size_t carve(adn_cae* m, char* base, int B) {
     m->a7 = c.take<float>(N * m->D7); m->code = c.take<float>(N * m->ldb);
     m->a8 = c.take<float>(N * m->D7); m->a9 = c.take<float>(N * m->flat);
     m->a11 = c.take<float>(N * m->d11.H * m->d11.W * m->F2);
-    m->u12 = c.take<float>(N * 4 * m->d11.H * m->d11.W * m->F2);
     m->a13 = c.take<float>(N * m->d13.H * m->d13.W * m->F1);
-    m->u14 = c.take<float>(N * 4 * m->d13.H * m->d13.W * m->F1);
     m->a15 = c.take<float>(N * m->H * m->W);
     m->target = c.take<float>(N * m->H * m->W);
     size_t sc = 0, act = N * m->H * m->W;
@@ -377,7 +354,7 @@ size_t carve(adn_cae* m, char* base, int B) {
     m->gA = c.take<float>(act); m->gB = c.take<float>(act);
     m->loss_dev = c.take<float>(8);
     m->a9_16 = c.take<char>(N * m->flat * 2);
-    m->u12_16 = c.take<char>(N * 4 * m->d11.H * m->d11.W * m->F2 * 2);
+    m->u12_16 = c.take<char>(N * m->d11.H * m->d11.W * m->F2 * 2);           // bf16 copy of a11 (the compact input of deconv2d13)
     m->t16 = c.take<char>(act * 2);
     if (m->drop && m->bn_mode == 0) { m->f6d = c.take<float>(N * m->flat); m->a7d = c.take<float>(N * m->D7); }   // dropped copies of a5 / a7
     if (m->bn_mode) {                                 // BatchNorm outputs, batch statistics, workspaces
@@ -546,17 +523,6 @@ int maxpool_bwd(adn_cae* m, const float* dy, const uint8_t* arg, int B, int H, i
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }
-int upscale_fwd(adn_cae* m, const float* x, int B, int H, int W, int C, float* y) {
-    hipLaunchKernelGGL(upscale_fwd_kernel, dim3(grid_of((int64_t)B * 4 * H * W * C)), dim3(256), 0, m->stream, x, y, B, H, W, C);
-    ADN_HIP_CHECK(hipGetLastError());
-    return ADN_OK;
-}
-int upscale_bwd(adn_cae* m, const float* dy, int B, int H, int W, int C, float* dx) {
-    hipLaunchKernelGGL(upscale_bwd_kernel, dim3(grid_of((int64_t)B * H * W * C)), dim3(256), 0, m->stream, dy, dx, B, H, W, C);
-    ADN_HIP_CHECK(hipGetLastError());
-    return ADN_OK;
-}
-
 int stage(adn_cae* m, const float* x, const float* target, int B, int flags) {
     const hipMemcpyKind kind = (flags & ADN_FLAG_DEVICE_INPUTS) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     const size_t bytes = (size_t)B * m->H * m->W * sizeof(float);
