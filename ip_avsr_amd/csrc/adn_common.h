@@ -224,6 +224,7 @@ struct LstmStep {          // one LSTM instance taking part in a (possibly multi
     const void* W_hid16;   // [H][ldg]   bf16: W_hid as stored (row = k of the forward, contiguous gate columns)
     const void* W_frag_fwd;  // W_hid in MFMA-fragment order for the persistent kernels (lstm_persistent.hip)
     const void* W_frag_bwd;
+    const void* W_frag_fwd_lo = nullptr;   // bf16x3 mode: the fragment image of W_hid - bf16(W_hid) (W_frag_fwd then holds the hi part)
     void* h16;             // [(T+1)*B][ldh] bf16 shadow of hbuf
     void* dG16;            // [T*B][ldg]     bf16 shadow of dG
     void* xchg = nullptr;  // exchange buffer of the weight-stationary kernels (lstm_cluster.hip), lstm_cluster_xchg_bytes(B)
@@ -244,7 +245,7 @@ bool lstm_persistent_supported(int H);
 size_t lstm_frag_elems(int H);
 int lstm_pack_frags(const float* W, void* fwd, void* bwd, int H, hipStream_t s);
 // the same for n <= 8 LSTMs in one launch
-int lstm_pack_frags_batch(int n, const float* const* W, void* const* fwd, void* const* bwd, int H, hipStream_t s);
+int lstm_pack_frags_batch(int n, const float* const* W, void* const* fwd, void* const* bwd, int H, hipStream_t s, int lo_part = 0);
 int repack_rows_bf16(int n, const float* const* in, void* const* out, int nblk, int rows, int rows_pad, int ld, hipStream_t s);
 int lstm_forward_persistent(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
 int lstm_backward_persistent(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s,
@@ -253,6 +254,8 @@ int lstm_backward_persistent(const LstmStep* l, int n, const uint8_t* mask_tb, i
 bool lstm_cluster_supported(const LstmStep* l, int n, int B, int T, int H);
 size_t lstm_cluster_xchg_bytes(int B, int H);
 int lstm_forward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
+bool lstm_cluster_x3_supported(const LstmStep* l, int n, int B, int T, int H);
+int lstm_forward_cluster_x3(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
 int lstm_backward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
 int lstm_cluster_error_word(int** out);   // device word raised by a poll that gave up (checked at synchronisation)
 static inline int lstm_ldk(int H) { return (int)((H + 31) / 32 * 32); }

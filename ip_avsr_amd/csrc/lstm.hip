@@ -315,6 +315,11 @@ int lstm_pack_whid_t(const float* W, void* out, int H, hipStream_t s) {
 
 int lstm_forward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, int precision, hipStream_t s) {
     ADN_CHECK(n >= 1 && n <= kMaxLstmPerLaunch, ADN_ERR_INVALID, "lstm_forward: bad LSTM count");
+    // bf16x3 mode: the weight-stationary forward kernel with fp32-grade products where it applies, the fp32 step kernels else
+    if (precision == ADN_PRECISION_BF16X3) {
+        if (lstm_cluster_x3_supported(l, n, B, T, H)) return lstm_forward_cluster_x3(l, n, mask_tb, B, T, H, s);
+        precision = ADN_PRECISION_F32;
+    }
     LstmLaunch L;
     bool have16 = precision == ADN_PRECISION_BF16;
     for (int k = 0; k < n; ++k) { L.l[k] = l[k]; have16 = have16 && l[k].W_hid16T && l[k].h16; }

@@ -305,6 +305,149 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const LstmCluster
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// bf16x3 forward (ADN_PRECISION_BF16X3, H <= 256): the same schedule with fp32-grade recurrent products.
+//   h = hi + lo and W_hid = W_hi + W_lo in bf16;  h W ~ h_hi W_hi + h_lo W_hi + h_hi W_lo  (fp32 accumulate, 2^-17 per product)
+// Resources of a workgroup (4 per 32-utterance group): W_hi fragments in registers as in the bf16 kernel (128 VGPRs);
+// W_lo: k-steps 0..6 in LDS (112 KB), k-step 7 in 16 more VGPRs; both h images in LDS (2 x 16.5 KB).  A granule carries
+// the (hi, lo) pair of ONE (row, unit) -- 16 polled granules per thread and step (all four workgroups' slots of its
+// column, its own included: the addresses are one base plus constants).  State, gates and outputs stay fp32; no bf16
+// shadows are read or written.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kX3KsLds = 7;                                            // k-steps of W_lo that live in LDS
+constexpr int kX3WLds = 4 * 4 * kX3KsLds * 512;                        // [4 unit tiles][4 gates][7][64][8] bf16
+__global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClusterP L, const uint8_t* __restrict__ mask_tb,
+                                                                  int B, int T, int H, int ldh, int ldg, unsigned tag0, int* err) {
+    using G = ClusterGeom<4>;
+    constexpr int CWG = 4, HP = G::HP, KS = G::KS, HS = G::HS, NF = 16;
+    extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
+    __bf16* wl = lds;
+    __bf16 (*hs_hi)[HS] = reinterpret_cast<__bf16 (*)[HS]>(lds + kX3WLds);
+    __bf16 (*hs_lo)[HS] = reinterpret_cast<__bf16 (*)[HS]>(lds + kX3WLds + kCRows * HS);
+    const LstmStep& P = L.l[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int group = blockIdx.x / CWG, j = blockIdx.x % CWG;
+    const int r0 = group * kCRows;
+    const int rt = wave >> 2, ut = wave & 3;
+    const int u = kCUnits * j + 16 * ut + i;
+    const int uc = min(u, H - 1);
+    // exchange buffer of the group: [2 parities][32 rows][HP units] granules
+    unsigned long long* xb = reinterpret_cast<unsigned long long*>(P.xchg) + (size_t)group * 2 * kCRows * HP;
+
+    const bf16x8* wsrc_hi = reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(P.W_frag_fwd) + (size_t)j * G::WElems);
+    const bf16x8* wsrc_lo = reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(P.W_frag_fwd_lo) + (size_t)j * G::WElems);
+    for (int e = tid; e < kX3WLds / 8; e += 512) {
+        const int l64 = e & 63, s_ = (e >> 6) % kX3KsLds, tg = (e >> 6) / kX3KsLds;         // tg = 4 * unit tile + gate
+        reinterpret_cast<bf16x8*>(wl)[e] = wsrc_lo[((size_t)tg * KS + s_) * 64 + l64];
+    }
+    bf16x8 wreg[4][KS], wreg_lo[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) wreg[g][s_] = wsrc_hi[((size_t)(4 * ut + g) * KS + s_) * 64 + lane];
+        wreg_lo[g] = wsrc_lo[((size_t)(4 * ut + g) * KS + kX3KsLds) * 64 + lane];
+    }
+    // ---- initial state: both images from the fp32 block
+    const int blk0 = P.backwards ? T : 0;
+    for (int e = tid; e < kCRows * HP; e += 512) {
+        const int rr = e / HP, cc = e % HP;
+        const float v = cc < H ? P.hbuf[((size_t)blk0 * B + min(r0 + rr, B - 1)) * ldh + cc] : 0.f;
+        const __bf16 hi = (__bf16)v;
+        hs_hi[rr][cc] = hi;
+        hs_lo[rr][cc] = (__bf16)(v - (float)hi);
+    }
+    float c_st[4], h_st[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const size_t idx = ((size_t)blk0 * B + min(r0 + 16 * rt + 4 * kq + r, B - 1)) * ldh + uc;
+        c_st[r] = P.cbuf[idx];
+        h_st[r] = P.hbuf[idx];
+    }
+    __syncthreads();
+
+    const bf16x8* wfrag_lo = reinterpret_cast<const bf16x8*>(wl) + (size_t)ut * 4 * kX3KsLds * 64 + lane;
+    uint8_t m[4];
+    float4 xp[4];
+    for (int step = 0; step < T; ++step) {
+        const int t = P.backwards ? (T - 1 - step) : step;
+        const int out_blk = t + (P.backwards ? 0 : 1);
+        const unsigned tag = tag0 + (unsigned)step;
+        unsigned long long* xpar = xb + (size_t)(step & 1) * kCRows * HP;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const size_t ridx = (size_t)t * B + min(r0 + 16 * rt + 4 * kq + r, B - 1);
+            m[r] = mask_tb[ridx];
+            xp[r] = *reinterpret_cast<const float4*>(P.xproj + ridx * ldg + uc * 4);
+        }
+        // ---- recurrent product: three MFMAs per (gate, k-step)
+        f32x4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bf16x8 a_hi = *reinterpret_cast<const bf16x8*>(&hs_hi[16 * rt + i][s * 32 + kq * 8]);
+            const bf16x8 a_lo = *reinterpret_cast<const bf16x8*>(&hs_lo[16 * rt + i][s * 32 + kq * 8]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const bf16x8 w_lo = s < kX3KsLds ? wfrag_lo[(g * kX3KsLds + (s < kX3KsLds ? s : 0)) * 64] : wreg_lo[g];
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, wreg[g][s], acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, wreg[g][s], acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, w_lo, acc[g], 0, 0, 0);
+            }
+        }
+        lds_barrier();                                // every wave has read h_{t-1}: the images may be overwritten
+        // ---- gate math, row by row: publish (the partners are waiting), own image, outputs -- nothing of a row stays live
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float a_i = xp[r].x + acc[0][r], a_f = xp[r].y + acc[1][r];
+            float a_g = xp[r].z + acc[2][r], a_o = xp[r].w + acc[3][r];
+            const float c_prev = c_st[r], h_prev = h_st[r];
+            if (P.peep) { a_i += c_prev * P.peep[uc]; a_f += c_prev * P.peep[ldh + uc]; }
+            const float gi = c_sigmoid(a_i), gf = c_sigmoid(a_f), gg = c_tanh(a_g);
+            const float c_new = gf * c_prev + gi * gg;
+            if (P.peep) a_o += c_new * P.peep[2 * ldh + uc];
+            const float go = c_sigmoid(a_o);
+            const float h_new = go * c_tanh(c_new);
+            c_st[r] = m[r] ? c_new : c_prev;
+            float h_o = m[r] ? h_new : h_prev;
+            h_st[r] = h_o;
+            if (u >= H) h_o = 0.f;
+            bf16x2 pr; pr[0] = (__bf16)h_o; pr[1] = (__bf16)(h_o - (float)pr[0]);
+            const int row = 16 * rt + 4 * kq + r;
+            granule_store(xpar + (size_t)row * HP + u, __builtin_bit_cast(unsigned, pr), tag);
+            hs_hi[row][u] = pr[0];
+            hs_lo[row][u] = pr[1];
+            const int grow = r0 + row;
+            if (u < H && grow < B) {
+                const size_t ridx = (size_t)t * B + grow;
+                const size_t oidx = ((size_t)out_blk * B + grow) * ldh + u;
+                P.cbuf[oidx] = c_st[r];
+                P.hbuf[oidx] = h_o;
+                if (P.gates) *reinterpret_cast<float4*>(P.gates + ridx * ldg + u * 4) = make_float4(gi, gf, gg, go);
+            }
+        }
+        // ---- gather h_t of every workgroup's units (own slots included: already there)
+        if (step + 1 < T) {
+            const unsigned long long* ptr[NF];
+            unsigned pay[NF];
+            const unsigned long long* base = xpar + (size_t)(tid >> 6) * HP + (tid & 63);
+#pragma unroll
+            for (int k = 0; k < NF; ++k) { pay[k] = 0u; ptr[k] = base + (size_t)(8 * (k & 3)) * HP + kCUnits * (k >> 2); }
+            granule_wait<NF>(ptr, tag, pay, err);
+#pragma unroll
+            for (int k = 0; k < NF; ++k) {
+                if ((k >> 2) == j) continue;          // own units: written above
+                const bf16x2 pr = __builtin_bit_cast(bf16x2, pay[k]);
+                const int row = (tid >> 6) + 8 * (k & 3), fu = kCUnits * (k >> 2) + (tid & 63);
+                hs_hi[row][fu] = pr[0];
+                hs_lo[row][fu] = pr[1];
+            }
+        }
+        lds_barrier();
+    }
+}
+
 // =========================================================================================
 // backward (BPTT): see lstm.hip for the per-step math
 // =========================================================================================
@@ -644,6 +787,46 @@ static int forward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int
 
 int lstm_forward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s) {
     return H <= 256 ? forward_cluster<4>(l, n, mask_tb, B, T, H, s) : forward_cluster<8>(l, n, mask_tb, B, T, H, s);
+}
+
+// bf16x3 forward (lstm_fwd_cluster_x3_kernel): H <= 256, hi and lo fragment images of W_hid, the exchange buffer of the bf16
+// kernels (its forward region needs 2 x 32 x 256 granules per group: less than the buffer's forward + backward regions)
+bool lstm_cluster_x3_supported(const LstmStep* l, int n, int B, int T, int H) {
+    if (H > 256 || T >= 1024 || getenv("ADN_LSTM_NO_CLUSTER") || getenv("ADN_LSTM_NO_X3_CLUSTER")) return false;
+    for (int k = 0; k < n; ++k)
+        if (!l[k].xchg || !l[k].W_frag_fwd || !l[k].W_frag_fwd_lo) return false;
+    if (cdiv(B, kCRows) * 4 > cluster_cus()) return false;
+    return lstm_frag_elems(H) == (size_t)4 * 256 * 256 &&
+           (size_t)cdiv(B, kCRows) * 2 * kCRows * 256 * 8 <= lstm_cluster_xchg_bytes(B, H);
+}
+
+int lstm_forward_cluster_x3(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s) {
+    using G = ClusterGeom<4>;
+    const int groups = cdiv(B, kCRows), per = groups * 4, cus = cluster_cus();
+    ADN_CHECK(cus >= per, ADN_ERR_STATE, "lstm cluster kernel: one LSTM does not fit the device");
+    int* err = nullptr;
+    ADN_TRY(lstm_cluster_error_word(&err));
+    const int ldh = ld_of(H), ldg = ld_of(4 * H);
+    const size_t lds = (size_t)(kX3WLds + 2 * kCRows * G::HS) * 2;
+    static bool attr_set[kMaxDevices] = {};
+    bool& attr = attr_set[current_device()];
+    if (!attr) {
+        ADN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_cluster_x3_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    const double bytes = (double)n * T * (4.0 * (12.0 * B * H + 4.0 * H * H) + B), flops = (double)n * T * 8.0 * B * H * H;
+    ProfScope prof(PROF_LSTM_FWD, flops, bytes, s, T);
+    const int chunk = std::max(1, cus / per);
+    for (int k0 = 0; k0 < n; k0 += chunk) {
+        const int nn = std::min(chunk, n - k0);
+        LstmClusterP L;
+        for (int k = 0; k < nn; ++k) L.l[k] = l[k0 + k];
+        const unsigned tag0 = (g_cluster_epoch++ & 0x3fffffu) * 1024u + 1u;
+        hipLaunchKernelGGL(lstm_fwd_cluster_x3_kernel, dim3(per, nn), dim3(512), lds, s, L, mask_tb, B, T, H, ldh, ldg, tag0, err);
+        ADN_HIP_CHECK(hipGetLastError());
+    }
+    return ADN_OK;
 }
 
 template <int CWG>

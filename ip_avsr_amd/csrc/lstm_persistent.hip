@@ -323,7 +323,8 @@ __global__ __launch_bounds__(512) void lstm_bwd_persistent_kernel(const LstmLaun
 //   bwd: [UW*8/16 unit tiles][4*UW*8/32 k-steps][64 lanes][8]     value = W[unit][k], unit = 16*tile + (lane&15)
 // with k = 32*step + 8*(lane>>4) + j; zero outside the matrix.
 struct PackFragArgs { const float* W[8]; void* fwd[8]; void* bwd[8]; };
-__global__ __launch_bounds__(256) void pack_frags_kernel(const PackFragArgs a, int H, int ldg, int UW) {
+// lo_part: the images of W - bf16(W) instead of W (bf16x3 mode: hi and lo fragment images); null targets are skipped
+__global__ __launch_bounds__(256) void pack_frags_kernel(const PackFragArgs a, int H, int ldg, int UW, int lo_part) {
     const float* __restrict__ W = a.W[blockIdx.y];
     __bf16* __restrict__ fwd = reinterpret_cast<__bf16*>(a.fwd[blockIdx.y]);
     __bf16* __restrict__ bwd = reinterpret_cast<__bf16*>(a.bwd[blockIdx.y]);
@@ -335,25 +336,29 @@ __global__ __launch_bounds__(256) void pack_frags_kernel(const PackFragArgs a, i
             const int ks = HP / 32, s = rest % ks, tile = rest / ks;      // tile = 4 * (16-unit tile) + gate
             const int unit = 16 * (tile >> 2) + (lane & 15), col = 4 * unit + (tile & 3);
             const int k = 32 * s + 8 * (lane >> 4) + j;
-            fwd[e] = (__bf16)((k < H && unit < H) ? W[(size_t)k * ldg + col] : 0.f);
+            float v = (k < H && unit < H) ? W[(size_t)k * ldg + col] : 0.f;
+            if (lo_part) v -= (float)(__bf16)v;
+            if (fwd) fwd[e] = (__bf16)v;
         }
         {   // backward image
             const int j = e & 7, lane = (e >> 3) & 63, rest = e >> 9;
             const int ks = GP / 32, s = rest % ks, tile = rest / ks;
             const int unit = 16 * tile + (lane & 15), k = 32 * s + 8 * (lane >> 4) + j;
-            bwd[e] = (__bf16)((unit < H && k < 4 * H) ? W[(size_t)unit * ldg + k] : 0.f);
+            float v = (unit < H && k < 4 * H) ? W[(size_t)unit * ldg + k] : 0.f;
+            if (lo_part) v -= (float)(__bf16)v;
+            if (bwd) bwd[e] = (__bf16)v;
         }
     }
 }
 
 size_t lstm_frag_elems(int H) { const int UW = H <= 256 ? 32 : 64; return (size_t)4 * UW * kPWaves * UW * kPWaves; }
 
-int lstm_pack_frags_batch(int n, const float* const* W, void* const* fwd, void* const* bwd, int H, hipStream_t s) {
+int lstm_pack_frags_batch(int n, const float* const* W, void* const* fwd, void* const* bwd, int H, hipStream_t s, int lo_part) {
     ADN_CHECK(n >= 1 && n <= 8, ADN_ERR_INVALID, "lstm_pack_frags_batch: 1..8 matrices per launch");
     const int UW = H <= 256 ? 32 : 64;
     PackFragArgs a{};
-    for (int k = 0; k < n; ++k) { a.W[k] = W[k]; a.fwd[k] = fwd[k]; a.bwd[k] = bwd[k]; }
-    hipLaunchKernelGGL(pack_frags_kernel, dim3(1024, n), dim3(256), 0, s, a, H, ld_of(4 * H), UW);
+    for (int k = 0; k < n; ++k) { a.W[k] = W[k]; a.fwd[k] = fwd ? fwd[k] : nullptr; a.bwd[k] = bwd ? bwd[k] : nullptr; }
+    hipLaunchKernelGGL(pack_frags_kernel, dim3(1024, n), dim3(256), 0, s, a, H, ld_of(4 * H), UW, lo_part);
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }
