@@ -22,6 +22,8 @@
 #include "adn_common.h"
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
+#include <unordered_map>
 
 namespace adn {
 
@@ -308,54 +310,69 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const LstmCluster
 // ---------------------------------------------------------------------------------------------------------
 // bf16x3 forward (ADN_PRECISION_BF16X3, H <= 256): the same schedule with fp32-grade recurrent products.
 //   h = hi + lo and W_hid = W_hi + W_lo in bf16;  h W ~ h_hi W_hi + h_lo W_hi + h_hi W_lo  (fp32 accumulate, 2^-17 per product)
-// Resources of a workgroup (4 per 32-utterance group): W_hi fragments in registers as in the bf16 kernel (128 VGPRs);
-// W_lo: k-steps 0..6 in LDS (112 KB), k-step 7 in 16 more VGPRs; both h images in LDS (2 x 16.5 KB).  A granule carries
-// the (hi, lo) pair of ONE (row, unit) -- 16 polled granules per thread and step (all four workgroups' slots of its
-// column, its own included: the addresses are one base plus constants).  State, gates and outputs stay fp32; no bf16
-// shadows are read or written.
+// Resources of a workgroup (4 per 32-utterance group): the hi AND lo fragments of its 128 K-element W slice sit in
+// registers with no copy held twice -- for the product, wave w takes unit tile w & 3 and the gate PAIR w >> 2 for both
+// 16-row tiles (2 gates x 8 k-steps x (hi + lo) = 128 VGPRs; the bf16 kernel's (row tile, unit tile) split keeps every
+// fragment in two waves, which leaves no room for the lo part).  The accumulators then cross to the gate-math lanes
+// ((row tile, unit tile) per wave: all 4 gates of a (row, unit) in one lane) through 32 KB of LDS, on the barrier the
+// step needs anyway; both h images live in LDS (2 x 16.5 KB).  A step costs 96 MFMAs per wave (1.3 us of the matrix pipe
+// at 2 waves per SIMD) against 32 in the bf16 kernel.
+// Exchange: h_t travels as q = h rounded to a 16-bit significand -- exactly what hi + lo can hold (hi = bf16(q), lo = q - hi
+// is exact in bf16) -- in the top 24 bits of its fp32 pattern; the freed low byte carries half of a 16-bit step tag, so one
+// 8-byte granule holds 2 rows of one unit as in the bf16 kernel (6 foreign granules per thread and step: 3 partners x
+// 2 row pairs).  The owner builds its own images from the same q: all four workgroups multiply identical operands.  A 16-bit tag cannot be made
+// unique over all launches of a process the way the bf16 kernel's 32-bit tag is; the host numbers the launches PER
+// EXCHANGE BUFFER instead (x3_launch_seq): a slot can only hold values of the previous launch on the same buffer or of
+// this one, and those differ in the sequence bits or, within a launch, in the step.  State, gates and outputs stay
+// fp32; no bf16 shadows are read or written.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kX3KsLds = 7;                                            // k-steps of W_lo that live in LDS
-constexpr int kX3WLds = 4 * 4 * kX3KsLds * 512;                        // [4 unit tiles][4 gates][7][64][8] bf16
-__global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClusterP L, const uint8_t* __restrict__ mask_tb,
-                                                                  int B, int T, int H, int ldh, int ldg, unsigned tag0, int* err) {
+struct LstmClusterX3P {
+    LstmStep l[kMaxLstmPerLaunch];
+    unsigned tag0[kMaxLstmPerLaunch];                                  // 1024 seq + 1, seq in [0, 64): tag0 + step < 65536
+};
+__device__ __forceinline__ unsigned x3_quant(float h) { return (__builtin_bit_cast(unsigned, h) + 0x80u) & ~0xffu; }
+__device__ __forceinline__ void x3_split(unsigned qbits, __bf16& hi, __bf16& lo) {
+    const float q = __builtin_bit_cast(float, qbits);
+    hi = (__bf16)q;
+    lo = (__bf16)(q - (float)hi);
+}
+constexpr int kX3AccLds = 4 * 2 * 4 * 64 * 4;                          // fp32 words: [4 gates][2 row tiles][4 unit tiles][64 lanes] x 4 rows
+__global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClusterX3P L, const uint8_t* __restrict__ mask_tb,
+                                                                  int B, int T, int H, int ldh, int ldg, int* err) {
     using G = ClusterGeom<4>;
-    constexpr int CWG = 4, HP = G::HP, KS = G::KS, HS = G::HS, NF = 16;
+    constexpr int CWG = 4, HP = G::HP, KS = G::KS, HS = G::HS, NF = 8;
+    const unsigned tag0 = L.tag0[blockIdx.y];
     extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
-    __bf16* wl = lds;
-    __bf16 (*hs_hi)[HS] = reinterpret_cast<__bf16 (*)[HS]>(lds + kX3WLds);
-    __bf16 (*hs_lo)[HS] = reinterpret_cast<__bf16 (*)[HS]>(lds + kX3WLds + kCRows * HS);
+    __bf16 (*hs_hi)[HS] = reinterpret_cast<__bf16 (*)[HS]>(lds);
+    __bf16 (*hs_lo)[HS] = reinterpret_cast<__bf16 (*)[HS]>(lds + kCRows * HS);
+    f32x4* xacc = reinterpret_cast<f32x4*>(lds + 2 * kCRows * HS);       // (2 * 32 * 264 * 2 bytes: 16-byte aligned)
     const LstmStep& P = L.l[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, kq = lane >> 4;
     const int group = blockIdx.x / CWG, j = blockIdx.x % CWG;
     const int r0 = group * kCRows;
-    const int rt = wave >> 2, ut = wave & 3;
+    const int rt = wave >> 2, ut = wave & 3;          // gate math: row tile, unit tile;  product: gate pair rt, unit tile ut
     const int u = kCUnits * j + 16 * ut + i;
     const int uc = min(u, H - 1);
-    // exchange buffer of the group: [2 parities][32 rows][HP units] granules
-    unsigned long long* xb = reinterpret_cast<unsigned long long*>(P.xchg) + (size_t)group * 2 * kCRows * HP;
+    // exchange buffer of the group: [2 parities][16 row pairs][HP units] granules
+    unsigned long long* xb = reinterpret_cast<unsigned long long*>(P.xchg) + (size_t)group * 2 * 16 * HP;
 
     const bf16x8* wsrc_hi = reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(P.W_frag_fwd) + (size_t)j * G::WElems);
     const bf16x8* wsrc_lo = reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(P.W_frag_fwd_lo) + (size_t)j * G::WElems);
-    for (int e = tid; e < kX3WLds / 8; e += 512) {
-        const int l64 = e & 63, s_ = (e >> 6) % kX3KsLds, tg = (e >> 6) / kX3KsLds;         // tg = 4 * unit tile + gate
-        reinterpret_cast<bf16x8*>(wl)[e] = wsrc_lo[((size_t)tg * KS + s_) * 64 + l64];
-    }
-    bf16x8 wreg[4][KS], wreg_lo[4];
+    bf16x8 whi[2][KS], wlo[2][KS];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int gi = 0; gi < 2; ++gi)
 #pragma unroll
-        for (int s_ = 0; s_ < KS; ++s_) wreg[g][s_] = wsrc_hi[((size_t)(4 * ut + g) * KS + s_) * 64 + lane];
-        wreg_lo[g] = wsrc_lo[((size_t)(4 * ut + g) * KS + kX3KsLds) * 64 + lane];
-    }
+        for (int s_ = 0; s_ < KS; ++s_) {
+            whi[gi][s_] = wsrc_hi[((size_t)(4 * ut + 2 * rt + gi) * KS + s_) * 64 + lane];
+            wlo[gi][s_] = wsrc_lo[((size_t)(4 * ut + 2 * rt + gi) * KS + s_) * 64 + lane];
+        }
     // ---- initial state: both images from the fp32 block
     const int blk0 = P.backwards ? T : 0;
     for (int e = tid; e < kCRows * HP; e += 512) {
         const int rr = e / HP, cc = e % HP;
         const float v = cc < H ? P.hbuf[((size_t)blk0 * B + min(r0 + rr, B - 1)) * ldh + cc] : 0.f;
-        const __bf16 hi = (__bf16)v;
-        hs_hi[rr][cc] = hi;
-        hs_lo[rr][cc] = (__bf16)(v - (float)hi);
+        x3_split(x3_quant(v), hs_hi[rr][cc], hs_lo[rr][cc]);
     }
     float c_st[4], h_st[4];
 #pragma unroll
@@ -366,38 +383,58 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClus
     }
     __syncthreads();
 
-    const bf16x8* wfrag_lo = reinterpret_cast<const bf16x8*>(wl) + (size_t)ut * 4 * kX3KsLds * 64 + lane;
     uint8_t m[4];
     float4 xp[4];
     for (int step = 0; step < T; ++step) {
         const int t = P.backwards ? (T - 1 - step) : step;
         const int out_blk = t + (P.backwards ? 0 : 1);
         const unsigned tag = tag0 + (unsigned)step;
-        unsigned long long* xpar = xb + (size_t)(step & 1) * kCRows * HP;
+        unsigned long long* xpar = xb + (size_t)(step & 1) * 16 * HP;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const size_t ridx = (size_t)t * B + min(r0 + 16 * rt + 4 * kq + r, B - 1);
             m[r] = mask_tb[ridx];
             xp[r] = *reinterpret_cast<const float4*>(P.xproj + ridx * ldg + uc * 4);
         }
-        // ---- recurrent product: three MFMAs per (gate, k-step)
-        f32x4 acc[4];
+        // ---- recurrent product of this wave's gate pair, both row tiles: three MFMAs per (gate, row tile, k-step)
+        f32x4 pacc[2][2];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) pacc[gi][q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const bf16x8 a_hi = *reinterpret_cast<const bf16x8*>(&hs_hi[16 * rt + i][s * 32 + kq * 8]);
-            const bf16x8 a_lo = *reinterpret_cast<const bf16x8*>(&hs_lo[16 * rt + i][s * 32 + kq * 8]);
+            bf16x8 a_hi[2], a_lo[2];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const bf16x8 w_lo = s < kX3KsLds ? wfrag_lo[(g * kX3KsLds + (s < kX3KsLds ? s : 0)) * 64] : wreg_lo[g];
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, wreg[g][s], acc[g], 0, 0, 0);
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, wreg[g][s], acc[g], 0, 0, 0);
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, w_lo, acc[g], 0, 0, 0);
+            for (int q = 0; q < 2; ++q) {
+                a_hi[q] = *reinterpret_cast<const bf16x8*>(&hs_hi[16 * q + i][s * 32 + kq * 8]);
+                a_lo[q] = *reinterpret_cast<const bf16x8*>(&hs_lo[16 * q + i][s * 32 + kq * 8]);
             }
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) pacc[gi][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[q], whi[gi][s], pacc[gi][q], 0, 0, 0);
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) pacc[gi][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[q], whi[gi][s], pacc[gi][q], 0, 0, 0);
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) pacc[gi][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[q], wlo[gi][s], pacc[gi][q], 0, 0, 0);
         }
-        lds_barrier();                                // every wave has read h_{t-1}: the images may be overwritten
-        // ---- gate math, row by row: publish (the partners are waiting), own image, outputs -- nothing of a row stays live
+        // accumulator lane map = gate-math lane map (unit lane & 15, rows 4 (lane >> 4) ..+3): hand each tile to its wave
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) xacc[(((2 * rt + gi) * 2 + q) * 4 + ut) * 64 + lane] = pacc[gi][q];
+        lds_barrier();                                // every wave has read h_{t-1} (the images may be overwritten); tiles are in place
+        f32x4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = xacc[((g * 2 + rt) * 4 + ut) * 64 + lane];
+        // ---- gate math, row by row: own images, publish each row pair at once (the partners are waiting), outputs --
+        //      nothing of a row stays live
+        unsigned q_even = 0u;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float a_i = xp[r].x + acc[0][r], a_f = xp[r].y + acc[1][r];
@@ -413,11 +450,15 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClus
             float h_o = m[r] ? h_new : h_prev;
             h_st[r] = h_o;
             if (u >= H) h_o = 0.f;
-            bf16x2 pr; pr[0] = (__bf16)h_o; pr[1] = (__bf16)(h_o - (float)pr[0]);
+            const unsigned qb = x3_quant(h_o);
             const int row = 16 * rt + 4 * kq + r;
-            granule_store(xpar + (size_t)row * HP + u, __builtin_bit_cast(unsigned, pr), tag);
-            hs_hi[row][u] = pr[0];
-            hs_lo[row][u] = pr[1];
+            x3_split(qb, hs_hi[row][u], hs_lo[row][u]);
+            if (r & 1)
+                __hip_atomic_store(xpar + (size_t)(8 * rt + 2 * kq + (r >> 1)) * HP + u,
+                                   ((unsigned long long)(qb | (tag >> 8)) << 32) | (q_even | (tag & 255u)), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            else
+                q_even = qb;
             const int grow = r0 + row;
             if (u < H && grow < B) {
                 const size_t ridx = (size_t)t * B + grow;
@@ -427,21 +468,39 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClus
                 if (P.gates) *reinterpret_cast<float4*>(P.gates + ridx * ldg + u * 4) = make_float4(gi, gf, gg, go);
             }
         }
-        // ---- gather h_t of every workgroup's units (own slots included: already there)
+        // ---- gather the partners' h_t: slot k = (workgroup k >> 1, row pair (tid >> 6) + 8 (k & 1)) of this thread's unit
+        //      column; the own workgroup's two slots are skipped (already in the images).  Global and LDS addresses are
+        //      one base plus compile-time constants.
         if (step + 1 < T) {
-            const unsigned long long* ptr[NF];
-            unsigned pay[NF];
-            const unsigned long long* base = xpar + (size_t)(tid >> 6) * HP + (tid & 63);
+            const unsigned long long* p0 = xpar + (size_t)(tid >> 6) * HP + (tid & 63);
+            const unsigned long long* p1 = p0 + (size_t)8 * HP;
+            __bf16* img = &hs_hi[2 * (tid >> 6)][tid & 63];              // lo image: + kCRows * HS elements
+            unsigned long long g[NF];
+            unsigned pending = ((1u << NF) - 1u) & ~(3u << (2 * j));
+            unsigned long long t_start = 0;
+            for (int spin = 0; pending; ++spin) {
+                unsigned long long v[NF];
 #pragma unroll
-            for (int k = 0; k < NF; ++k) { pay[k] = 0u; ptr[k] = base + (size_t)(8 * (k & 3)) * HP + kCUnits * (k >> 2); }
-            granule_wait<NF>(ptr, tag, pay, err);
+                for (int k = 0; k < NF; ++k)
+                    if (pending & (1u << k)) v[k] = granule_load(((k & 1) ? p1 : p0) + kCUnits * (k >> 1));
+#pragma unroll
+                for (int k = 0; k < NF; ++k)
+                    if ((pending & (1u << k)) && (((unsigned)v[k] & 255u) | (((unsigned)(v[k] >> 32) & 255u) << 8)) == tag) {
+                        g[k] = v[k]; pending &= ~(1u << k);
+                    }
+                if (pending && (spin & 1023) == 1023) {
+                    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                    const unsigned long long now = wall_ticks();
+                    if (!t_start) t_start = now;
+                    else if (now - t_start > kPollTimeoutTicks) { atomicCAS(err, 0, 1 | ((int)(step & 1023) << 4) | ((int)blockIdx.x << 16)); break; }
+                }
+            }
 #pragma unroll
             for (int k = 0; k < NF; ++k) {
-                if ((k >> 2) == j) continue;          // own units: written above
-                const bf16x2 pr = __builtin_bit_cast(bf16x2, pay[k]);
-                const int row = (tid >> 6) + 8 * (k & 3), fu = kCUnits * (k >> 2) + (tid & 63);
-                hs_hi[row][fu] = pr[0];
-                hs_lo[row][fu] = pr[1];
+                if ((k >> 1) == j) continue;
+                __bf16* d = img + (16 * (k & 1)) * HS + kCUnits * (k >> 1);
+                x3_split((unsigned)g[k] & ~255u, d[0], d[kCRows * HS]);
+                x3_split((unsigned)(g[k] >> 32) & ~255u, d[HS], d[HS + kCRows * HS]);
             }
         }
         lds_barrier();
@@ -796,8 +855,15 @@ bool lstm_cluster_x3_supported(const LstmStep* l, int n, int B, int T, int H) {
     for (int k = 0; k < n; ++k)
         if (!l[k].xchg || !l[k].W_frag_fwd || !l[k].W_frag_fwd_lo) return false;
     if (cdiv(B, kCRows) * 4 > cluster_cus()) return false;
-    return lstm_frag_elems(H) == (size_t)4 * 256 * 256 &&
-           (size_t)cdiv(B, kCRows) * 2 * kCRows * 256 * 8 <= lstm_cluster_xchg_bytes(B, H);
+    return lstm_frag_elems(H) == (size_t)4 * 256 * 256;
+}
+
+// launch number (mod 64) of an exchange buffer: the sequence bits of the x3 kernel's 16-bit tags
+static unsigned x3_launch_seq(const void* xchg) {
+    static std::mutex mu;
+    static std::unordered_map<const void*, unsigned> seq;
+    std::lock_guard<std::mutex> lock(mu);
+    return seq[xchg]++ & 63u;
 }
 
 int lstm_forward_cluster_x3(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s) {
@@ -807,7 +873,7 @@ int lstm_forward_cluster_x3(const LstmStep* l, int n, const uint8_t* mask_tb, in
     int* err = nullptr;
     ADN_TRY(lstm_cluster_error_word(&err));
     const int ldh = ld_of(H), ldg = ld_of(4 * H);
-    const size_t lds = (size_t)(kX3WLds + 2 * kCRows * G::HS) * 2;
+    const size_t lds = (size_t)2 * kCRows * G::HS * 2 + (size_t)kX3AccLds * 4;
     static bool attr_set[kMaxDevices] = {};
     bool& attr = attr_set[current_device()];
     if (!attr) {
@@ -820,10 +886,9 @@ int lstm_forward_cluster_x3(const LstmStep* l, int n, const uint8_t* mask_tb, in
     const int chunk = std::max(1, cus / per);
     for (int k0 = 0; k0 < n; k0 += chunk) {
         const int nn = std::min(chunk, n - k0);
-        LstmClusterP L;
-        for (int k = 0; k < nn; ++k) L.l[k] = l[k0 + k];
-        const unsigned tag0 = (g_cluster_epoch++ & 0x3fffffu) * 1024u + 1u;
-        hipLaunchKernelGGL(lstm_fwd_cluster_x3_kernel, dim3(per, nn), dim3(512), lds, s, L, mask_tb, B, T, H, ldh, ldg, tag0, err);
+        LstmClusterX3P L;
+        for (int k = 0; k < nn; ++k) { L.l[k] = l[k0 + k]; L.tag0[k] = x3_launch_seq(l[k0 + k].xchg) * 1024u + 1u; }
+        hipLaunchKernelGGL(lstm_fwd_cluster_x3_kernel, dim3(per, nn), dim3(512), lds, s, L, mask_tb, B, T, H, ldh, ldg, err);
         ADN_HIP_CHECK(hipGetLastError());
     }
     return ADN_OK;
