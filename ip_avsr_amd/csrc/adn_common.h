@@ -225,6 +225,7 @@ struct LstmStep {          // one LSTM instance taking part in a (possibly multi
     const void* W_frag_fwd;  // W_hid in MFMA-fragment order for the persistent kernels (lstm_persistent.hip)
     const void* W_frag_bwd;
     const void* W_frag_fwd_lo = nullptr;   // bf16x3 mode: the fragment image of W_hid - bf16(W_hid) (W_frag_fwd then holds the hi part)
+    const void* W_frag_bwd_lo = nullptr;   // ... of the backward image
     void* h16;             // [(T+1)*B][ldh] bf16 shadow of hbuf
     void* dG16;            // [T*B][ldg]     bf16 shadow of dG
     void* xchg = nullptr;  // exchange buffer of the weight-stationary kernels (lstm_cluster.hip), lstm_cluster_xchg_bytes(B)
@@ -256,6 +257,8 @@ size_t lstm_cluster_xchg_bytes(int B, int H);
 int lstm_forward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
 bool lstm_cluster_x3_supported(const LstmStep* l, int n, int B, int T, int H);
 int lstm_forward_cluster_x3(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
+bool lstm_cluster_x3_bwd_supported(const LstmStep* l, int n, int B, int T, int H);
+int lstm_backward_cluster_x3(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
 int lstm_backward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
 int lstm_cluster_error_word(int** out);   // device word raised by a poll that gave up (checked at synchronisation)
 static inline int lstm_ldk(int H) { return (int)((H + 31) / 32 * 32); }

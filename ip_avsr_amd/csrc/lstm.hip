@@ -453,6 +453,13 @@ int lstm_backward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T
                   bool* sums_done) {
     ADN_CHECK(n >= 1 && n <= kMaxLstmPerLaunch, ADN_ERR_INVALID, "lstm_backward: bad LSTM count");
     if (sums_done) *sums_done = false;
+    if (precision == ADN_PRECISION_BF16X3) {          // fp32-grade products on the bf16 matrix pipe, or the fp32 step kernels
+        if (lstm_cluster_x3_bwd_supported(l, n, B, T, H)) {
+            if (sums_done) *sums_done = true;         // bias / initial-state gradients are added inside the kernel
+            return lstm_backward_cluster_x3(l, n, mask_tb, B, T, H, s);
+        }
+        precision = ADN_PRECISION_F32;
+    }
     LstmLaunch L;
     bool have16 = precision == ADN_PRECISION_BF16;
     for (int k = 0; k < n; ++k) { L.l[k] = l[k]; have16 = have16 && l[k].W_hid16 && l[k].dG16; }

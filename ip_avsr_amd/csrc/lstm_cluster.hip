@@ -764,6 +764,279 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_kernel(const LstmCluster
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// bf16x3 backward (H <= 256): the schedule of lstm_bwd_cluster_kernel<4> with fp32-grade products
+//   dG W^T ~ dG_hi W_hi + dG_lo W_hi + dG_hi W_lo.
+// The hi and lo fragments of a workgroup's 256 rows of W_hid^T (2 x 128 KB) fill the registers of its 8 waves exactly once:
+// for the product, wave w takes destination w >> 1 and the unit-tile pair 2 (w & 1) of that destination's 64 units, for
+// both 16-row tiles (2 tiles x 8 k-steps x (hi + lo) = 128 VGPRs).  LDS holds only the hi / lo images of the own
+// dG_{t+1} and the own quarter of the partial dh.  Exchange, tags, inbox hygiene, gate math and the sums are those of
+// the bf16 kernel (partials travel as fp32 with 4 tag bits each: 2^-20, finer than the products); no bf16 shadow of dG
+// is written.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kX3BwdLds = 3;                                           // lo k-steps of a wave's W fragments that live in LDS
+constexpr int kX3BwdWOff = (2 * kCRows * kCDS * 2 + kCRows * (kCUnits + 1) * 4 + 15) / 16 * 16 / 2;   // bf16 elements
+__global__ __launch_bounds__(512) void lstm_bwd_cluster_x3_kernel(const LstmClusterP L, const uint8_t* __restrict__ mask_tb,
+                                                                  int B, int T, int H, int ldh, int ldg, int* err) {
+    using G = ClusterGeom<4>;
+    constexpr int CWG = 4, HP = G::HP, NF = G::NB;
+    extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
+    __bf16 (*dgs_hi)[kCDS] = reinterpret_cast<__bf16 (*)[kCDS]>(lds);                          // [32][kCDS] own dG_{t+1}, hi
+    __bf16 (*dgs_lo)[kCDS] = reinterpret_cast<__bf16 (*)[kCDS]>(lds + kCRows * kCDS);          // ... lo
+    float (*part)[kCUnits + 1] = reinterpret_cast<float (*)[kCUnits + 1]>(lds + 2 * kCRows * kCDS);   // [32][65]
+    bf16x8* wl = reinterpret_cast<bf16x8*>(lds + kX3BwdWOff);            // [8 waves][2 tiles][kX3BwdLds k-steps][64 lanes] lo fragments
+    const LstmStep& P = L.l[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int group = blockIdx.x / CWG, j = blockIdx.x % CWG;
+    const int r0 = group * kCRows;
+    const int rt = wave >> 2, ut = wave & 3;          // gate math: row tile, local unit tile
+    const int dst = wave >> 1, tp = 2 * (wave & 1);   // product: destination workgroup, first of its two unit tiles
+    const int ul = 16 * ut + i;
+    const int u = kCUnits * j + ul;
+    unsigned long long* xb = reinterpret_cast<unsigned long long*>(P.xchg) + (size_t)((B + kCRows - 1) / kCRows) * 2 * 16 * HP +
+                             (size_t)group * 2 * CWG * CWG * kBxPair;
+
+    // resident W slice: k-steps [8j, 8j+8) (this workgroup's gate columns) of unit tiles 4 dst + tp + {0, 1}
+    const bf16x8* wsrc_hi = reinterpret_cast<const bf16x8*>(P.W_frag_bwd) + (size_t)(8 * j) * 64;
+    const bf16x8* wsrc_lo = reinterpret_cast<const bf16x8*>(P.W_frag_bwd_lo) + (size_t)(8 * j) * 64;
+    // (the last kX3BwdLds lo k-steps of a wave sit in LDS: with all 128 fragment registers taken the step's other values spill)
+    constexpr int KR = 8 - kX3BwdLds;
+    bf16x8 whi[2][8], wlo[2][KR];
+    bf16x8* wmine = wl + (size_t)wave * 2 * kX3BwdLds * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) {
+            whi[c][s_] = wsrc_hi[((size_t)(4 * dst + tp + c) * (4 * G::KS) + s_) * 64 + lane];
+            const bf16x8 lo = wsrc_lo[((size_t)(4 * dst + tp + c) * (4 * G::KS) + s_) * 64 + lane];
+            if (s_ < KR) wlo[c][s_ < KR ? s_ : 0] = lo;
+            else wmine[(c * kX3BwdLds + (s_ - KR)) * 64] = lo;
+        }
+    for (int e = tid; e < 2 * kCRows * kCDS / 8; e += 512) reinterpret_cast<bf16x8*>(lds)[e] = bf16x8{};
+    float dh_c[4], dc_s[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { dh_c[r] = 0.f; dc_s[r] = 0.f; }
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+
+    const int uc = min(u, H - 1);
+    // per-lane element offsets of its 4 rows inside one time block (32 bits: the block bases are wave-uniform)
+    const int ld_dhs = P.ld_dhs ? P.ld_dhs : ldh;
+    unsigned rowc[4], goff[4], hoff[4], doff[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        rowc[r] = (unsigned)min(r0 + 16 * rt + 4 * kq + r, B - 1);
+        goff[r] = rowc[r] * (unsigned)ldg + (unsigned)uc * 4u;
+        hoff[r] = rowc[r] * (unsigned)ldh + (unsigned)uc;
+        doff[r] = rowc[r] * (unsigned)ld_dhs + (unsigned)uc;
+    }
+    float l_dhs[4], l_ct[4], l_cp[4];
+    float4 l_gt[4];
+    uint8_t l_m[4];
+    auto request_state = [&](int step_) {
+        const int t_ = P.backwards ? step_ : (T - 1 - step_);
+        const int pb = t_ + (P.backwards ? 1 : 0), ob = t_ + (P.backwards ? 0 : 1);
+        const uint8_t* mk = mask_tb + (size_t)t_ * B;
+        const float* dh_ = P.dhs + (size_t)t_ * B * ld_dhs;
+        const float* gt_ = P.gates + (size_t)t_ * B * ldg;
+        const float* co_ = P.cbuf + (size_t)ob * B * ldh;
+        const float* cp_ = P.cbuf + (size_t)pb * B * ldh;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            l_m[r] = mk[rowc[r]];
+            l_dhs[r] = dh_[doff[r]];
+            l_gt[r] = *reinterpret_cast<const float4*>(gt_ + goff[r]);
+            l_ct[r] = co_[hoff[r]];
+            l_cp[r] = cp_[hoff[r]];
+        }
+    };
+    for (int step = 0; step <= T; ++step) {
+        const int t = P.backwards ? step : (T - 1 - step);
+        const unsigned tag8 = 1u + (unsigned)(step % 255);
+        unsigned long long* xpar = xb + (size_t)(step & 1) * CWG * CWG * kBxPair;
+        float rec[4] = {0.f, 0.f, 0.f, 0.f};
+        if (step > 0) {
+            // ---- partial dh for destination dst, unit tiles tp, tp + 1, both row tiles
+            f32x4 acc[2][2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[c][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                bf16x8 a_hi[2], a_lo[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    a_hi[q] = *reinterpret_cast<const bf16x8*>(&dgs_hi[16 * q + i][s * 32 + kq * 8]);
+                    a_lo[q] = *reinterpret_cast<const bf16x8*>(&dgs_lo[16 * q + i][s * 32 + kq * 8]);
+                }
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) acc[c][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[q], whi[c][s], acc[c][q], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) acc[c][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[q], whi[c][s], acc[c][q], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        acc[c][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            a_hi[q], s < KR ? wlo[c][s < KR ? s : 0] : wmine[(c * kX3BwdLds + (s < KR ? 0 : s - KR)) * 64], acc[c][q], 0, 0, 0);
+            }
+            // accumulator map: unit = 64 dst + 16 (tp + c) + (lane & 15), row = 16 q + 4 kq + r
+            if (dst == j) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) part[16 * q + 4 * kq + r][16 * (tp + c) + i] = acc[c][q][r];
+            } else {
+                unsigned long long* box = xpar + (size_t)(dst * CWG + (j - dst - 1 + CWG) % CWG) * kBxPair;
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int rp = 0; rp < 2; ++rp)
+                            __hip_atomic_store(box + (size_t)(8 * q + 2 * kq + rp) * kCUnits + 16 * (tp + c) + i,
+                                               pack_partials(acc[c][q][2 * rp], acc[c][q][2 * rp + 1], tag8), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // what the gate math reads from HBM is requested AFTER the product (its 128 fragment registers leave no room for
+        // 32 more values in flight); the round trips hide under the exchange hop
+        request_state(min(step, T - 1));
+        if (step > 0) {
+            lds_barrier();                            // own part is in `part`; dG_{t+1} has been consumed
+            // ---- collect the 3 foreign parts of this lane's pairs
+            const unsigned long long* ptr[NF];
+            unsigned long long g[NF];
+#pragma unroll
+            for (int k = 0; k < NF; ++k) {
+                const int slot = k / 2, rp = k & 1;        // source (j + 1 + slot) mod CWG
+                ptr[k] = xpar + (size_t)(j * CWG + slot) * kBxPair + (size_t)(8 * rt + 2 * kq + rp) * kCUnits + ul;
+            }
+            unsigned pending = (1u << NF) - 1u;
+            unsigned long long t_start = 0;
+            for (int spin = 0; pending; ++spin) {
+                unsigned long long v[NF];
+#pragma unroll
+                for (int k = 0; k < NF; ++k)
+                    if (pending & (1u << k)) v[k] = granule_load(ptr[k]);
+#pragma unroll
+                for (int k = 0; k < NF; ++k)
+                    if ((pending & (1u << k)) && (((unsigned)v[k] & 15u) | (((unsigned)(v[k] >> 32) & 15u) << 4)) == tag8) {
+                        g[k] = v[k]; pending &= ~(1u << k);
+                    }
+                if (pending && (spin & 1023) == 1023) {
+                    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                    const unsigned long long now = wall_ticks();
+                    if (!t_start) t_start = now;
+                    else if (now - t_start > kPollTimeoutTicks) { atomicCAS(err, 0, 2 | (step << 4) | ((int)blockIdx.x << 16)); break; }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rec[r] = part[16 * rt + 4 * kq + r][ul];
+#pragma unroll
+            for (int k = 0; k < NF; ++k) {
+                const int rp = k & 1;
+                rec[2 * rp] += __builtin_bit_cast(float, (unsigned)g[k] & ~15u);
+                rec[2 * rp + 1] += __builtin_bit_cast(float, (unsigned)(g[k] >> 32) & ~15u);
+            }
+        }
+        if (step == T) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dh_c[r] += rec[r];
+            break;
+        }
+        // ---- gate math of step t for this lane's unit and 4 rows (fp32; see lstm.hip)
+        float pw_i = 0.f, pw_f = 0.f, pw_o = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * rt + 4 * kq + r, grow = r0 + row;
+            const bool ok = grow < B && u < H;
+            float4 dg = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                const float dh = l_dhs[r] + dh_c[r] + rec[r];
+                const float dc = dc_s[r];
+                if (l_m[r]) {
+                    const float4 gt = l_gt[r];
+                    const float c_t = l_ct[r], c_prev = l_cp[r];
+                    const float tc = c_tanh(c_t);
+                    const float da_o = dh * tc * gt.w * (1.f - gt.w);
+                    float dcn = dc + dh * gt.w * (1.f - tc * tc);
+                    if (P.peep) { dcn += da_o * P.peep[2 * ldh + u]; pw_o += da_o * c_t; }
+                    const float da_i = dcn * gt.z * gt.x * (1.f - gt.x);
+                    const float da_f = dcn * c_prev * gt.y * (1.f - gt.y);
+                    const float da_g = dcn * gt.x * (1.f - gt.z * gt.z);
+                    float dcp = dcn * gt.y;
+                    if (P.peep) {
+                        dcp += da_i * P.peep[u] + da_f * P.peep[ldh + u];
+                        pw_i += da_i * c_prev; pw_f += da_f * c_prev;
+                    }
+                    dg = make_float4(c_clip5(da_i), c_clip5(da_f), c_clip5(da_g), c_clip5(da_o));
+                    dh_c[r] = 0.f;
+                    dc_s[r] = dcp;
+                } else {
+                    dh_c[r] = dh;
+                }
+                *reinterpret_cast<float4*>(P.dG + (size_t)t * B * ldg + goff[r]) = dg;      // (ok: goff is this row and unit)
+                bsum.x += dg.x; bsum.y += dg.y; bsum.z += dg.z; bsum.w += dg.w;
+            }
+            bf16x4 dhi, dlo;
+            dhi[0] = (__bf16)dg.x; dhi[1] = (__bf16)dg.y; dhi[2] = (__bf16)dg.z; dhi[3] = (__bf16)dg.w;
+            dlo[0] = (__bf16)(dg.x - (float)dhi[0]); dlo[1] = (__bf16)(dg.y - (float)dhi[1]);
+            dlo[2] = (__bf16)(dg.z - (float)dhi[2]); dlo[3] = (__bf16)(dg.w - (float)dhi[3]);
+            *reinterpret_cast<bf16x4*>(&dgs_hi[row][ul * 4]) = dhi;
+            *reinterpret_cast<bf16x4*>(&dgs_lo[row][ul * 4]) = dlo;
+        }
+        if (P.dpeep_part) {
+            float si = pw_i, sf = pw_f, so = pw_o;
+            si += __shfl_xor(si, 16, 64); si += __shfl_xor(si, 32, 64);
+            sf += __shfl_xor(sf, 16, 64); sf += __shfl_xor(sf, 32, 64);
+            so += __shfl_xor(so, 16, 64); so += __shfl_xor(so, 32, 64);
+            if (kq == 0 && u < H) {
+                atomicAdd(P.dpeep_part + u, si);
+                atomicAdd(P.dpeep_part + ldh + u, sf);
+                atomicAdd(P.dpeep_part + 2 * (size_t)ldh + u, so);
+            }
+        }
+        lds_barrier();
+    }
+    float sh = 0.f, sc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int grow = r0 + 16 * rt + 4 * kq + r;
+        if (grow < B && u < H) {
+            P.dh_carry[(size_t)grow * ldh + u] = dh_c[r];
+            P.dc_state[(size_t)grow * ldh + u] = dc_s[r];
+            sh += dh_c[r]; sc += dc_s[r];
+        }
+    }
+    if (P.dbias) {
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {
+            bsum.x += __shfl_xor(bsum.x, o, 64); bsum.y += __shfl_xor(bsum.y, o, 64);
+            bsum.z += __shfl_xor(bsum.z, o, 64); bsum.w += __shfl_xor(bsum.w, o, 64);
+            sh += __shfl_xor(sh, o, 64); sc += __shfl_xor(sc, o, 64);
+        }
+        if (kq == 0 && u < H) {
+            atomicAdd(P.dbias + 4 * u, bsum.x); atomicAdd(P.dbias + 4 * u + 1, bsum.y);
+            atomicAdd(P.dbias + 4 * u + 2, bsum.z); atomicAdd(P.dbias + 4 * u + 3, bsum.w);
+            atomicAdd(P.dhid_init + u, sh); atomicAdd(P.dcell_init + u, sc);
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * CWG * kBxPair; e += 512) {
+        const int par = e / (CWG * kBxPair), rest = e % (CWG * kBxPair);
+        xb[(size_t)par * CWG * CWG * kBxPair + (size_t)j * CWG * kBxPair + rest] = 0ull;
+    }
+}
+
 // per-device launcher state (one process may drive several devices: a model polls the error word of ITS device and
 // sizes its launches by ITS device's CU count)
 constexpr int kMaxDevices = 64;
@@ -925,6 +1198,42 @@ static int backward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, in
 
 int lstm_backward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s) {
     return H <= 256 ? backward_cluster<4>(l, n, mask_tb, B, T, H, s) : backward_cluster<8>(l, n, mask_tb, B, T, H, s);
+}
+
+bool lstm_cluster_x3_bwd_supported(const LstmStep* l, int n, int B, int T, int H) {
+    if (H > 256 || T >= 1024 || getenv("ADN_LSTM_NO_CLUSTER") || getenv("ADN_LSTM_NO_X3_CLUSTER") ||
+        getenv("ADN_LSTM_NO_X3_CLUSTER_BWD")) return false;
+    for (int k = 0; k < n; ++k)
+        if (!l[k].xchg || !l[k].W_frag_bwd || !l[k].W_frag_bwd_lo) return false;
+    if (cdiv(B, kCRows) * 4 > cluster_cus()) return false;
+    return lstm_frag_elems(H) == (size_t)4 * 256 * 256;
+}
+
+int lstm_backward_cluster_x3(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s) {
+    const int groups = cdiv(B, kCRows), per = groups * 4, cus = cluster_cus();
+    ADN_CHECK(cus >= per, ADN_ERR_STATE, "lstm cluster kernel: one LSTM does not fit the device");
+    int* err = nullptr;
+    ADN_TRY(lstm_cluster_error_word(&err));
+    const int ldh = ld_of(H), ldg = ld_of(4 * H);
+    const size_t lds = (size_t)kX3BwdWOff * 2 + (size_t)8 * 2 * kX3BwdLds * 64 * 16;
+    static bool attr_set[kMaxDevices] = {};
+    bool& attr = attr_set[current_device()];
+    if (!attr) {
+        ADN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_cluster_x3_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    const double bytes = (double)n * T * 4.0 * (15.0 * B * H + 4.0 * H * H), flops = (double)n * T * 8.0 * B * H * H;
+    ProfScope prof(PROF_LSTM_BWD, flops, bytes, s, T + 1);
+    const int chunk = std::max(1, cus / per);
+    for (int k0 = 0; k0 < n; k0 += chunk) {
+        const int nn = std::min(chunk, n - k0);
+        LstmClusterP L;
+        for (int k = 0; k < nn; ++k) L.l[k] = l[k0 + k];
+        hipLaunchKernelGGL(lstm_bwd_cluster_x3_kernel, dim3(per, nn), dim3(512), lds, s, L, mask_tb, B, T, H, ldh, ldg, err);
+        ADN_HIP_CHECK(hipGetLastError());
+    }
+    return ADN_OK;
 }
 
 }  // namespace adn

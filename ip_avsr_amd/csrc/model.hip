@@ -98,6 +98,7 @@ struct ParamDesc {
 struct LstmParams {      // physical tensors (float offsets into the flat buffers)
     char* whid16t = nullptr;   // bf16 mode: transposed bf16 copy of W_hid, refreshed with the parameter shadow
     char* wfrag_fwd_lo = nullptr;   // bf16x3 mode: fragment image of W_hid - bf16(W_hid) (wfrag_fwd = the hi part)
+    char* wfrag_bwd_lo = nullptr;   // ... of the backward image
     char* wfrag_fwd = nullptr; // ... and the two MFMA-fragment-ordered copies the persistent kernels stream
     char* wfrag_bwd = nullptr;
     char* wcat16 = nullptr;    // concat consumers: bf16 W_in with every input block padded to ldh rows ([S*ldh][ldg])
@@ -642,22 +643,25 @@ int refresh_transposed(adn_model* m) {
     return transpose_to_bf16_batch(m->transw_items, (int)items.size(), m->transw_blocks, m->stream);
 }
 
-// bf16x3 mode: hi / lo fragment images of every W_hid for the weight-stationary forward kernel (H <= 256)
+// bf16x3 mode: hi / lo fragment images of every W_hid for the weight-stationary kernels (H <= 256)
 int refresh_params_x3(adn_model* m) {
     if (m->H > 256 || !m->params16_dirty) return ADN_OK;
-    std::vector<const float*> fw; std::vector<void*> fhi, flo;
+    std::vector<const float*> fw; std::vector<void*> fhi, flo, bhi, blo;
     auto add = [&](LstmParams& lp) -> int {
         if (!lp.wfrag_fwd) ADN_HIP_CHECK(hipMalloc((void**)&lp.wfrag_fwd, lstm_frag_elems(m->H) * 2));
+        if (!lp.wfrag_bwd) ADN_HIP_CHECK(hipMalloc((void**)&lp.wfrag_bwd, lstm_frag_elems(m->H) * 2));
         if (!lp.wfrag_fwd_lo) ADN_HIP_CHECK(hipMalloc((void**)&lp.wfrag_fwd_lo, lstm_frag_elems(m->H) * 2));
+        if (!lp.wfrag_bwd_lo) ADN_HIP_CHECK(hipMalloc((void**)&lp.wfrag_bwd_lo, lstm_frag_elems(m->H) * 2));
         fw.push_back(m->P(lp.W_hid)); fhi.push_back(lp.wfrag_fwd); flo.push_back(lp.wfrag_fwd_lo);
+        bhi.push_back(lp.wfrag_bwd); blo.push_back(lp.wfrag_bwd_lo);
         return ADN_OK;
     };
     for (auto& st : m->st) for (auto& lp : st.lstm) ADN_TRY(add(lp));
     for (auto& lp : m->agg) ADN_TRY(add(lp));
     for (size_t k0 = 0; k0 < fw.size(); k0 += 8) {
         const int n = (int)std::min<size_t>(8, fw.size() - k0);
-        ADN_TRY(lstm_pack_frags_batch(n, fw.data() + k0, fhi.data() + k0, nullptr, m->H, m->stream, 0));
-        ADN_TRY(lstm_pack_frags_batch(n, fw.data() + k0, flo.data() + k0, nullptr, m->H, m->stream, 1));
+        ADN_TRY(lstm_pack_frags_batch(n, fw.data() + k0, fhi.data() + k0, bhi.data() + k0, m->H, m->stream, 0));
+        ADN_TRY(lstm_pack_frags_batch(n, fw.data() + k0, flo.data() + k0, blo.data() + k0, m->H, m->stream, 1));
     }
     m->params16_dirty = false;
     return ADN_OK;
@@ -728,8 +732,9 @@ LstmStep make_step(const adn_model* m, const LstmParams& lp, const LstmWork& w, 
     s.W_hid16T = b16 ? lp.whid16t : nullptr;
     const bool x3 = m->cfg.precision == ADN_PRECISION_BF16X3 && m->H <= 256;
     s.W_frag_fwd = (b16 || x3) ? lp.wfrag_fwd : nullptr;
-    s.W_frag_bwd = b16 ? lp.wfrag_bwd : nullptr;
+    s.W_frag_bwd = (b16 || x3) ? lp.wfrag_bwd : nullptr;
     s.W_frag_fwd_lo = x3 ? lp.wfrag_fwd_lo : nullptr;
+    s.W_frag_bwd_lo = x3 ? lp.wfrag_bwd_lo : nullptr;
     s.W_hid16 = b16 ? m->shadow_of(m->P(lp.W_hid)) : nullptr;
     s.h16 = b16 ? m->shadow_of(w.hbuf) : nullptr;
     s.dG16 = b16 ? m->shadow_of(w.dG) : nullptr;
@@ -745,7 +750,8 @@ int run_lstm_group(adn_model* m, std::vector<LstmStep>& steps, int B, int T, boo
         const int n = (int)std::min<size_t>(kMaxLstmPerLaunch, steps.size() - i);
         bool done = false;
         if (backward)
-            ADN_TRY(lstm_backward(steps.data() + i, n, m->mask_tb, B, T, m->H, m->lstm_precision(), m->stream, &done));
+            ADN_TRY(lstm_backward(steps.data() + i, n, m->mask_tb, B, T, m->H,
+                                  m->cfg.precision == ADN_PRECISION_BF16X3 ? ADN_PRECISION_BF16X3 : m->lstm_precision(), m->stream, &done));
         else ADN_TRY(lstm_forward(steps.data() + i, n, m->mask_tb, B, T, m->H,
                                   m->cfg.precision == ADN_PRECISION_BF16X3 ? ADN_PRECISION_BF16X3 : m->lstm_precision(), m->stream));
         all = all && done;
@@ -1578,6 +1584,7 @@ void adn_destroy(adn_model* m) {
         if (lp.wfrag_fwd) (void)hipFree(lp.wfrag_fwd);
         if (lp.wfrag_bwd) (void)hipFree(lp.wfrag_bwd);
         if (lp.wfrag_fwd_lo) (void)hipFree(lp.wfrag_fwd_lo);
+        if (lp.wfrag_bwd_lo) (void)hipFree(lp.wfrag_bwd_lo);
     };
     for (auto& st : m->st) for (auto& lp : st.lstm) free_lp(lp);
     for (auto& lp : m->agg) free_lp(lp);
