@@ -229,8 +229,9 @@ def rooflines(prof, steps, prof_elapsed, precision, hbm_measured, traffic_file):
         if key in prof and prof[key]["ms"]:
             e = prof[key]
             a = e["bytes"] / (e["ms"] * 1e-3) / 1e9
-            kern = ("lstm_%s_cluster_kernel (weight-stationary, all T steps in one launch; per time step)"
-                    % key[5:8]) if precision == "bf16" else key + "_kernel (one launch per time step)"
+            kern = {"bf16": "lstm_%s_cluster_kernel (weight-stationary, all T steps in one launch; per time step)",
+                    "bf16x3": "lstm_%s_cluster_x3_kernel (weight-stationary, hi/lo bf16 products, all T steps in one launch; "
+                              "per time step)"}.get(precision, "lstm_%s_step_kernel (one launch per time step)") % key[5:8]
             out[name] = {"kernel": kern, "bound": "hbm", "achieved": a, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "algorithmic_bytes": "SURVEY 8d formula: e(12BH+4H^2)+B forward, e(15BH+4H^2) backward, per LSTM and step",
                          "frac": a / PEAK_HBM_GBS,

@@ -337,6 +337,7 @@ __device__ __forceinline__ void x3_split(unsigned qbits, __bf16& hi, __bf16& lo)
     lo = (__bf16)(q - (float)hi);
 }
 constexpr int kX3AccLds = 4 * 2 * 4 * 64 * 4;                          // fp32 words: [4 gates][2 row tiles][4 unit tiles][64 lanes] x 4 rows
+constexpr int kX3FwdLds = 2;                                           // lo k-steps of a wave's W fragments that live in LDS
 __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClusterX3P L, const uint8_t* __restrict__ mask_tb,
                                                                   int B, int T, int H, int ldh, int ldg, int* err) {
     using G = ClusterGeom<4>;
@@ -346,6 +347,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClus
     __bf16 (*hs_hi)[HS] = reinterpret_cast<__bf16 (*)[HS]>(lds);
     __bf16 (*hs_lo)[HS] = reinterpret_cast<__bf16 (*)[HS]>(lds + kCRows * HS);
     f32x4* xacc = reinterpret_cast<f32x4*>(lds + 2 * kCRows * HS);       // (2 * 32 * 264 * 2 bytes: 16-byte aligned)
+    bf16x8* wl = reinterpret_cast<bf16x8*>(lds + 2 * kCRows * HS + kX3AccLds * 2);   // [8 waves][2 gates][kX3FwdLds][64 lanes]
     const LstmStep& P = L.l[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, kq = lane >> 4;
@@ -359,13 +361,18 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClus
 
     const bf16x8* wsrc_hi = reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(P.W_frag_fwd) + (size_t)j * G::WElems);
     const bf16x8* wsrc_lo = reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(P.W_frag_fwd_lo) + (size_t)j * G::WElems);
-    bf16x8 whi[2][KS], wlo[2][KS];
+    // (the last kX3FwdLds lo k-steps of a wave sit in LDS: with all 128 fragment registers taken the step's other values spill)
+    constexpr int KR = KS - kX3FwdLds;
+    bf16x8 whi[2][KS], wlo[2][KR];
+    bf16x8* wmine = wl + (size_t)wave * 2 * kX3FwdLds * 64 + lane;
 #pragma unroll
     for (int gi = 0; gi < 2; ++gi)
 #pragma unroll
         for (int s_ = 0; s_ < KS; ++s_) {
             whi[gi][s_] = wsrc_hi[((size_t)(4 * ut + 2 * rt + gi) * KS + s_) * 64 + lane];
-            wlo[gi][s_] = wsrc_lo[((size_t)(4 * ut + 2 * rt + gi) * KS + s_) * 64 + lane];
+            const bf16x8 lo = wsrc_lo[((size_t)(4 * ut + 2 * rt + gi) * KS + s_) * 64 + lane];
+            if (s_ < KR) wlo[gi][s_ < KR ? s_ : 0] = lo;
+            else wmine[(gi * kX3FwdLds + (s_ - KR)) * 64] = lo;
         }
     // ---- initial state: both images from the fp32 block
     const int blk0 = P.backwards ? T : 0;
@@ -421,7 +428,9 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClus
 #pragma unroll
             for (int gi = 0; gi < 2; ++gi)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) pacc[gi][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[q], wlo[gi][s], pacc[gi][q], 0, 0, 0);
+                for (int q = 0; q < 2; ++q)
+                    pacc[gi][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        a_hi[q], s < KR ? wlo[gi][s < KR ? s : 0] : wmine[(gi * kX3FwdLds + (s < KR ? 0 : s - KR)) * 64], pacc[gi][q], 0, 0, 0);
         }
         // accumulator lane map = gate-math lane map (unit lane & 15, rows 4 (lane >> 4) ..+3): hand each tile to its wave
 #pragma unroll
@@ -432,9 +441,10 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClus
         f32x4 acc[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = xacc[((g * 2 + rt) * 4 + ut) * 64 + lane];
-        // ---- gate math, row by row: own images, publish each row pair at once (the partners are waiting), outputs --
-        //      nothing of a row stays live
+        // ---- gate math; own images and the publication of each row pair first (the partners are waiting for it)
         unsigned q_even = 0u;
+        float h_out[4];
+        float4 gts[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float a_i = xp[r].x + acc[0][r], a_f = xp[r].y + acc[1][r];
@@ -450,6 +460,8 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClus
             float h_o = m[r] ? h_new : h_prev;
             h_st[r] = h_o;
             if (u >= H) h_o = 0.f;
+            h_out[r] = h_o;
+            gts[r] = make_float4(gi, gf, gg, go);
             const unsigned qb = x3_quant(h_o);
             const int row = 16 * rt + 4 * kq + r;
             x3_split(qb, hs_hi[row][u], hs_lo[row][u]);
@@ -459,13 +471,19 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClus
                                    __HIP_MEMORY_SCOPE_AGENT);
             else
                 q_even = qb;
-            const int grow = r0 + row;
-            if (u < H && grow < B) {
-                const size_t ridx = (size_t)t * B + grow;
-                const size_t oidx = ((size_t)out_blk * B + grow) * ldh + u;
-                P.cbuf[oidx] = c_st[r];
-                P.hbuf[oidx] = h_o;
-                if (P.gates) *reinterpret_cast<float4*>(P.gates + ridx * ldg + u * 4) = make_float4(gi, gf, gg, go);
+        }
+        // ---- the step's outputs
+        if (u < H) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int grow = r0 + 16 * rt + 4 * kq + r;
+                if (grow < B) {
+                    const size_t ridx = (size_t)t * B + grow;
+                    const size_t oidx = ((size_t)out_blk * B + grow) * ldh + u;
+                    P.cbuf[oidx] = c_st[r];
+                    P.hbuf[oidx] = h_out[r];
+                    if (P.gates) *reinterpret_cast<float4*>(P.gates + ridx * ldg + u * 4) = gts[r];
+                }
             }
         }
         // ---- gather the partners' h_t: slot k = (workgroup k >> 1, row pair (tid >> 6) + 8 (k & 1)) of this thread's unit
@@ -1146,7 +1164,7 @@ int lstm_forward_cluster_x3(const LstmStep* l, int n, const uint8_t* mask_tb, in
     int* err = nullptr;
     ADN_TRY(lstm_cluster_error_word(&err));
     const int ldh = ld_of(H), ldg = ld_of(4 * H);
-    const size_t lds = (size_t)2 * kCRows * G::HS * 2 + (size_t)kX3AccLds * 4;
+    const size_t lds = (size_t)2 * kCRows * G::HS * 2 + (size_t)kX3AccLds * 4 + (size_t)8 * 2 * kX3FwdLds * 64 * 16;
     static bool attr_set[kMaxDevices] = {};
     bool& attr = attr_set[current_device()];
     if (!attr) {
