@@ -155,3 +155,72 @@ def test_bf16x3_at_the_bench_geometry_against_f32_mode(torch_cuda, lib):
     for k in ("fc1_s1.W", "fc2_s2.W", "fc3_s3.W", "fc3_s1.b"):
         assert rel(k) <= 1e-2, (k, rel(k))
     m.close()
+
+
+def _small_x3_model(lstm_size, peepholes, seed, dims=(60, 44)):
+    from ip_avsr_amd.model import AdeNetModel
+    spec = O.spec_nstream(list(dims), enc_shapes=(96, 48, 24), enc_acts=("rectify", "rectify", "linear"),
+                          lstm_size=lstm_size, peepholes=peepholes)
+    spec["agg_peepholes"] = peepholes
+    rng = np.random.default_rng(seed)
+    p = O.init_params(spec, rng, np.float32, enc_std=0.1)
+    for k in p:
+        if "W_hid" in k or "W_cell" in k:
+            p[k] = (p[k] * 3).astype(np.float32)           # a recurrent part that matters
+    m = AdeNetModel(spec)
+    m.set_precision("bf16x3")
+    m.set_params_dict(p)
+    return spec, p, m, rng
+
+
+@pytest.mark.parametrize("H,B,T,peep", [(250, 70, 9, False), (250, 33, 2, True), (100, 5, 1, False), (64, 100, 12, True),
+                                        (256, 32, 5, False), (17, 40, 7, True)])
+def test_x3_weight_stationary_lstm_kernels_match_the_fp32_step_kernels(torch_cuda, lib, monkeypatch, H, B, T, peep):
+    """lstm_{fwd,bwd}_cluster_x3_kernel (csrc/lstm_cluster.hip) against the fp32 step kernels the mode falls back to
+    (ADN_LSTM_NO_X3_CLUSTER): ragged masks, partial 32-row groups, padded hidden sizes, peepholes, T = 1 / 2, backwards LSTMs
+    (the aggregation pair).  h travels with a 16-bit significand between the workgroups: probabilities to 2e-6, gradients to
+    1e-4 of each tensor's scale (measured <= 2.1e-5 with the recurrent weights scaled up 3 x)."""
+    spec, p, m, rng = _small_x3_model(H, peep, 100 * H + B + T)
+    theta = min(9, 2 * T + 1) if T > 1 else 3
+    mask = ragged_mask(rng, B, T) if T > 2 else np.ones((B, T), np.uint8)
+    xs = [(rng.normal(size=(B, T, d)) * mask[..., None]).astype(np.float32) for d in (60, 44)]
+    y = np.repeat((np.arange(B) % 26)[:, None], T, axis=1).astype(np.int32)
+    res = {}
+    for mode in ("cluster", "steps"):
+        if mode == "steps":
+            monkeypatch.setenv("ADN_LSTM_NO_X3_CLUSTER", "1")
+        else:
+            monkeypatch.delenv("ADN_LSTM_NO_X3_CLUSTER", raising=False)
+        res[mode] = (m.predict(xs, mask, theta), m.compute_grads(xs, y, mask, theta), m.get_grads_dict())
+    monkeypatch.delenv("ADN_LSTM_NO_X3_CLUSTER", raising=False)
+    assert np.abs(res["cluster"][0] - res["steps"][0]).max() <= 2e-6
+    assert abs(res["cluster"][1] - res["steps"][1]) <= 2e-6 * abs(res["steps"][1])
+    gscale = max(np.abs(v).max() for v in res["steps"][2].values())
+    for k, g in res["steps"][2].items():
+        e = np.abs(res["cluster"][2][k] - g).max() / max(np.abs(g).max(), 1e-3 * gscale)
+        assert e <= 1e-4, (k, e)
+    # and against the fp64 oracle: the mode's parity gate on this graph
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    probs_ref = O.forward(spec, p64, [x.astype(np.float64) for x in xs], mask, theta)
+    assert np.abs(res["cluster"][0] - probs_ref).max() <= 2e-5
+    m.close()
+
+
+def test_x3_exchange_tags_survive_more_launches_than_their_sequence_field(torch_cuda, lib, monkeypatch):
+    """The forward kernel's granules carry a 16-bit tag = 6 launch-sequence bits (per exchange buffer) + 10 step bits: 150
+    launches on the same buffers (two wraps of the sequence), each with fresh inputs, must each reproduce the fp32 step
+    kernels' result; so must launches of different T that leave old tags of other steps behind."""
+    spec, p, m, rng = _small_x3_model(250, False, 7)
+    B = 40
+    cases = [(rng.integers(2, 12), rng.normal(size=(B, 12, 60)).astype(np.float32), rng.normal(size=(B, 12, 44)).astype(np.float32))
+             for _ in range(6)]
+    want = []
+    monkeypatch.setenv("ADN_LSTM_NO_X3_CLUSTER", "1")
+    for T, a, b in cases:
+        want.append(m.predict([a[:, :T].copy(), b[:, :T].copy()], np.ones((B, T), np.uint8), 3))
+    monkeypatch.delenv("ADN_LSTM_NO_X3_CLUSTER", raising=False)
+    for it in range(150):
+        T, a, b = cases[it % len(cases)]
+        got = m.predict([a[:, :T].copy(), b[:, :T].copy()], np.ones((B, T), np.uint8), 3)
+        assert np.abs(got - want[it % len(cases)]).max() <= 2e-6, it
+    m.close()
