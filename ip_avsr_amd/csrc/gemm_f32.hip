@@ -322,9 +322,19 @@ static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used
     return ADN_OK;
 }
 
+static bool x3_takes(const GemmArgs& g);
+static int gemm_grouped_bf16x3(const GemmArgs* gs, int n, hipStream_t stream);
+
 int gemm_grouped(const GemmArgs* gs, int n, hipStream_t stream) {
     if (n <= 0) return ADN_OK;
     if (gs[0].M <= 0 || gs[0].N <= 0) return ADN_OK;
+    if (n > 1 && n <= kMaxGemmGroups && gs[0].precision == ADN_PRECISION_BF16X3 && !getenv("ADN_X3_NO_GROUPS")) {
+        bool all = true;
+        for (int k = 0; k < n; ++k)
+            all = all && x3_takes(gs[k]) && gs[k].precision == ADN_PRECISION_BF16X3 && gs[k].layout == gs[0].layout &&
+                  gs[k].M == gs[0].M && gs[k].N == gs[0].N && gs[k].K == gs[0].K;
+        if (all) return gemm_grouped_bf16x3(gs, n, stream);
+    }
     bool used = false;
     if (n > 1) ADN_TRY(gemm_pp_try(gs, n, stream, &used));
     if (used) return ADN_OK;
@@ -357,30 +367,87 @@ int x3_workspace(hipStream_t stream, size_t bytes, void** out) {
 }
 }  // namespace
 
-static int gemm_bf16x3(const GemmArgs& g, hipStream_t stream) {
-    const int Kp = (int)round_up(g.K, 8);
-    const bool a_rows = g.layout == GEMM_TN;                     // A given as [K][M]: k along its rows
+// operand images of one product: sizes, then the split passes + the bf16 problem that multiplies them
+struct X3Plan {
+    int Kp, lda3, ldb3;
+    bool a_rows, b_transpose;
+    size_t a_bytes, b_bytes;
+};
+
+static X3Plan x3_plan(const GemmArgs& g) {
+    X3Plan p;
+    p.Kp = (int)round_up(g.K, 8);
+    p.a_rows = g.layout == GEMM_TN;                              // A given as [K][M]: k along its rows
     // B given as [N][K] (NT: the input-gradient GEMMs dZ W^T) is written TRANSPOSED into the k-strided form, so that the
     // product runs through the NN kernels (both operands k-contiguous is the slow form of the bf16 kernels: 3.4 -> 2.3 ms
     // per train step at the bench geometry)
-    const bool b_transpose = g.layout == GEMM_NT;
-    const int lda3 = a_rows ? (int)round_up(g.M, 64) : 3 * Kp, ldb3 = (int)round_up(g.N, 64);
-    const size_t a_elems = a_rows ? (size_t)3 * Kp * lda3 : (size_t)g.M * lda3;
-    const size_t b_elems = (size_t)3 * Kp * ldb3;
-    const size_t a_bytes = (size_t)round_up((int64_t)a_elems * 2, 256);
+    p.b_transpose = g.layout == GEMM_NT;
+    p.lda3 = p.a_rows ? (int)round_up(g.M, 64) : 3 * p.Kp;
+    p.ldb3 = (int)round_up(g.N, 64);
+    const size_t a_elems = p.a_rows ? (size_t)3 * p.Kp * p.lda3 : (size_t)g.M * p.lda3;
+    p.a_bytes = (size_t)round_up((int64_t)a_elems * 2, 256);
+    p.b_bytes = (size_t)round_up((int64_t)3 * p.Kp * p.ldb3 * 2, 256);
+    return p;
+}
+
+// (split_a / split_b false: the image at A3 / B3 is already there -- an operand shared with an earlier problem of the group)
+static int x3_split_operands(const GemmArgs& g, const X3Plan& p, void* A3, void* B3, GemmArgs* h, hipStream_t stream,
+                             bool split_a = true, bool split_b = true) {
+    if (split_a) {
+        if (p.a_rows) ADN_TRY(split3_rows(g.A, g.lda, g.K, p.Kp, g.M, A3, p.lda3, 0b100, stream));
+        else ADN_TRY(split3_cols(g.A, g.lda, g.M, g.K, p.Kp, A3, 0b100, stream));
+    }
+    if (split_b) {
+        if (p.b_transpose) ADN_TRY(split3_transpose(g.B, g.ldb, g.N, g.K, p.Kp, B3, p.ldb3, 0b010, stream));
+        else ADN_TRY(split3_rows(g.B, g.ldb, g.K, p.Kp, g.N, B3, p.ldb3, 0b010, stream));
+    }
+    *h = g;
+    h->precision = ADN_PRECISION_BF16;
+    if (p.b_transpose) h->layout = GEMM_NN;
+    h->A16 = A3; h->B16 = B3; h->lda = p.lda3; h->ldb = p.ldb3; h->K = 3 * p.Kp;
+    h->C16 = nullptr; h->Y16 = nullptr;                         // fp32 outputs and masks, as in fp32 mode
+    return ADN_OK;
+}
+
+static bool x3_takes(const GemmArgs& g) {
+    // small problems (launch-bound; the split passes would cost more than they save) stay on the fp32 MFMA kernels
+    // (ADN_X3_MIN_WORK: test hook -- 0 sends every shape through the split path)
+    static const double min_work = getenv("ADN_X3_MIN_WORK") ? atof(getenv("ADN_X3_MIN_WORK")) : 6.4e7;
+    return (double)g.M * g.N * g.K >= min_work && (g.K >= 32 || min_work == 0) && g.A && g.B && g.C && g.lda % 4 == 0 &&
+           g.ldb % 4 == 0 && ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0;
+}
+
+static int gemm_bf16x3(const GemmArgs& g, hipStream_t stream) {
+    const X3Plan p = x3_plan(g);
     void* ws = nullptr;
-    ADN_TRY(x3_workspace(stream, a_bytes + b_elems * 2 + 256, &ws));
-    void* A3 = ws; void* B3 = static_cast<char*>(ws) + a_bytes;
-    if (a_rows) ADN_TRY(split3_rows(g.A, g.lda, g.K, Kp, g.M, A3, lda3, 0b100, stream));
-    else ADN_TRY(split3_cols(g.A, g.lda, g.M, g.K, Kp, A3, 0b100, stream));
-    if (b_transpose) ADN_TRY(split3_transpose(g.B, g.ldb, g.N, g.K, Kp, B3, ldb3, 0b010, stream));
-    else ADN_TRY(split3_rows(g.B, g.ldb, g.K, Kp, g.N, B3, ldb3, 0b010, stream));
-    GemmArgs h = g;
-    h.precision = ADN_PRECISION_BF16;
-    if (b_transpose) h.layout = GEMM_NN;
-    h.A16 = A3; h.B16 = B3; h.lda = lda3; h.ldb = ldb3; h.K = 3 * Kp;
-    h.C16 = nullptr; h.Y16 = nullptr;                           // fp32 outputs and masks, as in fp32 mode
+    ADN_TRY(x3_workspace(stream, p.a_bytes + p.b_bytes, &ws));
+    GemmArgs h;
+    ADN_TRY(x3_split_operands(g, p, ws, static_cast<char*>(ws) + p.a_bytes, &h, stream));
     return gemm(h, stream);
+}
+
+// n problems of one shape: every problem's images side by side in the stream's workspace, then ONE grouped bf16 launch
+// (the ping-pong kernel fills its rounds with the tiles of all of them) -- or, if that kernel declines, one launch each
+static int gemm_grouped_bf16x3(const GemmArgs* gs, int n, hipStream_t stream) {
+    const X3Plan p = x3_plan(gs[0]);
+    void* ws = nullptr;
+    ADN_TRY(x3_workspace(stream, (size_t)n * (p.a_bytes + p.b_bytes), &ws));
+    GemmArgs h[kMaxGemmGroups];
+    for (int k = 0; k < n; ++k) {
+        char* base = static_cast<char*>(ws) + (size_t)k * (p.a_bytes + p.b_bytes);
+        void* A3 = base; void* B3 = base + p.a_bytes;
+        bool split_a = true, split_b = true;
+        for (int j = 0; j < k; ++j) {          // an operand the group shares (the dG of one LSTM under its weight gradients) is split once
+            if (split_a && gs[j].A == gs[k].A && gs[j].lda == gs[k].lda) { A3 = const_cast<void*>(h[j].A16); split_a = false; }
+            if (split_b && gs[j].B == gs[k].B && gs[j].ldb == gs[k].ldb) { B3 = const_cast<void*>(h[j].B16); split_b = false; }
+        }
+        ADN_TRY(x3_split_operands(gs[k], p, A3, B3, &h[k], stream, split_a, split_b));
+    }
+    bool used = false;
+    ADN_TRY(gemm_pp_try(h, n, stream, &used));
+    if (used) return ADN_OK;
+    for (int k = 0; k < n; ++k) ADN_TRY(gemm(h[k], stream));
+    return ADN_OK;
 }
 
 int gemm(const GemmArgs& g, hipStream_t stream) {
@@ -388,12 +455,7 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
     if (g.M <= 0 || g.N <= 0) return ADN_OK;
     ADN_CHECK(g.K > 0, ADN_ERR_INVALID, "gemm: K must be positive");
     if (g.precision == ADN_PRECISION_BF16X3) {
-        // small problems (launch-bound; the split passes would cost more than they save) stay on the fp32 MFMA kernels
-        // (ADN_X3_MIN_WORK: test hook -- 0 sends every shape through the split path)
-        static const double min_work = getenv("ADN_X3_MIN_WORK") ? atof(getenv("ADN_X3_MIN_WORK")) : 6.4e7;
-        if ((double)g.M * g.N * g.K >= min_work && (g.K >= 32 || min_work == 0) && g.A && g.B && g.C && g.lda % 4 == 0 && g.ldb % 4 == 0 &&
-            ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0)
-            return gemm_bf16x3(g, stream);
+        if (x3_takes(g)) return gemm_bf16x3(g, stream);
         GemmArgs h = g;
         h.precision = ADN_PRECISION_F32;
         return gemm(h, stream);

@@ -1188,14 +1188,59 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             }
             for (int j = 0; j < m->S; ++j) { dfin.push_back(m->dcat + (size_t)j * ldh); m->st[j].dout_ld = ldcat; }
         } else {
-            for (size_t k = 0; k < m->agg.size(); ++k)
-                ADN_TRY(lstm_param_grads(m, m->agg[k], m->aggw[k], fin.data(), fld.data(), (int)fin.size(), H, B, T, sums_done));
-            for (size_t j = 0; j < fin.size(); ++j) {
-                float* dst = per_stream_fused ? m->st[j].dout_buf : m->dfused;
-                for (size_t k = 0; k < m->agg.size(); ++k)
-                    ADN_TRY(lstm_input_grad(m, m->agg[k], m->aggw[k], (int)j, H, dst, ldh, N, k > 0));
-                dfin.push_back(dst);
+            // Per aggregation LSTM: the weight gradients of its input blocks and of W_hid are GEMMs of one shape that share
+            // dG, and so are the input gradients of its blocks -- grouped launches (one shared tile list; in bf16x3 mode
+            // the shared operand is also split only once).  Where grouping does not apply they go out one by one.
+            const bool group = (int)fin.size() + 1 <= kMaxGemmGroups && !streams_concurrent(m);
+            for (size_t k = 0; k < m->agg.size(); ++k) {
+                const LstmParams& lp = m->agg[k]; const LstmWork& w = m->aggw[k];
+                if (!group) {
+                    ADN_TRY(lstm_param_grads(m, lp, w, fin.data(), fld.data(), (int)fin.size(), H, B, T, sums_done));
+                    continue;
+                }
+                GemmArgs gs[kMaxGemmGroups];
+                int n = 0;
+                for (size_t j = 0; j <= fin.size(); ++j) {        // dW_in of every block, then dW_hid (all [H] x [4H] over K = N)
+                    GemmArgs& g = gs[n++];
+                    g.layout = GEMM_TN; g.M = H; g.N = 4 * H; g.K = N; g.B = w.dG; g.ldb = m->ldg; g.ldc = m->ldg; g.accumulate = 1;
+                    if (j < fin.size()) { g.A = fin[j]; g.lda = fld[j]; g.C = m->G(lp.W_in) + j * (size_t)H * m->ldg; }
+                    else { g.A = w.prev(B, ldh, lp.backwards); g.lda = ldh; g.C = m->G(lp.W_hid); }
+                    mgemm_prepare(m, g, false);
+                }
+                bool same = true;
+                for (int j = 1; j < n; ++j) same = same && gs[j].lda == gs[0].lda && (gs[j].A16 == nullptr) == (gs[0].A16 == nullptr);
+                if (same) ADN_TRY(gemm_grouped(gs, n, s));
+                else for (int j = 0; j < n; ++j) ADN_TRY(gemm(gs[j], s));
+                if (!sums_done) {
+                    ADN_TRY(col_sum(w.dG, m->ldg, N, 4 * H, m->G(lp.b), 1, s));
+                    ADN_TRY(col_sum(w.dh_carry, ldh, B, H, m->G(lp.hid_init), 1, s));
+                    ADN_TRY(col_sum(w.dc_state, ldh, B, H, m->G(lp.cell_init), 1, s));
+                }
             }
+            std::vector<float*> dsts;
+            for (size_t j = 0; j < fin.size(); ++j) dsts.push_back(per_stream_fused ? m->st[j].dout_buf : m->dfused);
+            for (size_t k = 0; k < m->agg.size(); ++k) {
+                if (!group || fin.size() < 2) {
+                    for (size_t j = 0; j < fin.size(); ++j)
+                        ADN_TRY(lstm_input_grad(m, m->agg[k], m->aggw[k], (int)j, H, dsts[j], ldh, N, k > 0));
+                    continue;
+                }
+                GemmArgs gs[kMaxGemmGroups];
+                int n = 0;
+                for (size_t j = 0; j < fin.size(); ++j) {         // dX_j (+)= dG W_in[block j]^T
+                    GemmArgs& g = gs[n++];
+                    g.layout = GEMM_NT; g.M = N; g.N = H; g.K = 4 * H;
+                    g.A = m->aggw[k].dG; g.lda = m->ldg; g.B = m->P(m->agg[k].W_in) + j * (size_t)H * m->ldg; g.ldb = m->ldg;
+                    g.C = dsts[j]; g.ldc = ldh; g.accumulate = k > 0;
+                    mgemm_prepare(m, g, false);
+                }
+                bool same = true;
+                for (int j = 1; j < n; ++j)
+                    same = same && gs[j].layout == gs[0].layout && gs[j].ldb == gs[0].ldb && (gs[j].B16 == nullptr) == (gs[0].B16 == nullptr);
+                if (same) ADN_TRY(gemm_grouped(gs, n, s));
+                else for (int j = 0; j < n; ++j) ADN_TRY(gemm(gs[j], s));
+            }
+            for (size_t j = 0; j < fin.size(); ++j) dfin.push_back(dsts[j]);
         }
     } else {
         dfin.push_back(m->dcls);
