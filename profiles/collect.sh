@@ -29,6 +29,11 @@ ADN_GEMM_TRACE=1 timeout 300 rocprofv3 --kernel-trace -d $OUT/bd -o bd --output-
 BD=$(find $OUT/bd -name "bd_kernel_trace.csv" | head -1)
 python3 $ROOT/profiles/gemm_breakdown.py join $OUT/gemm_trace.txt $BD > $OUT/gemm_breakdown_bf16.txt
 python3 $ROOT/profiles/step_breakdown.py $BD > $OUT/step_breakdown_bf16.txt
+# the same two tables for the bf16x3 (fp32-grade) mode
+ADN_PRECISION=bf16x3 ADN_GEMM_TRACE=1 timeout 300 rocprofv3 --kernel-trace -d $OUT/bd3 -o bd --output-format csv -- python3 $ROOT/profiles/gemm_breakdown.py run 2> $OUT/gemm_trace_x3.txt > $OUT/bd3.log
+BD3=$(find $OUT/bd3 -name "bd_kernel_trace.csv" | head -1)
+python3 $ROOT/profiles/gemm_breakdown.py join $OUT/gemm_trace_x3.txt $BD3 > $OUT/gemm_breakdown_bf16x3.txt
+python3 $ROOT/profiles/step_breakdown.py $BD3 > $OUT/step_breakdown_bf16x3.txt
 # conv auto-encoder: MFMA-busy share of its GEMM kernels
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmcC -o c --output-format csv -- python3 $ROOT/profiles/convae_profile.py > $OUT/pmcC.log 2>&1
 python3 $ROOT/profiles/pmc_summary.py $(find $OUT/pmcC -name "c_counter_collection.csv" | head -1) mfma > $OUT/pmc_mfma_convae.txt
@@ -45,5 +50,5 @@ timeout 300 python3 profiles/convae_bench.py > $OUT/convae_bench.txt 2>/dev/null
 # the bench lines last, so that roofline.traffic comes from the PMC passes of THIS build
 mkdir -p profiles/$ROUND && cp $OUT/pmc_traffic_bf16.json profiles/$ROUND/pmc_traffic_bf16.json
 timeout 400 python3 bench.py --precision bf16 2>/dev/null | tail -1 > $OUT/final_bf16_bench.json
-rm -rf $OUT/ks_bf16 $OUT/ks_f32 $OUT/ks_bf16x3 $OUT/pmcA $OUT/pmcB $OUT/pmcM $OUT/pmcC $OUT/bd
+rm -rf $OUT/ks_bf16 $OUT/ks_f32 $OUT/ks_bf16x3 $OUT/pmcA $OUT/pmcB $OUT/pmcM $OUT/pmcC $OUT/bd $OUT/bd3 $OUT/gemm_trace_x3.txt
 ls -la $OUT
