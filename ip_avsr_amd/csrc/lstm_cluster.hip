@@ -337,7 +337,7 @@ __device__ __forceinline__ void x3_split(unsigned qbits, __bf16& hi, __bf16& lo)
     lo = (__bf16)(q - (float)hi);
 }
 constexpr int kX3AccLds = 4 * 2 * 4 * 64 * 4;                          // fp32 words: [4 gates][2 row tiles][4 unit tiles][64 lanes] x 4 rows
-constexpr int kX3FwdLds = 2;                                           // lo k-steps of a wave's W fragments that live in LDS
+constexpr int kX3FwdLds = 3;                                           // lo k-steps of a wave's W fragments that live in LDS
 __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClusterX3P L, const uint8_t* __restrict__ mask_tb,
                                                                   int B, int T, int H, int ldh, int ldg, int* err) {
     using G = ClusterGeom<4>;
@@ -369,8 +369,9 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClus
     for (int gi = 0; gi < 2; ++gi)
 #pragma unroll
         for (int s_ = 0; s_ < KS; ++s_) {
-            whi[gi][s_] = wsrc_hi[((size_t)(4 * ut + 2 * rt + gi) * KS + s_) * 64 + lane];
-            const bf16x8 lo = wsrc_lo[((size_t)(4 * ut + 2 * rt + gi) * KS + s_) * 64 + lane];
+            const int ks = (2 * j + s_) & (KS - 1);          // register slot s_ holds k-step ks: the own units' two k-steps first
+            whi[gi][s_] = wsrc_hi[((size_t)(4 * ut + 2 * rt + gi) * KS + ks) * 64 + lane];
+            const bf16x8 lo = wsrc_lo[((size_t)(4 * ut + 2 * rt + gi) * KS + ks) * 64 + lane];
             if (s_ < KR) wlo[gi][s_ < KR ? s_ : 0] = lo;
             else wmine[(gi * kX3FwdLds + (s_ - KR)) * 64] = lo;
         }
@@ -390,8 +391,46 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClus
     }
     __syncthreads();
 
+    // product of this wave's gate pair, both row tiles, one k-step (register slot s = k-step (2j + s) mod 8): three MFMAs
+    // per (gate, row tile)
+    f32x4 pacc[2][2];
+    const int acol = kq * 8;
+    auto kstep = [&](int s) {
+        const int col = ((2 * j + s) & (KS - 1)) * 32 + acol;
+        bf16x8 a_hi[2], a_lo[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            a_hi[q] = *reinterpret_cast<const bf16x8*>(&hs_hi[16 * q + i][col]);
+            a_lo[q] = *reinterpret_cast<const bf16x8*>(&hs_lo[16 * q + i][col]);
+        }
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) pacc[gi][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[q], whi[gi][s], pacc[gi][q], 0, 0, 0);
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) pacc[gi][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[q], whi[gi][s], pacc[gi][q], 0, 0, 0);
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                pacc[gi][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    a_hi[q], s < KR ? wlo[gi][s < KR ? s : 0] : wmine[(gi * kX3FwdLds + (s < KR ? 0 : s - KR)) * 64], pacc[gi][q], 0, 0, 0);
+    };
+    auto own_part = [&]() {                           // the two k-steps of this workgroup's own units: a fresh accumulator
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) pacc[gi][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        kstep(0);
+        kstep(1);
+    };
+    own_part();
+
     uint8_t m[4];
     float4 xp[4];
+    STAMP_INIT
     for (int step = 0; step < T; ++step) {
         const int t = P.backwards ? (T - 1 - step) : step;
         const int out_blk = t + (P.backwards ? 0 : 1);
@@ -403,41 +442,16 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClus
             m[r] = mask_tb[ridx];
             xp[r] = *reinterpret_cast<const float4*>(P.xproj + ridx * ldg + uc * 4);
         }
-        // ---- recurrent product of this wave's gate pair, both row tiles: three MFMAs per (gate, row tile, k-step)
-        f32x4 pacc[2][2];
+        // ---- recurrent product, the partners' six k-steps (the own units' two were multiplied while their granules travelled)
 #pragma unroll
-        for (int gi = 0; gi < 2; ++gi)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) pacc[gi][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            bf16x8 a_hi[2], a_lo[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                a_hi[q] = *reinterpret_cast<const bf16x8*>(&hs_hi[16 * q + i][s * 32 + kq * 8]);
-                a_lo[q] = *reinterpret_cast<const bf16x8*>(&hs_lo[16 * q + i][s * 32 + kq * 8]);
-            }
-#pragma unroll
-            for (int gi = 0; gi < 2; ++gi)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) pacc[gi][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[q], whi[gi][s], pacc[gi][q], 0, 0, 0);
-#pragma unroll
-            for (int gi = 0; gi < 2; ++gi)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) pacc[gi][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[q], whi[gi][s], pacc[gi][q], 0, 0, 0);
-#pragma unroll
-            for (int gi = 0; gi < 2; ++gi)
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    pacc[gi][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        a_hi[q], s < KR ? wlo[gi][s < KR ? s : 0] : wmine[(gi * kX3FwdLds + (s < KR ? 0 : s - KR)) * 64], pacc[gi][q], 0, 0, 0);
-        }
+        for (int s = 2; s < KS; ++s) kstep(s);
         // accumulator lane map = gate-math lane map (unit lane & 15, rows 4 (lane >> 4) ..+3): hand each tile to its wave
 #pragma unroll
         for (int gi = 0; gi < 2; ++gi)
 #pragma unroll
             for (int q = 0; q < 2; ++q) xacc[(((2 * rt + gi) * 2 + q) * 4 + ut) * 64 + lane] = pacc[gi][q];
         lds_barrier();                                // every wave has read h_{t-1} (the images may be overwritten); tiles are in place
+        STAMP(0);
         f32x4 acc[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = xacc[((g * 2 + rt) * 4 + ut) * 64 + lane];
@@ -472,6 +486,8 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClus
             else
                 q_even = qb;
         }
+        STAMP(1);
+        lds_barrier();                                // the own units' h_t is complete in both images
         // ---- the step's outputs
         if (u < H) {
 #pragma unroll
@@ -486,6 +502,9 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClus
                 }
             }
         }
+        // ---- the own units' share of the NEXT step's product, while the partners' granules are in flight
+        if (step + 1 < T) own_part();
+        STAMP(2);
         // ---- gather the partners' h_t: slot k = (workgroup k >> 1, row pair (tid >> 6) + 8 (k & 1)) of this thread's unit
         //      column; the own workgroup's two slots are skipped (already in the images).  Global and LDS addresses are
         //      one base plus compile-time constants.
@@ -513,6 +532,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClus
                     else if (now - t_start > kPollTimeoutTicks) { atomicCAS(err, 0, 1 | ((int)(step & 1023) << 4) | ((int)blockIdx.x << 16)); break; }
                 }
             }
+            STAMP(3);
 #pragma unroll
             for (int k = 0; k < NF; ++k) {
                 if ((k >> 1) == j) continue;
@@ -522,6 +542,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClus
             }
         }
         lds_barrier();
+        STAMP(4);
     }
 }
 
