@@ -64,7 +64,8 @@ typedef enum {
     ADN_PRECISION_BF16X3 = 2 /* fp32 everywhere like ADN_PRECISION_F32, but every large GEMM runs as three bf16 MFMA
                               products of the operands' bf16 hi / lo parts (a_hi b_hi + a_hi b_lo + a_lo b_hi, fp32
                               accumulate: ~4e-6 relative, inside the 1e-4 parity gate) at the bf16 matrix rate; the
-                              recurrent kernels are the fp32 ones */
+                              recurrent products likewise, in weight-stationary kernels, for LSTMs of <= 256 units
+                              (wider ones run the fp32 per-step kernels) */
 } adn_precision;
 
 enum {

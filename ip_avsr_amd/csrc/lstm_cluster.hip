@@ -1,4 +1,5 @@
-// Weight-stationary LSTM kernels (bf16 mode, H <= 512): W_hid never leaves the CU.
+// Weight-stationary LSTM kernels (bf16 mode, H <= 512; bf16x3 mode, H <= 256: the *_x3 kernels further down): W_hid never
+// leaves the CU.
 //
 // The persistent kernels of lstm_persistent.hip give a 16-utterance slice to ONE workgroup, which must then stream
 // the whole W_hid (512 KB as bf16 at H = 250, 2 MB at H = 500) from L2 every time step: 12-14 us per step (34-70 us at
