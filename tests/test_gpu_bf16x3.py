@@ -174,11 +174,12 @@ def _small_x3_model(lstm_size, peepholes, seed, dims=(60, 44)):
 
 
 @pytest.mark.parametrize("H,B,T,peep", [(250, 70, 9, False), (250, 33, 2, True), (100, 5, 1, False), (64, 100, 12, True),
-                                        (256, 32, 5, False), (17, 40, 7, True)])
+                                        (256, 32, 5, False), (17, 40, 7, True), (32, 2100, 3, False)])
 def test_x3_weight_stationary_lstm_kernels_match_the_fp32_step_kernels(torch_cuda, lib, monkeypatch, H, B, T, peep):
     """lstm_{fwd,bwd}_cluster_x3_kernel (csrc/lstm_cluster.hip) against the fp32 step kernels the mode falls back to
     (ADN_LSTM_NO_X3_CLUSTER): ragged masks, partial 32-row groups, padded hidden sizes, peepholes, T = 1 / 2, backwards LSTMs
-    (the aggregation pair).  h travels with a 16-bit significand between the workgroups: probabilities to 2e-6, gradients to
+    (the aggregation pair); B = 2100 does not fit one resident launch (66 groups x 4 workgroups > 256 CUs): both runs then take
+    the step kernels.  h travels with a 16-bit significand between the workgroups: probabilities to 2e-6, gradients to
     1e-4 of each tensor's scale (measured <= 2.1e-5 with the recurrent weights scaled up 3 x)."""
     spec, p, m, rng = _small_x3_model(H, peep, 100 * H + B + T)
     theta = min(9, 2 * T + 1) if T > 1 else 3
