@@ -204,7 +204,7 @@ struct adn_model {
     bool side_ready = false;
     // concat fusion in bf16 mode: the aggregation LSTMs read ONE materialised [N][S*ldh] bf16 matrix, so their input
     // projection, dW_in and the gradient wrt the concat are one GEMM each per LSTM instead of S
-    char* cat16 = nullptr; float* dcat = nullptr; float* wcat_tmp = nullptr;
+    char* cat16 = nullptr; float* dcat = nullptr; float* wcat_tmp = nullptr; size_t wcat_tmp_slots = 1;
     // partial slabs of the split-K weight-gradient GEMMs (gemm_bf16_pp_kernel): one workgroup = one 256 x 256 fp32 tile
     float* splitk_ws = nullptr; size_t splitk_ws_floats = 0;
     int lastB = 0, lastT = 0;
@@ -484,7 +484,8 @@ size_t carve(adn_model* m, char* base, int B, int T, bool host_inputs) {
     if (m->cfg.fusion == ADN_FUSE_CONCAT && m->S > 1 && !m->agg.empty()) {
         m->cat16 = cv.take<char>(N * (size_t)m->S * ldh * 2);
         m->dcat = cv.take<float>(N * (size_t)m->S * ldh);
-        m->wcat_tmp = cv.take<float>((size_t)m->S * ldh * ldg);
+        m->wcat_tmp_slots = std::max<size_t>(1, std::min<size_t>(m->agg.size(), kMaxGemmGroups));
+        m->wcat_tmp = cv.take<float>(m->wcat_tmp_slots * (size_t)m->S * ldh * ldg);
     }
     (void)host_inputs;
     return cv.cursor;
@@ -784,7 +785,7 @@ bool cat_path(const adn_model* m) {
 }
 
 // x*W_in + b with x = the materialised concat (ONE GEMM, K = S*ldh; the pad rows of wcat16 are zero)
-int lstm_project_cat(adn_model* m, const LstmParams& lp, const LstmWork& w, int rows) {
+GemmArgs lstm_project_cat_args(adn_model* m, const LstmParams& lp, const LstmWork& w, int rows) {
     GemmArgs g;
     g.layout = GEMM_NN; g.M = rows; g.N = 4 * m->H; g.K = m->S * m->ldh;
     g.A = reinterpret_cast<const float*>(m->cat16); g.lda = m->S * m->ldh;      // (only the bf16 operands are read)
@@ -793,7 +794,7 @@ int lstm_project_cat(adn_model* m, const LstmParams& lp, const LstmWork& w, int 
     g.C = w.xproj; g.ldc = m->ldg; g.bias = m->P(lp.b);
     g.precision = m->cfg.precision;
     g.no_split = 1;                                              // forward pass: reproducible bits
-    return gemm(g, m->stream);
+    return g;
 }
 
 int lstm_init_state(adn_model* m, const LstmParams& lp, const LstmWork& w, int B, int T) {
@@ -985,9 +986,17 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
             for (int j = 0; j < m->S; ++j) in16[j] = m->shadow_of(fin[j]);
             ADN_TRY(concat_cols_bf16(m->S, in16, ldh, m->cat16, m->S * ldh, N, ldh, s));
         }
+        if (cat) {                                               // the pair's projections share the concat: one grouped launch
+            GemmArgs gs[kMaxGemmGroups];
+            size_t k = 0;
+            while (k < m->agg.size()) {
+                int n = 0;
+                for (; k < m->agg.size() && n < kMaxGemmGroups; ++k) gs[n++] = lstm_project_cat_args(m, m->agg[k], m->aggw[k], N);
+                ADN_TRY(gemm_grouped(gs, n, s));
+            }
+        }
         for (size_t k = 0; k < m->agg.size(); ++k) {
-            if (cat) ADN_TRY(lstm_project_cat(m, m->agg[k], m->aggw[k], N));
-            else ADN_TRY(lstm_project(m, m->agg[k], m->aggw[k], fin.data(), fld.data(), (int)fin.size(), H, N));
+            if (!cat) ADN_TRY(lstm_project(m, m->agg[k], m->aggw[k], fin.data(), fld.data(), (int)fin.size(), H, N));
             ADN_TRY(lstm_init_state(m, m->agg[k], m->aggw[k], B, T));
             steps.push_back(make_step(m, m->agg[k], m->aggw[k], nullptr, false));
         }
@@ -1162,16 +1171,30 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         for (auto& st : m->st) st.dout_ld = 0;
         if (cat) {
             const int ldcat = m->S * ldh;
+            // dW_in for all S blocks: cat^T dG into a scratch matrix per LSTM (pad rows dropped by add_row_blocks); the LSTMs'
+            // GEMMs share the concat: one grouped launch when the scratch holds them all
+            const size_t wcat_elems = (size_t)ldcat * m->ldg;
+            const bool group_dw = m->agg.size() >= 2 && m->agg.size() <= (size_t)kMaxGemmGroups && m->agg.size() <= m->wcat_tmp_slots;
+            GemmArgs dws[kMaxGemmGroups];
             for (size_t k = 0; k < m->agg.size(); ++k) {
-                const LstmParams& lp = m->agg[k]; const LstmWork& w = m->aggw[k];
-                GemmArgs g;                                   // dW_in for all S blocks: cat^T dG, pad rows dropped afterwards
+                const LstmWork& w = m->aggw[k];
+                GemmArgs g;
                 g.layout = GEMM_TN; g.M = ldcat; g.N = 4 * H; g.K = N;
                 g.A = reinterpret_cast<const float*>(m->cat16); g.lda = ldcat; g.A16 = m->cat16;
                 g.B = w.dG; g.ldb = m->ldg; g.B16 = m->shadow_of(w.dG);
-                g.C = m->wcat_tmp; g.ldc = m->ldg; g.precision = m->cfg.precision;
+                g.C = m->wcat_tmp + (group_dw ? k * wcat_elems : 0); g.ldc = m->ldg; g.precision = m->cfg.precision;
                 g.splitk_ws = m->splitk_ws; g.splitk_ws_floats = m->splitk_ws_floats;      // (main stream: before the fork)
+                if (group_dw) { dws[k] = g; continue; }
                 ADN_TRY(gemm(g, s));
-                ADN_TRY(add_row_blocks(m->wcat_tmp, m->G(lp.W_in), m->ldg, m->S, H, ldh, 4 * H, s));
+                ADN_TRY(add_row_blocks(m->wcat_tmp, m->G(m->agg[k].W_in), m->ldg, m->S, H, ldh, 4 * H, s));
+            }
+            if (group_dw) {
+                ADN_TRY(gemm_grouped(dws, (int)m->agg.size(), s));
+                for (size_t k = 0; k < m->agg.size(); ++k)
+                    ADN_TRY(add_row_blocks(m->wcat_tmp + k * wcat_elems, m->G(m->agg[k].W_in), m->ldg, m->S, H, ldh, 4 * H, s));
+            }
+            for (size_t k = 0; k < m->agg.size(); ++k) {
+                const LstmParams& lp = m->agg[k]; const LstmWork& w = m->aggw[k];
                 GemmArgs d;                                   // d(concat) (+)= dG W_in^T through the side-by-side W^T copies
                 d.layout = GEMM_NN; d.M = N; d.N = ldcat; d.K = 4 * H;
                 d.A = w.dG; d.lda = m->ldg; d.A16 = m->shadow_of(w.dG);
