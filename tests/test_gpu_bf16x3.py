@@ -225,3 +225,45 @@ def test_x3_exchange_tags_survive_more_launches_than_their_sequence_field(torch_
         got = m.predict([a[:, :T].copy(), b[:, :T].copy()], np.ones((B, T), np.uint8), 3)
         assert np.abs(got - want[it % len(cases)]).max() <= 2e-6, it
     m.close()
+
+
+def test_bf16x3_adam_trajectory_and_clip_against_the_oracle(torch_cuda, lib):
+    """Four Adam steps of the mode (split GEMMs where they are large enough, the hi / lo weight-stationary LSTM kernels
+    throughout) against the fp64 oracle on a 2-stream concat graph with peepholes: losses to 2e-5, parameters within 5 % of
+    the step size; then a saturating case in which the +-5 clip on d(gates) must bind as in the oracle."""
+    spec, p, m, rng = _small_x3_model(48, True, 21)
+    B, T, theta, lr = 37, 8, 2, 1e-3
+    mask = ragged_mask(rng, B, T)
+    xs = [(rng.normal(size=(B, T, d)) * mask[..., None]).astype(np.float32) for d in (60, 44)]
+    y = np.repeat((np.arange(B) % 26)[:, None], T, axis=1).astype(np.int32)
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    st = O.adam_init(p64)
+    x64 = [x.astype(np.float64) for x in xs]
+    for step in range(4):
+        l_ref = O.train_step(spec, p64, st, x64, y, mask, theta, lr)
+        l = m.train_step(xs, y, mask, theta, lr)
+        assert abs(l - l_ref) <= 2e-5 * abs(l_ref), (step, l, l_ref)
+    got = m.get_params_dict()
+    for k in p64:
+        assert np.abs(got[k] - p64[k]).max() <= 0.05 * lr, k
+    # saturation: a huge classifier makes the back-propagated dh large enough for the clip inside BPTT to bind.  With logits of
+    # ~4000 h the loss gradient comes from a handful of borderline frames and EVERY tensor's gradient scales with their
+    # probabilities: a perturbation of h by 2^-17 (the 16-bit significand h travels with between the workgroups) moves that
+    # common factor by a few per cent (measured 3.6 %; the fp32 mode's 2^-24 moves it by 0.17 %, the oracle in fp32 by 0.03 %),
+    # uniformly over all tensors to 4 digits.  The clip is an element-wise nonlinearity: if it fired differently the
+    # DIRECTION would change -- so the direction is held to 1e-6 and the common factor to 10 %.
+    q = {k: v.copy() for k, v in p.items()}
+    q["softmax.W"] = (rng.normal(size=q["softmax.W"].shape) * 4000).astype(np.float32)
+    m.set_params_dict(q)
+    q64 = {k: v.astype(np.float64) for k, v in q.items()}
+    _, g_ref, _ = O.loss_and_grads(spec, q64, x64, y, mask, theta)
+    m.compute_grads(xs, y, mask, theta)
+    g = m.get_grads_dict()
+    scales = []
+    for k in ("f_lstm_agg.b_ingate", "b_lstm_agg.b_outgate", "lstm_s1.W_hid_to_cell", "lstm_s2.W_cell_to_outgate", "fc1_s1.W"):
+        a, b = g[k].astype(np.float64).ravel(), g_ref[k].ravel()
+        cos = a @ b / np.sqrt((a @ a) * (b @ b))
+        assert 1.0 - cos <= 1e-6, (k, 1.0 - cos)
+        scales.append(a @ b / (b @ b))
+    assert max(abs(sc - 1.0) for sc in scales) <= 0.1 and max(scales) - min(scales) <= 1e-3, scales
+    m.close()
