@@ -36,12 +36,12 @@ def summarise(fa, fb, match):
 def main():
     fa, fb, prec = sys.argv[1:4]
     commit = sys.argv[4] if len(sys.argv) > 4 else "unknown"
-    match = "gemm_bf16" if prec == "bf16" else "gemm_f32_kernel"      # (gemm_bf16_kernel and gemm_bf16_pp_kernel)
+    match = "gemm_bf16" if prec in ("bf16", "bf16x3") else "gemm_f32_kernel"      # (gemm_bf16_kernel and gemm_bf16_pp_kernel)
     out = {"kernel_class": "%s (all instantiations)" % match, "commit": "PMC passes taken at commit %s" % commit}
     out.update(summarise(fa, fb, match))
     # the LSTM kernels: one launch covers all T time steps of up to 3 LSTMs (bench.py divides by what a launch covered)
-    for key, m in (("lstm_fwd", "lstm_fwd_cluster_kernel" if prec == "bf16" else "lstm_fwd_step_kernel"),
-                   ("lstm_bwd", "lstm_bwd_cluster_kernel" if prec == "bf16" else "lstm_bwd_step_kernel")):
+    lstm = {"bf16": "lstm_%s_cluster_kernel", "bf16x3": "lstm_%s_cluster_x3_kernel"}.get(prec, "lstm_%s_step_kernel")
+    for key, m in (("lstm_fwd", lstm % "fwd"), ("lstm_bwd", lstm % "bwd")):
         d = summarise(fa, fb, m)
         if d["launches"]:
             d["kernel"] = m
