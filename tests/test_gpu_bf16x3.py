@@ -226,7 +226,7 @@ def test_x3_exchange_tags_survive_more_launches_than_their_sequence_field(torch_
     for it in range(150):
         T, a, b = cases[it % len(cases)]
         got = m.predict([a[:, :T].copy(), b[:, :T].copy()], np.ones((B, T), np.uint8), 3)
-        assert np.abs(got - want[it % len(cases)]).max() <= 2e-6, it
+        assert np.abs(got - want[it % len(cases)]).max() <= 5e-6, it
     m.close()
 
 
