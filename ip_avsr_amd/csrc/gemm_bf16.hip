@@ -479,7 +479,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 
 // WM x 2 waves per workgroup, each owning a (BM/WM) x (BN/2) block of the tile
 template <int BM, int BN, int WM, bool A_KC, bool B_KC, typename T>
-__global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams p) {
+__global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams pin) {
+    // grouped launch (host: gemm_rs, bf16 operand copies only): blockIdx.z picks the problem's buffers
+    GemmParams p = pin;
+    if (pin.ngroups > 1) {
+        const GemmGroup& g = pin.grp[blockIdx.z];
+        p.A16 = g.A16; p.B16 = g.B16; p.C = g.C; p.C16 = g.C16; p.Y16 = g.Y16; p.Y = g.Y; p.bias = g.bias; p.colsum = g.colsum;
+    }
     constexpr int NT = WM * 128;
     typedef typename StageSel<BM, A_KC, T, NT>::type SA;
     typedef typename StageSel<BN, B_KC, T, NT>::type SB;

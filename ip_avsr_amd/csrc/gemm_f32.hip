@@ -180,7 +180,8 @@ static int device_cus() {
 }
 
 // Runs `n` problems of identical shape / layout / flags through the ping-pong kernel if it applies; *used says whether.
-static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used) {
+// dry: only answer whether the kernel WOULD take the launch (no side effects)
+static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used, bool dry = false) {
     *used = false;
     const GemmArgs& g = gs[0];
     static const int mode_env = getenv("ADN_GEMM_PP") ? atoi(getenv("ADN_GEMM_PP")) : -1;   // 0: off, 4/5/6: force a tile shape
@@ -272,6 +273,7 @@ static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used
         if (!g.splitk_ws || need > g.splitk_ws_floats || ((uintptr_t)g.splitk_ws % 16)) return ADN_OK;
         p.partial = g.splitk_ws;
     }
+    if (dry) { *used = true; return ADN_OK; }
     bool fused_colsum = false;
     if (g.colsum && splits == 1) {
         fused_colsum = true;
@@ -324,6 +326,8 @@ static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used
 
 static bool x3_takes(const GemmArgs& g);
 static int gemm_grouped_bf16x3(const GemmArgs* gs, int n, hipStream_t stream);
+static int gemm_rs(const GemmArgs* gs, int n, hipStream_t stream);
+static bool rs_groupable(const GemmArgs* gs, int n);
 
 int gemm_grouped(const GemmArgs* gs, int n, hipStream_t stream) {
     if (n <= 0) return ADN_OK;
@@ -338,6 +342,10 @@ int gemm_grouped(const GemmArgs* gs, int n, hipStream_t stream) {
     bool used = false;
     if (n > 1) ADN_TRY(gemm_pp_try(gs, n, stream, &used));
     if (used) return ADN_OK;
+    // (a problem the ping-pong kernel takes alone -- the 2000 x 1000 weight gradients: 3 x 80 us against 450 us as one
+    //  register-staged launch -- goes out alone)
+    if (n > 1) ADN_TRY(gemm_pp_try(gs, 1, stream, &used, /*dry=*/true));
+    if (!used && rs_groupable(gs, n)) return gemm_rs(gs, n, stream);
     for (int k = 0; k < n; ++k) ADN_TRY(gemm(gs[k], stream));
     return ADN_OK;
 }
@@ -446,33 +454,27 @@ static int gemm_grouped_bf16x3(const GemmArgs* gs, int n, hipStream_t stream) {
     bool used = false;
     ADN_TRY(gemm_pp_try(h, n, stream, &used));
     if (used) return ADN_OK;
+    ADN_TRY(gemm_pp_try(h, 1, stream, &used, /*dry=*/true));
+    if (!used && rs_groupable(h, n)) return gemm_rs(h, n, stream);
     for (int k = 0; k < n; ++k) ADN_TRY(gemm(h[k], stream));
     return ADN_OK;
 }
 
-int gemm(const GemmArgs& g, hipStream_t stream) {
-    ADN_CHECK(g.layout >= GEMM_NN && g.layout <= GEMM_TN, ADN_ERR_INVALID, "gemm: bad layout");
-    if (g.M <= 0 || g.N <= 0) return ADN_OK;
-    ADN_CHECK(g.K > 0, ADN_ERR_INVALID, "gemm: K must be positive");
-    if (g.precision == ADN_PRECISION_BF16X3) {
-        if (x3_takes(g)) return gemm_bf16x3(g, stream);
-        GemmArgs h = g;
-        h.precision = ADN_PRECISION_F32;
-        return gemm(h, stream);
-    }
+// The register-staged kernels for n >= 1 problems of ONE configuration (identical shapes, strides, flags and pointer
+// null-ness -- the caller checked): n > 1 goes out as ONE launch whose blockIdx.z picks the problem (bf16 kernels reading
+// bf16 operand copies only).  What a small-batch step gains from it: its GEMMs are latency-bound (M = B T = 1040 rows at the
+// reference's minibatch: 6-27 us per launch whatever the flops), and three streams' layers in one launch cost one latency.
+static int gemm_rs(const GemmArgs* gs, int n, hipStream_t stream) {
+    const GemmArgs& g = gs[0];
     const bool lean_c = !g.C && g.C16 && g.precision == ADN_PRECISION_BF16 && g.A16 && g.B16 && !g.accumulate;
-    ADN_CHECK(g.A && g.B && (g.C || lean_c), ADN_ERR_INVALID, "gemm: null operand");
+    for (int k = 0; k < n; ++k) {
+        const GemmArgs& q = gs[k];
+        ADN_CHECK(q.A && q.B && (q.C || lean_c), ADN_ERR_INVALID, "gemm: null operand");
+        ADN_CHECK(((uintptr_t)q.A % 16) == 0 && ((uintptr_t)q.B % 16) == 0, ADN_ERR_INVALID, "gemm: A and B must be 16-byte aligned");
+    }
     ADN_CHECK(g.lda % 4 == 0 && g.ldb % 4 == 0, ADN_ERR_INVALID, "gemm: lda/ldb must be multiples of 4 floats");
-    ADN_CHECK(((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0, ADN_ERR_INVALID,
-              "gemm: A and B must be 16-byte aligned");
     ADN_CHECK(g.precision == ADN_PRECISION_F32 || g.precision == ADN_PRECISION_BF16, ADN_ERR_INVALID,
               "gemm: unsupported precision");
-
-    {
-        bool used = false;
-        ADN_TRY(gemm_pp_try(&g, 1, stream, &used));
-        if (used) return ADN_OK;
-    }
     GemmParams p;
     std::memset(static_cast<void*>(&p), 0, sizeof(p));
     p.M = g.M; p.N = g.N; p.K = g.K;
@@ -481,11 +483,12 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
     p.A16 = g.A16; p.B16 = g.B16; p.C16 = g.C16;
     p.colsum = nullptr; p.colsum_ld = 0;
     p.Y16 = (g.precision == ADN_PRECISION_BF16 && g.A16 && g.B16) ? g.Y16 : nullptr;
-    if (g.colsum_done) *g.colsum_done = 0;
+    for (int k = 0; k < n; ++k) if (gs[k].colsum_done) *gs[k].colsum_done = 0;
     p.act = g.act; p.act_grad = g.act_grad; p.accumulate = g.accumulate;
 
-    const int64_t t128 = (int64_t)cdiv(g.M, 128) * cdiv(g.N, 128);
-    const int64_t t64 = (int64_t)cdiv(g.M, 64) * cdiv(g.N, 64);
+    // (tile counts of the whole launch: a group fills the device where one of its problems would not)
+    const int64_t t128 = (int64_t)cdiv(g.M, 128) * cdiv(g.N, 128) * n;
+    const int64_t t64 = (int64_t)cdiv(g.M, 64) * cdiv(g.N, 64) * n;
     // (the split-K epilogue adds bare partial sums: no bias, no act'(Y) mask)
     const bool can_split = g.act == ADN_ACT_LINEAR && !g.bias && !g.Y && !g.Y16;
     // 128x128 tiles (4 MFMA tiles per wave, half the LDS fragment reads per MFMA of the 64x64 shape) whenever
@@ -496,18 +499,18 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
     // cannot hide it: at K <= 512 the 64x64 shape, 8 workgroups per CU, is 1.3-2.2x faster; equal at K = 1024)
     // ... and the 128-wide tiles do not waste much more of their area on the matrix edges than 64-wide ones would
     // (N = 152: 59 % vs 79 % useful)
-    const double fill128 = (double)g.M * g.N / ((double)t128 * 128 * 128), fill64 = (double)g.M * g.N / ((double)t64 * 64 * 64);
+    const double fill128 = (double)g.M * g.N * n / ((double)t128 * 128 * 128), fill64 = (double)g.M * g.N * n / ((double)t64 * 64 * 64);
     const bool big = force_tile ? force_tile == 128
                                 : (g.K >= 768 && fill128 >= 0.85 * fill64 &&
                                    (t128 >= 384 || (can_split && t128 >= 24 && g.K >= 2048)));
     // 256 x 64 tiles (bf16 kernels): a narrow output under many rows -- the B panel is re-read once per 256 rows
     // instead of once per 64, at the per-wave tile of the 128 x 128 shape
-    const int64_t t_tall = (int64_t)cdiv(g.M, 256) * cdiv(g.N, 64);
+    const int64_t t_tall = (int64_t)cdiv(g.M, 256) * cdiv(g.N, 64) * n;
     // (measured, profiles/r02/gemm_lab_tall.txt: 129024 x 152 x 2504 -- the conv auto-encoder's second convolution at batch
     //  1024 -- 266 us against 331 (64 x 64) / 293 (128 x 128); N = 104 / 150 / 200 and the 20800-row shapes: no gain)
     const bool tall = g.precision == ADN_PRECISION_BF16 &&
                       (force_tile ? force_tile == 256 : (!big && g.N > 128 && g.N <= 192 && g.M >= 65536 && g.K >= 1024));
-    const int64_t tiles = tall ? t_tall : (big ? t128 : t64);
+    const int64_t tiles = tall ? t_tall : (big ? t128 : t64);    // of the whole launch
     int split = 1;
     // split-K: enough workgroups for two per CU (measured on the weight-gradient shapes: 512 beats 768 / 1024 by 0-12 %,
     // fewer partial sums to add atomically; 256 leaves CUs idle on the large ones)
@@ -523,27 +526,45 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
     if (p.atomic) p.C16 = nullptr;            // partial sums: the bf16 copy is made after the kernel (below)
     if (g.precision == ADN_PRECISION_BF16 && p.A16 && p.B16)
         ADN_CHECK(g.lda % 8 == 0 && g.ldb % 8 == 0, ADN_ERR_INVALID, "gemm: bf16 shadows need lda/ldb % 8 == 0");
-    ProfScope prof(PROF_GEMM_NN + g.layout, 2.0 * g.M * g.N * g.K,
-                   4.0 * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N), stream);
+    ProfScope prof(PROF_GEMM_NN + g.layout, 2.0 * g.M * g.N * g.K * n,
+                   4.0 * n * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N), stream);
     if (p.atomic && !g.accumulate)
-        ADN_HIP_CHECK(hipMemset2DAsync(g.C, (size_t)g.ldc * 4, 0, (size_t)g.N * 4, g.M, stream));
-    if (lean_c) ADN_CHECK(g.ldc % 4 == 0 && g.N % 4 == 0 && ((uintptr_t)g.C16 % 8) == 0, ADN_ERR_INVALID,
-                          "gemm: bf16-only output needs N and ldc to be multiples of 4");
+        for (int k = 0; k < n; ++k)
+            ADN_HIP_CHECK(hipMemset2DAsync(gs[k].C, (size_t)g.ldc * 4, 0, (size_t)g.N * 4, g.M, stream));
+    if (lean_c)
+        for (int k = 0; k < n; ++k)
+            ADN_CHECK(g.ldc % 4 == 0 && g.N % 4 == 0 && ((uintptr_t)gs[k].C16 % 8) == 0, ADN_ERR_INVALID,
+                      "gemm: bf16-only output needs N and ldc to be multiples of 4");
     const int tsz = big ? 128 : 64;
     p.tiles_m = cdiv(g.M, tall ? 256 : tsz); p.tiles_n = cdiv(g.N, tsz);
     const int cs_ld = (int)round_up(g.N, 4);
-    if (g.colsum && g.precision == ADN_PRECISION_BF16 && !p.atomic && g.ldc % 4 == 0 &&
-        ((uintptr_t)g.C % 16) == 0 && (!g.Y || (g.ldy % 4 == 0 && ((uintptr_t)g.Y % 16) == 0)) && g.N % 4 == 0 &&
-        g.colsum_ws && ((uintptr_t)g.colsum_ws % 16) == 0 && (size_t)p.tiles_m * cs_ld <= g.colsum_ws_floats) {
-        p.colsum = g.colsum_ws; p.colsum_ld = cs_ld;   // the vectorised epilogue path is guaranteed for every element
-        if (g.colsum_done) *g.colsum_done = 1;
+    bool fused_colsum = g.colsum && g.precision == ADN_PRECISION_BF16 && !p.atomic && g.ldc % 4 == 0 &&
+                        (!g.Y || g.ldy % 4 == 0) && g.N % 4 == 0;
+    for (int k = 0; k < n && fused_colsum; ++k) {
+        const GemmArgs& q = gs[k];
+        fused_colsum = ((uintptr_t)q.C % 16) == 0 && (!q.Y || ((uintptr_t)q.Y % 16) == 0) && q.colsum_ws &&
+                       ((uintptr_t)q.colsum_ws % 16) == 0 && (size_t)p.tiles_m * cs_ld <= q.colsum_ws_floats;
     }
+    if (fused_colsum) {
+        p.colsum = g.colsum_ws; p.colsum_ld = cs_ld;   // the vectorised epilogue path is guaranteed for every element
+        for (int k = 0; k < n; ++k) if (gs[k].colsum_done) *gs[k].colsum_done = 1;
+    }
+    const int64_t tiles_one = tiles / n;      // blockIdx.x walks ONE problem's tiles, blockIdx.z the problems
     {   // square-ish per-XCD tile blocks: panel width ~ sqrt(tiles per XCD)
-        const int chunk = std::max<int64_t>(1, tiles / 8);
+        const int chunk = std::max<int64_t>(1, tiles_one / 8);
         int bn = (int)std::lround(std::sqrt((double)chunk));
         p.panel_n = std::max(1, std::min(bn, p.tiles_n));
     }
-    const dim3 grid((unsigned)tiles, split);
+    if (n > 1) {
+        p.ngroups = n;
+        for (int k = 0; k < n; ++k) {
+            GemmGroup& q = p.grp[k];
+            q.A16 = gs[k].A16; q.B16 = gs[k].B16; q.C = gs[k].C; q.C16 = p.atomic ? nullptr : gs[k].C16;
+            q.Y16 = p.Y16 ? gs[k].Y16 : nullptr; q.Y = gs[k].Y; q.bias = gs[k].bias;
+            q.colsum = fused_colsum ? gs[k].colsum_ws : nullptr;
+        }
+    }
+    const dim3 grid((unsigned)tiles_one, split, n);
     static const bool trace = getenv("ADN_GEMM_TRACE") != nullptr;       // one line per launch, pairs with a kernel trace
     if (trace)
         fprintf(stderr, "ADN_GEMM %s M=%d N=%d K=%d tile=%d tiles=%lld split=%d shadows=%d lean=%d acc=%d\n",
@@ -553,15 +574,55 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
     else if (big) launch<128, 128>(p, g.layout, grid, stream);
     else launch<64, 64>(p, g.layout, grid, stream);
     ADN_HIP_CHECK(hipGetLastError());
-    if (p.colsum) {
-        if (g.colsum_batch && g.colsum_batch->n < 8) col_sum_batch_add(*g.colsum_batch, p.colsum, p.colsum_ld, p.tiles_m, g.N, g.colsum);
-        else ADN_TRY(col_sum(p.colsum, p.colsum_ld, p.tiles_m, g.N, g.colsum, 1, stream));
-    }
-    if (g.C16 && p.atomic) {                  // split-K result: refresh the bf16 shadow of whole rows
-        ADN_CHECK(g.ldc % 8 == 0, ADN_ERR_INVALID, "gemm: bf16 shadow of C needs ldc % 8 == 0");
-        ADN_TRY(to_bf16(g.C, g.C16, (size_t)g.M * g.ldc, stream));
+    for (int k = 0; k < n; ++k) {
+        const GemmArgs& q = gs[k];
+        if (fused_colsum) {
+            if (q.colsum_batch && q.colsum_batch->n < 8) col_sum_batch_add(*q.colsum_batch, q.colsum_ws, p.colsum_ld, p.tiles_m, g.N, q.colsum);
+            else ADN_TRY(col_sum(q.colsum_ws, p.colsum_ld, p.tiles_m, g.N, q.colsum, 1, stream));
+        }
+        if (q.C16 && p.atomic) {                  // split-K result: refresh the bf16 shadow of whole rows
+            ADN_CHECK(g.ldc % 8 == 0, ADN_ERR_INVALID, "gemm: bf16 shadow of C needs ldc % 8 == 0");
+            ADN_TRY(to_bf16(q.C, q.C16, (size_t)g.M * g.ldc, stream));
+        }
     }
     return ADN_OK;
+}
+
+// may these problems share one launch of the register-staged bf16 kernels?
+static bool rs_groupable(const GemmArgs* gs, int n) {
+    const GemmArgs& g = gs[0];
+    if (n < 2 || n > kMaxGemmGroups || g.precision != ADN_PRECISION_BF16 || getenv("ADN_GEMM_NO_RS_GROUPS")) return false;
+    for (int k = 0; k < n; ++k) {
+        const GemmArgs& q = gs[k];
+        if (!q.A16 || !q.B16 || q.precision != g.precision || q.layout != g.layout || q.M != g.M || q.N != g.N || q.K != g.K ||
+            q.lda != g.lda || q.ldb != g.ldb || q.ldc != g.ldc || q.ldy != g.ldy || q.act != g.act || q.act_grad != g.act_grad ||
+            q.accumulate != g.accumulate || q.no_split != g.no_split || (q.C == nullptr) != (g.C == nullptr) ||
+            (q.C16 == nullptr) != (g.C16 == nullptr) || (q.bias == nullptr) != (g.bias == nullptr) ||
+            (q.Y == nullptr) != (g.Y == nullptr) || (q.Y16 == nullptr) != (g.Y16 == nullptr) ||
+            (q.colsum == nullptr) != (g.colsum == nullptr))
+            return false;
+    }
+    return true;
+}
+
+int gemm(const GemmArgs& g, hipStream_t stream) {
+    ADN_CHECK(g.layout >= GEMM_NN && g.layout <= GEMM_TN, ADN_ERR_INVALID, "gemm: bad layout");
+    if (g.M <= 0 || g.N <= 0) return ADN_OK;
+    ADN_CHECK(g.K > 0, ADN_ERR_INVALID, "gemm: K must be positive");
+    if (g.precision == ADN_PRECISION_BF16X3) {
+        if (x3_takes(g)) return gemm_bf16x3(g, stream);
+        GemmArgs h = g;
+        h.precision = ADN_PRECISION_F32;
+        return gemm(h, stream);
+    }
+    ADN_CHECK(g.precision == ADN_PRECISION_F32 || g.precision == ADN_PRECISION_BF16, ADN_ERR_INVALID,
+              "gemm: unsupported precision");
+    {
+        bool used = false;
+        ADN_TRY(gemm_pp_try(&g, 1, stream, &used));
+        if (used) return ADN_OK;
+    }
+    return gemm_rs(&g, 1, stream);
 }
 
 }  // namespace adn

@@ -761,6 +761,27 @@ int run_lstm_group(adn_model* m, std::vector<LstmStep>& steps, int B, int T, boo
     return ADN_OK;
 }
 
+// a list of prepared GEMMs as grouped launches: neighbours in the list that share shape, strides and flags go out together
+int issue_grouped(adn_model* m, std::vector<GemmArgs>& list) {
+    std::vector<char> done(list.size(), 0);
+    for (size_t i = 0; i < list.size(); ++i) {
+        if (done[i]) continue;
+        GemmArgs batch[kMaxGemmGroups];
+        int nb = 0;
+        batch[nb++] = list[i]; done[i] = 1;
+        for (size_t j = i + 1; j < list.size() && nb < kMaxGemmGroups; ++j) {
+            const GemmArgs& a = list[i]; const GemmArgs& b = list[j];
+            if (done[j] || a.layout != b.layout || a.M != b.M || a.N != b.N || a.K != b.K || a.lda != b.lda || a.ldb != b.ldb ||
+                a.ldc != b.ldc || a.accumulate != b.accumulate || (a.bias == nullptr) != (b.bias == nullptr) ||
+                (a.A16 == nullptr) != (b.A16 == nullptr) || (a.B16 == nullptr) != (b.B16 == nullptr) || a.C == b.C)
+                continue;
+            batch[nb++] = b; done[j] = 1;
+        }
+        ADN_TRY(gemm_grouped(batch, nb, m->stream));
+    }
+    return ADN_OK;
+}
+
 // x*W_in + b for one LSTM whose input is the (virtual) concatenation of `nblk` matrices of width `blkw`
 int lstm_project(adn_model* m, const LstmParams& lp, const LstmWork& w, const float* const* in, const int* ld_in,
                  int nblk, int blkw, int rows) {
@@ -896,6 +917,7 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
             }
         }
     }
+    std::vector<GemmArgs> stream_proj;
     for (auto& st : m->st) {
         OnSideStream on(m, (int)(&st - m->st.data()));           // encoder, delta layer, input projection of this stream
         const float* a = st.x; int lda = st.ldx;
@@ -927,12 +949,22 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
         if (!feat16) ADN_TRY(refresh(m, st.feat, (size_t)N * ld_of(st.feat_dim)));
         for (size_t k = 0; k < st.lstm.size(); ++k) {
             const float* in[1] = {st.feat}; const int ld[1] = {ld_of(st.feat_dim)};
-            ADN_TRY(lstm_project(m, st.lstm[k], st.lw[k], in, ld, 1, st.feat_dim, N));
+            if (grouped) {                                       // the streams' projections go out together below
+                GemmArgs g;
+                g.layout = GEMM_NN; g.M = N; g.N = 4 * m->H; g.K = st.feat_dim;
+                g.A = st.feat; g.lda = ld[0]; g.B = m->P(st.lstm[k].W_in); g.ldb = m->ldg;
+                g.C = st.lw[k].xproj; g.ldc = m->ldg; g.bias = m->P(st.lstm[k].b); g.no_split = 1;
+                mgemm_prepare(m, g, false);
+                stream_proj.push_back(g);
+            } else {
+                ADN_TRY(lstm_project(m, st.lstm[k], st.lw[k], in, ld, 1, st.feat_dim, N));
+            }
             ADN_TRY(lstm_init_state(m, st.lstm[k], st.lw[k], B, T));
             steps.push_back(make_step(m, st.lstm[k], st.lw[k], nullptr, false));
         }
     }
     ADN_TRY(join_streams(m));
+    ADN_TRY(issue_grouped(m, stream_proj));
     ADN_TRY(run_lstm_group(m, steps, B, T, false));
     for (auto& st : m->st) {
         if (st.lstm.size() == 2) {                               // summed BLSTM sub-stream
@@ -1320,6 +1352,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
     };
     std::vector<Walk> walk(m->st.size());
     // everything of stream si above its encoder: LSTM parameter / input gradients, dropout, delta layer, BatchNorm, act'
+    std::vector<char> first_dx_done(m->st.size(), 0);          // layer-major: the first LSTM's input gradient went out grouped
     auto stream_head = [&](size_t si, bool lstm_grads_done) -> int {
         StreamState& st = m->st[si];
         Walk& w = walk[si];
@@ -1334,7 +1367,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         w.split_first = st.cfg.n_enc >= 2;
         w.L = st.cfg.n_enc;
         if (st.cfg.n_enc == 0) { ADN_TRY(bucket_ready(w.b_rest)); return ADN_OK; }   // nothing trainable below the LSTM
-        for (size_t k = 0; k < st.lstm.size(); ++k)
+        for (size_t k = first_dx_done[si] ? 1 : 0; k < st.lstm.size(); ++k)
             ADN_TRY(lstm_input_grad(m, st.lstm[k], st.lw[k], 0, st.feat_dim, st.dfeat, ldf, N, k > 0));
         if (m->stochastic && st.cfg.dropout_p > 0.f)
             ADN_TRY(dropout_apply(st.dfeat, ldf, st.dfeat, ldf, B, T, st.feat_dim, st.feat_dim, 0, st.cfg.dropout_p,
@@ -1431,6 +1464,21 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
                 for (size_t k = 0; k < st.lstm.size(); ++k)
                     jobs.push_back(LstmGradJob{&st.lstm[k], &st.lw[k], st.feat, ld_of(st.feat_dim), st.feat_dim});
             ADN_TRY(lstm_param_grads_grouped(m, jobs, B, T, stream_sums_done));
+        }
+        {                                      // dfeat = dG W_in^T of every stream's first LSTM: grouped launches
+            std::vector<GemmArgs> dx;
+            for (size_t si = 0; si < m->st.size(); ++si) {
+                StreamState& st = m->st[si];
+                if (st.cfg.n_enc == 0 || st.lstm.empty()) continue;
+                GemmArgs g;
+                g.layout = GEMM_NT; g.M = N; g.N = st.feat_dim; g.K = 4 * m->H;
+                g.A = st.lw[0].dG; g.lda = m->ldg; g.B = m->P(st.lstm[0].W_in); g.ldb = m->ldg;
+                g.C = st.dfeat; g.ldc = ld_of(st.feat_dim);
+                mgemm_prepare(m, g, false);
+                dx.push_back(g);
+                first_dx_done[si] = 1;
+            }
+            ADN_TRY(issue_grouped(m, dx));
         }
         for (size_t si = 0; si < m->st.size(); ++si) { ADN_TRY(stream_head(si, true)); max_depth = std::max(max_depth, walk[si].active ? walk[si].L : 0); }
         for (int d = 0; d < max_depth; ++d) {

@@ -22,7 +22,10 @@ def run():
     model = AdeNetModel(bench.build_spec())
     model.set_precision(os.environ.get("ADN_PRECISION", "bf16"))
     bench.synthetic_params(model)
-    xs, y, m_d, _ = bench.synthetic_batch(torch, 0, bench.B_PER_GPU, device)
+    xs, y, m_d, _ = bench.synthetic_batch(torch, 0, int(os.environ.get("BD_BATCH", bench.B_PER_GPU)), device)   # BD_BATCH=26: the reference's minibatch
+    for _ in range(int(os.environ.get("BD_WARM", 0))):     # (small batches: past the idle-clock transient)
+        model.train_step(xs, y, m_d, bench.THETA, bench.LR, want_loss=False)
+    torch.cuda.synchronize()
     for _ in range(2):
         sys.stderr.write("ADN_STEP\n"); sys.stderr.flush()
         model.train_step(xs, y, m_d, bench.THETA, bench.LR, want_loss=False)
