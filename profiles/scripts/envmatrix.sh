@@ -1,5 +1,5 @@
 # the core parity tests under every diagnostic switch that changes the kernel selection or the schedule
-for e in "X=1" "ADN_GEMM_PP=0" "ADN_GEMM_PP_BARRIERS=2" "ADN_NO_GROUPED_BACKWARD=1" "ADN_STREAMS=1" "ADN_GEMM_NO_XCD_SLICES=1" "ADN_LSTM_NO_CLUSTER=1" "ADN_NO_CAT=1"; do
+for e in "X=1" "ADN_GEMM_PP=0" "ADN_GEMM_PP_BARRIERS=2" "ADN_NO_GROUPED_BACKWARD=1" "ADN_STREAMS=1" "ADN_GEMM_NO_XCD_SLICES=1" "ADN_LSTM_NO_CLUSTER=1" "ADN_NO_CAT=1" "ADN_GEMM_NO_RS_GROUPS=1"; do
   echo "=== $e"
   env $e python -m pytest tests/test_gpu_parity.py tests/test_gpu_bench_geometry.py tests/test_gpu_last_head.py tests/test_gpu_adenet_v1.py -q -x 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -2
 done

@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 RUN = r'''
-import sys, numpy as np, torch
+import os, sys, numpy as np, torch
 sys.path.insert(0, %r)
 import bench
 from ip_avsr_amd.model import AdeNetModel
@@ -32,7 +32,7 @@ torch.cuda.set_device(0)
 m = AdeNetModel(bench.build_spec())
 m.set_precision("bf16")
 bench.synthetic_params(m)
-xs, y, m_d, mask = bench.synthetic_batch(torch, 0, bench.B_PER_GPU, torch.device("cuda", 0))
+xs, y, m_d, mask = bench.synthetic_batch(torch, 0, int(os.environ.get("GEOM_BATCH", bench.B_PER_GPU)), torch.device("cuda", 0))
 if len(sys.argv) > 2:                                # every variant evaluates the SAME parameters
     saved = np.load(sys.argv[2])
     for p in m.params:
@@ -66,7 +66,10 @@ def runs(tmp_path_factory):
     ref = os.path.join(str(d), "default.npz")
     return dict(default=default, nocluster=_run(d, "nocluster", ref, ADN_LSTM_NO_CLUSTER="1"),
                 nopp=_run(d, "nopp", ref, ADN_GEMM_PP="0"), streams=_run(d, "streams", ref, ADN_STREAMS="1"),
-                streammajor=_run(d, "streammajor", ref, ADN_NO_GROUPED_BACKWARD="1"))
+                streammajor=_run(d, "streammajor", ref, ADN_NO_GROUPED_BACKWARD="1"),
+                norsgroups=_run(d, "norsgroups", ref, ADN_GEMM_NO_RS_GROUPS="1"),
+                b26=_run(d, "b26", ref, GEOM_BATCH="26"),
+                b26_norsgroups=_run(d, "b26_norsgroups", ref, GEOM_BATCH="26", ADN_GEMM_NO_RS_GROUPS="1"))
 
 
 def _close(a, b, what, p_tol=1e-3, g_tol=3e-2, cos_tol=0.9995, bit_equal_forward=False):
@@ -110,6 +113,20 @@ def test_schedules_of_the_backward_pass_agree_at_b520(runs):
     _close(runs["default"], runs["streammajor"], "layer-major vs stream-major backward", g_tol=1e-4, cos_tol=0.999999,
            bit_equal_forward=True)
     _close(runs["default"], runs["streams"], "default vs forked HIP streams", g_tol=1e-4, cos_tol=0.999999, bit_equal_forward=True)
+
+
+def test_grouped_launches_of_the_register_staged_kernels_change_nothing(runs):
+    """Same-shape GEMMs the ping-pong kernel declines go out as one launch of the register-staged kernels (blockIdx.z = problem;
+    csrc/gemm_f32.hip::gemm_rs): a few at B = 520, nearly every GEMM of the step at the reference's minibatch B = 26.  The
+    same products in the same k order; a group may pick another tile shape or split than one problem alone."""
+    _close(runs["default"], runs["norsgroups"], "grouped vs single register-staged launches, B = 520", g_tol=1e-4, cos_tol=0.999999,
+           bit_equal_forward=True)
+    # (B = 26: forward bit-identical.  The gradients carry the run-to-run noise of this batch size -- float atomics in arrival
+    #  order (split-K partial sums, the LSTM kernels' bias / initial-state sums), re-rounded to bf16 on the way down: two runs
+    #  of the SAME configuration differ by 2e-4 ... 1.7e-3 relative L2, grouped against single launches by the same amounts
+    #  (profiles/scripts/b26_noise.py))
+    _close(runs["b26"], runs["b26_norsgroups"], "grouped vs single register-staged launches, B = 26", g_tol=1e-2, cos_tol=0.9999,
+           bit_equal_forward=True)
 
 
 def test_bf16_against_the_fp64_oracle_on_a_26_utterance_slice(runs):
