@@ -1452,10 +1452,15 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         ADN_TRY(col_sum_batch(w.bias_sums, m->stream));
         return bucket_ready(w.split_first ? w.b_rest + 1 : w.b_rest);        // every gradient of this stream is final
     };
-    // Layer-major with grouped launches (the streams' layers of equal geometry share tile lists, like the forward pass) on
-    // a single GPU; stream-major when gradient buckets are released to an all-reduce as they complete (data parallel: a
-    // stream's transfer hides under the next stream's GEMMs) or when the streams run on forked HIP streams.
-    const bool layer_major = m->bucket_events.empty() && !streams_concurrent(m) && !getenv("ADN_NO_GROUPED_BACKWARD");
+    // Layer-major with grouped launches (the streams' layers of equal geometry share tile lists, like the forward pass);
+    // stream-major when the streams run on forked HIP streams.  Data parallel runs (gradient buckets released to an
+    // all-reduce as they complete) are layer-major too: every stream's [layers >= 1 + LSTM] bucket becomes final just ahead
+    // of the grouped layer-0 weight-gradient launch and travels under it, the [layer 0] buckets go last -- more of the
+    // transfer is exposed than in the stream-major order (where a whole stream's buckets hide under the next stream's
+    // GEMMs), but that order costs 0.5 ms of GEMM time per step (3.9 -> 4.4 ms at B = 520), more than the ~0.2 ms of
+    // transfer it hides.  ADN_DP_STREAM_MAJOR=1 selects it for data parallel runs, ADN_NO_GROUPED_BACKWARD=1 always.
+    const bool layer_major = (m->bucket_events.empty() || !getenv("ADN_DP_STREAM_MAJOR")) && !streams_concurrent(m) &&
+                             !getenv("ADN_NO_GROUPED_BACKWARD");
     if (layer_major) {
         int max_depth = 0;
         {                                      // parameter gradients of all stream LSTMs: grouped launches

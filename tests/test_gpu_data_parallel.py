@@ -112,3 +112,56 @@ def test_empty_shard_and_poisoned_gradients_single_rank():
         m.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("order", ["default", "stream_major"])
+def test_a_bucket_is_final_when_its_event_fires(order, monkeypatch):
+    """What the overlap relies on, checked on one GPU: at the moment a bucket's event completes, that range of the gradient
+    buffer already holds its FINAL values (a copy taken behind the event on a side stream equals the range after the whole
+    backward pass, bit for bit) -- for the layer-major order with grouped launches and for the stream-major one
+    (ADN_DP_STREAM_MAJOR), at the bench geometry so that back-propagation is still running while the copies are taken."""
+    import torch
+    import bench
+    from ip_avsr_amd.model import AdeNetModel
+    from ip_avsr_amd.parallel import wrap_flat_buffer
+    if order == "stream_major":
+        monkeypatch.setenv("ADN_DP_STREAM_MAJOR", "1")
+    else:
+        monkeypatch.delenv("ADN_DP_STREAM_MAJOR", raising=False)
+    torch.cuda.set_device(0)
+    m = AdeNetModel(bench.build_spec())
+    m.set_precision("bf16")
+    bench.synthetic_params(m)
+    xs, y, m_d, _ = bench.synthetic_batch(torch, 0, bench.B_PER_GPU, torch.device("cuda", 0))
+    for _ in range(3):
+        m.train_step(xs, y, m_d, bench.THETA, 2e-3, want_loss=False)
+    g = wrap_flat_buffer(m)
+    buckets = m.grad_buckets()
+    events = []
+    for _ in buckets:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        events.append(ev)
+    m.set_bucket_events([ev.cuda_event for ev in events])
+    side = torch.cuda.Stream()
+    end = torch.cuda.Event(enable_timing=True)
+    for rep in range(3):
+        torch.cuda.synchronize()
+        m.compute_grads(xs, y, m_d, bench.THETA, want_loss=False)        # enqueues the step; the events are recorded inside
+        end.record()
+        snaps = []
+        with torch.cuda.stream(side):
+            for (b, e), ev in zip(buckets, events):
+                side.wait_event(ev)
+                snaps.append(g[b:e].clone())
+        torch.cuda.synchronize()
+        early = 0
+        for (b, e), ev, snap in zip(buckets, events, snaps):
+            assert torch.equal(snap, g[b:e]), ("bucket released before it was final", order, (b, e))
+            early += ev.elapsed_time(end) > 0.05                          # ms between the bucket's event and the end of the step
+        assert early >= 1, "no bucket was released ahead of the end of the backward pass: the check would be vacuous"
+    # the buckets tile the buffer
+    cover = sorted(buckets)
+    assert cover[0][0] == 0 and cover[-1][1] == g.numel() and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+    m.set_bucket_events([])
+    m.close()
