@@ -65,7 +65,7 @@ class DataParallel(object):
         self._inflight = False
         # Overlap (GPU replicas only): the library records one HIP event per gradient bucket as soon as that
         # bucket is final; a communication stream waits on it and all-reduces the bucket while back-propagation
-        # of the remaining streams is still running.  Only the last stream's first encoder layer is exposed.
+        # is still running (which buckets hide under what in the layer-major and the stream-major order).
         if overlap is None:
             overlap = grad_tensor is None and not os.environ.get("ADN_DP_NO_OVERLAP")
         self.overlap = bool(overlap) and hasattr(model, "grad_buckets")
