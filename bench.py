@@ -410,6 +410,20 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
                 model.profile(False)
             out["accurate" if prec == "bf16x3" else "accurate_" + prec] = acc
             model.set_precision(args.precision)
+        if on_gpu and world == 1:
+            # the same model at the reference's own minibatch (runners/3stream.py: 26 utterances per update): every GEMM is a
+            # latency-bound launch there and the step is a chain of ~160 LSTM time steps -- reported beside the headline, not as it
+            xb, yb, mb_d, _ = batch_fn(rank + 2000, 26)
+            for _ in range(30):
+                model.train_step(xb, yb, mb_d, THETA, LR, want_loss=False)
+            fence()
+            t3 = time.perf_counter()
+            for _ in range(20):
+                model.train_step(xb, yb, mb_d, THETA, LR, want_loss=False)
+            fence()
+            t3 = time.perf_counter() - t3
+            out["reference_minibatch"] = {"utterances_per_step": 26, "steps": 20, "ms_per_step": 1e3 * t3 / 20,
+                                          "value": 26 * 20 / t3, "unit": "sequences/s", "dtype": args.precision}
         if on_gpu and world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
