@@ -253,8 +253,16 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ 
     const int c = blockIdx.x * 64 + cl;
     const int r0 = blockIdx.y * rows_per_split, r1 = min(rows, r0 + rows_per_split);
     float acc = 0.f;
-    if (c < cols)
-        for (int r = r0 + rl; r < r1; r += 4) acc += in[(size_t)r * ld + c];
+    if (c < cols) {                                  // four independent loads in flight per lane (one per iteration: latency-bound)
+        float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int r = r0 + rl;
+        for (; r + 12 < r1; r += 16) {
+            acc += in[(size_t)r * ld + c]; a1 += in[(size_t)(r + 4) * ld + c];
+            a2 += in[(size_t)(r + 8) * ld + c]; a3 += in[(size_t)(r + 12) * ld + c];
+        }
+        for (; r < r1; r += 4) acc += in[(size_t)r * ld + c];
+        acc += a1 + a2 + a3;
+    }
     part[rl][cl] = acc;
     __syncthreads();
     if (rl == 0 && c < cols) atomicAdd(out + c, part[0][cl] + part[1][cl] + part[2][cl] + part[3][cl]);
@@ -264,7 +272,7 @@ int col_sum(const float* in, int ld, int rows, int cols, float* out, int accumul
     if (!accumulate) ADN_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), s));
     if (rows <= 0) return ADN_OK;
     const int ctiles = cdiv(cols, 64);
-    int splits = std::max(1, std::min(cdiv(rows, 64), cdiv(1024, ctiles)));
+    int splits = std::max(1, std::min(cdiv(rows, 64), cdiv(rows >= (1 << 18) ? 4096 : 1024, ctiles)));
     const int rps = cdiv(rows, splits);
     splits = cdiv(rows, rps);
     hipLaunchKernelGGL(col_sum_kernel, dim3(ctiles, splits), dim3(256), 0, s, in, ld, rows, cols, out, rps);
@@ -284,8 +292,16 @@ __global__ __launch_bounds__(256) void col_sum_batch_kernel(const ColSumBatch b)
     const int c = ct * 64 + cl;
     const int r0 = sp * it.rps, r1 = min(it.rows, r0 + it.rps);
     float acc = 0.f;
-    if (c < it.cols)
-        for (int r = r0 + rl; r < r1; r += 4) acc += it.in[(size_t)r * it.ld + c];
+    if (c < it.cols) {
+        float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int r = r0 + rl;
+        for (; r + 12 < r1; r += 16) {
+            acc += it.in[(size_t)r * it.ld + c]; a1 += it.in[(size_t)(r + 4) * it.ld + c];
+            a2 += it.in[(size_t)(r + 8) * it.ld + c]; a3 += it.in[(size_t)(r + 12) * it.ld + c];
+        }
+        for (; r < r1; r += 4) acc += it.in[(size_t)r * it.ld + c];
+        acc += a1 + a2 + a3;
+    }
     part[rl][cl] = acc;
     __syncthreads();
     if (rl == 0 && c < it.cols) atomicAdd(it.out + c, part[0][cl] + part[1][cl] + part[2][cl] + part[3][cl]);
