@@ -1391,6 +1391,14 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         w.dZ = st.dE; w.lddz = ldE; w.bias_done = 0; w.active = true;
         return ADN_OK;
     };
+    std::vector<char> tail_done(m->st.size(), 0);
+    auto stream_tail = [&](size_t si) -> int {
+        if (tail_done[si]) return ADN_OK;
+        tail_done[si] = 1;
+        Walk& w = walk[si];
+        ADN_TRY(col_sum_batch(w.bias_sums, m->stream));
+        return bucket_ready(w.split_first ? w.b_rest + 1 : w.b_rest);        // every gradient of this stream is final
+    };
     // encoder layer L - 1 - depth of the streams `sis` (same geometry when more than one): weight gradients, bias
     // gradients, input gradients -- each kind as ONE grouped launch where the ping-pong kernel takes it
     auto layer_step = [&](const std::vector<size_t>& sis, int depth) -> int {
@@ -1404,10 +1412,6 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             gw.layout = GEMM_TN; gw.M = in_w; gw.N = out_w; gw.K = N; gw.A = l > 0 ? st.act[l - 1] : st.x;
             gw.lda = l > 0 ? ld_of(in_w) : st.ldx;
             gw.B = w.dZ; gw.ldb = w.lddz; gw.C = m->G(st.encW[l]); gw.ldc = ld_of(out_w); gw.accumulate = 1;
-            if (l == 0 && w.split_first) {         // everything but layer 0's weight gradient is final: release that bucket
-                ADN_TRY(col_sum_batch(w.bias_sums, m->stream));                // (all bias sums are queued by now)
-                ADN_TRY(bucket_ready(w.b_rest));
-            }
             mgemm_prepare(m, gw, false);
         }
         ADN_TRY(gemm_grouped(gws, n, m->stream));
@@ -1421,6 +1425,13 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
                 else ADN_TRY(col_sum(w.dZ, w.lddz, N, out_w, m->G(st.encb[l]), 1, m->stream));
             }
             w.bias_done = 0;
+            if (l == 1 && w.split_first) {
+                // [layers >= 1 + LSTM] of this stream is final: W_1 by the launch above, b_1 .. and everything above it queued
+                // or written earlier (b_0 alone is still to come: it rides on the input-gradient GEMM below).  Released HERE,
+                // ahead of that GEMM and of layer 0's weight gradient, which then cover its transfer.
+                ADN_TRY(col_sum_batch(w.bias_sums, m->stream));
+                ADN_TRY(bucket_ready(w.b_rest));
+            }
             if (l == 0) continue;
             any_dx = true;
             float* dst = (w.dZ == st.pingA) ? st.pingB : st.pingA;
@@ -1446,11 +1457,6 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             w.dZ = dst; w.lddz = st.ping_ld;
         }
         return ADN_OK;
-    };
-    auto stream_tail = [&](size_t si) -> int {
-        Walk& w = walk[si];
-        ADN_TRY(col_sum_batch(w.bias_sums, m->stream));
-        return bucket_ready(w.split_first ? w.b_rest + 1 : w.b_rest);        // every gradient of this stream is final
     };
     // Layer-major with grouped launches (the streams' layers of equal geometry share tile lists, like the forward pass);
     // stream-major when the streams run on forked HIP streams.  Data parallel runs (gradient buckets released to an
