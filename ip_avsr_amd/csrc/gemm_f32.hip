@@ -413,7 +413,8 @@ static int x3_split_operands(const GemmArgs& g, const X3Plan& p, void* A3, void*
     h->precision = ADN_PRECISION_BF16;
     if (p.b_transpose) h->layout = GEMM_NN;
     h->A16 = A3; h->B16 = B3; h->lda = p.lda3; h->ldb = p.ldb3; h->K = 3 * p.Kp;
-    h->C16 = nullptr; h->Y16 = nullptr;                         // fp32 outputs and masks, as in fp32 mode
+    // fp32 outputs; a bf16 copy of C / a bf16 mask only where the caller asked for them (rectifier masks: model.hip)
+    h->C16 = g.C16; h->Y16 = (g.act_grad == ADN_ACT_RECTIFY) ? g.Y16 : nullptr;
     return ADN_OK;
 }
 
@@ -613,7 +614,11 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
         if (x3_takes(g)) return gemm_bf16x3(g, stream);
         GemmArgs h = g;
         h.precision = ADN_PRECISION_F32;
-        return gemm(h, stream);
+        h.C16 = nullptr; h.Y16 = nullptr;
+        ADN_TRY(gemm(h, stream));
+        if (g.C16 && g.C)                      // (the fp32 kernels do not write bf16 copies: a requested one is made here)
+            ADN_TRY(to_bf16(g.C, g.C16, (size_t)round_up((int64_t)g.M * g.ldc, 8), stream));
+        return ADN_OK;
     }
     ADN_CHECK(g.precision == ADN_PRECISION_F32 || g.precision == ADN_PRECISION_BF16, ADN_ERR_INVALID,
               "gemm: unsupported precision");

@@ -575,6 +575,14 @@ void mgemm_prepare(adn_model* m, GemmArgs& g, bool lean) {
     //  concurrently -- those runs keep the atomic split-K of the register-staged kernel)
     const bool shared_ws_ok = !streams_concurrent(m);
     g.splitk_ws = shared_ws_ok ? m->splitk_ws : nullptr; g.splitk_ws_floats = shared_ws_ok ? m->splitk_ws_floats : 0;
+    if (m->cfg.precision == ADN_PRECISION_BF16X3 && !getenv("ADN_X3_NO_MASK_SHADOWS")) {
+        // A rectifier's mask is the sign pattern of its output, and bf16(y) > 0 <=> y > 0: the forward producers of rectified
+        // activations also write the bf16 copy, and the masked input-gradient GEMMs read THAT as their mask (half the bytes,
+        // and the form the ping-pong kernel's epilogue takes: the streams' input gradients then go out as grouped launches
+        // like in bf16 mode).  Values and products stay fp32-grade; only the mask's carrier changes.
+        if (g.act == ADN_ACT_RECTIFY && g.C && !g.accumulate) g.C16 = m->shadow_of(g.C);
+        if (g.Y && g.act_grad == ADN_ACT_RECTIFY) g.Y16 = m->shadow_of(g.Y);
+    }
     if (shadows_on(m)) {                                  // env switch: convert-in-flight reference path
         g.A16 = m->shadow_of(g.A);
         g.B16 = m->shadow_of(g.B);
