@@ -1529,7 +1529,8 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         }
     }
     ADN_TRY(join_streams(m));
-    if (m->bf16()) {                          // this device's exchange status -> tail[1] (summed over ranks by the all-reduce)
+    if (m->cfg.precision != ADN_PRECISION_F32) {   // (bf16 and bf16x3 run the weight-stationary LSTM kernels) this device's
+                                                   // exchange status -> tail[1] (summed over ranks by the all-reduce)
         int* word = nullptr;
         ADN_TRY(lstm_cluster_error_word(&word));
         ADN_TRY(poison_tail(word, m->poison_word(), m->stream));
@@ -1562,7 +1563,7 @@ int check_shape(const adn_model* m, int B, int T, int theta) {
 // the weight-stationary LSTM kernels raise a device word when a workgroup gave up waiting for its partners
 // (lstm_cluster.hip); call after the stream has been synchronised
 int check_device_errors(adn_model* m) {
-    if (!m->bf16()) return ADN_OK;
+    if (m->cfg.precision == ADN_PRECISION_F32) return ADN_OK;   // (only the weight-stationary LSTM kernels can raise the word)
     int sticky = 0;
     ADN_HIP_CHECK(hipMemcpy(&sticky, m->poison_sticky, sizeof(int), hipMemcpyDeviceToHost));
     if (sticky) ADN_HIP_CHECK(hipMemset(m->poison_sticky, 0, sizeof(int)));

@@ -65,8 +65,9 @@ def test_single_rank_nccl_dataparallel_equals_plain_step():
         dist.destroy_process_group()
 
 
-def test_empty_shard_and_poisoned_gradients_single_rank():
-    """(1) A rank with an EMPTY shard joins the all-reduce with zero gradients (adn_zero_grads) -- with one rank the step
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_empty_shard_and_poisoned_gradients_single_rank(precision):
+    """(both modes that run the weight-stationary LSTM kernels)  (1) A rank with an EMPTY shard joins the all-reduce with zero gradients (adn_zero_grads) -- with one rank the step
     must then leave the parameters untouched apart from Adam's zero-gradient update (m = v = 0 -> no change).
     (2) A raised exchange flag in the gradient tail makes the optimiser kernel skip the update and the next host read
     report it (what every rank sees when a peer's weight-stationary LSTM exchange timed out)."""
@@ -82,7 +83,7 @@ def test_empty_shard_and_poisoned_gradients_single_rank():
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         spec = dict(O.spec_nstream([12, 9], enc_shapes=(14, 6), enc_acts=("rectify", "linear"), lstm_size=10, classes=5,
-                                   fusion="sum"), precision="bf16")
+                                   fusion="sum"), precision=precision)
         rng = np.random.default_rng(7)
         p = O.init_params(spec, rng, np.float32, enc_std=0.3, perturb=0.1)
         B, T = 5, 8
