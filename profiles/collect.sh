@@ -28,6 +28,8 @@ python3 $ROOT/profiles/make_traffic_json.py $FA $FB bf16 $COMMIT > $OUT/pmc_traf
 # the same two passes for the bf16x3 mode (roofline.traffic of the bench line's `accurate` sub-object)
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmcA3 -o a --output-format csv -- python3 $B --precision bf16x3 > $OUT/pmcA3.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmcB3 -o b --output-format csv -- python3 $B --precision bf16x3 > $OUT/pmcB3.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $OUT/pmcM3 -o m --output-format csv -- python3 $B --precision bf16x3 > $OUT/pmcM3.log 2>&1
+python3 $ROOT/profiles/pmc_summary.py $(find $OUT/pmcM3 -name "m_counter_collection.csv" | head -1) mfma > $OUT/pmc_mfma_bf16x3.txt
 python3 $ROOT/profiles/make_traffic_json.py $(find $OUT/pmcA3 -name "a_counter_collection.csv" | head -1) $(find $OUT/pmcB3 -name "b_counter_collection.csv" | head -1) bf16x3 $COMMIT > $OUT/pmc_traffic_bf16x3.json
 ADN_GEMM_TRACE=1 timeout 300 rocprofv3 --kernel-trace -d $OUT/bd -o bd --output-format csv -- python3 $ROOT/profiles/gemm_breakdown.py run 2> $OUT/gemm_trace.txt > $OUT/bd.log
 BD=$(find $OUT/bd -name "bd_kernel_trace.csv" | head -1)
@@ -54,5 +56,5 @@ timeout 300 python3 profiles/convae_bench.py > $OUT/convae_bench.txt 2>/dev/null
 # the bench lines last, so that roofline.traffic comes from the PMC passes of THIS build
 mkdir -p profiles/$ROUND && cp $OUT/pmc_traffic_bf16.json profiles/$ROUND/pmc_traffic_bf16.json && cp $OUT/pmc_traffic_bf16x3.json profiles/$ROUND/pmc_traffic_bf16x3.json
 timeout 400 python3 bench.py --precision bf16 2>/dev/null | tail -1 > $OUT/final_bf16_bench.json
-rm -rf $OUT/ks_bf16 $OUT/ks_f32 $OUT/ks_bf16x3 $OUT/pmcA $OUT/pmcB $OUT/pmcA3 $OUT/pmcB3 $OUT/pmcM $OUT/pmcC $OUT/bd $OUT/bd3 $OUT/gemm_trace_x3.txt
+rm -rf $OUT/ks_bf16 $OUT/ks_f32 $OUT/ks_bf16x3 $OUT/pmcA $OUT/pmcB $OUT/pmcA3 $OUT/pmcB3 $OUT/pmcM3 $OUT/pmcM $OUT/pmcC $OUT/bd $OUT/bd3 $OUT/gemm_trace_x3.txt
 ls -la $OUT
