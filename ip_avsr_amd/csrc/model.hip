@@ -182,7 +182,7 @@ struct adn_model {
     std::vector<LstmParams> agg;       // 0, 1 or 2
     std::vector<LstmWork> aggw;
     size_t tail_begin = 0;             // first float of the [fuse | agg | softmax] parameters
-    std::vector<hipEvent_t> bucket_events;   // caller-owned; [0] = tail bucket, [1+s] = stream s (see adn_grad_buckets)
+    std::vector<hipEvent_t> bucket_events;   // caller-owned; in the order of adn_grad_buckets (bucket_ranges)
     size_t adacoeff = 0;               // S scalars (one 8-float block)
     size_t smW = 0, smb = 0;
     int fused_dim = 0;
@@ -1160,6 +1160,21 @@ int lstm_input_grad(adn_model* m, const LstmParams& lp, const LstmWork& w, int j
 // ------------------------------------------------------------------------------------------
 // backward (theano.grad of the loss wrt every parameter)
 // ------------------------------------------------------------------------------------------
+// positions of a stream's two gradient buckets in the bucket list (see bucket_ranges)
+void bucket_slots(const adn_model* m, size_t si, size_t* rest, size_t* first) {
+    const bool stream_major = getenv("ADN_DP_STREAM_MAJOR") != nullptr;
+    size_t r = 1, f = 0;
+    if (stream_major) {
+        for (size_t q = 0; q < si; ++q) r += m->st[q].cfg.n_enc >= 2 ? 2 : 1;
+        f = r + 1;
+    } else {
+        r = 1 + si;
+        f = 1 + (size_t)m->S;
+        for (size_t q = 0; q < si; ++q) f += m->st[q].cfg.n_enc >= 2 ? 1 : 0;
+    }
+    *rest = r; *first = f;
+}
+
 int backward_pass(adn_model* m, int B, int T, int theta) {
     const int N = B * T, H = m->H, ldh = m->ldh;
     hipStream_t s = m->stream;
@@ -1355,7 +1370,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
     // Per-stream walk state of the encoder's back-propagation.
     struct Walk {
         float* dZ = nullptr; int lddz = 0; int bias_done = 0; int L = 0;
-        size_t b_rest = 0; bool split_first = false, active = false;
+        size_t b_rest = 0, b_first = 0; bool split_first = false, active = false;
         ColSumBatch bias_sums;                 // bf16 mode: every bias reduction of the stream in ONE launch at the end
     };
     std::vector<Walk> walk(m->st.size());
@@ -1370,8 +1385,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             ADN_TRY(lstm_param_grads(m, st.lstm[k], st.lw[k], in, ld, 1, st.feat_dim, B, T, stream_sums_done));
         // this stream's buckets: `b_rest` (encoder layers >= 1 + LSTM; the whole stream when it has < 2 encoder layers),
         // then `b_first` (encoder layer 0) where it exists
-        w.b_rest = 1;
-        for (size_t q = 0; q < si; ++q) w.b_rest += m->st[q].cfg.n_enc >= 2 ? 2 : 1;
+        bucket_slots(m, si, &w.b_rest, &w.b_first);
         w.split_first = st.cfg.n_enc >= 2;
         w.L = st.cfg.n_enc;
         if (st.cfg.n_enc == 0) { ADN_TRY(bucket_ready(w.b_rest)); return ADN_OK; }   // nothing trainable below the LSTM
@@ -1405,7 +1419,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         tail_done[si] = 1;
         Walk& w = walk[si];
         ADN_TRY(col_sum_batch(w.bias_sums, m->stream));
-        return bucket_ready(w.split_first ? w.b_rest + 1 : w.b_rest);        // every gradient of this stream is final
+        return bucket_ready(w.split_first ? w.b_first : w.b_rest);           // every gradient of this stream is final
     };
     // encoder layer L - 1 - depth of the streams `sis` (same geometry when more than one): weight gradients, bias
     // gradients, input gradients -- each kind as ONE grouped launch where the ping-pong kernel takes it
@@ -1778,20 +1792,25 @@ int adn_flat_buffer(adn_model* m, int buffer, void** device_ptr, size_t* bytes) 
     return ADN_OK;
 }
 
-// bucket list in the order the ranges become final (the order a communication stream should reduce them in):
-//   [tail]  then per stream  [layers >= 1 of the encoder + LSTM]  and  [encoder layer 0]  (the latter only when the
-//   stream has at least two encoder layers -- its weight gradient is the last GEMM of the stream's backward pass)
+// Bucket list in the order the ranges become final = the order a communication stream should reduce them in.  Layer-major
+// back-propagation (the default): [tail], every stream's [layers >= 1 of the encoder + LSTM] (final together, right behind
+// layer 1's weight gradients), then every stream's [encoder layer 0] (only for streams with at least two encoder layers;
+// final behind the last launch).  Stream-major (ADN_DP_STREAM_MAJOR): [tail], then per stream its two ranges.
 static void bucket_ranges(const adn_model* m, std::vector<std::pair<size_t, size_t>>& out) {
-    out.clear();
-    out.emplace_back(m->tail_begin, m->flat_floats + kAuxFloats);
+    size_t n = 1;
+    for (int s = 0; s < m->S; ++s) n += m->st[s].cfg.n_enc >= 2 ? 2 : 1;
+    out.assign(n, std::make_pair((size_t)0, (size_t)0));
+    out[0] = std::make_pair(m->tail_begin, m->flat_floats + kAuxFloats);
     for (int s = 0; s < m->S; ++s) {
         const StreamState& st = m->st[s];
         const size_t begin = st.param_begin, end = s + 1 < m->S ? m->st[s + 1].param_begin : m->tail_begin;
+        size_t rest = 0, first = 0;
+        bucket_slots(m, (size_t)s, &rest, &first);
         if (st.cfg.n_enc >= 2) {
-            out.emplace_back(st.encW[1], end);
-            out.emplace_back(begin, st.encW[1]);
+            out[rest] = std::make_pair(st.encW[1], end);
+            out[first] = std::make_pair(begin, st.encW[1]);
         } else {
-            out.emplace_back(begin, end);
+            out[rest] = std::make_pair(begin, end);
         }
     }
 }
