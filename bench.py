@@ -45,6 +45,7 @@ PEAK_HBM_GBS = 8000.0
 B_PER_GPU, T_MAX, THETA, H, C, D = 520, 40, 9, 250, 26, 1200
 ENC = (2000, 1000, 500, 50)
 LR = 1e-3
+PROFILE_ROUND = "r03"      # profiles/<round>/pmc_traffic_<precision>.json feeds roofline.traffic
 PREWARM_STEPS = 20         # untimed steps ahead of the warm-up (see run(): idle clocks after the host-side setup)
 
 
@@ -91,17 +92,15 @@ def synthetic_batch(torch, rank, B, device):
     return xs, torch.tensor(y, device=device), m_d, mask
 
 
-def lstm_traffic(d, steps_per_train_step):
-    """HBM bytes per LSTM and time step from the PMC summary of the LSTM kernel class (profiles/make_traffic_json.py).
-    `steps_per_train_step` = T (or T + 1) time steps x the kernel launches of a train step; every launch of the bench model
-    holds several LSTMs (3 stream LSTMs, then the 2 directions of the BLSTM): 5 LSTMs over 2 launches."""
-    if not d or not d.get("launches"):
+def lstm_traffic(d, algorithmic_bytes_per_train_step, unit_bytes):
+    """HBM bytes per LSTM and time step from the PMC summary of the LSTM kernel class (profiles/make_traffic_json.py, taken
+    over whole B=520 train steps only): the class's counter bytes of one train step / the (LSTM, time step) units of one
+    train step.  The units come from the live profile: algorithmic bytes it booked per train step / SURVEY 8d's per-unit
+    figure -- the same unit `achieved` is priced in."""
+    if not d or not d.get("launches") or "traffic_bytes_per_train_step" not in d:
         return None
-    per_launch = d["traffic_bytes_per_launch"]
-    if d.get("kernel", "").endswith("step_kernel"):                # f32 mode: one launch = one time step of 3 or 2 LSTMs
-        return per_launch / 2.5
-    t_steps = steps_per_train_step / 2.0                           # bf16: one launch = all T steps of its LSTMs; the
-    return per_launch * 2.0 / (5.0 * t_steps)                      # profiler counts T per launch, 2 launches per step
+    units = algorithmic_bytes_per_train_step / unit_bytes
+    return d["traffic_bytes_per_train_step"] / units if units > 0 else None
 
 
 def _cpu_model_name():
@@ -198,6 +197,11 @@ def parse_args(argv=None):
                     help="also time the parity-grade modes (sub-objects `accurate` = bf16x3, `accurate_f32`; N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel timing")
+    ap.add_argument("--no-reference-minibatch", action="store_true", help="skip the B=26 sub-run")
+    ap.add_argument("--only-train-steps", action="store_true",
+                    help="counter passes (profiles/collect.sh): run NOTHING but warmup + steps train steps of the B=520 workload "
+                         "-- no pre-warm, no evaluation epoch, no copy yardstick, no accurate / B=26 sub-runs, no CPU baseline -- "
+                         "so that every kernel launch a profiler sees belongs to the headline step")
     return ap.parse_args(argv)
 
 
@@ -229,6 +233,7 @@ def rooflines(prof, steps, prof_elapsed, precision, hbm_measured, traffic_file):
         if key in prof and prof[key]["ms"]:
             e = prof[key]
             a = e["bytes"] / (e["ms"] * 1e-3) / 1e9
+            unit = (4.0 * (12 * B_PER_GPU * H + 4 * H * H) + B_PER_GPU) if key == "lstm_fwd_step" else 4.0 * (15 * B_PER_GPU * H + 4 * H * H)
             kern = {"bf16": "lstm_%s_cluster_kernel (weight-stationary, all T steps in one launch; per time step)",
                     "bf16x3": "lstm_%s_cluster_x3_kernel (weight-stationary, hi/lo bf16 products, all T steps in one launch; "
                               "per time step)"}.get(precision, "lstm_%s_step_kernel (one launch per time step)") % key[5:8]
@@ -238,7 +243,8 @@ def rooflines(prof, steps, prof_elapsed, precision, hbm_measured, traffic_file):
                          "peak_measured": hbm_measured, "frac_of_measured": (a / hbm_measured) if hbm_measured else None,
                          # PMC bytes of all kernel launches of this class in a step / the LSTM time steps they cover
                          # (same unit as `achieved`'s numerator: one LSTM, one time step)
-                         "traffic": lstm_traffic(pmc.get(key[:8]), e["launches"] / steps),
+                         "traffic": lstm_traffic(pmc.get(key[:8]), e["bytes"] / steps, unit),
+                         "algorithmic_bytes_per_unit": unit,
                          "avg_launch_us": 1e3 * e["ms"] / e["launches"],
                          "share_of_step": e["ms"] / (1e3 * prof_elapsed)}
     out["kernel_ms_per_step"] = {k: v["ms"] / steps for k, v in prof.items()}
@@ -249,6 +255,9 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
     """The benchmark body.  `make_model` / `batch_fn` / `device` are injection points for the CPU test of the N > 1 branch
     (tests/test_bench_distributed_gloo.py: an oracle-backed replica under gloo); on a GPU box leave them None."""
     import torch
+    only = bool(getattr(args, "only_train_steps", False))
+    if only:
+        args.no_profile = True; args.no_cpu_baseline = True; args.accurate_precision = "none"; args.no_reference_minibatch = True
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -326,7 +335,7 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
     # setup, not measurement: the GPU idles while the host builds the model and the synthetic batch, and the first steps after
     # that can run at idle clocks (seen as a 3x slower first ~10 steps at small batches, profiles/configs_bench.py); a fixed
     # number of extra untimed steps ahead of the W warm-up steps of the contract takes that out of every run alike
-    for _ in range(PREWARM_STEPS if on_gpu else 0):
+    for _ in range(PREWARM_STEPS if on_gpu and not only else 0):
         step()
     for _ in range(args.warmup):
         step()
@@ -345,6 +354,13 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    if only:                                     # counter pass: the train steps above are everything this process launches
+        if rank == 0:
+            print(json.dumps({"only_train_steps": args.warmup + args.steps, "ms_per_step": 1e3 * elapsed / args.steps,
+                              "dtype": args.precision, "batch": B_PER_GPU}))
+        if distributed and dist_backend is None:
+            dist.destroy_process_group()
+        return None
     loss = float(model.loss(xs, y, m_d, THETA))
     assert np.isfinite(loss), "training diverged"
     # epoch = one pass over the 520 training utterances + what the reference's loop does after it
@@ -369,7 +385,7 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
         out = {
             "metric": "sequences_per_sec_train_avletters_trimodal_adenet", "value": seqs / elapsed,
             "unit": "sequences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "prewarm_steps": PREWARM_STEPS if on_gpu else 0,
+            "prewarm_steps": PREWARM_STEPS if on_gpu and not only else 0,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "AVLetters trimodal AdeNet (3 encoder streams 1200-2000-1000-500-50, theta=9, "
@@ -386,7 +402,7 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
             hbm = measured_hbm_gbs(torch, device)
             out["hbm_copy_measured_GBs"] = hbm
         if prof:
-            tfile = os.path.join(ROOT, "profiles", "r02", "pmc_traffic_%s.json" % args.precision)
+            tfile = os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_traffic_%s.json" % args.precision)
             out.update(rooflines(prof, args.steps, prof_elapsed, args.precision, hbm, tfile))
         # ---- the fp32-accurate mode, same workload, same process (the mode the 1e-4 / exact-top-1 parity tests run in)
         acc_modes = {"both": ["bf16x3", "f32"], "none": []}.get(args.accurate_precision, [args.accurate_precision])
@@ -406,11 +422,11 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
                 model.profile(True)
                 pe = timed(k)
                 acc.update(rooflines(model.profile_read(), k, pe, prec, hbm,
-                                     os.path.join(ROOT, "profiles", "r02", "pmc_traffic_%s.json" % prec)))
+                                     os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_traffic_%s.json" % prec)))
                 model.profile(False)
             out["accurate" if prec == "bf16x3" else "accurate_" + prec] = acc
             model.set_precision(args.precision)
-        if on_gpu and world == 1:
+        if on_gpu and world == 1 and not getattr(args, "no_reference_minibatch", False):
             # the same model at the reference's own minibatch (runners/3stream.py: 26 utterances per update): every GEMM is a
             # latency-bound launch there and the step is a chain of ~160 LSTM time steps -- reported beside the headline, not as it
             xb, yb, mb_d, _ = batch_fn(rank + 2000, 26)

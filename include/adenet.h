@@ -216,6 +216,10 @@ int adn_train_step(adn_model* m, const void* const* inputs, const int32_t* targe
 int adn_read_encoder_activation(adn_model* m, int stream, int layer, float* host_dst);
 
 int adn_synchronize(adn_model* m);
+/* test hook: writes `value` into the current device's LSTM-exchange error word (what a weight-stationary LSTM kernel raises
+ * when a workgroup gave up waiting for its partners; 0 clears it).  Lets a test follow the word's way through the gradient
+ * tail, the data-parallel all-reduce and the optimiser's skip without provoking a real time-out. */
+int adn_debug_raise_exchange_error(int value);
 
 /* per-kernel-class timing with HIP events recorded on the model's stream around every launch of the
  * class (bench.py's live roofline measurement).  flops / bytes are the ALGORITHMIC work of the launches

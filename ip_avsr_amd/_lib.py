@@ -96,6 +96,7 @@ _SIGNATURES = {
     "adn_train_step": (C.c_int, [_P, C.POINTER(_P), _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
     "adn_read_encoder_activation": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "adn_synchronize": (C.c_int, [_P]),
+    "adn_debug_raise_exchange_error": (C.c_int, [C.c_int]),
     "adn_profile_enable": (C.c_int, [_P, C.c_int]),
     "adn_profile_read": (C.c_int, [_P, C.POINTER(ProfileEntry), C.c_int, C.POINTER(C.c_int)]),
     "adn_op_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int, _P,

@@ -1364,6 +1364,14 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
                 steps.back().ld_dhs = st.dout_ld;
             }
         ADN_TRY(run_lstm_group(m, steps, B, T, true, &stream_sums_done));
+        // Every weight-stationary LSTM launch of this step (forward, aggregation backward, stream backward) is enqueued by
+        // now: this device's exchange status goes into tail[1] HERE, ahead of bucket 0's release -- tail[1] lies inside
+        // bucket 0, and a word written after the release would be reduced as 0 (and overwritten under the collective).
+        if (m->cfg.precision != ADN_PRECISION_F32) {   // (bf16 and bf16x3 run the weight-stationary LSTM kernels)
+            int* word = nullptr;
+            ADN_TRY(lstm_cluster_error_word(&word));
+            ADN_TRY(poison_tail(word, m->poison_word(), m->stream));
+        }
         ADN_TRY(bucket_ready(0));
     }
     ADN_TRY(fork_streams(m));                 // below the stream LSTMs the S streams back-propagate independently
@@ -1543,12 +1551,6 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         }
     }
     ADN_TRY(join_streams(m));
-    if (m->cfg.precision != ADN_PRECISION_F32) {   // (bf16 and bf16x3 run the weight-stationary LSTM kernels) this device's
-                                                   // exchange status -> tail[1] (summed over ranks by the all-reduce)
-        int* word = nullptr;
-        ADN_TRY(lstm_cluster_error_word(&word));
-        ADN_TRY(poison_tail(word, m->poison_word(), m->stream));
-    }
     m->grads_valid = true;
     return ADN_OK;
 }
@@ -2024,6 +2026,13 @@ int adn_profile_read(adn_model* m, adn_profile_entry* out, int max_entries, int*
         ++n;
     }
     *n_out = n;
+    return ADN_OK;
+}
+
+int adn_debug_raise_exchange_error(int value) {
+    int* word = nullptr;
+    ADN_TRY(lstm_cluster_error_word(&word));
+    ADN_HIP_CHECK(hipMemcpy(word, &value, sizeof(int), hipMemcpyHostToDevice));
     return ADN_OK;
 }
 

@@ -5,15 +5,18 @@
 #   conv AE counters.
 # Usage (from the repo root, on an MI355X):   bash profiles/collect.sh [rNN] [commit]
 set -u
-ROUND=${1:-r02}; COMMIT=${2:-unknown}
+ROUND=${1:-r03}; COMMIT=${2:-unknown}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/collect
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="$ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --accurate-precision none"
+# counter passes: NOTHING but 1 + 3 train steps of the B=520 workload (no pre-warm, evaluation, B=26 sub-run): every launch the
+# counters see is a launch of the headline step (make_traffic_json.py checks the launch counts against PMC_STEPS)
+PMC_STEPS=4
+B="$ROOT/bench.py --only-train-steps --steps 3 --warmup 1"
 # (kernel-stats passes: one per arithmetic mode, the mode under test as --precision)
 for prec in bf16 f32 bf16x3; do
-  timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/ks_$prec -o ks --output-format csv -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --accurate-precision none --precision $prec > $OUT/ks_$prec.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/ks_$prec -o ks --output-format csv -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --accurate-precision none --no-reference-minibatch --precision $prec > $OUT/ks_$prec.log 2>&1
   cp $(find $OUT/ks_$prec -name "ks_kernel_stats.csv" | head -1) $OUT/final_${prec}_kernel_stats.csv
 done
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmcA -o a --output-format csv -- python3 $B --precision bf16 > $OUT/pmcA.log 2>&1
@@ -24,13 +27,13 @@ FM=$(find $OUT/pmcM -name "m_counter_collection.csv" | head -1)
 python3 $ROOT/profiles/pmc_summary.py $FA > $OUT/pmc_final_bf16_fA.txt
 python3 $ROOT/profiles/pmc_summary.py $FB > $OUT/pmc_final_bf16_fB.txt
 python3 $ROOT/profiles/pmc_summary.py $FM mfma > $OUT/pmc_mfma_bf16.txt
-python3 $ROOT/profiles/make_traffic_json.py $FA $FB bf16 $COMMIT > $OUT/pmc_traffic_bf16.json
+python3 $ROOT/profiles/make_traffic_json.py $FA $FB bf16 $COMMIT $PMC_STEPS > $OUT/pmc_traffic_bf16.json
 # the same two passes for the bf16x3 mode (roofline.traffic of the bench line's `accurate` sub-object)
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmcA3 -o a --output-format csv -- python3 $B --precision bf16x3 > $OUT/pmcA3.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmcB3 -o b --output-format csv -- python3 $B --precision bf16x3 > $OUT/pmcB3.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $OUT/pmcM3 -o m --output-format csv -- python3 $B --precision bf16x3 > $OUT/pmcM3.log 2>&1
 python3 $ROOT/profiles/pmc_summary.py $(find $OUT/pmcM3 -name "m_counter_collection.csv" | head -1) mfma > $OUT/pmc_mfma_bf16x3.txt
-python3 $ROOT/profiles/make_traffic_json.py $(find $OUT/pmcA3 -name "a_counter_collection.csv" | head -1) $(find $OUT/pmcB3 -name "b_counter_collection.csv" | head -1) bf16x3 $COMMIT > $OUT/pmc_traffic_bf16x3.json
+python3 $ROOT/profiles/make_traffic_json.py $(find $OUT/pmcA3 -name "a_counter_collection.csv" | head -1) $(find $OUT/pmcB3 -name "b_counter_collection.csv" | head -1) bf16x3 $COMMIT $PMC_STEPS > $OUT/pmc_traffic_bf16x3.json
 ADN_GEMM_TRACE=1 timeout 300 rocprofv3 --kernel-trace -d $OUT/bd -o bd --output-format csv -- python3 $ROOT/profiles/gemm_breakdown.py run 2> $OUT/gemm_trace.txt > $OUT/bd.log
 BD=$(find $OUT/bd -name "bd_kernel_trace.csv" | head -1)
 python3 $ROOT/profiles/gemm_breakdown.py join $OUT/gemm_trace.txt $BD > $OUT/gemm_breakdown_bf16.txt

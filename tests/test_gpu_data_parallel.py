@@ -184,3 +184,66 @@ def test_a_bucket_is_final_when_its_event_fires(order, monkeypatch):
             y2 = np.repeat(rng.integers(0, 7, size=(B, 1)), T, axis=1).astype(np.int32)
             _bucket_snapshots_equal_final(mm, xs2, y2, mask, 2, order, need_early=False)
             mm.close()
+
+
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_exchange_error_word_is_in_bucket_0_when_its_event_fires(precision):
+    """The LSTM-exchange status of this device must already sit in tail[1] of the gradient buffer when bucket 0 (which
+    contains the tail) is released to the all-reduce: a word written later would be reduced as 0 on the peers, and only the
+    failing rank would skip its optimiser step.  The device word is raised by hand (adn_debug_raise_exchange_error) ahead
+    of compute_grads with bucket events registered; a copy of bucket 0 taken BEHIND its event on a side stream must hold
+    tail[1] == 1, the optimiser must skip the update and the next host read must report it."""
+    import torch
+    from ip_avsr_amd import _lib
+    from ip_avsr_amd._lib import AdenetError
+    from ip_avsr_amd.model import AdeNetModel
+    from ip_avsr_amd.parallel import wrap_flat_buffer
+    torch.cuda.set_device(0)
+    lib = _lib.load()
+    spec = dict(O.spec_nstream([40, 36], enc_shapes=(48, 20), enc_acts=("rectify", "linear"), lstm_size=32, classes=7,
+                               fusion="concat"), precision=precision)
+    rng = np.random.default_rng(11)
+    B, T = 64, 12
+    m = AdeNetModel(spec)
+    m.set_params_dict(O.init_params(spec, rng, np.float32, enc_std=0.2, perturb=0.1))
+    mask = np.ones((B, T), np.uint8)
+    xs = [rng.normal(size=(B, T, st["input_dim"])).astype(np.float32) for st in spec["streams"]]
+    y = np.repeat(rng.integers(0, 7, size=(B, 1)), T, axis=1).astype(np.int32)
+    m.train_step(xs, y, mask, 2, 1e-3)
+    before = m.get_all_param_values()
+    g = wrap_flat_buffer(m)
+    buckets = m.grad_buckets()
+    events = []
+    for _ in buckets:
+        ev = torch.cuda.Event()
+        ev.record()
+        events.append(ev)
+    m.set_bucket_events([ev.cuda_event for ev in events])
+    side = torch.cuda.Stream()
+    try:
+        for raised in (0, 1 | (3 << 4)):
+            _lib.check(lib.adn_debug_raise_exchange_error(raised))
+            torch.cuda.synchronize()
+            m.compute_grads(xs, y, mask, 2, want_loss=False)
+            b0, e0 = buckets[0]
+            assert e0 == g.numel(), "bucket 0 holds the tail"
+            with torch.cuda.stream(side):
+                side.wait_event(events[0])
+                snap = g[b0:e0].clone()
+            torch.cuda.synchronize()
+            assert float(snap[-7].item()) == (1.0 if raised else 0.0), "tail[1] was not final when bucket 0 was released"
+            assert float(g[-7].item()) == (1.0 if raised else 0.0)
+            if raised:
+                _lib.check(lib.adn_debug_raise_exchange_error(0))   # (the optimiser reads tail[1], not the device word)
+                m.apply_adam(1e-2)
+                with pytest.raises(AdenetError, match="skipped"):
+                    m.get_all_param_values()
+                for u, v in zip(before, m.get_all_param_values()):
+                    np.testing.assert_array_equal(u, v)
+            else:
+                m.apply_adam(0.0)
+                before = m.get_all_param_values()
+    finally:
+        lib.adn_debug_raise_exchange_error(0)
+        m.set_bucket_events([])
+        m.close()
