@@ -15,6 +15,21 @@ def create_model(dbn, input_shape, input_var, mask_shape, mask_var, lstm_size=25
     return F.build(streams, lstm_size, output_classes, "none", {}, [], False, w_init_fn, return_fuse=False)
 
 
+def create_model_using_pretrained_encoder(weights, biases, input_shape, input_var, mask_shape, mask_var, lstm_size=250,
+                                          win=None, output_classes=26, w_init_fn='ortho', use_peepholes=False,
+                                          nonlinearities='rectify'):
+    """What cuave/unimodal_with_val.py:259-263 and oulu/unimodal_with_val.py:311-314 call.  The reference's
+    modelzoo/deltanet_majority_vote.py does NOT define it (those two scripts fail with AttributeError as shipped); the only
+    function of this name, modelzoo/deltanet.py:12-56, has this argument list but the last-timestep head, while both scripts
+    train with temporal_softmax_loss on per-frame targets and evaluate by majority vote.  So: deltanet.py's argument list
+    and encoder construction (``[nonlinearities] * 3 + [linear]``, layer names fc1..bottleneck), this module's per-frame
+    summed-BLSTM graph."""
+    n = len(weights)
+    ae = (list(weights), list(biases), [int(w.shape[1]) for w in weights], [nonlinearities] * (n - 1) + ["linear"])
+    return create_model(ae, input_shape, input_var, mask_shape, mask_var, lstm_size, win, output_classes, w_init_fn,
+                        use_peepholes, use_blstm=True)
+
+
 def load_saved_model(model_path, stream_params, input_shape, input_var, mask_shape, mask_var, lstm_size=250, win=None,
                      output_classes=26, w_init_fn='glorot', use_peepholes=False, use_blstm=True):
     """Rebuild the graph with a fresh (randomly initialised) encoder of the given widths and load a

@@ -15,6 +15,23 @@ files of ``runners/*.py``:
                                                                             ``decay_rate/decay_start``, ``t1`` and
                                                                             ``momentum_schedule``
 
+    cuave/unimodal_with_val.py      cuave/unimodal_with_val.py:150-372      deltanet_majority_vote (pretrained encoder), subject
+                                                                            split of the whole-set .mat, adam(lr)
+    cuave/unimodal_dct_with_val.py  cuave/unimodal_dct_with_val.py:130-329  lstm_classifier_majority_vote on the DCT features
+                                                                            (no delta layer), adam with DEFAULT parameters
+    cuave/trimodal_with_val.py      cuave/trimodal_with_val.py:163-377      adenet_v3 on the pre-split file (raw as stored, DCT,
+                                                                            diff of raw), adadelta with lr decay
+    cuave/audio_visual_runner.py    cuave/audio_visual_runner.py:242-472    avnet: visual + audio encoder sub-streams
+                                                                            (create_pretrained_substream x 2 -> create_model)
+    oulu/unimodal_with_val.py       oulu/unimodal_with_val.py:219-403       deltanet_majority_vote, subject split, adam(lr)
+    oulu/bimodal_with_val.py        oulu/bimodal_with_val.py:217-451        adenet_v2 (encoder + DCT stream), adam(lr); the
+                                                                            script overwrites the .ini's epochsize / batchsize
+                                                                            with 120 / 10 (:366-367)
+    avletters/bimodal_diff_image.py avletters/bimodal_diff_image.py:215-498 adenet_v2_1 (raw + diff encoders, last-timestep
+                                                                            head), the four update rules, BOTH decay rules
+    avletters/unimodal.py           avletters/unimodal.py:121-304           schema-1 ``[stream1]`` .ini, iterVec split,
+                                                                            deltanet_majority_vote / deltanet_v1, adam(lr)
+
 Same keys, same preprocessing order, same epoch statistics (GL / Pk / PQ), same printed lines and results files.  What
 differs, on purpose:
   * the encoders: the reference un-pickles *nolearn* networks (``finetuned``, ``finetuned_diff``); nolearn does not
@@ -40,7 +57,8 @@ import scipy.io as sio
 
 from .. import init as las_init
 from ..custom.nonlinearities import select_nonlinearity
-from ..modelzoo import adenet_v2, adenet_v2_3, adenet_v3
+from ..modelzoo import (adenet_v2, adenet_v2_1, adenet_v2_3, adenet_v3, avnet, deltanet_majority_vote, deltanet_v1,
+                        lstm_classifier_majority_vote)
 from ..utils.data_structures import circular_list
 from ..utils.datagen import compute_integral_len, gen_lstm_batch_random, gen_seq_batch_from_idx
 from ..utils.io import load_mat_file, read_data_split_file
@@ -50,7 +68,19 @@ from ..utils.preprocessing import (compute_diff_images, create_split_index, feat
 from ..utils.regularization import early_stop, early_stop2
 from .nstream import evaluate_model2
 
-SCRIPTS = {('cuave', 'bimodal_with_val'), ('oulu', 'trimodal_with_val'), ('avletters', 'trimodal'), ('avletters', 'bimodal')}
+# (dataset, script) -> default --config of the reference script
+SCRIPTS = {('cuave', 'bimodal_with_val'): 'config/bimodal_meanrm_raw_dct.ini',
+           ('cuave', 'unimodal_with_val'): 'config/unimodal_meanrmraw.ini',
+           ('cuave', 'unimodal_dct_with_val'): 'config/unimodal_dct.ini',
+           ('cuave', 'trimodal_with_val'): 'config/trimodal.ini',
+           ('cuave', 'audio_visual_runner'): 'config/avnet.ini',
+           ('oulu', 'trimodal_with_val'): 'config/trimodal.ini',
+           ('oulu', 'unimodal_with_val'): 'config/unimodal.ini',
+           ('oulu', 'bimodal_with_val'): 'config/bimodal.ini',
+           ('avletters', 'trimodal'): 'config/trimodal.ini',
+           ('avletters', 'bimodal'): 'config/bimodal.ini',
+           ('avletters', 'bimodal_diff_image'): 'config/bimodal_diff_image.ini',
+           ('avletters', 'unimodal'): 'config/normal.ini'}
 
 
 # --------------------------------------------------------------------------------------------------------- encoders
@@ -92,6 +122,10 @@ def parse_options(argv, default_config):
     parser.add_argument('--t1', help='epoch to start learning rate decay, eg: 10')
     parser.add_argument('--weight_init', help='norm,glorot,ortho,uniform')
     parser.add_argument('--num_epoch', help='number of epochs to run')
+    parser.add_argument('--no_epochs', help='Max epochs to run (cuave/unimodal*_with_val.py)')
+    parser.add_argument('--epochsize', help='Number of mini batches to run for each epoch')
+    parser.add_argument('--batchsize', help='Mini batch size')
+    parser.add_argument('--save_best', help='save best model (cuave/unimodal_with_val.py)')
     parser.add_argument('--use_peepholes', action='store_true', help='use peephole connections in LSTM')
     parser.add_argument('--no_plot', dest='no_plot', action='store_true', help='disable plots')
     parser.add_argument('--seed', type=int, default=None, help='seed for initialisers, dropout and minibatch order '
@@ -99,7 +133,7 @@ def parse_options(argv, default_config):
     args = parser.parse_args(argv)
     options = {'config': args.config or default_config, 'no_plot': bool(args.no_plot), 'seed': args.seed}
     for key in ('write_results', 'update_rule', 'learning_rate', 'decay_rate', 'momentum', 'momentum_schedule',
-                'validation_window', 't1', 'weight_init', 'num_epoch'):
+                'validation_window', 't1', 'weight_init', 'num_epoch', 'no_epochs', 'epochsize', 'batchsize', 'save_best'):
         if getattr(args, key):
             options[key] = getattr(args, key)
     if args.use_peepholes:
@@ -115,15 +149,19 @@ class _Cfg(object):
         self.config, self.options = config, options
 
     def get(self, section, key, conv=str, default=None):
-        if key in self.options and section == 'training':
-            return conv(self.options[key])
-        if self.config.has_option(section, key):
-            raw = self.config.get(section, key)
-            if conv is bool:
-                return self.config.getboolean(section, key)
-            return conv(raw)
+        """``key`` may be a tuple of spellings (the scripts disagree: num_epoch / no_epochs, lstm_size / lstm_units,
+        no_coeff / no_coeffs, input_dimension / input_dimensions); the first one present wins."""
+        keys = key if isinstance(key, tuple) else (key,)
+        for k in keys:
+            if k in self.options and section == 'training':
+                return conv(self.options[k])
+        for k in keys:
+            if self.config.has_option(section, k):
+                if conv is bool:
+                    return self.config.getboolean(section, k)
+                return conv(self.config.get(section, k))
         if default is None:
-            raise configparser.NoOptionError(key, section)
+            raise configparser.NoOptionError(keys[0], section)
         return default
 
 
@@ -250,13 +288,507 @@ def _load_avletters(cfg, with_diff, normalise_images, target_offset):
     return split, ys, lens
 
 
+
+
+def _presplit_cuave(cfg, key='images'):
+    """The pre-split CUAVE file (App. C): per split its frames, lengths and targets (+1: the -1 introduced in lstm_gendata)."""
+    data = load_mat_file(cfg.get('data', key))
+    X, lens, ys = {}, {}, {}
+    for k, pre in (('train', 'tr'), ('val', 'val'), ('test', 'test')):
+        lens[k] = _vec(data, pre + 'VideoLengthVec')
+        X[k] = data[pre + 'Data'].astype('float32')
+        if pre + 'TargetsVec' in data:
+            ys[k] = _vec(data, pre + 'TargetsVec') + 1
+    return X, lens, ys
+
+
+def _cuave_dct(cfg, with_train_stats=True):
+    dct_data = load_mat_file(cfg.get('data', 'dct'))
+    d = {k: dct_data[pre + 'DctFeatures'].astype('float32') for k, pre in (('train', 'tr'), ('val', 'val'), ('test', 'test'))}
+    tr, mean, std = featurewise_normalize_sequence(d['train'])
+    return dict(train=tr, val=(d['val'] - mean) / std, test=(d['test'] - mean) / std)
+
+
+def _load_cuave_dct(cfg):
+    """cuave/unimodal_dct_with_val.py:176-194: the DCT features alone (lengths / targets from the images file)."""
+    _, lens, ys = _presplit_cuave(cfg)
+    d = _cuave_dct(cfg)
+    return {k: [d[k]] for k in d}, ys, lens
+
+
+def _load_cuave_trimodal(cfg):
+    """cuave/trimodal_with_val.py:189-208: raw frames AS STORED (no reordering, mean removal or normalisation), the
+    train-normalised DCT features, diff images of the raw frames.  Stream order of adenet_v3: raw, dct, diff."""
+    X, lens, ys = _presplit_cuave(cfg)
+    d = _cuave_dct(cfg)
+    return {k: [X[k], d[k], compute_diff_images(X[k], lens[k])] for k in X}, ys, lens
+
+
+def _load_cuave_av(cfg):
+    """cuave/audio_visual_runner.py:295-312: the visual frames re-ordered to C order (nothing else), the audio features of
+    the second pre-split file as stored."""
+    X, lens, ys = _presplit_cuave(cfg)
+    A, _, _ = _presplit_cuave(cfg, 'audio')
+    imagesize = tuple(int(v) for v in cfg.get('data', 'imagesize', str, '30,50').split(','))
+    return {k: [reorder_data(X[k], imagesize), A[k]] for k in X}, ys, lens
+
+
+def _subject_ids(cfg):
+    return [read_data_split_file(cfg.get('training', k + '_subjects_file', str, 'data/%s.txt' % k)) for k in ('train', 'val', 'test')]
+
+
+def _load_cuave_subject_unimodal(cfg):
+    """cuave/unimodal_with_val.py:201-244: per-sequence mean removal of the WHOLE set, subject split, targets + 1,
+    re-ordering to C order, a second per-sequence mean removal per split, per-frame z-normalisation."""
+    data = load_mat_file(cfg.get('data', 'images'))
+    X = data['dataMatrix'].astype('float32')
+    y, subjects, lens_all = _vec(data, 'targetsVec'), _vec(data, 'subjectsVec'), _vec(data, 'videoLengthVec')
+    X = sequencewise_mean_image_subtraction(X, lens_all)
+    ids = _subject_ids(cfg)
+    parts = split_seq_data(X, y, subjects, lens_all, ids[0], ids[1], ids[2])
+    imagesize = tuple(int(v) for v in cfg.get('data', 'imagesize', str, '30,50').split(','))
+    split, ys, lens = {}, {}, {}
+    for k, o in (('train', 0), ('val', 4), ('test', 8)):
+        lens[k] = np.asarray(parts[o + 2], int)
+        ys[k] = np.asarray(parts[o + 1]) + 1
+        Xk = reorder_data(parts[o], imagesize)
+        Xk = sequencewise_mean_image_subtraction(Xk, lens[k])
+        split[k] = [normalize_input(Xk, centralize=True)]
+    return split, ys, lens
+
+
+def _load_oulu(cfg, with_dct):
+    """oulu/unimodal_with_val.py:263-296 / oulu/bimodal_with_val.py:270-316: subject split, per-frame z-normalisation of
+    the frames; with_dct: the DCT features ride along, feature-wise normalised with the TRAIN statistics."""
+    data = load_mat_file(cfg.get('data', 'images'))
+    X = data['dataMatrix'].astype('float32')
+    y, subjects, lens_all = _vec(data, 'targetsVec', 'int32'), _vec(data, 'subjectsVec'), _vec(data, 'videoLengthVec')
+    ids = _subject_ids(cfg)
+    mats = [X] + ([load_mat_file(cfg.get('data', 'dct'))['dctFeatures'].astype('float32')] if with_dct else [])
+    split = dict(train=[], val=[], test=[])
+    for mat in mats:
+        parts = split_seq_data(mat, y, subjects, lens_all, ids[0], ids[1], ids[2])
+        split['train'].append(parts[0]); split['val'].append(parts[4]); split['test'].append(parts[8])
+        ys = dict(train=parts[1], val=parts[5], test=parts[9])
+        lens = dict(train=parts[2], val=parts[6], test=parts[10])
+    for k in split:
+        split[k][0] = normalize_input(split[k][0], centralize=True)
+    if with_dct:
+        tr, mean, std = featurewise_normalize_sequence(split['train'][1])
+        split['train'][1] = tr
+        for k in ('val', 'test'):
+            split[k][1] = (split[k][1] - mean) / std
+    return split, ys, lens
+
+
+def _load_avletters_diff(cfg):
+    """avletters/bimodal_diff_image.py:269-304: raw and diff-image matrices as stored (every normalisation is commented
+    out in the script), targets as stored, iterVec split; the test split doubles as the validation split."""
+    data = load_mat_file(cfg.get('data', 'images'))
+    mats = [data['dataMatrix'].astype('float32'), load_mat_file(cfg.get('data', 'diff'))['dataMatrix'].astype('float32')]
+    targets_vec, vid_len_vec, iter_vec = _vec(data, 'targetsVec'), _vec(data, 'videoLengthVec'), _vec(data, 'iterVec')
+    indexes = create_split_index(len(mats[0]), vid_len_vec, iter_vec)
+    train_lens, test_lens = split_videolen(vid_len_vec, iter_vec)
+    assert np.sum(vid_len_vec) == len(mats[0])
+    split = dict(train=[m[indexes] for m in mats], test=[m[~indexes] for m in mats])
+    split['val'] = split['test']
+    ys = dict(train=targets_vec[indexes], test=targets_vec[~indexes])
+    ys['val'] = ys['test']
+    lens = dict(train=np.asarray(train_lens, int), test=np.asarray(test_lens, int))
+    lens['val'] = lens['test']
+    return split, ys, lens
+
+
+def _load_avletters_stream1(config):
+    """avletters/unimodal.py:178-204: the schema-1 ``[stream1]`` section's switches (reorderdata / meanremove / diffimage /
+    samplewisenormalize ahead of the split, featurewisenormalize behind it), iterVec split, matlab_target_offset."""
+    from .nstream import presplit_dataprocessing
+    data = load_mat_file(config.get('stream1', 'data'))
+    imagesize = tuple(int(d) for d in config.get('stream1', 'imagesize').split(','))
+    X = data['dataMatrix'].astype('float32')
+    targets_vec, vid_len_vec, iter_vec = _vec(data, 'targetsVec'), _vec(data, 'videoLengthVec'), _vec(data, 'iterVec')
+    X = presplit_dataprocessing(X, vid_len_vec, config, 'stream1', imagesize=imagesize)
+    indexes = create_split_index(len(X), vid_len_vec, iter_vec)
+    train_lens, test_lens = split_videolen(vid_len_vec, iter_vec)
+    if config.getboolean('lstm_classifier', 'matlab_target_offset'):
+        targets_vec = targets_vec - 1
+    tr, te = X[indexes], X[~indexes]
+    if config.getboolean('stream1', 'featurewisenormalize'):
+        tr, mean, std = featurewise_normalize_sequence(tr)
+        te = (te - mean) / std
+    split = dict(train=[tr], test=[te])
+    split['val'] = split['test']
+    ys = dict(train=targets_vec[indexes], test=targets_vec[~indexes])
+    ys['val'] = ys['test']
+    lens = dict(train=np.asarray(train_lens, int), test=np.asarray(test_lens, int))
+    lens['val'] = lens['test']
+    return split, ys, lens
+
+
+# --------------------------------------------------------------------------------------------------------- per-script plans
+_DIGITS = '0,1,2,3,4,5,6,7,8,9'
+_PHRASES = 'p1,p2,p3,p4,p5,p6,p7,p8,p9,p10'
+_LETTERS = ','.join('abcdefghijklmnopqrstuvwxyz')
+_MS = (None, None)
+
+
+class Plan(object):
+    """Everything one reference script decides ahead of its epoch loop.  Defaults = the most common choice."""
+    head = 'frames'            # per-frame softmax + temporal loss + majority vote | 'last': SliceLayer(-1) + cross-entropy
+    has_test = True            # a held-out test split besides the validation split (the AVLetters scripts have none)
+    stop = 'early_stop2'       # utils/regularization.py:14-23 | 'early_stop' (strictly increasing window, :1-11)
+    decay = False              # lr *= decay_rate after every epoch from decay_start on
+    t1_rule = False            # avletters/bimodal*.py: no improvement and epoch >= t1 -> lr = max(lr * decay, 0.001), next momentum
+    rule = 'adam'
+    l_fuse = None
+    fusiontype = None
+    window = 9                 # WINDOW_SIZE of the older scripts
+    conf_fmt = 'latex'
+    plot_name = 'valid_cost'
+    final = 'CR: {best_cr}, val loss: {best_val}, Test CR: {test_cr}'
+    progress = 'Epoch {e} batch {i}/{n}: {b} examples using adam at learning rate = {lr:.4f}'
+    results = None             # callable(f, st) writing the --write_results lines
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def _hyper(cfg, plan, num_epoch=None, epochsize=None, batchsize=None, validation_window=None):
+    """Loop sizes: the .ini / CLI value, else the constant the reference script hard-codes."""
+    plan.num_epoch = cfg.get('training', ('num_epoch', 'no_epochs'), int, num_epoch)
+    plan.epochsize = cfg.get('training', 'epochsize', int, epochsize)
+    plan.batchsize = cfg.get('training', 'batchsize', int, batchsize)
+    plan.validation_window = cfg.get('training', 'validation_window', int, validation_window)
+
+
+def _series(f, st):
+    for series in (st['cost_train'], st['cost_val'], st['class_rate']):
+        f.write('{}\n'.format(','.join(str(v) for v in series)))
+
+
+def _adam_plan(cfg, network, learning_rate, **kw):
+    plan = Plan(network=network, rule='adam', **kw)
+    plan.update = Updater(network, 'adam', learning_rate)     # (carries lr for the progress line)
+    plan.train = lambda ins, y, m, w: network.train_step(ins, y, m, w, learning_rate)   # adam(cost, params, learning_rate)
+    return plan
+
+
+def _plan_cuave_bimodal(cfg, config, options):
+    split, ys, lens = _load_cuave(cfg)
+    weight_init = cfg.get('training', 'weight_init')
+    use_peepholes = cfg.get('training', 'use_peepholes', bool)
+    nonlinearity = select_nonlinearity(cfg.get('models', 'nonlinearity'))
+    use_blstm, use_finetuning = cfg.get('training', 'use_blstm', bool), cfg.get('training', 'use_finetuning', bool)
+    learning_rate = cfg.get('training', 'learning_rate', float)
+    fusiontype = cfg.get('models', 'fusiontype')
+    ae = load_dbn(cfg.get('models', 'pretrained'))
+    network, l_fuse = adenet_v2.create_model(ae, (None, None, cfg.get('models', 'input_dimension', int, 1500)), None, _MS, None,
+                                             (None, None, cfg.get('models', 'no_coeff', int, 30) * 3), None,
+                                             cfg.get('models', 'lstm_size', int, 250), None,
+                                             cfg.get('models', 'output_classes', int, 10), fusiontype,
+                                             las_init.select(weight_init), use_peepholes, nonlinearity)
+    plan = _adam_plan(cfg, network, learning_rate, split=split, ys=ys, lens=lens, l_fuse=l_fuse, fusiontype=fusiontype,
+                      names=_DIGITS, progress='Epoch {e} batch {i}/{n}: {b} examples at learning rate = {lr:.4f}')
+    _hyper(cfg, plan)
+
+    def results(f, st):                              # cuave/bimodal_with_val.py:376-381
+        f.write('{},{},{},{},{},{},{},{},{},{},{},{}\n'.format(use_finetuning, 'yes', use_peepholes, 'adam', weight_init, 'RELU',
+                                                               use_blstm, learning_rate, st['best_tr'], st['best_val'],
+                                                               st['best_cr'] * 100, st['test_cr'] * 100))
+        _series(f, st)
+    plan.results = results
+    return plan
+
+
+def _encoder_of(cfg, nonlinearity):
+    weights, biases, _, _ = load_dbn(cfg.get('models', 'pretrained'))
+    return weights, biases
+
+
+def _plan_unimodal_encoder(cfg, config, options, dataset):
+    """cuave/unimodal_with_val.py, oulu/unimodal_with_val.py: ONE encoder stream, summed BLSTM, per-frame softmax.  Both
+    scripts call ``deltanet_majority_vote.create_model_using_pretrained_encoder`` -- a function the reference module does
+    not define (only modelzoo/deltanet.py:12 has one of that name, with the last-timestep head, while the scripts train
+    with temporal_softmax_loss and vote per frame): the per-frame model with that argument list is what they mean."""
+    cuave = dataset == 'cuave'
+    split, ys, lens = _load_cuave_subject_unimodal(cfg) if cuave else _load_oulu(cfg, with_dct=False)
+    nonlinearity = select_nonlinearity(cfg.get('models', 'nonlinearity'))
+    weight_init = cfg.get('training' if cuave else 'models', 'weight_init')
+    use_peepholes = cfg.get('training', 'use_peepholes', bool)
+    learning_rate = cfg.get('training', 'learning_rate', float)
+    weights, biases = _encoder_of(cfg, nonlinearity)
+    network = deltanet_majority_vote.create_model_using_pretrained_encoder(
+        weights, biases, (None, None, cfg.get('models', 'input_dimension', int, 1500 if cuave else 1144)), None, _MS, None,
+        cfg.get('models', ('lstm_size', 'lstm_units'), int), None, cfg.get('models', 'output_classes', int),
+        las_init.select(weight_init), use_peepholes, nonlinearity)
+    plan = _adam_plan(cfg, network, learning_rate, split=split, ys=ys, lens=lens, names=_DIGITS if cuave else _PHRASES,
+                      conf_fmt='grid', plot_name=None,
+                      final='test CR: {test_cr}, val CR: {best_cr}, val loss: {best_val}' if cuave
+                      else 'classification rate: {test_cr}, validation loss: {best_val}')
+    plan.window = 9 if cuave else cfg.get('models', 'delta_window', int)
+    _hyper(cfg, plan)
+    if cuave:
+        plan.results = lambda f, st: f.write('{},{},{}\n'.format(st['test_cr'], st['best_cr'], st['best_val']))
+        plan.save_best = options.get('save_best')
+    return plan
+
+
+def _plan_cuave_unimodal_dct(cfg, config, options):
+    split, ys, lens = _load_cuave_dct(cfg)
+    weight_init = cfg.get('training', 'weight_init')
+    use_peepholes = cfg.get('training', 'use_peepholes', bool)
+    use_blstm, use_finetuning = cfg.get('training', 'use_blstm', bool), cfg.get('training', 'use_finetuning', bool)
+    learning_rate = cfg.get('training', 'learning_rate', float)       # read and reported; adam runs with its defaults (:217)
+    network = lstm_classifier_majority_vote.create_model((None, None, cfg.get('models', 'no_coeff', int) * 3), None, _MS, None,
+                                                         cfg.get('models', 'lstm_size', int), cfg.get('models', 'output_classes', int),
+                                                         w_init=las_init.select(weight_init))
+    plan = Plan(network=network, rule='adam', split=split, ys=ys, lens=lens, names=_DIGITS,
+                progress='Epoch {e} batch {i}/{n}: {b} examples using adam')
+    plan.update = Updater(network, 'adam', 1e-3)
+    plan.train = plan.update
+    _hyper(cfg, plan)
+
+    def results(f, st):                              # cuave/unimodal_dct_with_val.py:313-325
+        f.write('{},{},{},{},{},{},{},{},{},{},{},{}\n'.format(use_finetuning, 'yes', use_peepholes, 'adam', weight_init, 'N/A',
+                                                               use_blstm, learning_rate, st['best_tr'], st['best_val'],
+                                                               st['best_cr'] * 100, st['test_cr'] * 100))
+        _series(f, st)
+    plan.results = results
+    return plan
+
+
+def _plan_trimodal(cfg, config, options, dataset, script):
+    """adenet_v3 scripts: oulu/trimodal_with_val.py, avletters/trimodal.py, cuave/trimodal_with_val.py."""
+    for key in ('do_finetune', 'save_finetune'):
+        if cfg.get('training', key, bool, False):
+            raise NotImplementedError('%s: nolearn auto-encoder fine-tuning is outside this package (SURVEY 8: out of scope); '
+                                      'fine-tune offline and point `finetuned` to the weights' % key)
+    if dataset == 'oulu':
+        split, ys, lens = _load_subject_split(cfg)
+        consts = dict(num_epoch=12, epochsize=120, batchsize=10, validation_window=4, dim=1144, classes=10, names=_PHRASES)
+    elif dataset == 'cuave':
+        split, ys, lens = _load_cuave_trimodal(cfg)
+        consts = dict(num_epoch=30, epochsize=45, batchsize=20, validation_window=4, dim=1500, classes=10, names=_DIGITS)
+    else:
+        split, ys, lens = _load_avletters(cfg, with_diff=True, normalise_images=False, target_offset=False)
+        consts = dict(num_epoch=25, epochsize=20, batchsize=26, validation_window=4, dim=1200, classes=26, names=_LETTERS)
+    fusiontype = cfg.get('models', 'fusiontype')
+    learning_rate = cfg.get('training', 'learning_rate', float)
+    if not cfg.get('training', 'load_finetune', bool, True) or not cfg.get('training', 'load_finetune_diff', bool, True):
+        raise ValueError('load_finetune / load_finetune_diff must be true: the scripts define `ae` / `diff_ae` nowhere else')
+    ae = load_ae(cfg.get('models', 'finetuned'))
+    ae_diff = load_ae(cfg.get('models', 'finetuned_diff'))
+    network, l_fuse = adenet_v3.create_model(ae, ae_diff, (None, None, cfg.get('models', 'input_dimension', int, consts['dim'])), None,
+                                             _MS, None, (None, None, split['train'][1].shape[1]), None,
+                                             (None, None, split['train'][2].shape[1]), None,
+                                             cfg.get('models', 'lstm_size', int, 250), None,
+                                             cfg.get('models', 'output_classes', int, consts['classes']), fusiontype)
+    plan = Plan(network=network, l_fuse=l_fuse, fusiontype=fusiontype, rule='adadelta', head='last', stop='early_stop', decay=True,
+                split=split, ys=ys, lens=lens, names=consts['names'], has_test=dataset != 'avletters',
+                progress='Epoch {e} batch {i}/{n}: {b} examples at learning rate = {lr:.4f}')
+    plan.update = Updater(network, 'adadelta', learning_rate)
+    plan.train = plan.update
+    plan.decay_rate, plan.decay_start = cfg.get('training', 'decay_rate', float), cfg.get('training', 'decay_start', int)
+    _hyper(cfg, plan, consts['num_epoch'], consts['epochsize'], consts['batchsize'], consts['validation_window'])
+    if dataset == 'avletters':
+        plan.final, plan.plot_name = 'classification rate: {best_cr}, validation loss: {best_val}', 'e2e_valid_cost'
+        plan.results = lambda f, st: f.write('{},{},{}\n'.format(fusiontype, st['best_cr'], st['best_val']))
+    elif dataset == 'cuave':                         # cuave/trimodal_with_val.py:374-377
+        plan.results = lambda f, st: f.write('{},{},{}\n'.format(fusiontype, st['test_cr'], st['best_val']))
+    else:
+        plan.results = lambda f, st: f.write('{},{},{}\n'.format(fusiontype, st['best_cr'], st['best_val']))
+    return plan
+
+
+def _plan_oulu_bimodal(cfg, config, options):
+    split, ys, lens = _load_oulu(cfg, with_dct=True)
+    fusiontype = cfg.get('models', 'fusiontype')
+    learning_rate = cfg.get('training', 'learning_rate', float)
+    dbn = load_dbn(cfg.get('models', 'pretrained'))
+    network, l_fuse = adenet_v2.create_model(dbn, (None, None, cfg.get('models', ('input_dimensions', 'input_dimension'), int)), None,
+                                             _MS, None, (None, None, cfg.get('models', ('no_coeffs', 'no_coeff'), int)), None,
+                                             cfg.get('models', 'lstm_size', int), None, cfg.get('models', 'output_classes', int),
+                                             fusiontype, w_init_fn=las_init.select(cfg.get('training', 'weight_init')),
+                                             use_peepholes=cfg.get('models', 'use_peepholes', bool))
+    plan = _adam_plan(cfg, network, learning_rate, split=split, ys=ys, lens=lens, l_fuse=l_fuse, fusiontype=fusiontype,
+                      names=_PHRASES)
+    plan.window = cfg.get('models', 'delta_window', int)
+    _hyper(cfg, plan)
+    if not cfg.get('training', 'honour_ini_sizes', bool, False):
+        plan.epochsize, plan.batchsize = 120, 10     # oulu/bimodal_with_val.py:366-367 overwrites what it read from the .ini
+    plan.results = lambda f, st: f.write('{},{},{}\n'.format(fusiontype, st['test_cr'], st['best_val']))
+    return plan
+
+
+def _rule_plan(cfg, plan, momentum_default=0.9):
+    """``update_rule`` switch + both decay rules of avletters/bimodal.py:446-455,541-555 / bimodal_diff_image.py."""
+    rule = cfg.get('training', 'update_rule')
+    plan.rule = rule
+    plan.decay_rate, plan.decay_start = cfg.get('training', 'decay_rate', float), cfg.get('training', 'decay_start', int)
+    plan.t1 = cfg.get('training', 't1', int)
+    plan.momentum, plan.mm_schedule = momentum_default, []
+    if rule in ('sgdm', 'sgdnm'):
+        plan.momentum = cfg.get('training', 'momentum', float)
+        plan.mm_schedule = [float(m) for m in cfg.get('training', 'momentum_schedule').split(',')]
+    plan.update = Updater(plan.network, rule, cfg.get('training', 'learning_rate', float), plan.momentum)
+    plan.train = plan.update
+    plan.decay, plan.t1_rule = True, True
+    if rule == 'adam':
+        plan.progress = 'Epoch {e} batch {i}/{n}: {b} examples with {rule} using default params'
+    elif rule in ('sgdm', 'sgdnm'):
+        plan.progress = 'Epoch {e} batch {i}/{n}: {b} examples at learning rate = {lr:.4f}, momentum = {mm:.4f} with {rule}'
+    else:
+        plan.progress = plan.adadelta_progress
+
+
+def _plan_avletters_bimodal(cfg, config, options):
+    split, ys, lens = _load_avletters(cfg, with_diff=False, normalise_images=True, target_offset=True)
+    fusiontype = cfg.get('models', 'fusiontype')
+    weight_init = cfg.get('training', 'weight_init')
+    use_peepholes = cfg.get('training', 'use_peepholes', bool)
+    use_blstm, use_finetuning = cfg.get('training', 'use_blstm', bool), cfg.get('training', 'use_finetuning', bool)
+    dbn = load_ae(cfg.get('models', 'pretrained'))
+    if not isinstance(dbn, (tuple, list)) or len(dbn) == 2:
+        from ..modelzoo._factory import nolearn_weights
+        dbn = nolearn_weights(dbn, nonlinearities=('rectify', 'rectify', 'rectify', 'linear'))
+    factory = adenet_v2 if use_blstm else adenet_v2_3
+    network, l_fuse = factory.create_model(dbn, (None, None, cfg.get('models', 'input_dimension', int, 1200)), None, _MS, None,
+                                           (None, None, cfg.get('models', 'no_coeff', int, 30) * 3), None,
+                                           cfg.get('models', 'lstm_size', int, 250), None,
+                                           cfg.get('models', 'output_classes', int, 26), fusiontype,
+                                           w_init_fn=las_init.select(weight_init), use_peepholes=use_peepholes)
+    plan = Plan(network=network, l_fuse=l_fuse, fusiontype=fusiontype, split=split, ys=ys, lens=lens, names=_LETTERS,
+                has_test=False, conf_fmt='pipe', plot_name='e2e_valid_cost', adasum_at_end=True,
+                final='classification rate: {best_cr}, validation loss: {best_val}',
+                adadelta_progress='Epoch {e} batch {i}/{n}: {b} examples at learning rate = {lr:.4f}')
+    _rule_plan(cfg, plan)
+    plan.decay = False                               # avletters/bimodal.py has the t1 rule only
+    _hyper(cfg, plan, None, 20, 26, None)
+
+    def results(f, st):                              # avletters/bimodal.py:592-606
+        f.write('{},{},{},{},{}\n'.format(plan.validation_window, weight_init, use_peepholes, use_blstm, use_finetuning))
+        _series(f, st)
+        f.write('{},{},{}\n'.format(fusiontype, st['best_cr'], st['best_val']))
+    plan.results = results
+    return plan
+
+
+def _plan_avletters_bimodal_diff(cfg, config, options):
+    for key in ('do_finetune', 'save_finetune'):
+        if cfg.get('training', key, bool, False):
+            raise NotImplementedError('%s: nolearn auto-encoder fine-tuning is outside this package (SURVEY 8: out of scope)' % key)
+    split, ys, lens = _load_avletters_diff(cfg)
+    fusiontype = cfg.get('models', 'fusiontype')
+    model = cfg.get('models', 'model')
+    if model != 'adenet_v2_1':
+        raise ValueError("avletters/bimodal_diff_image.py:344 builds a network only for model = adenet_v2_1 (got %r)" % model)
+    weight_init = cfg.get('training', 'weight_init')
+    # parse_options() of the script sets use_peepholes=True as the parser default and copies it into `options` whenever it is
+    # truthy (:176,207-208): the .ini's value never wins
+    use_peepholes = True
+    if not cfg.get('training', 'load_finetune', bool, True) or not cfg.get('training', 'load_finetune_diff', bool, True):
+        raise ValueError('load_finetune / load_finetune_diff must be true: the script defines `ae` / `diff_ae` nowhere else')
+    ae, diff_ae = load_ae(cfg.get('models', 'finetuned')), load_ae(cfg.get('models', 'finetuned_diff'))
+    network, l_fuse = adenet_v2_1.create_model(ae, diff_ae, (None, None, cfg.get('models', 'input_dimension', int, 1200)), None, _MS,
+                                               None, (None, None, split['train'][1].shape[1]), None,
+                                               cfg.get('models', 'lstm_size', int, 250), None,
+                                               cfg.get('models', 'output_classes', int, 26), fusiontype,
+                                               w_init_fn=las_init.select(weight_init), use_peepholes=use_peepholes)
+    plan = Plan(network=network, l_fuse=l_fuse, fusiontype=fusiontype, head='last', split=split, ys=ys, lens=lens, names=_LETTERS,
+                has_test=False, plot_name='e2e_valid_cost', adasum_at_end=True,
+                final='classification rate: {best_cr}, validation loss: {best_val}',
+                adadelta_progress='Epoch {e} batch {i}/{n}: {b} examples at learning rate = {lr:.4f} with {rule}')
+    _rule_plan(cfg, plan)
+    _hyper(cfg, plan, None, 20, 26, None)
+    learning_rate = cfg.get('training', 'learning_rate', float)
+
+    def results(f, st):                              # avletters/bimodal_diff_image.py:481-497
+        f.write('{},{},{},{},{},{},{},{},{}\n'.format(plan.rule, learning_rate, plan.decay_rate, plan.momentum, plan.decay_start,
+                                                      plan.t1, plan.validation_window, weight_init, use_peepholes))
+        _series(f, st)
+        f.write('{},{},{}\n'.format(fusiontype, st['best_cr'], st['best_val']))
+    plan.results = results
+    return plan
+
+
+def _plan_avletters_unimodal(cfg, config, options):
+    """avletters/unimodal.py: the one schema-1 file in this family ([stream1] / [lstm_classifier] / [training])."""
+    from .nstream import load_decoder
+    split, ys, lens = _load_avletters_stream1(config)
+    lc = 'lstm_classifier'
+    has_encoder = config.getboolean('stream1', 'has_encoder')
+    dim = config.getint('stream1', 'input_dimensions')
+    w_init = las_init.select(options.get('weight_init', config.get(lc, 'weight_init')))
+    use_peepholes = options.get('use_peepholes', config.getboolean(lc, 'use_peepholes'))
+    use_blstm = config.has_option(lc, 'use_blstm')              # presence test, avletters/unimodal.py:155
+    H, C = config.getint(lc, 'lstm_size'), config.getint(lc, 'output_classes')
+    learning_rate = float(options.get('learning_rate', config.getfloat('training', 'learning_rate')))
+    if has_encoder:
+        ae1 = load_decoder(config.get('stream1', 'model'), config.get('stream1', 'shape'), config.get('stream1', 'nonlinearities'))
+        network = deltanet_majority_vote.create_model(ae1, (None, None, dim), None, _MS, None, H, None, C, w_init, use_peepholes)
+    else:
+        network = deltanet_v1.create_model((None, None, dim), None, _MS, None, None, H, C, w_init, use_peepholes, use_blstm)
+    plan = _adam_plan(cfg, network, learning_rate, split=split, ys=ys, lens=lens, names=config.get(lc, 'output_classnames'),
+                      has_test=False, plot_name=None, final='classification rate: {best_cr}, validation loss: {best_val}',
+                      progress='Epoch {e} batch {i}/{n}: {b} examples at learning rate = {lr:.4f}')
+    plan.window = config.getint(lc, 'windowsize')
+    plan.num_epoch = int(options.get('num_epoch', config.getint('training', 'num_epoch')))
+    plan.validation_window = int(options.get('validation_window', config.getint('training', 'validation_window')))
+    plan.epochsize, plan.batchsize = config.getint('training', 'epochsize'), config.getint('training', 'batchsize')
+    return plan
+
+
+def _plan_cuave_avnet(cfg, config, options):
+    """cuave/audio_visual_runner.py:242-472."""
+    split, ys, lens = _load_cuave_av(cfg)
+    fusiontype = cfg.get('models', 'fusiontype')
+    lstm_size, output_classes = cfg.get('models', 'lstm_size', int), cfg.get('models', 'output_classes', int)
+    nonlinearity = select_nonlinearity(cfg.get('models', 'nonlinearity'))
+    weight_init = cfg.get('training', 'weight_init')
+    w_init = las_init.select(weight_init)
+    use_peepholes = cfg.get('training', 'use_peepholes', bool)
+    use_blstm, use_finetuning = cfg.get('training', 'use_blstm', bool), cfg.get('training', 'use_finetuning', bool)
+    learning_rate = cfg.get('training', 'learning_rate', float)
+    vw, vb, _, _ = load_dbn(cfg.get('models', 'pretrained'))
+    aw, ab, _, _ = load_dbn(cfg.get('models', 'pretrained_diff'))
+    visual_net = avnet.create_pretrained_substream(vw, vb, (None, None, cfg.get('models', 'input_dimension', int)), None, _MS, None,
+                                                   'visual', lstm_size, None, nonlinearity, w_init, use_peepholes)
+    audio_net = avnet.create_pretrained_substream(aw, ab, (None, None, cfg.get('models', 'input_dimension2', int)), None, _MS, None,
+                                                  'audio', lstm_size, None, nonlinearity, w_init, use_peepholes)
+    network, l_fuse = avnet.create_model([visual_net, audio_net], _MS, None, lstm_size, output_classes, fusiontype, w_init,
+                                         use_peepholes)
+    plan = _adam_plan(cfg, network, learning_rate, split=split, ys=ys, lens=lens, l_fuse=l_fuse, fusiontype=fusiontype,
+                      names=_DIGITS, progress='Epoch {e} batch {i}/{n}: {b} examples using adam with learning rate {lr:.4f}')
+    _hyper(cfg, plan, None, 90, 10, None)
+
+    def results(f, st):                              # cuave/audio_visual_runner.py:456-472
+        f.write('{},{},{},{},{},{},{},{},{},{},{},{}\n'.format(use_finetuning, 'yes', use_peepholes, 'adam', weight_init, 'RELU',
+                                                               use_blstm, learning_rate, st['best_tr'], st['best_val'],
+                                                               st['best_cr'] * 100, st['test_cr'] * 100))
+        _series(f, st)
+    plan.results = results
+    return plan
+
+
+_PLANS = {('cuave', 'bimodal_with_val'): _plan_cuave_bimodal,
+          ('cuave', 'unimodal_with_val'): lambda c, k, o: _plan_unimodal_encoder(c, k, o, 'cuave'),
+          ('cuave', 'unimodal_dct_with_val'): _plan_cuave_unimodal_dct,
+          ('cuave', 'trimodal_with_val'): lambda c, k, o: _plan_trimodal(c, k, o, 'cuave', 'trimodal_with_val'),
+          ('cuave', 'audio_visual_runner'): _plan_cuave_avnet,
+          ('oulu', 'trimodal_with_val'): lambda c, k, o: _plan_trimodal(c, k, o, 'oulu', 'trimodal_with_val'),
+          ('oulu', 'unimodal_with_val'): lambda c, k, o: _plan_unimodal_encoder(c, k, o, 'oulu'),
+          ('oulu', 'bimodal_with_val'): _plan_oulu_bimodal,
+          ('avletters', 'trimodal'): lambda c, k, o: _plan_trimodal(c, k, o, 'avletters', 'trimodal'),
+          ('avletters', 'bimodal'): _plan_avletters_bimodal,
+          ('avletters', 'bimodal_diff_image'): _plan_avletters_bimodal_diff,
+          ('avletters', 'unimodal'): _plan_avletters_unimodal}
+
+
 # --------------------------------------------------------------------------------------------------------- driver
 def main(dataset, script, argv=None):
     if (dataset, script) not in SCRIPTS:
         raise ValueError('no driver for %s/%s.py (have: %s)' % (dataset, script, sorted(SCRIPTS)))
-    default_cfg = {'bimodal_with_val': 'config/bimodal_meanrm_raw_dct.ini', 'trimodal_with_val': 'config/trimodal.ini',
-                   'trimodal': 'config/trimodal.ini', 'bimodal': 'config/bimodal.ini'}[script]
-    options = parse_options(argv, default_cfg)
+    options = parse_options(argv, SCRIPTS[(dataset, script)])
     if options['seed'] is not None:
         np.random.seed(options['seed'])
         las_init.set_rng(np.random.RandomState(options['seed']))
@@ -266,107 +798,21 @@ def main(dataset, script, argv=None):
     cfg = _Cfg(config, options)
     print('CLI options: {}'.format(list(options.items())))
     print('Reading Config File: {}...'.format(options['config']))
-    for sec in ('data', 'models', 'training'):
+    for sec in (('stream1', 'lstm_classifier', 'training') if config.has_section('stream1') else ('data', 'models', 'training')):
         print(config.items(sec))
     print('preprocessing dataset...')
-
-    trimodal = script in ('trimodal', 'trimodal_with_val')
-    frames_head = not trimodal                       # per-frame softmax + temporal loss vs. last timestep + cross-entropy
-    fusiontype = cfg.get('models', 'fusiontype')
-    if trimodal:
-        for key in ('do_finetune', 'save_finetune'):
-            if cfg.get('training', key, bool, False):
-                raise NotImplementedError('%s: nolearn auto-encoder fine-tuning is outside this package (SURVEY 8: out of scope); '
-                                          'fine-tune offline and point `finetuned` to the weights' % key)
-    # ---- data
-    if dataset == 'cuave':
-        split, ys, lens = _load_cuave(cfg)
-    elif dataset == 'oulu':
-        split, ys, lens = _load_subject_split(cfg)
-    elif script == 'trimodal':
-        split, ys, lens = _load_avletters(cfg, with_diff=True, normalise_images=False, target_offset=False)
-    else:
-        split, ys, lens = _load_avletters(cfg, with_diff=False, normalise_images=True, target_offset=True)
+    plan = _PLANS[(dataset, script)](cfg, config, options)
+    network, update, train = plan.network, plan.update, plan.train
+    split, ys, lens = plan.split, plan.ys, plan.lens
     n_streams = len(split['train'])
-
-    # ---- hyper-parameters (reference constants as defaults)
-    consts = {('cuave', 'bimodal_with_val'): dict(num_epoch=None, epochsize=None, batchsize=None, validation_window=None, dim=1500,
-                                                  classes=10, names='0,1,2,3,4,5,6,7,8,9'),
-              ('oulu', 'trimodal_with_val'): dict(num_epoch=12, epochsize=120, batchsize=10, validation_window=4, dim=1144, classes=10,
-                                                  names='p1,p2,p3,p4,p5,p6,p7,p8,p9,p10'),
-              ('avletters', 'trimodal'): dict(num_epoch=25, epochsize=20, batchsize=26, validation_window=4, dim=1200, classes=26,
-                                              names=','.join('abcdefghijklmnopqrstuvwxyz')),
-              ('avletters', 'bimodal'): dict(num_epoch=None, epochsize=20, batchsize=26, validation_window=None, dim=1200, classes=26,
-                                             names=','.join('abcdefghijklmnopqrstuvwxyz'))}[(dataset, script)]
-    num_epoch = cfg.get('training', 'num_epoch', int, consts['num_epoch'])
-    epochsize = cfg.get('training', 'epochsize', int, consts['epochsize'])
-    batchsize = cfg.get('training', 'batchsize', int, consts['batchsize'])
-    validation_window = cfg.get('training', 'validation_window', int, consts['validation_window'])
-    learning_rate = cfg.get('training', 'learning_rate', float)
-    input_dimension = cfg.get('models', 'input_dimension', int, consts['dim'])
-    output_classes = cfg.get('models', 'output_classes', int, consts['classes'])
-    lstm_size = cfg.get('models', 'lstm_size', int, 250)
-    no_coeff = cfg.get('models', 'no_coeff', int, 30)
-    classnames = cfg.get('models', 'output_classnames', str, consts['names']).split(',')
-    WINDOW_SIZE = cfg.get('models', 'delta_window', int, 9)
-    STRIP_SIZE = 3
-
-    # ---- model
+    frames_head, has_test, rule, fusiontype = plan.head == 'frames', plan.has_test, plan.rule, plan.fusiontype
+    num_epoch, epochsize, batchsize, validation_window = plan.num_epoch, plan.epochsize, plan.batchsize, plan.validation_window
+    WINDOW_SIZE, STRIP_SIZE = plan.window, 3
+    classnames = cfg.get('models', 'output_classnames', str, plan.names).split(',') if config.has_section('models') \
+        else plan.names.split(',')
     print('constructing end to end model...')
-    ms = (None, None)
-    if trimodal:
-        decay_rate = cfg.get('training', 'decay_rate', float)
-        decay_start = cfg.get('training', 'decay_start', int)
-        if not cfg.get('training', 'load_finetune', bool, True) or not cfg.get('training', 'load_finetune_diff', bool, True):
-            raise ValueError('load_finetune / load_finetune_diff must be true: the scripts define `ae` / `diff_ae` nowhere else')
-        ae = load_ae(cfg.get('models', 'finetuned'))
-        ae_diff = load_ae(cfg.get('models', 'finetuned_diff'))
-        network, l_fuse = adenet_v3.create_model(ae, ae_diff, (None, None, input_dimension), None, ms, None,
-                                                 (None, None, split['train'][1].shape[1]), None,
-                                                 (None, None, split['train'][2].shape[1]), None, lstm_size, None, output_classes,
-                                                 fusiontype)
-        update = Updater(network, 'adadelta', learning_rate)
-        rule = 'adadelta'
-    elif dataset == 'cuave':
-        weight_init = cfg.get('training', 'weight_init')
-        use_peepholes = cfg.get('training', 'use_peepholes', bool)
-        nonlinearity = select_nonlinearity(cfg.get('models', 'nonlinearity'))
-        cfg.get('training', 'use_blstm', bool); cfg.get('training', 'use_finetuning', bool)      # read (and required) like the script
-        ae = load_dbn(cfg.get('models', 'pretrained'))
-        network, l_fuse = adenet_v2.create_model(ae, (None, None, input_dimension), None, ms, None, (None, None, no_coeff * 3), None,
-                                                 lstm_size, None, output_classes, fusiontype, las_init.select(weight_init),
-                                                 use_peepholes, nonlinearity)
-        update = Updater(network, 'adam', learning_rate)       # (only carries lr for the progress line; see `train` below)
-        rule = 'adam'
-    else:                                            # avletters/bimodal.py
-        rule = cfg.get('training', 'update_rule')
-        decay_rate = cfg.get('training', 'decay_rate', float)
-        decay_start = cfg.get('training', 'decay_start', int)
-        t1 = cfg.get('training', 't1', int)
-        weight_init = cfg.get('training', 'weight_init')
-        use_peepholes = cfg.get('training', 'use_peepholes', bool)
-        use_blstm = cfg.get('training', 'use_blstm', bool)
-        use_finetuning = cfg.get('training', 'use_finetuning', bool)
-        momentum, mm_schedule = 0.9, []
-        if rule in ('sgdm', 'sgdnm'):
-            momentum = cfg.get('training', 'momentum', float)
-            mm_schedule = [float(m) for m in cfg.get('training', 'momentum_schedule').split(',')]
-        dbn = load_ae(cfg.get('models', 'pretrained'))
-        if not isinstance(dbn, (tuple, list)) or len(dbn) == 2:
-            from ..modelzoo._factory import nolearn_weights
-            dbn = nolearn_weights(dbn, nonlinearities=('rectify', 'rectify', 'rectify', 'linear'))
-        factory = adenet_v2 if use_blstm else adenet_v2_3
-        network, l_fuse = factory.create_model(dbn, (None, None, input_dimension), None, ms, None, (None, None, no_coeff * 3), None,
-                                               lstm_size, None, output_classes, fusiontype,
-                                               w_init_fn=las_init.select(weight_init), use_peepholes=use_peepholes)
-        update = Updater(network, rule, learning_rate, momentum)
     print_network(network)
     print('compiling model...')
-    if rule == 'adam' and dataset == 'cuave':        # adam(cost, all_params, learning_rate=learning_rate) (:286)
-        def train(ins, y, m, w):
-            return network.train_step(ins, y, m, w, learning_rate)
-    else:
-        train = update
     compute_train_cost = lambda ins, y, m, w: network.loss(ins, y, m, w, deterministic=False)
     compute_test_cost = lambda ins, y, m, w: network.loss(ins, y, m, w)
     eval_fn = lambda *a: network.predict(list(a[:n_streams]), a[n_streams], a[n_streams + 1])
@@ -378,6 +824,7 @@ def main(dataset, script, argv=None):
     val_window = circular_list(validation_window)
     train_strip = np.zeros((STRIP_SIZE,))
     best_val, best_tr, best_cr, best_conf, test_cr, test_conf, adascale_param = float('inf'), float('inf'), 0.0, None, None, None, None
+    best_params = None
     tr_lens = np.asarray(lens['train'], int)
     tmax_train = int(np.max(tr_lens))
     datagen = gen_lstm_batch_random(split['train'][0], ys['train'], tr_lens, batchsize=batchsize)
@@ -395,10 +842,9 @@ def main(dataset, script, argv=None):
 
     X_val, y_val_evaluate, mask_val = whole_split('val')
     y_val = targets_of(y_val_evaluate, mask_val)
-    has_test = dataset in ('cuave', 'oulu')          # the AVLetters scripts evaluate on their validation (= test) split only
     if has_test:
         X_test, y_test, mask_test = whole_split('test')
-    stop = (lambda w, best: early_stop(w)) if trimodal else (lambda w, best: early_stop2(w, best, validation_window))
+    stop = (lambda w, best: early_stop(w)) if plan.stop == 'early_stop' else (lambda w, best: early_stop2(w, best, validation_window))
 
     for epoch in range(num_epoch):
         time_start = time.time()
@@ -407,15 +853,7 @@ def main(dataset, script, argv=None):
             yy = targets_of(y, m)
             Xs = [X1] + [gen_seq_batch_from_idx(split['train'][s], batch_idxs, tr_lens, integral_lens, tmax_train)
                          for s in range(1, n_streams)]
-            if rule == 'adam' and dataset != 'cuave':
-                msg = 'Epoch {} batch {}/{}: {} examples with {} using default params'.format(epoch + 1, i + 1, epochsize, len(X1), rule)
-            elif rule in ('sgdm', 'sgdnm'):
-                msg = 'Epoch {} batch {}/{}: {} examples at learning rate = {:.4f}, momentum = {:.4f} with {}'.format(
-                    epoch + 1, i + 1, epochsize, len(X1), update.lr, update.mm, rule)
-            else:
-                msg = 'Epoch {} batch {}/{}: {} examples at learning rate = {:.4f}'.format(epoch + 1, i + 1, epochsize, len(X1),
-                                                                                          update.lr)
-            print(msg, end='')
+            print(plan.progress.format(e=epoch + 1, i=i + 1, n=epochsize, b=len(X1), lr=update.lr, mm=update.mm, rule=rule), end='')
             sys.stdout.flush()
             train(Xs, yy, m, WINDOW_SIZE)
             print('\r', end='')
@@ -436,10 +874,12 @@ def main(dataset, script, argv=None):
             if improved:
                 best_val, best_tr, best_conf, best_cr = val_cost, cost, val_conf, cr
                 if fusiontype == 'adasum':
-                    adascale_param = l_fuse.get_all_param_values(scaling_param=True)
+                    adascale_param = plan.l_fuse.get_all_param_values(scaling_param=True)
                 test_cr, test_conf = evaluate(X_test, y_test, mask_test, WINDOW_SIZE, eval_fn)
                 print("Epoch {} train cost = {}, val cost = {}, GL loss = {:.3f}, GQ = {:.3f}, CR = {:.3f}, Test CR= {:.3f} "
                       "({:.1f}sec)".format(epoch + 1, cost_train[-1], cost_val[-1], gl, pq, cr, test_cr, time.time() - time_start))
+                if getattr(plan, 'save_best', None):
+                    best_params = network.get_all_param_values()
             else:
                 print("Epoch {} train cost = {}, val cost = {}, GL loss = {:.3f}, GQ = {:.3f}, CR = {:.3f} ({:.1f}sec)"
                       .format(epoch + 1, cost_train[-1], cost_val[-1], gl, pq, cr, time.time() - time_start))
@@ -450,49 +890,41 @@ def main(dataset, script, argv=None):
             if improved:
                 best_val, best_tr, best_conf, best_cr = val_cost, cost, val_conf, cr
                 if fusiontype == 'adasum':
-                    adascale_param = l_fuse.get_all_param_values(scaling_param=True)
-            elif script == 'bimodal' and epoch >= t1 and rule in ('sgdm', 'sgdnm'):     # avletters/bimodal.py:541-545
-                update.lr = max(update.lr * decay_rate, 0.001)
-                if mm_schedule:
-                    update.mm = mm_schedule.pop(0)
+                    adascale_param = plan.l_fuse.get_all_param_values(scaling_param=True)
+            elif plan.t1_rule and epoch >= plan.t1 and rule in ('sgdm', 'sgdnm'):     # avletters/bimodal.py:541-545
+                update.lr = max(update.lr * plan.decay_rate, 0.001)
+                if plan.mm_schedule:
+                    update.mm = plan.mm_schedule.pop(0)
         if epoch >= validation_window and stop(val_window, best_val):
             break
-        if dataset != 'cuave' and epoch + 1 >= decay_start:      # learning rate decay (oulu/trimodal_with_val.py:508-510)
-            update.lr = float(np.float32(update.lr) * np.float32(decay_rate))
+        if plan.decay and epoch + 1 >= plan.decay_start:         # learning rate decay (oulu/trimodal_with_val.py:508-510)
+            update.lr = float(np.float32(update.lr) * np.float32(plan.decay_rate))
 
     # ---- report
-    if has_test:
-        print('Final Model')
-        print('CR: {}, val loss: {}, Test CR: {}'.format(best_cr, best_val, test_cr))
-    else:
-        print('Best Model')
-        print('classification rate: {}, validation loss: {}'.format(best_cr, best_val))
+    print('Final Model' if has_test else 'Best Model')
+    print(plan.final.format(best_cr=best_cr, best_val=best_val, test_cr=test_cr))
     if fusiontype == 'adasum':
-        if script == 'bimodal':
-            adascale_param = l_fuse.get_all_param_values(scaling_param=True)
+        if getattr(plan, 'adasum_at_end', False):
+            adascale_param = plan.l_fuse.get_all_param_values(scaling_param=True)
         print("final scaling params: {}".format(adascale_param))
     print('confusion matrix: ')
     conf = test_conf if has_test else best_conf
     if not options['no_plot'] and conf is not None:
-        print(plot_confusion_matrix(conf, classnames[:conf.shape[0]], fmt='latex' if script != 'bimodal' else 'pipe'))
+        print(plot_confusion_matrix(conf, classnames[:conf.shape[0]], fmt=plan.conf_fmt))
         try:
-            plot_validation_cost(cost_train, cost_val, savefilename='valid_cost' if has_test else 'e2e_valid_cost')
+            plot_validation_cost(cost_train, cost_val, class_rate if plan.plot_name is None else None, savefilename=plan.plot_name)
         except Exception as e:                        # matplotlib is optional here
             print('(no plot: %s)' % e)
-    if options.get('write_results'):
+    st = dict(best_cr=best_cr, best_val=best_val, best_tr=best_tr, test_cr=test_cr, cost_train=cost_train, cost_val=cost_val,
+              class_rate=class_rate)
+    if options.get('write_results') and plan.results is not None:
         with open(options['write_results'], mode='a') as f:
-            if dataset == 'cuave':                    # cuave/bimodal_with_val.py:376-381
-                f.write('{},{},{},{},{},{},{},{},{},{},{},{}\n'.format(
-                    cfg.get('training', 'use_finetuning', bool), 'yes', use_peepholes, 'adam', weight_init, 'RELU',
-                    cfg.get('training', 'use_blstm', bool), learning_rate, best_tr, best_val, best_cr * 100, test_cr * 100))
-                for series in (cost_train, cost_val, class_rate):
-                    f.write('{}\n'.format(','.join(str(v) for v in series)))
-            elif script == 'bimodal':                 # avletters/bimodal.py:592-606
-                f.write('{},{},{},{},{}\n'.format(validation_window, weight_init, use_peepholes, use_blstm, use_finetuning))
-                for series in (cost_train, cost_val, class_rate):
-                    f.write('{}\n'.format(','.join(str(v) for v in series)))
-                f.write('{},{},{}\n'.format(fusiontype, best_cr, best_val))
-            else:
-                f.write('{},{},{}\n'.format(fusiontype, best_cr, best_val))
-    return dict(best_cr=best_cr, best_val=best_val, test_cr=test_cr, cost_train=cost_train, cost_val=cost_val,
-                class_rate=class_rate, network=network, learning_rate=update.lr, momentum=update.mm)
+            plan.results(f, st)
+    if getattr(plan, 'save_best', None) and best_params is not None:      # cuave/unimodal_with_val.py:364-368
+        from ..utils.io import save_model_params
+        print('Saving the best model so far...')
+        network.set_all_param_values(best_params)
+        save_model_params(network, plan.save_best)
+        print('Model Saved!')
+    st.update(network=network, learning_rate=update.lr, momentum=update.mm)
+    return st

@@ -55,3 +55,146 @@ def test_avletters_trimodal_and_bimodal(tmp_path):
     out = bimodal.main(["--config", bi, "--seed", "1", "--no_plot", "--update_rule", "adadelta", "--learning_rate", "1.0"])
     assert np.isfinite(out["cost_val"]).all()
     out["network"].close()
+
+
+# ----------------------------------------------------------------------------------------------- round 3: the rest of the family
+def test_cuave_unimodal_scripts(tmp_path):
+    """cuave/unimodal_with_val.py (encoder + BLSTM, adam(lr), --save_best) and cuave/unimodal_dct_with_val.py (BLSTM on the DCT
+    features, adam with default parameters)."""
+    from ip_avsr_amd.cuave import unimodal_dct_with_val, unimodal_with_val
+    from ip_avsr_amd.utils.io import load_model_params
+    root = str(tmp_path)
+    res, best = os.path.join(root, "uni.csv"), os.path.join(root, "best.pkl")
+    out = unimodal_with_val.main(["--config", MF.make_cuave_subject(root), "--write_results", res, "--save_best", best, "--seed", "3",
+                                  "--no_plot"])
+    net = out["network"]
+    assert net.head == "frames" and net.S == 1 and "f_blstm1.W_in_to_ingate" in net.param_index
+    assert np.isfinite(out["cost_val"]).all() and out["test_cr"] is not None
+    line = open(res).read().strip().split(",")
+    assert len(line) == 3 and float(line[0]) == out["test_cr"] and float(line[2]) == out["best_val"]
+    saved = net.get_all_param_values()                                  # --save_best restored the best snapshot and pickled it
+    load_model_params(net, best)
+    for a, b in zip(saved, net.get_all_param_values()):
+        np.testing.assert_array_equal(a, b)
+    net.close()
+    dct, _, _ = MF.make_cuave_family(root)
+    out = unimodal_dct_with_val.main(["--config", dct, "--write_results", res + "2", "--seed", "4", "--no_plot"])
+    net = out["network"]
+    assert net.S == 1 and not net.spec["streams"][0]["delta"] and not net.spec["streams"][0]["enc_names"]
+    assert "f_lstm.W_hid_to_cell" in net.param_index and np.isfinite(out["cost_val"]).all()
+    lines = open(res + "2").read().strip().split("\n")
+    assert len(lines) == 4 and lines[0].split(",")[5] == "N/A" and lines[0].split(",")[3] == "adam"
+    net.close()
+
+
+def test_cuave_trimodal_and_audio_visual_runner(tmp_path):
+    from ip_avsr_amd.cuave import audio_visual_runner, trimodal_with_val
+    root = str(tmp_path)
+    _, tri, av = MF.make_cuave_family(root)
+    res = os.path.join(root, "tri.csv")
+    out = trimodal_with_val.main(["--config", tri, "--write_results", res, "--seed", "2", "--no_plot"])
+    net = out["network"]
+    assert net.head == "last" and net.S == 3 and net.spec["fusion"] == "adasum" and net.H == 12
+    n = len(out["cost_val"])
+    assert np.isfinite(out["cost_val"]).all() and abs(out["learning_rate"] - 0.5 ** max(0, n - 1)) < 1e-6
+    line = open(res).read().strip().split(",")
+    assert line[0] == "adasum" and float(line[1]) == out["test_cr"]
+    net.close()
+    res = os.path.join(root, "av.csv")
+    out = audio_visual_runner.main(["--config", av, "--write_results", res, "--seed", "2", "--no_plot"])
+    net = out["network"]
+    assert net.head == "frames" and net.S == 2 and net.spec["fusion"] == "concat"
+    assert [s["input_dim"] for s in net.spec["streams"]] == [MF.D, 14]
+    assert "lstm_visual.W_cell_to_ingate" in net.param_index and "f_lstm_agg.W_cell_to_ingate" not in net.param_index
+    assert "bottleneck_audio.W" in net.param_index and np.isfinite(out["cost_val"]).all()
+    lines = open(res).read().strip().split("\n")
+    assert len(lines) == 4 and lines[0].split(",")[5] == "RELU" and len(lines[0].split(",")) == 12
+    assert min(out["cost_val"]) < out["cost_val"][0] or out["best_cr"] >= 0.5
+    net.close()
+
+
+def test_oulu_unimodal_and_bimodal_with_val(tmp_path):
+    from ip_avsr_amd.oulu import bimodal_with_val, unimodal_with_val
+    uni, bi = MF.make_oulu_family(str(tmp_path))
+    out = unimodal_with_val.main(["--config", uni, "--seed", "1", "--no_plot"])
+    net = out["network"]
+    assert net.S == 1 and net.H == 8 and "f_blstm1.W_cell_to_outgate" in net.param_index       # use_peepholes = True
+    assert np.isfinite(out["cost_val"]).all() and len(out["cost_val"]) <= 4
+    net.close()
+    res = os.path.join(str(tmp_path), "bi.csv")
+    out = bimodal_with_val.main(["--config", bi, "--seed", "1", "--no_plot", "--write_results", res])
+    net = out["network"]
+    assert net.S == 2 and net.spec["fusion"] == "sum" and net.spec["streams"][1]["input_dim"] == MF.DCT
+    assert np.isfinite(out["cost_val"]).all() and open(res).read().startswith("sum,")
+    net.close()
+
+
+def test_avletters_bimodal_diff_image_and_unimodal(tmp_path):
+    from ip_avsr_amd.avletters import bimodal_diff_image, unimodal
+    diff, enc, raw = MF.make_avletters_family(str(tmp_path))
+    res = os.path.join(str(tmp_path), "diff.csv")
+    out = bimodal_diff_image.main(["--config", diff, "--seed", "1", "--no_plot", "--write_results", res])
+    net = out["network"]
+    assert net.head == "last" and net.S == 2 and net.spec["fusion"] == "adasum"
+    assert "lstm_diff.W_cell_to_ingate" in net.param_index                      # the script's CLI default forces peepholes on
+    assert np.isfinite(out["cost_val"]).all() and out["test_cr"] is None
+    n = len(out["cost_val"])
+    assert out["learning_rate"] <= 0.05 * 0.8 ** max(0, n - 1) + 1e-9           # decay from decay_start = 2 (+ the t1 rule)
+    lines = open(res).read().strip().split("\n")
+    assert len(lines) == 5 and lines[0].split(",")[0] == "sgdnm" and lines[-1].startswith("adasum,")
+    net.close()
+    out = bimodal_diff_image.main(["--config", diff, "--seed", "1", "--no_plot", "--update_rule", "adam"])
+    assert np.isfinite(out["cost_val"]).all()
+    out["network"].close()
+    out = unimodal.main(["--config", enc, "--seed", "1", "--no_plot"])
+    net = out["network"]
+    assert net.S == 1 and net.spec["streams"][0]["enc_names"] == ["fc1", "fc2", "fc3", "bottleneck"] and out["test_cr"] is None
+    assert "f_blstm1.b_cell" in net.param_index and np.isfinite(out["cost_val"]).all()
+    net.close()
+    out = unimodal.main(["--config", raw, "--seed", "1", "--no_plot"])
+    net = out["network"]
+    assert not net.spec["streams"][0]["enc_names"] and net.spec["streams"][0]["delta"] and "lstm.W_in_to_cell" in net.param_index
+    net.close()
+
+
+def test_avnet_matches_the_oracle(tmp_path):
+    """create_pretrained_substream x 2 -> create_model (modelzoo/avnet.py:30-114) against the oracle's N-stream graph with
+    the same layer names: probabilities, loss and every gradient, all three fusion types, with and without peepholes."""
+    from oracle import adenet_oracle as O
+    from ip_avsr_amd.modelzoo import avnet
+    rng = np.random.default_rng(7)
+    Dv, Da, H, C, B, T, theta = 24, 14, 10, 4, 5, 9, 2
+    shapes = (16, 12, 8, 5)
+    lens = rng.integers(3, T + 1, size=B); lens[0] = T
+    mask = (np.arange(T)[None, :] < lens[:, None]).astype(np.uint8)
+    xs = [(rng.normal(size=(B, T, d)) * mask[..., None]).astype(np.float32) for d in (Dv, Da)]
+    y = np.repeat(rng.integers(0, C, size=(B, 1)), T, axis=1).astype(np.int32)
+    for fusion, peep in (("concat", True), ("adasum", False), ("sum", True)):
+        spec = O.spec_nstream([Dv, Da], enc_shapes=shapes, enc_acts=("sigmoid", "sigmoid", "sigmoid", "linear"), lstm_size=H,
+                              classes=C, fusion=fusion, peepholes=peep)
+        for s, name in zip(spec["streams"], ("visual", "audio")):           # avnet's layer names
+            s["enc_names"] = ["%s_%s" % (n, name) for n in ("fc1", "fc2", "fc3", "bottleneck")]
+            s["lstm_names"] = ["lstm_" + name]
+        p = O.init_params(spec, rng, np.float64, enc_std=0.3, perturb=0.1)
+        subs = []
+        for s, d, name in zip(spec["streams"], (Dv, Da), ("visual", "audio")):
+            ws = [p[n + ".W"].astype(np.float32) for n in s["enc_names"]]
+            bs = [p[n + ".b"].astype(np.float32) for n in s["enc_names"]]
+            subs.append(avnet.create_pretrained_substream(ws, bs, (None, None, d), None, (None, None), None, name, H, None,
+                                                          "sigmoid", "glorot", peep))
+        net, l_fuse = avnet.create_model(subs, (None, None), None, H, C, fusion, "glorot", peep)
+        assert [q.name for q in net.params] == O.param_names(spec)
+        net.set_params_dict({k: v.astype(np.float32) for k, v in p.items()})
+        x64 = [x.astype(np.float64) for x in xs]
+        ref = O.forward(spec, p, x64, mask, theta)
+        np.testing.assert_allclose(net.predict(xs, mask, theta), ref, atol=2e-5)
+        l_ref, g_ref, _ = O.loss_and_grads(spec, p, x64, y, mask, theta)
+        l = net.compute_grads(xs, y, mask, theta)
+        assert abs(l - l_ref) < 1e-5 * abs(l_ref)
+        g = net.get_grads_dict()
+        for k in g_ref:
+            scale = max(1e-6, np.abs(g_ref[k]).max())
+            assert np.abs(g[k] - g_ref[k]).max() <= 1e-4 * scale + 1e-7, (fusion, k)
+        if fusion == "adasum":
+            assert np.allclose(np.ravel(l_fuse.get_all_param_values(scaling_param=True)), [p["adasum1.adacoeff0"], p["adasum1.adacoeff1"]])
+        net.close()

@@ -103,3 +103,73 @@ def test_load_ae_accepts_mat_and_pickle(tmp_path):
     b = modal.load_ae(MF._ae(rng, str(tmp_path), "b.pkl", as_pickle=True))
     for w, bias in (a, b):
         assert [x.shape for x in w] == [(24, 16), (16, 12), (12, 8), (8, 5)] and [x.shape for x in bias] == [(16,), (12,), (8,), (5,)]
+
+
+# ----------------------------------------------------------------------------------------------- round 3: the rest of the family
+def test_every_reference_script_of_the_family_has_a_plan_and_an_entry_point():
+    import importlib
+    assert set(modal.SCRIPTS) == set(modal._PLANS)
+    for ds, sc in modal.SCRIPTS:
+        mod = importlib.import_module("ip_avsr_amd.%s.%s" % (ds, sc))
+        assert callable(mod.main)
+    assert modal.SCRIPTS[("cuave", "audio_visual_runner")] == "config/avnet.ini"
+    assert modal.SCRIPTS[("avletters", "unimodal")] == "config/normal.ini"
+    with pytest.raises(ValueError):
+        modal.main("cuave", "no_such_script", [])
+
+
+def test_key_aliases_of_the_scripts(tmp_path):
+    uni, bi = MF.make_oulu_family(str(tmp_path))
+    cfg = _cfg(uni, ["--no_epochs", "9"])
+    assert cfg.get("training", ("num_epoch", "no_epochs"), int) == 9                    # CLI wins, under either spelling
+    assert cfg.get("models", ("lstm_size", "lstm_units"), int) == 8
+    cfg = _cfg(bi)
+    assert cfg.get("models", ("no_coeffs", "no_coeff"), int) == MF.DCT and cfg.get("training", ("num_epoch", "no_epochs"), int) == 3
+
+
+def test_cuave_subject_unimodal_loader(tmp_path):
+    """cuave/unimodal_with_val.py:201-244: subjects 1-5 / 6-7 / 8, targets + 1, per-frame z-normalised, per-sequence mean
+    removed (so every utterance's frames sum to ~0 BEFORE the z-normalisation; after it each frame has zero mean)."""
+    cfg = _cfg(MF.make_cuave_subject(str(tmp_path)))
+    split, ys, lens = modal._load_cuave_subject_unimodal(cfg)
+    assert [len(lens[k]) for k in ("train", "val", "test")] == [30, 12, 6]
+    assert set(np.unique(ys["train"])) == set(range(MF.CLASSES))
+    for k in split:
+        (X,) = split[k]
+        assert X.shape == (int(np.sum(lens[k])), MF.D) and np.allclose(X.mean(1), 0, atol=1e-5) and np.allclose(X.std(1), 1, atol=1e-3)
+
+
+def test_cuave_family_loaders(tmp_path):
+    dct, tri, av = MF.make_cuave_family(str(tmp_path))
+    split, ys, lens = modal._load_cuave_dct(_cfg(dct))
+    assert len(split["train"]) == 1 and split["train"][0].shape == (int(lens["train"].sum()), MF.DCT)
+    assert np.allclose(split["train"][0].mean(0), 0, atol=1e-5) and set(ys["val"]) == set(range(MF.CLASSES))
+    split, ys, lens = modal._load_cuave_trimodal(_cfg(tri))
+    raw, d, diff = split["test"]
+    assert raw.shape == diff.shape and d.shape[1] == MF.DCT and np.array_equal(diff[0], diff[1])
+    assert abs(raw.mean(1)).max() > 1e-3                                                # raw frames as stored: NOT normalised
+    l0 = int(lens["test"][0])
+    assert np.allclose(diff[1:l0], raw[1:l0] - raw[:l0 - 1])
+    split, ys, lens = modal._load_cuave_av(_cfg(av))
+    vis, aud = split["train"]
+    assert vis.shape == (int(lens["train"].sum()), MF.D) and aud.shape == (int(lens["train"].sum()), 14)
+    stored = MF.sio.loadmat(str(tmp_path / "cuave.mat"))["trData"].astype("float32")
+    assert np.array_equal(vis, stored.reshape(-1, 6, 4).transpose(0, 2, 1).reshape(-1, 24))   # F -> C pixel order, nothing else
+
+
+def test_oulu_and_avletters_family_loaders(tmp_path):
+    uni, bi = MF.make_oulu_family(str(tmp_path))
+    split, ys, lens = modal._load_oulu(_cfg(uni), with_dct=False)
+    assert [len(lens[k]) for k in ("train", "val", "test")] == [30, 12, 6] and len(split["val"]) == 1
+    split, ys, lens = modal._load_oulu(_cfg(bi), with_dct=True)
+    assert np.allclose(split["train"][0].mean(1), 0, atol=1e-5) and np.allclose(split["train"][1].mean(0), 0, atol=1e-5)
+    diff, enc, raw = MF.make_avletters_family(str(tmp_path))
+    split, ys, lens = modal._load_avletters_diff(_cfg(diff))
+    assert len(split["train"]) == 2 and len(lens["train"]) == 32 and len(lens["test"]) == 16 and split["val"] is split["test"]
+    config = configparser.ConfigParser(); config.read(raw)
+    split, ys, lens = modal._load_avletters_stream1(config)
+    assert set(np.unique(ys["train"])) == set(range(MF.CLASSES))                        # matlab_target_offset removed the 1
+    assert np.allclose(split["train"][0].mean(0), 0, atol=1e-4)                         # featurewisenormalize, train statistics
+    config = configparser.ConfigParser(); config.read(enc)
+    split2, _, _ = modal._load_avletters_stream1(config)
+    assert np.allclose(split2["train"][0].mean(1), 0, atol=1e-5)                        # samplewisenormalize only

@@ -100,3 +100,40 @@ def test_adenet_v1_and_v1_1_parameter_lists(spec_only):
     spec11 = adenet_v1_1.create_model(*args(), lstm_size=4, output_classes=3)
     assert F.param_names(spec11) == want and spec11["stream_lstm_size"] == 8
     assert spec11["streams"][0]["dropout"] == 0.5 and spec11["agg_dropout"] == 0.5
+
+
+def test_avnet_substreams_parameter_list_and_activations(spec_only):
+    """modelzoo/avnet.py:30-114: ``create_pretrained_substream`` names its layers fc1_<name> .. bottleneck_<name> /
+    lstm_<name> (:45-48,58-66), uses [nonlinearity] * 3 + [linear] (:47), passes ``peepholes=use_peepholes`` to the stream
+    LSTM; ``create_model`` fuses the substreams in list order, its BLSTM comes from create_blstm WITHOUT the peephole
+    argument (custom/layers.py:55: default False), the classifier is 'softmax'.  get_all_params order = depth first
+    through the fusion layer's inputs."""
+    from ip_avsr_amd.modelzoo import avnet
+    w = lambda d: ([np.zeros((a, b), np.float32) for a, b in zip([d, 20, 12, 8], [20, 12, 8, 5])],
+                   [np.zeros(b, np.float32) for b in (20, 12, 8, 5)])
+    vw, vb = w(30)
+    aw, ab = w(14)
+    for fusion, peep in (("adasum", True), ("concat", False), ("sum", True)):
+        vis = avnet.create_pretrained_substream(vw, vb, (None, None, 30), None, (None, None), None, 'visual', 6, None, 'sigmoid',
+                                                'glorot', peep)
+        aud = avnet.create_pretrained_substream(aw, ab, (None, None, 14), None, (None, None), None, 'audio', 6, None, 'sigmoid',
+                                                'glorot', peep)
+        assert vis["enc_acts"] == ["sigmoid", "sigmoid", "sigmoid", "linear"] and aud["input_dim"] == 14 and vis["delta"]
+        spec, _ = avnet.create_model([vis, aud], (None, None), None, 6, 3, fusion, 'glorot', peep)
+        want = (enc("_visual") + lstm("lstm_visual", peep) + enc("_audio") + lstm("lstm_audio", peep) +
+                (["adasum1.adacoeff0", "adasum1.adacoeff1"] if fusion == "adasum" else []) +
+                lstm("f_lstm_agg", False) + lstm("b_lstm_agg", False) + ["softmax.W", "softmax.b"])
+        assert F.param_names(spec) == want
+        assert spec["fusion"] == fusion and spec["fuse_name"] == {"adasum": "adasum1", "concat": "concat", "sum": "sum1"}[fusion]
+        assert spec["lstm_size"] == 6 and spec["classes"] == 3 and spec.get("head", "frames") == "frames"
+
+
+def test_unimodal_scripts_encoder_factory(spec_only):
+    """``deltanet_majority_vote.create_model_using_pretrained_encoder`` as cuave/unimodal_with_val.py:259-263 calls it."""
+    from ip_avsr_amd.modelzoo import deltanet_majority_vote as dmv
+    ws = [np.zeros((a, b), np.float32) for a, b in zip([30, 20, 12, 8], [20, 12, 8, 5])]
+    bs = [np.zeros(b, np.float32) for b in (20, 12, 8, 5)]
+    spec = dmv.create_model_using_pretrained_encoder(ws, bs, (None, None, 30), None, (None, None), None, 6, None, 4, 'glorot', True,
+                                                     'sigmoid')
+    assert F.param_names(spec) == enc("") + lstm("f_blstm1") + lstm("b_blstm1") + ["softmax.W", "softmax.b"]
+    assert spec["streams"][0]["enc_acts"] == ["sigmoid", "sigmoid", "sigmoid", "linear"] and spec["fusion"] == "none"
