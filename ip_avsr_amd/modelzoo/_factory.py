@@ -134,6 +134,19 @@ def param_names(spec):
 # set by tests that only need the graph description of a zoo module (no device, no libadenet_hip.so)
 SPEC_ONLY = False
 
+# arithmetic of the models the factories build ('f32' | 'bf16x3' | 'bf16', include/adenet.h adn_precision).  The reference is
+# fp32 throughout (floatX = float32); the drivers' ``--precision`` option / the ADN_PRECISION environment variable set this
+# before they call ``create_model`` (whose reference signature has no room for it).
+import os as _os
+DEFAULT_PRECISION = _os.environ.get("ADN_PRECISION", "f32")
+
+
+def set_default_precision(precision):
+    global DEFAULT_PRECISION
+    if precision not in ("f32", "bf16x3", "bf16"):
+        raise ValueError("precision must be f32, bf16x3 or bf16 (got %r)" % (precision,))
+    DEFAULT_PRECISION = precision
+
 
 def build(streams, lstm_size, output_classes, fusiontype, fuse_names, agg_names, agg_peepholes, w_init_fn,
           softmax_name="softmax", return_fuse=True, head="frames", agg_dropout=0.0, stream_lstm_size=None):
@@ -146,7 +159,7 @@ def build(streams, lstm_size, output_classes, fusiontype, fuse_names, agg_names,
         head=head, agg_dropout=float(agg_dropout), stream_lstm_size=int(stream_lstm_size or lstm_size),
         fusion=fusiontype, fuse_name=fuse_names.get(fusiontype, ""), agg_names=list(agg_names),
         agg_peepholes=bool(agg_peepholes), lstm_size=int(lstm_size), classes=int(output_classes),
-        softmax_name=softmax_name)
+        softmax_name=softmax_name, precision=DEFAULT_PRECISION)
     if SPEC_ONLY:
         return (spec, None) if return_fuse else spec
     model = AdeNetModel(spec)

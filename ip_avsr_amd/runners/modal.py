@@ -47,6 +47,7 @@ differs, on purpose:
 from __future__ import print_function
 
 import argparse
+import os
 import configparser
 import pickle
 import sys
@@ -130,8 +131,11 @@ def parse_options(argv, default_config):
     parser.add_argument('--no_plot', dest='no_plot', action='store_true', help='disable plots')
     parser.add_argument('--seed', type=int, default=None, help='seed for initialisers, dropout and minibatch order '
                                                                '(the reference never seeds)')
+    parser.add_argument('--precision', default=None, choices=['f32', 'bf16x3', 'bf16'],
+                        help='arithmetic of the model (default f32 = the reference); also ADN_PRECISION')
     args = parser.parse_args(argv)
-    options = {'config': args.config or default_config, 'no_plot': bool(args.no_plot), 'seed': args.seed}
+    options = {'config': args.config or default_config, 'no_plot': bool(args.no_plot), 'seed': args.seed,
+               'precision': args.precision}
     for key in ('write_results', 'update_rule', 'learning_rate', 'decay_rate', 'momentum', 'momentum_schedule',
                 'validation_window', 't1', 'weight_init', 'num_epoch', 'no_epochs', 'epochsize', 'batchsize', 'save_best'):
         if getattr(args, key):
@@ -801,6 +805,8 @@ def main(dataset, script, argv=None):
     for sec in (('stream1', 'lstm_classifier', 'training') if config.has_section('stream1') else ('data', 'models', 'training')):
         print(config.items(sec))
     print('preprocessing dataset...')
+    from ..modelzoo import _factory
+    _factory.set_default_precision(options.get('precision') or os.environ.get('ADN_PRECISION', 'f32'))
     plan = _PLANS[(dataset, script)](cfg, config, options)
     network, update, train = plan.network, plan.update, plan.train
     split, ys, lens = plan.split, plan.ys, plan.lens

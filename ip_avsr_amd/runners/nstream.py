@@ -107,8 +107,11 @@ def parse_options(argv=None):
                              'must diverge, runners/1stream_variable_lr.py:327-333)')
     parser.add_argument('--seed', type=int, default=None, help='seed for initialisers and minibatch order '
                                                                '(the reference never seeds; required >1 GPU)')
+    parser.add_argument('--precision', default=None, choices=['f32', 'bf16x3', 'bf16'],
+                        help='arithmetic of the model (default f32 = the reference; bf16x3 = fp32-grade products on the bf16 '
+                             'matrix pipe, meets the 1e-4 parity gate; bf16 = fastest); also ADN_PRECISION')
     args = parser.parse_args(argv)
-    options = {'config': args.config or 'config/bimodal_meanrm_raw_diff.ini'}
+    options = {'config': args.config or 'config/bimodal_meanrm_raw_diff.ini', 'precision': args.precision}
     for key in ('write_results', 'save_best', 'save_plot'):
         if getattr(args, key):
             options[key] = getattr(args, key)
@@ -285,6 +288,8 @@ def main(n_streams, argv=None, variant=None):
                 lens = dict(train=parts[2], val=parts[6], test=parts[10])
 
     say('constructing end to end model...')
+    from ..modelzoo import _factory
+    _factory.set_default_precision(options.get('precision') or os.environ.get('ADN_PRECISION', 'f32'))
     if variant == 'noencoder':           # runners/1stream_noencoder.py:233-236
         network, l_fuse = deltanet_v1.create_model((None, None, dims[0]), None, (None, None), None, None, cfg['lstm_size'],
                                                    cfg['output_classes'], cfg['weight_init_fn'], cfg['use_peepholes']), None
@@ -443,4 +448,5 @@ def main(n_streams, argv=None, variant=None):
     if dist is not None:
         dist.destroy_process_group()
     return dict(best_cr=best_cr, best_val=best_val, test_cr=test_cr, cost_train=cost_train, cost_val=cost_val,
-                class_rate=class_rate, network=network)
+                class_rate=class_rate, network=network, windowsize=windowsize,
+                heldout=dict(X_val=X_val, y_val=y_val_evaluate, mask_val=mask_val, X_test=X_test, y_test=y_test, mask_test=mask_test))

@@ -145,6 +145,32 @@ def test_bf16_against_the_fp64_oracle_on_a_26_utterance_slice(runs):
     frame_agree = float(((got.argmax(-1) == ref.argmax(-1)) | (mask == 0)).mean())
     print("bf16 vs fp64 oracle at the bench geometry: max |dp| = %.2e, majority-vote agreement %.3f, per-frame top-1 %.4f"
           % (err, agree, frame_agree))
-    assert err <= 5e-3                                   # measured 3.2e-4
+    assert err <= 1e-3                                   # measured 3.2e-4
     assert agree == 1.0                                  # measured: all 26 majority votes identical
     assert frame_agree >= 0.995                          # measured: every valid frame's top-1 identical
+
+
+def test_bf16_gradients_against_the_fp64_oracle_at_the_reference_minibatch(runs):
+    """The b26 run (bench model, the reference's 26 utterances x 40 frames, bf16 mode: grouped register-staged GEMMs,
+    weight-stationary LSTM launches) against the ORACLE's gradients for the same parameters and batch -- not against another
+    HIP path: every kept gradient tensor by cosine and relative L2 distance.  Measured: relative L2 0.4 % at the recurrent
+    and classifier tensors, 0.9 % at the bottleneck, 1.9 % at fc2, 4.1 % at fc1 (every encoder layer re-rounds the gradient it
+    passes down to bf16; fc1 sits below four of them and the delta layer), cosine 0.99916 (fc1) ... 0.99999.  The bounds:
+    5 % relative L2 everywhere, i.e. cosine >= 1 - 0.05^2 / 2; >= 0.9995 above the first encoder layer."""
+    r = runs["b26"]
+    spec = O.spec_nstream([1200, 1200, 1200])
+    p64 = {k[2:]: v.astype(np.float64) for k, v in r.items() if k.startswith("p_")}
+    mask = r["mask"]
+    assert mask.shape == (26, 40)
+    xs = [r["x%d" % k].astype(np.float64) for k in range(3)]
+    y = np.repeat((np.arange(26) % 26)[:, None], 40, axis=1).astype(np.int32)      # bench.synthetic_batch: labels i mod 26
+    loss, g_ref, _ = O.loss_and_grads(spec, p64, xs, y, mask, 9)
+    assert abs(float(r["loss"]) - loss) <= 1e-3 * abs(loss)
+    worst = {}
+    for k in r:
+        if k.startswith("g_"):
+            a, b = r[k].astype(np.float64).ravel(), g_ref[k[2:]].ravel()
+            worst[k[2:]] = (round(float(np.linalg.norm(a - b) / np.linalg.norm(b)), 5), round(float(a @ b / np.sqrt((a @ a) * (b @ b))), 6))
+    print("bf16 vs fp64 oracle gradients at B = 26 (relative L2, cosine):", worst)
+    for k, (rel, cos) in worst.items():
+        assert rel <= 0.05 and cos >= (0.9987 if k.startswith("fc1") else 0.9995), (k, rel, cos)
