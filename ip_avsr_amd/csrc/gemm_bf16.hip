@@ -641,6 +641,13 @@ __device__ __forceinline__ GemmGroup pick_group(const GemmParams& p, int g) {
     return r;
 }
 
+// a wave-uniform pointer the compiler may have parked in VGPRs, back in an SGPR pair (asm "s" operands)
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N >= 0 && N <= 63, "vmcnt immediate");
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
@@ -1003,6 +1010,381 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
     if (!late && !one) __builtin_amdgcn_s_barrier();               // every wave executes the same number of barriers
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Four-wave variant of the LDS-DMA kernel (round 3): the same 256 x 256 tile, ring, DMA images, swizzles, tail and
+// epilogue conventions as gemm_bf16_pp_kernel above, but ONE wave per SIMD with a 128 x 128 wave tile (8 x 8 MFMA tiles:
+// 64 MFMAs per K-step of 32 against 16 A + 16 B fragment registers, i.e. 0.25 (NN) .. 0.375 (TN) LDS reads per MFMA where
+// the eight-wave kernel's 64 x 128 wave tile needs 0.625 .. 0.75), the accumulators in the AGPR half of the 512-entry
+// register file, and the overlap of LDS traffic with the matrix pipe done INSIDE the wave instead of between two waves of
+// a SIMD: the fragments of stage s + 1 are read into a second register set while the MFMAs of stage s issue
+// (MI355X_MICROARCH.md: a single wave per SIMD issues 1-2 LDS reads per MFMA gap at <= 3 cycles per gap, whereas two
+// waves per SIMD pay ~20 cycles of issue per LDS / DMA instruction while the partner holds the vector issue port with
+// MFMAs -- the eight-wave kernel's in-kernel stamps: reads + DMA issue + waits ~1150 cycles next to 540 of MFMA per wave).
+//
+// One K-step of one wave:
+//     wait (own DMA pieces of stage s + 1)  |  s_barrier  |  DMA issue for stage s + 3  |  fragment reads of stage s + 1 ->
+//     set (s + 1) & 1, interleaved by the compiler with the 64 MFMAs on set s & 1  |  (tile epilogue after the last K-step)
+// Hazards (barrier #s = the one at the top of step s):
+//   RAW  stage s + 1 is read after barrier #s; every wave waited for its own pieces of it before that barrier.
+//   WAR  stage s + 3 overwrites the slot of stage s - 1, whose fragment reads were issued in step s - 2 and consumed by the
+//        MFMAs of step s - 1 -- issued by every wave before it reached barrier #s.
+// The epilogue's stores sit in the in-order vmcnt queue behind the DMA groups the next wait needs: the first wait after an
+// epilogue is vmcnt(0) (once per tile).  The step body exists twice (even / odd register set).
+// ---------------------------------------------------------------------------------------------------------
+// MFMAs of the four-wave kernel as inline assembly with the accumulator pinned to the AGPR file ("a" constraint): left to
+// hipcc, a 256-register accumulator block next to 128 fragment registers ends up shuttled between VGPRs, AGPRs and scratch
+// inside the K-loop (the first build of this kernel: 577 - 790 spilled registers, v_accvgpr_write ahead of every MFMA).
+// The statements are volatile, so their order -- and their position relative to the DMA issue and the waits -- is the
+// source order; the compiler still places the (non-volatile) LDS fragment reads among them.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mfma_acc(f32x4& c, const bf16x8& x, const bf16x8& y) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(__builtin_bit_cast(u32x4_t, x)), "v"(__builtin_bit_cast(u32x4_t, y)));
+}
+// first K-step of a tile: C = 0 -- a fresh definition of the accumulator (the kernel peels that step out of the K-loop, so
+// the value never has to be merged with the previous tile's)
+__device__ __forceinline__ void mfma_first(f32x4& c, const bf16x8& x, const bf16x8& y) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(__builtin_bit_cast(u32x4_t, x)), "v"(__builtin_bit_cast(u32x4_t, y)));
+}
+
+// LDS fragment reads of the four-wave kernel as volatile inline assembly: they stay exactly where the source puts them (between
+// the MFMAs) and the compiler's wait-count pass does not see them -- the kernel counts lgkmcnt by hand.
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+template <int OFF> __device__ __forceinline__ void lds_read_b128(bf16x8& dst, unsigned addr) {
+    u32x4_t r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    dst = __builtin_bit_cast(bf16x8, r);
+}
+// one 16 x 32 fragment of a k-strided image: two transposing reads (k-rows 0-3 | 8-11 ... and 4-7 | 12-15 ...: HALF bytes apart)
+template <int HALF> __device__ __forceinline__ void lds_read_tr_frag(bf16x8& dst, unsigned addr) {
+    u32x2_t lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(addr));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(HALF));
+    dst = __builtin_bit_cast(bf16x8, (u32x4_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3));
+}
+template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
+    static_assert(N >= 0 && N <= 15, "lgkmcnt immediate");
+    asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory");
+}
+
+template <bool A_KC, bool SPLIT>
+__global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(const GemmParams p) {
+    constexpr int BM = 256, BN = 256, BK = kPpBK, NS = 4, D = 3;
+    constexpr int WTM = 128, WTN = 128, TM = WTM / 16, TN = WTN / 16;
+    constexpr int kAElems = BM * BK, kBElems = BK * BN, kStageElems = kAElems + kBElems;
+    constexpr int APW = BM / 64, BPW = BN / 64, PW = APW + BPW;          // 1-KiB DMA pieces per wave and stage
+    __shared__ __attribute__((aligned(1024))) __bf16 smem[NS * kStageElems];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int per_group = p.tiles_m * p.tiles_n;
+    const int ntiles = per_group * p.ngroups;
+    const int G = (int)gridDim.x;
+    int bid = (int)blockIdx.x, slice = (int)blockIdx.y;
+    if (SPLIT && p.xcd_slices) {                                   // (see gemm_bf16_pp_kernel)
+        const int S = (int)gridDim.y, lin = (int)blockIdx.y * G + (int)blockIdx.x, xcd = lin & 7, q = lin >> 3;
+        if (S >= 8) { const int m_ = S >> 3; slice = xcd * m_ + q % m_; bid = q / m_; }
+        else { const int d_ = 8 / S; slice = xcd % S; bid = q * d_ + xcd / S; }
+    }
+    const int my_tiles = (ntiles - bid + G - 1) / G;
+    const int kbeg = slice * p.k_chunk;
+    const int kend = min(p.K, kbeg + p.k_chunk);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    const int ktail = (kend - kbeg) - (nk - 1) * BK;
+    const bool has_tail = ktail < BK;
+    const int total = my_tiles * nk;
+    if (total <= 0) return;
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_void_t*)smem;
+
+    // ---- DMA side (as in the eight-wave kernel, four pieces per operand and wave) ------------------------
+    constexpr int A_CPR = BM / 8, B_CPR = BN / 8;
+    const char* baseA = nullptr; const char* baseB = nullptr;
+    unsigned offA[APW], offB[BPW];
+    int a_aux[APW], b_row[BPW];
+#pragma unroll
+    for (int t = 0; t < APW; ++t)
+        a_aux[t] = A_KC ? ((lane & 3) ^ swz_f((lane >> 4) & 3)) * 8 : (64 / A_CPR) * (wave * APW + t) + lane / A_CPR;
+#pragma unroll
+    for (int t = 0; t < BPW; ++t) b_row[t] = (64 / B_CPR) * (wave * BPW + t) + lane / B_CPR;
+    auto tile_of = [&](int ord, int& grp, int& tm, int& tn) {
+        const int q = xcd_tile(bid + ord * G, ntiles);
+        grp = q / per_group;
+        tile_coords(p, q - grp * per_group, tm, tn);
+    };
+    auto setup_src = [&](int ord) {
+        int grp, tm, tn;
+        tile_of(ord, grp, tm, tn);
+        const GemmGroup sg = pick_group(p, grp);
+        const char* A16 = reinterpret_cast<const char*>(sg.A16);
+        const char* B16 = reinterpret_cast<const char*>(sg.B16);
+        const int m0 = tm * BM, n0 = tn * BN;
+        baseA = A_KC ? A16 + ((size_t)m0 * p.lda + kbeg) * 2 : A16 + (size_t)kbeg * p.lda * 2;
+        baseB = B16 + (size_t)kbeg * p.ldb * 2;
+#pragma unroll
+        for (int t = 0; t < APW; ++t) {
+            if (A_KC) {
+                const int row = min(m0 + 16 * (wave * APW + t) + (lane >> 2), p.M - 1) - m0;
+                offA[t] = (unsigned)(row * p.lda + a_aux[t]) * 2u;
+            } else {
+                int col = m0 + (((lane % A_CPR) ^ (swz_g(a_aux[t]) << 1)) * 8);
+                if (col + 8 > p.lda) col = 0;
+                offA[t] = (unsigned)(a_aux[t] * p.lda + col) * 2u;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < BPW; ++t) {
+            int col = n0 + (((lane % B_CPR) ^ (swz_g(b_row[t]) << 1)) * 8);
+            if (col + 8 > p.ldb) col = 0;
+            offB[t] = (unsigned)(b_row[t] * p.ldb + col) * 2u;
+        }
+    };
+    const size_t a_step = A_KC ? (size_t)BK * 2 : (size_t)BK * p.lda * 2;
+    const size_t b_step = (size_t)BK * p.ldb * 2;
+    const unsigned dstA_w = __builtin_amdgcn_readfirstlane(lds_base + wave * APW * 1024);
+    const unsigned dstB_w = __builtin_amdgcn_readfirstlane(lds_base + NS * kAElems * 2 + wave * BPW * 1024);
+    int is_k = 0, is_ord = 0, is_slot = 0;
+    auto issue_one = [&](auto tail_c) {
+        constexpr bool tail = decltype(tail_c)::value;
+        const unsigned dA = dstA_w + (unsigned)(is_slot * kAElems * 2);
+        const unsigned dB = dstB_w + (unsigned)(is_slot * kBElems * 2);
+        const int k0 = kbeg + is_k * BK;
+        const char* uA = uniform_ptr(baseA); const char* uB = uniform_ptr(baseB);
+#pragma unroll
+        for (int t = 0; t < APW; ++t) {
+            if (tail) {
+                const char* g = baseA + offA[t];
+                if (A_KC) { if (k0 + a_aux[t] >= kend) g -= (size_t)(k0 + a_aux[t] - (kend - 8)) * 2; }
+                else if (k0 + a_aux[t] >= kend) g -= (size_t)(k0 + a_aux[t] - (kend - 1)) * p.lda * 2;
+                glds16(g, __builtin_amdgcn_readfirstlane(dA + t * 1024));
+            } else {
+                glds16_s<0>(offA[t], uA, __builtin_amdgcn_readfirstlane(dA + t * 1024));
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < BPW; ++t) {
+            if (tail) {
+                const char* g = baseB + offB[t];
+                if (k0 + b_row[t] >= kend) g -= (size_t)(k0 + b_row[t] - (kend - 1)) * p.ldb * 2;
+                glds16(g, __builtin_amdgcn_readfirstlane(dB + t * 1024));
+            } else {
+                glds16_s<0>(offB[t], uB, __builtin_amdgcn_readfirstlane(dB + t * 1024));
+            }
+        }
+        baseA += a_step; baseB += b_step;
+    };
+    auto issue_next = [&]() {
+        if (has_tail && is_k == nk - 1) issue_one(std::true_type{});
+        else issue_one(std::false_type{});
+        if (++is_slot == NS) is_slot = 0;
+        if (++is_k == nk) {
+            is_k = 0;
+            if (++is_ord < my_tiles) setup_src(is_ord);
+        }
+    };
+
+    // ---- per-lane fragment addresses inside ring slot 0 ---------------------------------------------------
+    const int q = (lane & 15) >> 2, pp = lane & 3, hi = lane >> 4;
+    const int g_lane = q | ((hi & 1) << 2);
+    unsigned a_off[TM], b_off[TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        if (A_KC) a_off[a] = lds_base + (wm * WTM + a * 16 + (lane & 15)) * 64 + ((hi ^ swz_f(q)) << 4);
+        else a_off[a] = lds_base + (hi * 8 + q) * (BM * 2) + ((((wm * WTM + a * 16) / 8 + (pp >> 1)) ^ (g_lane << 1)) << 4) + (pp & 1) * 8;
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+        b_off[b] = lds_base + NS * kAElems * 2 + (hi * 8 + q) * (BN * 2) + ((((wn * WTN + b * 16) / 8 + (pp >> 1)) ^ (g_lane << 1)) << 4) + (pp & 1) * 8;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 amask;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        amask[j] = ((8 * hi + 2 * j < ktail) ? 0x0000FFFFu : 0u) | ((8 * hi + 2 * j + 1 < ktail) ? 0xFFFF0000u : 0u);
+
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    typedef __attribute__((address_space(3))) bf16x8 lds_bf16x8;
+    f32x4 acc[TM][TN];                                             // AGPRs; written by the asm MFMAs only (first K-step: C = 0)
+
+    // own pieces of stage s + 1 landed?  (called at the top of step s, BEFORE the DMA issue of that step: the youngest stage
+    // this wave has issued is s + 2)
+    auto wait_next = [&](int s, bool fresh_epi) {
+        if (s + 1 >= total) return;
+        if (fresh_epi || s + 2 >= total) wait_vmcnt<0>();
+        else wait_vmcnt<PW>();
+    };
+    // ---- fragments: ONE register set (64 VGPRs), refilled for stage s + 1 as the MFMAs of stage s retire their last use.
+    // The 8 x 8 MFMA grid of a K-step runs as two halves: columns 0-3 (all rows), then columns 4-7 (all rows).
+    //   fb[0..3] are free after the first half   -> refilled at the start of the second half
+    //   fa[a]    is free after row a of the second half -> refilled there
+    //   fb[4..7] are free after the last row's last four MFMAs -> refilled there; first used 32 MFMAs into the next K-step
+    // so every read has >= ~450 cycles before its first use.  The barrier of a K-step (and its DMA issue) sits between the
+    // halves: stage s + 1 is only read behind it, stage s + 3 only written behind it.
+    bf16x8 fa[TM], fb[TN];
+    unsigned a_cur = 0, b_cur = 0;                                 // byte offsets of the ring slot the next refills read
+    auto refill_a = [&](auto a_c) __attribute__((always_inline)) {
+        constexpr int a = decltype(a_c)::value;
+        if (A_KC) lds_read_b128<0>(fa[a], a_off[a] + a_cur);
+        else lds_read_tr_frag<4 * (BM * 2)>(fa[a], a_off[a] + a_cur);
+    };
+    auto refill_b = [&](auto b_c) __attribute__((always_inline)) {
+        constexpr int b = decltype(b_c)::value;
+        lds_read_tr_frag<4 * (BN * 2)>(fb[b], b_off[b] + b_cur);
+    };
+#define W4_EACH8(F) F(std::integral_constant<int, 0>{}); F(std::integral_constant<int, 1>{}); F(std::integral_constant<int, 2>{}); \
+    F(std::integral_constant<int, 3>{}); F(std::integral_constant<int, 4>{}); F(std::integral_constant<int, 5>{}); \
+    F(std::integral_constant<int, 6>{}); F(std::integral_constant<int, 7>{});
+
+    // ---- prologue: D stages in flight, stage 0 landed for everyone, its fragments in registers -------------
+    setup_src(0);
+    for (int s = 0; s < D && s < total; ++s) issue_next();
+    if (total >= 3) wait_vmcnt<2 * PW>(); else if (total == 2) wait_vmcnt<PW>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    W4_EACH8(refill_a)
+    W4_EACH8(refill_b)
+    wait_lgkmcnt<0>();
+
+    int rd_slot = 1, s = 0;
+    bool fresh = false;
+#ifdef ADN_GEMM_STAMPS
+    // [0] top wait, [1] first half (32 MFMAs), [2] vmcnt wait, [3] barrier, [4] DMA issue + B refills, [5] second half, [6] epilogue
+    const bool late = false;
+    const bool stamping = blockIdx.x == 3 && blockIdx.y == 0 && wave == 0;
+    unsigned long long gacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long gl_ = __builtin_amdgcn_s_memtime();
+#endif
+    // one K-step; FIRST: the first of its tile (accumulators defined by C = 0 MFMAs); last: the tile's last K-step
+    auto step = [&](auto first_c, bool last) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_c)::value;
+        auto mm = [&](auto a_c, auto b_c) __attribute__((always_inline)) {
+            constexpr int a = decltype(a_c)::value, b = decltype(b_c)::value;
+            if (FIRST) mfma_first(acc[a][b], fb[b], fa[a]);
+            else mfma_acc(acc[a][b], fb[b], fa[a]);
+        };
+        auto row_left = [&](auto a_c) __attribute__((always_inline)) {
+            mm(a_c, std::integral_constant<int, 0>{}); mm(a_c, std::integral_constant<int, 1>{});
+            mm(a_c, std::integral_constant<int, 2>{}); mm(a_c, std::integral_constant<int, 3>{});
+        };
+        // everything but the youngest reads of the previous step (fb[4..7], fa[7]) has landed: rows 0-6 can start
+        if (has_tail && last) {
+            wait_lgkmcnt<0>();
+            asm volatile("" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fa[5]), "+v"(fa[6]), "+v"(fa[7]));
+#pragma unroll
+            for (int a = 0; a < TM; ++a) fa[a] = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4, fa[a]) & amask);
+            asm volatile("s_nop 3" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fa[5]), "+v"(fa[6]), "+v"(fa[7]));
+        } else {
+            wait_lgkmcnt<A_KC ? 9 : 10>();
+        }
+        GSTAMP(0);
+        // ---- first half: columns 0-3
+        row_left(std::integral_constant<int, 0>{}); row_left(std::integral_constant<int, 1>{});
+        row_left(std::integral_constant<int, 2>{}); row_left(std::integral_constant<int, 3>{});
+        row_left(std::integral_constant<int, 4>{}); row_left(std::integral_constant<int, 5>{});
+        row_left(std::integral_constant<int, 6>{});
+        wait_lgkmcnt<0>();                                           // fa[7], fb[4..7] (no read has been issued since the step began)
+        row_left(std::integral_constant<int, 7>{});
+        GSTAMP(1);
+        // ---- between the halves: stage s + 1 landed for everyone; the slot of stage s - 1 is free
+        wait_next(s, fresh);
+        fresh = false;
+        GSTAMP(2);
+        __builtin_amdgcn_s_barrier();
+        GSTAMP(3);
+        a_cur = rd_slot * (kAElems * 2); b_cur = rd_slot * (kBElems * 2);
+        if (++rd_slot == NS) rd_slot = 0;
+        if (s + D < total) issue_next();
+        refill_b(std::integral_constant<int, 0>{}); refill_b(std::integral_constant<int, 1>{});
+        refill_b(std::integral_constant<int, 2>{}); refill_b(std::integral_constant<int, 3>{});
+        GSTAMP(4);
+        // ---- second half: columns 4-7; fa[a] is refilled behind its row
+#define W4_ROW_RIGHT(A) mm(std::integral_constant<int, A>{}, std::integral_constant<int, 4>{}); mm(std::integral_constant<int, A>{}, std::integral_constant<int, 5>{}); \
+        mm(std::integral_constant<int, A>{}, std::integral_constant<int, 6>{}); mm(std::integral_constant<int, A>{}, std::integral_constant<int, 7>{}); \
+        refill_a(std::integral_constant<int, A>{});
+        W4_ROW_RIGHT(0) W4_ROW_RIGHT(1) W4_ROW_RIGHT(2) W4_ROW_RIGHT(3) W4_ROW_RIGHT(4) W4_ROW_RIGHT(5) W4_ROW_RIGHT(6)
+        mm(std::integral_constant<int, 7>{}, std::integral_constant<int, 4>{}); refill_b(std::integral_constant<int, 4>{});
+        mm(std::integral_constant<int, 7>{}, std::integral_constant<int, 5>{}); refill_b(std::integral_constant<int, 5>{});
+        mm(std::integral_constant<int, 7>{}, std::integral_constant<int, 6>{}); refill_b(std::integral_constant<int, 6>{});
+        mm(std::integral_constant<int, 7>{}, std::integral_constant<int, 7>{}); refill_b(std::integral_constant<int, 7>{});
+        refill_a(std::integral_constant<int, 7>{});
+#undef W4_ROW_RIGHT
+        GSTAMP(5);
+        ++s;
+    };
+    for (int ord = 0; ord < my_tiles; ++ord) {
+        int grp, tile_m, tile_n;
+        tile_of(ord, grp, tile_m, tile_n);
+        step(std::true_type{}, nk == 1);
+        for (int kt = 1; kt < nk; ++kt) step(std::false_type{}, kt == nk - 1);
+        wait_lgkmcnt<0>();                                           // no fragment register is still being written when the
+                                                                     // compiler's epilogue code may touch the register file
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");             // MFMA results -> accumulator reads of the epilogue (the hazard
+                                                                     // recogniser does not look inside inline assembly)
+        {
+            // ---- epilogue of tile `ord` from the (transposed) accumulators: lane = row (lane & 15), columns 4 hi .. 4 hi + 3
+            //      of every 16-column block (the eight-wave kernel's epilogue on an 8 x 8 grid of blocks)
+            const GemmGroup gp = pick_group(p, grp);
+            float* Cg = SPLIT ? p.partial + ((size_t)(grp * (int)gridDim.y + slice) * p.M) * p.ldc : gp.C;
+            const int row0 = tile_m * BM + wm * WTM + (lane & 15), col0 = tile_n * BN + wn * WTN + 4 * hi;
+            constexpr int TNH = 2;
+#pragma clang loop unroll(full)
+            for (int half = 0; half < TN / TNH; ++half) {
+                bf16x4 yv[TM][TNH];
+                if (!SPLIT && gp.Y16) {
+#pragma clang loop unroll(full)
+                    for (int bb = 0; bb < TNH; ++bb)
+#pragma clang loop unroll(full)
+                        for (int a = 0; a < TM; ++a) {
+                            const int row = min(row0 + a * 16, p.M - 1), col = min(col0 + (half * TNH + bb) * 16, p.N - 4);
+                            yv[a][bb] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(gp.Y16) + (size_t)row * p.ldy + col);
+                        }
+                }
+                const int b0 = half * TNH;
+                const int colA = col0 + b0 * 16, colB = colA + 16;
+                float4 biasA = make_float4(0.f, 0.f, 0.f, 0.f), biasB = biasA, csumA = biasA, csumB = biasA;
+                if (!SPLIT && gp.bias) {
+                    biasA = *reinterpret_cast<const float4*>(gp.bias + min(colA, p.N - 4));
+                    biasB = *reinterpret_cast<const float4*>(gp.bias + min(colB, p.N - 4));
+                }
+                const bool odd = hi & 1;
+#pragma clang loop unroll(full)
+                for (int a = 0; a < TM; ++a) {
+                    __builtin_amdgcn_sched_barrier(0);             // (keeps the scheduler from pulling all 256 accumulators into VGPRs)
+                    const int row = row0 + a * 16;
+                    const bool rok = row < p.M;
+                    const float4 vA = pp_epi4<SPLIT>(p, gp, Cg, acc[a][b0], biasA, yv[a][0], row, colA, rok && colA < p.N, csumA);
+                    const float4 vB = pp_epi4<SPLIT>(p, gp, Cg, acc[a][b0 + 1], biasB, yv[a][1], row, colB, rok && colB < p.N, csumB);
+                    if (!SPLIT && gp.C16) {
+                        const uint2 pA = __builtin_bit_cast(uint2, cvt4(vA)), pB = __builtin_bit_cast(uint2, cvt4(vB));
+                        const uint2 give = odd ? pA : pB;
+                        uint2 take;
+                        take.x = __shfl_xor(give.x, 16, 64); take.y = __shfl_xor(give.y, 16, 64);
+                        const uint4 out = odd ? make_uint4(take.x, take.y, pB.x, pB.y) : make_uint4(pA.x, pA.y, take.x, take.y);
+                        const int cs = odd ? colB - 4 : colA;
+                        __bf16* dst = reinterpret_cast<__bf16*>(gp.C16) + (size_t)row * p.ldc + cs;
+                        if (rok && cs + 8 <= p.N) *reinterpret_cast<uint4*>(dst) = out;
+                        else if (rok && cs + 4 <= p.N) *reinterpret_cast<uint2*>(dst) = make_uint2(out.x, out.y);
+                    }
+                }
+                if (!SPLIT && gp.colsum) {                         // column sums over this wave's WTM rows: [tiles_m * 2][colsum_ld]
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) {
+                        csumA.x += __shfl_xor(csumA.x, o, 64); csumA.y += __shfl_xor(csumA.y, o, 64);
+                        csumA.z += __shfl_xor(csumA.z, o, 64); csumA.w += __shfl_xor(csumA.w, o, 64);
+                        csumB.x += __shfl_xor(csumB.x, o, 64); csumB.y += __shfl_xor(csumB.y, o, 64);
+                        csumB.z += __shfl_xor(csumB.z, o, 64); csumB.w += __shfl_xor(csumB.w, o, 64);
+                    }
+                    if ((lane & 15) == 0) {
+                        float* cs_row = gp.colsum + (size_t)(tile_m * 2 + wm) * p.colsum_ld;
+                        if (colA < p.N) *reinterpret_cast<float4*>(cs_row + colA) = csumA;
+                        if (colB < p.N) *reinterpret_cast<float4*>(cs_row + colB) = csumB;
+                    }
+                }
+            }
+        }
+        fresh = true;
+        GSTAMP(6);
+    }
+    GSTAMP_FLUSH;
+#undef W4_EACH8
+}
+
 // C (+)= sum of the split-K partial slabs ([group][split][M][ldc] floats); float4 per lane
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, int splits) {
     const size_t slab4 = (size_t)p.M * p.ldc / 4;                 // float4 per slab; pad columns (>= N) are never touched
@@ -1034,12 +1416,23 @@ static void launch_pp_t(const GemmParams& p, int layout, bool split, dim3 grid, 
     }
 }
 
-// tile_mode: 4 = 256 x 256, 5 = 256 x 128, 6 = 128 x 256
+// tile_mode: 4 = 256 x 256, 5 = 256 x 128, 6 = 128 x 256 (eight waves); 7 = 256 x 256, four waves of 128 x 128
 void launch_gemm_bf16_pp(const GemmParams& p, int layout, int tile_mode, int splits, dim3 grid, hipStream_t s) {
     const bool split = splits > 1;
-    if (tile_mode == 4) launch_pp_t<256, 256>(p, layout, split, grid, s);
+    if (tile_mode == 7) {
+        if (layout == GEMM_NN) {
+            if (split) hipLaunchKernelGGL((gemm_bf16_w4_kernel<true, true>), grid, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((gemm_bf16_w4_kernel<true, false>), grid, dim3(256), 0, s, p);
+        } else {
+            if (split) hipLaunchKernelGGL((gemm_bf16_w4_kernel<false, true>), grid, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((gemm_bf16_w4_kernel<false, false>), grid, dim3(256), 0, s, p);
+        }
+    }
+#ifndef ADN_W4_ONLY
+    else if (tile_mode == 4) launch_pp_t<256, 256>(p, layout, split, grid, s);
     else if (tile_mode == 5) launch_pp_t<256, 128>(p, layout, split, grid, s);
     else launch_pp_t<128, 256>(p, layout, split, grid, s);
+#endif
     if (split) {
         const size_t n4 = (size_t)p.M * (p.N / 4);
         const int blocks = (int)std::min<size_t>(2048, (n4 + 255) / 256);
@@ -1059,6 +1452,7 @@ static void launch_bf16_t(const GemmParams& p, int layout, dim3 grid, hipStream_
 
 // tile_mode: 0 = 64 x 64, 1 = 128 x 128, 2 = 256 x 64 (tall: narrow outputs under many rows)
 void launch_gemm_bf16(const GemmParams& p, int layout, int tile_mode, dim3 grid, hipStream_t s) {
+#ifndef ADN_W4_ONLY
     const bool shadows = p.A16 && p.B16;      // operands already available as bf16 copies
     const bool big = tile_mode == 1;
     if (tile_mode == 2) {
@@ -1073,6 +1467,7 @@ void launch_gemm_bf16(const GemmParams& p, int layout, int tile_mode, dim3 grid,
         if (big) launch_bf16_t<128, 128, 2, float>(p, layout, grid, s);
         else launch_bf16_t<64, 64, 2, float>(p, layout, grid, s);
     }
+#endif
 }
 
 // fp32 -> bf16 shadow copy (RNE), 8 elements per lane

@@ -181,6 +181,7 @@ static int device_cus() {
 
 // Runs `n` problems of identical shape / layout / flags through the ping-pong kernel if it applies; *used says whether.
 // dry: only answer whether the kernel WOULD take the launch (no side effects)
+constexpr int kDefaultPpMode = 4;       // tile mode the selection uses unless ADN_GEMM_PP forces one (4: eight waves, 7: four waves)
 static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used, bool dry = false) {
     *used = false;
     const GemmArgs& g = gs[0];
@@ -221,16 +222,17 @@ static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used
     //     loses the difference to its last round), 142 against 161 us for 20800 x 2000 x 1200
     //   * NOT the input-gradient GEMMs: the transposed-accumulator epilogue reads the act'(Y) mask in 32-byte
     //     row pieces (205 against 146 us), and not 128-wide tiles (445 TFLOP/s: B-fragment reads per flop double)
-    struct Cand { int mode, bm, bn; double rate; };
-    static const Cand cands[3] = {{4, 256, 256, 1.0}, {5, 256, 128, 0.70}, {6, 128, 256, 0.70}};
+    struct Cand { int mode, bm, bn; double rate; int wave_rows; };
+    // mode 7: the four-wave kernel (128 x 128 per wave); ADN_GEMM_PP=4 forces the eight-wave kernel
+    static const Cand cands[4] = {{7, 256, 256, 1.0, 2}, {4, 256, 256, 1.0, 4}, {5, 256, 128, 0.70, 4}, {6, 128, 256, 0.70, 4}};
     int best = -1, splits = 1; double best_cost = 0;
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < 4; ++c) {
         if (mode_env >= 4 && cands[c].mode != mode_env) continue;
-        if (mode_env < 4 && cands[c].mode != 4) continue;
+        if (mode_env < 4 && cands[c].mode != kDefaultPpMode) continue;
         const int64_t tiles = (int64_t)cdiv(g.M, cands[c].bm) * cdiv(g.N, cands[c].bn) * n;
         int sp = 1;
         if (tiles * 2 <= cus && can_split && g.K >= 2048) {
-            if (cands[c].mode != 4) continue;
+            if (cands[c].mode != 4 && cands[c].mode != 7) continue;
             sp = (int)std::min<int64_t>(cus / tiles, g.K / 512);
         }
         const int64_t rounds = (tiles * sp + cus - 1) / cus;
@@ -278,7 +280,7 @@ static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used
     if (g.colsum && splits == 1) {
         fused_colsum = true;
         for (int k = 0; k < n; ++k)
-            if (!gs[k].colsum_ws || ((uintptr_t)gs[k].colsum_ws % 16) || (size_t)p.tiles_m * 4 * cs_ld > gs[k].colsum_ws_floats) fused_colsum = false;
+            if (!gs[k].colsum_ws || ((uintptr_t)gs[k].colsum_ws % 16) || (size_t)p.tiles_m * cd.wave_rows * cs_ld > gs[k].colsum_ws_floats) fused_colsum = false;
     }
     p.colsum_ld = cs_ld;
     for (int k = 0; k < n; ++k) {
@@ -312,8 +314,8 @@ static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used
     for (int k = 0; k < n; ++k) {
         if (fused_colsum) {
             if (gs[k].colsum_batch && gs[k].colsum_batch->n < 8)
-                col_sum_batch_add(*gs[k].colsum_batch, gs[k].colsum_ws, cs_ld, p.tiles_m * 4, g.N, gs[k].colsum);
-            else ADN_TRY(col_sum(gs[k].colsum_ws, cs_ld, p.tiles_m * 4, g.N, gs[k].colsum, 1, stream));
+                col_sum_batch_add(*gs[k].colsum_batch, gs[k].colsum_ws, cs_ld, p.tiles_m * cd.wave_rows, g.N, gs[k].colsum);
+            else ADN_TRY(col_sum(gs[k].colsum_ws, cs_ld, p.tiles_m * cd.wave_rows, g.N, gs[k].colsum, 1, stream));
         }
         if (gs[k].C16 && splits > 1) {            // split-K result: refresh the bf16 shadow of whole rows
             ADN_CHECK(g.ldc % 8 == 0, ADN_ERR_INVALID, "gemm: bf16 shadow of C needs ldc % 8 == 0");

@@ -150,7 +150,9 @@ int main(int argc, char** argv) {
 #ifdef ADN_GEMM_STAMPS
         { unsigned long long s16[16];
           adn_debug_gemm_stamps(s16, 0);
-          const char* nm[8] = {"frag reads", "DMA issue", "lgkm wait", "vmcnt wait", "barrier(L)", "MFMA", "epilogue", "barrier(C)"};
+          const char* nm8[8] = {"frag reads", "DMA issue", "lgkm wait", "vmcnt wait", "barrier(L)", "MFMA", "epilogue", "barrier(C)"};
+          const char* nm4[8] = {"top wait", "half L (32 MFMA)", "vmcnt wait", "barrier", "DMA issue + 8 reads", "half R (32 MFMA + reads)", "epilogue", "-"};
+          const char** nm = (getenv("ADN_GEMM_PP") && atoi(getenv("ADN_GEMM_PP")) == 7) ? nm4 : nm8;
           for (int h = 0; h < 2; ++h) {
               double tot = 0; for (int k = 0; k < 8; ++k) tot += (double)s16[8 * h + k];
               printf("   stamps %s half (cycles per launch %.0f):", h ? "late " : "early", tot / iters);
