@@ -628,6 +628,14 @@ template <int IMM> __device__ __forceinline__ void glds16_s(unsigned off, const 
                  : "=&s"(keep) : "v"(off), "s"(base), "s"(lds_dst), "n"(IMM) : "memory", "scc");
 }
 
+// the four-wave kernel's form: its base may arrive through v_readfirstlane right ahead of the statement (VALU-written SGPR ->
+// VMEM reading it as its scalar base: 5 wait states; the two SALU instructions and the nop make them up)
+template <int IMM> __device__ __forceinline__ void glds16_su(unsigned off, const char* base, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %3, %4\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(base), "s"(lds_dst), "n"(IMM) : "memory", "scc");
+}
+
 __device__ __forceinline__ int swz_g(int kr) { return (kr & 3) | (((kr >> 3) & 1) << 2); }
 __device__ __forceinline__ int swz_f(int q) { return (0x1320 >> (4 * q)) & 3; }     // {0, 2, 3, 1}
 
@@ -1095,7 +1103,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(const GemmParams p) {
     if (total <= 0) return;
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_void_t*)smem;
 
-    // ---- DMA side (as in the eight-wave kernel, four pieces per operand and wave) ------------------------
+    // ---- DMA side: the eight-wave kernel's images, four 1-KiB pieces per operand, wave and stage, all eight issued right
+    // behind the barrier.  MEASURED (profiles/r03/gemm_w4_lab.txt, in-kernel stamps): an LDS-DMA piece costs the issuing wave
+    // 60 - 130 cycles (MI355X_MICROARCH.md: ~60 among bare MFMAs) during which it issues no MFMA -- 8 pieces = ~580 of a
+    // ~2500-cycle K-step with ONE wave per SIMD; spreading the pieces one by one between the MFMA rows made every piece cost
+    // more (half of a K-step 560 -> 1070 cycles: 548 against 646 TFLOP/s on 20800 x 2000 x 1200).  The eight-wave kernel pays
+    // the same issue cycles but its second wave per SIMD multiplies meanwhile: that is why this kernel ends 8 - 10 % BEHIND it
+    // (646 against 713 TFLOP/s) although its K-loop issues 40 % fewer LDS reads -- kept for ADN_GEMM_PP=7 and as the record
+    // of that measurement, not selected by default.  The two operands keep their own (tile, K-step, ring slot) cursors.
     constexpr int A_CPR = BM / 8, B_CPR = BN / 8;
     const char* baseA = nullptr; const char* baseB = nullptr;
     unsigned offA[APW], offB[BPW];
@@ -1110,15 +1125,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(const GemmParams p) {
         grp = q / per_group;
         tile_coords(p, q - grp * per_group, tm, tn);
     };
-    auto setup_src = [&](int ord) {
+    auto setup_a = [&](int ord) {
         int grp, tm, tn;
         tile_of(ord, grp, tm, tn);
-        const GemmGroup sg = pick_group(p, grp);
-        const char* A16 = reinterpret_cast<const char*>(sg.A16);
-        const char* B16 = reinterpret_cast<const char*>(sg.B16);
-        const int m0 = tm * BM, n0 = tn * BN;
+        const char* A16 = reinterpret_cast<const char*>(pick_group(p, grp).A16);
+        const int m0 = tm * BM;
         baseA = A_KC ? A16 + ((size_t)m0 * p.lda + kbeg) * 2 : A16 + (size_t)kbeg * p.lda * 2;
-        baseB = B16 + (size_t)kbeg * p.ldb * 2;
 #pragma unroll
         for (int t = 0; t < APW; ++t) {
             if (A_KC) {
@@ -1130,6 +1142,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(const GemmParams p) {
                 offA[t] = (unsigned)(a_aux[t] * p.lda + col) * 2u;
             }
         }
+    };
+    auto setup_b = [&](int ord) {
+        int grp, tm, tn;
+        tile_of(ord, grp, tm, tn);
+        const char* B16 = reinterpret_cast<const char*>(pick_group(p, grp).B16);
+        const int n0 = tn * BN;
+        baseB = B16 + (size_t)kbeg * p.ldb * 2;
 #pragma unroll
         for (int t = 0; t < BPW; ++t) {
             int col = n0 + (((lane % B_CPR) ^ (swz_g(b_row[t]) << 1)) * 8);
@@ -1141,44 +1160,47 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(const GemmParams p) {
     const size_t b_step = (size_t)BK * p.ldb * 2;
     const unsigned dstA_w = __builtin_amdgcn_readfirstlane(lds_base + wave * APW * 1024);
     const unsigned dstB_w = __builtin_amdgcn_readfirstlane(lds_base + NS * kAElems * 2 + wave * BPW * 1024);
-    int is_k = 0, is_ord = 0, is_slot = 0;
-    auto issue_one = [&](auto tail_c) {
-        constexpr bool tail = decltype(tail_c)::value;
-        const unsigned dA = dstA_w + (unsigned)(is_slot * kAElems * 2);
-        const unsigned dB = dstB_w + (unsigned)(is_slot * kBElems * 2);
-        const int k0 = kbeg + is_k * BK;
-        const char* uA = uniform_ptr(baseA); const char* uB = uniform_ptr(baseB);
-#pragma unroll
-        for (int t = 0; t < APW; ++t) {
-            if (tail) {
-                const char* g = baseA + offA[t];
-                if (A_KC) { if (k0 + a_aux[t] >= kend) g -= (size_t)(k0 + a_aux[t] - (kend - 8)) * 2; }
-                else if (k0 + a_aux[t] >= kend) g -= (size_t)(k0 + a_aux[t] - (kend - 1)) * p.lda * 2;
-                glds16(g, __builtin_amdgcn_readfirstlane(dA + t * 1024));
-            } else {
-                glds16_s<0>(offA[t], uA, __builtin_amdgcn_readfirstlane(dA + t * 1024));
-            }
+    int ia_k = 0, ia_ord = 0, ia_slot = 0, ib_k = 0, ib_ord = 0, ib_slot = 0;       // next stage to issue, per operand
+    auto issue_a = [&](auto t_c) __attribute__((always_inline)) {                   // piece t of the A part; t == APW - 1 advances
+        constexpr int t = decltype(t_c)::value;
+        const unsigned dA = __builtin_amdgcn_readfirstlane(dstA_w + (unsigned)(ia_slot * kAElems * 2) + t * 1024);
+        if (has_tail && ia_k == nk - 1) {
+            const int k0 = kbeg + ia_k * BK;
+            const char* g = baseA + offA[t];
+            if (A_KC) { if (k0 + a_aux[t] >= kend) g -= (size_t)(k0 + a_aux[t] - (kend - 8)) * 2; }
+            else if (k0 + a_aux[t] >= kend) g -= (size_t)(k0 + a_aux[t] - (kend - 1)) * p.lda * 2;
+            glds16(g, dA);
+        } else {
+            glds16_su<0>(offA[t], uniform_ptr(baseA), dA);
         }
-#pragma unroll
-        for (int t = 0; t < BPW; ++t) {
-            if (tail) {
-                const char* g = baseB + offB[t];
-                if (k0 + b_row[t] >= kend) g -= (size_t)(k0 + b_row[t] - (kend - 1)) * p.ldb * 2;
-                glds16(g, __builtin_amdgcn_readfirstlane(dB + t * 1024));
-            } else {
-                glds16_s<0>(offB[t], uB, __builtin_amdgcn_readfirstlane(dB + t * 1024));
-            }
+        if (t == APW - 1) {
+            baseA += a_step;
+            if (++ia_slot == NS) ia_slot = 0;
+            if (++ia_k == nk) { ia_k = 0; if (++ia_ord < my_tiles) setup_a(ia_ord); }
         }
-        baseA += a_step; baseB += b_step;
     };
-    auto issue_next = [&]() {
-        if (has_tail && is_k == nk - 1) issue_one(std::true_type{});
-        else issue_one(std::false_type{});
-        if (++is_slot == NS) is_slot = 0;
-        if (++is_k == nk) {
-            is_k = 0;
-            if (++is_ord < my_tiles) setup_src(is_ord);
+    auto issue_b = [&](auto t_c) __attribute__((always_inline)) {
+        constexpr int t = decltype(t_c)::value;
+        const unsigned dB = __builtin_amdgcn_readfirstlane(dstB_w + (unsigned)(ib_slot * kBElems * 2) + t * 1024);
+        if (has_tail && ib_k == nk - 1) {
+            const int k0 = kbeg + ib_k * BK;
+            const char* g = baseB + offB[t];
+            if (k0 + b_row[t] >= kend) g -= (size_t)(k0 + b_row[t] - (kend - 1)) * p.ldb * 2;
+            glds16(g, dB);
+        } else {
+            glds16_su<0>(offB[t], uniform_ptr(baseB), dB);
         }
+        if (t == BPW - 1) {
+            baseB += b_step;
+            if (++ib_slot == NS) ib_slot = 0;
+            if (++ib_k == nk) { ib_k = 0; if (++ib_ord < my_tiles) setup_b(ib_ord); }
+        }
+    };
+    auto issue_stage = [&]() __attribute__((always_inline)) {       // a whole stage at once
+        issue_a(std::integral_constant<int, 0>{}); issue_a(std::integral_constant<int, 1>{});
+        issue_a(std::integral_constant<int, 2>{}); issue_a(std::integral_constant<int, 3>{});
+        issue_b(std::integral_constant<int, 0>{}); issue_b(std::integral_constant<int, 1>{});
+        issue_b(std::integral_constant<int, 2>{}); issue_b(std::integral_constant<int, 3>{});
     };
 
     // ---- per-lane fragment addresses inside ring slot 0 ---------------------------------------------------
@@ -1204,8 +1226,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(const GemmParams p) {
     typedef __attribute__((address_space(3))) bf16x8 lds_bf16x8;
     f32x4 acc[TM][TN];                                             // AGPRs; written by the asm MFMAs only (first K-step: C = 0)
 
-    // own pieces of stage s + 1 landed?  (called at the top of step s, BEFORE the DMA issue of that step: the youngest stage
-    // this wave has issued is s + 2)
+    // own pieces of stage s + 1 landed?  (called between the halves of step s, BEFORE the A pieces of stage s + 3 go out: the
+    // youngest stage this wave has issued is s + 2 -- its A part in the second half of step s - 1, its B part just now)
     auto wait_next = [&](int s, bool fresh_epi) {
         if (s + 1 >= total) return;
         if (fresh_epi || s + 2 >= total) wait_vmcnt<0>();
@@ -1234,8 +1256,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(const GemmParams p) {
     F(std::integral_constant<int, 6>{}); F(std::integral_constant<int, 7>{});
 
     // ---- prologue: D stages in flight, stage 0 landed for everyone, its fragments in registers -------------
-    setup_src(0);
-    for (int s = 0; s < D && s < total; ++s) issue_next();
+    static_assert(APW == 4 && BPW == 4, "piece schedule below");
+    setup_a(0); setup_b(0);
+    for (int s = 0; s < D && s < total; ++s) issue_stage();
     if (total >= 3) wait_vmcnt<2 * PW>(); else if (total == 2) wait_vmcnt<PW>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     W4_EACH8(refill_a)
@@ -1262,7 +1285,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(const GemmParams p) {
             mm(a_c, std::integral_constant<int, 0>{}); mm(a_c, std::integral_constant<int, 1>{});
             mm(a_c, std::integral_constant<int, 2>{}); mm(a_c, std::integral_constant<int, 3>{});
         };
-        // everything but the youngest reads of the previous step (fb[4..7], fa[7]) has landed: rows 0-6 can start
         if (has_tail && last) {
             wait_lgkmcnt<0>();
             asm volatile("" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fa[5]), "+v"(fa[6]), "+v"(fa[7]));
@@ -1270,14 +1292,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(const GemmParams p) {
             for (int a = 0; a < TM; ++a) fa[a] = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4, fa[a]) & amask);
             asm volatile("s_nop 3" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fa[5]), "+v"(fa[6]), "+v"(fa[7]));
         } else {
-            wait_lgkmcnt<A_KC ? 9 : 10>();
+            wait_lgkmcnt<15>();                                       // fb[0..3] and fa[0]: the oldest reads of the previous step
         }
         GSTAMP(0);
-        // ---- first half: columns 0-3
-        row_left(std::integral_constant<int, 0>{}); row_left(std::integral_constant<int, 1>{});
-        row_left(std::integral_constant<int, 2>{}); row_left(std::integral_constant<int, 3>{});
-        row_left(std::integral_constant<int, 4>{}); row_left(std::integral_constant<int, 5>{});
-        row_left(std::integral_constant<int, 6>{});
+        // ---- first half: columns 0-3.  Row a needs fa[a]: the waits count what may still be in flight behind its refill (A_KC: 6 - a refills of later rows
+        // + the 9 youngest reads; k-strided A: two reads per refill, capped by the 4-bit counter)
+        row_left(std::integral_constant<int, 0>{});
+        wait_lgkmcnt<A_KC ? 14 : 15>(); row_left(std::integral_constant<int, 1>{});
+        wait_lgkmcnt<A_KC ? 13 : 15>(); row_left(std::integral_constant<int, 2>{});
+        wait_lgkmcnt<A_KC ? 12 : 15>(); row_left(std::integral_constant<int, 3>{});
+        wait_lgkmcnt<A_KC ? 11 : 14>(); row_left(std::integral_constant<int, 4>{});
+        wait_lgkmcnt<A_KC ? 10 : 12>(); row_left(std::integral_constant<int, 5>{});
+        wait_lgkmcnt<A_KC ? 9 : 10>(); row_left(std::integral_constant<int, 6>{});
         wait_lgkmcnt<0>();                                           // fa[7], fb[4..7] (no read has been issued since the step began)
         row_left(std::integral_constant<int, 7>{});
         GSTAMP(1);
@@ -1289,7 +1315,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(const GemmParams p) {
         GSTAMP(3);
         a_cur = rd_slot * (kAElems * 2); b_cur = rd_slot * (kBElems * 2);
         if (++rd_slot == NS) rd_slot = 0;
-        if (s + D < total) issue_next();
+        if (s + D < total) issue_stage();                            // all eight pieces of stage s + 3 (see the DMA notes above)
         refill_b(std::integral_constant<int, 0>{}); refill_b(std::integral_constant<int, 1>{});
         refill_b(std::integral_constant<int, 2>{}); refill_b(std::integral_constant<int, 3>{});
         GSTAMP(4);
