@@ -197,6 +197,8 @@ def parse_args(argv=None):
                     help="also time the parity-grade modes (sub-objects `accurate` = bf16x3, `accurate_f32`; N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event per-kernel timing")
+    ap.add_argument("--fp32-inputs", action="store_true",
+                    help="bf16 mode: keep the resident batch in float32 (the library then converts it every step) instead of bfloat16")
     ap.add_argument("--no-reference-minibatch", action="store_true", help="skip the B=26 sub-run")
     ap.add_argument("--only-train-steps", action="store_true",
                     help="counter passes (profiles/collect.sh): run NOTHING but warmup + steps train steps of the B=520 workload "
@@ -305,6 +307,12 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
         xs, y, m_d, mask = batch_fn(rank, B_PER_GPU)
         total_frames = float(mask.sum())
         global_batch = B_PER_GPU * world
+    # bf16 headline: the batch is resident as bfloat16 (what a bf16 feature front-end leaves in HBM; ADN_FLAG_BF16_INPUTS): the
+    # first encoder GEMM reads it in place.  The parity-grade modes below get the same frames as float32.
+    xs32 = xs
+    if on_gpu and args.precision == "bf16" and not args.fp32_inputs:
+        xs = [x.to(torch.bfloat16) for x in xs32]
+    inputs_desc = "bfloat16, resident in HBM" if xs is not xs32 else "float32, resident in HBM"
     if distributed:
         if args.scaling == "weak":
             t = torch.tensor([total_frames], device=device, dtype=torch.float64)
@@ -394,6 +402,7 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
                                    % ("per GPU" if args.scaling == "weak" else "split over the GPUs"),
                        "global_batch": global_batch, "frames_per_utterance": T_MAX,
                        "parallelism": "dp%d" % world, "params": model.count_params(),
+                       "inputs": inputs_desc,
                        "epoch_time_s": (elapsed / args.steps + eval_s) if eval_s is not None else None,
                        "epoch_eval_s": eval_s, "final_loss": loss},
         }
@@ -410,6 +419,7 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
             if prec == args.precision:
                 continue
             model.set_precision(prec)
+            xs = xs32                                  # (the step closure reads `xs`: float32 frames for the parity-grade modes)
             k = max(3, min(args.steps, 10))
             for _ in range(2):
                 step()
@@ -430,6 +440,8 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
             # the same model at the reference's own minibatch (runners/3stream.py: 26 utterances per update): every GEMM is a
             # latency-bound launch there and the step is a chain of ~160 LSTM time steps -- reported beside the headline, not as it
             xb, yb, mb_d, _ = batch_fn(rank + 2000, 26)
+            if inputs_desc.startswith("bfloat16"):
+                xb = [x.to(torch.bfloat16) for x in xb]
             for _ in range(30):
                 model.train_step(xb, yb, mb_d, THETA, LR, want_loss=False)
             fence()

@@ -72,7 +72,12 @@ enum {
     ADN_FLAG_DEVICE_INPUTS = 1,
     ADN_FLAG_DEVICE_OUTPUTS = 2,
     ADN_FLAG_STOCHASTIC = 4,     /* adn_loss: dropout layers active (compute_train_cost, runners/3stream.py:372) */
-    ADN_FLAG_DETERMINISTIC = 8   /* adn_compute_grads / adn_train_step: dropout layers off (they are on by default) */
+    ADN_FLAG_DETERMINISTIC = 8,  /* adn_compute_grads / adn_train_step: dropout layers off (they are on by default) */
+    ADN_FLAG_BF16_INPUTS = 16    /* the stream (and auxiliary) inputs are bfloat16 arrays instead of float32 -- what a bf16
+                                    feature front-end leaves in HBM.  In ADN_PRECISION_BF16 a device array of an encoder stream
+                                    is then read in place by the first encoder GEMM (no staging copy, no conversion pass);
+                                    everywhere else it is widened to float32 (exact) first.  The reference's theano functions
+                                    take float32 (allow_input_downcast) only: this is an addition, not a replacement. */
 };
 
 /* what the classifier sees and how it is trained */

@@ -22,6 +22,7 @@ PRECISION = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "bf16x
 FLAG_DEVICE_INPUTS = 1
 FLAG_STOCHASTIC = 4
 FLAG_DETERMINISTIC = 8
+FLAG_BF16_INPUTS = 16
 HEAD = {"frames": 0, "last": 1}
 FLAG_DEVICE_OUTPUTS = 2
 BUF_PARAM, BUF_GRAD, BUF_ADAM_M, BUF_ADAM_V = 0, 1, 2, 3

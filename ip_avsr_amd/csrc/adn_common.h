@@ -138,7 +138,7 @@ int delta_backward(const float* dout, int ld_out, float* din, int ld_in, int B, 
                    int append, hipStream_t s, void* din16 = nullptr);
 // out[r][c] = sum_k alpha_k * in_k[r][c]  (alpha = device scalars or null for 1)
 int sum_k(int n_in, const float* const* in, const float* const* alpha, int ld_in, float* out, int ld_out,
-          int rows, int cols, hipStream_t s);
+          int rows, int cols, hipStream_t s, void* out16 = nullptr);
 // out[r][c] = alpha[0] * in[r][c]   (alpha device scalar)
 int scale_by(const float* in, int ld_in, const float* alpha, float* out, int ld_out, int rows, int cols,
              hipStream_t s);
@@ -163,7 +163,7 @@ int lstm_init_state_rows(const float* hid, const float* cell, float* h, float* c
 //   z (T*B rows, time-major, ldz) -> probs_bt (B,T,C) batch-major dense (may be null),
 //   row_loss[r] = -mask*log softmax(softmax(z))[y]  (if y != null), dz (may be null)
 int softmax_loss(const float* z, int ldz, int B, int T, int C, const uint8_t* mask_tb, const int32_t* y_bt,
-                 const float* total, float* probs_bt, float* row_loss, float* dz, int lddz, hipStream_t s);
+                 const float* total, float* probs_bt, float* row_loss, float* dz, int lddz, hipStream_t s, void* dz16 = nullptr);
 // out[0] = (sum_i v[i]) / total[0], fixed summation order
 int reduce_loss(const float* v, int n, const float* total, float* out, hipStream_t s);
 // p16: optional bf16 shadow of the parameters, written with the update

@@ -203,7 +203,7 @@ struct SumKArgs {
 };
 
 __global__ __launch_bounds__(256) void sum_k_kernel(SumKArgs a, int ld_in, float* __restrict__ out, int ld_out,
-                                                    int rows, int cols4) {
+                                                    int rows, int cols4, __bf16* __restrict__ out16) {
     const int64_t total = (int64_t)rows * cols4;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int r = (int)(e / cols4), c = (int)(e % cols4) * 4;
@@ -214,6 +214,11 @@ __global__ __launch_bounds__(256) void sum_k_kernel(SumKArgs a, int ld_in, float
             acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
         }
         *reinterpret_cast<float4*>(out + (size_t)r * ld_out + c) = acc;
+        if (out16) {                        // bf16 copy for the GEMM that reads the sum (same row stride)
+            typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+            bf16x4_t h; h[0] = (__bf16)acc.x; h[1] = (__bf16)acc.y; h[2] = (__bf16)acc.z; h[3] = (__bf16)acc.w;
+            *reinterpret_cast<bf16x4_t*>(out16 + (size_t)r * ld_out + c) = h;
+        }
     }
 }
 
@@ -225,14 +230,14 @@ static inline int grid_for(int64_t work_items) {
 // NOTE: operates on whole float4 groups up to round_up(cols,4) <= ld; pad columns of the inputs are
 // zero by construction, so the pad columns of the output stay zero.
 int sum_k(int n_in, const float* const* in, const float* const* alpha, int ld_in, float* out, int ld_out, int rows,
-          int cols, hipStream_t s) {
+          int cols, hipStream_t s, void* out16) {
     ADN_CHECK(n_in >= 1 && n_in <= ADN_MAX_STREAMS, ADN_ERR_INVALID, "sum_k: bad operand count");
     SumKArgs a;
     a.n = n_in;
     for (int k = 0; k < n_in; ++k) { a.in[k] = in[k]; a.alpha[k] = alpha ? alpha[k] : nullptr; }
     const int cols4 = cdiv(cols, 4);
     hipLaunchKernelGGL(sum_k_kernel, dim3(grid_for((int64_t)rows * cols4)), dim3(256), 0, s, a, ld_in, out, ld_out,
-                       rows, cols4);
+                       rows, cols4, reinterpret_cast<__bf16*>(out16));
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }
@@ -701,7 +706,7 @@ __global__ __launch_bounds__(256) void softmax_loss_kernel(const float* __restri
                                                            const int32_t* __restrict__ y_bt,
                                                            const float* __restrict__ total,
                                                            float* __restrict__ probs_bt, float* __restrict__ row_loss,
-                                                           float* __restrict__ dz, int lddz) {
+                                                           float* __restrict__ dz, int lddz, __bf16* __restrict__ dz16) {
     const int rows = B * T;
     const int r = (blockIdx.x * 256 + threadIdx.x) / G;
     const int c = threadIdx.x % G;
@@ -725,20 +730,21 @@ __global__ __launch_bounds__(256) void softmax_loss_kernel(const float* __restri
         const float dp = cv ? (msk / total[0]) * (q - (c == y ? 1.f : 0.f)) : 0.f;
         const float dot = group_sum<G>(dp * p);
         if (cv) dz[(size_t)r * lddz + c] = p * (dp - dot);
+        if (cv && dz16) dz16[(size_t)r * lddz + c] = (__bf16)(p * (dp - dot));
     }
 }
 
 int softmax_loss(const float* z, int ldz, int B, int T, int C, const uint8_t* mask_tb, const int32_t* y_bt,
-                 const float* total, float* probs_bt, float* row_loss, float* dz, int lddz, hipStream_t s) {
+                 const float* total, float* probs_bt, float* row_loss, float* dz, int lddz, hipStream_t s, void* dz16) {
     ADN_CHECK(C >= 1 && C <= ADN_MAX_CLASSES, ADN_ERR_INVALID, "softmax: unsupported number of classes");
     const int rows = B * T;
     ProfScope prof(PROF_SOFTMAX_LOSS, 0.0, 4.0 * rows * (double)C * (dz ? 3.0 : 2.0), s);
     if (C <= 32) {
         hipLaunchKernelGGL(softmax_loss_kernel<32>, dim3(cdiv(rows, 8)), dim3(256), 0, s, z, ldz, B, T, C, mask_tb,
-                           y_bt, total, probs_bt, row_loss, dz, lddz);
+                           y_bt, total, probs_bt, row_loss, dz, lddz, reinterpret_cast<__bf16*>(dz16));
     } else {
         hipLaunchKernelGGL(softmax_loss_kernel<64>, dim3(cdiv(rows, 4)), dim3(256), 0, s, z, ldz, B, T, C, mask_tb,
-                           y_bt, total, probs_bt, row_loss, dz, lddz);
+                           y_bt, total, probs_bt, row_loss, dz, lddz, reinterpret_cast<__bf16*>(dz16));
     }
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;

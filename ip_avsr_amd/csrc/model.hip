@@ -512,20 +512,64 @@ int refresh_params(adn_model* m);
 // ------------------------------------------------------------------------------------------
 // staging of the caller's arrays
 // ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void widen_bf16_rows_kernel(const uint16_t* __restrict__ src, int ld_src, float* __restrict__ dst,
+                                                              int ld_dst, int64_t rows, int cols) {
+    const int64_t total = rows * cols;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / cols; const int c = (int)(e - r * cols);
+        dst[r * ld_dst + c] = __uint_as_float((uint32_t)src[r * ld_src + c] << 16);
+    }
+}
+
+// bf16 rows [rows][cols] (row stride ld_src elements, device memory) -> fp32 rows with stride ld_dst
+int widen_bf16_rows(const void* src, int ld_src, float* dst, int ld_dst, int64_t rows, int cols, hipStream_t s) {
+    const int64_t total = rows * cols;
+    if (total <= 0) return ADN_OK;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, 8192));
+    hipLaunchKernelGGL(widen_bf16_rows_kernel, dim3(grid), dim3(256), 0, s, static_cast<const uint16_t*>(src), ld_src, dst, ld_dst,
+                       rows, cols);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
 int stage_inputs(adn_model* m, const void* const* inputs, const int32_t* targets, const uint8_t* mask, int B, int T,
                  int flags) {
     const size_t N = (size_t)B * T;
     const bool dev = flags & ADN_FLAG_DEVICE_INPUTS;
+    const bool in16 = flags & ADN_FLAG_BF16_INPUTS;              // stream (and auxiliary) inputs arrive as bf16 arrays
     const hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     ADN_CHECK(inputs && mask, ADN_ERR_INVALID, "null inputs / mask");
     for (int s = 0; s < m->S; ++s) {
         StreamState& st = m->st[s];
         ADN_CHECK(inputs[s], ADN_ERR_INVALID, "null stream input");
         const int D = st.cfg.input_dim;
+        st.x16 = nullptr;
+        if (in16) {
+            // bf16 mode, an encoder in front (every consumer of the input is a GEMM reading bf16 operands): the caller's
+            // device array IS the operand -- no copy, no conversion; st.x only names it (shadow_of), it is never read
+            const bool direct16 = dev && m->bf16() && st.cfg.n_enc > 0 && D % 8 == 0 && ((uintptr_t)inputs[s]) % 16 == 0 &&
+                                  !getenv("ADN_BF16_NO_SHADOW");
+            if (direct16) {
+                st.x = static_cast<const float*>(inputs[s]); st.ldx = D;
+                st.x16 = const_cast<void*>(inputs[s]);
+                continue;
+            }
+            // otherwise widened into the fp32 staging buffer (exact), through the staging buffer's bf16 shadow for host arrays
+            const int ld = ld_of(D);
+            const void* src16 = inputs[s]; int ld16 = D;
+            if (!dev) {
+                void* sh = m->shadow_of(st.xstage);
+                ADN_CHECK(sh, ADN_ERR_STATE, "internal: the input staging buffer has no bf16 shadow");
+                ADN_HIP_CHECK(hipMemcpy2DAsync(sh, (size_t)ld * 2, inputs[s], (size_t)D * 2, (size_t)D * 2, N, kind, m->stream));
+                src16 = sh; ld16 = ld;
+            }
+            ADN_TRY(widen_bf16_rows(src16, ld16, st.xstage, ld, (int64_t)N, D, m->stream));
+            st.x = st.xstage; st.ldx = ld;
+            continue;
+        }
         // device inputs are used in place when the GEMM loader can read them directly; in bf16 mode they
         // are copied into the staging buffer instead, which owns a bf16 shadow
         const bool direct = dev && (D % (m->bf16() ? 8 : 4) == 0) && (((uintptr_t)inputs[s]) % 16 == 0);
-        st.x16 = nullptr;
         if (direct) {
             st.x = static_cast<const float*>(inputs[s]); st.ldx = D;
             if (m->bf16()) {                   // the staging buffer's shadow holds the bf16 copy (ld_of(D) == D)
@@ -544,8 +588,13 @@ int stage_inputs(adn_model* m, const void* const* inputs, const int32_t* targets
         if (st.cfg.aux_dim <= 0) continue;
         const void* src = inputs[m->S + aux_k++];
         ADN_CHECK(src, ADN_ERR_INVALID, "null auxiliary input");
-        ADN_HIP_CHECK(hipMemcpy2DAsync(st.aux_stage, (size_t)ld_of(st.cfg.aux_dim) * 4, src, (size_t)st.cfg.aux_dim * 4,
-                                       (size_t)st.cfg.aux_dim * 4, N, kind, m->stream));
+        const int ad = st.cfg.aux_dim, ald = ld_of(ad);
+        if (in16) {
+            ADN_CHECK(dev, ADN_ERR_INVALID, "bf16 auxiliary inputs must be device arrays");
+            ADN_TRY(widen_bf16_rows(src, ad, st.aux_stage, ald, (int64_t)N, ad, m->stream));
+        } else {
+            ADN_HIP_CHECK(hipMemcpy2DAsync(st.aux_stage, (size_t)ald * 4, src, (size_t)ad * 4, (size_t)ad * 4, N, kind, m->stream));
+        }
     }
     for (auto& st : m->st) if (!st.x16) ADN_TRY(refresh(m, st.x, N * st.ldx));
     ADN_TRY(refresh_params(m));
@@ -1043,8 +1092,7 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
         ADN_TRY(run_lstm_group(m, steps, B, T, false));
         if (m->agg.size() == 2) {
             const float* in[2] = {m->aggw[0].out(B, ldh, false), m->aggw[1].out(B, ldh, true)};
-            ADN_TRY(sum_k(2, in, nullptr, ldh, m->cls_in, ldh, N, H, s));
-            ADN_TRY(refresh(m, m->cls_in, (size_t)N * ldh));
+            ADN_TRY(sum_k(2, in, nullptr, ldh, m->cls_in, ldh, N, H, s, m->bf16() ? m->shadow_of(m->cls_in) : nullptr));
             cls = m->cls_in;
         } else {
             cls = m->aggw[0].out(B, ldh, false);
@@ -1074,8 +1122,8 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
         ADN_TRY(mgemm(m, g));
     }
     ADN_TRY(softmax_loss(m->z, m->ldc, B, T, m->C, m->mask_tb, want_loss ? m->y_bt : nullptr, m->total, m->probs_bt,
-                         want_loss ? m->row_loss : nullptr, want_dz ? m->dz : nullptr, m->ldc, s));
-    if (want_dz) ADN_TRY(refresh(m, m->dz, (size_t)N * m->ldc));
+                         want_loss ? m->row_loss : nullptr, want_dz ? m->dz : nullptr, m->ldc, s,
+                         (want_dz && m->bf16()) ? m->shadow_of(m->dz) : nullptr));      // (pad columns of dz stay zero in both copies)
     if (want_loss) ADN_TRY(reduce_loss(m->row_loss, N, m->total, m->loss, s));
     m->lastB = B; m->lastT = T;
     return ADN_OK;

@@ -296,6 +296,9 @@ class AdeNetModel(object):
                              % (self.S, " + %d auxiliary inputs" % len(self.aux_dims) if self.aux_dims else "", len(inputs)))
         inputs = self._apply_front_ends(inputs)
         dev = self._is_device(inputs[0])
+        # bfloat16 torch tensors (all inputs) go to the library as they are (ADN_FLAG_BF16_INPUTS): in bf16 mode the first
+        # encoder GEMM reads a device array in place
+        in16 = all(hasattr(x, "dtype") and str(x.dtype) == "torch.bfloat16" for x in inputs)
         keep = []
         ptrs = (C.c_void_p * n_in)()
         shape = None
@@ -303,7 +306,10 @@ class AdeNetModel(object):
         for k, x in enumerate(inputs):
             if self._is_device(x) != dev:
                 raise ValueError("all streams must live on the same side (host or device)")
-            if dev:
+            if in16:
+                x = x.contiguous()
+                p = x.data_ptr()
+            elif dev:
                 import torch
                 if x.dtype != torch.float32 or not x.is_contiguous():
                     x = x.to(torch.float32).contiguous()
@@ -343,7 +349,7 @@ class AdeNetModel(object):
             import torch
             raw = torch.cuda.current_stream().cuda_stream
             _lib.check(self._lib.adn_set_stream(self._handle, C.c_void_p(int(raw))))
-        flags = _lib.FLAG_DEVICE_INPUTS if dev else 0
+        flags = (_lib.FLAG_DEVICE_INPUTS if dev else 0) | (_lib.FLAG_BF16_INPUTS if in16 else 0)
         return ptrs, mp, tp, B, T, flags, keep
 
     def predict(self, inputs, mask, window):
