@@ -103,6 +103,16 @@ struct GemmArgs {
     // bf16 kernels with shadows only: C may be null when C16 is given (the fp32 copy is simply not written; the
     // launch is then never split over K), and Y16 may replace Y (bf16 copy of the activation, same ld)
     const void* Y16 = nullptr;
+    // bf16x3 mode: the lo planes of A and B (bf16(x - bf16(x)), layouts of A16 / B16, which then hold the hi planes).  With all
+    // four planes at hand the product runs over the planes (three K-segments in the ping-pong kernel) instead of over split
+    // images made for this one launch
+    const void* A16lo = nullptr; const void* B16lo = nullptr;
+    // ... for an NT problem (B given as [N][K]): planes of B^T ([K][ldbT], k-strided), with which the product runs as NN
+    const void* BT16 = nullptr; const void* BT16lo = nullptr; int ldbT = 0;
+    // ... and the result's own planes: C16 (hi) and C16lo, written by the kernel that multiplies over planes; *planes_done reports
+    // whether they were (otherwise the caller splits C itself)
+    void* C16lo = nullptr; int* planes_done = nullptr;
+    int lean_ok = 0;               // ... and nobody reads the fp32 C then: the kernel that writes both planes skips it
     // split-K workspace of the persistent ping-pong kernel (partial tiles as plain stores + a reduce pass instead of
     // float atomics); without it large weight-gradient GEMMs stay on the atomic split-K kernels
     float* splitk_ws = nullptr; size_t splitk_ws_floats = 0;
@@ -112,6 +122,7 @@ constexpr int kMaxGemmGroups = 4;
 // n <= kMaxGemmGroups problems of identical shape, layout and flags (different buffers) as ONE launch where the persistent kernel
 // applies (their tiles share one list: fuller last round); otherwise n launches
 int gemm_grouped(const GemmArgs* g, int n, hipStream_t stream);
+bool gemm_planes_would_run(const GemmArgs* g, int n);      // bf16x3: would these problems run over their hi / lo planes?
 // dst[i] = bf16(src[i]), n a multiple of 8
 int to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 // out[c * ldT + r] = bf16(W[r * ld + c]) for r < rows, c < cols (LDS-tiled transpose)
@@ -124,7 +135,8 @@ int col_sum_batch(ColSumBatch& b, hipStream_t s);          // launches (if any i
 
 // the same for a table of matrices in ONE launch (items: device array; block_end[k] = running total of 32x32 tiles)
 struct TransposeItem { const float* W; void* out; int rows, cols, ld, ldT, block_end; };
-int transpose_to_bf16_batch(const TransposeItem* dev_items, int n, int total_blocks, hipStream_t s);
+int transpose_to_bf16_batch(const TransposeItem* dev_items, int n, int total_blocks, hipStream_t s, int lo_part = 0);
+int split_hilo(const float* src, void* hi, void* lo, size_t n, hipStream_t s);   // fp32 -> the bf16x3 mode's two planes
 
 // ---------------------------------------------------------------------------------------
 // element-wise / HBM-bound kernels (elementwise.hip)
@@ -228,6 +240,7 @@ struct LstmStep {          // one LSTM instance taking part in a (possibly multi
     const void* W_frag_bwd_lo = nullptr;   // ... of the backward image
     void* h16;             // [(T+1)*B][ldh] bf16 shadow of hbuf
     void* dG16;            // [T*B][ldg]     bf16 shadow of dG
+    void* dG16lo = nullptr;  // bf16x3 mode: with dG16 the hi / lo planes of dG, written by the weight-stationary backward kernel
     void* xchg = nullptr;  // exchange buffer of the weight-stationary kernels (lstm_cluster.hip), lstm_cluster_xchg_bytes(B)
     // optional (backward): gradients that are plain sums of what the kernel already holds in registers -- the bias
     // (column sums of dG over all frames) and the learnt initial state (sums of dh_carry / dc_state over the batch).
@@ -247,6 +260,7 @@ size_t lstm_frag_elems(int H);
 int lstm_pack_frags(const float* W, void* fwd, void* bwd, int H, hipStream_t s);
 // the same for n <= 8 LSTMs in one launch
 int lstm_pack_frags_batch(int n, const float* const* W, void* const* fwd, void* const* bwd, int H, hipStream_t s, int lo_part = 0);
+int repack_rows_bf16_lo(int n, const float* const* in, void* const* out, int nblk, int rows, int rows_pad, int ld, hipStream_t s);
 int repack_rows_bf16(int n, const float* const* in, void* const* out, int nblk, int rows, int rows_pad, int ld, hipStream_t s);
 int lstm_forward_persistent(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
 int lstm_backward_persistent(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s,

@@ -335,7 +335,7 @@ int col_sum_batch(ColSumBatch& b, hipStream_t s) {
 // bf16 copies of up to 4 weight matrices [nblk * rows][ld] with every block of `rows` rows re-spaced to `rows_pad` rows
 // (the K-padding of the concatenated-input GEMM); one launch, pointers by value
 struct RepackArgs { const float* in[4]; void* out[4]; };
-__global__ __launch_bounds__(256) void repack_rows_bf16_kernel(RepackArgs a, int nblk, int rows, int rows_pad, int ld) {
+__global__ __launch_bounds__(256) void repack_rows_bf16_kernel(RepackArgs a, int nblk, int rows, int rows_pad, int ld, int lo_part) {
     const float* in = a.in[blockIdx.y];
     __bf16* out = reinterpret_cast<__bf16*>(a.out[blockIdx.y]);
     const int ld4 = ld / 4;
@@ -344,19 +344,30 @@ __global__ __launch_bounds__(256) void repack_rows_bf16_kernel(RepackArgs a, int
         const int c = (int)(e % ld4), r = (int)(e / ld4), j = r / rows, k = r % rows;
         const float4 v = reinterpret_cast<const float4*>(in)[(size_t)r * ld4 + c];
         __bf16 o[4] = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        if (lo_part) {                       // the bf16x3 mode's second plane: bf16(v - bf16(v))
+            o[0] = (__bf16)(v.x - (float)o[0]); o[1] = (__bf16)(v.y - (float)o[1]);
+            o[2] = (__bf16)(v.z - (float)o[2]); o[3] = (__bf16)(v.w - (float)o[3]);
+        }
         *reinterpret_cast<uint2*>(out + ((size_t)(j * rows_pad + k) * ld + 4 * c)) = *reinterpret_cast<const uint2*>(o);
     }
 }
 
-int repack_rows_bf16(int n, const float* const* in, void* const* out, int nblk, int rows, int rows_pad, int ld, hipStream_t s) {
+static int repack_rows_impl(int n, const float* const* in, void* const* out, int nblk, int rows, int rows_pad, int ld, hipStream_t s,
+                            int lo_part) {
     ADN_CHECK(n >= 1 && n <= 4 && ld % 4 == 0 && rows_pad >= rows, ADN_ERR_INVALID, "repack_rows_bf16: bad shape");
     RepackArgs a{};
     for (int j = 0; j < n; ++j) { a.in[j] = in[j]; a.out[j] = out[j]; }
     const int64_t total = (int64_t)nblk * rows * (ld / 4);
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, 2048));
-    hipLaunchKernelGGL(repack_rows_bf16_kernel, dim3(grid, n), dim3(256), 0, s, a, nblk, rows, rows_pad, ld);
+    hipLaunchKernelGGL(repack_rows_bf16_kernel, dim3(grid, n), dim3(256), 0, s, a, nblk, rows, rows_pad, ld, lo_part);
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
+}
+int repack_rows_bf16(int n, const float* const* in, void* const* out, int nblk, int rows, int rows_pad, int ld, hipStream_t s) {
+    return repack_rows_impl(n, in, out, nblk, rows, rows_pad, ld, s, 0);
+}
+int repack_rows_bf16_lo(int n, const float* const* in, void* const* out, int nblk, int rows, int rows_pad, int ld, hipStream_t s) {
+    return repack_rows_impl(n, in, out, nblk, rows, rows_pad, ld, s, 1);
 }
 
 // out[r][j * cols + c] = in_j[r][c]  (bf16; cols a multiple of 8): the materialised concat of up to 4 matrices

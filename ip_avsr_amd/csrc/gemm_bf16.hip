@@ -41,6 +41,13 @@ __device__ __forceinline__ bf16x8 join(const bf16x4 lo, const bf16x4 hi) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi)  (bf16x3 mode)
+__device__ __forceinline__ void split4(const float4& v, bf16x4& hi, bf16x4& lo) {
+    hi = cvt4(v);
+    const float4 r = make_float4(v.x - (float)hi[0], v.y - (float)hi[1], v.z - (float)hi[2], v.w - (float)hi[3]);
+    lo = cvt4(r);
+}
+
 // ---- k-contiguous operand: global [R][K] fp32 -------------------------------------------------------
 template <int R, typename T, int NT>
 struct StageKC;
@@ -757,6 +764,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
         grp = q / per_group;
         tile_coords(p, q - grp * per_group, tm, tn);
     };
+    // bf16x3 through hi / lo PLANES (p.kseg > 0): K runs over three segments of p.kseg (a multiple of BK) -- A_hi B_hi, A_hi B_lo,
+    // A_lo B_hi -- read from the two bf16 planes of each operand (same layout, written once by the operand's producer) instead of
+    // from [hi | hi | lo] / [hi ; lo ; hi] images made per use.  Only the DMA cursors know: a tile keeps its four plane bases
+    // and counts the stages to the next segment boundary.
+    const int kseg_steps = p.kseg / BK;
+    const char *segA_hi = nullptr, *segA_lo = nullptr, *segB_hi = nullptr, *segB_lo = nullptr;
+    int seg_cur = 0, seg_left = 0;
     auto setup_src = [&](int ord) {
         int grp, tm, tn;
         tile_of(ord, grp, tm, tn);
@@ -764,8 +778,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
         const char* A16 = reinterpret_cast<const char*>(sg.A16);
         const char* B16 = reinterpret_cast<const char*>(sg.B16);
         const int m0 = tm * BM, n0 = tn * BN;
-        baseA = A_KC ? A16 + ((size_t)m0 * p.lda + kbeg) * 2 : A16 + (size_t)kbeg * p.lda * 2;
-        baseB = B16 + (size_t)kbeg * p.ldb * 2;
+        int kin = kbeg;
+        if (p.kseg) {
+            seg_cur = kbeg / p.kseg; kin = kbeg - seg_cur * p.kseg; seg_left = kseg_steps - kin / BK;
+            segA_hi = A_KC ? A16 + (size_t)m0 * p.lda * 2 : A16;
+            segA_lo = reinterpret_cast<const char*>(sg.A16lo) + (segA_hi - A16);
+            segB_hi = B16; segB_lo = reinterpret_cast<const char*>(sg.B16lo);
+            A16 = seg_cur == 2 ? reinterpret_cast<const char*>(sg.A16lo) : A16;
+            B16 = seg_cur == 1 ? segB_lo : B16;
+        }
+        baseA = A_KC ? A16 + ((size_t)m0 * p.lda + kin) * 2 : A16 + (size_t)kin * p.lda * 2;
+        baseB = B16 + (size_t)kin * p.ldb * 2;
 #pragma unroll
         for (int t = 0; t < APW; ++t) {
             if (A_KC) {
@@ -817,6 +840,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
             }
         }
         baseA += a_step; baseB += b_step;
+        if (p.kseg && --seg_left == 0) {                           // next stage opens the next segment
+            ++seg_cur; seg_left = kseg_steps;
+            baseA = seg_cur == 2 ? segA_lo : segA_hi;
+            baseB = seg_cur == 1 ? segB_lo : segB_hi;
+        }
     };
     auto issue_next = [&]() {
         if (has_tail && is_k == nk - 1) issue_one(std::true_type{});
@@ -842,10 +870,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
         b_off[b] = lds_base + NS * kAElems * 2 + (hi * 8 + q) * (BN * 2) + ((((wn * WTN + b * 16) / 8 + (pp >> 1)) ^ (g_lane << 1)) << 4) + (pp & 1) * 8;
     // k >= K mask of an A fragment in the last stage: element j of this lane is k = 8 hi + j
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    // (planes: every segment ends with the same partial stage when the real K is not a multiple of BK -- the A operand's
+    //  columns behind K may hold anything, e.g. a wider earlier use of a reused gradient buffer)
+    const int ktail_m = p.kseg ? p.kreal - (p.kseg - BK) : ktail;
+    const bool seg_tail = p.kseg && ktail_m < BK;
     u32x4 amask;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        amask[j] = ((8 * hi + 2 * j < ktail) ? 0x0000FFFFu : 0u) | ((8 * hi + 2 * j + 1 < ktail) ? 0xFFFF0000u : 0u);
+        amask[j] = ((8 * hi + 2 * j < ktail_m) ? 0x0000FFFFu : 0u) | ((8 * hi + 2 * j + 1 < ktail_m) ? 0xFFFF0000u : 0u);
 
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -877,6 +909,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
     int kt = 0, ord = 0;
     int grp, tile_m, tile_n;
     tile_of(0, grp, tile_m, tile_n);
+    const int cseg_first = p.kseg ? kseg_steps - (kbeg % p.kseg) / BK : 0;      // K-steps to the first segment boundary of a tile
+    int cseg_left = cseg_first;
     GSTAMP_INIT
     typedef __attribute__((address_space(3))) bf16x8 lds_bf16x8;
     bf16x8 fa[TM], fb[TN];
@@ -917,10 +951,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         GSTAMP(2);
-        if (has_tail && kt == nk - 1) {
+        if ((has_tail && kt == nk - 1) || (seg_tail && cseg_left == 1)) {
 #pragma unroll
             for (int a = 0; a < TM; ++a) fa[a] = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4, fa[a]) & amask);
         }
+        if (p.kseg && --cseg_left == 0) cseg_left = kseg_steps;
         wait_next(s, kt == 0 && s > 0);
         GSTAMP(3);
         if (!one || late) __builtin_amdgcn_s_barrier();
@@ -980,6 +1015,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
                         __bf16* dst = reinterpret_cast<__bf16*>(gp.C16) + (size_t)row * p.ldc + cs;
                         if (rok && cs + 8 <= p.N) *reinterpret_cast<uint4*>(dst) = out;
                         else if (rok && cs + 4 <= p.N) *reinterpret_cast<uint2*>(dst) = make_uint2(out.x, out.y);
+                        if (gp.C16lo) {                              // bf16x3: the lo plane bf16(v - bf16(v)) beside it, same exchange
+                            const bf16x4 hA = __builtin_bit_cast(bf16x4, pA), hB = __builtin_bit_cast(bf16x4, pB);
+                            const float4 rA = make_float4(vA.x - (float)hA[0], vA.y - (float)hA[1], vA.z - (float)hA[2], vA.w - (float)hA[3]);
+                            const float4 rB = make_float4(vB.x - (float)hB[0], vB.y - (float)hB[1], vB.z - (float)hB[2], vB.w - (float)hB[3]);
+                            const uint2 qA = __builtin_bit_cast(uint2, cvt4(rA)), qB = __builtin_bit_cast(uint2, cvt4(rB));
+                            const uint2 giv = odd ? qA : qB;
+                            uint2 tk;
+                            tk.x = __shfl_xor(giv.x, 16, 64); tk.y = __shfl_xor(giv.y, 16, 64);
+                            const uint4 outl = odd ? make_uint4(tk.x, tk.y, qB.x, qB.y) : make_uint4(qA.x, qA.y, tk.x, tk.y);
+                            __bf16* dl = reinterpret_cast<__bf16*>(gp.C16lo) + (size_t)row * p.ldc + cs;
+                            if (rok && cs + 8 <= p.N) *reinterpret_cast<uint4*>(dl) = outl;
+                            else if (rok && cs + 4 <= p.N) *reinterpret_cast<uint2*>(dl) = make_uint2(outl.x, outl.y);
+                        }
                     }
                 }
                 if (!SPLIT && gp.colsum) {                         // column sums over this wave's WTM rows
@@ -1004,6 +1052,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
                 for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (++ord < my_tiles) tile_of(ord, grp, tile_m, tile_n);
             kt = 0;
+            cseg_left = cseg_first;
         } else {
             ++kt;
         }
@@ -1529,7 +1578,7 @@ int transpose_to_bf16(const float* W, int rows, int cols, int ld, void* out, int
     return ADN_OK;
 }
 
-__global__ __launch_bounds__(256) void transpose_bf16_batch_kernel(const TransposeItem* __restrict__ items, int n) {
+__global__ __launch_bounds__(256) void transpose_bf16_batch_kernel(const TransposeItem* __restrict__ items, int n, int lo_part) {
     __shared__ float tile[32][33];
     int k = 0;
     while (k + 1 < n && (int)blockIdx.x >= items[k].block_end) ++k;
@@ -1546,13 +1595,39 @@ __global__ __launch_bounds__(256) void transpose_bf16_batch_kernel(const Transpo
     __bf16* out = reinterpret_cast<__bf16*>(it.out);
     for (int j = ty; j < 32; j += 8) {
         const int c = c0 + j, r = r0 + tx;
-        if (c < it.cols && r < it.rows) out[(size_t)c * it.ldT + r] = (__bf16)tile[tx][j];
+        if (c < it.cols && r < it.rows) {
+            const float v = tile[tx][j];
+            const __bf16 h = (__bf16)v;
+            out[(size_t)c * it.ldT + r] = lo_part ? (__bf16)(v - (float)h) : h;      // (lo_part: the bf16x3 mode's second plane)
+        }
     }
 }
 
-int transpose_to_bf16_batch(const TransposeItem* dev_items, int n, int total_blocks, hipStream_t s) {
+int transpose_to_bf16_batch(const TransposeItem* dev_items, int n, int total_blocks, hipStream_t s, int lo_part) {
     if (n <= 0 || total_blocks <= 0) return ADN_OK;
-    hipLaunchKernelGGL(transpose_bf16_batch_kernel, dim3(total_blocks), dim3(256), 0, s, dev_items, n);
+    hipLaunchKernelGGL(transpose_bf16_batch_kernel, dim3(total_blocks), dim3(256), 0, s, dev_items, n, lo_part);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+// fp32 -> the two bf16 planes of the bf16x3 mode: hi = bf16(x), lo = bf16(x - hi); 8 elements per lane
+__global__ __launch_bounds__(256) void split_hilo_kernel(const float* __restrict__ src, __bf16* __restrict__ hi, __bf16* __restrict__ lo,
+                                                         size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+        bf16x4 ha, la, hb, lb;
+        split4(a, ha, la); split4(b, hb, lb);
+        reinterpret_cast<bf16x8*>(hi)[i] = join(ha, hb);
+        reinterpret_cast<bf16x8*>(lo)[i] = join(la, lb);
+    }
+}
+
+int split_hilo(const float* src, void* hi, void* lo, size_t n, hipStream_t s) {
+    ADN_CHECK(n % 8 == 0, ADN_ERR_INVALID, "split_hilo: element count must be a multiple of 8");
+    if (!n) return ADN_OK;
+    const size_t n8 = n / 8;
+    const int grid = (int)std::max<size_t>(1, std::min<size_t>((n8 + 255) / 256, 4096));
+    hipLaunchKernelGGL(split_hilo_kernel, dim3(grid), dim3(256), 0, s, src, reinterpret_cast<__bf16*>(hi), reinterpret_cast<__bf16*>(lo), n8);
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }
@@ -1575,12 +1650,6 @@ int to_bf16(const float* src, void* dst, size_t n, hipStream_t s) {
 // split images; the GEMM kernels above then run unchanged on them.
 //   lo_mask: bit s set = segment s holds the lo part (A: 0b100, B: 0b010)
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void split4(const float4& v, bf16x4& hi, bf16x4& lo) {
-    hi = cvt4(v);
-    const float4 r = make_float4(v.x - (float)hi[0], v.y - (float)hi[1], v.z - (float)hi[2], v.w - (float)hi[3]);
-    lo = cvt4(r);
-}
-
 // k along the COLUMNS of src [rows][ld_src]: dst [rows][3 Kp], dst[r][s Kp + k]
 __global__ __launch_bounds__(256) void split3_cols_kernel(const float* __restrict__ src, int ld_src, int rows, int K, int Kp,
                                                           __bf16* __restrict__ dst, int lo_mask) {

@@ -10,6 +10,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // one problem of a grouped launch (gemm_bf16_pp_kernel): same shape, leading dimensions and flags, own buffers
 struct GemmGroup {
     const void* A16; const void* B16;
+    const void* A16lo; const void* B16lo;          // bf16x3 through planes (GemmParams::kseg > 0): the lo planes, layouts of A16 / B16
+    void* C16lo;                                   // ... and the lo plane of the result, written beside C16 (the hi plane)
     float* C; void* C16;
     const void* Y16; const float* Y;
     const float* bias;
@@ -34,6 +36,8 @@ struct GemmParams {
     int ngroups;
     int xcd_slices;     // split-K: K-slice = function of the workgroup's XCD (see the kernel)
     int one_barrier;    // ping-pong kernel: one s_barrier per K-step (halves offset inside the interval) instead of two
+    int kseg;           // ping-pong kernel, bf16x3 through hi / lo planes: k per segment (multiple of 32; K = 3 kseg); 0: plain
+    int kreal;          // ... and the real K of a segment (the last stage of every segment is masked behind it)
     float* partial;     // split-K partial slabs [group][split][M][ldc]
     GemmGroup grp[kMaxGemmGroups];
 };

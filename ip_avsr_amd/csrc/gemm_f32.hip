@@ -182,12 +182,32 @@ static int device_cus() {
 // Runs `n` problems of identical shape / layout / flags through the ping-pong kernel if it applies; *used says whether.
 // dry: only answer whether the kernel WOULD take the launch (no side effects)
 constexpr int kDefaultPpMode = 4;       // tile mode the selection uses unless ADN_GEMM_PP forces one (4: eight waves, 7: four waves)
+static int gemm_pp_try_impl(const GemmArgs* gs, int n, const GemmArgs& g, int kseg, hipStream_t stream, bool* used, bool dry);
 static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used, bool dry = false) {
     *used = false;
     const GemmArgs& g = gs[0];
     static const int mode_env = getenv("ADN_GEMM_PP") ? atoi(getenv("ADN_GEMM_PP")) : -1;   // 0: off, 4/5/6: force a tile shape
     if (mode_env == 0 || n > kMaxGemmGroups) return ADN_OK;
     if (g.precision != ADN_PRECISION_BF16 || g.layout == GEMM_NT) return ADN_OK;
+    // bf16x3 through hi / lo planes (see GemmArgs::A16lo): three K-segments of kseg = K rounded up to the kernel's K-step.
+    // The pad k of a k-contiguous A are its zero pad columns (lda >= kseg); k-strided operands have no pad: K % 32 == 0 then.
+    const bool planes = g.A16lo != nullptr || g.B16lo != nullptr;
+    const int kseg = planes ? (int)round_up(g.K, 32) : 0;
+    if (planes) {
+        if (!g.A16lo || !g.B16lo || !g.A16 || !g.B16) return ADN_OK;
+        // (NN: the partial last stage of a segment is masked in the A fragments -- the columns of A behind K may hold anything;
+        //  the k-strided B is then read up to 31 rows past K: finite values of the next tensor or zero slack, times zero.
+        //  TN: both operands are k-strided and neither is masked: K % 32 == 0 there, or the image path)
+        if (g.layout != GEMM_NN && g.K % 32 != 0) return ADN_OK;
+        if (mode_env == 7) return ADN_OK;         // (the experimental four-wave kernel has no segment cursors)
+    }
+    GemmArgs gv = g;                              // the problem the tile / split heuristics see: K = all three segments
+    if (planes) gv.K = 3 * kseg;
+    return gemm_pp_try_impl(gs, n, gv, kseg, stream, used, dry);
+}
+
+static int gemm_pp_try_impl(const GemmArgs* gs, int n, const GemmArgs& g, int kseg, hipStream_t stream, bool* used, bool dry) {
+    static const int mode_env = getenv("ADN_GEMM_PP") ? atoi(getenv("ADN_GEMM_PP")) : -1;
     // (one output of < 256 rows wastes too much of its 256-row tiles; several of them in one launch still win: three
     //  250 x 1000 x 20800 weight gradients 66 against 3 x 33 us, three 150 x 1000 62 against 3 x 30)
     if (g.M < (n >= 2 ? 128 : 256) || g.N < 256 || g.K < 256) return ADN_OK;
@@ -202,7 +222,8 @@ static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used
         if (!q.C && !q.C16) return ADN_OK;
         if ((q.C && ((uintptr_t)q.C % 16)) || (q.C16 && (((uintptr_t)q.C16 % 16) || g.ldc % 8))) return ADN_OK;
         if ((q.Y && ((uintptr_t)q.Y % 16)) || (q.Y16 && ((uintptr_t)q.Y16 % 8)) || (q.bias && ((uintptr_t)q.bias % 16))) return ADN_OK;
-        if (q.M != g.M || q.N != g.N || q.K != g.K || q.lda != g.lda || q.ldb != g.ldb || q.ldc != g.ldc || q.ldy != g.ldy ||
+        if ((q.A16lo == nullptr) != (gs[0].A16lo == nullptr) || (q.B16lo == nullptr) != (gs[0].B16lo == nullptr)) return ADN_OK;
+        if (q.M != g.M || q.N != g.N || q.K != gs[0].K || q.lda != g.lda || q.ldb != g.ldb || q.ldc != g.ldc || q.ldy != g.ldy ||
             q.layout != g.layout || q.act != g.act || q.act_grad != g.act_grad || q.accumulate != g.accumulate ||
             q.no_split != g.no_split || (q.C == nullptr) != (g.C == nullptr) || (q.C16 == nullptr) != (g.C16 == nullptr) ||
             (q.bias == nullptr) != (g.bias == nullptr) || (q.Y16 == nullptr) != (g.Y16 == nullptr) ||
@@ -250,7 +271,9 @@ static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used
         //  against 3 x 120 with 6 slabs each -- the same GEMM time and a third of the reduce traffic)
         const bool wgrad = splits > 1 && (int64_t)g.M * g.N * n >= 400000 &&
                            (n == 1 || per_group_tiles <= 16 || per_group_tiles * n * splits * 10 >= (int64_t)cus * 9);
-        const bool fwd_group = splits == 1 && plain && !g.accumulate && fill >= 0.80;      // (accumulate: the epilogue would read C back)
+        // (accumulate: the epilogue would read C back -- bf16 mode leaves those to the register-staged kernel; over planes the
+        //  alternative is a split pass per operand, so the ping-pong kernel takes them)
+        const bool fwd_group = splits == 1 && plain && (!g.accumulate || kseg) && fill >= (kseg ? 0.60 : 0.80);
         // input-gradient GEMMs of several streams (act'(Y) mask from the bf16 copy, fused column sums): 445 against 3 x 153 us
         // for 20800 x 2000 x 1000, 178 against 3 x 59 for 20800 x 1000 x 500; one alone is no faster than the 128 x 128 kernel
         const bool bwd_group = splits == 1 && n >= 2 && g.Y16 && fill >= 0.85;
@@ -264,6 +287,7 @@ static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used
     p.act = g.act; p.act_grad = g.act_grad; p.accumulate = g.accumulate;
     static const int barriers_env = getenv("ADN_GEMM_PP_BARRIERS") ? atoi(getenv("ADN_GEMM_PP_BARRIERS")) : 1;   // 2: the two-barrier schedule
     p.one_barrier = barriers_env != 2;
+    p.kseg = kseg; p.kreal = gs[0].K;
     p.tiles_m = cdiv(g.M, cd.bm); p.tiles_n = cdiv(g.N, cd.bn);
     p.k_chunk = (int)round_up(cdiv(g.K, splits), 32);
     splits = cdiv(g.K, p.k_chunk);
@@ -286,6 +310,12 @@ static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used
     for (int k = 0; k < n; ++k) {
         GemmGroup& q = p.grp[k];
         q.A16 = gs[k].A16; q.B16 = gs[k].B16; q.C = gs[k].C; q.C16 = splits > 1 ? nullptr : gs[k].C16;
+        q.A16lo = kseg ? gs[k].A16lo : nullptr; q.B16lo = kseg ? gs[k].B16lo : nullptr;
+        q.C16lo = (kseg && splits == 1 && q.C16) ? gs[k].C16lo : nullptr;
+        if (gs[k].planes_done) *gs[k].planes_done = q.C16lo ? 1 : 0;
+        // (planes: the fp32 copy of a result every reader takes from its planes is not written -- unless the bias gradient
+        //  that rides on this launch could not be fused and will be summed from the fp32 values)
+        if (q.C16lo && gs[k].lean_ok && !g.accumulate && (!g.colsum || fused_colsum)) q.C = nullptr;
         q.Y16 = (g.act_grad == ADN_ACT_RECTIFY) ? gs[k].Y16 : nullptr; q.Y = nullptr; q.bias = gs[k].bias;
         q.colsum = fused_colsum ? gs[k].colsum_ws : nullptr;
         if (gs[k].colsum_done) *gs[k].colsum_done = fused_colsum ? 1 : 0;
@@ -302,9 +332,9 @@ static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used
     } else if (gx >= 8) gx = gx / 8 * 8;      // a workgroup's tiles then stay on its own XCD's chunk of the tile list
     static const bool trace = getenv("ADN_GEMM_TRACE") != nullptr;
     if (trace)
-        fprintf(stderr, "ADN_GEMM %s M=%d N=%d K=%d tile=%d tiles=%lld split=%d shadows=1 lean=%d acc=%d groups=%d\n",
+        fprintf(stderr, "ADN_GEMM %s M=%d N=%d K=%d tile=%d tiles=%lld split=%d shadows=1 lean=%d acc=%d groups=%d%s\n",
                 g.layout == GEMM_NN ? "NN" : "TN", g.M, g.N, g.K, cd.bm * 1000 + cd.bn, (long long)tiles, splits, (int)lean_c,
-                g.accumulate, n);
+                g.accumulate, n, kseg ? " planes=1" : "");
     {
         ProfScope prof(PROF_GEMM_NN + g.layout, 2.0 * g.M * g.N * g.K * n,
                        4.0 * n * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N), stream, n);
@@ -327,13 +357,29 @@ static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used
 }
 
 static bool x3_takes(const GemmArgs& g);
+static int gemm_bf16x3_images(const GemmArgs& g, hipStream_t stream);
+static int x3_try_planes(const GemmArgs* gs, int n, hipStream_t stream, bool* used, bool dry);
 static int gemm_grouped_bf16x3(const GemmArgs* gs, int n, hipStream_t stream);
 static int gemm_rs(const GemmArgs* gs, int n, hipStream_t stream);
 static bool rs_groupable(const GemmArgs* gs, int n);
 
+// would gemm_grouped() multiply these n problems over their hi / lo planes (bf16x3 mode)?  model.hip asks before it builds
+// operands that exist only as planes (the materialised concat)
+bool gemm_planes_would_run(const GemmArgs* gs, int n) {
+    bool used = false;
+    if (n < 1 || n > kMaxGemmGroups) return false;
+    if (x3_try_planes(gs, n, nullptr, &used, /*dry=*/true) != ADN_OK) return false;
+    return used;
+}
+
 int gemm_grouped(const GemmArgs* gs, int n, hipStream_t stream) {
     if (n <= 0) return ADN_OK;
     if (gs[0].M <= 0 || gs[0].N <= 0) return ADN_OK;
+    if (n >= 1 && n <= kMaxGemmGroups && gs[0].precision == ADN_PRECISION_BF16X3) {       // over the operands' planes first
+        bool used = false;
+        ADN_TRY(x3_try_planes(gs, n, stream, &used, false));
+        if (used) return ADN_OK;
+    }
     if (n > 1 && n <= kMaxGemmGroups && gs[0].precision == ADN_PRECISION_BF16X3 && !getenv("ADN_X3_NO_GROUPS")) {
         bool all = true;
         for (int k = 0; k < n; ++k)
@@ -415,6 +461,7 @@ static int x3_split_operands(const GemmArgs& g, const X3Plan& p, void* A3, void*
     h->precision = ADN_PRECISION_BF16;
     if (p.b_transpose) h->layout = GEMM_NN;
     h->A16 = A3; h->B16 = B3; h->lda = p.lda3; h->ldb = p.ldb3; h->K = 3 * p.Kp;
+    h->A16lo = nullptr; h->B16lo = nullptr;
     // fp32 outputs; a bf16 copy of C / a bf16 mask only where the caller asked for them (rectifier masks: model.hip)
     h->C16 = g.C16; h->Y16 = (g.act_grad == ADN_ACT_RECTIFY) ? g.Y16 : nullptr;
     return ADN_OK;
@@ -428,7 +475,27 @@ static bool x3_takes(const GemmArgs& g) {
            g.ldb % 4 == 0 && ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0;
 }
 
-static int gemm_bf16x3(const GemmArgs& g, hipStream_t stream) {
+// the product over the operands' hi / lo planes (model.hip keeps them for every GEMM operand in this mode) where the ping-pong
+// kernel takes the shape; *used says whether.  No split passes, no workspace.
+static int x3_try_planes(const GemmArgs* gs, int n, hipStream_t stream, bool* used, bool dry) {
+    *used = false;
+    static const bool off = getenv("ADN_X3_NO_PLANES") != nullptr;
+    if (off) return ADN_OK;
+    GemmArgs h[kMaxGemmGroups];
+    for (int k = 0; k < n; ++k) {
+        h[k] = gs[k];
+        if (h[k].layout == GEMM_NT && h[k].BT16 && h[k].BT16lo) {        // dZ W^T over the planes of W^T
+            h[k].layout = GEMM_NN; h[k].B16 = h[k].BT16; h[k].B16lo = h[k].BT16lo; h[k].ldb = h[k].ldbT;
+        }
+        if (!h[k].A16 || !h[k].A16lo || !h[k].B16 || !h[k].B16lo) return ADN_OK;
+        h[k].precision = ADN_PRECISION_BF16;
+        h[k].Y16 = (gs[k].act_grad == ADN_ACT_RECTIFY) ? gs[k].Y16 : nullptr;
+    }
+    return gemm_pp_try(h, n, stream, used, dry);
+}
+
+// the product over split images of the fp32 operands, made for this launch in the stream's workspace
+static int gemm_bf16x3_images(const GemmArgs& g, hipStream_t stream) {
     const X3Plan p = x3_plan(g);
     void* ws = nullptr;
     ADN_TRY(x3_workspace(stream, p.a_bytes + p.b_bytes, &ws));
@@ -440,6 +507,20 @@ static int gemm_bf16x3(const GemmArgs& g, hipStream_t stream) {
 // n problems of one shape: every problem's images side by side in the stream's workspace, then ONE grouped bf16 launch
 // (the ping-pong kernel fills its rounds with the tiles of all of them) -- or, if that kernel declines, one launch each
 static int gemm_grouped_bf16x3(const GemmArgs* gs, int n, hipStream_t stream) {
+    {
+        bool used = false;
+        ADN_TRY(x3_try_planes(gs, n, stream, &used, false));
+        if (used) return ADN_OK;
+        // (a shape the ping-pong kernel takes alone but not as a group -- the 2000 x 1000 weight gradients: one by one over the planes)
+        ADN_TRY(x3_try_planes(gs, 1, stream, &used, /*dry=*/true));
+        if (used) {
+            for (int k = 0; k < n; ++k) {
+                ADN_TRY(x3_try_planes(gs + k, 1, stream, &used, false));
+                if (!used) ADN_TRY(gemm_bf16x3_images(gs[k], stream));
+            }
+            return ADN_OK;
+        }
+    }
     const X3Plan p = x3_plan(gs[0]);
     void* ws = nullptr;
     ADN_TRY(x3_workspace(stream, (size_t)n * (p.a_bytes + p.b_bytes), &ws));
@@ -613,7 +694,12 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
     if (g.M <= 0 || g.N <= 0) return ADN_OK;
     ADN_CHECK(g.K > 0, ADN_ERR_INVALID, "gemm: K must be positive");
     if (g.precision == ADN_PRECISION_BF16X3) {
-        if (x3_takes(g)) return gemm_bf16x3(g, stream);
+        {                                      // over the operands' planes wherever the ping-pong kernel takes the shape ...
+            bool used = false;
+            ADN_TRY(x3_try_planes(&g, 1, stream, &used, false));
+            if (used) return ADN_OK;
+        }
+        if (x3_takes(g)) return gemm_bf16x3_images(g, stream);      // ... over split images of the fp32 operands ... (else fp32 MFMA)
         GemmArgs h = g;
         h.precision = ADN_PRECISION_F32;
         h.C16 = nullptr; h.Y16 = nullptr;

@@ -1033,6 +1033,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_x3_kernel(const LstmClus
             dlo[2] = (__bf16)(dg.z - (float)dhi[2]); dlo[3] = (__bf16)(dg.w - (float)dhi[3]);
             *reinterpret_cast<bf16x4*>(&dgs_hi[row][ul * 4]) = dhi;
             *reinterpret_cast<bf16x4*>(&dgs_lo[row][ul * 4]) = dlo;
+
         }
         if (P.dpeep_part) {
             float si = pw_i, sf = pw_f, so = pw_o;

@@ -102,6 +102,7 @@ struct LstmParams {      // physical tensors (float offsets into the flat buffer
     char* wfrag_fwd = nullptr; // ... and the two MFMA-fragment-ordered copies the persistent kernels stream
     char* wfrag_bwd = nullptr;
     char* wcat16 = nullptr;    // concat consumers: bf16 W_in with every input block padded to ldh rows ([S*ldh][ldg])
+    char* wcat16lo = nullptr;  // ... its lo plane (bf16x3 mode)
     int fin = 0;
     size_t W_in = 0, W_hid = 0, b = 0, peep = 0, cell_init = 0, hid_init = 0;
     bool peepholes = false;
@@ -131,6 +132,7 @@ struct StreamState {
     const float* x = nullptr; int ldx = 0;     // staged input (batch-major)
     float* xstage = nullptr;
     void* x16 = nullptr;                       // bf16 copy of x when x is the caller's own device buffer
+    void* x16lo = nullptr;                     // ... and its lo plane (bf16x3 mode)
     std::vector<float*> act;                   // encoder activations (batch-major)
     float* feat = nullptr;                     // time-major LSTM input
     std::vector<LstmWork> lw;
@@ -205,15 +207,18 @@ struct adn_model {
     // concat fusion in bf16 mode: the aggregation LSTMs read ONE materialised [N][S*ldh] bf16 matrix, so their input
     // projection, dW_in and the gradient wrt the concat are one GEMM each per LSTM instead of S
     char* cat16 = nullptr; float* dcat = nullptr; float* wcat_tmp = nullptr; size_t wcat_tmp_slots = 1;
+    char* cat16lo = nullptr;           // bf16x3 mode: the concat's lo plane
+    bool cat_planes_ok = false;        // bf16x3 mode: the last forward pass took the concat path (all of its GEMMs run over planes)
     // partial slabs of the split-K weight-gradient GEMMs (gemm_bf16_pp_kernel): one workgroup = one 256 x 256 fp32 tile
     float* splitk_ws = nullptr; size_t splitk_ws_floats = 0;
     int lastB = 0, lastT = 0;
     Profiler prof;
     // bf16 shadow copies of every GEMM operand (bf16 mode): fp32 range -> bf16 buffer with the same layout
-    struct ShadowRange { const float* base; size_t n; char* shadow; };
+    struct ShadowRange { const float* base; size_t n; char* shadow; char* shadow_lo; };
     std::vector<ShadowRange> shadows;
     std::vector<const float*> fused_in;     // what the aggregation layer read in the last forward pass (after dropout)
     char* params16 = nullptr;
+    char* params16lo = nullptr;           // bf16x3 mode: bf16(p - bf16(p)), the lo plane of the parameter buffer (params16 = hi)
     bool params16_dirty = true;
     bool params16_values_fresh = false;   // Adam wrote the bf16 parameter shadow itself; only the derived images are stale
     void mark_params_dirty() { params16_dirty = true; params16_values_fresh = false; }
@@ -222,10 +227,17 @@ struct adn_model {
     struct TransW { const float* key; char* buf; int ldT; };
     std::vector<TransW> transw;
     char* transw_slab = nullptr;
+    size_t transw_slab_bytes = 0;               // one plane; bf16x3 mode keeps a second (lo) plane right behind it
     TransposeItem* transw_items = nullptr;      // device table for the one-launch refresh
+    TransposeItem* transw_items_lo = nullptr;   // ... of the lo planes
     int transw_blocks = 0;
     bool packed_for_persistent = false;         // which LSTM weight images the last refresh produced
     bool bf16() const { return cfg.precision == ADN_PRECISION_BF16; }
+    // bf16x3 mode keeps TWO bf16 planes (hi = bf16(x), lo = bf16(x - hi)) of every GEMM operand -- written once per tensor by a
+    // split pass behind its producer -- and its large GEMMs run over the planes (three K-segments in the ping-pong kernel)
+    // instead of over [hi | hi | lo] / [hi ; lo ; hi] images made for every single use (ADN_X3_NO_PLANES: the image path)
+    bool planes() const { return cfg.precision == ADN_PRECISION_BF16X3 && !getenv("ADN_X3_NO_PLANES"); }
+
     // bf16x3 mode is fp32 mode everywhere but inside gemm(): fp32 activations, no shadows, the fp32 recurrent kernels
     int lstm_precision() const { return bf16() ? ADN_PRECISION_BF16 : ADN_PRECISION_F32; }
     bool keep_fp32 = false;        // debug: also write the fp32 copies that bf16 mode normally skips
@@ -237,6 +249,16 @@ struct adn_model {
             if (st_.x16 && p == st_.x) return st_.x16;
         for (const auto& r : shadows)
             if (p >= r.base && p < r.base + r.n) return r.shadow + 2 * (size_t)(p - r.base);
+        return nullptr;
+    }
+    void* shadow_lo_of(const float* p) const {
+        if (!p) return nullptr;
+        if (p >= flat[ADN_BUF_PARAM] && p < flat[ADN_BUF_PARAM] + flat_floats)
+            return params16lo ? params16lo + 2 * (size_t)(p - flat[ADN_BUF_PARAM]) : nullptr;
+        for (const auto& st_ : st)
+            if (st_.x16lo && p == st_.x) return st_.x16lo;
+        for (const auto& r : shadows)
+            if (p >= r.base && p < r.base + r.n) return r.shadow_lo + 2 * (size_t)(p - r.base);
         return nullptr;
     }
 
@@ -406,7 +428,8 @@ float* take_shadowed(adn_model* m, Carver& cv, size_t floats) {
     floats = (size_t)round_up((int64_t)floats, 8);
     float* p = cv.take<float>(floats);
     char* sh = cv.take<char>(floats * 2);
-    if (p) m->shadows.push_back({p, floats, sh});
+    char* lo = cv.take<char>(floats * 2);
+    if (p) m->shadows.push_back({p, floats, sh, lo});
     return p;
 }
 
@@ -483,6 +506,7 @@ size_t carve(adn_model* m, char* base, int B, int T, bool host_inputs) {
     (void)maxw;
     if (m->cfg.fusion == ADN_FUSE_CONCAT && m->S > 1 && !m->agg.empty()) {
         m->cat16 = cv.take<char>(N * (size_t)m->S * ldh * 2);
+        m->cat16lo = cv.take<char>(N * (size_t)m->S * ldh * 2);
         m->dcat = cv.take<float>(N * (size_t)m->S * ldh);
         m->wcat_tmp_slots = std::max<size_t>(1, std::min<size_t>(m->agg.size(), kMaxGemmGroups));
         m->wcat_tmp = cv.take<float>(m->wcat_tmp_slots * (size_t)m->S * ldh * ldg);
@@ -543,7 +567,7 @@ int stage_inputs(adn_model* m, const void* const* inputs, const int32_t* targets
         StreamState& st = m->st[s];
         ADN_CHECK(inputs[s], ADN_ERR_INVALID, "null stream input");
         const int D = st.cfg.input_dim;
-        st.x16 = nullptr;
+        st.x16 = nullptr; st.x16lo = nullptr;
         if (in16) {
             // bf16 mode, an encoder in front (every consumer of the input is a GEMM reading bf16 operands): the caller's
             // device array IS the operand -- no copy, no conversion; st.x only names it (shadow_of), it is never read
@@ -575,6 +599,9 @@ int stage_inputs(adn_model* m, const void* const* inputs, const int32_t* targets
             if (m->bf16()) {                   // the staging buffer's shadow holds the bf16 copy (ld_of(D) == D)
                 st.x16 = m->shadow_of(st.xstage);
                 ADN_TRY(to_bf16(st.x, st.x16, N * (size_t)D, m->stream));
+            } else if (m->planes() && D % 8 == 0) {     // ... its two planes the hi / lo parts (dense rows of D, like x)
+                st.x16 = m->shadow_of(st.xstage); st.x16lo = m->shadow_lo_of(st.xstage);
+                ADN_TRY(split_hilo(st.x, st.x16, st.x16lo, N * (size_t)D, m->stream));
             }
         } else {
             const int ld = ld_of(D);
@@ -632,6 +659,25 @@ void mgemm_prepare(adn_model* m, GemmArgs& g, bool lean) {
         if (g.act == ADN_ACT_RECTIFY && g.C && !g.accumulate) g.C16 = m->shadow_of(g.C);
         if (g.Y && g.act_grad == ADN_ACT_RECTIFY) g.Y16 = m->shadow_of(g.Y);
     }
+    if (m->planes()) {
+        // every GEMM operand of this mode has its two planes (refresh() behind non-GEMM producers, planes_of_output() behind
+        // GEMMs, refresh_params_x3() for the weights): handed to gemm(), which multiplies over them where the ping-pong
+        // kernel takes the shape and otherwise falls back to split images of the fp32 operands
+        g.A16 = m->shadow_of(g.A); g.A16lo = m->shadow_lo_of(g.A);
+        g.B16 = m->shadow_of(g.B); g.B16lo = m->shadow_lo_of(g.B);
+        // (opt-in, ADN_X3_LEAN=1: skip the fp32 copy of a result whose planes the kernel writes -- only sound when EVERY reader of
+        //  that tensor runs over planes; a narrow next layer (the 50-unit bottleneck) reads fp32 through the image path, so the
+        //  default keeps the fp32 copies: measured 9.09 -> 8.81 ms per step at the bench geometry, with the bottleneck's input wrong)
+        g.lean_ok = lean && !m->keep_fp32 && getenv("ADN_X3_LEAN") != nullptr;
+        if (!g.A16 || !g.A16lo || !g.B16 || !g.B16lo) { g.A16 = g.B16 = g.A16lo = g.B16lo = nullptr; }
+        else if (g.layout == GEMM_NT) {                    // dX = dZ W^T: the transposed plane copies of W (k-strided B), offered
+                                                           // beside the NT operands -- gemm() switches to NN only if it uses them
+            g.B16 = g.B16lo = nullptr;
+            for (const auto& t : m->transw)
+                if (t.key == g.B) { g.BT16 = t.buf; g.BT16lo = t.buf + m->transw_slab_bytes; g.ldbT = t.ldT; break; }
+            if (!g.BT16) { g.A16 = g.A16lo = nullptr; }
+        }
+    }
     if (shadows_on(m)) {                                  // env switch: convert-in-flight reference path
         g.A16 = m->shadow_of(g.A);
         g.B16 = m->shadow_of(g.B);
@@ -645,17 +691,61 @@ void mgemm_prepare(adn_model* m, GemmArgs& g, bool lean) {
     }
 }
 
+int planes_of_output(adn_model* m, const GemmArgs& g);
+int m_gemm(adn_model* m, const GemmArgs& g);
 int mgemm(adn_model* m, GemmArgs& g, bool lean = false) {
     mgemm_prepare(m, g, lean);
-    return gemm(g, m->stream);
+    return m_gemm(m, g);
 }
+
+int m_gemm(adn_model* m, const GemmArgs& g);
+int m_gemm_grouped(adn_model* m, const GemmArgs* gs, int n);
 
 // bring the bf16 shadow of an fp32 matrix written by a non-GEMM kernel up to date (bf16 mode only)
 int refresh(adn_model* m, const float* p, size_t floats) {
+    if (m->planes()) {                                     // bf16x3: both planes
+        void* hi = m->shadow_of(p); void* lo = m->shadow_lo_of(p);
+        if (!hi || !lo) return ADN_OK;
+        return split_hilo(p, hi, lo, (size_t)round_up((int64_t)floats, 8), m->stream);
+    }
     if (!m->bf16()) return ADN_OK;
     void* sh = m->shadow_of(p);
     if (!sh) return ADN_OK;
     return to_bf16(p, sh, (size_t)round_up((int64_t)floats, 8), m->stream);
+}
+
+// bf16x3 through planes: the output of a GEMM that later GEMMs read gets its planes here (whole rows: the pad columns are
+// zero in fp32 and stay zero in both planes)
+int planes_of_output(adn_model* m, const GemmArgs& g) {
+    if (!m->planes() || !g.C || g.accumulate) return ADN_OK;
+    if (g.planes_done && *g.planes_done) return ADN_OK;             // the kernel wrote both planes in its epilogue
+    if (!m->shadow_of(g.C)) return ADN_OK;
+    return refresh(m, g.C, (size_t)g.M * g.ldc);
+}
+// (planes mode) offer the result's planes to the kernel: the ping-pong kernel writes them from its epilogue
+void offer_output_planes(adn_model* m, GemmArgs& g, int* done) {
+    *done = 0;
+    if (!m->planes() || !g.C || g.accumulate || g.ldc % 8) return;
+    void* hi = m->shadow_of(g.C); void* lo = m->shadow_lo_of(g.C);
+    if (!hi || !lo) return;
+    g.C16 = hi; g.C16lo = lo; g.planes_done = done;
+}
+int m_gemm(adn_model* m, const GemmArgs& g0) {
+    GemmArgs g = g0; int done = 0;
+    offer_output_planes(m, g, &done);
+    ADN_TRY(gemm(g, m->stream));
+    return planes_of_output(m, g);
+}
+int m_gemm_grouped(adn_model* m, const GemmArgs* gs0, int n) {
+    GemmArgs gs[kMaxGemmGroups]; int done[kMaxGemmGroups];
+    if (n > kMaxGemmGroups) {                                       // (never: the callers batch at most kMaxGemmGroups)
+        for (int k = 0; k < n; ++k) ADN_TRY(m_gemm(m, gs0[k]));
+        return ADN_OK;
+    }
+    for (int k = 0; k < n; ++k) { gs[k] = gs0[k]; offer_output_planes(m, gs[k], &done[k]); }
+    ADN_TRY(gemm_grouped(gs, n, m->stream));
+    for (int k = 0; k < n; ++k) ADN_TRY(planes_of_output(m, gs[k]));
+    return ADN_OK;
 }
 
 // W^T copies: encoder weights of layers >= 1, every LSTM's W_in (per input block), the classifier weights
@@ -679,8 +769,11 @@ int refresh_transposed(adn_model* m) {
         size_t bytes = 0;
         for (auto& it : items)
             if (it.col_off == 0) bytes += (size_t)round_up((int64_t)it.cols * it.ldT * 2, 256);
-        ADN_HIP_CHECK(hipMalloc((void**)&m->transw_slab, bytes));
-        ADN_HIP_CHECK(hipMemsetAsync(m->transw_slab, 0, bytes, m->stream));
+        // (two planes -- the second one only written in bf16x3 mode -- each with zero slack behind it: a k-strided operand is
+        //  read in whole 32-row stages)
+        m->transw_slab_bytes = (size_t)round_up((int64_t)(bytes + ((size_t)1 << 20)), 256);
+        ADN_HIP_CHECK(hipMalloc((void**)&m->transw_slab, 2 * m->transw_slab_bytes));
+        ADN_HIP_CHECK(hipMemsetAsync(m->transw_slab, 0, 2 * m->transw_slab_bytes, m->stream));
         size_t cur = 0; char* base = nullptr;
         for (auto& it : items) {
             if (it.col_off == 0) { base = m->transw_slab + cur; cur += (size_t)round_up((int64_t)it.cols * it.ldT * 2, 256); }
@@ -696,14 +789,54 @@ int refresh_transposed(adn_model* m) {
         }
         ADN_HIP_CHECK(hipMalloc((void**)&m->transw_items, tab.size() * sizeof(TransposeItem)));
         ADN_HIP_CHECK(hipMemcpy(m->transw_items, tab.data(), tab.size() * sizeof(TransposeItem), hipMemcpyHostToDevice));
+        for (auto& t : tab) t.out = static_cast<char*>(t.out) + m->transw_slab_bytes;        // the same table for the lo planes
+        ADN_HIP_CHECK(hipMalloc((void**)&m->transw_items_lo, tab.size() * sizeof(TransposeItem)));
+        ADN_HIP_CHECK(hipMemcpy(m->transw_items_lo, tab.data(), tab.size() * sizeof(TransposeItem), hipMemcpyHostToDevice));
         m->transw_blocks = total;
     }
-    return transpose_to_bf16_batch(m->transw_items, (int)items.size(), m->transw_blocks, m->stream);
+    ADN_TRY(transpose_to_bf16_batch(m->transw_items, (int)items.size(), m->transw_blocks, m->stream));
+    if (m->planes()) ADN_TRY(transpose_to_bf16_batch(m->transw_items_lo, (int)items.size(), m->transw_blocks, m->stream, 1));
+    return ADN_OK;
 }
 
 // bf16x3 mode: hi / lo fragment images of every W_hid for the weight-stationary kernels (H <= 256)
+int refresh_transposed(adn_model* m);
+constexpr size_t kPlaneSlack = (size_t)1 << 20;       // bytes behind a bf16 plane that k-strided stage reads may touch: zero
+int ensure_params16(adn_model* m) {
+    if (m->params16) return ADN_OK;
+    ADN_HIP_CHECK(hipMalloc((void**)&m->params16, m->flat_floats * 2 + kPlaneSlack));
+    ADN_HIP_CHECK(hipMemsetAsync(m->params16, 0, m->flat_floats * 2 + kPlaneSlack, m->stream));
+    return ADN_OK;
+}
 int refresh_params_x3(adn_model* m) {
-    if (m->H > 256 || !m->params16_dirty) return ADN_OK;
+    if (!m->params16_dirty) return ADN_OK;
+    if (m->planes()) {               // hi / lo planes of the whole parameter buffer + of the transposed copies (dX = dZ W^T as NN)
+        ADN_TRY(ensure_params16(m));
+        if (!m->params16lo) {        // (+ zero slack: a k-strided B operand is read in whole 32-row stages past a short last one)
+            ADN_HIP_CHECK(hipMalloc((void**)&m->params16lo, m->flat_floats * 2 + kPlaneSlack));
+            ADN_HIP_CHECK(hipMemsetAsync(m->params16lo, 0, m->flat_floats * 2 + kPlaneSlack, m->stream));
+        }
+        ADN_TRY(split_hilo(m->flat[ADN_BUF_PARAM], m->params16, m->params16lo, (size_t)round_up((int64_t)m->flat_floats, 8), m->stream));
+        ADN_TRY(refresh_transposed(m));
+        if (m->cfg.fusion == ADN_FUSE_CONCAT && m->S > 1 && m->S <= 4) {      // the concat consumers' padded W_in, both planes
+            const size_t blk = (size_t)m->ldh * m->ldg;
+            std::vector<const float*> win; std::vector<void*> whi, wlo;
+            for (auto& lp : m->agg) {
+                for (char** pl : {&lp.wcat16, &lp.wcat16lo})
+                    if (!*pl) {
+                        ADN_HIP_CHECK(hipMalloc((void**)pl, (size_t)m->S * blk * 2 + kPlaneSlack));
+                        ADN_HIP_CHECK(hipMemsetAsync(*pl, 0, (size_t)m->S * blk * 2 + kPlaneSlack, m->stream));
+                    }
+                win.push_back(m->P(lp.W_in)); whi.push_back(lp.wcat16); wlo.push_back(lp.wcat16lo);
+            }
+            for (size_t k0 = 0; k0 < win.size(); k0 += 4) {
+                const int nn = (int)std::min<size_t>(4, win.size() - k0);
+                ADN_TRY(repack_rows_bf16(nn, win.data() + k0, whi.data() + k0, m->S, m->H, m->ldh, m->ldg, m->stream));
+                ADN_TRY(repack_rows_bf16_lo(nn, win.data() + k0, wlo.data() + k0, m->S, m->H, m->ldh, m->ldg, m->stream));
+            }
+        }
+    }
+    if (m->H > 256) { m->params16_dirty = false; return ADN_OK; }
     std::vector<const float*> fw; std::vector<void*> fhi, flo, bhi, blo;
     auto add = [&](LstmParams& lp) -> int {
         if (!lp.wfrag_fwd) ADN_HIP_CHECK(hipMalloc((void**)&lp.wfrag_fwd, lstm_frag_elems(m->H) * 2));
@@ -733,7 +866,7 @@ int refresh_params(adn_model* m) {
     if (persistent != m->packed_for_persistent) m->params16_dirty = true;
     if (!m->params16_dirty) return ADN_OK;
     m->packed_for_persistent = persistent;
-    if (!m->params16) ADN_HIP_CHECK(hipMalloc((void**)&m->params16, m->flat_floats * 2));
+    ADN_TRY(ensure_params16(m));
     if (!m->params16_values_fresh) ADN_TRY(to_bf16(m->flat[ADN_BUF_PARAM], m->params16, m->flat_floats, m->stream));
     m->params16_values_fresh = false;
     std::vector<const float*> fw; std::vector<void*> ff, fb;       // fragment images to (re)build
@@ -764,8 +897,8 @@ int refresh_params(adn_model* m) {
         std::vector<const float*> win; std::vector<void*> wout;
         for (auto& lp : m->agg) {
             if (!lp.wcat16) {
-                ADN_HIP_CHECK(hipMalloc((void**)&lp.wcat16, (size_t)m->S * blk * 2));
-                ADN_HIP_CHECK(hipMemsetAsync(lp.wcat16, 0, (size_t)m->S * blk * 2, m->stream));
+                ADN_HIP_CHECK(hipMalloc((void**)&lp.wcat16, (size_t)m->S * blk * 2 + kPlaneSlack));
+                ADN_HIP_CHECK(hipMemsetAsync(lp.wcat16, 0, (size_t)m->S * blk * 2 + kPlaneSlack, m->stream));
             }
             win.push_back(m->P(lp.W_in)); wout.push_back(lp.wcat16);
         }
@@ -796,6 +929,9 @@ LstmStep make_step(const adn_model* m, const LstmParams& lp, const LstmWork& w, 
     s.W_hid16 = b16 ? m->shadow_of(m->P(lp.W_hid)) : nullptr;
     s.h16 = b16 ? m->shadow_of(w.hbuf) : nullptr;
     s.dG16 = b16 ? m->shadow_of(w.dG) : nullptr;
+    // (the planes of dG are made by a split pass behind the kernel: written from inside it -- 8-byte stores from the gate-math
+    //  lanes, or 16-byte stores from its LDS images one step later -- they cost the step 0.3 / 0.7 us of its 6.4: measured 0.52
+    //  -> 0.58 / 0.67 ms of backward LSTM time per train step against 0.19 ms of split passes, and the kernel below the 40 % line)
     s.xchg = (b16 || x3) ? w.xchg : nullptr;
     if (grads) { s.dbias = m->G(lp.b); s.dhid_init = m->G(lp.hid_init); s.dcell_init = m->G(lp.cell_init); }
     return s;
@@ -804,6 +940,7 @@ LstmStep make_step(const adn_model* m, const LstmParams& lp, const LstmWork& w, 
 // sums_done: the backward kernels already added the bias / initial-state gradients of every LSTM of the group
 int run_lstm_group(adn_model* m, std::vector<LstmStep>& steps, int B, int T, bool backward, bool* sums_done = nullptr) {
     bool all = true;
+    std::vector<char> planes_done(steps.size(), 0);
     for (size_t i = 0; i < steps.size(); i += kMaxLstmPerLaunch) {
         const int n = (int)std::min<size_t>(kMaxLstmPerLaunch, steps.size() - i);
         bool done = false;
@@ -813,8 +950,16 @@ int run_lstm_group(adn_model* m, std::vector<LstmStep>& steps, int B, int T, boo
         else ADN_TRY(lstm_forward(steps.data() + i, n, m->mask_tb, B, T, m->H,
                                   m->cfg.precision == ADN_PRECISION_BF16X3 ? ADN_PRECISION_BF16X3 : m->lstm_precision(), m->stream));
         all = all && done;
+        // (bf16x3: `done` <=> the weight-stationary hi / lo kernel ran, which also writes the planes of dG when they are offered)
+        for (int k = 0; k < n; ++k) planes_done[i + k] = backward && done && steps[i + k].dG16 && steps[i + k].dG16lo;
     }
     if (sums_done) *sums_done = backward && all;
+    if (m->planes())                 // (bf16 mode: the kernels write the 16-bit copies themselves)
+        for (size_t q = 0; q < steps.size(); ++q) {
+            const LstmStep& st_ = steps[q];
+            if (backward) { if (!planes_done[q]) ADN_TRY(refresh(m, st_.dG, (size_t)B * T * m->ldg)); }
+            else ADN_TRY(refresh(m, st_.hbuf, (size_t)(T + 1) * B * m->ldh));
+        }
     return ADN_OK;
 }
 
@@ -834,7 +979,7 @@ int issue_grouped(adn_model* m, std::vector<GemmArgs>& list) {
                 continue;
             batch[nb++] = b; done[j] = 1;
         }
-        ADN_TRY(gemm_grouped(batch, nb, m->stream));
+        ADN_TRY(m_gemm_grouped(m, batch, nb));
     }
     return ADN_OK;
 }
@@ -858,8 +1003,8 @@ int lstm_project(adn_model* m, const LstmParams& lp, const LstmWork& w, const fl
 
 // bf16 mode, concat fusion: the aggregation LSTMs consume one materialised [N][S*ldh] bf16 matrix
 bool cat_path(const adn_model* m) {
-    return shadows_on(m) && m->cfg.fusion == ADN_FUSE_CONCAT && m->S > 1 && m->S <= 4 && !m->agg.empty() && m->cat16 &&
-           !getenv("ADN_NO_CAT");
+    return (shadows_on(m) || m->planes()) && m->cfg.fusion == ADN_FUSE_CONCAT && m->S > 1 && m->S <= 4 && !m->agg.empty() &&
+           m->cat16 && !getenv("ADN_NO_CAT");
 }
 
 // x*W_in + b with x = the materialised concat (ONE GEMM, K = S*ldh; the pad rows of wcat16 are zero)
@@ -869,10 +1014,38 @@ GemmArgs lstm_project_cat_args(adn_model* m, const LstmParams& lp, const LstmWor
     g.A = reinterpret_cast<const float*>(m->cat16); g.lda = m->S * m->ldh;      // (only the bf16 operands are read)
     g.B = m->P(lp.W_in); g.ldb = m->ldg;
     g.A16 = m->cat16; g.B16 = lp.wcat16;
+    if (m->planes()) { g.A16lo = m->cat16lo; g.B16lo = lp.wcat16lo; }
     g.C = w.xproj; g.ldc = m->ldg; g.bias = m->P(lp.b);
     g.precision = m->cfg.precision;
     g.no_split = 1;                                              // forward pass: reproducible bits
     return g;
+}
+
+// the concat path's backward GEMMs of aggregation LSTM k: dW_in for all S blocks (cat^T dG into a scratch matrix), and
+// d(concat) (+)= dG W_in^T through the side-by-side W^T copies
+GemmArgs cat_dw_args(adn_model* m, size_t k, bool group_dw, int N) {
+    const int ldcat = m->S * m->ldh;
+    const LstmWork& w = m->aggw[k];
+    GemmArgs g;
+    g.layout = GEMM_TN; g.M = ldcat; g.N = 4 * m->H; g.K = N;
+    g.A = reinterpret_cast<const float*>(m->cat16); g.lda = ldcat; g.A16 = m->cat16;
+    g.B = w.dG; g.ldb = m->ldg; g.B16 = m->shadow_of(w.dG);
+    if (m->planes()) { g.A16lo = m->cat16lo; g.B16lo = m->shadow_lo_of(w.dG); }
+    g.C = m->wcat_tmp + (group_dw ? k * (size_t)ldcat * m->ldg : 0); g.ldc = m->ldg; g.precision = m->cfg.precision;
+    g.splitk_ws = m->splitk_ws; g.splitk_ws_floats = m->splitk_ws_floats;      // (main stream: before the fork)
+    return g;
+}
+GemmArgs cat_dx_args(adn_model* m, size_t k, int N) {
+    const int ldcat = m->S * m->ldh;
+    const LstmParams& lp = m->agg[k]; const LstmWork& w = m->aggw[k];
+    GemmArgs d;
+    d.layout = GEMM_NN; d.M = N; d.N = ldcat; d.K = 4 * m->H;
+    d.A = w.dG; d.lda = m->ldg; d.A16 = m->shadow_of(w.dG);
+    d.B = m->P(lp.W_in); d.ldb = ldcat;
+    for (const auto& t : m->transw) if (t.key == d.B) { d.B16 = t.buf; break; }
+    if (m->planes()) { d.A16lo = m->shadow_lo_of(w.dG); d.B16lo = d.B16 ? static_cast<const char*>(d.B16) + m->transw_slab_bytes : nullptr; }
+    d.C = m->dcat; d.ldc = ldcat; d.accumulate = k > 0; d.precision = m->cfg.precision;
+    return d;
 }
 
 int lstm_init_state(adn_model* m, const LstmParams& lp, const LstmWork& w, int B, int T) {
@@ -970,7 +1143,7 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
                         batch[nb++] = c; done[j] = 1;
                     }
                 }
-                ADN_TRY(gemm_grouped(batch, nb, m->stream));
+                ADN_TRY(m_gemm_grouped(m, batch, nb));
             }
         }
     }
@@ -979,7 +1152,7 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
         OnSideStream on(m, (int)(&st - m->st.data()));           // encoder, delta layer, input projection of this stream
         const float* a = st.x; int lda = st.ldx;
         for (int l = 0; l < st.cfg.n_enc; ++l) {
-            if (!grouped) { GemmArgs g = enc_gemm(st, l); ADN_TRY(gemm(g, m->stream)); }
+            if (!grouped) { GemmArgs g = enc_gemm(st, l); ADN_TRY(m_gemm(m, g)); }
             a = st.act[l]; lda = ld_of(st.cfg.enc_units[l]);
         }
         if (st.cfg.batchnorm) {                                  // BatchNormLayer on the (B*T, E) encoder output (adenet_v1.py:82)
@@ -1069,11 +1242,30 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
     const float* cls = nullptr;
     if (!m->agg.empty()) {                                       // custom/layers.py:55-80
         steps.clear();
-        const bool cat = cat_path(m) && (int)fin.size() == m->S;
+        bool cat = cat_path(m) && (int)fin.size() == m->S;
+        m->cat_planes_ok = false;
+        if (cat && m->planes()) {
+            // the concat exists only as planes: the path is taken when every GEMM that reads it (projection, weight gradient,
+            // input gradient with and without accumulation) runs over planes at this shape -- none may fall back to images
+            GemmArgs pr[kMaxGemmGroups];
+            const int np = (int)std::min<size_t>(m->agg.size(), kMaxGemmGroups);
+            for (int k = 0; k < np; ++k) pr[k] = lstm_project_cat_args(m, m->agg[k], m->aggw[k], N);
+            for (int k = 0; k < np; ++k) pr[k].precision = ADN_PRECISION_BF16X3;
+            cat = gemm_planes_would_run(pr, np) && m->agg.size() <= (size_t)kMaxGemmGroups;
+            const bool group_dw = m->agg.size() >= 2 && m->agg.size() <= m->wcat_tmp_slots;
+            for (int k = 0; k < np && cat; ++k) pr[k] = cat_dw_args(m, (size_t)k, group_dw, N);
+            cat = cat && gemm_planes_would_run(pr, group_dw ? np : 1);
+            for (size_t k = 0; k < m->agg.size() && cat; ++k) { GemmArgs d = cat_dx_args(m, k, N); cat = d.B16 && gemm_planes_would_run(&d, 1); }
+            m->cat_planes_ok = cat;
+        }
         if (cat) {
             const void* in16[4];
             for (int j = 0; j < m->S; ++j) in16[j] = m->shadow_of(fin[j]);
             ADN_TRY(concat_cols_bf16(m->S, in16, ldh, m->cat16, m->S * ldh, N, ldh, s));
+            if (m->planes()) {
+                for (int j = 0; j < m->S; ++j) in16[j] = m->shadow_lo_of(fin[j]);
+                ADN_TRY(concat_cols_bf16(m->S, in16, ldh, m->cat16lo, m->S * ldh, N, ldh, s));
+            }
         }
         if (cat) {                                               // the pair's projections share the concat: one grouped launch
             GemmArgs gs[kMaxGemmGroups];
@@ -1081,7 +1273,7 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
             while (k < m->agg.size()) {
                 int n = 0;
                 for (; k < m->agg.size() && n < kMaxGemmGroups; ++k) gs[n++] = lstm_project_cat_args(m, m->agg[k], m->aggw[k], N);
-                ADN_TRY(gemm_grouped(gs, n, s));
+                ADN_TRY(m_gemm_grouped(m, gs, n));
             }
         }
         for (size_t k = 0; k < m->agg.size(); ++k) {
@@ -1093,6 +1285,7 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
         if (m->agg.size() == 2) {
             const float* in[2] = {m->aggw[0].out(B, ldh, false), m->aggw[1].out(B, ldh, true)};
             ADN_TRY(sum_k(2, in, nullptr, ldh, m->cls_in, ldh, N, H, s, m->bf16() ? m->shadow_of(m->cls_in) : nullptr));
+            if (!m->bf16()) ADN_TRY(refresh(m, m->cls_in, (size_t)N * ldh));
             cls = m->cls_in;
         } else {
             cls = m->aggw[0].out(B, ldh, false);
@@ -1124,6 +1317,7 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
     ADN_TRY(softmax_loss(m->z, m->ldc, B, T, m->C, m->mask_tb, want_loss ? m->y_bt : nullptr, m->total, m->probs_bt,
                          want_loss ? m->row_loss : nullptr, want_dz ? m->dz : nullptr, m->ldc, s,
                          (want_dz && m->bf16()) ? m->shadow_of(m->dz) : nullptr));      // (pad columns of dz stay zero in both copies)
+    if (want_dz && !m->bf16()) ADN_TRY(refresh(m, m->dz, (size_t)N * m->ldc));
     if (want_loss) ADN_TRY(reduce_loss(m->row_loss, N, m->total, m->loss, s));
     m->lastB = B; m->lastT = T;
     return ADN_OK;
@@ -1183,7 +1377,7 @@ int lstm_param_grads_grouped(adn_model* m, const std::vector<LstmGradJob>& jobs,
                 else { g.M = H; g.A = jb.w->prev(B, ldh, jb.lp->backwards); g.lda = ldh; g.C = m->G(jb.lp->W_hid); }
                 mgemm_prepare(m, g, false);
             }
-            if (n) ADN_TRY(gemm_grouped(gs, n, m->stream));
+            if (n) ADN_TRY(m_gemm_grouped(m, gs, n));
         }
     }
     if (!sums_done)
@@ -1270,7 +1464,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         for (size_t k = 0; k < m->agg.size(); ++k) steps.push_back(make_step(m, m->agg[k], m->aggw[k], m->dcls, true));
         bool sums_done = false;
         ADN_TRY(run_lstm_group(m, steps, B, T, true, &sums_done));
-        const bool cat = cat_path(m) && (int)fin.size() == m->S && per_stream_fused;
+        const bool cat = cat_path(m) && (int)fin.size() == m->S && per_stream_fused && (!m->planes() || m->cat_planes_ok);
         for (auto& st : m->st) st.dout_ld = 0;
         if (cat) {
             const int ldcat = m->S * ldh;
@@ -1280,13 +1474,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             const bool group_dw = m->agg.size() >= 2 && m->agg.size() <= (size_t)kMaxGemmGroups && m->agg.size() <= m->wcat_tmp_slots;
             GemmArgs dws[kMaxGemmGroups];
             for (size_t k = 0; k < m->agg.size(); ++k) {
-                const LstmWork& w = m->aggw[k];
-                GemmArgs g;
-                g.layout = GEMM_TN; g.M = ldcat; g.N = 4 * H; g.K = N;
-                g.A = reinterpret_cast<const float*>(m->cat16); g.lda = ldcat; g.A16 = m->cat16;
-                g.B = w.dG; g.ldb = m->ldg; g.B16 = m->shadow_of(w.dG);
-                g.C = m->wcat_tmp + (group_dw ? k * wcat_elems : 0); g.ldc = m->ldg; g.precision = m->cfg.precision;
-                g.splitk_ws = m->splitk_ws; g.splitk_ws_floats = m->splitk_ws_floats;      // (main stream: before the fork)
+                GemmArgs g = cat_dw_args(m, k, group_dw, N);
                 if (group_dw) { dws[k] = g; continue; }
                 ADN_TRY(gemm(g, s));
                 ADN_TRY(add_row_blocks(m->wcat_tmp, m->G(m->agg[k].W_in), m->ldg, m->S, H, ldh, 4 * H, s));
@@ -1297,14 +1485,8 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
                     ADN_TRY(add_row_blocks(m->wcat_tmp + k * wcat_elems, m->G(m->agg[k].W_in), m->ldg, m->S, H, ldh, 4 * H, s));
             }
             for (size_t k = 0; k < m->agg.size(); ++k) {
-                const LstmParams& lp = m->agg[k]; const LstmWork& w = m->aggw[k];
-                GemmArgs d;                                   // d(concat) (+)= dG W_in^T through the side-by-side W^T copies
-                d.layout = GEMM_NN; d.M = N; d.N = ldcat; d.K = 4 * H;
-                d.A = w.dG; d.lda = m->ldg; d.A16 = m->shadow_of(w.dG);
-                d.B = m->P(lp.W_in); d.ldb = ldcat;
-                for (const auto& t : m->transw) if (t.key == d.B) { d.B16 = t.buf; break; }
+                GemmArgs d = cat_dx_args(m, k, N);
                 ADN_CHECK(d.B16, ADN_ERR_STATE, "internal: transposed copy of an aggregation W_in is missing");
-                d.C = m->dcat; d.ldc = ldcat; d.accumulate = k > 0; d.precision = m->cfg.precision;
                 ADN_TRY(gemm(d, s));
             }
             {                                                 // dW_hid (+ sums) of the aggregation LSTMs: one grouped launch
@@ -1335,8 +1517,8 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
                 }
                 bool same = true;
                 for (int j = 1; j < n; ++j) same = same && gs[j].lda == gs[0].lda && (gs[j].A16 == nullptr) == (gs[0].A16 == nullptr);
-                if (same) ADN_TRY(gemm_grouped(gs, n, s));
-                else for (int j = 0; j < n; ++j) ADN_TRY(gemm(gs[j], s));
+                if (same) ADN_TRY(m_gemm_grouped(m, gs, n));
+                else for (int j = 0; j < n; ++j) ADN_TRY(m_gemm(m, gs[j]));
                 if (!sums_done) {
                     ADN_TRY(col_sum(w.dG, m->ldg, N, 4 * H, m->G(lp.b), 1, s));
                     ADN_TRY(col_sum(w.dh_carry, ldh, B, H, m->G(lp.hid_init), 1, s));
@@ -1363,8 +1545,8 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
                 bool same = true;
                 for (int j = 1; j < n; ++j)
                     same = same && gs[j].layout == gs[0].layout && gs[j].ldb == gs[0].ldb && (gs[j].B16 == nullptr) == (gs[0].B16 == nullptr);
-                if (same) ADN_TRY(gemm_grouped(gs, n, s));
-                else for (int j = 0; j < n; ++j) ADN_TRY(gemm(gs[j], s));
+                if (same) ADN_TRY(m_gemm_grouped(m, gs, n));
+                else for (int j = 0; j < n; ++j) ADN_TRY(m_gemm(m, gs[j]));
             }
             for (size_t j = 0; j < fin.size(); ++j) dfin.push_back(dsts[j]);
         }
@@ -1492,7 +1674,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             gw.B = w.dZ; gw.ldb = w.lddz; gw.C = m->G(st.encW[l]); gw.ldc = ld_of(out_w); gw.accumulate = 1;
             mgemm_prepare(m, gw, false);
         }
-        ADN_TRY(gemm_grouped(gws, n, m->stream));
+        ADN_TRY(m_gemm_grouped(m, gws, n));
         bool any_dx = false;
         for (int q = 0; q < n; ++q) {
             StreamState& st = m->st[sis[q]]; Walk& w = walk[sis[q]];
@@ -1523,7 +1705,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             mgemm_prepare(m, gx, /*lean=*/true);
         }
         if (!any_dx) return ADN_OK;                 // (streams of one group share l == 0)
-        ADN_TRY(gemm_grouped(gxs, n, m->stream));
+        ADN_TRY(m_gemm_grouped(m, gxs, n));
         for (int q = 0; q < n; ++q) {
             StreamState& st = m->st[sis[q]]; Walk& w = walk[sis[q]];
             const int l = w.L - 1 - depth, in_w = st.enc_in[l];
@@ -1771,6 +1953,8 @@ void adn_destroy(adn_model* m) {
     if (m->params16) (void)hipFree(m->params16);
     if (m->transw_slab) (void)hipFree(m->transw_slab);
     if (m->transw_items) (void)hipFree(m->transw_items);
+    if (m->transw_items_lo) (void)hipFree(m->transw_items_lo);
+    if (m->params16lo) (void)hipFree(m->params16lo);
     if (m->side_ready) {
         for (int k = 0; k < m->S; ++k) {
             if (m->side[k]) { (void)hipStreamSynchronize(m->side[k]); (void)hipStreamDestroy(m->side[k]); }
@@ -1781,6 +1965,7 @@ void adn_destroy(adn_model* m) {
     auto free_lp = [](LstmParams& lp) {
         if (lp.whid16t) (void)hipFree(lp.whid16t);
         if (lp.wcat16) (void)hipFree(lp.wcat16);
+        if (lp.wcat16lo) (void)hipFree(lp.wcat16lo);
         if (lp.wfrag_fwd) (void)hipFree(lp.wfrag_fwd);
         if (lp.wfrag_bwd) (void)hipFree(lp.wfrag_bwd);
         if (lp.wfrag_fwd_lo) (void)hipFree(lp.wfrag_fwd_lo);
@@ -2036,6 +2221,19 @@ int adn_read_encoder_activation(adn_model* m, int stream, int layer, float* host
     const int u = st.cfg.enc_units[layer];
     ADN_HIP_CHECK(hipStreamSynchronize(m->stream));
     const size_t rows = (size_t)m->lastB * m->lastT;
+    if (m->planes() && layer + 1 < st.cfg.n_enc && m->shadow_of(st.act[layer]) && !m->keep_fp32 && getenv("ADN_X3_LEAN")) {
+        // bf16x3 keeps intermediate activations as their hi / lo planes only: x = hi + lo to 2^-17
+        std::vector<uint16_t> hi(rows * ld_of(u)), lo(rows * ld_of(u));
+        ADN_HIP_CHECK(hipMemcpy(hi.data(), m->shadow_of(st.act[layer]), hi.size() * 2, hipMemcpyDeviceToHost));
+        ADN_HIP_CHECK(hipMemcpy(lo.data(), m->shadow_lo_of(st.act[layer]), lo.size() * 2, hipMemcpyDeviceToHost));
+        for (size_t r = 0; r < rows; ++r)
+            for (int c = 0; c < u; ++c) {
+                const uint32_t a = (uint32_t)hi[r * ld_of(u) + c] << 16, b = (uint32_t)lo[r * ld_of(u) + c] << 16;
+                float fa, fb; memcpy(&fa, &a, 4); memcpy(&fb, &b, 4);
+                host_dst[r * u + c] = fa + fb;
+            }
+        return ADN_OK;
+    }
     if (shadows_on(m) && layer + 1 < st.cfg.n_enc && m->shadow_of(st.act[layer])) {
         // bf16 mode keeps only the bf16 copy of intermediate activations: widen it on the host
         std::vector<uint16_t> tmp(rows * ld_of(u));

@@ -789,7 +789,7 @@ _PLANS = {('cuave', 'bimodal_with_val'): _plan_cuave_bimodal,
 
 
 # --------------------------------------------------------------------------------------------------------- driver
-def main(dataset, script, argv=None):
+def _main(dataset, script, argv=None):
     if (dataset, script) not in SCRIPTS:
         raise ValueError('no driver for %s/%s.py (have: %s)' % (dataset, script, sorted(SCRIPTS)))
     options = parse_options(argv, SCRIPTS[(dataset, script)])
@@ -934,3 +934,14 @@ def main(dataset, script, argv=None):
         print('Model Saved!')
     st.update(network=network, learning_rate=update.lr, momentum=update.mm)
     return st
+
+
+def main(dataset, script, argv=None):
+    """(the model-zoo factories take their arithmetic from a module-level default that ``--precision`` sets: restored on the
+    way out, so that a process which calls several drivers -- the tests do -- builds every model in the mode it asked for)"""
+    from ..modelzoo import _factory
+    saved = _factory.DEFAULT_PRECISION
+    try:
+        return _main(dataset, script, argv)
+    finally:
+        _factory.DEFAULT_PRECISION = saved

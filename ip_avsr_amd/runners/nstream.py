@@ -168,7 +168,7 @@ def build_network(n_streams, aes, dims, lstm_weights, cfg):
     raise ValueError('1 to 4 streams are supported')
 
 
-def main(n_streams, argv=None, variant=None):
+def _main(n_streams, argv=None, variant=None):
     """variant: None = runners/{1,2,3,4}stream.py; 1 stream: 'noencoder' = runners/1stream_noencoder.py (deltanet_v1 on
     the raw features), 'dct' = runners/1stream_dct.py (host deltas of the DCT features, lstm_classifier_majority_vote);
     2 streams: 'dct' = runners/2stream_dct.py (adenet_v2: encoder stream + encoder-less DCT stream), 'nodelta' =
@@ -450,3 +450,14 @@ def main(n_streams, argv=None, variant=None):
     return dict(best_cr=best_cr, best_val=best_val, test_cr=test_cr, cost_train=cost_train, cost_val=cost_val,
                 class_rate=class_rate, network=network, windowsize=windowsize,
                 heldout=dict(X_val=X_val, y_val=y_val_evaluate, mask_val=mask_val, X_test=X_test, y_test=y_test, mask_test=mask_test))
+
+
+def main(n_streams, argv=None, variant=None):
+    """(the model-zoo factories take their arithmetic from a module-level default that ``--precision`` sets: restored on the
+    way out, so that a process which calls several drivers -- the tests do -- builds every model in the mode it asked for)"""
+    from ..modelzoo import _factory
+    saved = _factory.DEFAULT_PRECISION
+    try:
+        return _main(n_streams, argv, variant)
+    finally:
+        _factory.DEFAULT_PRECISION = saved

@@ -49,15 +49,16 @@ def join(trace_txt, kernel_csv):
         if step != 1:
             continue
         us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-        key = (lay, kv["M"], kv["N"], kv["K"], kv["tile"], kv["split"], kv["lean"], kv["acc"])
+        key = (lay, kv["M"], kv["N"], kv["K"], kv["tile"], kv["split"], kv["lean"], kv["acc"], kv.get("groups", 1), kv.get("planes", 0))
         a = agg.setdefault(key, [0, 0.0])
         a[0] += 1; a[1] += us
     tot = sum(a[1] for a in agg.values())
-    print("layout      M      N      K tile split lean acc  count   us/launch   TFLOP/s   share")
+    print("layout      M      N      K   tile split lean acc grp pl  count   us/launch   TFLOP/s   share   (grp = problems per launch; "
+          "pl = bf16x3 over hi / lo planes; K = executed k; TFLOP/s = executed, all problems of the launch)")
     for key, (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        lay, M, N, K, tile, split, lean, acc = key
-        tf = 2.0 * M * N * K * n / us / 1e6
-        print(f"{lay:>4} {M:8d} {N:6d} {K:6d} {tile:4d} {split:5d} {lean:4d} {acc:3d} {n:6d} {us / n:11.1f} {tf:9.1f} {us / tot:7.1%}")
+        lay, M, N, K, tile, split, lean, acc, grp, pl = key
+        tf = 2.0 * M * N * K * grp * n / us / 1e6
+        print(f"{lay:>4} {M:8d} {N:6d} {K:6d} {tile:6d} {split:5d} {lean:4d} {acc:3d} {grp:3d} {pl:2d} {n:6d} {us / n:11.1f} {tf:9.1f} {us / tot:7.1%}")
     print(f"total GEMM kernel time per step: {tot / 1e3:.3f} ms")
 
 
