@@ -277,7 +277,10 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
             local_rank %= max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
-    distributed = world > 1
+    # ADN_BENCH_FORCE_DP=1 under torch.distributed.run with ONE rank: the step goes through DataParallel (bucket events, one
+    # all-reduce per bucket on the communication stream, per-bucket Adam) -- what the data-parallel machinery costs a step
+    # before any transfer, measurable on a 1-GPU box
+    distributed = world > 1 or bool(os.environ.get("ADN_BENCH_FORCE_DP") and "RANK" in os.environ)
     if distributed and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":

@@ -173,13 +173,22 @@ int adn_flat_buffer(adn_model* m, int buffer /*adn_buffer*/, void** device_ptr, 
 
 /* Gradient buckets for overlapping the data-parallel all-reduce with back-propagation (new; the reference is
  * single-device).  Listed in the order they become final: bucket 0 = [fusion | aggregation LSTMs | classifier |
- * cost tail] (released behind the stream LSTMs' backward launch); then for every stream s its [encoder layers >= 1 |
- * LSTM] range, final before the stream's last weight-gradient GEMM, and its [encoder layer 0] range, final when the
- * stream's backward is enqueued (one range per stream when it has fewer than two encoder layers).
+ * cost tail] (released behind the stream LSTMs' backward launch); one bucket per stream for everything behind its
+ * encoder ([BatchNorm | LSTMs]; the whole stream when it has no encoder), final before the encoder's backward starts;
+ * one bucket [W_l | b_l] per stream and encoder layer, final behind that layer's weight-gradient GEMM and released
+ * ahead of its input-gradient GEMM.  Order: layer-major (all streams' tops, then depth by depth) by default,
+ * stream-major (a stream's top, then its layers, stream after stream) when back-propagation runs stream-major
+ * (ADN_DP_STREAM_MAJOR / ADN_NO_GROUPED_BACKWARD / ADN_STREAMS); decided at the first of adn_grad_buckets /
+ * adn_set_bucket_events / adn_compute_grads and kept for the model's lifetime.
  * adn_compute_grads records the caller's HIP events (one per bucket, on the model's stream) at
  * those points; a caller makes its communication stream wait on event k and reduces range k while the rest of
- * the backward pass still runs.  Ranges are in floats inside adn_flat_buffer(ADN_BUF_GRAD). */
+ * the backward pass still runs.  Ranges are in floats inside adn_flat_buffer(ADN_BUF_GRAD); together they cover
+ * the buffer exactly once. */
 int adn_grad_buckets(const adn_model* m, int max_buckets, int64_t* begin_floats, int64_t* end_floats, int* n_out);
+/* group_of_bucket[k]: buckets with the same number are released at the same point of back-propagation (the streams' ranges
+ * behind one grouped launch); they are consecutive in the list, and a caller may reduce them with ONE grouped collective
+ * behind the last one's event. */
+int adn_grad_bucket_groups(const adn_model* m, int max_buckets, int* group_of_bucket, int* n_out);
 int adn_set_bucket_events(adn_model* m, void* const* hip_events, int n); /* n = 0 clears */
 
 /* <- val_fn(inputs..., mask, window) -> probabilities (B,T,C)  (runners/3stream.py:320) */
@@ -206,6 +215,13 @@ int adn_compute_grads(adn_model* m, const void* const* inputs, const int32_t* ta
  * valid, i.e. it is adn_compute_grads of nothing. */
 int adn_zero_grads(adn_model* m);
 int adn_apply_adam(adn_model* m, float learning_rate);
+/* The same step applied range by range of the flat buffers (floats, begin a multiple of 8; the ranges of
+ * adn_grad_buckets qualify): begin, any number of ranges, end.  Covering every parameter once equals
+ * adn_apply_adam bit for bit.  Data parallel (no reference counterpart): a bucket is updated as soon as
+ * its all-reduce has landed, while later buckets are still being reduced. */
+int adn_adam_begin(adn_model* m, float learning_rate);
+int adn_adam_range(adn_model* m, int64_t begin_floats, int64_t end_floats);
+int adn_adam_end(adn_model* m);
 /* <- custom/updates.py:35-99 adam_vlr: Adam with one learning rate per parameter tensor (index order of
  * adn_param_info); tensors of one layer must share theirs, as generate_lr_map (custom/updates.py:10-32) gives */
 int adn_apply_adam_vlr(adn_model* m, const float* lr_by_param, int n);

@@ -242,6 +242,9 @@ struct LstmStep {          // one LSTM instance taking part in a (possibly multi
     void* dG16;            // [T*B][ldg]     bf16 shadow of dG
     void* dG16lo = nullptr;  // bf16x3 mode: with dG16 the hi / lo planes of dG, written by the weight-stationary backward kernel
     void* xchg = nullptr;  // exchange buffer of the weight-stationary kernels (lstm_cluster.hip), lstm_cluster_xchg_bytes(B)
+    // HOST pointer: launch counter of `xchg`, owned by whoever owns the buffer and reset to 0 whenever the buffer is (re)made
+    // and zeroed -- the bf16x3 kernel's 16-bit tags carry it (mod 64); not read on the device
+    unsigned* xchg_seq = nullptr;
     // optional (backward): gradients that are plain sums of what the kernel already holds in registers -- the bias
     // (column sums of dG over all frames) and the learnt initial state (sums of dh_carry / dc_state over the batch).
     // Kernels that add them report it through lstm_backward()'s `sums_done`; otherwise the caller runs col_sum.

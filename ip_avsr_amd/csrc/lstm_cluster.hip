@@ -23,8 +23,6 @@
 #include "adn_common.h"
 #include <algorithm>
 #include <cstdlib>
-#include <mutex>
-#include <unordered_map>
 
 namespace adn {
 
@@ -1172,12 +1170,14 @@ bool lstm_cluster_x3_supported(const LstmStep* l, int n, int B, int T, int H) {
     return lstm_frag_elems(H) == (size_t)4 * 256 * 256;
 }
 
-// launch number (mod 64) of an exchange buffer: the sequence bits of the x3 kernel's 16-bit tags
-static unsigned x3_launch_seq(const void* xchg) {
-    static std::mutex mu;
-    static std::unordered_map<const void*, unsigned> seq;
-    std::lock_guard<std::mutex> lock(mu);
-    return seq[xchg]++ & 63u;
+// Launch number (mod 64) of an exchange buffer: the sequence bits of the x3 kernel's 16-bit tags.  The counter lives with the
+// buffer (LstmStep::xchg_seq) and restarts at 0 when the buffer is carved; the scheme relies on the owner ZEROING the buffer
+// at that point (model.hip: ensure_workspace memsets the slab), so that no slot can hold a tag of an earlier life of the
+// memory -- tags start at 1, a zeroed slot never matches.
+static int x3_launch_seq(const LstmStep& l, unsigned* seq) {
+    ADN_CHECK(l.xchg && l.xchg_seq, ADN_ERR_INVALID, "bf16x3 LSTM kernel: no exchange buffer / launch counter");
+    *seq = (*l.xchg_seq)++ & 63u;
+    return ADN_OK;
 }
 
 int lstm_forward_cluster_x3(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s) {
@@ -1201,7 +1201,11 @@ int lstm_forward_cluster_x3(const LstmStep* l, int n, const uint8_t* mask_tb, in
     for (int k0 = 0; k0 < n; k0 += chunk) {
         const int nn = std::min(chunk, n - k0);
         LstmClusterX3P L;
-        for (int k = 0; k < nn; ++k) { L.l[k] = l[k0 + k]; L.tag0[k] = x3_launch_seq(l[k0 + k].xchg) * 1024u + 1u; }
+        for (int k = 0; k < nn; ++k) {
+            unsigned seq = 0;
+            ADN_TRY(x3_launch_seq(l[k0 + k], &seq));
+            L.l[k] = l[k0 + k]; L.tag0[k] = seq * 1024u + 1u;
+        }
         hipLaunchKernelGGL(lstm_fwd_cluster_x3_kernel, dim3(per, nn), dim3(512), lds, s, L, mask_tb, B, T, H, ldh, ldg, err);
         ADN_HIP_CHECK(hipGetLastError());
     }

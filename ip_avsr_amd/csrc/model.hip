@@ -113,6 +113,7 @@ struct LstmWork {        // per-shape workspace pointers
     float *xproj = nullptr, *gates = nullptr, *dG = nullptr, *hbuf = nullptr, *cbuf = nullptr;
     float *dh_carry = nullptr, *dc_state = nullptr;
     void* xchg = nullptr;    // lstm_cluster.hip exchange buffer
+    unsigned xchg_seq = 0;   // launches of the bf16x3 kernel on `xchg` since it was carved (and zeroed with the slab)
     float* out(int B, int ldh, bool backwards) const { return hbuf + (backwards ? 0 : (size_t)B * ldh); }
     float* prev(int B, int ldh, bool backwards) const { return hbuf + (backwards ? (size_t)B * ldh : 0); }
 };
@@ -185,6 +186,8 @@ struct adn_model {
     std::vector<LstmWork> aggw;
     size_t tail_begin = 0;             // first float of the [fuse | agg | softmax] parameters
     std::vector<hipEvent_t> bucket_events;   // caller-owned; in the order of adn_grad_buckets (bucket_ranges)
+    int dp_order = -1;                       // -1: not latched yet; 0: layer-major buckets / back-propagation, 1: stream-major
+    float adam_a_t = 0.f; bool adam_open = false;   // step size of the optimiser step opened by adn_adam_begin
     size_t adacoeff = 0;               // S scalars (one 8-float block)
     size_t smW = 0, smb = 0;
     int fused_dim = 0;
@@ -443,6 +446,7 @@ void carve_lstm(adn_model* m, Carver& cv, LstmWork& w, int B, int T, int ldh, in
     w.dh_carry = cv.take<float>((size_t)B * ldh);
     w.dc_state = cv.take<float>((size_t)B * ldh);
     w.xchg = cv.take<char>(lstm_cluster_xchg_bytes(B, m->H));
+    w.xchg_seq = 0;          // ensure_workspace zeroes the whole slab behind every carve: all tag slots read 0
 }
 
 size_t carve(adn_model* m, char* base, int B, int T, bool host_inputs) {
@@ -933,6 +937,7 @@ LstmStep make_step(const adn_model* m, const LstmParams& lp, const LstmWork& w, 
     //  lanes, or 16-byte stores from its LDS images one step later -- they cost the step 0.3 / 0.7 us of its 6.4: measured 0.52
     //  -> 0.58 / 0.67 ms of backward LSTM time per train step against 0.19 ms of split passes, and the kernel below the 40 % line)
     s.xchg = (b16 || x3) ? w.xchg : nullptr;
+    s.xchg_seq = const_cast<unsigned*>(&w.xchg_seq);
     if (grads) { s.dbias = m->G(lp.b); s.dhid_init = m->G(lp.hid_init); s.dcell_init = m->G(lp.cell_init); }
     return s;
 }
@@ -1402,19 +1407,63 @@ int lstm_input_grad(adn_model* m, const LstmParams& lp, const LstmWork& w, int j
 // ------------------------------------------------------------------------------------------
 // backward (theano.grad of the loss wrt every parameter)
 // ------------------------------------------------------------------------------------------
-// positions of a stream's two gradient buckets in the bucket list (see bucket_ranges)
-void bucket_slots(const adn_model* m, size_t si, size_t* rest, size_t* first) {
-    const bool stream_major = getenv("ADN_DP_STREAM_MAJOR") != nullptr;
-    size_t r = 1, f = 0;
-    if (stream_major) {
-        for (size_t q = 0; q < si; ++q) r += m->st[q].cfg.n_enc >= 2 ? 2 : 1;
-        f = r + 1;
-    } else {
-        r = 1 + si;
-        f = 1 + (size_t)m->S;
-        for (size_t q = 0; q < si; ++q) f += m->st[q].cfg.n_enc >= 2 ? 1 : 0;
+// ---- gradient buckets (data parallel).  One bucket per [fusion | aggregation | classifier | tail], per stream's "top" (everything
+// behind its encoder: BatchNorm, LSTMs; the whole stream when it has no encoder) and per (stream, encoder layer) = [W_l | b_l].
+// The list is in the order the ranges become final, which is the order an in-order communication stream must take them in:
+//   layer-major (default):  tail, top_0 .. top_{S-1}, then depth by depth (depth d = layer L_s - 1 - d of stream s) every stream
+//   stream-major:           tail, then per stream its top and its layers from the last to the first
+// Which of the two a model uses is decided ONCE (adn_grad_buckets / adn_set_bucket_events, whichever comes first) from the
+// same predicate back-propagation uses, and kept.
+bool streams_concurrent(const adn_model* m);
+int dp_stream_major(adn_model* m) {
+    if (m->dp_order < 0)
+        m->dp_order = (getenv("ADN_DP_STREAM_MAJOR") || getenv("ADN_NO_GROUPED_BACKWARD") || streams_concurrent(m)) ? 1 : 0;
+    return m->dp_order;
+}
+size_t bucket_of_top(const adn_model* m, size_t si) {
+    if (!m->dp_order) return 1 + si;
+    size_t k = 1;
+    for (size_t q = 0; q < si; ++q) k += 1 + (size_t)m->st[q].cfg.n_enc;
+    return k;
+}
+// layer-major back-propagation, depth d: the streams whose layer L_s - 1 - d exists, grouped by geometry (one grouped
+// launch per group) in the order the groups are issued
+std::vector<std::vector<size_t>> depth_groups(const adn_model* m, int d) {
+    std::vector<std::vector<size_t>> out;
+    std::vector<char> done(m->st.size(), 0);
+    for (size_t i = 0; i < m->st.size(); ++i) {
+        const StreamState& a = m->st[i];
+        if (done[i] || d >= a.cfg.n_enc) continue;
+        std::vector<size_t> sis{i};
+        done[i] = 1;
+        const int la = a.cfg.n_enc - 1 - d;
+        for (size_t j = i + 1; j < m->st.size() && sis.size() < (size_t)kMaxGemmGroups; ++j) {
+            const StreamState& o = m->st[j];
+            if (done[j] || d >= o.cfg.n_enc) continue;
+            const int lo = o.cfg.n_enc - 1 - d;
+            if (o.cfg.enc_units[lo] == a.cfg.enc_units[la] && o.enc_in[lo] == a.enc_in[la] && (lo == 0) == (la == 0) &&
+                (lo == 0 || o.cfg.enc_act[lo - 1] == a.cfg.enc_act[la - 1])) { sis.push_back(j); done[j] = 1; }
+        }
+        out.push_back(sis);
     }
-    *rest = r; *first = f;
+    return out;
+}
+size_t bucket_of_layer(const adn_model* m, size_t si, int l) {
+    const int depth = m->st[si].cfg.n_enc - 1 - l;
+    if (m->dp_order) return bucket_of_top(m, si) + 1 + (size_t)depth;
+    size_t k = 1 + (size_t)m->S;
+    for (int d = 0; d <= depth; ++d)
+        for (const auto& grp : depth_groups(m, d))
+            for (size_t q : grp) {
+                if (d == depth && q == si) return k;
+                ++k;
+            }
+    return k;
+}
+size_t bucket_count(const adn_model* m) {
+    size_t n = 1 + (size_t)m->S;
+    for (int s = 0; s < m->S; ++s) n += (size_t)m->st[s].cfg.n_enc;
+    return n;
 }
 
 int backward_pass(adn_model* m, int B, int T, int theta) {
@@ -1608,10 +1657,11 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
     // Per-stream walk state of the encoder's back-propagation.
     struct Walk {
         float* dZ = nullptr; int lddz = 0; int bias_done = 0; int L = 0;
-        size_t b_rest = 0, b_first = 0; bool split_first = false, active = false;
-        ColSumBatch bias_sums;                 // bf16 mode: every bias reduction of the stream in ONE launch at the end
+        bool active = false;
     };
     std::vector<Walk> walk(m->st.size());
+    ColSumBatch bias_sums;                     // bias reductions queued by the layer in flight, all streams: ONE launch per flush
+    const bool stream_major = dp_stream_major(m) != 0;
     // everything of stream si above its encoder: LSTM parameter / input gradients, dropout, delta layer, BatchNorm, act'
     std::vector<char> first_dx_done(m->st.size(), 0);          // layer-major: the first LSTM's input gradient went out grouped
     auto stream_head = [&](size_t si, bool lstm_grads_done) -> int {
@@ -1621,12 +1671,8 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         const float* in[1] = {st.feat}; const int ld[1] = {ldf};
         for (size_t k = 0; k < st.lstm.size() && !lstm_grads_done; ++k)
             ADN_TRY(lstm_param_grads(m, st.lstm[k], st.lw[k], in, ld, 1, st.feat_dim, B, T, stream_sums_done));
-        // this stream's buckets: `b_rest` (encoder layers >= 1 + LSTM; the whole stream when it has < 2 encoder layers),
-        // then `b_first` (encoder layer 0) where it exists
-        bucket_slots(m, si, &w.b_rest, &w.b_first);
-        w.split_first = st.cfg.n_enc >= 2;
         w.L = st.cfg.n_enc;
-        if (st.cfg.n_enc == 0) { ADN_TRY(bucket_ready(w.b_rest)); return ADN_OK; }   // nothing trainable below the LSTM
+        if (st.cfg.n_enc == 0) { ADN_TRY(bucket_ready(bucket_of_top(m, si))); return ADN_OK; }   // nothing trainable below the LSTM
         for (size_t k = first_dx_done[si] ? 1 : 0; k < st.lstm.size(); ++k)
             ADN_TRY(lstm_input_grad(m, st.lstm[k], st.lw[k], 0, st.feat_dim, st.dfeat, ldf, N, k > 0));
         if (m->stochastic && st.cfg.dropout_p > 0.f)
@@ -1649,15 +1695,8 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             ADN_TRY(act_backward(st.dE, ldE, st.act[L - 1], ldE, N, st.enc_out, st.cfg.enc_act[L - 1], m->stream));
         if (!dE16) ADN_TRY(refresh(m, st.dE, (size_t)N * ldE));
         w.dZ = st.dE; w.lddz = ldE; w.bias_done = 0; w.active = true;
-        return ADN_OK;
-    };
-    std::vector<char> tail_done(m->st.size(), 0);
-    auto stream_tail = [&](size_t si) -> int {
-        if (tail_done[si]) return ADN_OK;
-        tail_done[si] = 1;
-        Walk& w = walk[si];
-        ADN_TRY(col_sum_batch(w.bias_sums, m->stream));
-        return bucket_ready(w.split_first ? w.b_first : w.b_rest);           // every gradient of this stream is final
+        // this stream's "top" bucket (BatchNorm, LSTMs) is final: its last writers are the launches above
+        return bucket_ready(bucket_of_top(m, si));
     };
     // encoder layer L - 1 - depth of the streams `sis` (same geometry when more than one): weight gradients, bias
     // gradients, input gradients -- each kind as ONE grouped launch where the ping-pong kernel takes it
@@ -1679,19 +1718,23 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         for (int q = 0; q < n; ++q) {
             StreamState& st = m->st[sis[q]]; Walk& w = walk[sis[q]];
             const int l = w.L - 1 - depth;
-            const int out_w = st.cfg.enc_units[l], in_w = st.enc_in[l];
-            if (!w.bias_done) {
-                if (m->bf16() && w.dZ == st.dE) col_sum_batch_add(w.bias_sums, w.dZ, w.lddz, (int)N, out_w, m->G(st.encb[l]));   // (dE is not reused)
+            const int out_w = st.cfg.enc_units[l];
+            if (!w.bias_done) {           // b_l did not ride on the input-gradient GEMM of the layer above: summed from dZ now
+                if (m->bf16() && w.dZ == st.dE && bias_sums.n < 8) col_sum_batch_add(bias_sums, w.dZ, w.lddz, (int)N, out_w, m->G(st.encb[l]));   // (dE is not reused)
                 else ADN_TRY(col_sum(w.dZ, w.lddz, N, out_w, m->G(st.encb[l]), 1, m->stream));
             }
             w.bias_done = 0;
-            if (l == 1 && w.split_first) {
-                // [layers >= 1 + LSTM] of this stream is final: W_1 by the launch above, b_1 .. and everything above it queued
-                // or written earlier (b_0 alone is still to come: it rides on the input-gradient GEMM below).  Released HERE,
-                // ahead of that GEMM and of layer 0's weight gradient, which then cover its transfer.
-                ADN_TRY(col_sum_batch(w.bias_sums, m->stream));
-                ADN_TRY(bucket_ready(w.b_rest));
-            }
+        }
+        // [W_l | b_l] of these streams is final behind the weight-gradient launch above and the queued bias reductions
+        // (partial column sums of the layer above's input-gradient GEMM, or the sums just queued): one launch, then the
+        // buckets are released -- AHEAD of this layer's input-gradient GEMM, which then covers their transfer
+        // (without bucket events the queue is only drained when it runs full, and once at the end)
+        if (!m->bucket_events.empty() || bias_sums.n + n > 8) ADN_TRY(col_sum_batch(bias_sums, m->stream));
+        for (int q = 0; q < n; ++q) ADN_TRY(bucket_ready(bucket_of_layer(m, sis[q], walk[sis[q]].L - 1 - depth)));
+        for (int q = 0; q < n; ++q) {
+            StreamState& st = m->st[sis[q]]; Walk& w = walk[sis[q]];
+            const int l = w.L - 1 - depth;
+            const int out_w = st.cfg.enc_units[l], in_w = st.enc_in[l];
             if (l == 0) continue;
             any_dx = true;
             float* dst = (w.dZ == st.pingA) ? st.pingB : st.pingA;
@@ -1701,7 +1744,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             gx.Y = st.act[l - 1]; gx.ldy = ld_of(in_w); gx.act_grad = st.cfg.enc_act[l - 1];
             gx.colsum = m->G(st.encb[l - 1]); gx.colsum_done = &w.bias_done;     // db_{l-1} rides on this GEMM
             gx.colsum_ws = st.colsum_ws + (size_t)l * st.colsum_ws_floats; gx.colsum_ws_floats = st.colsum_ws_floats;
-            gx.colsum_batch = &w.bias_sums;
+            gx.colsum_batch = &bias_sums;
             mgemm_prepare(m, gx, /*lean=*/true);
         }
         if (!any_dx) return ADN_OK;                 // (streams of one group share l == 0)
@@ -1725,8 +1768,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
     // transfer is exposed than in the stream-major order (where a whole stream's buckets hide under the next stream's
     // GEMMs), but that order costs 0.5 ms of GEMM time per step (3.9 -> 4.4 ms at B = 520), more than the ~0.2 ms of
     // transfer it hides.  ADN_DP_STREAM_MAJOR=1 selects it for data parallel runs, ADN_NO_GROUPED_BACKWARD=1 always.
-    const bool layer_major = (m->bucket_events.empty() || !getenv("ADN_DP_STREAM_MAJOR")) && !streams_concurrent(m) &&
-                             !getenv("ADN_NO_GROUPED_BACKWARD");
+    const bool layer_major = !stream_major;
     if (layer_major) {
         int max_depth = 0;
         {                                      // parameter gradients of all stream LSTMs: grouped launches
@@ -1752,32 +1794,16 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             ADN_TRY(issue_grouped(m, dx));
         }
         for (size_t si = 0; si < m->st.size(); ++si) { ADN_TRY(stream_head(si, true)); max_depth = std::max(max_depth, walk[si].active ? walk[si].L : 0); }
-        for (int d = 0; d < max_depth; ++d) {
-            std::vector<char> done(m->st.size(), 0);
-            for (size_t i = 0; i < m->st.size(); ++i) {
-                if (done[i] || !walk[i].active || d >= walk[i].L) continue;
-                std::vector<size_t> sis{i};
-                done[i] = 1;
-                const StreamState& a = m->st[i];
-                const int la = walk[i].L - 1 - d;
-                for (size_t j = i + 1; j < m->st.size() && sis.size() < (size_t)kMaxGemmGroups; ++j) {
-                    if (done[j] || !walk[j].active || d >= walk[j].L) continue;
-                    const StreamState& o = m->st[j];
-                    const int lo = walk[j].L - 1 - d;
-                    if (o.cfg.enc_units[lo] == a.cfg.enc_units[la] && o.enc_in[lo] == a.enc_in[la] && (lo == 0) == (la == 0) &&
-                        (lo == 0 || o.cfg.enc_act[lo - 1] == a.cfg.enc_act[la - 1])) { sis.push_back(j); done[j] = 1; }
-                }
-                ADN_TRY(layer_step(sis, d));
-            }
-        }
-        for (size_t si = 0; si < m->st.size(); ++si) if (walk[si].active) ADN_TRY(stream_tail(si));
+        for (int d = 0; d < max_depth; ++d)
+            for (const auto& sis : depth_groups(m, d)) ADN_TRY(layer_step(sis, d));
+        ADN_TRY(col_sum_batch(bias_sums, m->stream));
     } else {
         for (size_t si = 0; si < m->st.size(); ++si) {
             OnSideStream on(m, (int)si);
             ADN_TRY(stream_head(si, false));
             if (!walk[si].active) continue;
             for (int d = 0; d < walk[si].L; ++d) ADN_TRY(layer_step(std::vector<size_t>{si}, d));
-            ADN_TRY(stream_tail(si));
+            ADN_TRY(col_sum_batch(bias_sums, m->stream));
         }
     }
     ADN_TRY(join_streams(m));
@@ -2027,36 +2053,56 @@ int adn_flat_buffer(adn_model* m, int buffer, void** device_ptr, size_t* bytes) 
     return ADN_OK;
 }
 
-// Bucket list in the order the ranges become final = the order a communication stream should reduce them in.  Layer-major
-// back-propagation (the default): [tail], every stream's [layers >= 1 of the encoder + LSTM] (final together, right behind
-// layer 1's weight gradients), then every stream's [encoder layer 0] (only for streams with at least two encoder layers;
-// final behind the last launch).  Stream-major (ADN_DP_STREAM_MAJOR): [tail], then per stream its two ranges.
-static void bucket_ranges(const adn_model* m, std::vector<std::pair<size_t, size_t>>& out) {
-    size_t n = 1;
-    for (int s = 0; s < m->S; ++s) n += m->st[s].cfg.n_enc >= 2 ? 2 : 1;
-    out.assign(n, std::make_pair((size_t)0, (size_t)0));
+// Bucket list in the order the ranges become final (see "gradient buckets" above backward_pass)
+static void bucket_ranges(adn_model* m, std::vector<std::pair<size_t, size_t>>& out) {
+    (void)dp_stream_major(m);                      // latch the order
+    out.assign(bucket_count(m), std::make_pair((size_t)0, (size_t)0));
     out[0] = std::make_pair(m->tail_begin, m->flat_floats + kAuxFloats);
     for (int s = 0; s < m->S; ++s) {
         const StreamState& st = m->st[s];
         const size_t begin = st.param_begin, end = s + 1 < m->S ? m->st[s + 1].param_begin : m->tail_begin;
-        size_t rest = 0, first = 0;
-        bucket_slots(m, (size_t)s, &rest, &first);
-        if (st.cfg.n_enc >= 2) {
-            out[rest] = std::make_pair(st.encW[1], end);
-            out[first] = std::make_pair(begin, st.encW[1]);
-        } else {
-            out[rest] = std::make_pair(begin, end);
-        }
+        const int L = st.cfg.n_enc;
+        // behind the encoder: [end of the last layer's bias, end) -- the first tensor behind the encoder starts there
+        size_t top_begin = begin;
+        if (L > 0) top_begin = st.cfg.batchnorm ? st.bn_beta : st.lstm[0].W_in;
+        out[bucket_of_top(m, (size_t)s)] = std::make_pair(top_begin, end);
+        for (int l = 0; l < L; ++l)
+            out[bucket_of_layer(m, (size_t)s, l)] = std::make_pair(st.encW[l], l + 1 < L ? st.encW[l + 1] : top_begin);
     }
 }
 
-int adn_grad_buckets(const adn_model* m, int max_buckets, int64_t* begin_floats, int64_t* end_floats, int* n_out) {
+int adn_grad_buckets(const adn_model* cm, int max_buckets, int64_t* begin_floats, int64_t* end_floats, int* n_out) {
+    adn_model* m = const_cast<adn_model*>(cm);     // (latches the bucket order)
     ADN_CHECK(m && begin_floats && end_floats && n_out, ADN_ERR_INVALID, "null argument");
     std::vector<std::pair<size_t, size_t>> r;
     bucket_ranges(m, r);
     ADN_CHECK(max_buckets >= (int)r.size(), ADN_ERR_INVALID, "bucket arrays too small");
     for (size_t k = 0; k < r.size(); ++k) { begin_floats[k] = (int64_t)r[k].first; end_floats[k] = (int64_t)r[k].second; }
     *n_out = (int)r.size();
+    return ADN_OK;
+}
+
+int adn_grad_bucket_groups(const adn_model* cm, int max_buckets, int* group_of_bucket, int* n_out) {
+    adn_model* m = const_cast<adn_model*>(cm);
+    ADN_CHECK(m && group_of_bucket && n_out, ADN_ERR_INVALID, "null argument");
+    (void)dp_stream_major(m);
+    const size_t n = bucket_count(m);
+    ADN_CHECK((int)n <= max_buckets, ADN_ERR_INVALID, "bucket table too small");
+    for (size_t k = 0; k < n; ++k) group_of_bucket[k] = (int)k;              // stream-major: every bucket on its own
+    if (!m->dp_order) {
+        int g = 0;
+        group_of_bucket[0] = g++;
+        for (int s = 0; s < m->S; ++s) group_of_bucket[bucket_of_top(m, (size_t)s)] = g;   // the tops: back to back
+        ++g;
+        int max_depth = 0;
+        for (int s = 0; s < m->S; ++s) max_depth = std::max(max_depth, m->st[s].cfg.n_enc);
+        for (int d = 0; d < max_depth; ++d)
+            for (const auto& grp : depth_groups(m, d)) {
+                for (size_t si : grp) group_of_bucket[bucket_of_layer(m, si, m->st[si].cfg.n_enc - 1 - d)] = g;
+                ++g;
+            }
+    }
+    *n_out = (int)n;
     return ADN_OK;
 }
 
@@ -2133,6 +2179,41 @@ int adn_apply_adam(adn_model* m, float learning_rate) {
     m->grads_valid = false;
     m->mark_params_dirty();
     m->params16_values_fresh = p16 != nullptr;
+    return ADN_OK;
+}
+
+// One Adam step applied range by range (data parallel: each gradient bucket is updated as soon as its reduction has
+// landed, while later buckets are still on the wire).  begin .. range* .. end == adn_apply_adam bit for bit when the ranges
+// cover [0, parameter floats) once: the update is element-wise and every range starts on an 8-float boundary.
+int adn_adam_begin(adn_model* m, float learning_rate) {
+    ADN_CHECK(m, ADN_ERR_INVALID, "null model");
+    ADN_CHECK(m->grads_valid, ADN_ERR_STATE, "adn_adam_begin called without gradients (call adn_compute_grads first)");
+    ADN_CHECK(!m->adam_open, ADN_ERR_STATE, "adn_adam_begin: the previous ranged step was not closed with adn_adam_end");
+    m->adam_t += 1;
+    const float t = (float)m->adam_t;
+    m->adam_a_t = learning_rate * sqrtf(1.f - powf(kBeta2, t)) / (1.f - powf(kBeta1, t));
+    m->adam_open = true;
+    return ADN_OK;
+}
+int adn_adam_range(adn_model* m, int64_t begin_floats, int64_t end_floats) {
+    ADN_CHECK(m, ADN_ERR_INVALID, "null model");
+    ADN_CHECK(m->adam_open, ADN_ERR_STATE, "adn_adam_range outside adn_adam_begin / adn_adam_end");
+    ADN_CHECK(begin_floats >= 0 && begin_floats <= end_floats && begin_floats % 8 == 0, ADN_ERR_INVALID, "bad range");
+    const int64_t e = std::min<int64_t>(end_floats, (int64_t)m->flat_floats);      // (the tail slots behind the parameters)
+    if (e <= begin_floats) return ADN_OK;
+    const size_t b = (size_t)begin_floats;
+    void* p16 = (shadows_on(m) && m->params16) ? static_cast<void*>(m->params16 + b * 2) : nullptr;   // (char*: bf16 elements)
+    return adam_update(m->flat[ADN_BUF_PARAM] + b, m->flat[ADN_BUF_GRAD] + b, m->flat[ADN_BUF_ADAM_M] + b, m->flat[ADN_BUF_ADAM_V] + b,
+                       e - begin_floats, m->adam_a_t, kBeta1, kBeta2, kEps, m->stream, p16,
+                       m->poison_word(), m->poison_sticky);
+}
+int adn_adam_end(adn_model* m) {
+    ADN_CHECK(m, ADN_ERR_INVALID, "null model");
+    ADN_CHECK(m->adam_open, ADN_ERR_STATE, "adn_adam_end without adn_adam_begin");
+    m->adam_open = false;
+    m->grads_valid = false;
+    m->mark_params_dirty();
+    m->params16_values_fresh = shadows_on(m) && m->params16;
     return ADN_OK;
 }
 

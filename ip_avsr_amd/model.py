@@ -203,6 +203,11 @@ class AdeNetModel(object):
                     if not (p.name.rsplit(".", 1)[0] in bn and p.name.rsplit(".", 1)[1] in ("mean", "inv_std"))]
         return list(self.params)
 
+    def running_statistic_names(self):
+        """Names of the non-trainable running statistics (BatchNormLayer ``mean`` / ``inv_std``)."""
+        trainable = {p.name for p in self.get_all_params(trainable=True)}
+        return [p.name for p in self.params if p.name not in trainable]
+
     def get_all_param_values(self, **tags):
         return [p.get_value() for p in self.get_all_params(**tags)]
 
@@ -251,10 +256,18 @@ class AdeNetModel(object):
 
     def grad_buckets(self):
         """[(begin, end)] float ranges of the flat gradient buffer in the order they become final during
-        back-propagation: [fusion | aggregation | classifier | cost tail] first, then stream 0, 1, ..."""
-        b = (C.c_int64 * 16)(); e = (C.c_int64 * 16)(); n = C.c_int()
-        _lib.check(self._lib.adn_grad_buckets(self._handle, 16, b, e, C.byref(n)))
+        back-propagation: [fusion | aggregation | classifier | cost tail] first, then every stream's [BatchNorm | LSTM]
+        range, then one [W_l | b_l] range per encoder layer (include/adenet.h: adn_grad_buckets)."""
+        b = (C.c_int64 * 256)(); e = (C.c_int64 * 256)(); n = C.c_int()
+        _lib.check(self._lib.adn_grad_buckets(self._handle, 256, b, e, C.byref(n)))
         return [(int(b[k]), int(e[k])) for k in range(n.value)]
+
+    def grad_bucket_groups(self):
+        """For every bucket of ``grad_buckets`` the number of its release point: buckets that share it (the streams' ranges
+        behind one grouped launch) are consecutive and may be reduced by one grouped collective."""
+        g = (C.c_int * 256)(); n = C.c_int()
+        _lib.check(self._lib.adn_grad_bucket_groups(self._handle, 256, g, C.byref(n)))
+        return [int(g[k]) for k in range(n.value)]
 
     def set_bucket_events(self, raw_events):
         """Raw hipEvent_t handles (ints), one per bucket, recorded by compute_grads; [] clears."""
@@ -397,6 +410,17 @@ class AdeNetModel(object):
 
     def apply_adam(self, learning_rate):
         _lib.check(self._lib.adn_apply_adam(self._handle, float(learning_rate)))
+
+    def adam_begin(self, learning_rate):
+        """Opens an Adam step that is applied range by range (``adam_range``) and closed with ``adam_end``; covering
+        every parameter once equals ``apply_adam`` bit for bit (data parallel: per-bucket updates)."""
+        _lib.check(self._lib.adn_adam_begin(self._handle, float(learning_rate)))
+
+    def adam_range(self, begin, end):
+        _lib.check(self._lib.adn_adam_range(self._handle, int(begin), int(end)))
+
+    def adam_end(self):
+        _lib.check(self._lib.adn_adam_end(self._handle))
 
     def apply_sgd(self, learning_rate, momentum=0.0, nesterov=False):
         """lasagne.updates.sgd / momentum / nesterov_momentum on the gradients of the last compute_grads."""

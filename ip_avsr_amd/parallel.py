@@ -63,16 +63,35 @@ class DataParallel(object):
         self._own_grad = grad_tensor           # CPU test path: the replica owns host tensors instead of device buffers
         self._own_buffers = getattr(model, "host_buffers", None)
         self._inflight = False
-        # Overlap (GPU replicas only): the library records one HIP event per gradient bucket as soon as that
-        # bucket is final; a communication stream waits on it and all-reduces the bucket while back-propagation
-        # is still running (which buckets hide under what in the layer-major and the stream-major order).
+        # Overlap: the library records one HIP event per gradient bucket as soon as that bucket is final; a communication
+        # stream waits on it and all-reduces the bucket while back-propagation is still running, and Adam is applied to a
+        # bucket as soon as ITS reduction has landed, while later buckets are still on the wire.  Default on
+        # for GPU replicas; a CPU test replica (host gradient tensor) takes the same bucket-by-bucket path without events
+        # and streams when asked to (``overlap=True``).
         if overlap is None:
             overlap = grad_tensor is None and not os.environ.get("ADN_DP_NO_OVERLAP")
         self.overlap = bool(overlap) and hasattr(model, "grad_buckets")
+        self.on_device = grad_tensor is None
+        self.per_bucket_update = hasattr(model, "adam_range") and not os.environ.get("ADN_DP_WHOLE_BUFFER_ADAM")
         if self.overlap:
+            self.buckets = model.grad_buckets()
+            covered = sorted(self.buckets)
+            if covered[0][0] != 0 or covered[-1][1] != self.grad.numel() or any(a[1] != b[0] for a, b in zip(covered, covered[1:])):
+                raise RuntimeError("data parallel: the gradient buckets do not cover the gradient buffer exactly once")
+            # buckets released at the same point of back-propagation (the streams' ranges behind one grouped launch) go out as
+            # ONE grouped collective: fewer, larger launches on the communication stream (ADN_DP_NO_COALESCE=1: one each)
+            groups = model.grad_bucket_groups() if hasattr(model, "grad_bucket_groups") else list(range(len(self.buckets)))
+            if os.environ.get("ADN_DP_NO_COALESCE"):
+                groups = list(range(len(self.buckets)))
+            self.launches = []
+            for k, g in enumerate(groups):
+                if self.launches and groups[self.launches[-1][-1]] == g:
+                    self.launches[-1].append(k)
+                else:
+                    self.launches.append([k])
+        if self.overlap and self.on_device:
             import torch
             self._torch = torch
-            self.buckets = model.grad_buckets()
             self.comm_stream = torch.cuda.Stream()
             self.events = []
             for _ in self.buckets:
@@ -117,29 +136,76 @@ class DataParallel(object):
         else:
             self.model.compute_grads(inputs, targets, mask, window, total_frames=float(global_total_frames),
                                      want_loss=False)
+        ranged = self.overlap and update is None and self.per_bucket_update
         if self.overlap:
-            torch = self._torch
             works = []
             self._inflight = True
-            with torch.cuda.stream(self.comm_stream):
-                for (b, e), ev in zip(self.buckets, self.events):
-                    self.comm_stream.wait_event(ev)      # bucket final on the compute stream
-                    works.append(self.dist.all_reduce(self.grad[b:e], op=self.dist.ReduceOp.SUM, group=self.group,
-                                                      async_op=True))
-            for w in works:
-                w.wait()                                 # the compute stream waits for the reductions
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+            if self.on_device:
+                with self._torch.cuda.stream(self.comm_stream):
+                    for idxs in self.launches:
+                        for k in idxs:
+                            self.comm_stream.wait_event(self.events[k])      # bucket final on the compute stream
+                        works.append(self._reduce([self.buckets[k] for k in idxs]))
+            else:
+                for idxs in self.launches:
+                    works.append(self._reduce([self.buckets[k] for k in idxs]))
+            # Bucket 0 comes first and holds the step's status word (a rank whose LSTM exchange timed out poisons it); every
+            # update kernel reads the REDUCED word, so all ranks skip -- or apply -- the step together.
+            if ranged:
+                self.model.adam_begin(learning_rate)
+            for idxs, w in zip(self.launches, works):
+                w.wait()                                 # the compute stream waits for THIS reduction only
+                if ranged:
+                    for k in idxs:
+                        self.model.adam_range(*self.buckets[k])
+            if self.on_device:
+                self._torch.cuda.current_stream().wait_stream(self.comm_stream)
             self._inflight = False
+            if ranged:
+                self.model.adam_end()
         elif self.world_size > 1:
             # same stream as the model's kernels (torch's current stream): ordered after the backward pass
             self.dist.all_reduce(self.grad, op=self.dist.ReduceOp.SUM, group=self.group)
-        if update is None:
+        if ranged:
+            pass
+        elif update is None:
             self.model.apply_adam(learning_rate)
         else:
             update(self.model)
         if want_loss:
             return float(self.grad[-8].item())
         return None
+
+    def _reduce(self, ranges):
+        """Sum over the ranks of the given ranges of the gradient buffer as one (grouped) asynchronous collective."""
+        if len(ranges) == 1:
+            b, e = ranges[0]
+            return self.dist.all_reduce(self.grad[b:e], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        from torch.distributed.distributed_c10d import _coalescing_manager
+        with _coalescing_manager(group=self.group, async_ops=True) as cm:
+            for b, e in ranges:
+                self.dist.all_reduce(self.grad[b:e], op=self.dist.ReduceOp.SUM, group=self.group)
+        return cm
+
+    def sync_running_statistics(self):
+        """BatchNorm running statistics (adenet_v1 / v1_1: ``streamK.bn.mean`` / ``.bn.inv_std``) are updated from each
+        rank's LOCAL shard and carry no gradient, so the all-reduce never touches them and the replicas' copies drift
+        apart.  This averages them over the ranks (the batch statistics themselves stay per-shard, like any
+        data-parallel BatchNorm without synchronised statistics).  Called before sharded evaluation; call it before a
+        checkpoint is written as well.  No-op for models without BatchNorm."""
+        names = self.model.running_statistic_names() if hasattr(self.model, "running_statistic_names") else []
+        if not names or self.world_size == 1:
+            return 0
+        import torch
+        vals = [np.asarray(self.model.get_param(n), np.float32).reshape(-1) for n in names]
+        flat = torch.as_tensor(np.concatenate(vals), device=self.grad.device)
+        self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
+        flat = (flat / float(self.world_size)).cpu().numpy()
+        off = 0
+        for n, v in zip(names, vals):
+            self.model.set_param(n, flat[off:off + v.size].reshape(np.asarray(self.model.get_param(n)).shape))
+            off += v.size
+        return len(names)
 
     # ------------------------------------------------------------------ sharded evaluation
     def shard(self, n):
@@ -166,7 +232,9 @@ class DataParallel(object):
 
     def predict_sharded(self, predict, inputs, mask, window):
         """``val_fn`` on the whole batch with the utterances split over the ranks; every rank gets the full result
-        (shard the held-out utterances, gather the votes)."""
+        (shard the held-out utterances, gather the votes).  BatchNorm running statistics are averaged over the
+        ranks first, so that every row is normalised with the same statistics."""
+        self.sync_running_statistics()
         n = len(mask)
         idx = self.shard(n)
         if idx:
@@ -180,6 +248,7 @@ class DataParallel(object):
         """A cost that is a weighted mean over utterance shards (the temporal loss: weights = valid frames per shard;
         the last-timestep cross-entropy: utterances per shard), evaluated shard-wise and combined over the ranks."""
         import torch
+        self.sync_running_statistics()
         n = len(mask)
         idx = self.shard(n)
         w = float(np.sum(mask[idx])) if weights is None else float(np.sum(np.asarray(weights)[idx]))

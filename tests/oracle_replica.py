@@ -34,6 +34,46 @@ class OracleReplica(object):
             off += sz
         self.O.adam_step(self.p, g, self.state, lr)
 
+    # --- the bucket-by-bucket surface (DataParallel(overlap=True) on a host tensor): two parameter tensors per bucket,
+    # listed back to front like the library's completion order, the 8-float tail in the first bucket
+    def grad_buckets(self):
+        edges = np.concatenate([[0], np.cumsum(self.sizes)]).astype(int)
+        cuts = list(edges[::2])
+        if cuts[-1] != edges[-1]:
+            cuts.append(int(edges[-1]))
+        ranges = [(int(a), int(b)) for a, b in zip(cuts[:-1], cuts[1:])]
+        ranges[-1] = (ranges[-1][0], ranges[-1][1] + 8)
+        return ranges[::-1]
+
+    def grad_bucket_groups(self):
+        n = len(self.grad_buckets())
+        return [0] + [1 + (k - 1) // 2 for k in range(1, n)]          # pairs of buckets share a release point
+
+    def adam_begin(self, lr):
+        self._ranged = dict(lr=lr, t=self.state["t"] + 1, done=[])
+
+    def adam_range(self, begin, end):
+        """Adam on the parameter tensors inside [begin, end) -- the oracle's own adam_step on that subset, with the
+        step count held at the value adam_begin fixed."""
+        flat = self.grad.numpy()
+        off, sub_p, sub_g, sub_state = 0, {}, {}, dict(t=self._ranged["t"] - 1, m={}, v={})
+        for n, sz in zip(self.names, self.sizes):
+            if begin <= off and off + sz <= end:
+                sub_p[n] = self.p[n]; sub_g[n] = flat[off:off + sz].reshape(self.p[n].shape)
+                sub_state["m"][n] = self.state["m"][n]; sub_state["v"][n] = self.state["v"][n]
+            else:
+                assert off + sz <= begin or off >= min(end, sum(self.sizes)), "a bucket must not cut a tensor"
+            off += sz
+        self.O.adam_step(sub_p, sub_g, sub_state, self._ranged["lr"])
+        for n in sub_p:
+            self.p[n] = sub_p[n]; self.state["m"][n] = sub_state["m"][n]; self.state["v"][n] = sub_state["v"][n]
+        self._ranged["done"] += list(sub_p)
+
+    def adam_end(self):
+        assert sorted(self._ranged["done"]) == sorted(self.names), "every parameter exactly once"
+        self.state["t"] = self._ranged["t"]
+        del self._ranged
+
     # --- the rest of the surface DataParallel / bench.py touch
     def zero_grads(self):
         self.grad.zero_()

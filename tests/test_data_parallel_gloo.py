@@ -174,3 +174,123 @@ def test_outstanding_reduction_blocks_the_next_step():
         dp.assert_quiescent()
     dp._inflight = False
     dp.assert_quiescent()
+
+
+def _worker_buckets(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ip_avsr_amd.parallel import DataParallel, shard_indices
+        spec, p, xs, y, mask = _make_problem()
+        mine = shard_indices(list(range(len(mask))), rank, world)
+        total = float(mask.sum())
+        out = []
+        for bucketed in (True, False):
+            rep = OracleReplica(spec, p)
+            dp = DataParallel(rep, grad_tensor=rep.grad, overlap=bucketed)
+            assert dp.overlap == bucketed and (not bucketed or len(dp.buckets) >= 3)
+            losses = [dp.train_step([x[mine] for x in xs], y[mine], mask[mine], 2, 1e-2, total, want_loss=True)
+                      for _ in range(3)]
+            state = np.concatenate([rep.p[n].reshape(-1) for n in rep.names] +
+                                   [rep.state["m"][n].reshape(-1) for n in rep.names] +
+                                   [rep.state["v"][n].reshape(-1) for n in rep.names])
+            out.append((losses, state, rep.adam_step_count()))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_per_bucket_adam_equals_whole_buffer_adam_bit_for_bit():
+    """the bucket-by-bucket path (one all-reduce per bucket, Adam on a bucket as soon as its reduction has
+    landed) leaves parameters, both Adam moments and the step count exactly where one all-reduce of the whole buffer
+    followed by one Adam step leaves them."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_buckets, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    results = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    for rank, (bucketed, whole) in results:
+        assert bucketed[2] == whole[2] == 3
+        np.testing.assert_array_equal(bucketed[0], whole[0])
+        np.testing.assert_array_equal(bucketed[1], whole[1])
+    np.testing.assert_array_equal(results[0][1][0][1], results[1][1][0][1])          # replicas in lock-step
+
+
+def test_bucket_list_must_cover_the_gradient_buffer():
+    from ip_avsr_amd.parallel import DataParallel
+
+    class Holes(object):
+        def grad_buckets(self):
+            return [(8, 16), (0, 4)]
+
+    import torch.distributed as d
+    if not d.is_initialized():
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(_free_port())
+        d.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        with pytest.raises(RuntimeError, match="cover"):
+            DataParallel(Holes(), grad_tensor=torch.zeros(16), overlap=True)
+    finally:
+        d.destroy_process_group()
+
+
+class _StatsReplica(object):
+    """Just the surface sync_running_statistics touches."""
+
+    def __init__(self, rank):
+        self.v = {"bn_s1.mean": np.full((1, 5), 1.0 + rank, np.float32), "bn_s1.inv_std": np.arange(5, dtype=np.float32) * (rank + 1)}
+
+    def running_statistic_names(self):
+        return list(self.v)
+
+    def get_param(self, n):
+        return self.v[n]
+
+    def set_param(self, n, value):
+        assert np.asarray(value).shape == self.v[n].shape
+        self.v[n] = np.asarray(value, np.float32)
+
+
+def _worker_stats(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ip_avsr_amd.parallel import DataParallel
+        rep = _StatsReplica(rank)
+        dp = DataParallel(rep, grad_tensor=torch.zeros(8))
+        n = dp.sync_running_statistics()
+        q.put((rank, n, rep.v))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_batchnorm_running_statistics_are_averaged_over_the_ranks():
+    """ADVICE r2: a BatchNorm layer's running mean / inv_std are updated from each rank's shard and have no gradient;
+    sync_running_statistics (called by predict_sharded / loss_sharded) makes the replicas agree on their average."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_stats, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    results = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    for rank, n, v in results:
+        assert n == 2
+        np.testing.assert_array_equal(v["bn_s1.mean"], np.full((1, 5), 1.5, np.float32))
+        np.testing.assert_array_equal(v["bn_s1.inv_std"], np.arange(5, dtype=np.float32) * 1.5)

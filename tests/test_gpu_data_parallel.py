@@ -46,7 +46,8 @@ def test_single_rank_nccl_dataparallel_equals_plain_step():
         ptr, nbytes = dpm.flat_buffer(_lib.BUF_GRAD)
         assert g.data_ptr() == ptr and g.numel() * 4 == nbytes and g.dtype == torch.float32
         dp = DataParallel(dpm)
-        assert dp.overlap and len(dp.buckets) == 1 + sum(2 if len(s["enc_shapes"]) >= 2 else 1 for s in spec["streams"])
+        # [tail] + per stream its [BatchNorm | LSTM] range + one [W | b] range per encoder layer
+        assert dp.overlap and len(dp.buckets) == 1 + sum(1 + len(s["enc_shapes"]) for s in spec["streams"])
         # the buckets tile the whole flat buffer (incl. the cost tail) without overlap
         cover = sorted(dp.buckets)
         assert cover[0][0] == 0 and cover[-1][1] == g.numel()
@@ -139,6 +140,9 @@ def _bucket_snapshots_equal_final(m, xs, y, m_d, theta, order, need_early):
                 snaps.append(g[b:e].clone())
         torch.cuda.synchronize()
         early = 0
+        if order != "forked":                 # the list is in completion order: an in-order communication stream never holds a
+            for a, b_ in zip(events, events[1:]):                         # ready bucket behind a later one
+                assert a.elapsed_time(b_) >= -0.02, ("bucket list out of completion order", order)
         for (b, e), ev, snap in zip(buckets, events, snaps):
             assert torch.equal(snap, g[b:e]), ("bucket released before it was final", order, (b, e))
             early += ev.elapsed_time(end) > 0.05                          # ms between the bucket's event and the end of the step
@@ -148,20 +152,27 @@ def _bucket_snapshots_equal_final(m, xs, y, m_d, theta, order, need_early):
     m.set_bucket_events([])
 
 
-@pytest.mark.parametrize("order", ["default", "stream_major"])
+def _expected_bucket_count(spec):
+    return 1 + sum(1 + len(s["enc_shapes"]) for s in spec["streams"])
+
+
+@pytest.mark.parametrize("order", ["default", "stream_major", "ungrouped", "forked"])
 def test_a_bucket_is_final_when_its_event_fires(order, monkeypatch):
     """What the overlap relies on, checked on one GPU: at the moment a bucket's event completes, that range of the gradient
     buffer already holds its FINAL values (a copy taken behind the event on a side stream equals the range after the whole
     backward pass, bit for bit) -- for the layer-major order with grouped launches and for the stream-major one
     (ADN_DP_STREAM_MAJOR), at the bench geometry so that back-propagation is still running while the copies are taken; and
-    for graphs whose streams have no encoder, one encoder layer (one bucket per stream) or several."""
+    for graphs whose streams have no encoder, one encoder layer or several.  The bucket list (one bucket per stream top and
+    per encoder layer) must also be in the order the events fire -- in every mode that makes back-propagation stream-major
+    (ADN_DP_STREAM_MAJOR, ADN_NO_GROUPED_BACKWARD, forked streams), not only the one named after data parallel."""
     import torch
     import bench
     from ip_avsr_amd.model import AdeNetModel
-    if order == "stream_major":
-        monkeypatch.setenv("ADN_DP_STREAM_MAJOR", "1")
-    else:
-        monkeypatch.delenv("ADN_DP_STREAM_MAJOR", raising=False)
+    for var in ("ADN_DP_STREAM_MAJOR", "ADN_NO_GROUPED_BACKWARD", "ADN_STREAMS"):
+        monkeypatch.delenv(var, raising=False)
+    if order != "default":
+        monkeypatch.setenv({"stream_major": "ADN_DP_STREAM_MAJOR", "ungrouped": "ADN_NO_GROUPED_BACKWARD",
+                            "forked": "ADN_STREAMS"}[order], "1")
     torch.cuda.set_device(0)
     m = AdeNetModel(bench.build_spec())
     m.set_precision("bf16")
@@ -169,6 +180,7 @@ def test_a_bucket_is_final_when_its_event_fires(order, monkeypatch):
     xs, y, m_d, _ = bench.synthetic_batch(torch, 0, bench.B_PER_GPU, torch.device("cuda", 0))
     for _ in range(3):
         m.train_step(xs, y, m_d, bench.THETA, 2e-3, want_loss=False)
+    assert len(m.grad_buckets()) == _expected_bucket_count(m.spec)
     _bucket_snapshots_equal_final(m, xs, y, m_d, bench.THETA, order, need_early=True)
     m.close()
     rng = np.random.default_rng(3)
@@ -179,6 +191,7 @@ def test_a_bucket_is_final_when_its_event_fires(order, monkeypatch):
         for precision in ("bf16", "f32"):
             mm = AdeNetModel(dict(spec, precision=precision))
             mm.set_params_dict(O.init_params(spec, rng, np.float32, enc_std=0.2, perturb=0.1))
+            assert len(mm.grad_buckets()) == _expected_bucket_count(spec)
             mask = np.ones((B, T), np.uint8)
             xs2 = [rng.normal(size=(B, T, st["input_dim"])).astype(np.float32) for st in spec["streams"]]
             y2 = np.repeat(rng.integers(0, 7, size=(B, 1)), T, axis=1).astype(np.int32)
@@ -247,3 +260,47 @@ def test_exchange_error_word_is_in_bucket_0_when_its_event_fires(precision):
         lib.adn_debug_raise_exchange_error(0)
         m.set_bucket_events([])
         m.close()
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16", "bf16x3"])
+def test_ranged_adam_equals_whole_buffer_adam_on_the_device(precision):
+    """adn_adam_begin / adn_adam_range over the bucket list / adn_adam_end leaves parameters, Adam moments, the step count
+    and (bf16 modes) the next step's loss exactly where adn_apply_adam leaves them -- the bf16 parameter shadow written by
+    the ranged kernels included; call-sequence errors are reported."""
+    import torch
+    from ip_avsr_amd._lib import AdenetError
+    from ip_avsr_amd.model import AdeNetModel
+    torch.cuda.set_device(0)
+    spec = dict(O.spec_nstream([40, 36, 30], enc_shapes=(48, 20), enc_acts=("rectify", "linear"), lstm_size=32, classes=7,
+                               fusion="concat", has_encoder=[True, True, False]), precision=precision)
+    rng = np.random.default_rng(21)
+    p = O.init_params(spec, rng, np.float32, enc_std=0.2, perturb=0.1)
+    B, T = 48, 10
+    mask = np.ones((B, T), np.uint8)
+    xs = [rng.normal(size=(B, T, st["input_dim"])).astype(np.float32) for st in spec["streams"]]
+    y = np.repeat(rng.integers(0, 7, size=(B, 1)), T, axis=1).astype(np.int32)
+    a, b = AdeNetModel(spec), AdeNetModel(spec)
+    a.set_params_dict(p); b.set_params_dict(p)
+    buckets = b.grad_buckets()
+    with pytest.raises(AdenetError):
+        b.adam_range(0, 8)                                     # no step open
+    with pytest.raises(AdenetError):
+        b.adam_begin(1e-3)                                     # no gradients
+    from ip_avsr_amd.parallel import wrap_flat_buffer
+    ga, gb = wrap_flat_buffer(a), wrap_flat_buffer(b)
+    for step in range(3):
+        a.compute_grads(xs, y, mask, 2, want_loss=False)
+        b.zero_grads()                                         # (marks b's gradients valid) ... and b gets a's gradients:
+        gb.copy_(ga)                                           # two runs of one step may differ in the last bit (atomics)
+        a.apply_adam(2e-3)
+        b.adam_begin(2e-3)
+        for (lo, hi) in buckets:
+            b.adam_range(lo, hi)
+        b.adam_end()
+    assert a.adam_step_count() == b.adam_step_count() == 3
+    sa, sb = a.get_adam_state(), b.get_adam_state()
+    for u, v in zip(a.get_all_param_values() + sa["m"] + sa["v"], b.get_all_param_values() + sb["m"] + sb["v"]):
+        np.testing.assert_array_equal(u, v)
+    la, lb = float(a.loss(xs, y, mask, 2)), float(b.loss(xs, y, mask, 2))   # (a stale bf16 shadow would show at ~1e-3)
+    assert abs(la - lb) <= 2e-6 * abs(la)
+    a.close(); b.close()
