@@ -7,8 +7,7 @@ run() {
     bench.py --gpus 1 --steps 40 --warmup 10 --no-profile --accurate-precision none --no-reference-minibatch --no-cpu-baseline 2>/dev/null \
     | tail -1 | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print("%.3f ms/step" % d["ms_per_step"])'
 }
-run "plain step, no DataParallel                          " "ADN_BENCH_FORCE_DP="
-run "one all-reduce of the whole buffer (no overlap)      " "ADN_DP_NO_OVERLAP=1"
+run "one all-reduce of the whole buffer, Adam (no overlap)" "ADN_DP_NO_OVERLAP=1"
 run "16 buckets, one collective each, Adam per bucket     " "ADN_DP_NO_COALESCE=1"
 run "16 buckets, grouped collectives (6), Adam per bucket " "X=1"
 run "16 buckets, grouped collectives, whole-buffer Adam   " "ADN_DP_WHOLE_BUFFER_ADAM=1"

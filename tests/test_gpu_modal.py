@@ -198,3 +198,98 @@ def test_avnet_matches_the_oracle(tmp_path):
         if fusion == "adasum":
             assert np.allclose(np.ravel(l_fuse.get_all_param_values(scaling_param=True)), [p["adasum1.adacoeff0"], p["adasum1.adacoeff1"]])
         net.close()
+
+
+# ------------------------------------------------------------------- the drivers' training follows the oracle's update rule
+def _run_and_replay(monkeypatch, run, tol):
+    """Runs a schema-2 driver with a spy on the network's training calls (records the parameters ahead of the first step and
+    every minibatch, rule, learning rate and momentum the driver hands over; pins the dropout stream to (seed 4321, call number)),
+    then replays the SAME batches through the oracle's graph and update rules in float64 from the same parameters and
+    compares every trained tensor."""
+    from oracle import adenet_oracle as O
+    from ip_avsr_amd.model import AdeNetModel
+    rec = dict(calls=[], p0=None, spec=None)
+    plain = {k: getattr(AdeNetModel, k) for k in ("train_step", "compute_grads", "apply_sgd", "apply_adadelta")}
+
+    def note(net, inputs, targets, mask, window, **rule):
+        if rec["p0"] is None:
+            rec["p0"] = {k: np.asarray(v, np.float64) for k, v in net.get_params_dict().items()}
+            rec["spec"] = net.spec
+        net.set_dropout_state(4321, len(rec["calls"]))
+        rec["calls"].append(dict(xs=[np.array(x, np.float64) for x in inputs], y=np.array(targets), mask=np.array(mask),
+                                 window=int(window), **rule))
+
+    def train_step(self, inputs, targets, mask, window, learning_rate, *a, **k):      # forward + backward + Adam
+        note(self, inputs, targets, mask, window, rule="adam", lr=float(learning_rate), mm=0.0)
+        return plain["train_step"](self, inputs, targets, mask, window, learning_rate, *a, **k)
+
+    def compute_grads(self, inputs, targets, mask, window, *a, **k):                  # ... the other rules: gradients,
+        note(self, inputs, targets, mask, window, rule=None)
+        return plain["compute_grads"](self, inputs, targets, mask, window, *a, **k)
+
+    def apply_sgd(self, learning_rate, momentum=0.0, nesterov=False):                 # ... then one of these
+        rec["calls"][-1].update(rule="sgdnm" if nesterov else "sgdm", lr=float(learning_rate), mm=float(momentum))
+        return plain["apply_sgd"](self, learning_rate, momentum, nesterov)
+
+    def apply_adadelta(self, learning_rate=1.0, *a, **k):
+        rec["calls"][-1].update(rule="adadelta", lr=float(learning_rate), mm=0.0)
+        return plain["apply_adadelta"](self, learning_rate, *a, **k)
+
+    for k, f in (("train_step", train_step), ("compute_grads", compute_grads), ("apply_sgd", apply_sgd), ("apply_adadelta", apply_adadelta)):
+        monkeypatch.setattr(AdeNetModel, k, f)
+    out = run()
+    for k, f in plain.items():
+        monkeypatch.setattr(AdeNetModel, k, f)
+    net, spec, p = out["network"], rec["spec"], {k: v.copy() for k, v in rec["p0"].items()}
+    assert list(p) == O.param_names(spec)
+    has_dropout = bool(spec.get("agg_dropout")) or any(s.get("dropout") for s in spec["streams"])
+    adam, vel, ada = O.adam_init(p), O.momentum_init(p), O.adadelta_init(p)
+    for k, c in enumerate(rec["calls"]):
+        _, g, cache = O.loss_and_grads(spec, p, c["xs"], c["y"], c["mask"], c["window"],
+                                       dropout=dict(seed=4321, counter=k) if has_dropout else None, training=True)
+        if c["rule"] == "adam":
+            O.adam_step(p, g, adam, c["lr"])
+        elif c["rule"] == "adadelta":
+            O.adadelta_step(p, g, ada, c["lr"])
+        else:
+            O.momentum_step(p, g, vel, c["lr"], c["mm"], nesterov=(c["rule"] == "sgdnm"))
+        O.bn_running_update(spec, p, cache)
+    got = net.get_params_dict()
+    worst = 0.0
+    for name in p:
+        moved = np.abs(p[name] - rec["p0"][name]).max()
+        err = np.abs(got[name] - p[name]).max()
+        scale = max(np.abs(p[name]).max(), 1e-3)
+        worst = max(worst, err / scale)
+        assert err <= tol * scale, (name, err, scale, moved)
+    trained = sum(np.abs(p[n] - rec["p0"][n]).max() > 1e-5 for n in p)
+    assert trained >= len(p) - 2 * len(spec["streams"]) - 2, "the replay must have moved the parameters"   # (BatchNorm statistics aside)
+    return out, rec, worst
+
+
+def test_schema2_training_follows_the_oracle_update_rules(tmp_path, monkeypatch):
+    """not only finite costs -- the parameters a schema-2 driver leaves behind are the ones the oracle's
+    graph + update rule produce from the same initial parameters over the same minibatches, learning-rate / momentum
+    schedules included: Adam at Lasagne's default rate (cuave/bimodal_with_val.py:333), sgd with classic momentum and the
+    t1 / decay schedule, Nesterov momentum and adadelta (avletters/bimodal.py:446-455,541-545), adadelta with the per-epoch
+    decay on the dropout model adenet_v3 (oulu/trimodal_with_val.py:388,508-510)."""
+    from ip_avsr_amd.avletters import bimodal
+    from ip_avsr_amd.cuave import bimodal_with_val
+    from ip_avsr_amd.oulu import trimodal_with_val
+    root = str(tmp_path)
+    for sub in "cao":
+        os.makedirs(os.path.join(root, sub))
+    out, rec, worst = _run_and_replay(monkeypatch, lambda: bimodal_with_val.main(
+        ["--config", MF.make_cuave(os.path.join(root, "c")), "--seed", "3", "--no_plot", "--no_epochs", "3"]), 2e-4)
+    assert {c["rule"] for c in rec["calls"]} == {"adam"} and len(rec["calls"]) >= 3
+    out["network"].close()
+    tri, bi = MF.make_avletters(os.path.join(root, "a"))
+    for extra in (["--update_rule", "sgdm"], ["--update_rule", "sgdnm"], ["--update_rule", "adadelta", "--learning_rate", "1.0"]):
+        out, rec, worst = _run_and_replay(monkeypatch, lambda: bimodal.main(["--config", bi, "--seed", "1", "--no_plot"] + extra), 2e-4)
+        assert {c["rule"] for c in rec["calls"]} == {extra[1]}
+        out["network"].close()
+    out, rec, worst = _run_and_replay(monkeypatch, lambda: trimodal_with_val.main(
+        ["--config", MF.make_oulu(os.path.join(root, "o")), "--seed", "5", "--no_plot"]), 5e-4)
+    assert any(s.get("dropout") for s in rec["spec"]["streams"]) or rec["spec"].get("agg_dropout")
+    assert len({c["lr"] for c in rec["calls"]}) >= 2, "the per-epoch decay must have fired inside the recorded run"
+    out["network"].close()
