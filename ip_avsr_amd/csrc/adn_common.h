@@ -112,6 +112,9 @@ struct GemmArgs {
     // ... and the result's own planes: C16 (hi) and C16lo, written by the kernel that multiplies over planes; *planes_done reports
     // whether they were (otherwise the caller splits C itself)
     void* C16lo = nullptr; int* planes_done = nullptr;
+    int b_pad_zero = 0;                // the columns of B behind N (up to ldb) hold zeros: a kernel may then compute (and write zeros
+                                       // into) the pad columns of C up to round_up(N, 4)
+    int* fp32_skipped = nullptr;       // (out) lean_ok was used: C was NOT written, the result lives in its planes only
     int lean_ok = 0;               // ... and nobody reads the fp32 C then: the kernel that writes both planes skips it
     // split-K workspace of the persistent ping-pong kernel (partial tiles as plain stores + a reduce pass instead of
     // float atomics); without it large weight-gradient GEMMs stay on the atomic split-K kernels
@@ -137,6 +140,7 @@ int col_sum_batch(ColSumBatch& b, hipStream_t s);          // launches (if any i
 struct TransposeItem { const float* W; void* out; int rows, cols, ld, ldT, block_end; };
 int transpose_to_bf16_batch(const TransposeItem* dev_items, int n, int total_blocks, hipStream_t s, int lo_part = 0);
 int split_hilo(const float* src, void* hi, void* lo, size_t n, hipStream_t s);   // fp32 -> the bf16x3 mode's two planes
+int join_hilo(const void* hi, const void* lo, float* dst, size_t n, hipStream_t s);   // ... and back (hi + lo)
 
 // ---------------------------------------------------------------------------------------
 // element-wise / HBM-bound kernels (elementwise.hip)
@@ -240,7 +244,9 @@ struct LstmStep {          // one LSTM instance taking part in a (possibly multi
     const void* W_frag_bwd_lo = nullptr;   // ... of the backward image
     void* h16;             // [(T+1)*B][ldh] bf16 shadow of hbuf
     void* dG16;            // [T*B][ldg]     bf16 shadow of dG
-    void* dG16lo = nullptr;  // bf16x3 mode: with dG16 the hi / lo planes of dG, written by the weight-stationary backward kernel
+    void* dG16lo = nullptr;  // bf16x3 mode: with dG16 the hi / lo planes of dG; the weight-stationary backward kernel then writes the
+                             // planes INSTEAD of the fp32 matrix (same bytes; the caller's readers take the planes)
+    int dG_fp32_off = 0;     // bf16 mode: the weight-stationary backward kernel writes dG16 only (every reader takes the bf16 copy)
     void* xchg = nullptr;  // exchange buffer of the weight-stationary kernels (lstm_cluster.hip), lstm_cluster_xchg_bytes(B)
     // HOST pointer: launch counter of `xchg`, owned by whoever owns the buffer and reset to 0 whenever the buffer is (re)made
     // and zeroed -- the bf16x3 kernel's 16-bit tags carry it (mod 64); not read on the device

@@ -183,8 +183,22 @@ static int device_cus() {
 // dry: only answer whether the kernel WOULD take the launch (no side effects)
 constexpr int kDefaultPpMode = 4;       // tile mode the selection uses unless ADN_GEMM_PP forces one (4: eight waves, 7: four waves)
 static int gemm_pp_try_impl(const GemmArgs* gs, int n, const GemmArgs& g, int kseg, hipStream_t stream, bool* used, bool dry);
-static int gemm_pp_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used, bool dry = false) {
+static int gemm_pp_try(const GemmArgs* gs0, int n, hipStream_t stream, bool* used, bool dry = false) {
     *used = false;
+    if (n < 1 || n > kMaxGemmGroups) return ADN_OK;
+    // an output width that is not a multiple of 4 (the 150-column input gradient of the stream LSTMs): the kernel's epilogue works
+    // in float4 -- widened into C's pad columns where B's pad columns are known to be zero (the transposed weight copies)
+    GemmArgs widened[kMaxGemmGroups];
+    const GemmArgs* gs = gs0;
+    if (gs0[0].N % 4 && gs0[0].layout == GEMM_NN) {
+        const int nr = (int)round_up(gs0[0].N, 4);
+        for (int k = 0; k < n; ++k) {
+            const GemmArgs& q = gs0[k];
+            if (!q.b_pad_zero || q.N != gs0[0].N || q.ldc < nr || q.ldb < nr || q.bias || q.Y || q.Y16 || q.colsum || q.accumulate) return ADN_OK;
+            widened[k] = q; widened[k].N = nr;
+        }
+        gs = widened;
+    }
     const GemmArgs& g = gs[0];
     static const int mode_env = getenv("ADN_GEMM_PP") ? atoi(getenv("ADN_GEMM_PP")) : -1;   // 0: off, 4/5/6: force a tile shape
     if (mode_env == 0 || n > kMaxGemmGroups) return ADN_OK;
@@ -210,7 +224,11 @@ static int gemm_pp_try_impl(const GemmArgs* gs, int n, const GemmArgs& g, int ks
     static const int mode_env = getenv("ADN_GEMM_PP") ? atoi(getenv("ADN_GEMM_PP")) : -1;
     // (one output of < 256 rows wastes too much of its 256-row tiles; several of them in one launch still win: three
     //  250 x 1000 x 20800 weight gradients 66 against 3 x 33 us, three 150 x 1000 62 against 3 x 30)
-    if (g.M < (n >= 2 ? 128 : 256) || g.N < 256 || g.K < 256) return ADN_OK;
+    // (narrow outputs: a 150-column input gradient fills 59 % of its one tile column -- over planes still 2.6x the register-staged
+    //  kernel's rate on split images, 232 -> 9x us for the three streams' 20800 x 150 x 1000)
+    static const int min_n_env = getenv("ADN_GEMM_PP_MIN_N") ? atoi(getenv("ADN_GEMM_PP_MIN_N")) : 0;
+    const int min_n = min_n_env ? min_n_env : (kseg ? 128 : 256);
+    if (g.M < (n >= 2 ? 128 : 256) || g.N < min_n || g.K < 256) return ADN_OK;
     if (g.N % 4 || g.ldc % 4 || g.lda % 8 || g.ldb % 8) return ADN_OK;
     if (g.layout == GEMM_NN && g.K % 8 && g.lda < round_up(g.K, 8)) return ADN_OK;
     // epilogue forms of the kernel: linear / rectify output; optional rectify'(Y) from the bf16 copy of Y
@@ -273,7 +291,8 @@ static int gemm_pp_try_impl(const GemmArgs* gs, int n, const GemmArgs& g, int ks
                            (n == 1 || per_group_tiles <= 16 || per_group_tiles * n * splits * 10 >= (int64_t)cus * 9);
         // (accumulate: the epilogue would read C back -- bf16 mode leaves those to the register-staged kernel; over planes the
         //  alternative is a split pass per operand, so the ping-pong kernel takes them)
-        const bool fwd_group = splits == 1 && plain && (!g.accumulate || kseg) && fill >= (kseg ? 0.60 : 0.80);
+        static const double fill_env = getenv("ADN_GEMM_PP_FILL") ? atof(getenv("ADN_GEMM_PP_FILL")) : 0.0;
+        const bool fwd_group = splits == 1 && plain && (!g.accumulate || kseg) && fill >= (fill_env > 0 ? fill_env : kseg ? 0.50 : 0.80);
         // input-gradient GEMMs of several streams (act'(Y) mask from the bf16 copy, fused column sums): 445 against 3 x 153 us
         // for 20800 x 2000 x 1000, 178 against 3 x 59 for 20800 x 1000 x 500; one alone is no faster than the 128 x 128 kernel
         const bool bwd_group = splits == 1 && n >= 2 && g.Y16 && fill >= 0.85;
@@ -287,6 +306,8 @@ static int gemm_pp_try_impl(const GemmArgs* gs, int n, const GemmArgs& g, int ks
     p.act = g.act; p.act_grad = g.act_grad; p.accumulate = g.accumulate;
     static const int barriers_env = getenv("ADN_GEMM_PP_BARRIERS") ? atoi(getenv("ADN_GEMM_PP_BARRIERS")) : 1;   // 2: the two-barrier schedule
     p.one_barrier = barriers_env != 2;
+    static const bool epi_drain = getenv("ADN_GEMM_EPI_DRAIN") != nullptr;
+    p.no_epi_overlap = epi_drain ? 1 : 0;
     p.kseg = kseg; p.kreal = gs[0].K;
     p.tiles_m = cdiv(g.M, cd.bm); p.tiles_n = cdiv(g.N, cd.bn);
     p.k_chunk = (int)round_up(cdiv(g.K, splits), 32);
@@ -315,7 +336,11 @@ static int gemm_pp_try_impl(const GemmArgs* gs, int n, const GemmArgs& g, int ks
         if (gs[k].planes_done) *gs[k].planes_done = q.C16lo ? 1 : 0;
         // (planes: the fp32 copy of a result every reader takes from its planes is not written -- unless the bias gradient
         //  that rides on this launch could not be fused and will be summed from the fp32 values)
-        if (q.C16lo && gs[k].lean_ok && !g.accumulate && (!g.colsum || fused_colsum)) q.C = nullptr;
+        if (gs[k].fp32_skipped) *gs[k].fp32_skipped = 0;
+        if (q.C16lo && gs[k].lean_ok && !g.accumulate && (!g.colsum || fused_colsum)) {
+            q.C = nullptr;
+            if (gs[k].fp32_skipped) *gs[k].fp32_skipped = 1;
+        }
         q.Y16 = (g.act_grad == ADN_ACT_RECTIFY) ? gs[k].Y16 : nullptr; q.Y = nullptr; q.bias = gs[k].bias;
         q.colsum = fused_colsum ? gs[k].colsum_ws : nullptr;
         if (gs[k].colsum_done) *gs[k].colsum_done = fused_colsum ? 1 : 0;
@@ -486,6 +511,7 @@ static int x3_try_planes(const GemmArgs* gs, int n, hipStream_t stream, bool* us
         h[k] = gs[k];
         if (h[k].layout == GEMM_NT && h[k].BT16 && h[k].BT16lo) {        // dZ W^T over the planes of W^T
             h[k].layout = GEMM_NN; h[k].B16 = h[k].BT16; h[k].B16lo = h[k].BT16lo; h[k].ldb = h[k].ldbT;
+            h[k].b_pad_zero = 1;                  // (transposed weight planes: written for the valid columns only, zero elsewhere)
         }
         if (!h[k].A16 || !h[k].A16lo || !h[k].B16 || !h[k].B16lo) return ADN_OK;
         h[k].precision = ADN_PRECISION_BF16;

@@ -746,7 +746,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_kernel(const LstmCluster
                 } else {
                     dh_c[r] = dh;
                 }
-                *reinterpret_cast<float4*>(P.dG + ridx * ldg + u * 4) = dg;
+                if (!P.dG_fp32_off) *reinterpret_cast<float4*>(P.dG + ridx * ldg + u * 4) = dg;
                 bsum.x += dg.x; bsum.y += dg.y; bsum.z += dg.z; bsum.w += dg.w;
             }
             bf16x4 d16;
@@ -1022,13 +1022,17 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_x3_kernel(const LstmClus
                 } else {
                     dh_c[r] = dh;
                 }
-                *reinterpret_cast<float4*>(P.dG + (size_t)t * B * ldg + goff[r]) = dg;      // (ok: goff is this row and unit)
+                if (!P.dG16lo) *reinterpret_cast<float4*>(P.dG + (size_t)t * B * ldg + goff[r]) = dg;      // (ok: goff is this row and unit)
                 bsum.x += dg.x; bsum.y += dg.y; bsum.z += dg.z; bsum.w += dg.w;
             }
             bf16x4 dhi, dlo;
             dhi[0] = (__bf16)dg.x; dhi[1] = (__bf16)dg.y; dhi[2] = (__bf16)dg.z; dhi[3] = (__bf16)dg.w;
             dlo[0] = (__bf16)(dg.x - (float)dhi[0]); dlo[1] = (__bf16)(dg.y - (float)dhi[1]);
             dlo[2] = (__bf16)(dg.z - (float)dhi[2]); dlo[3] = (__bf16)(dg.w - (float)dhi[3]);
+            if (ok && P.dG16lo) {                     // the two planes in place of the fp32 row piece: the same 16 bytes per (row, unit)
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.dG16) + (size_t)t * B * ldg + goff[r]) = dhi;
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.dG16lo) + (size_t)t * B * ldg + goff[r]) = dlo;
+            }
             *reinterpret_cast<bf16x4*>(&dgs_hi[row][ul * 4]) = dhi;
             *reinterpret_cast<bf16x4*>(&dgs_lo[row][ul * 4]) = dlo;
 

@@ -186,6 +186,9 @@ struct adn_model {
     std::vector<LstmWork> aggw;
     size_t tail_begin = 0;             // first float of the [fuse | agg | softmax] parameters
     std::vector<hipEvent_t> bucket_events;   // caller-owned; in the order of adn_grad_buckets (bucket_ranges)
+    // bf16x3 over planes: results whose fp32 copy was not written (their readers take the planes); a reader that needs fp32 after
+    // all -- a GEMM the ping-pong kernel declines, adn_read_encoder_activation -- gets hi + lo written back first
+    std::vector<std::pair<const float*, size_t>> fp32_stale;
     int dp_order = -1;                       // -1: not latched yet; 0: layer-major buckets / back-propagation, 1: stream-major
     float adam_a_t = 0.f; bool adam_open = false;   // step size of the optimiser step opened by adn_adam_begin
     size_t adacoeff = 0;               // S scalars (one 8-float block)
@@ -452,6 +455,7 @@ void carve_lstm(adn_model* m, Carver& cv, LstmWork& w, int B, int T, int ldh, in
 size_t carve(adn_model* m, char* base, int B, int T, bool host_inputs) {
     Carver cv{base};
     m->shadows.clear();
+    m->fp32_stale.clear();
     const size_t N = (size_t)B * T;
     const int ldh = m->ldh, ldg = m->ldg;
     m->mask_bt = cv.take<uint8_t>(N);
@@ -669,10 +673,10 @@ void mgemm_prepare(adn_model* m, GemmArgs& g, bool lean) {
         // kernel takes the shape and otherwise falls back to split images of the fp32 operands
         g.A16 = m->shadow_of(g.A); g.A16lo = m->shadow_lo_of(g.A);
         g.B16 = m->shadow_of(g.B); g.B16lo = m->shadow_lo_of(g.B);
-        // (opt-in, ADN_X3_LEAN=1: skip the fp32 copy of a result whose planes the kernel writes -- only sound when EVERY reader of
-        //  that tensor runs over planes; a narrow next layer (the 50-unit bottleneck) reads fp32 through the image path, so the
-        //  default keeps the fp32 copies: measured 9.09 -> 8.81 ms per step at the bench geometry, with the bottleneck's input wrong)
-        g.lean_ok = lean && !m->keep_fp32 && getenv("ADN_X3_LEAN") != nullptr;
+        // (the fp32 copy of a result whose planes the kernel writes is skipped; m_gemm() keeps a list of such tensors and writes
+        //  hi + lo back ahead of a reader that does not run over planes -- the 50-unit bottleneck's GEMMs take the image path.
+        //  ADN_X3_NO_LEAN=1 keeps every fp32 copy)
+        g.lean_ok = lean && !m->keep_fp32 && !getenv("ADN_X3_NO_LEAN");
         if (!g.A16 || !g.A16lo || !g.B16 || !g.B16lo) { g.A16 = g.B16 = g.A16lo = g.B16lo = nullptr; }
         else if (g.layout == GEMM_NT) {                    // dX = dZ W^T: the transposed plane copies of W (k-strided B), offered
                                                            // beside the NT operands -- gemm() switches to NN only if it uses them
@@ -689,13 +693,14 @@ void mgemm_prepare(adn_model* m, GemmArgs& g, bool lean) {
         if (g.Y) g.Y16 = m->shadow_of(g.Y);
         if (g.layout == GEMM_NT && g.A16 && !getenv("ADN_NO_TRANSW"))
             for (const auto& t : m->transw)
-                if (t.key == g.B) { g.layout = GEMM_NN; g.B16 = t.buf; g.ldb = t.ldT; break; }
+                if (t.key == g.B) { g.layout = GEMM_NN; g.B16 = t.buf; g.ldb = t.ldT; g.b_pad_zero = 1; break; }
         if (lean && g.A16 && g.B16 && g.C16 && !g.accumulate && g.N % 4 == 0 && g.ldc % 4 == 0 && !m->keep_fp32)
             g.C = nullptr;
     }
 }
 
 int planes_of_output(adn_model* m, const GemmArgs& g);
+int restore_fp32(adn_model* m, const float* p);
 int m_gemm(adn_model* m, const GemmArgs& g);
 int mgemm(adn_model* m, GemmArgs& g, bool lean = false) {
     mgemm_prepare(m, g, lean);
@@ -734,21 +739,59 @@ void offer_output_planes(adn_model* m, GemmArgs& g, int* done) {
     if (!hi || !lo) return;
     g.C16 = hi; g.C16lo = lo; g.planes_done = done;
 }
+// fp32 copies that were skipped (see mgemm_prepare): bookkeeping around every GEMM of the model
+static void stale_forget(adn_model* m, const float* p) {
+    for (size_t k = 0; k < m->fp32_stale.size(); ++k)
+        if (m->fp32_stale[k].first == p) { m->fp32_stale.erase(m->fp32_stale.begin() + (long)k); return; }
+}
+int restore_fp32(adn_model* m, const float* p) {
+    for (size_t k = 0; k < m->fp32_stale.size(); ++k)
+        if (m->fp32_stale[k].first == p) {
+            const size_t n = m->fp32_stale[k].second;
+            m->fp32_stale.erase(m->fp32_stale.begin() + (long)k);
+            return join_hilo(m->shadow_of(p), m->shadow_lo_of(p), const_cast<float*>(p), (size_t)round_up((int64_t)n, 8), m->stream);
+        }
+    return ADN_OK;
+}
+static int operands_ready(adn_model* m, const GemmArgs* gs, int n) {
+    if (m->fp32_stale.empty()) return ADN_OK;
+    if (gemm_planes_would_run(gs, n)) return ADN_OK;               // the whole group reads planes
+    for (int k = 0; k < n; ++k) {
+        if (n > 1 && gemm_planes_would_run(&gs[k], 1)) continue;    // (a declined group is retried problem by problem)
+        ADN_TRY(restore_fp32(m, gs[k].A));
+        ADN_TRY(restore_fp32(m, gs[k].B));
+        if (gs[k].Y && !gs[k].Y16) ADN_TRY(restore_fp32(m, gs[k].Y));
+    }
+    return ADN_OK;
+}
+static void result_written(adn_model* m, const GemmArgs& g, int skipped) {
+    if (!g.C) return;
+    if (skipped) {
+        for (auto& e : m->fp32_stale) if (e.first == g.C) { e.second = (size_t)g.M * g.ldc; return; }
+        m->fp32_stale.push_back({g.C, (size_t)g.M * g.ldc});
+    } else if (!m->fp32_stale.empty()) stale_forget(m, g.C);
+}
 int m_gemm(adn_model* m, const GemmArgs& g0) {
-    GemmArgs g = g0; int done = 0;
+    GemmArgs g = g0; int done = 0, skipped = 0;
     offer_output_planes(m, g, &done);
+    g.fp32_skipped = &skipped;
+    ADN_TRY(operands_ready(m, &g, 1));
+    if (g.accumulate) ADN_TRY(restore_fp32(m, g.C));
     ADN_TRY(gemm(g, m->stream));
+    result_written(m, g, skipped);
     return planes_of_output(m, g);
 }
 int m_gemm_grouped(adn_model* m, const GemmArgs* gs0, int n) {
-    GemmArgs gs[kMaxGemmGroups]; int done[kMaxGemmGroups];
+    GemmArgs gs[kMaxGemmGroups]; int done[kMaxGemmGroups], skipped[kMaxGemmGroups];
     if (n > kMaxGemmGroups) {                                       // (never: the callers batch at most kMaxGemmGroups)
         for (int k = 0; k < n; ++k) ADN_TRY(m_gemm(m, gs0[k]));
         return ADN_OK;
     }
-    for (int k = 0; k < n; ++k) { gs[k] = gs0[k]; offer_output_planes(m, gs[k], &done[k]); }
+    for (int k = 0; k < n; ++k) { gs[k] = gs0[k]; offer_output_planes(m, gs[k], &done[k]); skipped[k] = 0; gs[k].fp32_skipped = &skipped[k]; }
+    ADN_TRY(operands_ready(m, gs, n));
+    for (int k = 0; k < n; ++k) if (gs[k].accumulate) ADN_TRY(restore_fp32(m, gs[k].C));
     ADN_TRY(gemm_grouped(gs, n, m->stream));
-    for (int k = 0; k < n; ++k) ADN_TRY(planes_of_output(m, gs[k]));
+    for (int k = 0; k < n; ++k) { result_written(m, gs[k], skipped[k]); ADN_TRY(planes_of_output(m, gs[k])); }
     return ADN_OK;
 }
 
@@ -933,9 +976,12 @@ LstmStep make_step(const adn_model* m, const LstmParams& lp, const LstmWork& w, 
     s.W_hid16 = b16 ? m->shadow_of(m->P(lp.W_hid)) : nullptr;
     s.h16 = b16 ? m->shadow_of(w.hbuf) : nullptr;
     s.dG16 = b16 ? m->shadow_of(w.dG) : nullptr;
-    // (the planes of dG are made by a split pass behind the kernel: written from inside it -- 8-byte stores from the gate-math
-    //  lanes, or 16-byte stores from its LDS images one step later -- they cost the step 0.3 / 0.7 us of its 6.4: measured 0.52
-    //  -> 0.58 / 0.67 ms of backward LSTM time per train step against 0.19 ms of split passes, and the kernel below the 40 % line)
+    static const bool dg_fp32 = getenv("ADN_LSTM_DG_FP32") != nullptr;       // (A/B: keep the fp32 copy of dG)
+    if (grads && shadows_on(m) && s.dG16 && !m->keep_fp32 && !dg_fp32) s.dG_fp32_off = 1;       // bf16 mode: the bf16 copy is the only one read
+    if (grads && x3 && m->planes() && !m->keep_fp32 && !dg_fp32) { s.dG16 = m->shadow_of(w.dG); s.dG16lo = m->shadow_lo_of(w.dG); if (!s.dG16 || !s.dG16lo) s.dG16 = s.dG16lo = nullptr; }
+    // (dG leaves the weight-stationary backward kernels in the form its readers take -- the bf16 copy in bf16 mode, the two planes
+    //  in bf16x3 mode -- INSTEAD of as fp32: the same or fewer bytes per step from the kernel, no split pass behind it.  Writing
+    //  the planes in ADDITION to fp32 cost the bf16x3 step 0.3 - 0.7 us of its 6.4 and put the kernel below the 40 % line.)
     s.xchg = (b16 || x3) ? w.xchg : nullptr;
     s.xchg_seq = const_cast<unsigned*>(&w.xchg_seq);
     if (grads) { s.dbias = m->G(lp.b); s.dhid_init = m->G(lp.hid_init); s.dcell_init = m->G(lp.cell_init); }
@@ -962,7 +1008,14 @@ int run_lstm_group(adn_model* m, std::vector<LstmStep>& steps, int B, int T, boo
     if (m->planes())                 // (bf16 mode: the kernels write the 16-bit copies themselves)
         for (size_t q = 0; q < steps.size(); ++q) {
             const LstmStep& st_ = steps[q];
-            if (backward) { if (!planes_done[q]) ADN_TRY(refresh(m, st_.dG, (size_t)B * T * m->ldg)); }
+            if (backward) {
+                if (!planes_done[q]) ADN_TRY(refresh(m, st_.dG, (size_t)B * T * m->ldg));
+                else {                                   // fp32 dG was not written: a reader that needs it asks restore_fp32()
+                    bool have = false;
+                    for (auto& e : m->fp32_stale) if (e.first == st_.dG) { e.second = (size_t)B * T * m->ldg; have = true; }
+                    if (!have) m->fp32_stale.push_back({st_.dG, (size_t)B * T * m->ldg});
+                }
+            }
             else ADN_TRY(refresh(m, st_.hbuf, (size_t)(T + 1) * B * m->ldh));
         }
     return ADN_OK;
@@ -1354,6 +1407,7 @@ int lstm_param_grads(adn_model* m, const LstmParams& lp, const LstmWork& w, cons
         ADN_TRY(mgemm(m, g));
     }
     if (!sums_done) {
+        ADN_TRY(restore_fp32(m, w.dG));
         ADN_TRY(col_sum(w.dG, ldg, N, 4 * H, m->G(lp.b), 1, s));
         ADN_TRY(col_sum(w.dh_carry, ldh, B, H, m->G(lp.hid_init), 1, s));
         ADN_TRY(col_sum(w.dc_state, ldh, B, H, m->G(lp.cell_init), 1, s));
@@ -1569,6 +1623,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
                 if (same) ADN_TRY(m_gemm_grouped(m, gs, n));
                 else for (int j = 0; j < n; ++j) ADN_TRY(m_gemm(m, gs[j]));
                 if (!sums_done) {
+                    ADN_TRY(restore_fp32(m, w.dG));
                     ADN_TRY(col_sum(w.dG, m->ldg, N, 4 * H, m->G(lp.b), 1, s));
                     ADN_TRY(col_sum(w.dh_carry, ldh, B, H, m->G(lp.hid_init), 1, s));
                     ADN_TRY(col_sum(w.dc_state, ldh, B, H, m->G(lp.cell_init), 1, s));
@@ -2302,18 +2357,9 @@ int adn_read_encoder_activation(adn_model* m, int stream, int layer, float* host
     const int u = st.cfg.enc_units[layer];
     ADN_HIP_CHECK(hipStreamSynchronize(m->stream));
     const size_t rows = (size_t)m->lastB * m->lastT;
-    if (m->planes() && layer + 1 < st.cfg.n_enc && m->shadow_of(st.act[layer]) && !m->keep_fp32 && getenv("ADN_X3_LEAN")) {
-        // bf16x3 keeps intermediate activations as their hi / lo planes only: x = hi + lo to 2^-17
-        std::vector<uint16_t> hi(rows * ld_of(u)), lo(rows * ld_of(u));
-        ADN_HIP_CHECK(hipMemcpy(hi.data(), m->shadow_of(st.act[layer]), hi.size() * 2, hipMemcpyDeviceToHost));
-        ADN_HIP_CHECK(hipMemcpy(lo.data(), m->shadow_lo_of(st.act[layer]), lo.size() * 2, hipMemcpyDeviceToHost));
-        for (size_t r = 0; r < rows; ++r)
-            for (int c = 0; c < u; ++c) {
-                const uint32_t a = (uint32_t)hi[r * ld_of(u) + c] << 16, b = (uint32_t)lo[r * ld_of(u) + c] << 16;
-                float fa, fb; memcpy(&fa, &a, 4); memcpy(&fb, &b, 4);
-                host_dst[r * u + c] = fa + fb;
-            }
-        return ADN_OK;
+    if (m->planes()) {                       // bf16x3: an activation kept as its two planes only gets hi + lo written back first
+        ADN_TRY(restore_fp32(m, st.act[layer]));
+        ADN_HIP_CHECK(hipStreamSynchronize(m->stream));
     }
     if (shadows_on(m) && layer + 1 < st.cfg.n_enc && m->shadow_of(st.act[layer])) {
         // bf16 mode keeps only the bf16 copy of intermediate activations: widen it on the host
