@@ -58,6 +58,12 @@ timeout 200 python3 profiles/hipblaslt_calibration.py > $OUT/hipblaslt_calibrati
 timeout 300 python3 profiles/convae_bench.py > $OUT/convae_bench.txt 2>/dev/null
 # the bench lines last, so that roofline.traffic comes from the PMC passes of THIS build
 mkdir -p profiles/$ROUND && cp $OUT/pmc_traffic_bf16.json profiles/$ROUND/pmc_traffic_bf16.json && cp $OUT/pmc_traffic_bf16x3.json profiles/$ROUND/pmc_traffic_bf16x3.json
+# data parallel machinery on one GPU (no transfer): bucket events / per-bucket Adam / grouped collectives, and the HIP-graph A/B
+# of the reference minibatch
+timeout 300 python3 profiles/scripts/dp_order_bench.py > $OUT/dp_order_bench.txt 2>&1
+timeout 600 bash profiles/scripts/dp_forced.sh > $OUT/dp_forced.txt 2>&1
+timeout 300 python3 profiles/scripts/graph_b26.py > $OUT/graph_b26.txt 2>&1
+timeout 600 python3 profiles/configs_bench.py > $OUT/configs_bench.txt 2>/dev/null
 timeout 400 python3 bench.py --precision bf16 2>/dev/null | tail -1 > $OUT/final_bf16_bench.json
 rm -rf $OUT/ks_bf16 $OUT/ks_f32 $OUT/ks_bf16x3 $OUT/pmcA $OUT/pmcB $OUT/pmcA3 $OUT/pmcB3 $OUT/pmcM3 $OUT/pmcM $OUT/pmcC $OUT/bd $OUT/bd3 $OUT/gemm_trace_x3.txt
 ls -la $OUT
