@@ -887,41 +887,25 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
 #pragma unroll
         for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // Wait until this wave's pieces of stage s + 1 have landed.  vmcnt counts loads, stores and LDS-DMA together, in issue
-    // order, so the wait names how many YOUNGER operations may stay outstanding: the stages behind s + 1 ... and, during the
-    // first D - 1 K-steps of a tile, the stores of the previous tile's epilogue, which sit in the queue between stage s + 1 (issued
-    // ahead of the epilogue) and the stages issued since.  Draining them here is what the kernel used to do (vmcnt <= one stage
-    // after every epilogue): all 256 workgroups finish a round of tiles together, their stores -- 33 MB per round for a bf16
-    // output, 134 MB with fp32 + two planes -- leave at HBM rate, and every wave sat out that burst before its next K-step.
-    // `epi_left`: a LOWER bound of the vector-memory operations this wave's last epilogue issued that need not have completed
-    // (a multiple of 16; an under-count only waits for a few of the oldest stores); -1: unknown (edge tile, accumulate): drain.
-    int epi_left = 0;
-    auto vm_wait = [&](int n) {
-        switch (n) {
-#define ADN_VMW(k) case k: wait_vmcnt<k>(); break;
-            ADN_VMW(0) ADN_VMW(1) ADN_VMW(2) ADN_VMW(3) ADN_VMW(4) ADN_VMW(5) ADN_VMW(6) ADN_VMW(7) ADN_VMW(8) ADN_VMW(9) ADN_VMW(10) ADN_VMW(11)
-            ADN_VMW(12) ADN_VMW(16) ADN_VMW(19) ADN_VMW(20) ADN_VMW(22) ADN_VMW(24) ADN_VMW(28) ADN_VMW(32) ADN_VMW(35) ADN_VMW(36) ADN_VMW(38)
-            ADN_VMW(40) ADN_VMW(44) ADN_VMW(48) ADN_VMW(51) ADN_VMW(52) ADN_VMW(54) ADN_VMW(56) ADN_VMW(60)
-#undef ADN_VMW
-            default: wait_vmcnt<0>(); break;
-        }
-    };
-    static_assert((D - 1) * PW + 48 <= 63, "vmcnt immediate");
-    auto wait_next = [&](int s, int kt_now, bool after_epi) {
+    // wait until this wave's pieces of stage s + 1 have landed; `fresh_epi`: an epilogue's stores are in the queue.
+    // (vmcnt counts loads, stores and LDS-DMA in issue order, so the stores of a tile's epilogue could be left outstanding
+    //  under a counted wait -- vmcnt <= stages + stores -- for the first D - 1 K-steps of the next tile instead of being
+    //  drained here.  Built and measured in round 3: no gain -- the DMA issued behind the stores cannot be seen complete
+    //  before them, so the drain only moves D - 1 K-steps later -- and the extra scalar state cost the K-loop 10 %.)
+    auto wait_next = [&](int s, bool fresh_epi) {
         int younger = min(D - 1, total - 2 - s);                   // younger stages this wave has issued
         if (younger < 0) return;                                   // there is no stage s + 1
-        int extra = 0;
-        if (after_epi && kt_now <= D - 2) {                        // (stage s + 1 was issued ahead of that epilogue)
-            if (epi_left < 0) { younger = min(younger, 1); epi_left = 0; }     // unknown count: leave one stage in flight, nothing else
-            else extra = epi_left;
-        }
-        vm_wait(younger * PW + extra);
+        if (fresh_epi) younger = min(younger, 1);
+        if (D >= 4 && younger >= 3) wait_vmcnt<(D >= 4 ? 3 : 2) * PW>();
+        else if (younger >= 2) wait_vmcnt<2 * PW>();
+        else if (younger == 1) wait_vmcnt<PW>();
+        else wait_vmcnt<0>();
     };
 
     // ---- prologue: D stages in flight, stage 0 landed for everyone -----------------------------------
     setup_src(0);
     for (int s = 0; s < D && s < total; ++s) issue_next();
-    wait_next(-1, 0, false);
+    wait_next(-1, false);
     __builtin_amdgcn_s_barrier();                                  // #0
     const bool one = p.one_barrier != 0;
     if (late && !one) __builtin_amdgcn_s_barrier();                // the lower half starts one segment later
@@ -976,7 +960,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
             for (int a = 0; a < TM; ++a) fa[a] = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4, fa[a]) & amask);
         }
         if (p.kseg && --cseg_left == 0) cseg_left = kseg_steps;
-        wait_next(s, kt, ord > 0);
+        wait_next(s, kt == 0 && s > 0);
         GSTAMP(3);
         if (!one || late) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -991,15 +975,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
             const GemmGroup gp = pick_group(p, grp);
             float* Cg = SPLIT ? p.partial + ((size_t)(grp * (int)gridDim.y + slice) * p.M) * p.ldc : gp.C;
             const int row0 = tile_m * BM + wm * WTM + (lane & 15), col0 = tile_n * BN + wn * WTN + 4 * hi;
-            {   // what the next tile's first waits may leave outstanding of this epilogue (see wait_next): only counted where
-                // every lane of the wave stores every element (interior tile), nothing is read back (accumulate), and the
-                // tile is long enough that one epilogue at most is in the window
-                const bool interior = tile_m * BM + wm * WTM + WTM <= p.M && tile_n * BN + wn * WTN + WTN <= p.N;
-                const int per_a = (Cg ? 2 : 0) + (gp.C16 ? 1 : 0) + (gp.C16lo ? 1 : 0);
-                // (with the act'(Y) mask every burst of mask loads waits for the stores ahead of it: the last burst's stores remain)
-                const int lb = per_a * TM * (gp.Y16 ? 1 : TN / 2);
-                epi_left = (SPLIT || !interior || p.accumulate || nk < D || p.no_epi_overlap || lb < 16) ? -1 : min(48, lb & ~15);
-            }
             // The act'(Y) mask of two 16-column blocks is requested in ONE burst ahead of them (2 TM eight-byte loads per
             // lane, from addresses clamped into the matrix): issued block by block, every block paid a full memory round
             // trip (measured 47 us on a 156 us launch: the epilogue holds up the barrier cadence of both wave halves).

@@ -36,7 +36,6 @@ struct GemmParams {
     int ngroups;
     int xcd_slices;     // split-K: K-slice = function of the workgroup's XCD (see the kernel)
     int one_barrier;    // ping-pong kernel: one s_barrier per K-step (halves offset inside the interval) instead of two
-    int no_epi_overlap; // ping-pong kernel: drain a tile's epilogue stores before the next tile's second K-step (ADN_GEMM_EPI_DRAIN=1; A/B)
     int kseg;           // ping-pong kernel, bf16x3 through hi / lo planes: k per segment (multiple of 32; K = 3 kseg); 0: plain
     int kreal;          // ... and the real K of a segment (the last stage of every segment is masked behind it)
     float* partial;     // split-K partial slabs [group][split][M][ldc]

@@ -306,8 +306,6 @@ static int gemm_pp_try_impl(const GemmArgs* gs, int n, const GemmArgs& g, int ks
     p.act = g.act; p.act_grad = g.act_grad; p.accumulate = g.accumulate;
     static const int barriers_env = getenv("ADN_GEMM_PP_BARRIERS") ? atoi(getenv("ADN_GEMM_PP_BARRIERS")) : 1;   // 2: the two-barrier schedule
     p.one_barrier = barriers_env != 2;
-    static const bool epi_drain = getenv("ADN_GEMM_EPI_DRAIN") != nullptr;
-    p.no_epi_overlap = epi_drain ? 1 : 0;
     p.kseg = kseg; p.kreal = gs[0].K;
     p.tiles_m = cdiv(g.M, cd.bm); p.tiles_n = cdiv(g.N, cd.bn);
     p.k_chunk = (int)round_up(cdiv(g.K, splits), 32);
