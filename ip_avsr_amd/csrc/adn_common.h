@@ -185,7 +185,8 @@ int reduce_loss(const float* v, int n, const float* total, float* out, hipStream
 // p16: optional bf16 shadow of the parameters, written with the update
 // poison / sticky (all three update rules): when *poison != 0 the kernel changes nothing and raises *sticky
 int adam_update(float* p, const float* g, float* m, float* v, int64_t n, float a_t, float beta1,
-                float beta2, float eps, hipStream_t s, void* p16 = nullptr, const float* poison = nullptr, int* sticky = nullptr);
+                float beta2, float eps, hipStream_t s, void* p16 = nullptr, const float* poison = nullptr, int* sticky = nullptr,
+                void* p16lo = nullptr);     // (p16lo: with p16 the hi / lo planes of the bf16x3 mode)
 int poison_tail(const int* err_word, float* tail1, hipStream_t s);
 int copy_bench(const float* src, float* dst, int64_t n, int repeats, hipStream_t s, float* ms);
 // lasagne.updates.sgd (momentum == 0) / momentum / nesterov_momentum; adadelta

@@ -797,7 +797,8 @@ int reduce_loss(const float* v, int n, const float* total, float* out, hipStream
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n4,
                                                    int64_t n, float a_t, float b1, float b2, float eps,
-                                                   __bf16* __restrict__ p16, const float* poison, int* sticky) {
+                                                   __bf16* __restrict__ p16, const float* poison, int* sticky,
+                                                   __bf16* __restrict__ p16lo) {
     if (poison && *poison != 0.f) {          // a rank's LSTM exchange timed out: the gradients are invalid on EVERY rank
         if (sticky && blockIdx.x == 0 && threadIdx.x == 0) *sticky = 1;
         return;
@@ -819,6 +820,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         if (p16) {                                               // the bf16 shadow the next step's GEMMs read
             __bf16 o[4] = {(__bf16)pp.x, (__bf16)pp.y, (__bf16)pp.z, (__bf16)pp.w};
             reinterpret_cast<uint2*>(p16)[i] = *reinterpret_cast<const uint2*>(o);
+            if (p16lo) {                                         // bf16x3: the lo plane bf16(p - bf16(p)) beside it
+                __bf16 l[4] = {(__bf16)(pp.x - (float)o[0]), (__bf16)(pp.y - (float)o[1]), (__bf16)(pp.z - (float)o[2]), (__bf16)(pp.w - (float)o[3])};
+                reinterpret_cast<uint2*>(p16lo)[i] = *reinterpret_cast<const uint2*>(l);
+            }
         }
     }
     if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) {      // tail (n not a multiple of 4)
@@ -829,7 +834,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         m[i] = mi; v[i] = vi;
         const float pi = p[i] - a_t * mi / (sqrtf(vi) + eps);
         p[i] = pi;
-        if (p16) p16[i] = (__bf16)pi;
+        if (p16) { p16[i] = (__bf16)pi; if (p16lo) p16lo[i] = (__bf16)(pi - (float)p16[i]); }
     }
 }
 
@@ -867,12 +872,12 @@ int poison_tail(const int* err_word, float* tail1, hipStream_t s) {
 }
 
 int adam_update(float* p, const float* g, float* m, float* v, int64_t n, float a_t, float beta1, float beta2,
-                float eps, hipStream_t s, void* p16, const float* poison, int* sticky) {
+                float eps, hipStream_t s, void* p16, const float* poison, int* sticky, void* p16lo) {
     if (n <= 0) return ADN_OK;
     const int64_t n4 = n / 4;
     ProfScope prof(PROF_ADAM, 0.0, 7.0 * 4.0 * (double)n, s);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(std::max<int64_t>(n4, 1))), dim3(256), 0, s, p, g, m, v, n4, n, a_t,
-                       beta1, beta2, eps, reinterpret_cast<__bf16*>(p16), poison, sticky);
+                       beta1, beta2, eps, reinterpret_cast<__bf16*>(p16), poison, sticky, reinterpret_cast<__bf16*>(p16lo));
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }

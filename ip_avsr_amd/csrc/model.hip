@@ -863,7 +863,9 @@ int refresh_params_x3(adn_model* m) {
             ADN_HIP_CHECK(hipMalloc((void**)&m->params16lo, m->flat_floats * 2 + kPlaneSlack));
             ADN_HIP_CHECK(hipMemsetAsync(m->params16lo, 0, m->flat_floats * 2 + kPlaneSlack, m->stream));
         }
-        ADN_TRY(split_hilo(m->flat[ADN_BUF_PARAM], m->params16, m->params16lo, (size_t)round_up((int64_t)m->flat_floats, 8), m->stream));
+        if (!m->params16_values_fresh)      // (Adam writes both planes with the update)
+            ADN_TRY(split_hilo(m->flat[ADN_BUF_PARAM], m->params16, m->params16lo, (size_t)round_up((int64_t)m->flat_floats, 8), m->stream));
+        m->params16_values_fresh = false;
         ADN_TRY(refresh_transposed(m));
         if (m->cfg.fusion == ADN_FUSE_CONCAT && m->S > 1 && m->S <= 4) {      // the concat consumers' padded W_in, both planes
             const size_t blk = (size_t)m->ldh * m->ldg;
@@ -1175,6 +1177,9 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
         g.C = st.act[l]; g.ldc = ld_of(g.N); g.bias = m->P(st.encb[l]); g.act = st.cfg.enc_act[l];
         g.no_split = 1;                                          // forward pass: reproducible bits
         mgemm_prepare(m, g, /*lean=*/l + 1 < st.cfg.n_enc);      // the delta layer reads the last one in fp32
+        // (bf16x3: a narrow next layer -- the 50-unit bottleneck -- multiplies over split images of the fp32 values: writing them
+        //  here is cheaper than writing hi + lo back ahead of that layer)
+        if (m->planes() && l + 1 < st.cfg.n_enc && st.cfg.enc_units[l + 1] < 128) g.lean_ok = 0;
         return g;
     };
     // Encoders layer by layer; the streams whose layer l has the same geometry go out as ONE grouped launch (their
@@ -2228,9 +2233,12 @@ int adn_apply_adam(adn_model* m, float learning_rate) {
     m->adam_t += 1;
     const float t = (float)m->adam_t;
     const float a_t = learning_rate * sqrtf(1.f - powf(kBeta2, t)) / (1.f - powf(kBeta1, t));
-    void* p16 = shadows_on(m) ? m->params16 : nullptr;          // the update writes the bf16 shadow as well
+    // the update writes the bf16 shadow as well (bf16x3 over planes: both planes, once they exist)
+    const bool pl = m->planes() && m->params16 && m->params16lo;
+    void* p16 = (shadows_on(m) || pl) ? m->params16 : nullptr;
     ADN_TRY(adam_update(m->flat[ADN_BUF_PARAM], m->flat[ADN_BUF_GRAD], m->flat[ADN_BUF_ADAM_M], m->flat[ADN_BUF_ADAM_V],
-                        (int64_t)m->flat_floats, a_t, kBeta1, kBeta2, kEps, m->stream, p16, m->poison_word(), m->poison_sticky));
+                        (int64_t)m->flat_floats, a_t, kBeta1, kBeta2, kEps, m->stream, p16, m->poison_word(), m->poison_sticky,
+                        pl ? m->params16lo : nullptr));
     m->grads_valid = false;
     m->mark_params_dirty();
     m->params16_values_fresh = p16 != nullptr;
@@ -2257,10 +2265,11 @@ int adn_adam_range(adn_model* m, int64_t begin_floats, int64_t end_floats) {
     const int64_t e = std::min<int64_t>(end_floats, (int64_t)m->flat_floats);      // (the tail slots behind the parameters)
     if (e <= begin_floats) return ADN_OK;
     const size_t b = (size_t)begin_floats;
-    void* p16 = (shadows_on(m) && m->params16) ? static_cast<void*>(m->params16 + b * 2) : nullptr;   // (char*: bf16 elements)
+    const bool pl = m->planes() && m->params16 && m->params16lo;
+    void* p16 = ((shadows_on(m) || pl) && m->params16) ? static_cast<void*>(m->params16 + b * 2) : nullptr;   // (char*: bf16 elements)
     return adam_update(m->flat[ADN_BUF_PARAM] + b, m->flat[ADN_BUF_GRAD] + b, m->flat[ADN_BUF_ADAM_M] + b, m->flat[ADN_BUF_ADAM_V] + b,
                        e - begin_floats, m->adam_a_t, kBeta1, kBeta2, kEps, m->stream, p16,
-                       m->poison_word(), m->poison_sticky);
+                       m->poison_word(), m->poison_sticky, pl ? static_cast<void*>(m->params16lo + b * 2) : nullptr);
 }
 int adn_adam_end(adn_model* m) {
     ADN_CHECK(m, ADN_ERR_INVALID, "null model");
@@ -2268,7 +2277,7 @@ int adn_adam_end(adn_model* m) {
     m->adam_open = false;
     m->grads_valid = false;
     m->mark_params_dirty();
-    m->params16_values_fresh = shadows_on(m) && m->params16;
+    m->params16_values_fresh = (shadows_on(m) || (m->planes() && m->params16lo)) && m->params16;
     return ADN_OK;
 }
 
