@@ -945,7 +945,103 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
                 acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[b], fa[a], acc[a][b], 0, 0, 0);
     };
     int rd_slot = 0;
-    for (int s = 0; s < total;) {
+    // The epilogue of a finished tile runs at the TOP of the next iteration (or of one extra, epilogue-only pass behind the last
+    // K-step), not behind the tile's last MFMA block.  For waves 4-7 nothing moves (C(last), epilogue, L(next)); waves 0-3, whose
+    // barrier sits behind C, used to run it inside the interval of their last K-step -- the other half then waited out that whole
+    // epilogue at its barrier, and one interval later the roles swapped: a tile paid for BOTH halves' epilogues back to back
+    // (stamps: epilogue 17-28 % + partner's barrier wait 19-25 % of a launch).  Deferred, the two halves' epilogues fall
+    // into the same interval and overlap.
+    for (int s = 0;;) {
+        if (kt == 0 && s > 0) {
+        {
+        // ---- epilogue of tile `ord`, straight from the (transposed) accumulators: lane = row (lane & 15),
+        //      columns 4 hi .. 4 hi + 3 of every 16-column block
+        const GemmGroup gp = pick_group(p, grp);
+        float* Cg = SPLIT ? p.partial + ((size_t)(grp * (int)gridDim.y + slice) * p.M) * p.ldc : gp.C;
+        const int row0 = tile_m * BM + wm * WTM + (lane & 15), col0 = tile_n * BN + wn * WTN + 4 * hi;
+        // The act'(Y) mask of two 16-column blocks is requested in ONE burst ahead of them (2 TM eight-byte loads per
+        // lane, from addresses clamped into the matrix): issued block by block, every block paid a full memory round
+        // trip (measured 47 us on a 156 us launch: the epilogue holds up the barrier cadence of both wave halves).
+        constexpr int TNH = 2;                               // 16-column blocks per burst (TM x 2 loads in flight per lane)
+#pragma clang loop unroll(full)
+        for (int half = 0; half < TN / TNH; ++half) {
+            bf16x4 yv[TM][TNH];
+            if (!SPLIT && gp.Y16) {
+#pragma clang loop unroll(full)
+                for (int bb = 0; bb < TNH; ++bb)
+#pragma clang loop unroll(full)
+                    for (int a = 0; a < TM; ++a) {
+                        const int row = min(row0 + a * 16, p.M - 1), col = min(col0 + (half * TNH + bb) * 16, p.N - 4);
+                        yv[a][bb] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(gp.Y16) + (size_t)row * p.ldy + col);
+                    }
+            }
+            // blocks b0, b0 + 1 together: after the lane exchange a lane holds EIGHT consecutive columns of one of them, so
+            // that the bf16 copy leaves in 16-byte stores covering 64 contiguous bytes of a row per instruction.  (With
+            // 8-byte stores = 32-byte row pieces the lean forward GEMMs wrote their output at 1.6 - 1.9 TB/s: 130 us of a
+            // 514 us launch; fp32 rows already go out in 64-byte pieces.)
+            const int b0 = half * TNH;
+            const int colA = col0 + b0 * 16, colB = colA + 16;
+            float4 biasA = make_float4(0.f, 0.f, 0.f, 0.f), biasB = biasA, csumA = biasA, csumB = biasA;
+            if (!SPLIT && gp.bias) {
+                biasA = *reinterpret_cast<const float4*>(gp.bias + min(colA, p.N - 4));
+                biasB = *reinterpret_cast<const float4*>(gp.bias + min(colB, p.N - 4));
+            }
+            const bool odd = hi & 1;
+#pragma clang loop unroll(full)
+            for (int a = 0; a < TM; ++a) {
+                const int row = row0 + a * 16;
+                const bool rok = row < p.M;
+                const float4 vA = pp_epi4<SPLIT>(p, gp, Cg, acc[a][b0], biasA, yv[a][0], row, colA, rok && colA < p.N, csumA);
+                const float4 vB = pp_epi4<SPLIT>(p, gp, Cg, acc[a][b0 + 1], biasB, yv[a][1], row, colB, rok && colB < p.N, csumB);
+                if (!SPLIT && gp.C16) {
+                    const uint2 pA = __builtin_bit_cast(uint2, cvt4(vA)), pB = __builtin_bit_cast(uint2, cvt4(vB));
+                    const uint2 give = odd ? pA : pB;            // even hi keeps block A and takes the partner's half of it
+                    uint2 take;
+                    take.x = __shfl_xor(give.x, 16, 64); take.y = __shfl_xor(give.y, 16, 64);
+                    const uint4 out = odd ? make_uint4(take.x, take.y, pB.x, pB.y) : make_uint4(pA.x, pA.y, take.x, take.y);
+                    const int cs = odd ? colB - 4 : colA;        // first of the 8 columns this lane now holds
+                    __bf16* dst = reinterpret_cast<__bf16*>(gp.C16) + (size_t)row * p.ldc + cs;
+                    if (rok && cs + 8 <= p.N) *reinterpret_cast<uint4*>(dst) = out;
+                    else if (rok && cs + 4 <= p.N) *reinterpret_cast<uint2*>(dst) = make_uint2(out.x, out.y);
+                    if (gp.C16lo) {                              // bf16x3: the lo plane bf16(v - bf16(v)) beside it, same exchange
+                        const bf16x4 hA = __builtin_bit_cast(bf16x4, pA), hB = __builtin_bit_cast(bf16x4, pB);
+                        const float4 rA = make_float4(vA.x - (float)hA[0], vA.y - (float)hA[1], vA.z - (float)hA[2], vA.w - (float)hA[3]);
+                        const float4 rB = make_float4(vB.x - (float)hB[0], vB.y - (float)hB[1], vB.z - (float)hB[2], vB.w - (float)hB[3]);
+                        const uint2 qA = __builtin_bit_cast(uint2, cvt4(rA)), qB = __builtin_bit_cast(uint2, cvt4(rB));
+                        const uint2 giv = odd ? qA : qB;
+                        uint2 tk;
+                        tk.x = __shfl_xor(giv.x, 16, 64); tk.y = __shfl_xor(giv.y, 16, 64);
+                        const uint4 outl = odd ? make_uint4(tk.x, tk.y, qB.x, qB.y) : make_uint4(qA.x, qA.y, tk.x, tk.y);
+                        __bf16* dl = reinterpret_cast<__bf16*>(gp.C16lo) + (size_t)row * p.ldc + cs;
+                        if (rok && cs + 8 <= p.N) *reinterpret_cast<uint4*>(dl) = outl;
+                        else if (rok && cs + 4 <= p.N) *reinterpret_cast<uint2*>(dl) = make_uint2(outl.x, outl.y);
+                    }
+                }
+            }
+            if (!SPLIT && gp.colsum) {                         // column sums over this wave's WTM rows
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    csumA.x += __shfl_xor(csumA.x, o, 64); csumA.y += __shfl_xor(csumA.y, o, 64);
+                    csumA.z += __shfl_xor(csumA.z, o, 64); csumA.w += __shfl_xor(csumA.w, o, 64);
+                    csumB.x += __shfl_xor(csumB.x, o, 64); csumB.y += __shfl_xor(csumB.y, o, 64);
+                    csumB.z += __shfl_xor(csumB.z, o, 64); csumB.w += __shfl_xor(csumB.w, o, 64);
+                }
+                if ((lane & 15) == 0) {
+                    float* cs_row = gp.colsum + (size_t)(tile_m * 4 + wm) * p.colsum_ld;
+                    if (colA < p.N) *reinterpret_cast<float4*>(cs_row + colA) = csumA;
+                    if (colB < p.N) *reinterpret_cast<float4*>(cs_row + colB) = csumB;
+                }
+            }
+        }
+        }
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (++ord < my_tiles) tile_of(ord, grp, tile_m, tile_n);
+        }
+        GSTAMP(6);
+        if (s == total) break;
         // ---------------- the general step.  L(s): fragments of stage s -> registers, DMA for stage s + D
         read_frags(rd_slot * (kAElems * 2), rd_slot * (kBElems * 2));
         if (++rd_slot == NS) rd_slot = 0;
@@ -968,99 +1064,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
         // ---------------- C(s)
         mfmas();
         GSTAMP(5);
-        if (__builtin_expect(kt == nk - 1, 0)) {
-            {
-            // ---- epilogue of tile `ord`, straight from the (transposed) accumulators: lane = row (lane & 15),
-            //      columns 4 hi .. 4 hi + 3 of every 16-column block
-            const GemmGroup gp = pick_group(p, grp);
-            float* Cg = SPLIT ? p.partial + ((size_t)(grp * (int)gridDim.y + slice) * p.M) * p.ldc : gp.C;
-            const int row0 = tile_m * BM + wm * WTM + (lane & 15), col0 = tile_n * BN + wn * WTN + 4 * hi;
-            // The act'(Y) mask of two 16-column blocks is requested in ONE burst ahead of them (2 TM eight-byte loads per
-            // lane, from addresses clamped into the matrix): issued block by block, every block paid a full memory round
-            // trip (measured 47 us on a 156 us launch: the epilogue holds up the barrier cadence of both wave halves).
-            constexpr int TNH = 2;                               // 16-column blocks per burst (TM x 2 loads in flight per lane)
-#pragma clang loop unroll(full)
-            for (int half = 0; half < TN / TNH; ++half) {
-                bf16x4 yv[TM][TNH];
-                if (!SPLIT && gp.Y16) {
-#pragma clang loop unroll(full)
-                    for (int bb = 0; bb < TNH; ++bb)
-#pragma clang loop unroll(full)
-                        for (int a = 0; a < TM; ++a) {
-                            const int row = min(row0 + a * 16, p.M - 1), col = min(col0 + (half * TNH + bb) * 16, p.N - 4);
-                            yv[a][bb] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(gp.Y16) + (size_t)row * p.ldy + col);
-                        }
-                }
-                // blocks b0, b0 + 1 together: after the lane exchange a lane holds EIGHT consecutive columns of one of them, so
-                // that the bf16 copy leaves in 16-byte stores covering 64 contiguous bytes of a row per instruction.  (With
-                // 8-byte stores = 32-byte row pieces the lean forward GEMMs wrote their output at 1.6 - 1.9 TB/s: 130 us of a
-                // 514 us launch; fp32 rows already go out in 64-byte pieces.)
-                const int b0 = half * TNH;
-                const int colA = col0 + b0 * 16, colB = colA + 16;
-                float4 biasA = make_float4(0.f, 0.f, 0.f, 0.f), biasB = biasA, csumA = biasA, csumB = biasA;
-                if (!SPLIT && gp.bias) {
-                    biasA = *reinterpret_cast<const float4*>(gp.bias + min(colA, p.N - 4));
-                    biasB = *reinterpret_cast<const float4*>(gp.bias + min(colB, p.N - 4));
-                }
-                const bool odd = hi & 1;
-#pragma clang loop unroll(full)
-                for (int a = 0; a < TM; ++a) {
-                    const int row = row0 + a * 16;
-                    const bool rok = row < p.M;
-                    const float4 vA = pp_epi4<SPLIT>(p, gp, Cg, acc[a][b0], biasA, yv[a][0], row, colA, rok && colA < p.N, csumA);
-                    const float4 vB = pp_epi4<SPLIT>(p, gp, Cg, acc[a][b0 + 1], biasB, yv[a][1], row, colB, rok && colB < p.N, csumB);
-                    if (!SPLIT && gp.C16) {
-                        const uint2 pA = __builtin_bit_cast(uint2, cvt4(vA)), pB = __builtin_bit_cast(uint2, cvt4(vB));
-                        const uint2 give = odd ? pA : pB;            // even hi keeps block A and takes the partner's half of it
-                        uint2 take;
-                        take.x = __shfl_xor(give.x, 16, 64); take.y = __shfl_xor(give.y, 16, 64);
-                        const uint4 out = odd ? make_uint4(take.x, take.y, pB.x, pB.y) : make_uint4(pA.x, pA.y, take.x, take.y);
-                        const int cs = odd ? colB - 4 : colA;        // first of the 8 columns this lane now holds
-                        __bf16* dst = reinterpret_cast<__bf16*>(gp.C16) + (size_t)row * p.ldc + cs;
-                        if (rok && cs + 8 <= p.N) *reinterpret_cast<uint4*>(dst) = out;
-                        else if (rok && cs + 4 <= p.N) *reinterpret_cast<uint2*>(dst) = make_uint2(out.x, out.y);
-                        if (gp.C16lo) {                              // bf16x3: the lo plane bf16(v - bf16(v)) beside it, same exchange
-                            const bf16x4 hA = __builtin_bit_cast(bf16x4, pA), hB = __builtin_bit_cast(bf16x4, pB);
-                            const float4 rA = make_float4(vA.x - (float)hA[0], vA.y - (float)hA[1], vA.z - (float)hA[2], vA.w - (float)hA[3]);
-                            const float4 rB = make_float4(vB.x - (float)hB[0], vB.y - (float)hB[1], vB.z - (float)hB[2], vB.w - (float)hB[3]);
-                            const uint2 qA = __builtin_bit_cast(uint2, cvt4(rA)), qB = __builtin_bit_cast(uint2, cvt4(rB));
-                            const uint2 giv = odd ? qA : qB;
-                            uint2 tk;
-                            tk.x = __shfl_xor(giv.x, 16, 64); tk.y = __shfl_xor(giv.y, 16, 64);
-                            const uint4 outl = odd ? make_uint4(tk.x, tk.y, qB.x, qB.y) : make_uint4(qA.x, qA.y, tk.x, tk.y);
-                            __bf16* dl = reinterpret_cast<__bf16*>(gp.C16lo) + (size_t)row * p.ldc + cs;
-                            if (rok && cs + 8 <= p.N) *reinterpret_cast<uint4*>(dl) = outl;
-                            else if (rok && cs + 4 <= p.N) *reinterpret_cast<uint2*>(dl) = make_uint2(outl.x, outl.y);
-                        }
-                    }
-                }
-                if (!SPLIT && gp.colsum) {                         // column sums over this wave's WTM rows
-#pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) {
-                        csumA.x += __shfl_xor(csumA.x, o, 64); csumA.y += __shfl_xor(csumA.y, o, 64);
-                        csumA.z += __shfl_xor(csumA.z, o, 64); csumA.w += __shfl_xor(csumA.w, o, 64);
-                        csumB.x += __shfl_xor(csumB.x, o, 64); csumB.y += __shfl_xor(csumB.y, o, 64);
-                        csumB.z += __shfl_xor(csumB.z, o, 64); csumB.w += __shfl_xor(csumB.w, o, 64);
-                    }
-                    if ((lane & 15) == 0) {
-                        float* cs_row = gp.colsum + (size_t)(tile_m * 4 + wm) * p.colsum_ld;
-                        if (colA < p.N) *reinterpret_cast<float4*>(cs_row + colA) = csumA;
-                        if (colB < p.N) *reinterpret_cast<float4*>(cs_row + colB) = csumB;
-                    }
-                }
-            }
-            }
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (++ord < my_tiles) tile_of(ord, grp, tile_m, tile_n);
+        if (__builtin_expect(kt == nk - 1, 0)) {        // the tile is complete: its epilogue opens the next iteration
             kt = 0;
             cseg_left = cseg_first;
         } else {
             ++kt;
         }
-        GSTAMP(6);
         __builtin_amdgcn_sched_barrier(0);
         if (!one || !late) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
