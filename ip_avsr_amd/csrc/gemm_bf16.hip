@@ -959,77 +959,139 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
         const GemmGroup gp = pick_group(p, grp);
         float* Cg = SPLIT ? p.partial + ((size_t)(grp * (int)gridDim.y + slice) * p.M) * p.ldc : gp.C;
         const int row0 = tile_m * BM + wm * WTM + (lane & 15), col0 = tile_n * BN + wn * WTN + 4 * hi;
-        // The act'(Y) mask of two 16-column blocks is requested in ONE burst ahead of them (2 TM eight-byte loads per
-        // lane, from addresses clamped into the matrix): issued block by block, every block paid a full memory round
-        // trip (measured 47 us on a 156 us launch: the epilogue holds up the barrier cadence of both wave halves).
         constexpr int TNH = 2;                               // 16-column blocks per burst (TM x 2 loads in flight per lane)
-#pragma clang loop unroll(full)
-        for (int half = 0; half < TN / TNH; ++half) {
-            bf16x4 yv[TM][TNH];
-            if (!SPLIT && gp.Y16) {
-#pragma clang loop unroll(full)
-                for (int bb = 0; bb < TNH; ++bb)
-#pragma clang loop unroll(full)
-                    for (int a = 0; a < TM; ++a) {
-                        const int row = min(row0 + a * 16, p.M - 1), col = min(col0 + (half * TNH + bb) * 16, p.N - 4);
-                        yv[a][bb] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(gp.Y16) + (size_t)row * p.ldy + col);
-                    }
-            }
-            // blocks b0, b0 + 1 together: after the lane exchange a lane holds EIGHT consecutive columns of one of them, so
-            // that the bf16 copy leaves in 16-byte stores covering 64 contiguous bytes of a row per instruction.  (With
-            // 8-byte stores = 32-byte row pieces the lean forward GEMMs wrote their output at 1.6 - 1.9 TB/s: 130 us of a
-            // 514 us launch; fp32 rows already go out in 64-byte pieces.)
-            const int b0 = half * TNH;
-            const int colA = col0 + b0 * 16, colB = colA + 16;
-            float4 biasA = make_float4(0.f, 0.f, 0.f, 0.f), biasB = biasA, csumA = biasA, csumB = biasA;
-            if (!SPLIT && gp.bias) {
-                biasA = *reinterpret_cast<const float4*>(gp.bias + min(colA, p.N - 4));
-                biasB = *reinterpret_cast<const float4*>(gp.bias + min(colB, p.N - 4));
-            }
+        // Addressing: ONE 32-bit element offset per lane from the matrix start (the rows of every matrix span < 4 GB) plus
+        // compile-time constants and wave-uniform strides; bounds as three lane predicates per pair of blocks; flag tests
+        // once per pair.  (The first form of this epilogue recomputed a 64-bit address with clamps per access and went
+        // through a dozen wave-uniform branches per float4: ~80 instructions per float4, 5000 per wave and tile, which two
+        // waves per SIMD took 18 us to issue -- a quarter to a half of a launch by the stamps.)
+        {
+            const int wr0 = tile_m * BM + wm * WTM, wc0 = tile_n * BN + wn * WTN;                  // the wave's corner (uniform)
+            const int rl = (lane & 15), cl = 4 * hi;
+            const int rlim = p.M - wr0, clim = p.N - wc0;                                        // rows / columns of it inside the matrix
+            const unsigned lo32 = (unsigned)(wr0 + rl) * (unsigned)p.ldc + (unsigned)(wc0 + cl);
+            const unsigned ly32 = (unsigned)(wr0 + rl) * (unsigned)p.ldy + (unsigned)(wc0 + cl);
+            const unsigned rstep = 16u * (unsigned)p.ldc, ystep = 16u * (unsigned)p.ldy;       // one row block further (uniform)
+            __bf16* C16m = (!SPLIT && gp.C16) ? reinterpret_cast<__bf16*>(gp.C16) : nullptr;
+            __bf16* C16lm = (!SPLIT && gp.C16lo) ? reinterpret_cast<__bf16*>(gp.C16lo) : nullptr;
+            const __bf16* Ym = (!SPLIT && gp.Y16) ? reinterpret_cast<const __bf16*>(gp.Y16) : nullptr;
+            const float* biasm = (!SPLIT && gp.bias) ? gp.bias : nullptr;
+            const float lower = (!SPLIT && p.act == ADN_ACT_RECTIFY) ? 0.f : -3.0e38f;
             const bool odd = hi & 1;
+            // What the epilogue READS is requested in two bursts per tile, each ahead of its half's first store: while an LDS-DMA
+            // is in flight hipcc waits vmcnt(0) -- not a counted vmcnt -- at the first use of an ordinary load's result, which
+            // also waits for every store issued before that point; with the requests at the top of each pair of blocks every
+            // pair sat out the write acknowledgements of the pair before (4 drains per tile, 2 us each).  One register array
+            // serves both kinds (a launch has a bias or an act'(Y) mask, never both): 4 float4 of bias, or TM x 4 8-byte masks.
+            constexpr int QB = TN / 2;                         // blocks per request burst: two bursts per tile (all of it at once spills)
+            uint2 pre[TM * QB];
 #pragma clang loop unroll(full)
-            for (int a = 0; a < TM; ++a) {
-                const int row = row0 + a * 16;
-                const bool rok = row < p.M;
-                const float4 vA = pp_epi4<SPLIT>(p, gp, Cg, acc[a][b0], biasA, yv[a][0], row, colA, rok && colA < p.N, csumA);
-                const float4 vB = pp_epi4<SPLIT>(p, gp, Cg, acc[a][b0 + 1], biasB, yv[a][1], row, colB, rok && colB < p.N, csumB);
-                if (!SPLIT && gp.C16) {
-                    const uint2 pA = __builtin_bit_cast(uint2, cvt4(vA)), pB = __builtin_bit_cast(uint2, cvt4(vB));
-                    const uint2 give = odd ? pA : pB;            // even hi keeps block A and takes the partner's half of it
-                    uint2 take;
-                    take.x = __shfl_xor(give.x, 16, 64); take.y = __shfl_xor(give.y, 16, 64);
-                    const uint4 out = odd ? make_uint4(take.x, take.y, pB.x, pB.y) : make_uint4(pA.x, pA.y, take.x, take.y);
-                    const int cs = odd ? colB - 4 : colA;        // first of the 8 columns this lane now holds
-                    __bf16* dst = reinterpret_cast<__bf16*>(gp.C16) + (size_t)row * p.ldc + cs;
-                    if (rok && cs + 8 <= p.N) *reinterpret_cast<uint4*>(dst) = out;
-                    else if (rok && cs + 4 <= p.N) *reinterpret_cast<uint2*>(dst) = make_uint2(out.x, out.y);
-                    if (gp.C16lo) {                              // bf16x3: the lo plane bf16(v - bf16(v)) beside it, same exchange
-                        const bf16x4 hA = __builtin_bit_cast(bf16x4, pA), hB = __builtin_bit_cast(bf16x4, pB);
-                        const float4 rA = make_float4(vA.x - (float)hA[0], vA.y - (float)hA[1], vA.z - (float)hA[2], vA.w - (float)hA[3]);
-                        const float4 rB = make_float4(vB.x - (float)hB[0], vB.y - (float)hB[1], vB.z - (float)hB[2], vB.w - (float)hB[3]);
-                        const uint2 qA = __builtin_bit_cast(uint2, cvt4(rA)), qB = __builtin_bit_cast(uint2, cvt4(rB));
-                        const uint2 giv = odd ? qA : qB;
-                        uint2 tk;
-                        tk.x = __shfl_xor(giv.x, 16, 64); tk.y = __shfl_xor(giv.y, 16, 64);
-                        const uint4 outl = odd ? make_uint4(tk.x, tk.y, qB.x, qB.y) : make_uint4(qA.x, qA.y, tk.x, tk.y);
-                        __bf16* dl = reinterpret_cast<__bf16*>(gp.C16lo) + (size_t)row * p.ldc + cs;
-                        if (rok && cs + 8 <= p.N) *reinterpret_cast<uint4*>(dl) = outl;
-                        else if (rok && cs + 4 <= p.N) *reinterpret_cast<uint2*>(dl) = make_uint2(outl.x, outl.y);
+            for (int half = 0; half < TN / TNH; ++half) {
+                const int b0 = half * TNH;
+                const int q0 = (b0 / QB) * QB;                 // first block of this burst
+                if (b0 == q0) {
+                    if (Ym) {
+#pragma clang loop unroll(full)
+                        for (int b = 0; b < QB; ++b)
+#pragma clang loop unroll(full)
+                            for (int a = 0; a < TM; ++a) {
+                                const bool ok = rl + a * 16 < rlim && cl + (q0 + b) * 16 < clim;
+                                pre[a * QB + b] = *reinterpret_cast<const uint2*>(Ym + (ok ? ly32 + a * ystep + (q0 + b) * 16 : 0u));
+                            }
+                    } else if (biasm) {
+#pragma clang loop unroll(full)
+                        for (int b = 0; b < QB; ++b) {
+                            const float4 bv = *reinterpret_cast<const float4*>(biasm + (cl + (q0 + b) * 16 < clim ? wc0 + cl + (q0 + b) * 16 : 0));
+                            pre[2 * b] = make_uint2(__builtin_bit_cast(unsigned, bv.x), __builtin_bit_cast(unsigned, bv.y));
+                            pre[2 * b + 1] = make_uint2(__builtin_bit_cast(unsigned, bv.z), __builtin_bit_cast(unsigned, bv.w));
+                        }
+                    } else {
+#pragma clang loop unroll(full)
+                        for (int k = 0; k < 2 * QB; ++k) pre[k] = make_uint2(0u, 0u);
                     }
                 }
-            }
-            if (!SPLIT && gp.colsum) {                         // column sums over this wave's WTM rows
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    csumA.x += __shfl_xor(csumA.x, o, 64); csumA.y += __shfl_xor(csumA.y, o, 64);
-                    csumA.z += __shfl_xor(csumA.z, o, 64); csumA.w += __shfl_xor(csumA.w, o, 64);
-                    csumB.x += __shfl_xor(csumB.x, o, 64); csumB.y += __shfl_xor(csumB.y, o, 64);
-                    csumB.z += __shfl_xor(csumB.z, o, 64); csumB.w += __shfl_xor(csumB.w, o, 64);
+                const int bq = b0 - q0;                        // block index inside the burst
+                const bool cA = cl + b0 * 16 < clim, cB = cl + b0 * 16 + 16 < clim;          // this lane's 4 columns of block A / B inside
+                // after the exchange a lane holds 8 consecutive columns: even lanes A's cl .. cl+7, odd lanes cl+12 .. cl+19 (= B's cl-4 .. cl+3)
+                const int cs = cl + (odd ? 12 : 0) + b0 * 16;
+                const bool c16 = cs + 8 <= clim;                                                 // all 8 inside
+                const bool c8 = cs + 4 <= clim;                                                  // the first 4 only (right edge)
+                const unsigned l16 = lo32 + (odd ? 12u : 0u) + (unsigned)(b0 * 16);
+                float4 biasA = make_float4(0.f, 0.f, 0.f, 0.f), biasB = biasA, csumA = biasA, csumB = biasA;
+                if (!Ym) {                                   // (zeros without a bias)
+                    biasA = make_float4(__builtin_bit_cast(float, pre[2 * bq].x), __builtin_bit_cast(float, pre[2 * bq].y),
+                                        __builtin_bit_cast(float, pre[2 * bq + 1].x), __builtin_bit_cast(float, pre[2 * bq + 1].y));
+                    biasB = make_float4(__builtin_bit_cast(float, pre[2 * bq + 2].x), __builtin_bit_cast(float, pre[2 * bq + 2].y),
+                                        __builtin_bit_cast(float, pre[2 * bq + 3].x), __builtin_bit_cast(float, pre[2 * bq + 3].y));
                 }
-                if ((lane & 15) == 0) {
-                    float* cs_row = gp.colsum + (size_t)(tile_m * 4 + wm) * p.colsum_ld;
-                    if (colA < p.N) *reinterpret_cast<float4*>(cs_row + colA) = csumA;
-                    if (colB < p.N) *reinterpret_cast<float4*>(cs_row + colB) = csumB;
+#pragma clang loop unroll(full)
+                for (int a = 0; a < TM; ++a) {
+                    __builtin_amdgcn_sched_barrier(0);         // (keeps the scheduler from interleaving all 32 block pairs: spills)
+                    const bool rok = rl + a * 16 < rlim;
+                    const bool okA = rok && cA, okB = rok && cB;
+                    float4 vA = make_float4(acc[a][b0][0], acc[a][b0][1], acc[a][b0][2], acc[a][b0][3]);
+                    float4 vB = make_float4(acc[a][b0 + 1][0], acc[a][b0 + 1][1], acc[a][b0 + 1][2], acc[a][b0 + 1][3]);
+                    const unsigned oA = lo32 + a * rstep + (unsigned)(b0 * 16), oB = oA + 16u;
+                    if (!SPLIT) {
+                        vA.x = fmaxf(vA.x + biasA.x, lower); vA.y = fmaxf(vA.y + biasA.y, lower); vA.z = fmaxf(vA.z + biasA.z, lower); vA.w = fmaxf(vA.w + biasA.w, lower);
+                        vB.x = fmaxf(vB.x + biasB.x, lower); vB.y = fmaxf(vB.y + biasB.y, lower); vB.z = fmaxf(vB.z + biasB.z, lower); vB.w = fmaxf(vB.w + biasB.w, lower);
+                        if (Ym) {
+                            const bf16x4 yA = __builtin_bit_cast(bf16x4, pre[a * QB + bq]), yB = __builtin_bit_cast(bf16x4, pre[a * QB + bq + 1]);
+                            vA.x = (float)yA[0] > 0.f ? vA.x : 0.f; vA.y = (float)yA[1] > 0.f ? vA.y : 0.f;
+                            vA.z = (float)yA[2] > 0.f ? vA.z : 0.f; vA.w = (float)yA[3] > 0.f ? vA.w : 0.f;
+                            vB.x = (float)yB[0] > 0.f ? vB.x : 0.f; vB.y = (float)yB[1] > 0.f ? vB.y : 0.f;
+                            vB.z = (float)yB[2] > 0.f ? vB.z : 0.f; vB.w = (float)yB[3] > 0.f ? vB.w : 0.f;
+                        }
+                        if (p.accumulate) {
+                            if (okA) { const float4 c = *reinterpret_cast<const float4*>(Cg + oA); vA.x += c.x; vA.y += c.y; vA.z += c.z; vA.w += c.w; }
+                            if (okB) { const float4 c = *reinterpret_cast<const float4*>(Cg + oB); vB.x += c.x; vB.y += c.y; vB.z += c.z; vB.w += c.w; }
+                        }
+                    }
+                    if (Cg) {
+                        if (okA) *reinterpret_cast<float4*>(Cg + oA) = vA;
+                        if (okB) *reinterpret_cast<float4*>(Cg + oB) = vB;
+                    }
+                    if (!SPLIT) {
+                        if (okA) { csumA.x += vA.x; csumA.y += vA.y; csumA.z += vA.z; csumA.w += vA.w; }
+                        if (okB) { csumB.x += vB.x; csumB.y += vB.y; csumB.z += vB.z; csumB.w += vB.w; }
+                    }
+                    if (C16m) {
+                        const uint2 pA = __builtin_bit_cast(uint2, cvt4(vA)), pB = __builtin_bit_cast(uint2, cvt4(vB));
+                        const uint2 give = odd ? pA : pB;        // even hi keeps block A and takes the partner's half of it
+                        uint2 take;
+                        take.x = __shfl_xor(give.x, 16, 64); take.y = __shfl_xor(give.y, 16, 64);
+                        const uint4 out = odd ? make_uint4(take.x, take.y, pB.x, pB.y) : make_uint4(pA.x, pA.y, take.x, take.y);
+                        __bf16* dst = C16m + (l16 + a * rstep);
+                        if (rok && c16) *reinterpret_cast<uint4*>(dst) = out;
+                        else if (rok && c8) *reinterpret_cast<uint2*>(dst) = make_uint2(out.x, out.y);
+                        if (C16lm) {                             // bf16x3: the lo plane bf16(v - bf16(v)) beside it, same exchange
+                            const bf16x4 hA = __builtin_bit_cast(bf16x4, pA), hB = __builtin_bit_cast(bf16x4, pB);
+                            const float4 rA = make_float4(vA.x - (float)hA[0], vA.y - (float)hA[1], vA.z - (float)hA[2], vA.w - (float)hA[3]);
+                            const float4 rB = make_float4(vB.x - (float)hB[0], vB.y - (float)hB[1], vB.z - (float)hB[2], vB.w - (float)hB[3]);
+                            const uint2 qA = __builtin_bit_cast(uint2, cvt4(rA)), qB = __builtin_bit_cast(uint2, cvt4(rB));
+                            const uint2 giv = odd ? qA : qB;
+                            uint2 tk;
+                            tk.x = __shfl_xor(giv.x, 16, 64); tk.y = __shfl_xor(giv.y, 16, 64);
+                            const uint4 outl = odd ? make_uint4(tk.x, tk.y, qB.x, qB.y) : make_uint4(qA.x, qA.y, tk.x, tk.y);
+                            __bf16* dl = C16lm + (l16 + a * rstep);
+                            if (rok && c16) *reinterpret_cast<uint4*>(dl) = outl;
+                            else if (rok && c8) *reinterpret_cast<uint2*>(dl) = make_uint2(outl.x, outl.y);
+                        }
+                    }
+                }
+                if (!SPLIT && gp.colsum) {                     // column sums over this wave's WTM rows
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) {
+                        csumA.x += __shfl_xor(csumA.x, o, 64); csumA.y += __shfl_xor(csumA.y, o, 64);
+                        csumA.z += __shfl_xor(csumA.z, o, 64); csumA.w += __shfl_xor(csumA.w, o, 64);
+                        csumB.x += __shfl_xor(csumB.x, o, 64); csumB.y += __shfl_xor(csumB.y, o, 64);
+                        csumB.z += __shfl_xor(csumB.z, o, 64); csumB.w += __shfl_xor(csumB.w, o, 64);
+                    }
+                    if ((lane & 15) == 0) {
+                        float* cs_row = gp.colsum + (size_t)(tile_m * 4 + wm) * p.colsum_ld + wc0 + cl + b0 * 16;
+                        if (cA) *reinterpret_cast<float4*>(cs_row) = csumA;
+                        if (cB) *reinterpret_cast<float4*>(cs_row + 16) = csumB;
+                    }
                 }
             }
         }
