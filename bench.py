@@ -221,12 +221,19 @@ def rooflines(prof, steps, prof_elapsed, precision, hbm_measured, traffic_file):
     traffic, pmc = None, {}                # HBM bytes per launch from the committed PMC passes (labelled with their commit)
     if os.path.exists(traffic_file):
         pmc = json.load(open(traffic_file))
-        traffic = pmc.get("traffic_bytes_per_launch")
+        # per LAUNCH in this object's sense: one GEMM problem (a grouped kernel dispatch carries up to four; the PMC summary
+        # counts dispatches), so that `traffic` and `algorithmic_flops_per_launch` share their denominator
+        if pmc.get("traffic_bytes_per_train_step") and n:
+            traffic = pmc["traffic_bytes_per_train_step"] / (n / steps)
+        else:
+            traffic = pmc.get("traffic_bytes_per_launch")
     out["roofline"] = {"kernel": "gemm_%s kernels (encoder / projection GEMMs, all layouts and tile shapes)" % precision,
                        "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                        "frac": ach / peak, "traffic": traffic, "traffic_source": pmc.get("commit", "profiles/ (see file)") if pmc else None,
                        "algorithmic_flops_per_launch": flops / max(n, 1),
-                       "launches_per_step": n / steps, "avg_launch_ms": ms / max(n, 1),
+                       "algorithmic_bytes_per_launch": sum(e.get("bytes", 0.0) for e in g) / max(n, 1),
+                       "launches_per_step": n / steps, "dispatches_per_step": pmc.get("launches_per_train_step") if pmc else None,
+                       "avg_launch_ms": ms / max(n, 1),
                        "share_of_step": ms / (1e3 * prof_elapsed),
                        "measured": "HIP events on the model stream, separate pass of %d steps "
                                    "(%.2f ms/step with events on)" % (steps, 1e3 * prof_elapsed / steps)}
