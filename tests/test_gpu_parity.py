@@ -809,3 +809,32 @@ def test_evaluation_is_reproducible_bit_for_bit(torch_cuda, lib, H, B, T, fusion
     l0 = m.loss(inputs, y, mask, 2)
     assert all(m.loss(inputs, y, mask, 2) == l0 for _ in range(3))
     m.close()
+
+
+@pytest.mark.parametrize("N", [4052, 4056, 3844])
+def test_pingpong_gemm_bf16_output_edges(torch_cuda, lib, N):
+    """The ping-pong kernel's bf16 copy leaves in 16-byte stores after a lane exchange (a lane then holds 8 consecutive columns);
+    at the right edge a lane may hold 4 valid columns -- its own or its partner's.  Shapes one launch of that kernel takes alone
+    (16 x 16 tiles = one round of 256 CUs): N = 4052 ends 4 columns into a lane pair (the partner's half is what remains: a
+    first version dropped exactly those), 4056 ends on the pair, 3844 leaves most of the last tile column empty.  Every element of the
+    fp32 result and of the bf16 copy against the product of the bf16-rounded operands; pads untouched; M edge included."""
+    torch = torch_cuda
+    from ip_avsr_amd import _lib as L
+    M, K = 4090, 256
+    rng = np.random.default_rng(N)
+    A = rng.normal(size=(M, K)).astype(np.float32); Bm = rng.normal(size=(K, N)).astype(np.float32)
+    ld = (N + 63) // 64 * 64
+    a_d = torch.tensor(A, device="cuda")
+    b_d = torch.zeros((K, ld), device="cuda"); b_d[:, :N] = torch.tensor(Bm, device="cuda")
+    a16, b16 = a_d.bfloat16().contiguous(), b_d.bfloat16().contiguous()
+    ref = (a16.float() @ b16.float()[:, :N]).cpu().numpy()
+    c_d = torch.full((M + 3, ld), 7.0, device="cuda")
+    c16 = torch.full((M + 3, ld), 3.0, device="cuda", dtype=torch.bfloat16)
+    L.check(lib.adn_op_gemm_shadow(0, M, N, K, dptr(a_d), K, dptr(b_d), ld, dptr(c_d), ld, dptr(a16), dptr(b16), dptr(c16), 0, None))
+    torch.cuda.synchronize()
+    out, out16 = c_d.cpu().numpy(), c16.float().cpu().numpy()
+    assert np.abs(out[:M, :N] - ref).max() <= 2e-4
+    assert (out[:M, N:] == 7.0).all() and (out[M:] == 7.0).all()
+    want16 = torch.tensor(out[:M, :N]).bfloat16().float().numpy()
+    np.testing.assert_array_equal(out16[:M, :N], want16)                 # the bf16 copy is the rounding of the fp32 result, everywhere
+    assert (out16[:M, N:] == 3.0).all() and (out16[M:] == 3.0).all()
