@@ -43,6 +43,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
 
 B_PER_GPU, T_MAX, THETA, H, C, D = 520, 40, 9, 250, 26, 1200
+B_PER_GPU = int(os.environ.get("ADN_BENCH_B", B_PER_GPU))      # (profiling aid for profiles/scripts/timeline.sh: the judged workload is 520)
 ENC = (2000, 1000, 500, 50)
 LR = 1e-3
 PROFILE_ROUND = "r03"      # profiles/<round>/pmc_traffic_<precision>.json feeds roofline.traffic

@@ -175,6 +175,13 @@ int mask_prepare(const uint8_t* mask_bt, uint8_t* mask_tb, int B, int T, float* 
 int broadcast_rows(const float* vec, float* dst, int ld, int rows, int cols, hipStream_t s);
 // h[r][:] = hid, c[r][:] = cell for r < rows (pad columns 0), h16 = optional bf16 copy of h
 int lstm_init_state_rows(const float* hid, const float* cell, float* h, float* c, void* h16, int ld, int rows, int cols, hipStream_t s);
+// housekeeping of several same-shape tensors in ONE launch (the S input streams' delta layers, the LSTMs' initial states)
+constexpr int kMaxDeltaJobs = 4, kMaxInitJobs = 8;
+struct DeltaJob { const float* src; int ld_src; float* dst; int ld_dst; int F; int append; void* dst16; };
+struct LstmInitJob { const float* hid; const float* cell; float* h; float* c; void* h16; };
+int delta_forward_batch(const DeltaJob* jobs, int n, int B, int T, int theta, hipStream_t s);    // dst = [x | dx | ddx] (append) or a copy
+int delta_backward_batch(const DeltaJob* jobs, int n, int B, int T, int theta, hipStream_t s);   // src = d[x | dx | ddx], dst = dx
+int lstm_init_state_batch(const LstmInitJob* jobs, int n, int ld, int rows, int cols, hipStream_t s);
 // softmax classifier head + double-softmax temporal loss (custom/objectives.py:4-39)
 //   z (T*B rows, time-major, ldz) -> probs_bt (B,T,C) batch-major dense (may be null),
 //   row_loss[r] = -mask*log softmax(softmax(z))[y]  (if y != null), dz (may be null)

@@ -21,9 +21,9 @@ constexpr int kDeltaFC = 32;
 // plain offsets), zeros in the backward kernel -- and TH > 0 fixes theta at compile time: the k-loop unrolls into 2 TH
 // independent LDS reads with constant weights (theta = 9, the reference's window: 21 -> 10 us per launch at 520 x 40 x 50).
 template <int TH>
-__global__ __launch_bounds__(256) void delta_fwd_kernel(const float* __restrict__ in, int ld_in,
-                                                        float* __restrict__ out, int ld_out, int B, int T, int F,
-                                                        int theta_rt, int append, __bf16* __restrict__ out16) {
+__device__ __forceinline__ void delta_fwd_body(const float* __restrict__ in, int ld_in,
+                                               float* __restrict__ out, int ld_out, int B, int T, int F,
+                                               int theta_rt, int append, __bf16* __restrict__ out16) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int theta = TH ? TH : theta_rt;
     const int R = T + 2 * theta;
@@ -97,9 +97,9 @@ __device__ __forceinline__ float delta_adjoint_at(const float* c, int tau, int T
 }
 
 template <int TH>
-__global__ __launch_bounds__(256) void delta_bwd_kernel(const float* __restrict__ dout, int ld_out,
-                                                        float* __restrict__ din, int ld_in, int B, int T, int F,
-                                                        int theta_rt, int append, __bf16* __restrict__ din16) {
+__device__ __forceinline__ void delta_bwd_body(const float* __restrict__ dout, int ld_out,
+                                               float* __restrict__ din, int ld_in, int B, int T, int F,
+                                               int theta_rt, int append, __bf16* __restrict__ din16) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int theta = TH ? TH : theta_rt;
     const int R = T + 2 * theta;
@@ -138,6 +138,41 @@ __global__ __launch_bounds__(256) void delta_bwd_kernel(const float* __restrict_
             if (din16) din16[((size_t)b * T + t) * ld_in + f] = (__bf16)v;
         }
     }
+}
+
+// the kernels: one tensor per launch, or up to kMaxDeltaJobs tensors of one (B, T, theta) -- the S input streams' delta layers --
+// with blockIdx.z = tensor (at the reference's minibatch every one of these launches is a 6 us latency)
+template <int TH>
+__global__ __launch_bounds__(256) void delta_fwd_kernel(const float* __restrict__ in, int ld_in,
+                                                        float* __restrict__ out, int ld_out, int B, int T, int F,
+                                                        int theta_rt, int append, __bf16* __restrict__ out16) {
+    delta_fwd_body<TH>(in, ld_in, out, ld_out, B, T, F, theta_rt, append, out16);
+}
+template <int TH>
+__global__ __launch_bounds__(256) void delta_bwd_kernel(const float* __restrict__ dout, int ld_out,
+                                                        float* __restrict__ din, int ld_in, int B, int T, int F,
+                                                        int theta_rt, int append, __bf16* __restrict__ din16) {
+    delta_bwd_body<TH>(dout, ld_out, din, ld_in, B, T, F, theta_rt, append, din16);
+}
+struct DeltaJobTable { DeltaJob j[kMaxDeltaJobs]; };
+__device__ __forceinline__ DeltaJob pick_delta_job(const DeltaJobTable& t, int k) {      // (explicit selects: no scratch copy of the table)
+    DeltaJob r = t.j[0];
+    if (k == 1) r = t.j[1];
+    if (k == 2) r = t.j[2];
+    if (k == 3) r = t.j[3];
+    return r;
+}
+template <int TH>
+__global__ __launch_bounds__(256) void delta_fwd_batch_kernel(const DeltaJobTable tab, int B, int T, int theta_rt) {
+    const DeltaJob j = pick_delta_job(tab, blockIdx.z);
+    if ((int)blockIdx.y * kDeltaFC >= j.F) return;
+    delta_fwd_body<TH>(j.src, j.ld_src, j.dst, j.ld_dst, B, T, j.F, theta_rt, j.append, reinterpret_cast<__bf16*>(j.dst16));
+}
+template <int TH>
+__global__ __launch_bounds__(256) void delta_bwd_batch_kernel(const DeltaJobTable tab, int B, int T, int theta_rt) {
+    const DeltaJob j = pick_delta_job(tab, blockIdx.z);
+    if ((int)blockIdx.y * kDeltaFC >= j.F) return;
+    delta_bwd_body<TH>(j.src, j.ld_src, j.dst, j.ld_dst, B, T, j.F, theta_rt, j.append, reinterpret_cast<__bf16*>(j.dst16));
 }
 
 // The column slab of one utterance lives in LDS: 2 (T + 2 theta) rows of 32 floats.  Up to 64 KiB that is a plain
@@ -191,6 +226,38 @@ int delta_backward(const float* dout, int ld_out, float* din, int ld_in, int B, 
                            reinterpret_cast<__bf16*>(din16));
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
+}
+
+// the same for up to kMaxDeltaJobs tensors of one (B, T, theta) in ONE launch (jobs: src = layer input / output gradient)
+template <bool FWD>
+static int delta_batch(const DeltaJob* jobs, int n, int B, int T, int theta, hipStream_t s) {
+    ADN_CHECK(n >= 1 && n <= kMaxDeltaJobs && T > 0 && B > 0 && theta >= 0, ADN_ERR_INVALID, "delta batch: bad arguments");
+    const size_t lds = (size_t)2 * (T + 2 * theta) * kDeltaFC * sizeof(float);
+    ADN_CHECK(lds <= kDeltaMaxLds, ADN_ERR_INVALID, "delta layer: T + 2 theta too large (max 640 rows)");
+    DeltaJobTable tab;
+    int fmax = 0; double bytes = 0.0;
+    for (int k = 0; k < n; ++k) {
+        ADN_CHECK(jobs[k].F > 0, ADN_ERR_INVALID, "delta batch: empty tensor");
+        tab.j[k] = jobs[k]; fmax = std::max(fmax, jobs[k].F);
+        bytes += 4.0 * B * T * (double)jobs[k].F * (jobs[k].append ? 4.0 : 2.0);
+    }
+    for (int k = n; k < kMaxDeltaJobs; ++k) tab.j[k] = jobs[0];
+    const dim3 grid(B, cdiv(fmax, kDeltaFC), n);
+    ProfScope prof(FWD ? PROF_DELTA_FWD : PROF_DELTA_BWD, 0.0, bytes, s, n);
+#define ADN_DELTA_LAUNCH(K, TH) do { ADN_TRY(delta_allow_lds(&K<TH>, lds)); hipLaunchKernelGGL(K<TH>, grid, dim3(256), lds, s, tab, B, T, theta); } while (0)
+    if (FWD) { if (theta == 9) ADN_DELTA_LAUNCH(delta_fwd_batch_kernel, 9); else if (theta == 3) ADN_DELTA_LAUNCH(delta_fwd_batch_kernel, 3); else ADN_DELTA_LAUNCH(delta_fwd_batch_kernel, 0); }
+    else { if (theta == 9) ADN_DELTA_LAUNCH(delta_bwd_batch_kernel, 9); else if (theta == 3) ADN_DELTA_LAUNCH(delta_bwd_batch_kernel, 3); else ADN_DELTA_LAUNCH(delta_bwd_batch_kernel, 0); }
+#undef ADN_DELTA_LAUNCH
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+int delta_forward_batch(const DeltaJob* jobs, int n, int B, int T, int theta, hipStream_t s) {
+    if (n == 1) return delta_forward(jobs[0].src, jobs[0].ld_src, jobs[0].dst, jobs[0].ld_dst, B, T, jobs[0].F, theta, jobs[0].append, s, jobs[0].dst16);
+    return delta_batch<true>(jobs, n, B, T, theta, s);
+}
+int delta_backward_batch(const DeltaJob* jobs, int n, int B, int T, int theta, hipStream_t s) {
+    if (n == 1) return delta_backward(jobs[0].src, jobs[0].ld_src, jobs[0].dst, jobs[0].ld_dst, B, T, jobs[0].F, theta, jobs[0].append, s, jobs[0].dst16);
+    return delta_batch<false>(jobs, n, B, T, theta, s);
 }
 
 // =========================================================================================
@@ -679,6 +746,34 @@ __global__ __launch_bounds__(256) void lstm_init_state_kernel(const float* __res
     }
 }
 
+// ... for up to kMaxInitJobs LSTMs of one shape in ONE launch (blockIdx.y = LSTM)
+struct InitJobTable { LstmInitJob j[kMaxInitJobs]; };
+__global__ __launch_bounds__(256) void lstm_init_state_batch_kernel(const InitJobTable tab, int ld, int rows, int cols) {
+    LstmInitJob j = tab.j[0];
+#pragma unroll
+    for (int k = 1; k < kMaxInitJobs; ++k) if ((int)blockIdx.y == k) j = tab.j[k];
+    const int64_t total = (int64_t)rows * ld;
+    __bf16* h16 = reinterpret_cast<__bf16*>(j.h16);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int col = (int)(e % ld);
+        const float hv = col < cols ? j.hid[col] : 0.f, cv = col < cols ? j.cell[col] : 0.f;
+        j.h[e] = hv; j.c[e] = cv;
+        if (h16) h16[e] = (__bf16)hv;
+    }
+}
+int lstm_init_state_batch(const LstmInitJob* jobs, int n, int ld, int rows, int cols, hipStream_t s) {
+    for (int k0 = 0; k0 < n; k0 += kMaxInitJobs) {
+        const int nn = std::min(kMaxInitJobs, n - k0);
+        if (nn == 1) { ADN_TRY(lstm_init_state_rows(jobs[k0].hid, jobs[k0].cell, jobs[k0].h, jobs[k0].c, jobs[k0].h16, ld, rows, cols, s)); continue; }
+        InitJobTable tab;
+        for (int k = 0; k < kMaxInitJobs; ++k) tab.j[k] = jobs[k0 + (k < nn ? k : 0)];
+        hipLaunchKernelGGL(lstm_init_state_batch_kernel, dim3(std::min(grid_for((int64_t)rows * ld), 1024), nn), dim3(256), 0, s, tab, ld, rows, cols);
+        ADN_HIP_CHECK(hipGetLastError());
+    }
+    return ADN_OK;
+}
+
+int lstm_init_state_rows(const float* hid, const float* cell, float* h, float* c, void* h16, int ld, int rows, int cols, hipStream_t s);
 int lstm_init_state_rows(const float* hid, const float* cell, float* h, float* c, void* h16, int ld, int rows, int cols, hipStream_t s) {
     hipLaunchKernelGGL(lstm_init_state_kernel, dim3(grid_for((int64_t)rows * ld)), dim3(256), 0, s, hid, cell, h, c,
                        reinterpret_cast<__bf16*>(h16), ld, rows, cols);

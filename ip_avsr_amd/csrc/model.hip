@@ -189,6 +189,10 @@ struct adn_model {
     // bf16x3 over planes: results whose fp32 copy was not written (their readers take the planes); a reader that needs fp32 after
     // all -- a GEMM the ping-pong kernel declines, adn_read_encoder_activation -- gets hi + lo written back first
     std::vector<std::pair<const float*, size_t>> fp32_stale;
+    // housekeeping launches of one phase queued for ONE batched launch each (the S streams' delta layers, the LSTMs' initial
+    // states): flushed ahead of the first reader
+    std::vector<DeltaJob> delta_q; int delta_q_theta = 0; bool delta_q_fwd = true;
+    std::vector<LstmInitJob> init_q;
     int dp_order = -1;                       // -1: not latched yet; 0: layer-major buckets / back-propagation, 1: stream-major
     float adam_a_t = 0.f; bool adam_open = false;   // step size of the optimiser step opened by adn_adam_begin
     size_t adacoeff = 0;               // S scalars (one 8-float block)
@@ -991,7 +995,9 @@ LstmStep make_step(const adn_model* m, const LstmParams& lp, const LstmWork& w, 
 }
 
 // sums_done: the backward kernels already added the bias / initial-state gradients of every LSTM of the group
+int flush_init_states(adn_model* m, int B);
 int run_lstm_group(adn_model* m, std::vector<LstmStep>& steps, int B, int T, bool backward, bool* sums_done = nullptr) {
+    ADN_TRY(flush_init_states(m, B));
     bool all = true;
     std::vector<char> planes_done(steps.size(), 0);
     for (size_t i = 0; i < steps.size(); i += kMaxLstmPerLaunch) {
@@ -1108,11 +1114,45 @@ GemmArgs cat_dx_args(adn_model* m, size_t k, int N) {
     return d;
 }
 
+// Batched housekeeping pays where its launches are latency-bound -- the reference's own minibatches: B = 26, 1.276 -> 1.251 ms per
+// train step -- and costs at the whole-split batch (B = 520: 3.880 -> 3.913 ms, three times measured): small batches only.
+bool batched_housekeeping(const adn_model* m, int B, int T) {
+    static const bool off = getenv("ADN_NO_BATCHED_HOUSEKEEPING") != nullptr;
+    return !off && !streams_concurrent(m) && (int64_t)B * T <= 8192;
+}
+// queued: run_lstm_group() flushes the queue as one launch ahead of the LSTM kernels (with the streams on forked HIP streams every
+// job goes out at once, on its stream)
+int flush_init_states(adn_model* m, int B) {
+    if (m->init_q.empty()) return ADN_OK;
+    const int rc = lstm_init_state_batch(m->init_q.data(), (int)m->init_q.size(), m->ldh, B, m->H, m->stream);
+    m->init_q.clear();
+    return rc;
+}
 int lstm_init_state(adn_model* m, const LstmParams& lp, const LstmWork& w, int B, int T) {
     const size_t blk = lp.backwards ? (size_t)T * B * m->ldh : 0;
     char* h16 = m->bf16() ? static_cast<char*>(m->shadow_of(w.hbuf)) : nullptr;     // bf16 copy of the initial-state block
-    return lstm_init_state_rows(m->P(lp.hid_init), m->P(lp.cell_init), w.hbuf + blk, w.cbuf + blk, h16 ? h16 + blk * 2 : nullptr,
-                                m->ldh, B, m->H, m->stream);
+    m->init_q.push_back(LstmInitJob{m->P(lp.hid_init), m->P(lp.cell_init), w.hbuf + blk, w.cbuf + blk, h16 ? h16 + blk * 2 : nullptr});
+    if (!batched_housekeeping(m, B, T)) return flush_init_states(m, B);
+    return ADN_OK;
+}
+// the delta layers of the streams: queued while consecutive jobs share direction and window, flushed by the first reader
+int flush_deltas(adn_model* m, int B, int T) {
+    if (m->delta_q.empty()) return ADN_OK;
+    int rc = ADN_OK;
+    for (size_t k0 = 0; k0 < m->delta_q.size() && rc == ADN_OK; k0 += kMaxDeltaJobs) {
+        const int n = (int)std::min<size_t>(kMaxDeltaJobs, m->delta_q.size() - k0);
+        rc = m->delta_q_fwd ? delta_forward_batch(m->delta_q.data() + k0, n, B, T, m->delta_q_theta, m->stream)
+                            : delta_backward_batch(m->delta_q.data() + k0, n, B, T, m->delta_q_theta, m->stream);
+    }
+    m->delta_q.clear();
+    return rc;
+}
+int queue_delta(adn_model* m, bool fwd, const DeltaJob& j, int B, int T, int theta, bool flush_now) {
+    if (!m->delta_q.empty() && (m->delta_q_fwd != fwd || m->delta_q_theta != theta)) ADN_TRY(flush_deltas(m, B, T));
+    m->delta_q_fwd = fwd; m->delta_q_theta = theta;
+    m->delta_q.push_back(j);
+    if (flush_now || !batched_housekeeping(m, B, T)) return flush_deltas(m, B, T);
+    return ADN_OK;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1231,11 +1271,15 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
         }
         const bool drop = m->stochastic && st.cfg.dropout_p > 0.f;
         void* feat16 = (m->bf16() && !drop) ? m->shadow_of(st.feat) : nullptr;      // written by the delta kernel itself
-        ADN_TRY(delta_forward(a, lda, st.feat, ld_of(st.feat_dim), B, T, st.enc_out, theta, st.cfg.use_delta, m->stream, feat16));
+        // (queued: the streams' delta layers go out as ONE launch ahead of their first reader -- the dropout / bf16-copy pass
+        //  right below where a stream has one, else the grouped input projections behind this loop)
+        ADN_TRY(queue_delta(m, true, DeltaJob{a, lda, st.feat, ld_of(st.feat_dim), st.enc_out, st.cfg.use_delta, feat16}, B, T, theta, false));
         if (st.cfg.aux_dim > 0)                                  // ConcatLayer([l_delta, l_dct], axis=2): columns behind the deltas
-            ADN_TRY(delta_forward(st.aux_stage, ld_of(st.cfg.aux_dim), st.feat + st.delta_dim, ld_of(st.feat_dim), B, T,
-                                  st.cfg.aux_dim, theta, 0, m->stream,
-                                  feat16 ? static_cast<char*>(feat16) + 2 * (size_t)st.delta_dim : nullptr));
+            ADN_TRY(queue_delta(m, true, DeltaJob{st.aux_stage, ld_of(st.cfg.aux_dim), st.feat + st.delta_dim, ld_of(st.feat_dim),
+                                                  st.cfg.aux_dim, 0,
+                                                  feat16 ? static_cast<void*>(static_cast<char*>(feat16) + 2 * (size_t)st.delta_dim) : nullptr},
+                                B, T, theta, false));
+        if (drop || !feat16 || !grouped) ADN_TRY(flush_deltas(m, B, T));
         if (drop)                                                // DropoutLayer ahead of the LSTM (adenet_v3.py:112,123,134)
             ADN_TRY(dropout_apply(st.feat, ld_of(st.feat_dim), st.feat, ld_of(st.feat_dim), B, T, st.feat_dim, st.feat_dim, 0,
                                   st.cfg.dropout_p, m->drop_seed, m->drop_counter, (uint32_t)(&st - m->st.data()), m->stream));
@@ -1256,6 +1300,7 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
             steps.push_back(make_step(m, st.lstm[k], st.lw[k], nullptr, false));
         }
     }
+    ADN_TRY(flush_deltas(m, B, T));
     ADN_TRY(join_streams(m));
     ADN_TRY(issue_grouped(m, stream_proj));
     ADN_TRY(run_lstm_group(m, steps, B, T, false));
@@ -1744,8 +1789,11 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         const bool last_linear = L > 0 && st.cfg.enc_act[L - 1] == ADN_ACT_LINEAR;
         void* dE16 = (m->bf16() && (L == 0 || last_linear)) ? m->shadow_of(st.dE) : nullptr;   // bf16 copy straight from the kernel
         // (an auxiliary input sits in the columns behind the delta features: data, no gradient)
-        ADN_TRY(delta_backward(st.dfeat, ldf, st.dE, ldE, B, T, st.enc_out, theta, st.cfg.use_delta, m->stream,
-                               st.cfg.batchnorm ? nullptr : dE16));
+        // (queued: where nothing of this stream reads dE before the encoder's back-propagation starts -- no BatchNorm, a linear
+        //  bottleneck, the bf16 copy written by the kernel -- the streams' delta layers go out as ONE launch behind this loop)
+        const bool dE_read_here = st.cfg.batchnorm || !last_linear || !dE16 || stream_major;
+        ADN_TRY(queue_delta(m, false, DeltaJob{st.dfeat, ldf, st.dE, ldE, st.enc_out, st.cfg.use_delta, st.cfg.batchnorm ? nullptr : dE16},
+                            B, T, theta, dE_read_here));
         if (st.cfg.batchnorm)                     // through the BatchNormLayer: d(bn_out) -> d(encoder output), dgamma, dbeta
             ADN_TRY(batchnorm_backward(st.act[L - 1], ldE, st.dE, ldE, st.dE, ldE, N, st.enc_out, m->P(st.bn_gamma),
                                        m->training ? st.bn_save_mean : m->P(st.bn_mean),
@@ -1854,6 +1902,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             ADN_TRY(issue_grouped(m, dx));
         }
         for (size_t si = 0; si < m->st.size(); ++si) { ADN_TRY(stream_head(si, true)); max_depth = std::max(max_depth, walk[si].active ? walk[si].L : 0); }
+        ADN_TRY(flush_deltas(m, B, T));
         for (int d = 0; d < max_depth; ++d)
             for (const auto& sis : depth_groups(m, d)) ADN_TRY(layer_step(sis, d));
         ADN_TRY(col_sum_batch(bias_sums, m->stream));
