@@ -712,8 +712,10 @@ __device__ unsigned long long g_gstamps[16];
 #define GSTAMP_FLUSH do {} while (0)
 #endif
 
-template <int BM, int BN, bool A_KC, bool SPLIT>
+// PLANES: the launch may run over hi / lo planes (kseg_p > 0); false compiles the segment cursors out of the K-loop
+template <int BM, int BN, bool A_KC, bool SPLIT, bool PLANES>
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
+    const int kseg_p = PLANES ? p.kseg : 0;
     constexpr int BK = kPpBK, NS = kPpNS, D = kPpD;
     constexpr int WTM = BM / 4, WTN = BN / 2, TM = WTM / 16, TN = WTN / 16;
     constexpr int kAElems = BM * BK, kBElems = BK * BN, kStageElems = kAElems + kBElems;
@@ -764,11 +766,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
         grp = q / per_group;
         tile_coords(p, q - grp * per_group, tm, tn);
     };
-    // bf16x3 through hi / lo PLANES (p.kseg > 0): K runs over three segments of p.kseg (a multiple of BK) -- A_hi B_hi, A_hi B_lo,
+    // bf16x3 through hi / lo PLANES (kseg_p > 0): K runs over three segments of kseg_p (a multiple of BK) -- A_hi B_hi, A_hi B_lo,
     // A_lo B_hi -- read from the two bf16 planes of each operand (same layout, written once by the operand's producer) instead of
     // from [hi | hi | lo] / [hi ; lo ; hi] images made per use.  Only the DMA cursors know: a tile keeps its four plane bases
     // and counts the stages to the next segment boundary.
-    const int kseg_steps = p.kseg / BK;
+    const int kseg_steps = kseg_p / BK;
     const char *segA_hi = nullptr, *segA_lo = nullptr, *segB_hi = nullptr, *segB_lo = nullptr;
     int seg_cur = 0, seg_left = 0;
     auto setup_src = [&](int ord) {
@@ -779,8 +781,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
         const char* B16 = reinterpret_cast<const char*>(sg.B16);
         const int m0 = tm * BM, n0 = tn * BN;
         int kin = kbeg;
-        if (p.kseg) {
-            seg_cur = kbeg / p.kseg; kin = kbeg - seg_cur * p.kseg; seg_left = kseg_steps - kin / BK;
+        if (kseg_p) {
+            seg_cur = kbeg / kseg_p; kin = kbeg - seg_cur * kseg_p; seg_left = kseg_steps - kin / BK;
             segA_hi = A_KC ? A16 + (size_t)m0 * p.lda * 2 : A16;
             segA_lo = reinterpret_cast<const char*>(sg.A16lo) + (segA_hi - A16);
             segB_hi = B16; segB_lo = reinterpret_cast<const char*>(sg.B16lo);
@@ -840,7 +842,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
             }
         }
         baseA += a_step; baseB += b_step;
-        if (p.kseg && --seg_left == 0) {                           // next stage opens the next segment
+        if (kseg_p && --seg_left == 0) {                           // next stage opens the next segment
             ++seg_cur; seg_left = kseg_steps;
             baseA = seg_cur == 2 ? segA_lo : segA_hi;
             baseB = seg_cur == 1 ? segB_lo : segB_hi;
@@ -872,8 +874,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     // (planes: every segment ends with the same partial stage when the real K is not a multiple of BK -- the A operand's
     //  columns behind K may hold anything, e.g. a wider earlier use of a reused gradient buffer)
-    const int ktail_m = p.kseg ? p.kreal - (p.kseg - BK) : ktail;
-    const bool seg_tail = p.kseg && ktail_m < BK;
+    const int ktail_m = kseg_p ? p.kreal - (kseg_p - BK) : ktail;
+    const bool seg_tail = kseg_p && ktail_m < BK;
     u32x4 amask;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -907,13 +909,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
     for (int s = 0; s < D && s < total; ++s) issue_next();
     wait_next(-1, false);
     __builtin_amdgcn_s_barrier();                                  // #0
-    const bool one = p.one_barrier != 0;
+    constexpr bool one = true;                                     // (the two-barrier schedule of round 2 is gone: 7 - 16 % slower)
     if (late && !one) __builtin_amdgcn_s_barrier();                // the lower half starts one segment later
 
     int kt = 0, ord = 0;
     int grp, tile_m, tile_n;
     tile_of(0, grp, tile_m, tile_n);
-    const int cseg_first = p.kseg ? kseg_steps - (kbeg % p.kseg) / BK : 0;      // K-steps to the first segment boundary of a tile
+    const int cseg_first = kseg_p ? kseg_steps - (kbeg % kseg_p) / BK : 0;      // K-steps to the first segment boundary of a tile
     int cseg_left = cseg_first;
     GSTAMP_INIT
     typedef __attribute__((address_space(3))) bf16x8 lds_bf16x8;
@@ -1117,7 +1119,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
 #pragma unroll
             for (int a = 0; a < TM; ++a) fa[a] = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4, fa[a]) & amask);
         }
-        if (p.kseg && --cseg_left == 0) cseg_left = kseg_steps;
+        if (kseg_p && --cseg_left == 0) cseg_left = kseg_steps;
         wait_next(s, kt == 0 && s > 0);
         GSTAMP(3);
         if (!one || late) __builtin_amdgcn_s_barrier();
@@ -1555,14 +1557,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool PLANES>
 static void launch_pp_t(const GemmParams& p, int layout, bool split, dim3 grid, hipStream_t s) {
     if (layout == GEMM_NN) {
-        if (split) hipLaunchKernelGGL((gemm_bf16_pp_kernel<BM, BN, true, true>), grid, dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((gemm_bf16_pp_kernel<BM, BN, true, false>), grid, dim3(512), 0, s, p);
+        if (split) hipLaunchKernelGGL((gemm_bf16_pp_kernel<BM, BN, true, true, PLANES>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((gemm_bf16_pp_kernel<BM, BN, true, false, PLANES>), grid, dim3(512), 0, s, p);
     } else {
-        if (split) hipLaunchKernelGGL((gemm_bf16_pp_kernel<BM, BN, false, true>), grid, dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((gemm_bf16_pp_kernel<BM, BN, false, false>), grid, dim3(512), 0, s, p);
+        if (split) hipLaunchKernelGGL((gemm_bf16_pp_kernel<BM, BN, false, true, PLANES>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((gemm_bf16_pp_kernel<BM, BN, false, false, PLANES>), grid, dim3(512), 0, s, p);
     }
 }
 
@@ -1579,9 +1581,9 @@ void launch_gemm_bf16_pp(const GemmParams& p, int layout, int tile_mode, int spl
         }
     }
 #ifndef ADN_W4_ONLY
-    else if (tile_mode == 4) launch_pp_t<256, 256>(p, layout, split, grid, s);
-    else if (tile_mode == 5) launch_pp_t<256, 128>(p, layout, split, grid, s);
-    else launch_pp_t<128, 256>(p, layout, split, grid, s);
+    else if (tile_mode == 4) { if (p.kseg) launch_pp_t<256, 256, true>(p, layout, split, grid, s); else launch_pp_t<256, 256, false>(p, layout, split, grid, s); }
+    else if (tile_mode == 5) launch_pp_t<256, 128, true>(p, layout, split, grid, s);      // (diagnostic tile shapes: the general form only)
+    else launch_pp_t<128, 256, true>(p, layout, split, grid, s);
 #endif
     if (split) {
         const size_t n4 = (size_t)p.M * (p.N / 4);
