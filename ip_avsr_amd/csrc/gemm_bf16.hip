@@ -985,7 +985,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
             // also waits for every store issued before that point; with the requests at the top of each pair of blocks every
             // pair sat out the write acknowledgements of the pair before (4 drains per tile, 2 us each).  One register array
             // serves both kinds (a launch has a bias or an act'(Y) mask, never both): 4 float4 of bias, or TM x 4 8-byte masks.
-            constexpr int QB = TN / 2;                         // blocks per request burst: two bursts per tile (all of it at once spills)
+            // blocks per request burst: two bursts per tile (all of it at once spills); four in the k-strided-A form, whose fragment
+            // addressing leaves fewer registers (2 VGPRs went to scratch there -- and scratch traffic sits in the vmcnt queue
+            // this kernel counts by hand)
+            constexpr int QB = A_KC ? TN / 2 : TN / 4;
             uint2 pre[TM * QB];
 #pragma clang loop unroll(full)
             for (int half = 0; half < TN / TNH; ++half) {
@@ -1106,6 +1109,29 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
         }
         GSTAMP(6);
         if (s == total) break;
+        // ---------------- the interior steps of a tile, stripped of every test the general step carries: the stage issued
+        //      (s + D) lies inside this tile and ahead of its masked last one (kt + D < nk - 1), this step is neither the first
+        //      behind an epilogue (kt >= 1) nor masked, D - 1 younger stages are in flight.  Same L / wait / barrier / C order.
+        if constexpr (!PLANES && !SPLIT) {
+            while (kt >= 1 && kt + D < nk - 1) {
+                read_frags(rd_slot * (kAElems * 2), rd_slot * (kBElems * 2));
+                if (++rd_slot == NS) rd_slot = 0;
+                issue_one(std::false_type{});
+                if (++is_slot == NS) is_slot = 0;
+                ++is_k;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                wait_vmcnt<(D - 1) * PW>();
+                if (late) __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas();
+                ++kt;
+                __builtin_amdgcn_sched_barrier(0);
+                if (!late) __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                ++s;
+            }
+        }
         // ---------------- the general step.  L(s): fragments of stage s -> registers, DMA for stage s + D
         read_frags(rd_slot * (kAElems * 2), rd_slot * (kBElems * 2));
         if (++rd_slot == NS) rd_slot = 0;
