@@ -988,7 +988,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
             // blocks per request burst: two bursts per tile (all of it at once spills); four in the k-strided-A form, whose fragment
             // addressing leaves fewer registers (2 VGPRs went to scratch there -- and scratch traffic sits in the vmcnt queue
             // this kernel counts by hand)
-            constexpr int QB = A_KC ? TN / 2 : TN / 4;
+            constexpr int QB = (A_KC && !PLANES) ? TN / 2 : TN / 4;       // (... and over planes: the segment cursors take their share)
             uint2 pre[TM * QB];
 #pragma clang loop unroll(full)
             for (int half = 0; half < TN / TNH; ++half) {
@@ -1112,8 +1112,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
         // ---------------- the interior steps of a tile, stripped of every test the general step carries: the stage issued
         //      (s + D) lies inside this tile and ahead of its masked last one (kt + D < nk - 1), this step is neither the first
         //      behind an epilogue (kt >= 1) nor masked, D - 1 younger stages are in flight.  Same L / wait / barrier / C order.
-        if constexpr (!PLANES && !SPLIT) {
-            while (kt >= 1 && kt + D < nk - 1) {
+        {
+            // (over planes: neither the stage issued nor the step consumed may touch a segment boundary)
+            while (kt >= 1 && kt + D < nk - 1 && (!PLANES || !kseg_p || (seg_left > 1 && cseg_left > 1))) {
                 read_frags(rd_slot * (kAElems * 2), rd_slot * (kBElems * 2));
                 if (++rd_slot == NS) rd_slot = 0;
                 issue_one(std::false_type{});
@@ -1126,6 +1127,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
                 __builtin_amdgcn_sched_barrier(0);
                 mfmas();
                 ++kt;
+                if (PLANES && kseg_p) --cseg_left;
                 __builtin_amdgcn_sched_barrier(0);
                 if (!late) __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
