@@ -1106,6 +1106,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
 #pragma unroll
             for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (++ord < my_tiles) tile_of(ord, grp, tile_m, tile_n);
+        // A compiler-visible vmcnt(0) behind the epilogue: its loads and stores are the only vector-memory operations hipcc
+        // knows of in this kernel (the DMA and its waits are inline asm), and with any of them possibly pending it put an
+        // s_waitcnt vmcnt(0) at the head of the interior loop below -- the whole ring drained at every K-step.  Here the wait
+        // is free: the stages in flight were issued before the epilogue, and the next wait site drains the stores anyway.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         }
         GSTAMP(6);
         if (s == total) break;
