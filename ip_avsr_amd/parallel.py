@@ -181,11 +181,23 @@ class DataParallel(object):
         if len(ranges) == 1:
             b, e = ranges[0]
             return self.dist.all_reduce(self.grad[b:e], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
-        from torch.distributed.distributed_c10d import _coalescing_manager
-        with _coalescing_manager(group=self.group, async_ops=True) as cm:
-            for b, e in ranges:
-                self.dist.all_reduce(self.grad[b:e], op=self.dist.ReduceOp.SUM, group=self.group)
-        return cm
+        if not getattr(self, "_no_coalescing", False):
+            try:
+                from torch.distributed.distributed_c10d import _coalescing_manager
+                with _coalescing_manager(group=self.group, async_ops=True) as cm:
+                    for b, e in ranges:
+                        self.dist.all_reduce(self.grad[b:e], op=self.dist.ReduceOp.SUM, group=self.group)
+                return cm
+            except (RuntimeError, NotImplementedError, AttributeError, ImportError):
+                # (a backend without grouped all-reduce for these tensors -- gloo on device memory: one collective per range)
+                self._no_coalescing = True
+        works = [self.dist.all_reduce(self.grad[b:e], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True) for b, e in ranges]
+
+        class _All(object):
+            def wait(self_inner):
+                for w in works:
+                    w.wait()
+        return _All()
 
     def sync_running_statistics(self):
         """BatchNorm running statistics (adenet_v1 / v1_1: ``streamK.bn.mean`` / ``.bn.inv_std``) are updated from each
