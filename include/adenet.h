@@ -221,6 +221,7 @@ int adn_apply_adam(adn_model* m, float learning_rate);
  * its all-reduce has landed, while later buckets are still being reduced. */
 int adn_adam_begin(adn_model* m, float learning_rate);
 int adn_adam_range(adn_model* m, int64_t begin_floats, int64_t end_floats);
+int adn_adam_ranges(adn_model* m, const int64_t* begin_floats, const int64_t* end_floats, int n);   /* n ranges, one launch per 16 */
 int adn_adam_end(adn_model* m);
 /* <- custom/updates.py:35-99 adam_vlr: Adam with one learning rate per parameter tensor (index order of
  * adn_param_info); tensors of one layer must share theirs, as generate_lr_map (custom/updates.py:10-32) gives */

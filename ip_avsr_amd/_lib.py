@@ -94,6 +94,7 @@ _SIGNATURES = {
     "adn_grad_bucket_groups": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "adn_adam_begin": (C.c_int, [_P, C.c_float]),
     "adn_adam_range": (C.c_int, [_P, C.c_int64, C.c_int64]),
+    "adn_adam_ranges": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int]),
     "adn_adam_end": (C.c_int, [_P]),
     "adn_apply_adam_vlr": (C.c_int, [_P, C.POINTER(C.c_float), C.c_int]),
     "adn_adam_step_count": (C.c_int, [_P]),

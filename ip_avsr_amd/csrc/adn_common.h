@@ -194,6 +194,10 @@ int reduce_loss(const float* v, int n, const float* total, float* out, hipStream
 int adam_update(float* p, const float* g, float* m, float* v, int64_t n, float a_t, float beta1,
                 float beta2, float eps, hipStream_t s, void* p16 = nullptr, const float* poison = nullptr, int* sticky = nullptr,
                 void* p16lo = nullptr);     // (p16lo: with p16 the hi / lo planes of the bf16x3 mode)
+constexpr int kMaxAdamRanges = 16;
+struct AdamRanges { int64_t begin[kMaxAdamRanges], end[kMaxAdamRanges]; };    // float offsets into the flat buffers (multiples of 8)
+int adam_update_ranges(float* p, const float* g, float* m, float* v, const int64_t* begin, const int64_t* end, int n_ranges, float a_t,
+                       float beta1, float beta2, float eps, hipStream_t s, void* p16, const float* poison, int* sticky, void* p16lo);
 int poison_tail(const int* err_word, float* tail1, hipStream_t s);
 int copy_bench(const float* src, float* dst, int64_t n, int repeats, hipStream_t s, float* ms);
 // lasagne.updates.sgd (momentum == 0) / momentum / nesterov_momentum; adadelta

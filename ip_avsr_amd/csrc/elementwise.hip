@@ -889,15 +889,10 @@ int reduce_loss(const float* v, int n, const float* total, float* out, hipStream
 // Adam: lasagne.updates.adam == custom/updates.py:73-99.  a_t = lr*sqrt(1-b2^t)/(1-b1^t) from the host.
 // 7 floats of traffic per parameter (read p,g,m,v; write p,m,v): pure HBM stream, float4 per lane.
 // =========================================================================================
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                   float* __restrict__ m, float* __restrict__ v, int64_t n4,
-                                                   int64_t n, float a_t, float b1, float b2, float eps,
-                                                   __bf16* __restrict__ p16, const float* poison, int* sticky,
-                                                   __bf16* __restrict__ p16lo) {
-    if (poison && *poison != 0.f) {          // a rank's LSTM exchange timed out: the gradients are invalid on EVERY rank
-        if (sticky && blockIdx.x == 0 && threadIdx.x == 0) *sticky = 1;
-        return;
-    }
+__device__ __forceinline__ void adam_body(float* __restrict__ p, const float* __restrict__ g,
+                                          float* __restrict__ m, float* __restrict__ v, int64_t n4,
+                                          int64_t n, float a_t, float b1, float b2, float eps,
+                                          __bf16* __restrict__ p16, __bf16* __restrict__ p16lo) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         float4 pp = reinterpret_cast<float4*>(p)[i];
         const float4 gg = reinterpret_cast<const float4*>(g)[i];
@@ -931,6 +926,35 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         p[i] = pi;
         if (p16) { p16[i] = (__bf16)pi; if (p16lo) p16lo[i] = (__bf16)(pi - (float)p16[i]); }
     }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n4,
+                                                   int64_t n, float a_t, float b1, float b2, float eps,
+                                                   __bf16* __restrict__ p16, const float* poison, int* sticky,
+                                                   __bf16* __restrict__ p16lo) {
+    if (poison && *poison != 0.f) {          // a rank's LSTM exchange timed out: the gradients are invalid on EVERY rank
+        if (sticky && blockIdx.x == 0 && threadIdx.x == 0) *sticky = 1;
+        return;
+    }
+    adam_body(p, g, m, v, n4, n, a_t, b1, b2, eps, p16, p16lo);
+}
+// the same update on up to kMaxAdamRanges ranges of the flat buffers in ONE launch (blockIdx.y = range): the data-parallel
+// wrapper updates every gradient bucket whose reduction has landed with one launch
+__global__ __launch_bounds__(256) void adam_ranges_kernel(const AdamRanges R, float* __restrict__ p, const float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v, float a_t, float b1, float b2,
+                                                          float eps, __bf16* __restrict__ p16, const float* poison, int* sticky,
+                                                          __bf16* __restrict__ p16lo) {
+    if (poison && *poison != 0.f) {
+        if (sticky && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *sticky = 1;
+        return;
+    }
+    int64_t b = R.begin[0], e = R.end[0];
+#pragma unroll
+    for (int k = 1; k < kMaxAdamRanges; ++k) if ((int)blockIdx.y == k) { b = R.begin[k]; e = R.end[k]; }
+    const int64_t n = e - b;
+    if (n <= 0) return;
+    adam_body(p + b, g + b, m + b, v + b, n / 4, n, a_t, b1, b2, eps, p16 ? p16 + b : nullptr, p16lo ? p16lo + b : nullptr);
 }
 
 // float4 copy (bench.py's measured-HBM yardstick)
@@ -974,6 +998,25 @@ int adam_update(float* p, const float* g, float* m, float* v, int64_t n, float a
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(std::max<int64_t>(n4, 1))), dim3(256), 0, s, p, g, m, v, n4, n, a_t,
                        beta1, beta2, eps, reinterpret_cast<__bf16*>(p16), poison, sticky, reinterpret_cast<__bf16*>(p16lo));
     ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+int adam_update_ranges(float* p, const float* g, float* m, float* v, const int64_t* begin, const int64_t* end, int n_ranges, float a_t,
+                       float beta1, float beta2, float eps, hipStream_t s, void* p16, const float* poison, int* sticky, void* p16lo) {
+    for (int k0 = 0; k0 < n_ranges; k0 += kMaxAdamRanges) {
+        const int nn = std::min(kMaxAdamRanges, n_ranges - k0);
+        AdamRanges R;
+        int64_t longest = 0; double total = 0.0;
+        for (int k = 0; k < kMaxAdamRanges; ++k) {
+            R.begin[k] = k < nn ? begin[k0 + k] : 0; R.end[k] = k < nn ? end[k0 + k] : 0;
+            longest = std::max(longest, R.end[k] - R.begin[k]); total += (double)(R.end[k] - R.begin[k]);
+        }
+        if (longest <= 0) continue;
+        ProfScope prof(PROF_ADAM, 0.0, 7.0 * 4.0 * total, s);
+        hipLaunchKernelGGL(adam_ranges_kernel, dim3(grid_for(std::max<int64_t>(longest / 4, 1)), nn), dim3(256), 0, s, R, p, g, m, v, a_t,
+                           beta1, beta2, eps, reinterpret_cast<__bf16*>(p16), poison, sticky, reinterpret_cast<__bf16*>(p16lo));
+        ADN_HIP_CHECK(hipGetLastError());
+    }
     return ADN_OK;
 }
 

@@ -2320,6 +2320,22 @@ int adn_adam_range(adn_model* m, int64_t begin_floats, int64_t end_floats) {
                        e - begin_floats, m->adam_a_t, kBeta1, kBeta2, kEps, m->stream, p16,
                        m->poison_word(), m->poison_sticky, pl ? static_cast<void*>(m->params16lo + b * 2) : nullptr);
 }
+int adn_adam_ranges(adn_model* m, const int64_t* begin_floats, const int64_t* end_floats, int n) {
+    ADN_CHECK(m && begin_floats && end_floats && n >= 0, ADN_ERR_INVALID, "bad argument");
+    ADN_CHECK(m->adam_open, ADN_ERR_STATE, "adn_adam_ranges outside adn_adam_begin / adn_adam_end");
+    std::vector<int64_t> b, e;
+    for (int k = 0; k < n; ++k) {
+        ADN_CHECK(begin_floats[k] >= 0 && begin_floats[k] <= end_floats[k] && begin_floats[k] % 8 == 0, ADN_ERR_INVALID, "bad range");
+        const int64_t ee = std::min<int64_t>(end_floats[k], (int64_t)m->flat_floats);
+        if (ee > begin_floats[k]) { b.push_back(begin_floats[k]); e.push_back(ee); }
+    }
+    if (b.empty()) return ADN_OK;
+    const bool pl = m->planes() && m->params16 && m->params16lo;
+    void* p16 = ((shadows_on(m) || pl) && m->params16) ? static_cast<void*>(m->params16) : nullptr;
+    return adam_update_ranges(m->flat[ADN_BUF_PARAM], m->flat[ADN_BUF_GRAD], m->flat[ADN_BUF_ADAM_M], m->flat[ADN_BUF_ADAM_V], b.data(), e.data(),
+                              (int)b.size(), m->adam_a_t, kBeta1, kBeta2, kEps, m->stream, p16, m->poison_word(), m->poison_sticky,
+                              pl ? static_cast<void*>(m->params16lo) : nullptr);
+}
 int adn_adam_end(adn_model* m) {
     ADN_CHECK(m, ADN_ERR_INVALID, "null model");
     ADN_CHECK(m->adam_open, ADN_ERR_STATE, "adn_adam_end without adn_adam_begin");

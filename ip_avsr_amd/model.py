@@ -419,6 +419,12 @@ class AdeNetModel(object):
     def adam_range(self, begin, end):
         _lib.check(self._lib.adn_adam_range(self._handle, int(begin), int(end)))
 
+    def adam_ranges(self, ranges):
+        """``adam_range`` for a list of (begin, end) ranges with one launch per 16 of them."""
+        n = len(ranges)
+        b = (C.c_int64 * max(1, n))(*[int(r[0]) for r in ranges]); e = (C.c_int64 * max(1, n))(*[int(r[1]) for r in ranges])
+        _lib.check(self._lib.adn_adam_ranges(self._handle, b, e, n))
+
     def adam_end(self):
         _lib.check(self._lib.adn_adam_end(self._handle))
 

@@ -8,7 +8,7 @@ run() {
     | tail -1 | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print("%.3f ms/step" % d["ms_per_step"])'
 }
 run "one all-reduce of the whole buffer, Adam (no overlap)" "ADN_DP_NO_OVERLAP=1"
-run "16 buckets, one collective each, Adam per bucket     " "ADN_DP_NO_COALESCE=1"
-run "16 buckets, grouped collectives (6), Adam per bucket " "X=1"
+run "16 buckets, one collective + event each, Adam x2     " "ADN_DP_NO_COALESCE=1"
+run "16 buckets, 6 grouped collectives, Adam x2 (default) " "X=1"
 run "16 buckets, grouped collectives, whole-buffer Adam   " "ADN_DP_WHOLE_BUFFER_ADAM=1"
 run "stream-major, one collective per bucket              " "ADN_DP_STREAM_MAJOR=1"

@@ -294,8 +294,14 @@ def test_ranged_adam_equals_whole_buffer_adam_on_the_device(precision):
         gb.copy_(ga)                                           # two runs of one step may differ in the last bit (atomics)
         a.apply_adam(2e-3)
         b.adam_begin(2e-3)
-        for (lo, hi) in buckets:
-            b.adam_range(lo, hi)
+        if step == 1:                                          # ... or every range in one launch (what DataParallel issues)
+            b.adam_ranges(buckets)
+        elif step == 2:                                        # ... or some of them singly and the rest together
+            b.adam_range(*buckets[0])
+            b.adam_ranges(buckets[1:])
+        else:
+            for (lo, hi) in buckets:
+                b.adam_range(lo, hi)
         b.adam_end()
     assert a.adam_step_count() == b.adam_step_count() == 3
     sa, sb = a.get_adam_state(), b.get_adam_state()
