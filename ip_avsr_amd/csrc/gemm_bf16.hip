@@ -960,7 +960,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
         //      columns 4 hi .. 4 hi + 3 of every 16-column block
         const GemmGroup gp = pick_group(p, grp);
         float* Cg = SPLIT ? p.partial + ((size_t)(grp * (int)gridDim.y + slice) * p.M) * p.ldc : gp.C;
-        const int row0 = tile_m * BM + wm * WTM + (lane & 15), col0 = tile_n * BN + wn * WTN + 4 * hi;
         constexpr int TNH = 2;                               // 16-column blocks per burst (TM x 2 loads in flight per lane)
         // Addressing: ONE 32-bit element offset per lane from the matrix start (the rows of every matrix span < 4 GB) plus
         // compile-time constants and wave-uniform strides; bounds as three lane predicates per pair of blocks; flag tests
@@ -1380,9 +1379,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(const GemmParams p) {
     for (int j = 0; j < 4; ++j)
         amask[j] = ((8 * hi + 2 * j < ktail) ? 0x0000FFFFu : 0u) | ((8 * hi + 2 * j + 1 < ktail) ? 0xFFFF0000u : 0u);
 
-    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-    typedef short s16x8 __attribute__((ext_vector_type(8)));
-    typedef __attribute__((address_space(3))) bf16x8 lds_bf16x8;
     f32x4 acc[TM][TN];                                             // AGPRs; written by the asm MFMAs only (first K-step: C = 0)
 
     // own pieces of stage s + 1 landed?  (called between the halves of step s, BEFORE the A pieces of stage s + 3 go out: the
