@@ -285,10 +285,11 @@ static int gemm_pp_try_impl(const GemmArgs* gs, int n, const GemmArgs& g, int ks
         // (several weight gradients in one launch only when each alone has too few tiles to split well: three 1000 x 500
         //  162 -> 89 us, but three 2000 x 1000 332 against 3 x 97)
         const int64_t per_group_tiles = (int64_t)cdiv(g.M, cands[best].bm) * cdiv(g.N, cands[best].bn);
-        // (... or when the joint launch still fills the device: three 1200 x 2000 take 359 us grouped with 2 slabs each
-        //  against 3 x 120 with 6 slabs each -- the same GEMM time and a third of the reduce traffic)
+        // (... or when the joint launch still fills three quarters of the device: three 1200 x 2000 take 359 us grouped with 2
+        //  slabs each against 3 x 120 with 6 slabs each -- the same GEMM time and a third of the reduce traffic; three
+        //  2000 x 1000 (192 workgroups, 2 slabs) 223 us against 3 x 72 with 8 slabs: 0.015 ms less per step with the reduce)
         const bool wgrad = splits > 1 && (int64_t)g.M * g.N * n >= 400000 &&
-                           (n == 1 || per_group_tiles <= 16 || per_group_tiles * n * splits * 10 >= (int64_t)cus * 9);
+                           (n == 1 || per_group_tiles <= 16 || per_group_tiles * n * splits * 4 >= (int64_t)cus * 3);
         // (accumulate: the epilogue would read C back -- bf16 mode leaves those to the register-staged kernel; over planes the
         //  alternative is a split pass per operand, so the ping-pong kernel takes them)
         static const double fill_env = getenv("ADN_GEMM_PP_FILL") ? atof(getenv("ADN_GEMM_PP_FILL")) : 0.0;
