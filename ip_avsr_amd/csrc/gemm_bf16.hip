@@ -571,8 +571,8 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams pi
 // lock-step (in-kernel stamps of the lock-step predecessor: 45 % of a K-step in reads + MFMA, 23 % DMA issue, 32 % waits;
 // MFMA pipe 29 % busy).  (Round 2's first version separated L and C by a barrier each -- waves 0-3: L | C | L | C, waves 4-7
 // one barrier behind: a K-step then costs 2 max(L, C) + two barriers, and L is the longer segment; with one barrier it is
-// L + C + one barrier: 7 - 16 % faster on every shape, profiles/r02/pp_one_barrier.txt; ADN_GEMM_PP_BARRIERS=2 selects the
-// old schedule.)
+// L + C + one barrier: 7 - 16 % faster on every shape, profiles/r02/pp_one_barrier.txt; the old schedule was removed
+// in round 3; GemmParams::one_barrier stays set.)
 //
 // LDS hazards are settled by counted waits and the barrier sequence alone (interval s = between barrier #s-1 and #s):
 //   RAW  stage s + 1 is first read in interval s + 1.  Every wave waits for ITS pieces of stage s + 1 (s_waitcnt vmcnt(N),

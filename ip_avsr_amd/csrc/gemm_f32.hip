@@ -305,8 +305,7 @@ static int gemm_pp_try_impl(const GemmArgs* gs, int n, const GemmArgs& g, int ks
     std::memset(static_cast<void*>(&p), 0, sizeof(p));
     p.M = g.M; p.N = g.N; p.K = g.K; p.lda = g.lda; p.ldb = g.ldb; p.ldc = g.ldc; p.ldy = g.ldy;
     p.act = g.act; p.act_grad = g.act_grad; p.accumulate = g.accumulate;
-    static const int barriers_env = getenv("ADN_GEMM_PP_BARRIERS") ? atoi(getenv("ADN_GEMM_PP_BARRIERS")) : 1;   // 2: the two-barrier schedule
-    p.one_barrier = barriers_env != 2;
+    p.one_barrier = 1;
     p.kseg = kseg; p.kreal = gs[0].K;
     p.tiles_m = cdiv(g.M, cd.bm); p.tiles_n = cdiv(g.N, cd.bn);
     p.k_chunk = (int)round_up(cdiv(g.K, splits), 32);
