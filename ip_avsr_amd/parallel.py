@@ -156,22 +156,38 @@ class DataParallel(object):
             # stream waits for THAT one, updates all those buckets with one launch while the last group is still on the wire,
             # then waits for the last reduction and updates its buckets: two cross-stream waits and two update launches per step
             # (one wait + update per bucket measured 0.1 ms more per step on one GPU: every wait is a bubble on the compute stream).
-            if ranged:
-                self.model.adam_begin(learning_rate)
             n_l = len(self.launches)
             phases = [list(range(n_l))] if n_l < 2 else [list(range(n_l - 1)), [n_l - 1]]
-            for phase in phases:
-                works[phase[-1]].wait()
+            if ranged:
+                self.model.adam_begin(learning_rate)
+            try:
+                for phase in phases:
+                    # every work of the phase is waited on: RCCL completes in order on its one stream (the waits on the earlier
+                    # works are then free), but gloo runs works on several threads and may finish k ahead of k - 1
+                    for li in phase:
+                        works[li].wait()
+                    if ranged:
+                        ranges = [self.buckets[k] for li in phase for k in self.launches[li]]
+                        if hasattr(self.model, "adam_ranges"):
+                            self.model.adam_ranges(ranges)
+                        else:
+                            for b, e in ranges:
+                                self.model.adam_range(b, e)
+            except BaseException:
+                # a failed wait / update must not leave the ranged step open (every later step would be refused) nor the
+                # collectives unobserved: drain what is outstanding, roll the step counter back, then re-raise
+                for w in works:
+                    try:
+                        w.wait()
+                    except Exception:
+                        pass
                 if ranged:
-                    ranges = [self.buckets[k] for li in phase for k in self.launches[li]]
-                    if hasattr(self.model, "adam_ranges"):
-                        self.model.adam_ranges(ranges)
-                    else:
-                        for b, e in ranges:
-                            self.model.adam_range(b, e)
-            if self.on_device:
-                self._torch.cuda.current_stream().wait_stream(self.comm_stream)
-            self._inflight = False
+                    self._abort_ranged_step()
+                raise
+            finally:
+                if self.on_device:
+                    self._torch.cuda.current_stream().wait_stream(self.comm_stream)
+                self._inflight = False
             if ranged:
                 self.model.adam_end()
         elif self.world_size > 1:
@@ -186,6 +202,15 @@ class DataParallel(object):
         if want_loss:
             return float(self.grad[-8].item())
         return None
+
+    def _abort_ranged_step(self):
+        """Closes a ranged Adam step that failed half-way and takes its increment of the step counter back."""
+        try:
+            t = self.model.adam_step_count()
+            self.model.adam_end()
+            self.model.set_adam_step_count(max(0, t - 1))
+        except Exception:
+            pass
 
     def _reduce(self, ranges):
         """Sum over the ranks of the given ranges of the gradient buffer as one (grouped) asynchronous collective."""
@@ -210,7 +235,7 @@ class DataParallel(object):
                     w.wait()
         return _All()
 
-    def sync_running_statistics(self):
+    def sync_running_statistics(self, force=False):
         """BatchNorm running statistics (adenet_v1 / v1_1: ``streamK.bn.mean`` / ``.bn.inv_std``) are updated from each
         rank's LOCAL shard and carry no gradient, so the all-reduce never touches them and the replicas' copies drift
         apart.  This averages them over the ranks (the batch statistics themselves stay per-shard, like any
@@ -219,6 +244,12 @@ class DataParallel(object):
         names = self.model.running_statistic_names() if hasattr(self.model, "running_statistic_names") else []
         if not names or self.world_size == 1:
             return 0
+        # once per training state, not per evaluation call: each set_param marks the parameters dirty (the bf16 copies / planes
+        # are repacked) and the average costs a host round trip; nothing changes the statistics between two optimiser steps
+        stamp = self.model.adam_step_count() if hasattr(self.model, "adam_step_count") else None
+        if not force and stamp is not None and stamp == getattr(self, "_stats_synced_at", None):
+            return 0
+        self._stats_synced_at = stamp
         import torch
         vals = [np.asarray(self.model.get_param(n), np.float32).reshape(-1) for n in names]
         flat = torch.as_tensor(np.concatenate(vals), device=self.grad.device)

@@ -665,8 +665,7 @@ def _plan_avletters_bimodal(cfg, config, options):
                 has_test=False, conf_fmt='pipe', plot_name='e2e_valid_cost', adasum_at_end=True,
                 final='classification rate: {best_cr}, validation loss: {best_val}',
                 adadelta_progress='Epoch {e} batch {i}/{n}: {b} examples at learning rate = {lr:.4f}')
-    _rule_plan(cfg, plan)
-    plan.decay = False                               # avletters/bimodal.py has the t1 rule only
+    _rule_plan(cfg, plan)                            # t1 rule AND the per-epoch decay (avletters/bimodal.py:541-555)
     _hyper(cfg, plan, None, 20, 26, None)
 
     def results(f, st):                              # avletters/bimodal.py:592-606

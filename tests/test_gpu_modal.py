@@ -287,6 +287,12 @@ def test_schema2_training_follows_the_oracle_update_rules(tmp_path, monkeypatch)
     for extra in (["--update_rule", "sgdm"], ["--update_rule", "sgdnm"], ["--update_rule", "adadelta", "--learning_rate", "1.0"]):
         out, rec, worst = _run_and_replay(monkeypatch, lambda: bimodal.main(["--config", bi, "--seed", "1", "--no_plot"] + extra), 2e-4)
         assert {c["rule"] for c in rec["calls"]} == {extra[1]}
+        if extra[1] == "adadelta":
+            # avletters/bimodal.py:552-555 decays the rate of EVERY update rule from decay_start (= 3) on, behind the t1 rule
+            # (which touches sgdm / sgdnm only): 1.0 -> 0.8 -> 0.64 ... (the driver had dropped this decay)
+            n = len(out["cost_val"])
+            assert n >= 4 and any(abs(out["learning_rate"] - 0.8 ** k) < 1e-5 for k in (n - 2, n - 3)), (n, out["learning_rate"])
+            assert {round(c["lr"], 4) for c in rec["calls"]} >= {1.0, 0.8}
         out["network"].close()
     out, rec, worst = _run_and_replay(monkeypatch, lambda: trimodal_with_val.main(
         ["--config", MF.make_oulu(os.path.join(root, "o")), "--seed", "5", "--no_plot"]), 5e-4)
