@@ -46,7 +46,7 @@ B_PER_GPU, T_MAX, THETA, H, C, D = 520, 40, 9, 250, 26, 1200
 B_PER_GPU = int(os.environ.get("ADN_BENCH_B", B_PER_GPU))      # (profiling aid for profiles/scripts/timeline.sh: the judged workload is 520)
 ENC = (2000, 1000, 500, 50)
 LR = 1e-3
-PROFILE_ROUND = "r03"      # profiles/<round>/pmc_traffic_<precision>.json feeds roofline.traffic
+PROFILE_ROUNDS = ("r04", "r03")      # profiles/<round>/pmc_traffic_<precision>.json feeds roofline.traffic (newest round that has one)
 PREWARM_STEPS = 20         # untimed steps ahead of the warm-up (see run(): idle clocks after the host-side setup)
 
 
@@ -91,6 +91,56 @@ def synthetic_batch(torch, rank, B, device):
         x = (x - x.mean(-1, keepdim=True)) / x.std(-1, unbiased=False, keepdim=True)
         xs.append((x * m_d[..., None]).contiguous())
     return xs, torch.tensor(y, device=device), m_d, mask
+
+
+def synthetic_splits(torch, device, sizes=(("train", 520), ("val", 260), ("test", 260)), seed=77):
+    """The AVLetters-shaped dataset of SURVEY 8d as the epoch drivers take it: per split three (sum of lengths, 1200) frame
+    matrices (per-frame z-normalised Gaussian frames, generated in HBM), per-frame labels, utterance lengths ~ UniformInt[12, 40]
+    with one utterance at 40 per split."""
+    rng = np.random.RandomState(seed)
+    gen = torch.Generator(device=device).manual_seed(seed)
+    split, ys, lens = {}, {}, {}
+    for name, n in sizes:
+        ln = rng.randint(12, T_MAX + 1, size=n); ln[0] = T_MAX
+        total = int(ln.sum())
+        xs = []
+        for _ in range(3):
+            x = torch.randn(total, D, device=device, generator=gen)
+            xs.append(((x - x.mean(-1, keepdim=True)) / x.std(-1, unbiased=False, keepdim=True)).contiguous())
+        split[name], lens[name] = xs, ln
+        ys[name] = np.repeat(np.arange(n) % C, ln)
+    return split, ys, lens
+
+
+def runner_measurements(torch, model, device, steps):
+    """The headline workload through the PRODUCT entry point: ip_avsr_amd/runners/nstream.py's epoch loop (``fit``) on splits
+    resident in HBM, minibatches assembled by adn_batch_gather.  (a) the AVLetters epoch of the reference scripts -- 20
+    minibatches of 26 utterances, the train cost of the last one, the validation cost and the majority-vote evaluation of the
+    260 held-out utterances (+ the test split's when the validation cost improved), runners/3stream.py:357-405; (b) the
+    whole-train batch (B = 520) as the runner steps it: ms per step of the minibatch loop, to set beside ``ms_per_step``."""
+    from ip_avsr_amd.runners import nstream
+    split, ys, lens = synthetic_splits(torch, device)
+    quiet = lambda *a, **k: None
+    saved_t, saved = model.adam_step_count(), model.snapshot_params()
+    kw = dict(windowsize=THETA, validation_window=1000, learning_rate=LR, say=quiet, progress=False)
+    st = nstream.fit(model, split, ys, lens, 3, num_epoch=7, epochsize=20, batchsize=26, **kw)
+    big = nstream.fit(model, split, ys, lens, 3, num_epoch=4, epochsize=steps, batchsize=B_PER_GPU, **kw)
+    model.restore_params(saved); model.set_adam_step_count(saved_t)
+    ep, tr = st["epoch_seconds"][2:], st["train_seconds"][2:]
+    return {"epoch_s": float(np.median(ep)), "epoch_s_min": float(min(ep)), "epoch_train_loop_s": float(np.median(tr)),
+            "epoch": "20 x 26 utterances + train cost + validation cost + vote on 260 (+ test 260 on improvement), through "
+                     "runners/nstream.fit, splits resident in HBM (%s), median of %d epochs" % (nstream.resident_dtype(model), len(ep)),
+            "step_ms_B520": 1e3 * float(np.median(big["train_seconds"][1:])) / steps,
+            "step_B520": "the runner's minibatch loop at batchsize 520: median of %d epochs of %d steps, gather included"
+                         % (len(big["train_seconds"]) - 1, steps)}
+
+
+def traffic_file(precision):
+    for rnd in PROFILE_ROUNDS:
+        f = os.path.join(ROOT, "profiles", rnd, "pmc_traffic_%s.json" % precision)
+        if os.path.exists(f):
+            return f
+    return os.path.join(ROOT, "profiles", PROFILE_ROUNDS[0], "pmc_traffic_%s.json" % precision)
 
 
 def lstm_traffic(d, algorithmic_bytes_per_train_step, unit_bytes):
@@ -201,6 +251,7 @@ def parse_args(argv=None):
     ap.add_argument("--fp32-inputs", action="store_true",
                     help="bf16 mode: keep the resident batch in float32 (the library then converts it every step) instead of bfloat16")
     ap.add_argument("--no-reference-minibatch", action="store_true", help="skip the B=26 sub-run")
+    ap.add_argument("--no-runner", action="store_true", help="skip the epoch / step measurements through runners/nstream.fit")
     ap.add_argument("--only-train-steps", action="store_true",
                     help="counter passes (profiles/collect.sh): run NOTHING but warmup + steps train steps of the B=520 workload "
                          "-- no pre-warm, no evaluation epoch, no copy yardstick, no accurate / B=26 sub-runs, no CPU baseline -- "
@@ -268,6 +319,7 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
     only = bool(getattr(args, "only_train_steps", False))
     if only:
         args.no_profile = True; args.no_cpu_baseline = True; args.accurate_precision = "none"; args.no_reference_minibatch = True
+        args.no_runner = True
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -422,8 +474,20 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
             hbm = measured_hbm_gbs(torch, device)
             out["hbm_copy_measured_GBs"] = hbm
         if prof:
-            tfile = os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_traffic_%s.json" % args.precision)
-            out.update(rooflines(prof, args.steps, prof_elapsed, args.precision, hbm, tfile))
+            out.update(rooflines(prof, args.steps, prof_elapsed, args.precision, hbm, traffic_file(args.precision)))
+        if on_gpu and world == 1 and xs is not xs32:
+            # the like-for-like figure against rounds 1-2 and against the f32 / bf16x3 rows: the SAME bf16 arithmetic fed with
+            # the float32 frames the reference's theano functions take (the library converts them every step)
+            xs16, xs = xs, xs32
+            for _ in range(3):
+                step()
+            t_f = timed(args.steps)
+            out["fp32_inputs"] = {"ms_per_step": 1e3 * t_f / args.steps, "value": B_PER_GPU * args.steps / t_f, "unit": "sequences/s",
+                                  "dtype": args.precision, "inputs": "float32, resident in HBM"}
+            xs = xs16
+        if on_gpu and world == 1 and not getattr(args, "no_runner", False):
+            out["runner"] = runner_measurements(torch, model, device, args.steps)
+            out["epoch_via_runner_s"] = out["runner"]["epoch_s"]
         # ---- the fp32-accurate mode, same workload, same process (the mode the 1e-4 / exact-top-1 parity tests run in)
         acc_modes = {"both": ["bf16x3", "f32"], "none": []}.get(args.accurate_precision, [args.accurate_precision])
         for prec in (acc_modes if on_gpu and world == 1 else []):
@@ -442,8 +506,7 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
             if profile:
                 model.profile(True)
                 pe = timed(k)
-                acc.update(rooflines(model.profile_read(), k, pe, prec, hbm,
-                                     os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_traffic_%s.json" % prec)))
+                acc.update(rooflines(model.profile_read(), k, pe, prec, hbm, traffic_file(prec)))
                 model.profile(False)
             out["accurate" if prec == "bf16x3" else "accurate_" + prec] = acc
             model.set_precision(args.precision)

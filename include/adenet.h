@@ -321,6 +321,28 @@ int adn_prep_gather_columns(const float* in, int ld_in, float* out, int ld_out, 
 int adn_prep_lcn(const float* x, float* y, int n_images, int H, int W, const float* filter_host, int ksize, float threshold,
                  void* hip_stream);
 
+/* ---- minibatch assembly on the GPU (reference utils/datagen.py:92-153,219-229) --------------
+ * The splits stay resident in HBM (one frame matrix [sum of lengths][width] per stream, float32 or bfloat16, row-major,
+ * contiguous); ONE launch builds what gen_lstm_batch_random + gen_seq_batch_from_idx + the runner's label repeat
+ * (runners/3stream.py:360-361) build on the host for one minibatch:
+ *   out_s[i, :l]  = frames_s[offsets[u] : offsets[u] + l],  out_s[i, l:] = 0     (u = idxs[i], l = lens[u])
+ *   mask[i, :l]   = 1, mask[i, l:] = 0                                           (uint8)
+ *   y[i]          = uint8(frame_labels[offsets[u]])                              (datagen.py:130,142: a uint8 array)
+ *   targets[i, :] = y[i]                                                         (int32, repeated over all T frames)
+ * T is the caller's padding length (the split-wide maximum in the reference, datagen.py:104).  Which utterances form the
+ * batch -- the np.random permutation stream, the short last batch and the reshuffle of datagen.py:117-152 -- stays on the
+ * host (ip_avsr_amd/utils/datagen_gpu.py); a data-parallel rank passes only its own idxs[rank::world].  All pointers but
+ * `streams` are device memory; mask / targets / y may be null.  An index outside [0, n_utt) yields an empty row. */
+typedef struct {
+    const void* frames;  /* device: the split's frame matrix of this stream */
+    int32_t width;       /* features per frame */
+    int32_t elem_bytes;  /* 4 = float32, 2 = bfloat16 (what ADN_FLAG_BF16_INPUTS takes) */
+    void* out;           /* device: (B, T, width), same element type */
+} adn_batch_stream;
+int adn_batch_gather(const adn_batch_stream* streams, int n_streams, const int64_t* offsets, const int32_t* lens,
+                     const int32_t* frame_labels, int n_utt, const int32_t* idxs, int B, int T, uint8_t* mask, int32_t* targets,
+                     uint8_t* y, void* hip_stream);
+
 /* ---- convolutional auto-encoder (reference modelzoo/avletters_convae.py:33-69) ---------------------
  * conv 5x5 (100) - maxpool 2 - conv 5x5 (150) - maxpool 2 pad (1,0) - conv 3x3 (200) - dense - bottleneck, and the
  * tied-weight decoder (transposed dense layers, Deconv2DLayer on the encoder's filters, Upscale2DLayer); ScaledTanh

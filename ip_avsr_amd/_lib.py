@@ -14,7 +14,7 @@ ADN_MAX_STREAMS = 8
 ADN_MAX_ENC_LAYERS = 8
 ADN_MAX_CLASSES = 64
 
-ADN_OK = 0
+ADN_OK, ADN_ERR_INVALID, ADN_ERR_HIP, ADN_ERR_NO_DEVICE, ADN_ERR_STATE = 0, 1, 2, 3, 4     # enum adn_status
 ACT = {"linear": 0, "identity": 0, "rectify": 1, "sigmoid": 2, "tanh": 3, "leaky_rectify": 4,
        "very_leaky_rectify": 5, "scaled_tanh": 6, "scaled_tanh_lecun": 7}
 FUSION = {"none": 0, "sum": 1, "adasum": 2, "concat": 3}
@@ -56,6 +56,10 @@ class RbmConfig(C.Structure):
 
 class ParamInfo(C.Structure):
     _fields_ = [("name", C.c_char * 96), ("ndim", C.c_int32), ("dims", C.c_int64 * 2), ("numel", C.c_int64)]
+
+
+class BatchStream(C.Structure):
+    _fields_ = [("frames", C.c_void_p), ("width", C.c_int32), ("elem_bytes", C.c_int32), ("out", C.c_void_p)]
 
 
 class ProfileEntry(C.Structure):
@@ -149,6 +153,7 @@ _SIGNATURES = {
     "adn_prep_apply_column_norm": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "adn_prep_gather_columns": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, _P]),
     "adn_prep_lcn": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_float, _P]),
+    "adn_batch_gather": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
 

@@ -139,6 +139,7 @@ class AdeNetModel(object):
     def set_precision(self, precision):
         """'f32' (exact, parity-grade) or 'bf16' (GEMM operands rounded to bf16 in flight, fp32 accumulate)."""
         _lib.check(self._lib.adn_set_precision(self._handle, _lib.PRECISION[precision]))
+        self.spec["precision"] = precision
 
     def synchronize(self):
         _lib.check(self._lib.adn_synchronize(self._handle))
@@ -245,6 +246,28 @@ class AdeNetModel(object):
             self._write(_lib.BUF_ADAM_M, p.index, m)
             self._write(_lib.BUF_ADAM_V, p.index, v)
 
+    def snapshot_params(self):
+        """The current parameters as ONE device-side copy of the flat buffer (72 MB for the 3-stream model: microseconds in
+        HBM, against a per-tensor download for ``get_all_param_values``): what the epoch drivers keep as "best parameters so
+        far" (runners/3stream.py:393) -- only a run that saves its best model ever needs them on the host."""
+        import torch
+        from .parallel import wrap_flat_buffer
+        self.synchronize()
+        snap = wrap_flat_buffer(self, _lib.BUF_PARAM).clone()
+        torch.cuda.current_stream().synchronize()
+        return snap
+
+    def restore_params(self, snapshot):
+        """Writes a ``snapshot_params`` copy back (the bf16 copies / planes are re-derived on the next use)."""
+        import torch
+        from .parallel import wrap_flat_buffer
+        self.synchronize()
+        flat = wrap_flat_buffer(self, _lib.BUF_PARAM)          # (adn_flat_buffer marks the parameters as written)
+        if flat.numel() != snapshot.numel():
+            raise ValueError("mismatch: the snapshot belongs to another model")
+        flat.copy_(snapshot)
+        torch.cuda.current_stream().synchronize()
+
     def count_params(self):
         return int(self._lib.adn_total_param_count(self._handle))
 
@@ -343,6 +366,8 @@ class AdeNetModel(object):
         def small(a, np_dtype, torch_name):
             if dev:
                 import torch
+                if getattr(a, "dev", None) is not None:        # utils/datagen_gpu.Resident: the HBM copy is at hand
+                    a = a.dev
                 if not self._is_device(a):
                     a = torch.as_tensor(np.ascontiguousarray(a, dtype=np_dtype), device=keep[0].device)
                 a = a.to(getattr(torch, torch_name)).contiguous()

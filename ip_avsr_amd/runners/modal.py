@@ -180,11 +180,12 @@ class Updater(object):
         self.network, self.rule = network, rule
         self.lr, self.mm = float(learning_rate), float(momentum)
 
-    def __call__(self, inputs, targets, mask, window):
+    def __call__(self, inputs, targets, mask, window, want_loss=False):
+        """(the loops discard the cost ``train`` returns -- avletters/bimodal.py:515 -- so it is not waited for by default)"""
         net = self.network
         if self.rule == 'adam':                 # las.updates.adam(cost, all_params): DEFAULT parameters, lr is not passed
-            return net.train_step(inputs, targets, mask, window, 1e-3)
-        cost = net.compute_grads(inputs, targets, mask, window)
+            return net.train_step(inputs, targets, mask, window, 1e-3, want_loss=want_loss)
+        cost = net.compute_grads(inputs, targets, mask, window, want_loss=want_loss)
         if self.rule == 'adadelta':
             net.apply_adadelta(self.lr)
         else:                                   # sgd + apply_momentum / apply_nesterov_momentum
@@ -473,7 +474,7 @@ def _series(f, st):
 def _adam_plan(cfg, network, learning_rate, **kw):
     plan = Plan(network=network, rule='adam', **kw)
     plan.update = Updater(network, 'adam', learning_rate)     # (carries lr for the progress line)
-    plan.train = lambda ins, y, m, w: network.train_step(ins, y, m, w, learning_rate)   # adam(cost, params, learning_rate)
+    plan.train = lambda ins, y, m, w: network.train_step(ins, y, m, w, learning_rate, want_loss=False)   # adam(cost, params, learning_rate)
     return plan
 
 
@@ -831,34 +832,57 @@ def _main(dataset, script, argv=None):
     best_val, best_tr, best_cr, best_conf, test_cr, test_conf, adascale_param = float('inf'), float('inf'), 0.0, None, None, None, None
     best_params = None
     tr_lens = np.asarray(lens['train'], int)
-    tmax_train = int(np.max(tr_lens))
-    datagen = gen_lstm_batch_random(split['train'][0], ys['train'], tr_lens, batchsize=batchsize)
-    integral_lens = compute_integral_len(tr_lens)
-
-    def whole_split(k):
-        ln = np.asarray(lens[k], int)
-        X1, y, m, idxs = next(gen_lstm_batch_random(split[k][0], ys[k], ln, batchsize=len(ln)))
-        il = compute_integral_len(ln)
-        return [X1] + [gen_seq_batch_from_idx(split[k][s], idxs, ln, il, np.max(ln)) for s in range(1, n_streams)], y, m
+    # Minibatches are assembled on the GPU from splits resident in HBM (utils/datagen_gpu.py: same utterance order, padding and
+    # label conventions as gen_lstm_batch_random / gen_seq_batch_from_idx); ADN_HOST_BATCHES=1 selects the reference's host-side
+    # assembly with an upload per batch (A/B runs, the equality test between the two)
+    host_batches = bool(os.environ.get('ADN_HOST_BATCHES'))
 
     def targets_of(y, m):                            # per-frame targets for the temporal loss; the last-step head takes (B,)
         y = np.asarray(y).reshape((-1, 1)).repeat(m.shape[-1], axis=-1)
         return y
 
-    X_val, y_val_evaluate, mask_val = whole_split('val')
-    y_val = targets_of(y_val_evaluate, mask_val)
+    if host_batches:
+        tmax_train = int(np.max(tr_lens))
+        datagen = gen_lstm_batch_random(split['train'][0], ys['train'], tr_lens, batchsize=batchsize)
+        integral_lens = compute_integral_len(tr_lens)
+
+        def whole_split(k):
+            ln = np.asarray(lens[k], int)
+            X1, y, m, idxs = next(gen_lstm_batch_random(split[k][0], ys[k], ln, batchsize=len(ln)))
+            il = compute_integral_len(ln)
+            return ([X1] + [gen_seq_batch_from_idx(split[k][s], idxs, ln, il, np.max(ln)) for s in range(1, n_streams)], y, m,
+                    targets_of(y, m))
+    else:
+        from ..utils.datagen_gpu import DeviceSplit
+        from .nstream import resident_dtype
+        dtype = resident_dtype(network)
+        resident = {}
+        for k in ('train', 'val') + (('test',) if has_test else ()):
+            same = [j for j in resident if split[j] is split[k] and lens[j] is lens[k]]     # (avletters: 'val' IS the test split)
+            resident[k] = resident[same[0]] if same else DeviceSplit(split[k], ys[k], np.asarray(lens[k], int), dtype=dtype)
+        datagen = resident['train'].batches(batchsize, prefetch=not os.environ.get('ADN_NO_PREFETCH'))
+
+        def whole_split(k):
+            b = resident[k].whole()
+            return b.Xs, b.y, b.mask, b.targets
+
+    X_val, y_val_evaluate, mask_val, y_val = whole_split('val')
     if has_test:
-        X_test, y_test, mask_test = whole_split('test')
+        X_test, y_test, mask_test, _ = whole_split('test')
     stop = (lambda w, best: early_stop(w)) if plan.stop == 'early_stop' else (lambda w, best: early_stop2(w, best, validation_window))
 
     for epoch in range(num_epoch):
         time_start = time.time()
         for i in range(epochsize):
-            X1, y, m, batch_idxs = next(datagen)
-            yy = targets_of(y, m)
-            Xs = [X1] + [gen_seq_batch_from_idx(split['train'][s], batch_idxs, tr_lens, integral_lens, tmax_train)
-                         for s in range(1, n_streams)]
-            print(plan.progress.format(e=epoch + 1, i=i + 1, n=epochsize, b=len(X1), lr=update.lr, mm=update.mm, rule=rule), end='')
+            if host_batches:
+                X1, y, m, batch_idxs = next(datagen)
+                yy = targets_of(y, m)
+                Xs = [X1] + [gen_seq_batch_from_idx(split['train'][s], batch_idxs, tr_lens, integral_lens, tmax_train)
+                             for s in range(1, n_streams)]
+            else:
+                batch = next(datagen)
+                Xs, yy, m = batch.Xs, batch.targets, batch.mask
+            print(plan.progress.format(e=epoch + 1, i=i + 1, n=epochsize, b=len(m), lr=update.lr, mm=update.mm, rule=rule), end='')
             sys.stdout.flush()
             train(Xs, yy, m, WINDOW_SIZE)
             print('\r', end='')
@@ -884,7 +908,7 @@ def _main(dataset, script, argv=None):
                 print("Epoch {} train cost = {}, val cost = {}, GL loss = {:.3f}, GQ = {:.3f}, CR = {:.3f}, Test CR= {:.3f} "
                       "({:.1f}sec)".format(epoch + 1, cost_train[-1], cost_val[-1], gl, pq, cr, test_cr, time.time() - time_start))
                 if getattr(plan, 'save_best', None):
-                    best_params = network.get_all_param_values()
+                    best_params = network.snapshot_params()      # (a device copy; fetched only when the model is saved)
             else:
                 print("Epoch {} train cost = {}, val cost = {}, GL loss = {:.3f}, GQ = {:.3f}, CR = {:.3f} ({:.1f}sec)"
                       .format(epoch + 1, cost_train[-1], cost_val[-1], gl, pq, cr, time.time() - time_start))
@@ -928,7 +952,7 @@ def _main(dataset, script, argv=None):
     if getattr(plan, 'save_best', None) and best_params is not None:      # cuave/unimodal_with_val.py:364-368
         from ..utils.io import save_model_params
         print('Saving the best model so far...')
-        network.set_all_param_values(best_params)
+        network.restore_params(best_params)
         save_model_params(network, plan.save_best)
         print('Model Saved!')
     st.update(network=network, learning_rate=update.lr, momentum=update.mm)

@@ -168,6 +168,169 @@ def build_network(n_streams, aes, dims, lstm_weights, cfg):
     raise ValueError('1 to 4 streams are supported')
 
 
+def resident_dtype(network):
+    """Element type of the HBM-resident splits: bfloat16 when the model computes in bf16 and every stream enters through an
+    encoder GEMM (which rounds its input to bfloat16 anyway: identical results, half the bytes, ADN_FLAG_BF16_INPUTS);
+    float32 otherwise (an encoder-less stream feeds the delta layer / LSTM projection in fp32)."""
+    spec = network.spec
+    if spec.get('precision') == 'bf16' and all(s.get('enc_shapes') and not s.get('aux_dim') for s in spec['streams']) \
+            and not getattr(network, '_front', None) and not os.environ.get('ADN_FP32_RESIDENT'):
+        return 'bfloat16'
+    return 'float32'
+
+
+def fit(network, split, ys, lens, n_streams, windowsize, num_epoch, epochsize, batchsize, validation_window, learning_rate,
+        options=None, say=print, rank=0, world=1, dp=None, lr_map=None, host_batches=None, prefetch=None, progress=True):
+    """The epoch loop of reference runners/3stream.py:322-427 (identical in 1/2/4stream.py) on splits that stay resident in
+    HBM: ``split[k]`` = list of (sum of lengths, D_s) frame matrices for k in train / val / test, ``ys[k]`` per-frame labels,
+    ``lens[k]`` utterance lengths.  Minibatches are assembled on the GPU by index (utils/datagen_gpu.py; same utterance
+    order, padding and label conventions as gen_lstm_batch_random / gen_seq_batch_from_idx), the held-out batches are built
+    once and stay resident, and ``train`` does not wait for its cost (the reference discards it, runners/3stream.py:370), so
+    the host runs ahead of the device inside an epoch.  ``host_batches`` (or ADN_HOST_BATCHES=1): the reference's host-side
+    assembly instead, every batch uploaded -- the slow path, kept for A/B runs and for the bit-equality test between the two.
+    Returns the statistics dict of the run (incl. ``epoch_seconds``)."""
+    options = options or {}
+    if host_batches is None:
+        host_batches = bool(os.environ.get('ADN_HOST_BATCHES'))
+    if prefetch is None:
+        prefetch = not os.environ.get('ADN_NO_PREFETCH')
+    order = 'in1,targets,mask,in2,window' if n_streams == 2 else 'inputs,targets,mask,window'
+    train, compute_train_cost, compute_test_cost, val_fn = network.compile(learning_rate, order)
+
+    def call(fn, Xs, *rest):                        # the 2-stream runner interleaves its arguments
+        if n_streams == 2:
+            if len(rest) == 3:
+                return fn(Xs[0], rest[0], rest[1], Xs[1], rest[2])
+            return fn(Xs[0], rest[0], Xs[1], rest[1])
+        return fn(*(list(Xs) + list(rest)))
+
+    def eval_fn(*args):                             # evaluate_model2 passes inputs..., mask, window
+        if dp is not None:                          # held-out utterances split over the ranks, predictions gathered
+            return dp.predict_sharded(network.predict, list(args[:n_streams]), args[n_streams], args[n_streams + 1])
+        return call(val_fn, list(args[:n_streams]), *args[n_streams:])
+
+    def heldout_cost(Xs_, y_, m_):                  # compute_test_cost of a whole split
+        if dp is not None:
+            return dp.loss_sharded(network.loss, Xs_, y_, m_, windowsize,
+                                   weights=None if network.head == "frames" else np.ones(len(m_)))
+        return float(call(compute_test_cost, Xs_, y_, m_, windowsize))
+
+    say('begin training...')
+    cost_train, cost_val, class_rate, epoch_seconds, train_seconds = [], [], [], [], []
+    STRIP_SIZE = 3
+    val_window = circular_list(validation_window)
+    train_strip = np.zeros((STRIP_SIZE,))
+    best_val, best_cr, test_cr, test_conf, best_params = float('inf'), 0.0, 0.0, None, None
+
+    tr_lens = lens['train']
+    if host_batches:
+        tmax_train = int(np.max(tr_lens))
+        datagen = gen_lstm_batch_random(split['train'][0], ys['train'], tr_lens, batchsize=batchsize)
+        integral_lens = compute_integral_len(tr_lens)
+
+        def whole_split(k):
+            gen = gen_lstm_batch_random(split[k][0], ys[k], lens[k], batchsize=len(lens[k]))
+            X1, y, m, idxs = next(gen)
+            il = compute_integral_len(lens[k])
+            Xs = [X1] + [gen_seq_batch_from_idx(split[k][s], idxs, lens[k], il, np.max(lens[k]))
+                         for s in range(1, n_streams)]
+            return Xs, y, m, y.reshape((-1, 1)).repeat(m.shape[-1], axis=-1)
+    else:
+        from ..utils.datagen_gpu import DeviceSplit
+        dtype = resident_dtype(network)
+        resident = {k: DeviceSplit(split[k], ys[k], lens[k], dtype=dtype) for k in ('train', 'val', 'test')}
+        # (one stream of batches per rank: a rank gathers only its own rows of every global minibatch)
+        datagen = resident['train'].batches(batchsize, rank=rank if dp is not None else 0, world=world if dp is not None else 1,
+                                            prefetch=prefetch)
+
+        def whole_split(k):
+            b = resident[k].whole()
+            return b.Xs, b.y, b.mask, b.targets
+
+    X_val, y_val_evaluate, mask_val, y_val = whole_split('val')
+    X_test, y_test, mask_test, _ = whole_split('test')
+
+    for epoch in range(num_epoch):
+        time_start = time.time()
+        for i in range(epochsize):
+            if host_batches:
+                X1, y, m, batch_idxs = next(datagen)
+                y = y.reshape((-1, 1)).repeat(m.shape[-1], axis=-1)
+                Xs = [X1] + [gen_seq_batch_from_idx(split['train'][s], batch_idxs, tr_lens, integral_lens, tmax_train)
+                             for s in range(1, n_streams)]
+                n_examples, total_frames = len(X1), float(m.sum())
+                if dp is not None:
+                    mine = list(range(len(X1)))[rank::world]
+                    Xs_r, y_r, m_r = [x[mine] for x in Xs], y[mine], m[mine]
+                else:
+                    Xs_r, y_r, m_r = Xs, y, m
+            else:
+                batch = next(datagen)
+                Xs_r, y_r, m_r = batch.Xs, batch.targets, batch.mask
+                n_examples, total_frames = len(batch.global_idxs), batch.total_frames
+            if rank == 0 and progress:
+                print('Epoch {} batch {}/{}: {} examples using adam with learning rate = {}'.format(
+                    epoch + 1, i + 1, epochsize, n_examples, learning_rate), end='')
+                sys.stdout.flush()
+            if lr_map is not None and dp is None:
+                network.compute_grads(Xs_r, y_r, m_r, windowsize, want_loss=False)
+                network.apply_adam_vlr(lr_map)
+            elif dp is None:
+                # train(...): the cost it returns is discarded by the reference loop (runners/3stream.py:370) -- not waited for
+                network.train_step(Xs_r, y_r, m_r, windowsize, learning_rate, want_loss=False)
+            else:
+                # (a short last minibatch can leave high ranks without an utterance: they contribute zero gradients)
+                upd = (lambda mdl: mdl.apply_adam_vlr(lr_map)) if lr_map is not None else None
+                dp.train_step(Xs_r, y_r, m_r, windowsize, learning_rate, total_frames, update=upd)
+            if rank == 0 and progress:
+                print('\r', end='')
+        network.synchronize()                        # (the cost call below waits for the steps anyway)
+        train_seconds.append(time.time() - time_start)
+        # the train cost of an epoch is the cost of its LAST minibatch, re-evaluated after the update (App. E-7), on the WHOLE
+        # minibatch: a data-parallel rank that holds only its rows gathers the others for this one call
+        if not host_batches and dp is not None:
+            full = resident['train'].gather(batch.global_idxs, slot='epoch_cost')
+            Xs, y, m = full.Xs, full.targets, full.mask
+        elif not host_batches:
+            Xs, y, m = batch.Xs, batch.targets, batch.mask
+        cost = float(call(compute_train_cost, Xs, y, m, windowsize))
+        val_cost = heldout_cost(X_val, y_val, mask_val)
+        cost_train.append(cost)
+        cost_val.append(val_cost)
+        train_strip[epoch % STRIP_SIZE] = cost
+        val_window.push(val_cost)
+        gl = 100 * (cost_val[-1] / np.min(cost_val) - 1)
+        with np.errstate(divide='ignore', invalid='ignore'):    # the strip holds zeros until STRIP_SIZE epochs ran
+            pk = 1000 * (np.sum(train_strip) / (STRIP_SIZE * np.min(train_strip)) - 1)
+            pq = gl / pk
+        cr, val_conf = evaluate_model2(X_val, y_val_evaluate, mask_val, windowsize, eval_fn)
+        class_rate.append(cr)
+        if val_cost < best_val:
+            best_val, best_cr = val_cost, cr
+            test_cr, test_conf = evaluate_model2(X_test, y_test, mask_test, windowsize, eval_fn)
+            epoch_seconds.append(time.time() - time_start)
+            say("Epoch {} train cost = {}, val cost = {}, GL loss = {:.3f}, GQ = {:.3f}, CR = {:.3f}, "
+                "Test CR= {:.3f} ({:.1f}sec)".format(epoch + 1, cost_train[-1], cost_val[-1], gl, pq, cr, test_cr,
+                                                     epoch_seconds[-1]))
+            # (kept in HBM: one device copy of the flat buffer instead of a download per tensor; --save_best fetches it at the end)
+            best_params = network.snapshot_params() if hasattr(network, 'snapshot_params') else network.get_all_param_values()
+        else:
+            epoch_seconds.append(time.time() - time_start)
+            say("Epoch {} train cost = {}, val cost = {}, GL loss = {:.3f}, GQ = {:.3f}, CR = {:.3f} ({:.1f}sec)"
+                .format(epoch + 1, cost_train[-1], cost_val[-1], gl, pq, cr, epoch_seconds[-1]))
+        if epoch >= validation_window and early_stop2(val_window, best_val, validation_window):
+            break
+        if lr_map is not None and 'explode_layer_lr' in options and epoch + 1 == options['explode_layer_lr'][0]:
+            rate = options['explode_layer_lr'][1]
+            say('explode {} learning rates to {}'.format(','.join(sorted(options['layer_lr'])), rate))
+            from ..custom.updates import generate_lr_map
+            lr_map = generate_lr_map(network.get_all_params(trainable=True), {k: rate for k in options['layer_lr']},
+                                     learning_rate)
+    return dict(best_cr=best_cr, best_val=best_val, test_cr=test_cr, test_conf=test_conf, best_params=best_params,
+                cost_train=cost_train, cost_val=cost_val, class_rate=class_rate, epoch_seconds=epoch_seconds, train_seconds=train_seconds,
+                heldout=dict(X_val=X_val, y_val=y_val_evaluate, mask_val=mask_val, X_test=X_test, y_test=y_test, mask_test=mask_test))
+
+
 def _main(n_streams, argv=None, variant=None):
     """variant: None = runners/{1,2,3,4}stream.py; 1 stream: 'noencoder' = runners/1stream_noencoder.py (deltanet_v1 on
     the raw features), 'dct' = runners/1stream_dct.py (host deltas of the DCT features, lstm_classifier_majority_vote);
@@ -315,8 +478,6 @@ def _main(n_streams, argv=None, variant=None):
     if rank == 0:
         print_network(network)
     say('compiling model...')
-    order = 'in1,targets,mask,in2,window' if n_streams == 2 else 'inputs,targets,mask,window'
-    train, compute_train_cost, compute_test_cost, val_fn = network.compile(learning_rate, order)
     lr_map = None
     if 'layer_lr' in options:
         from ..custom.updates import generate_lr_map
@@ -327,101 +488,11 @@ def _main(n_streams, argv=None, variant=None):
         dp = DataParallel(network)
         dp.broadcast_parameters(0)
 
-    def call(fn, Xs, *rest):                        # the 2-stream runner interleaves its arguments
-        if n_streams == 2:
-            if len(rest) == 3:
-                return fn(Xs[0], rest[0], rest[1], Xs[1], rest[2])
-            return fn(Xs[0], rest[0], Xs[1], rest[1])
-        return fn(*(list(Xs) + list(rest)))
-
-    def eval_fn(*args):                             # evaluate_model2 passes inputs..., mask, window
-        if dp is not None:                          # held-out utterances split over the ranks, predictions gathered
-            return dp.predict_sharded(network.predict, list(args[:n_streams]), args[n_streams], args[n_streams + 1])
-        return call(val_fn, list(args[:n_streams]), *args[n_streams:])
-
-    def heldout_cost(Xs_, y_, m_):                  # compute_test_cost of a whole split
-        if dp is not None:
-            return dp.loss_sharded(network.loss, Xs_, y_, m_, windowsize,
-                                   weights=None if network.head == "frames" else np.ones(len(m_)))
-        return float(call(compute_test_cost, Xs_, y_, m_, windowsize))
-
-    say('begin training...')
-    cost_train, cost_val, class_rate = [], [], []
-    STRIP_SIZE = 3
-    val_window = circular_list(validation_window)
-    train_strip = np.zeros((STRIP_SIZE,))
-    best_val, best_cr, test_cr, test_conf, best_params = float('inf'), 0.0, 0.0, None, None
-
-    tr_lens = lens['train']
-    tmax_train = int(np.max(tr_lens))
-    datagen = gen_lstm_batch_random(split['train'][0], ys['train'], tr_lens, batchsize=batchsize)
-    integral_lens = compute_integral_len(tr_lens)
-
-    def whole_split(k):
-        gen = gen_lstm_batch_random(split[k][0], ys[k], lens[k], batchsize=len(lens[k]))
-        X1, y, m, idxs = next(gen)
-        il = compute_integral_len(lens[k])
-        Xs = [X1] + [gen_seq_batch_from_idx(split[k][s], idxs, lens[k], il, np.max(lens[k]))
-                     for s in range(1, n_streams)]
-        return Xs, y, m
-
-    X_val, y_val_evaluate, mask_val = whole_split('val')
-    X_test, y_test, mask_test = whole_split('test')
-    y_val = y_val_evaluate.reshape((-1, 1)).repeat(mask_val.shape[-1], axis=-1)
-
-    for epoch in range(num_epoch):
-        time_start = time.time()
-        for i in range(epochsize):
-            X1, y, m, batch_idxs = next(datagen)
-            y = y.reshape((-1, 1)).repeat(m.shape[-1], axis=-1)
-            Xs = [X1] + [gen_seq_batch_from_idx(split['train'][s], batch_idxs, tr_lens, integral_lens, tmax_train)
-                         for s in range(1, n_streams)]
-            if rank == 0:
-                print('Epoch {} batch {}/{}: {} examples using adam with learning rate = {}'.format(
-                    epoch + 1, i + 1, epochsize, len(X1), learning_rate), end='')
-                sys.stdout.flush()
-            if lr_map is not None and dp is None:
-                network.compute_grads(Xs, y, m, windowsize, want_loss=False)
-                network.apply_adam_vlr(lr_map)
-            elif dp is None:
-                call(train, Xs, y, m, windowsize)
-            else:
-                # (a short last minibatch can leave high ranks without an utterance: they contribute zero gradients)
-                mine = list(range(len(X1)))[rank::world]
-                upd = (lambda mdl: mdl.apply_adam_vlr(lr_map)) if lr_map is not None else None
-                dp.train_step([x[mine] for x in Xs], y[mine], m[mine], windowsize, learning_rate, float(m.sum()), update=upd)
-            if rank == 0:
-                print('\r', end='')
-        cost = float(call(compute_train_cost, Xs, y, m, windowsize))
-        val_cost = heldout_cost(X_val, y_val, mask_val)
-        cost_train.append(cost)
-        cost_val.append(val_cost)
-        train_strip[epoch % STRIP_SIZE] = cost
-        val_window.push(val_cost)
-        gl = 100 * (cost_val[-1] / np.min(cost_val) - 1)
-        with np.errstate(divide='ignore', invalid='ignore'):    # the strip holds zeros until STRIP_SIZE epochs ran
-            pk = 1000 * (np.sum(train_strip) / (STRIP_SIZE * np.min(train_strip)) - 1)
-            pq = gl / pk
-        cr, val_conf = evaluate_model2(X_val, y_val_evaluate, mask_val, windowsize, eval_fn)
-        class_rate.append(cr)
-        if val_cost < best_val:
-            best_val, best_cr = val_cost, cr
-            test_cr, test_conf = evaluate_model2(X_test, y_test, mask_test, windowsize, eval_fn)
-            say("Epoch {} train cost = {}, val cost = {}, GL loss = {:.3f}, GQ = {:.3f}, CR = {:.3f}, "
-                "Test CR= {:.3f} ({:.1f}sec)".format(epoch + 1, cost_train[-1], cost_val[-1], gl, pq, cr, test_cr,
-                                                     time.time() - time_start))
-            best_params = network.get_all_param_values()
-        else:
-            say("Epoch {} train cost = {}, val cost = {}, GL loss = {:.3f}, GQ = {:.3f}, CR = {:.3f} ({:.1f}sec)"
-                .format(epoch + 1, cost_train[-1], cost_val[-1], gl, pq, cr, time.time() - time_start))
-        if epoch >= validation_window and early_stop2(val_window, best_val, validation_window):
-            break
-        if lr_map is not None and 'explode_layer_lr' in options and epoch + 1 == options['explode_layer_lr'][0]:
-            rate = options['explode_layer_lr'][1]
-            say('explode {} learning rates to {}'.format(','.join(sorted(options['layer_lr'])), rate))
-            from ..custom.updates import generate_lr_map
-            lr_map = generate_lr_map(network.get_all_params(trainable=True), {k: rate for k in options['layer_lr']},
-                                     learning_rate)
+    st = fit(network, split, ys, lens, n_streams, windowsize=windowsize, num_epoch=num_epoch, epochsize=epochsize,
+             batchsize=batchsize, validation_window=validation_window, learning_rate=learning_rate, options=options, say=say,
+             rank=rank, world=world, dp=dp, lr_map=lr_map)
+    best_cr, best_val, test_cr, test_conf, best_params = st['best_cr'], st['best_val'], st['test_cr'], st['test_conf'], st['best_params']
+    cost_train, cost_val, class_rate = st['cost_train'], st['cost_val'], st['class_rate']
 
     say('Final Model')
     say('CR: {}, val loss: {}, Test CR: {}'.format(best_cr, best_val, test_cr))
@@ -442,14 +513,16 @@ def _main(n_streams, argv=None, variant=None):
                 f.write('{},{},{}\n'.format(test_cr, best_cr, best_val))
         if 'save_best' in options:
             print('saving best model...')
-            network.set_all_param_values(best_params)
+            if hasattr(network, 'restore_params') and not isinstance(best_params, list):
+                network.restore_params(best_params)
+            else:
+                network.set_all_param_values(best_params)
             save_model_params(network, options['save_best'])
             print('best model saved to {}'.format(options['save_best']))
     if dist is not None:
         dist.destroy_process_group()
-    return dict(best_cr=best_cr, best_val=best_val, test_cr=test_cr, cost_train=cost_train, cost_val=cost_val,
-                class_rate=class_rate, network=network, windowsize=windowsize,
-                heldout=dict(X_val=X_val, y_val=y_val_evaluate, mask_val=mask_val, X_test=X_test, y_test=y_test, mask_test=mask_test))
+    st.update(network=network, windowsize=windowsize)
+    return st
 
 
 def main(n_streams, argv=None, variant=None):

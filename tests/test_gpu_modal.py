@@ -216,7 +216,8 @@ def _run_and_replay(monkeypatch, run, tol):
             rec["p0"] = {k: np.asarray(v, np.float64) for k, v in net.get_params_dict().items()}
             rec["spec"] = net.spec
         net.set_dropout_state(4321, len(rec["calls"]))
-        rec["calls"].append(dict(xs=[np.array(x, np.float64) for x in inputs], y=np.array(targets), mask=np.array(mask),
+        host = lambda x: x.float().cpu().numpy() if hasattr(x, "cpu") else x      # (the drivers hand over HBM-resident batches)
+        rec["calls"].append(dict(xs=[np.array(host(x), np.float64) for x in inputs], y=np.array(targets), mask=np.array(mask),
                                  window=int(window), **rule))
 
     def train_step(self, inputs, targets, mask, window, learning_rate, *a, **k):      # forward + backward + Adam

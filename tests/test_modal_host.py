@@ -71,11 +71,11 @@ class _FakeNet(object):
     def __init__(self):
         self.calls = []
 
-    def train_step(self, ins, y, m, w, lr):
-        self.calls.append(("adam", lr)); return 1.0
+    def train_step(self, ins, y, m, w, lr, want_loss=True):
+        self.calls.append(("adam", lr)); return 1.0 if want_loss else None
 
-    def compute_grads(self, ins, y, m, w):
-        self.calls.append(("grads",)); return 2.0
+    def compute_grads(self, ins, y, m, w, want_loss=True):
+        self.calls.append(("grads",)); return 2.0 if want_loss else None
 
     def apply_adadelta(self, lr):
         self.calls.append(("adadelta", lr))
@@ -90,8 +90,9 @@ def test_update_rule_switch():
                        ("adam", ("adam", 1e-3))):
         net = _FakeNet()
         up = modal.Updater(net, rule, 0.3, 0.6)
-        up(None, None, None, 9)
+        assert up(None, None, None, 9) is None            # the loops discard train's cost: not waited for by default
         assert net.calls[-1] == want, rule
+        assert up(None, None, None, 9, want_loss=True) in (1.0, 2.0)
     up.lr = 0.1
     with pytest.raises(ValueError):
         modal.Updater(_FakeNet(), "rmsprop", 0.1)
