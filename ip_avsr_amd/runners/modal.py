@@ -860,7 +860,7 @@ def _main(dataset, script, argv=None):
         for k in ('train', 'val') + (('test',) if has_test else ()):
             same = [j for j in resident if split[j] is split[k] and lens[j] is lens[k]]     # (avletters: 'val' IS the test split)
             resident[k] = resident[same[0]] if same else DeviceSplit(split[k], ys[k], np.asarray(lens[k], int), dtype=dtype)
-        datagen = resident['train'].batches(batchsize, prefetch=not os.environ.get('ADN_NO_PREFETCH'))
+        datagen = resident['train'].batches(batchsize, prefetch=bool(os.environ.get('ADN_PREFETCH')))
 
         def whole_split(k):
             b = resident[k].whole()

@@ -193,7 +193,7 @@ def fit(network, split, ys, lens, n_streams, windowsize, num_epoch, epochsize, b
     if host_batches is None:
         host_batches = bool(os.environ.get('ADN_HOST_BATCHES'))
     if prefetch is None:
-        prefetch = not os.environ.get('ADN_NO_PREFETCH')
+        prefetch = bool(os.environ.get('ADN_PREFETCH'))
     order = 'in1,targets,mask,in2,window' if n_streams == 2 else 'inputs,targets,mask,window'
     train, compute_train_cost, compute_test_cost, val_fn = network.compile(learning_rate, order)
 

@@ -18,8 +18,12 @@ generator, and by tests/test_gpu_batch.py for this one against it):
 Data parallel: a rank gathers only ``idxs[rank::world]`` (ip_avsr_amd/parallel.py ``shard_indices``); every rank draws the same
 permutation, so the global valid-frame count of a batch is known everywhere without communication.
 
-Prefetch: batch t + 1 is gathered on a side stream while step t runs on the model's stream (two output slots, events both
-ways).  The gather moves bytes only; it needs no workspace of the model.
+Prefetch (``prefetch=True``, off by default): batch t + 1 is gathered on a side stream while step t runs on the model's stream
+(two output slots, events both ways).  Measured on MI355X (profiles/r04/epoch_bench.txt) it LOSES to the plain in-stream
+gather at both ends -- B = 26: 1.292 against 1.255 ms per step in bf16, 2.90 against 2.70 in bf16x3; B = 520: 3.87 against
+3.80 ms -- the gather is 5-80 us of HBM traffic, less than what the two cross-stream event waits per step cost the model's
+stream, and a byte-moving kernel beside the weight-stationary LSTM launches delays the workgroups it shares CUs with.  Kept
+as an option for hosts whose step is short enough to be launch-bound.
 """
 import ctypes as C
 
@@ -116,7 +120,7 @@ class DeviceSplit(object):
             return
         host = torch.from_numpy(np.ascontiguousarray(idxs, dtype=np.int32)).pin_memory()
         with torch.cuda.stream(stream):
-            d_idx = host.to(self.device, non_blocking=True)
+            d_idx = host.to(self.device, non_blocking=True)      # (torch's pinned-block cache keeps `host` until the copy ran)
             arr = (_lib.BatchStream * len(self.frames))()
             for k, f in enumerate(self.frames):
                 arr[k].frames, arr[k].width, arr[k].elem_bytes, arr[k].out = f.data_ptr(), self.widths[k], self.elem_bytes, \
@@ -165,7 +169,7 @@ class DeviceSplit(object):
         return b
 
     # ------------------------------------------------------------------ the endless generator
-    def batches(self, batchsize=30, shuffle=True, rank=0, world=1, prefetch=True):
+    def batches(self, batchsize=30, shuffle=True, rank=0, world=1, prefetch=False):
         """Endless generator of ``Batch`` objects in the order ``gen_lstm_batch_random(X, y, seqlen, batchsize, shuffle)``
         produces its batches (reference utils/datagen.py:92-153), the other streams gathered by the same indices
         (``gen_seq_batch_from_idx``, :219-229)."""

@@ -57,10 +57,21 @@ for precision in args.precisions.split(","):
         print("%-6s epoch 20 x 26 + costs + votes, %-52s median %6.1f ms (min %6.1f), minibatch loop %6.1f ms = %.3f ms / step; "
               "resident dtype %s" % (precision, label + ":", np.median(ep), ep.min(), np.median(tr), np.median(tr) / 20,
                                      "host" if host else nstream.resident_dtype(model)))
-    for label, host in (("HBM-resident", False), ("host assembly", True)):
-        st = run(model, host, True, 10, 520, 4)
+    for label, host, prefetch in (("HBM-resident, side-stream gather", False, True), ("HBM-resident, in-stream gather", False, False),
+                                  ("host assembly", True, False)):
+        st = run(model, host, prefetch, 10, 520, 5)
         tr = np.array(st["train_seconds"][1:]) * 1e3 / 10
-        print("%-6s runner step at B = 520, %-14s %.3f ms / step (median of %d x 10 steps)" % (precision, label + ":", np.median(tr), len(tr)))
+        print("%-6s runner step at B = 520, %-34s %.3f ms / step (median of %d x 10 steps)" % (precision, label + ":", np.median(tr), len(tr)))
+    b = B.synthetic_batch(torch, 0, 520, device)
+    xs = [x.to(torch.bfloat16) for x in b[0]] if nstream.resident_dtype(model) == "bfloat16" else b[0]
+    for _ in range(10):
+        model.train_step(xs, b[1], b[2], B.THETA, B.LR, want_loss=False)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(20):
+        model.train_step(xs, b[1], b[2], B.THETA, B.LR, want_loss=False)
+    torch.cuda.synchronize()
+    print("%-6s bare train_step at B = 520, batch resident: %.3f ms / step" % (precision, (time.perf_counter() - t) * 50))
+    del b, xs
     # the bare kernel time of the same work, for the gap: 20 steps at B = 26 with the batch already assembled
     b = B.synthetic_batch(torch, 2000, 26, device)
     xs = [x.to(torch.bfloat16) for x in b[0]] if nstream.resident_dtype(model) == "bfloat16" else b[0]

@@ -129,9 +129,7 @@ def test_prefetched_slots_are_not_overwritten_while_in_use():
     streams, y, lens = _random_split(rng, 40, (1200, 1200), tmin=20, tmax=40, classes=26)
     sp = _split(streams, y, lens)
     np.random.seed(3)
-    gen = sp.batches(8)
-    np.random.seed(3)
-    ref = dg.gen_lstm_batch_random(streams[0], y, lens, batchsize=8)
+    gen = sp.batches(8, prefetch=True)
     big = torch.randn(4096, 4096, device="cuda")
     sums = []
     for _ in range(12):
@@ -141,6 +139,8 @@ def test_prefetched_slots_are_not_overwritten_while_in_use():
         sums.append((b.Xs[0].double().sum() + b.Xs[1].double().sum(), b.Xs[0].clone()))
     torch.cuda.synchronize()
     il = dg.compute_integral_len(lens)
+    np.random.seed(3)                                    # (both generators draw lazily from the global stream)
+    ref = dg.gen_lstm_batch_random(streams[0], y, lens, batchsize=8)
     for k in range(12):
         X1, yb, mb, ib = next(ref)
         X2 = dg.gen_seq_batch_from_idx(streams[1], ib, lens, il, int(lens.max()))
@@ -154,18 +154,22 @@ def test_data_parallel_ranks_gather_only_their_rows():
     full = _split(streams, y, lens)
     world = 4
     np.random.seed(21)
-    ref = [next(g) for g in [full.batches(6)] for _ in range(8)]
+    ref, g = [], full.batches(6)
+    for _ in range(8):                                   # (a batch's tensors are its slot's: copied out before the slot is reused)
+        b = next(g)
+        ref.append(dict(global_idxs=b.global_idxs, idxs=b.idxs, total_frames=b.total_frames, Xs=[_host(x) for x in b.Xs],
+                        mask=np.array(b.mask)))
     for rank in range(world):
         np.random.seed(21)
         gen = _split(streams, y, lens).batches(6, rank=rank, world=world)
         for k in range(8):
             b = next(gen)
-            rows = list(range(len(ref[k].global_idxs)))[rank::world]
-            assert list(b.global_idxs) == list(ref[k].global_idxs) and list(b.idxs) == list(ref[k].idxs[rows])
-            assert b.total_frames == ref[k].total_frames               # the GLOBAL normaliser, known without communication
+            rows = list(range(len(ref[k]["global_idxs"])))[rank::world]
+            assert list(b.global_idxs) == list(ref[k]["global_idxs"]) and list(b.idxs) == list(ref[k]["idxs"][rows])
+            assert b.total_frames == ref[k]["total_frames"]            # the GLOBAL normaliser, known without communication
             for s in range(2):
-                assert np.array_equal(_host(b.Xs[s]), _host(ref[k].Xs[s])[rows])
-            assert np.array_equal(np.asarray(b.mask), np.asarray(ref[k].mask)[rows])
+                assert np.array_equal(_host(b.Xs[s]), ref[k]["Xs"][s][rows])
+            assert np.array_equal(np.asarray(b.mask), ref[k]["mask"][rows])
             assert len(b) == len(rows)                                  # 3 rows of a short batch over 4 ranks: rank 3 gets none
 
 
