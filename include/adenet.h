@@ -242,6 +242,14 @@ int adn_synchronize(adn_model* m);
  * when a workgroup gave up waiting for its partners; 0 clears it).  Lets a test follow the word's way through the gradient
  * tail, the data-parallel all-reduce and the optimiser's skip without provoking a real time-out. */
 int adn_debug_raise_exchange_error(int value);
+/* test hook: launches n_workgroups workgroups on hip_stream that each hold lds_bytes of LDS (<= 160 KB: at that size nothing
+ * else fits on their CU) for `ms` milliseconds -- a stand-in for a foreign tenant (another process' kernel, a collective
+ * waiting for a slow rank) beside the weight-stationary LSTM launches, whose workgroups wait for their partners
+ * (tests/test_gpu_residency.py: such a tenant delays a pass, it does not break it) */
+int adn_debug_occupy_cus(int n_workgroups, int lds_bytes, double ms, void* hip_stream);
+/* test hook: LSTM forward passes dispatched so far per kernel family: [0] one launch per time step, [1] one-workgroup
+ * persistent kernels, [2] weight-stationary kernels, [3] weight-stationary bf16x3 kernels */
+int adn_debug_lstm_family_counts(int64_t out[4]);
 
 /* per-kernel-class timing with HIP events recorded on the model's stream around every launch of the
  * class (bench.py's live roofline measurement).  flops / bytes are the ALGORITHMIC work of the launches

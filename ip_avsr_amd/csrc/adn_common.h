@@ -287,6 +287,9 @@ int lstm_forward_persistent(const LstmStep* l, int n, const uint8_t* mask_tb, in
 int lstm_backward_persistent(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s,
                              bool* sums_done = nullptr);
 // weight-stationary variants (lstm_cluster.hip): groups of 4 workgroups share a 32-utterance slice, W_hid stays in LDS
+// forward passes dispatched per kernel family since the library was loaded: [per-step launches, one-workgroup persistent,
+// weight-stationary, weight-stationary bf16x3] (adn_debug_lstm_family_counts: lets a test see WHICH family ran)
+extern long long g_lstm_family_forwards[4];
 bool lstm_cluster_supported(const LstmStep* l, int n, int B, int T, int H);
 size_t lstm_cluster_xchg_bytes(int B, int H);
 int lstm_forward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);

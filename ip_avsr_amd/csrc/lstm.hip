@@ -313,11 +313,13 @@ int lstm_pack_whid_t(const float* W, void* out, int H, hipStream_t s) {
     return ADN_OK;
 }
 
+long long g_lstm_family_forwards[4] = {0, 0, 0, 0};
+
 int lstm_forward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, int precision, hipStream_t s) {
     ADN_CHECK(n >= 1 && n <= kMaxLstmPerLaunch, ADN_ERR_INVALID, "lstm_forward: bad LSTM count");
     // bf16x3 mode: the weight-stationary forward kernel with fp32-grade products where it applies, the fp32 step kernels else
     if (precision == ADN_PRECISION_BF16X3) {
-        if (lstm_cluster_x3_supported(l, n, B, T, H)) return lstm_forward_cluster_x3(l, n, mask_tb, B, T, H, s);
+        if (lstm_cluster_x3_supported(l, n, B, T, H)) { g_lstm_family_forwards[3] += n; return lstm_forward_cluster_x3(l, n, mask_tb, B, T, H, s); }
         precision = ADN_PRECISION_F32;
     }
     LstmLaunch L;
@@ -328,6 +330,7 @@ int lstm_forward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T,
     // kernel (H <= 256 only: at H > 256 streaming 2 MB of W_hid per step into one CU is slower than the per-step launches)
     if (have16 && lstm_persistent_supported(H) && l[0].W_frag_fwd && (H <= 256 || lstm_cluster_supported(l, n, B, T, H) || getenv("ADN_LSTM_WIDE_PERSISTENT")))
         return lstm_forward_persistent(l, n, mask_tb, B, T, H, s);
+    g_lstm_family_forwards[0] += n;
     if (have16) {
         const double bytes = n * (4.0 * (12.0 * B * H + 4.0 * H * H) + B), flops = n * 8.0 * B * H * H;
         const dim3 grid16(cdiv(B, 32), cdiv(4 * H, 64), n);

@@ -1099,8 +1099,43 @@ static int cluster_cus() {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
         g_cluster_cus[dev] = prop.multiProcessorCount;
+        // ADN_LSTM_CUS=n: size the launches for n CUs (a partitioned device / a CU mask the runtime does not report; the
+        // tests use it to drive an LSTM onto the one-workgroup kernels the way a too-small device would)
+        if (const char* e = getenv("ADN_LSTM_CUS")) {
+            const int n = atoi(e);
+            if (n > 0 && n < g_cluster_cus[dev]) g_cluster_cus[dev] = n;
+        }
     }
     return g_cluster_cus[dev];
+}
+
+// Residency guard.  The weight-stationary kernels are plain launches of one 512-thread workgroup per CU whose workgroups
+// wait for their group's partners.  What makes that safe is checked here instead of assumed: (1) the runtime's occupancy
+// answer for the kernel with its dynamic LDS is asked once per device and kernel -- a workgroup that cannot become resident
+// at all (a driver that reserves LDS, a smaller register file) turns the kernel family off and the LSTM runs on the
+// one-workgroup kernels; (2) groups are independent and their workgroups have consecutive blockIdx.x, so with in-order
+// dispatch a launch makes progress on any number >= CWG of free CUs: a foreign kernel that holds CUs (a profiler's, another
+// tenant's, a collective's) delays the launch, group by group, and does not deadlock it
+// (tests/test_gpu_residency.py occupies 240 of the CUs for 20 ms beside a forward / backward pass); (3) polls are
+// bounded, so that even a dispatcher that breaks (2) ends in ADN_ERR_STATE, never in a hang.
+template <auto Kernel>                             // (the kernel as a template argument: one cache per kernel, not per signature)
+static bool cluster_kernel_fits(size_t lds_bytes) {
+    static int cached[kMaxDevices] = {};           // 0 = not asked, 1 = fits, -1 = does not
+    int& c = cached[current_device()];
+    if (!c) {
+        int blocks = 0;
+        const void* f = reinterpret_cast<const void*>(Kernel);
+        const bool ok = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess &&
+                        hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, f, 512, lds_bytes) == hipSuccess && blocks >= 1;
+        if (!ok) (void)hipGetLastError();
+        c = ok ? 1 : -1;
+    }
+    return c > 0;
+}
+template <int CWG> static size_t fwd_lds_bytes() { using G = ClusterGeom<CWG>; return (size_t)(G::WLdsFwd + kCRows * G::HS) * 2; }
+template <int CWG> static size_t bwd_lds_bytes() {
+    using G = ClusterGeom<CWG>;
+    return (size_t)(G::WLdsBwd + kCRows * kCDS) * 2 + (size_t)kCRows * (kCUnits + 1) * 4;
 }
 
 static int cluster_wgs(int H) { return H <= 256 ? 4 : 8; }      // workgroups per group: 64 hidden units each
@@ -1112,7 +1147,11 @@ bool lstm_cluster_supported(const LstmStep* l, int n, int B, int T, int H) {
         if (!l[k].xchg || !l[k].W_frag_fwd || !l[k].W_frag_bwd) return false;
     if (cdiv(B, kCRows) * cluster_wgs(H) > cluster_cus()) return false;     // every workgroup of one LSTM must be resident at once
     const size_t hp = (size_t)cluster_wgs(H) * kCUnits;
-    return lstm_frag_elems(H) == 4 * hp * hp;
+    if (lstm_frag_elems(H) != 4 * hp * hp) return false;
+    return H <= 256 ? cluster_kernel_fits<&lstm_fwd_cluster_kernel<4>>(fwd_lds_bytes<4>()) &&
+                          cluster_kernel_fits<&lstm_bwd_cluster_kernel<4>>(bwd_lds_bytes<4>())
+                    : cluster_kernel_fits<&lstm_fwd_cluster_kernel<8>>(fwd_lds_bytes<8>()) &&
+                          cluster_kernel_fits<&lstm_bwd_cluster_kernel<8>>(bwd_lds_bytes<8>());
 }
 
 size_t lstm_cluster_xchg_bytes(int B, int H) {   // forward region (h granules) + backward region (partial-dh granules)
@@ -1171,7 +1210,9 @@ bool lstm_cluster_x3_supported(const LstmStep* l, int n, int B, int T, int H) {
     for (int k = 0; k < n; ++k)
         if (!l[k].xchg || !l[k].W_frag_fwd || !l[k].W_frag_fwd_lo) return false;
     if (cdiv(B, kCRows) * 4 > cluster_cus()) return false;
-    return lstm_frag_elems(H) == (size_t)4 * 256 * 256;
+    if (lstm_frag_elems(H) != (size_t)4 * 256 * 256) return false;
+    using G = ClusterGeom<4>;
+    return cluster_kernel_fits<&lstm_fwd_cluster_x3_kernel>((size_t)2 * kCRows * G::HS * 2 + (size_t)kX3AccLds * 4 + (size_t)8 * 2 * kX3FwdLds * 64 * 16);
 }
 
 // Launch number (mod 64) of an exchange buffer: the sequence bits of the x3 kernel's 16-bit tags.  The counter lives with the
@@ -1255,7 +1296,8 @@ bool lstm_cluster_x3_bwd_supported(const LstmStep* l, int n, int B, int T, int H
     for (int k = 0; k < n; ++k)
         if (!l[k].xchg || !l[k].W_frag_bwd || !l[k].W_frag_bwd_lo) return false;
     if (cdiv(B, kCRows) * 4 > cluster_cus()) return false;
-    return lstm_frag_elems(H) == (size_t)4 * 256 * 256;
+    if (lstm_frag_elems(H) != (size_t)4 * 256 * 256) return false;
+    return cluster_kernel_fits<&lstm_bwd_cluster_x3_kernel>((size_t)kX3BwdWOff * 2 + (size_t)8 * 2 * kX3BwdLds * 64 * 16);
 }
 
 int lstm_backward_cluster_x3(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s) {
@@ -1285,7 +1327,35 @@ int lstm_backward_cluster_x3(const LstmStep* l, int n, const uint8_t* mask_tb, i
     return ADN_OK;
 }
 
+// test hook: n workgroups of 64 threads that each claim `lds_bytes` of LDS (160 KB: nothing else fits on their CU) and spin
+// for `ms` milliseconds of wall clock
+__global__ __launch_bounds__(64) void occupy_cus_kernel(unsigned long long ticks, int* sink) {
+    extern __shared__ int pad[];
+    const unsigned long long t0 = wall_ticks();
+    pad[threadIdx.x] = (int)t0;
+    while (wall_ticks() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+    if (sink && pad[threadIdx.x] == 0x7fffffff) *sink = 1;       // (keeps the LDS allocation alive)
+}
+
 }  // namespace adn
+
+extern "C" int adn_debug_occupy_cus(int n_workgroups, int lds_bytes, double ms, void* hip_stream) {
+    using namespace adn;
+    ADN_CHECK(n_workgroups >= 1 && lds_bytes >= 256 && lds_bytes <= 160 * 1024 && ms >= 0 && ms <= 2000.0, ADN_ERR_INVALID,
+              "adn_debug_occupy_cus: bad argument");
+    ADN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&occupy_cus_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      lds_bytes));
+    hipLaunchKernelGGL(occupy_cus_kernel, dim3(n_workgroups), dim3(64), (size_t)lds_bytes, static_cast<hipStream_t>(hip_stream),
+                       (unsigned long long)(ms * 1e5), nullptr);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+extern "C" int adn_debug_lstm_family_counts(int64_t out[4]) {
+    if (!out) return ADN_ERR_INVALID;
+    for (int k = 0; k < 4; ++k) out[k] = adn::g_lstm_family_forwards[k];
+    return ADN_OK;
+}
 
 #ifdef ADN_LSTM_STAMPS
 extern "C" int adn_debug_lstm_stamps(unsigned long long* out, int reset) {

@@ -370,7 +370,8 @@ int lstm_pack_frags(const float* W, void* fwd, void* bwd, int H, hipStream_t s) 
 bool lstm_persistent_supported(int H) { return H <= 512 && !getenv("ADN_LSTM_STEPWISE"); }
 
 int lstm_forward_persistent(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s) {
-    if (lstm_cluster_supported(l, n, B, T, H)) return lstm_forward_cluster(l, n, mask_tb, B, T, H, s);
+    if (lstm_cluster_supported(l, n, B, T, H)) { g_lstm_family_forwards[2] += n; return lstm_forward_cluster(l, n, mask_tb, B, T, H, s); }
+    g_lstm_family_forwards[1] += n;
     LstmLaunchP L;
     for (int k = 0; k < n; ++k) L.l[k] = l[k];
     const int ldh = ld_of(H), ldg = ld_of(4 * H);
