@@ -238,6 +238,13 @@ int adn_train_step(adn_model* m, const void* const* inputs, const int32_t* targe
 int adn_read_encoder_activation(adn_model* m, int stream, int layer, float* host_dst);
 
 int adn_synchronize(adn_model* m);
+/* Deterministic mode (process-wide; also ADN_DETERMINISTIC=1 in the environment): every reduction whose order otherwise follows
+ * the arrival order of float atomics -- bias / initial-state / peephole gradients of the LSTM kernels, column and scalar sums, the
+ * register-staged GEMMs' split-K -- runs in a fixed order, so that two runs from the same parameters, batches and dropout state
+ * give the same bits (the reference itself is not reproducible: it never seeds).  Slower; the
+ * arithmetic is otherwise the selected adn_precision's. */
+int adn_set_deterministic(int on);
+int adn_get_deterministic(void);
 /* test hook: writes `value` into the current device's LSTM-exchange error word (what a weight-stationary LSTM kernel raises
  * when a workgroup gave up waiting for its partners; 0 clears it).  Lets a test follow the word's way through the gradient
  * tail, the data-parallel all-reduce and the optimiser's skip without provoking a real time-out. */

@@ -106,6 +106,8 @@ _SIGNATURES = {
     "adn_train_step": (C.c_int, [_P, C.POINTER(_P), _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
     "adn_read_encoder_activation": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "adn_synchronize": (C.c_int, [_P]),
+    "adn_set_deterministic": (C.c_int, [C.c_int]),
+    "adn_get_deterministic": (C.c_int, []),
     "adn_debug_raise_exchange_error": (C.c_int, [C.c_int]),
     "adn_debug_occupy_cus": (C.c_int, [C.c_int, C.c_int, C.c_double, _P]),
     "adn_debug_lstm_family_counts": (C.c_int, [C.POINTER(C.c_int64)]),

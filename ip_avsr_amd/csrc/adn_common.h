@@ -10,6 +10,12 @@
 namespace adn {
 
 void set_error(const std::string& msg);
+// Deterministic mode (ADN_DETERMINISTIC=1 or adn_set_deterministic): every reduction whose order would otherwise depend on the
+// arrival order of float atomics runs in a fixed order -- column / scalar sums in one block per column tile, the register-staged
+// GEMMs without their atomic split-K, the LSTM kernels' group sums (bias, learnt initial state, peephole gradients) through
+// per-(group, row tile) slots and a fixed-order pass (lstm.hip).  Two runs from the same seed then give the same bits; slower.
+bool deterministic();
+void set_deterministic(bool on);
 
 #define ADN_HIP_CHECK(expr)                                                              \
     do {                                                                                 \
@@ -266,6 +272,17 @@ struct LstmStep {          // one LSTM instance taking part in a (possibly multi
     // optional (backward): gradients that are plain sums of what the kernel already holds in registers -- the bias
     // (column sums of dG over all frames) and the learnt initial state (sums of dh_carry / dc_state over the batch).
     // Kernels that add them report it through lstm_backward()'s `sums_done`; otherwise the caller runs col_sum.
+    // optional (forward, bf16 mode, H <= 256): the kernel computes the input projection itself (lstm_cluster.hip, KXS > 0) --
+    // x16: the LSTM's input as a bf16 matrix [T*B][ld_x], time-major, Kx <= 160 features; W_in_frag: lstm_pack_win_frags' image of
+    // W_in; b_in: the bias [ldg].  Offered together with xproj; lstm_forward_folds_projection() tells which one will be read.
+    const void* x16 = nullptr; int ld_x = 0; int Kx = 0;
+    const void* W_in_frag = nullptr;
+    const float* b_in = nullptr;
+    // deterministic mode (lstm.hip fills these in): [slots][det_stride] zeroed floats, one block
+    // [dbias ldg | dhid_init ldh | dcell_init ldh | dpeep 3 ldh] per slot; a kernel adds what it would add atomically into the
+    // block of ITS slot (the weight-stationary kernels: slot = 2 group + row tile; the others: slot = row slice = blockIdx.x) with
+    // plain adds -- one writer per address -- and lstm_det_reduce sums the slots in order into the gradients
+    float* det_ws = nullptr; int det_stride = 0;
     float* dbias = nullptr;      // [ldg]  += sum_{t,b} dG
     float* dhid_init = nullptr;  // [ldh]  += sum_b dh_carry
     float* dcell_init = nullptr; // [ldh]  += sum_b dc_state
@@ -291,6 +308,13 @@ int lstm_backward_persistent(const LstmStep* l, int n, const uint8_t* mask_tb, i
 // weight-stationary, weight-stationary bf16x3] (adn_debug_lstm_family_counts: lets a test see WHICH family ran)
 extern long long g_lstm_family_forwards[4];
 bool lstm_cluster_supported(const LstmStep* l, int n, int B, int T, int H);
+// true when lstm_forward(l, n, ...) will compute every LSTM's input projection inside the weight-stationary kernel (all of them
+// offer x16 / W_in_frag / b_in with the same Kx <= 160): the caller then skips the projection GEMM, xproj is not read
+bool lstm_forward_folds_projection(const LstmStep* l, int n, int B, int T, int H, int precision);
+// W_in [Kx][ldg] fp32 (gate columns interleaved) -> MFMA B-fragment image [HP/16 unit tiles x 4 gates][KXS][64 lanes][8] bf16 of
+// lstm_win_frag_elems(Kx, H) elements, zero beyond Kx features / H units; n <= 8 matrices per launch
+size_t lstm_win_frag_elems(int Kx, int H);
+int lstm_pack_win_frags(int n, const float* const* W_in, void* const* out, int Kx, int H, hipStream_t s);
 size_t lstm_cluster_xchg_bytes(int B, int H);
 int lstm_forward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
 bool lstm_cluster_x3_supported(const LstmStep* l, int n, int B, int T, int H);

@@ -141,6 +141,7 @@ int batchnorm_backward(const float* x, int ldx, const float* dy, int lddy, float
     ADN_HIP_CHECK(hipMemsetAsync(sums, 0, (size_t)2 * C * sizeof(float), s));
     const int ctiles = cdiv(C, 32);
     int splits = std::max(1, std::min(cdiv(rows, 64), cdiv(1024, ctiles)));
+    if (deterministic()) splits = 1;                 // one add per channel: no arrival order
     const int rps = cdiv(rows, splits);
     splits = cdiv(rows, rps);
     hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(ctiles, splits), dim3(256), 0, s, x, ldx, dy, lddy, rows, C, save_mean, save_inv_std,

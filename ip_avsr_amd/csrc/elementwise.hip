@@ -345,6 +345,7 @@ int col_sum(const float* in, int ld, int rows, int cols, float* out, int accumul
     if (rows <= 0) return ADN_OK;
     const int ctiles = cdiv(cols, 64);
     int splits = std::max(1, std::min(cdiv(rows, 64), cdiv(rows >= (1 << 18) ? 4096 : 1024, ctiles)));
+    if (deterministic()) splits = 1;                 // one block per column tile: ONE add per column and call, rows in a fixed order
     const int rps = cdiv(rows, splits);
     splits = cdiv(rows, rps);
     hipLaunchKernelGGL(col_sum_kernel, dim3(ctiles, splits), dim3(256), 0, s, in, ld, rows, cols, out, rps);
@@ -385,6 +386,7 @@ void col_sum_batch_add(ColSumBatch& b, const float* in, int ld, int rows, int co
     it.in = in; it.out = out; it.ld = ld; it.rows = rows; it.cols = cols;
     it.ctiles = cdiv(cols, 64);
     int splits = std::max(1, std::min(cdiv(rows, 64), cdiv(1024, it.ctiles)));
+    if (deterministic()) splits = 1;
     it.rps = cdiv(rows, splits);
     it.splits = cdiv(rows, it.rps);
     it.block_end = (b.n ? b.it[b.n - 1].block_end : 0) + it.ctiles * it.splits;
@@ -663,7 +665,7 @@ __global__ __launch_bounds__(256) void dot_all_kernel(const float* __restrict__ 
 
 int dot_all(const float* a, int lda, const float* b, int ldb, int rows, int cols, float* out, float* /*scratch*/,
             hipStream_t s) {
-    hipLaunchKernelGGL(dot_all_kernel, dim3(grid_for((int64_t)rows * cols / 4 + 1)), dim3(256), 0, s, a, lda, b, ldb,
+    hipLaunchKernelGGL(dot_all_kernel, dim3(deterministic() ? 1 : grid_for((int64_t)rows * cols / 4 + 1)), dim3(256), 0, s, a, lda, b, ldb,
                        rows, cols, out);
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;

@@ -623,7 +623,7 @@ static int gemm_rs(const GemmArgs* gs, int n, hipStream_t stream) {
     // split-K: enough workgroups for two per CU (measured on the weight-gradient shapes: 512 beats 768 / 1024 by 0-12 %,
     // fewer partial sums to add atomically; 256 leaves CUs idle on the large ones)
     static const int split_target = getenv("ADN_GEMM_SPLIT_TARGET") ? atoi(getenv("ADN_GEMM_SPLIT_TARGET")) : 512;
-    if (tiles < 384 && g.K >= 512 && can_split && !lean_c && !g.no_split) {
+    if (tiles < 384 && g.K >= 512 && can_split && !lean_c && !g.no_split && !deterministic()) {      // (partial sums meet in float atomics)
         split = (int)((split_target + tiles - 1) / tiles);
         split = std::min(split, g.K / 128);
         split = std::max(1, std::min(split, 128));

@@ -290,7 +290,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_bf16_kernel(const LstmLaunc
             float sum = 0.f;
 #pragma unroll
             for (int rr = 0; rr < 32; ++rr) sum += pred[which][rr][c];
-            if (u0 + c < H) atomicAdd(P.dpeep_part + (size_t)which * ldh + u0 + c, sum);
+            if (u0 + c < H) {
+                if (P.det_ws) P.det_ws[(size_t)blockIdx.x * P.det_stride + ldg + (2 + which) * (size_t)ldh + u0 + c] += sum;   // deterministic mode
+                else atomicAdd(P.dpeep_part + (size_t)which * ldh + u0 + c, sum);
+            }
         }
     }
 }
@@ -447,13 +450,66 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const LstmLaunch L, 
             float sum = 0.f;
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) sum += pred[which][rr][c];
-            if (u0 + c < H) atomicAdd(P.dpeep_part + (size_t)which * ldh + u0 + c, sum);
+            if (u0 + c < H) {
+                if (P.det_ws) P.det_ws[(size_t)blockIdx.x * P.det_stride + ldg + (2 + which) * (size_t)ldh + u0 + c] += sum;   // deterministic mode
+                else atomicAdd(P.dpeep_part + (size_t)which * ldh + u0 + c, sum);
+            }
         }
     }
 }
 
+// ---- deterministic mode: the kernels' group sums go through slots (LstmStep::det_ws), then this fixed-order pass
+struct DetReduceArgs { const float* ws[kMaxLstmPerLaunch]; float* dbias[kMaxLstmPerLaunch]; float* dhid[kMaxLstmPerLaunch];
+                       float* dcell[kMaxLstmPerLaunch]; float* dpeep[kMaxLstmPerLaunch]; };
+__global__ __launch_bounds__(256) void lstm_det_reduce_kernel(const DetReduceArgs a, int slots, int stride, int ldg, int ldh) {
+    const float* __restrict__ ws = a.ws[blockIdx.y];
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < stride; e += gridDim.x * 256) {
+        float sum = 0.f;
+        for (int sl = 0; sl < slots; ++sl) sum += ws[(size_t)sl * stride + e];          // slot order: the same every run
+        float* dst = e < ldg ? (a.dbias[blockIdx.y] ? a.dbias[blockIdx.y] + e : nullptr)
+                   : e < ldg + ldh ? (a.dhid[blockIdx.y] ? a.dhid[blockIdx.y] + (e - ldg) : nullptr)
+                   : e < ldg + 2 * ldh ? (a.dcell[blockIdx.y] ? a.dcell[blockIdx.y] + (e - ldg - ldh) : nullptr)
+                   : (a.dpeep[blockIdx.y] ? a.dpeep[blockIdx.y] + (e - ldg - 2 * ldh) : nullptr);
+        if (dst) *dst += sum;
+    }
+}
+
+static int lstm_backward_impl(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, int precision, hipStream_t s,
+                              bool* sums_done);
+
 int lstm_backward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, int precision, hipStream_t s,
                   bool* sums_done) {
+    ADN_CHECK(n >= 1 && n <= kMaxLstmPerLaunch, ADN_ERR_INVALID, "lstm_backward: bad LSTM count");
+    if (!deterministic()) return lstm_backward_impl(l, n, mask_tb, B, T, H, precision, s, sums_done);
+    // slots: >= 2 per 32-utterance group (weight-stationary kernels) and >= 1 per 16-row slice (the other families)
+    const int ldh = ld_of(H), ldg = ld_of(4 * H), stride = ldg + 5 * ldh, slots = cdiv(B, 16) + 2;
+    static float* ws = nullptr; static size_t ws_floats = 0;       // (one stream drives a model in this mode)
+    const size_t need = (size_t)n * slots * stride;
+    if (need > ws_floats) {
+        if (ws) { ADN_HIP_CHECK(hipStreamSynchronize(s)); (void)hipFree(ws); ws = nullptr; ws_floats = 0; }
+        ADN_HIP_CHECK(hipMalloc((void**)&ws, need * sizeof(float)));
+        ws_floats = need;
+    }
+    ADN_HIP_CHECK(hipMemsetAsync(ws, 0, need * sizeof(float), s));
+    LstmStep q[kMaxLstmPerLaunch];
+    DetReduceArgs a{};
+    for (int k = 0; k < n; ++k) {
+        q[k] = l[k];
+        q[k].det_ws = ws + (size_t)k * slots * stride; q[k].det_stride = stride;
+        a.ws[k] = q[k].det_ws; a.dbias[k] = l[k].dbias; a.dhid[k] = l[k].dhid_init; a.dcell[k] = l[k].dcell_init; a.dpeep[k] = l[k].dpeep_part;
+    }
+    bool done = false;
+    ADN_TRY(lstm_backward_impl(q, n, mask_tb, B, T, H, precision, s, &done));
+    if (sums_done) *sums_done = done;
+    if (!done)                       // (the kernel left bias / initial state to the caller's column sums: only the peephole slots hold anything)
+        for (int k = 0; k < n; ++k) a.dbias[k] = a.dhid[k] = a.dcell[k] = nullptr;
+    hipLaunchKernelGGL(lstm_det_reduce_kernel, dim3(cdiv(stride, 256), n), dim3(256), 0, s, a, slots, stride, ldg, ldh);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+static int lstm_backward_impl(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, int precision, hipStream_t s,
+                              bool* sums_done) {
     ADN_CHECK(n >= 1 && n <= kMaxLstmPerLaunch, ADN_ERR_INVALID, "lstm_backward: bad LSTM count");
     if (sums_done) *sums_done = false;
     if (precision == ADN_PRECISION_BF16X3) {          // fp32-grade products on the bf16 matrix pipe, or the fp32 step kernels

@@ -47,12 +47,15 @@ constexpr int kCRows = 32;       // utterances per group
 constexpr int kCUnits = 64;      // hidden units per workgroup
 // Geometry of a group of CWG workgroups (4: H <= 256, everything LDS-resident;  8: H <= 512, where a workgroup's W slice
 // is 256 KB and its k-steps are split between LDS and the waves' registers).
-template <int CWG> struct ClusterGeom {
+template <int CWG, int KXS = 0> struct ClusterGeom {     // (KXS > 0: the forward kernel that also multiplies x_t W_in)
     static constexpr int HP = CWG * kCUnits;                // padded hidden size (256 | 512)
     static constexpr int KS = HP / 32;                      // k-steps of the forward product (8 | 16)
-    static constexpr int KSL = CWG == 4 ? 0 : 7;            // ... of which LDS-resident; the rest sit in registers
+    static constexpr int KSL = CWG == 4 ? (KXS > 0 ? 1 : 0) : 7;   // ... of which LDS-resident; the rest sit in registers
                                                             // (CWG = 4: all 8 in registers, 128 VGPRs -- the product phase
-                                                            // is LDS-bandwidth bound otherwise: -0.2 us per step)
+                                                            // is LDS-bandwidth bound otherwise: -0.2 us per step; the folding
+                                                            // kernel gives one k-step's 16 registers to its x pipeline: with all
+                                                            // 8 held the loop reloads spilled addresses from scratch every step,
+                                                            // +1.1 us per step)
     static constexpr int KSR = KS - KSL;
     static constexpr int WElems = kCUnits * 4 * HP;         // bf16 elements of one workgroup's W slice (128 | 256 KB)
     static constexpr int WLdsFwd = 4 * 4 * KSL * 512;       // ... of which in LDS, forward  [4 unit tiles][4 gates][KSL][64][8]
@@ -96,6 +99,12 @@ __device__ __forceinline__ unsigned long long stamp_now() {
 #define STAMP(k) do {} while (0)
 #define STAMP_INIT
 #endif
+
+// one term of a gradient that sums over utterance groups: a float atomic into the gradient (arrival order), or -- deterministic
+// mode -- a plain add into the caller's own slot, which no other lane writes
+__device__ __forceinline__ void group_sum_add(float* grad, float* slot, float v) {
+    if (slot) *slot += v; else atomicAdd(grad, v);
+}
 
 __device__ __forceinline__ unsigned long long granule_load(const unsigned long long* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -144,14 +153,27 @@ __device__ __forceinline__ bool granule_wait(const unsigned long long* const (&p
 // =========================================================================================
 // grid (CWG * groups, n LSTMs); 512 threads: wave w -> row tile w >> 2 (16 rows), local unit tile w & 3 (16 units);
 // lane -> unit (lane & 15), rows 4 (lane >> 4) .. +3 of the row tile.
-template <int CWG>
+// KXS > 0: the kernel also computes the LSTM's INPUT projection x_t W_in + b itself (k-steps of 32 input features, KXS = 3: up to
+// 96, KXS = 5: up to 160 -- the 150 = 3 x 50 delta features of an encoder stream): the workgroup's 256 gate columns of W_in stay in
+// LDS beside the h image ([16 tiles][KXS][64 lanes][8] bf16: 80 KB at KXS = 5; the W_hid slice of a 4-workgroup group sits in
+// registers), x_{t+1} arrives as MFMA A fragments straight from the bf16 feature matrix (requested at the top of step t), and its
+// 4 x KXS MFMAs per wave run between the step's output stores and the poll for the partners' h_t, i.e. while the own granules
+// travel.  Against the projection as a GEMM ahead of the launch this drops a [T B][4H] fp32 matrix from HBM twice (written by
+// the GEMM: 250 MB for the three stream LSTMs of the bench model, 91 us; read back here, where the step waited ~0.7 us for it)
+// and a launch.  Same products: bf16 operands, fp32 accumulation over the k-steps in order, bias added last.
+template <int CWG, int KXS = 0>
 __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const LstmClusterP L, const uint8_t* __restrict__ mask_tb,
                                                                int B, int T, int H, int ldh, int ldg, unsigned tag0, int* err) {
-    using G = ClusterGeom<CWG>;
+    using G = ClusterGeom<CWG, KXS>;
     constexpr int HP = G::HP, KS = G::KS, KSL = G::KSL, KSR = G::KSR, HS = G::HS, NF = G::NF;
+    constexpr bool FOLD = KXS > 0;
+    static_assert(!FOLD || CWG == 4, "the folded input projection needs the LDS the 8-workgroup geometry gives to W_hid");
     extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
     __bf16* wl = lds;                                 // [4 unit tiles][4 gates][KSL k-steps][64 lanes][8]
     __bf16 (*hs)[HS] = reinterpret_cast<__bf16 (*)[HS]>(lds + G::WLdsFwd);     // [32][HS]
+    bf16x8* win = reinterpret_cast<bf16x8*>(lds + G::WLdsFwd + kCRows * HS);   // FOLD: [16 (unit tile, gate)][KXS][64 lanes] fragments
+    constexpr int XS = 32 * KXS + 8;                  // FOLD: row stride of the x tiles [2 parities][32 rows][XS] (bf16)
+    __bf16* xs = lds + G::WLdsFwd + kCRows * HS + 16 * KXS * 64 * 8;
     const LstmStep& P = L.l[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, kq = lane >> 4;
@@ -178,6 +200,12 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const LstmCluster
     for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int s_ = 0; s_ < KSR; ++s_) wreg[g][s_] = wsrc[((size_t)(4 * ut + g) * KS + KSL + s_) * 64 + lane];
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (FOLD) {
+        const bf16x8* wi = reinterpret_cast<const bf16x8*>(P.W_in_frag) + (size_t)j * 16 * KXS * 64;
+        for (int e = tid; e < 16 * KXS * 64; e += 512) win[e] = wi[e];
+        bias4 = *reinterpret_cast<const float4*>(P.b_in + uc * 4);
+    }
     // ---- initial state
     const int blk0 = P.backwards ? T : 0;
     for (int e = tid; e < kCRows * (HS / 8); e += 512) {
@@ -194,6 +222,60 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const LstmCluster
         h_st[r] = P.hbuf[idx];
     }
     __syncthreads();
+
+    // FOLD: the group's x_t tile (32 rows x 32 KXS features) travels HBM -> registers -> LDS two steps ahead of its use: thread
+    // e (and e + 512) owns the 16-byte chunk (row e / (4 KXS), features 8 (e % (4 KXS))) -- one or two chunks per thread, a
+    // whole step in registers so that no wave ever waits for the load; features beyond Kx are cleared on the way (the pad
+    // columns of the matrix may hold anything; W_in's image is zero there, but 0 x NaN is not)
+    const __bf16* x16 = reinterpret_cast<const __bf16*>(P.x16);
+    constexpr int XCH = FOLD ? 4 * KXS : 1;           // chunks per row
+    constexpr int XN = FOLD ? (kCRows * XCH + 511) / 512 : 1;
+    bf16x8 xreg[XN];
+    f32x4 xacc[4];                                    // x_t W_in of the step whose gate math comes next (4 gates x 4 rows of this lane)
+    auto request_x = [&](int step_) {
+        const int t_ = P.backwards ? (T - 1 - step_) : step_;
+#pragma unroll
+        for (int q = 0; q < XN; ++q) {
+            const int e = tid + 512 * q;
+            if (e < kCRows * XCH)
+                xreg[q] = *reinterpret_cast<const bf16x8*>(x16 + ((size_t)t_ * B + min(r0 + e / XCH, B - 1)) * P.ld_x + 8 * (e % XCH));
+        }
+    };
+    auto stage_x = [&](int par) {
+#pragma unroll
+        for (int q = 0; q < XN; ++q) {
+            const int e = tid + 512 * q;
+            if (e < kCRows * XCH) {
+                const int keep = P.Kx - 8 * (e % XCH);
+                uint4 d = __builtin_bit_cast(uint4, xreg[q]);
+                d.x &= (keep > 0 ? 0xffffu : 0u) | (keep > 1 ? 0xffff0000u : 0u);
+                d.y &= (keep > 2 ? 0xffffu : 0u) | (keep > 3 ? 0xffff0000u : 0u);
+                d.z &= (keep > 4 ? 0xffffu : 0u) | (keep > 5 ? 0xffff0000u : 0u);
+                d.w &= (keep > 6 ? 0xffffu : 0u) | (keep > 7 ? 0xffff0000u : 0u);
+                *reinterpret_cast<uint4*>(xs + ((size_t)par * kCRows + e / XCH) * XS + 8 * (e % XCH)) = d;
+            }
+        }
+    };
+    auto project_x = [&](int par) {                   // xacc = x W_in for the tile in parity `par`
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xacc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bf16x8* wf = win + (size_t)ut * 4 * KXS * 64 + lane;
+        const __bf16* xr = xs + ((size_t)par * kCRows + 16 * rt + i) * XS + 8 * kq;
+#pragma unroll
+        for (int s_ = 0; s_ < KXS; ++s_) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(xr + 32 * s_);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xacc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wf[(g * KXS + s_) * 64], xacc[g], 0, 0, 0);
+        }
+    };
+    if constexpr (FOLD) {
+        // pipeline fill: x_0 -> its projection; x_1 staged for step 0's project_x; x_2 on its way
+        request_x(0); stage_x(0);
+        if (T > 1) { request_x(1); stage_x(1); }
+        __syncthreads();
+        project_x(0);
+        if (T > 2) request_x(2);
+    }
 
     // foreign granules this thread fetches every step: (CWG - 1) partners x 16 row pairs x 64 units = NF per thread;
     // granule k of the thread: id = tid + 512 k -> partner (j + 1 + id / 1024) % CWG, row pair (id % 1024) / 64, unit id % 64
@@ -219,7 +301,12 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const LstmCluster
         unsigned long long* xpar = xb + (size_t)(step & 1) * 16 * HP;
         // masks and input projections of the step (the round trip hides under the recurrent product; requesting them a
         // step ahead, before or after the polls, measured no faster)
-        request_inputs(step, m, xp);
+        if constexpr (FOLD) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m[r] = mask_tb[(size_t)t * B + min(r0 + 16 * rt + 4 * kq + r, B - 1)];
+        } else {
+            request_inputs(step, m, xp);
+        }
         // ---- recurrent product: 4 gate tiles x KS k-steps, W fragments out of LDS (s < KSL) or registers
         f32x4 acc[4];
 #pragma unroll
@@ -234,11 +321,18 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const LstmCluster
         }
         lds_barrier();                                // every wave has read h_{t-1}: the image may be overwritten
         STAMP(0);
+        if constexpr (FOLD) {
+            // x_{t+2} (requested a step ago) goes into the tile project_x read during the previous step; x_{t+3} sets out
+            if (step + 2 < T) stage_x(step & 1);
+            if (step + 3 < T) request_x(step + 3);
+        }
         // ---- gate math; lane = (unit, 4 rows)
         float h_out[4];
         float4 gts[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+            // (FOLD: the projection of this step, (x_t W_in) + b, the bias added last like the GEMM's epilogue adds it)
+            if constexpr (FOLD) xp[r] = make_float4(xacc[0][r] + bias4.x, xacc[1][r] + bias4.y, xacc[2][r] + bias4.z, xacc[3][r] + bias4.w);
             float a_i = xp[r].x + acc[0][r], a_f = xp[r].y + acc[1][r];
             float a_g = xp[r].z + acc[2][r], a_o = xp[r].w + acc[3][r];
             const float c_prev = c_st[r], h_prev = h_st[r];
@@ -280,6 +374,9 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const LstmCluster
                     if (P.gates) *reinterpret_cast<float4*>(P.gates + ridx * ldg + u * 4) = gts[r];
                 }
             }
+        }
+        if constexpr (FOLD) {
+            if (step + 1 < T) project_x((step + 1) & 1);   // the own granules are on their way: the matrix pipe is idle until the poll
         }
         STAMP(2);
         // ---- gather the partners' h_t
@@ -760,9 +857,10 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_kernel(const LstmCluster
             sf += __shfl_xor(sf, 16, 64); sf += __shfl_xor(sf, 32, 64);
             so += __shfl_xor(so, 16, 64); so += __shfl_xor(so, 32, 64);
             if (kq == 0 && u < H) {
-                atomicAdd(P.dpeep_part + u, si);
-                atomicAdd(P.dpeep_part + ldh + u, sf);
-                atomicAdd(P.dpeep_part + 2 * (size_t)ldh + u, so);
+                float* ds = P.det_ws ? P.det_ws + (size_t)(2 * group + rt) * P.det_stride + ldg + 2 * ldh : nullptr;
+                group_sum_add(P.dpeep_part + u, ds ? ds + u : nullptr, si);
+                group_sum_add(P.dpeep_part + ldh + u, ds ? ds + ldh + u : nullptr, sf);
+                group_sum_add(P.dpeep_part + 2 * (size_t)ldh + u, ds ? ds + 2 * ldh + u : nullptr, so);
             }
         }
         lds_barrier();
@@ -789,9 +887,10 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_kernel(const LstmCluster
             sh += __shfl_xor(sh, o, 64); sc += __shfl_xor(sc, o, 64);
         }
         if (kq == 0 && u < H) {
-            atomicAdd(P.dbias + 4 * u, bsum.x); atomicAdd(P.dbias + 4 * u + 1, bsum.y);
-            atomicAdd(P.dbias + 4 * u + 2, bsum.z); atomicAdd(P.dbias + 4 * u + 3, bsum.w);
-            atomicAdd(P.dhid_init + u, sh); atomicAdd(P.dcell_init + u, sc);
+            float* ds = P.det_ws ? P.det_ws + (size_t)(2 * group + rt) * P.det_stride : nullptr;
+            group_sum_add(P.dbias + 4 * u, ds ? ds + 4 * u : nullptr, bsum.x); group_sum_add(P.dbias + 4 * u + 1, ds ? ds + 4 * u + 1 : nullptr, bsum.y);
+            group_sum_add(P.dbias + 4 * u + 2, ds ? ds + 4 * u + 2 : nullptr, bsum.z); group_sum_add(P.dbias + 4 * u + 3, ds ? ds + 4 * u + 3 : nullptr, bsum.w);
+            group_sum_add(P.dhid_init + u, ds ? ds + ldg + u : nullptr, sh); group_sum_add(P.dcell_init + u, ds ? ds + ldg + ldh + u : nullptr, sc);
         }
     }
     // leave this workgroup's inbox empty for the next launch (after EVERY lane has taken its last granules)
@@ -1043,9 +1142,10 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_x3_kernel(const LstmClus
             sf += __shfl_xor(sf, 16, 64); sf += __shfl_xor(sf, 32, 64);
             so += __shfl_xor(so, 16, 64); so += __shfl_xor(so, 32, 64);
             if (kq == 0 && u < H) {
-                atomicAdd(P.dpeep_part + u, si);
-                atomicAdd(P.dpeep_part + ldh + u, sf);
-                atomicAdd(P.dpeep_part + 2 * (size_t)ldh + u, so);
+                float* ds = P.det_ws ? P.det_ws + (size_t)(2 * group + rt) * P.det_stride + ldg + 2 * ldh : nullptr;
+                group_sum_add(P.dpeep_part + u, ds ? ds + u : nullptr, si);
+                group_sum_add(P.dpeep_part + ldh + u, ds ? ds + ldh + u : nullptr, sf);
+                group_sum_add(P.dpeep_part + 2 * (size_t)ldh + u, ds ? ds + 2 * ldh + u : nullptr, so);
             }
         }
         lds_barrier();
@@ -1068,9 +1168,10 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_x3_kernel(const LstmClus
             sh += __shfl_xor(sh, o, 64); sc += __shfl_xor(sc, o, 64);
         }
         if (kq == 0 && u < H) {
-            atomicAdd(P.dbias + 4 * u, bsum.x); atomicAdd(P.dbias + 4 * u + 1, bsum.y);
-            atomicAdd(P.dbias + 4 * u + 2, bsum.z); atomicAdd(P.dbias + 4 * u + 3, bsum.w);
-            atomicAdd(P.dhid_init + u, sh); atomicAdd(P.dcell_init + u, sc);
+            float* ds = P.det_ws ? P.det_ws + (size_t)(2 * group + rt) * P.det_stride : nullptr;
+            group_sum_add(P.dbias + 4 * u, ds ? ds + 4 * u : nullptr, bsum.x); group_sum_add(P.dbias + 4 * u + 1, ds ? ds + 4 * u + 1 : nullptr, bsum.y);
+            group_sum_add(P.dbias + 4 * u + 2, ds ? ds + 4 * u + 2 : nullptr, bsum.z); group_sum_add(P.dbias + 4 * u + 3, ds ? ds + 4 * u + 3 : nullptr, bsum.w);
+            group_sum_add(P.dhid_init + u, ds ? ds + ldg + u : nullptr, sh); group_sum_add(P.dcell_init + u, ds ? ds + ldg + ldh + u : nullptr, sc);
         }
     }
     __syncthreads();
@@ -1132,7 +1233,10 @@ static bool cluster_kernel_fits(size_t lds_bytes) {
     }
     return c > 0;
 }
-template <int CWG> static size_t fwd_lds_bytes() { using G = ClusterGeom<CWG>; return (size_t)(G::WLdsFwd + kCRows * G::HS) * 2; }
+template <int CWG, int KXS = 0> static size_t fwd_lds_bytes() {
+    using G = ClusterGeom<CWG, KXS>;
+    return (size_t)(G::WLdsFwd + kCRows * G::HS) * 2 + (size_t)16 * KXS * 64 * 16 + (KXS ? (size_t)2 * kCRows * (32 * KXS + 8) * 2 : 0);
+}
 template <int CWG> static size_t bwd_lds_bytes() {
     using G = ClusterGeom<CWG>;
     return (size_t)(G::WLdsBwd + kCRows * kCDS) * 2 + (size_t)kCRows * (kCUnits + 1) * 4;
@@ -1148,9 +1252,9 @@ bool lstm_cluster_supported(const LstmStep* l, int n, int B, int T, int H) {
     if (cdiv(B, kCRows) * cluster_wgs(H) > cluster_cus()) return false;     // every workgroup of one LSTM must be resident at once
     const size_t hp = (size_t)cluster_wgs(H) * kCUnits;
     if (lstm_frag_elems(H) != 4 * hp * hp) return false;
-    return H <= 256 ? cluster_kernel_fits<&lstm_fwd_cluster_kernel<4>>(fwd_lds_bytes<4>()) &&
+    return H <= 256 ? cluster_kernel_fits<&lstm_fwd_cluster_kernel<4, 0>>(fwd_lds_bytes<4>()) &&
                           cluster_kernel_fits<&lstm_bwd_cluster_kernel<4>>(bwd_lds_bytes<4>())
-                    : cluster_kernel_fits<&lstm_fwd_cluster_kernel<8>>(fwd_lds_bytes<8>()) &&
+                    : cluster_kernel_fits<&lstm_fwd_cluster_kernel<8, 0>>(fwd_lds_bytes<8>()) &&
                           cluster_kernel_fits<&lstm_bwd_cluster_kernel<8>>(bwd_lds_bytes<8>());
 }
 
@@ -1169,23 +1273,73 @@ int lstm_cluster_error_word(int** out) {
     return ADN_OK;
 }
 
-template <int CWG>
+// ---- folded input projection (KXS > 0 instantiations of the forward kernel) -------------------------------------------------
+static int fold_ksteps(int Kx) { return Kx <= 0 ? 0 : (Kx <= 96 ? 3 : (Kx <= 160 ? 5 : 0)); }
+template <int KXS> static size_t fwd_fold_lds_bytes() { return fwd_lds_bytes<4, KXS>(); }
+
+size_t lstm_win_frag_elems(int Kx, int H) { return (size_t)(H <= 256 ? 256 : 512) / 16 * 4 * fold_ksteps(Kx) * 512; }
+
+struct PackWinArgs { const float* W[8]; void* out[8]; };
+__global__ __launch_bounds__(256) void pack_win_frags_kernel(const PackWinArgs a, int Kx, int H, int ldg, int kxs, int total) {
+    const float* __restrict__ W = a.W[blockIdx.y];
+    __bf16* __restrict__ out = reinterpret_cast<__bf16*>(a.out[blockIdx.y]);
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int q = e & 7, lane = (e >> 3) & 63, rest = e >> 9;
+        const int s_ = rest % kxs, tile = rest / kxs;             // tile = 4 * (16-unit tile) + gate, like the W_hid image
+        const int unit = 16 * (tile >> 2) + (lane & 15), col = 4 * unit + (tile & 3);
+        const int k = 32 * s_ + 8 * (lane >> 4) + q;
+        out[e] = (__bf16)((k < Kx && unit < H) ? W[(size_t)k * ldg + col] : 0.f);
+    }
+}
+int lstm_pack_win_frags(int n, const float* const* W_in, void* const* out, int Kx, int H, hipStream_t s) {
+    ADN_CHECK(n >= 1 && n <= 8 && fold_ksteps(Kx) > 0, ADN_ERR_INVALID, "lstm_pack_win_frags: 1..8 matrices of <= 160 input features");
+    PackWinArgs a{};
+    for (int k = 0; k < n; ++k) { a.W[k] = W_in[k]; a.out[k] = out[k]; }
+    const int total = (int)lstm_win_frag_elems(Kx, H);
+    hipLaunchKernelGGL(pack_win_frags_kernel, dim3(cdiv(total, 256 * 4), n), dim3(256), 0, s, a, Kx, H, ld_of(4 * H), fold_ksteps(Kx), total);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+// (measured on the bench model, profiles/r04: B = 520 -- projection GEMM 91 us gone, forward LSTM class +4 us: 3.563 -> 3.478 ms
+//  per train step; B = 26 -- the GEMM is a 10 us launch there and the step's 20 extra MFMAs per wave sit on the exchange's
+//  critical path: 1.246 -> 1.263 ms.  Folded from three groups on; ADN_LSTM_FOLD_MIN_B moves the threshold.)
+static bool fold_offered(const LstmStep* l, int n, int H, int B) {
+    static const int min_b = getenv("ADN_LSTM_FOLD_MIN_B") ? atoi(getenv("ADN_LSTM_FOLD_MIN_B")) : 65;
+    if (H > 256 || B < min_b || getenv("ADN_LSTM_NO_FOLD")) return false;
+    const int kxs = fold_ksteps(l[0].Kx);
+    if (!kxs) return false;
+    for (int k = 0; k < n; ++k)
+        if (!l[k].x16 || !l[k].W_in_frag || !l[k].b_in || l[k].Kx != l[0].Kx || l[k].ld_x < 32 * kxs || (l[k].ld_x & 7)) return false;
+    return kxs == 3 ? cluster_kernel_fits<&lstm_fwd_cluster_kernel<4, 3>>(fwd_fold_lds_bytes<3>())
+                    : cluster_kernel_fits<&lstm_fwd_cluster_kernel<4, 5>>(fwd_fold_lds_bytes<5>());
+}
+
+bool lstm_forward_folds_projection(const LstmStep* l, int n, int B, int T, int H, int precision) {
+    if (precision != ADN_PRECISION_BF16 || n < 1) return false;
+    for (int k = 0; k < n; ++k)
+        if (!l[k].W_hid16T || !l[k].h16) return false;            // (lstm_forward's own test for the bf16 kernels)
+    return lstm_persistent_supported(H) && lstm_cluster_supported(l, n, B, T, H) && fold_offered(l, n, H, B);
+}
+
+template <int CWG, int KXS>
 static int forward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s) {
-    using G = ClusterGeom<CWG>;
     const int groups = cdiv(B, kCRows), per = groups * CWG, cus = cluster_cus();
     ADN_CHECK(cus >= per, ADN_ERR_STATE, "lstm cluster kernel: one LSTM does not fit the device");
     int* err = nullptr;
     ADN_TRY(lstm_cluster_error_word(&err));
     const int ldh = ld_of(H), ldg = ld_of(4 * H);
-    const size_t lds = (size_t)(G::WLdsFwd + kCRows * G::HS) * 2;
+    const size_t lds = fwd_lds_bytes<CWG, KXS>();
     static bool attr_set[kMaxDevices] = {};        // (a function attribute is per device)
     bool& attr = attr_set[current_device()];
     if (!attr) {
-        ADN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_cluster_kernel<CWG>),
+        ADN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_cluster_kernel<CWG, KXS>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
-    const double bytes = (double)n * T * (4.0 * (12.0 * B * H + 4.0 * H * H) + B), flops = (double)n * T * 8.0 * B * H * H;
+    // (KXS > 0: the step also multiplies x_t W_in -- its flops are booked with the recurrence's, its bytes replace the xproj read)
+    const double bytes = (double)n * T * (4.0 * (12.0 * B * H + 4.0 * H * H) + B),
+                 flops = (double)n * T * (8.0 * B * H * H + (KXS ? 8.0 * B * H * l[0].Kx : 0.0));
     ProfScope prof(PROF_LSTM_FWD, flops, bytes, s, T);
     const int chunk = std::max(1, cus / per);        // LSTMs per launch: every workgroup must be resident
     for (int k0 = 0; k0 < n; k0 += chunk) {
@@ -1193,14 +1347,17 @@ static int forward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int
         LstmClusterP L;
         for (int k = 0; k < nn; ++k) L.l[k] = l[k0 + k];
         const unsigned tag0 = (g_cluster_epoch++ & 0x3fffffu) * 1024u + 1u;
-        hipLaunchKernelGGL(lstm_fwd_cluster_kernel<CWG>, dim3(per, nn), dim3(512), lds, s, L, mask_tb, B, T, H, ldh, ldg, tag0, err);
+        hipLaunchKernelGGL((lstm_fwd_cluster_kernel<CWG, KXS>), dim3(per, nn), dim3(512), lds, s, L, mask_tb, B, T, H, ldh, ldg, tag0, err);
         ADN_HIP_CHECK(hipGetLastError());
     }
     return ADN_OK;
 }
 
 int lstm_forward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s) {
-    return H <= 256 ? forward_cluster<4>(l, n, mask_tb, B, T, H, s) : forward_cluster<8>(l, n, mask_tb, B, T, H, s);
+    if (H > 256) return forward_cluster<8, 0>(l, n, mask_tb, B, T, H, s);
+    if (fold_offered(l, n, H, B))
+        return fold_ksteps(l[0].Kx) == 3 ? forward_cluster<4, 3>(l, n, mask_tb, B, T, H, s) : forward_cluster<4, 5>(l, n, mask_tb, B, T, H, s);
+    return forward_cluster<4, 0>(l, n, mask_tb, B, T, H, s);
 }
 
 // bf16x3 forward (lstm_fwd_cluster_x3_kernel): H <= 256, hi and lo fragment images of W_hid, the exchange buffer of the bf16

@@ -293,9 +293,14 @@ __global__ __launch_bounds__(512) void lstm_bwd_persistent_kernel(const LstmLaun
                 sf += __shfl_xor(sf, 16, 64); sf += __shfl_xor(sf, 32, 64);
                 so += __shfl_xor(so, 16, 64); so += __shfl_xor(so, 32, 64);
                 if (kq == 0 && u < H) {
-                    atomicAdd(P.dpeep_part + u, si);
-                    atomicAdd(P.dpeep_part + ldh + u, sf);
-                    atomicAdd(P.dpeep_part + 2 * (size_t)ldh + u, so);
+                    if (P.det_ws) {                  // deterministic mode: this row slice's own slot, plain adds (one writer per address)
+                        float* ds = P.det_ws + (size_t)blockIdx.x * P.det_stride + ldg + 2 * ldh;
+                        ds[u] += si; ds[ldh + u] += sf; ds[2 * ldh + u] += so;
+                    } else {
+                        atomicAdd(P.dpeep_part + u, si);
+                        atomicAdd(P.dpeep_part + ldh + u, sf);
+                        atomicAdd(P.dpeep_part + 2 * (size_t)ldh + u, so);
+                    }
                 }
                 pw_i = pw_f = pw_o = 0.f;
             }

@@ -29,6 +29,13 @@ namespace adn {
 static thread_local std::string g_last_error;
 void set_error(const std::string& msg) { g_last_error = msg; }
 
+static int g_deterministic = -1;                     // -1: not decided yet (ADN_DETERMINISTIC at first use)
+bool deterministic() {
+    if (g_deterministic < 0) { const char* e = getenv("ADN_DETERMINISTIC"); g_deterministic = (e && *e && *e != '0') ? 1 : 0; }
+    return g_deterministic > 0;
+}
+void set_deterministic(bool on) { g_deterministic = on ? 1 : 0; }
+
 // ------------------------------------------------------------------------------------------
 // profiler
 // ------------------------------------------------------------------------------------------
@@ -101,6 +108,8 @@ struct LstmParams {      // physical tensors (float offsets into the flat buffer
     char* wfrag_bwd_lo = nullptr;   // ... of the backward image
     char* wfrag_fwd = nullptr; // ... and the two MFMA-fragment-ordered copies the persistent kernels stream
     char* wfrag_bwd = nullptr;
+    char* win_frag = nullptr;  // bf16 mode, stream LSTMs of <= 160 input features: MFMA-fragment image of W_in for the kernels that
+                               // compute their own input projection (lstm_pack_win_frags)
     char* wcat16 = nullptr;    // concat consumers: bf16 W_in with every input block padded to ldh rows ([S*ldh][ldg])
     char* wcat16lo = nullptr;  // ... its lo plane (bf16x3 mode)
     int fin = 0;
@@ -942,6 +951,22 @@ int refresh_params(adn_model* m) {
     };
     for (auto& st : m->st) for (auto& lp : st.lstm) ADN_TRY(pack(lp));
     for (auto& lp : m->agg) ADN_TRY(pack(lp));
+    // W_in images of the stream LSTMs whose forward kernel can multiply x_t W_in itself (lstm_cluster.hip, KXS > 0): one launch
+    // per input width
+    if (persistent && m->H <= 256) {
+        std::vector<int> widths;
+        for (auto& st : m->st) for (auto& lp : st.lstm) {
+            if (lstm_win_frag_elems(lp.fin, m->H) == 0) continue;
+            if (!lp.win_frag) ADN_HIP_CHECK(hipMalloc((void**)&lp.win_frag, lstm_win_frag_elems(lp.fin, m->H) * 2));
+            if (std::find(widths.begin(), widths.end(), lp.fin) == widths.end()) widths.push_back(lp.fin);
+        }
+        for (int wdt : widths) {
+            std::vector<const float*> wi; std::vector<void*> wo;
+            for (auto& st : m->st) for (auto& lp : st.lstm) if (lp.fin == wdt && lp.win_frag) { wi.push_back(m->P(lp.W_in)); wo.push_back(lp.win_frag); }
+            for (size_t k0 = 0; k0 < wi.size(); k0 += 8)
+                ADN_TRY(lstm_pack_win_frags((int)std::min<size_t>(8, wi.size() - k0), wi.data() + k0, wo.data() + k0, wdt, m->H, m->stream));
+        }
+    }
     for (size_t k0 = 0; k0 < fw.size(); k0 += 8)                 // every fragment image in one launch (per 8 LSTMs)
         ADN_TRY(lstm_pack_frags_batch((int)std::min<size_t>(8, fw.size() - k0), fw.data() + k0, ff.data() + k0, fb.data() + k0,
                                       m->H, m->stream));
@@ -1298,10 +1323,33 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
             }
             ADN_TRY(lstm_init_state(m, st.lstm[k], st.lw[k], B, T));
             steps.push_back(make_step(m, st.lstm[k], st.lw[k], nullptr, false));
+            if (grouped && m->bf16() && st.lstm[k].win_frag && m->shadow_of(st.feat)) {
+                // offer: the forward kernel may multiply x_t W_in + b itself (decided per launch group below)
+                LstmStep& q = steps.back();
+                q.x16 = m->shadow_of(st.feat); q.ld_x = ld[0]; q.Kx = st.feat_dim;
+                q.W_in_frag = st.lstm[k].win_frag; q.b_in = m->P(st.lstm[k].b);
+            }
         }
     }
     ADN_TRY(flush_deltas(m, B, T));
     ADN_TRY(join_streams(m));
+    if (grouped && stream_proj.size() == steps.size()) {
+        // launch groups as run_lstm_group forms them: where the kernel folds the projection in, its GEMM is dropped; elsewhere
+        // the offer is withdrawn, so that exactly one of the two computes it
+        std::vector<GemmArgs> kept;
+        for (size_t i = 0; i < steps.size(); i += kMaxLstmPerLaunch) {
+            const int n = (int)std::min<size_t>(kMaxLstmPerLaunch, steps.size() - i);
+            const bool fold = lstm_forward_folds_projection(steps.data() + i, n, B, T, m->H, m->lstm_precision());
+            for (int k = 0; k < n; ++k) {
+                if (fold) continue;
+                steps[i + k].x16 = nullptr; steps[i + k].W_in_frag = nullptr;
+                kept.push_back(stream_proj[i + k]);
+            }
+        }
+        stream_proj.swap(kept);
+    } else {
+        for (auto& q : steps) { q.x16 = nullptr; q.W_in_frag = nullptr; }
+    }
     ADN_TRY(issue_grouped(m, stream_proj));
     ADN_TRY(run_lstm_group(m, steps, B, T, false));
     for (auto& st : m->st) {
@@ -2102,6 +2150,7 @@ void adn_destroy(adn_model* m) {
         if (lp.wcat16) (void)hipFree(lp.wcat16);
         if (lp.wcat16lo) (void)hipFree(lp.wcat16lo);
         if (lp.wfrag_fwd) (void)hipFree(lp.wfrag_fwd);
+        if (lp.win_frag) (void)hipFree(lp.win_frag);
         if (lp.wfrag_bwd) (void)hipFree(lp.wfrag_bwd);
         if (lp.wfrag_fwd_lo) (void)hipFree(lp.wfrag_fwd_lo);
         if (lp.wfrag_bwd_lo) (void)hipFree(lp.wfrag_bwd_lo);
@@ -2475,6 +2524,9 @@ int adn_profile_read(adn_model* m, adn_profile_entry* out, int max_entries, int*
     *n_out = n;
     return ADN_OK;
 }
+
+int adn_set_deterministic(int on) { set_deterministic(on != 0); return ADN_OK; }
+int adn_get_deterministic(void) { return deterministic() ? 1 : 0; }
 
 int adn_debug_raise_exchange_error(int value) {
     int* word = nullptr;

@@ -68,7 +68,7 @@ def test_a_foreign_tenant_delays_the_weight_stationary_launches_and_does_not_bre
     crowded = one_pass()                                 # raises AdenetError (ADN_ERR_STATE) if a poll gave up
     t_crowded = time.perf_counter() - t0
     torch.cuda.synchronize()
-    assert t_crowded > 0.3 * hold_ms * 1e-3 and t_crowded > 3 * t_quiet, (t_quiet, t_crowded)      # it did run beside the tenant
+    assert t_crowded > t_quiet + 0.3 * hold_ms * 1e-3, (t_quiet, t_crowded)      # it did run beside the tenant
     assert t_crowded < 5.0                               # ... and nowhere near the 10 s poll time-out
     np.testing.assert_array_equal(crowded[0], quiet[0])
     assert abs(crowded[1] - quiet[1]) <= 1e-6 * abs(quiet[1])
