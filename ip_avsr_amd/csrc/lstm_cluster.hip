@@ -1305,7 +1305,8 @@ int lstm_pack_win_frags(int n, const float* const* W_in, void* const* out, int K
 //  per train step; B = 26 -- the GEMM is a 10 us launch there and the step's 20 extra MFMAs per wave sit on the exchange's
 //  critical path: 1.246 -> 1.263 ms.  Folded from three groups on; ADN_LSTM_FOLD_MIN_B moves the threshold.)
 static bool fold_offered(const LstmStep* l, int n, int H, int B) {
-    static const int min_b = getenv("ADN_LSTM_FOLD_MIN_B") ? atoi(getenv("ADN_LSTM_FOLD_MIN_B")) : 65;
+    const char* mb = getenv("ADN_LSTM_FOLD_MIN_B");          // (read per call: the tests move it)
+    const int min_b = mb ? atoi(mb) : 65;
     if (H > 256 || B < min_b || getenv("ADN_LSTM_NO_FOLD")) return false;
     const int kxs = fold_ksteps(l[0].Kx);
     if (!kxs) return false;

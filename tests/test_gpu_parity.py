@@ -763,6 +763,48 @@ def test_weight_stationary_lstm_edge_shapes(torch_cuda, lib, monkeypatch, B, T):
     assert np.abs((out["cluster"][0] - probs_ref) * valid).max() <= 3e-2
 
 
+@pytest.mark.parametrize("feat,B,T,bidir", [(6, 70, 13, True), (50, 70, 9, False), (50, 33, 1, True), (30, 9, 2, False), (50, 200, 5, True)])
+def test_folded_input_projection_equals_the_projection_gemm(torch_cuda, lib, monkeypatch, feat, B, T, bidir):
+    """bf16 mode, H <= 256: the weight-stationary forward kernel multiplies x_t W_in + b itself (csrc/lstm_cluster.hip, KXS = 3 for
+    up to 96 input features, 5 for up to 160 -- the 3 x 50 delta features of an encoder stream) instead of reading a projection a
+    GEMM wrote.  Same bf16 operands, fp32 accumulation over the k-steps in order, bias last: identical probabilities, the same
+    gradients (the backward pass is untouched), in both directions of a BLSTM stream, on ragged masks, at T = 1 / 2 (pipeline
+    fill only) and across several 32-utterance groups; both against the oracle."""
+    from ip_avsr_amd.model import AdeNetModel
+    spec = dict(O.spec_nstream([20, 14], enc_shapes=(24, feat), enc_acts=("rectify", "linear"), lstm_size=40, classes=5,
+                               fusion="concat", peepholes=True), precision="bf16")
+    if bidir:                                        # summed forward / backward pair per stream (use_blstm_substream)
+        for k, st in enumerate(spec["streams"]):
+            st["lstm_names"] = ["f_lstm_s%d" % (k + 1), "b_lstm_s%d" % (k + 1)]
+    p, inputs, y, mask = make_case(spec, B, T, seed=7 * feat + B)
+    out = {}
+    for mode in ("fold", "gemm"):
+        monkeypatch.setenv("ADN_LSTM_FOLD_MIN_B", "1")
+        if mode == "gemm":
+            monkeypatch.setenv("ADN_LSTM_NO_FOLD", "1")
+        else:
+            monkeypatch.delenv("ADN_LSTM_NO_FOLD", raising=False)
+        m = AdeNetModel(spec)
+        m.set_params_dict(p)
+        probs = m.predict(inputs, mask, 2)
+        probs2 = m.predict(inputs, mask, 2)
+        loss = m.compute_grads(inputs, y, mask, 2)
+        out[mode] = (probs, loss, m.get_grads_dict())
+        np.testing.assert_array_equal(probs, probs2)
+        m.close()
+    monkeypatch.delenv("ADN_LSTM_NO_FOLD", raising=False)
+    monkeypatch.delenv("ADN_LSTM_FOLD_MIN_B", raising=False)
+    valid = mask[..., None].astype(bool)
+    assert np.abs((out["fold"][0] - out["gemm"][0]) * valid).max() <= 1e-6
+    assert abs(out["fold"][1] - out["gemm"][1]) <= 1e-6 * abs(out["gemm"][1])
+    for k, g in out["fold"][2].items():
+        ref = out["gemm"][2][k]
+        assert np.abs(g - ref).max() <= 2e-3 * max(np.abs(ref).max(), 1e-6), k
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    probs_ref = O.forward(spec, p64, [x.astype(np.float64) for x in inputs], mask, 2)
+    assert np.abs((out["fold"][0] - probs_ref) * valid).max() <= 3e-2
+
+
 @pytest.mark.parametrize("B,T", [(1, 1), (33, 2)])
 def test_wide_weight_stationary_lstm_edge_shapes(torch_cuda, lib, monkeypatch, B, T):
     """The 8-workgroup kernels (256 < H <= 512) at the same edges, against the one-workgroup kernel."""
