@@ -89,6 +89,16 @@ class DataParallel(object):
                     self.launches[-1].append(k)
                 else:
                     self.launches.append([k])
+            # Two collectives per step by default: everything that is final before the encoders' first layer (tops, classifier,
+            # layers L-1 .. 1: 43 of 72 MB for the bench model) goes out as ONE grouped collective behind layer 1's weight
+            # gradients -- layer 0's input-free backward (its weight-gradient GEMM, 0.24 ms) covers it -- and layer 0 as the
+            # second.  One event, one collective and one cross-stream wait per release point cost a single rank +0.17 ms per
+            # step (6 points, profiles/r03/dp_forced.txt) before any byte moves; at 8 ranks 43 MB are ~0.2 ms of xGMI time,
+            # which the one layer still to run hides as well as five earlier starts did.  ADN_DP_FINE_BUCKETS=1: one
+            # collective per release point (round 3's schedule).
+            if len(self.launches) > 2 and not os.environ.get("ADN_DP_FINE_BUCKETS") and not os.environ.get("ADN_DP_NO_COALESCE"):
+                head = [k for idxs in self.launches[:-1] for k in idxs]
+                self.launches = [head, self.launches[-1]]
         if self.overlap and self.on_device:
             import torch
             self._torch = torch
