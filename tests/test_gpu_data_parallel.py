@@ -310,3 +310,49 @@ def test_ranged_adam_equals_whole_buffer_adam_on_the_device(precision):
     la, lb = float(a.loss(xs, y, mask, 2)), float(b.loss(xs, y, mask, 2))   # (a stale bf16 shadow would show at ~1e-3)
     assert abs(la - lb) <= 2e-6 * abs(la)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("precision,world", [("f32", 2), ("bf16", 3)])
+def test_ranks_sharing_one_gpu_equal_the_single_process_run(tmp_path, precision, world):
+    """More than one rank with the real kernels (no multi-GPU node was ever available: this is as close as one GPU gets).  N
+    processes share cuda:0 under gloo; each gathers ITS rows of every global minibatch on the GPU from its own resident copy of
+    the split, back-propagates with the global frame count, all-reduces bucket by bucket on a communication stream and applies
+    the ranged Adam -- the weight-stationary LSTM launches of the processes run beside each other (tests/test_gpu_residency.py:
+    tenants delay, they do not deadlock).  After six steps (one of them the short last batch of a pass: 9 utterances over the
+    ranks) every rank holds the same parameters, equal to a single process training on the whole minibatches up to summation
+    order."""
+    import subprocess
+    import sys
+    import torch
+    from tests import dp_worker_one_gpu as W
+    from ip_avsr_amd.model import AdeNetModel
+    from ip_avsr_amd.utils.datagen_gpu import DeviceSplit
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29540 + world
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
+                    "--master-port", str(port), os.path.join(root, "tests", "dp_worker_one_gpu.py"), str(tmp_path), precision],
+                   check=True, cwd=root, env=env, timeout=900)
+    torch.cuda.set_device(0)
+    spec, p, streams, y, lens = W.case()
+    spec["precision"] = precision
+    m = AdeNetModel(spec)
+    m.set_params_dict(p)
+    single = W.train(m, DeviceSplit(streams, y, lens), 6, 10)
+    m.close()
+    ranks = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    # (Adam turns a gradient element at noise level into a +-lr step with the noise's sign: the comparison is on the UPDATE as a
+    #  whole -- relative L2 per tensor -- not on single elements; the shards' sums differ from the whole batch's in fp32
+    #  summation order only)
+    tol = 2e-2 if precision == "f32" else 0.2
+    trained = 0
+    for k, v in single.items():
+        for r in range(1, world):
+            np.testing.assert_array_equal(ranks[r][k], ranks[0][k], err_msg="replicas diverged: " + k)
+        upd = np.linalg.norm((v - p[k]).ravel().astype(np.float64))
+        if upd < 1e-6:
+            continue
+        trained += 1
+        err = np.linalg.norm((ranks[0][k] - v).ravel().astype(np.float64))
+        assert err <= tol * upd, (k, err, upd)
+    assert trained >= len(single) - 6                    # the steps did train
