@@ -146,6 +146,32 @@ __global__ __launch_bounds__(256) void col2im4_kernel(const float4* __restrict__
 
 // im2col straight to bf16 (C % 4 == 0): the patches matrix of the bf16 GEMMs, half the bytes of the fp32 one
 typedef __bf16 cae_bf16x4 __attribute__((ext_vector_type(4)));
+
+// col2im4_kernel reading a bf16 matrix (round 4): the product dy Wm^T leaves its GEMM as bf16 only -- the largest one, the
+// input gradient of the second convolution at batch 1024, is 1.29 GB as fp32 -- and is summed here in fp32
+__global__ __launch_bounds__(256) void col2im4_bf16_kernel(const cae_bf16x4* __restrict__ dcols, int ldc4, float4* __restrict__ out, int B,
+                                                           int H, int W, int C4, int kh, int kw, int ph, int pw, int OH, int OW,
+                                                           const float4* __restrict__ bias, int act, int up) {
+    const int64_t total = (int64_t)B * H * W * C4;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % C4);
+        const int64_t p = e / C4;
+        const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((int64_t)W * H));
+        float4 acc = bias ? bias[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < kh; ++i) {
+            const int oy = y + ph - i;
+            if (oy < 0 || oy >= OH) continue;
+            for (int j = 0; j < kw; ++j) {
+                const int ox = x + pw - j;
+                if (ox < 0 || ox >= OW) continue;
+                const cae_bf16x4 v = dcols[(up ? ((size_t)b * (OH / 2) + oy / 2) * (OW / 2) + ox / 2 : ((size_t)b * OH + oy) * OW + ox) * ldc4 + (i * kw + j) * C4 + c];
+                acc.x += (float)v[0]; acc.y += (float)v[1]; acc.z += (float)v[2]; acc.w += (float)v[3];
+            }
+        }
+        acc.x = cae_act(act, acc.x); acc.y = cae_act(act, acc.y); acc.z = cae_act(act, acc.z); acc.w = cae_act(act, acc.w);
+        out[e] = acc;
+    }
+}
 __global__ __launch_bounds__(256) void im2col4_bf16_kernel(const float4* __restrict__ x, cae_bf16x4* __restrict__ cols, int B, int H,
                                                            int W, int C4, int kh, int kw, int ph, int pw, int OH, int OW, int ldc4, int up) {
     const int K4 = kh * kw * C4;
@@ -215,6 +241,50 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
         }
         if (act_y && g != 0.f) g *= cae_act_grad(act, act_y[e]);
         dx[e] = g;
+    }
+}
+
+// The same adjoint from the POOLED side (round 4; 2 x 2 windows that tile the padded input exactly, C % 4 == 0): one thread per
+// (pooled position, 4 channels) writes its window -- the winner gets dy * act'(.), the other three positions zero.  act' comes
+// from the pooled VALUE (the activation is applied before the pooling, so the pooled value is the winner's activation): the
+// full-resolution activation tensor is not read at all (383 MB at batch 1024 for the first convolution).  Also leaves, in the
+// same pass, the bf16 copy of the gradient that the convolution's backward GEMMs read (dx16) and the bias gradient: the column
+// sums of the full-resolution gradient are the column sums of the winners, accumulated per workgroup in LDS and added with one
+// float atomic per channel and workgroup (dbias; null in deterministic mode: the caller sums the columns instead).
+__global__ __launch_bounds__(256) void maxpool_bwd_pooled_kernel(const float4* __restrict__ dy, const uchar4* __restrict__ arg,
+                                                                 const float4* __restrict__ pooled, float4* __restrict__ dx,
+                                                                 cae_bf16x4* __restrict__ dx16, float* __restrict__ dbias, int B, int H,
+                                                                 int W, int C4, int ph, int OH, int OW, int act) {
+    extern __shared__ float csum[];                  // [4 C4]
+    for (int c = threadIdx.x; c < 4 * C4; c += 256) csum[c] = 0.f;
+    __syncthreads();
+    const int64_t total = (int64_t)B * OH * OW * C4;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % C4);
+        const int64_t p = e / C4;
+        const int ox = (int)(p % OW), oy = (int)((p / OW) % OH), b = (int)(p / ((int64_t)OW * OH));
+        float4 g = dy[e];
+        const uchar4 a = arg[e];
+        if (pooled) {
+            const float4 y = pooled[e];
+            g.x *= cae_act_grad(act, y.x); g.y *= cae_act_grad(act, y.y); g.z *= cae_act_grad(act, y.z); g.w *= cae_act_grad(act, y.w);
+        }
+        if (dbias) {
+            atomicAdd(&csum[4 * c], g.x); atomicAdd(&csum[4 * c + 1], g.y); atomicAdd(&csum[4 * c + 2], g.z); atomicAdd(&csum[4 * c + 3], g.w);
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int yy = 2 * oy + (d >> 1) - ph, xx = 2 * ox + (d & 1);
+            if (yy < 0 || yy >= H || xx >= W) continue;
+            const float4 v = make_float4(a.x == d ? g.x : 0.f, a.y == d ? g.y : 0.f, a.z == d ? g.z : 0.f, a.w == d ? g.w : 0.f);
+            const size_t o = (((size_t)b * H + yy) * W + xx) * C4 + c;
+            dx[o] = v;
+            if (dx16) { cae_bf16x4 h; h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w; dx16[o] = h; }
+        }
+    }
+    if (dbias) {
+        __syncthreads();
+        for (int c = threadIdx.x; c < 4 * C4; c += 256) if (csum[c] != 0.f) atomicAdd(dbias + c, csum[c]);
     }
 }
 
@@ -445,6 +515,25 @@ int col2im(adn_cae* m, const float* dcols, const ConvGeom& g, int B, float* out,
     return ADN_OK;
 }
 
+int col2im16(adn_cae* m, const void* dcols16, const ConvGeom& g, int B, float* out, const float* bias, int act, int up = 0) {
+    const int64_t total = (int64_t)B * g.H * g.W * g.C;
+    hipLaunchKernelGGL(col2im4_bf16_kernel, dim3(grid_of(total / 4)), dim3(256), 0, m->stream, reinterpret_cast<const cae_bf16x4*>(dcols16),
+                       g.ldk / 4, reinterpret_cast<float4*>(out), B, g.H, g.W, g.C / 4, g.k, g.k, g.ph, g.pw, g.OH, g.OW,
+                       reinterpret_cast<const float4*>(bias), act, up);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+// a product whose only reader takes bf16: the GEMM writes the bf16 matrix alone (no fp32 copy)
+int mm16_lean(adn_cae* m, int layout, int M, int N, int K, const void* A16, int lda, const void* B16, int ldb, void* C16, int ldc) {
+    GemmArgs g;
+    g.layout = layout; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.C = nullptr; g.C16 = C16; g.ldc = ldc;
+    g.A = reinterpret_cast<const float*>(A16); g.B = reinterpret_cast<const float*>(B16);
+    g.A16 = A16; g.B16 = B16; g.precision = ADN_PRECISION_BF16;
+    return gemm(g, m->stream);
+}
+static bool lean_scratch() { static const bool off = getenv("ADN_CAE_FP32_SCRATCH") != nullptr; return !off; }   // (A/B switch)
+
 // y = act(conv(x) + b): patches kept in `cols` for the backward pass
 int conv_fwd(adn_cae* m, const float* x, const ConvGeom& g, int B, float* cols, size_t W, size_t b, float* y) {
     if (fast16(m, g)) {                              // `cols` holds the bf16 patches matrix in this mode
@@ -455,16 +544,22 @@ int conv_fwd(adn_cae* m, const float* x, const ConvGeom& g, int B, float* cols, 
     return mm(m, GEMM_NN, (int)rows_of(g, B), g.O, g.K, cols, g.ldk, m->P(W), g.O, y, g.O, m->P(b), m->S);
 }
 
-// dy (already multiplied by act') -> dW, db, and (optionally) dx
-int conv_bwd(adn_cae* m, const ConvGeom& g, int B, const float* cols, const float* dy, size_t W, size_t b, float* dx) {
+// dy (already multiplied by act') -> dW, db, and (optionally) dx.  `ready`: the pass that produced dy already left its bf16 copy
+// in t16 and added the bias gradient (maxpool_bwd's pooled-grid form)
+int conv_bwd(adn_cae* m, const ConvGeom& g, int B, const float* cols, const float* dy, size_t W, size_t b, float* dx, bool ready = false) {
     const int R = (int)rows_of(g, B);
     if (fast16(m, g)) {
-        ADN_TRY(to_bf16(dy, m->t16, (size_t)R * g.O, m->stream));
+        if (!ready) ADN_TRY(to_bf16(dy, m->t16, (size_t)R * g.O, m->stream));
         ADN_TRY(mm16(m, GEMM_TN, g.K, g.O, R, cols, g.ldk, m->t16, g.O, m->G(W), g.O, nullptr, ADN_ACT_LINEAR, 1));
-        ADN_TRY(col_sum(dy, g.O, R, g.O, m->G(b), 1, m->stream));
+        if (!ready) ADN_TRY(col_sum(dy, g.O, R, g.O, m->G(b), 1, m->stream));
         if (dx) {
-            ADN_TRY(mm16(m, GEMM_NT, R, g.K, g.O, m->t16, g.O, W16(m, W), g.O, m->scratch, g.ldk));
-            ADN_TRY(col2im(m, m->scratch, g, B, dx, nullptr, ADN_ACT_LINEAR));
+            if (lean_scratch()) {                    // dy Wm^T as bf16 only: its one reader sums it in fp32
+                ADN_TRY(mm16_lean(m, GEMM_NT, R, g.K, g.O, m->t16, g.O, W16(m, W), g.O, m->scratch, g.ldk));
+                ADN_TRY(col2im16(m, m->scratch, g, B, dx, nullptr, ADN_ACT_LINEAR));
+            } else {
+                ADN_TRY(mm16(m, GEMM_NT, R, g.K, g.O, m->t16, g.O, W16(m, W), g.O, m->scratch, g.ldk));
+                ADN_TRY(col2im(m, m->scratch, g, B, dx, nullptr, ADN_ACT_LINEAR));
+            }
         }
         return ADN_OK;
     }
@@ -487,6 +582,10 @@ int deconv_fwd(adn_cae* m, const float* x, void* x16, const ConvGeom& g, int B, 
     const int R = (int)rows_of(g, B) / (up ? 4 : 1);
     if (x16 && fast16(m, g)) {
         ADN_TRY(to_bf16(x, x16, (size_t)R * g.O, m->stream));
+        if (lean_scratch()) {
+            ADN_TRY(mm16_lean(m, GEMM_NT, R, g.K, g.O, x16, g.O, W16(m, W), g.O, m->scratch, g.ldk));
+            return col2im16(m, m->scratch, g, B, z, m->P(b), m->S, up);
+        }
         ADN_TRY(mm16(m, GEMM_NT, R, g.K, g.O, x16, g.O, W16(m, W), g.O, m->scratch, g.ldk));
         return col2im(m, m->scratch, g, B, z, m->P(b), m->S, up);
     }
@@ -516,8 +615,25 @@ int maxpool_fwd(adn_cae* m, const float* x, int B, int H, int W, int C, int ph, 
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }
+// `pooled` (optional): the pooling's OUTPUT, still as the forward pass wrote it -- act' is then taken from it (the pooled value is
+// the winner's activation) instead of from the full-resolution activation act_y.  `dbias` / `*ready`: bf16 mode, the pooled-grid
+// kernel also leaves the gradient's bf16 copy in t16 and adds the bias gradient; conv_bwd then skips both passes
 int maxpool_bwd(adn_cae* m, const float* dy, const uint8_t* arg, int B, int H, int W, int C, int ph, int OH, int OW, float* dx,
-                const float* act_y = nullptr) {
+                const float* act_y = nullptr, const float* pooled = nullptr, float* dbias = nullptr, bool* ready = nullptr) {
+    if (ready) *ready = false;
+    static const bool old_form = getenv("ADN_CAE_POOL_BWD_FULL") != nullptr;      // (A/B switch)
+    const bool tiles = 2 * OH - ph >= H && 2 * OW >= W && C % 4 == 0;
+    if (tiles && !old_form && (pooled || !act_y)) {
+        const bool fuse = dbias && ready && m->precision == ADN_PRECISION_BF16 && !deterministic();
+        const int64_t total = (int64_t)B * OH * OW * (C / 4);
+        hipLaunchKernelGGL(maxpool_bwd_pooled_kernel, dim3(grid_of(total)), dim3(256), (size_t)C * sizeof(float), m->stream,
+                           reinterpret_cast<const float4*>(dy), reinterpret_cast<const uchar4*>(arg), reinterpret_cast<const float4*>(pooled),
+                           reinterpret_cast<float4*>(dx), fuse ? reinterpret_cast<cae_bf16x4*>(m->t16) : nullptr, fuse ? dbias : nullptr,
+                           B, H, W, C / 4, ph, OH, OW, m->S);
+        ADN_HIP_CHECK(hipGetLastError());
+        if (fuse) *ready = true;
+        return ADN_OK;
+    }
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_of((int64_t)B * H * W * C)), dim3(256), 0, m->stream, dy, arg, dx, B, H, W, C, ph, OH, OW,
                        act_y, m->S);
     ADN_HIP_CHECK(hipGetLastError());
@@ -666,15 +782,21 @@ int backward(adn_cae* m, int B) {
     ADN_TRY(dropout_inplace(m, 2, gA, P4, m->p4h * m->p4w, m->F2L, F2));
     if (m->bn_mode == 1) ADN_TRY(bn_bwd(m, 1, m->p4, gA, P4));                             // gA = d p4
     // (the pooling's input is the activation itself unless a BatchNorm sits between them: act' rides on the pooling's backward)
-    ADN_TRY(maxpool_bwd(m, gA, m->arg4, B, m->c3.OH, m->c3.OW, F2, 1, m->p4h, m->p4w, gB, m->bn_mode == 2 ? nullptr : m->a3));   // gB = d (pool input)
+    // (the pooled tensor still holds the winners' activations unless a dropout layer rescaled it in place)
+    const bool pooled_intact = !(m->drop && m->training && m->bn_mode == 0);
+    bool ready3 = false, ready1 = false;
+    ADN_TRY(maxpool_bwd(m, gA, m->arg4, B, m->c3.OH, m->c3.OW, F2, 1, m->p4h, m->p4w, gB, m->bn_mode == 2 ? nullptr : m->a3,
+                        (m->bn_mode != 2 && pooled_intact) ? m->p4 : nullptr, m->bn_mode == 2 ? nullptr : m->G(m->b3), &ready3));   // gB = d (pool input)
     if (m->bn_mode == 2) {
         ADN_TRY(bn_bwd(m, 1, m->a3, gB, R3));                                             // gB = d a3
         ADN_TRY(act_backward(gB, F2, m->a3, F2, R3, F2, S, s));
     }
-    ADN_TRY(conv_bwd(m, m->c3, B, m->cols3, gB, m->W3, m->b3, gA));                       // gA = d (conv3 input)
+    ADN_TRY(conv_bwd(m, m->c3, B, m->cols3, gB, m->W3, m->b3, gA, ready3 && fast16(m, m->c3)));   // gA = d (conv3 input)
     ADN_TRY(dropout_inplace(m, 1, gA, P2, m->p2h * m->p2w, m->F1L, F1));
     if (m->bn_mode == 1) ADN_TRY(bn_bwd(m, 0, m->p2, gA, P2));                             // gA = d p2
-    ADN_TRY(maxpool_bwd(m, gA, m->arg2, B, m->c1.OH, m->c1.OW, F1, 0, m->p2h, m->p2w, gB, m->bn_mode == 2 ? nullptr : m->a1));   // gB = d (pool input)
+    // (conv1 is not a bf16-operand layer (C_in = 1): only the activation read is saved there, the sums stay with conv_bwd)
+    ADN_TRY(maxpool_bwd(m, gA, m->arg2, B, m->c1.OH, m->c1.OW, F1, 0, m->p2h, m->p2w, gB, m->bn_mode == 2 ? nullptr : m->a1,
+                        (m->bn_mode != 2 && pooled_intact) ? m->p2 : nullptr, nullptr, &ready1));   // gB = d (pool input)
     if (m->bn_mode == 2) {
         ADN_TRY(bn_bwd(m, 0, m->a1, gB, R1));                                             // gB = d a1
         ADN_TRY(act_backward(gB, F1, m->a1, F1, R1, F1, S, s));

@@ -273,3 +273,32 @@ def test_variant_zoo_factories_and_trainer(ConvAE, tmp_path):
     assert os.path.exists(prefix + "_ae.dat") and os.path.exists(prefix + "_encoder.dat")
     assert np.isfinite(out["costs"]).all() and np.isfinite(out["val_costs"]).all()
     out["network"].close()
+
+
+@pytest.mark.parametrize("variant", ["normal", "batchnorm", "dropout", "bn+dropout"])
+@pytest.mark.parametrize("stochastic", [False, True])
+def test_bf16_gradients_follow_the_f32_ones_in_every_variant(ConvAE, variant, stochastic):
+    """bf16 mode (round 4: the pooling's adjoint from the pooled grid with act' from the pooled values, fused bias sums and the
+    gradient's bf16 copy; the input gradients' patch matrices as bf16 only) against f32 mode from the same parameters, masks and
+    batch statistics: every gradient tensor points the same way (cosine) with the same length, also with dropout rescaling the
+    pooled tensors in place (the path that must NOT read act' from them)."""
+    rng = np.random.default_rng(5)
+    hw, dense, nb, B = (30, 40), 120, 20, 6
+    p = CO.init_params(rng, np.float32, dense=dense, bottleneck=nb, image_hw=hw, bias_noise=0.05, variant=variant)
+    x = np.tanh(rng.normal(size=(B, hw[0] * hw[1]))).astype(np.float32)
+    out = {}
+    for prec in ("f32", "bf16"):
+        m = ConvAE(hw, dense, nb, precision=prec, variant=variant)
+        m.set_params_dict(p)
+        m.set_dropout_state(77, 3)
+        loss = m.compute_grads(x, deterministic=not stochastic)
+        out[prec] = (float(loss), m.get_grads_dict())
+        m.close()
+    assert abs(out["bf16"][0] - out["f32"][0]) <= 3e-2 * out["f32"][0]
+    for k, g in out["f32"][1].items():
+        a, b = g.ravel().astype(np.float64), out["bf16"][1][k].ravel().astype(np.float64)
+        if np.linalg.norm(a) < 1e-12:
+            assert np.linalg.norm(b) < 1e-9, k
+            continue
+        cos = a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)
+        assert cos > 0.985 and abs(np.linalg.norm(b) / np.linalg.norm(a) - 1) < 0.1, (variant, k, cos, np.linalg.norm(b) / np.linalg.norm(a))
