@@ -122,6 +122,9 @@ struct GemmArgs {
                                        // into) the pad columns of C up to round_up(N, 4)
     int* fp32_skipped = nullptr;       // (out) lean_ok was used: C was NOT written, the result lives in its planes only
     int lean_ok = 0;               // ... and nobody reads the fp32 C then: the kernel that writes both planes skips it
+    int pp_force = 0;              // take the persistent ping-pong kernel wherever it CAN run (validity checks only), not only where
+                                   // the selection measured on the AdeNet shapes says it pays: narrow outputs under very many rows
+                                   // (the conv auto-encoder's 129024 x 152 x 2504), whose alternative is the register-staged kernel
     // split-K workspace of the persistent ping-pong kernel (partial tiles as plain stores + a reduce pass instead of
     // float atomics); without it large weight-gradient GEMMs stay on the atomic split-K kernels
     float* splitk_ws = nullptr; size_t splitk_ws_floats = 0;

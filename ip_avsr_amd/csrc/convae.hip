@@ -357,7 +357,8 @@ struct adn_cae {
     float *x0 = nullptr, *cols1 = nullptr, *a1 = nullptr, *p2 = nullptr, *cols3 = nullptr, *a3 = nullptr, *p4 = nullptr,
           *cols5 = nullptr, *a5 = nullptr, *a7 = nullptr, *code = nullptr, *a8 = nullptr, *a9 = nullptr, *a11 = nullptr,
           *a13 = nullptr, *a15 = nullptr, *target = nullptr, *scratch = nullptr,
-          *gA = nullptr, *gB = nullptr, *loss_dev = nullptr, *f6d = nullptr, *a7d = nullptr;
+          *gA = nullptr, *gB = nullptr, *loss_dev = nullptr, *f6d = nullptr, *a7d = nullptr, *splitk = nullptr;
+    size_t splitk_floats = 0;               // split-K slabs of the ping-pong kernel (mm16 with pp)
     // what each layer actually read in the last forward pass (the BatchNorm output where one sits in front of it)
     const float *in3 = nullptr, *in5 = nullptr, *in7 = nullptr, *inb = nullptr;
     uint8_t *arg2 = nullptr, *arg4 = nullptr;
@@ -423,6 +424,8 @@ size_t carve(adn_cae* m, char* base, int B) {
     m->scratch = c.take<float>(sc);
     m->gA = c.take<float>(act); m->gB = c.take<float>(act);
     m->loss_dev = c.take<float>(8);
+    m->splitk_floats = std::max<size_t>((size_t)16 << 20, N * 16384);     // (25 slabs of 2504 x 152; 2 of 32256 x 152 at batch 1024)
+    m->splitk = c.take<float>(m->splitk_floats);
     m->a9_16 = c.take<char>(N * m->flat * 2);
     m->u12_16 = c.take<char>(N * m->d11.H * m->d11.W * m->F2 * 2);           // bf16 copy of a11 (the compact input of deconv2d13)
     m->t16 = c.take<char>(act * 2);
@@ -468,13 +471,17 @@ bool fast16(const adn_cae* m, const ConvGeom& g) {
 }
 const void* W16(const adn_cae* m, size_t off) { return m->p16 + off * 2; }
 
+// pp: the persistent ping-pong kernel wherever it can run (GemmArgs::pp_force) -- the auto-encoder's big products are narrow
+// (100 - 200 output channels) under very many rows, a shape the AdeNet-tuned selection leaves to the register-staged kernels
 int mm16(adn_cae* m, int layout, int M, int N, int K, const void* A16, int lda, const void* B16, int ldb, float* C, int ldc,
-         const float* bias = nullptr, int act = ADN_ACT_LINEAR, int accumulate = 0) {
+         const float* bias = nullptr, int act = ADN_ACT_LINEAR, int accumulate = 0, bool pp = false) {
+    static const bool no_pp = getenv("ADN_CAE_NO_PP") != nullptr;       // (A/B switch)
     GemmArgs g;
     g.layout = layout; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.A = reinterpret_cast<const float*>(A16); g.B = reinterpret_cast<const float*>(B16);      // (only the bf16 views are read)
     g.A16 = A16; g.B16 = B16;
     g.bias = bias; g.act = act; g.accumulate = accumulate; g.precision = ADN_PRECISION_BF16;
+    if (pp && !no_pp) { g.pp_force = 1; g.splitk_ws = m->splitk; g.splitk_ws_floats = m->splitk_floats; }
     return gemm(g, m->stream);
 }
 
@@ -550,7 +557,7 @@ int conv_bwd(adn_cae* m, const ConvGeom& g, int B, const float* cols, const floa
     const int R = (int)rows_of(g, B);
     if (fast16(m, g)) {
         if (!ready) ADN_TRY(to_bf16(dy, m->t16, (size_t)R * g.O, m->stream));
-        ADN_TRY(mm16(m, GEMM_TN, g.K, g.O, R, cols, g.ldk, m->t16, g.O, m->G(W), g.O, nullptr, ADN_ACT_LINEAR, 1));
+        ADN_TRY(mm16(m, GEMM_TN, g.K, g.O, R, cols, g.ldk, m->t16, g.O, m->G(W), g.O, nullptr, ADN_ACT_LINEAR, 1, true));
         if (!ready) ADN_TRY(col_sum(dy, g.O, R, g.O, m->G(b), 1, m->stream));
         if (dx) {
             if (lean_scratch()) {                    // dy Wm^T as bf16 only: its one reader sums it in fp32
@@ -602,8 +609,8 @@ int deconv_bwd(adn_cae* m, const ConvGeom& g, int B, const float* x, const void*
     ADN_TRY(col_sum(dz, g.C, B * g.H * g.W, g.C, m->G(b), 1, m->stream));
     if (x16 && fast16(m, g)) {
         ADN_TRY(im2col16(m, dz, g, B, m->scratch, up));
-        ADN_TRY(mm16(m, GEMM_NN, R, g.O, g.K, m->scratch, g.ldk, W16(m, W), g.O, dx, g.O));
-        return mm16(m, GEMM_TN, g.K, g.O, R, m->scratch, g.ldk, x16, g.O, m->G(W), g.O, nullptr, ADN_ACT_LINEAR, 1);
+        ADN_TRY(mm16(m, GEMM_NN, R, g.O, g.K, m->scratch, g.ldk, W16(m, W), g.O, dx, g.O, nullptr, ADN_ACT_LINEAR, 0, true));
+        return mm16(m, GEMM_TN, g.K, g.O, R, m->scratch, g.ldk, x16, g.O, m->G(W), g.O, nullptr, ADN_ACT_LINEAR, 1, true);
     }
     ADN_TRY(im2col(m, dz, g, B, m->scratch, up));
     ADN_TRY(mm(m, GEMM_NN, R, g.O, g.K, m->scratch, g.ldk, m->P(W), g.O, dx, g.O));

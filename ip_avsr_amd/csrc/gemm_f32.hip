@@ -227,7 +227,7 @@ static int gemm_pp_try_impl(const GemmArgs* gs, int n, const GemmArgs& g, int ks
     // (narrow outputs: a 150-column input gradient fills 59 % of its one tile column -- over planes still 2.6x the register-staged
     //  kernel's rate on split images, 232 -> 9x us for the three streams' 20800 x 150 x 1000)
     static const int min_n_env = getenv("ADN_GEMM_PP_MIN_N") ? atoi(getenv("ADN_GEMM_PP_MIN_N")) : 0;
-    const int min_n = min_n_env ? min_n_env : (kseg ? 128 : 256);
+    const int min_n = g.pp_force ? 96 : (min_n_env ? min_n_env : (kseg ? 128 : 256));
     if (g.M < (n >= 2 ? 128 : 256) || g.N < min_n || g.K < 256) return ADN_OK;
     if (g.N % 4 || g.ldc % 4 || g.lda % 8 || g.ldb % 8) return ADN_OK;
     if (g.layout == GEMM_NN && g.K % 8 && g.lda < round_up(g.K, 8)) return ADN_OK;
@@ -243,7 +243,7 @@ static int gemm_pp_try_impl(const GemmArgs* gs, int n, const GemmArgs& g, int ks
         if ((q.A16lo == nullptr) != (gs[0].A16lo == nullptr) || (q.B16lo == nullptr) != (gs[0].B16lo == nullptr)) return ADN_OK;
         if (q.M != g.M || q.N != g.N || q.K != gs[0].K || q.lda != g.lda || q.ldb != g.ldb || q.ldc != g.ldc || q.ldy != g.ldy ||
             q.layout != g.layout || q.act != g.act || q.act_grad != g.act_grad || q.accumulate != g.accumulate ||
-            q.no_split != g.no_split || (q.C == nullptr) != (g.C == nullptr) || (q.C16 == nullptr) != (g.C16 == nullptr) ||
+            q.no_split != g.no_split || q.pp_force != g.pp_force || (q.C == nullptr) != (g.C == nullptr) || (q.C16 == nullptr) != (g.C16 == nullptr) ||
             (q.bias == nullptr) != (g.bias == nullptr) || (q.Y16 == nullptr) != (g.Y16 == nullptr) ||
             (q.Y == nullptr) != (g.Y == nullptr) || (q.colsum == nullptr) != (g.colsum == nullptr))
             return ADN_OK;
@@ -279,7 +279,7 @@ static int gemm_pp_try_impl(const GemmArgs* gs, int n, const GemmArgs& g, int ks
         if (best < 0 || cost < best_cost) { best = c; best_cost = cost; splits = sp; }
     }
     if (best < 0) return ADN_OK;
-    if (mode_env < 4) {
+    if (mode_env < 4 && !g.pp_force) {
         const double fill = ((double)g.M * g.N * n / cus) / best_cost;       // useful share of the tile-rounds
         const bool plain = !g.Y && !g.Y16 && !g.colsum;
         // (several weight gradients in one launch only when each alone has too few tiles to split well: three 1000 x 500
