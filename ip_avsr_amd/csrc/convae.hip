@@ -196,8 +196,10 @@ __global__ __launch_bounds__(256) void im2col4_bf16_kernel(const float4* __restr
 }
 
 // 2x2 / stride 2 max pooling, ignore_border, `ph` rows of padding above and below that never win; code = dy*2 + dx
+// post_act != LINEAR: x holds PRE-activations and the (monotone) activation is applied to the maximum -- pool(act(x)) = act(pool(x)),
+// on a quarter of the elements -- so that the convolution in front runs with a plain bias epilogue
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ arg,
-                                                          int B, int H, int W, int C, int ph, int OH, int OW) {
+                                                          int B, int H, int W, int C, int ph, int OH, int OW, int post_act) {
     const int64_t total = (int64_t)B * OH * OW * C;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int c = (int)(e % C);
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
                 if (v > best) { best = v; code = dy * 2 + dx; }
             }
         }
-        y[e] = best; arg[e] = (uint8_t)code;
+        y[e] = cae_act(post_act, best); arg[e] = (uint8_t)code;
     }
 }
 
@@ -365,6 +367,7 @@ struct adn_cae {
     // bf16 mode: bf16 copy of the parameters (same layout), of the deconv inputs, and a scratch for gradients
     char *p16 = nullptr, *a9_16 = nullptr, *u12_16 = nullptr, *t16 = nullptr;
     bool p16_dirty = true;
+    bool preact3 = false;                 // last forward pass: a3 holds conv3's pre-activations (see forward())
     bool grads_valid = false;
     int adam_t = 0;
     float* P(size_t off) const { return buf[0] + off; }
@@ -542,10 +545,14 @@ int mm16_lean(adn_cae* m, int layout, int M, int N, int K, const void* A16, int 
 static bool lean_scratch() { static const bool off = getenv("ADN_CAE_FP32_SCRATCH") != nullptr; return !off; }   // (A/B switch)
 
 // y = act(conv(x) + b): patches kept in `cols` for the backward pass
-int conv_fwd(adn_cae* m, const float* x, const ConvGeom& g, int B, float* cols, size_t W, size_t b, float* y) {
+// preact: y = conv(x) + b WITHOUT the activation (the pooling behind it applies it to its maxima): a plain bias epilogue, which the
+// ping-pong kernel has -- 129024 x 152 x 2500 at batch 1024
+int conv_fwd(adn_cae* m, const float* x, const ConvGeom& g, int B, float* cols, size_t W, size_t b, float* y, bool preact = false) {
     if (fast16(m, g)) {                              // `cols` holds the bf16 patches matrix in this mode
         ADN_TRY(im2col16(m, x, g, B, cols));
-        return mm16(m, GEMM_NN, (int)rows_of(g, B), g.O, g.K, cols, g.ldk, W16(m, W), g.O, y, g.O, m->P(b), m->S);
+        const int R = (int)rows_of(g, B);
+        if (preact) return mm16(m, GEMM_NN, R, g.O, g.K, cols, g.ldk, W16(m, W), g.O, y, g.O, m->P(b), ADN_ACT_LINEAR, 0, R >= 65536);
+        return mm16(m, GEMM_NN, R, g.O, g.K, cols, g.ldk, W16(m, W), g.O, y, g.O, m->P(b), m->S);
     }
     ADN_TRY(im2col(m, x, g, B, cols));
     return mm(m, GEMM_NN, (int)rows_of(g, B), g.O, g.K, cols, g.ldk, m->P(W), g.O, y, g.O, m->P(b), m->S);
@@ -555,6 +562,14 @@ int conv_fwd(adn_cae* m, const float* x, const ConvGeom& g, int B, float* cols, 
 // in t16 and added the bias gradient (maxpool_bwd's pooled-grid form)
 int conv_bwd(adn_cae* m, const ConvGeom& g, int B, const float* cols, const float* dy, size_t W, size_t b, float* dx, bool ready = false) {
     const int R = (int)rows_of(g, B);
+    if (!fast16(m, g) && ready) {                    // (fp32-operand layer: only the bias gradient came with dy)
+        ADN_TRY(mm(m, GEMM_TN, g.K, g.O, R, cols, g.ldk, dy, g.O, m->G(W), g.O, nullptr, ADN_ACT_LINEAR, 1));
+        if (dx) {
+            ADN_TRY(mm(m, GEMM_NT, R, g.K, g.O, dy, g.O, m->P(W), g.O, m->scratch, g.ldk));
+            ADN_TRY(col2im(m, m->scratch, g, B, dx, nullptr, ADN_ACT_LINEAR));
+        }
+        return ADN_OK;
+    }
     if (fast16(m, g)) {
         if (!ready) ADN_TRY(to_bf16(dy, m->t16, (size_t)R * g.O, m->stream));
         ADN_TRY(mm16(m, GEMM_TN, g.K, g.O, R, cols, g.ldk, m->t16, g.O, m->G(W), g.O, nullptr, ADN_ACT_LINEAR, 1, true));
@@ -609,7 +624,9 @@ int deconv_bwd(adn_cae* m, const ConvGeom& g, int B, const float* x, const void*
     ADN_TRY(col_sum(dz, g.C, B * g.H * g.W, g.C, m->G(b), 1, m->stream));
     if (x16 && fast16(m, g)) {
         ADN_TRY(im2col16(m, dz, g, B, m->scratch, up));
-        ADN_TRY(mm16(m, GEMM_NN, R, g.O, g.K, m->scratch, g.ldk, W16(m, W), g.O, dx, g.O, nullptr, ADN_ACT_LINEAR, 0, true));
+        // (NN over the ping-pong kernel only where its 256-row tiles fill the device: 35840 x 152 x 2500 took 157 us on 140
+        //  tiles against ~110 on the register-staged kernel, 15360 x 200 x 1368 68 against 37)
+        ADN_TRY(mm16(m, GEMM_NN, R, g.O, g.K, m->scratch, g.ldk, W16(m, W), g.O, dx, g.O, nullptr, ADN_ACT_LINEAR, 0, R >= 65536));
         return mm16(m, GEMM_TN, g.K, g.O, R, m->scratch, g.ldk, x16, g.O, m->G(W), g.O, nullptr, ADN_ACT_LINEAR, 1, true);
     }
     ADN_TRY(im2col(m, dz, g, B, m->scratch, up));
@@ -617,25 +634,34 @@ int deconv_bwd(adn_cae* m, const ConvGeom& g, int B, const float* x, const void*
     return mm(m, GEMM_TN, g.K, g.O, R, m->scratch, g.ldk, x, g.O, m->G(W), g.O, nullptr, ADN_ACT_LINEAR, 1);
 }
 
-int maxpool_fwd(adn_cae* m, const float* x, int B, int H, int W, int C, int ph, int OH, int OW, float* y, uint8_t* arg) {
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_of((int64_t)B * OH * OW * C)), dim3(256), 0, m->stream, x, y, arg, B, H, W, C, ph, OH, OW);
+int maxpool_fwd(adn_cae* m, const float* x, int B, int H, int W, int C, int ph, int OH, int OW, float* y, uint8_t* arg,
+                int post_act = ADN_ACT_LINEAR) {
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_of((int64_t)B * OH * OW * C)), dim3(256), 0, m->stream, x, y, arg, B, H, W, C, ph, OH, OW,
+                       post_act);
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }
+// may the pooling's adjoint run from the pooled grid (maxpool_bwd_pooled_kernel)?  2 x 2 windows that cover every input position
+bool pool_bwd_from_pooled(int H, int W, int C, int ph, int OH, int OW) {
+    static const bool old_form = getenv("ADN_CAE_POOL_BWD_FULL") != nullptr;      // (A/B switch)
+    return !old_form && 2 * OH - ph >= H && 2 * OW >= W && C % 4 == 0;
+}
+
 // `pooled` (optional): the pooling's OUTPUT, still as the forward pass wrote it -- act' is then taken from it (the pooled value is
 // the winner's activation) instead of from the full-resolution activation act_y.  `dbias` / `*ready`: bf16 mode, the pooled-grid
 // kernel also leaves the gradient's bf16 copy in t16 and adds the bias gradient; conv_bwd then skips both passes
 int maxpool_bwd(adn_cae* m, const float* dy, const uint8_t* arg, int B, int H, int W, int C, int ph, int OH, int OW, float* dx,
-                const float* act_y = nullptr, const float* pooled = nullptr, float* dbias = nullptr, bool* ready = nullptr) {
+                const float* act_y = nullptr, const float* pooled = nullptr, float* dbias = nullptr, bool* ready = nullptr, bool want16 = true) {
     if (ready) *ready = false;
-    static const bool old_form = getenv("ADN_CAE_POOL_BWD_FULL") != nullptr;      // (A/B switch)
-    const bool tiles = 2 * OH - ph >= H && 2 * OW >= W && C % 4 == 0;
-    if (tiles && !old_form && (pooled || !act_y)) {
-        const bool fuse = dbias && ready && m->precision == ADN_PRECISION_BF16 && !deterministic();
+    if (pool_bwd_from_pooled(H, W, C, ph, OH, OW) && (pooled || !act_y)) {
+        const bool fuse = dbias && ready && !deterministic();
+        const bool copy16 = fuse && m->precision == ADN_PRECISION_BF16 && want16;
         const int64_t total = (int64_t)B * OH * OW * (C / 4);
-        hipLaunchKernelGGL(maxpool_bwd_pooled_kernel, dim3(grid_of(total)), dim3(256), (size_t)C * sizeof(float), m->stream,
+        // (with the fused bias sums: at most 2048 workgroups -- every workgroup ends with one float atomic per channel into the
+        //  same C addresses, and 16384 of them queueing there cost more than the column-sum pass they replace)
+        hipLaunchKernelGGL(maxpool_bwd_pooled_kernel, dim3(fuse ? std::min(grid_of(total), 2048) : grid_of(total)), dim3(256), (size_t)C * sizeof(float), m->stream,
                            reinterpret_cast<const float4*>(dy), reinterpret_cast<const uchar4*>(arg), reinterpret_cast<const float4*>(pooled),
-                           reinterpret_cast<float4*>(dx), fuse ? reinterpret_cast<cae_bf16x4*>(m->t16) : nullptr, fuse ? dbias : nullptr,
+                           reinterpret_cast<float4*>(dx), copy16 ? reinterpret_cast<cae_bf16x4*>(m->t16) : nullptr, fuse ? dbias : nullptr,
                            B, H, W, C / 4, ph, OH, OW, m->S);
         ADN_HIP_CHECK(hipGetLastError());
         if (fuse) *ready = true;
@@ -699,10 +725,15 @@ int forward(adn_cae* m, int B, bool decode) {
     if (m->bn_mode == 1) { ADN_TRY(bn_fwd(m, 0, u, P2)); u = m->bn[0].out; }
     ADN_TRY(dropout_inplace(m, 1, u, P2, m->p2h * m->p2w, m->F1L, m->F1));
     m->in3 = u;
-    ADN_TRY(conv_fwd(m, u, m->c3, B, m->cols3, m->W3, m->b3, m->a3));
+    // bf16 mode, activation directly in front of the pooling and nobody else reading it (a dropout layer that rescales the pooled
+    // tensor in place sends the backward pass to the full-resolution activation for act'): a3 then holds PRE-activations
+    static const bool no_preact = getenv("ADN_CAE_NO_PREACT") != nullptr;       // (A/B switch)
+    m->preact3 = fast16(m, m->c3) && m->bn_mode != 2 && !m->drop && !no_preact &&
+                 pool_bwd_from_pooled(m->c3.OH, m->c3.OW, m->F2, 1, m->p4h, m->p4w);
+    ADN_TRY(conv_fwd(m, u, m->c3, B, m->cols3, m->W3, m->b3, m->a3, m->preact3));
     t = m->a3;
     if (m->bn_mode == 2) { ADN_TRY(bn_fwd(m, 1, t, R3)); t = m->bn[1].out; }
-    ADN_TRY(maxpool_fwd(m, t, B, m->c3.OH, m->c3.OW, m->F2, 1, m->p4h, m->p4w, m->p4, m->arg4));
+    ADN_TRY(maxpool_fwd(m, t, B, m->c3.OH, m->c3.OW, m->F2, 1, m->p4h, m->p4w, m->p4, m->arg4, m->preact3 ? S : ADN_ACT_LINEAR));
     u = m->p4;
     if (m->bn_mode == 1) { ADN_TRY(bn_fwd(m, 1, u, P4)); u = m->bn[1].out; }
     ADN_TRY(dropout_inplace(m, 2, u, P4, m->p4h * m->p4w, m->F2L, m->F2));
@@ -792,23 +823,25 @@ int backward(adn_cae* m, int B) {
     // (the pooled tensor still holds the winners' activations unless a dropout layer rescaled it in place)
     const bool pooled_intact = !(m->drop && m->training && m->bn_mode == 0);
     bool ready3 = false, ready1 = false;
+    ADN_CHECK(!m->preact3 || (m->bn_mode != 2 && pooled_intact), ADN_ERR_STATE, "conv AE: pre-activation forward without intact pooled values");
     ADN_TRY(maxpool_bwd(m, gA, m->arg4, B, m->c3.OH, m->c3.OW, F2, 1, m->p4h, m->p4w, gB, m->bn_mode == 2 ? nullptr : m->a3,
                         (m->bn_mode != 2 && pooled_intact) ? m->p4 : nullptr, m->bn_mode == 2 ? nullptr : m->G(m->b3), &ready3));   // gB = d (pool input)
     if (m->bn_mode == 2) {
         ADN_TRY(bn_bwd(m, 1, m->a3, gB, R3));                                             // gB = d a3
         ADN_TRY(act_backward(gB, F2, m->a3, F2, R3, F2, S, s));
     }
-    ADN_TRY(conv_bwd(m, m->c3, B, m->cols3, gB, m->W3, m->b3, gA, ready3 && fast16(m, m->c3)));   // gA = d (conv3 input)
+    ADN_TRY(conv_bwd(m, m->c3, B, m->cols3, gB, m->W3, m->b3, gA, ready3));   // gA = d (conv3 input)
     ADN_TRY(dropout_inplace(m, 1, gA, P2, m->p2h * m->p2w, m->F1L, F1));
     if (m->bn_mode == 1) ADN_TRY(bn_bwd(m, 0, m->p2, gA, P2));                             // gA = d p2
-    // (conv1 is not a bf16-operand layer (C_in = 1): only the activation read is saved there, the sums stay with conv_bwd)
+    // (conv1 is not a bf16-operand layer (C_in = 1): no bf16 copy of its gradient, the bias sums ride along all the same)
     ADN_TRY(maxpool_bwd(m, gA, m->arg2, B, m->c1.OH, m->c1.OW, F1, 0, m->p2h, m->p2w, gB, m->bn_mode == 2 ? nullptr : m->a1,
-                        (m->bn_mode != 2 && pooled_intact) ? m->p2 : nullptr, nullptr, &ready1));   // gB = d (pool input)
+                        (m->bn_mode != 2 && pooled_intact) ? m->p2 : nullptr, m->bn_mode == 2 ? nullptr : m->G(m->b1), &ready1,
+                        fast16(m, m->c1)));           // gB = d (pool input)
     if (m->bn_mode == 2) {
         ADN_TRY(bn_bwd(m, 0, m->a1, gB, R1));                                             // gB = d a1
         ADN_TRY(act_backward(gB, F1, m->a1, F1, R1, F1, S, s));
     }
-    ADN_TRY(conv_bwd(m, m->c1, B, m->cols1, gB, m->W1, m->b1, nullptr));
+    ADN_TRY(conv_bwd(m, m->c1, B, m->cols1, gB, m->W1, m->b1, nullptr, ready1));
     m->grads_valid = true;
     return ADN_OK;
 }
