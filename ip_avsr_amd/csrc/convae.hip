@@ -195,6 +195,27 @@ __global__ __launch_bounds__(256) void im2col4_bf16_kernel(const float4* __restr
     }
 }
 
+// The same patches matrix for an unpadded, un-upscaled convolution, by RUNS: in NHWC the patch of output pixel r is kh runs of
+// kw * C contiguous values (one per filter row), so a workgroup of 128 threads copies the runs of 4 output pixels with no index
+// arithmetic per element (the generic kernel spends 6 integer divisions per 8-byte store and runs at half the HBM rate).
+__global__ __launch_bounds__(128) void im2col_runs_bf16_kernel(const float4* __restrict__ x, cae_bf16x4* __restrict__ cols, int R, int H,
+                                                               int W, int C4, int kh, int kw, int OH, int OW, int ldc4) {
+    const int run4 = kw * C4;
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = blockIdx.x * 4 + rr;
+        if (r >= R) return;
+        const int ox = r % OW, oy = (r / OW) % OH, b = r / (OW * OH);
+        const float4* src = x + (((size_t)b * H + oy) * W + ox) * C4;
+        cae_bf16x4* dst = cols + (size_t)r * ldc4;
+        for (int i = 0; i < kh; ++i)
+            for (int q = threadIdx.x; q < run4; q += 128) {
+                const float4 t = src[(size_t)i * W * C4 + q];
+                cae_bf16x4 o; o[0] = (__bf16)t.x; o[1] = (__bf16)t.y; o[2] = (__bf16)t.z; o[3] = (__bf16)t.w;
+                dst[i * run4 + q] = o;
+            }
+    }
+}
+
 // 2x2 / stride 2 max pooling, ignore_border, `ph` rows of padding above and below that never win; code = dy*2 + dx
 // post_act != LINEAR: x holds PRE-activations and the (monotone) activation is applied to the maximum -- pool(act(x)) = act(pool(x)),
 // on a quarter of the elements -- so that the convolution in front runs with a plain bias epilogue
@@ -492,6 +513,14 @@ int mm16(adn_cae* m, int layout, int M, int N, int K, const void* A16, int lda, 
 int im2col16(adn_cae* m, const float* x, const ConvGeom& g, int B, void* cols16, int up = 0) {
     const int oh = up ? g.OH / 2 : g.OH, ow = up ? g.OW / 2 : g.OW;
     const int64_t total = (int64_t)B * oh * ow * g.K;
+    static const bool no_runs = getenv("ADN_CAE_IM2COL_GENERIC") != nullptr;     // (A/B switch)
+    if (!up && g.ph == 0 && g.pw == 0 && !no_runs) {
+        const int R = B * g.OH * g.OW;
+        hipLaunchKernelGGL(im2col_runs_bf16_kernel, dim3((R + 3) / 4), dim3(128), 0, m->stream, reinterpret_cast<const float4*>(x),
+                           reinterpret_cast<cae_bf16x4*>(cols16), R, g.H, g.W, g.C / 4, g.k, g.k, g.OH, g.OW, g.ldk / 4);
+        ADN_HIP_CHECK(hipGetLastError());
+        return ADN_OK;
+    }
     hipLaunchKernelGGL(im2col4_bf16_kernel, dim3(grid_of(total / 4)), dim3(256), 0, m->stream, reinterpret_cast<const float4*>(x),
                        reinterpret_cast<cae_bf16x4*>(cols16), B, g.H, g.W, g.C / 4, g.k, g.k, g.ph, g.pw, oh, ow, g.ldk / 4, up);
     ADN_HIP_CHECK(hipGetLastError());
