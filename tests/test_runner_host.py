@@ -95,3 +95,66 @@ def test_initialisers():
     assert isinstance(las_init.select("ortho"), las_init.Orthogonal)
     assert isinstance(las_init.select("anything-else"), las_init.GlorotUniform)
     assert isinstance(las_init.resolve(las_init.GlorotUniform), las_init.GlorotUniform)
+
+
+class _FakeNetwork(object):
+    """Stands in for AdeNetModel in runners/nstream.fit (host_batches=True: the reference's generators, no GPU): records what
+    the loop hands over and returns costs that improve for three epochs, then get worse."""
+
+    def __init__(self, n_streams, classes):
+        self.S, self.C, self.head, self.spec = n_streams, classes, "frames", {"streams": [{} for _ in range(n_streams)]}
+        self.steps, self.evals, self.snapshots = [], 0, 0
+
+    def compile(self, lr, order):
+        def cost(*a):
+            self.evals += 1
+            e = self.evals // 2                        # (train cost + validation cost per epoch)
+            return np.float32(2.0 - 0.1 * e if e <= 3 else 1.7 + 0.05 * (e - 3))
+        def val_fn(*a):
+            mask = a[1] if self.S == 2 else a[self.S]          # (the 2-stream runner compiles val_fn(in1, mask, in2, window))
+            probs = np.zeros(mask.shape + (self.C,), np.float32); probs[..., 1] = 1.0
+            return probs
+        return None, cost, cost, val_fn
+
+    def train_step(self, Xs, y, m, w, lr, want_loss=True):
+        assert not want_loss                           # the loop must not wait for the cost the reference discards
+        self.steps.append((len(Xs), Xs[0].shape, y.shape, y.dtype, m.dtype, int(m.sum()), w, lr, [x[:, 0, 0].copy() for x in Xs]))
+
+    def synchronize(self):
+        pass
+
+    def snapshot_params(self):
+        self.snapshots += 1
+        return ("snapshot", self.snapshots)
+
+
+def test_epoch_loop_on_the_host_generators():
+    """runners/nstream.fit with the reference's host-side generators (ADN_HOST_BATCHES path) and a recording network: batch
+    shapes and dtypes as runners/3stream.py:357-370 builds them, the utterance order of gen_lstm_batch_random from the global
+    NumPy stream (after the two held-out draws), best-parameter snapshots only on improvement, early stop by early_stop2."""
+    from ip_avsr_amd.runners import nstream
+    from ip_avsr_amd.utils import datagen as dg
+    rng = np.random.RandomState(3)
+    lens = {k: rng.randint(3, 9, size=n) for k, n in (("train", 11), ("val", 5), ("test", 4))}
+    split = {k: [rng.normal(size=(int(l.sum()), d)).astype(np.float32) for d in (6, 4)] for k, l in lens.items()}
+    ys = {k: np.repeat(np.arange(len(l)) % 3, l) for k, l in lens.items()}
+    net = _FakeNetwork(2, 3)
+    np.random.seed(21)
+    st = nstream.fit(net, split, ys, lens, 2, windowsize=3, num_epoch=9, epochsize=4, batchsize=4, validation_window=2, learning_rate=0.5,
+                     say=lambda *a, **k: None, host_batches=True, progress=False)
+    assert len(net.steps) == 4 * len(st["cost_val"]) and len(st["train_seconds"]) == len(st["epoch_seconds"]) == len(st["cost_val"])
+    assert 4 <= len(st["cost_val"]) < 9                                           # stopped early once the cost kept rising
+    assert net.snapshots == 3 and st["best_params"] == ("snapshot", 3)            # three improving epochs
+    assert st["best_val"] == min(st["cost_val"])
+    # the same draws in the same order: held-out splits first (two permutations each), then the training stream
+    np.random.seed(21)
+    for k in ("val", "test"):
+        next(dg.gen_lstm_batch_random(split[k][0], ys[k], lens[k], batchsize=len(lens[k])))
+    ref = dg.gen_lstm_batch_random(split["train"][0], ys["train"], lens["train"], batchsize=4)
+    tmax = int(lens["train"].max())
+    for n_in, shape, yshape, ydt, mdt, frames, w, lr, firsts in net.steps[:6]:
+        X1, yb, mb, ib = next(ref)
+        assert n_in == 2 and shape == X1.shape and yshape == (len(ib), tmax) and ydt == np.uint8 and mdt == np.uint8
+        assert frames == int(mb.sum()) and w == 3 and lr == 0.5
+        assert np.array_equal(firsts[0], X1[:, 0, 0])
+    assert [s[1][0] for s in net.steps[:3]] == [4, 4, 3]                          # 11 utterances: 4, 4, 3 (short), reshuffle
