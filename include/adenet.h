@@ -200,6 +200,12 @@ int adn_forward(adn_model* m, const void* const* inputs, const uint8_t* mask, in
 int adn_loss(adn_model* m, const void* const* inputs, const int32_t* targets, const uint8_t* mask, int B,
              int T, int theta, int flags, float* loss);
 
+/* The probabilities of the LAST forward pass (adn_forward / adn_loss / adn_compute_grads on a (B, T) batch), in adn_forward's
+ * layout.  The reference's epoch loop runs compute_test_cost and val_fn back to back on the same held-out split with the same
+ * parameters (runners/3stream.py:373,383): two compiled functions there, one forward pass here -- adn_loss without
+ * ADN_FLAG_STOCHASTIC leaves exactly what adn_forward would return. */
+int adn_read_probs(adn_model* m, int B, int T, int flags, float* probs);
+
 /* forward + temporal_softmax_loss (custom/objectives.py:4-39) + back-propagation into the gradient
  * buffer.  total_frames <= 0: normalise by this batch's valid frames (single-GPU semantics);
  * > 0: normalise by that number (data parallel: the global count, so that the SUM of the ranks'

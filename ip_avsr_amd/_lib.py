@@ -92,6 +92,7 @@ _SIGNATURES = {
     "adn_set_bucket_events": (C.c_int, [_P, C.POINTER(_P), C.c_int]),
     "adn_forward": (C.c_int, [_P, C.POINTER(_P), _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "adn_loss": (C.c_int, [_P, C.POINTER(_P), _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "adn_read_probs": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "adn_compute_grads": (C.c_int, [_P, C.POINTER(_P), _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _P]),
     "adn_zero_grads": (C.c_int, [_P]),
     "adn_apply_adam": (C.c_int, [_P, C.c_float]),

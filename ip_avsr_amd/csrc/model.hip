@@ -2300,6 +2300,13 @@ int adn_loss(adn_model* m, const void* const* inputs, const int32_t* targets, co
     return fetch(m, loss, m->loss, sizeof(float), flags & ADN_FLAG_DEVICE_OUTPUTS);
 }
 
+int adn_read_probs(adn_model* m, int B, int T, int flags, float* probs) {
+    ADN_CHECK(m && probs, ADN_ERR_INVALID, "null argument");
+    ADN_CHECK(m->lastB == B && m->lastT == T && B >= 1, ADN_ERR_STATE, "adn_read_probs: no forward pass of this (B, T) to read from");
+    const size_t rows = m->head_last() ? (size_t)B : (size_t)B * T;
+    return fetch(m, probs, m->probs_bt, rows * m->C * sizeof(float), flags & ADN_FLAG_DEVICE_OUTPUTS);
+}
+
 int adn_compute_grads(adn_model* m, const void* const* inputs, const int32_t* targets, const uint8_t* mask, int B,
                       int T, int theta, int flags, double total_frames, float* loss) {
     ADN_TRY(check_shape(m, B, T, theta));

@@ -408,6 +408,17 @@ class AdeNetModel(object):
         _lib.check(self._lib.adn_loss(self._handle, ptrs, tp, mp, B, T, int(window), flags, C.byref(out)))
         return np.float32(out.value)
 
+    def loss_and_probs(self, inputs, targets, mask, window):
+        """compute_test_cost and val_fn of one batch from ONE forward pass: (cost, probabilities).  The reference's epoch loop
+        calls the two compiled functions back to back on the held-out split (runners/3stream.py:373,383); both are
+        deterministic passes over the same graph, so the second forward pass only recomputes what the first left behind."""
+        ptrs, mp, tp, B, T, flags, keep = self._prep(inputs, mask, targets)
+        out = C.c_float()
+        _lib.check(self._lib.adn_loss(self._handle, ptrs, tp, mp, B, T, int(window), flags, C.byref(out)))
+        probs = np.empty((B, self.C) if self.head == "last" else (B, T, self.C), dtype=np.float32)
+        _lib.check(self._lib.adn_read_probs(self._handle, B, T, 0, probs.ctypes.data_as(C.c_void_p)))
+        return np.float32(out.value), probs
+
     def set_dropout_state(self, seed, counter=0):
         """Dropout masks are a hash of (seed, counter, layer, element); the counter advances after every stochastic
         pass.  Setting both reproduces a draw (the oracle uses the same function)."""

@@ -887,7 +887,14 @@ def _main(dataset, script, argv=None):
             train(Xs, yy, m, WINDOW_SIZE)
             print('\r', end='')
         cost = float(compute_train_cost(Xs, yy, m, WINDOW_SIZE))
-        val_cost = float(compute_test_cost(X_val, y_val, mask_val, WINDOW_SIZE))
+        # (validation cost and the predictions the vote / arg-max is taken on: one forward pass instead of the scripts' two --
+        #  compute_test_cost, then val_fn, the same deterministic graph on the same inputs)
+        val_probs = None
+        if not os.environ.get('ADN_TWO_PASS_EVAL'):
+            val_cost, val_probs = network.loss_and_probs(X_val, y_val, mask_val, WINDOW_SIZE)
+            val_cost = float(val_cost)
+        else:
+            val_cost = float(compute_test_cost(X_val, y_val, mask_val, WINDOW_SIZE))
         cost_train.append(cost)
         cost_val.append(val_cost)
         train_strip[epoch % STRIP_SIZE] = cost
@@ -896,7 +903,7 @@ def _main(dataset, script, argv=None):
         with np.errstate(divide='ignore', invalid='ignore'):
             pk = 1000 * (np.sum(train_strip) / (STRIP_SIZE * np.min(train_strip)) - 1)
             pq = gl / pk
-        cr, val_conf = evaluate(X_val, y_val_evaluate, mask_val, WINDOW_SIZE, eval_fn)
+        cr, val_conf = evaluate(X_val, y_val_evaluate, mask_val, WINDOW_SIZE, eval_fn if val_probs is None else (lambda *a: val_probs))
         class_rate.append(cr)
         improved = val_cost < best_val
         if has_test:

@@ -294,7 +294,14 @@ def fit(network, split, ys, lens, n_streams, windowsize, num_epoch, epochsize, b
         elif not host_batches:
             Xs, y, m = batch.Xs, batch.targets, batch.mask
         cost = float(call(compute_train_cost, Xs, y, m, windowsize))
-        val_cost = heldout_cost(X_val, y_val, mask_val)
+        # validation cost and the predictions evaluate_model2 votes on: one forward pass over the split instead of the
+        # reference's two (compute_test_cost, then val_fn: the same deterministic graph on the same inputs)
+        val_probs = None
+        if dp is None and hasattr(network, 'loss_and_probs') and not os.environ.get('ADN_TWO_PASS_EVAL'):
+            val_cost, val_probs = network.loss_and_probs(X_val, y_val, mask_val, windowsize)
+            val_cost = float(val_cost)
+        else:
+            val_cost = heldout_cost(X_val, y_val, mask_val)
         cost_train.append(cost)
         cost_val.append(val_cost)
         train_strip[epoch % STRIP_SIZE] = cost
@@ -303,7 +310,8 @@ def fit(network, split, ys, lens, n_streams, windowsize, num_epoch, epochsize, b
         with np.errstate(divide='ignore', invalid='ignore'):    # the strip holds zeros until STRIP_SIZE epochs ran
             pk = 1000 * (np.sum(train_strip) / (STRIP_SIZE * np.min(train_strip)) - 1)
             pq = gl / pk
-        cr, val_conf = evaluate_model2(X_val, y_val_evaluate, mask_val, windowsize, eval_fn)
+        cr, val_conf = evaluate_model2(X_val, y_val_evaluate, mask_val, windowsize,
+                                       eval_fn if val_probs is None else (lambda *a: val_probs))
         class_rate.append(cr)
         if val_cost < best_val:
             best_val, best_cr = val_cost, cr

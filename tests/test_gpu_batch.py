@@ -251,3 +251,31 @@ def test_runner_fed_from_hbm_equals_runner_fed_from_the_host(tmp_path, monkeypat
     assert np.array_equal(_host(a["heldout"]["X_val"][1]), b["heldout"]["X_val"][1])
     for o in outs:
         o["network"].close()
+
+
+@pytest.mark.parametrize("head", ["frames", "last"])
+def test_cost_and_predictions_from_one_forward_pass(head):
+    """AdeNetModel.loss_and_probs (adn_loss + adn_read_probs: what the epoch loops use for the held-out split) returns exactly
+    what compute_test_cost and val_fn return from two passes -- bit for bit, in every arithmetic, for both heads"""
+    import torch
+    from ip_avsr_amd.model import AdeNetModel
+    from oracle import adenet_oracle as O
+    torch.cuda.set_device(0)
+    rng = np.random.default_rng(6)
+    spec = O.spec_nstream([30, 22], enc_shapes=(32, 16, 8), enc_acts=("rectify", "rectify", "linear"), lstm_size=20, classes=6, fusion="sum")
+    if head == "last":
+        spec["head"] = "last"
+    p = O.init_params(spec, rng, np.float32, enc_std=0.2, perturb=0.05)
+    B, T = 13, 9
+    lens = rng.integers(2, T + 1, size=B); lens[0] = T
+    mask = (np.arange(T)[None, :] < lens[:, None]).astype(np.uint8)
+    xs = [(rng.normal(size=(B, T, d)) * mask[..., None]).astype(np.float32) for d in (30, 22)]
+    y = np.repeat((np.arange(B) % 6)[:, None], T, axis=1).astype(np.int32)
+    for precision in ("f32", "bf16x3", "bf16"):
+        m = AdeNetModel(dict(spec, precision=precision))
+        m.set_params_dict(p)
+        cost2, probs2 = m.loss(xs, y, mask, 2), m.predict(xs, mask, 2)
+        cost1, probs1 = m.loss_and_probs(xs, y, mask, 2)
+        assert cost1 == cost2 and probs1.shape == probs2.shape
+        np.testing.assert_array_equal(probs1, probs2)
+        m.close()
