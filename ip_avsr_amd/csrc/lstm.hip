@@ -483,10 +483,14 @@ int lstm_backward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T
     if (!deterministic()) return lstm_backward_impl(l, n, mask_tb, B, T, H, precision, s, sums_done);
     // slots: >= 2 per 32-utterance group (weight-stationary kernels) and >= 1 per 16-row slice (the other families)
     const int ldh = ld_of(H), ldg = ld_of(4 * H), stride = ldg + 5 * ldh, slots = cdiv(B, 16) + 2;
-    static float* ws = nullptr; static size_t ws_floats = 0;       // (one stream drives a model in this mode)
+    // (per device: one process may drive several; within a device one stream drives the models in this mode)
+    static float* ws_dev[64] = {}; static size_t ws_floats_dev[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    float*& ws = ws_dev[dev]; size_t& ws_floats = ws_floats_dev[dev];
     const size_t need = (size_t)n * slots * stride;
     if (need > ws_floats) {
-        if (ws) { ADN_HIP_CHECK(hipStreamSynchronize(s)); (void)hipFree(ws); ws = nullptr; ws_floats = 0; }
+        if (ws) { ADN_HIP_CHECK(hipDeviceSynchronize()); (void)hipFree(ws); ws = nullptr; ws_floats = 0; }
         ADN_HIP_CHECK(hipMalloc((void**)&ws, need * sizeof(float)));
         ws_floats = need;
     }

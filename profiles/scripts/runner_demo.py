@@ -22,6 +22,10 @@ root = tempfile.mkdtemp(prefix="avletters_demo_")
 t0 = time.time()
 ini = LA.build(root, seed=1234, amplitude=tuple(5.0 * a for a in (0.16, 0.12, 0.10)), num_epoch=epochs, validation_window=epochs)
 print("dataset + DBN files written in %.1f s: %s" % (time.time() - t0, ini), flush=True)
+# (a throw-away one-epoch run first: the first process of a fresh box pages in the ROCm libraries and torch, ~5 s)
+subprocess.run([sys.executable, os.path.join(ROOT, "ip_avsr_amd", "runners", "3stream.py"), "--config", LA.build(tempfile.mkdtemp(prefix="avletters_warm_"),
+                seed=1234, num_epoch=1, validation_window=1), "--seed", "1", "--precision", precision], cwd=ROOT, stdout=subprocess.DEVNULL,
+               stderr=subprocess.DEVNULL)
 for env_extra, label in (({}, "splits resident in HBM, minibatches gathered on the GPU (default)"),
                          ({"ADN_HOST_BATCHES": "1"}, "ADN_HOST_BATCHES=1: the reference's host-side batch assembly, upload per batch")):
     print("== %s, --precision %s" % (label, precision), flush=True)
