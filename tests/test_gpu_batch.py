@@ -279,3 +279,27 @@ def test_cost_and_predictions_from_one_forward_pass(head):
         assert cost1 == cost2 and probs1.shape == probs2.shape
         np.testing.assert_array_equal(probs1, probs2)
         m.close()
+
+
+def test_edge_splits_one_utterance_one_frame_and_whole_split_batches():
+    """a split of ONE utterance of ONE frame (T = 1: every row is the utterance's only frame), a batch size beyond the split (every
+    batch is the whole split in a fresh order, each flagged as the last of its pass -> a reshuffle per batch, as the reference's
+    generator does), and the whole() form of the held-out splits: against the host generators draw for draw"""
+    rng = np.random.default_rng(3)
+    one = _split([rng.normal(size=(1, 5)).astype(np.float32)], np.array([4]), np.array([1]))
+    b = next(one.batches(3))
+    assert b.Xs[0].shape == (1, 1, 5) and b.mask.tolist() == [[1]] and b.targets.tolist() == [[4]] and list(b.idxs) == [0]
+    streams, y, lens = _random_split(rng, 7, (12, 20), classes=9)
+    sp = _split(streams, y, lens)
+    np.random.seed(4)
+    gen = sp.batches(50)
+    got = [(list(next(gen).idxs)) for _ in range(3)]
+    whole = sp.whole()
+    np.random.seed(4)
+    ref = dg.gen_lstm_batch_random(streams[0], y, lens, batchsize=50)
+    want = [list(next(ref)[3]) for _ in range(3)]
+    assert got == want and all(len(g) == 7 for g in got)
+    X1, yb, mb, ib = next(dg.gen_lstm_batch_random(streams[0], y, lens, batchsize=len(lens)))     # (the draw whole() made)
+    assert list(whole.idxs) == list(ib) and np.array_equal(_host(whole.Xs[0]), X1) and np.array_equal(np.asarray(whole.y), yb)
+    il = dg.compute_integral_len(lens)
+    assert np.array_equal(_host(whole.Xs[1]), dg.gen_seq_batch_from_idx(streams[1], ib, lens, il, int(lens.max())))
