@@ -323,6 +323,7 @@ int lstm_forward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T,
     // bf16x3 mode: the weight-stationary forward kernel with fp32-grade products where it applies, the fp32 step kernels else
     if (precision == ADN_PRECISION_BF16X3) {
         if (lstm_cluster_x3_supported(l, n, B, T, H)) { g_lstm_family_forwards[3] += n; return lstm_forward_cluster_x3(l, n, mask_tb, B, T, H, s); }
+        if (lstm_cluster_x3w_supported(l, n, B, T, H)) { g_lstm_family_forwards[3] += n; return lstm_forward_cluster_x3w(l, n, mask_tb, B, T, H, s); }
         precision = ADN_PRECISION_F32;
     }
     LstmLaunch L;

@@ -642,6 +642,206 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClus
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// bf16x3 forward, 256 < H <= 512 ("wide").  hi + lo fragments of a 64-unit slice would be 512 KB: no CU holds that, so a
+// group is 16 workgroups of 32 hidden units (256 KB of fragments each, in registers as in the kernel above) and -- to keep
+// 16 workgroups per group within the device at the whole-split batches (B = 520: 11 groups = 176 CUs) -- 48 utterances.
+//   product     wave w: gate w >> 1, unit tile w & 1, ALL 16 k-steps and the 3 row tiles: 16 x (hi + lo) = 128 VGPRs of
+//               fragments (kWFwdLds lo k-steps of them in LDS), 144 MFMAs per step; no fragment is held twice, no partial
+//               sums over k to combine
+//   gate math   wave w < 6: row tile w >> 1, unit tile w & 1; the accumulators cross through 24 KB of LDS
+//   exchange    [2 parities][24 row pairs][512 units] granules per group, tagged as above; a thread owns one unit column and
+//               polls its 24 row pairs in three rounds of 8 (the own workgroup's 32 columns sit out)
+// LDS: the two h images 2 x 48 x 520 x 2 B = 97.5 KB + 24 KB + 24 KB of lo fragments.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kWRows = 48, kWUnits = 32, kWCWG = 16, kWHP = 512, kWKS = 16, kWHS = kWHP + 8;
+constexpr int kWAccLds = 4 * 3 * 2 * 64 * 4;                           // fp32 words: [4 gates][3 row tiles][2 unit tiles][64 lanes] x 4 rows
+constexpr int kWFwdLds = 3;                                            // lo k-steps of a wave's W fragments that live in LDS
+constexpr size_t kWFwdLdsBytes = (size_t)2 * kWRows * kWHS * 2 + (size_t)kWAccLds * 4 + (size_t)8 * kWFwdLds * 64 * 16;
+__global__ __launch_bounds__(512) void lstm_fwd_cluster_x3w_kernel(const LstmClusterX3P L, const uint8_t* __restrict__ mask_tb,
+                                                                   int B, int T, int H, int ldh, int ldg, int* err) {
+    constexpr int HP = kWHP, KS = kWKS, HS = kWHS, R = kWRows, NF = 8;
+    const unsigned tag0 = L.tag0[blockIdx.y];
+    extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
+    __bf16 (*hs_hi)[HS] = reinterpret_cast<__bf16 (*)[HS]>(lds);
+    __bf16 (*hs_lo)[HS] = reinterpret_cast<__bf16 (*)[HS]>(lds + R * HS);
+    f32x4* xacc = reinterpret_cast<f32x4*>(lds + 2 * R * HS);            // (2 * 48 * 520 * 2 bytes: 16-byte aligned)
+    bf16x8* wl = reinterpret_cast<bf16x8*>(lds + 2 * R * HS + kWAccLds * 2);   // [8 waves][kWFwdLds][64 lanes]
+    const LstmStep& P = L.l[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int group = blockIdx.x / kWCWG, j = blockIdx.x % kWCWG;
+    const int r0 = group * R;
+    const int rt = wave >> 1, ut = wave & 1;          // gate math: row tile (3: this wave has none), unit tile;  product: gate rt, unit tile ut
+    const bool gm = rt < 3;
+    const int u = kWUnits * j + 16 * ut + i;
+    const int uc = min(u, H - 1);
+    unsigned long long* xb = reinterpret_cast<unsigned long long*>(P.xchg) + (size_t)group * 2 * (R / 2) * HP;
+
+    const bf16x8* wsrc_hi = reinterpret_cast<const bf16x8*>(P.W_frag_fwd) + ((size_t)(4 * (2 * j + ut) + rt) * KS) * 64 + lane;
+    const bf16x8* wsrc_lo = reinterpret_cast<const bf16x8*>(P.W_frag_fwd_lo) + ((size_t)(4 * (2 * j + ut) + rt) * KS) * 64 + lane;
+    constexpr int KR = KS - kWFwdLds;
+    bf16x8 whi[KS], wlo[KR];
+    bf16x8* wmine = wl + (size_t)wave * kWFwdLds * 64 + lane;
+#pragma unroll
+    for (int s_ = 0; s_ < KS; ++s_) {
+        whi[s_] = wsrc_hi[(size_t)s_ * 64];
+        const bf16x8 lo = wsrc_lo[(size_t)s_ * 64];
+        if (s_ < KR) wlo[s_ < KR ? s_ : 0] = lo;
+        else wmine[(s_ - KR) * 64] = lo;
+    }
+    // ---- initial state: both images from the fp32 block
+    const int blk0 = P.backwards ? T : 0;
+    for (int e = tid; e < R * HP; e += 512) {
+        const int rr = e / HP, cc = e % HP;
+        const float v = cc < H ? P.hbuf[((size_t)blk0 * B + min(r0 + rr, B - 1)) * ldh + cc] : 0.f;
+        x3_split(x3_quant(v), hs_hi[rr][cc], hs_lo[rr][cc]);
+    }
+    float c_st[4], h_st[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const size_t idx = ((size_t)blk0 * B + min(r0 + 16 * min(rt, 2) + 4 * kq + r, B - 1)) * ldh + uc;
+        c_st[r] = P.cbuf[idx];
+        h_st[r] = P.hbuf[idx];
+    }
+    __syncthreads();
+
+    const int acol = kq * 8;
+    uint8_t m[4];
+    float4 xp[4];
+    STAMP_INIT
+    for (int step = 0; step < T; ++step) {
+        const int t = P.backwards ? (T - 1 - step) : step;
+        const int out_blk = t + (P.backwards ? 0 : 1);
+        const unsigned tag = tag0 + (unsigned)step;
+        unsigned long long* xpar = xb + (size_t)(step & 1) * (R / 2) * HP;
+        if (gm) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const size_t ridx = (size_t)t * B + min(r0 + 16 * rt + 4 * kq + r, B - 1);
+                m[r] = mask_tb[ridx];
+                xp[r] = *reinterpret_cast<const float4*>(P.xproj + ridx * ldg + uc * 4);
+            }
+        }
+        // ---- recurrent product of this wave's gate: three MFMAs per (row tile, k-step)
+        f32x4 pacc[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) pacc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int col = s * 32 + acol;
+            bf16x8 a_hi[3], a_lo[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                a_hi[q] = *reinterpret_cast<const bf16x8*>(&hs_hi[16 * q + i][col]);
+                a_lo[q] = *reinterpret_cast<const bf16x8*>(&hs_lo[16 * q + i][col]);
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) pacc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[q], whi[s], pacc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) pacc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[q], whi[s], pacc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                pacc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    a_hi[q], s < KR ? wlo[s < KR ? s : 0] : wmine[(s < KR ? 0 : s - KR) * 64], pacc[q], 0, 0, 0);
+        }
+        // accumulator lane map = gate-math lane map (unit lane & 15, rows 4 (lane >> 4) ..+3): hand each tile to its wave
+#pragma unroll
+        for (int q = 0; q < 3; ++q) xacc[((rt * 3 + q) * 2 + ut) * 64 + lane] = pacc[q];
+        lds_barrier();                                // every wave has read h_{t-1} (the images may be overwritten); tiles are in place
+        STAMP(0);
+        if (gm) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = xacc[((g * 3 + rt) * 2 + ut) * 64 + lane];
+            // ---- gate math; own images and the publication of each row pair first (the partners are waiting for it)
+            unsigned q_even = 0u;
+            float h_out[4];
+            float4 gts[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a_i = xp[r].x + acc[0][r], a_f = xp[r].y + acc[1][r];
+                float a_g = xp[r].z + acc[2][r], a_o = xp[r].w + acc[3][r];
+                const float c_prev = c_st[r], h_prev = h_st[r];
+                if (P.peep) { a_i += c_prev * P.peep[uc]; a_f += c_prev * P.peep[ldh + uc]; }
+                const float gi = c_sigmoid(a_i), gf = c_sigmoid(a_f), gg = c_tanh(a_g);
+                const float c_new = gf * c_prev + gi * gg;
+                if (P.peep) a_o += c_new * P.peep[2 * ldh + uc];
+                const float go = c_sigmoid(a_o);
+                const float h_new = go * c_tanh(c_new);
+                c_st[r] = m[r] ? c_new : c_prev;
+                float h_o = m[r] ? h_new : h_prev;
+                h_st[r] = h_o;
+                if (u >= H) h_o = 0.f;
+                h_out[r] = h_o;
+                gts[r] = make_float4(gi, gf, gg, go);
+                const unsigned qb = x3_quant(h_o);
+                const int row = 16 * rt + 4 * kq + r;
+                x3_split(qb, hs_hi[row][u], hs_lo[row][u]);
+                if (r & 1)
+                    __hip_atomic_store(xpar + (size_t)(8 * rt + 2 * kq + (r >> 1)) * HP + u,
+                                       ((unsigned long long)(qb | (tag >> 8)) << 32) | (q_even | (tag & 255u)), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                else
+                    q_even = qb;
+            }
+            STAMP(1);
+            // ---- the step's outputs
+            if (u < H) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int grow = r0 + 16 * rt + 4 * kq + r;
+                    if (grow < B) {
+                        const size_t ridx = (size_t)t * B + grow;
+                        const size_t oidx = ((size_t)out_blk * B + grow) * ldh + u;
+                        P.cbuf[oidx] = c_st[r];
+                        P.hbuf[oidx] = h_out[r];
+                        if (P.gates) *reinterpret_cast<float4*>(P.gates + ridx * ldg + u * 4) = gts[r];
+                    }
+                }
+            }
+        }
+        STAMP(2);
+        // ---- gather the partners' h_t: this thread's unit column, 24 row pairs in three rounds of 8
+        if (step + 1 < T && (tid >> 5) != j) {
+#pragma unroll 1
+            for (int rd = 0; rd < 3; ++rd) {
+                const unsigned long long* p0 = xpar + (size_t)(NF * rd) * HP + tid;
+                unsigned long long g[NF];
+                unsigned pending = (1u << NF) - 1u;
+                unsigned long long t_start = 0;
+                for (int spin = 0; pending; ++spin) {
+                    unsigned long long v[NF];
+#pragma unroll
+                    for (int k = 0; k < NF; ++k)
+                        if (pending & (1u << k)) v[k] = granule_load(p0 + (size_t)k * HP);
+#pragma unroll
+                    for (int k = 0; k < NF; ++k)
+                        if ((pending & (1u << k)) && (((unsigned)v[k] & 255u) | (((unsigned)(v[k] >> 32) & 255u) << 8)) == tag) {
+                            g[k] = v[k]; pending &= ~(1u << k);
+                        }
+                    if (pending && (spin & 1023) == 1023) {
+                        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                        const unsigned long long now = wall_ticks();
+                        if (!t_start) t_start = now;
+                        else if (now - t_start > kPollTimeoutTicks) { atomicCAS(err, 0, 1 | ((int)(step & 1023) << 4) | ((int)blockIdx.x << 16)); break; }
+                    }
+                }
+                __bf16* img = &hs_hi[2 * NF * rd][tid];                      // lo image: + R * HS elements
+#pragma unroll
+                for (int k = 0; k < NF; ++k) {
+                    __bf16* d = img + (2 * k) * HS;
+                    x3_split((unsigned)g[k] & ~255u, d[0], d[R * HS]);
+                    x3_split((unsigned)(g[k] >> 32) & ~255u, d[HS], d[HS + R * HS]);
+                }
+            }
+        }
+        STAMP(3);
+        lds_barrier();
+        STAMP(4);
+    }
+}
+
 // =========================================================================================
 // backward (BPTT): see lstm.hip for the per-step math
 // =========================================================================================
@@ -1410,6 +1610,47 @@ int lstm_forward_cluster_x3(const LstmStep* l, int n, const uint8_t* mask_tb, in
             L.l[k] = l[k0 + k]; L.tag0[k] = seq * 1024u + 1u;
         }
         hipLaunchKernelGGL(lstm_fwd_cluster_x3_kernel, dim3(per, nn), dim3(512), lds, s, L, mask_tb, B, T, H, ldh, ldg, err);
+        ADN_HIP_CHECK(hipGetLastError());
+    }
+    return ADN_OK;
+}
+
+// bf16x3 forward at 256 < H <= 512 (lstm_fwd_cluster_x3w_kernel): 16 workgroups per 48-utterance group
+bool lstm_cluster_x3w_supported(const LstmStep* l, int n, int B, int T, int H) {
+    if (H <= 256 || H > kWHP || T >= 1024 || getenv("ADN_LSTM_NO_CLUSTER") || getenv("ADN_LSTM_NO_X3_CLUSTER") ||
+        getenv("ADN_LSTM_NO_X3_WIDE")) return false;
+    for (int k = 0; k < n; ++k)
+        if (!l[k].xchg || !l[k].W_frag_fwd || !l[k].W_frag_fwd_lo) return false;
+    if (cdiv(B, kWRows) * kWCWG > cluster_cus()) return false;
+    if (lstm_frag_elems(H) != (size_t)4 * kWHP * kWHP) return false;
+    return cluster_kernel_fits<&lstm_fwd_cluster_x3w_kernel>(kWFwdLdsBytes);
+}
+
+int lstm_forward_cluster_x3w(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s) {
+    const int groups = cdiv(B, kWRows), per = groups * kWCWG, cus = cluster_cus();
+    ADN_CHECK(cus >= per, ADN_ERR_STATE, "lstm cluster kernel: one LSTM does not fit the device");
+    int* err = nullptr;
+    ADN_TRY(lstm_cluster_error_word(&err));
+    const int ldh = ld_of(H), ldg = ld_of(4 * H);
+    static bool attr_set[kMaxDevices] = {};
+    bool& attr = attr_set[current_device()];
+    if (!attr) {
+        ADN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_cluster_x3w_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWFwdLdsBytes));
+        attr = true;
+    }
+    const double bytes = (double)n * T * (4.0 * (12.0 * B * H + 4.0 * H * H) + B), flops = (double)n * T * 8.0 * B * H * H;
+    ProfScope prof(PROF_LSTM_FWD, flops, bytes, s, T);
+    const int chunk = std::max(1, cus / per);
+    for (int k0 = 0; k0 < n; k0 += chunk) {
+        const int nn = std::min(chunk, n - k0);
+        LstmClusterX3P L;
+        for (int k = 0; k < nn; ++k) {
+            unsigned seq = 0;
+            ADN_TRY(x3_launch_seq(l[k0 + k], &seq));
+            L.l[k] = l[k0 + k]; L.tag0[k] = seq * 1024u + 1u;
+        }
+        hipLaunchKernelGGL(lstm_fwd_cluster_x3w_kernel, dim3(per, nn), dim3(512), kWFwdLdsBytes, s, L, mask_tb, B, T, H, ldh, ldg, err);
         ADN_HIP_CHECK(hipGetLastError());
     }
     return ADN_OK;

@@ -157,6 +157,13 @@ def test_bf16x3_at_the_bench_geometry_against_f32_mode(torch_cuda, lib):
     m.close()
 
 
+def _families(lib):
+    from ip_avsr_amd import _lib
+    fam = (C.c_int64 * 4)()
+    _lib.check(lib.adn_debug_lstm_family_counts(fam))
+    return np.array(list(fam))
+
+
 def _small_x3_model(lstm_size, peepholes, seed, dims=(60, 44)):
     from ip_avsr_amd.model import AdeNetModel
     spec = O.spec_nstream(list(dims), enc_shapes=(96, 48, 24), enc_acts=("rectify", "rectify", "linear"),
@@ -174,12 +181,15 @@ def _small_x3_model(lstm_size, peepholes, seed, dims=(60, 44)):
 
 
 @pytest.mark.parametrize("H,B,T,peep", [(250, 70, 9, False), (250, 33, 2, True), (100, 5, 1, False), (64, 100, 12, True),
-                                        (256, 32, 5, False), (17, 40, 7, True), (32, 2100, 3, False)])
+                                        (256, 32, 5, False), (17, 40, 7, True), (32, 2100, 3, False),
+                                        (300, 70, 9, True), (512, 50, 5, False), (500, 100, 12, True), (257, 48, 1, False),
+                                        (400, 49, 2, True), (384, 800, 3, False)])
 def test_x3_weight_stationary_lstm_kernels_match_the_fp32_step_kernels(torch_cuda, lib, monkeypatch, H, B, T, peep):
     """lstm_{fwd,bwd}_cluster_x3_kernel (csrc/lstm_cluster.hip) against the fp32 step kernels the mode falls back to
     (ADN_LSTM_NO_X3_CLUSTER): ragged masks, partial 32-row groups, padded hidden sizes, peepholes, T = 1 / 2, backwards LSTMs
     (the aggregation pair); B = 2100 does not fit one resident launch (66 groups x 4 workgroups > 256 CUs): both runs then take
-    the step kernels.  h travels with a 16-bit significand between the workgroups: probabilities to 5e-6, gradients to
+    the step kernels.  256 < H <= 512: the wide forward kernel (16 workgroups per 48-utterance group; B = 800 does not fit) with
+    the fp32 step kernels behind it in the backward pass.  h travels with a 16-bit significand between the workgroups: probabilities to 5e-6, gradients to
     3e-4 of each tensor's scale (measured <= 1e-6 / 6e-5 with the recurrent weights scaled up 3 x; the bf16 mode's gates are 5e-3)."""
     spec, p, m, rng = _small_x3_model(H, peep, 100 * H + B + T)
     theta = min(9, 2 * T + 1) if T > 1 else 3
@@ -192,7 +202,13 @@ def test_x3_weight_stationary_lstm_kernels_match_the_fp32_step_kernels(torch_cud
             monkeypatch.setenv("ADN_LSTM_NO_X3_CLUSTER", "1")
         else:
             monkeypatch.delenv("ADN_LSTM_NO_X3_CLUSTER", raising=False)
+        fam0 = _families(lib)
         res[mode] = (m.predict(xs, mask, theta), m.compute_grads(xs, y, mask, theta), m.get_grads_dict())
+        fam = _families(lib) - fam0
+        if mode == "steps" or B > 700:
+            assert fam[3] == 0 and fam[0] > 0
+        else:
+            assert fam[3] > 0 and fam[0] == 0               # the weight-stationary kernels did run
     monkeypatch.delenv("ADN_LSTM_NO_X3_CLUSTER", raising=False)
     dp = np.abs(res["cluster"][0] - res["steps"][0]).max()
     dl = abs(res["cluster"][1] - res["steps"][1]) / abs(res["steps"][1])
