@@ -656,7 +656,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClus
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kWRows = 48, kWUnits = 32, kWCWG = 16, kWHP = 512, kWKS = 16, kWHS = kWHP + 8;
 constexpr int kWAccLds = 4 * 3 * 2 * 64 * 4;                           // fp32 words: [4 gates][3 row tiles][2 unit tiles][64 lanes] x 4 rows
-constexpr int kWFwdLds = 3;                                            // lo k-steps of a wave's W fragments that live in LDS
+constexpr int kWFwdLds = 4;                                            // lo k-steps of a wave's W fragments that live in LDS
 constexpr size_t kWFwdLdsBytes = (size_t)2 * kWRows * kWHS * 2 + (size_t)kWAccLds * 4 + (size_t)8 * kWFwdLds * 64 * 16;
 __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3w_kernel(const LstmClusterX3P L, const uint8_t* __restrict__ mask_tb,
                                                                    int B, int T, int H, int ldh, int ldg, int* err) {
@@ -707,6 +707,9 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3w_kernel(const LstmClu
     __syncthreads();
 
     const int acol = kq * 8;
+    const int row0 = r0 + 16 * min(rt, 2) + 4 * kq;
+    float pw_i = 0.f, pw_f = 0.f, pw_o = 0.f;          // peephole weights of this lane's unit (0: none -- c * 0 adds nothing)
+    if (P.peep) { pw_i = P.peep[uc]; pw_f = P.peep[ldh + uc]; pw_o = P.peep[2 * ldh + uc]; }
     uint8_t m[4];
     float4 xp[4];
     STAMP_INIT
@@ -715,12 +718,18 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3w_kernel(const LstmClu
         const int out_blk = t + (P.backwards ? 0 : 1);
         const unsigned tag = tag0 + (unsigned)step;
         unsigned long long* xpar = xb + (size_t)(step & 1) * (R / 2) * HP;
+        // (the row index is made opaque once per step: the compiler otherwise keeps a 64-bit address per row and array across the
+        //  loop -- 16 registers spilled to scratch and reloaded every step)
+        int rw = row0;
+        asm volatile("" : "+v"(rw));
+        int ucl = uc;
+        asm volatile("" : "+v"(ucl));
         if (gm) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const size_t ridx = (size_t)t * B + min(r0 + 16 * rt + 4 * kq + r, B - 1);
+                const size_t ridx = (size_t)t * B + min(rw + r, B - 1);
                 m[r] = mask_tb[ridx];
-                xp[r] = *reinterpret_cast<const float4*>(P.xproj + ridx * ldg + uc * 4);
+                xp[r] = *reinterpret_cast<const float4*>(P.xproj + ridx * ldg + ucl * 4);
             }
         }
         // ---- recurrent product of this wave's gate: three MFMAs per (row tile, k-step)
@@ -763,10 +772,10 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3w_kernel(const LstmClu
                 float a_i = xp[r].x + acc[0][r], a_f = xp[r].y + acc[1][r];
                 float a_g = xp[r].z + acc[2][r], a_o = xp[r].w + acc[3][r];
                 const float c_prev = c_st[r], h_prev = h_st[r];
-                if (P.peep) { a_i += c_prev * P.peep[uc]; a_f += c_prev * P.peep[ldh + uc]; }
+                a_i += c_prev * pw_i; a_f += c_prev * pw_f;
                 const float gi = c_sigmoid(a_i), gf = c_sigmoid(a_f), gg = c_tanh(a_g);
                 const float c_new = gf * c_prev + gi * gg;
-                if (P.peep) a_o += c_new * P.peep[2 * ldh + uc];
+                a_o += c_new * pw_o;
                 const float go = c_sigmoid(a_o);
                 const float h_new = go * c_tanh(c_new);
                 c_st[r] = m[r] ? c_new : c_prev;
@@ -790,7 +799,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3w_kernel(const LstmClu
             if (u < H) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int grow = r0 + 16 * rt + 4 * kq + r;
+                    const int grow = rw + r;
                     if (grow < B) {
                         const size_t ridx = (size_t)t * B + grow;
                         const size_t oidx = ((size_t)out_blk * B + grow) * ldh + u;

@@ -29,6 +29,10 @@ lens = rng.randint(12, T + 1, size=B); lens[0] = T
 mask = torch.as_tensor((np.arange(T)[None, :] < lens[:, None]).astype(np.uint8), device="cuda")
 x = [torch.as_tensor(rng.normal(size=(B, T, 1200)).astype(np.float32), device="cuda") * mask[..., None] for _ in range(4)]
 y = torch.as_tensor(np.repeat(rng.randint(0, 26, size=(B, 1)), T, axis=1).astype(np.int32), device="cuda")
-for _ in range(10):
+import time
+for it in range(int(os.environ.get("C4_STEPS", 10)) + 2):
+    if it == 2:
+        torch.cuda.synchronize(); t0 = time.perf_counter()
     m.train_step(x, y, mask, THETA, 1e-4, want_loss=False)
 torch.cuda.synchronize()
+print("configs[4] %s B=%d: %.3f ms per train step" % (sys.argv[1] if len(sys.argv) > 1 else "bf16x3", B, (time.perf_counter() - t0) * 1e3 / (it - 1)), flush=True)
