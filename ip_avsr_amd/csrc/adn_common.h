@@ -324,6 +324,8 @@ bool lstm_cluster_x3_supported(const LstmStep* l, int n, int B, int T, int H);
 int lstm_forward_cluster_x3(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
 bool lstm_cluster_x3w_supported(const LstmStep* l, int n, int B, int T, int H);      // 256 < H <= 512
 int lstm_forward_cluster_x3w(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
+bool lstm_cluster_x3w_bwd_supported(const LstmStep* l, int n, int B, int T, int H);
+int lstm_backward_cluster_x3w(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
 bool lstm_cluster_x3_bwd_supported(const LstmStep* l, int n, int B, int T, int H);
 int lstm_backward_cluster_x3(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
 int lstm_backward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);

@@ -522,6 +522,10 @@ static int lstm_backward_impl(const LstmStep* l, int n, const uint8_t* mask_tb, 
             if (sums_done) *sums_done = true;         // bias / initial-state gradients are added inside the kernel
             return lstm_backward_cluster_x3(l, n, mask_tb, B, T, H, s);
         }
+        if (lstm_cluster_x3w_bwd_supported(l, n, B, T, H)) {
+            if (sums_done) *sums_done = true;
+            return lstm_backward_cluster_x3w(l, n, mask_tb, B, T, H, s);
+        }
         precision = ADN_PRECISION_F32;
     }
     LstmLaunch L;

@@ -1390,6 +1390,291 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_x3_kernel(const LstmClus
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// bf16x3 backward, 256 < H <= 512 ("wide"): the geometry of lstm_fwd_cluster_x3w_kernel (16 workgroups of 32 units per
+// 48-utterance group).  Workgroup j holds the hi + lo fragments of ITS 128 rows of W_hid^T (its gate columns: 4 k-steps) for all
+// 512 units (2 x 128 KB: wave w takes unit tiles 4 w ..+3 = destinations 2 w, 2 w + 1; 12 of its 16 lo fragments sit in LDS),
+// multiplies its own dG_{t+1} (48 x 128, hi / lo images in LDS) into a partial dh for all units, keeps its 32 and sends the
+// other 15 x (48 x 32) to their owners as tagged granules (2 rows of a unit; pack_partials).  Inbox of a workgroup:
+// [2 parities][16 source slots][24 row pairs][32 units]; ALL 512 threads collect (three rounds of <= 8 granules of one
+// (row pair, unit): sources 0-7 | 8-14, summed in slot order) and hand the two half sums to the gate-math lanes through LDS.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kWDS = 4 * kWUnits + 8;                                  // LDS row stride of the dG image (own 128 gate columns)
+constexpr int kWPair = kWRows / 2 * kWUnits;                           // granules of one (destination, source) pair
+constexpr int kWBwdLds = 3;                                            // lo k-steps (of a wave's 4) whose fragments live in LDS
+constexpr int kWBwdWOff = (2 * kWRows * kWDS * 2 + 3 * kWRows * (kWUnits + 1) * 4 + 15) / 16 * 16 / 2;   // bf16 elements
+constexpr size_t kWBwdLdsBytes = (size_t)kWBwdWOff * 2 + (size_t)8 * 4 * kWBwdLds * 64 * 16;
+__global__ __launch_bounds__(512) void lstm_bwd_cluster_x3w_kernel(const LstmClusterP L, const uint8_t* __restrict__ mask_tb,
+                                                                   int B, int T, int H, int ldh, int ldg, int* err) {
+    constexpr int R = kWRows, CWG = kWCWG, HP = kWHP, NF = 8;
+    extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
+    __bf16 (*dgs_hi)[kWDS] = reinterpret_cast<__bf16 (*)[kWDS]>(lds);                            // [48][kWDS] own dG_{t+1}, hi
+    __bf16 (*dgs_lo)[kWDS] = reinterpret_cast<__bf16 (*)[kWDS]>(lds + R * kWDS);                 // ... lo
+    float (*part)[kWUnits + 1] = reinterpret_cast<float (*)[kWUnits + 1]>(lds + 2 * R * kWDS);  // [48][33] own share of the own partial
+    float (*recv)[kWUnits + 1] = part + R;                                                       // [2 halves x 48][33] sums of the foreign shares
+    bf16x8* wl = reinterpret_cast<bf16x8*>(lds + kWBwdWOff);             // [8 waves][4 tiles][kWBwdLds k-steps][64 lanes] lo fragments
+    const LstmStep& P = L.l[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int group = blockIdx.x / CWG, j = blockIdx.x % CWG;
+    const int r0 = group * R;
+    const int rt = wave >> 1, ut = wave & 1;          // gate math: row tile (3: none), local unit tile
+    const bool gm = rt < 3;
+    const int ul = 16 * ut + i;
+    const int u = kWUnits * j + ul;
+    unsigned long long* xb = reinterpret_cast<unsigned long long*>(P.xchg) + (size_t)((B + R - 1) / R) * 2 * (R / 2) * HP +
+                             (size_t)group * 2 * CWG * CWG * kWPair;
+
+    // resident W slice: k-steps [4j, 4j+4) (this workgroup's gate columns) of unit tiles 4 wave + {0..3}
+    const bf16x8* wsrc_hi = reinterpret_cast<const bf16x8*>(P.W_frag_bwd) + (size_t)(4 * j) * 64 + lane;
+    const bf16x8* wsrc_lo = reinterpret_cast<const bf16x8*>(P.W_frag_bwd_lo) + (size_t)(4 * j) * 64 + lane;
+    constexpr int KR = 4 - kWBwdLds;
+    bf16x8 whi[4][4], wlo[4][KR];
+    bf16x8* wmine = wl + (size_t)wave * 4 * kWBwdLds * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            whi[c][s_] = wsrc_hi[((size_t)(4 * wave + c) * (HP / 8) + s_) * 64];
+            const bf16x8 lo = wsrc_lo[((size_t)(4 * wave + c) * (HP / 8) + s_) * 64];
+            if (s_ < KR) wlo[c][s_ < KR ? s_ : 0] = lo;
+            else wmine[(c * kWBwdLds + (s_ - KR)) * 64] = lo;
+        }
+    for (int e = tid; e < 2 * R * kWDS / 8; e += 512) reinterpret_cast<bf16x8*>(lds)[e] = bf16x8{};
+    float dh_c[4], dc_s[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { dh_c[r] = 0.f; dc_s[r] = 0.f; }
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+
+    const int uc = min(u, H - 1);
+    float pk_i = 0.f, pk_f = 0.f, pk_o = 0.f;          // peephole weights of this lane's unit
+    if (P.peep) { pk_i = P.peep[uc]; pk_f = P.peep[ldh + uc]; pk_o = P.peep[2 * ldh + uc]; }
+    // (row and unit indices are made opaque once per use: the compiler otherwise keeps a 64-bit offset per row and array live
+    //  across the loop and spills them, and the loaded values with them)
+    const int ld_dhs = P.ld_dhs ? P.ld_dhs : ldh;
+    const int rowb = r0 + 16 * min(rt, 2) + 4 * kq;
+    float l_dhs[4], l_ct[4], l_cp[4];
+    float4 l_gt[4];
+    uint8_t l_m[4];
+    auto request_state = [&](int step_) {
+        const int t_ = P.backwards ? step_ : (T - 1 - step_);
+        const int pb = t_ + (P.backwards ? 1 : 0), ob = t_ + (P.backwards ? 0 : 1);
+        const uint8_t* mk = mask_tb + (size_t)t_ * B;
+        const float* dh_ = P.dhs + (size_t)t_ * B * ld_dhs;
+        const float* gt_ = P.gates + (size_t)t_ * B * ldg;
+        const float* co_ = P.cbuf + (size_t)ob * B * ldh;
+        const float* cp_ = P.cbuf + (size_t)pb * B * ldh;
+        int rb = rowb, ucl = uc;
+        asm volatile("" : "+v"(rb), "+v"(ucl));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned rc = (unsigned)min(rb + r, B - 1);
+            l_m[r] = mk[rc];
+            l_dhs[r] = dh_[rc * (unsigned)ld_dhs + (unsigned)ucl];
+            l_gt[r] = *reinterpret_cast<const float4*>(gt_ + (rc * (unsigned)ldg + (unsigned)ucl * 4u));
+            l_ct[r] = co_[rc * (unsigned)ldh + (unsigned)ucl];
+            l_cp[r] = cp_[rc * (unsigned)ldh + (unsigned)ucl];
+        }
+    };
+    for (int step = 0; step <= T; ++step) {
+        const int t = P.backwards ? step : (T - 1 - step);
+        const unsigned tag8 = 1u + (unsigned)(step % 255);
+        unsigned long long* xpar = xb + (size_t)(step & 1) * CWG * CWG * kWPair;
+        float rec[4] = {0.f, 0.f, 0.f, 0.f};
+        if (step > 0) {
+            // ---- partial dh of unit tiles 4 wave ..+3 (destinations 2 wave, 2 wave + 1), one row tile after the other (the
+            //      accumulators of all three at once leave no room: 48 registers on top of the 80 of the fragments)
+            const bf16x8* wm = wmine;                 // (opaque: the fragments in LDS are read where they are used, not hoisted
+            asm volatile("" : "+v"(wm));              //  into 48 more registers ahead of the loop)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                f32x4 acc[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const bf16x8 a_hi = *reinterpret_cast<const bf16x8*>(&dgs_hi[16 * q + i][s * 32 + kq * 8]);
+                    const bf16x8 a_lo = *reinterpret_cast<const bf16x8*>(&dgs_lo[16 * q + i][s * 32 + kq * 8]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, whi[c][s], acc[c], 0, 0, 0);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, whi[c][s], acc[c], 0, 0, 0);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            a_hi, s < KR ? wlo[c][s < KR ? s : 0] : wm[(c * kWBwdLds + (s < KR ? 0 : s - KR)) * 64], acc[c], 0, 0, 0);
+                }
+                // accumulator map: unit = 16 (4 wave + c) + (lane & 15), row = 16 q + 4 kq + r
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int dst = 2 * wave + (c >> 1), tl = c & 1;
+                    if (dst == j) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) part[16 * q + 4 * kq + r][16 * tl + i] = acc[c][r];
+                    } else {
+                        unsigned long long* box = xpar + (size_t)(dst * CWG + (j - dst - 1 + CWG) % CWG) * kWPair + 16 * tl + i;
+#pragma unroll
+                        for (int rp = 0; rp < 2; ++rp)
+                            __hip_atomic_store(box + (size_t)(8 * q + 2 * kq + rp) * kWUnits,
+                                               pack_partials(acc[c][2 * rp], acc[c][2 * rp + 1], tag8), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+        }
+        // what the gate math reads from HBM is requested AFTER the product; the round trips hide under the exchange hop
+        if (gm) request_state(min(step, T - 1));
+        if (step > 0) {
+            // ---- collect: work item w = 512 round + tid -> (half w / 768: sources 0-7 | 8-14, position w % 768 = (row pair, unit))
+#pragma unroll 1
+            for (int rd = 0; rd < 3; ++rd) {
+                const int w = rd * 512 + tid;
+                const int half = w >= kWPair ? 1 : 0, pos = w - kWPair * half;
+                const unsigned long long* p0 = xpar + (size_t)(j * CWG + 8 * half) * kWPair + pos;
+                unsigned long long g[NF];
+                unsigned pending = half ? 0x7fu : 0xffu;
+                unsigned long long t_start = 0;
+                for (int spin = 0; pending; ++spin) {
+                    unsigned long long v[NF];
+#pragma unroll
+                    for (int k = 0; k < NF; ++k)
+                        if (pending & (1u << k)) v[k] = granule_load(p0 + (size_t)k * kWPair);
+#pragma unroll
+                    for (int k = 0; k < NF; ++k)
+                        if ((pending & (1u << k)) && (((unsigned)v[k] & 15u) | (((unsigned)(v[k] >> 32) & 15u) << 4)) == tag8) {
+                            g[k] = v[k]; pending &= ~(1u << k);
+                        }
+                    if (pending && (spin & 1023) == 1023) {
+                        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                        const unsigned long long now = wall_ticks();
+                        if (!t_start) t_start = now;
+                        else if (now - t_start > kPollTimeoutTicks) { atomicCAS(err, 0, 2 | (step << 4) | ((int)blockIdx.x << 16)); break; }
+                    }
+                }
+                float sa = 0.f, sb = 0.f;
+#pragma unroll
+                for (int k = 0; k < NF; ++k)
+                    if (k < 7 || !half) {
+                        sa += __builtin_bit_cast(float, (unsigned)g[k] & ~15u);
+                        sb += __builtin_bit_cast(float, (unsigned)(g[k] >> 32) & ~15u);
+                    }
+                float* d = &recv[R * half + 2 * (pos >> 5)][pos & 31];
+                d[0] = sa;
+                d[kWUnits + 1] = sb;
+            }
+            lds_barrier();                            // own share in `part`, the foreign sums in `recv`; dG_{t+1} has been consumed
+            if (gm) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * rt + 4 * kq + r;
+                    rec[r] = part[row][ul] + recv[row][ul] + recv[R + row][ul];
+                }
+            }
+        }
+        if (step == T) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dh_c[r] += rec[r];
+            break;
+        }
+        // ---- gate math of step t for this lane's unit and 4 rows (fp32; see lstm.hip)
+        if (gm) {
+            float pw_i = 0.f, pw_f = 0.f, pw_o = 0.f;
+            int rb = rowb, ucl = uc;
+            asm volatile("" : "+v"(rb), "+v"(ucl));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * rt + 4 * kq + r, grow = rb + r;
+                const bool ok = grow < B && u < H;
+                const unsigned goff = (unsigned)grow * (unsigned)ldg + (unsigned)ucl * 4u;       // (used where ok: this row and unit)
+                float4 dg = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) {
+                    const float dh = l_dhs[r] + dh_c[r] + rec[r];
+                    const float dc = dc_s[r];
+                    if (l_m[r]) {
+                        const float4 gt = l_gt[r];
+                        const float c_t = l_ct[r], c_prev = l_cp[r];
+                        const float tc = c_tanh(c_t);
+                        const float da_o = dh * tc * gt.w * (1.f - gt.w);
+                        float dcn = dc + dh * gt.w * (1.f - tc * tc);
+                        if (P.peep) { dcn += da_o * pk_o; pw_o += da_o * c_t; }
+                        const float da_i = dcn * gt.z * gt.x * (1.f - gt.x);
+                        const float da_f = dcn * c_prev * gt.y * (1.f - gt.y);
+                        const float da_g = dcn * gt.x * (1.f - gt.z * gt.z);
+                        float dcp = dcn * gt.y;
+                        if (P.peep) {
+                            dcp += da_i * pk_i + da_f * pk_f;
+                            pw_i += da_i * c_prev; pw_f += da_f * c_prev;
+                        }
+                        dg = make_float4(c_clip5(da_i), c_clip5(da_f), c_clip5(da_g), c_clip5(da_o));
+                        dh_c[r] = 0.f;
+                        dc_s[r] = dcp;
+                    } else {
+                        dh_c[r] = dh;
+                    }
+                    if (!P.dG16lo) *reinterpret_cast<float4*>(P.dG + (size_t)t * B * ldg + goff) = dg;      // (ok: goff is this row and unit)
+                    bsum.x += dg.x; bsum.y += dg.y; bsum.z += dg.z; bsum.w += dg.w;
+                }
+                bf16x4 dhi, dlo;
+                dhi[0] = (__bf16)dg.x; dhi[1] = (__bf16)dg.y; dhi[2] = (__bf16)dg.z; dhi[3] = (__bf16)dg.w;
+                dlo[0] = (__bf16)(dg.x - (float)dhi[0]); dlo[1] = (__bf16)(dg.y - (float)dhi[1]);
+                dlo[2] = (__bf16)(dg.z - (float)dhi[2]); dlo[3] = (__bf16)(dg.w - (float)dhi[3]);
+                if (ok && P.dG16lo) {                     // the two planes in place of the fp32 row piece: the same 16 bytes per (row, unit)
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.dG16) + (size_t)t * B * ldg + goff) = dhi;
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(P.dG16lo) + (size_t)t * B * ldg + goff) = dlo;
+                }
+                *reinterpret_cast<bf16x4*>(&dgs_hi[row][ul * 4]) = dhi;
+                *reinterpret_cast<bf16x4*>(&dgs_lo[row][ul * 4]) = dlo;
+            }
+            if (P.dpeep_part) {
+                float si = pw_i, sf = pw_f, so = pw_o;
+                si += __shfl_xor(si, 16, 64); si += __shfl_xor(si, 32, 64);
+                sf += __shfl_xor(sf, 16, 64); sf += __shfl_xor(sf, 32, 64);
+                so += __shfl_xor(so, 16, 64); so += __shfl_xor(so, 32, 64);
+                if (kq == 0 && u < H) {
+                    float* ds = P.det_ws ? P.det_ws + (size_t)(3 * group + rt) * P.det_stride + ldg + 2 * ldh : nullptr;
+                    group_sum_add(P.dpeep_part + u, ds ? ds + u : nullptr, si);
+                    group_sum_add(P.dpeep_part + ldh + u, ds ? ds + ldh + u : nullptr, sf);
+                    group_sum_add(P.dpeep_part + 2 * (size_t)ldh + u, ds ? ds + 2 * ldh + u : nullptr, so);
+                }
+            }
+        }
+        lds_barrier();
+    }
+    if (gm) {
+        float sh = 0.f, sc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int grow = r0 + 16 * rt + 4 * kq + r;
+            if (grow < B && u < H) {
+                P.dh_carry[(size_t)grow * ldh + u] = dh_c[r];
+                P.dc_state[(size_t)grow * ldh + u] = dc_s[r];
+                sh += dh_c[r]; sc += dc_s[r];
+            }
+        }
+        if (P.dbias) {
+#pragma unroll
+            for (int o = 16; o < 64; o <<= 1) {
+                bsum.x += __shfl_xor(bsum.x, o, 64); bsum.y += __shfl_xor(bsum.y, o, 64);
+                bsum.z += __shfl_xor(bsum.z, o, 64); bsum.w += __shfl_xor(bsum.w, o, 64);
+                sh += __shfl_xor(sh, o, 64); sc += __shfl_xor(sc, o, 64);
+            }
+            if (kq == 0 && u < H) {
+                float* ds = P.det_ws ? P.det_ws + (size_t)(3 * group + rt) * P.det_stride : nullptr;
+                group_sum_add(P.dbias + 4 * u, ds ? ds + 4 * u : nullptr, bsum.x); group_sum_add(P.dbias + 4 * u + 1, ds ? ds + 4 * u + 1 : nullptr, bsum.y);
+                group_sum_add(P.dbias + 4 * u + 2, ds ? ds + 4 * u + 2 : nullptr, bsum.z); group_sum_add(P.dbias + 4 * u + 3, ds ? ds + 4 * u + 3 : nullptr, bsum.w);
+                group_sum_add(P.dhid_init + u, ds ? ds + ldg + u : nullptr, sh); group_sum_add(P.dcell_init + u, ds ? ds + ldg + ldh + u : nullptr, sc);
+            }
+        }
+    }
+    // leave this workgroup's inbox empty for the next launch (after EVERY lane has taken its last granules)
+    __syncthreads();
+    for (int e = tid; e < 2 * CWG * kWPair; e += 512) {
+        const int par = e / (CWG * kWPair), rest = e % (CWG * kWPair);
+        xb[(size_t)par * CWG * CWG * kWPair + (size_t)j * CWG * kWPair + rest] = 0ull;
+    }
+}
+
 // per-device launcher state (one process may drive several devices: a model polls the error word of ITS device and
 // sizes its launches by ITS device's CU count)
 constexpr int kMaxDevices = 64;
@@ -1469,7 +1754,11 @@ bool lstm_cluster_supported(const LstmStep* l, int n, int B, int T, int H) {
 
 size_t lstm_cluster_xchg_bytes(int B, int H) {   // forward region (h granules) + backward region (partial-dh granules)
     const int cwg = cluster_wgs(H);
-    return (size_t)cdiv(B, kCRows) * (2 * 16 * cwg * kCUnits + 2 * cwg * cwg * kBxPair) * 8;
+    const size_t narrow = (size_t)cdiv(B, kCRows) * (2 * 16 * cwg * kCUnits + 2 * cwg * cwg * kBxPair) * 8;
+    if (H <= 256) return narrow;
+    // 256 < H <= 512 also serves the bf16x3 mode's wide kernels: 16 workgroups per 48-utterance group
+    const size_t wide = (size_t)cdiv(B, kWRows) * (2 * (kWRows / 2) * kWHP + 2 * kWCWG * kWCWG * kWPair) * 8;
+    return std::max(narrow, wide);
 }
 
 int lstm_cluster_error_word(int** out) {
@@ -1660,6 +1949,43 @@ int lstm_forward_cluster_x3w(const LstmStep* l, int n, const uint8_t* mask_tb, i
             L.l[k] = l[k0 + k]; L.tag0[k] = seq * 1024u + 1u;
         }
         hipLaunchKernelGGL(lstm_fwd_cluster_x3w_kernel, dim3(per, nn), dim3(512), kWFwdLdsBytes, s, L, mask_tb, B, T, H, ldh, ldg, err);
+        ADN_HIP_CHECK(hipGetLastError());
+    }
+    return ADN_OK;
+}
+
+// ... and its backward kernel (the exchange buffer's wide layout: lstm_cluster_xchg_bytes)
+bool lstm_cluster_x3w_bwd_supported(const LstmStep* l, int n, int B, int T, int H) {
+    if (H <= 256 || H > kWHP || T >= 1024 || getenv("ADN_LSTM_NO_CLUSTER") || getenv("ADN_LSTM_NO_X3_CLUSTER") ||
+        getenv("ADN_LSTM_NO_X3_WIDE") || getenv("ADN_LSTM_NO_X3_CLUSTER_BWD")) return false;
+    for (int k = 0; k < n; ++k)
+        if (!l[k].xchg || !l[k].W_frag_bwd || !l[k].W_frag_bwd_lo) return false;
+    if (cdiv(B, kWRows) * kWCWG > cluster_cus()) return false;
+    if (lstm_frag_elems(H) != (size_t)4 * kWHP * kWHP) return false;
+    return cluster_kernel_fits<&lstm_bwd_cluster_x3w_kernel>(kWBwdLdsBytes);
+}
+
+int lstm_backward_cluster_x3w(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s) {
+    const int groups = cdiv(B, kWRows), per = groups * kWCWG, cus = cluster_cus();
+    ADN_CHECK(cus >= per, ADN_ERR_STATE, "lstm cluster kernel: one LSTM does not fit the device");
+    int* err = nullptr;
+    ADN_TRY(lstm_cluster_error_word(&err));
+    const int ldh = ld_of(H), ldg = ld_of(4 * H);
+    static bool attr_set[kMaxDevices] = {};
+    bool& attr = attr_set[current_device()];
+    if (!attr) {
+        ADN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_cluster_x3w_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWBwdLdsBytes));
+        attr = true;
+    }
+    const double bytes = (double)n * T * 4.0 * (15.0 * B * H + 4.0 * H * H), flops = (double)n * T * 8.0 * B * H * H;
+    ProfScope prof(PROF_LSTM_BWD, flops, bytes, s, T + 1);
+    const int chunk = std::max(1, cus / per);
+    for (int k0 = 0; k0 < n; k0 += chunk) {
+        const int nn = std::min(chunk, n - k0);
+        LstmClusterP L;
+        for (int k = 0; k < nn; ++k) L.l[k] = l[k0 + k];
+        hipLaunchKernelGGL(lstm_bwd_cluster_x3w_kernel, dim3(per, nn), dim3(512), kWBwdLdsBytes, s, L, mask_tb, B, T, H, ldh, ldg, err);
         ADN_HIP_CHECK(hipGetLastError());
     }
     return ADN_OK;

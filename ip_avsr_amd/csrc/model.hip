@@ -1010,7 +1010,7 @@ LstmStep make_step(const adn_model* m, const LstmParams& lp, const LstmWork& w, 
     s.dG16 = b16 ? m->shadow_of(w.dG) : nullptr;
     static const bool dg_fp32 = getenv("ADN_LSTM_DG_FP32") != nullptr;       // (A/B: keep the fp32 copy of dG)
     if (grads && shadows_on(m) && s.dG16 && !m->keep_fp32 && !dg_fp32) s.dG_fp32_off = 1;       // bf16 mode: the bf16 copy is the only one read
-    if (grads && x3 && m->H <= 256 && m->planes() && !m->keep_fp32 && !dg_fp32) { s.dG16 = m->shadow_of(w.dG); s.dG16lo = m->shadow_lo_of(w.dG); if (!s.dG16 || !s.dG16lo) s.dG16 = s.dG16lo = nullptr; }
+    if (grads && x3 && m->planes() && !m->keep_fp32 && !dg_fp32) { s.dG16 = m->shadow_of(w.dG); s.dG16lo = m->shadow_lo_of(w.dG); if (!s.dG16 || !s.dG16lo) s.dG16 = s.dG16lo = nullptr; }
     // (dG leaves the weight-stationary backward kernels in the form its readers take -- the bf16 copy in bf16 mode, the two planes
     //  in bf16x3 mode -- INSTEAD of as fp32: the same or fewer bytes per step from the kernel, no split pass behind it.  Writing
     //  the planes in ADDITION to fp32 cost the bf16x3 step 0.3 - 0.7 us of its 6.4 and put the kernel below the 40 % line.)
