@@ -263,6 +263,8 @@ int adn_debug_occupy_cus(int n_workgroups, int lds_bytes, double ms, void* hip_s
 /* test hook: LSTM forward passes dispatched so far per kernel family: [0] one launch per time step, [1] one-workgroup
  * persistent kernels, [2] weight-stationary kernels, [3] weight-stationary bf16x3 kernels */
 int adn_debug_lstm_family_counts(int64_t out[4]);
+/* ... and LSTM backward passes, same families */
+int adn_debug_lstm_backward_family_counts(int64_t out[4]);
 
 /* per-kernel-class timing with HIP events recorded on the model's stream around every launch of the
  * class (bench.py's live roofline measurement).  flops / bytes are the ALGORITHMIC work of the launches

@@ -112,6 +112,7 @@ _SIGNATURES = {
     "adn_debug_raise_exchange_error": (C.c_int, [C.c_int]),
     "adn_debug_occupy_cus": (C.c_int, [C.c_int, C.c_int, C.c_double, _P]),
     "adn_debug_lstm_family_counts": (C.c_int, [C.POINTER(C.c_int64)]),
+    "adn_debug_lstm_backward_family_counts": (C.c_int, [C.POINTER(C.c_int64)]),
     "adn_profile_enable": (C.c_int, [_P, C.c_int]),
     "adn_profile_read": (C.c_int, [_P, C.POINTER(ProfileEntry), C.c_int, C.POINTER(C.c_int)]),
     "adn_op_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int, _P,

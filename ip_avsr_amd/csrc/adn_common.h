@@ -310,6 +310,7 @@ int lstm_backward_persistent(const LstmStep* l, int n, const uint8_t* mask_tb, i
 // forward passes dispatched per kernel family since the library was loaded: [per-step launches, one-workgroup persistent,
 // weight-stationary, weight-stationary bf16x3] (adn_debug_lstm_family_counts: lets a test see WHICH family ran)
 extern long long g_lstm_family_forwards[4];
+extern long long g_lstm_family_backwards[4];
 bool lstm_cluster_supported(const LstmStep* l, int n, int B, int T, int H);
 // true when lstm_forward(l, n, ...) will compute every LSTM's input projection inside the weight-stationary kernel (all of them
 // offer x16 / W_in_frag / b_in with the same Kx <= 160): the caller then skips the projection GEMM, xproj is not read

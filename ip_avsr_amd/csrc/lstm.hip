@@ -317,6 +317,7 @@ int lstm_pack_whid_t(const float* W, void* out, int H, hipStream_t s) {
 }
 
 long long g_lstm_family_forwards[4] = {0, 0, 0, 0};
+long long g_lstm_family_backwards[4] = {0, 0, 0, 0};
 
 int lstm_forward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, int precision, hipStream_t s) {
     ADN_CHECK(n >= 1 && n <= kMaxLstmPerLaunch, ADN_ERR_INVALID, "lstm_forward: bad LSTM count");
@@ -520,10 +521,12 @@ static int lstm_backward_impl(const LstmStep* l, int n, const uint8_t* mask_tb, 
     if (precision == ADN_PRECISION_BF16X3) {          // fp32-grade products on the bf16 matrix pipe, or the fp32 step kernels
         if (lstm_cluster_x3_bwd_supported(l, n, B, T, H)) {
             if (sums_done) *sums_done = true;         // bias / initial-state gradients are added inside the kernel
+            g_lstm_family_backwards[3] += n;
             return lstm_backward_cluster_x3(l, n, mask_tb, B, T, H, s);
         }
         if (lstm_cluster_x3w_bwd_supported(l, n, B, T, H)) {
             if (sums_done) *sums_done = true;
+            g_lstm_family_backwards[3] += n;
             return lstm_backward_cluster_x3w(l, n, mask_tb, B, T, H, s);
         }
         precision = ADN_PRECISION_F32;
@@ -536,6 +539,7 @@ static int lstm_backward_impl(const LstmStep* l, int n, const uint8_t* mask_tb, 
         (H <= 256 || (lstm_cluster_supported(l, n, B, T, H) && !getenv("ADN_LSTM_NO_CLUSTER_BWD")) ||
          getenv("ADN_LSTM_WIDE_PERSISTENT")))
         return lstm_backward_persistent(l, n, mask_tb, B, T, H, s, sums_done);
+    g_lstm_family_backwards[0] += n;
     for (int k = 0; k < n; ++k) {
         ADN_HIP_CHECK(hipMemsetAsync(l[k].dh_carry, 0, (size_t)B * ldh * sizeof(float), s));
         ADN_HIP_CHECK(hipMemsetAsync(l[k].dc_state, 0, (size_t)B * ldh * sizeof(float), s));

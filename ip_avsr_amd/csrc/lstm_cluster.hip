@@ -1477,6 +1477,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_x3w_kernel(const LstmClu
             l_cp[r] = cp_[rc * (unsigned)ldh + (unsigned)ucl];
         }
     };
+    STAMP_INIT
     for (int step = 0; step <= T; ++step) {
         const int t = P.backwards ? step : (T - 1 - step);
         const unsigned tag8 = 1u + (unsigned)(step % 255);
@@ -1523,6 +1524,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_x3w_kernel(const LstmClu
                 }
             }
         }
+        STAMP(5);
         // what the gate math reads from HBM is requested AFTER the product; the round trips hide under the exchange hop
         if (gm) request_state(min(step, T - 1));
         if (step > 0) {
@@ -1563,6 +1565,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_x3w_kernel(const LstmClu
                 d[0] = sa;
                 d[kWUnits + 1] = sb;
             }
+            STAMP(6);
             lds_barrier();                            // own share in `part`, the foreign sums in `recv`; dG_{t+1} has been consumed
             if (gm) {
 #pragma unroll
@@ -1640,6 +1643,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_x3w_kernel(const LstmClu
             }
         }
         lds_barrier();
+        STAMP(7);
     }
     if (gm) {
         float sh = 0.f, sc = 0.f;
@@ -2088,6 +2092,12 @@ extern "C" int adn_debug_occupy_cus(int n_workgroups, int lds_bytes, double ms, 
 extern "C" int adn_debug_lstm_family_counts(int64_t out[4]) {
     if (!out) return ADN_ERR_INVALID;
     for (int k = 0; k < 4; ++k) out[k] = adn::g_lstm_family_forwards[k];
+    return ADN_OK;
+}
+
+extern "C" int adn_debug_lstm_backward_family_counts(int64_t out[4]) {
+    if (!out) return ADN_ERR_INVALID;
+    for (int k = 0; k < 4; ++k) out[k] = adn::g_lstm_family_backwards[k];
     return ADN_OK;
 }
 

@@ -396,8 +396,10 @@ int lstm_backward_persistent(const LstmStep* l, int n, const uint8_t* mask_tb, i
                              bool* sums_done) {
     if (lstm_cluster_supported(l, n, B, T, H) && !getenv("ADN_LSTM_NO_CLUSTER_BWD")) {
         if (sums_done) *sums_done = true;             // bias / initial-state gradients are added inside the kernel
+        g_lstm_family_backwards[2] += n;
         return lstm_backward_cluster(l, n, mask_tb, B, T, H, s);
     }
+    g_lstm_family_backwards[1] += n;
     LstmLaunchP L;
     for (int k = 0; k < n; ++k) L.l[k] = l[k];
     const int ldh = ld_of(H), ldg = ld_of(4 * H);

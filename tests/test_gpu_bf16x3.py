@@ -158,10 +158,12 @@ def test_bf16x3_at_the_bench_geometry_against_f32_mode(torch_cuda, lib):
 
 
 def _families(lib):
+    """forward passes per kernel family [step, one-workgroup, weight-stationary bf16, ... bf16x3] + the same for backward passes"""
     from ip_avsr_amd import _lib
-    fam = (C.c_int64 * 4)()
+    fam, bam = (C.c_int64 * 4)(), (C.c_int64 * 4)()
     _lib.check(lib.adn_debug_lstm_family_counts(fam))
-    return np.array(list(fam))
+    _lib.check(lib.adn_debug_lstm_backward_family_counts(bam))
+    return np.array(list(fam) + list(bam))
 
 
 def _small_x3_model(lstm_size, peepholes, seed, dims=(60, 44)):
@@ -206,9 +208,9 @@ def test_x3_weight_stationary_lstm_kernels_match_the_fp32_step_kernels(torch_cud
         res[mode] = (m.predict(xs, mask, theta), m.compute_grads(xs, y, mask, theta), m.get_grads_dict())
         fam = _families(lib) - fam0
         if mode == "steps" or B > 700:
-            assert fam[3] == 0 and fam[0] > 0
+            assert fam[3] == 0 and fam[0] > 0 and fam[7] == 0 and fam[4] > 0
         else:
-            assert fam[3] > 0 and fam[0] == 0               # the weight-stationary kernels did run
+            assert fam[3] > 0 and fam[0] == 0 and fam[7] > 0 and fam[4] == 0    # the weight-stationary kernels did run, both ways
     monkeypatch.delenv("ADN_LSTM_NO_X3_CLUSTER", raising=False)
     dp = np.abs(res["cluster"][0] - res["steps"][0]).max()
     dl = abs(res["cluster"][1] - res["steps"][1]) / abs(res["steps"][1])
@@ -226,11 +228,12 @@ def test_x3_weight_stationary_lstm_kernels_match_the_fp32_step_kernels(torch_cud
     m.close()
 
 
-def test_x3_exchange_tags_survive_more_launches_than_their_sequence_field(torch_cuda, lib, monkeypatch):
+@pytest.mark.parametrize("H", [250, 320])
+def test_x3_exchange_tags_survive_more_launches_than_their_sequence_field(torch_cuda, lib, monkeypatch, H):
     """The forward kernel's granules carry a 16-bit tag = 6 launch-sequence bits (per exchange buffer) + 10 step bits: 150
     launches on the same buffers (two wraps of the sequence), each with fresh inputs, must each reproduce the fp32 step
     kernels' result; so must launches of different T that leave old tags of other steps behind."""
-    spec, p, m, rng = _small_x3_model(250, False, 7)
+    spec, p, m, rng = _small_x3_model(H, False, 7)       # (320: the wide forward kernel, same tag scheme)
     B = 40
     cases = [(rng.integers(2, 12), rng.normal(size=(B, 12, 60)).astype(np.float32), rng.normal(size=(B, 12, 44)).astype(np.float32))
              for _ in range(6)]
