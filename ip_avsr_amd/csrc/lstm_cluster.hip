@@ -1,4 +1,5 @@
-// Weight-stationary LSTM kernels (bf16 mode, H <= 512; bf16x3 mode, H <= 256: the *_x3 kernels further down): W_hid never
+// Weight-stationary LSTM kernels (bf16 mode, H <= 512; bf16x3 mode: the *_x3 kernels (H <= 256) and *_x3w kernels (H <= 512)
+// further down): W_hid never
 // leaves the CU.
 //
 // The persistent kernels of lstm_persistent.hip give a 16-utterance slice to ONE workgroup, which must then stream

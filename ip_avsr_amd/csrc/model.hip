@@ -859,7 +859,7 @@ int refresh_transposed(adn_model* m) {
     return ADN_OK;
 }
 
-// bf16x3 mode: hi / lo fragment images of every W_hid for the weight-stationary kernels (H <= 256)
+// bf16x3 mode: hi / lo fragment images of every W_hid for the weight-stationary kernels (H <= 512)
 int refresh_transposed(adn_model* m);
 constexpr size_t kPlaneSlack = (size_t)1 << 20;       // bytes behind a bf16 plane that k-strided stage reads may touch: zero
 int ensure_params16(adn_model* m) {
