@@ -31,6 +31,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct LstmClusterP {
     LstmStep l[kMaxLstmPerLaunch];
@@ -651,8 +652,10 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClus
 //               fragments (kWFwdLds lo k-steps of them in LDS), 144 MFMAs per step; no fragment is held twice, no partial
 //               sums over k to combine
 //   gate math   wave w < 6: row tile w >> 1, unit tile w & 1; the accumulators cross through 24 KB of LDS
-//   exchange    [2 parities][24 row pairs][512 units] granules per group, tagged as above; a thread owns one unit column and
-//               polls its 24 row pairs in three rounds of 8 (the own workgroup's 32 columns sit out)
+//   exchange    [2 parities][12 row quads][512 units][2 granules] per group, granules tagged as above; a lane publishes its 4
+//               rows (2 granules) with ONE 16-byte write-through store; a thread owns one unit column and polls its 12 quads
+//               in three rounds of 4 16-byte sc1 buffer loads, each half validated by its own tag (the own workgroup's 32
+//               columns sit out)
 // LDS: the two h images 2 x 48 x 520 x 2 B = 97.5 KB + 24 KB + 24 KB of lo fragments.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kWRows = 48, kWUnits = 32, kWCWG = 16, kWHP = 512, kWKS = 16, kWHS = kWHP + 8;
@@ -661,7 +664,7 @@ constexpr int kWFwdLds = 4;                                            // lo k-s
 constexpr size_t kWFwdLdsBytes = (size_t)2 * kWRows * kWHS * 2 + (size_t)kWAccLds * 4 + (size_t)8 * kWFwdLds * 64 * 16;
 __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3w_kernel(const LstmClusterX3P L, const uint8_t* __restrict__ mask_tb,
                                                                    int B, int T, int H, int ldh, int ldg, int* err) {
-    constexpr int HP = kWHP, KS = kWKS, HS = kWHS, R = kWRows, NF = 8;
+    constexpr int HP = kWHP, KS = kWKS, HS = kWHS, R = kWRows, NF = 4;
     const unsigned tag0 = L.tag0[blockIdx.y];
     extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
     __bf16 (*hs_hi)[HS] = reinterpret_cast<__bf16 (*)[HS]>(lds);
@@ -719,6 +722,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3w_kernel(const LstmClu
         const int out_blk = t + (P.backwards ? 0 : 1);
         const unsigned tag = tag0 + (unsigned)step;
         unsigned long long* xpar = xb + (size_t)(step & 1) * (R / 2) * HP;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xpar, 0, (R / 2) * HP * 8, 0x00020000);
         // (the row index is made opaque once per step: the compiler otherwise keeps a 64-bit address per row and array across the
         //  loop -- 16 registers spilled to scratch and reloaded every step)
         int rw = row0;
@@ -766,6 +770,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3w_kernel(const LstmClu
             for (int g = 0; g < 4; ++g) acc[g] = xacc[((g * 3 + rt) * 2 + ut) * 64 + lane];
             // ---- gate math; own images and the publication of each row pair first (the partners are waiting for it)
             unsigned q_even = 0u;
+            unsigned long long g_first = 0ull;
             float h_out[4];
             float4 gts[4];
 #pragma unroll
@@ -788,12 +793,14 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3w_kernel(const LstmClu
                 const unsigned qb = x3_quant(h_o);
                 const int row = 16 * rt + 4 * kq + r;
                 x3_split(qb, hs_hi[row][u], hs_lo[row][u]);
-                if (r & 1)
-                    __hip_atomic_store(xpar + (size_t)(8 * rt + 2 * kq + (r >> 1)) * HP + u,
-                                       ((unsigned long long)(qb | (tag >> 8)) << 32) | (q_even | (tag & 255u)), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-                else
+                if (r == 1) {
+                    g_first = ((unsigned long long)(qb | (tag >> 8)) << 32) | (q_even | (tag & 255u));
+                } else if (r == 3) {
+                    const u32x4 pk = {(unsigned)g_first, (unsigned)(g_first >> 32), q_even | (tag & 255u), qb | (tag >> 8)};
+                    __builtin_amdgcn_raw_buffer_store_b128(pk, rs, (unsigned)(((4 * rt + kq) * HP + u) * 16), 0, 16);
+                } else {
                     q_even = qb;
+                }
             }
             STAMP(1);
             // ---- the step's outputs
@@ -812,24 +819,22 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3w_kernel(const LstmClu
             }
         }
         STAMP(2);
-        // ---- gather the partners' h_t: this thread's unit column, 24 row pairs in three rounds of 8
+        // ---- gather the partners' h_t: this thread's unit column, 12 row quads in three rounds of 4
         if (step + 1 < T && (tid >> 5) != j) {
 #pragma unroll 1
             for (int rd = 0; rd < 3; ++rd) {
-                const unsigned long long* p0 = xpar + (size_t)(NF * rd) * HP + tid;
-                unsigned long long g[NF];
+                const unsigned soff = (unsigned)(NF * rd * HP * 16);
+                u32x4 v[NF];
                 unsigned pending = (1u << NF) - 1u;
                 unsigned long long t_start = 0;
                 for (int spin = 0; pending; ++spin) {
-                    unsigned long long v[NF];
 #pragma unroll
                     for (int k = 0; k < NF; ++k)
-                        if (pending & (1u << k)) v[k] = granule_load(p0 + (size_t)k * HP);
+                        if (pending & (1u << k)) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)tid * 16u + (unsigned)(k * HP * 16), soff, 16);
 #pragma unroll
                     for (int k = 0; k < NF; ++k)
-                        if ((pending & (1u << k)) && (((unsigned)v[k] & 255u) | (((unsigned)(v[k] >> 32) & 255u) << 8)) == tag) {
-                            g[k] = v[k]; pending &= ~(1u << k);
-                        }
+                        if ((pending & (1u << k)) && ((v[k].x & 255u) | ((v[k].y & 255u) << 8)) == tag && ((v[k].z & 255u) | ((v[k].w & 255u) << 8)) == tag)
+                            pending &= ~(1u << k);
                     if (pending && (spin & 1023) == 1023) {
                         if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
                         const unsigned long long now = wall_ticks();
@@ -837,12 +842,14 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3w_kernel(const LstmClu
                         else if (now - t_start > kPollTimeoutTicks) { atomicCAS(err, 0, 1 | ((int)(step & 1023) << 4) | ((int)blockIdx.x << 16)); break; }
                     }
                 }
-                __bf16* img = &hs_hi[2 * NF * rd][tid];                      // lo image: + R * HS elements
+                __bf16* img = &hs_hi[4 * NF * rd][tid];                      // lo image: + R * HS elements
 #pragma unroll
                 for (int k = 0; k < NF; ++k) {
-                    __bf16* d = img + (2 * k) * HS;
-                    x3_split((unsigned)g[k] & ~255u, d[0], d[R * HS]);
-                    x3_split((unsigned)(g[k] >> 32) & ~255u, d[HS], d[HS + R * HS]);
+                    __bf16* d = img + (4 * k) * HS;
+                    x3_split(v[k].x & ~255u, d[0], d[R * HS]);
+                    x3_split(v[k].y & ~255u, d[HS], d[HS + R * HS]);
+                    x3_split(v[k].z & ~255u, d[2 * HS], d[2 * HS + R * HS]);
+                    x3_split(v[k].w & ~255u, d[3 * HS], d[3 * HS + R * HS]);
                 }
             }
         }
@@ -1396,23 +1403,25 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_x3_kernel(const LstmClus
 // 48-utterance group).  Workgroup j holds the hi + lo fragments of ITS 128 rows of W_hid^T (its gate columns: 4 k-steps) for all
 // 512 units (2 x 128 KB: wave w takes unit tiles 4 w ..+3 = destinations 2 w, 2 w + 1; 12 of its 16 lo fragments sit in LDS),
 // multiplies its own dG_{t+1} (48 x 128, hi / lo images in LDS) into a partial dh for all units, keeps its 32 and sends the
-// other 15 x (48 x 32) to their owners as tagged granules (2 rows of a unit; pack_partials).  Inbox of a workgroup:
-// [2 parities][16 source slots][24 row pairs][32 units]; ALL 512 threads collect (three rounds of <= 8 granules of one
-// (row pair, unit): sources 0-7 | 8-14, summed in slot order) and hand the two half sums to the gate-math lanes through LDS.
+// other 15 x (48 x 32) to their owners as tagged granules (2 rows of a unit; pack_partials), two granules -- the lane's 4 rows --
+// per 16-byte write-through store.  Inbox of a workgroup: [2 parities][16 source slots][12 row quads][32 units][2 granules];
+// ALL 512 threads collect: thread = (128 positions x 3 rounds, source quarter), one 16-byte sc1 buffer load per (position,
+// source), each half validated by its own tag; the <= 4 sources of a quarter are summed in slot order and the four quarter
+// sums handed to the gate-math lanes through LDS (fixed order: deterministic).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kWDS = 4 * kWUnits + 8;                                  // LDS row stride of the dG image (own 128 gate columns)
 constexpr int kWPair = kWRows / 2 * kWUnits;                           // granules of one (destination, source) pair
 constexpr int kWBwdLds = 3;                                            // lo k-steps (of a wave's 4) whose fragments live in LDS
-constexpr int kWBwdWOff = (2 * kWRows * kWDS * 2 + 3 * kWRows * (kWUnits + 1) * 4 + 15) / 16 * 16 / 2;   // bf16 elements
+constexpr int kWBwdWOff = (2 * kWRows * kWDS * 2 + 5 * kWRows * (kWUnits + 1) * 4 + 15) / 16 * 16 / 2;   // bf16 elements
 constexpr size_t kWBwdLdsBytes = (size_t)kWBwdWOff * 2 + (size_t)8 * 4 * kWBwdLds * 64 * 16;
 __global__ __launch_bounds__(512) void lstm_bwd_cluster_x3w_kernel(const LstmClusterP L, const uint8_t* __restrict__ mask_tb,
                                                                    int B, int T, int H, int ldh, int ldg, int* err) {
-    constexpr int R = kWRows, CWG = kWCWG, HP = kWHP, NF = 8;
+    constexpr int R = kWRows, CWG = kWCWG, HP = kWHP, NQ = 4;
     extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
     __bf16 (*dgs_hi)[kWDS] = reinterpret_cast<__bf16 (*)[kWDS]>(lds);                            // [48][kWDS] own dG_{t+1}, hi
     __bf16 (*dgs_lo)[kWDS] = reinterpret_cast<__bf16 (*)[kWDS]>(lds + R * kWDS);                 // ... lo
     float (*part)[kWUnits + 1] = reinterpret_cast<float (*)[kWUnits + 1]>(lds + 2 * R * kWDS);  // [48][33] own share of the own partial
-    float (*recv)[kWUnits + 1] = part + R;                                                       // [2 halves x 48][33] sums of the foreign shares
+    float (*recv)[kWUnits + 1] = part + R;                                                       // [4 source quarters x 48][33] sums of the foreign shares
     bf16x8* wl = reinterpret_cast<bf16x8*>(lds + kWBwdWOff);             // [8 waves][4 tiles][kWBwdLds k-steps][64 lanes] lo fragments
     const LstmStep& P = L.l[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1478,11 +1487,16 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_x3w_kernel(const LstmClu
             l_cp[r] = cp_[rc * (unsigned)ldh + (unsigned)ucl];
         }
     };
+    const int pb = tid & 127, sq = tid >> 7;           // collect: position block, source quarter
+    const unsigned send_off = (unsigned)((kq * kWUnits + i) * 16);     // sends: lane part of the byte offset inside a (dst, slot) block
     STAMP_INIT
     for (int step = 0; step <= T; ++step) {
         const int t = P.backwards ? step : (T - 1 - step);
         const unsigned tag8 = 1u + (unsigned)(step % 255);
         unsigned long long* xpar = xb + (size_t)(step & 1) * CWG * CWG * kWPair;
+        // the exchange runs on sc1 (write-through / L1-bypassing) buffer accesses: 32-bit lane offsets, no address registers
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(xpar, 0, CWG * CWG * kWPair * 8, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(xpar + (size_t)j * CWG * kWPair, 0, CWG * kWPair * 8, 0x00020000);
         float rec[4] = {0.f, 0.f, 0.f, 0.f};
         if (step > 0) {
             // ---- partial dh of unit tiles 4 wave ..+3 (destinations 2 wave, 2 wave + 1), one row tile after the other (the
@@ -1515,12 +1529,11 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_x3w_kernel(const LstmClu
 #pragma unroll
                         for (int r = 0; r < 4; ++r) part[16 * q + 4 * kq + r][16 * tl + i] = acc[c][r];
                     } else {
-                        unsigned long long* box = xpar + (size_t)(dst * CWG + (j - dst - 1 + CWG) % CWG) * kWPair + 16 * tl + i;
-#pragma unroll
-                        for (int rp = 0; rp < 2; ++rp)
-                            __hip_atomic_store(box + (size_t)(8 * q + 2 * kq + rp) * kWUnits,
-                                               pack_partials(acc[c][2 * rp], acc[c][2 * rp + 1], tag8), __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
+                        // block (dst, slot): [12 quads][32 units][2 granules]; this lane's 4 rows are quad 4 q + kq
+                        const unsigned blk = (unsigned)__builtin_amdgcn_readfirstlane((dst * CWG + (j - dst - 1 + CWG) % CWG) * (kWPair * 8));
+                        const unsigned long long g0 = pack_partials(acc[c][0], acc[c][1], tag8), g1 = pack_partials(acc[c][2], acc[c][3], tag8);
+                        const u32x4 pk = {(unsigned)g0, (unsigned)(g0 >> 32), (unsigned)g1, (unsigned)(g1 >> 32)};
+                        __builtin_amdgcn_raw_buffer_store_b128(pk, rs_out, send_off + (unsigned)((4 * q * kWUnits + 16 * tl) * 16), blk, 16);
                     }
                 }
             }
@@ -1529,25 +1542,22 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_x3w_kernel(const LstmClu
         // what the gate math reads from HBM is requested AFTER the product; the round trips hide under the exchange hop
         if (gm) request_state(min(step, T - 1));
         if (step > 0) {
-            // ---- collect: work item w = 512 round + tid -> (half w / 768: sources 0-7 | 8-14, position w % 768 = (row pair, unit))
+            // ---- collect: position (quad, unit) = pb + 128 round, sources 4 sq .. 4 sq + 3 (slot 15 does not exist)
 #pragma unroll 1
             for (int rd = 0; rd < 3; ++rd) {
-                const int w = rd * 512 + tid;
-                const int half = w >= kWPair ? 1 : 0, pos = w - kWPair * half;
-                const unsigned long long* p0 = xpar + (size_t)(j * CWG + 8 * half) * kWPair + pos;
-                unsigned long long g[NF];
-                unsigned pending = half ? 0x7fu : 0xffu;
+                const int pos = pb + 128 * rd;
+                const unsigned voff = (unsigned)(pos * 16 + sq * NQ * (kWPair * 8));
+                u32x4 v[NQ];
+                unsigned pending = sq == 3 ? 0x7u : 0xfu;
                 unsigned long long t_start = 0;
                 for (int spin = 0; pending; ++spin) {
-                    unsigned long long v[NF];
 #pragma unroll
-                    for (int k = 0; k < NF; ++k)
-                        if (pending & (1u << k)) v[k] = granule_load(p0 + (size_t)k * kWPair);
+                    for (int k = 0; k < NQ; ++k)
+                        if (pending & (1u << k)) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, k * (kWPair * 8), 16);
 #pragma unroll
-                    for (int k = 0; k < NF; ++k)
-                        if ((pending & (1u << k)) && (((unsigned)v[k] & 15u) | (((unsigned)(v[k] >> 32) & 15u) << 4)) == tag8) {
-                            g[k] = v[k]; pending &= ~(1u << k);
-                        }
+                    for (int k = 0; k < NQ; ++k)
+                        if ((pending & (1u << k)) && ((v[k].x & 15u) | ((v[k].y & 15u) << 4)) == tag8 && ((v[k].z & 15u) | ((v[k].w & 15u) << 4)) == tag8)
+                            pending &= ~(1u << k);
                     if (pending && (spin & 1023) == 1023) {
                         if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
                         const unsigned long long now = wall_ticks();
@@ -1555,16 +1565,16 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_x3w_kernel(const LstmClu
                         else if (now - t_start > kPollTimeoutTicks) { atomicCAS(err, 0, 2 | (step << 4) | ((int)blockIdx.x << 16)); break; }
                     }
                 }
-                float sa = 0.f, sb = 0.f;
+                float sr[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < NF; ++k)
-                    if (k < 7 || !half) {
-                        sa += __builtin_bit_cast(float, (unsigned)g[k] & ~15u);
-                        sb += __builtin_bit_cast(float, (unsigned)(g[k] >> 32) & ~15u);
+                for (int k = 0; k < NQ; ++k)
+                    if (k < 3 || sq != 3) {
+                        sr[0] += __builtin_bit_cast(float, v[k].x & ~15u); sr[1] += __builtin_bit_cast(float, v[k].y & ~15u);
+                        sr[2] += __builtin_bit_cast(float, v[k].z & ~15u); sr[3] += __builtin_bit_cast(float, v[k].w & ~15u);
                     }
-                float* d = &recv[R * half + 2 * (pos >> 5)][pos & 31];
-                d[0] = sa;
-                d[kWUnits + 1] = sb;
+                float* d = &recv[R * sq + 4 * (pos >> 5)][pos & 31];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d[r * (kWUnits + 1)] = sr[r];
             }
             STAMP(6);
             lds_barrier();                            // own share in `part`, the foreign sums in `recv`; dG_{t+1} has been consumed
@@ -1572,7 +1582,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_x3w_kernel(const LstmClu
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * rt + 4 * kq + r;
-                    rec[r] = part[row][ul] + recv[row][ul] + recv[R + row][ul];
+                    rec[r] = part[row][ul] + recv[row][ul] + recv[R + row][ul] + recv[2 * R + row][ul] + recv[3 * R + row][ul];
                 }
             }
         }
