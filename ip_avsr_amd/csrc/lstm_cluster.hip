@@ -23,6 +23,7 @@
 // poll that gives up raises the launch's error word and the host reports ADN_ERR_STATE -- never a hang.
 #include "adn_common.h"
 #include <algorithm>
+#include <vector>
 #include <cstdlib>
 
 namespace adn {
@@ -33,8 +34,13 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// A launch covers a range of (LSTM, utterance group) PAIRS of one call -- pair = LSTM index * groups + group, CWG consecutive
+// workgroups each.  Pairs are independent of each other (the exchange stays inside a group), so a call's pairs are dealt over
+// as few launches as the device holds resident at once, in equal shares: four 512-unit LSTMs of 17 groups x 8 workgroups are
+// three launches of 23 / 23 / 22 pairs, not four of 17 (+ 120 idle CUs each).
 struct LstmClusterP {
     LstmStep l[kMaxLstmPerLaunch];
+    int pair0, groups;
 };
 
 __device__ __forceinline__ float c_sigmoid(float x) {
@@ -176,10 +182,11 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const LstmCluster
     bf16x8* win = reinterpret_cast<bf16x8*>(lds + G::WLdsFwd + kCRows * HS);   // FOLD: [16 (unit tile, gate)][KXS][64 lanes] fragments
     constexpr int XS = 32 * KXS + 8;                  // FOLD: row stride of the x tiles [2 parities][32 rows][XS] (bf16)
     __bf16* xs = lds + G::WLdsFwd + kCRows * HS + 16 * KXS * 64 * 8;
-    const LstmStep& P = L.l[blockIdx.y];
+    const int pair_ = L.pair0 + (int)blockIdx.x / CWG, lstm_ = pair_ / L.groups;
+    const LstmStep& P = L.l[lstm_];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, kq = lane >> 4;
-    const int group = blockIdx.x / CWG, j = blockIdx.x % CWG;
+    const int group = pair_ - lstm_ * L.groups, j = blockIdx.x % CWG;
     const int r0 = group * kCRows;
     const int rt = wave >> 2, ut = wave & 3;
     const int u = kCUnits * j + 16 * ut + i;          // this lane's hidden unit
@@ -427,6 +434,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const LstmCluster
 struct LstmClusterX3P {
     LstmStep l[kMaxLstmPerLaunch];
     unsigned tag0[kMaxLstmPerLaunch];                                  // 1024 seq + 1, seq in [0, 64): tag0 + step < 65536
+    int pair0, groups;
 };
 __device__ __forceinline__ unsigned x3_quant(float h) { return (__builtin_bit_cast(unsigned, h) + 0x80u) & ~0xffu; }
 __device__ __forceinline__ void x3_split(unsigned qbits, __bf16& hi, __bf16& lo) {
@@ -440,16 +448,17 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClus
                                                                   int B, int T, int H, int ldh, int ldg, int* err) {
     using G = ClusterGeom<4>;
     constexpr int CWG = 4, HP = G::HP, KS = G::KS, HS = G::HS, NF = 8;
-    const unsigned tag0 = L.tag0[blockIdx.y];
+    const unsigned tag0 = L.tag0[(L.pair0 + (int)blockIdx.x / CWG) / L.groups];
     extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
     __bf16 (*hs_hi)[HS] = reinterpret_cast<__bf16 (*)[HS]>(lds);
     __bf16 (*hs_lo)[HS] = reinterpret_cast<__bf16 (*)[HS]>(lds + kCRows * HS);
     f32x4* xacc = reinterpret_cast<f32x4*>(lds + 2 * kCRows * HS);       // (2 * 32 * 264 * 2 bytes: 16-byte aligned)
     bf16x8* wl = reinterpret_cast<bf16x8*>(lds + 2 * kCRows * HS + kX3AccLds * 2);   // [8 waves][2 gates][kX3FwdLds][64 lanes]
-    const LstmStep& P = L.l[blockIdx.y];
+    const int pair_ = L.pair0 + (int)blockIdx.x / CWG, lstm_ = pair_ / L.groups;
+    const LstmStep& P = L.l[lstm_];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, kq = lane >> 4;
-    const int group = blockIdx.x / CWG, j = blockIdx.x % CWG;
+    const int group = pair_ - lstm_ * L.groups, j = blockIdx.x % CWG;
     const int r0 = group * kCRows;
     const int rt = wave >> 2, ut = wave & 3;          // gate math: row tile, unit tile;  product: gate pair rt, unit tile ut
     const int u = kCUnits * j + 16 * ut + i;
@@ -665,16 +674,17 @@ constexpr size_t kWFwdLdsBytes = (size_t)2 * kWRows * kWHS * 2 + (size_t)kWAccLd
 __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3w_kernel(const LstmClusterX3P L, const uint8_t* __restrict__ mask_tb,
                                                                    int B, int T, int H, int ldh, int ldg, int* err) {
     constexpr int HP = kWHP, KS = kWKS, HS = kWHS, R = kWRows, NF = 4;
-    const unsigned tag0 = L.tag0[blockIdx.y];
+    const unsigned tag0 = L.tag0[(L.pair0 + (int)blockIdx.x / kWCWG) / L.groups];
     extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
     __bf16 (*hs_hi)[HS] = reinterpret_cast<__bf16 (*)[HS]>(lds);
     __bf16 (*hs_lo)[HS] = reinterpret_cast<__bf16 (*)[HS]>(lds + R * HS);
     f32x4* xacc = reinterpret_cast<f32x4*>(lds + 2 * R * HS);            // (2 * 48 * 520 * 2 bytes: 16-byte aligned)
     bf16x8* wl = reinterpret_cast<bf16x8*>(lds + 2 * R * HS + kWAccLds * 2);   // [8 waves][kWFwdLds][64 lanes]
-    const LstmStep& P = L.l[blockIdx.y];
+    const int pair_ = L.pair0 + (int)blockIdx.x / kWCWG, lstm_ = pair_ / L.groups;
+    const LstmStep& P = L.l[lstm_];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, kq = lane >> 4;
-    const int group = blockIdx.x / kWCWG, j = blockIdx.x % kWCWG;
+    const int group = pair_ - lstm_ * L.groups, j = blockIdx.x % kWCWG;
     const int r0 = group * R;
     const int rt = wave >> 1, ut = wave & 1;          // gate math: row tile (3: this wave has none), unit tile;  product: gate rt, unit tile ut
     const bool gm = rt < 3;
@@ -885,10 +895,11 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_kernel(const LstmCluster
     __bf16* wl = lds;                                 // [HP/16 unit tiles][KSLB k-steps][64 lanes][8]: W_hid[unit][own gate columns]
     __bf16 (*dgs)[kCDS] = reinterpret_cast<__bf16 (*)[kCDS]>(lds + G::WLdsBwd);            // [32][kCDS] own dG_{t+1}
     float (*part)[kCUnits + 1] = reinterpret_cast<float (*)[kCUnits + 1]>(lds + G::WLdsBwd + kCRows * kCDS);   // [32][65]
-    const LstmStep& P = L.l[blockIdx.y];
+    const int pair_ = L.pair0 + (int)blockIdx.x / CWG, lstm_ = pair_ / L.groups;
+    const LstmStep& P = L.l[lstm_];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, kq = lane >> 4;
-    const int group = blockIdx.x / CWG, j = blockIdx.x % CWG;
+    const int group = pair_ - lstm_ * L.groups, j = blockIdx.x % CWG;
     const int r0 = group * kCRows;
     const int rt = wave >> 2, ut = wave & 3;          // gate math: row tile, local unit tile
     const int dst = CWG == 4 ? ut : wave;             // MFMA role: destination workgroup (and row tile rt when CWG == 4)
@@ -1139,10 +1150,11 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_x3_kernel(const LstmClus
     __bf16 (*dgs_lo)[kCDS] = reinterpret_cast<__bf16 (*)[kCDS]>(lds + kCRows * kCDS);          // ... lo
     float (*part)[kCUnits + 1] = reinterpret_cast<float (*)[kCUnits + 1]>(lds + 2 * kCRows * kCDS);   // [32][65]
     bf16x8* wl = reinterpret_cast<bf16x8*>(lds + kX3BwdWOff);            // [8 waves][2 tiles][kX3BwdLds k-steps][64 lanes] lo fragments
-    const LstmStep& P = L.l[blockIdx.y];
+    const int pair_ = L.pair0 + (int)blockIdx.x / CWG, lstm_ = pair_ / L.groups;
+    const LstmStep& P = L.l[lstm_];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, kq = lane >> 4;
-    const int group = blockIdx.x / CWG, j = blockIdx.x % CWG;
+    const int group = pair_ - lstm_ * L.groups, j = blockIdx.x % CWG;
     const int r0 = group * kCRows;
     const int rt = wave >> 2, ut = wave & 3;          // gate math: row tile, local unit tile
     const int dst = wave >> 1, tp = 2 * (wave & 1);   // product: destination workgroup, first of its two unit tiles
@@ -1423,10 +1435,11 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_x3w_kernel(const LstmClu
     float (*part)[kWUnits + 1] = reinterpret_cast<float (*)[kWUnits + 1]>(lds + 2 * R * kWDS);  // [48][33] own share of the own partial
     float (*recv)[kWUnits + 1] = part + R;                                                       // [4 source quarters x 48][33] sums of the foreign shares
     bf16x8* wl = reinterpret_cast<bf16x8*>(lds + kWBwdWOff);             // [8 waves][4 tiles][kWBwdLds k-steps][64 lanes] lo fragments
-    const LstmStep& P = L.l[blockIdx.y];
+    const int pair_ = L.pair0 + (int)blockIdx.x / CWG, lstm_ = pair_ / L.groups;
+    const LstmStep& P = L.l[lstm_];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, kq = lane >> 4;
-    const int group = blockIdx.x / CWG, j = blockIdx.x % CWG;
+    const int group = pair_ - lstm_ * L.groups, j = blockIdx.x % CWG;
     const int r0 = group * R;
     const int rt = wave >> 1, ut = wave & 1;          // gate math: row tile (3: none), local unit tile
     const bool gm = rt < 3;
@@ -1836,6 +1849,20 @@ bool lstm_forward_folds_projection(const LstmStep* l, int n, int B, int T, int H
     return lstm_persistent_supported(H) && lstm_cluster_supported(l, n, B, T, H) && fold_offered(l, n, H, B);
 }
 
+// the (LSTM, group) pairs of a call over the fewest launches that keep every workgroup of a launch resident, in equal shares
+struct PairRange { int pair0, count; };
+static std::vector<PairRange> plan_pairs(int n, int groups, int cwg, int cus) {
+    const int pairs = n * groups, cap = std::max(1, cus / cwg);
+    const int launches = cdiv(pairs, cap);
+    std::vector<PairRange> out;
+    for (int k = 0, p0 = 0; k < launches; ++k) {
+        const int cnt = pairs / launches + (k < pairs % launches ? 1 : 0);
+        out.push_back({p0, cnt});
+        p0 += cnt;
+    }
+    return out;
+}
+
 template <int CWG, int KXS>
 static int forward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s) {
     const int groups = cdiv(B, kCRows), per = groups * CWG, cus = cluster_cus();
@@ -1855,13 +1882,13 @@ static int forward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int
     const double bytes = (double)n * T * (4.0 * (12.0 * B * H + 4.0 * H * H) + B),
                  flops = (double)n * T * (8.0 * B * H * H + (KXS ? 8.0 * B * H * l[0].Kx : 0.0));
     ProfScope prof(PROF_LSTM_FWD, flops, bytes, s, T);
-    const int chunk = std::max(1, cus / per);        // LSTMs per launch: every workgroup must be resident
-    for (int k0 = 0; k0 < n; k0 += chunk) {
-        const int nn = std::min(chunk, n - k0);
-        LstmClusterP L;
-        for (int k = 0; k < nn; ++k) L.l[k] = l[k0 + k];
+    LstmClusterP L;
+    for (int k = 0; k < n; ++k) L.l[k] = l[k];
+    L.groups = groups;
+    for (const PairRange& r : plan_pairs(n, groups, CWG, cus)) {      // every workgroup of a launch must be resident
+        L.pair0 = r.pair0;
         const unsigned tag0 = (g_cluster_epoch++ & 0x3fffffu) * 1024u + 1u;
-        hipLaunchKernelGGL((lstm_fwd_cluster_kernel<CWG, KXS>), dim3(per, nn), dim3(512), lds, s, L, mask_tb, B, T, H, ldh, ldg, tag0, err);
+        hipLaunchKernelGGL((lstm_fwd_cluster_kernel<CWG, KXS>), dim3(r.count * CWG), dim3(512), lds, s, L, mask_tb, B, T, H, ldh, ldg, tag0, err);
         ADN_HIP_CHECK(hipGetLastError());
     }
     return ADN_OK;
@@ -1913,16 +1940,17 @@ int lstm_forward_cluster_x3(const LstmStep* l, int n, const uint8_t* mask_tb, in
     }
     const double bytes = (double)n * T * (4.0 * (12.0 * B * H + 4.0 * H * H) + B), flops = (double)n * T * 8.0 * B * H * H;
     ProfScope prof(PROF_LSTM_FWD, flops, bytes, s, T);
-    const int chunk = std::max(1, cus / per);
-    for (int k0 = 0; k0 < n; k0 += chunk) {
-        const int nn = std::min(chunk, n - k0);
-        LstmClusterX3P L;
-        for (int k = 0; k < nn; ++k) {
-            unsigned seq = 0;
-            ADN_TRY(x3_launch_seq(l[k0 + k], &seq));
-            L.l[k] = l[k0 + k]; L.tag0[k] = seq * 1024u + 1u;
+    LstmClusterX3P L;
+    for (int k = 0; k < n; ++k) { L.l[k] = l[k]; L.tag0[k] = 0u; }
+    L.groups = groups;
+    for (const PairRange& r : plan_pairs(n, groups, 4, cus)) {
+        L.pair0 = r.pair0;
+        for (int k = r.pair0 / groups; k <= (r.pair0 + r.count - 1) / groups; ++k) {     // the LSTMs this launch touches: a new
+            unsigned seq = 0;                                                            // sequence number on their buffers
+            ADN_TRY(x3_launch_seq(l[k], &seq));
+            L.tag0[k] = seq * 1024u + 1u;
         }
-        hipLaunchKernelGGL(lstm_fwd_cluster_x3_kernel, dim3(per, nn), dim3(512), lds, s, L, mask_tb, B, T, H, ldh, ldg, err);
+        hipLaunchKernelGGL(lstm_fwd_cluster_x3_kernel, dim3(r.count * 4), dim3(512), lds, s, L, mask_tb, B, T, H, ldh, ldg, err);
         ADN_HIP_CHECK(hipGetLastError());
     }
     return ADN_OK;
@@ -1954,16 +1982,17 @@ int lstm_forward_cluster_x3w(const LstmStep* l, int n, const uint8_t* mask_tb, i
     }
     const double bytes = (double)n * T * (4.0 * (12.0 * B * H + 4.0 * H * H) + B), flops = (double)n * T * 8.0 * B * H * H;
     ProfScope prof(PROF_LSTM_FWD, flops, bytes, s, T);
-    const int chunk = std::max(1, cus / per);
-    for (int k0 = 0; k0 < n; k0 += chunk) {
-        const int nn = std::min(chunk, n - k0);
-        LstmClusterX3P L;
-        for (int k = 0; k < nn; ++k) {
+    LstmClusterX3P L;
+    for (int k = 0; k < n; ++k) { L.l[k] = l[k]; L.tag0[k] = 0u; }
+    L.groups = groups;
+    for (const PairRange& r : plan_pairs(n, groups, kWCWG, cus)) {
+        L.pair0 = r.pair0;
+        for (int k = r.pair0 / groups; k <= (r.pair0 + r.count - 1) / groups; ++k) {
             unsigned seq = 0;
-            ADN_TRY(x3_launch_seq(l[k0 + k], &seq));
-            L.l[k] = l[k0 + k]; L.tag0[k] = seq * 1024u + 1u;
+            ADN_TRY(x3_launch_seq(l[k], &seq));
+            L.tag0[k] = seq * 1024u + 1u;
         }
-        hipLaunchKernelGGL(lstm_fwd_cluster_x3w_kernel, dim3(per, nn), dim3(512), kWFwdLdsBytes, s, L, mask_tb, B, T, H, ldh, ldg, err);
+        hipLaunchKernelGGL(lstm_fwd_cluster_x3w_kernel, dim3(r.count * kWCWG), dim3(512), kWFwdLdsBytes, s, L, mask_tb, B, T, H, ldh, ldg, err);
         ADN_HIP_CHECK(hipGetLastError());
     }
     return ADN_OK;
@@ -1995,12 +2024,12 @@ int lstm_backward_cluster_x3w(const LstmStep* l, int n, const uint8_t* mask_tb, 
     }
     const double bytes = (double)n * T * 4.0 * (15.0 * B * H + 4.0 * H * H), flops = (double)n * T * 8.0 * B * H * H;
     ProfScope prof(PROF_LSTM_BWD, flops, bytes, s, T + 1);
-    const int chunk = std::max(1, cus / per);
-    for (int k0 = 0; k0 < n; k0 += chunk) {
-        const int nn = std::min(chunk, n - k0);
-        LstmClusterP L;
-        for (int k = 0; k < nn; ++k) L.l[k] = l[k0 + k];
-        hipLaunchKernelGGL(lstm_bwd_cluster_x3w_kernel, dim3(per, nn), dim3(512), kWBwdLdsBytes, s, L, mask_tb, B, T, H, ldh, ldg, err);
+    LstmClusterP L;
+    for (int k = 0; k < n; ++k) L.l[k] = l[k];
+    L.groups = groups;
+    for (const PairRange& r : plan_pairs(n, groups, kWCWG, cus)) {
+        L.pair0 = r.pair0;
+        hipLaunchKernelGGL(lstm_bwd_cluster_x3w_kernel, dim3(r.count * kWCWG), dim3(512), kWBwdLdsBytes, s, L, mask_tb, B, T, H, ldh, ldg, err);
         ADN_HIP_CHECK(hipGetLastError());
     }
     return ADN_OK;
@@ -2024,12 +2053,12 @@ static int backward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, in
     }
     const double bytes = (double)n * T * 4.0 * (15.0 * B * H + 4.0 * H * H), flops = (double)n * T * 8.0 * B * H * H;
     ProfScope prof(PROF_LSTM_BWD, flops, bytes, s, T + 1);
-    const int chunk = std::max(1, cus / per);
-    for (int k0 = 0; k0 < n; k0 += chunk) {
-        const int nn = std::min(chunk, n - k0);
-        LstmClusterP L;
-        for (int k = 0; k < nn; ++k) L.l[k] = l[k0 + k];
-        hipLaunchKernelGGL(lstm_bwd_cluster_kernel<CWG>, dim3(per, nn), dim3(512), lds, s, L, mask_tb, B, T, H, ldh, ldg, err);
+    LstmClusterP L;
+    for (int k = 0; k < n; ++k) L.l[k] = l[k];
+    L.groups = groups;
+    for (const PairRange& r : plan_pairs(n, groups, CWG, cus)) {
+        L.pair0 = r.pair0;
+        hipLaunchKernelGGL(lstm_bwd_cluster_kernel<CWG>, dim3(r.count * CWG), dim3(512), lds, s, L, mask_tb, B, T, H, ldh, ldg, err);
         ADN_HIP_CHECK(hipGetLastError());
     }
     return ADN_OK;
@@ -2065,12 +2094,12 @@ int lstm_backward_cluster_x3(const LstmStep* l, int n, const uint8_t* mask_tb, i
     }
     const double bytes = (double)n * T * 4.0 * (15.0 * B * H + 4.0 * H * H), flops = (double)n * T * 8.0 * B * H * H;
     ProfScope prof(PROF_LSTM_BWD, flops, bytes, s, T + 1);
-    const int chunk = std::max(1, cus / per);
-    for (int k0 = 0; k0 < n; k0 += chunk) {
-        const int nn = std::min(chunk, n - k0);
-        LstmClusterP L;
-        for (int k = 0; k < nn; ++k) L.l[k] = l[k0 + k];
-        hipLaunchKernelGGL(lstm_bwd_cluster_x3_kernel, dim3(per, nn), dim3(512), lds, s, L, mask_tb, B, T, H, ldh, ldg, err);
+    LstmClusterP L;
+    for (int k = 0; k < n; ++k) L.l[k] = l[k];
+    L.groups = groups;
+    for (const PairRange& r : plan_pairs(n, groups, 4, cus)) {
+        L.pair0 = r.pair0;
+        hipLaunchKernelGGL(lstm_bwd_cluster_x3_kernel, dim3(r.count * 4), dim3(512), lds, s, L, mask_tb, B, T, H, ldh, ldg, err);
         ADN_HIP_CHECK(hipGetLastError());
     }
     return ADN_OK;

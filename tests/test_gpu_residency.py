@@ -34,14 +34,15 @@ def _case(B=520, T=40, H=250, seed=7):
     return spec, p, xs, y, mask
 
 
-@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
-def test_a_foreign_tenant_delays_the_weight_stationary_launches_and_does_not_break_them(precision):
+@pytest.mark.parametrize("precision,H", [("bf16", 250), ("bf16x3", 250), ("bf16", 320), ("bf16x3", 320)])
+def test_a_foreign_tenant_delays_the_weight_stationary_launches_and_does_not_break_them(precision, H):
+    """H = 320: the 8-workgroup bf16 kernels / the 16-workgroup bf16x3 kernels (one LSTM per launch at this batch)"""
     import torch
     from ip_avsr_amd import _lib
     from ip_avsr_amd.model import AdeNetModel
     torch.cuda.set_device(0)
     lib = _lib.load()
-    spec, p, xs, y, mask = _case()
+    spec, p, xs, y, mask = _case(H=H)
     spec["precision"] = precision
     dev = torch.device("cuda", 0)
     xs_d = [torch.as_tensor(x, device=dev) for x in xs]
