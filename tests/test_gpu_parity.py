@@ -557,7 +557,7 @@ def test_adam_with_per_layer_learning_rates(torch_cuda, lib):
 
 def test_four_streams_512_units_config5_shape(torch_cuda, lib):
     """BASELINE configs[4] topology: adenet_4stream, concat fusion, 512-unit LSTMs (small encoders / batch so
-    that the fp64 oracle stays fast).  f32 mode against the oracle; bf16 mode must track it."""
+    that the fp64 oracle stays fast).  f32 and bf16x3 modes against the oracle; bf16 mode must track it."""
     from ip_avsr_amd.model import AdeNetModel
     spec = O.spec_nstream([40, 36, 44, 30], enc_shapes=(48, 24, 10), enc_acts=("rectify", "rectify", "linear"),
                           lstm_size=512, classes=10, fusion="concat")
@@ -580,6 +580,15 @@ def test_four_streams_512_units_config5_shape(torch_cuda, lib):
     assert np.abs(m.predict(inputs, mask, theta) - probs_ref).max() <= 3e-2
     l16 = m.compute_grads(inputs, y, mask, theta)
     assert abs(l16 - l_ref) <= 2e-2 * abs(l_ref)
+    # the parity-grade mode on this topology: the 16-workgroup bf16x3 LSTM kernels (csrc/lstm_cluster.hip, *_x3w_*) under the
+    # fp32 mode's gate
+    m.set_precision("bf16x3")
+    assert np.abs(m.predict(inputs, mask, theta) - probs_ref).max() <= 5e-5
+    l3 = m.compute_grads(inputs, y, mask, theta)
+    assert abs(l3 - l_ref) <= 1e-5 * abs(l_ref)
+    g = m.get_grads_dict()
+    for k in O.param_names(spec):
+        assert np.abs(g[k] - g_ref[k]).max() <= 2e-4 * max(np.abs(g_ref[k]).max(), 1e-3 * gscale), k
     m.close()
 
 
