@@ -139,6 +139,9 @@ bool gemm_planes_would_run(const GemmArgs* g, int n);      // bf16x3: would thes
 int to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 // out[c * ldT + r] = bf16(W[r * ld + c]) for r < rows, c < cols (LDS-tiled transpose)
 int transpose_to_bf16(const float* W, int rows, int cols, int ld, void* out, int ldT, hipStream_t s);
+// A-stationary NT product, K <= 256, bf16-only output (gemm_bf16.hip)
+bool gemm_nt_astat_takes(int M, int N, int K, int lda, int ldb, int ldc, const void* A16, const void* B16, const void* C16);
+int gemm_nt_astat(const void* A16, int lda, const void* B16, int ldb, void* C16, int ldc, int M, int N, int K, hipStream_t s);
 // several column sums in one launch (out[c] += sum_r in[r][c]); items by value in the kernel arguments
 struct ColSumItem { const float* in; float* out; int ld, rows, cols, ctiles, splits, rps, block_end; };
 struct ColSumBatch { ColSumItem it[8]; int n = 0; };

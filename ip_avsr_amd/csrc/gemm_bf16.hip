@@ -1631,6 +1631,142 @@ static void launch_bf16_t(const GemmParams& p, int layout, dim3 grid, hipStream_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// A-stationary NT product for a SHORT K under very many rows and a wide output:  C16 [M][N] (bf16 only) = A16 [M][K] . B16 [N][K]^T,
+// K <= 256.  The conv auto-encoder's patch-gradient matrices (129024 x 2500 x 152 at batch 1024: dY W^T, 645 MB of output) are this
+// shape.  With 64 x 64 tiles every workgroup reloads its A rows for each of the 40 column tiles and spends its life in the
+// prologue / epilogue of a 5-step K loop (363 us, 1.8 TB/s of output).  Here a workgroup owns RB x 64 rows for ALL columns: its
+// A fragments (RB row tiles x K / 32 steps) sit in registers, B streams through LDS in 64-column chunks (double-buffered,
+// L2-resident: every workgroup reads the same 760 KB), and each chunk is multiplied as C^T = B A^T so that a lane ends up with
+// 4 consecutive COLUMNS of one row: an 8-byte store, 32 contiguous bytes per row and tile, no LDS bounce.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kAsCols = 64;                      // columns per chunk
+template <int KS, int RB>                        // k-steps (K <= 32 KS), 16-row tiles per wave
+__global__ __launch_bounds__(256) void gemm_bf16_nt_astat_kernel(const __bf16* __restrict__ A, int lda, const __bf16* __restrict__ B, int ldb,
+                                                                 __bf16* __restrict__ C, int ldc, int M, int N, int K) {
+    constexpr int LS = 32 * KS + 8;               // LDS row stride of a B chunk (bf16): [64 columns][LS]
+    __shared__ __attribute__((aligned(16))) __bf16 bs[2][kAsCols][LS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int row0 = (blockIdx.x * 4 + wave) * 16 * RB;
+    // ---- this wave's A fragments (as the B operand of C^T = B A^T: lane (m = i, k = 32 s + 8 kq ..+7)); zero beyond M / K
+    bf16x8 af[RB][KS];
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) {
+            const int m = row0 + 16 * r + i, k = 32 * s_ + 8 * kq;
+            bf16x8 v = bf16x8{};
+            if (m < M && k < K) {
+                v = *reinterpret_cast<const bf16x8*>(A + (size_t)m * lda + k);
+                if (k + 8 > K) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (k + e >= K) v[e] = (__bf16)0.f;
+                }
+            }
+            af[r][s_] = v;
+        }
+    // ---- B chunks: thread t loads 16-byte pieces (column t / CH, k 8 (t % CH)), CH pieces per column
+    constexpr int CH = 4 * KS;
+    constexpr int PIECES = kAsCols * CH, PER = (PIECES + 255) / 256;
+    bf16x8 stage[PER];
+    auto request = [&](int chunk) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int e = tid + 256 * q, col = chunk * kAsCols + e / CH, k = 8 * (e % CH);
+            bf16x8 v = bf16x8{};
+            if (e < PIECES && col < N && k < K) {
+                v = *reinterpret_cast<const bf16x8*>(B + (size_t)col * ldb + k);
+                if (k + 8 > K) {
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) if (k + x >= K) v[x] = (__bf16)0.f;
+                }
+            }
+            stage[q] = v;
+        }
+    };
+    auto commit = [&](int par) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int e = tid + 256 * q;
+            if (e < PIECES) *reinterpret_cast<bf16x8*>(&bs[par][e / CH][8 * (e % CH)]) = stage[q];
+        }
+    };
+    const int chunks = (N + kAsCols - 1) / kAsCols;
+    request(0);
+    commit(0);
+    __syncthreads();
+    for (int c = 0; c < chunks; ++c) {
+        const int par = c & 1;
+        if (c + 1 < chunks) request(c + 1);          // the next chunk travels while this one is multiplied
+        f32x4 acc[RB][4];
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) {
+            bf16x8 bf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bf[t] = *reinterpret_cast<const bf16x8*>(&bs[par][16 * t + i][32 * s_ + 8 * kq]);
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[t], af[r][s_], acc[r][t], 0, 0, 0);
+        }
+        // C^T tile: lane (column of the tile = m = i, rows = n = 4 kq ..+3)  ->  C[m][16 t + 4 kq ..+3]
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int m = row0 + 16 * r + i;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int n0 = c * kAsCols + 16 * t + 4 * kq;
+                if (m < M && n0 < N) {
+                    bf16x4 o;
+                    o[0] = (__bf16)acc[r][t][0]; o[1] = (__bf16)acc[r][t][1]; o[2] = (__bf16)acc[r][t][2]; o[3] = (__bf16)acc[r][t][3];
+                    if (n0 + 4 <= N) *reinterpret_cast<bf16x4*>(C + (size_t)m * ldc + n0) = o;
+                    else for (int e = 0; e < 4 && n0 + e < N; ++e) C[(size_t)m * ldc + n0 + e] = o[e];
+                }
+            }
+        }
+        if (c + 1 < chunks) commit(par ^ 1);         // (the chunk before this one was read before the barrier below, two iterations ago)
+        __syncthreads();
+    }
+}
+
+// may the A-stationary kernel take this product?  (bf16 operands, bf16-only output, no epilogue terms)
+bool gemm_nt_astat_takes(int M, int N, int K, int lda, int ldb, int ldc, const void* A16, const void* B16, const void* C16) {
+    static const bool off = getenv("ADN_GEMM_NO_ASTAT") != nullptr;      // (A/B switch)
+    // (measured, conv auto-encoder at batch 1024: 129024 x 2500 x 152 363 -> 221 us, 35840 x 2500 x 152 101 -> 90; 15360 x 1368 x 200
+    //  33 -> 42: with 240 workgroups each walks its 22 chunks alone on its CU, a barrier and a round trip per chunk)
+    return !off && K >= 16 && K <= 256 && M >= 32768 && N >= 256 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 &&
+           ((uintptr_t)A16 % 16) == 0 && ((uintptr_t)B16 % 16) == 0 && ((uintptr_t)C16 % 8) == 0;
+}
+
+template <int KS>
+static void launch_astat(const void* A16, int lda, const void* B16, int ldb, void* C16, int ldc, int M, int N, int K, hipStream_t s) {
+    const __bf16* A = reinterpret_cast<const __bf16*>(A16); const __bf16* B = reinterpret_cast<const __bf16*>(B16);
+    __bf16* C = reinterpret_cast<__bf16*>(C16);
+    // 128 rows per workgroup where that still gives every CU two workgroups, 64 otherwise
+    if (cdiv(M, 128) >= 512) hipLaunchKernelGGL((gemm_bf16_nt_astat_kernel<KS, 2>), dim3(cdiv(M, 128)), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K);
+    else hipLaunchKernelGGL((gemm_bf16_nt_astat_kernel<KS, 1>), dim3(cdiv(M, 64)), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K);
+}
+
+int gemm_nt_astat(const void* A16, int lda, const void* B16, int ldb, void* C16, int ldc, int M, int N, int K, hipStream_t s) {
+    switch (cdiv(K, 32)) {
+        case 1: launch_astat<1>(A16, lda, B16, ldb, C16, ldc, M, N, K, s); break;
+        case 2: launch_astat<2>(A16, lda, B16, ldb, C16, ldc, M, N, K, s); break;
+        case 3: launch_astat<3>(A16, lda, B16, ldb, C16, ldc, M, N, K, s); break;
+        case 4: launch_astat<4>(A16, lda, B16, ldb, C16, ldc, M, N, K, s); break;
+        case 5: launch_astat<5>(A16, lda, B16, ldb, C16, ldc, M, N, K, s); break;
+        case 6: launch_astat<6>(A16, lda, B16, ldb, C16, ldc, M, N, K, s); break;
+        case 7: launch_astat<7>(A16, lda, B16, ldb, C16, ldc, M, N, K, s); break;
+        default: launch_astat<8>(A16, lda, B16, ldb, C16, ldc, M, N, K, s); break;
+    }
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
 // tile_mode: 0 = 64 x 64, 1 = 128 x 128, 2 = 256 x 64 (tall: narrow outputs under many rows)
 void launch_gemm_bf16(const GemmParams& p, int layout, int tile_mode, dim3 grid, hipStream_t s) {
 #ifndef ADN_W4_ONLY

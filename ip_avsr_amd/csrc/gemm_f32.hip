@@ -583,6 +583,14 @@ static int gemm_rs(const GemmArgs* gs, int n, hipStream_t stream) {
     ADN_CHECK(g.lda % 4 == 0 && g.ldb % 4 == 0, ADN_ERR_INVALID, "gemm: lda/ldb must be multiples of 4 floats");
     ADN_CHECK(g.precision == ADN_PRECISION_F32 || g.precision == ADN_PRECISION_BF16, ADN_ERR_INVALID,
               "gemm: unsupported precision");
+    // a short-K NT product into a bf16-only matrix under very many rows: the A-stationary kernel (gemm_bf16.hip)
+    if (n == 1 && lean_c && g.layout == GEMM_NT && !g.bias && !g.Y && !g.Y16 && !g.colsum && g.act == ADN_ACT_LINEAR &&
+        gemm_nt_astat_takes(g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.A16, g.B16, g.C16)) {
+        ProfScope prof(PROF_GEMM_NN + g.layout, 2.0 * g.M * g.N * g.K, 2.0 * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N), stream);
+        static const bool trace = getenv("ADN_GEMM_TRACE") != nullptr;
+        if (trace) fprintf(stderr, "ADN_GEMM NT M=%d N=%d K=%d tile=1 tiles=%d split=1 shadows=1 lean=1 acc=0\n", g.M, g.N, g.K, cdiv(g.M, 128));
+        return gemm_nt_astat(g.A16, g.lda, g.B16, g.ldb, g.C16, g.ldc, g.M, g.N, g.K, stream);
+    }
     GemmParams p;
     std::memset(static_cast<void*>(&p), 0, sizeof(p));
     p.M = g.M; p.N = g.N; p.K = g.K;
