@@ -48,6 +48,124 @@ __device__ __forceinline__ bool cae_keep(uint32_t key, uint32_t idx, float p) { 
 // ---------------------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------------------
+// The first convolution has ONE input channel: its patches are 25 pixels of the frame, a GEMM over them (K = 25) spends its time
+// writing and re-reading a patch matrix 25 times the size of its input and runs at 20 TFLOP/s.  Direct form, no patch matrix: a
+// workgroup takes frames into LDS (4.8 KB each); thread (channel quad cq, pixel lane pl) keeps its 25 x 4 filter taps in
+// registers and walks the output pixels pl, pl + lanes, ...: 25 LDS reads (broadcast) + 100 fp32 FMAs + one 16-byte store per
+// pixel; a pixel's O channels leave as one contiguous row.  fp32 arithmetic throughout (the GEMM path rounds the operands to
+// bfloat16 in bf16 mode).   y[b][oy][ox][o] = act(bias[o] + sum_{i,j} x[b][oy + i][ox + j] Wm[i k + j][o])
+// (tanh through exp2 + rcp, 2 ulp-ish: with tanhf the kernel is bound by the activation's ~40 instructions per value -- 156 us,
+//  twice its store time)
+__device__ __forceinline__ float cae_act_fast(int act, float v) {
+    if (act == ADN_ACT_LINEAR) return v;
+    const float s_in = act == ADN_ACT_SCALED_TANH ? 0.5f : (2.f / 3.f), s_out = act == ADN_ACT_SCALED_TANH ? 2.4f : 1.7159f;
+    const float t = 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.88539008177792681f * s_in * v));
+    return s_out * t;
+}
+
+template <int KK>
+__global__ __launch_bounds__(256) void conv1_direct_fwd_kernel(const float* __restrict__ x, const float* __restrict__ Wm,
+                                                               const float* __restrict__ bias, float* __restrict__ y, int B, int H,
+                                                               int W, int k, int O, int OH, int OW, int act) {
+    extern __shared__ float img[];                       // [H][W]
+    const int tid = threadIdx.x, Q = O / 4, lanes = 256 / Q;
+    const int cq = tid % Q, pl = tid / Q;
+    float4 w[KK];
+#pragma unroll
+    for (int t = 0; t < KK; ++t) w[t] = pl < lanes ? *reinterpret_cast<const float4*>(Wm + (size_t)t * O + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 bq = pl < lanes ? *reinterpret_cast<const float4*>(bias + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();                                 // (the previous frame has been consumed)
+        for (int e = tid; e < H * W; e += 256) img[e] = x[(size_t)b * H * W + e];
+        __syncthreads();
+        if (pl >= lanes) continue;
+        float* yb = y + (size_t)b * OH * OW * O + 4 * cq;
+        for (int p = pl; p < OH * OW; p += lanes) {
+            const int oy = p / OW, ox = p - oy * OW;
+            const float* ip = img + oy * W + ox;
+            float4 a = bq;
+#pragma unroll
+            for (int t = 0; t < KK; ++t) {
+                const float xv = ip[(t / 5) * W + (t % 5)];      // (KK = 25: a 5 x 5 window)
+                a.x += xv * w[t].x; a.y += xv * w[t].y; a.z += xv * w[t].z; a.w += xv * w[t].w;
+            }
+            a.x = cae_act_fast(act, a.x); a.y = cae_act_fast(act, a.y); a.z = cae_act_fast(act, a.z); a.w = cae_act_fast(act, a.w);
+            *reinterpret_cast<float4*>(yb + (size_t)p * O) = a;
+        }
+    }
+}
+
+// ... and its weight gradient: dW[i k + j][o] = sum_{b, oy, ox} x[b][oy + i][ox + j] g[b][oy][ox][o].  Same thread map; a thread
+// accumulates its 25 x 4 taps over the frames of its workgroup, the pixel lanes are then summed in lane order through LDS and the
+// workgroup's 25 x O block goes to its own slot (conv1_direct_dw_reduce_kernel adds the slots in order: no atomics anywhere).
+template <int KK>
+__global__ __launch_bounds__(256) void conv1_direct_dw_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                              float* __restrict__ slots, int B, int H, int W, int k, int O, int OH, int OW) {
+    extern __shared__ float sm[];                        // [H][W] frame, then [KK][O] block sums
+    float* img = sm;
+    float* red = sm + H * W;
+    const int tid = threadIdx.x, Q = O / 4, lanes = 256 / Q;
+    const int cq = tid % Q, pl = tid / Q;
+    float4 acc[KK];
+#pragma unroll
+    for (int t = 0; t < KK; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();
+        for (int e = tid; e < H * W; e += 256) img[e] = x[(size_t)b * H * W + e];
+        __syncthreads();
+        if (pl >= lanes) continue;
+        const float* gb = g + (size_t)b * OH * OW * O + 4 * cq;
+        for (int p0 = pl; p0 < OH * OW; p0 += 4 * lanes) {       // four gradient rows in flight per thread (one alone: a round trip per pixel)
+            float4 gv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = p0 + u * lanes;
+                gv[u] = p < OH * OW ? *reinterpret_cast<const float4*>(gb + (size_t)p * O) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = min(p0 + u * lanes, OH * OW - 1);     // (a pixel past the end multiplies a zero gradient)
+                const int oy = p / OW, ox = p - oy * OW;
+                const float* ip = img + oy * W + ox;
+#pragma unroll
+                for (int t = 0; t < KK; ++t) {
+                    const float xv = ip[(t / 5) * W + (t % 5)];
+                    acc[t].x += xv * gv[u].x; acc[t].y += xv * gv[u].y; acc[t].z += xv * gv[u].z; acc[t].w += xv * gv[u].w;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < KK * O; e += 256) red[e] = 0.f;
+    for (int l = 0; l < lanes; ++l) {                    // pixel lanes in order: a fixed summation order
+        __syncthreads();
+        if (pl == l) {
+#pragma unroll
+            for (int t = 0; t < KK; ++t) {
+                float4* r4 = reinterpret_cast<float4*>(red + t * O + 4 * cq);
+                float4 v = *r4;
+                v.x += acc[t].x; v.y += acc[t].y; v.z += acc[t].z; v.w += acc[t].w;
+                *r4 = v;
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < KK * O; e += 256) slots[(size_t)blockIdx.x * KK * O + e] = red[e];
+}
+
+// 64 outputs per workgroup x 4 slot quarters: a thread adds its quarter's slots in order, the quarters are added in order
+__global__ __launch_bounds__(256) void conv1_direct_dw_reduce_kernel(const float* __restrict__ slots, int nslots, int n, float* __restrict__ dW) {
+    __shared__ float part[4][64];
+    const int o = threadIdx.x & 63, q = threadIdx.x >> 6, e = blockIdx.x * 64 + o;
+    const int per = (nslots + 3) / 4;
+    float v = 0.f;
+    if (e < n)
+        for (int s_ = q * per; s_ < min(nslots, (q + 1) * per); ++s_) v += slots[(size_t)s_ * n + e];
+    part[q][o] = v;
+    __syncthreads();
+    if (q == 0 && e < n) dW[e] += ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];      // (the tied deconvolution adds to the same gradient)
+}
+
 // cols[(b, oy, ox)][(i*kw + j)*C + c] = x[b][oy + i - ph][ox + j - pw][c]  (0 outside); row stride ldc
 // `up` = 1: the patch rows belong to a 2x upscaled grid and are wanted SUMMED over every 2 x 2 block of it (OH, OW = the
 // compact grid): row (b, oy, ox) = sum over dy, dx in {0, 1} of the patch at (2 oy + dy, 2 ox + dx) -- see deconv_bwd
@@ -576,7 +694,21 @@ static bool lean_scratch() { static const bool off = getenv("ADN_CAE_FP32_SCRATC
 // y = act(conv(x) + b): patches kept in `cols` for the backward pass
 // preact: y = conv(x) + b WITHOUT the activation (the pooling behind it applies it to its maxima): a plain bias epilogue, which the
 // ping-pong kernel has -- 129024 x 152 x 2500 at batch 1024
+// the one-input-channel first convolution without a patch matrix (conv1_direct_*_kernel): bf16 mode only -- the fp32 mode keeps
+// its GEMM path, the oracle-parity reference
+bool direct1(const adn_cae* m, const ConvGeom& g) {
+    static const bool off = getenv("ADN_CAE_NO_DIRECT1") != nullptr;      // (A/B switch)
+    return !off && m->precision == ADN_PRECISION_BF16 && g.C == 1 && g.k == 5 && g.ph == 0 && g.pw == 0 && g.O % 4 == 0 && g.O <= 256 &&
+           (m->S == ADN_ACT_SCALED_TANH || m->S == ADN_ACT_SCALED_TANH_LECUN || m->S == ADN_ACT_LINEAR);
+}
+
 int conv_fwd(adn_cae* m, const float* x, const ConvGeom& g, int B, float* cols, size_t W, size_t b, float* y, bool preact = false) {
+    if (!preact && direct1(m, g)) {
+        hipLaunchKernelGGL(conv1_direct_fwd_kernel<25>, dim3(std::min(B, 2048)), dim3(256), (size_t)g.H * g.W * sizeof(float), m->stream,
+                           x, m->P(W), m->P(b), y, B, g.H, g.W, g.k, g.O, g.OH, g.OW, m->S);
+        ADN_HIP_CHECK(hipGetLastError());
+        return ADN_OK;
+    }
     if (fast16(m, g)) {                              // `cols` holds the bf16 patches matrix in this mode
         ADN_TRY(im2col16(m, x, g, B, cols));
         const int R = (int)rows_of(g, B);
@@ -589,8 +721,21 @@ int conv_fwd(adn_cae* m, const float* x, const ConvGeom& g, int B, float* cols, 
 
 // dy (already multiplied by act') -> dW, db, and (optionally) dx.  `ready`: the pass that produced dy already left its bf16 copy
 // in t16 and added the bias gradient (maxpool_bwd's pooled-grid form)
-int conv_bwd(adn_cae* m, const ConvGeom& g, int B, const float* cols, const float* dy, size_t W, size_t b, float* dx, bool ready = false) {
+// x_direct: the layer's input when conv_fwd took the direct form (no patches in `cols`)
+int conv_bwd(adn_cae* m, const ConvGeom& g, int B, const float* cols, const float* dy, size_t W, size_t b, float* dx, bool ready = false,
+             const float* x_direct = nullptr) {
     const int R = (int)rows_of(g, B);
+    if (x_direct) {
+        ADN_CHECK(direct1(m, g) && !dx, ADN_ERR_STATE, "conv AE: direct first-layer backward without its forward");
+        const int nslots = std::min(B, 512), n = g.K * g.O;
+        ADN_CHECK((size_t)nslots * n <= m->splitk_floats, ADN_ERR_STATE, "conv AE: slot workspace too small");
+        hipLaunchKernelGGL(conv1_direct_dw_kernel<25>, dim3(nslots), dim3(256), (size_t)(g.H * g.W + n) * sizeof(float), m->stream,
+                           x_direct, dy, m->splitk, B, g.H, g.W, g.k, g.O, g.OH, g.OW);
+        hipLaunchKernelGGL(conv1_direct_dw_reduce_kernel, dim3(cdiv(n, 64)), dim3(256), 0, m->stream, m->splitk, nslots, n, m->G(W));
+        ADN_HIP_CHECK(hipGetLastError());
+        if (!ready) ADN_TRY(col_sum(dy, g.O, R, g.O, m->G(b), 1, m->stream));
+        return ADN_OK;
+    }
     if (!fast16(m, g) && ready) {                    // (fp32-operand layer: only the bias gradient came with dy)
         ADN_TRY(mm(m, GEMM_TN, g.K, g.O, R, cols, g.ldk, dy, g.O, m->G(W), g.O, nullptr, ADN_ACT_LINEAR, 1));
         if (dx) {
@@ -870,7 +1015,7 @@ int backward(adn_cae* m, int B) {
         ADN_TRY(bn_bwd(m, 0, m->a1, gB, R1));                                             // gB = d a1
         ADN_TRY(act_backward(gB, F1, m->a1, F1, R1, F1, S, s));
     }
-    ADN_TRY(conv_bwd(m, m->c1, B, m->cols1, gB, m->W1, m->b1, nullptr, ready1));
+    ADN_TRY(conv_bwd(m, m->c1, B, m->cols1, gB, m->W1, m->b1, nullptr, ready1, direct1(m, m->c1) ? m->x0 : nullptr));
     m->grads_valid = true;
     return ADN_OK;
 }
