@@ -276,6 +276,24 @@ __global__ __launch_bounds__(256) void col2im4_bf16_kernel(const cae_bf16x4* __r
         const int64_t p = e / C4;
         const int x = (int)(p % W), y = (int)((p / W) % H), b = (int)(p / ((int64_t)W * H));
         float4 acc = bias ? bias[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kw == 5) {                                  // a filter row's five taps requested together (one at a time behind its own
+            for (int i = 0; i < kh; ++i) {              // bounds test: a round trip per tap, 2.6 TB/s)
+                const int oy = y + ph - i;
+                if (oy < 0 || oy >= OH) continue;
+                cae_bf16x4 v[5];
+                bool ok[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const int ox = x + pw - j;
+                    ok[j] = ox >= 0 && ox < OW;
+                    const int oxc = ok[j] ? ox : 0;
+                    v[j] = dcols[(up ? ((size_t)b * (OH / 2) + oy / 2) * (OW / 2) + oxc / 2 : ((size_t)b * OH + oy) * OW + oxc) * ldc4 + (i * 5 + j) * C4 + c];
+                }
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+                    if (ok[j]) { acc.x += (float)v[j][0]; acc.y += (float)v[j][1]; acc.z += (float)v[j][2]; acc.w += (float)v[j][3]; }
+            }
+        } else {
         for (int i = 0; i < kh; ++i) {
             const int oy = y + ph - i;
             if (oy < 0 || oy >= OH) continue;
@@ -285,6 +303,7 @@ __global__ __launch_bounds__(256) void col2im4_bf16_kernel(const cae_bf16x4* __r
                 const cae_bf16x4 v = dcols[(up ? ((size_t)b * (OH / 2) + oy / 2) * (OW / 2) + ox / 2 : ((size_t)b * OH + oy) * OW + ox) * ldc4 + (i * kw + j) * C4 + c];
                 acc.x += (float)v[0]; acc.y += (float)v[1]; acc.z += (float)v[2]; acc.w += (float)v[3];
             }
+        }
         }
         acc.x = cae_act(act, acc.x); acc.y = cae_act(act, acc.y); acc.z = cae_act(act, acc.z); acc.w = cae_act(act, acc.w);
         out[e] = acc;
