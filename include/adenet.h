@@ -265,6 +265,10 @@ int adn_debug_occupy_cus(int n_workgroups, int lds_bytes, double ms, void* hip_s
 int adn_debug_lstm_family_counts(int64_t out[4]);
 /* ... and LSTM backward passes, same families */
 int adn_debug_lstm_backward_family_counts(int64_t out[4]);
+/* test hook, host logic only: the launches a set of n_lstm LSTMs of `groups` utterance groups (wg_per_group workgroups each) is
+ * dealt over on a device of `cus` compute units -- ranges of (LSTM, group) pairs, pair = lstm * groups + group; returns the
+ * number of launches (the first max_launches of them written), < 0 on bad arguments */
+int adn_debug_plan_lstm_launches(int n_lstm, int groups, int wg_per_group, int cus, int32_t* pair0, int32_t* count, int max_launches);
 
 /* per-kernel-class timing with HIP events recorded on the model's stream around every launch of the
  * class (bench.py's live roofline measurement).  flops / bytes are the ALGORITHMIC work of the launches

@@ -113,6 +113,7 @@ _SIGNATURES = {
     "adn_debug_occupy_cus": (C.c_int, [C.c_int, C.c_int, C.c_double, _P]),
     "adn_debug_lstm_family_counts": (C.c_int, [C.POINTER(C.c_int64)]),
     "adn_debug_lstm_backward_family_counts": (C.c_int, [C.POINTER(C.c_int64)]),
+    "adn_debug_plan_lstm_launches": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int]),
     "adn_profile_enable": (C.c_int, [_P, C.c_int]),
     "adn_profile_read": (C.c_int, [_P, C.POINTER(ProfileEntry), C.c_int, C.POINTER(C.c_int)]),
     "adn_op_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.c_int, _P,

@@ -2135,6 +2135,14 @@ extern "C" int adn_debug_lstm_family_counts(int64_t out[4]) {
     return ADN_OK;
 }
 
+// host logic only (no device call): how a call's (LSTM, group) pairs are dealt over launches
+extern "C" int adn_debug_plan_lstm_launches(int n_lstm, int groups, int wg_per_group, int cus, int32_t* pair0, int32_t* count, int max_launches) {
+    if (n_lstm < 1 || groups < 1 || wg_per_group < 1 || cus < 1 || !pair0 || !count) return -1;
+    const std::vector<adn::PairRange> plan = adn::plan_pairs(n_lstm, groups, wg_per_group, cus);
+    for (size_t k = 0; k < plan.size() && (int)k < max_launches; ++k) { pair0[k] = plan[k].pair0; count[k] = plan[k].count; }
+    return (int)plan.size();
+}
+
 extern "C" int adn_debug_lstm_backward_family_counts(int64_t out[4]) {
     if (!out) return ADN_ERR_INVALID;
     for (int k = 0; k < 4; ++k) out[k] = adn::g_lstm_family_backwards[k];

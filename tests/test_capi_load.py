@@ -86,3 +86,26 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(dirpath, f)
+
+
+def test_lstm_launch_plan_covers_every_pair_once_and_fits_the_device(lib):
+    """csrc/lstm_cluster.hip::plan_pairs (host logic, runs without a GPU): the (LSTM, utterance group) pairs of a call go out in
+    the fewest launches whose workgroups are all resident at once, in equal shares"""
+    def plan(n, groups, cwg, cus):
+        p0, cnt = (C.c_int32 * 64)(), (C.c_int32 * 64)()
+        k = lib.adn_debug_plan_lstm_launches(n, groups, cwg, cus, p0, cnt, 64)
+        assert 0 < k <= 64
+        return [(p0[i], cnt[i]) for i in range(k)]
+    for n, groups, cwg, cus in [(3, 17, 4, 256), (2, 17, 4, 256), (4, 17, 8, 256), (2, 17, 8, 256), (4, 11, 16, 256), (2, 11, 16, 256),
+                                (6, 1, 16, 256), (5, 7, 4, 24), (1, 64, 4, 256), (8, 3, 16, 64)]:
+        launches = plan(n, groups, cwg, cus)
+        cap = max(1, cus // cwg)
+        assert len(launches) == -(-n * groups // cap)                      # the fewest launches the device allows
+        nxt = 0
+        for p0, cnt in launches:
+            assert p0 == nxt and 1 <= cnt <= cap                           # contiguous, resident
+            nxt += cnt
+        assert nxt == n * groups                                           # every pair once
+        assert max(c for _, c in launches) - min(c for _, c in launches) <= 1          # equal shares
+    assert plan(4, 17, 8, 256) == [(0, 23), (23, 23), (46, 22)]            # four 512-unit LSTMs at B = 520: three launches, not four
+    assert lib.adn_debug_plan_lstm_launches(0, 1, 4, 256, None, None, 0) < 0
