@@ -154,7 +154,9 @@ __global__ __launch_bounds__(256) void conv1_direct_dw_kernel(const float* __res
 }
 
 // 64 outputs per workgroup x 4 slot quarters: a thread adds its quarter's slots in order, the quarters are added in order
-__global__ __launch_bounds__(256) void conv1_direct_dw_reduce_kernel(const float* __restrict__ slots, int nslots, int n, float* __restrict__ dW) {
+// (elements [0, nW) of a slot belong to dW, [nW, n) -- the fused form's bias sums -- to db)
+__global__ __launch_bounds__(256) void conv1_direct_dw_reduce_kernel(const float* __restrict__ slots, int nslots, int n, float* __restrict__ dW,
+                                                                     int nW, float* __restrict__ db) {
     __shared__ float part[4][64];
     const int o = threadIdx.x & 63, q = threadIdx.x >> 6, e = blockIdx.x * 64 + o;
     const int per = (nslots + 3) / 4;
@@ -163,7 +165,11 @@ __global__ __launch_bounds__(256) void conv1_direct_dw_reduce_kernel(const float
         for (int s_ = q * per; s_ < min(nslots, (q + 1) * per); ++s_) v += slots[(size_t)s_ * n + e];
     part[q][o] = v;
     __syncthreads();
-    if (q == 0 && e < n) dW[e] += ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];      // (the tied deconvolution adds to the same gradient)
+    if (q == 0 && e < n) {
+        const float sum = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
+        if (e < nW) dW[e] += sum;                        // (the tied deconvolution adds to the same gradient)
+        else db[e - nW] += sum;
+    }
 }
 
 // cols[(b, oy, ox)][(i*kw + j)*C + c] = x[b][oy + i - ph][ox + j - pw][c]  (0 outside); row stride ldc
@@ -404,6 +410,134 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
     }
 }
 
+// The first convolution FUSED with the 2 x 2 pooling behind it (no BatchNorm between them, no dropout): the full-resolution
+// activation (383 MB at batch 1024) is never written or read.  Forward: a thread computes the four pre-activations of a pooled
+// position from its 6 x 6 window (36 LDS reads), keeps the maximum (first one on ties, like maxpool_fwd_kernel) and applies the
+// -- monotone -- activation to it: pool(act(x)) = act(pool(x)), a quarter of the activations.
+template <int KK>
+__global__ __launch_bounds__(256) void conv1_pool_direct_fwd_kernel(const float* __restrict__ x, const float* __restrict__ Wm,
+                                                                    const float* __restrict__ bias, float* __restrict__ pooled,
+                                                                    uint8_t* __restrict__ arg, int B, int H, int W, int O, int PH, int PW, int act) {
+    extern __shared__ float img[];
+    const int tid = threadIdx.x, Q = O / 4, lanes = 256 / Q;
+    const int cq = tid % Q, pl = tid / Q;
+    float4 w[KK];
+#pragma unroll
+    for (int t = 0; t < KK; ++t) w[t] = pl < lanes ? *reinterpret_cast<const float4*>(Wm + (size_t)t * O + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 bq = pl < lanes ? *reinterpret_cast<const float4*>(bias + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();
+        for (int e = tid; e < H * W; e += 256) img[e] = x[(size_t)b * H * W + e];
+        __syncthreads();
+        if (pl >= lanes) continue;
+        for (int q = pl; q < PH * PW; q += lanes) {
+            const int py = q / PW, px = q - py * PW;
+            const float* ip = img + 2 * py * W + 2 * px;
+            float xw[36];
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = 0; c < 6; ++c) xw[r * 6 + c] = ip[r * W + c];
+            float4 best = bq;
+            uchar4 code = make_uchar4(0, 0, 0, 0);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                float4 a = bq;
+#pragma unroll
+                for (int t = 0; t < KK; ++t) {
+                    const float xv = xw[(t / 5 + (d >> 1)) * 6 + (t % 5) + (d & 1)];
+                    a.x += xv * w[t].x; a.y += xv * w[t].y; a.z += xv * w[t].z; a.w += xv * w[t].w;
+                }
+                if (d == 0) best = a;
+                else {
+                    if (a.x > best.x) { best.x = a.x; code.x = d; }
+                    if (a.y > best.y) { best.y = a.y; code.y = d; }
+                    if (a.z > best.z) { best.z = a.z; code.z = d; }
+                    if (a.w > best.w) { best.w = a.w; code.w = d; }
+                }
+            }
+            best.x = cae_act_fast(act, best.x); best.y = cae_act_fast(act, best.y); best.z = cae_act_fast(act, best.z); best.w = cae_act_fast(act, best.w);
+            const size_t o = ((size_t)b * PH * PW + q) * O + 4 * cq;
+            *reinterpret_cast<float4*>(pooled + o) = best;
+            *reinterpret_cast<uchar4*>(arg + o) = code;
+        }
+    }
+}
+
+// Backward of the fused pair: the pooled position's gradient (times act' of the pooled value) belongs to its winner's conv
+// position, per channel -- dW[i k + j][o] = sum x[b][2 py + dy_o + i][2 px + dx_o + j] g[b][py][px][o], db[o] = sum g: a quarter of the
+// multiply-adds of the unfused weight gradient, and neither the 383 MB full-resolution gradient nor the pooling's adjoint pass.
+template <int KK>
+__global__ __launch_bounds__(256) void conv1_pool_direct_dw_kernel(const float* __restrict__ x, const float* __restrict__ gp,
+                                                                   const float* __restrict__ pooled, const uint8_t* __restrict__ arg,
+                                                                   float* __restrict__ slots, int B, int H, int W, int O, int PH, int PW, int act) {
+    extern __shared__ float sm[];                        // [H][W] frame, then [KK][O] block sums + [O] bias sums
+    float* img = sm;
+    float* red = sm + H * W;
+    const int tid = threadIdx.x, Q = O / 4, lanes = 256 / Q;
+    const int cq = tid % Q, pl = tid / Q;
+    float4 acc[KK];
+#pragma unroll
+    for (int t = 0; t < KK; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();
+        for (int e = tid; e < H * W; e += 256) img[e] = x[(size_t)b * H * W + e];
+        __syncthreads();
+        if (pl >= lanes) continue;
+        for (int q0 = pl; q0 < PH * PW; q0 += 2 * lanes) {       // two positions in flight per thread
+            float4 g[2], y[2];
+            uchar4 a[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int q = q0 + u * lanes;
+                const size_t o = ((size_t)b * PH * PW + min(q, PH * PW - 1)) * O + 4 * cq;
+                g[u] = q < PH * PW ? *reinterpret_cast<const float4*>(gp + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+                y[u] = *reinterpret_cast<const float4*>(pooled + o);
+                a[u] = *reinterpret_cast<const uchar4*>(arg + o);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int q = min(q0 + u * lanes, PH * PW - 1);      // (a position past the end carries a zero gradient)
+                const int py = q / PW, px = q - py * PW;
+                float4 gv = g[u];
+                gv.x *= cae_act_grad(act, y[u].x); gv.y *= cae_act_grad(act, y[u].y); gv.z *= cae_act_grad(act, y[u].z); gv.w *= cae_act_grad(act, y[u].w);
+                bsum.x += gv.x; bsum.y += gv.y; bsum.z += gv.z; bsum.w += gv.w;
+                const float* base = img + 2 * py * W + 2 * px;
+                const float* ix = base + (a[u].x >> 1) * W + (a[u].x & 1);
+                const float* iy = base + (a[u].y >> 1) * W + (a[u].y & 1);
+                const float* iz = base + (a[u].z >> 1) * W + (a[u].z & 1);
+                const float* iw = base + (a[u].w >> 1) * W + (a[u].w & 1);
+#pragma unroll
+                for (int t = 0; t < KK; ++t) {
+                    const int off = (t / 5) * W + (t % 5);
+                    acc[t].x += ix[off] * gv.x; acc[t].y += iy[off] * gv.y; acc[t].z += iz[off] * gv.z; acc[t].w += iw[off] * gv.w;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < KK * O + O; e += 256) red[e] = 0.f;
+    for (int l = 0; l < lanes; ++l) {                    // pixel lanes in order: a fixed summation order
+        __syncthreads();
+        if (pl == l) {
+#pragma unroll
+            for (int t = 0; t < KK; ++t) {
+                float4* r4 = reinterpret_cast<float4*>(red + t * O + 4 * cq);
+                float4 v = *r4;
+                v.x += acc[t].x; v.y += acc[t].y; v.z += acc[t].z; v.w += acc[t].w;
+                *r4 = v;
+            }
+            float4* b4 = reinterpret_cast<float4*>(red + KK * O + 4 * cq);
+            float4 v = *b4;
+            v.x += bsum.x; v.y += bsum.y; v.z += bsum.z; v.w += bsum.w;
+            *b4 = v;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < KK * O + O; e += 256) slots[(size_t)blockIdx.x * (KK * O + O) + e] = red[e];
+}
+
 // The same adjoint from the POOLED side (round 4; 2 x 2 windows that tile the padded input exactly, C % 4 == 0): one thread per
 // (pooled position, 4 channels) writes its window -- the winner gets dy * act'(.), the other three positions zero.  act' comes
 // from the pooled VALUE (the activation is applied before the pooling, so the pooled value is the winner's activation): the
@@ -526,6 +660,7 @@ struct adn_cae {
     char *p16 = nullptr, *a9_16 = nullptr, *u12_16 = nullptr, *t16 = nullptr;
     bool p16_dirty = true;
     bool preact3 = false;                 // last forward pass: a3 holds conv3's pre-activations (see forward())
+    bool fused1 = false;                  // last forward pass: conv1 + pool2 ran fused (no a1; conv1_pool_direct_*_kernel)
     bool grads_valid = false;
     int adam_t = 0;
     float* P(size_t off) const { return buf[0] + off; }
@@ -750,7 +885,7 @@ int conv_bwd(adn_cae* m, const ConvGeom& g, int B, const float* cols, const floa
         ADN_CHECK((size_t)nslots * n <= m->splitk_floats, ADN_ERR_STATE, "conv AE: slot workspace too small");
         hipLaunchKernelGGL(conv1_direct_dw_kernel<25>, dim3(nslots), dim3(256), (size_t)(g.H * g.W + n) * sizeof(float), m->stream,
                            x_direct, dy, m->splitk, B, g.H, g.W, g.k, g.O, g.OH, g.OW);
-        hipLaunchKernelGGL(conv1_direct_dw_reduce_kernel, dim3(cdiv(n, 64)), dim3(256), 0, m->stream, m->splitk, nslots, n, m->G(W));
+        hipLaunchKernelGGL(conv1_direct_dw_reduce_kernel, dim3(cdiv(n, 64)), dim3(256), 0, m->stream, m->splitk, nslots, n, m->G(W), n, (float*)nullptr);
         ADN_HIP_CHECK(hipGetLastError());
         if (!ready) ADN_TRY(col_sum(dy, g.O, R, g.O, m->G(b), 1, m->stream));
         return ADN_OK;
@@ -910,10 +1045,21 @@ int forward(adn_cae* m, int B, bool decode) {
     // (a dropout layer works in place on the tensor the next layer reads: a BatchNorm output, a pooling output -- whose
     //  backward needs only the argmax codes -- or the staged input)
     ADN_TRY(dropout_inplace(m, 0, m->x0, (int64_t)B * m->H * m->W, m->H * m->W, 1, 1));
-    ADN_TRY(conv_fwd(m, m->x0, m->c1, B, m->cols1, m->W1, m->b1, m->a1));
+    // the one-channel first convolution and the pooling behind it in one kernel where nothing else needs the full-resolution
+    // activation: no BatchNorm between them, no dropout (whose in-place rescaling of the pooled tensor sends the backward pass
+    // to it for act')
+    static const bool no_fuse1 = getenv("ADN_CAE_NO_FUSE1") != nullptr;       // (A/B switch)
+    m->fused1 = direct1(m, m->c1) && m->bn_mode != 2 && !m->drop && !no_fuse1 && 2 * m->p2h == m->c1.OH && 2 * m->p2w == m->c1.OW;
     const float* t = m->a1;
+    if (m->fused1) {
+        hipLaunchKernelGGL(conv1_pool_direct_fwd_kernel<25>, dim3(std::min(B, 2048)), dim3(256), (size_t)m->H * m->W * sizeof(float), m->stream,
+                           m->x0, m->P(m->W1), m->P(m->b1), m->p2, m->arg2, B, m->H, m->W, m->F1, m->p2h, m->p2w, S);
+        ADN_HIP_CHECK(hipGetLastError());
+    } else {
+    ADN_TRY(conv_fwd(m, m->x0, m->c1, B, m->cols1, m->W1, m->b1, m->a1));
     if (m->bn_mode == 2) { ADN_TRY(bn_fwd(m, 0, t, R1)); t = m->bn[0].out; }
     ADN_TRY(maxpool_fwd(m, t, B, m->c1.OH, m->c1.OW, m->F1, 0, m->p2h, m->p2w, m->p2, m->arg2));
+    }
     float* u = m->p2;
     if (m->bn_mode == 1) { ADN_TRY(bn_fwd(m, 0, u, P2)); u = m->bn[0].out; }
     ADN_TRY(dropout_inplace(m, 1, u, P2, m->p2h * m->p2w, m->F1L, m->F1));
@@ -1026,6 +1172,17 @@ int backward(adn_cae* m, int B) {
     ADN_TRY(conv_bwd(m, m->c3, B, m->cols3, gB, m->W3, m->b3, gA, ready3));   // gA = d (conv3 input)
     ADN_TRY(dropout_inplace(m, 1, gA, P2, m->p2h * m->p2w, m->F1L, F1));
     if (m->bn_mode == 1) ADN_TRY(bn_bwd(m, 0, m->p2, gA, P2));                             // gA = d p2
+    if (m->fused1) {                                  // pooling adjoint + weight and bias gradient of conv1 in one kernel
+        ADN_CHECK(m->bn_mode != 2 && pooled_intact, ADN_ERR_STATE, "conv AE: fused first layer without intact pooled values");
+        const int nslots = std::min(B, 512), nW = m->c1.K * F1, n = nW + F1;
+        ADN_CHECK((size_t)nslots * n <= m->splitk_floats, ADN_ERR_STATE, "conv AE: slot workspace too small");
+        hipLaunchKernelGGL(conv1_pool_direct_dw_kernel<25>, dim3(nslots), dim3(256), (size_t)(m->H * m->W + n) * sizeof(float), s,
+                           m->x0, gA, m->p2, m->arg2, m->splitk, B, m->H, m->W, F1, m->p2h, m->p2w, S);
+        hipLaunchKernelGGL(conv1_direct_dw_reduce_kernel, dim3(cdiv(n, 64)), dim3(256), 0, s, m->splitk, nslots, n, m->G(m->W1), nW, m->G(m->b1));
+        ADN_HIP_CHECK(hipGetLastError());
+        m->grads_valid = true;
+        return ADN_OK;
+    }
     // (conv1 is not a bf16-operand layer (C_in = 1): no bf16 copy of its gradient, the bias sums ride along all the same)
     ADN_TRY(maxpool_bwd(m, gA, m->arg2, B, m->c1.OH, m->c1.OW, F1, 0, m->p2h, m->p2w, gB, m->bn_mode == 2 ? nullptr : m->a1,
                         (m->bn_mode != 2 && pooled_intact) ? m->p2 : nullptr, m->bn_mode == 2 ? nullptr : m->G(m->b1), &ready1,
