@@ -359,6 +359,21 @@ __global__ __launch_bounds__(128) void im2col_runs_bf16_kernel(const float4* __r
     }
 }
 
+// ... from a bf16 copy of the input (the fused first layer leaves one beside its fp32 output): a plain copy of runs, half the bytes read
+__global__ __launch_bounds__(128) void im2col_runs_from_bf16_kernel(const cae_bf16x4* __restrict__ x, cae_bf16x4* __restrict__ cols, int R,
+                                                                    int H, int W, int C4, int kh, int kw, int OH, int OW, int ldc4) {
+    const int run4 = kw * C4;
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = blockIdx.x * 4 + rr;
+        if (r >= R) return;
+        const int ox = r % OW, oy = (r / OW) % OH, b = r / (OW * OH);
+        const cae_bf16x4* src = x + (((size_t)b * H + oy) * W + ox) * C4;
+        cae_bf16x4* dst = cols + (size_t)r * ldc4;
+        for (int i = 0; i < kh; ++i)
+            for (int q = threadIdx.x; q < run4; q += 128) dst[i * run4 + q] = src[(size_t)i * W * C4 + q];
+    }
+}
+
 // 2x2 / stride 2 max pooling, ignore_border, `ph` rows of padding above and below that never win; code = dy*2 + dx
 // post_act != LINEAR: x holds PRE-activations and the (monotone) activation is applied to the maximum -- pool(act(x)) = act(pool(x)),
 // on a quarter of the elements -- so that the convolution in front runs with a plain bias epilogue
@@ -417,7 +432,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
 template <int KK>
 __global__ __launch_bounds__(256) void conv1_pool_direct_fwd_kernel(const float* __restrict__ x, const float* __restrict__ Wm,
                                                                     const float* __restrict__ bias, float* __restrict__ pooled,
-                                                                    uint8_t* __restrict__ arg, int B, int H, int W, int O, int PH, int PW, int act) {
+                                                                    cae_bf16x4* __restrict__ pooled16, uint8_t* __restrict__ arg, int B, int H,
+                                                                    int W, int O, int PH, int PW, int act) {
     extern __shared__ float img[];
     const int tid = threadIdx.x, Q = O / 4, lanes = 256 / Q;
     const int cq = tid % Q, pl = tid / Q;
@@ -460,6 +476,10 @@ __global__ __launch_bounds__(256) void conv1_pool_direct_fwd_kernel(const float*
             const size_t o = ((size_t)b * PH * PW + q) * O + 4 * cq;
             *reinterpret_cast<float4*>(pooled + o) = best;
             *reinterpret_cast<uchar4*>(arg + o) = code;
+            if (pooled16) {                              // the next convolution's patch matrix is built from this copy
+                cae_bf16x4 h; h[0] = (__bf16)best.x; h[1] = (__bf16)best.y; h[2] = (__bf16)best.z; h[3] = (__bf16)best.w;
+                pooled16[o / 4] = h;
+            }
         }
     }
 }
@@ -661,6 +681,8 @@ struct adn_cae {
     bool p16_dirty = true;
     bool preact3 = false;                 // last forward pass: a3 holds conv3's pre-activations (see forward())
     bool fused1 = false;                  // last forward pass: conv1 + pool2 ran fused (no a1; conv1_pool_direct_*_kernel)
+    char* p2_16 = nullptr;                // ... and left this bf16 copy of p2 for conv3's patch matrix
+    bool p2_16_valid = false;
     bool grads_valid = false;
     int adam_t = 0;
     float* P(size_t off) const { return buf[0] + off; }
@@ -725,6 +747,7 @@ size_t carve(adn_cae* m, char* base, int B) {
     m->a9_16 = c.take<char>(N * m->flat * 2);
     m->u12_16 = c.take<char>(N * m->d11.H * m->d11.W * m->F2 * 2);           // bf16 copy of a11 (the compact input of deconv2d13)
     m->t16 = c.take<char>(act * 2);
+    m->p2_16 = c.take<char>(N * m->p2h * m->p2w * m->F1 * 2);
     if (m->drop && m->bn_mode == 0) { m->f6d = c.take<float>(N * m->flat); m->a7d = c.take<float>(N * m->D7); }   // dropped copies of a5 / a7
     if (m->bn_mode) {                                 // BatchNorm outputs, batch statistics, workspaces
         const size_t rows[4] = {m->bn_mode == 1 ? N * m->p2h * m->p2w : rows_of(m->c1, B), m->bn_mode == 1 ? N * m->p4h * m->p4w : rows_of(m->c3, B),
@@ -788,6 +811,12 @@ int im2col16(adn_cae* m, const float* x, const ConvGeom& g, int B, void* cols16,
     static const bool no_runs = getenv("ADN_CAE_IM2COL_GENERIC") != nullptr;     // (A/B switch)
     if (!up && g.ph == 0 && g.pw == 0 && !no_runs) {
         const int R = B * g.OH * g.OW;
+        if (x == m->p2 && m->p2_16_valid) {
+            hipLaunchKernelGGL(im2col_runs_from_bf16_kernel, dim3((R + 3) / 4), dim3(128), 0, m->stream, reinterpret_cast<const cae_bf16x4*>(m->p2_16),
+                               reinterpret_cast<cae_bf16x4*>(cols16), R, g.H, g.W, g.C / 4, g.k, g.k, g.OH, g.OW, g.ldk / 4);
+            ADN_HIP_CHECK(hipGetLastError());
+            return ADN_OK;
+        }
         hipLaunchKernelGGL(im2col_runs_bf16_kernel, dim3((R + 3) / 4), dim3(128), 0, m->stream, reinterpret_cast<const float4*>(x),
                            reinterpret_cast<cae_bf16x4*>(cols16), R, g.H, g.W, g.C / 4, g.k, g.k, g.OH, g.OW, g.ldk / 4);
         ADN_HIP_CHECK(hipGetLastError());
@@ -1053,7 +1082,8 @@ int forward(adn_cae* m, int B, bool decode) {
     const float* t = m->a1;
     if (m->fused1) {
         hipLaunchKernelGGL(conv1_pool_direct_fwd_kernel<25>, dim3(std::min(B, 2048)), dim3(256), (size_t)m->H * m->W * sizeof(float), m->stream,
-                           m->x0, m->P(m->W1), m->P(m->b1), m->p2, m->arg2, B, m->H, m->W, m->F1, m->p2h, m->p2w, S);
+                           m->x0, m->P(m->W1), m->P(m->b1), m->p2, reinterpret_cast<cae_bf16x4*>(m->p2_16), m->arg2, B, m->H, m->W, m->F1,
+                           m->p2h, m->p2w, S);
         ADN_HIP_CHECK(hipGetLastError());
     } else {
     ADN_TRY(conv_fwd(m, m->x0, m->c1, B, m->cols1, m->W1, m->b1, m->a1));
@@ -1069,7 +1099,9 @@ int forward(adn_cae* m, int B, bool decode) {
     static const bool no_preact = getenv("ADN_CAE_NO_PREACT") != nullptr;       // (A/B switch)
     m->preact3 = fast16(m, m->c3) && m->bn_mode != 2 && !m->drop && !no_preact &&
                  pool_bwd_from_pooled(m->c3.OH, m->c3.OW, m->F2, 1, m->p4h, m->p4w);
+    m->p2_16_valid = m->fused1 && u == m->p2;         // (a BatchNorm behind the pooling puts another tensor in front of conv3)
     ADN_TRY(conv_fwd(m, u, m->c3, B, m->cols3, m->W3, m->b3, m->a3, m->preact3));
+    m->p2_16_valid = false;
     t = m->a3;
     if (m->bn_mode == 2) { ADN_TRY(bn_fwd(m, 1, t, R3)); t = m->bn[1].out; }
     ADN_TRY(maxpool_fwd(m, t, B, m->c3.OH, m->c3.OW, m->F2, 1, m->p4h, m->p4w, m->p4, m->arg4, m->preact3 ? S : ADN_ACT_LINEAR));
