@@ -581,6 +581,136 @@ __global__ __launch_bounds__(256) void conv1_pool_direct_dw_kernel(const float* 
     for (int e = tid; e < KK * O + O; e += 256) slots[(size_t)blockIdx.x * (KK * O + O) + e] = red[e];
 }
 
+// The LAST deconvolution (tied to the first convolution: ONE output channel, 5 x 5, its input upscaled 2 x) without patch matrices.
+// Forward, per frame: P[r][t] = x[r][:] . Wm[t][:] for the CH x CW compact input pixels r and the 25 taps t (thread = pixel, its
+// 25 sums in registers, Wm in LDS), then z[y][x] = act(b + sum over the taps whose source (y + ph - i, x + pw - j) lies inside the
+// upscaled grid of P[((y + ph - i) / 2, (x + pw - j) / 2)][i k + j]) out of LDS.  (GEMM + col2im: 46 + 61 us at batch 1024.)
+template <int KK>
+__global__ __launch_bounds__(256) void deconv1_direct_fwd_kernel(const float* __restrict__ x, const float* __restrict__ Wm,
+                                                                 const float* __restrict__ bias, float* __restrict__ z, int B, int H, int W,
+                                                                 int O, int CH, int CW, int ph, int pw, int act) {
+    extern __shared__ float sm[];                        // Wl [KK][O], then P [CH CW][KK + 1]
+    float* Wl = sm;
+    float* P = sm + KK * O;
+    const int tid = threadIdx.x, OH = 2 * CH, OW = 2 * CW;
+    for (int e = tid; e < KK * O; e += 256) Wl[e] = Wm[e];
+    const float b0 = bias ? bias[0] : 0.f;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();                                 // (Wl is in place; the previous frame's P has been consumed)
+        for (int r = tid; r < CH * CW; r += 256) {
+            float acc[KK];
+#pragma unroll
+            for (int t = 0; t < KK; ++t) acc[t] = 0.f;
+            const float4* xr = reinterpret_cast<const float4*>(x + ((size_t)b * CH * CW + r) * O);
+            for (int o4 = 0; o4 < O / 4; ++o4) {
+                const float4 a = xr[o4];
+#pragma unroll
+                for (int t = 0; t < KK; ++t) {
+                    const float4 w = *reinterpret_cast<const float4*>(Wl + t * O + 4 * o4);
+                    acc[t] += ((a.x * w.x + a.y * w.y) + a.z * w.z) + a.w * w.w;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < KK; ++t) P[r * (KK + 1) + t] = acc[t];
+        }
+        __syncthreads();
+        for (int e = tid; e < H * W; e += 256) {
+            const int y = e / W, xx = e - y * W;
+            float acc = b0;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int oy = y + ph - i;
+                if (oy < 0 || oy >= OH) continue;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const int ox = xx + pw - j;
+                    if (ox < 0 || ox >= OW) continue;
+                    acc += P[((oy >> 1) * CW + (ox >> 1)) * (KK + 1) + i * 5 + j];
+                }
+            }
+            z[(size_t)b * H * W + e] = cae_act(act, acc);
+        }
+    }
+}
+
+// ... and its backward: patches[r][t] = sum over the 2 x 2 block of the upscaled grid of dz[2 cy + dy + i - ph][2 cx + dx + j - pw]
+// (zero outside the frame) into LDS, then thread (channel quad, pixel lane): dx[r][o] = sum_t patches[r][t] Wm[t][o] stored, and
+// dW[t][o] += patches[r][t] x[r][o] accumulated in registers over the workgroup's frames -> slots (conv1_direct_dw_reduce_kernel);
+// the bias gradient (the sum of dz) rides in the slot's last element.  (im2col + two K = 25 GEMMs + a column sum before.)
+template <int KK>
+__global__ __launch_bounds__(256) void deconv1_direct_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+                                                                 const float* __restrict__ Wm, float* __restrict__ dx, float* __restrict__ slots,
+                                                                 int B, int H, int W, int O, int CH, int CW, int ph, int pw) {
+    extern __shared__ float sm[];                        // Wl [KK][O] (later the block sums), img [H][W], patches [CH CW][KK + 1], bred [256]
+    float* Wl = sm;
+    float* img = sm + KK * O;
+    float* pt = img + H * W;
+    float* bred = pt + CH * CW * (KK + 1);
+    const int tid = threadIdx.x, Q = O / 4, lanes = 256 / Q;
+    const int cq = tid % Q, pl = tid / Q;
+    for (int e = tid; e < KK * O; e += 256) Wl[e] = Wm[e];
+    float4 acc[KK];
+#pragma unroll
+    for (int t = 0; t < KK; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float bsum = 0.f;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();
+        for (int e = tid; e < H * W; e += 256) { const float v = dz[(size_t)b * H * W + e]; img[e] = v; bsum += v; }
+        __syncthreads();
+        for (int idx = tid; idx < CH * CW * KK; idx += 256) {
+            const int r = idx / KK, t = idx - r * KK;
+            const int cy = r / CW, cx = r - cy * CW, i = t / 5, j = t - 5 * i;
+            float v = 0.f;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dxx = 0; dxx < 2; ++dxx) {
+                    const int y = 2 * cy + dy + i - ph, xx = 2 * cx + dxx + j - pw;
+                    if (y >= 0 && y < H && xx >= 0 && xx < W) v += img[y * W + xx];
+                }
+            pt[r * (KK + 1) + t] = v;
+        }
+        __syncthreads();
+        if (pl < lanes) {
+            for (int r = pl; r < CH * CW; r += lanes) {
+                const size_t o = ((size_t)b * CH * CW + r) * O + 4 * cq;
+                const float4 a = *reinterpret_cast<const float4*>(x + o);
+                float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int t = 0; t < KK; ++t) {
+                    const float pv = pt[r * (KK + 1) + t];
+                    const float4 w = *reinterpret_cast<const float4*>(Wl + t * O + 4 * cq);
+                    d.x += pv * w.x; d.y += pv * w.y; d.z += pv * w.z; d.w += pv * w.w;
+                    acc[t].x += pv * a.x; acc[t].y += pv * a.y; acc[t].z += pv * a.z; acc[t].w += pv * a.w;
+                }
+                *reinterpret_cast<float4*>(dx + o) = d;
+            }
+        }
+    }
+    __syncthreads();                                     // Wl has been read for the last time: it becomes the block sums
+    for (int e = tid; e < KK * O; e += 256) Wl[e] = 0.f;
+    for (int l = 0; l < lanes; ++l) {                    // pixel lanes in order: a fixed summation order
+        __syncthreads();
+        if (pl == l) {
+#pragma unroll
+            for (int t = 0; t < KK; ++t) {
+                float4* r4 = reinterpret_cast<float4*>(Wl + t * O + 4 * cq);
+                float4 v = *r4;
+                v.x += acc[t].x; v.y += acc[t].y; v.z += acc[t].z; v.w += acc[t].w;
+                *r4 = v;
+            }
+        }
+    }
+    bred[tid] = bsum;
+    __syncthreads();
+    for (int e = tid; e < KK * O; e += 256) slots[(size_t)blockIdx.x * (KK * O + 1) + e] = Wl[e];
+    if (tid == 0) {
+        float v = 0.f;
+        for (int k = 0; k < 256; ++k) v += bred[k];      // (thread order: fixed)
+        slots[(size_t)blockIdx.x * (KK * O + 1) + KK * O] = v;
+    }
+}
+
 // The same adjoint from the POOLED side (round 4; 2 x 2 windows that tile the padded input exactly, C % 4 == 0): one thread per
 // (pooled position, 4 channels) writes its window -- the winner gets dy * act'(.), the other three positions zero.  act' comes
 // from the pooled VALUE (the activation is applied before the pooling, so the pooled value is the winner's activation): the
@@ -915,6 +1045,13 @@ bool direct1(const adn_cae* m, const ConvGeom& g) {
            (m->S == ADN_ACT_SCALED_TANH || m->S == ADN_ACT_SCALED_TANH_LECUN || m->S == ADN_ACT_LINEAR);
 }
 
+// ... and the last deconvolution, tied to it (deconv1_direct_*_kernel; its input arrives 2 x upscaled)
+bool direct15(const adn_cae* m, const ConvGeom& g) {
+    static const bool off = getenv("ADN_CAE_NO_DIRECT15") != nullptr;     // (A/B switch)
+    return !off && m->precision == ADN_PRECISION_BF16 && g.C == 1 && g.k == 5 && g.O % 4 == 0 && g.O <= 256 && g.OH % 2 == 0 && g.OW % 2 == 0 &&
+           (g.OH / 2) * (g.OW / 2) <= 1024;
+}
+
 int conv_fwd(adn_cae* m, const float* x, const ConvGeom& g, int B, float* cols, size_t W, size_t b, float* y, bool preact = false) {
     if (!preact && direct1(m, g)) {
         hipLaunchKernelGGL(conv1_direct_fwd_kernel<25>, dim3(std::min(B, 2048)), dim3(256), (size_t)g.H * g.W * sizeof(float), m->stream,
@@ -998,6 +1135,13 @@ int deconv_fwd(adn_cae* m, const float* x, void* x16, const ConvGeom& g, int B, 
         ADN_TRY(mm16(m, GEMM_NT, R, g.K, g.O, x16, g.O, W16(m, W), g.O, m->scratch, g.ldk));
         return col2im(m, m->scratch, g, B, z, m->P(b), m->S, up);
     }
+    if (up && direct15(m, g)) {
+        const int CH = g.OH / 2, CW = g.OW / 2;
+        hipLaunchKernelGGL(deconv1_direct_fwd_kernel<25>, dim3(std::min(B, 2048)), dim3(256), (size_t)(25 * g.O + CH * CW * 26) * sizeof(float),
+                           m->stream, x, m->P(W), m->P(b), z, B, g.H, g.W, g.O, CH, CW, g.ph, g.pw, m->S);
+        ADN_HIP_CHECK(hipGetLastError());
+        return ADN_OK;
+    }
     ADN_TRY(mm(m, GEMM_NT, R, g.K, g.O, x, g.O, m->P(W), g.O, m->scratch, g.ldk));
     return col2im(m, m->scratch, g, B, z, m->P(b), m->S, up);
 }
@@ -1008,6 +1152,16 @@ int deconv_fwd(adn_cae* m, const float* x, void* x16, const ConvGeom& g, int B, 
 int deconv_bwd(adn_cae* m, const ConvGeom& g, int B, const float* x, const void* x16, const float* dz, size_t W, size_t b,
                float* dx, int up = 0) {
     const int R = (int)rows_of(g, B) / (up ? 4 : 1);
+    if (!x16 && up && direct15(m, g)) {
+        const int CH = g.OH / 2, CW = g.OW / 2, nslots = std::min(B, 512), nW = 25 * g.O, n = nW + 1;
+        ADN_CHECK((size_t)nslots * n <= m->splitk_floats, ADN_ERR_STATE, "conv AE: slot workspace too small");
+        hipLaunchKernelGGL(deconv1_direct_bwd_kernel<25>, dim3(nslots), dim3(256),
+                           (size_t)(25 * g.O + g.H * g.W + CH * CW * 26 + 256) * sizeof(float), m->stream, dz, x, m->P(W), dx, m->splitk, B, g.H,
+                           g.W, g.O, CH, CW, g.ph, g.pw);
+        hipLaunchKernelGGL(conv1_direct_dw_reduce_kernel, dim3(cdiv(n, 64)), dim3(256), 0, m->stream, m->splitk, nslots, n, m->G(W), nW, m->G(b));
+        ADN_HIP_CHECK(hipGetLastError());
+        return ADN_OK;
+    }
     ADN_TRY(col_sum(dz, g.C, B * g.H * g.W, g.C, m->G(b), 1, m->stream));
     if (x16 && fast16(m, g)) {
         ADN_TRY(im2col16(m, dz, g, B, m->scratch, up));
