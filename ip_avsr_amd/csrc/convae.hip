@@ -1041,15 +1041,18 @@ static bool lean_scratch() { static const bool off = getenv("ADN_CAE_FP32_SCRATC
 // its GEMM path, the oracle-parity reference
 bool direct1(const adn_cae* m, const ConvGeom& g) {
     static const bool off = getenv("ADN_CAE_NO_DIRECT1") != nullptr;      // (A/B switch)
+    const size_t lds = ((size_t)g.H * g.W + (size_t)26 * g.O) * sizeof(float);      // (frame + block sums: within a plain launch's 64 KB)
     return !off && m->precision == ADN_PRECISION_BF16 && g.C == 1 && g.k == 5 && g.ph == 0 && g.pw == 0 && g.O % 4 == 0 && g.O <= 256 &&
-           (m->S == ADN_ACT_SCALED_TANH || m->S == ADN_ACT_SCALED_TANH_LECUN || m->S == ADN_ACT_LINEAR);
+           lds <= 65536 && (m->S == ADN_ACT_SCALED_TANH || m->S == ADN_ACT_SCALED_TANH_LECUN || m->S == ADN_ACT_LINEAR);
 }
 
 // ... and the last deconvolution, tied to it (deconv1_direct_*_kernel; its input arrives 2 x upscaled)
 bool direct15(const adn_cae* m, const ConvGeom& g) {
     static const bool off = getenv("ADN_CAE_NO_DIRECT15") != nullptr;     // (A/B switch)
+    // (the kernels' LDS -- filter, frame, per-frame tap sums / patches -- must stay within the 64 KB a plain launch may ask for)
+    const size_t lds = ((size_t)25 * g.O + (size_t)g.H * g.W + (size_t)(g.OH / 2) * (g.OW / 2) * 26 + 256) * sizeof(float);
     return !off && m->precision == ADN_PRECISION_BF16 && g.C == 1 && g.k == 5 && g.O % 4 == 0 && g.O <= 256 && g.OH % 2 == 0 && g.OW % 2 == 0 &&
-           (g.OH / 2) * (g.OW / 2) <= 1024;
+           lds <= 65536;
 }
 
 int conv_fwd(adn_cae* m, const float* x, const ConvGeom& g, int B, float* cols, size_t W, size_t b, float* y, bool preact = false) {

@@ -6,6 +6,7 @@
     majority votes, gradients 2e-4 of scale against the fp64 oracle) at the real AVLetters widths, and a three-step Adam
     trajectory against the oracle on a small graph."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -207,7 +208,7 @@ def test_x3_weight_stationary_lstm_kernels_match_the_fp32_step_kernels(torch_cud
         fam0 = _families(lib)
         res[mode] = (m.predict(xs, mask, theta), m.compute_grads(xs, y, mask, theta), m.get_grads_dict())
         fam = _families(lib) - fam0
-        import os                                            # (the diagnostic switches of profiles/scripts/envmatrix.sh turn families off)
+        # (the diagnostic switches of profiles/scripts/envmatrix.sh turn families off)
         fwd_ws = mode == "cluster" and B <= 700 and not (H > 256 and os.environ.get("ADN_LSTM_NO_X3_WIDE"))
         bwd_ws = fwd_ws and not os.environ.get("ADN_LSTM_NO_X3_CLUSTER_BWD")
         assert (fam[3] > 0 and fam[0] == 0) if fwd_ws else (fam[3] == 0 and fam[0] > 0)       # the weight-stationary kernels did run
