@@ -186,13 +186,13 @@ def _small_x3_model(lstm_size, peepholes, seed, dims=(60, 44)):
 @pytest.mark.parametrize("H,B,T,peep", [(250, 70, 9, False), (250, 33, 2, True), (100, 5, 1, False), (64, 100, 12, True),
                                         (256, 32, 5, False), (17, 40, 7, True), (32, 2100, 3, False),
                                         (300, 70, 9, True), (512, 50, 5, False), (500, 100, 12, True), (257, 48, 1, False),
-                                        (400, 49, 2, True), (384, 800, 3, False)])
+                                        (400, 49, 2, True), (384, 800, 3, False), (512, 520, 40, True)])
 def test_x3_weight_stationary_lstm_kernels_match_the_fp32_step_kernels(torch_cuda, lib, monkeypatch, H, B, T, peep):
     """lstm_{fwd,bwd}_cluster_x3_kernel (csrc/lstm_cluster.hip) against the fp32 step kernels the mode falls back to
     (ADN_LSTM_NO_X3_CLUSTER): ragged masks, partial 32-row groups, padded hidden sizes, peepholes, T = 1 / 2, backwards LSTMs
     (the aggregation pair); B = 2100 does not fit one resident launch (66 groups x 4 workgroups > 256 CUs): both runs then take
     the step kernels.  256 < H <= 512: the wide forward kernel (16 workgroups per 48-utterance group; B = 800 does not fit) with
-    the fp32 step kernels behind it in the backward pass.  h travels with a 16-bit significand between the workgroups: probabilities to 5e-6, gradients to
+    the fp32 step kernels it is compared with; (512, 520, 40): configs[4]'s LSTM geometry at full size (11 groups x 16 workgroups, 40 steps).  h travels with a 16-bit significand between the workgroups: probabilities to 5e-6, gradients to
     3e-4 of each tensor's scale (measured <= 1e-6 / 6e-5 with the recurrent weights scaled up 3 x; the bf16 mode's gates are 5e-3)."""
     spec, p, m, rng = _small_x3_model(H, peep, 100 * H + B + T)
     theta = min(9, 2 * T + 1) if T > 1 else 3
@@ -219,10 +219,17 @@ def test_x3_weight_stationary_lstm_kernels_match_the_fp32_step_kernels(torch_cud
     gscale = max(np.abs(v).max() for v in res["steps"][2].values())
     worst = max(np.abs(res["cluster"][2][k] - g).max() / max(np.abs(g).max(), 1e-3 * gscale) for k, g in res["steps"][2].items())
     print("x3 cluster vs step kernels, H=%d B=%d T=%d peep=%d: max |dp| %.1e, loss %.1e, worst gradient tensor %.1e" % (H, B, T, peep, dp, dl, worst))
-    assert dp <= 5e-6 and dl <= 2e-6
+    # T = 40 with these 3 x scaled recurrent weights amplifies every rounding step after step: the fp32 step kernels are 2e-5 from the
+    # fp64 oracle there, the 16-bit-significand exchange 4e-5 ... 1e-4, narrow and wide kernels alike (profiles/scripts/x3_scale_check.py);
+    # the long case checks the full-size geometry (11 groups x 16 workgroups x 40 steps), not the last digits
+    p_tol, l_tol, g_tol = (5e-6, 2e-6, 3e-4) if T <= 12 else (3e-4, 1e-4, 1.5e-2)
+    assert dp <= p_tol and dl <= l_tol
     for k, g in res["steps"][2].items():
         e = np.abs(res["cluster"][2][k] - g).max() / max(np.abs(g).max(), 1e-3 * gscale)
-        assert e <= 3e-4, (k, e)
+        assert e <= g_tol, (k, e)
+    if B * T > 5000:                                     # (BASELINE configs[4]'s LSTM geometry at full size: kernel against kernel only)
+        m.close()
+        return
     # and against the fp64 oracle: the mode's parity gate on this graph
     p64 = {k: v.astype(np.float64) for k, v in p.items()}
     probs_ref = O.forward(spec, p64, [x.astype(np.float64) for x in xs], mask, theta)
