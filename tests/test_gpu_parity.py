@@ -889,3 +889,32 @@ def test_pingpong_gemm_bf16_output_edges(torch_cuda, lib, N):
     want16 = torch.tensor(out[:M, :N]).bfloat16().float().numpy()
     np.testing.assert_array_equal(out16[:M, :N], want16)                 # the bf16 copy is the rounding of the fp32 result, everywhere
     assert (out16[:M, N:] == 3.0).all() and (out16[M:] == 3.0).all()
+
+
+@pytest.mark.parametrize("M,N,K", [(40001, 300, 152), (33000, 2500, 150), (70000, 260, 25), (36000, 1000, 256)])
+def test_a_stationary_nt_gemm_against_the_fp64_product(torch_cuda, lib, M, N, K):
+    """gemm_bf16_nt_astat_kernel (csrc/gemm_bf16.hip: short K, bf16-only output, very many rows -- the conv auto-encoder's
+    patch-gradient products): C16 = A16 . B16^T against the fp64 product of the bf16 operands, rounded to bfloat16; M not a
+    multiple of the 64 / 128-row workgroups, N not a multiple of the 64-column chunks nor of 4 x 16, K with a masked tail inside
+    an 8-element piece (150), K = 25 (one k-step), K = 256 (the limit); operand pad columns full of 1e30, output pad columns and the
+    rows behind M untouched.  (ADN_GEMM_NO_ASTAT=1 sends the same call to the register-staged kernel.)"""
+    torch = torch_cuda
+    from ip_avsr_amd import _lib as L
+    rng = np.random.default_rng(M + N + K)
+    lda = (K + 7) // 8 * 8
+    ldc = (N + 7) // 8 * 8 + 8
+    A = np.zeros((M, lda), np.float32); A[:, :K] = rng.normal(size=(M, K))
+    Bm = np.zeros((N, lda), np.float32); Bm[:, :K] = rng.normal(size=(N, K))
+    if lda > K:                                       # what sits in the pad columns must not matter
+        A[:, K:] = 1e30; Bm[:, K:] = -1e30
+    a16 = torch.tensor(A, device="cuda").bfloat16().contiguous()
+    b16 = torch.tensor(Bm, device="cuda").bfloat16().contiguous()
+    ref = a16[:, :K].double().cpu().numpy() @ b16[:, :K].double().cpu().numpy().T
+    want = torch.tensor(ref).bfloat16().float().numpy()
+    c16 = torch.full((M + 2, ldc), 3.0, device="cuda", dtype=torch.bfloat16)
+    L.check(lib.adn_op_gemm_shadow(1, M, N, K, dptr(a16), lda, dptr(b16), lda, None, ldc, dptr(a16), dptr(b16), dptr(c16), 0, None))
+    torch.cuda.synchronize()
+    out = c16.float().cpu().numpy()
+    # one bfloat16 ulp of slack: fp32 accumulation order against the fp64 product
+    assert (np.abs(out[:M, :N] - want) <= np.abs(want) * 2.0 ** -7 + 1e-2).all()
+    assert (out[:M, N:] == 3.0).all() and (out[M:] == 3.0).all()
