@@ -154,9 +154,11 @@ __global__ __launch_bounds__(256) void conv1_direct_dw_kernel(const float* __res
 }
 
 // 64 outputs per workgroup x 4 slot quarters: a thread adds its quarter's slots in order, the quarters are added in order
-// (elements [0, nW) of a slot belong to dW, [nW, n) -- the fused form's bias sums -- to db)
+// (elements [0, nW) of a slot belong to dW, [nW, nW + nb) -- the fused forms' bias sums -- to db, the rest -- the column sums of an
+//  input gradient, i.e. the NEXT layer's bias gradient -- to dc)
 __global__ __launch_bounds__(256) void conv1_direct_dw_reduce_kernel(const float* __restrict__ slots, int nslots, int n, float* __restrict__ dW,
-                                                                     int nW, float* __restrict__ db) {
+                                                                     int nW, float* __restrict__ db, int nb = 1 << 30,
+                                                                     float* __restrict__ dc = nullptr) {
     __shared__ float part[4][64];
     const int o = threadIdx.x & 63, q = threadIdx.x >> 6, e = blockIdx.x * 64 + o;
     const int per = (nslots + 3) / 4;
@@ -168,7 +170,8 @@ __global__ __launch_bounds__(256) void conv1_direct_dw_reduce_kernel(const float
     if (q == 0 && e < n) {
         const float sum = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
         if (e < nW) dW[e] += sum;                        // (the tied deconvolution adds to the same gradient)
-        else db[e - nW] += sum;
+        else if (e - nW < nb) db[e - nW] += sum;
+        else dc[e - nW - nb] += sum;
     }
 }
 
@@ -640,7 +643,8 @@ __global__ __launch_bounds__(256) void deconv1_direct_fwd_kernel(const float* __
 template <int KK>
 __global__ __launch_bounds__(256) void deconv1_direct_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                                                  const float* __restrict__ Wm, float* __restrict__ dx, float* __restrict__ slots,
-                                                                 int B, int H, int W, int O, int CH, int CW, int ph, int pw) {
+                                                                 int B, int H, int W, int O, int CH, int CW, int ph, int pw, int act_dx,
+                                                                 int want_colsum) {
     extern __shared__ float sm[];                        // Wl [KK][O] (later the block sums), img [H][W], patches [CH CW][KK + 1], bred [256]
     float* Wl = sm;
     float* img = sm + KK * O;
@@ -653,6 +657,7 @@ __global__ __launch_bounds__(256) void deconv1_direct_bwd_kernel(const float* __
 #pragma unroll
     for (int t = 0; t < KK; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     float bsum = 0.f;
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);       // column sums of the stored input gradient (want_colsum)
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         __syncthreads();
         for (int e = tid; e < H * W; e += 256) { const float v = dz[(size_t)b * H * W + e]; img[e] = v; bsum += v; }
@@ -683,6 +688,10 @@ __global__ __launch_bounds__(256) void deconv1_direct_bwd_kernel(const float* __
                     d.x += pv * w.x; d.y += pv * w.y; d.z += pv * w.z; d.w += pv * w.w;
                     acc[t].x += pv * a.x; acc[t].y += pv * a.y; acc[t].z += pv * a.z; acc[t].w += pv * a.w;
                 }
+                // x is the OUTPUT of the layer below (its activation applied): the gradient leaves multiplied by act'(x), and its
+                // column sums -- that layer's bias gradient -- are taken on the way (a separate act' pass and a column-sum pass before)
+                d.x *= cae_act_grad(act_dx, a.x); d.y *= cae_act_grad(act_dx, a.y); d.z *= cae_act_grad(act_dx, a.z); d.w *= cae_act_grad(act_dx, a.w);
+                csum.x += d.x; csum.y += d.y; csum.z += d.z; csum.w += d.w;
                 *reinterpret_cast<float4*>(dx + o) = d;
             }
         }
@@ -703,11 +712,27 @@ __global__ __launch_bounds__(256) void deconv1_direct_bwd_kernel(const float* __
     }
     bred[tid] = bsum;
     __syncthreads();
-    for (int e = tid; e < KK * O; e += 256) slots[(size_t)blockIdx.x * (KK * O + 1) + e] = Wl[e];
+    const size_t slot = (size_t)blockIdx.x * (KK * O + 1 + (want_colsum ? O : 0));
+    for (int e = tid; e < KK * O; e += 256) slots[slot + e] = Wl[e];
     if (tid == 0) {
         float v = 0.f;
         for (int k = 0; k < 256; ++k) v += bred[k];      // (thread order: fixed)
-        slots[(size_t)blockIdx.x * (KK * O + 1) + KK * O] = v;
+        slots[slot + KK * O] = v;
+    }
+    if (want_colsum) {                                   // pixel lanes in order again, into the first O words of Wl
+        __syncthreads();
+        for (int e = tid; e < O; e += 256) Wl[e] = 0.f;
+        for (int l = 0; l < lanes; ++l) {
+            __syncthreads();
+            if (pl == l) {
+                float4* r4 = reinterpret_cast<float4*>(Wl + 4 * cq);
+                float4 v = *r4;
+                v.x += csum.x; v.y += csum.y; v.z += csum.z; v.w += csum.w;
+                *r4 = v;
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < O; e += 256) slots[slot + KK * O + 1 + e] = Wl[e];
     }
 }
 
@@ -1152,20 +1177,28 @@ int deconv_fwd(adn_cae* m, const float* x, void* x16, const ConvGeom& g, int B, 
 // dz (already multiplied by act') -> db, dW (tied), dx.  up = 1: x and dx live on the compact grid; the adjoint of the 2 x 2
 // repetition is a sum, and it commutes with the products: dx = (sum4 cols') Wm, dW += (sum4 cols')^T x -- the patches are
 // summed while they are gathered (im2col `up`), both GEMMs run on a quarter of the rows
+// x_act / x_bias_grad / x_done: x is the activated output of the layer below; where this layer runs as the direct kernel, dx leaves
+// multiplied by act'(x) and its column sums go to that layer's bias gradient (*x_done = true: the caller skips both passes).
+// bias_ready: this layer's own bias gradient was added by the layer above in that way
 int deconv_bwd(adn_cae* m, const ConvGeom& g, int B, const float* x, const void* x16, const float* dz, size_t W, size_t b,
-               float* dx, int up = 0) {
+               float* dx, int up = 0, int x_act = ADN_ACT_LINEAR, float* x_bias_grad = nullptr, bool* x_done = nullptr, bool bias_ready = false) {
     const int R = (int)rows_of(g, B) / (up ? 4 : 1);
+    if (x_done) *x_done = false;
     if (!x16 && up && direct15(m, g)) {
-        const int CH = g.OH / 2, CW = g.OW / 2, nslots = std::min(B, 512), nW = 25 * g.O, n = nW + 1;
+        static const bool no_fuse = getenv("ADN_CAE_NO_FUSE15") != nullptr;      // (A/B switch)
+        const bool fuse = x_done && x_bias_grad && !no_fuse;
+        const int CH = g.OH / 2, CW = g.OW / 2, nslots = std::min(B, 512), nW = 25 * g.O, n = nW + 1 + (fuse ? g.O : 0);
         ADN_CHECK((size_t)nslots * n <= m->splitk_floats, ADN_ERR_STATE, "conv AE: slot workspace too small");
         hipLaunchKernelGGL(deconv1_direct_bwd_kernel<25>, dim3(nslots), dim3(256),
                            (size_t)(25 * g.O + g.H * g.W + CH * CW * 26 + 256) * sizeof(float), m->stream, dz, x, m->P(W), dx, m->splitk, B, g.H,
-                           g.W, g.O, CH, CW, g.ph, g.pw);
-        hipLaunchKernelGGL(conv1_direct_dw_reduce_kernel, dim3(cdiv(n, 64)), dim3(256), 0, m->stream, m->splitk, nslots, n, m->G(W), nW, m->G(b));
+                           g.W, g.O, CH, CW, g.ph, g.pw, fuse ? x_act : (int)ADN_ACT_LINEAR, fuse ? 1 : 0);
+        hipLaunchKernelGGL(conv1_direct_dw_reduce_kernel, dim3(cdiv(n, 64)), dim3(256), 0, m->stream, m->splitk, nslots, n, m->G(W), nW, m->G(b),
+                           1, fuse ? x_bias_grad : nullptr);
         ADN_HIP_CHECK(hipGetLastError());
+        if (fuse) *x_done = true;
         return ADN_OK;
     }
-    ADN_TRY(col_sum(dz, g.C, B * g.H * g.W, g.C, m->G(b), 1, m->stream));
+    if (!bias_ready) ADN_TRY(col_sum(dz, g.C, B * g.H * g.W, g.C, m->G(b), 1, m->stream));
     if (x16 && fast16(m, g)) {
         ADN_TRY(im2col16(m, dz, g, B, m->scratch, up));
         // (NN over the ping-pong kernel only where its 256-row tiles fill the device: 35840 x 152 x 2500 took 157 us on 140
@@ -1348,9 +1381,10 @@ int backward(adn_cae* m, int B) {
     const int P2 = B * m->p2h * m->p2w, P4 = B * m->p4h * m->p4w;
     // decoder
     ADN_TRY(act_backward(gA, 1, m->a15, 1, B * m->H * m->W, 1, S, s));
-    ADN_TRY(deconv_bwd(m, m->d15, B, m->a13, nullptr, gA, m->W1, m->b15, gB, 1));                  // gB = d a13 (through upscale2d14)
-    ADN_TRY(act_backward(gB, F1, m->a13, F1, B * m->d13.H * m->d13.W, F1, S, s));
-    ADN_TRY(deconv_bwd(m, m->d13, B, m->a11, m->u12_16, gB, m->W3, m->b13, gA, 1));                // gA = d a11 (through upscale2d12)
+    bool a13_done = false;                             // (the direct kernel applies act'(a13) and takes b13's gradient on the way)
+    ADN_TRY(deconv_bwd(m, m->d15, B, m->a13, nullptr, gA, m->W1, m->b15, gB, 1, S, m->G(m->b13), &a13_done));   // gB = d a13 (through upscale2d14)
+    if (!a13_done) ADN_TRY(act_backward(gB, F1, m->a13, F1, B * m->d13.H * m->d13.W, F1, S, s));
+    ADN_TRY(deconv_bwd(m, m->d13, B, m->a11, m->u12_16, gB, m->W3, m->b13, gA, 1, ADN_ACT_LINEAR, nullptr, nullptr, a13_done));   // gA = d a11 (through upscale2d12)
     ADN_TRY(act_backward(gA, F2, m->a11, F2, B * m->d11.H * m->d11.W, F2, S, s));
     ADN_TRY(deconv_bwd(m, m->d11, B, m->a9, m->a9_16, gA, m->W5, m->b11, gB));                     // gB = d a9 (as [B][flat])
     ADN_TRY(act_backward(gB, m->flat, m->a9, m->flat, B, m->flat, S, s));
