@@ -859,6 +859,7 @@ struct adn_cae {
     bool p16_dirty = true;
     bool preact3 = false;                 // last forward pass: a3 holds conv3's pre-activations (see forward())
     bool fused1 = false;                  // last forward pass: conv1 + pool2 ran fused (no a1; conv1_pool_direct_*_kernel)
+    float* cs_ws = nullptr; size_t cs_ws_floats = 0;      // per-tile column sums of a GEMM's fused bias-gradient epilogue
     char* p2_16 = nullptr;                // ... and left this bf16 copy of p2 for conv3's patch matrix
     bool p2_16_valid = false;
     bool grads_valid = false;
@@ -926,6 +927,7 @@ size_t carve(adn_cae* m, char* base, int B) {
     m->u12_16 = c.take<char>(N * m->d11.H * m->d11.W * m->F2 * 2);           // bf16 copy of a11 (the compact input of deconv2d13)
     m->t16 = c.take<char>(act * 2);
     m->p2_16 = c.take<char>(N * m->p2h * m->p2w * m->F1 * 2);
+    m->cs_ws_floats = (size_t)1 << 20; m->cs_ws = c.take<float>(m->cs_ws_floats);
     if (m->drop && m->bn_mode == 0) { m->f6d = c.take<float>(N * m->flat); m->a7d = c.take<float>(N * m->D7); }   // dropped copies of a5 / a7
     if (m->bn_mode) {                                 // BatchNorm outputs, batch statistics, workspaces
         const size_t rows[4] = {m->bn_mode == 1 ? N * m->p2h * m->p2w : rows_of(m->c1, B), m->bn_mode == 1 ? N * m->p4h * m->p4w : rows_of(m->c3, B),
@@ -1203,6 +1205,21 @@ int deconv_bwd(adn_cae* m, const ConvGeom& g, int B, const float* x, const void*
         ADN_TRY(im2col16(m, dz, g, B, m->scratch, up));
         // (NN over the ping-pong kernel only where its 256-row tiles fill the device: 35840 x 152 x 2500 took 157 us on 140
         //  tiles against ~110 on the register-staged kernel, 15360 x 200 x 1368 68 against 37)
+        // dx = d (this layer's input) = d (the activated output of the layer below): where the register-staged kernel runs it,
+        // its epilogue multiplies by act'(x) and sums the columns -- that layer's bias gradient -- in the same pass
+        static const bool no_epi = getenv("ADN_CAE_NO_DX_EPILOGUE") != nullptr;      // (A/B switch)
+        if (x_done && x_bias_grad && !no_epi && R < 65536 && x_act != ADN_ACT_LINEAR) {
+            GemmArgs q;
+            q.layout = GEMM_NN; q.M = R; q.N = g.O; q.K = g.K; q.lda = g.ldk; q.ldb = g.O; q.C = dx; q.ldc = g.O;
+            q.A = reinterpret_cast<const float*>(m->scratch); q.B = reinterpret_cast<const float*>(W16(m, W));
+            q.A16 = m->scratch; q.B16 = W16(m, W); q.precision = ADN_PRECISION_BF16;
+            q.Y = x; q.ldy = g.O; q.act_grad = x_act;
+            int fused = 0;
+            q.colsum = x_bias_grad; q.colsum_done = &fused; q.colsum_ws = m->cs_ws; q.colsum_ws_floats = m->cs_ws_floats;
+            ADN_TRY(gemm(q, m->stream));
+            if (!fused) ADN_TRY(col_sum(dx, g.O, R, g.O, x_bias_grad, 1, m->stream));
+            *x_done = true;
+        } else
         ADN_TRY(mm16(m, GEMM_NN, R, g.O, g.K, m->scratch, g.ldk, W16(m, W), g.O, dx, g.O, nullptr, ADN_ACT_LINEAR, 0, R >= 65536));
         return mm16(m, GEMM_TN, g.K, g.O, R, m->scratch, g.ldk, x16, g.O, m->G(W), g.O, nullptr, ADN_ACT_LINEAR, 1, true);
     }
@@ -1384,9 +1401,10 @@ int backward(adn_cae* m, int B) {
     bool a13_done = false;                             // (the direct kernel applies act'(a13) and takes b13's gradient on the way)
     ADN_TRY(deconv_bwd(m, m->d15, B, m->a13, nullptr, gA, m->W1, m->b15, gB, 1, S, m->G(m->b13), &a13_done));   // gB = d a13 (through upscale2d14)
     if (!a13_done) ADN_TRY(act_backward(gB, F1, m->a13, F1, B * m->d13.H * m->d13.W, F1, S, s));
-    ADN_TRY(deconv_bwd(m, m->d13, B, m->a11, m->u12_16, gB, m->W3, m->b13, gA, 1, ADN_ACT_LINEAR, nullptr, nullptr, a13_done));   // gA = d a11 (through upscale2d12)
-    ADN_TRY(act_backward(gA, F2, m->a11, F2, B * m->d11.H * m->d11.W, F2, S, s));
-    ADN_TRY(deconv_bwd(m, m->d11, B, m->a9, m->a9_16, gA, m->W5, m->b11, gB));                     // gB = d a9 (as [B][flat])
+    bool a11_done = false;
+    ADN_TRY(deconv_bwd(m, m->d13, B, m->a11, m->u12_16, gB, m->W3, m->b13, gA, 1, S, m->G(m->b11), &a11_done, a13_done));   // gA = d a11 (through upscale2d12)
+    if (!a11_done) ADN_TRY(act_backward(gA, F2, m->a11, F2, B * m->d11.H * m->d11.W, F2, S, s));
+    ADN_TRY(deconv_bwd(m, m->d11, B, m->a9, m->a9_16, gA, m->W5, m->b11, gB, 0, ADN_ACT_LINEAR, nullptr, nullptr, a11_done));   // gB = d a9 (as [B][flat])
     ADN_TRY(act_backward(gB, m->flat, m->a9, m->flat, B, m->flat, S, s));
     ADN_TRY(col_sum(gB, m->flat, B, m->flat, m->G(m->b9), 1, s));
     ADN_TRY(mm(m, GEMM_TN, m->flat, m->D7, B, gB, m->flat, m->a8, m->D7, m->G(m->W7), m->D7, nullptr, ADN_ACT_LINEAR, 1));

@@ -9,7 +9,7 @@ for e in "X=1" "ADN_X3_NO_PLANES=1" "ADN_X3_NO_LEAN=1" "ADN_LSTM_DG_FP32=1" "ADN
   env $e python -m pytest tests/test_gpu_bf16x3.py tests/test_gpu_fuzz.py -q -x -k "x3 or bf16x3" 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -2
 done
 # the conv auto-encoder's tests under its round-4 A/B switches
-for e in "X=1" "ADN_CAE_POOL_BWD_FULL=1" "ADN_CAE_FP32_SCRATCH=1" "ADN_CAE_NO_PP=1" "ADN_CAE_NO_PREACT=1" "ADN_CAE_IM2COL_GENERIC=1" "ADN_CAE_NO_DIRECT1=1" "ADN_CAE_NO_FUSE1=1" "ADN_CAE_NO_DIRECT15=1" "ADN_CAE_NO_FUSE15=1" "ADN_GEMM_NO_ASTAT=1" "ADN_DETERMINISTIC=1"; do
+for e in "X=1" "ADN_CAE_POOL_BWD_FULL=1" "ADN_CAE_FP32_SCRATCH=1" "ADN_CAE_NO_PP=1" "ADN_CAE_NO_PREACT=1" "ADN_CAE_IM2COL_GENERIC=1" "ADN_CAE_NO_DIRECT1=1" "ADN_CAE_NO_FUSE1=1" "ADN_CAE_NO_DIRECT15=1" "ADN_CAE_NO_FUSE15=1" "ADN_CAE_NO_DX_EPILOGUE=1" "ADN_GEMM_NO_ASTAT=1" "ADN_DETERMINISTIC=1"; do
   echo "=== conv AE: $e"
   env $e python -m pytest tests/test_gpu_convae.py -q -x 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -2
 done
