@@ -61,11 +61,15 @@ typedef enum {
     ADN_PRECISION_F32 = 0, /* exact fp32 on the f32 MFMA pipe (parity-grade; all parity tests run in it) */
     ADN_PRECISION_BF16 = 1, /* GEMM operands rounded to bf16 (RNE) in flight, fp32 accumulate, fp32 master
                               weights / activations / recurrence / optimiser (BASELINE configs[1]: bf16) */
-    ADN_PRECISION_BF16X3 = 2 /* fp32 everywhere like ADN_PRECISION_F32, but every large GEMM runs as three bf16 MFMA
+    ADN_PRECISION_BF16X3 = 2, /* fp32 everywhere like ADN_PRECISION_F32, but every large GEMM runs as three bf16 MFMA
                               products of the operands' bf16 hi / lo parts (a_hi b_hi + a_hi b_lo + a_lo b_hi, fp32
                               accumulate: ~4e-6 relative, inside the 1e-4 parity gate) at the bf16 matrix rate; the
                               recurrent products likewise, in weight-stationary kernels, for LSTMs of <= 256 units
                               (wider ones run the fp32 per-step kernels) */
+    ADN_PRECISION_MIXED = 3 /* ADN_PRECISION_BF16X3 for everything the forward pass computes (activations, probabilities,
+                              votes: the same bits) and for the recurrent kernels; the GEMMs of back-propagation run ONE bf16
+                              product over the operands' hi planes (gradients of bf16 grade, as in ADN_PRECISION_BF16).  Not a
+                              parity mode for gradients: reported under its own name, never as bf16x3 */
 } adn_precision;
 
 enum {
@@ -170,6 +174,10 @@ int64_t adn_total_param_count(const adn_model* m); /* logical elements (17 999 6
  * tail float of the gradient buffer holds this call's share of the cost, so ONE all-reduce sums the
  * gradients and the cost together. */
 int adn_flat_buffer(adn_model* m, int buffer /*adn_buffer*/, void** device_ptr, size_t* bytes);
+/* The same address for a caller that only READS the buffer (a device-side snapshot of the parameters: what the epoch drivers
+ * keep as "best parameters so far", runners/3stream.py:393): unlike adn_flat_buffer(ADN_BUF_PARAM, ...) it does not mark the
+ * parameters as written, so the bf16 copies / planes / MFMA-fragment images derived from them are not re-made. */
+int adn_flat_buffer_const(const adn_model* m, int buffer /*adn_buffer*/, const void** device_ptr, size_t* bytes);
 
 /* Gradient buckets for overlapping the data-parallel all-reduce with back-propagation (new; the reference is
  * single-device).  Listed in the order they become final: bucket 0 = [fusion | aggregation LSTMs | classifier |

@@ -18,7 +18,7 @@ ADN_OK, ADN_ERR_INVALID, ADN_ERR_HIP, ADN_ERR_NO_DEVICE, ADN_ERR_STATE = 0, 1, 2
 ACT = {"linear": 0, "identity": 0, "rectify": 1, "sigmoid": 2, "tanh": 3, "leaky_rectify": 4,
        "very_leaky_rectify": 5, "scaled_tanh": 6, "scaled_tanh_lecun": 7}
 FUSION = {"none": 0, "sum": 1, "adasum": 2, "concat": 3}
-PRECISION = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "bf16x3": 2}
+PRECISION = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "bf16x3": 2, "mixed": 3}
 FLAG_DEVICE_INPUTS = 1
 FLAG_STOCHASTIC = 4
 FLAG_DETERMINISTIC = 8
@@ -88,6 +88,7 @@ _SIGNATURES = {
     "adn_write_tensor": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "adn_total_param_count": (C.c_int64, [_P]),
     "adn_flat_buffer": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "adn_flat_buffer_const": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "adn_grad_buckets": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     "adn_set_bucket_events": (C.c_int, [_P, C.POINTER(_P), C.c_int]),
     "adn_forward": (C.c_int, [_P, C.POINTER(_P), _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

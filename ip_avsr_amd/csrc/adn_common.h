@@ -118,6 +118,8 @@ struct GemmArgs {
     // ... and the result's own planes: C16 (hi) and C16lo, written by the kernel that multiplies over planes; *planes_done reports
     // whether they were (otherwise the caller splits C itself)
     void* C16lo = nullptr; int* planes_done = nullptr;
+    int hi_product = 0;                // ADN_PRECISION_MIXED, back-propagation: ONE bf16 product over the hi planes (A16 / B16 given,
+                                       // no lo planes, precision = bf16) whose result is still offered as planes (C16 / C16lo, lean_ok)
     int b_pad_zero = 0;                // the columns of B behind N (up to ldb) hold zeros: a kernel may then compute (and write zeros
                                        // into) the pad columns of C up to round_up(N, 4)
     int* fp32_skipped = nullptr;       // (out) lean_ok was used: C was NOT written, the result lives in its planes only

@@ -16,6 +16,7 @@
 // that the epilogue drops, so their loads are merely clamped in-bounds); only the last partial k-stage pays
 // for zero-filling.  Register prefetch of stage s+1 overlaps the MFMAs of stage s.
 #include "gemm_common.h"
+#include "pp_dma.h"
 #include <algorithm>
 #include <type_traits>
 
@@ -608,8 +609,6 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_kernel(const GemmParams pi
 // share one tile list, which fills the last round of 256 CUs far better than each alone (656 tiles = 2.56 rounds;
 // 3 x 656 = 7.7).
 // ---------------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void lds_void_t;
-
 // ring depth: 4 stages (128 KB of LDS), three in flight.  -DADN_PP_NS=5 (all 160 KB, four in flight) measured no faster on any
 // shape of profiles/gemm_lab: the K-step is not bound by the DMA latency
 #ifndef ADN_PP_NS
@@ -617,56 +616,8 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 #endif
 constexpr int kPpBK = 32, kPpNS = ADN_PP_NS, kPpD = ADN_PP_NS - 1;
 
-// One LDS-DMA wave-instruction: lane l fetches 16 bytes from its own global address into LDS byte address
-// lds_dst + 16 l (lds_dst wave-uniform, in an SGPR).  Inline asm on purpose: hipcc orders every ds_read behind a
-// pending __builtin_amdgcn_global_load_lds with s_waitcnt vmcnt(0), which would drain the stages this kernel keeps in
-// flight; the waits are counted by hand instead.  M0 (the DMA destination base) is compiler-reserved, hence saved and
-// restored (cdna_hip_programming.md, LDS-DMA recipe).
-__device__ __forceinline__ void glds16(const void* g, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g), "s"(lds_dst) : "memory");
-}
-// the same with the address split into a wave-uniform 64-bit base (SGPR pair) and a 32-bit per-lane byte offset: a K-step then
-// advances ONE scalar per operand instead of a 64-bit VGPR pointer per piece.  LDS destination = lds_dst + IMM.
-template <int IMM> __device__ __forceinline__ void glds16_s(unsigned off, const char* base, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %3, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(off), "s"(base), "s"(lds_dst), "n"(IMM) : "memory", "scc");
-}
-
-// the four-wave kernel's form: its base may arrive through v_readfirstlane right ahead of the statement (VALU-written SGPR ->
-// VMEM reading it as its scalar base: 5 wait states; the two SALU instructions and the nop make them up)
-template <int IMM> __device__ __forceinline__ void glds16_su(unsigned off, const char* base, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_add_u32 m0, %3, %4\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(off), "s"(base), "s"(lds_dst), "n"(IMM) : "memory", "scc");
-}
-
 __device__ __forceinline__ int swz_g(int kr) { return (kr & 3) | (((kr >> 3) & 1) << 2); }
 __device__ __forceinline__ int swz_f(int q) { return (0x1320 >> (4 * q)) & 3; }     // {0, 2, 3, 1}
-
-// group `g` of a grouped launch by value (explicit selects: a dynamic index into the kernel-argument block makes hipcc
-// copy the whole block to scratch, and scratch traffic would sit in the vmcnt queue this kernel counts by hand)
-__device__ __forceinline__ GemmGroup pick_group(const GemmParams& p, int g) {
-    GemmGroup r = p.grp[0];
-    if (g == 1) r = p.grp[1];
-    if (g == 2) r = p.grp[2];
-    if (g == 3) r = p.grp[3];
-    return r;
-}
-
-// a wave-uniform pointer the compiler may have parked in VGPRs, back in an SGPR pair (asm "s" operands)
-__device__ __forceinline__ const char* uniform_ptr(const char* p) {
-    const uint64_t v = (uint64_t)(uintptr_t)p;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return (const char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
-}
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N >= 0 && N <= 63, "vmcnt immediate");
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
-}
 
 // one float4 of the transposed-accumulator epilogue: 4 consecutive columns of one row.  ONE body for every flag
 // combination the host routes here (linear / rectify output, optional rectify'(Y) mask from the bf16 copy of Y,
@@ -1586,6 +1537,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
     }
 }
 
+void launch_splitk_reduce(const GemmParams& p, int splits, hipStream_t s) {
+    const size_t n4 = (size_t)p.M * (p.N / 4);
+    const int blocks = (int)std::min<size_t>(2048, (n4 + 255) / 256);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p, splits);
+}
+
 template <int BM, int BN, bool PLANES>
 static void launch_pp_t(const GemmParams& p, int layout, bool split, dim3 grid, hipStream_t s) {
     if (layout == GEMM_NN) {
@@ -1614,11 +1571,7 @@ void launch_gemm_bf16_pp(const GemmParams& p, int layout, int tile_mode, int spl
     else if (tile_mode == 5) launch_pp_t<256, 128, true>(p, layout, split, grid, s);      // (diagnostic tile shapes: the general form only)
     else launch_pp_t<128, 256, true>(p, layout, split, grid, s);
 #endif
-    if (split) {
-        const size_t n4 = (size_t)p.M * (p.N / 4);
-        const int blocks = (int)std::min<size_t>(2048, (n4 + 255) / 256);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p, splits);
-    }
+    if (split) launch_splitk_reduce(p, splits, s);
 }
 
 template <int BM, int BN, int WM, typename T>
@@ -1645,6 +1598,7 @@ template <int KS, int RB>                        // k-steps (K <= 32 KS), 16-row
 __global__ __launch_bounds__(256) void gemm_bf16_nt_astat_kernel(const __bf16* __restrict__ A, int lda, const __bf16* __restrict__ B, int ldb,
                                                                  __bf16* __restrict__ C, int ldc, int M, int N, int K) {
     constexpr int LS = 32 * KS + 8;               // LDS row stride of a B chunk (bf16): [64 columns][LS]
+    static_assert(2 * kAsCols * LS * 2 <= 160 * 1024, "gemm_bf16_nt_astat_kernel: the two B chunks need gfx950's 160 KB of LDS (KS = 8: 66 KB)");
     __shared__ __attribute__((aligned(16))) __bf16 bs[2][kAsCols][LS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, kq = lane >> 4;

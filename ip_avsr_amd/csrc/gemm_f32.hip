@@ -183,6 +183,23 @@ static int device_cus() {
 // dry: only answer whether the kernel WOULD take the launch (no side effects)
 constexpr int kDefaultPpMode = 4;       // tile mode the selection uses unless ADN_GEMM_PP forces one (4: eight waves, 7: four waves)
 static int gemm_pp_try_impl(const GemmArgs* gs, int n, const GemmArgs& g, int kseg, hipStream_t stream, bool* used, bool dry);
+// bf16x3 over planes: the fused-plane kernel (gemm_x3f.hip: the four planes of a 16-k unit staged once, three products from four
+// fragment sets) instead of the ping-pong kernel's three K-segments.  Measured (profiles/r05/lab_x3f.txt, MI355X): a third less
+// LDS-DMA and fragment traffic per flop buys nothing in wall time on the NN shapes (0.97 - 1.00 x: the chip holds ~1.5 GHz under
+// either kernel -- both are bound by the energy of their MFMAs, and the 32x32x16 shape the 16-k unit needs holds a lower clock
+// than 16x16x32, MI355X_MICROARCH.md 'DVFS give-back' item 7) and 2 - 7 % on the weight gradients (TN), where it also takes any K
+// (the three-segment walk needs K % 32 == 0).  Default: TN over planes.  ADN_GEMM_NO_X3F=1: never; ADN_GEMM_X3F=all: NN too
+static bool x3f_enabled() {
+    static const bool off = getenv("ADN_GEMM_NO_X3F") != nullptr;
+    return !off;
+}
+// the tile mode a product over planes runs in: 8 = fused-plane kernel, otherwise the ping-pong kernel's (forced or default) mode
+static int planes_tile_mode(int layout, int mode_env, int default_mode) {
+    static const bool all = getenv("ADN_GEMM_X3F") && !strcmp(getenv("ADN_GEMM_X3F"), "all");
+    if (mode_env >= 4) return (mode_env == 8 && !x3f_enabled()) ? default_mode : mode_env;
+    return (x3f_enabled() && (all || layout == GEMM_TN)) ? 8 : default_mode;
+}
+void launch_gemm_x3f(const GemmParams& p, int layout, bool planes, int splits, dim3 grid, hipStream_t s);      // gemm_x3f.hip
 static int gemm_pp_try(const GemmArgs* gs0, int n, hipStream_t stream, bool* used, bool dry = false) {
     *used = false;
     if (n < 1 || n > kMaxGemmGroups) return ADN_OK;
@@ -212,7 +229,8 @@ static int gemm_pp_try(const GemmArgs* gs0, int n, hipStream_t stream, bool* use
         // (NN: the partial last stage of a segment is masked in the A fragments -- the columns of A behind K may hold anything;
         //  the k-strided B is then read up to 31 rows past K: finite values of the next tensor or zero slack, times zero.
         //  TN: both operands are k-strided and neither is masked: K % 32 == 0 there, or the image path)
-        if (g.layout != GEMM_NN && g.K % 32 != 0) return ADN_OK;
+        // (the fused-plane kernel masks its A fragments in both layouts and clamps the k-rows it fetches: any K)
+        if (g.layout != GEMM_NN && g.K % 32 != 0 && planes_tile_mode(g.layout, mode_env, kDefaultPpMode) != 8) return ADN_OK;
         if (mode_env == 7) return ADN_OK;         // (the experimental four-wave kernel has no segment cursors)
     }
     GemmArgs gv = g;                              // the problem the tile / split heuristics see: K = all three segments
@@ -242,7 +260,7 @@ static int gemm_pp_try_impl(const GemmArgs* gs, int n, const GemmArgs& g, int ks
         if ((q.Y && ((uintptr_t)q.Y % 16)) || (q.Y16 && ((uintptr_t)q.Y16 % 8)) || (q.bias && ((uintptr_t)q.bias % 16))) return ADN_OK;
         if ((q.A16lo == nullptr) != (gs[0].A16lo == nullptr) || (q.B16lo == nullptr) != (gs[0].B16lo == nullptr)) return ADN_OK;
         if (q.M != g.M || q.N != g.N || q.K != gs[0].K || q.lda != g.lda || q.ldb != g.ldb || q.ldc != g.ldc || q.ldy != g.ldy ||
-            q.layout != g.layout || q.act != g.act || q.act_grad != g.act_grad || q.accumulate != g.accumulate ||
+            q.layout != g.layout || q.act != g.act || q.act_grad != g.act_grad || q.accumulate != g.accumulate || q.hi_product != g.hi_product ||
             q.no_split != g.no_split || q.pp_force != g.pp_force || (q.C == nullptr) != (g.C == nullptr) || (q.C16 == nullptr) != (g.C16 == nullptr) ||
             (q.bias == nullptr) != (g.bias == nullptr) || (q.Y16 == nullptr) != (g.Y16 == nullptr) ||
             (q.Y == nullptr) != (g.Y == nullptr) || (q.colsum == nullptr) != (g.colsum == nullptr))
@@ -263,15 +281,16 @@ static int gemm_pp_try_impl(const GemmArgs* gs, int n, const GemmArgs& g, int ks
     //     row pieces (205 against 146 us), and not 128-wide tiles (445 TFLOP/s: B-fragment reads per flop double)
     struct Cand { int mode, bm, bn; double rate; int wave_rows; };
     // mode 7: the four-wave kernel (128 x 128 per wave); ADN_GEMM_PP=4 forces the eight-wave kernel
-    static const Cand cands[4] = {{7, 256, 256, 1.0, 2}, {4, 256, 256, 1.0, 4}, {5, 256, 128, 0.70, 4}, {6, 128, 256, 0.70, 4}};
+    // mode 8: the fused-plane kernel (gemm_x3f.hip) -- the default over planes; ADN_GEMM_PP=8 also sends plain bf16 products to it
+    static const Cand cands[5] = {{7, 256, 256, 1.0, 2}, {4, 256, 256, 1.0, 4}, {5, 256, 128, 0.70, 4}, {6, 128, 256, 0.70, 4}, {8, 256, 256, 1.0, 4}};
+    const int want_mode = kseg ? planes_tile_mode(g.layout, mode_env, kDefaultPpMode) : (mode_env >= 4 ? mode_env : kDefaultPpMode);
     int best = -1, splits = 1; double best_cost = 0;
-    for (int c = 0; c < 4; ++c) {
-        if (mode_env >= 4 && cands[c].mode != mode_env) continue;
-        if (mode_env < 4 && cands[c].mode != kDefaultPpMode) continue;
+    for (int c = 0; c < 5; ++c) {
+        if (cands[c].mode != want_mode) continue;
         const int64_t tiles = (int64_t)cdiv(g.M, cands[c].bm) * cdiv(g.N, cands[c].bn) * n;
         int sp = 1;
         if (tiles * 2 <= cus && can_split && g.K >= 2048) {
-            if (cands[c].mode != 4 && cands[c].mode != 7) continue;
+            if (cands[c].mode != 4 && cands[c].mode != 7 && cands[c].mode != 8) continue;
             sp = (int)std::min<int64_t>(cus / tiles, g.K / 512);
         }
         const int64_t rounds = (tiles * sp + cus - 1) / cus;
@@ -308,8 +327,10 @@ static int gemm_pp_try_impl(const GemmArgs* gs, int n, const GemmArgs& g, int ks
     p.one_barrier = 1;
     p.kseg = kseg; p.kreal = gs[0].K;
     p.tiles_m = cdiv(g.M, cd.bm); p.tiles_n = cdiv(g.N, cd.bn);
-    p.k_chunk = (int)round_up(cdiv(g.K, splits), 32);
-    splits = cdiv(g.K, p.k_chunk);
+    const bool fused = cd.mode == 8;
+    if (fused) { p.K = kseg ? gs[0].K : g.K; p.kseg = 0; }       // the fused kernel walks the real K once
+    p.k_chunk = (int)round_up(cdiv(p.K, splits), 32);
+    splits = cdiv(p.K, p.k_chunk);
     p.ngroups = n;
     const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n * n;
     const int cs_ld = (int)round_up(g.N, 4);
@@ -330,7 +351,7 @@ static int gemm_pp_try_impl(const GemmArgs* gs, int n, const GemmArgs& g, int ks
         GemmGroup& q = p.grp[k];
         q.A16 = gs[k].A16; q.B16 = gs[k].B16; q.C = gs[k].C; q.C16 = splits > 1 ? nullptr : gs[k].C16;
         q.A16lo = kseg ? gs[k].A16lo : nullptr; q.B16lo = kseg ? gs[k].B16lo : nullptr;
-        q.C16lo = (kseg && splits == 1 && q.C16) ? gs[k].C16lo : nullptr;
+        q.C16lo = ((kseg || gs[k].hi_product) && splits == 1 && q.C16) ? gs[k].C16lo : nullptr;
         if (gs[k].planes_done) *gs[k].planes_done = q.C16lo ? 1 : 0;
         // (planes: the fp32 copy of a result every reader takes from its planes is not written -- unless the bias gradient
         //  that rides on this launch could not be fused and will be summed from the fp32 values)
@@ -357,11 +378,12 @@ static int gemm_pp_try_impl(const GemmArgs* gs, int n, const GemmArgs& g, int ks
     if (trace)
         fprintf(stderr, "ADN_GEMM %s M=%d N=%d K=%d tile=%d tiles=%lld split=%d shadows=1 lean=%d acc=%d groups=%d%s\n",
                 g.layout == GEMM_NN ? "NN" : "TN", g.M, g.N, g.K, cd.bm * 1000 + cd.bn, (long long)tiles, splits, (int)lean_c,
-                g.accumulate, n, kseg ? " planes=1" : "");
+                g.accumulate, n, kseg ? (fused ? " planes=1 fused=1" : " planes=1") : (fused ? " fused=1" : ""));
     {
         ProfScope prof(PROF_GEMM_NN + g.layout, 2.0 * g.M * g.N * g.K * n,
                        4.0 * n * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N), stream, n);
-        launch_gemm_bf16_pp(p, g.layout, cd.mode, splits, dim3((unsigned)gx, (unsigned)splits), stream);
+        if (fused) launch_gemm_x3f(p, g.layout, kseg != 0, splits, dim3((unsigned)gx, (unsigned)splits), stream);
+        else launch_gemm_bf16_pp(p, g.layout, cd.mode, splits, dim3((unsigned)gx, (unsigned)splits), stream);
         ADN_HIP_CHECK(hipGetLastError());
     }
     for (int k = 0; k < n; ++k) {

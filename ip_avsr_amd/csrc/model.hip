@@ -251,6 +251,9 @@ struct adn_model {
     TransposeItem* transw_items_lo = nullptr;   // ... of the lo planes
     int transw_blocks = 0;
     bool packed_for_persistent = false;         // which LSTM weight images the last refresh produced
+    // ADN_PRECISION_MIXED: cfg.precision is ADN_PRECISION_BF16X3 and back-propagation's GEMMs take the hi planes only (m_gemm)
+    bool bwd_hi_only = false;
+    bool in_backward = false;
     bool bf16() const { return cfg.precision == ADN_PRECISION_BF16; }
     // bf16x3 mode keeps TWO bf16 planes (hi = bf16(x), lo = bf16(x - hi)) of every GEMM operand -- written once per tensor by a
     // split pass behind its producer -- and its large GEMMs run over the planes (three K-segments in the ping-pong kernel)
@@ -351,7 +354,7 @@ int validate(const adn_config& c) {
         ADN_CHECK(c.streams[k].dropout_p >= 0.f && c.streams[k].dropout_p < 1.f, ADN_ERR_INVALID,
                   "dropout probability must be in [0, 1)");
     ADN_CHECK(c.agg >= 0 && c.agg <= 2, ADN_ERR_INVALID, "agg must be 0, 1 or 2");
-    ADN_CHECK(c.precision >= ADN_PRECISION_F32 && c.precision <= ADN_PRECISION_BF16X3, ADN_ERR_INVALID,
+    ADN_CHECK(c.precision >= ADN_PRECISION_F32 && c.precision <= ADN_PRECISION_MIXED, ADN_ERR_INVALID,
               "unsupported precision");
     if (c.fusion == ADN_FUSE_NONE) ADN_CHECK(c.n_streams == 1, ADN_ERR_INVALID, "fusion 'none' needs exactly one stream");
     if (c.fusion == ADN_FUSE_CONCAT && c.n_streams > 1)
@@ -766,11 +769,16 @@ int restore_fp32(adn_model* m, const float* p) {
         }
     return ADN_OK;
 }
+static bool reads_hi_planes_only(const GemmArgs& g);
 static int operands_ready(adn_model* m, const GemmArgs* gs, int n) {
     if (m->fp32_stale.empty()) return ADN_OK;
     if (gemm_planes_would_run(gs, n)) return ADN_OK;               // the whole group reads planes
     for (int k = 0; k < n; ++k) {
         if (n > 1 && gemm_planes_would_run(&gs[k], 1)) continue;    // (a declined group is retried problem by problem)
+        if (reads_hi_planes_only(gs[k])) {                          // (every bf16 kernel reads the copies it is handed)
+            if (gs[k].Y && !gs[k].Y16) ADN_TRY(restore_fp32(m, gs[k].Y));
+            continue;
+        }
         ADN_TRY(restore_fp32(m, gs[k].A));
         ADN_TRY(restore_fp32(m, gs[k].B));
         if (gs[k].Y && !gs[k].Y16) ADN_TRY(restore_fp32(m, gs[k].Y));
@@ -784,8 +792,23 @@ static void result_written(adn_model* m, const GemmArgs& g, int skipped) {
         m->fp32_stale.push_back({g.C, (size_t)g.M * g.ldc});
     } else if (!m->fp32_stale.empty()) stale_forget(m, g.C);
 }
+// ADN_PRECISION_MIXED: a GEMM of back-propagation whose operands have their planes runs as ONE bf16 product over the hi planes
+// (= the bf16 copies of bf16 mode).  Its result is still written as two planes where the kernel can (the readers further down
+// the backward pass take planes), otherwise as fp32 + a split pass -- the bookkeeping of m_gemm() is unchanged.
+static void mixed_backward(const adn_model* m, GemmArgs& g) {
+    if (!m->bwd_hi_only || !m->in_backward || g.precision != ADN_PRECISION_BF16X3 || !g.A16 || !g.A16lo) return;
+    if (g.layout == GEMM_NT) {
+        if (!g.BT16 || !g.BT16lo) return;
+        g.layout = GEMM_NN; g.B16 = g.BT16; g.ldb = g.ldbT; g.b_pad_zero = 1;
+    } else if (!g.B16 || !g.B16lo) return;
+    g.A16lo = g.B16lo = nullptr; g.BT16 = g.BT16lo = nullptr;
+    g.precision = ADN_PRECISION_BF16; g.hi_product = 1;
+}
+static bool reads_hi_planes_only(const GemmArgs& g) { return g.hi_product && g.A16 && g.B16; }
+
 int m_gemm(adn_model* m, const GemmArgs& g0) {
     GemmArgs g = g0; int done = 0, skipped = 0;
+    mixed_backward(m, g);
     offer_output_planes(m, g, &done);
     g.fp32_skipped = &skipped;
     ADN_TRY(operands_ready(m, &g, 1));
@@ -800,7 +823,10 @@ int m_gemm_grouped(adn_model* m, const GemmArgs* gs0, int n) {
         for (int k = 0; k < n; ++k) ADN_TRY(m_gemm(m, gs0[k]));
         return ADN_OK;
     }
-    for (int k = 0; k < n; ++k) { gs[k] = gs0[k]; offer_output_planes(m, gs[k], &done[k]); skipped[k] = 0; gs[k].fp32_skipped = &skipped[k]; }
+    for (int k = 0; k < n; ++k) {
+        gs[k] = gs0[k]; mixed_backward(m, gs[k]);
+        offer_output_planes(m, gs[k], &done[k]); skipped[k] = 0; gs[k].fp32_skipped = &skipped[k];
+    }
     ADN_TRY(operands_ready(m, gs, n));
     for (int k = 0; k < n; ++k) if (gs[k].accumulate) ADN_TRY(restore_fp32(m, gs[k].C));
     ADN_TRY(gemm_grouped(gs, n, m->stream));
@@ -1620,6 +1646,7 @@ size_t bucket_count(const adn_model* m) {
 }
 
 int backward_pass(adn_model* m, int B, int T, int theta) {
+    struct InBackward { adn_model* m; explicit InBackward(adn_model* m_) : m(m_) { m->in_backward = true; } ~InBackward() { m->in_backward = false; } } in_backward(m);
     const int N = B * T, H = m->H, ldh = m->ldh;
     hipStream_t s = m->stream;
     ADN_HIP_CHECK(hipMemsetAsync(m->flat[ADN_BUF_GRAD], 0, (m->flat_floats + kAuxFloats) * sizeof(float), s));
@@ -2108,6 +2135,8 @@ int adn_create(const adn_config* cfg, adn_model** out) {
     }
     adn_model* m = new adn_model();
     m->cfg = *cfg;
+    m->bwd_hi_only = cfg->precision == ADN_PRECISION_MIXED;
+    if (m->bwd_hi_only) m->cfg.precision = ADN_PRECISION_BF16X3;
     m->S = cfg->n_streams; m->H = cfg->lstm_size; m->C = cfg->classes;
     m->ldh = ld_of(m->H); m->ldg = ld_of(4 * m->H); m->ldc = ld_of(m->C);
     int st = build_params(m);
@@ -2172,9 +2201,10 @@ int adn_set_stream(adn_model* m, void* hip_stream) {
 
 int adn_set_precision(adn_model* m, int precision) {
     ADN_CHECK(m, ADN_ERR_INVALID, "null model");
-    ADN_CHECK(precision >= ADN_PRECISION_F32 && precision <= ADN_PRECISION_BF16X3, ADN_ERR_INVALID,
+    ADN_CHECK(precision >= ADN_PRECISION_F32 && precision <= ADN_PRECISION_MIXED, ADN_ERR_INVALID,
               "unsupported precision");
-    m->cfg.precision = precision;
+    m->bwd_hi_only = precision == ADN_PRECISION_MIXED;
+    m->cfg.precision = m->bwd_hi_only ? (int)ADN_PRECISION_BF16X3 : precision;
     m->mark_params_dirty();
     m->wsB = 0;                       // input staging differs between the modes: re-carve on the next call
     return ADN_OK;
@@ -2207,6 +2237,14 @@ int adn_flat_buffer(adn_model* m, int buffer, void** device_ptr, size_t* bytes) 
     ADN_CHECK(m && device_ptr && bytes, ADN_ERR_INVALID, "null argument");
     ADN_CHECK(buffer >= 0 && buffer < 4, ADN_ERR_INVALID, "bad buffer id");
     if (buffer == ADN_BUF_PARAM) m->mark_params_dirty();      // the caller may write through the pointer
+    *device_ptr = m->flat[buffer];
+    *bytes = (m->flat_floats + kAuxFloats) * sizeof(float);
+    return ADN_OK;
+}
+
+int adn_flat_buffer_const(const adn_model* m, int buffer, const void** device_ptr, size_t* bytes) {
+    ADN_CHECK(m && device_ptr && bytes, ADN_ERR_INVALID, "null argument");
+    ADN_CHECK(buffer >= 0 && buffer < 4, ADN_ERR_INVALID, "bad buffer id");
     *device_ptr = m->flat[buffer];
     *bytes = (m->flat_floats + kAuxFloats) * sizeof(float);
     return ADN_OK;

@@ -137,7 +137,9 @@ class AdeNetModel(object):
         _lib.check(self._lib.adn_set_stream(self._handle, C.c_void_p(int(raw))))
 
     def set_precision(self, precision):
-        """'f32' (exact, parity-grade) or 'bf16' (GEMM operands rounded to bf16 in flight, fp32 accumulate)."""
+        """'f32' (exact, parity-grade), 'bf16x3' (fp32-grade products as three bf16 MFMA passes), 'mixed' (bf16x3 forward pass
+        and recurrences, ONE bf16 product per GEMM of back-propagation) or 'bf16' (GEMM operands rounded to bf16, fp32
+        accumulate)."""
         _lib.check(self._lib.adn_set_precision(self._handle, _lib.PRECISION[precision]))
         self.spec["precision"] = precision
 
@@ -253,7 +255,7 @@ class AdeNetModel(object):
         import torch
         from .parallel import wrap_flat_buffer
         self.synchronize()
-        snap = wrap_flat_buffer(self, _lib.BUF_PARAM).clone()
+        snap = wrap_flat_buffer(self, _lib.BUF_PARAM, read_only=True).clone()     # (does not dirty the derived copies)
         torch.cuda.current_stream().synchronize()
         return snap
 
@@ -268,13 +270,34 @@ class AdeNetModel(object):
         flat.copy_(snapshot)
         torch.cuda.current_stream().synchronize()
 
+    def snapshot_state(self):
+        """Parameters, Adam moments and step count as device-side copies (what ``restore_state`` needs to put the training
+        state back exactly): lets a measurement run extra steps without leaving a trace (bench.py's local-step clock)."""
+        import torch
+        from .parallel import wrap_flat_buffer
+        self.synchronize()
+        bufs = [wrap_flat_buffer(self, w, read_only=True).clone() for w in (_lib.BUF_PARAM, _lib.BUF_ADAM_M, _lib.BUF_ADAM_V)]
+        torch.cuda.current_stream().synchronize()
+        return dict(buffers=bufs, t=self.adam_step_count())
+
+    def restore_state(self, snap):
+        import torch
+        from .parallel import wrap_flat_buffer
+        self.synchronize()
+        for w, src in zip((_lib.BUF_PARAM, _lib.BUF_ADAM_M, _lib.BUF_ADAM_V), snap["buffers"]):
+            wrap_flat_buffer(self, w).copy_(src)             # (BUF_PARAM through adn_flat_buffer: marks the parameters as written)
+        torch.cuda.current_stream().synchronize()
+        self.set_adam_step_count(snap["t"])
+
     def count_params(self):
         return int(self._lib.adn_total_param_count(self._handle))
 
-    def flat_buffer(self, which=_lib.BUF_GRAD):
-        """(device pointer, bytes) of a flat fp32 buffer; BUF_GRAD is what data-parallel ranks all-reduce."""
+    def flat_buffer(self, which=_lib.BUF_GRAD, read_only=False):
+        """(device pointer, bytes) of a flat fp32 buffer; BUF_GRAD is what data-parallel ranks all-reduce.  ``read_only``: the
+        caller will not write through the pointer (adn_flat_buffer_const: the parameters are not marked as written)."""
         ptr, nbytes = C.c_void_p(), C.c_size_t()
-        _lib.check(self._lib.adn_flat_buffer(self._handle, which, C.byref(ptr), C.byref(nbytes)))
+        fn = self._lib.adn_flat_buffer_const if read_only else self._lib.adn_flat_buffer
+        _lib.check(fn(self._handle, which, C.byref(ptr), C.byref(nbytes)))
         return ptr.value, nbytes.value
 
     def grad_buckets(self):

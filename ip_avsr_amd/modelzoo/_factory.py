@@ -131,10 +131,66 @@ def param_names(spec):
     return names + [spec["softmax_name"] + ".W", spec["softmax_name"] + ".b"]
 
 
+def layer_listing(spec):
+    """``[(layer.name, layer.output_shape) for layer in lasagne.layers.get_all_layers(network)]`` of the graph ``spec``
+    describes, as ``utils/plotting_utils.print_network`` prints it: Lasagne lists a layer behind everything it depends on,
+    walking each layer's inputs in order (an LSTMLayer's: its incoming layer, then the mask), so the streams come in the
+    order the fusion layer names them and the shared ``mask`` input right ahead of the first LSTM.  The only record of that
+    order in the reference is the notebook's print-out of ``adenet_v3`` (avletters/avletters_training.ipynb, pinned by
+    tests/golden/adenet_v3_layers.json); ``param_names`` is this list restricted to the layers that own parameters.
+    Names outside the parameterised layers follow the zoo's ``<kind><suffix>`` pattern (modelzoo/adenet_v3.py:64-188);
+    a stream's suffix is read off its encoder / LSTM names, its input layer is ``input_names[k]`` of the spec."""
+    out = []
+    mask_done = False
+    S = len(spec["streams"])
+    H = spec["stream_lstm_size"]
+    for k, s in enumerate(spec["streams"]):
+        ref = s["enc_names"][0] if s["enc_names"] else s["lstm_names"][0]
+        sfx = ref[ref.index("_"):] if "_" in ref else ""
+        D = s["input_dim"]
+        out.append(((spec.get("input_names") or [])[k] if k < len(spec.get("input_names") or []) else "input" + sfx, (None, None, D)))
+        width = D
+        if s["enc_names"]:
+            out.append(("reshape1" + sfx, (None, D)))
+            for n, u in zip(s["enc_names"], s["enc_shapes"]):
+                out.append((n, (None, int(u))))
+            width = int(s["enc_shapes"][-1])
+            out.append(("reshape2" + sfx, (None, None, width)))
+        if s["delta"]:
+            width *= 3
+            out.append(("delta" + sfx, (None, None, width)))
+        if s["dropout"] > 0:
+            out.append(("dropout" + sfx, (None, None, width)))
+        if not mask_done:
+            out.append(("mask", (None, None)))
+            mask_done = True
+        for ln in s["lstm_names"]:
+            out.append((ln, (None, None, H)))
+    width = H
+    if spec["fusion"] != "none" and S > 1:
+        width = H * S if spec["fusion"] == "concat" else H
+        out.append((spec["fuse_name"], (None, None, width)))
+    if spec.get("agg_dropout", 0.0) > 0:
+        out.append(("dropout_agg", (None, None, width)))
+    for ln in spec["agg_names"]:
+        out.append((ln, (None, None, spec["lstm_size"])))
+        width = spec["lstm_size"]
+    if len(spec["agg_names"]) == 2:
+        out.append(("sum2", (None, None, width)))
+    if spec.get("head") == "last":
+        out.append(("slice1", (None, width)))
+        out.append((spec["softmax_name"], (None, spec["classes"])))
+    else:
+        out.append(("reshape3", (None, width)))
+        out.append((spec["softmax_name"], (None, spec["classes"])))
+        out.append(("output", (None, None, spec["classes"])))
+    return out
+
+
 # set by tests that only need the graph description of a zoo module (no device, no libadenet_hip.so)
 SPEC_ONLY = False
 
-# arithmetic of the models the factories build ('f32' | 'bf16x3' | 'bf16', include/adenet.h adn_precision).  The reference is
+# arithmetic of the models the factories build ('f32' | 'bf16x3' | 'mixed' | 'bf16', include/adenet.h adn_precision).  The reference is
 # fp32 throughout (floatX = float32); the drivers' ``--precision`` option / the ADN_PRECISION environment variable set this
 # before they call ``create_model`` (whose reference signature has no room for it).
 import os as _os
@@ -143,13 +199,13 @@ DEFAULT_PRECISION = _os.environ.get("ADN_PRECISION", "f32")
 
 def set_default_precision(precision):
     global DEFAULT_PRECISION
-    if precision not in ("f32", "bf16x3", "bf16"):
-        raise ValueError("precision must be f32, bf16x3 or bf16 (got %r)" % (precision,))
+    if precision not in ("f32", "bf16x3", "mixed", "bf16"):
+        raise ValueError("precision must be f32, bf16x3, mixed or bf16 (got %r)" % (precision,))
     DEFAULT_PRECISION = precision
 
 
 def build(streams, lstm_size, output_classes, fusiontype, fuse_names, agg_names, agg_peepholes, w_init_fn,
-          softmax_name="softmax", return_fuse=True, head="frames", agg_dropout=0.0, stream_lstm_size=None):
+          softmax_name="softmax", return_fuse=True, head="frames", agg_dropout=0.0, stream_lstm_size=None, input_names=None):
     if fusiontype not in ("none", "sum", "adasum", "concat"):
         # modelzoo/adenet_v2.py:74-75 (other factories fall through to a NameError)
         raise ValueError("Unsupported Fusion Type used!")
@@ -160,6 +216,8 @@ def build(streams, lstm_size, output_classes, fusiontype, fuse_names, agg_names,
         fusion=fusiontype, fuse_name=fuse_names.get(fusiontype, ""), agg_names=list(agg_names),
         agg_peepholes=bool(agg_peepholes), lstm_size=int(lstm_size), classes=int(output_classes),
         softmax_name=softmax_name, precision=DEFAULT_PRECISION)
+    if input_names:
+        spec["input_names"] = list(input_names)        # (layer names of the InputLayers: layer_listing only)
     if SPEC_ONLY:
         return (spec, None) if return_fuse else spec
     model = AdeNetModel(spec)

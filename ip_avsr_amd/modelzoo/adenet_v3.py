@@ -13,4 +13,5 @@ def create_model(ae, diff_ae, input_shape, input_var, mask_shape, mask_var, dct_
                F.stream(dct_shape, None, "_dct", delta=False, lstm_names=["lstm_dct"], dropout=0.2, peepholes=True),
                F.stream(diff_shape, F.nolearn_weights(diff_ae), "_diff", lstm_names=["lstm_diff"], dropout=0.5, peepholes=True)]
     return F.build(streams, wide, output_classes, fusiontype, {"sum": "sum1", "adasum": "adasum1", "concat": "concat"},
-                   ["f_lstm_agg", "b_lstm_agg"], True, 'ortho', softmax_name="output", head="last", agg_dropout=0.5)
+                   ["f_lstm_agg", "b_lstm_agg"], True, 'ortho', softmax_name="output", head="last", agg_dropout=0.5,
+                   input_names=["raw_im", "dct", "diff_im"])

@@ -29,10 +29,11 @@ class _DeviceBuffer(object):
                                          "version": 2, "strides": None}
 
 
-def wrap_flat_buffer(model, which=_lib.BUF_GRAD, device=None):
-    """Zero-copy torch view (1-D float32) of one of the model's flat buffers."""
+def wrap_flat_buffer(model, which=_lib.BUF_GRAD, device=None, read_only=False):
+    """Zero-copy torch view (1-D float32) of one of the model's flat buffers.  ``read_only``: a view the caller only reads
+    (a parameter snapshot) -- the library then does not re-derive the bf16 copies / planes of the parameters."""
     import torch
-    ptr, nbytes = model.flat_buffer(which)
+    ptr, nbytes = model.flat_buffer(which, read_only=True) if read_only else model.flat_buffer(which)
     dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
     t = torch.as_tensor(_DeviceBuffer(ptr, nbytes // 4), device=dev)
     if t.data_ptr() != ptr:
@@ -63,6 +64,8 @@ class DataParallel(object):
         self._own_grad = grad_tensor           # CPU test path: the replica owns host tensors instead of device buffers
         self._own_buffers = getattr(model, "host_buffers", None)
         self._inflight = False
+        self._state_serial = 0                 # bumped by everything that changes the training state (see sync_running_statistics)
+        self._stats_synced_at = None
         # Overlap: the library records one HIP event per gradient bucket as soon as that bucket is final; a communication
         # stream waits on it and all-reduces the bucket while back-propagation is still running, and Adam is applied to a
         # bucket as soon as ITS reduction has landed, while later buckets are still on the wire.  Default on
@@ -89,14 +92,23 @@ class DataParallel(object):
                     self.launches[-1].append(k)
                 else:
                     self.launches.append([k])
-            # Two collectives per step by default: everything that is final before the encoders' first layer (tops, classifier,
-            # layers L-1 .. 1: 43 of 72 MB for the bench model) goes out as ONE grouped collective behind layer 1's weight
-            # gradients -- layer 0's input-free backward (its weight-gradient GEMM, 0.24 ms) covers it -- and layer 0 as the
-            # second.  One event, one collective and one cross-stream wait per release point cost a single rank +0.17 ms per
+            # Two collectives per step by default IN THE LAYER-MAJOR ORDER: everything that is final before the encoders' first
+            # layer (tops, classifier, layers L-1 .. 1: 43 of 72 MB for the bench model) goes out as ONE grouped collective
+            # behind layer 1's weight gradients -- layer 0's input-free backward (its weight-gradient GEMM, 0.24 ms) covers
+            # it -- and layer 0 as the second.  One event, one collective and one cross-stream wait per release point cost a single rank +0.17 ms per
             # step (6 points, profiles/r03/dp_forced.txt) before any byte moves; at 8 ranks 43 MB are ~0.2 ms of xGMI time,
             # which the one layer still to run hides as well as five earlier starts did.  ADN_DP_FINE_BUCKETS=1: one
             # collective per release point (round 3's schedule).
-            if len(self.launches) > 2 and not os.environ.get("ADN_DP_FINE_BUCKETS") and not os.environ.get("ADN_DP_NO_COALESCE"):
+            # The merged head waits on ONE event (its last bucket's), which stands for the whole head only where every earlier
+            # bucket is final before that event in stream order: back-propagation on one stream in the layer-major order.  In
+            # the stream-major orders (ADN_DP_STREAM_MAJOR, ADN_NO_GROUPED_BACKWARD, forked side streams: the bucket groups are
+            # then the identity) a stream's events are recorded on its own side stream and the last launch is merely the last
+            # stream's layer 0 -- there every release point keeps its own collective behind its own event.
+            n_streams = len(getattr(model, "spec", {}).get("streams", [])) if isinstance(getattr(model, "spec", None), dict) else 0
+            self.layer_major = list(groups) != list(range(len(self.buckets))) or n_streams == 1 or \
+                bool(getattr(model, "dp_layer_major", False))
+            if (len(self.launches) > 2 and self.layer_major and not os.environ.get("ADN_DP_FINE_BUCKETS")
+                    and not os.environ.get("ADN_DP_NO_COALESCE")):
                 head = [k for idxs in self.launches[:-1] for k in idxs]
                 self.launches = [head, self.launches[-1]]
         if self.overlap and self.on_device:
@@ -126,6 +138,7 @@ class DataParallel(object):
             t = self.grad.new_tensor([float(self.model.adam_step_count())])
             self.dist.broadcast(t, src=src, group=self.group)
             self.model.set_adam_step_count(int(t.item()))
+        self._state_serial += 1
 
     def assert_quiescent(self):
         """The invariant of DESIGN.md 7 as a check: no bucket all-reduce of this replica may be outstanding when a step's
@@ -143,6 +156,7 @@ class DataParallel(object):
         rates: ``lambda m: m.apply_adam_vlr(lr_map)``; other update rules).  Returns the GLOBAL cost (a host float) when
         ``want_loss`` (forces a sync)."""
         self.assert_quiescent()
+        self._state_serial += 1
         if len(mask) == 0:
             self.model.zero_grads()
         else:
@@ -256,10 +270,10 @@ class DataParallel(object):
             return 0
         # once per training state, not per evaluation call: each set_param marks the parameters dirty (the bf16 copies / planes
         # are repacked) and the average costs a host round trip; nothing changes the statistics between two optimiser steps
-        stamp = self.model.adam_step_count() if hasattr(self.model, "adam_step_count") else None
-        if not force and stamp is not None and stamp == getattr(self, "_stats_synced_at", None):
+        # (keyed on THIS object's count of training-state changes -- train_step, broadcast_parameters, invalidate_statistics --
+        #  not on the Adam counter, which an `update` callable need not advance; stamped only once the averages are written back)
+        if not force and self._state_serial == self._stats_synced_at:
             return 0
-        self._stats_synced_at = stamp
         import torch
         vals = [np.asarray(self.model.get_param(n), np.float32).reshape(-1) for n in names]
         flat = torch.as_tensor(np.concatenate(vals), device=self.grad.device)
@@ -269,7 +283,13 @@ class DataParallel(object):
         for n, v in zip(names, vals):
             self.model.set_param(n, flat[off:off + v.size].reshape(np.asarray(self.model.get_param(n)).shape))
             off += v.size
+        self._stats_synced_at = self._state_serial
         return len(names)
+
+    def invalidate_statistics(self):
+        """Call after changing the model's state behind this object's back (set_param, restore_params, a checkpoint load): the
+        next sharded evaluation averages the BatchNorm running statistics again."""
+        self._state_serial += 1
 
     # ------------------------------------------------------------------ sharded evaluation
     def shard(self, n):

@@ -131,7 +131,7 @@ def parse_options(argv, default_config):
     parser.add_argument('--no_plot', dest='no_plot', action='store_true', help='disable plots')
     parser.add_argument('--seed', type=int, default=None, help='seed for initialisers, dropout and minibatch order '
                                                                '(the reference never seeds)')
-    parser.add_argument('--precision', default=None, choices=['f32', 'bf16x3', 'bf16'],
+    parser.add_argument('--precision', default=None, choices=['f32', 'bf16x3', 'mixed', 'bf16'],
                         help='arithmetic of the model (default f32 = the reference); also ADN_PRECISION')
     args = parser.parse_args(argv)
     options = {'config': args.config or default_config, 'no_plot': bool(args.no_plot), 'seed': args.seed,

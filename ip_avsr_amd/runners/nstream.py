@@ -107,9 +107,10 @@ def parse_options(argv=None):
                              'must diverge, runners/1stream_variable_lr.py:327-333)')
     parser.add_argument('--seed', type=int, default=None, help='seed for initialisers and minibatch order '
                                                                '(the reference never seeds; required >1 GPU)')
-    parser.add_argument('--precision', default=None, choices=['f32', 'bf16x3', 'bf16'],
+    parser.add_argument('--precision', default=None, choices=['f32', 'bf16x3', 'mixed', 'bf16'],
                         help='arithmetic of the model (default f32 = the reference; bf16x3 = fp32-grade products on the bf16 '
-                             'matrix pipe, meets the 1e-4 parity gate; bf16 = fastest); also ADN_PRECISION')
+                             'matrix pipe, meets the 1e-4 parity gate; mixed = bf16x3 forward pass, bf16 products in back-propagation; '
+                             'bf16 = fastest); also ADN_PRECISION')
     args = parser.parse_args(argv)
     options = {'config': args.config or 'config/bimodal_meanrm_raw_diff.ini', 'precision': args.precision}
     for key in ('write_results', 'save_best', 'save_plot'):
@@ -168,6 +169,60 @@ def build_network(n_streams, aes, dims, lstm_weights, cfg):
     raise ValueError('1 to 4 streams are supported')
 
 
+def build_network_avletters(n_streams, has_encoder, load_ae, dims, lstm_weights, cfg):
+    """The factory reference avletters/{1,2,3}stream.py picks from the streams' ``has_encoder`` options (schema 1 of SURVEY
+    App. B as those three scripts read it).  ``load_ae(k)`` loads stream k's encoder (only called where the script does):
+
+      1 stream   has_encoder -> deltanet_majority_vote, else deltanet_v1 on the raw features      (avletters/1stream.py:228-238)
+      2 streams  stream 2 has an encoder -> adenet_2stream.create_pretrained_model (both ``lstm_model`` given) / adenet_v2_2,
+                 else adenet_v2: encoder stream + encoder-less second stream                       (avletters/2stream.py:265-286)
+      3 streams  stream 2 has an encoder -> adenet_3stream (pretrained form when all three ``lstm_model`` are given);
+                 the script has NO branch for an encoder-less stream 2 (``network`` is never bound: NameError at
+                 avletters/3stream.py:298) and needs ae1 / ae3 in every branch                     (avletters/3stream.py:278-296)
+
+    Where the reference script would stop with a NameError this raises a ValueError that says which option did it."""
+    shapes = [(None, None, d) for d in dims]
+    ms = (None, None)
+    kw = dict(w_init_fn=cfg['weight_init_fn'], use_peepholes=cfg['use_peepholes'])
+    H, C, fuse = cfg['lstm_size'], cfg['output_classes'], cfg['fusiontype']
+
+    def need(k):
+        if not has_encoder[k]:
+            raise ValueError('stream{}: has_encoder = false, but the {}-stream script uses its encoder in every branch '
+                             '(the reference stops with a NameError on ae{})'.format(k + 1, n_streams, k + 1))
+        return load_ae(k)
+    if n_streams == 1:
+        if has_encoder[0]:
+            return deltanet_majority_vote.create_model(load_ae(0), shapes[0], None, ms, None, H, None, C, cfg['weight_init_fn'],
+                                                       cfg['use_peepholes'], cfg['use_blstm']), None
+        return deltanet_v1.create_model(shapes[0], None, ms, None, None, H, C, cfg['weight_init_fn'], cfg['use_peepholes'],
+                                        cfg['use_blstm']), None
+    if n_streams == 2:
+        ae1 = need(0)
+        if not has_encoder[1]:
+            return adenet_v2.create_model(ae1, shapes[0], None, ms, None, shapes[1], None, H, None, C, fuse,
+                                          cfg['weight_init_fn'], cfg['use_peepholes'])
+        ae2 = load_ae(1)
+        if lstm_weights[0] is not None and lstm_weights[1] is not None:
+            return adenet_2stream.create_pretrained_model(ae1, lstm_weights[0], ae2, lstm_weights[1], shapes[0], None, shapes[1],
+                                                          None, ms, None, H, None, C, fuse,
+                                                          use_blstm_substream=cfg['use_blstm_substream'], **kw)
+        return adenet_v2_2.create_model(ae1, ae2, shapes[0], None, ms, None, shapes[1], None, H, None, C, fuse, **kw)
+    if n_streams == 3:
+        if not has_encoder[1]:
+            raise ValueError('stream2: has_encoder = false -- avletters/3stream.py builds a network only when stream 2 has an '
+                             'encoder (:278); use the 2-stream script for an encoder-less second stream')
+        ae1, ae2, ae3 = need(0), load_ae(1), need(2)
+        if all(w is not None for w in lstm_weights[:3]):
+            return adenet_3stream.create_pretrained_model(ae1, lstm_weights[0], ae2, lstm_weights[1], ae3, lstm_weights[2],
+                                                          shapes[0], None, shapes[1], None, shapes[2], None, ms, None, H, None, C,
+                                                          fuse, cfg['weight_init_fn'], cfg['use_peepholes'],
+                                                          cfg['use_blstm_substream'])
+        return adenet_3stream.create_model(ae1, ae2, ae3, shapes[0], None, shapes[1], None, shapes[2], None, ms, None, H, None, C,
+                                           fuse, **kw)
+    raise ValueError('the avletters N-stream scripts exist for 1, 2 and 3 streams')
+
+
 def resident_dtype(network):
     """Element type of the HBM-resident splits: bfloat16 when the model computes in bf16 and every stream enters through an
     encoder GEMM (which rounds its input to bfloat16 anyway: identical results, half the bytes, ADN_FLAG_BF16_INPUTS);
@@ -180,7 +235,8 @@ def resident_dtype(network):
 
 
 def fit(network, split, ys, lens, n_streams, windowsize, num_epoch, epochsize, batchsize, validation_window, learning_rate,
-        options=None, say=print, rank=0, world=1, dp=None, lr_map=None, host_batches=None, prefetch=None, progress=True):
+        options=None, say=print, rank=0, world=1, dp=None, lr_map=None, host_batches=None, prefetch=None, progress=True,
+        two_way=False):
     """The epoch loop of reference runners/3stream.py:322-427 (identical in 1/2/4stream.py) on splits that stay resident in
     HBM: ``split[k]`` = list of (sum of lengths, D_s) frame matrices for k in train / val / test, ``ys[k]`` per-frame labels,
     ``lens[k]`` utterance lengths.  Minibatches are assembled on the GPU by index (utils/datagen_gpu.py; same utterance
@@ -188,6 +244,8 @@ def fit(network, split, ys, lens, n_streams, windowsize, num_epoch, epochsize, b
     once and stay resident, and ``train`` does not wait for its cost (the reference discards it, runners/3stream.py:370), so
     the host runs ahead of the device inside an epoch.  ``host_batches`` (or ADN_HOST_BATCHES=1): the reference's host-side
     assembly instead, every batch uploaded -- the slow path, kept for A/B runs and for the bit-equality test between the two.
+    ``two_way``: the loop of reference avletters/{1,2,3}stream.py (:322-404) -- train / val only: no test split, the confusion
+    matrix kept is the validation one of the best epoch, no 'Test CR' in the epoch line.
     Returns the statistics dict of the run (incl. ``epoch_seconds``)."""
     options = options or {}
     if host_batches is None:
@@ -238,7 +296,7 @@ def fit(network, split, ys, lens, n_streams, windowsize, num_epoch, epochsize, b
     else:
         from ..utils.datagen_gpu import DeviceSplit
         dtype = resident_dtype(network)
-        resident = {k: DeviceSplit(split[k], ys[k], lens[k], dtype=dtype) for k in ('train', 'val', 'test')}
+        resident = {k: DeviceSplit(split[k], ys[k], lens[k], dtype=dtype) for k in (('train', 'val') if two_way else ('train', 'val', 'test'))}
         # (one stream of batches per rank: a rank gathers only its own rows of every global minibatch)
         datagen = resident['train'].batches(batchsize, rank=rank if dp is not None else 0, world=world if dp is not None else 1,
                                             prefetch=prefetch)
@@ -248,7 +306,7 @@ def fit(network, split, ys, lens, n_streams, windowsize, num_epoch, epochsize, b
             return b.Xs, b.y, b.mask, b.targets
 
     X_val, y_val_evaluate, mask_val, y_val = whole_split('val')
-    X_test, y_test, mask_test, _ = whole_split('test')
+    X_test, y_test, mask_test, _ = (None, None, None, None) if two_way else whole_split('test')
 
     for epoch in range(num_epoch):
         time_start = time.time()
@@ -313,7 +371,13 @@ def fit(network, split, ys, lens, n_streams, windowsize, num_epoch, epochsize, b
         cr, val_conf = evaluate_model2(X_val, y_val_evaluate, mask_val, windowsize,
                                        eval_fn if val_probs is None else (lambda *a: val_probs))
         class_rate.append(cr)
-        if val_cost < best_val:
+        if val_cost < best_val and two_way:          # avletters/3stream.py:382-392: the best epoch's VALIDATION confusion matrix
+            best_val, best_cr, test_conf = val_cost, cr, val_conf
+            epoch_seconds.append(time.time() - time_start)
+            say("Epoch {} train cost = {}, val cost = {}, GL loss = {:.3f}, GQ = {:.3f}, CR = {:.3f} ({:.1f}sec)"
+                .format(epoch + 1, cost_train[-1], cost_val[-1], gl, pq, cr, epoch_seconds[-1]))
+            best_params = network.snapshot_params() if hasattr(network, 'snapshot_params') else network.get_all_param_values()
+        elif val_cost < best_val:
             best_val, best_cr = val_cost, cr
             test_cr, test_conf = evaluate_model2(X_test, y_test, mask_test, windowsize, eval_fn)
             epoch_seconds.append(time.time() - time_start)
@@ -343,8 +407,11 @@ def _main(n_streams, argv=None, variant=None):
     """variant: None = runners/{1,2,3,4}stream.py; 1 stream: 'noencoder' = runners/1stream_noencoder.py (deltanet_v1 on
     the raw features), 'dct' = runners/1stream_dct.py (host deltas of the DCT features, lstm_classifier_majority_vote);
     2 streams: 'dct' = runners/2stream_dct.py (adenet_v2: encoder stream + encoder-less DCT stream), 'nodelta' =
-    runners/2stream_nodelta.py (adenet_v2_nodelta)."""
-    if (variant, n_streams) not in ((None, n_streams), ('noencoder', 1), ('dct', 1), ('dct', 2), ('nodelta', 2)):
+    runners/2stream_nodelta.py (adenet_v2_nodelta); 'avletters' = avletters/{1,2,3}stream.py: the same INI sections with a
+    ``has_encoder`` option per stream, a train / val split by the ``iterVec`` of the ``.mat`` file instead of subject files,
+    no test split (results line ``best_cr,best_val``)."""
+    if (variant, n_streams) not in ((None, n_streams), ('noencoder', 1), ('dct', 1), ('dct', 2), ('nodelta', 2),
+                                    ('avletters', 1), ('avletters', 2), ('avletters', 3)):
         raise ValueError('unknown runner variant %r for %d stream(s)' % (variant, n_streams))
     options = parse_options(argv)
     dist, rank, world = _dist_context()
@@ -380,6 +447,8 @@ def _main(n_streams, argv=None, variant=None):
         use_blstm=config.getboolean(lc, 'use_blstm') if config.has_option(lc, 'use_blstm') else True,
         use_blstm_substream=(config.getboolean(lc, 'use_blstm_substream')
                              if config.has_option(lc, 'use_blstm_substream') else False))
+    if variant == 'avletters':                      # avletters/1stream.py:161: the option's PRESENCE selects the BLSTM
+        cfg['use_blstm'] = config.has_option(lc, 'use_blstm')
     cfg['weight_init_fn'] = las_init.select(config.get(lc, 'weight_init'))
     windowsize = config.getint(lc, 'windowsize')
     output_classnames = config.get(lc, 'output_classnames').split(',')
@@ -393,9 +462,12 @@ def _main(n_streams, argv=None, variant=None):
     learning_rate = options.get('learning_rate', config.getfloat('training', 'learning_rate'))
     epochsize = config.getint('training', 'epochsize')
     batchsize = config.getint('training', 'batchsize')
-    train_ids = read_data_split_file(config.get('training', 'train_subjects_file'))
-    val_ids = read_data_split_file(config.get('training', 'val_subjects_file'))
-    test_ids = read_data_split_file(config.get('training', 'test_subjects_file'))
+    avl = variant == 'avletters'
+    if not avl or config.has_option('training', 'train_subjects_file'):
+        # (avletters/2stream.py:199-201 reads the three files and never uses them: read, so that a missing file fails alike)
+        train_ids = read_data_split_file(config.get('training', 'train_subjects_file'))
+        val_ids = read_data_split_file(config.get('training', 'val_subjects_file'))
+        test_ids = read_data_split_file(config.get('training', 'test_subjects_file'))
 
     mats = [d['dataMatrix'].astype('float32') for d in data]
     targets_vec = data[0]['targetsVec'].reshape((-1,)).astype('int64')
@@ -404,7 +476,29 @@ def _main(n_streams, argv=None, variant=None):
     if matlab_target_offset:
         targets_vec = targets_vec - 1
 
-    if variant == 'dct' and n_streams == 1:
+    if avl:
+        # avletters/3stream.py:217-250 (2stream.py / 1stream.py alike): optional force_align of streams 1 and 2, the
+        # pre-split chain per stream, the iterVec split (iterations 1, 2 train; the rest validation), train-split statistics
+        from ..utils.preprocessing import create_split_index, force_align, split_videolen
+        iter_vec = data[0]['iterVec'].reshape((-1,))
+        if n_streams >= 2 and config.getboolean('stream1', 'force_align_data'):
+            s1_new, s2_new = force_align((mats[0], targets_vec, vidlen_vec),
+                                         (mats[1], data[1]['targetsVec'].reshape((-1,)), data[1]['videoLengthVec'].reshape((-1,))))
+            mats[0], targets_vec, vidlen_vec = s1_new
+            mats[1] = s2_new[0]
+        mats = [presplit_dataprocessing(mats[k], vidlen_vec, config, names[k], imagesize=imagesizes[k]) for k in range(n_streams)]
+        indexes = create_split_index(len(mats[0]), vidlen_vec, iter_vec)
+        tr_lens, va_lens = split_videolen(vidlen_vec, iter_vec)
+        split = dict(train=[], val=[])
+        for k in range(n_streams):
+            tr, va = mats[k][indexes], mats[k][~indexes]
+            if config.getboolean(names[k], 'featurewisenormalize'):       # avletters/3stream.py:102-107
+                tr, mean, std = featurewise_normalize_sequence(tr)
+                va = (va - mean) / std
+            split['train'].append(tr); split['val'].append(va)
+        ys = dict(train=targets_vec[indexes].reshape((-1,)), val=targets_vec[~indexes].reshape((-1,)))
+        lens = dict(train=np.asarray(tr_lens), val=np.asarray(va_lens))
+    elif variant == 'dct' and n_streams == 1:
         # runners/1stream_dct.py:185-206: normalise, mean-remove, host deltas (x3 features) BEFORE the split, then the
         # train-split featurewise normalisation
         X = mats[0]
@@ -461,7 +555,13 @@ def _main(n_streams, argv=None, variant=None):
     say('constructing end to end model...')
     from ..modelzoo import _factory
     _factory.set_default_precision(options.get('precision') or os.environ.get('ADN_PRECISION', 'f32'))
-    if variant == 'noencoder':           # runners/1stream_noencoder.py:233-236
+    if avl:
+        has_encoder = [config.getboolean(n, 'has_encoder') for n in names]
+        network, l_fuse = build_network_avletters(
+            n_streams, has_encoder,
+            lambda k: load_decoder(config.get(names[k], 'model'), config.get(names[k], 'shape'), config.get(names[k], 'nonlinearities')),
+            dims, lstm_weights, cfg)
+    elif variant == 'noencoder':           # runners/1stream_noencoder.py:233-236
         network, l_fuse = deltanet_v1.create_model((None, None, dims[0]), None, (None, None), None, None, cfg['lstm_size'],
                                                    cfg['output_classes'], cfg['weight_init_fn'], cfg['use_peepholes']), None
     elif variant == 'dct' and n_streams == 2:           # runners/2stream_dct.py: stream 2 has no encoder
@@ -498,12 +598,15 @@ def _main(n_streams, argv=None, variant=None):
 
     st = fit(network, split, ys, lens, n_streams, windowsize=windowsize, num_epoch=num_epoch, epochsize=epochsize,
              batchsize=batchsize, validation_window=validation_window, learning_rate=learning_rate, options=options, say=say,
-             rank=rank, world=world, dp=dp, lr_map=lr_map)
+             rank=rank, world=world, dp=dp, lr_map=lr_map, two_way=avl)
     best_cr, best_val, test_cr, test_conf, best_params = st['best_cr'], st['best_val'], st['test_cr'], st['test_conf'], st['best_params']
     cost_train, cost_val, class_rate = st['cost_train'], st['cost_val'], st['class_rate']
 
     say('Final Model')
-    say('CR: {}, val loss: {}, Test CR: {}'.format(best_cr, best_val, test_cr))
+    if avl:
+        say('CR: {}, val loss: {}'.format(best_cr, best_val))              # avletters/3stream.py:397
+    else:
+        say('CR: {}, val loss: {}, Test CR: {}'.format(best_cr, best_val, test_cr))
     if rank == 0:
         table_str = plot_confusion_matrix(test_conf, output_classnames, fmt='pipe')
         print('confusion matrix: ')
@@ -518,7 +621,7 @@ def _main(n_streams, argv=None, variant=None):
         if 'write_results' in options:
             print('writing results to {}'.format(options['write_results']))
             with open(options['write_results'], mode='a') as f:
-                f.write('{},{},{}\n'.format(test_cr, best_cr, best_val))
+                f.write('{},{}\n'.format(best_cr, best_val) if avl else '{},{},{}\n'.format(test_cr, best_cr, best_val))
         if 'save_best' in options:
             print('saving best model...')
             if hasattr(network, 'restore_params') and not isinstance(best_params, list):

@@ -15,6 +15,7 @@
 using namespace adn;
 #ifdef ADN_GEMM_STAMPS
 extern "C" int adn_debug_gemm_stamps(unsigned long long*, int);   // the library built with -DADN_GEMM_STAMPS
+extern "C" int adn_debug_x3f_stamps(unsigned long long*, int);
 #endif
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -111,12 +112,15 @@ int main(int argc, char** argv) {
     float* wsk; CK(hipMalloc((void**)&wsk, wsk_floats * 4));
     for (const auto& c : cases) {
         if (only && !strstr(c.name, only)) continue;
+        if (getenv("LAB_PLANES") && (!strncmp(c.name, "x3 ", 3) || c.layout == GEMM_NT)) continue;     // (3R-row stand-ins of the split-image path)
         const int ar = c.layout == GEMM_TN ? c.K : c.M, ac = pad(c.layout == GEMM_TN ? c.M : c.K);
         const int br = c.layout == GEMM_NT ? c.N : c.K, bc = pad(c.layout == GEMM_NT ? c.K : c.N);
         const int ldc = pad(c.N);
         const size_t wsf = (size_t)((c.M + 63) / 64 + 8) * ldc;
         float *A[4], *B[4], *C[4], *Y[4], *bias[4], *cs[4], *ws[4];
-        void *A16[4], *B16[4], *C16[4], *Y16[4];
+        void *A16[4], *B16[4], *C16[4], *Y16[4], *A16lo[4], *B16lo[4], *C16lo[4];
+        const bool planes = getenv("LAB_PLANES") != nullptr;       // bf16x3 over hi / lo planes (the product path of that mode)
+        int pdone[4] = {0, 0, 0, 0}, skipped[4] = {0, 0, 0, 0};
         GemmArgs g[4];
         int done[4] = {0, 0, 0, 0};
         for (int k = 0; k < NG; ++k) {
@@ -125,7 +129,10 @@ int main(int argc, char** argv) {
             bias[k] = dalloc(ldc + 64 * k, true); cs[k] = dalloc(ldc, false); ws[k] = dalloc(wsf, false);
             CK(hipMalloc(&A16[k], (size_t)ar * ac * 2 + 64)); CK(hipMalloc(&B16[k], (size_t)br * bc * 2 + 64));
             CK(hipMalloc(&C16[k], (size_t)c.M * ldc * 2)); CK(hipMalloc(&Y16[k], (size_t)c.M * ldc * 2));
-            to_bf16(A[k], A16[k], (size_t)ar * ac, st); to_bf16(B[k], B16[k], (size_t)br * bc, st); to_bf16(Y[k], Y16[k], (size_t)c.M * ldc, st);
+            CK(hipMalloc(&A16lo[k], (size_t)ar * ac * 2 + 64)); CK(hipMalloc(&B16lo[k], (size_t)br * bc * 2 + 64)); CK(hipMalloc(&C16lo[k], (size_t)c.M * ldc * 2));
+            if (planes) { split_hilo(A[k], A16[k], A16lo[k], (size_t)ar * ac / 8 * 8, st); split_hilo(B[k], B16[k], B16lo[k], (size_t)br * bc / 8 * 8, st); }
+            else { to_bf16(A[k], A16[k], (size_t)ar * ac, st); to_bf16(B[k], B16[k], (size_t)br * bc, st); }
+            to_bf16(Y[k], Y16[k], (size_t)c.M * ldc, st);
             GemmArgs& q = g[k];
             q.layout = c.layout; q.M = c.M; q.N = c.N; q.K = c.K; q.A = A[k]; q.lda = ac; q.B = B[k]; q.ldb = bc;
             q.C = c.lean ? nullptr : C[k]; q.ldc = ldc; q.accumulate = c.acc; q.precision = ADN_PRECISION_BF16;
@@ -135,11 +142,15 @@ int main(int argc, char** argv) {
             if (c.biasrelu) { q.bias = bias[k]; q.act = ADN_ACT_RECTIFY; }
             if (c.layout != GEMM_TN) q.no_split = 1;
             q.splitk_ws = wsk; q.splitk_ws_floats = wsk_floats;
+            if (planes) {
+                q.precision = ADN_PRECISION_BF16X3; q.C = C[k]; q.lean_ok = c.lean; q.A16lo = A16lo[k]; q.B16lo = B16lo[k];
+                q.C16lo = (c.layout == GEMM_TN) ? nullptr : C16lo[k]; q.planes_done = &pdone[k]; q.fp32_skipped = &skipped[k];
+            }
         }
         for (int i = 0; i < 3; ++i) if (gemm_grouped(g, NG, st) != 0) { fprintf(stderr, "gemm failed: %s\n", c.name); return 1; }
         const int iters = 20;
 #ifdef ADN_GEMM_STAMPS
-        adn_debug_gemm_stamps(nullptr, 1);
+        adn_debug_gemm_stamps(nullptr, 1); adn_debug_x3f_stamps(nullptr, 1);
 #endif
         CK(hipEventRecord(e0, st));
         for (int i = 0; i < iters; ++i) gemm_grouped(g, NG, st);
@@ -150,6 +161,11 @@ int main(int argc, char** argv) {
 #ifdef ADN_GEMM_STAMPS
         { unsigned long long s16[16];
           adn_debug_gemm_stamps(s16, 0);
+          { unsigned long long f16[18]; adn_debug_x3f_stamps(f16, 0); double tf = 0; for (int k = 0; k < 16; ++k) tf += (double)f16[k];
+            if (tf > 0) {                                                      // the launch ran on the fused-plane kernel
+                for (int k = 0; k < 16; ++k) s16[k] = f16[k];
+                printf("   in-kernel clock (wave 0 of workgroup 3, s_memtime / s_memrealtime x 100 MHz): %.3f GHz\n", f16[17] ? 0.1 * (double)f16[16] / (double)f16[17] : 0.0);
+            } }
           const char* nm8[8] = {"frag reads", "DMA issue", "lgkm wait", "vmcnt wait", "barrier(L)", "MFMA", "epilogue", "barrier(C)"};
           const char* nm4[8] = {"top wait", "half L (32 MFMA)", "vmcnt wait", "barrier", "DMA issue + 8 reads", "half R (32 MFMA + reads)", "epilogue", "-"};
           const char** nm = (getenv("ADN_GEMM_PP") && atoi(getenv("ADN_GEMM_PP")) == 7) ? nm4 : nm8;
@@ -173,7 +189,14 @@ int main(int argc, char** argv) {
           CK(hipStreamSynchronize(st));
           for (int k = 0; k < NG; ++k) {
             std::vector<unsigned short> hA((size_t)ar * ac), hB((size_t)br * bc), hC16((size_t)c.M * ldc), hY16((size_t)c.M * ldc);
-            std::vector<float> hC((size_t)c.M * ldc), hb(ldc), hcs(ldc);
+            std::vector<float> hC((size_t)c.M * ldc), hb(ldc), hcs(ldc), hAf, hBf;
+            std::vector<unsigned short> hC16lo;
+            if (planes) {
+                hAf.resize((size_t)ar * ac); hBf.resize((size_t)br * bc); hC16lo.resize((size_t)c.M * ldc);
+                CK(hipMemcpy(hAf.data(), A[k], hAf.size() * 4, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(hBf.data(), B[k], hBf.size() * 4, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(hC16lo.data(), C16lo[k], hC16lo.size() * 2, hipMemcpyDeviceToHost));
+            }
             CK(hipMemcpy(hA.data(), A16[k], hA.size() * 2, hipMemcpyDeviceToHost));
             CK(hipMemcpy(hB.data(), B16[k], hB.size() * 2, hipMemcpyDeviceToHost));
             CK(hipMemcpy(hC16.data(), C16[k], hC16.size() * 2, hipMemcpyDeviceToHost));
@@ -191,35 +214,43 @@ int main(int argc, char** argv) {
                 if (sidx >= 64 && sidx < 128) { j = (sidx & 1) ? c.N - 1 - ((sidx - 64) >> 1) : ((sidx - 64) >> 1); }
                 double acc = 0;
                 for (int kk = 0; kk < c.K; ++kk) {
-                    const float a = c.layout == GEMM_TN ? f(hA[(size_t)kk * ac + i]) : f(hA[(size_t)i * ac + kk]);
-                    const float b = c.layout == GEMM_NT ? f(hB[(size_t)j * bc + kk]) : f(hB[(size_t)kk * bc + j]);
+                    const size_t ia = c.layout == GEMM_TN ? (size_t)kk * ac + i : (size_t)i * ac + kk;
+                    const size_t ib = c.layout == GEMM_NT ? (size_t)j * bc + kk : (size_t)kk * bc + j;
+                    const float a = planes ? hAf[ia] : f(hA[ia]);
+                    const float b = planes ? hBf[ib] : f(hB[ib]);
                     acc += (double)a * b;
                 }
                 if (c.biasrelu) { acc += hb[j]; if (acc < 0) acc = 0; }
                 if (c.ygrad && !(f(hY16[(size_t)i * ldc + j]) > 0.f)) acc = 0;
-                const double got = c.lean ? f(hC16[(size_t)i * ldc + j]) : hC[(size_t)i * ldc + j];
-                const double tol = (c.lean ? 1.0e-2 : 2e-3) * (fabs(acc) + 1.0);
+                const bool from_planes = planes && (skipped[k] || (c.lean && pdone[k]));
+                const double got = from_planes ? (double)f(hC16[(size_t)i * ldc + j]) + (double)f(hC16lo[(size_t)i * ldc + j])
+                                               : ((c.lean && !planes) ? f(hC16[(size_t)i * ldc + j]) : hC[(size_t)i * ldc + j]);
+                const double tol = planes ? 2e-4 * (fabs(acc) + 1.0) : (c.lean ? 1.0e-2 : 2e-3) * (fabs(acc) + 1.0);
                 const double err = fabs(got - acc);
                 if (err > tol) { if (bad < 5) printf("   MISMATCH g%d (%d,%d): got %g want %g\n", k, i, j, got, acc); ++bad; }
                 if (err > worst) worst = err;
             }
             // pad columns of C must stay zero; the fused column sums must equal the column sums of the stored result
             int padbad = 0;
-            if (!c.lean) for (int i = 0; i < c.M; i += 97) for (int j = c.N; j < ldc; ++j) if (hC[(size_t)i * ldc + j] != 0.f) ++padbad;
+            if (!c.lean && !skipped[k]) for (int i = 0; i < c.M; i += 97) for (int j = c.N; j < ldc; ++j) if (hC[(size_t)i * ldc + j] != 0.f) ++padbad;
             double csworst = 0;
-            if (c.colsum && done[k] && !c.lean) {
+            const bool res_planes = planes && (skipped[k] || (c.lean && pdone[k]));
+            if (c.colsum && done[k] && (res_planes || (!c.lean && !skipped[k]))) {
                 for (int j = 0; j < c.N; j += 37) {
-                    double sum = 0; for (int i = 0; i < c.M; ++i) sum += hC[(size_t)i * ldc + j];
+                    double sum = 0;
+                    for (int i = 0; i < c.M; ++i)
+                        sum += res_planes ? (double)f(hC16[(size_t)i * ldc + j]) + (double)f(hC16lo[(size_t)i * ldc + j]) : hC[(size_t)i * ldc + j];
                     csworst = std::max(csworst, fabs(sum - hcs[j]) / (fabs(sum) + 1.0));
                 }
             }
-            printf("   verify g%d: %d/%d outside tolerance, worst abs err %.3g, dirty pads %d, colsum rel err %.2g\n", k, bad, nsamp, worst,
-                   padbad, csworst);
+            printf("   verify g%d: %d/%d outside tolerance, worst abs err %.3g, dirty pads %d, colsum rel err %.2g%s\n", k, bad, nsamp, worst,
+                   padbad, csworst, planes ? (pdone[k] ? (skipped[k] ? "  (planes written, fp32 skipped)" : "  (planes written)") : "  (no planes)") : "");
           }
         }
         for (int k = 0; k < NG; ++k) {
             (void)hipFree(A[k]); (void)hipFree(B[k]); (void)hipFree(C[k]); (void)hipFree(Y[k]); (void)hipFree(bias[k]); (void)hipFree(cs[k]);
             (void)hipFree(ws[k]); (void)hipFree(A16[k]); (void)hipFree(B16[k]); (void)hipFree(C16[k]); (void)hipFree(Y16[k]);
+            (void)hipFree(A16lo[k]); (void)hipFree(B16lo[k]); (void)hipFree(C16lo[k]);
         }
     }
     return 0;

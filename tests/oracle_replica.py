@@ -97,6 +97,16 @@ class OracleReplica(object):
         self.apply_adam(lr)
         return l if want_loss else None
 
+    def snapshot_state(self):
+        return dict(p={k: v.copy() for k, v in self.p.items()}, m={k: v.copy() for k, v in self.state["m"].items()},
+                    v={k: v.copy() for k, v in self.state["v"].items()}, t=int(self.state["t"]))
+
+    def restore_state(self, snap):
+        self.p = {k: v.copy() for k, v in snap["p"].items()}
+        self.state["m"] = {k: v.copy() for k, v in snap["m"].items()}
+        self.state["v"] = {k: v.copy() for k, v in snap["v"].items()}
+        self.state["t"] = snap["t"]
+
     def count_params(self):
         return int(sum(self.sizes))
 

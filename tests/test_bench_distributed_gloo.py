@@ -90,6 +90,14 @@ def test_bench_n_gt_1_branch_under_gloo(world, scaling):
     assert line["config"]["global_batch"] == (B * world if scaling == "weak" else B)
     assert line["config"]["parallelism"] == "dp%d" % world and line["unit"] == "sequences/s" and line["value"] > 0
     assert abs(line["value"] - line["config"]["global_batch"] * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
+    # the record verifies itself: the ranks of the process group, every rank's own clock, the exchange's cost beside a local step
+    d = line["distributed"]
+    assert d["process_group_ranks"] == world and d["backend"] == "gloo" and d["rccl_ranks"] is None       # (nccl would say = world)
+    assert len(d["per_rank_ms_per_step"]["all"]) == world
+    assert d["per_rank_ms_per_step"]["min"] <= d["per_rank_ms_per_step"]["max"] and d["per_rank_ms_per_step"]["max"] <= line["ms_per_step"] * (1 + 1e-9)
+    assert d["local_step_ms"] > 0 and d["exposed_allreduce_ms_per_step"] >= 0 and d["collectives_per_step"] >= 1
+    assert d["allreduce_bytes_per_step"] > 0
+    assert line["config"]["prewarm_steps"] == 0 and "inputs" in line["config"]
     for r in results[1:]:
         np.testing.assert_array_equal(r[3], results[0][3])                             # replicas in lock-step
     # the same job in one process: the union of the ranks' utterances, three steps (1 warm-up + 2 timed)

@@ -298,3 +298,70 @@ def test_bf16x3_adam_trajectory_and_clip_against_the_oracle(torch_cuda, lib):
         scales.append(a @ b / (b @ b))
     assert max(abs(sc - 1.0) for sc in scales) <= 0.1 and max(scales) - min(scales) <= 1e-3, scales
     m.close()
+
+
+def test_mixed_mode_forward_is_bf16x3_and_its_gradients_are_bf16_grade(torch_cuda, lib):
+    """ADN_PRECISION_MIXED (include/adenet.h): the forward pass -- encoder activations, probabilities, loss -- must equal
+    the bf16x3 mode's bit for bit (it IS that code path: same 1e-4 / exact-top-1 gate), and the gradients, whose GEMMs run one
+    bf16 product over the operands' hi planes, must sit inside the band the bf16 mode is held to, far outside bf16x3's."""
+    from ip_avsr_amd.model import AdeNetModel
+    spec = O.spec_nstream([1200, 1200, 1200])
+    B, T, theta = 10, 14, 9
+    rng = np.random.default_rng(1234)
+    p = O.init_params(spec, rng, np.float32, enc_std=0.01)
+    for k in p:
+        if k.endswith(".b"):
+            p[k] = rng.normal(0, 0.05, p[k].shape).astype(np.float32)
+    mask = ragged_mask(rng, B, T)
+    inputs = [(rng.normal(size=(B, T, 1200)) * mask[..., None]).astype(np.float32) for _ in range(3)]
+    y = np.repeat((np.arange(B) % 26)[:, None], T, axis=1).astype(np.int32)
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    x64 = [x.astype(np.float64) for x in inputs]
+    l_ref, g_ref, _ = O.loss_and_grads(spec, p64, x64, y, mask, theta)
+    got = {}
+    for prec in ("bf16x3", "mixed"):
+        m = AdeNetModel(spec)
+        m.set_precision(prec)
+        m.set_params_dict(p)
+        probs = m.predict(inputs, mask, theta)
+        acts = [m.encoder_activation(s, l, B, T) for s in range(3) for l in range(4)]
+        loss = m.compute_grads(inputs, y, mask, theta)
+        got[prec] = (probs, acts, loss, m.get_grads_dict())
+        m.close()
+    np.testing.assert_array_equal(got["mixed"][0], got["bf16x3"][0])
+    for a, b in zip(got["mixed"][1], got["bf16x3"][1]):
+        np.testing.assert_array_equal(a, b)
+    assert got["mixed"][2] == got["bf16x3"][2] and abs(got["mixed"][2] - l_ref) <= 1e-5 * abs(l_ref)
+    gscale = max(np.abs(v).max() for v in g_ref.values())
+    worst = {"bf16x3": 0.0, "mixed": 0.0}
+    for prec in worst:
+        for k in O.param_names(spec):
+            e = np.abs(got[prec][3][k] - g_ref[k]).max() / max(np.abs(g_ref[k]).max(), 1e-3 * gscale)
+            worst[prec] = max(worst[prec], e)
+    print("gradients against the fp64 oracle, worst tensor error of its scale: bf16x3 %.2e, mixed %.2e" % (worst["bf16x3"], worst["mixed"]))
+    assert worst["bf16x3"] <= 2e-4
+    assert 2e-4 < worst["mixed"] <= 3e-2          # one bf16 product per backward GEMM: bf16-grade, not fp32-grade
+
+
+def test_mixed_mode_train_steps_track_bf16x3(torch_cuda, lib):
+    """Six Adam steps at the bench geometry: the mixed mode's probabilities stay within 2e-3 of the bf16x3 mode's (the two
+    differ only by the rounding of the backward products) and the votes agree on >= 99 % of the utterances."""
+    import bench
+    from ip_avsr_amd.model import AdeNetModel
+    torch = torch_cuda
+    xs, y, m_d, mask = bench.synthetic_batch(torch, 0, 104, torch.device("cuda", 0))
+    out = {}
+    for prec in ("bf16x3", "mixed"):
+        m = AdeNetModel(bench.build_spec())
+        bench.synthetic_params(m)
+        m.set_precision(prec)
+        for _ in range(6):
+            m.train_step(xs, y, m_d, bench.THETA, 2e-3, want_loss=False)
+        out[prec] = m.predict(xs, m_d, bench.THETA)
+        m.close()
+    d = np.abs(out["mixed"] - out["bf16x3"]).max()
+    print("mixed vs bf16x3 after 6 steps: max |dp| = %.2e" % d)
+    assert d <= 2e-3
+    mk = mask if isinstance(mask, np.ndarray) else np.asarray(m_d.cpu())
+    v1, v2 = O.majority_vote(out["mixed"], mk), O.majority_vote(out["bf16x3"], mk)
+    assert (v1 == v2).mean() >= 0.99

@@ -106,6 +106,39 @@ def test_runner_end_to_end(tmp_path, n_streams, fusion, dropout):
     net.close()
 
 
+def test_avletters_two_stream_script_with_an_encoderless_stream(tmp_path):
+    """reference avletters/2stream.py on an INI whose second stream has ``has_encoder = False`` (:244, :265-286: adenet_v2 --
+    an encoder stream + a raw second stream): the iterVec train / val split (:230-231), no test split, the two-field
+    results line (:415) and the best-epoch checkpoint."""
+    from ip_avsr_amd.runners import nstream
+    from ip_avsr_amd.utils.io import load_model
+    root = str(tmp_path)
+    make_dataset(root, 2)
+    # the .mat files of the avletters scripts carry an iteration vector: utterances of iterations 1, 2 train, 3 validates
+    for k in (1, 2):
+        path = os.path.join(root, "s%d.mat" % k)
+        d = {key: v for key, v in sio.loadmat(path).items() if not key.startswith("__")}
+        d["iterVec"] = (np.arange(len(d["videoLengthVec"])) % 3 + 1)[:, None]
+        sio.savemat(path, d)
+    ini = "".join(INI.format(k=k, root=root, reorder=(k == 1), diff=False) + "has_encoder = %s\n" % (k == 1) for k in (1, 2))
+    ini += TAIL.format(root=root, fusion="sum", dropout=False) + "use_blstm_substream = False\n"
+    cfg = os.path.join(root, "cfg.ini")
+    open(cfg, "w").write(ini)
+    res_file, best_file = os.path.join(root, "results.csv"), os.path.join(root, "best.pkl")
+    out = nstream.main(2, ["--config", cfg, "--write_results", res_file, "--save_best", best_file, "--seed", "7"], variant="avletters")
+    net = out["network"]
+    assert len(net.spec["streams"][0]["enc_names"]) == 4 and net.spec["streams"][1]["enc_names"] == []
+    assert len(out["cost_val"]) >= 2 and np.isfinite(out["cost_val"]).all()
+    assert min(out["cost_val"]) < out["cost_val"][0] or out["best_cr"] >= 0.5
+    assert out["heldout"]["X_test"] is None and out["heldout"]["mask_val"].shape[0] == 16       # 48 utterances, every third
+    assert out["test_conf"].sum() == 16                       # the confusion matrix kept is the validation one
+    line = open(res_file).read().strip().split(",")
+    assert len(line) == 2 and abs(float(line[0]) - out["best_cr"]) < 1e-9
+    values = load_model(best_file)
+    assert len(values) == len(net.params)
+    net.close()
+
+
 def test_extract_tools_round_trip(tmp_path):
     """runners/extract_encoder_from_model.py / extract_lstm_from_model.py: a saved 1-stream model -> the .mat files the
     stream loaders (load_decoder) and create_pretrained_model read."""

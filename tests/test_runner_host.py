@@ -158,3 +158,43 @@ def test_epoch_loop_on_the_host_generators():
         assert frames == int(mb.sum()) and w == 3 and lr == 0.5
         assert np.array_equal(firsts[0], X1[:, 0, 0])
     assert [s[1][0] for s in net.steps[:3]] == [4, 4, 3]                          # 11 utterances: 4, 4, 3 (short), reshuffle
+
+
+def test_avletters_scripts_pick_their_network_from_has_encoder(monkeypatch):
+    """reference avletters/{1,2,3}stream.py read a ``has_encoder`` option per stream (schema 1 of SURVEY App. B as those
+    scripts use it): an encoder-less single stream is deltanet_v1 (:213-238), an encoder-less SECOND stream of the 2-stream
+    script is adenet_v2 (:265-286); the 3-stream script only builds a network when stream 2 has an encoder (:278) and needs
+    ae1 / ae3 in every branch -- there this package raises instead of the reference's NameError."""
+    import pytest
+    from ip_avsr_amd.modelzoo import _factory as F
+    from ip_avsr_amd.runners.nstream import build_network_avletters
+    monkeypatch.setattr(F, "SPEC_ONLY", True)
+    rng = np.random.default_rng(0)
+    dims = [24, 16, 12, 8, 5]
+    loaded = []
+
+    def load_ae(k):
+        loaded.append(k)
+        return ([rng.normal(size=(a, b)).astype(np.float32) for a, b in zip(dims[:-1], dims[1:])],
+                [np.zeros(b, np.float32) for b in dims[1:]], dims[1:], ["rectify", "rectify", "rectify", "linear"])
+    cfg = dict(weight_init_fn="glorot", use_peepholes=False, lstm_size=6, output_classes=4, fusiontype="sum", use_blstm=True,
+               use_blstm_substream=False)
+    spec = build_network_avletters(1, [False], load_ae, [24], [None], cfg)[0]
+    assert loaded == [] and spec["streams"][0]["enc_names"] == [] and spec["streams"][0]["delta"]
+    assert spec["streams"][0]["lstm_names"] == ["f_lstm", "b_lstm"]
+    spec = build_network_avletters(1, [True], load_ae, [24], [None], cfg)[0]
+    assert loaded == [0] and len(spec["streams"][0]["enc_names"]) == 4
+    del loaded[:]
+    spec, _ = build_network_avletters(2, [True, False], load_ae, [24, 9], [None, None], cfg)
+    assert loaded == [0]                                     # stream 2's encoder file is never opened (avletters/2stream.py:248)
+    assert len(spec["streams"][0]["enc_names"]) == 4 and spec["streams"][1]["enc_names"] == [] and spec["streams"][1]["input_dim"] == 9
+    spec, _ = build_network_avletters(2, [True, True], load_ae, [24, 24], [None, None], cfg)
+    assert all(len(s["enc_names"]) == 4 for s in spec["streams"])
+    spec, _ = build_network_avletters(3, [True, True, True], load_ae, [24, 24, 24], [None, None, None], dict(cfg, fusiontype="concat"))
+    assert len(spec["streams"]) == 3 and spec["fusion"] == "concat"
+    with pytest.raises(ValueError, match="stream2"):
+        build_network_avletters(3, [True, False, True], load_ae, [24, 9, 24], [None, None, None], cfg)
+    with pytest.raises(ValueError, match="ae3"):
+        build_network_avletters(3, [True, True, False], load_ae, [24, 24, 9], [None, None, None], cfg)
+    with pytest.raises(ValueError, match="ae1"):
+        build_network_avletters(2, [False, True], load_ae, [24, 24], [None, None], cfg)

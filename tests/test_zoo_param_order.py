@@ -137,3 +137,40 @@ def test_unimodal_scripts_encoder_factory(spec_only):
                                                      'sigmoid')
     assert F.param_names(spec) == enc("") + lstm("f_blstm1") + lstm("b_blstm1") + ["softmax.W", "softmax.b"]
     assert spec["streams"][0]["enc_acts"] == ["sigmoid", "sigmoid", "sigmoid", "linear"] and spec["fusion"] == "none"
+
+
+def test_adenet_v3_layer_order_matches_the_notebooks_recorded_print_network(spec_only):
+    """The only record of Lasagne's ``get_all_layers`` order inside /root/reference: the print-out of ``adenet_v3`` kept in
+    avletters/avletters_training.ipynb (tests/golden/adenet_v3_layers.json, made by tests/golden/make_adenet_v3_layers.py).
+    The zoo module must list the same layers in the same order with the same widths -- 500-unit LSTMs for the call's
+    ``lstm_size`` 250, 'output' of 26 -- and the checkpoint (pickle) order must be that list restricted to the layers that
+    own parameters: raw encoder, lstm_raw, lstm_dct, diff encoder, lstm_diff, aggregation, output."""
+    import json
+    import os
+    from ip_avsr_amd.modelzoo import adenet_v3
+    rec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "adenet_v3_layers.json")))
+    dims = {l["name"]: l["shape"][-1] for l in rec["layers"]}
+
+    class Net(object):
+        def __init__(self, d):
+            sizes = [d, dims["fc1_raw"], dims["fc2_raw"], dims["fc3_raw"], dims["bottleneck_raw"]]
+            self.layers = [None] + [_Layer(np.zeros((a, b), np.float32), np.zeros(b, np.float32)) for a, b in zip(sizes[:-1], sizes[1:])]
+
+        def get_all_layers(self):
+            return self.layers
+
+    spec, _ = adenet_v3.create_model(Net(dims["raw_im"]), Net(dims["diff_im"]), (None, None, dims["raw_im"]), None, (None, None), None,
+                                     (None, None, dims["dct"]), None, (None, None, dims["diff_im"]), None,
+                                     rec["lstm_size_argument"], None, rec["output_classes_argument"], "sum")
+    got = [(n, list(shape)) for n, shape in F.layer_listing(spec)]
+    want = [(l["name"], l["shape"]) for l in rec["layers"]]
+    assert got == want
+    assert dims["lstm_raw"] == 2 * rec["lstm_size_argument"] == dims["f_lstm_agg"] and dims["output"] == 26
+    # the checkpoint order = the recorded layer order, parameterised layers only
+    owners = []
+    for n in F.param_names(spec):
+        layer = n.split(".")[0]
+        if not owners or owners[-1] != layer:
+            owners.append(layer)
+    recorded = [l["name"] for l in rec["layers"] if l["name"].startswith(("fc", "bottleneck", "lstm", "f_lstm", "b_lstm", "output"))]
+    assert owners == recorded
