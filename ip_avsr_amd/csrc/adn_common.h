@@ -145,8 +145,8 @@ int transpose_to_bf16(const float* W, int rows, int cols, int ld, void* out, int
 bool gemm_nt_astat_takes(int M, int N, int K, int lda, int ldb, int ldc, const void* A16, const void* B16, const void* C16);
 int gemm_nt_astat(const void* A16, int lda, const void* B16, int ldb, void* C16, int ldc, int M, int N, int K, hipStream_t s);
 // several column sums in one launch (out[c] += sum_r in[r][c]); items by value in the kernel arguments
-struct ColSumItem { const float* in; float* out; int ld, rows, cols, ctiles, splits, rps, block_end; };
-struct ColSumBatch { ColSumItem it[8]; int n = 0; };
+struct ColSumItem { const float* in; float* out; int ld, rows, cols, ctiles, splits, rps, block_end, ws_off; };
+struct ColSumBatch { ColSumItem it[8]; int n = 0; float* ws = nullptr; };      // ws: deterministic mode's per-split partial sums
 void col_sum_batch_add(ColSumBatch& b, const float* in, int ld, int rows, int cols, float* out);
 int col_sum_batch(ColSumBatch& b, hipStream_t s);          // launches (if any item is pending) and clears the batch
 

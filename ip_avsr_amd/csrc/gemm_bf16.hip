@@ -289,7 +289,8 @@ __device__ __forceinline__ void store_tile16(const GemmParams& p, const f32x4& a
         float* c = p.C + (size_t)row * p.ldc + col;
         if (p.atomic) {
             if (p.Y) v *= act_grad_from_output(p.act_grad, p.Y[(size_t)row * p.ldy + col]);
-            atomicAdd(c, v);
+            if (p.partial) p.partial[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * p.M + row) * p.ldc + col] = v;
+            else atomicAdd(c, v);
         } else {
             v = act_apply(p.act, v);
             if (p.Y) v *= act_grad_from_output(p.act_grad, p.Y[(size_t)row * p.ldy + col]);
@@ -437,7 +438,10 @@ __device__ __forceinline__ void tile_epilogue_atomic(const GemmParams& p, f32x4 
             float v = strip[lr * LW + c];
             if (row >= p.M || col >= p.N) continue;
             if (p.Y) v *= act_grad_from_output(p.act_grad, p.Y[(size_t)row * p.ldy + col]);
-            atomicAdd(p.C + (size_t)row * p.ldc + col, v);
+            // (deterministic mode: this (problem, K-slice)'s slab, plain stores; added in slice order by rs_splitk_reduce_kernel.
+            //  `p` is the group's view here: p.C was re-pointed, p.partial is the launch's)
+            if (p.partial) p.partial[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * p.M + row) * p.ldc + col] = v;
+            else atomicAdd(p.C + (size_t)row * p.ldc + col, v);
         }
     };
     slice(std::integral_constant<int, 0>{});

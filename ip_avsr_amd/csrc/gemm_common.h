@@ -105,7 +105,10 @@ __device__ __forceinline__ void store_tile32(const GemmParams& p, const f32x16& 
         float* c = p.C + (size_t)row * p.ldc + col;
         if (p.atomic) {
             if (p.Y) v *= act_grad_from_output(p.act_grad, p.Y[(size_t)row * p.ldy + col]);
-            atomicAdd(c, v);
+            // deterministic mode: the partial tile goes into this (problem, K-slice)'s slab with plain stores; a fixed-order
+            // pass adds the slabs (rs_splitk_reduce_kernel)
+            if (p.partial) p.partial[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * p.M + row) * p.ldc + col] = v;
+            else atomicAdd(c, v);
         } else {
             v = act_apply(p.act, v);
             if (p.Y) v *= act_grad_from_output(p.act_grad, p.Y[(size_t)row * p.ldy + col]);

@@ -157,6 +157,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
             store_tile32(p, acc[a][b], m0 + wm * WTM + a * 32, n0 + wn * WTN + b * 32, lane, first_split);
 }
 
+// deterministic split-K of the register-staged kernels: C (+)= the K-slices' slabs ([problem][slice][M][ldc]) in slice order
+struct RsReduceArgs { float* C[kMaxGemmGroups]; };
+__global__ __launch_bounds__(256) void rs_splitk_reduce_kernel(const RsReduceArgs a, const float* __restrict__ partial, int M, int N, int ldc,
+                                                               int splits, int accumulate) {
+    const int g = blockIdx.z;
+    float* C = g == 0 ? a.C[0] : g == 1 ? a.C[1] : g == 2 ? a.C[2] : a.C[3];
+    const float* part = partial + (size_t)g * splits * M * ldc;
+    const size_t slab = (size_t)M * ldc;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)M * N; e += (int64_t)gridDim.x * 256) {
+        const size_t i = (size_t)(e / N) * ldc + (size_t)(e % N);
+        float v = accumulate ? C[i] : 0.f;
+        for (int s = 0; s < splits; ++s) v += part[(size_t)s * slab + i];
+        C[i] = v;
+    }
+}
+
 template <int BM, int BN>
 static void launch(const GemmParams& p, int layout, dim3 grid, hipStream_t s) {
     switch (layout) {
@@ -653,20 +669,27 @@ static int gemm_rs(const GemmArgs* gs, int n, hipStream_t stream) {
     // split-K: enough workgroups for two per CU (measured on the weight-gradient shapes: 512 beats 768 / 1024 by 0-12 %,
     // fewer partial sums to add atomically; 256 leaves CUs idle on the large ones)
     static const int split_target = getenv("ADN_GEMM_SPLIT_TARGET") ? atoi(getenv("ADN_GEMM_SPLIT_TARGET")) : 512;
-    if (tiles < 384 && g.K >= 512 && can_split && !lean_c && !g.no_split && !deterministic()) {      // (partial sums meet in float atomics)
+    // (partial sums meet in float atomics -- or, in deterministic mode, in per-slice slabs that a fixed-order pass adds: the
+    //  mode then keeps the split where the caller's slab workspace holds the launch's slices, and runs unsplit otherwise)
+    if (tiles < 384 && g.K >= 512 && can_split && !lean_c && !g.no_split) {
         split = (int)((split_target + tiles - 1) / tiles);
         split = std::min(split, g.K / 128);
         split = std::max(1, std::min(split, 128));
     }
     p.k_chunk = (int)round_up(cdiv(g.K, split), BK);
     split = cdiv(g.K, p.k_chunk);
+    p.partial = nullptr;
+    if (split > 1 && deterministic()) {
+        if (g.splitk_ws && (size_t)n * split * g.M * g.ldc <= g.splitk_ws_floats) p.partial = g.splitk_ws;
+        else { split = 1; p.k_chunk = (int)round_up(g.K, BK); }
+    }
     p.atomic = split > 1;
     if (p.atomic) p.C16 = nullptr;            // partial sums: the bf16 copy is made after the kernel (below)
     if (g.precision == ADN_PRECISION_BF16 && p.A16 && p.B16)
         ADN_CHECK(g.lda % 8 == 0 && g.ldb % 8 == 0, ADN_ERR_INVALID, "gemm: bf16 shadows need lda/ldb % 8 == 0");
     ProfScope prof(PROF_GEMM_NN + g.layout, 2.0 * g.M * g.N * g.K * n,
                    4.0 * n * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N), stream);
-    if (p.atomic && !g.accumulate)
+    if (p.atomic && !g.accumulate && !p.partial)
         for (int k = 0; k < n; ++k)
             ADN_HIP_CHECK(hipMemset2DAsync(gs[k].C, (size_t)g.ldc * 4, 0, (size_t)g.N * 4, g.M, stream));
     if (lean_c)
@@ -712,6 +735,14 @@ static int gemm_rs(const GemmArgs* gs, int n, hipStream_t stream) {
     else if (big) launch<128, 128>(p, g.layout, grid, stream);
     else launch<64, 64>(p, g.layout, grid, stream);
     ADN_HIP_CHECK(hipGetLastError());
+    if (p.partial) {                              // deterministic split-K: C (+)= slab 0 + slab 1 + ... in that order
+        RsReduceArgs ra;
+        for (int k = 0; k < n; ++k) ra.C[k] = gs[k].C;
+        const int64_t work = (int64_t)g.M * g.N;
+        hipLaunchKernelGGL(rs_splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>(2048, (work + 255) / 256), 1, (unsigned)n), dim3(256), 0, stream,
+                           ra, p.partial, g.M, g.N, g.ldc, split, g.accumulate);
+        ADN_HIP_CHECK(hipGetLastError());
+    }
     for (int k = 0; k < n; ++k) {
         const GemmArgs& q = gs[k];
         if (fused_colsum) {

