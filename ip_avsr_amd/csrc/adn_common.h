@@ -118,6 +118,9 @@ struct GemmArgs {
     // ... and the result's own planes: C16 (hi) and C16lo, written by the kernel that multiplies over planes; *planes_done reports
     // whether they were (otherwise the caller splits C itself)
     void* C16lo = nullptr; int* planes_done = nullptr;
+    // B as a k-contiguous [N][K] bf16 matrix (hi / lo planes), leading dimension ldbkc: for an NN problem the transposed copy of the
+    // weights the model keeps, for an NT problem B itself.  The skinny kernels (gemm_skinny.hip) read B in this form
+    const void* Bkc16 = nullptr; const void* Bkc16lo = nullptr; int ldbkc = 0;
     int hi_product = 0;                // ADN_PRECISION_MIXED, back-propagation: ONE bf16 product over the hi planes (A16 / B16 given,
                                        // no lo planes, precision = bf16) whose result is still offered as planes (C16 / C16lo, lean_ok)
     int b_pad_zero = 0;                // the columns of B behind N (up to ldb) hold zeros: a kernel may then compute (and write zeros
@@ -132,6 +135,8 @@ struct GemmArgs {
     float* splitk_ws = nullptr; size_t splitk_ws_floats = 0;
 };
 int gemm(const GemmArgs& g, hipStream_t stream);
+// streaming kernels for the skinny shapes (N <= 64 / K <= 64 / narrow weight gradients); *used says whether one took the launch
+int gemm_skinny_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used, bool dry);
 constexpr int kMaxGemmGroups = 4;
 // n <= kMaxGemmGroups problems of identical shape, layout and flags (different buffers) as ONE launch where the persistent kernel
 // applies (their tiles share one list: fuller last round); otherwise n launches

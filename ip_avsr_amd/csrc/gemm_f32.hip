@@ -429,6 +429,7 @@ static bool rs_groupable(const GemmArgs* gs, int n);
 bool gemm_planes_would_run(const GemmArgs* gs, int n) {
     bool used = false;
     if (n < 1 || n > kMaxGemmGroups) return false;
+    if (gs[0].precision == ADN_PRECISION_BF16X3 && gemm_skinny_try(gs, n, nullptr, &used, /*dry=*/true) == ADN_OK && used) return true;
     if (x3_try_planes(gs, n, nullptr, &used, /*dry=*/true) != ADN_OK) return false;
     return used;
 }
@@ -436,6 +437,11 @@ bool gemm_planes_would_run(const GemmArgs* gs, int n) {
 int gemm_grouped(const GemmArgs* gs, int n, hipStream_t stream) {
     if (n <= 0) return ADN_OK;
     if (gs[0].M <= 0 || gs[0].N <= 0) return ADN_OK;
+    if (n <= kMaxGemmGroups) {                     // the skinny shapes: streaming kernels (gemm_skinny.hip)
+        bool used = false;
+        ADN_TRY(gemm_skinny_try(gs, n, stream, &used, false));
+        if (used) return ADN_OK;
+    }
     if (n >= 1 && n <= kMaxGemmGroups && gs[0].precision == ADN_PRECISION_BF16X3) {       // over the operands' planes first
         bool used = false;
         ADN_TRY(x3_try_planes(gs, n, stream, &used, false));
@@ -778,6 +784,11 @@ int gemm(const GemmArgs& g, hipStream_t stream) {
     ADN_CHECK(g.layout >= GEMM_NN && g.layout <= GEMM_TN, ADN_ERR_INVALID, "gemm: bad layout");
     if (g.M <= 0 || g.N <= 0) return ADN_OK;
     ADN_CHECK(g.K > 0, ADN_ERR_INVALID, "gemm: K must be positive");
+    {
+        bool used = false;
+        ADN_TRY(gemm_skinny_try(&g, 1, stream, &used, false));
+        if (used) return ADN_OK;
+    }
     if (g.precision == ADN_PRECISION_BF16X3) {
         {                                      // over the operands' planes wherever the ping-pong kernel takes the shape ...
             bool used = false;

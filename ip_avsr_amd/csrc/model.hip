@@ -519,7 +519,10 @@ size_t carve(adn_model* m, char* base, int B, int T, bool host_inputs) {
             if (st.cfg.n_enc > 1) {
                 st.pingA = take_shadowed(m, cv, N * w);
                 st.pingB = take_shadowed(m, cv, N * w);
-                st.colsum_ws_floats = (size_t)cdiv((int)N, 64) * w;      // per layer: the reductions are batched
+                // per layer (the reductions are batched): one row of partial sums per 64 rows -- the register-staged kernels' 64-row
+                // tiles, the persistent kernels' 4 wave rows per 256-row tile, whose last tile may add up to 3 rows more
+                // (N = 5200: 84 rows against 82: the fused bias gradient was declined and the lean dZ had no sums -- B = 130)
+                st.colsum_ws_floats = (size_t)(cdiv((int)N, 64) + 4) * w;
                 st.colsum_ws = cv.take<float>(st.colsum_ws_floats * st.cfg.n_enc);
             }
         }
@@ -682,6 +685,14 @@ void mgemm_prepare(adn_model* m, GemmArgs& g, bool lean) {
         // like in bf16 mode).  Values and products stay fp32-grade; only the mask's carrier changes.
         if (g.act == ADN_ACT_RECTIFY && g.C && !g.accumulate) g.C16 = m->shadow_of(g.C);
         if (g.Y && g.act_grad == ADN_ACT_RECTIFY) g.Y16 = m->shadow_of(g.Y);
+    }
+    // B as a k-contiguous [N][K] matrix for the skinny kernels (gemm_skinny.hip): an NT problem's B is that already (the weights
+    // of dX = dZ W^T), an NN problem's is the transposed copy of its weights where the model keeps one
+    if (shadows_on(m) || m->planes()) {
+        if (g.layout == GEMM_NT) { g.Bkc16 = m->shadow_of(g.B); g.Bkc16lo = m->planes() ? m->shadow_lo_of(g.B) : nullptr; g.ldbkc = g.ldb; }
+        else if (g.layout == GEMM_NN)
+            for (const auto& t : m->transw)
+                if (t.key == g.B) { g.Bkc16 = t.buf; g.Bkc16lo = m->planes() ? t.buf + m->transw_slab_bytes : nullptr; g.ldbkc = t.ldT; break; }
     }
     if (m->planes()) {
         // every GEMM operand of this mode has its two planes (refresh() behind non-GEMM producers, planes_of_output() behind

@@ -73,6 +73,9 @@ int main(int argc, char** argv) {
         // as GEMMs at batch 1024 (rows = B x OH x OW; N = filters; K = kh kw C_in)
         {"narrow dfeat N=150", GEMM_NN, R, 150, 1000, 0, 0, 0, 0, 0},
         {"narrow fwd bn N=50", GEMM_NN, R, 50, 500, 0, 0, 0, 0, 1},
+        {"narrow fwd cls N=26", GEMM_NN, R, 26, 250, 0, 0, 0, 0, 0},
+        {"narrow dX cls K=26", GEMM_NN, R, 250, 26, 0, 0, 0, 0, 0},
+        {"narrow dW cls TN acc", GEMM_TN, 250, 26, R, 0, 1, 0, 0, 0},
         {"narrow cae conv3 N=152", GEMM_NN, 129024, 152, 2504, 0, 0, 0, 0, 1},
         {"narrow cae conv5 N=200", GEMM_NN, 15360, 200, 1368, 0, 0, 0, 0, 1},
         {"narrow cae deconv13 N=104", GEMM_NN, 338 * 1024, 104, 3800, 0, 0, 0, 0, 0},
@@ -118,7 +121,9 @@ int main(int argc, char** argv) {
         const int ldc = pad(c.N);
         const size_t wsf = (size_t)((c.M + 63) / 64 + 8) * ldc;
         float *A[4], *B[4], *C[4], *Y[4], *bias[4], *cs[4], *ws[4];
-        void *A16[4], *B16[4], *C16[4], *Y16[4], *A16lo[4], *B16lo[4], *C16lo[4];
+        void *A16[4], *B16[4], *C16[4], *Y16[4], *A16lo[4], *B16lo[4], *C16lo[4], *BT16[4], *BT16lo[4];
+        float* BT[4];
+        const int ldbt = pad(c.K);                 // B^T [N][K] k-contiguous (NN cases): what the skinny kernels read
         const bool planes = getenv("LAB_PLANES") != nullptr;       // bf16x3 over hi / lo planes (the product path of that mode)
         int pdone[4] = {0, 0, 0, 0}, skipped[4] = {0, 0, 0, 0};
         GemmArgs g[4];
@@ -133,6 +138,16 @@ int main(int argc, char** argv) {
             if (planes) { split_hilo(A[k], A16[k], A16lo[k], (size_t)ar * ac / 8 * 8, st); split_hilo(B[k], B16[k], B16lo[k], (size_t)br * bc / 8 * 8, st); }
             else { to_bf16(A[k], A16[k], (size_t)ar * ac, st); to_bf16(B[k], B16[k], (size_t)br * bc, st); }
             to_bf16(Y[k], Y16[k], (size_t)c.M * ldc, st);
+            BT[k] = nullptr; BT16[k] = BT16lo[k] = nullptr;
+            if (c.layout == GEMM_NN && (c.N <= 64 || c.K <= 64)) {
+                std::vector<float> hb((size_t)br * bc), hbt((size_t)c.N * ldbt, 0.f);
+                CK(hipMemcpy(hb.data(), B[k], hb.size() * 4, hipMemcpyDeviceToHost));
+                for (int kk = 0; kk < c.K; ++kk) for (int j = 0; j < c.N; ++j) hbt[(size_t)j * ldbt + kk] = hb[(size_t)kk * bc + j];
+                CK(hipMalloc((void**)&BT[k], hbt.size() * 4 + 64)); CK(hipMemcpy(BT[k], hbt.data(), hbt.size() * 4, hipMemcpyHostToDevice));
+                CK(hipMalloc(&BT16[k], hbt.size() * 2 + 64)); CK(hipMalloc(&BT16lo[k], hbt.size() * 2 + 64));
+                if (planes) split_hilo(BT[k], BT16[k], BT16lo[k], hbt.size() / 8 * 8, st);
+                else to_bf16(BT[k], BT16[k], hbt.size() / 8 * 8, st);
+            }
             GemmArgs& q = g[k];
             q.layout = c.layout; q.M = c.M; q.N = c.N; q.K = c.K; q.A = A[k]; q.lda = ac; q.B = B[k]; q.ldb = bc;
             q.C = c.lean ? nullptr : C[k]; q.ldc = ldc; q.accumulate = c.acc; q.precision = ADN_PRECISION_BF16;
@@ -142,6 +157,7 @@ int main(int argc, char** argv) {
             if (c.biasrelu) { q.bias = bias[k]; q.act = ADN_ACT_RECTIFY; }
             if (c.layout != GEMM_TN) q.no_split = 1;
             q.splitk_ws = wsk; q.splitk_ws_floats = wsk_floats;
+            if (BT16[k]) { q.Bkc16 = BT16[k]; q.Bkc16lo = planes ? BT16lo[k] : nullptr; q.ldbkc = ldbt; }
             if (planes) {
                 q.precision = ADN_PRECISION_BF16X3; q.C = C[k]; q.lean_ok = c.lean; q.A16lo = A16lo[k]; q.B16lo = B16lo[k];
                 q.C16lo = (c.layout == GEMM_TN) ? nullptr : C16lo[k]; q.planes_done = &pdone[k]; q.fp32_skipped = &skipped[k];
@@ -251,6 +267,7 @@ int main(int argc, char** argv) {
             (void)hipFree(A[k]); (void)hipFree(B[k]); (void)hipFree(C[k]); (void)hipFree(Y[k]); (void)hipFree(bias[k]); (void)hipFree(cs[k]);
             (void)hipFree(ws[k]); (void)hipFree(A16[k]); (void)hipFree(B16[k]); (void)hipFree(C16[k]); (void)hipFree(Y16[k]);
             (void)hipFree(A16lo[k]); (void)hipFree(B16lo[k]); (void)hipFree(C16lo[k]);
+            if (BT[k]) { (void)hipFree(BT[k]); (void)hipFree(BT16[k]); (void)hipFree(BT16lo[k]); }
         }
     }
     return 0;

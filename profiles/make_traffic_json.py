@@ -19,8 +19,9 @@ import sys
 
 def per_kernel(path, match):
     tot, n = collections.Counter(), collections.Counter()
+    matches = match if isinstance(match, (tuple, list)) else (match,)
     for r in csv.DictReader(open(path)):
-        if match in r["Kernel_Name"]:
+        if any(mm in r["Kernel_Name"] for mm in matches):
             tot[r["Counter_Name"]] += float(r["Counter_Value"])
             n[r["Counter_Name"]] += 1
     return tot, n
@@ -47,13 +48,14 @@ def main():
     fa, fb, prec = sys.argv[1:4]
     commit = sys.argv[4] if len(sys.argv) > 4 else "unknown"
     train_steps = int(sys.argv[5]) if len(sys.argv) > 5 else 4
-    match = "gemm_bf16" if prec in ("bf16", "bf16x3") else "gemm_f32_kernel"      # (gemm_bf16_kernel and gemm_bf16_pp_kernel)
-    out = {"kernel_class": "%s (all instantiations)" % match, "commit": "PMC passes taken at commit %s" % commit,
+    # (gemm_bf16_kernel and gemm_bf16_pp_kernel; over planes also the fused-plane kernel gemm_x3f_kernel)
+    match = ("gemm_bf16", "gemm_x3f") if prec in ("bf16", "bf16x3", "mixed") else ("gemm_f32_kernel",)
+    out = {"kernel_class": "%s (all instantiations)" % " + ".join(match), "commit": "PMC passes taken at commit %s" % commit,
            "train_steps": train_steps}
     out.update(summarise(fa, fb, match, train_steps))
     # the LSTM kernels: one launch covers all T time steps of up to 3 LSTMs (bench.py divides the bytes of a train step by
     # the LSTM time steps of a train step)
-    lstm = {"bf16": "lstm_%s_cluster_kernel", "bf16x3": "lstm_%s_cluster_x3_kernel"}.get(prec, "lstm_%s_step_kernel")
+    lstm = {"bf16": "lstm_%s_cluster_kernel", "bf16x3": "lstm_%s_cluster_x3_kernel", "mixed": "lstm_%s_cluster_x3_kernel"}.get(prec, "lstm_%s_step_kernel")
     for key, m in (("lstm_fwd", lstm % "fwd"), ("lstm_bwd", lstm % "bwd")):
         d = summarise(fa, fb, m, train_steps)
         if d["launches"]:

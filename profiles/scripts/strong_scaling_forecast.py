@@ -22,10 +22,13 @@ HEAD, TAIL, LAT = 43e6, 29e6, 30e-6
 
 def step_ms(batch):
     env = dict(os.environ, ADN_BENCH_B=str(batch))
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--precision", prec, "--steps", "20", "--warmup", "5",
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--precision", prec, "--steps", "20", "--warmup", "5",
                           "--no-cpu-baseline", "--accurate-precision", "none", "--no-runner", "--no-reference-minibatch", "--no-profile"],
-                         env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout.strip().splitlines()[-1]
-    return json.loads(out)["ms_per_step"]
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    lines = [l for l in res.stdout.strip().splitlines() if l.startswith("{")]
+    if not lines:
+        raise SystemExit("bench.py failed at B = %d:\n%s" % (batch, res.stderr[-2000:]))
+    return json.loads(lines[-1])["ms_per_step"]
 
 
 t = {b: step_ms(b) for b in (520, 260, 130, 65)}

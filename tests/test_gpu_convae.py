@@ -192,6 +192,65 @@ def test_conv_encoder_as_the_front_end_of_a_stream(ConvAE):
     model.close(); ref.close(); net.close()
 
 
+def test_conv_front_end_in_the_four_stream_512_unit_model_against_the_oracle(ConvAE):
+    """BASELINE configs[4] as one graph: runners/4stream.py's adenet_4stream (concat fusion, 512-unit stream LSTMs and BLSTM)
+    with the mouth-ROI stream entering through the (frozen) conv auto-encoder's bottleneck instead of a dense encoder.
+    Forward probabilities, loss and every gradient against the fp64 oracle of the SAME 4-stream graph fed the oracle-side
+    conv codes (oracle/convae_oracle.py -> oracle/adenet_oracle.py): f32 and bf16x3 arithmetic inside the 1e-4 gate, identical
+    votes; bf16 tracks."""
+    from ip_avsr_amd.modelzoo import adenet_4stream, avletters_convae
+    from oracle import adenet_oracle as O
+    hw = (22, 28)
+    D = hw[0] * hw[1]
+    rng = np.random.default_rng(77)
+    pc = CO.init_params(rng, np.float32, dense=32, bottleneck=12, image_hw=hw, bias_noise=0.05)
+    net, bottleneck = avletters_convae.create_model((None, 1) + hw, {"DENSE": 32, "BOTTLENECK": 12})
+    net.set_params_dict(pc)
+
+    def dense(d_in):
+        dims = [d_in, 48, 24, 10]
+        return ([rng.normal(0, 0.2, (a, b)).astype(np.float32) for a, b in zip(dims[:-1], dims[1:])],
+                [rng.normal(0, 0.05, b).astype(np.float32) for b in dims[1:]], dims[1:], ["rectify", "rectify", "linear"])
+    dims = [D, 36, 44, 30]
+    aes = [bottleneck, dense(36), dense(44), dense(30)]
+    shapes = [(None, None, d) for d in dims]
+    model, _ = adenet_4stream.create_model(aes[0], aes[1], aes[2], aes[3], shapes[0], None, shapes[1], None, shapes[2], None,
+                                           shapes[3], None, (None, None), None, 512, None, 10, "concat", w_init_fn="glorot",
+                                           use_peepholes=True)
+    # the same graph for the oracle: stream 1 is an encoder-less 12-d stream fed the conv codes
+    spec = O.spec_nstream([12, 36, 44, 30], enc_shapes=(48, 24, 10), enc_acts=("rectify", "rectify", "linear"), lstm_size=512,
+                          classes=10, fusion="concat", has_encoder=[False, True, True, True], peepholes=True)
+    names = O.param_names(spec)
+    got_names = [p.name for p in model.params]
+    assert len(names) == len(got_names)
+    p64 = {n: np.asarray(model.get_param(g), np.float64) for n, g in zip(names, got_names)}
+    B, T, theta = 5, 8, 3
+    lens = np.array([8, 5, 8, 3, 6])
+    mask = (np.arange(T)[None, :] < lens[:, None]).astype(np.uint8)
+    frames = (rng.normal(size=(B, T, D)) * mask[..., None]).astype(np.float32)
+    others = [(rng.normal(size=(B, T, d)) * mask[..., None]).astype(np.float32) for d in dims[1:]]
+    y = np.repeat(rng.integers(0, 10, size=(B, 1)), T, axis=1).astype(np.int32)
+    pc64 = {k: v.astype(np.float64) for k, v in pc.items()}
+    _, codes = CO.forward(pc64, frames.reshape(B * T, D).astype(np.float64), hw)
+    x64 = [codes.reshape(B, T, 12)] + [x.astype(np.float64) for x in others]
+    probs_ref = O.forward(spec, p64, x64, mask, theta)
+    l_ref, g_ref, _ = O.loss_and_grads(spec, p64, x64, y, mask, theta)
+    gscale = max(np.abs(v).max() for v in g_ref.values())
+    for prec, tol_p, tol_g in (("f32", 1e-4, 2e-4), ("bf16x3", 1e-4, 2e-4), ("bf16", 3e-2, None)):
+        model.set_precision(prec)
+        probs = model.predict([frames] + others, mask, theta)
+        assert np.abs(probs - probs_ref).max() <= tol_p, prec
+        if prec != "bf16":
+            np.testing.assert_array_equal(O.majority_vote(probs, mask), O.majority_vote(probs_ref, mask))
+        l = model.compute_grads([frames] + others, y, mask, theta)
+        assert abs(l - l_ref) <= (2e-2 if prec == "bf16" else 2e-5) * abs(l_ref), prec
+        if tol_g:
+            g = model.get_grads_dict()
+            for n, gn in zip(names, got_names):
+                assert np.abs(g[gn] - g_ref[n]).max() <= tol_g * max(np.abs(g_ref[n]).max(), 1e-3 * gscale), (prec, n)
+    model.close(); net.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # BatchNorm / dropout variants (modelzoo/avletters_convae_{bn,drop,bndrop}.py)
 # ---------------------------------------------------------------------------------------------------------------------
