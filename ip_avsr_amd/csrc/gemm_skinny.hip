@@ -477,9 +477,9 @@ int gemm_skinny_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used, b
     std::memset(static_cast<void*>(&p), 0, sizeof(p));
     p.M = g.M; p.N = g.N; p.K = g.K; p.lda = g.lda; p.ldc = g.ldc; p.ldy = g.ldy; p.act = g.act; p.accumulate = g.accumulate;
     static const bool trace = getenv("ADN_GEMM_TRACE") != nullptr;
-    auto say = [&](const char* kind, int split) {
+    auto say = [&](int kind, int split) {        // (tile codes of profiles/gemm_breakdown.py: 1001 skinny_nn, 1002 skinny_nk, 1003 skinny_tn)
         if (trace)
-            fprintf(stderr, "ADN_GEMM %s M=%d N=%d K=%d tile=%s tiles=%d split=%d shadows=1 lean=%d acc=%d groups=%d%s\n",
+            fprintf(stderr, "ADN_GEMM %s M=%d N=%d K=%d tile=%d tiles=%d split=%d shadows=1 lean=%d acc=%d groups=%d%s\n",
                     g.layout == GEMM_TN ? "TN" : "NN", g.M, g.N, planes ? 3 * g.K : g.K, kind, 0, split, (int)(g.C == nullptr || g.lean_ok), g.accumulate, n,
                     planes ? " planes=1" : "");
     };
@@ -513,7 +513,7 @@ int gemm_skinny_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used, b
         const int NT = g.N <= 32 ? 2 : 4;
         const size_t lds = (size_t)(planes ? 2 : 1) * 16 * NT * kNnLdsStride * 2;
         const dim3 grid((unsigned)cdiv(g.M, 256), (unsigned)n);
-        say("skinny_nn", 1);
+        say(1001, 1);
         ProfScope prof(PROF_GEMM_NN, 2.0 * g.M * g.N * (planes ? 3.0 : 1.0) * g.K * n, 4.0 * n * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N), stream, n);
 #define ADN_SK_NN(NTv, PL) do { \
         static bool attr_done = false; \
@@ -561,7 +561,7 @@ int gemm_skinny_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used, b
         }
         const int nchunks = cdiv(cdiv(g.N, 16), kNkTC);
         const dim3 grid((unsigned)(cdiv(g.M, 256) * nchunks), (unsigned)n);
-        say("skinny_nk", 1);
+        say(1002, 1);
         {
             ProfScope prof(PROF_GEMM_NN, 2.0 * g.M * g.N * (planes ? 3.0 : 1.0) * g.K * n, 4.0 * n * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N), stream, n);
             if (planes) hipLaunchKernelGGL((skinny_nk_kernel<true>), grid, dim3(256), 0, stream, p, nchunks);
@@ -596,7 +596,7 @@ int gemm_skinny_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used, b
         if (dry) { *used = true; return ADN_OK; }
         p.ldb = g.ldb; p.splits = splits; p.partial = g.splitk_ws;
         fill_groups(p, gs, n, planes, false);
-        say("skinny_tn", splits);
+        say(1003, splits);
         ProfScope prof(PROF_GEMM_TN, 2.0 * g.M * g.N * (planes ? 3.0 : 1.0) * g.K * n, 4.0 * n * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N), stream, n);
         const dim3 grid((unsigned)mblocks, (unsigned)splits, (unsigned)n);
         if (planes) hipLaunchKernelGGL((skinny_tn_kernel<true>), grid, dim3(256), 0, stream, p);

@@ -5,7 +5,7 @@
 #   conv AE counters.
 # Usage (from the repo root, on an MI355X):   bash profiles/collect.sh [rNN] [commit]
 set -u
-ROUND=${1:-r04}; COMMIT=${2:-unknown}
+ROUND=${1:-r05}; COMMIT=${2:-unknown}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/collect
 mkdir -p $OUT
@@ -15,7 +15,7 @@ cd /tmp && export TMPDIR=/tmp
 PMC_STEPS=4
 B="$ROOT/bench.py --only-train-steps --steps 3 --warmup 1"
 # (kernel-stats passes: one per arithmetic mode, the mode under test as --precision)
-for prec in bf16 f32 bf16x3; do
+for prec in bf16 f32 bf16x3 mixed; do
   timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/ks_$prec -o ks --output-format csv -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --accurate-precision none --no-reference-minibatch --precision $prec > $OUT/ks_$prec.log 2>&1
   cp $(find $OUT/ks_$prec -name "ks_kernel_stats.csv" | head -1) $OUT/final_${prec}_kernel_stats.csv
 done
@@ -34,6 +34,13 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmcB3 -o
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $OUT/pmcM3 -o m --output-format csv -- python3 $B --precision bf16x3 > $OUT/pmcM3.log 2>&1
 python3 $ROOT/profiles/pmc_summary.py $(find $OUT/pmcM3 -name "m_counter_collection.csv" | head -1) mfma > $OUT/pmc_mfma_bf16x3.txt
 python3 $ROOT/profiles/make_traffic_json.py $(find $OUT/pmcA3 -name "a_counter_collection.csv" | head -1) $(find $OUT/pmcB3 -name "b_counter_collection.csv" | head -1) bf16x3 $COMMIT $PMC_STEPS > $OUT/pmc_traffic_bf16x3.json
+# round 5: the f32 mode's and the mixed mode's counter traffic too (roofline.traffic of `accurate_f32` / `mixed`)
+for prec in f32 mixed; do
+  timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmcA_$prec -o a --output-format csv -- python3 $B --precision $prec > $OUT/pmcA_$prec.log 2>&1
+  timeout 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmcB_$prec -o b --output-format csv -- python3 $B --precision $prec > $OUT/pmcB_$prec.log 2>&1
+  python3 $ROOT/profiles/make_traffic_json.py $(find $OUT/pmcA_$prec -name "a_counter_collection.csv" | head -1) $(find $OUT/pmcB_$prec -name "b_counter_collection.csv" | head -1) $prec $COMMIT $PMC_STEPS > $OUT/pmc_traffic_$prec.json
+  rm -rf $OUT/pmcA_$prec $OUT/pmcB_$prec
+done
 ADN_GEMM_TRACE=1 timeout 300 rocprofv3 --kernel-trace -d $OUT/bd -o bd --output-format csv -- python3 $ROOT/profiles/gemm_breakdown.py run 2> $OUT/gemm_trace.txt > $OUT/bd.log
 BD=$(find $OUT/bd -name "bd_kernel_trace.csv" | head -1)
 python3 $ROOT/profiles/gemm_breakdown.py join $OUT/gemm_trace.txt $BD > $OUT/gemm_breakdown_bf16.txt
@@ -43,6 +50,22 @@ ADN_PRECISION=bf16x3 ADN_GEMM_TRACE=1 timeout 300 rocprofv3 --kernel-trace -d $O
 BD3=$(find $OUT/bd3 -name "bd_kernel_trace.csv" | head -1)
 python3 $ROOT/profiles/gemm_breakdown.py join $OUT/gemm_trace_x3.txt $BD3 > $OUT/gemm_breakdown_bf16x3.txt
 python3 $ROOT/profiles/step_breakdown.py $BD3 > $OUT/step_breakdown_bf16x3.txt
+# ... and for the mixed mode (bf16x3 forward, bf16 backward products)
+ADN_PRECISION=mixed ADN_GEMM_TRACE=1 timeout 300 rocprofv3 --kernel-trace -d $OUT/bdm -o bd --output-format csv -- python3 $ROOT/profiles/gemm_breakdown.py run 2> $OUT/gemm_trace_mixed.txt > $OUT/bdm.log
+BDM=$(find $OUT/bdm -name "bd_kernel_trace.csv" | head -1)
+python3 $ROOT/profiles/gemm_breakdown.py join $OUT/gemm_trace_mixed.txt $BDM > $OUT/gemm_breakdown_mixed.txt
+python3 $ROOT/profiles/step_breakdown.py $BDM > $OUT/step_breakdown_mixed.txt
+# ... the deterministic schedule of the bf16 step, and the bf16 step at B = 65 (the per-rank batch of an 8-way strong-scaled run)
+ADN_DETERMINISTIC=1 ADN_GEMM_TRACE=1 timeout 300 rocprofv3 --kernel-trace -d $OUT/bdd -o bd --output-format csv -- python3 $ROOT/profiles/gemm_breakdown.py run 2> /dev/null > $OUT/bdd.log
+python3 $ROOT/profiles/step_breakdown.py $(find $OUT/bdd -name "bd_kernel_trace.csv" | head -1) > $OUT/step_breakdown_bf16_deterministic.txt
+BD_BATCH=65 ADN_GEMM_TRACE=1 timeout 300 rocprofv3 --kernel-trace -d $OUT/bd65 -o bd --output-format csv -- python3 $ROOT/profiles/gemm_breakdown.py run 2> $OUT/gemm_trace_b65.txt > $OUT/bd65.log
+python3 $ROOT/profiles/gemm_breakdown.py join $OUT/gemm_trace_b65.txt $(find $OUT/bd65 -name "bd_kernel_trace.csv" | head -1) > $OUT/gemm_breakdown_bf16_B65.txt
+python3 $ROOT/profiles/step_breakdown.py $(find $OUT/bd65 -name "bd_kernel_trace.csv" | head -1) > $OUT/step_breakdown_bf16_B65.txt
+rm -rf $OUT/bdm $OUT/bdd $OUT/bd65 $OUT/gemm_trace_mixed.txt $OUT/gemm_trace_b65.txt
+# conv auto-encoder: HBM bytes of its train step at batch 1024 (two PMC passes; 10 steps in the process)
+( cd /tmp; CAE_BATCH=1024 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/caeA -o a --output-format csv -- python3 $ROOT/profiles/convae_profile.py bf16 > $OUT/caeA.log 2>&1
+  CAE_BATCH=1024 timeout 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/caeB -o b --output-format csv -- python3 $ROOT/profiles/convae_profile.py bf16 > $OUT/caeB.log 2>&1
+  python3 $ROOT/profiles/pmc_bytes_total.py $(find $OUT/caeA -name "a_counter_collection.csv" | head -1) $(find $OUT/caeB -name "b_counter_collection.csv" | head -1) 10 > $OUT/pmc_bytes_convae_b1024.txt; rm -rf $OUT/caeA $OUT/caeB )
 # conv auto-encoder: MFMA-busy share of its GEMM kernels
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmcC -o c --output-format csv -- python3 $ROOT/profiles/convae_profile.py > $OUT/pmcC.log 2>&1
 python3 $ROOT/profiles/pmc_summary.py $(find $OUT/pmcC -name "c_counter_collection.csv" | head -1) mfma > $OUT/pmc_mfma_convae.txt
@@ -54,10 +77,17 @@ cd $ROOT
   echo "=== ping-pong forced, 256 x 256 tiles (ADN_GEMM_PP=4)"; ADN_GEMM_PP=4 timeout 200 profiles/gemm_lab
   echo "=== three problems per launch (LAB_GROUPS=3), selection as shipped"; LAB_GROUPS=3 timeout 200 profiles/gemm_lab
   echo "=== three problems per launch, ping-pong forced"; LAB_GROUPS=3 ADN_GEMM_PP=4 timeout 200 profiles/gemm_lab ) > $OUT/gemm_lab_pp.txt 2>&1
+# round 5: the fused-plane kernel against the three K-segments (+ the 32x32x16 body in plain bf16), in-kernel stamps and clock, the
+# skinny kernels against the register-staged / split-image paths
+timeout 900 bash profiles/scripts/lab_x3f.sh > $OUT/lab_x3f.txt 2>&1
+timeout 300 bash profiles/scripts/x3f_stamps.sh > $OUT/x3f_stamps.txt 2>&1
+timeout 600 bash profiles/scripts/lab_skinny.sh > $OUT/lab_skinny.txt 2>&1
+timeout 600 python3 profiles/scripts/strong_scaling_forecast.py bf16 > $OUT/strong_scaling_forecast.txt 2>&1
 timeout 200 python3 profiles/hipblaslt_calibration.py > $OUT/hipblaslt_calibration.txt 2>/dev/null
 timeout 300 python3 profiles/convae_bench.py > $OUT/convae_bench.txt 2>/dev/null
 # the bench lines last, so that roofline.traffic comes from the PMC passes of THIS build
 mkdir -p profiles/$ROUND && cp $OUT/pmc_traffic_bf16.json profiles/$ROUND/pmc_traffic_bf16.json && cp $OUT/pmc_traffic_bf16x3.json profiles/$ROUND/pmc_traffic_bf16x3.json
+cp $OUT/pmc_traffic_f32.json $OUT/pmc_traffic_mixed.json profiles/$ROUND/ 2>/dev/null
 # data parallel machinery on one GPU (no transfer): bucket events / per-bucket Adam / grouped collectives, and the HIP-graph A/B
 # of the reference minibatch
 timeout 300 python3 profiles/scripts/dp_order_bench.py > $OUT/dp_order_bench.txt 2>&1
@@ -67,7 +97,8 @@ timeout 600 python3 profiles/configs_bench.py > $OUT/configs_bench.txt 2>/dev/nu
 # round 4: the epoch through the product entry point (runners/nstream.fit, HBM-resident splits), the deterministic mode's cost,
 # the folded input projection A/B, the conv auto-encoder's kernel table at batch 1024
 timeout 600 python3 profiles/epoch_bench.py > $OUT/epoch_bench.txt 2>/dev/null
-( for d in 0 1; do echo -n "ADN_DETERMINISTIC=$d: "; ADN_DETERMINISTIC=$d timeout 300 python3 bench.py --no-cpu-baseline --accurate-precision bf16x3 --no-runner --no-profile 2>/dev/null | tail -1 | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print("bf16 %.3f ms/step, bf16x3 %.3f, B=26 %.3f" % (d["ms_per_step"], d["accurate"]["ms_per_step"], d["reference_minibatch"]["ms_per_step"]))'; done
+( for d in 0 1; do echo -n "ADN_DETERMINISTIC=$d: "; ADN_DETERMINISTIC=$d timeout 300 python3 bench.py --no-cpu-baseline --accurate-precision all --no-runner --no-profile 2>/dev/null | tail -1 | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print("bf16 %.3f ms/step, bf16x3 %.3f, mixed %.3f, f32 %.3f, B=26 %.3f" % (d["ms_per_step"], d["accurate"]["ms_per_step"], d["mixed"]["ms_per_step"], d["accurate_f32"]["ms_per_step"], d["reference_minibatch"]["ms_per_step"]))'; done
+  for v in "ADN_GEMM_NO_X3F=1" "ADN_GEMM_X3F=all" "ADN_GEMM_NO_SKINNY=1"; do echo -n "$v: "; env $v timeout 300 python3 bench.py --no-cpu-baseline --accurate-precision all --no-runner --no-profile --no-reference-minibatch 2>/dev/null | tail -1 | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print("bf16 %.3f ms/step, bf16x3 %.3f, mixed %.3f" % (d["ms_per_step"], d["accurate"]["ms_per_step"], d["mixed"]["ms_per_step"]))'; done
   for f in 0 1; do echo -n "ADN_LSTM_NO_FOLD=$f: "; if [ $f = 1 ]; then export ADN_LSTM_NO_FOLD=1; fi; timeout 300 python3 bench.py --no-cpu-baseline --accurate-precision none --no-runner 2>/dev/null | tail -1 | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); k=d["kernel_ms_per_step"]; print("bf16 %.3f ms/step, GEMM class %.3f ms = %.4f of peak, LSTM fwd %.3f ms, B=26 %.3f" % (d["ms_per_step"], k["gemm_nn"]+k.get("gemm_nt",0)+k["gemm_tn"], d["roofline"]["frac"], k["lstm_fwd_step"], d["reference_minibatch"]["ms_per_step"]))'; done ) > $OUT/mode_costs.txt 2>&1
 # the gather kernel's own time inside the runner (B = 26 and B = 520 launches in one table), and the CLI driver end to end
 ( cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/eb -o eb --output-format csv -- python3 $ROOT/profiles/epoch_bench.py --precisions bf16 --epochs 4 > $OUT/eb.log 2>&1; grep -i "batch_gather\|\"Name\"" $(find $OUT/eb -name "eb_kernel_stats.csv" | head -1) > $OUT/batch_gather_kernel_stats.csv; rm -rf $OUT/eb )

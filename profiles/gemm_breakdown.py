@@ -41,7 +41,8 @@ def join(trace_txt, kernel_csv):
             f = line.split()
             kv = dict(x.split("=") for x in f[2:])
             calls.append((step, f[1], {k: int(v) for k, v in kv.items()}))
-    rows = [r for r in csv.DictReader(open(kernel_csv)) if "gemm_" in r["Kernel_Name"] and "kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(kernel_csv))
+            if ("gemm_" in r["Kernel_Name"] and "kernel" in r["Kernel_Name"]) or ("skinny_" in r["Kernel_Name"] and "reduce" not in r["Kernel_Name"])]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     assert len(rows) == len(calls), (len(rows), len(calls))
     agg = collections.OrderedDict()
@@ -54,7 +55,8 @@ def join(trace_txt, kernel_csv):
         a[0] += 1; a[1] += us
     tot = sum(a[1] for a in agg.values())
     print("layout      M      N      K   tile split lean acc grp pl  count   us/launch   TFLOP/s   share   (grp = problems per launch; "
-          "pl = bf16x3 over hi / lo planes; K = executed k; TFLOP/s = executed, all problems of the launch)")
+          "pl = bf16x3 over hi / lo planes; K = executed k; TFLOP/s = executed, all problems of the launch; tile 1001 / 1002 / 1003 = the "
+          "skinny kernels nn / nk / tn of gemm_skinny.hip)")
     for key, (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         lay, M, N, K, tile, split, lean, acc, grp, pl = key
         tf = 2.0 * M * N * K * grp * n / us / 1e6

@@ -12,12 +12,13 @@ import sys
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*", "", name)
     m = re.match(r"_ZN3adn16gemm_bf16_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)E(\w+?)EEvNS", name)
     if m:
         lay = {"10": "NN", "11": "NT", "00": "TN"}[m.group(4) + m.group(5)]
         return "gemm_bf16<%sx%s,%s,%s>" % (m.group(1), m.group(2), lay, "bf16" if "DF16b" in m.group(6) else "f32")
-    return name.replace("adn::", "").replace("void ", "")[:60]
+    return name.replace("adn::", "").replace("(anonymous namespace)::", "").replace("void ", "")[:60]
 
 
 def main():
