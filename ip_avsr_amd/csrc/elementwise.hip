@@ -1023,17 +1023,50 @@ __global__ __launch_bounds__(256) void adam_ranges_kernel(const AdamRanges R, fl
 __global__ __launch_bounds__(256) void copy4_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
 }
+// U float4 per thread and iteration, all U loads issued ahead of the stores (U x 16 B x 256 threads x resident blocks in flight per CU)
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void copy4u_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (U - 1) * stride < n4; i += U * stride) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+            if constexpr (NT) __builtin_nontemporal_store(nt_f32x4{v[u].x, v[u].y, v[u].z, v[u].w}, reinterpret_cast<nt_f32x4*>(dst + i + u * stride));
+            else dst[i + u * stride] = v[u];
+        }
+    }
+    for (; i < n4; i += stride) dst[i] = src[i];
+}
+constexpr int kCopyDefaultVariant = 0;
 int copy_bench(const float* src, float* dst, int64_t n, int repeats, hipStream_t s, float* ms) {
     ADN_CHECK(src && dst && ms && n >= 4 && repeats >= 1, ADN_ERR_INVALID, "copy_bench: bad argument");
     ADN_CHECK(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, ADN_ERR_INVALID, "copy_bench: 16-byte alignment");
     hipEvent_t a, b;
     ADN_HIP_CHECK(hipEventCreate(&a)); ADN_HIP_CHECK(hipEventCreate(&b));
     const int64_t n4 = n / 4;
-    const int grid = (int)std::min<int64_t>((n4 + 255) / 256, 256 * 32);
-    hipLaunchKernelGGL(copy4_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n4);
+    // ADN_COPY_VARIANT (experiments): 0 = one float4 per thread and iteration, grid-stride (round 1-4: 4.96 - 5.06 TB/s);
+    // U >= 2 = U float4 loads in flight per thread ahead of their stores; +16 = non-temporal stores
+    static const int variant = getenv("ADN_COPY_VARIANT") ? atoi(getenv("ADN_COPY_VARIANT")) : kCopyDefaultVariant;
+    // (profiles/r05/copy_variants.txt: 7 forms x 4 grid sizes on one box -- 4.1 - 5.3 TB/s, none near the guide's 6.29; the plain
+    //  grid-stride form with 64 blocks per CU is the fastest: 5.31 against 5.17 at 32)
+    static const int blocks_per_cu = getenv("ADN_COPY_BLOCKS") ? atoi(getenv("ADN_COPY_BLOCKS")) : 64;
+    const int unroll = variant & 15;
+    const bool nt = (variant & 16) != 0;
+    const int grid = (int)std::min<int64_t>((n4 / std::max(unroll, 1) + 255) / 256, 256 * blocks_per_cu);
+    auto launch = [&]() {
+        const float4* s4 = reinterpret_cast<const float4*>(src); float4* d4 = reinterpret_cast<float4*>(dst);
+        if (unroll == 4) { if (nt) hipLaunchKernelGGL((copy4u_kernel<4, true>), dim3(grid), dim3(256), 0, s, s4, d4, n4); else hipLaunchKernelGGL((copy4u_kernel<4, false>), dim3(grid), dim3(256), 0, s, s4, d4, n4); }
+        else if (unroll == 8) { if (nt) hipLaunchKernelGGL((copy4u_kernel<8, true>), dim3(grid), dim3(256), 0, s, s4, d4, n4); else hipLaunchKernelGGL((copy4u_kernel<8, false>), dim3(grid), dim3(256), 0, s, s4, d4, n4); }
+        else if (unroll == 2) { if (nt) hipLaunchKernelGGL((copy4u_kernel<2, true>), dim3(grid), dim3(256), 0, s, s4, d4, n4); else hipLaunchKernelGGL((copy4u_kernel<2, false>), dim3(grid), dim3(256), 0, s, s4, d4, n4); }
+        else hipLaunchKernelGGL(copy4_kernel, dim3(grid), dim3(256), 0, s, s4, d4, n4);
+    };
+    launch();
     ADN_HIP_CHECK(hipEventRecord(a, s));
-    for (int r = 0; r < repeats; ++r)
-        hipLaunchKernelGGL(copy4_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n4);
+    for (int r = 0; r < repeats; ++r) launch();
     ADN_HIP_CHECK(hipEventRecord(b, s));
     ADN_HIP_CHECK(hipEventSynchronize(b));
     ADN_HIP_CHECK(hipEventElapsedTime(ms, a, b));

@@ -204,16 +204,17 @@ static int gemm_pp_try_impl(const GemmArgs* gs, int n, const GemmArgs& g, int ks
 // LDS-DMA and fragment traffic per flop buys nothing in wall time on the NN shapes (0.97 - 1.00 x: the chip holds ~1.5 GHz under
 // either kernel -- both are bound by the energy of their MFMAs, and the 32x32x16 shape the 16-k unit needs holds a lower clock
 // than 16x16x32, MI355X_MICROARCH.md 'DVFS give-back' item 7) and 2 - 7 % on the weight gradients (TN), where it also takes any K
-// (the three-segment walk needs K % 32 == 0).  Default: TN over planes.  ADN_GEMM_NO_X3F=1: never; ADN_GEMM_X3F=all: NN too
+// (the three-segment walk needs K % 32 == 0).  In the train step itself (profiles/r05/mode_costs.txt, one box, bf16x3 ms per step):
+// never 7.717, TN only 7.662, every launch over planes 7.582 -- the default.  ADN_GEMM_NO_X3F=1: never; ADN_GEMM_X3F=tn: TN only
 static bool x3f_enabled() {
     static const bool off = getenv("ADN_GEMM_NO_X3F") != nullptr;
     return !off;
 }
 // the tile mode a product over planes runs in: 8 = fused-plane kernel, otherwise the ping-pong kernel's (forced or default) mode
 static int planes_tile_mode(int layout, int mode_env, int default_mode) {
-    static const bool all = getenv("ADN_GEMM_X3F") && !strcmp(getenv("ADN_GEMM_X3F"), "all");
+    static const bool tn_only = getenv("ADN_GEMM_X3F") && !strcmp(getenv("ADN_GEMM_X3F"), "tn");
     if (mode_env >= 4) return (mode_env == 8 && !x3f_enabled()) ? default_mode : mode_env;
-    return (x3f_enabled() && (all || layout == GEMM_TN)) ? 8 : default_mode;
+    return (x3f_enabled() && (!tn_only || layout == GEMM_TN)) ? 8 : default_mode;
 }
 void launch_gemm_x3f(const GemmParams& p, int layout, bool planes, int splits, dim3 grid, hipStream_t s);      // gemm_x3f.hip
 static int gemm_pp_try(const GemmArgs* gs0, int n, hipStream_t stream, bool* used, bool dry = false) {

@@ -1280,9 +1280,11 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
         g.C = st.act[l]; g.ldc = ld_of(g.N); g.bias = m->P(st.encb[l]); g.act = st.cfg.enc_act[l];
         g.no_split = 1;                                          // forward pass: reproducible bits
         mgemm_prepare(m, g, /*lean=*/l + 1 < st.cfg.n_enc);      // the delta layer reads the last one in fp32
-        // (bf16x3: a narrow next layer -- the 50-unit bottleneck -- multiplies over split images of the fp32 values: writing them
-        //  here is cheaper than writing hi + lo back ahead of that layer)
-        if (m->planes() && l + 1 < st.cfg.n_enc && st.cfg.enc_units[l + 1] < 128) g.lean_ok = 0;
+        // (bf16x3: a narrow next layer -- the 50-unit bottleneck -- reads the planes too since round 5 (gemm_skinny.hip); with those
+        //  kernels switched off it multiplies over split images of the fp32 values, and writing them here is cheaper than writing
+        //  hi + lo back ahead of that layer)
+        static const bool no_skinny = getenv("ADN_GEMM_NO_SKINNY") != nullptr;
+        if (no_skinny && m->planes() && l + 1 < st.cfg.n_enc && st.cfg.enc_units[l + 1] < 128) g.lean_ok = 0;
         return g;
     };
     // Encoders layer by layer; the streams whose layer l has the same geometry go out as ONE grouped launch (their

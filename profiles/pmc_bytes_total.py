@@ -12,7 +12,7 @@ def load(path, counter, scale):
     tot, n = collections.Counter(), collections.Counter()
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
-            k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("adn::", "")[:70]
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("adn::", "")[:70]
             tot[k] += scale * float(r["Counter_Value"]); n[k] += 1
     return tot, n
 
