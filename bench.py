@@ -535,8 +535,19 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
             if prec == args.precision:
                 continue
             model.set_precision(prec)
-            xs = xs32                                  # (the step closure reads `xs`: float32 frames for the parity-grade modes)
+            # (the step closure reads `xs`.)  f32 mode: float32 frames.  bf16x3 / mixed: the batch resident as its hi / lo bfloat16
+            # planes -- the operand form of those modes, what the epoch drivers keep in HBM for them (utils/datagen_gpu.DeviceSplit
+            # dtype 'planes': the bytes of float32) -- like the bf16 headline's bfloat16-resident batch; the float32-fed figure is
+            # reported beside it as `fp32_inputs`
+            xs = xs32
             k = max(3, min(args.steps, 10))
+            t_f32_in = None
+            if prec in ("bf16x3", "mixed") and not args.fp32_inputs:
+                for _ in range(2):
+                    step()
+                t_f32_in = timed(k)
+                from ip_avsr_amd.model import PlaneInput
+                xs = [PlaneInput.split(x) for x in xs32]
             for _ in range(2):
                 step()
             t_acc = timed(k)
@@ -547,6 +558,10 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
                               "grade: NOT the parity-grade figure (tests/test_gpu_bf16x3.py::test_mixed_mode_*)") if prec == "mixed" else
                              "forward 1e-4 / identical votes against the fp64 oracle (tests/test_gpu_parity.py, "
                              "tests/test_gpu_bf16x3.py)"}
+            acc["inputs"] = "hi / lo bfloat16 planes, resident in HBM" if t_f32_in is not None else "float32, resident in HBM"
+            if t_f32_in is not None:
+                acc["fp32_inputs"] = {"ms_per_step": 1e3 * t_f32_in / k, "value": B_PER_GPU * k / t_f32_in, "unit": "sequences/s",
+                                      "inputs": "float32, resident in HBM (the library splits them into planes every step)"}
             if profile:
                 model.profile(True)
                 pe = timed(k)
@@ -559,7 +574,7 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
         pg = out if args.precision in ("bf16x3", "f32") else out.get("accurate") or out.get("accurate_f32")
         if pg is not None:
             out["parity_grade"] = {"mode": pg.get("mode", args.precision), "value": pg["value"], "ms_per_step": pg["ms_per_step"],
-                                   "unit": "sequences/s"}
+                                   "unit": "sequences/s", "inputs": pg.get("inputs", inputs_desc)}
         if on_gpu and world == 1 and not getattr(args, "no_reference_minibatch", False):
             # the same model at the reference's own minibatch (runners/3stream.py: 26 utterances per update): every GEMM is a
             # latency-bound launch there and the step is a chain of ~160 LSTM time steps -- reported beside the headline, not as it

@@ -77,11 +77,18 @@ enum {
     ADN_FLAG_DEVICE_OUTPUTS = 2,
     ADN_FLAG_STOCHASTIC = 4,     /* adn_loss: dropout layers active (compute_train_cost, runners/3stream.py:372) */
     ADN_FLAG_DETERMINISTIC = 8,  /* adn_compute_grads / adn_train_step: dropout layers off (they are on by default) */
-    ADN_FLAG_BF16_INPUTS = 16    /* the stream (and auxiliary) inputs are bfloat16 arrays instead of float32 -- what a bf16
+    ADN_FLAG_BF16_INPUTS = 16,   /* the stream (and auxiliary) inputs are bfloat16 arrays instead of float32 -- what a bf16
                                     feature front-end leaves in HBM.  In ADN_PRECISION_BF16 a device array of an encoder stream
                                     is then read in place by the first encoder GEMM (no staging copy, no conversion pass);
                                     everywhere else it is widened to float32 (exact) first.  The reference's theano functions
                                     take float32 (allow_input_downcast) only: this is an addition, not a replacement. */
+    ADN_FLAG_PLANE_INPUTS = 32   /* ADN_PRECISION_BF16X3 / _MIXED, device inputs only: every stream input arrives as its two bfloat16
+                                    planes hi = bf16(x), lo = bf16(x - hi) -- what the GEMMs of that mode read (the library
+                                    otherwise makes them from the float32 array with a split pass per call).  `inputs` then holds
+                                    2 S pointers: the S hi planes, then the S lo planes (dense (B, T, D) bfloat16 each).  Every
+                                    stream needs an encoder and D % 8 == 0; no auxiliary inputs.  Results equal those of passing
+                                    the float32 values hi + lo to the last bit or two (the library's own split of hi + lo re-rounds
+                                    the hi plane where lo is exactly half a unit of it). */
 };
 
 /* what the classifier sees and how it is trained */

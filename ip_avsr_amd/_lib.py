@@ -23,6 +23,7 @@ FLAG_DEVICE_INPUTS = 1
 FLAG_STOCHASTIC = 4
 FLAG_DETERMINISTIC = 8
 FLAG_BF16_INPUTS = 16
+FLAG_PLANE_INPUTS = 32
 HEAD = {"frames": 0, "last": 1}
 FLAG_DEVICE_OUTPUTS = 2
 BUF_PARAM, BUF_GRAD, BUF_ADAM_M, BUF_ADAM_V = 0, 1, 2, 3

@@ -490,7 +490,10 @@ int gemm_skinny_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used, b
     // In plain bf16 the register-staged kernels already move these shapes at 2.6 - 3 TB/s (forward bottleneck 23.9 against 24.4
     // here; the K <= 64 input gradient 41.5 against 66.2: its 64-column tiles store 128-byte row pieces through an LDS bounce where
     // the transposed accumulators here store 32-byte pieces): only the 26-column classifier product (14.8 -> 11.6) comes here.
-    static const bool all_bf16 = getenv("ADN_GEMM_SKINNY_ALL") != nullptr;       // (A/B switch: every skinny kernel in plain bf16 too)
+    // (A/B switch: every skinny kernel in plain bf16 too.  The mixed mode's back-propagation -- one bf16 product whose result is still
+    //  wanted as planes -- takes them as well: the register-staged kernel would write fp32 + a split pass behind it; 5.66 -> 5.52 ms)
+    static const bool all_env = getenv("ADN_GEMM_SKINNY_ALL") != nullptr;
+    const bool all_bf16 = all_env || g.hi_product;
     if ((g.layout == GEMM_NN || g.layout == GEMM_NT) && g.Bkc16 && g.N <= 64 && g.K <= kNnKMax && g.K >= 32 && (planes || g.N <= 32 || all_bf16)) {
         // (Bkc16: B as [N][K] k-contiguous -- for an NT problem B itself, for NN the caller's transposed copy)
         for (int k = 0; k < n; ++k) {

@@ -588,6 +588,15 @@ int stage_inputs(adn_model* m, const void* const* inputs, const int32_t* targets
     const size_t N = (size_t)B * T;
     const bool dev = flags & ADN_FLAG_DEVICE_INPUTS;
     const bool in16 = flags & ADN_FLAG_BF16_INPUTS;              // stream (and auxiliary) inputs arrive as bf16 arrays
+    const bool in_planes = flags & ADN_FLAG_PLANE_INPUTS;        // ... as their hi / lo planes (inputs[S + s] = the lo plane of stream s)
+    // (a staging buffer listed as "fp32 copy not written" by an earlier call with plane inputs is about to be re-decided)
+    for (auto& st : m->st)
+        for (size_t k = 0; k < m->fp32_stale.size(); ++k)
+            if (m->fp32_stale[k].first == st.xstage) { m->fp32_stale.erase(m->fp32_stale.begin() + (long)k); break; }
+    if (in_planes) {
+        ADN_CHECK(dev && m->planes() && !in16, ADN_ERR_INVALID, "plane inputs: device arrays in the bf16x3 / mixed arithmetic only");
+        for (auto& st : m->st) ADN_CHECK(st.cfg.aux_dim <= 0, ADN_ERR_INVALID, "plane inputs: auxiliary inputs are not supported");
+    }
     const hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     ADN_CHECK(inputs && mask, ADN_ERR_INVALID, "null inputs / mask");
     for (int s = 0; s < m->S; ++s) {
@@ -595,6 +604,19 @@ int stage_inputs(adn_model* m, const void* const* inputs, const int32_t* targets
         ADN_CHECK(inputs[s], ADN_ERR_INVALID, "null stream input");
         const int D = st.cfg.input_dim;
         st.x16 = nullptr; st.x16lo = nullptr;
+        if (in_planes) {
+            // the caller's planes ARE the first GEMM's operands.  st.x names the fp32 staging buffer (dense rows of D), which holds
+            // nothing: it is listed as stale, so that a reader that does not run over planes gets hi + lo written there first
+            const void* lo = inputs[m->S + s];
+            ADN_CHECK(lo && st.cfg.n_enc > 0 && D % 8 == 0 && ((uintptr_t)inputs[s]) % 16 == 0 && ((uintptr_t)lo) % 16 == 0, ADN_ERR_INVALID,
+                      "plane inputs: every stream needs an encoder, D % 8 == 0 and 16-byte aligned planes");
+            st.x = st.xstage; st.ldx = D;
+            st.x16 = const_cast<void*>(inputs[s]); st.x16lo = const_cast<void*>(lo);
+            bool listed = false;
+            for (auto& e : m->fp32_stale) if (e.first == st.x) { e.second = N * (size_t)D; listed = true; }
+            if (!listed) m->fp32_stale.push_back({st.x, N * (size_t)D});
+            continue;
+        }
         if (in16) {
             // bf16 mode, an encoder in front (every consumer of the input is a GEMM reading bf16 operands): the caller's
             // device array IS the operand -- no copy, no conversion; st.x only names it (shadow_of), it is never read

@@ -49,6 +49,48 @@ class Param(object):
         return "<Param %s %s>" % (self.name, self.shape)
 
 
+class PlaneInput(object):
+    """A stream input as its two bfloat16 planes hi = bf16(x), lo = bf16(x - hi) (device tensors of x's shape): the operand
+    form of the bf16x3 / mixed arithmetic (ADN_FLAG_PLANE_INPUTS) -- a resident split kept this way costs the same bytes as
+    float32 and saves the model its split pass over every batch.  ``PlaneInput.split(x)`` makes one from a float32 tensor."""
+
+    __slots__ = ("hi", "lo")
+
+    def __init__(self, hi, lo):
+        if tuple(hi.shape) != tuple(lo.shape) or str(hi.dtype) != "torch.bfloat16" or str(lo.dtype) != "torch.bfloat16":
+            raise ValueError("PlaneInput: two bfloat16 tensors of one shape")
+        self.hi, self.lo = hi.contiguous(), lo.contiguous()
+
+    @classmethod
+    def split(cls, x):
+        import torch
+        x = x.to(torch.float32)
+        hi = x.to(torch.bfloat16)
+        return cls(hi, (x - hi.to(torch.float32)).to(torch.bfloat16))
+
+    @property
+    def shape(self):
+        return self.hi.shape
+
+    @property
+    def ndim(self):
+        return self.hi.ndim
+
+    @property
+    def device(self):
+        return self.hi.device
+
+    def __len__(self):
+        return len(self.hi)
+
+    def __getitem__(self, idx):
+        return PlaneInput(self.hi[idx], self.lo[idx])
+
+    def float(self):
+        import torch
+        return self.hi.to(torch.float32) + self.lo.to(torch.float32)
+
+
 class AdeNetModel(object):
     """S-stream AdeNet / DeltaNet graph on one MI355X.
 
@@ -353,6 +395,11 @@ class AdeNetModel(object):
         if len(inputs) != n_in:
             raise ValueError("expected %d input streams%s, got %d arrays"
                              % (self.S, " + %d auxiliary inputs" % len(self.aux_dims) if self.aux_dims else "", len(inputs)))
+        planes = all(isinstance(x, PlaneInput) for x in inputs)
+        if planes:                                   # hi / lo planes of every stream (bf16x3 / mixed arithmetic)
+            return self._prep_planes(inputs, mask, targets)
+        if any(isinstance(x, PlaneInput) for x in inputs):
+            raise ValueError("either every stream arrives as a PlaneInput or none")
         inputs = self._apply_front_ends(inputs)
         dev = self._is_device(inputs[0])
         # bfloat16 torch tensors (all inputs) go to the library as they are (ADN_FLAG_BF16_INPUTS): in bf16 mode the first
@@ -412,6 +459,42 @@ class AdeNetModel(object):
             _lib.check(self._lib.adn_set_stream(self._handle, C.c_void_p(int(raw))))
         flags = (_lib.FLAG_DEVICE_INPUTS if dev else 0) | (_lib.FLAG_BF16_INPUTS if in16 else 0)
         return ptrs, mp, tp, B, T, flags, keep
+
+    def _prep_planes(self, inputs, mask, targets=None):
+        import torch
+        if self.aux_dims or self._front or self.spec.get("precision") not in ("bf16x3", "mixed"):
+            # (another arithmetic, auxiliary inputs, a conv front end: the float32 values -- exact: hi + lo)
+            return self._prep([x.float() for x in inputs], mask, targets)
+        n = self.S
+        ptrs = (C.c_void_p * (2 * n))()
+        keep, shape = [], None
+        for k, x in enumerate(inputs):
+            if x.ndim != 3 or x.shape[2] != self.input_dims[k]:
+                raise ValueError("input %d: expected (B,T,%d), got %s" % (k, self.input_dims[k], tuple(x.shape)))
+            if shape is None:
+                shape = tuple(x.shape[:2])
+            elif tuple(x.shape[:2]) != shape:
+                raise ValueError("streams disagree on (B,T): %s vs %s" % (tuple(x.shape[:2]), shape))
+            keep += [x.hi, x.lo]
+            ptrs[k], ptrs[n + k] = x.hi.data_ptr(), x.lo.data_ptr()
+        B, T = shape
+
+        def small(a, torch_dtype):
+            if getattr(a, "dev", None) is not None:
+                a = a.dev
+            if not self._is_device(a):
+                a = torch.as_tensor(np.ascontiguousarray(a), device=keep[0].device)
+            a = a.to(torch_dtype).contiguous()
+            if tuple(a.shape) != (B, T):
+                raise ValueError("mask/targets must be (B,T)=%s, got %s" % ((B, T), tuple(a.shape)))
+            keep.append(a)
+            return a.data_ptr()
+
+        mp = small(mask, torch.uint8)
+        tp = small(targets, torch.int32) if targets is not None else None
+        if self._torch_stream is None:
+            _lib.check(self._lib.adn_set_stream(self._handle, C.c_void_p(int(torch.cuda.current_stream().cuda_stream))))
+        return ptrs, mp, tp, B, T, _lib.FLAG_DEVICE_INPUTS | _lib.FLAG_PLANE_INPUTS, keep
 
     def predict(self, inputs, mask, window):
         """val_fn (deterministic): probabilities (B,T,C) float32 -- (B,C) for the last-timestep head."""

@@ -226,11 +226,17 @@ def build_network_avletters(n_streams, has_encoder, load_ae, dims, lstm_weights,
 def resident_dtype(network):
     """Element type of the HBM-resident splits: bfloat16 when the model computes in bf16 and every stream enters through an
     encoder GEMM (which rounds its input to bfloat16 anyway: identical results, half the bytes, ADN_FLAG_BF16_INPUTS);
+    'planes' (hi / lo bfloat16 pairs, ADN_FLAG_PLANE_INPUTS) in the bf16x3 / mixed arithmetic under the same condition;
     float32 otherwise (an encoder-less stream feeds the delta layer / LSTM projection in fp32)."""
     spec = network.spec
     if spec.get('precision') == 'bf16' and all(s.get('enc_shapes') and not s.get('aux_dim') for s in spec['streams']) \
             and not getattr(network, '_front', None) and not os.environ.get('ADN_FP32_RESIDENT'):
         return 'bfloat16'
+    # bf16x3 / mixed: the two bfloat16 planes of every frame (the bytes of float32; the model's split pass over each batch goes)
+    if spec.get('precision') in ('bf16x3', 'mixed') and all(s.get('enc_shapes') and not s.get('aux_dim') and s['input_dim'] % 8 == 0
+                                                            for s in spec['streams']) \
+            and not getattr(network, '_front', None) and not os.environ.get('ADN_FP32_RESIDENT'):
+        return 'planes'
     return 'float32'
 
 

@@ -61,9 +61,9 @@ class DeviceSplit(object):
     """One split (train / val / test) of an S-stream dataset in HBM.
 
     ``streams``: list of (sum of lengths, D_s) arrays; ``y``: per-FRAME labels (sum of lengths,) like the reference's
-    ``targetsVec``; ``seqlen``: utterance lengths.  ``dtype``: 'float32' | 'bfloat16' element type of the resident copies
+    ``targetsVec``; ``seqlen``: utterance lengths.  ``dtype``: 'float32' | 'bfloat16' | 'planes' element type of the resident copies
     (bfloat16 = round-to-nearest-even of the float32 values, what the bf16 arithmetic's first GEMM would round them to
-    anyway)."""
+    anyway; planes = two bfloat16 matrices per stream, hi and lo: what the bf16x3 / mixed arithmetic's GEMMs read)."""
 
     def __init__(self, streams, y, seqlen, dtype="float32", device=None):
         import torch
@@ -78,7 +78,10 @@ class DeviceSplit(object):
         self.offsets = np.asarray(compute_integral_len(self.lens), dtype=np.int64)[:self.n]
         self.tmax = int(self.lens.max()) if self.n else 0
         total = int(self.lens.sum())
-        self.dtype = {"float32": torch.float32, "bfloat16": torch.bfloat16}[dtype]
+        # 'planes': every stream as its two bfloat16 planes hi = bf16(x), lo = bf16(x - hi) -- the operand form of the bf16x3 / mixed
+        # arithmetic (model.PlaneInput): the bytes of float32, gathered as 2 S two-byte streams, and the model skips its split pass
+        self.planes = dtype == "planes"
+        self.dtype = {"float32": torch.float32, "bfloat16": torch.bfloat16, "planes": torch.bfloat16}[dtype]
         self.elem_bytes = 4 if dtype == "float32" else 2
         self.frames = []
         self.widths = []
@@ -89,8 +92,15 @@ class DeviceSplit(object):
                 raise ValueError("stream %d: expected (>= %d, D) frames, got %s" % (k, total, tuple(x.shape)))
             t = x[:total] if hasattr(x, "data_ptr") else torch.as_tensor(np.ascontiguousarray(x[:total], dtype=np.float32),
                                                                          device=self.device)
-            self.frames.append(t.to(self.dtype).contiguous())
-            self.widths.append(int(x.shape[1]))
+            if self.planes:
+                t32 = t.to(torch.float32)
+                hi = t32.to(torch.bfloat16)
+                self.frames.append(hi.contiguous())
+                self.frames.append((t32 - hi.to(torch.float32)).to(torch.bfloat16).contiguous())
+                self.widths += [int(x.shape[1])] * 2
+            else:
+                self.frames.append(t.to(self.dtype).contiguous())
+                self.widths.append(int(x.shape[1]))
         yv = np.asarray(y).reshape(-1)
         self.y_first = yv[self.offsets].astype(np.uint8) if self.n else np.zeros((0,), np.uint8)   # datagen.py:130,142
         self.d_labels = torch.as_tensor(yv[:total].astype(np.int64).astype(np.int32), device=self.device)
@@ -141,6 +151,9 @@ class DeviceSplit(object):
         mask = (np.arange(T)[None, :] < lens[:, None]).astype(np.uint8)
         y = self.y_first[mine]
         b.Xs = out["Xs"]
+        if self.planes:                                 # (hi, lo) pairs of the 2 S gathered tensors
+            from ..model import PlaneInput
+            b.Xs = [PlaneInput(out["Xs"][2 * k], out["Xs"][2 * k + 1]) for k in range(len(out["Xs"]) // 2)]
         b.mask = Resident(mask, out["mask"])
         b.y = Resident(y, out["y"])
         b.targets = Resident(np.repeat(y.reshape(-1, 1), T, axis=-1).astype(np.int32), out["targets"])

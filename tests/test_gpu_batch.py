@@ -303,3 +303,33 @@ def test_edge_splits_one_utterance_one_frame_and_whole_split_batches():
     assert list(whole.idxs) == list(ib) and np.array_equal(_host(whole.Xs[0]), X1) and np.array_equal(np.asarray(whole.y), yb)
     il = dg.compute_integral_len(lens)
     assert np.array_equal(_host(whole.Xs[1]), dg.gen_seq_batch_from_idx(streams[1], ib, lens, il, int(lens.max())))
+
+
+def test_resident_planes_gather_the_two_planes_of_the_float32_batches():
+    """DeviceSplit(dtype='planes') -- the resident form of the bf16x3 / mixed arithmetic -- gathers for every stream the hi and
+    the lo bfloat16 plane of exactly the batches the float32 split gathers (same indices, padding, mask, targets)."""
+    import torch
+    from ip_avsr_amd.model import PlaneInput
+    rng = np.random.default_rng(3)
+    lens = rng.integers(3, 12, size=23)
+    total = int(lens.sum())
+    streams = [rng.normal(size=(total, d)).astype(np.float32) for d in (24, 40)]
+    y = np.repeat(np.arange(23) % 5, lens)
+    from ip_avsr_amd.utils.datagen_gpu import DeviceSplit
+    a, b = DeviceSplit(streams, y, lens), DeviceSplit(streams, y, lens, dtype="planes")
+    def run(split):                                      # (the generators draw from np.random as they go: one after the other)
+        np.random.seed(7)
+        gen, out = split.batches(batchsize=6), []
+        for _ in range(9):                               # two passes incl. the short last batch
+            bt = next(gen)
+            out.append((bt.idxs.copy(), np.asarray(bt.mask).copy(), np.asarray(bt.targets).copy(),
+                        [(x.hi.clone(), x.lo.clone()) if isinstance(x, PlaneInput) else x.clone() for x in bt.Xs]))
+        return out
+    for (ia, ma, ta, xa), (ib, mb, tb, xb) in zip(run(a), run(b)):
+        np.testing.assert_array_equal(ia, ib)
+        np.testing.assert_array_equal(ma, mb)
+        np.testing.assert_array_equal(ta, tb)
+        for fa, pb in zip(xa, xb):
+            assert isinstance(pb, tuple)
+            want = PlaneInput.split(fa)
+            assert torch.equal(pb[0], want.hi) and torch.equal(pb[1], want.lo)

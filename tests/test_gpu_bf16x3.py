@@ -370,3 +370,49 @@ def test_mixed_mode_train_steps_stay_as_close_to_bf16x3_as_bf16_does(torch_cuda,
     agree_mixed = (votes["mixed"] == votes["bf16x3"]).mean()
     agree_bf16 = (votes["bf16"] == votes["bf16x3"]).mean()
     assert agree_mixed >= agree_bf16 - 1.0 / len(mask) - 1e-9, (agree_mixed, agree_bf16)
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "mixed"])
+def test_plane_inputs_equal_float32_inputs(torch_cuda, lib, prec):
+    """ADN_FLAG_PLANE_INPUTS (include/adenet.h): the stream inputs handed over as their hi / lo bfloat16 planes -- what the
+    mode's first GEMMs read -- give the probabilities, loss and gradients of the float32 values hi + lo (which the library
+    would split into the same two planes, ties in the hi plane aside) to the last bit or two; also through a shape the GEMM over planes declines (a tiny
+    batch: the staging buffer is then filled from the planes on demand), and another arithmetic gets the float32 values."""
+    from ip_avsr_amd.model import AdeNetModel, PlaneInput
+    torch = torch_cuda
+    spec = O.spec_nstream([48, 40], enc_shapes=(64, 32, 16), enc_acts=("rectify", "rectify", "linear"), lstm_size=24, classes=7,
+                          fusion="concat")
+    rng = np.random.default_rng(5)
+    p = O.init_params(spec, rng, np.float32, enc_std=0.2, perturb=0.05)
+    was = lib.adn_get_deterministic()
+    lib.adn_set_deterministic(1)                 # (ordered reductions: two passes over the same operands give the same bits)
+    try:
+        _plane_inputs_cases(torch, spec, p, rng, prec)
+    finally:
+        lib.adn_set_deterministic(was)
+
+
+def _plane_inputs_cases(torch, spec, p, rng, prec):
+    from ip_avsr_amd.model import AdeNetModel, PlaneInput
+    for B, T in ((300, 24), (3, 5)):
+        mask = ragged_mask(rng, B, T)
+        xs = [torch.tensor((rng.normal(size=(B, T, d)) * mask[..., None]).astype(np.float32), device="cuda") for d in (48, 40)]
+        planes = [PlaneInput.split(x) for x in xs]
+        exact = [pl.float() for pl in planes]                       # hi + lo: what the planes represent exactly
+        y = np.repeat(rng.integers(0, 7, size=(B, 1)), T, axis=1).astype(np.int32)
+        m = AdeNetModel(dict(spec, precision=prec))
+        m.set_params_dict(p)
+        a = (m.predict(exact, mask, 2), m.compute_grads(exact, y, mask, 2), m.get_grads_dict())
+        b = (m.predict(planes, mask, 2), m.compute_grads(planes, y, mask, 2), m.get_grads_dict())
+        # (the library's own split of hi + lo can differ from (hi, lo) where lo is exactly half a unit of hi -- a tie re-rounds
+        #  the hi plane -- which moves the dropped lo x lo term: ~1e-10 in a few products, nothing beyond the last bit elsewhere)
+        np.testing.assert_allclose(a[0], b[0], rtol=0, atol=1e-7)
+        assert abs(a[1] - b[1]) <= 1e-6 * abs(a[1])
+        gscale = max(np.abs(v).max() for v in a[2].values())
+        # (mixed: the backward GEMMs read the hi plane alone, where a re-rounded tie is a whole bf16 unit in that element)
+        gtol = 1e-6 if prec == "bf16x3" else 2e-3
+        for k in a[2]:
+            assert np.abs(a[2][k] - b[2][k]).max() <= gtol * max(np.abs(a[2][k]).max(), 1e-3 * gscale), k
+        m.set_precision("f32")                                       # (no planes in this arithmetic: the float32 values are passed)
+        np.testing.assert_array_equal(m.predict(planes, mask, 2), m.predict(exact, mask, 2))
+        m.close()
