@@ -49,7 +49,7 @@ def main():
     commit = sys.argv[4] if len(sys.argv) > 4 else "unknown"
     train_steps = int(sys.argv[5]) if len(sys.argv) > 5 else 4
     # (gemm_bf16_kernel and gemm_bf16_pp_kernel; over planes also the fused-plane kernel gemm_x3f_kernel)
-    match = ("gemm_bf16", "gemm_x3f") if prec in ("bf16", "bf16x3", "mixed") else ("gemm_f32_kernel",)
+    match = ("gemm_bf16", "gemm_x3f", "skinny_n", "skinny_tn_kernel") if prec in ("bf16", "bf16x3", "mixed") else ("gemm_f32_kernel",)
     out = {"kernel_class": "%s (all instantiations)" % " + ".join(match), "commit": "PMC passes taken at commit %s" % commit,
            "train_steps": train_steps}
     out.update(summarise(fa, fb, match, train_steps))

@@ -416,3 +416,54 @@ def _plane_inputs_cases(torch, spec, p, rng, prec):
         m.set_precision("f32")                                       # (no planes in this arithmetic: the float32 values are passed)
         np.testing.assert_array_equal(m.predict(planes, mask, 2), m.predict(exact, mask, 2))
         m.close()
+
+
+def test_skinny_and_fused_plane_kernels_against_the_oracle(torch_cuda, lib):
+    """A geometry at which the narrow shapes leave the register-staged kernels -- 2 100 frames under a 50-unit bottleneck and a
+    26-way classifier: csrc/gemm_skinny.hip's forward (N <= 64), input-gradient (K <= 64, act'(Y) mask + fused bias sums) and
+    weight-gradient (TN, slabs) kernels over hi / lo planes, with ragged row / column / k edges (2 100 = 8 x 256 + 52 rows,
+    N = 50 / 26, K = 50 / 40) -- checked against the fp64 oracle: probabilities 1e-4, identical votes, loss 1e-5, every gradient
+    2e-4 of its scale -- for float32 inputs and for plane inputs (ADN_FLAG_PLANE_INPUTS); the mixed mode's forward pass must give
+    the same bits and its one-product backward kernels bf16-grade gradients."""
+    from ip_avsr_amd.model import AdeNetModel, PlaneInput
+    torch = torch_cuda
+    spec = O.spec_nstream([72, 56], enc_shapes=(160, 128, 50), enc_acts=("rectify", "rectify", "linear"), lstm_size=40, classes=26,
+                          fusion="concat")
+    B, T, theta = 70, 30, 3
+    rng = np.random.default_rng(99)
+    p = O.init_params(spec, rng, np.float32, enc_std=0.1, perturb=0.05)
+    mask = ragged_mask(rng, B, T)
+    inputs = [(rng.normal(size=(B, T, d)) * mask[..., None]).astype(np.float32) for d in (72, 56)]
+    y = np.repeat((np.arange(B) % 26)[:, None], T, axis=1).astype(np.int32)
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    x64 = [x.astype(np.float64) for x in inputs]
+    probs_ref = O.forward(spec, p64, x64, mask, theta)
+    l_ref, g_ref, _ = O.loss_and_grads(spec, p64, x64, y, mask, theta)
+    gscale = max(np.abs(v).max() for v in g_ref.values())
+    m = AdeNetModel(dict(spec, precision="bf16x3"))
+    m.set_params_dict(p)
+    dev = [torch.tensor(x, device="cuda") for x in inputs]
+    probs_x3 = None
+    for feed in (inputs, [PlaneInput.split(x) for x in dev]):
+        probs = m.predict(feed, mask, theta)
+        if probs_x3 is None:
+            probs_x3 = probs
+        assert np.abs(probs - probs_ref).max() <= 1e-4
+        np.testing.assert_array_equal(O.majority_vote(probs, mask), O.majority_vote(probs_ref, mask))
+        l = m.compute_grads(feed, y, mask, theta)
+        assert abs(l - l_ref) <= 1e-5 * abs(l_ref)
+        g = m.get_grads_dict()
+        worst = 0.0
+        for k in O.param_names(spec):
+            e = np.abs(g[k] - g_ref[k]).max() / max(np.abs(g_ref[k]).max(), 1e-3 * gscale)
+            worst = max(worst, e)
+            assert e <= 2e-4, (k, e)
+        print("narrow-shape kernels over planes vs fp64 oracle: max |dp| %.2e, worst gradient %.2e of its scale" % (np.abs(probs - probs_ref).max(), worst))
+    m.set_precision("mixed")                          # forward = the same kernels; backward = their one-product form with plane outputs
+    np.testing.assert_array_equal(m.predict(inputs, mask, theta), probs_x3)
+    l = m.compute_grads(inputs, y, mask, theta)
+    assert abs(l - l_ref) <= 1e-5 * abs(l_ref)
+    g = m.get_grads_dict()
+    for k in O.param_names(spec):
+        assert np.abs(g[k] - g_ref[k]).max() <= 3e-2 * max(np.abs(g_ref[k]).max(), 1e-3 * gscale), k
+    m.close()
