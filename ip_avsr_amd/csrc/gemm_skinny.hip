@@ -45,6 +45,7 @@ struct SkinnyGroup {
 };
 struct SkinnyParams {
     int M, N, K, lda, ldb, ldc, ldy, colsum_ld, act, accumulate;
+    int st16;                                 // (NK) bf16 results leave in 16-byte pieces
     int k_chunk, splits;                      // (TN) k per slice, slices
     float* partial;                           // (TN) slabs [group][slice][M][ldc]
     SkinnyGroup g[kMaxGemmGroups];
@@ -71,22 +72,27 @@ __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// skinny_nn_kernel: N <= 16 NT, K <= 512.  512 threads = 8 waves x 32 rows.
+// skinny_nn_kernel: N <= 16 NT; B^T is staged KCH k at a time (one pass when K <= KCH).  512 threads = 8 waves x 32 rows.
+// (NT = 2 / 4: KCH = 512, the whole of B^T once -- forward bottleneck, classifier.  NT = 10: 128 (planes) / 256 k per pass, the
+//  first LSTM's input gradient dfeat = dG W_in^T, N = 150, K = 4H: each pass costs two barriers, the A loads stay in flight across them)
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kNnKMax = 512, kNnLdsStride = kNnKMax + 8;      // bf16 per LDS row of a B^T plane
+constexpr int kNnKMax = 512;
 
-template <int NT, bool PLANES>
+template <int NT, bool PLANES, int KCH>
 __global__ __launch_bounds__(512) void skinny_nn_kernel(const SkinnyParams p) {
     extern __shared__ __attribute__((aligned(16))) __bf16 sk_lds[];
+    constexpr int kStride = KCH + 8;                                 // bf16 per LDS row of a B^T plane
     const SkinnyGroup g = pick(p, blockIdx.y);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
     const int ksteps = (p.K + 31) / 32, kp = ksteps * 32;
-    __bf16* bs_hi = sk_lds;                                          // [16 NT][kNnLdsStride]
-    __bf16* bs_lo = sk_lds + (size_t)16 * NT * kNnLdsStride;
+    __bf16* bs_hi = sk_lds;                                          // [16 NT][kStride]
+    __bf16* bs_lo = sk_lds + (size_t)16 * NT * kStride;
     const int row0 = blockIdx.x * 256 + wave * 32;
-    // ---- A fragments: chunk = 4 k-steps of both row tiles; `want` = k-steps of the chunk that exist
-    constexpr int CH = 4;
+    // ---- A fragments: chunk = CH k-steps of both row tiles; k-steps past the end read as zero
+    constexpr int CH = (NT > 4 && PLANES) ? 2 : 4;                   // (the wide form's accumulators leave room for two)
+    constexpr int CPB = KCH / (32 * CH);                             // chunks per staged pass of B^T
+    static_assert(KCH % (32 * CH) == 0, "a pass of B^T holds whole chunks");
     size_t aoff[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) aoff[r] = (size_t)min(row0 + 16 * r + i16, p.M - 1) * p.lda + 8 * kq;      // clamped rows feed dropped outputs
@@ -108,29 +114,38 @@ __global__ __launch_bounds__(512) void skinny_nn_kernel(const SkinnyParams p) {
         }
     };
     load_chunk(0, 0);                                                 // in flight while B^T is staged
-    // ---- B^T planes -> LDS: rows n < N (others zero), k < kp (the copies' pad k is zero)
-    {
-        const int chunks_per_row = kp / 8;
+    // ---- B^T planes -> LDS, k in [k0, k0 + KCH): rows n < N (others zero), k < K (others zero)
+    auto stage_b = [&](int k0) __attribute__((always_inline)) {
+        constexpr int chunks_per_row = KCH / 8;
+        const int kend = min(kp, k0 + KCH);
         for (int e = tid; e < 16 * NT * chunks_per_row; e += 512) {
-            const int n = e / chunks_per_row, c = e % chunks_per_row;
+            const int n = e / chunks_per_row, c = e % chunks_per_row, k = k0 + 8 * c;
+            if (k >= kend) continue;                                  // (never read: the k loop stops at ksteps)
             bf16x8 vh = zero8(), vl = zero8();
-            if (n < p.N && 8 * c < p.K) {
-                vh = *reinterpret_cast<const bf16x8*>(g.B + (size_t)n * p.ldb + 8 * c);
-                if (PLANES) vl = *reinterpret_cast<const bf16x8*>(g.Blo + (size_t)n * p.ldb + 8 * c);
-                if (8 * c + 8 > p.K) { vh = mask_k(vh, 8 * c, p.K); if (PLANES) vl = mask_k(vl, 8 * c, p.K); }
+            if (n < p.N && k < p.K) {
+                vh = *reinterpret_cast<const bf16x8*>(g.B + (size_t)n * p.ldb + k);
+                if (PLANES) vl = *reinterpret_cast<const bf16x8*>(g.Blo + (size_t)n * p.ldb + k);
+                if (k + 8 > p.K) { vh = mask_k(vh, k, p.K); if (PLANES) vl = mask_k(vl, k, p.K); }
             }
-            *reinterpret_cast<bf16x8*>(bs_hi + (size_t)n * kNnLdsStride + 8 * c) = vh;
-            if (PLANES) *reinterpret_cast<bf16x8*>(bs_lo + (size_t)n * kNnLdsStride + 8 * c) = vl;
+            *reinterpret_cast<bf16x8*>(bs_hi + (size_t)n * kStride + 8 * c) = vh;
+            if (PLANES) *reinterpret_cast<bf16x8*>(bs_lo + (size_t)n * kStride + 8 * c) = vl;
         }
-    }
-    __syncthreads();
+    };
     f32x4 acc[2][NT];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nchunks = (ksteps + CH - 1) / CH;
+    auto open_pass = [&](int c) __attribute__((always_inline)) {     // chunk c opens a pass of B^T (uniform over the block); called
+        if (c % CPB == 0) {                                           // BEFORE the next chunk's A loads are issued, so that the
+            if (c) __syncthreads();                                   // pass's own loads are not queued behind them
+            stage_b(32 * CH * c);
+            __syncthreads();
+        }
+    };
     auto multiply = [&](int buf, int c) __attribute__((always_inline)) {
+        const int kb = 32 * CH * (c % CPB);                           // the chunk's k offset inside the staged pass
 #pragma unroll
         for (int s = 0; s < CH; ++s) {
             const int ks = c * CH + s;
@@ -144,11 +159,11 @@ __global__ __launch_bounds__(512) void skinny_nn_kernel(const SkinnyParams p) {
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bs_hi + (size_t)(16 * t + i16) * kNnLdsStride + 32 * ks + 8 * kq);
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bs_hi + (size_t)(16 * t + i16) * kStride + kb + 32 * s + 8 * kq);
 #pragma unroll
                 for (int r = 0; r < 2; ++r) acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[r], acc[r][t], 0, 0, 0);
                 if (PLANES) {
-                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bs_lo + (size_t)(16 * t + i16) * kNnLdsStride + 32 * ks + 8 * kq);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bs_lo + (size_t)(16 * t + i16) * kStride + kb + 32 * s + 8 * kq);
 #pragma unroll
                     for (int r = 0; r < 2; ++r) {
                         acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[r], acc[r][t], 0, 0, 0);
@@ -159,9 +174,11 @@ __global__ __launch_bounds__(512) void skinny_nn_kernel(const SkinnyParams p) {
         }
     };
     for (int c = 0; c < nchunks; c += 2) {                            // (two chunks per iteration: the buffers are compile-time)
+        open_pass(c);
         if (c + 1 < nchunks) load_chunk(1, c + 1);
         multiply(0, c);
         if (c + 1 < nchunks) {
+            open_pass(c + 1);
             if (c + 2 < nchunks) load_chunk(0, c + 2);
             multiply(1, c + 1);
         }
@@ -205,8 +222,7 @@ __global__ __launch_bounds__(512) void skinny_nn_kernel(const SkinnyParams p) {
 // trip per tile: vmcnt retires in order, so the next tile's B fragments waited for the previous tile's stores: 36 / 80 us where
 // this form takes the time of its bytes.)
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kNkTC = 2;
-template <bool PLANES>
+template <bool PLANES, int kNkTC>
 __global__ __launch_bounds__(256) void skinny_nk_kernel(const SkinnyParams p, int nchunks) {
     const SkinnyGroup g = pick(p, blockIdx.y);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -255,70 +271,108 @@ __global__ __launch_bounds__(256) void skinny_nk_kernel(const SkinnyParams p, in
             const int k = 32 * s + 8 * kq;
             if (k + 8 > p.K) { a_hi[r][s] = mask_k(a_hi[r][s], k, p.K); if (PLANES) a_lo[r][s] = mask_k(a_lo[r][s], k, p.K); }
         }
+    // bf16 results leave in 16-byte pieces: lanes kq / kq ^ 1 of a row swap halves of a pair of column tiles, so that the even lane
+    // holds 8 consecutive columns of tile 2j and the odd lane 8 of tile 2j + 1 -- a store then writes 64 contiguous bytes per row
+    // where the accumulator layout alone gives 32 (p.st16: ldc % 8 == 0 and 16-byte aligned planes; otherwise 8-byte pieces)
+    const bool odd = (kq & 1) != 0;
 #pragma unroll
-    for (int c = 0; c < kNkTC; ++c) {
-        const int t = t0 + c;
-        if (16 * t >= p.N) break;                                      // (uniform: the chunk's tiles beyond N)
-        f32x4 acc[4];
+    for (int cp = 0; cp < kNkTC / 2; ++cp) {
+        if (16 * (t0 + 2 * cp) >= p.N) break;                          // (uniform: the chunk's tiles beyond N)
+        uint2 ph[2][4], pl[2][4];                                      // packed planes of the pair's tiles
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int h = 0; h < 2; ++h) {
+            const int c = 2 * cp + h, t = t0 + c;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            if (s >= ksteps) break;
+            for (int r = 0; r < 4; ++r) { ph[h][r] = make_uint2(0u, 0u); pl[h][r] = make_uint2(0u, 0u); }
+            if (16 * t >= p.N) continue;                               // (uniform)
+            f32x4 acc[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (s >= ksteps) break;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hi[c][s], a_hi[r][s], acc[r], 0, 0, 0);
+                    if (PLANES) {
+                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_lo[c][s], a_hi[r][s], acc[r], 0, 0, 0);
+                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hi[c][s], a_lo[r][s], acc[r], 0, 0, 0);
+                    }
+                }
+            }
+            // lane = row i16 of row tile r, columns 16 t + 4 kq .. + 3
+            const int col = 16 * t + 4 * kq;
+            float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool cok = col + 4 <= p.N;                          // the whole float4 inside (N % 4 != 0: the last one is partial)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hi[c][s], a_hi[r][s], acc[r], 0, 0, 0);
-                if (PLANES) {
-                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_lo[c][s], a_hi[r][s], acc[r], 0, 0, 0);
-                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hi[c][s], a_lo[r][s], acc[r], 0, 0, 0);
+                const int row = row0 + 16 * r + i16;
+                if (row >= p.M || col >= p.N) continue;
+                float4 v = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+                if (g.Y16) {                                          // rectify'(Y) from the bf16 copy of Y
+                    const bf16x4 y = __builtin_bit_cast(bf16x4, ym[c][r]);
+                    v.x = (float)y[0] > 0.f ? v.x : 0.f; v.y = (float)y[1] > 0.f ? v.y : 0.f;
+                    v.z = (float)y[2] > 0.f ? v.z : 0.f; v.w = (float)y[3] > 0.f ? v.w : 0.f;
                 }
+                const size_t off = (size_t)row * p.ldc + col;
+                if (g.C) {
+                    if (cok) {
+                        if (p.accumulate) { const float4 cc = *reinterpret_cast<const float4*>(g.C + off); v.x += cc.x; v.y += cc.y; v.z += cc.z; v.w += cc.w; }
+                        *reinterpret_cast<float4*>(g.C + off) = v;
+                    } else {                                          // partial float4 at the right edge: element by element
+                        float* ve = reinterpret_cast<float*>(&v);
+                        for (int e = 0; e < 4 && col + e < p.N; ++e) { if (p.accumulate) ve[e] += g.C[off + e]; g.C[off + e] = ve[e]; }
+                    }
+                }
+                if (cok) { cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w; }      // (no column sums over a partial float4: N % 4 == 0 where they are asked for)
+                if (g.C16) {
+                    const uint2 hp = pack4(v.x, v.y, v.z, v.w);
+                    const bf16x4 hb = __builtin_bit_cast(bf16x4, hp);
+                    const uint2 lp = pack4(v.x - (float)hb[0], v.y - (float)hb[1], v.z - (float)hb[2], v.w - (float)hb[3]);
+                    if (p.st16) { ph[h][r] = hp; pl[h][r] = lp; }
+                    else if (cok) {
+                        *reinterpret_cast<uint2*>(g.C16 + off) = hp;
+                        if (g.C16lo) *reinterpret_cast<uint2*>(g.C16lo + off) = lp;
+                    } else {
+                        const bf16x4 lb = __builtin_bit_cast(bf16x4, lp);
+                        for (int e = 0; e < 4 && col + e < p.N; ++e) { g.C16[off + e] = hb[e]; if (g.C16lo) g.C16lo[off + e] = lb[e]; }
+                    }
+                }
+            }
+            if (g.colsum) {                                           // sums over this wave's 64 rows -> row (row0 / 64) of the workspace
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    cs.x += __shfl_xor(cs.x, o, 64); cs.y += __shfl_xor(cs.y, o, 64);
+                    cs.z += __shfl_xor(cs.z, o, 64); cs.w += __shfl_xor(cs.w, o, 64);
+                }
+                if (i16 == 0 && cok && row0 < p.M) *reinterpret_cast<float4*>(g.colsum + (size_t)(row0 / 64) * p.colsum_ld + col) = cs;
             }
         }
-        // lane = row i16 of row tile r, columns 16 t + 4 kq .. + 3
-        const int col = 16 * t + 4 * kq;
-        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
-        const bool cok = col + 4 <= p.N;                              // the whole float4 inside (N % 4 != 0: the last one is partial)
+        if (g.C16 && p.st16) {
+            const int col8 = 16 * (t0 + 2 * cp + (odd ? 1 : 0)) + 8 * (kq >> 1);
+            const int nvalid = p.N - col8;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = row0 + 16 * r + i16;
-            if (row >= p.M || col >= p.N) continue;
-            float4 v = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
-            if (g.Y16) {                                              // rectify'(Y) from the bf16 copy of Y
-                const bf16x4 y = __builtin_bit_cast(bf16x4, ym[c][r]);
-                v.x = (float)y[0] > 0.f ? v.x : 0.f; v.y = (float)y[1] > 0.f ? v.y : 0.f;
-                v.z = (float)y[2] > 0.f ? v.z : 0.f; v.w = (float)y[3] > 0.f ? v.w : 0.f;
-            }
-            const size_t off = (size_t)row * p.ldc + col;
-            if (!cok) {                                               // partial float4 at the right edge: element by element (no column sums here)
-                const float ve[4] = {v.x, v.y, v.z, v.w};
-                for (int e = 0; e < 4 && col + e < p.N; ++e) {
-                    float x = ve[e];
-                    if (g.C) { if (p.accumulate) x += g.C[off + e]; g.C[off + e] = x; }
-                    if (g.C16) { const __bf16 hb = (__bf16)x; g.C16[off + e] = hb; if (g.C16lo) g.C16lo[off + e] = (__bf16)(x - (float)hb); }
-                }
-                continue;
-            }
-            if (g.C) {
-                if (p.accumulate) { const float4 cc = *reinterpret_cast<const float4*>(g.C + off); v.x += cc.x; v.y += cc.y; v.z += cc.z; v.w += cc.w; }
-                *reinterpret_cast<float4*>(g.C + off) = v;
-            }
-            cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
-            if (g.C16) {
-                const uint2 h = pack4(v.x, v.y, v.z, v.w);
-                *reinterpret_cast<uint2*>(g.C16 + off) = h;
-                if (g.C16lo) {
-                    const bf16x4 hb = __builtin_bit_cast(bf16x4, h);
-                    *reinterpret_cast<uint2*>(g.C16lo + off) = pack4(v.x - (float)hb[0], v.y - (float)hb[1], v.z - (float)hb[2], v.w - (float)hb[3]);
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + 16 * r + i16;
+                auto swap_halves = [&](const uint2 t_even, const uint2 t_odd) __attribute__((always_inline)) {
+                    const uint2 send = odd ? t_even : t_odd;          // the half the partner lane assembles
+                    uint2 recv;
+                    recv.x = (unsigned)__shfl_xor((int)send.x, 16, 64); recv.y = (unsigned)__shfl_xor((int)send.y, 16, 64);
+                    return odd ? make_uint4(recv.x, recv.y, t_odd.x, t_odd.y) : make_uint4(t_even.x, t_even.y, recv.x, recv.y);
+                };
+                const uint4 oh = swap_halves(ph[0][r], ph[1][r]);
+                uint4 ol = make_uint4(0u, 0u, 0u, 0u);
+                if (g.C16lo) ol = swap_halves(pl[0][r], pl[1][r]);
+                if (row >= p.M || nvalid <= 0) continue;
+                const size_t off = (size_t)row * p.ldc + col8;
+                if (nvalid >= 8) {
+                    *reinterpret_cast<uint4*>(g.C16 + off) = oh;
+                    if (g.C16lo) *reinterpret_cast<uint4*>(g.C16lo + off) = ol;
+                } else {
+                    const bf16x8 eh = __builtin_bit_cast(bf16x8, oh), el = __builtin_bit_cast(bf16x8, ol);
+                    for (int e = 0; e < nvalid; ++e) { g.C16[off + e] = eh[e]; if (g.C16lo) g.C16lo[off + e] = el[e]; }
                 }
             }
-        }
-        if (g.colsum) {                                               // sums over this wave's 64 rows -> row (row0 / 64) of the workspace
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                cs.x += __shfl_xor(cs.x, o, 64); cs.y += __shfl_xor(cs.y, o, 64);
-                cs.z += __shfl_xor(cs.z, o, 64); cs.w += __shfl_xor(cs.w, o, 64);
-            }
-            if (i16 == 0 && cok && row0 < p.M) *reinterpret_cast<float4*>(g.colsum + (size_t)(row0 / 64) * p.colsum_ld + col) = cs;
         }
     }
 }
@@ -488,13 +542,19 @@ int gemm_skinny_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used, b
     // bottleneck 134.9 -> 35.4, classifier 60.0 -> 17.1, bottleneck weight gradient 147.4 -> 55.9, classifier's 74.9 -> 43.3, input
     // gradient behind the bottleneck with act'(Y) and fused sums 118.5 -> 98.1 -- because their alternative is the split-image path.
     // In plain bf16 the register-staged kernels already move these shapes at 2.6 - 3 TB/s (forward bottleneck 23.9 against 24.4
-    // here; the K <= 64 input gradient 41.5 against 66.2: its 64-column tiles store 128-byte row pieces through an LDS bounce where
-    // the transposed accumulators here store 32-byte pieces): only the 26-column classifier product (14.8 -> 11.6) comes here.
+    // here; the K <= 64 input gradient 41.5 against 66.2 -- 53.8 with the paired 16-byte stores: its 64-column tiles store 128-byte row
+    // pieces through an LDS bounce where the transposed accumulators here store 32-byte pieces, 64 after the lane swap): only the 26-column classifier product (14.8 -> 11.6) comes here.
     // (A/B switch: every skinny kernel in plain bf16 too.  The mixed mode's back-propagation -- one bf16 product whose result is still
     //  wanted as planes -- takes them as well: the register-staged kernel would write fp32 + a split pass behind it; 5.66 -> 5.52 ms)
     static const bool all_env = getenv("ADN_GEMM_SKINNY_ALL") != nullptr;
     const bool all_bf16 = all_env || g.hi_product;
-    if ((g.layout == GEMM_NN || g.layout == GEMM_NT) && g.Bkc16 && g.N <= 64 && g.K <= kNnKMax && g.K >= 32 && (planes || g.N <= 32 || all_bf16)) {
+    static const bool no_wide = getenv("ADN_GEMM_NO_SKINNY_WIDE") != nullptr;
+    const bool nn_narrow = g.N <= 64 && g.K <= kNnKMax && (planes || g.N <= 32 || all_bf16);
+    // (wide form, profiles/r05/lab_skinny2.txt, the first LSTMs' input gradient N = 150, K = 1000, two problems per launch: over planes
+    //  83.6 us against 145 in the model for the ping-pong kernel's 256-column tiles; in plain bf16 the register-staged kernel's 48.8 us
+    //  beats this form's 53.7 -- its staged passes stall the whole workgroup on two barriers each -- so bf16 problems do not come here)
+    const bool nn_wide = planes && g.N > 64 && g.N <= 160 && g.K >= 256 && g.M >= 2048 && !no_wide;
+    if ((g.layout == GEMM_NN || g.layout == GEMM_NT) && g.Bkc16 && g.K >= 32 && (nn_narrow || nn_wide)) {
         // (Bkc16: B as [N][K] k-contiguous -- for an NT problem B itself, for NN the caller's transposed copy)
         for (int k = 0; k < n; ++k) {
             const GemmArgs& q = gs[k];
@@ -513,17 +573,18 @@ int gemm_skinny_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used, b
             if (gs[k].planes_done) *gs[k].planes_done = 0;
             if (gs[k].fp32_skipped) *gs[k].fp32_skipped = 0;
         }
-        const int NT = g.N <= 32 ? 2 : 4;
-        const size_t lds = (size_t)(planes ? 2 : 1) * 16 * NT * kNnLdsStride * 2;
+        const int NT = g.N <= 32 ? 2 : g.N <= 64 ? 4 : 10;
+        const int kch = NT <= 4 ? kNnKMax : planes ? 128 : 256;
+        const size_t lds = (size_t)(planes ? 2 : 1) * 16 * NT * (kch + 8) * 2;
         const dim3 grid((unsigned)cdiv(g.M, 256), (unsigned)n);
         say(1001, 1);
         ProfScope prof(PROF_GEMM_NN, 2.0 * g.M * g.N * (planes ? 3.0 : 1.0) * g.K * n, 4.0 * n * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N), stream, n);
-#define ADN_SK_NN(NTv, PL) do { \
+#define ADN_SK_NN(NTv, PL, KCHv) do { \
         static bool attr_done = false; \
-        if (!attr_done) { ADN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_nn_kernel<NTv, PL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; } \
-        hipLaunchKernelGGL((skinny_nn_kernel<NTv, PL>), grid, dim3(512), lds, stream, p); } while (0)
-        if (planes) { if (NT == 2) ADN_SK_NN(2, true); else ADN_SK_NN(4, true); }
-        else { if (NT == 2) ADN_SK_NN(2, false); else ADN_SK_NN(4, false); }
+        if (!attr_done) { ADN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_nn_kernel<NTv, PL, KCHv>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; } \
+        hipLaunchKernelGGL((skinny_nn_kernel<NTv, PL, KCHv>), grid, dim3(512), lds, stream, p); } while (0)
+        if (planes) { if (NT == 2) ADN_SK_NN(2, true, kNnKMax); else if (NT == 4) ADN_SK_NN(4, true, kNnKMax); else ADN_SK_NN(10, true, 128); }
+        else { if (NT == 2) ADN_SK_NN(2, false, kNnKMax); else if (NT == 4) ADN_SK_NN(4, false, kNnKMax); else ADN_SK_NN(10, false, 256); }
 #undef ADN_SK_NN
         ADN_HIP_CHECK(hipGetLastError());
         *used = true;
@@ -562,13 +623,21 @@ int gemm_skinny_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used, b
             }
             if (gs[k].colsum_done) *gs[k].colsum_done = fused_colsum ? 1 : 0;
         }
-        const int nchunks = cdiv(cdiv(g.N, 16), kNkTC);
+        static const bool st8 = getenv("ADN_GEMM_SKINNY_ST8") != nullptr;          // (A/B: the accumulator layout's 8-byte pieces)
+        p.st16 = (!st8 && g.ldc % 8 == 0) ? 1 : 0;
+        for (int k = 0; k < n; ++k)
+            if ((p.g[k].C16 && !aligned(p.g[k].C16, 16)) || (p.g[k].C16lo && !aligned(p.g[k].C16lo, 16))) p.st16 = 0;
+        static const int tc_env = getenv("ADN_GEMM_SKINNY_TC") ? atoi(getenv("ADN_GEMM_SKINNY_TC")) : 0;
+        // column tiles per workgroup: 4 halves the re-reads of A from L2 but costs a wave per SIMD; it pays with one k-step of
+        // fragments (classifier, K = 26: 57.8 -> 46.4 us over planes) and not with two (bottleneck, K = 50: 95.8 -> 105.0)
+        const int tc = (tc_env == 2 || tc_env == 4) ? tc_env : (g.K <= 32 ? 4 : 2);
+        const int nchunks = cdiv(cdiv(g.N, 16), tc);
         const dim3 grid((unsigned)(cdiv(g.M, 256) * nchunks), (unsigned)n);
         say(1002, 1);
         {
             ProfScope prof(PROF_GEMM_NN, 2.0 * g.M * g.N * (planes ? 3.0 : 1.0) * g.K * n, 4.0 * n * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N), stream, n);
-            if (planes) hipLaunchKernelGGL((skinny_nk_kernel<true>), grid, dim3(256), 0, stream, p, nchunks);
-            else hipLaunchKernelGGL((skinny_nk_kernel<false>), grid, dim3(256), 0, stream, p, nchunks);
+            if (planes) { if (tc == 4) hipLaunchKernelGGL((skinny_nk_kernel<true, 4>), grid, dim3(256), 0, stream, p, nchunks); else hipLaunchKernelGGL((skinny_nk_kernel<true, 2>), grid, dim3(256), 0, stream, p, nchunks); }
+            else { if (tc == 4) hipLaunchKernelGGL((skinny_nk_kernel<false, 4>), grid, dim3(256), 0, stream, p, nchunks); else hipLaunchKernelGGL((skinny_nk_kernel<false, 2>), grid, dim3(256), 0, stream, p, nchunks); }
             ADN_HIP_CHECK(hipGetLastError());
         }
         for (int k = 0; k < n; ++k)

@@ -139,7 +139,7 @@ int main(int argc, char** argv) {
             else { to_bf16(A[k], A16[k], (size_t)ar * ac, st); to_bf16(B[k], B16[k], (size_t)br * bc, st); }
             to_bf16(Y[k], Y16[k], (size_t)c.M * ldc, st);
             BT[k] = nullptr; BT16[k] = BT16lo[k] = nullptr;
-            if (c.layout == GEMM_NN && (c.N <= 64 || c.K <= 64)) {
+            if (c.layout == GEMM_NN && (c.N <= 160 || c.K <= 64)) {
                 std::vector<float> hb((size_t)br * bc), hbt((size_t)c.N * ldbt, 0.f);
                 CK(hipMemcpy(hb.data(), B[k], hb.size() * 4, hipMemcpyDeviceToHost));
                 for (int kk = 0; kk < c.K; ++kk) for (int j = 0; j < c.N; ++j) hbt[(size_t)j * ldbt + kk] = hb[(size_t)kk * bc + j];

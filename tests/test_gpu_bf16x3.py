@@ -209,7 +209,9 @@ def test_x3_weight_stationary_lstm_kernels_match_the_fp32_step_kernels(torch_cud
         res[mode] = (m.predict(xs, mask, theta), m.compute_grads(xs, y, mask, theta), m.get_grads_dict())
         fam = _families(lib) - fam0
         # (the diagnostic switches of profiles/scripts/envmatrix.sh turn families off)
-        fwd_ws = mode == "cluster" and B <= 700 and not (H > 256 and os.environ.get("ADN_LSTM_NO_X3_WIDE"))
+        # (... and a workgroup cap: 11 groups x 16 workgroups of the (512, 520) case do not fit 64)
+        fwd_ws = mode == "cluster" and B <= 700 and not (H > 256 and os.environ.get("ADN_LSTM_NO_X3_WIDE")) and \
+            not (H > 256 and B > 192 and os.environ.get("ADN_LSTM_CUS"))
         bwd_ws = fwd_ws and not os.environ.get("ADN_LSTM_NO_X3_CLUSTER_BWD")
         assert (fam[3] > 0 and fam[0] == 0) if fwd_ws else (fam[3] == 0 and fam[0] > 0)       # the weight-stationary kernels did run
         assert (fam[7] > 0 and fam[4] == 0) if bwd_ws else (fam[7] == 0 and fam[4] > 0)       # ... both ways
@@ -340,7 +342,9 @@ def test_mixed_mode_forward_is_bf16x3_and_its_gradients_are_bf16_grade(torch_cud
             worst[prec] = max(worst[prec], e)
     print("gradients against the fp64 oracle, worst tensor error of its scale: bf16x3 %.2e, mixed %.2e" % (worst["bf16x3"], worst["mixed"]))
     assert worst["bf16x3"] <= 2e-4
-    assert 2e-4 < worst["mixed"] <= 3e-2          # one bf16 product per backward GEMM: bf16-grade, not fp32-grade
+    # one bf16 product per backward GEMM: bf16-grade, not fp32-grade (without planes -- a diagnostic switch -- the mode has no
+    # hi plane to multiply and back-propagates like bf16x3)
+    assert (0.0 if os.environ.get("ADN_X3_NO_PLANES") else 2e-4) < worst["mixed"] <= 3e-2
 
 
 def test_mixed_mode_train_steps_stay_as_close_to_bf16x3_as_bf16_does(torch_cuda, lib):
@@ -378,6 +382,8 @@ def test_plane_inputs_equal_float32_inputs(torch_cuda, lib, prec):
     mode's first GEMMs read -- give the probabilities, loss and gradients of the float32 values hi + lo (which the library
     would split into the same two planes, ties in the hi plane aside) to the last bit or two; also through a shape the GEMM over planes declines (a tiny
     batch: the staging buffer is then filled from the planes on demand), and another arithmetic gets the float32 values."""
+    if os.environ.get("ADN_X3_NO_PLANES"):
+        pytest.skip("the diagnostic switch turns the planes off: plane inputs are refused (loudly) without them")
     from ip_avsr_amd.model import AdeNetModel, PlaneInput
     torch = torch_cuda
     spec = O.spec_nstream([48, 40], enc_shapes=(64, 32, 16), enc_acts=("rectify", "rectify", "linear"), lstm_size=24, classes=7,
@@ -418,16 +424,19 @@ def _plane_inputs_cases(torch, spec, p, rng, prec):
         m.close()
 
 
-def test_skinny_and_fused_plane_kernels_against_the_oracle(torch_cuda, lib):
+@pytest.mark.parametrize("widths,lstm_size", [((160, 128, 50), 40), ((160, 120, 50), 72)])
+def test_skinny_and_fused_plane_kernels_against_the_oracle(torch_cuda, lib, widths, lstm_size):
     """A geometry at which the narrow shapes leave the register-staged kernels -- 2 100 frames under a 50-unit bottleneck and a
     26-way classifier: csrc/gemm_skinny.hip's forward (N <= 64), input-gradient (K <= 64, act'(Y) mask + fused bias sums) and
     weight-gradient (TN, slabs) kernels over hi / lo planes, with ragged row / column / k edges (2 100 = 8 x 256 + 52 rows,
     N = 50 / 26, K = 50 / 40) -- checked against the fp64 oracle: probabilities 1e-4, identical votes, loss 1e-5, every gradient
     2e-4 of its scale -- for float32 inputs and for plane inputs (ADN_FLAG_PLANE_INPUTS); the mixed mode's forward pass must give
-    the same bits and its one-product backward kernels bf16-grade gradients."""
+    the same bits and its one-product backward kernels bf16-grade gradients.  The second geometry adds a partial 16-column
+    tile to the K <= 64 kernel's paired 16-byte stores (120 = 7.5 tiles) and brings the first LSTM's input gradient (N = 150,
+    K = 4 x 72 = 288: three staged passes of B^T over planes, two in bf16) to the wide form of the N <= 160 kernel."""
     from ip_avsr_amd.model import AdeNetModel, PlaneInput
     torch = torch_cuda
-    spec = O.spec_nstream([72, 56], enc_shapes=(160, 128, 50), enc_acts=("rectify", "rectify", "linear"), lstm_size=40, classes=26,
+    spec = O.spec_nstream([72, 56], enc_shapes=widths, enc_acts=("rectify", "rectify", "linear"), lstm_size=lstm_size, classes=26,
                           fusion="concat")
     B, T, theta = 70, 30, 3
     rng = np.random.default_rng(99)
@@ -444,7 +453,7 @@ def test_skinny_and_fused_plane_kernels_against_the_oracle(torch_cuda, lib):
     m.set_params_dict(p)
     dev = [torch.tensor(x, device="cuda") for x in inputs]
     probs_x3 = None
-    for feed in (inputs, [PlaneInput.split(x) for x in dev]):
+    for feed in (inputs,) if os.environ.get("ADN_X3_NO_PLANES") else (inputs, [PlaneInput.split(x) for x in dev]):
         probs = m.predict(feed, mask, theta)
         if probs_x3 is None:
             probs_x3 = probs
