@@ -305,6 +305,8 @@ def rooflines(prof, steps, prof_elapsed, precision, hbm_measured, traffic_file):
                               "per time step)",
                     "mixed": "lstm_%s_cluster_x3_kernel (weight-stationary, hi/lo bf16 products, all T steps in one launch; "
                              "per time step)"}.get(precision, "lstm_%s_step_kernel (one launch per time step)") % key[5:8]
+            if precision == "mixed" and key == "lstm_bwd_step":      # (one bf16 product per step, like the mode's backward GEMMs)
+                kern = "lstm_bwd_cluster_kernel (the bf16 mode's weight-stationary kernel over the hi image of W_hid; per time step)"
             out[name] = {"kernel": kern, "bound": "hbm", "achieved": a, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "algorithmic_bytes": "SURVEY 8d formula: e(12BH+4H^2)+B forward, e(15BH+4H^2) backward, per LSTM and step",
                          "frac": a / PEAK_HBM_GBS,

@@ -1836,7 +1836,10 @@ int split_hilo(const float* src, void* hi, void* lo, size_t n, hipStream_t s) {
 __global__ __launch_bounds__(256) void join_hilo_kernel(const __bf16* __restrict__ hi, const __bf16* __restrict__ lo, float* __restrict__ dst,
                                                         size_t n8) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
-        const bf16x8 h = reinterpret_cast<const bf16x8*>(hi)[i], l = reinterpret_cast<const bf16x8*>(lo)[i];
+        const bf16x8 h = reinterpret_cast<const bf16x8*>(hi)[i];
+        bf16x8 l;
+        if (lo) l = reinterpret_cast<const bf16x8*>(lo)[i];
+        else for (int j = 0; j < 8; ++j) l[j] = (__bf16)0.f;      // (a tensor that only ever had its hi plane written)
         reinterpret_cast<float4*>(dst)[2 * i] = make_float4((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]);
         reinterpret_cast<float4*>(dst)[2 * i + 1] = make_float4((float)h[4] + (float)l[4], (float)h[5] + (float)l[5], (float)h[6] + (float)l[6], (float)h[7] + (float)l[7]);
     }

@@ -793,12 +793,16 @@ static void stale_forget(adn_model* m, const float* p) {
     for (size_t k = 0; k < m->fp32_stale.size(); ++k)
         if (m->fp32_stale[k].first == p) { m->fp32_stale.erase(m->fp32_stale.begin() + (long)k); return; }
 }
+// (an entry's count with kStaleHiOnly set: only the hi plane holds the tensor -- the mixed mode's LSTM back-propagation writes dG
+//  as bf16 alone -- and the fp32 values are that plane's)
+constexpr size_t kStaleHiOnly = (size_t)1 << 62;
 int restore_fp32(adn_model* m, const float* p) {
     for (size_t k = 0; k < m->fp32_stale.size(); ++k)
         if (m->fp32_stale[k].first == p) {
-            const size_t n = m->fp32_stale[k].second;
+            const size_t n = m->fp32_stale[k].second & ~kStaleHiOnly;
+            const bool hi_only = (m->fp32_stale[k].second & kStaleHiOnly) != 0;
             m->fp32_stale.erase(m->fp32_stale.begin() + (long)k);
-            return join_hilo(m->shadow_of(p), m->shadow_lo_of(p), const_cast<float*>(p), (size_t)round_up((int64_t)n, 8), m->stream);
+            return join_hilo(m->shadow_of(p), hi_only ? nullptr : m->shadow_lo_of(p), const_cast<float*>(p), (size_t)round_up((int64_t)n, 8), m->stream);
         }
     return ADN_OK;
 }
@@ -1085,17 +1089,38 @@ int run_lstm_group(adn_model* m, std::vector<LstmStep>& steps, int B, int T, boo
     ADN_TRY(flush_init_states(m, B));
     bool all = true;
     std::vector<char> planes_done(steps.size(), 0);
+    // ADN_PRECISION_MIXED: back-propagation through the recurrences on the bf16 mode's weight-stationary kernel -- one bf16 product
+    // dG W_hid^T per step over the hi image of W_hid (the image bf16 mode packs), like the mode's backward GEMMs; dG leaves as its hi
+    // plane alone, which is all those GEMMs read.  Saved state (gates, c: fp32) and the exchange protocol are the two kernels' common
+    // ground; where the bf16 kernel cannot run (too many groups for the device, a switch) the bf16x3 one does as before.
+    static const bool mixed_x3 = getenv("ADN_MIXED_LSTM_X3") != nullptr, dg_fp32 = getenv("ADN_LSTM_DG_FP32") != nullptr;   // (A/B)
+    bool mixed16 = backward && m->bwd_hi_only && m->planes() && !m->keep_fp32 && !mixed_x3 && !dg_fp32 && lstm_persistent_supported(m->H) &&
+                   !getenv("ADN_LSTM_NO_CLUSTER_BWD");
+    std::vector<LstmStep> alt;
+    if (mixed16) {
+        alt = steps;
+        for (auto& q : alt) {
+            q.W_hid16 = m->shadow_of(q.W_hid); q.h16 = m->shadow_of(q.hbuf); q.dG16 = m->shadow_of(q.dG); q.dG16lo = nullptr;
+            q.dG_fp32_off = 1; q.W_frag_fwd_lo = q.W_frag_bwd_lo = nullptr;
+            if (!q.W_hid16 || !q.dG16 || !q.W_frag_bwd) mixed16 = false;
+        }
+        for (size_t i = 0; mixed16 && i < alt.size(); i += kMaxLstmPerLaunch)
+            mixed16 = lstm_cluster_supported(alt.data() + i, (int)std::min<size_t>(kMaxLstmPerLaunch, alt.size() - i), B, T, m->H);
+    }
     for (size_t i = 0; i < steps.size(); i += kMaxLstmPerLaunch) {
         const int n = (int)std::min<size_t>(kMaxLstmPerLaunch, steps.size() - i);
         bool done = false;
-        if (backward)
+        if (backward && mixed16) {
+            ADN_TRY(lstm_backward(alt.data() + i, n, m->mask_tb, B, T, m->H, ADN_PRECISION_BF16, m->stream, &done));
+            ADN_CHECK(done, ADN_ERR_STATE, "mixed mode: the weight-stationary bf16 backward kernel was expected to run");
+        } else if (backward)
             ADN_TRY(lstm_backward(steps.data() + i, n, m->mask_tb, B, T, m->H,
                                   m->cfg.precision == ADN_PRECISION_BF16X3 ? ADN_PRECISION_BF16X3 : m->lstm_precision(), m->stream, &done));
         else ADN_TRY(lstm_forward(steps.data() + i, n, m->mask_tb, B, T, m->H,
                                   m->cfg.precision == ADN_PRECISION_BF16X3 ? ADN_PRECISION_BF16X3 : m->lstm_precision(), m->stream));
         all = all && done;
         // (bf16x3: `done` <=> the weight-stationary hi / lo kernel ran, which also writes the planes of dG when they are offered)
-        for (int k = 0; k < n; ++k) planes_done[i + k] = backward && done && steps[i + k].dG16 && steps[i + k].dG16lo;
+        for (int k = 0; k < n; ++k) planes_done[i + k] = backward && done && (mixed16 || (steps[i + k].dG16 && steps[i + k].dG16lo));
     }
     if (sums_done) *sums_done = backward && all;
     if (m->planes())                 // (bf16 mode: the kernels write the 16-bit copies themselves)
@@ -1105,8 +1130,9 @@ int run_lstm_group(adn_model* m, std::vector<LstmStep>& steps, int B, int T, boo
                 if (!planes_done[q]) ADN_TRY(refresh(m, st_.dG, (size_t)B * T * m->ldg));
                 else {                                   // fp32 dG was not written: a reader that needs it asks restore_fp32()
                     bool have = false;
-                    for (auto& e : m->fp32_stale) if (e.first == st_.dG) { e.second = (size_t)B * T * m->ldg; have = true; }
-                    if (!have) m->fp32_stale.push_back({st_.dG, (size_t)B * T * m->ldg});
+                    const size_t count = ((size_t)B * T * m->ldg) | (mixed16 ? kStaleHiOnly : 0);
+                    for (auto& e : m->fp32_stale) if (e.first == st_.dG) { e.second = count; have = true; }
+                    if (!have) m->fp32_stale.push_back({st_.dG, count});
                 }
             }
             else ADN_TRY(refresh(m, st_.hbuf, (size_t)(T + 1) * B * m->ldh));
