@@ -123,6 +123,8 @@ struct GemmArgs {
     const void* Bkc16 = nullptr; const void* Bkc16lo = nullptr; int ldbkc = 0;
     int hi_product = 0;                // ADN_PRECISION_MIXED, back-propagation: ONE bf16 product over the hi planes (A16 / B16 given,
                                        // no lo planes, precision = bf16) whose result is still offered as planes (C16 / C16lo, lean_ok)
+    int hi_result = 0;                 // ... and whose readers take the hi plane alone: C16lo is NOT written, planes_done / lean_ok go by
+                                       // C16 (the caller marks the fp32 tensor "hi plane only")
     int b_pad_zero = 0;                // the columns of B behind N (up to ldb) hold zeros: a kernel may then compute (and write zeros
                                        // into) the pad columns of C up to round_up(N, 4)
     int* fp32_skipped = nullptr;       // (out) lean_ok was used: C was NOT written, the result lives in its planes only

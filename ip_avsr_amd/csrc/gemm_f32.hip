@@ -368,12 +368,14 @@ static int gemm_pp_try_impl(const GemmArgs* gs, int n, const GemmArgs& g, int ks
         GemmGroup& q = p.grp[k];
         q.A16 = gs[k].A16; q.B16 = gs[k].B16; q.C = gs[k].C; q.C16 = splits > 1 ? nullptr : gs[k].C16;
         q.A16lo = kseg ? gs[k].A16lo : nullptr; q.B16lo = kseg ? gs[k].B16lo : nullptr;
-        q.C16lo = ((kseg || gs[k].hi_product) && splits == 1 && q.C16) ? gs[k].C16lo : nullptr;
-        if (gs[k].planes_done) *gs[k].planes_done = q.C16lo ? 1 : 0;
+        const bool hi_res = gs[k].hi_product && gs[k].hi_result && splits == 1 && q.C16 && gs[k].C16lo;      // (the hi plane is the result)
+        q.C16lo = ((kseg || gs[k].hi_product) && splits == 1 && q.C16 && !hi_res) ? gs[k].C16lo : nullptr;
+        const bool planes_out = q.C16lo || hi_res;
+        if (gs[k].planes_done) *gs[k].planes_done = planes_out ? 1 : 0;
         // (planes: the fp32 copy of a result every reader takes from its planes is not written -- unless the bias gradient
         //  that rides on this launch could not be fused and will be summed from the fp32 values)
         if (gs[k].fp32_skipped) *gs[k].fp32_skipped = 0;
-        if (q.C16lo && gs[k].lean_ok && !g.accumulate && (!g.colsum || fused_colsum)) {
+        if (planes_out && gs[k].lean_ok && !g.accumulate && (!g.colsum || fused_colsum)) {
             q.C = nullptr;
             if (gs[k].fp32_skipped) *gs[k].fp32_skipped = 1;
         }

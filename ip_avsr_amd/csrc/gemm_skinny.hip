@@ -522,7 +522,7 @@ int gemm_skinny_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used, b
         if (q.layout != g.layout || q.M != g.M || q.N != g.N || q.K != g.K || q.lda != g.lda || q.ldb != g.ldb || q.ldc != g.ldc ||
             q.ldy != g.ldy || q.ldbkc != g.ldbkc || q.act != g.act || q.act_grad != g.act_grad || q.accumulate != g.accumulate ||
             q.precision != g.precision || (q.C == nullptr) != (g.C == nullptr) || (q.C16 == nullptr) != (g.C16 == nullptr) ||
-            (q.C16lo == nullptr) != (g.C16lo == nullptr) || (q.bias == nullptr) != (g.bias == nullptr) || (q.Y16 == nullptr) != (g.Y16 == nullptr) ||
+            (q.C16lo == nullptr) != (g.C16lo == nullptr) || q.hi_result != g.hi_result || q.hi_product != g.hi_product || (q.bias == nullptr) != (g.bias == nullptr) || (q.Y16 == nullptr) != (g.Y16 == nullptr) ||
             (q.Y == nullptr) != (g.Y == nullptr) || (q.colsum == nullptr) != (g.colsum == nullptr) || (q.Bkc16 == nullptr) != (g.Bkc16 == nullptr))
             return ADN_OK;
     }
@@ -614,10 +614,12 @@ int gemm_skinny_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used, b
             SkinnyGroup& q = p.g[k];
             q.Y16 = (g.act_grad == ADN_ACT_RECTIFY) ? reinterpret_cast<const __bf16*>(gs[k].Y16) : nullptr;
             q.colsum = fused_colsum ? gs[k].colsum_ws : nullptr;
-            q.C16lo = (planes || gs[k].hi_product) ? q.C16lo : nullptr;
-            if (gs[k].planes_done) *gs[k].planes_done = (q.C16 && q.C16lo) ? 1 : 0;
+            const bool hi_res = gs[k].hi_product && gs[k].hi_result && q.C16 && q.C16lo;      // (the hi plane is the result)
+            q.C16lo = ((planes || gs[k].hi_product) && !hi_res) ? q.C16lo : nullptr;
+            const bool planes_out = q.C16 && (q.C16lo || hi_res);
+            if (gs[k].planes_done) *gs[k].planes_done = planes_out ? 1 : 0;
             if (gs[k].fp32_skipped) *gs[k].fp32_skipped = 0;
-            if (q.C16 && q.C16lo && gs[k].lean_ok && !g.accumulate && (!g.colsum || fused_colsum)) {
+            if (planes_out && gs[k].lean_ok && !g.accumulate && (!g.colsum || fused_colsum)) {
                 q.C = nullptr;
                 if (gs[k].fp32_skipped) *gs[k].fp32_skipped = 1;
             }

@@ -825,8 +825,9 @@ static int operands_ready(adn_model* m, const GemmArgs* gs, int n) {
 static void result_written(adn_model* m, const GemmArgs& g, int skipped) {
     if (!g.C) return;
     if (skipped) {
-        for (auto& e : m->fp32_stale) if (e.first == g.C) { e.second = (size_t)g.M * g.ldc; return; }
-        m->fp32_stale.push_back({g.C, (size_t)g.M * g.ldc});
+        const size_t count = ((size_t)g.M * g.ldc) | ((g.hi_product && g.hi_result) ? kStaleHiOnly : 0);
+        for (auto& e : m->fp32_stale) if (e.first == g.C) { e.second = count; return; }
+        m->fp32_stale.push_back({g.C, count});
     } else if (!m->fp32_stale.empty()) stale_forget(m, g.C);
 }
 // ADN_PRECISION_MIXED: a GEMM of back-propagation whose operands have their planes runs as ONE bf16 product over the hi planes
@@ -840,6 +841,8 @@ static void mixed_backward(const adn_model* m, GemmArgs& g) {
     } else if (!g.B16 || !g.B16lo) return;
     g.A16lo = g.B16lo = nullptr; g.BT16 = g.BT16lo = nullptr;
     g.precision = ADN_PRECISION_BF16; g.hi_product = 1;
+    static const bool both = getenv("ADN_MIXED_BOTH_PLANES") != nullptr;        // (A/B: write the lo planes nobody reads)
+    g.hi_result = both ? 0 : 1;      // every reader of a back-propagated tensor's planes is such a product: the lo plane is not written
 }
 static bool reads_hi_planes_only(const GemmArgs& g) { return g.hi_product && g.A16 && g.B16; }
 
