@@ -67,9 +67,10 @@ typedef enum {
                               recurrent products likewise, in weight-stationary kernels, for LSTMs of <= 256 units
                               (wider ones run the fp32 per-step kernels) */
     ADN_PRECISION_MIXED = 3 /* ADN_PRECISION_BF16X3 for everything the forward pass computes (activations, probabilities,
-                              votes: the same bits) and for the recurrent kernels; the GEMMs of back-propagation run ONE bf16
-                              product over the operands' hi planes (gradients of bf16 grade, as in ADN_PRECISION_BF16).  Not a
-                              parity mode for gradients: reported under its own name, never as bf16x3 */
+                              votes: the same bits), recurrent kernels included; back-propagation runs ONE bf16 product per
+                              GEMM over the operands' hi planes and per recurrent step over the hi image of W_hid (gradients
+                              of bf16 grade, as in ADN_PRECISION_BF16; back-propagated tensors are kept as their hi plane).
+                              Not a parity mode for gradients: reported under its own name, never as bf16x3 */
 } adn_precision;
 
 enum {

@@ -376,6 +376,40 @@ def test_mixed_mode_train_steps_stay_as_close_to_bf16x3_as_bf16_does(torch_cuda,
     assert agree_mixed >= agree_bf16 - 1.0 / len(mask) - 1e-9, (agree_mixed, agree_bf16)
 
 
+@pytest.mark.parametrize("H,B,T", [(250, 70, 9), (300, 48, 6), (64, 33, 2)])
+def test_mixed_mode_backpropagates_through_the_recurrences_on_the_bf16_kernel(torch_cuda, lib, H, B, T):
+    """ADN_PRECISION_MIXED: the recurrent back-propagation is the bf16 mode's weight-stationary kernel over the hi image of W_hid
+    (csrc/model.hip::run_lstm_group) -- one product per step, dG as its hi plane alone -- behind the bf16x3 forward kernels: the
+    loss is the bf16x3 mode's (1e-5 of the fp64 oracle's), every gradient within 3e-2 of its scale (ragged masks, peepholes,
+    backwards LSTMs of the aggregation pair, a 300-unit layer on the 8-workgroup form), and the kernel families that ran are
+    those two."""
+    spec, p, m, rng = _small_x3_model(H, True, 4242 + H)
+    m.set_precision("mixed")
+    theta = min(9, 2 * T + 1)
+    mask = ragged_mask(rng, B, T) if T > 2 else np.ones((B, T), np.uint8)
+    xs = [(rng.normal(size=(B, T, d)) * mask[..., None]).astype(np.float32) for d in (60, 44)]
+    y = np.repeat((np.arange(B) % 26)[:, None], T, axis=1).astype(np.int32)
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    l_ref, g_ref, _ = O.loss_and_grads(spec, p64, [x.astype(np.float64) for x in xs], y, mask, theta)
+    gscale = max(np.abs(v).max() for v in g_ref.values())
+    fam0 = _families(lib)
+    l = m.compute_grads(xs, y, mask, theta)
+    g = m.get_grads_dict()
+    fam = _families(lib) - fam0
+    m.close()
+    switched = any(os.environ.get(k) for k in ("ADN_MIXED_LSTM_X3", "ADN_LSTM_NO_CLUSTER", "ADN_LSTM_NO_CLUSTER_BWD", "ADN_LSTM_DG_FP32",
+                                               "ADN_X3_NO_PLANES", "ADN_LSTM_NO_X3_CLUSTER", "ADN_LSTM_NO_X3_WIDE", "ADN_LSTM_CUS"))
+    if not switched:
+        assert fam[3] > 0 and fam[6] > 0 and fam[7] == 0 and fam[4] == 0, fam      # forward: bf16x3 kernels; backward: the bf16 one
+    assert abs(l - l_ref) <= 1e-5 * abs(l_ref)
+    worst = 0.0
+    for k in O.param_names(spec):
+        e = np.abs(g[k] - g_ref[k]).max() / max(np.abs(g_ref[k]).max(), 1e-3 * gscale)
+        worst = max(worst, e)
+        assert e <= 3e-2, (k, e)
+    print("mixed mode, H = %d: worst gradient %.2e of its scale against the fp64 oracle" % (H, worst))
+
+
 @pytest.mark.parametrize("prec", ["bf16x3", "mixed"])
 def test_plane_inputs_equal_float32_inputs(torch_cuda, lib, prec):
     """ADN_FLAG_PLANE_INPUTS (include/adenet.h): the stream inputs handed over as their hi / lo bfloat16 planes -- what the
