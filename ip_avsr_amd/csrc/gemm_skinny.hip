@@ -630,9 +630,11 @@ int gemm_skinny_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used, b
         for (int k = 0; k < n; ++k)
             if ((p.g[k].C16 && !aligned(p.g[k].C16, 16)) || (p.g[k].C16lo && !aligned(p.g[k].C16lo, 16))) p.st16 = 0;
         static const int tc_env = getenv("ADN_GEMM_SKINNY_TC") ? atoi(getenv("ADN_GEMM_SKINNY_TC")) : 0;
-        // column tiles per workgroup: 4 halves the re-reads of A from L2 but costs a wave per SIMD; it pays with one k-step of
-        // fragments (classifier, K = 26: 57.8 -> 46.4 us over planes) and not with two (bottleneck, K = 50: 95.8 -> 105.0)
-        const int tc = (tc_env == 2 || tc_env == 4) ? tc_env : (g.K <= 32 ? 4 : 2);
+        // column tiles per workgroup: 4 halves the re-reads of A from L2 but costs a wave per SIMD and half the workgroups.  With three
+        // problems per launch it paid on the one-k-step classifier shape in the lab (K = 26: 57.8 -> 46.4 us over planes) and not on the
+        // bottleneck (K = 50: 95.8 -> 105.0); in the model the classifier's input gradient is ONE problem -- 328 workgroups at 4 tiles --
+        // and went 14.7 -> 39.3 us: 2 everywhere
+        const int tc = (tc_env == 2 || tc_env == 4) ? tc_env : 2;
         const int nchunks = cdiv(cdiv(g.N, 16), tc);
         const dim3 grid((unsigned)(cdiv(g.M, 256) * nchunks), (unsigned)n);
         say(1002, 1);

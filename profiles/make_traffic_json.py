@@ -57,6 +57,8 @@ def main():
     # the LSTM time steps of a train step)
     lstm = {"bf16": "lstm_%s_cluster_kernel", "bf16x3": "lstm_%s_cluster_x3_kernel", "mixed": "lstm_%s_cluster_x3_kernel"}.get(prec, "lstm_%s_step_kernel")
     for key, m in (("lstm_fwd", lstm % "fwd"), ("lstm_bwd", lstm % "bwd")):
+        if prec == "mixed" and key == "lstm_bwd":
+            m = "lstm_bwd_cluster_kernel"        # (the mode back-propagates through the recurrences on the bf16 mode's kernel)
         d = summarise(fa, fb, m, train_steps)
         if d["launches"]:
             d["kernel"] = m
