@@ -580,8 +580,10 @@ int gemm_skinny_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used, b
         say(1001, 1);
         ProfScope prof(PROF_GEMM_NN, 2.0 * g.M * g.N * (planes ? 3.0 : 1.0) * g.K * n, 4.0 * n * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N), stream, n);
 #define ADN_SK_NN(NTv, PL, KCHv) do { \
-        static bool attr_done = false; \
-        if (!attr_done) { ADN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_nn_kernel<NTv, PL, KCHv>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; } \
+        static bool attr_done[64] = {};                /* (a function attribute is per device) */ \
+        int dev_ = 0; ADN_HIP_CHECK(hipGetDevice(&dev_)); \
+        ADN_CHECK(dev_ >= 0 && dev_ < 64, ADN_ERR_STATE, "gemm_skinny: device ordinal out of range"); \
+        if (!attr_done[dev_]) { ADN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_nn_kernel<NTv, PL, KCHv>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done[dev_] = true; } \
         hipLaunchKernelGGL((skinny_nn_kernel<NTv, PL, KCHv>), grid, dim3(512), lds, stream, p); } while (0)
         if (planes) { if (NT == 2) ADN_SK_NN(2, true, kNnKMax); else if (NT == 4) ADN_SK_NN(4, true, kNnKMax); else ADN_SK_NN(10, true, 128); }
         else { if (NT == 2) ADN_SK_NN(2, false, kNnKMax); else if (NT == 4) ADN_SK_NN(4, false, kNnKMax); else ADN_SK_NN(10, false, 256); }
