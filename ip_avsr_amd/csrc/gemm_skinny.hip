@@ -45,7 +45,6 @@ struct SkinnyGroup {
 };
 struct SkinnyParams {
     int M, N, K, lda, ldb, ldc, ldy, colsum_ld, act, accumulate;
-    int st16;                                 // (NK) bf16 results leave in 16-byte pieces
     int k_chunk, splits;                      // (TN) k per slice, slices
     float* partial;                           // (TN) slabs [group][slice][M][ldc]
     SkinnyGroup g[kMaxGemmGroups];
@@ -220,9 +219,13 @@ __global__ __launch_bounds__(512) void skinny_nn_kernel(const SkinnyParams p) {
 // requested up front (one exposed latency per wave); many small workgroups (61 waves per CU at the bench shape) hide it and the
 // store acknowledgements.  (The first form -- a wave walking all N / 16 tiles with a one-tile B prefetch -- paid a memory round
 // trip per tile: vmcnt retires in order, so the next tile's B fragments waited for the previous tile's stores: 36 / 80 us where
-// this form takes the time of its bytes.)
+// this form takes the time of its bytes.  Tried on top, round 5, and withdrawn: pairs of column tiles computed together so that lanes
+// kq / kq ^ 1 can swap halves and store 16-byte pieces (64 contiguous bytes per row), 2 or 4 tiles per workgroup -- on one box, against
+// this form: three problems per launch 97 -> 98..107 us (bottleneck shape), one problem per launch 19.5 -> 38.8 us (classifier shape):
+// profiles/r05/lab_skinny2.txt.)
 // ---------------------------------------------------------------------------------------------------------
-template <bool PLANES, int kNkTC>
+constexpr int kNkTC = 2;
+template <bool PLANES>
 __global__ __launch_bounds__(256) void skinny_nk_kernel(const SkinnyParams p, int nchunks) {
     const SkinnyGroup g = pick(p, blockIdx.y);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -271,108 +274,70 @@ __global__ __launch_bounds__(256) void skinny_nk_kernel(const SkinnyParams p, in
             const int k = 32 * s + 8 * kq;
             if (k + 8 > p.K) { a_hi[r][s] = mask_k(a_hi[r][s], k, p.K); if (PLANES) a_lo[r][s] = mask_k(a_lo[r][s], k, p.K); }
         }
-    // bf16 results leave in 16-byte pieces: lanes kq / kq ^ 1 of a row swap halves of a pair of column tiles, so that the even lane
-    // holds 8 consecutive columns of tile 2j and the odd lane 8 of tile 2j + 1 -- a store then writes 64 contiguous bytes per row
-    // where the accumulator layout alone gives 32 (p.st16: ldc % 8 == 0 and 16-byte aligned planes; otherwise 8-byte pieces)
-    const bool odd = (kq & 1) != 0;
 #pragma unroll
-    for (int cp = 0; cp < kNkTC / 2; ++cp) {
-        if (16 * (t0 + 2 * cp) >= p.N) break;                          // (uniform: the chunk's tiles beyond N)
-        uint2 ph[2][4], pl[2][4];                                      // packed planes of the pair's tiles
+    for (int c = 0; c < kNkTC; ++c) {
+        const int t = t0 + c;
+        if (16 * t >= p.N) break;                                      // (uniform: the chunk's tiles beyond N)
+        f32x4 acc[4];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int c = 2 * cp + h, t = t0 + c;
+        for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { ph[h][r] = make_uint2(0u, 0u); pl[h][r] = make_uint2(0u, 0u); }
-            if (16 * t >= p.N) continue;                               // (uniform)
-            f32x4 acc[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                if (s >= ksteps) break;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hi[c][s], a_hi[r][s], acc[r], 0, 0, 0);
-                    if (PLANES) {
-                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_lo[c][s], a_hi[r][s], acc[r], 0, 0, 0);
-                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hi[c][s], a_lo[r][s], acc[r], 0, 0, 0);
-                    }
-                }
-            }
-            // lane = row i16 of row tile r, columns 16 t + 4 kq .. + 3
-            const int col = 16 * t + 4 * kq;
-            float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
-            const bool cok = col + 4 <= p.N;                          // the whole float4 inside (N % 4 != 0: the last one is partial)
+        for (int s = 0; s < 2; ++s) {
+            if (s >= ksteps) break;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = row0 + 16 * r + i16;
-                if (row >= p.M || col >= p.N) continue;
-                float4 v = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
-                if (g.Y16) {                                          // rectify'(Y) from the bf16 copy of Y
-                    const bf16x4 y = __builtin_bit_cast(bf16x4, ym[c][r]);
-                    v.x = (float)y[0] > 0.f ? v.x : 0.f; v.y = (float)y[1] > 0.f ? v.y : 0.f;
-                    v.z = (float)y[2] > 0.f ? v.z : 0.f; v.w = (float)y[3] > 0.f ? v.w : 0.f;
+                acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hi[c][s], a_hi[r][s], acc[r], 0, 0, 0);
+                if (PLANES) {
+                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_lo[c][s], a_hi[r][s], acc[r], 0, 0, 0);
+                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hi[c][s], a_lo[r][s], acc[r], 0, 0, 0);
                 }
-                const size_t off = (size_t)row * p.ldc + col;
-                if (g.C) {
-                    if (cok) {
-                        if (p.accumulate) { const float4 cc = *reinterpret_cast<const float4*>(g.C + off); v.x += cc.x; v.y += cc.y; v.z += cc.z; v.w += cc.w; }
-                        *reinterpret_cast<float4*>(g.C + off) = v;
-                    } else {                                          // partial float4 at the right edge: element by element
-                        float* ve = reinterpret_cast<float*>(&v);
-                        for (int e = 0; e < 4 && col + e < p.N; ++e) { if (p.accumulate) ve[e] += g.C[off + e]; g.C[off + e] = ve[e]; }
-                    }
-                }
-                if (cok) { cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w; }      // (no column sums over a partial float4: N % 4 == 0 where they are asked for)
-                if (g.C16) {
-                    const uint2 hp = pack4(v.x, v.y, v.z, v.w);
-                    const bf16x4 hb = __builtin_bit_cast(bf16x4, hp);
-                    const uint2 lp = pack4(v.x - (float)hb[0], v.y - (float)hb[1], v.z - (float)hb[2], v.w - (float)hb[3]);
-                    if (p.st16) { ph[h][r] = hp; pl[h][r] = lp; }
-                    else if (cok) {
-                        *reinterpret_cast<uint2*>(g.C16 + off) = hp;
-                        if (g.C16lo) *reinterpret_cast<uint2*>(g.C16lo + off) = lp;
-                    } else {
-                        const bf16x4 lb = __builtin_bit_cast(bf16x4, lp);
-                        for (int e = 0; e < 4 && col + e < p.N; ++e) { g.C16[off + e] = hb[e]; if (g.C16lo) g.C16lo[off + e] = lb[e]; }
-                    }
-                }
-            }
-            if (g.colsum) {                                           // sums over this wave's 64 rows -> row (row0 / 64) of the workspace
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    cs.x += __shfl_xor(cs.x, o, 64); cs.y += __shfl_xor(cs.y, o, 64);
-                    cs.z += __shfl_xor(cs.z, o, 64); cs.w += __shfl_xor(cs.w, o, 64);
-                }
-                if (i16 == 0 && cok && row0 < p.M) *reinterpret_cast<float4*>(g.colsum + (size_t)(row0 / 64) * p.colsum_ld + col) = cs;
             }
         }
-        if (g.C16 && p.st16) {
-            const int col8 = 16 * (t0 + 2 * cp + (odd ? 1 : 0)) + 8 * (kq >> 1);
-            const int nvalid = p.N - col8;
+        // lane = row i16 of row tile r, columns 16 t + 4 kq .. + 3
+        const int col = 16 * t + 4 * kq;
+        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool cok = col + 4 <= p.N;                              // the whole float4 inside (N % 4 != 0: the last one is partial)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = row0 + 16 * r + i16;
-                auto swap_halves = [&](const uint2 t_even, const uint2 t_odd) __attribute__((always_inline)) {
-                    const uint2 send = odd ? t_even : t_odd;          // the half the partner lane assembles
-                    uint2 recv;
-                    recv.x = (unsigned)__shfl_xor((int)send.x, 16, 64); recv.y = (unsigned)__shfl_xor((int)send.y, 16, 64);
-                    return odd ? make_uint4(recv.x, recv.y, t_odd.x, t_odd.y) : make_uint4(t_even.x, t_even.y, recv.x, recv.y);
-                };
-                const uint4 oh = swap_halves(ph[0][r], ph[1][r]);
-                uint4 ol = make_uint4(0u, 0u, 0u, 0u);
-                if (g.C16lo) ol = swap_halves(pl[0][r], pl[1][r]);
-                if (row >= p.M || nvalid <= 0) continue;
-                const size_t off = (size_t)row * p.ldc + col8;
-                if (nvalid >= 8) {
-                    *reinterpret_cast<uint4*>(g.C16 + off) = oh;
-                    if (g.C16lo) *reinterpret_cast<uint4*>(g.C16lo + off) = ol;
-                } else {
-                    const bf16x8 eh = __builtin_bit_cast(bf16x8, oh), el = __builtin_bit_cast(bf16x8, ol);
-                    for (int e = 0; e < nvalid; ++e) { g.C16[off + e] = eh[e]; if (g.C16lo) g.C16lo[off + e] = el[e]; }
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + 16 * r + i16;
+            if (row >= p.M || col >= p.N) continue;
+            float4 v = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+            if (g.Y16) {                                              // rectify'(Y) from the bf16 copy of Y
+                const bf16x4 y = __builtin_bit_cast(bf16x4, ym[c][r]);
+                v.x = (float)y[0] > 0.f ? v.x : 0.f; v.y = (float)y[1] > 0.f ? v.y : 0.f;
+                v.z = (float)y[2] > 0.f ? v.z : 0.f; v.w = (float)y[3] > 0.f ? v.w : 0.f;
+            }
+            const size_t off = (size_t)row * p.ldc + col;
+            if (!cok) {                                               // partial float4 at the right edge: element by element (no column sums here)
+                const float ve[4] = {v.x, v.y, v.z, v.w};
+                for (int e = 0; e < 4 && col + e < p.N; ++e) {
+                    float x = ve[e];
+                    if (g.C) { if (p.accumulate) x += g.C[off + e]; g.C[off + e] = x; }
+                    if (g.C16) { const __bf16 hb = (__bf16)x; g.C16[off + e] = hb; if (g.C16lo) g.C16lo[off + e] = (__bf16)(x - (float)hb); }
+                }
+                continue;
+            }
+            if (g.C) {
+                if (p.accumulate) { const float4 cc = *reinterpret_cast<const float4*>(g.C + off); v.x += cc.x; v.y += cc.y; v.z += cc.z; v.w += cc.w; }
+                *reinterpret_cast<float4*>(g.C + off) = v;
+            }
+            cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+            if (g.C16) {
+                const uint2 h = pack4(v.x, v.y, v.z, v.w);
+                *reinterpret_cast<uint2*>(g.C16 + off) = h;
+                if (g.C16lo) {
+                    const bf16x4 hb = __builtin_bit_cast(bf16x4, h);
+                    *reinterpret_cast<uint2*>(g.C16lo + off) = pack4(v.x - (float)hb[0], v.y - (float)hb[1], v.z - (float)hb[2], v.w - (float)hb[3]);
                 }
             }
+        }
+        if (g.colsum) {                                               // sums over this wave's 64 rows -> row (row0 / 64) of the workspace
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                cs.x += __shfl_xor(cs.x, o, 64); cs.y += __shfl_xor(cs.y, o, 64);
+                cs.z += __shfl_xor(cs.z, o, 64); cs.w += __shfl_xor(cs.w, o, 64);
+            }
+            if (i16 == 0 && cok && row0 < p.M) *reinterpret_cast<float4*>(g.colsum + (size_t)(row0 / 64) * p.colsum_ld + col) = cs;
         }
     }
 }
@@ -542,8 +507,8 @@ int gemm_skinny_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used, b
     // bottleneck 134.9 -> 35.4, classifier 60.0 -> 17.1, bottleneck weight gradient 147.4 -> 55.9, classifier's 74.9 -> 43.3, input
     // gradient behind the bottleneck with act'(Y) and fused sums 118.5 -> 98.1 -- because their alternative is the split-image path.
     // In plain bf16 the register-staged kernels already move these shapes at 2.6 - 3 TB/s (forward bottleneck 23.9 against 24.4
-    // here; the K <= 64 input gradient 41.5 against 66.2 -- 53.8 with the paired 16-byte stores: its 64-column tiles store 128-byte row
-    // pieces through an LDS bounce where the transposed accumulators here store 32-byte pieces, 64 after the lane swap): only the 26-column classifier product (14.8 -> 11.6) comes here.
+    // here; the K <= 64 input gradient 41.5 against 66.2: its 64-column tiles store 128-byte row pieces through an LDS bounce where the
+    // transposed accumulators here store 32-byte pieces): only the 26-column classifier product (14.8 -> 11.6) comes here.
     // (A/B switch: every skinny kernel in plain bf16 too.  The mixed mode's back-propagation -- one bf16 product whose result is still
     //  wanted as planes -- takes them as well: the register-staged kernel would write fp32 + a split pass behind it; 5.66 -> 5.52 ms)
     static const bool all_env = getenv("ADN_GEMM_SKINNY_ALL") != nullptr;
@@ -627,23 +592,13 @@ int gemm_skinny_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used, b
             }
             if (gs[k].colsum_done) *gs[k].colsum_done = fused_colsum ? 1 : 0;
         }
-        static const bool st8 = getenv("ADN_GEMM_SKINNY_ST8") != nullptr;          // (A/B: the accumulator layout's 8-byte pieces)
-        p.st16 = (!st8 && g.ldc % 8 == 0) ? 1 : 0;
-        for (int k = 0; k < n; ++k)
-            if ((p.g[k].C16 && !aligned(p.g[k].C16, 16)) || (p.g[k].C16lo && !aligned(p.g[k].C16lo, 16))) p.st16 = 0;
-        static const int tc_env = getenv("ADN_GEMM_SKINNY_TC") ? atoi(getenv("ADN_GEMM_SKINNY_TC")) : 0;
-        // column tiles per workgroup: 4 halves the re-reads of A from L2 but costs a wave per SIMD and half the workgroups.  With three
-        // problems per launch it paid on the one-k-step classifier shape in the lab (K = 26: 57.8 -> 46.4 us over planes) and not on the
-        // bottleneck (K = 50: 95.8 -> 105.0); in the model the classifier's input gradient is ONE problem -- 328 workgroups at 4 tiles --
-        // and went 14.7 -> 39.3 us: 2 everywhere
-        const int tc = (tc_env == 2 || tc_env == 4) ? tc_env : 2;
-        const int nchunks = cdiv(cdiv(g.N, 16), tc);
+        const int nchunks = cdiv(cdiv(g.N, 16), kNkTC);
         const dim3 grid((unsigned)(cdiv(g.M, 256) * nchunks), (unsigned)n);
         say(1002, 1);
         {
             ProfScope prof(PROF_GEMM_NN, 2.0 * g.M * g.N * (planes ? 3.0 : 1.0) * g.K * n, 4.0 * n * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N), stream, n);
-            if (planes) { if (tc == 4) hipLaunchKernelGGL((skinny_nk_kernel<true, 4>), grid, dim3(256), 0, stream, p, nchunks); else hipLaunchKernelGGL((skinny_nk_kernel<true, 2>), grid, dim3(256), 0, stream, p, nchunks); }
-            else { if (tc == 4) hipLaunchKernelGGL((skinny_nk_kernel<false, 4>), grid, dim3(256), 0, stream, p, nchunks); else hipLaunchKernelGGL((skinny_nk_kernel<false, 2>), grid, dim3(256), 0, stream, p, nchunks); }
+            if (planes) hipLaunchKernelGGL((skinny_nk_kernel<true>), grid, dim3(256), 0, stream, p, nchunks);
+            else hipLaunchKernelGGL((skinny_nk_kernel<false>), grid, dim3(256), 0, stream, p, nchunks);
             ADN_HIP_CHECK(hipGetLastError());
         }
         for (int k = 0; k < n; ++k)
