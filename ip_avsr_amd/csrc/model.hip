@@ -921,7 +921,9 @@ int refresh_transposed(adn_model* m) {
         m->transw_blocks = total;
     }
     ADN_TRY(transpose_to_bf16_batch(m->transw_items, (int)items.size(), m->transw_blocks, m->stream));
-    if (m->planes()) ADN_TRY(transpose_to_bf16_batch(m->transw_items_lo, (int)items.size(), m->transw_blocks, m->stream, 1));
+    // (the transposed copies are read by back-propagation only, dX = dZ W^T: in the mixed arithmetic that is one product over the hi
+    //  planes, and the lo planes stay as they are -- adn_set_precision() marks the parameters dirty, so leaving the mode re-makes them)
+    if (m->planes() && !m->bwd_hi_only) ADN_TRY(transpose_to_bf16_batch(m->transw_items_lo, (int)items.size(), m->transw_blocks, m->stream, 1));
     return ADN_OK;
 }
 
