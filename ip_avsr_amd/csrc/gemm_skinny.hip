@@ -45,6 +45,7 @@ struct SkinnyGroup {
 };
 struct SkinnyParams {
     int M, N, K, lda, ldb, ldc, ldy, colsum_ld, act, accumulate;
+    int rblocks, xcd_map;                     // (NK) row blocks of 256; workgroups dealt so that the column chunks of a row block share an XCD
     int k_chunk, splits;                      // (TN) k per slice, slices
     float* partial;                           // (TN) slabs [group][slice][M][ldc]
     SkinnyGroup g[kMaxGemmGroups];
@@ -230,7 +231,15 @@ __global__ __launch_bounds__(256) void skinny_nk_kernel(const SkinnyParams p, in
     const SkinnyGroup g = pick(p, blockIdx.y);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
-    const int rblock = (int)blockIdx.x / nchunks, chunk = (int)blockIdx.x - rblock * nchunks;
+    // The chunks of a row block all read its A fragments: dealt over the XCDs round-robin (workgroup id mod 8) each of the eight L2s
+    // fetched the whole of A -- 264 MB per launch at the bench shape against 78 MB of operands (FETCH_SIZE, profiles/r05/pmc_lab_nk.txt).
+    // xcd_map: workgroup id -> (XCD = id mod 8, slot = id / 8); the slots of an XCD walk the chunks of ITS row blocks (8 j + XCD).
+    int rblock, chunk;
+    if (p.xcd_map) {
+        const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+        rblock = (slot / nchunks) * 8 + xcd; chunk = slot - (slot / nchunks) * nchunks;
+        if (rblock >= p.rblocks) return;                              // (the grid is padded to whole groups of 8 row blocks)
+    } else { rblock = (int)blockIdx.x / nchunks; chunk = (int)blockIdx.x - rblock * nchunks; }
     const int row0 = (rblock * 4 + wave) * 64;
     const int t0 = chunk * kNkTC;
     const int ksteps = (p.K + 31) / 32;                               // 1 or 2
@@ -593,7 +602,9 @@ int gemm_skinny_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used, b
             if (gs[k].colsum_done) *gs[k].colsum_done = fused_colsum ? 1 : 0;
         }
         const int nchunks = cdiv(cdiv(g.N, 16), kNkTC);
-        const dim3 grid((unsigned)(cdiv(g.M, 256) * nchunks), (unsigned)n);
+        static const bool no_xcd = getenv("ADN_GEMM_SKINNY_NO_XCD") != nullptr;        // (A/B)
+        p.rblocks = cdiv(g.M, 256); p.xcd_map = no_xcd ? 0 : 1;
+        const dim3 grid((unsigned)((p.xcd_map ? (int)round_up(p.rblocks, 8) : p.rblocks) * nchunks), (unsigned)n);
         say(1002, 1);
         {
             ProfScope prof(PROF_GEMM_NN, 2.0 * g.M * g.N * (planes ? 3.0 : 1.0) * g.K * n, 4.0 * n * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N), stream, n);
