@@ -7,10 +7,11 @@
 //                      B is taken as its k-contiguous transpose [N][K] (the W^T copies the model keeps anyway), staged once per
 //                      workgroup in LDS; a wave owns 32 rows and streams its A fragments HBM -> registers, a chunk of 4 k-steps
 //                      (up to 16 KB per wave) ahead of the chunk being multiplied: 8 waves x 16 KB = 128 KB in flight per CU.
+//                      Wide form (N <= 160, planes only): B^T staged 128 k per pass -- the first LSTMs' input gradient dG W_in^T.
 //   skinny_nk_kernel   C [M][N] = A [M][K <= 64] . B^T, B = [N][K] k-contiguous (the weights themselves: dX = dZ W^T), optional
 //                      rectify'(Y) mask from the bf16 copy of Y, optional fused column sums (db of the layer below), result as fp32
-//                      and / or bf16 hi (+ lo) planes.  Output-bound: a wave keeps the A fragments of its 64 rows in registers and
-//                      walks the N / 16 column tiles, the next tile's B fragments (L2-resident weights) one tile ahead.
+//                      and / or bf16 hi (+ lo) planes.  Output-bound: a workgroup takes 256 rows x 2 column tiles with every load
+//                      requested up front; the column chunks of a row block are dealt to ONE XCD (they share its A fragments).
 //   skinny_tn_kernel   C [M <= 1024][N <= 64] (+)= A^T B, A [K][M], B [K][N] both k-strided, K = all frames: 64 x 64 output blocks x
 //                      many K-slices (4 workgroups per CU), operands through LDS + transposing reads, two stages of register
 //                      prefetch; the slices' partial blocks go to slabs that a fixed-order pass adds (no atomics: deterministic
