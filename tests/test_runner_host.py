@@ -198,3 +198,26 @@ def test_avletters_scripts_pick_their_network_from_has_encoder(monkeypatch):
         build_network_avletters(3, [True, True, False], load_ae, [24, 24, 9], [None, None, None], cfg)
     with pytest.raises(ValueError, match="ae1"):
         build_network_avletters(2, [False, True], load_ae, [24, 24], [None, None], cfg)
+
+
+def test_plane_input_is_the_hi_lo_split_of_a_float32_tensor():
+    """model.PlaneInput (the resident form of the bf16x3 / mixed arithmetic, ADN_FLAG_PLANE_INPUTS): hi = bf16(x), lo = bf16(x - hi);
+    hi + lo recovers x to 2^-16 of its magnitude (a 16-bit significand), indexing slices both planes alike, and the constructor
+    refuses anything but two bfloat16 tensors of one shape.  Host logic only: CPU tensors."""
+    import pytest
+    import torch
+    from ip_avsr_amd.model import PlaneInput
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(7, 11, 24, generator=g) * torch.tensor([1e-3, 1.0, 300.0]).repeat(8)
+    p = PlaneInput.split(x)
+    assert p.hi.dtype == torch.bfloat16 and p.lo.dtype == torch.bfloat16 and tuple(p.shape) == (7, 11, 24) and p.ndim == 3 and len(p) == 7
+    assert torch.equal(p.hi, x.to(torch.bfloat16))
+    assert torch.equal(p.lo, (x - p.hi.float()).to(torch.bfloat16))
+    err = (p.float() - x).abs()
+    assert bool((err <= x.abs() * 2.0 ** -16 + 1e-30).all())
+    q = p[2:5]
+    assert torch.equal(q.hi, p.hi[2:5]) and torch.equal(q.lo, p.lo[2:5]) and q.hi.is_contiguous()
+    with pytest.raises(ValueError):
+        PlaneInput(p.hi, p.lo[:3])
+    with pytest.raises(ValueError):
+        PlaneInput(p.hi.float(), p.lo)
