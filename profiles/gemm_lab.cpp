@@ -66,6 +66,8 @@ int main(int argc, char** argv) {
         {"dW agg-cat TN", GEMM_TN, 768, 1000, R, 0, 0, 0, 0, 0},
         {"xproj agg-cat fp32", GEMM_NN, R, 1000, 768, 0, 0, 0, 0, 0},
         {"dcat fp32", GEMM_NN, R, 768, 1000, 0, 0, 0, 0, 0},
+        {"dcat fp32 acc", GEMM_NN, R, 768, 1000, 0, 1, 0, 0, 0},          // the second aggregation LSTM's input gradient: C += ...
+        {"dcat K2000 (the two as one product)", GEMM_NN, R, 768, 2000, 0, 0, 0, 0, 0},
         {"odd edges fwd", GEMM_NN, 20777, 1996, 1208, 0, 0, 0, 0, 1},
         {"odd edges dW", GEMM_TN, 1196, 2004, 20777, 0, 1, 0, 0, 0},
         {"dW bn TN acc", GEMM_TN, 500, 50, R, 0, 1, 0, 0, 0},
