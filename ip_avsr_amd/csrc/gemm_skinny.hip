@@ -374,8 +374,12 @@ __global__ __launch_bounds__(256) void skinny_tn_kernel(const SkinnyParams p) {
     __bf16* Asl = lds + 2 * 64 * kTnStride; __bf16* Bsl = lds + 3 * 64 * kTnStride;
     const SkinnyGroup g = pick(p, blockIdx.z);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * 64;
-    const int kbeg = blockIdx.y * p.k_chunk, kend = min(p.K, kbeg + p.k_chunk);
+    // xcd_map: blockIdx.x = K-slice (grid padded to a multiple of 8), blockIdx.y = 64-row block of C -- the row blocks of a slice, which
+    // all read its rows of B, then sit on ONE XCD (workgroup id mod 8 = slice mod 8); otherwise x = row block, y = slice as before
+    const int mblk = p.xcd_map ? (int)blockIdx.y : (int)blockIdx.x, slice = p.xcd_map ? (int)blockIdx.x : (int)blockIdx.y;
+    if (slice >= p.splits) return;                                    // (uniform; padding slices)
+    const int m0 = mblk * 64;
+    const int kbeg = slice * p.k_chunk, kend = min(p.K, kbeg + p.k_chunk);
     // staging: thread -> (k-row tid >> 3 (+ 32), 8 columns (tid & 7) * 8); columns beyond M / N read column block 0 (dropped / zero-masked below)
     const int srow = tid >> 3, scol = (tid & 7) * 8;
     const int acol = (m0 + scol + 8 <= p.lda) ? m0 + scol : 0;
@@ -444,7 +448,7 @@ __global__ __launch_bounds__(256) void skinny_tn_kernel(const SkinnyParams p) {
         }
     }
     // partial block -> this (group, slice)'s slab: acc[t]: col = 16 t + (lane & 15), rows m0 + 16 wave + 4 (lane >> 4) + r
-    float* slab = p.partial + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * p.M) * p.ldc;
+    float* slab = p.partial + ((size_t)((int)blockIdx.z * p.splits + slice) * p.M) * p.ldc;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int col = 16 * t + (lane & 15);
@@ -643,7 +647,9 @@ int gemm_skinny_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used, b
         fill_groups(p, gs, n, planes, false);
         say(1003, splits);
         ProfScope prof(PROF_GEMM_TN, 2.0 * g.M * g.N * (planes ? 3.0 : 1.0) * g.K * n, 4.0 * n * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N), stream, n);
-        const dim3 grid((unsigned)mblocks, (unsigned)splits, (unsigned)n);
+        static const bool no_xcd_tn = getenv("ADN_GEMM_SKINNY_NO_XCD") != nullptr;     // (A/B)
+        p.xcd_map = no_xcd_tn ? 0 : 1;
+        const dim3 grid = p.xcd_map ? dim3((unsigned)round_up(splits, 8), (unsigned)mblocks, (unsigned)n) : dim3((unsigned)mblocks, (unsigned)splits, (unsigned)n);
         if (planes) hipLaunchKernelGGL((skinny_tn_kernel<true>), grid, dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((skinny_tn_kernel<false>), grid, dim3(256), 0, stream, p);
         hipLaunchKernelGGL(skinny_tn_reduce_kernel, dim3((unsigned)std::min(256, cdiv(g.M * g.N, 256)), (unsigned)n), dim3(256), 0, stream, p);
