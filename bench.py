@@ -253,6 +253,8 @@ def parse_args(argv=None):
     ap.add_argument("--fp32-inputs", action="store_true",
                     help="bf16 mode: keep the resident batch in float32 (the library then converts it every step) instead of bfloat16")
     ap.add_argument("--no-reference-minibatch", action="store_true", help="skip the B=26 sub-run")
+    ap.add_argument("--padded", action="store_true",
+                    help="run the encoders over all B x T rows (no frame compaction: adn_set_batch_lengths is not called)")
     ap.add_argument("--no-runner", action="store_true", help="skip the epoch / step measurements through runners/nstream.fit")
     ap.add_argument("--only-train-steps", action="store_true",
                     help="counter passes (profiles/collect.sh): run NOTHING but warmup + steps train steps of the B=520 workload "
@@ -380,6 +382,15 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
         xs, y, m_d, mask = batch_fn(rank, B_PER_GPU)
         total_frames = float(mask.sum())
         global_batch = B_PER_GPU * world
+    # frame compaction (include/adenet.h adn_set_batch_lengths): the loader knows every utterance's length and pads with zero frames
+    # (utils/datagen.py:104,129-142); announcing the lengths lets the encoders skip the padding rows -- same results
+    batch_lens = np.asarray(mask).sum(axis=1).astype(np.int32)
+    compaction = bool(on_gpu and not args.padded)
+    announce = {"lens": batch_lens if compaction else None}     # (an announcement is used up by the call behind it: made per step)
+
+    def announce_lengths():
+        if announce["lens"] is not None:
+            model.set_batch_lengths(announce["lens"])
     # bf16 headline: the batch is resident as bfloat16 (what a bf16 feature front-end leaves in HBM; ADN_FLAG_BF16_INPUTS): the
     # first encoder GEMM reads it in place.  The parity-grade modes below get the same frames as float32.
     xs32 = xs
@@ -393,9 +404,9 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
             total_frames = float(t.item())
         dp = DataParallel(model, grad_tensor=grad_tensor)
         dp.broadcast_parameters(0)
-        step = lambda: dp.train_step(xs, y, m_d, THETA, LR, total_frames)
+        step = lambda: (announce_lengths(), dp.train_step(xs, y, m_d, THETA, LR, total_frames))[1]
     else:
-        step = lambda: model.train_step(xs, y, m_d, THETA, LR, want_loss=False)
+        step = lambda: (announce_lengths(), model.train_step(xs, y, m_d, THETA, LR, want_loss=False))[1]
 
     def fence():
         if distributed:
@@ -518,6 +529,18 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
             out["hbm_copy_guide_GBs"] = GUIDE_COPY_GBS
         if prof:
             out.update(rooflines(prof, args.steps, prof_elapsed, args.precision, hbm, traffic_file(args.precision)))
+        if on_gpu:
+            out["config"]["frame_compaction"] = {"on": compaction, "encoder_rows": model.compact_rows() or int(np.asarray(mask).size),
+                                                 "padded_rows": int(np.asarray(mask).size), "valid_frames": int(batch_lens.sum())}
+        if on_gpu and world == 1 and compaction:
+            # the same step with the encoders over all B x T rows (rounds 1-4, and this round before the compaction)
+            announce["lens"] = None
+            for _ in range(3):
+                step()
+            t_p = timed(args.steps)
+            out["padded_encoders"] = {"ms_per_step": 1e3 * t_p / args.steps, "value": B_PER_GPU * args.steps / t_p, "unit": "sequences/s",
+                                      "dtype": args.precision, "encoder_rows": int(np.asarray(mask).size)}
+            announce["lens"] = batch_lens
         if on_gpu and world == 1 and xs is not xs32:
             # the like-for-like figure against rounds 1-2 and against the f32 / bf16x3 rows: the SAME bf16 arithmetic fed with
             # the float32 frames the reference's theano functions take (the library converts them every step)
@@ -580,15 +603,20 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
         if on_gpu and world == 1 and not getattr(args, "no_reference_minibatch", False):
             # the same model at the reference's own minibatch (runners/3stream.py: 26 utterances per update): every GEMM is a
             # latency-bound launch there and the step is a chain of ~160 LSTM time steps -- reported beside the headline, not as it
-            xb, yb, mb_d, _ = batch_fn(rank + 2000, 26)
+            xb, yb, mb_d, mask_b = batch_fn(rank + 2000, 26)
+            lens_b = np.asarray(mask_b).sum(axis=1).astype(np.int32) if compaction else None
             if inputs_desc.startswith("bfloat16"):
                 xb = [x.to(torch.bfloat16) for x in xb]
-            for _ in range(30):
+            def small_step():
+                if lens_b is not None:
+                    model.set_batch_lengths(lens_b)
                 model.train_step(xb, yb, mb_d, THETA, LR, want_loss=False)
+            for _ in range(30):
+                small_step()
             fence()
             t3 = time.perf_counter()
             for _ in range(20):
-                model.train_step(xb, yb, mb_d, THETA, LR, want_loss=False)
+                small_step()
             fence()
             t3 = time.perf_counter() - t3
             out["reference_minibatch"] = {"utterances_per_step": 26, "steps": 20, "ms_per_step": 1e3 * t3 / 20,

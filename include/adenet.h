@@ -267,6 +267,18 @@ int adn_synchronize(adn_model* m);
  * arithmetic is otherwise the selected adn_precision's. */
 int adn_set_deterministic(int on);
 int adn_get_deterministic(void);
+/* Frame compaction (round 5; csrc/compact.hip).  The reference pads every utterance of a minibatch to the longest with ZERO frames
+ * (utils/datagen.py:104,129-142) and sends all B T frames through the dense encoders.  Announcing the lengths of the NEXT call's batch
+ * (host array of B ints, 1 <= len <= T; the announcement is used up by that call, whatever it decides) promises that the padding frames of the stream inputs are zero and lets the encoders run
+ * over the sum(len) valid frames plus ONE zero-input row that stands for every padding frame -- forward its output enc(0) is what the
+ * delta layer sees at the padding frames, backward it carries the sum of their gradients, which is all the parameter gradients ever
+ * see of them (the encoder is row-wise).  Same results as the padded computation up to summation order; everything from the delta
+ * layer up stays padded.  Applies when B matches the call's, in the 16-bit arithmetics (bf16 / bf16x3 / mixed) whose encoders end in a
+ * linear layer without BatchNorm, when at least 10 % of the rows are padding; otherwise the call runs padded as before.  The mask
+ * passed with the call must describe the same lengths (prefix masks).  ADN_NO_COMPACT=1 in the environment switches it off. */
+int adn_set_batch_lengths(adn_model* m, const int32_t* lengths, int B);
+/* rows of the encoder matrices in the last call: sum(len) + 1 when it ran compacted, 0 when it ran padded */
+int adn_get_compact_rows(const adn_model* m);
 /* test hook: writes `value` into the current device's LSTM-exchange error word (what a weight-stationary LSTM kernel raises
  * when a workgroup gave up waiting for its partners; 0 clears it).  Lets a test follow the word's way through the gradient
  * tail, the data-parallel all-reduce and the optimiser's skip without provoking a real time-out. */

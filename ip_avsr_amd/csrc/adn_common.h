@@ -162,6 +162,16 @@ struct TransposeItem { const float* W; void* out; int rows, cols, ld, ldT, block
 int transpose_to_bf16_batch(const TransposeItem* dev_items, int n, int total_blocks, hipStream_t s, int lo_part = 0);
 int split_hilo(const float* src, void* hi, void* lo, size_t n, hipStream_t s);   // fp32 -> the bf16x3 mode's two planes
 int join_hilo(const void* hi, const void* lo, float* dst, size_t n, hipStream_t s);   // ... and back (hi + lo)
+// frame compaction of the encoder path (compact.hip): row maps, gathers, the expand / compact-and-sum passes at the delta layer
+int compact_build_maps(const int32_t* d_lens, const int32_t* d_prefix, int B, int T, int Z, int32_t* comp_of_full, int32_t* full_of_comp,
+                       hipStream_t s);
+int compact_gather_rows16(const void* src, int ld_src, void* dst, int ld_dst, const int32_t* full_of_comp, int Nc, int cols, hipStream_t s);
+int compact_gather_rows_f32(const float* src, int ld_src, void* dst16, void* dst16lo, int ld_dst, const int32_t* full_of_comp, int Nc, int cols,
+                            hipStream_t s);
+int compact_expand_rows(const float* comp, int ld_comp, float* full, int ld_full, const int32_t* comp_of_full, int N, int cols, hipStream_t s);
+size_t compact_sum_ws_floats(int N, int cols);
+int compact_rows_sum(const float* full, int ld_full, float* comp, int ld_comp, const int32_t* comp_of_full, int N, int cols, int Z,
+                     float* ws, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
 // element-wise / HBM-bound kernels (elementwise.hip)

@@ -1,0 +1,155 @@
+// Frame compaction of the encoder path (round 5): a minibatch of B utterances padded to T frames holds sum(len) valid
+// frames and B T - sum(len) padding frames whose inputs are zero (utils/datagen.py:104,129-142 pads with zeros).  Every padding frame
+// goes through the dense encoder as the SAME row -- enc(0) -- and, the encoder being row-wise, their gradients only ever enter the
+// parameter gradients as a sum: dW_l += a_{l-1}(0)^T (sum of their dZ_l rows), and that sum propagates down the layers like one row
+// (dZ_{l-1} = act'(a_{l-1}(0)) * (dZ_l W_l^T) is linear in dZ_l for a fixed mask).  So the encoder GEMMs run over
+//     Nc = sum(len) + 1 rows:  the valid frames, utterance after utterance, and ONE zero-input row Z = Nc - 1
+// instead of B T (65 % of them at lengths ~ U[12, 40]).  What stays padded: everything from the delta layer up (time-major, B rows per
+// step), which reads the encoder output through expand_rows() and hands its gradient back through compact_rows_sum().
+//   full row  r = b T + t  ->  compact row  comp_of_full[r] = prefix[b] + t (t < len[b]) | Z
+//   compact row c < Z      ->  full row     full_of_comp[c];   full_of_comp[Z] = -1
+#include "adn_common.h"
+#include <algorithm>
+
+namespace adn {
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void compact_maps_kernel(const int32_t* __restrict__ lens, const int32_t* __restrict__ prefix, int B, int T,
+                                                           int Z, int32_t* __restrict__ comp_of_full, int32_t* __restrict__ full_of_comp) {
+    const int total = B * T;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < total; r += gridDim.x * 256) {
+        const int b = r / T, t = r - b * T;
+        const bool valid = t < lens[b];
+        const int c = valid ? prefix[b] + t : Z;
+        comp_of_full[r] = c;
+        if (valid) full_of_comp[c] = r;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) full_of_comp[Z] = -1;
+}
+
+// dst[c][0 .. cols16) = src[full_of_comp[c]][...] (16-byte pieces), the zero row for c = Z
+__global__ __launch_bounds__(256) void gather_rows16_kernel(const u32x4* __restrict__ src, int ld_src16, u32x4* __restrict__ dst, int ld_dst16,
+                                                            const int32_t* __restrict__ full_of_comp, int Nc, int cols16) {
+    const int64_t total = (int64_t)Nc * cols16;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e / cols16), q = (int)(e - (int64_t)c * cols16);
+        const int r = full_of_comp[c];
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (r >= 0) v = src[(size_t)r * ld_src16 + q];
+        dst[(size_t)c * ld_dst16 + q] = v;
+    }
+}
+
+// fp32 rows -> bf16 (or hi / lo planes) while gathering: dst16[c] = bf16(src[full_of_comp[c]]), dst16lo = bf16(x - hi)
+__global__ __launch_bounds__(256) void gather_rows_f32_kernel(const float* __restrict__ src, int ld_src, __bf16* __restrict__ dst16,
+                                                              __bf16* __restrict__ dst16lo, int ld_dst, const int32_t* __restrict__ full_of_comp,
+                                                              int Nc, int cols) {
+    const int64_t total = (int64_t)Nc * cols;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e / cols), q = (int)(e - (int64_t)c * cols);
+        const int r = full_of_comp[c];
+        const float x = r >= 0 ? src[(size_t)r * ld_src + q] : 0.f;
+        const __bf16 hi = (__bf16)x;
+        dst16[(size_t)c * ld_dst + q] = hi;
+        if (dst16lo) dst16lo[(size_t)c * ld_dst + q] = (__bf16)(x - (float)hi);
+    }
+}
+
+// full[r][0 .. cols) = comp[comp_of_full[r]][...]
+__global__ __launch_bounds__(256) void expand_rows_kernel(const float* __restrict__ comp, int ld_comp, float* __restrict__ full, int ld_full,
+                                                          const int32_t* __restrict__ comp_of_full, int N, int cols) {
+    const int64_t total = (int64_t)N * cols;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int r = (int)(e / cols), q = (int)(e - (int64_t)r * cols);
+        full[(size_t)r * ld_full + q] = comp[(size_t)comp_of_full[r] * ld_comp + q];
+    }
+}
+
+// comp[c] = full[full_of_comp[c]] for the valid rows; the padding rows of full are summed -- in row order, per block of kSumRows full
+// rows into partial[block], then by compact_sum_finish_kernel in block order: one fixed order, no atomics -- into comp[Z]
+constexpr int kSumRows = 256;
+__global__ __launch_bounds__(256) void compact_rows_sum_kernel(const float* __restrict__ full, int ld_full, float* __restrict__ comp, int ld_comp,
+                                                               const int32_t* __restrict__ comp_of_full, int N, int cols, int Z,
+                                                               float* __restrict__ partial) {
+    // blockIdx.x = block of kSumRows full rows, blockIdx.y = 32-column chunk; thread = (row lane ts of 8, column fl)
+    __shared__ float red[8][32];
+    const int fl = threadIdx.x & 31, ts = threadIdx.x >> 5;
+    const int q = blockIdx.y * 32 + fl;
+    const int r0 = blockIdx.x * kSumRows, r1 = min(N, r0 + kSumRows);
+    float acc = 0.f;
+    if (q < cols)
+        for (int r = r0 + ts; r < r1; r += 8) {
+            const float v = full[(size_t)r * ld_full + q];
+            const int c = comp_of_full[r];
+            if (c == Z) acc += v; else comp[(size_t)c * ld_comp + q] = v;
+        }
+    red[ts][fl] = acc;
+    __syncthreads();
+    if (ts == 0 && q < cols) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += red[k][fl];
+        partial[(size_t)blockIdx.x * cols + q] = s;
+    }
+}
+__global__ __launch_bounds__(256) void compact_sum_finish_kernel(const float* __restrict__ partial, int nblocks, float* __restrict__ comp, int ld_comp,
+                                                                 int cols, int ld_cols, int Z) {
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < ld_cols; q += gridDim.x * 256) {
+        float s = 0.f;
+        if (q < cols) for (int k = 0; k < nblocks; ++k) s += partial[(size_t)k * cols + q];
+        comp[(size_t)Z * ld_comp + q] = s;                            // (pad columns of the row: zero)
+    }
+}
+
+int grid_for_elems(int64_t total) { return (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, 16384)); }
+
+}  // namespace
+
+int compact_build_maps(const int32_t* d_lens, const int32_t* d_prefix, int B, int T, int Z, int32_t* comp_of_full, int32_t* full_of_comp,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(compact_maps_kernel, dim3(grid_for_elems((int64_t)B * T)), dim3(256), 0, s, d_lens, d_prefix, B, T, Z, comp_of_full,
+                       full_of_comp);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+int compact_gather_rows16(const void* src, int ld_src, void* dst, int ld_dst, const int32_t* full_of_comp, int Nc, int cols, hipStream_t s) {
+    ADN_CHECK(cols % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, ADN_ERR_INVALID,
+              "compact_gather_rows16: rows of whole 16-byte pieces");
+    hipLaunchKernelGGL(gather_rows16_kernel, dim3(grid_for_elems((int64_t)Nc * (cols / 8))), dim3(256), 0, s, static_cast<const u32x4*>(src),
+                       ld_src / 8, static_cast<u32x4*>(dst), ld_dst / 8, full_of_comp, Nc, cols / 8);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+int compact_gather_rows_f32(const float* src, int ld_src, void* dst16, void* dst16lo, int ld_dst, const int32_t* full_of_comp, int Nc, int cols,
+                            hipStream_t s) {
+    hipLaunchKernelGGL(gather_rows_f32_kernel, dim3(grid_for_elems((int64_t)Nc * cols)), dim3(256), 0, s, src, ld_src,
+                       static_cast<__bf16*>(dst16), static_cast<__bf16*>(dst16lo), ld_dst, full_of_comp, Nc, cols);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+int compact_expand_rows(const float* comp, int ld_comp, float* full, int ld_full, const int32_t* comp_of_full, int N, int cols, hipStream_t s) {
+    hipLaunchKernelGGL(expand_rows_kernel, dim3(grid_for_elems((int64_t)N * cols)), dim3(256), 0, s, comp, ld_comp, full, ld_full, comp_of_full,
+                       N, cols);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+size_t compact_sum_ws_floats(int N, int cols) { return (size_t)cdiv(N, kSumRows) * cols; }
+
+int compact_rows_sum(const float* full, int ld_full, float* comp, int ld_comp, const int32_t* comp_of_full, int N, int cols, int Z,
+                     float* ws, hipStream_t s) {
+    const int nblocks = cdiv(N, kSumRows);
+    hipLaunchKernelGGL(compact_rows_sum_kernel, dim3(nblocks, cdiv(cols, 32)), dim3(256), 0, s, full, ld_full, comp, ld_comp, comp_of_full, N,
+                       cols, Z, ws);
+    hipLaunchKernelGGL(compact_sum_finish_kernel, dim3(1), dim3(256), 0, s, ws, nblocks, comp, ld_comp, cols, ld_comp, Z);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+}  // namespace adn

@@ -156,6 +156,9 @@ struct StreamState {
     float* dout = nullptr;                     // ... the buffer actually holding it (may be a shared one)
     float* dfeat = nullptr;
     float* dE = nullptr;
+    // frame compaction (compact.hip): the first layer's operand gathered to the valid frames + one zero row, the encoder output
+    // expanded back to B T rows for the delta layer, the delta layer's gradient compacted (padding rows summed into the zero row)
+    float* xc = nullptr; float* enc_full = nullptr; float* dEc = nullptr; float* compact_ws = nullptr;
     float* out_ptr = nullptr;
     size_t param_begin = 0;                    // this stream's parameters start here in the flat buffers
 };
@@ -231,6 +234,11 @@ struct adn_model {
     // partial slabs of the split-K weight-gradient GEMMs (gemm_bf16_pp_kernel): one workgroup = one 256 x 256 fp32 tile
     float* splitk_ws = nullptr; size_t splitk_ws_floats = 0;
     int lastB = 0, lastT = 0;
+    // frame compaction: lengths announced by adn_set_batch_lengths (host), the row maps of the batch on the device, Nc = valid + 1
+    std::vector<int32_t> batch_lens, maps_lens;
+    int32_t *d_lens = nullptr, *d_prefix = nullptr, *comp_of_full = nullptr, *full_of_comp = nullptr;
+    std::vector<int32_t> h_comp_of_full;
+    int Nc = 0; bool compact = false; int maps_T = 0;
     Profiler prof;
     // bf16 shadow copies of every GEMM operand (bf16 mode): fp32 range -> bf16 buffer with the same layout
     struct ShadowRange { const float* base; size_t n; char* shadow; char* shadow_lo; };
@@ -476,6 +484,9 @@ size_t carve(adn_model* m, char* base, int B, int T, bool host_inputs) {
     const int ldh = m->ldh, ldg = m->ldg;
     m->mask_bt = cv.take<uint8_t>(N);
     m->mask_tb = cv.take<uint8_t>(N);
+    m->d_lens = cv.take<int32_t>((size_t)B); m->d_prefix = cv.take<int32_t>((size_t)B + 1);
+    m->comp_of_full = cv.take<int32_t>(N); m->full_of_comp = cv.take<int32_t>(N + 8);
+    m->maps_lens.clear(); m->compact = false;          // (the maps live in the slab: re-made after every carve)
     m->y_bt = cv.take<int32_t>(N);
     m->total = cv.take<float>(8);
     m->loss = cv.take<float>(8);
@@ -507,6 +518,12 @@ size_t carve(adn_model* m, char* base, int B, int T, bool host_inputs) {
         st.feat = take_shadowed(m, cv, N * ld_of(st.feat_dim));
         st.dfeat = cv.take<float>(N * ld_of(st.feat_dim));
         st.dE = take_shadowed(m, cv, N * ld_of(st.enc_out));
+        if (st.cfg.n_enc > 0) {                // frame compaction (row counts <= N)
+            st.xc = take_shadowed(m, cv, N * ld_of(st.cfg.input_dim));
+            st.enc_full = cv.take<float>(N * ld_of(st.enc_out));
+            st.dEc = take_shadowed(m, cv, N * ld_of(st.enc_out));
+            st.compact_ws = cv.take<float>(compact_sum_ws_floats((int)N, st.enc_out));
+        }
         st.lw.resize(st.lstm.size());
         for (auto& w : st.lw) carve_lstm(m, cv, w, B, T, ldh, ldg);
         st.hsum = take_shadowed(m, cv, N * ldh);
@@ -583,6 +600,8 @@ int widen_bf16_rows(const void* src, int ld_src, float* dst, int ld_dst, int64_t
     return ADN_OK;
 }
 
+int setup_compaction(adn_model* m, int B, int T);
+bool streams_concurrent(const adn_model* m);
 int stage_inputs(adn_model* m, const void* const* inputs, const int32_t* targets, const uint8_t* mask, int B, int T,
                  int flags) {
     const size_t N = (size_t)B * T;
@@ -591,8 +610,9 @@ int stage_inputs(adn_model* m, const void* const* inputs, const int32_t* targets
     const bool in_planes = flags & ADN_FLAG_PLANE_INPUTS;        // ... as their hi / lo planes (inputs[S + s] = the lo plane of stream s)
     // (a staging buffer listed as "fp32 copy not written" by an earlier call with plane inputs is about to be re-decided)
     for (auto& st : m->st)
-        for (size_t k = 0; k < m->fp32_stale.size(); ++k)
-            if (m->fp32_stale[k].first == st.xstage) { m->fp32_stale.erase(m->fp32_stale.begin() + (long)k); break; }
+        for (const float* gone : {(const float*)st.xstage, (const float*)st.xc})
+            for (size_t k = 0; k < m->fp32_stale.size(); ++k)
+                if (gone && m->fp32_stale[k].first == gone) { m->fp32_stale.erase(m->fp32_stale.begin() + (long)k); break; }
     if (in_planes) {
         ADN_CHECK(dev && m->planes() && !in16, ADN_ERR_INVALID, "plane inputs: device arrays in the bf16x3 / mixed arithmetic only");
         for (auto& st : m->st) ADN_CHECK(st.cfg.aux_dim <= 0, ADN_ERR_INVALID, "plane inputs: auxiliary inputs are not supported");
@@ -677,10 +697,66 @@ int stage_inputs(adn_model* m, const void* const* inputs, const int32_t* targets
     ADN_HIP_CHECK(hipMemcpyAsync(m->mask_bt, mask, N, kind, m->stream));
     if (targets) ADN_HIP_CHECK(hipMemcpyAsync(m->y_bt, targets, N * sizeof(int32_t), kind, m->stream));
     ADN_TRY(mask_prepare(m->mask_bt, m->mask_tb, B, T, m->total, m->stream));
-    return ADN_OK;
+    return setup_compaction(m, B, T);
 }
 
 bool shadows_on(const adn_model* m) { return m->bf16() && !getenv("ADN_BF16_NO_SHADOW"); }
+
+// Frame compaction (compact.hip): decided per call.  Needs the batch's lengths on the host (adn_set_batch_lengths: which also
+// promises that the padding frames of the inputs are zero, as the reference's generators make them), a 16-bit arithmetic (the
+// operands are gathered as bf16 / planes), encoders that end in a linear layer with no BatchNorm behind them (whose batch
+// statistics would see the padding rows), and enough padding to pay for the gather (>= 10 % of the rows).
+int setup_compaction(adn_model* m, int B, int T) {
+    const size_t N = (size_t)B * T;
+    m->compact = false; m->Nc = (int)N;
+    static const bool off = getenv("ADN_NO_COMPACT") != nullptr;
+    // (the announcement is for THIS call only: lengths that outlive their batch would compact the next one wrongly)
+    struct OneShot { std::vector<int32_t>& v; std::vector<int32_t> mine; explicit OneShot(std::vector<int32_t>& v_) : v(v_), mine(v_) { v.clear(); } } once(m->batch_lens);
+    const std::vector<int32_t>& lens = once.mine;
+    if (off || (int)lens.size() != B || !(shadows_on(m) || m->planes()) || m->keep_fp32 || streams_concurrent(m)) return ADN_OK;
+    bool any = false;
+    for (auto& st : m->st) {
+        if (st.cfg.n_enc == 0) continue;
+        if (st.cfg.batchnorm || st.cfg.enc_act[st.cfg.n_enc - 1] != ADN_ACT_LINEAR || st.cfg.input_dim % 8 || st.ldx % 8 || !st.xc) return ADN_OK;
+        if (!m->shadow_of(st.x) || (m->planes() && !m->shadow_lo_of(st.x))) return ADN_OK;
+        any = true;
+    }
+    if (!any) return ADN_OK;
+    int64_t valid = 0;
+    for (int b = 0; b < B; ++b) {
+        ADN_CHECK(lens[b] >= 1 && lens[b] <= T, ADN_ERR_INVALID, "adn_set_batch_lengths: a length outside [1, T]");
+        valid += lens[b];
+    }
+    if ((double)(valid + 1) > 0.9 * (double)N) return ADN_OK;
+    const int Z = (int)valid;
+    if (m->maps_lens != lens || m->maps_T != T) {
+        std::vector<int32_t> prefix((size_t)B + 1, 0);
+        for (int b = 0; b < B; ++b) prefix[b + 1] = prefix[b] + lens[b];
+        ADN_HIP_CHECK(hipMemcpy(m->d_lens, lens.data(), (size_t)B * 4, hipMemcpyHostToDevice));
+        ADN_HIP_CHECK(hipMemcpy(m->d_prefix, prefix.data(), ((size_t)B + 1) * 4, hipMemcpyHostToDevice));
+        ADN_TRY(compact_build_maps(m->d_lens, m->d_prefix, B, T, Z, m->comp_of_full, m->full_of_comp, m->stream));
+        m->h_comp_of_full.assign(N, Z);
+        for (int b = 0; b < B; ++b)
+            for (int t = 0; t < lens[b]; ++t) m->h_comp_of_full[(size_t)b * T + t] = prefix[b] + t;
+        m->maps_lens = lens; m->maps_T = T;
+    }
+    m->Nc = Z + 1; m->compact = true;
+    for (auto& st : m->st) {
+        if (st.cfg.n_enc == 0) continue;
+        const int D = st.cfg.input_dim, ld = ld_of(D);
+        const void* src_hi = m->shadow_of(st.x); const void* src_lo = m->planes() ? m->shadow_lo_of(st.x) : nullptr;
+        const int ld_src = st.ldx;
+        st.x = st.xc; st.ldx = ld; st.x16 = nullptr; st.x16lo = nullptr;      // (the staged names go: shadow_of(xc) is the slab's)
+        ADN_TRY(compact_gather_rows16(src_hi, ld_src, m->shadow_of(st.xc), ld, m->full_of_comp, m->Nc, D, m->stream));
+        if (src_lo) ADN_TRY(compact_gather_rows16(src_lo, ld_src, m->shadow_lo_of(st.xc), ld, m->full_of_comp, m->Nc, D, m->stream));
+        if (m->planes()) {                    // the fp32 matrix behind the planes holds nothing: a reader that wants it gets hi + lo first
+            bool listed = false;
+            for (auto& e : m->fp32_stale) if (e.first == st.xc) { e.second = (size_t)m->Nc * ld; listed = true; }
+            if (!listed) m->fp32_stale.push_back({st.xc, (size_t)m->Nc * ld});
+        }
+    }
+    return ADN_OK;
+}
 
 int ensure_splitk_ws(adn_model* m) {
     if (m->splitk_ws || m->cfg.precision == ADN_PRECISION_F32) return ADN_OK;
@@ -1327,7 +1403,7 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
     ADN_TRY(fork_streams(m));
     auto enc_gemm = [&](StreamState& st, int l) {                // modelzoo/pretrained_encoder.py:4-9
         GemmArgs g;
-        g.layout = GEMM_NN; g.M = N; g.N = st.cfg.enc_units[l]; g.K = st.enc_in[l];
+        g.layout = GEMM_NN; g.M = m->compact ? m->Nc : (int)N; g.N = st.cfg.enc_units[l]; g.K = st.enc_in[l];      // (compact.hip: valid frames + the zero row)
         g.A = l ? st.act[l - 1] : st.x; g.lda = l ? ld_of(st.enc_in[l]) : st.ldx;
         g.B = m->P(st.encW[l]); g.ldb = ld_of(g.N);
         g.C = st.act[l]; g.ldc = ld_of(g.N); g.bias = m->P(st.encb[l]); g.act = st.cfg.enc_act[l];
@@ -1386,6 +1462,10 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
                 ADN_TRY(batchnorm_forward_eval(a, lda, st.bn_out, ldE, N, st.enc_out, m->P(st.bn_gamma), m->P(st.bn_beta),
                                                m->P(st.bn_mean), m->P(st.bn_inv_std), m->stream));
             a = st.bn_out; lda = ldE;
+        }
+        if (m->compact && st.cfg.n_enc > 0) {                    // the delta layer reads B T rows: every padding frame sees enc(0)
+            ADN_TRY(compact_expand_rows(a, lda, st.enc_full, lda, m->comp_of_full, (int)N, st.enc_out, m->stream));
+            a = st.enc_full;
         }
         const bool drop = m->stochastic && st.cfg.dropout_p > 0.f;
         void* feat16 = (m->bf16() && !drop) ? m->shadow_of(st.feat) : nullptr;      // written by the delta kernel itself
@@ -1935,6 +2015,13 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         // (an auxiliary input sits in the columns behind the delta features: data, no gradient)
         // (queued: where nothing of this stream reads dE before the encoder's back-propagation starts -- no BatchNorm, a linear
         //  bottleneck, the bf16 copy written by the kernel -- the streams' delta layers go out as ONE launch behind this loop)
+        if (m->compact) {                         // compact.hip: the delta layer's gradient over B T rows -> valid rows + the padding rows' sum
+            ADN_TRY(queue_delta(m, false, DeltaJob{st.dfeat, ldf, st.dE, ldE, st.enc_out, st.cfg.use_delta, nullptr}, B, T, theta, true));
+            ADN_TRY(compact_rows_sum(st.dE, ldE, st.dEc, ldE, m->comp_of_full, N, st.enc_out, m->Nc - 1, st.compact_ws, m->stream));
+            ADN_TRY(refresh(m, st.dEc, (size_t)m->Nc * ldE));
+            w.dZ = st.dEc; w.lddz = ldE; w.bias_done = 0; w.active = true;
+            return bucket_ready(bucket_of_top(m, si));
+        }
         const bool dE_read_here = st.cfg.batchnorm || !last_linear || !dE16 || stream_major;
         ADN_TRY(queue_delta(m, false, DeltaJob{st.dfeat, ldf, st.dE, ldE, st.enc_out, st.cfg.use_delta, st.cfg.batchnorm ? nullptr : dE16},
                             B, T, theta, dE_read_here));
@@ -1954,13 +2041,14 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
     // gradients, input gradients -- each kind as ONE grouped launch where the ping-pong kernel takes it
     auto layer_step = [&](const std::vector<size_t>& sis, int depth) -> int {
         const int n = (int)sis.size();
+        const int Ne = m->compact ? m->Nc : N;       // rows of the encoder's matrices (compact.hip)
         GemmArgs gws[kMaxGemmGroups], gxs[kMaxGemmGroups];
         for (int q = 0; q < n; ++q) {
             StreamState& st = m->st[sis[q]]; Walk& w = walk[sis[q]];
             const int l = w.L - 1 - depth;
             const int out_w = st.cfg.enc_units[l], in_w = st.enc_in[l];
             GemmArgs& gw = gws[q];
-            gw.layout = GEMM_TN; gw.M = in_w; gw.N = out_w; gw.K = N; gw.A = l > 0 ? st.act[l - 1] : st.x;
+            gw.layout = GEMM_TN; gw.M = in_w; gw.N = out_w; gw.K = Ne; gw.A = l > 0 ? st.act[l - 1] : st.x;
             gw.lda = l > 0 ? ld_of(in_w) : st.ldx;
             gw.B = w.dZ; gw.ldb = w.lddz; gw.C = m->G(st.encW[l]); gw.ldc = ld_of(out_w); gw.accumulate = 1;
             mgemm_prepare(m, gw, false);
@@ -1972,8 +2060,8 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             const int l = w.L - 1 - depth;
             const int out_w = st.cfg.enc_units[l];
             if (!w.bias_done) {           // b_l did not ride on the input-gradient GEMM of the layer above: summed from dZ now
-                if (m->bf16() && w.dZ == st.dE && bias_sums.n < 8) col_sum_batch_add(bias_sums, w.dZ, w.lddz, (int)N, out_w, m->G(st.encb[l]));   // (dE is not reused)
-                else ADN_TRY(col_sum(w.dZ, w.lddz, N, out_w, m->G(st.encb[l]), 1, m->stream));
+                if (m->bf16() && (w.dZ == st.dE || w.dZ == st.dEc) && bias_sums.n < 8) col_sum_batch_add(bias_sums, w.dZ, w.lddz, Ne, out_w, m->G(st.encb[l]));   // (dE is not reused)
+                else ADN_TRY(col_sum(w.dZ, w.lddz, Ne, out_w, m->G(st.encb[l]), 1, m->stream));
             }
             w.bias_done = 0;
         }
@@ -1991,7 +2079,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             any_dx = true;
             float* dst = (w.dZ == st.pingA) ? st.pingB : st.pingA;
             GemmArgs& gx = gxs[q];
-            gx.layout = GEMM_NT; gx.M = N; gx.N = in_w; gx.K = out_w; gx.A = w.dZ; gx.lda = w.lddz;
+            gx.layout = GEMM_NT; gx.M = Ne; gx.N = in_w; gx.K = out_w; gx.A = w.dZ; gx.lda = w.lddz;
             gx.B = m->P(st.encW[l]); gx.ldb = ld_of(out_w); gx.C = dst; gx.ldc = st.ping_ld;
             gx.Y = st.act[l - 1]; gx.ldy = ld_of(in_w); gx.act_grad = st.cfg.enc_act[l - 1];
             gx.colsum = m->G(st.encb[l - 1]); gx.colsum_done = &w.bias_done;     // db_{l-1} rides on this GEMM
@@ -2277,6 +2365,15 @@ int adn_set_precision(adn_model* m, int precision) {
     m->wsB = 0;                       // input staging differs between the modes: re-carve on the next call
     return ADN_OK;
 }
+
+int adn_set_batch_lengths(adn_model* m, const int32_t* lengths, int B) {
+    ADN_CHECK(m, ADN_ERR_INVALID, "null model");
+    ADN_CHECK(B >= 0 && (lengths || B == 0), ADN_ERR_INVALID, "adn_set_batch_lengths: null lengths");
+    if (B == 0) m->batch_lens.clear(); else m->batch_lens.assign(lengths, lengths + B);
+    return ADN_OK;
+}
+
+int adn_get_compact_rows(const adn_model* m) { return (m && m->compact) ? m->Nc : 0; }
 
 int adn_num_params(const adn_model* m) { return m ? (int)m->params.size() : 0; }
 
@@ -2594,6 +2691,16 @@ int adn_read_encoder_activation(adn_model* m, int stream, int layer, float* host
     const int u = st.cfg.enc_units[layer];
     ADN_HIP_CHECK(hipStreamSynchronize(m->stream));
     const size_t rows = (size_t)m->lastB * m->lastT;
+    if (m->compact && m->h_comp_of_full.size() == rows) {      // compact.hip: the matrix holds Nc rows; row b T + t of the answer is row comp_of_full
+        std::vector<float> tmp((size_t)m->Nc * u);
+        const int saved = m->lastB; const bool was = m->compact;
+        m->compact = false; m->lastB = m->Nc; const int savedT = m->lastT; m->lastT = 1;      // (read the Nc rows through the code below)
+        const int rc = adn_read_encoder_activation(m, stream, layer, tmp.data());
+        m->compact = was; m->lastB = saved; m->lastT = savedT;
+        if (rc != ADN_OK) return rc;
+        for (size_t r = 0; r < rows; ++r) memcpy(host_dst + r * u, tmp.data() + (size_t)m->h_comp_of_full[r] * u, (size_t)u * 4);
+        return ADN_OK;
+    }
     if (m->planes()) {                       // bf16x3: an activation kept as its two planes only gets hi + lo written back first
         ADN_TRY(restore_fp32(m, st.act[layer]));
         ADN_HIP_CHECK(hipStreamSynchronize(m->stream));

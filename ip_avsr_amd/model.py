@@ -185,6 +185,20 @@ class AdeNetModel(object):
         _lib.check(self._lib.adn_set_precision(self._handle, _lib.PRECISION[precision]))
         self.spec["precision"] = precision
 
+    def set_batch_lengths(self, lengths):
+        """Frame compaction (include/adenet.h, csrc/compact.hip): announce the utterance lengths of the NEXT call's batch -- with the
+        promise that its padding frames are zero, as utils/datagen.py makes them -- so that the encoders run over the valid
+        frames + one zero row instead of all B x T.  Used up by that call; ``None`` withdraws an announcement."""
+        if lengths is None:
+            _lib.check(self._lib.adn_set_batch_lengths(self._handle, None, 0))
+            return
+        lens = np.ascontiguousarray(np.asarray(lengths).reshape(-1), dtype=np.int32)
+        _lib.check(self._lib.adn_set_batch_lengths(self._handle, lens.ctypes.data_as(C.POINTER(C.c_int32)), int(lens.size)))
+
+    def compact_rows(self):
+        """Rows of the encoder matrices in the last call: sum(len) + 1 when it ran compacted (set_batch_lengths), else 0."""
+        return int(self._lib.adn_get_compact_rows(self._handle))
+
     def synchronize(self):
         _lib.check(self._lib.adn_synchronize(self._handle))
 

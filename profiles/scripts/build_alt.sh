@@ -3,7 +3,7 @@
 set -eu
 FLAGS=${1:-}
 mkdir -p profiles/alt/obj
-for f in gemm_f32 gemm_bf16 gemm_x3f gemm_skinny elementwise lstm lstm_persistent lstm_cluster prep batch batchnorm convae rbm model; do
+for f in gemm_f32 gemm_bf16 gemm_x3f gemm_skinny compact elementwise lstm lstm_persistent lstm_cluster prep batch batchnorm convae rbm model; do
   src=ip_avsr_amd/csrc/$f.hip; obj=profiles/alt/obj/$f.o
   if [ "$f" = gemm_bf16 ] || [ "$f" = gemm_x3f ] || [ ! -f $obj ] || [ $src -nt $obj ]; then
     hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function $FLAGS -Iinclude -c $src -o $obj &

@@ -1,0 +1,133 @@
+"""Frame compaction of the encoder path (include/adenet.h adn_set_batch_lengths, csrc/compact.hip): the encoders run over the valid
+frames of a zero-padded minibatch + ONE zero-input row instead of all B x T rows.  Checked: the forward pass gives the padded run's
+results to rounding (the encoder is row-wise; everything from the delta layer up still sees B x T rows), the gradients agree with the
+padded run to rounding and with the fp64 oracle at the arithmetic's grade, the activation accessor answers in B x T rows, and the cases that
+must fall back to the padded computation do."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import adenet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch
+
+
+def _data(spec, B, T, dims, seed):
+    rng = np.random.default_rng(seed)
+    p = O.init_params(spec, rng, np.float32, enc_std=0.1, perturb=0.05)
+    lens = rng.integers(max(2, T // 3), T + 1, size=B)
+    lens[0] = T
+    mask = (np.arange(T)[None, :] < lens[:, None]).astype(np.uint8)
+    xs = [(rng.normal(size=(B, T, d)) * mask[..., None]).astype(np.float32) for d in dims]
+    y = np.repeat((np.arange(B) % 26)[:, None], T, axis=1).astype(np.int32)
+    return p, lens.astype(np.int32), mask, xs, y
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "mixed", "bf16"])
+def test_compacted_encoders_equal_the_padded_computation(torch_cuda, prec):
+    from ip_avsr_amd.model import AdeNetModel
+    dims = (72, 56)
+    spec = O.spec_nstream(list(dims), enc_shapes=(160, 128, 50), enc_acts=("rectify", "rectify", "linear"), lstm_size=40, classes=26,
+                          fusion="concat")
+    B, T, theta = 70, 30, 9
+    p, lens, mask, xs, y = _data(spec, B, T, dims, int(os.environ.get("TEST_COMPACT_SEED", "8")))
+    m = AdeNetModel(dict(spec, precision=prec))
+    m.set_params_dict(p)
+    out = {}
+    for mode in ("padded", "compact"):
+        announce = (lambda: m.set_batch_lengths(lens)) if mode == "compact" else (lambda: None)     # (used up by the call behind it)
+        announce()
+        probs = m.predict(xs, mask, theta)
+        acts = [m.encoder_activation(s, l, B, T) for s in range(2) for l in range(3)]
+        rows = m.compact_rows()
+        announce()
+        loss = m.compute_grads(xs, y, mask, theta)
+        out[mode] = (probs, acts, loss, m.get_grads_dict(), rows, m.compact_rows())
+    m.close()
+    assert out["padded"][4] == 0 and out["padded"][5] == 0
+    assert out["compact"][4] == int(lens.sum()) + 1 and out["compact"][5] == int(lens.sum()) + 1
+    # (not the same bits: Nc rows select other tile shapes / kernels than B T rows do, i.e. another summation order -- fp32-grade
+    #  differences in bf16x3 / mixed, one bf16 rounding step on some activations in bf16)
+    ptol, atol = {"bf16x3": (5e-6, 1e-5), "mixed": (5e-6, 1e-5), "bf16": (3e-3, 1e-2)}[prec]
+    assert np.abs(out["compact"][0] - out["padded"][0]).max() <= ptol
+    valid = mask.reshape(-1).astype(bool)
+    for a, b in zip(out["compact"][1], out["padded"][1]):
+        scale = max(np.abs(b).max(), 1e-6)
+        assert np.abs(a[valid] - b[valid]).max() <= atol * scale
+        assert np.abs(a[~valid] - a[~valid][0]).max() == 0                         # every padding frame: the one zero-input row
+        assert np.abs(a[~valid][0] - b[~valid][0]).max() <= atol * scale           # ... which is what the padded run computed for them
+    assert abs(out["compact"][2] - out["padded"][2]) <= (1e-6 if prec != "bf16" else 2e-3) * abs(out["padded"][2])
+    # (bf16-grade back-propagation rounds differently summed operands: 4e-3 per product.  The data set is one without a rectifier input
+    #  at the kink under either row count -- DESIGN.md 3: seed 7 flips one mask bit between the two runs, 3e-2 of fc2_s2.W's scale)
+    gtol = {"bf16x3": 1e-4, "mixed": 1e-2, "bf16": 1e-2}[prec]
+    gscale = max(np.abs(v).max() for v in out["padded"][3].values())
+    errs = {k: np.abs(out["compact"][3][k] - out["padded"][3][k]).max() / max(np.abs(out["padded"][3][k]).max(), 1e-3 * gscale)
+            for k in O.param_names(spec)}
+    print("compact vs padded, %s: worst gradient difference %.2e of its scale (%s)" % (prec, max(errs.values()), max(errs, key=errs.get)))
+    for k, e in errs.items():
+        assert e <= gtol, (k, e)
+
+
+def test_compacted_bf16x3_gradients_against_the_oracle(torch_cuda):
+    from ip_avsr_amd.model import AdeNetModel
+    dims = (72, 56, 64)
+    spec = O.spec_nstream(list(dims), enc_shapes=(96, 64, 24), enc_acts=("rectify", "rectify", "linear"), lstm_size=40, classes=26,
+                          fusion="sum")
+    B, T, theta = 33, 21, 9
+    p, lens, mask, xs, y = _data(spec, B, T, dims, 11)
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    probs_ref = O.forward(spec, p64, [x.astype(np.float64) for x in xs], mask, theta)
+    l_ref, g_ref, _ = O.loss_and_grads(spec, p64, [x.astype(np.float64) for x in xs], y, mask, theta)
+    m = AdeNetModel(dict(spec, precision="bf16x3"))
+    m.set_params_dict(p)
+    m.set_batch_lengths(lens)
+    probs = m.predict(xs, mask, theta)
+    assert m.compact_rows() == int(lens.sum()) + 1
+    m.set_batch_lengths(lens)
+    loss = m.compute_grads(xs, y, mask, theta)
+    g = m.get_grads_dict()
+    assert m.compact_rows() == int(lens.sum()) + 1
+    m.compute_grads(xs, y, mask, theta)
+    assert m.compact_rows() == 0                                       # the announcement was for one call
+    m.close()
+    assert np.abs(probs - probs_ref).max() <= 1e-4
+    assert abs(loss - l_ref) <= 1e-5 * abs(l_ref)
+    gscale = max(np.abs(v).max() for v in g_ref.values())
+    for k in O.param_names(spec):
+        assert np.abs(g[k] - g_ref[k]).max() <= 2e-4 * max(np.abs(g_ref[k]).max(), 1e-3 * gscale), k
+
+
+def test_compaction_declines_where_it_does_not_apply(torch_cuda):
+    """f32 arithmetic, a batch with (almost) no padding, lengths of another batch size: the call runs padded."""
+    from ip_avsr_amd.model import AdeNetModel
+    dims = (72, 56)
+    spec = O.spec_nstream(list(dims), enc_shapes=(96, 64, 24), enc_acts=("rectify", "rectify", "linear"), lstm_size=40, classes=26)
+    B, T, theta = 20, 12, 3
+    p, lens, mask, xs, y = _data(spec, B, T, dims, 3)
+    m = AdeNetModel(dict(spec, precision="f32"))
+    m.set_params_dict(p)
+    m.set_batch_lengths(lens)
+    m.predict(xs, mask, theta)
+    assert m.compact_rows() == 0                                       # f32: no 16-bit operands to gather
+    m.set_precision("bf16")
+    m.set_batch_lengths(lens)
+    m.predict(xs, mask, theta)
+    assert m.compact_rows() == int(lens.sum()) + 1
+    m.set_batch_lengths(lens[:-1])
+    m.predict(xs, mask, theta)
+    assert m.compact_rows() == 0                                       # lengths of another batch size
+    full = np.full(B, T, np.int32)
+    m.set_batch_lengths(full)
+    ones = np.ones((B, T), np.uint8)
+    m.predict(xs, ones, theta)
+    assert m.compact_rows() == 0                                       # nothing to drop
+    m.close()
