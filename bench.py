@@ -263,11 +263,25 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def rooflines(prof, steps, prof_elapsed, precision, hbm_measured, traffic_file):
-    """roofline objects of one precision from the per-class HIP-event profile of `steps` train steps."""
+def skipped_encoder_flops(rows, precision):
+    """Flops of the reference's algorithm that frame compaction does not execute: `rows` padding rows x three encoders x
+    (forward + weight gradient for every layer, input gradient for every layer but the first), priced like the executed ones
+    (bf16x3: three bf16 products per product; mixed: three forward, one in back-propagation)."""
+    dims = (D,) + ENC
+    per_layer = [2.0 * dims[l] * dims[l + 1] for l in range(len(ENC))]
+    fwd, dw, dx = sum(per_layer), sum(per_layer), sum(per_layer[1:])
+    k_f, k_b = {"bf16x3": (3.0, 3.0), "mixed": (3.0, 1.0)}.get(precision, (1.0, 1.0))
+    return 3.0 * rows * (k_f * fwd + k_b * (dw + dx))
+
+
+def rooflines(prof, steps, prof_elapsed, precision, hbm_measured, traffic_file, skipped_rows=0):
+    """roofline objects of one precision from the per-class HIP-event profile of `steps` train steps.  skipped_rows: padding rows
+    per step the encoders did not run over (frame compaction) -- `achieved` / `frac` price the ALGORITHMIC flops of the step, i.e.
+    the reference's B x T rows (an utterance = T frames); the executed figure is reported beside them."""
     out = {}
     g = [prof[k] for k in ("gemm_nn", "gemm_nt", "gemm_tn") if k in prof]
-    flops = sum(e["flops"] for e in g); ms = sum(e["ms"] for e in g); n = sum(e["launches"] for e in g)
+    executed = sum(e["flops"] for e in g); ms = sum(e["ms"] for e in g); n = sum(e["launches"] for e in g)
+    flops = executed + steps * skipped_encoder_flops(skipped_rows, precision)
     ach = flops / (ms * 1e-3) / 1e12 if ms else 0.0
     peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_BF16_MFMA_TFLOPS
     # bf16x3: the profile counts the EXECUTED flops of the three-fold-K bf16 launches (that is what the matrix pipe does and
@@ -297,6 +311,12 @@ def rooflines(prof, steps, prof_elapsed, precision, hbm_measured, traffic_file):
                        "measured": "HIP events on the model stream, separate pass of %d steps "
                                    "(%.2f ms/step with events on)" % (steps, 1e3 * prof_elapsed / steps)}
     out["roofline"].update(x3_note)
+    if skipped_rows:
+        ex = executed / (ms * 1e-3) / 1e12 if ms else 0.0
+        out["roofline"].update({"executed_TFLOPs": ex, "executed_frac": ex / peak, "skipped_padding_rows_per_step": int(skipped_rows),
+                                "algorithmic_note": "achieved / frac count the reference's B x T encoder rows (SURVEY 8d's unit: an utterance of "
+                                                    "T frames); frame compaction runs the encoders over the valid frames + one zero row, and "
+                                                    "executed_* price what the matrix pipe actually did"})
     for key, name in (("lstm_fwd_step", "roofline_lstm_fwd"), ("lstm_bwd_step", "roofline_lstm_bwd")):
         if key in prof and prof[key]["ms"]:
             e = prof[key]
@@ -429,6 +449,10 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
     # number of extra untimed steps ahead of the W warm-up steps of the contract takes that out of every run alike
     for _ in range(PREWARM_STEPS if on_gpu and not only else 0):
         step()
+    encoder_rows = None
+    if on_gpu:
+        step()
+        encoder_rows = model.compact_rows() or int(np.asarray(mask).size)      # (of the step just run)
     for _ in range(args.warmup):
         step()
     elapsed = timed(args.steps)
@@ -528,9 +552,10 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
             out["hbm_copy_measured_GBs"] = hbm
             out["hbm_copy_guide_GBs"] = GUIDE_COPY_GBS
         if prof:
-            out.update(rooflines(prof, args.steps, prof_elapsed, args.precision, hbm, traffic_file(args.precision)))
+            out.update(rooflines(prof, args.steps, prof_elapsed, args.precision, hbm, traffic_file(args.precision),
+                                 skipped_rows=(int(np.asarray(mask).size) - encoder_rows) if encoder_rows else 0))
         if on_gpu:
-            out["config"]["frame_compaction"] = {"on": compaction, "encoder_rows": model.compact_rows() or int(np.asarray(mask).size),
+            out["config"]["frame_compaction"] = {"on": compaction, "encoder_rows": encoder_rows,
                                                  "padded_rows": int(np.asarray(mask).size), "valid_frames": int(batch_lens.sum())}
         if on_gpu and world == 1 and compaction:
             # the same step with the encoders over all B x T rows (rounds 1-4, and this round before the compaction)
@@ -590,7 +615,8 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
             if profile:
                 model.profile(True)
                 pe = timed(k)
-                acc.update(rooflines(model.profile_read(), k, pe, prec, hbm, traffic_file(prec)))
+                acc.update(rooflines(model.profile_read(), k, pe, prec, hbm, traffic_file(prec),
+                                     skipped_rows=(int(np.asarray(mask).size) - encoder_rows) if (encoder_rows and compaction and prec in ("bf16x3", "mixed")) else 0))
                 model.profile(False)
             out[{"bf16x3": "accurate", "mixed": "mixed"}.get(prec, "accurate_" + prec)] = acc
             model.set_precision(args.precision)
