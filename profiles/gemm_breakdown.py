@@ -22,13 +22,19 @@ def run():
     model = AdeNetModel(bench.build_spec())
     model.set_precision(os.environ.get("ADN_PRECISION", "bf16"))
     bench.synthetic_params(model)
-    xs, y, m_d, _ = bench.synthetic_batch(torch, 0, int(os.environ.get("BD_BATCH", bench.B_PER_GPU)), device)   # BD_BATCH=26: the reference's minibatch
-    for _ in range(int(os.environ.get("BD_WARM", 0))):     # (small batches: past the idle-clock transient)
+    xs, y, m_d, mask = bench.synthetic_batch(torch, 0, int(os.environ.get("BD_BATCH", bench.B_PER_GPU)), device)   # BD_BATCH=26: the reference's minibatch
+    lens = None if os.environ.get("BD_PADDED") else mask.sum(axis=1).astype("int32")     # frame compaction, as bench.py announces it (BD_PADDED=1: off)
+
+    def step():
+        if lens is not None:
+            model.set_batch_lengths(lens)
         model.train_step(xs, y, m_d, bench.THETA, bench.LR, want_loss=False)
+    for _ in range(int(os.environ.get("BD_WARM", 0))):     # (small batches: past the idle-clock transient)
+        step()
     torch.cuda.synchronize()
     for _ in range(2):
         sys.stderr.write("ADN_STEP\n"); sys.stderr.flush()
-        model.train_step(xs, y, m_d, bench.THETA, bench.LR, want_loss=False)
+        step()
         torch.cuda.synchronize()
 
 
