@@ -293,7 +293,10 @@ def rooflines(prof, steps, prof_elapsed, precision, hbm_measured, traffic_file, 
                            "back-propagation"}
     traffic, pmc = None, {}                # HBM bytes per launch from the committed PMC passes (labelled with their commit)
     if os.path.exists(traffic_file):
-        pmc = json.load(open(traffic_file))
+        try:
+            pmc = json.load(open(traffic_file))
+        except ValueError:                     # (an unreadable summary must not take the bench line down: traffic stays null)
+            pmc = {}
         # per LAUNCH in this object's sense: one GEMM problem (a grouped kernel dispatch carries up to four; the PMC summary
         # counts dispatches), so that `traffic` and `algorithmic_flops_per_launch` share their denominator
         if pmc.get("traffic_bytes_per_train_step") and n:
@@ -449,13 +452,10 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
     # number of extra untimed steps ahead of the W warm-up steps of the contract takes that out of every run alike
     for _ in range(PREWARM_STEPS if on_gpu and not only else 0):
         step()
-    encoder_rows = None
-    if on_gpu:
-        step()
-        encoder_rows = model.compact_rows() or int(np.asarray(mask).size)      # (of the step just run)
     for _ in range(args.warmup):
         step()
     elapsed = timed(args.steps)
+    encoder_rows = (model.compact_rows() or int(np.asarray(mask).size)) if on_gpu else None      # (of the step just run)
     # per-kernel-class timing: a SECOND pass of the same K steps with HIP events recorded on the model's stream
     # around every launch (sequence of T launches for the recurrent step kernels).  Kept out of the timed region
     # above because ~700 event records per step cost ~15 % of a step.
