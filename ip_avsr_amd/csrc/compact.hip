@@ -95,12 +95,22 @@ __global__ __launch_bounds__(256) void compact_rows_sum_kernel(const float* __re
         partial[(size_t)blockIdx.x * cols + q] = s;
     }
 }
+// comp[Z][q] = sum over the blocks' partial sums, in one fixed order: lane ts adds blocks ts, ts + 8, ... and the eight lane sums are
+// added in lane order (blockIdx.x = 32-column chunk of the row, pad columns included: they become zero)
 __global__ __launch_bounds__(256) void compact_sum_finish_kernel(const float* __restrict__ partial, int nblocks, float* __restrict__ comp, int ld_comp,
                                                                  int cols, int ld_cols, int Z) {
-    for (int q = blockIdx.x * 256 + threadIdx.x; q < ld_cols; q += gridDim.x * 256) {
-        float s = 0.f;
-        if (q < cols) for (int k = 0; k < nblocks; ++k) s += partial[(size_t)k * cols + q];
-        comp[(size_t)Z * ld_comp + q] = s;                            // (pad columns of the row: zero)
+    __shared__ float red[8][32];
+    const int fl = threadIdx.x & 31, ts = threadIdx.x >> 5;
+    const int q = blockIdx.x * 32 + fl;
+    float s = 0.f;
+    if (q < cols) for (int k = ts; k < nblocks; k += 8) s += partial[(size_t)k * cols + q];
+    red[ts][fl] = s;
+    __syncthreads();
+    if (ts == 0 && q < ld_cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][fl];
+        comp[(size_t)Z * ld_comp + q] = t;
     }
 }
 
@@ -147,7 +157,7 @@ int compact_rows_sum(const float* full, int ld_full, float* comp, int ld_comp, c
     const int nblocks = cdiv(N, kSumRows);
     hipLaunchKernelGGL(compact_rows_sum_kernel, dim3(nblocks, cdiv(cols, 32)), dim3(256), 0, s, full, ld_full, comp, ld_comp, comp_of_full, N,
                        cols, Z, ws);
-    hipLaunchKernelGGL(compact_sum_finish_kernel, dim3(1), dim3(256), 0, s, ws, nblocks, comp, ld_comp, cols, ld_comp, Z);
+    hipLaunchKernelGGL(compact_sum_finish_kernel, dim3(cdiv(ld_comp, 32)), dim3(256), 0, s, ws, nblocks, comp, ld_comp, cols, ld_comp, Z);
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }

@@ -332,7 +332,10 @@ static int gemm_pp_try_impl(const GemmArgs* gs, int n, const GemmArgs& g, int ks
         const bool fwd_group = splits == 1 && plain && (!g.accumulate || kseg) && fill >= (fill_env > 0 ? fill_env : kseg ? 0.50 : 0.80);
         // input-gradient GEMMs of several streams (act'(Y) mask from the bf16 copy, fused column sums): 445 against 3 x 153 us
         // for 20800 x 2000 x 1000, 178 against 3 x 59 for 20800 x 1000 x 500; one alone is no faster than the 128 x 128 kernel
-        const bool bwd_group = splits == 1 && n >= 2 && g.Y16 && fill >= 0.85;
+        // (0.85 when the rule was measured at B T = 20800 rows -- fill 0.93; the compacted step's 13 730 rows fill 0.82 of their 6 / 3
+        //  rounds and the register-staged alternative costs 280 us for 13730 x 2000 x 1000 x 3: 0.80.  ADN_GEMM_PP_BWD_FILL overrides)
+        static const double bwd_fill_env = getenv("ADN_GEMM_PP_BWD_FILL") ? atof(getenv("ADN_GEMM_PP_BWD_FILL")) : 0.0;
+        const bool bwd_group = splits == 1 && n >= 2 && g.Y16 && fill >= (bwd_fill_env > 0 ? bwd_fill_env : 0.80);
         if (!wgrad && !fwd_group && !bwd_group) return ADN_OK;
     }
     const Cand& cd = cands[best];
