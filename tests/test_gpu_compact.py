@@ -139,3 +139,40 @@ def test_compaction_declines_where_it_does_not_apply(torch_cuda):
     m.predict(xs, ones, theta)
     assert m.compact_rows() == 0                                       # nothing to drop
     m.close()
+
+
+@pytest.mark.parametrize("prec,form", [("bf16", "bfloat16"), ("bf16", "float32"), ("bf16x3", "planes"), ("mixed", "planes"), ("bf16x3", "float32")])
+def test_compaction_with_device_resident_inputs(torch_cuda, prec, form):
+    """The forms bench.py and the epoch drivers hand over -- device tensors: bfloat16 (read in place by the first GEMM when padded),
+    hi / lo planes (ADN_FLAG_PLANE_INPUTS), float32 -- gathered to the compact layout: same probabilities and gradients as the padded
+    call on the same tensors, to the arithmetic's rounding."""
+    from ip_avsr_amd.model import AdeNetModel, PlaneInput
+    torch = torch_cuda
+    dims = (72, 56)
+    spec = O.spec_nstream(list(dims), enc_shapes=(160, 128, 50), enc_acts=("rectify", "rectify", "linear"), lstm_size=40, classes=26,
+                          fusion="concat")
+    B, T, theta = 70, 30, 9
+    p, lens, mask, xs, y = _data(spec, B, T, dims, 8)
+    dev = [torch.tensor(x, device="cuda") for x in xs]
+    feed = {"bfloat16": [x.to(torch.bfloat16) for x in dev], "planes": [PlaneInput.split(x) for x in dev], "float32": dev}[form]
+    m = AdeNetModel(dict(spec, precision=prec))
+    m.set_params_dict(p)
+    out = {}
+    for mode in ("padded", "compact"):
+        if mode == "compact":
+            m.set_batch_lengths(lens)
+        probs = m.predict(feed, mask, theta)
+        rows = m.compact_rows()
+        if mode == "compact":
+            m.set_batch_lengths(lens)
+        loss = m.compute_grads(feed, y, mask, theta)
+        out[mode] = (probs, loss, m.get_grads_dict(), rows)
+    m.close()
+    assert out["padded"][3] == 0 and out["compact"][3] == (0 if _declined(prec) else int(lens.sum()) + 1)
+    ptol, gtol = {"bf16x3": (5e-6, 1e-4), "mixed": (5e-6, 1e-2), "bf16": (3e-3, 1e-2)}[prec]
+    assert np.abs(out["compact"][0] - out["padded"][0]).max() <= ptol
+    assert abs(out["compact"][1] - out["padded"][1]) <= (1e-6 if prec != "bf16" else 2e-3) * abs(out["padded"][1])
+    gscale = max(np.abs(v).max() for v in out["padded"][2].values())
+    for k in O.param_names(spec):
+        a, b = out["compact"][2][k], out["padded"][2][k]
+        assert np.abs(a - b).max() <= gtol * max(np.abs(b).max(), 1e-3 * gscale), k
