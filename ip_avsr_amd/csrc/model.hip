@@ -237,7 +237,7 @@ struct adn_model {
     // frame compaction: lengths announced by adn_set_batch_lengths (host), the row maps of the batch on the device, Nc = valid + 1
     std::vector<int32_t> batch_lens, maps_lens;
     int32_t *d_lens = nullptr, *d_prefix = nullptr, *comp_of_full = nullptr, *full_of_comp = nullptr;
-    std::vector<int32_t> h_comp_of_full;
+    std::vector<int32_t> h_comp_of_full, h_prefix;
     int Nc = 0; bool compact = false; int maps_T = 0;
     Profiler prof;
     // bf16 shadow copies of every GEMM operand (bf16 mode): fp32 range -> bf16 buffer with the same layout
@@ -730,15 +730,18 @@ int setup_compaction(adn_model* m, int B, int T) {
     if ((double)(valid + 1) > 0.9 * (double)N) return ADN_OK;
     const int Z = (int)valid;
     if (m->maps_lens != lens || m->maps_T != T) {
-        std::vector<int32_t> prefix((size_t)B + 1, 0);
+        // (uploads ON the model's stream, from buffers the model owns: the host runs ahead of the device, and the previous call's map
+        //  kernel -- still queued, perhaps -- must read the previous call's lengths)
+        m->maps_lens = lens; m->maps_T = T;
+        std::vector<int32_t>& prefix = m->h_prefix;
+        prefix.assign((size_t)B + 1, 0);
         for (int b = 0; b < B; ++b) prefix[b + 1] = prefix[b] + lens[b];
-        ADN_HIP_CHECK(hipMemcpy(m->d_lens, lens.data(), (size_t)B * 4, hipMemcpyHostToDevice));
-        ADN_HIP_CHECK(hipMemcpy(m->d_prefix, prefix.data(), ((size_t)B + 1) * 4, hipMemcpyHostToDevice));
+        ADN_HIP_CHECK(hipMemcpyAsync(m->d_lens, m->maps_lens.data(), (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
+        ADN_HIP_CHECK(hipMemcpyAsync(m->d_prefix, prefix.data(), ((size_t)B + 1) * 4, hipMemcpyHostToDevice, m->stream));
         ADN_TRY(compact_build_maps(m->d_lens, m->d_prefix, B, T, Z, m->comp_of_full, m->full_of_comp, m->stream));
         m->h_comp_of_full.assign(N, Z);
         for (int b = 0; b < B; ++b)
             for (int t = 0; t < lens[b]; ++t) m->h_comp_of_full[(size_t)b * T + t] = prefix[b] + t;
-        m->maps_lens = lens; m->maps_T = T;
     }
     m->Nc = Z + 1; m->compact = true;
     for (auto& st : m->st) {

@@ -176,3 +176,32 @@ def test_compaction_with_device_resident_inputs(torch_cuda, prec, form):
     for k in O.param_names(spec):
         a, b = out["compact"][2][k], out["padded"][2][k]
         assert np.abs(a - b).max() <= gtol * max(np.abs(b).max(), 1e-3 * gscale), k
+
+
+def test_back_to_back_steps_over_batches_of_different_lengths(torch_cuda):
+    """train_step does not wait for the device: the next call's lengths and row maps are uploaded while the previous step may still be
+    queued.  Four steps alternating between two batches (other lengths, other sizes of the compact matrices), compacted against
+    padded, from the same start: the parameters' predictions stay together (Adam amplifies rounding, not row maps gone wrong)."""
+    from ip_avsr_amd.model import AdeNetModel
+    torch = torch_cuda
+    dims = (72, 56)
+    spec = O.spec_nstream(list(dims), enc_shapes=(160, 128, 50), enc_acts=("rectify", "rectify", "linear"), lstm_size=40, classes=26,
+                          fusion="concat")
+    B, T, theta = 70, 30, 9
+    p, lens_a, mask_a, xs_a, y_a = _data(spec, B, T, dims, 8)
+    _, lens_b, mask_b, xs_b, y_b = _data(spec, B, T, dims, 21)
+    dev = lambda xs: [torch.tensor(x, device="cuda") for x in xs]
+    batches = [(dev(xs_a), torch.tensor(y_a, device="cuda"), torch.tensor(mask_a, device="cuda"), lens_a),
+               (dev(xs_b), torch.tensor(y_b, device="cuda"), torch.tensor(mask_b, device="cuda"), lens_b)]
+    out = {}
+    for mode in ("padded", "compact"):
+        m = AdeNetModel(dict(spec, precision="bf16x3"))
+        m.set_params_dict(p)
+        for k in range(4):
+            xs, y, msk, lens = batches[k % 2]
+            if mode == "compact":
+                m.set_batch_lengths(lens)
+            m.train_step(xs, y, msk, theta, 1e-3, want_loss=False)
+        out[mode] = m.predict(xs_a, mask_a, theta)
+        m.close()
+    assert np.abs(out["compact"] - out["padded"]).max() <= 2e-3
