@@ -166,8 +166,6 @@ int join_hilo(const void* hi, const void* lo, float* dst, size_t n, hipStream_t 
 int compact_build_maps(const int32_t* d_lens, const int32_t* d_prefix, int B, int T, int Z, int32_t* comp_of_full, int32_t* full_of_comp,
                        hipStream_t s);
 int compact_gather_rows16(const void* src, int ld_src, void* dst, int ld_dst, const int32_t* full_of_comp, int Nc, int cols, hipStream_t s);
-int compact_gather_rows_f32(const float* src, int ld_src, void* dst16, void* dst16lo, int ld_dst, const int32_t* full_of_comp, int Nc, int cols,
-                            hipStream_t s);
 int compact_expand_rows(const float* comp, int ld_comp, float* full, int ld_full, const int32_t* comp_of_full, int N, int cols, hipStream_t s);
 size_t compact_sum_ws_floats(int N, int cols);
 int compact_rows_sum(const float* full, int ld_full, float* comp, int ld_comp, const int32_t* comp_of_full, int N, int cols, int Z,

@@ -43,21 +43,6 @@ __global__ __launch_bounds__(256) void gather_rows16_kernel(const u32x4* __restr
     }
 }
 
-// fp32 rows -> bf16 (or hi / lo planes) while gathering: dst16[c] = bf16(src[full_of_comp[c]]), dst16lo = bf16(x - hi)
-__global__ __launch_bounds__(256) void gather_rows_f32_kernel(const float* __restrict__ src, int ld_src, __bf16* __restrict__ dst16,
-                                                              __bf16* __restrict__ dst16lo, int ld_dst, const int32_t* __restrict__ full_of_comp,
-                                                              int Nc, int cols) {
-    const int64_t total = (int64_t)Nc * cols;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int c = (int)(e / cols), q = (int)(e - (int64_t)c * cols);
-        const int r = full_of_comp[c];
-        const float x = r >= 0 ? src[(size_t)r * ld_src + q] : 0.f;
-        const __bf16 hi = (__bf16)x;
-        dst16[(size_t)c * ld_dst + q] = hi;
-        if (dst16lo) dst16lo[(size_t)c * ld_dst + q] = (__bf16)(x - (float)hi);
-    }
-}
-
 // full[r][0 .. cols) = comp[comp_of_full[r]][...]
 __global__ __launch_bounds__(256) void expand_rows_kernel(const float* __restrict__ comp, int ld_comp, float* __restrict__ full, int ld_full,
                                                           const int32_t* __restrict__ comp_of_full, int N, int cols) {
@@ -131,14 +116,6 @@ int compact_gather_rows16(const void* src, int ld_src, void* dst, int ld_dst, co
               "compact_gather_rows16: rows of whole 16-byte pieces");
     hipLaunchKernelGGL(gather_rows16_kernel, dim3(grid_for_elems((int64_t)Nc * (cols / 8))), dim3(256), 0, s, static_cast<const u32x4*>(src),
                        ld_src / 8, static_cast<u32x4*>(dst), ld_dst / 8, full_of_comp, Nc, cols / 8);
-    ADN_HIP_CHECK(hipGetLastError());
-    return ADN_OK;
-}
-
-int compact_gather_rows_f32(const float* src, int ld_src, void* dst16, void* dst16lo, int ld_dst, const int32_t* full_of_comp, int Nc, int cols,
-                            hipStream_t s) {
-    hipLaunchKernelGGL(gather_rows_f32_kernel, dim3(grid_for_elems((int64_t)Nc * cols)), dim3(256), 0, s, src, ld_src,
-                       static_cast<__bf16*>(dst16), static_cast<__bf16*>(dst16lo), ld_dst, full_of_comp, Nc, cols);
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }
