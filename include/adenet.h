@@ -274,7 +274,8 @@ int adn_get_deterministic(void);
  * delta layer sees at the padding frames, backward it carries the sum of their gradients, which is all the parameter gradients ever
  * see of them (the encoder is row-wise).  Same results as the padded computation up to summation order; everything from the delta
  * layer up stays padded.  Applies when B matches the call's, in the 16-bit arithmetics (bf16 / bf16x3 / mixed) whose encoders end in a
- * linear layer without BatchNorm, when at least 10 % of the rows are padding; otherwise the call runs padded as before.  The mask
+ * linear layer without BatchNorm, when the batch has at least 8192 rows (B T; smaller ones are latency-bound and gain nothing) of
+ * which at least 10 % are padding; otherwise the call runs padded as before.  The mask
  * passed with the call must describe the same lengths (prefix masks).  ADN_NO_COMPACT=1 in the environment switches it off. */
 int adn_set_batch_lengths(adn_model* m, const int32_t* lengths, int B);
 /* rows of the encoder matrices in the last call: sum(len) + 1 when it ran compacted, 0 when it ran padded */

@@ -728,6 +728,12 @@ int setup_compaction(adn_model* m, int B, int T) {
         valid += lens[b];
     }
     if ((double)(valid + 1) > 0.9 * (double)N) return ADN_OK;
+    // (small batches: the encoder GEMMs are latency-bound and the dozen extra launches cost more than the rows save -- the reference's
+    //  26-utterance minibatch: 29.5 -> 30.3 ms per epoch of 20 steps with it; ADN_COMPACT_MIN_ROWS overrides, read per call)
+    {
+        const char* e = getenv("ADN_COMPACT_MIN_ROWS");
+        if ((int64_t)N < (e ? atoll(e) : 8192)) return ADN_OK;
+    }
     const int Z = (int)valid;
     if (m->maps_lens != lens || m->maps_T != T) {
         // (uploads ON the model's stream, from buffers the model owns: the host runs ahead of the device, and the previous call's map

@@ -332,6 +332,12 @@ def fit(network, split, ys, lens, n_streams, windowsize, num_epoch, epochsize, b
                 batch = next(datagen)
                 Xs_r, y_r, m_r = batch.Xs, batch.targets, batch.mask
                 n_examples, total_frames = len(batch.global_idxs), batch.total_frames
+            # frame compaction (include/adenet.h adn_set_batch_lengths): the loop knows the minibatch's lengths and both assemblies pad
+            # with zero frames -- announced for the training call right below (ADN_RUNNER_PADDED=1: not announced)
+            if hasattr(network, "set_batch_lengths") and not os.environ.get("ADN_RUNNER_PADDED"):
+                rows = batch.idxs if not host_batches else (np.asarray(batch_idxs)[mine] if dp is not None else batch_idxs)
+                if len(rows):
+                    network.set_batch_lengths(np.asarray(tr_lens)[np.asarray(rows, dtype=np.int64)])
             if rank == 0 and progress:
                 print('Epoch {} batch {}/{}: {} examples using adam with learning rate = {}'.format(
                     epoch + 1, i + 1, epochsize, n_examples, learning_rate), end='')

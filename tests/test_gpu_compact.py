@@ -21,6 +21,13 @@ def torch_cuda():
     return torch
 
 
+@pytest.fixture(autouse=True)
+def small_batches_compact_too(monkeypatch):
+    """the library leaves batches under 8192 rows padded (they are latency-bound: compaction costs more launches than it saves rows);
+    the tests' batches are 2100 rows"""
+    monkeypatch.setenv("ADN_COMPACT_MIN_ROWS", "0")
+
+
 def _declined(prec):
     """the diagnostic switches of profiles/scripts/envmatrix.sh under which a call runs padded by design"""
     return bool(os.environ.get("ADN_NO_COMPACT") or os.environ.get("ADN_STREAMS") or os.environ.get("ADN_BF16_NO_SHADOW") or
