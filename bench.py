@@ -47,7 +47,7 @@ B_PER_GPU, T_MAX, THETA, H, C, D = 520, 40, 9, 250, 26, 1200
 B_PER_GPU = int(os.environ.get("ADN_BENCH_B", B_PER_GPU))      # (profiling aid for profiles/scripts/timeline.sh: the judged workload is 520)
 ENC = (2000, 1000, 500, 50)
 LR = 1e-3
-PROFILE_ROUNDS = ("r05", "r04", "r03")      # profiles/<round>/pmc_traffic_<precision>.json feeds roofline.traffic (newest round that has one)
+PROFILE_ROUNDS = ("r06", "r05", "r04", "r03")      # profiles/<round>/pmc_traffic_<precision>.json feeds roofline.traffic (newest round that has one)
 PREWARM_STEPS = 20         # untimed steps ahead of the warm-up (see run(): idle clocks after the host-side setup)
 
 
@@ -275,13 +275,14 @@ def skipped_encoder_flops(rows, precision):
 
 
 def rooflines(prof, steps, prof_elapsed, precision, hbm_measured, traffic_file, skipped_rows=0):
-    """roofline objects of one precision from the per-class HIP-event profile of `steps` train steps.  skipped_rows: padding rows
-    per step the encoders did not run over (frame compaction) -- `achieved` / `frac` price the ALGORITHMIC flops of the step, i.e.
-    the reference's B x T rows (an utterance = T frames); the executed figure is reported beside them."""
+    """roofline objects of one precision from the per-class HIP-event profile of `steps` train steps.  `achieved` / `frac` price
+    the flops the launches EXECUTED (what a roofline prices: the units a launch processes).  skipped_rows: padding rows per step
+    the encoders did not run over (frame compaction); the figure that also counts those rows -- the reference's B x T rows, SURVEY
+    8d's unit -- is reported beside it as algorithmic_*_BxT, never as `frac`."""
     out = {}
     g = [prof[k] for k in ("gemm_nn", "gemm_nt", "gemm_tn") if k in prof]
     executed = sum(e["flops"] for e in g); ms = sum(e["ms"] for e in g); n = sum(e["launches"] for e in g)
-    flops = executed + steps * skipped_encoder_flops(skipped_rows, precision)
+    flops = executed
     ach = flops / (ms * 1e-3) / 1e12 if ms else 0.0
     peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_BF16_MFMA_TFLOPS
     # bf16x3: the profile counts the EXECUTED flops of the three-fold-K bf16 launches (that is what the matrix pipe does and
@@ -315,11 +316,11 @@ def rooflines(prof, steps, prof_elapsed, precision, hbm_measured, traffic_file, 
                                    "(%.2f ms/step with events on)" % (steps, 1e3 * prof_elapsed / steps)}
     out["roofline"].update(x3_note)
     if skipped_rows:
-        ex = executed / (ms * 1e-3) / 1e12 if ms else 0.0
-        out["roofline"].update({"executed_TFLOPs": ex, "executed_frac": ex / peak, "skipped_padding_rows_per_step": int(skipped_rows),
-                                "algorithmic_note": "achieved / frac count the reference's B x T encoder rows (SURVEY 8d's unit: an utterance of "
-                                                    "T frames); frame compaction runs the encoders over the valid frames + one zero row, and "
-                                                    "executed_* price what the matrix pipe actually did"})
+        alg = (executed + steps * skipped_encoder_flops(skipped_rows, precision)) / (ms * 1e-3) / 1e12 if ms else 0.0
+        out["roofline"].update({"algorithmic_TFLOPs_BxT": alg, "algorithmic_frac_BxT": alg / peak, "skipped_padding_rows_per_step": int(skipped_rows),
+                                "algorithmic_note": "achieved / frac = flops the launches executed (frame compaction runs the encoders over the "
+                                                    "valid frames + one zero row); algorithmic_*_BxT also counts the padding rows of the "
+                                                    "reference's B x T frames that no launch processed -- not a utilisation figure"})
     for key, name in (("lstm_fwd_step", "roofline_lstm_fwd"), ("lstm_bwd_step", "roofline_lstm_bwd")):
         if key in prof and prof[key]["ms"]:
             e = prof[key]
@@ -343,8 +344,28 @@ def rooflines(prof, steps, prof_elapsed, precision, hbm_measured, traffic_file, 
                          "algorithmic_bytes_per_unit": unit,
                          "avg_launch_us": 1e3 * e["ms"] / e["launches"],
                          "share_of_step": e["ms"] / (1e3 * prof_elapsed)}
+    for key, name in (("roofline_lstm_fwd", "lstm_fwd_frac"), ("roofline_lstm_bwd", "lstm_bwd_frac")):
+        if key in out:                      # (inside `roofline`: the record the driver keeps holds this object whole)
+            out["roofline"][name] = out[key]["frac"]
+            out["roofline"][name + "_of_measured_copy"] = out[key]["frac_of_measured"]
     out["kernel_ms_per_step"] = {k: v["ms"] / steps for k, v in prof.items()}
     return out
+
+
+def compaction_check(model, xs, m_d, lens, precision):
+    """Outside every timed region: ONE padded and ONE compacted forward pass of the bench batch, max |dp| between them asserted at
+    the arithmetic's grade (the encoder is row-wise: only the summation order inside other tile shapes differs) -- the step that is
+    timed computes what the padded step computes."""
+    model.set_batch_lengths(None)
+    padded = model.predict(xs, m_d, THETA)
+    assert model.compact_rows() == 0
+    model.set_batch_lengths(lens)
+    compact = model.predict(xs, m_d, THETA)
+    rows = model.compact_rows()
+    tol = {"bf16": 1e-3, "f32": 0.0}.get(precision, 1e-5)
+    dp = float(np.abs(padded - compact).max())
+    assert dp <= tol, "frame compaction changed the probabilities by %.3e (> %.1e) in %s" % (dp, tol, precision)
+    return {"max_abs_dp_padded_vs_compacted": dp, "tolerance": tol, "encoder_rows_compacted": rows, "dtype": precision}
 
 
 def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
@@ -478,7 +499,7 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
         t_local = None
         if hasattr(model, "snapshot_state"):
             snap = model.snapshot_state()            # (the local steps must leave no trace: the replicas stay in lock-step)
-            local_step = lambda: model.train_step(xs, y, m_d, THETA, LR, want_loss=False)
+            local_step = lambda: (announce_lengths(), model.train_step(xs, y, m_d, THETA, LR, want_loss=False))[1]   # (the same computation as the exchanged steps)
             saved_step, step = step, local_step
             for _ in range(2):
                 step()
@@ -557,6 +578,8 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
         if on_gpu:
             out["config"]["frame_compaction"] = {"on": compaction, "encoder_rows": encoder_rows,
                                                  "padded_rows": int(np.asarray(mask).size), "valid_frames": int(batch_lens.sum())}
+            if compaction and world == 1:
+                out["config"]["frame_compaction"]["check"] = compaction_check(model, xs, m_d, batch_lens, args.precision)
         if on_gpu and world == 1 and compaction:
             # the same step with the encoders over all B x T rows (rounds 1-4, and this round before the compaction)
             announce["lens"] = None
@@ -565,6 +588,7 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
             t_p = timed(args.steps)
             out["padded_encoders"] = {"ms_per_step": 1e3 * t_p / args.steps, "value": B_PER_GPU * args.steps / t_p, "unit": "sequences/s",
                                       "dtype": args.precision, "encoder_rows": int(np.asarray(mask).size)}
+            out["config"]["padded_encoders_ms"] = out["padded_encoders"]["ms_per_step"]
             announce["lens"] = batch_lens
         if on_gpu and world == 1 and xs is not xs32:
             # the like-for-like figure against rounds 1-2 and against the f32 / bf16x3 rows: the SAME bf16 arithmetic fed with
@@ -575,10 +599,13 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
             t_f = timed(args.steps)
             out["fp32_inputs"] = {"ms_per_step": 1e3 * t_f / args.steps, "value": B_PER_GPU * args.steps / t_f, "unit": "sequences/s",
                                   "dtype": args.precision, "inputs": "float32, resident in HBM"}
+            out["config"]["fp32_inputs_ms"] = out["fp32_inputs"]["ms_per_step"]
             xs = xs16
         if on_gpu and world == 1 and not getattr(args, "no_runner", False):
             out["runner"] = runner_measurements(torch, model, device, args.steps)
             out["epoch_via_runner_s"] = out["runner"]["epoch_s"]
+            out["config"]["epoch_via_runner_s"] = out["runner"]["epoch_s"]
+            out["config"]["runner_step_ms_B520"] = out["runner"]["step_ms_B520"]
         # ---- the fp32-accurate mode, same workload, same process (the mode the 1e-4 / exact-top-1 parity tests run in)
         acc_modes = {"all": ["bf16x3", "mixed", "f32"], "both": ["bf16x3", "f32"], "none": []}.get(args.accurate_precision, [args.accurate_precision])
         for prec in (acc_modes if on_gpu and world == 1 else []):
@@ -618,7 +645,17 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
                 acc.update(rooflines(model.profile_read(), k, pe, prec, hbm, traffic_file(prec),
                                      skipped_rows=(int(np.asarray(mask).size) - encoder_rows) if (encoder_rows and compaction and prec in ("bf16x3", "mixed")) else 0))
                 model.profile(False)
+            if compaction and prec in ("bf16x3", "mixed"):
+                acc["frame_compaction_check"] = compaction_check(model, xs, m_d, batch_lens, prec)
             out[{"bf16x3": "accurate", "mixed": "mixed"}.get(prec, "accurate_" + prec)] = acc
+            # (the objects the driver's record keeps whole are `config`, `roofline` and `cpu_baseline`: what qualifies the headline
+            #  is repeated there)
+            if prec == "mixed":
+                out["config"]["mixed_ms"] = acc["ms_per_step"]; out["config"]["mixed_seq_s"] = acc["value"]
+                if "roofline" in acc and "roofline" in out:
+                    out["roofline"]["gemm_frac_mixed"] = acc["roofline"]["frac"]
+            elif prec == "f32":
+                out["config"]["f32_ms"] = acc["ms_per_step"]
             model.set_precision(args.precision)
         # the throughput that carries parity (north_star's 1e-4 / exact-top-1 gate): the headline itself when it was asked for in a
         # parity-grade arithmetic, otherwise the bf16x3 sub-run
@@ -626,6 +663,16 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
         if pg is not None:
             out["parity_grade"] = {"mode": pg.get("mode", args.precision), "value": pg["value"], "ms_per_step": pg["ms_per_step"],
                                    "unit": "sequences/s", "inputs": pg.get("inputs", inputs_desc)}
+            out["config"]["parity_grade_mode"] = out["parity_grade"]["mode"]
+            out["config"]["parity_grade_ms"] = pg["ms_per_step"]; out["config"]["parity_grade_seq_s"] = pg["value"]
+            if pg is not out and "roofline" in out:
+                if "fp32_inputs" in pg:
+                    out["config"]["parity_grade_fp32_inputs_ms"] = pg["fp32_inputs"]["ms_per_step"]
+                for k_src, k_dst in (("roofline_lstm_fwd", "lstm_fwd_frac_parity_grade"), ("roofline_lstm_bwd", "lstm_bwd_frac_parity_grade")):
+                    if k_src in pg:
+                        out["roofline"][k_dst] = pg[k_src]["frac"]
+                if "roofline" in pg:
+                    out["roofline"]["gemm_frac_parity_grade"] = pg["roofline"]["frac"]
         if on_gpu and world == 1 and not getattr(args, "no_reference_minibatch", False):
             # the same model at the reference's own minibatch (runners/3stream.py: 26 utterances per update): every GEMM is a
             # latency-bound launch there and the step is a chain of ~160 LSTM time steps -- reported beside the headline, not as it
@@ -647,6 +694,7 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
             t3 = time.perf_counter() - t3
             out["reference_minibatch"] = {"utterances_per_step": 26, "steps": 20, "ms_per_step": 1e3 * t3 / 20,
                                           "value": 26 * 20 / t3, "unit": "sequences/s", "dtype": args.precision}
+            out["config"]["reference_minibatch_B26_ms"] = out["reference_minibatch"]["ms_per_step"]
         if on_gpu and world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

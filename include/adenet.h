@@ -268,18 +268,32 @@ int adn_synchronize(adn_model* m);
 int adn_set_deterministic(int on);
 int adn_get_deterministic(void);
 /* Frame compaction (round 5; csrc/compact.hip).  The reference pads every utterance of a minibatch to the longest with ZERO frames
- * (utils/datagen.py:104,129-142) and sends all B T frames through the dense encoders.  Announcing the lengths of the NEXT call's batch
- * (host array of B ints, 1 <= len <= T; the announcement is used up by that call, whatever it decides) promises that the padding frames of the stream inputs are zero and lets the encoders run
- * over the sum(len) valid frames plus ONE zero-input row that stands for every padding frame -- forward its output enc(0) is what the
- * delta layer sees at the padding frames, backward it carries the sum of their gradients, which is all the parameter gradients ever
- * see of them (the encoder is row-wise).  Same results as the padded computation up to summation order; everything from the delta
- * layer up stays padded.  Applies when B matches the call's, in the 16-bit arithmetics (bf16 / bf16x3 / mixed) whose encoders end in a
- * linear layer without BatchNorm, when the batch has at least 8192 rows (B T; smaller ones are latency-bound and gain nothing) of
- * which at least 10 % are padding; otherwise the call runs padded as before.  The mask
- * passed with the call must describe the same lengths (prefix masks).  ADN_NO_COMPACT=1 in the environment switches it off. */
+ * (utils/datagen.py:104,129-142) and sends all B T frames through the dense encoders.  With the lengths of a call's batch at hand the
+ * encoders run over the sum(len) valid frames plus ONE zero-input row that stands for every padding frame -- forward its output
+ * enc(0) is what the delta layer sees at the padding frames, backward it carries the sum of their gradients, which is all the
+ * parameter gradients ever see of them (the encoder is row-wise).  Same results as the padded computation up to summation order;
+ * everything from the delta layer up stays padded.  Applies in the 16-bit arithmetics (bf16 / bf16x3 / mixed) whose encoders end in
+ * a linear layer without BatchNorm, when the batch has at least 8192 rows (B T; smaller ones are latency-bound and gain nothing;
+ * ADN_COMPACT_MIN_ROWS overrides) of which at least 10 % are padding; otherwise the call runs padded as before.  ADN_NO_COMPACT=1
+ * in the environment switches it off.
+ * Where the lengths come from (round 6):
+ *  - HOST arrays (the reference's call: train(*inputs, targets, mask, window) carries no lengths, runners/3stream.py:309-320,370):
+ *    read off the mask when it is a prefix mask; the device then looks at the padding frames it was just sent, and a batch with a
+ *    non-zero padding frame simply runs padded.  Nothing to announce, nothing promised (adn_set_auto_compaction(m, 0) turns this off).
+ *  - DEVICE arrays (ADN_FLAG_DEVICE_INPUTS): the host must say how many rows there are -- adn_set_batch_lengths() announces the
+ *    lengths of the NEXT call's batch (host array of B ints, 1 <= len <= T; used up by that call, whatever becomes of it) and
+ *    promises that the padding frames of the stream inputs are zero.
+ * What is checked: an announcement whose B is not the call's, or with a length outside [1, T]: ADN_ERR_INVALID from that call, before
+ * anything runs.  An announcement against a host mask: compared on the host, ADN_ERR_INVALID.  Against a device mask: compared by the
+ * kernel that walks the mask anyway; a mismatch raises a device word that the next synchronising call (any call returning host
+ * results) reports as ADN_ERR_INVALID.  The zero padding frames behind an announcement: scanned for host arrays always
+ * (ADN_ERR_INVALID from the call), for device arrays under ADN_CHECK_PADDING=1 in the environment (which also makes both device checks
+ * synchronous: the failing call itself returns ADN_ERR_INVALID) -- the tests run with it. */
 int adn_set_batch_lengths(adn_model* m, const int32_t* lengths, int B);
 /* rows of the encoder matrices in the last call: sum(len) + 1 when it ran compacted, 0 when it ran padded */
 int adn_get_compact_rows(const adn_model* m);
+/* lengths read off a host mask (see above): on by default */
+int adn_set_auto_compaction(adn_model* m, int on);
 /* test hook: writes `value` into the current device's LSTM-exchange error word (what a weight-stationary LSTM kernel raises
  * when a workgroup gave up waiting for its partners; 0 clears it).  Lets a test follow the word's way through the gradient
  * tail, the data-parallel all-reduce and the optimiser's skip without provoking a real time-out. */

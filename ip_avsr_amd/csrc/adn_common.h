@@ -166,6 +166,8 @@ int join_hilo(const void* hi, const void* lo, float* dst, size_t n, hipStream_t 
 int compact_build_maps(const int32_t* d_lens, const int32_t* d_prefix, int B, int T, int Z, int32_t* comp_of_full, int32_t* full_of_comp,
                        hipStream_t s);
 int compact_gather_rows16(const void* src, int ld_src, void* dst, int ld_dst, const int32_t* full_of_comp, int Nc, int cols, hipStream_t s);
+// raises `bit` of *flag when a padding row (comp_of_full[r] == Z) of the 16-bit matrix holds anything but zeros
+int compact_check_padding16(const void* src, int ld_src, const int32_t* comp_of_full, int N, int cols, int Z, int* flag, int bit, hipStream_t s);
 int compact_expand_rows(const float* comp, int ld_comp, float* full, int ld_full, const int32_t* comp_of_full, int N, int cols, hipStream_t s);
 size_t compact_sum_ws_floats(int N, int cols);
 int compact_rows_sum(const float* full, int ld_full, float* comp, int ld_comp, const int32_t* comp_of_full, int N, int cols, int Z,
@@ -199,7 +201,9 @@ int dot_all(const float* a, int lda, const float* b, int ldb, int rows, int cols
 // dz = dy * act'(y) in place on dy
 int act_backward(float* dy, int ld_dy, const float* y, int ld_y, int rows, int cols, int act, hipStream_t s);
 // mask (B,T) uint8 batch-major -> (T,B) time-major; total[0] = number of valid frames
-int mask_prepare(const uint8_t* mask_bt, uint8_t* mask_tb, int B, int T, float* total, hipStream_t s);
+// lens / flag (optional): raises `bit` of *flag unless the mask is the prefix mask of lens (mask[b][t] != 0 <=> t < lens[b])
+int mask_prepare(const uint8_t* mask_bt, uint8_t* mask_tb, int B, int T, float* total, hipStream_t s, const int32_t* lens = nullptr,
+                 int* flag = nullptr, int bit = 0);
 // rows [0,B) of dst = vec (broadcast of a (1,H) init vector)
 int broadcast_rows(const float* vec, float* dst, int ld, int rows, int cols, hipStream_t s);
 // h[r][:] = hid, c[r][:] = cell for r < rows (pad columns 0), h16 = optional bf16 copy of h

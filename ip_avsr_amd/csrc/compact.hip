@@ -43,6 +43,21 @@ __global__ __launch_bounds__(256) void gather_rows16_kernel(const u32x4* __restr
     }
 }
 
+// the promise behind an announcement, checked: every 16-byte piece of a PADDING row (comp_of_full[r] == Z) of the 16-bit operand must be
+// zero (sign bits aside); a piece that is not raises bit `bit` of *flag
+__global__ __launch_bounds__(256) void check_padding16_kernel(const u32x4* __restrict__ src, int ld_src16, const int32_t* __restrict__ comp_of_full,
+                                                              int N, int cols16, int Z, int* __restrict__ flag, int bit) {
+    const int64_t total = (int64_t)N * cols16;
+    unsigned bad = 0u;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int r = (int)(e / cols16), q = (int)(e - (int64_t)r * cols16);
+        if (comp_of_full[r] != Z) continue;
+        const u32x4 v = src[(size_t)r * ld_src16 + q];
+        bad |= (v[0] | v[1] | v[2] | v[3]) & 0x7FFF7FFFu;
+    }
+    if (bad) atomicOr(flag, bit);
+}
+
 // full[r][0 .. cols) = comp[comp_of_full[r]][...]
 __global__ __launch_bounds__(256) void expand_rows_kernel(const float* __restrict__ comp, int ld_comp, float* __restrict__ full, int ld_full,
                                                           const int32_t* __restrict__ comp_of_full, int N, int cols) {
@@ -116,6 +131,14 @@ int compact_gather_rows16(const void* src, int ld_src, void* dst, int ld_dst, co
               "compact_gather_rows16: rows of whole 16-byte pieces");
     hipLaunchKernelGGL(gather_rows16_kernel, dim3(grid_for_elems((int64_t)Nc * (cols / 8))), dim3(256), 0, s, static_cast<const u32x4*>(src),
                        ld_src / 8, static_cast<u32x4*>(dst), ld_dst / 8, full_of_comp, Nc, cols / 8);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+int compact_check_padding16(const void* src, int ld_src, const int32_t* comp_of_full, int N, int cols, int Z, int* flag, int bit, hipStream_t s) {
+    ADN_CHECK(cols % 8 == 0 && ld_src % 8 == 0 && ((uintptr_t)src % 16) == 0, ADN_ERR_INVALID, "compact_check_padding16: rows of whole 16-byte pieces");
+    hipLaunchKernelGGL(check_padding16_kernel, dim3(grid_for_elems((int64_t)N * (cols / 8))), dim3(256), 0, s, static_cast<const u32x4*>(src),
+                       ld_src / 8, comp_of_full, N, cols / 8, Z, flag, bit);
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }

@@ -762,16 +762,20 @@ int act_backward(float* dy, int ld_dy, const float* y, int ld_y, int rows, int c
 }
 
 // mask (B,T) -> (T,B); total = number of valid frames (single block: B*T is tiny)
+// (lens: the lengths the caller announced for this batch -- frame compaction, compact.hip -- which the mask must agree with)
 __global__ __launch_bounds__(256) void mask_prepare_kernel(const uint8_t* __restrict__ m_bt, uint8_t* __restrict__ m_tb,
-                                                           int B, int T, float* __restrict__ total) {
+                                                           int B, int T, float* __restrict__ total, const int32_t* __restrict__ lens,
+                                                           int* __restrict__ flag, int bit) {
     __shared__ int part[4];
-    int cnt = 0;
+    int cnt = 0, bad = 0;
     for (int e = threadIdx.x; e < B * T; e += 256) {
         const int t = e / B, b = e % B;
         const uint8_t v = m_bt[(size_t)b * T + t] ? 1 : 0;
         m_tb[e] = v;
         cnt += v;
+        if (lens) bad |= (int)v ^ (t < lens[b] ? 1 : 0);
     }
+    if (bad) atomicOr(flag, bit);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = cnt;
@@ -779,8 +783,8 @@ __global__ __launch_bounds__(256) void mask_prepare_kernel(const uint8_t* __rest
     if (threadIdx.x == 0 && total) *total = (float)(part[0] + part[1] + part[2] + part[3]);
 }
 
-int mask_prepare(const uint8_t* mask_bt, uint8_t* mask_tb, int B, int T, float* total, hipStream_t s) {
-    hipLaunchKernelGGL(mask_prepare_kernel, dim3(1), dim3(256), 0, s, mask_bt, mask_tb, B, T, total);
+int mask_prepare(const uint8_t* mask_bt, uint8_t* mask_tb, int B, int T, float* total, hipStream_t s, const int32_t* lens, int* flag, int bit) {
+    hipLaunchKernelGGL(mask_prepare_kernel, dim3(1), dim3(256), 0, s, mask_bt, mask_tb, B, T, total, flag ? lens : nullptr, flag, bit);
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }

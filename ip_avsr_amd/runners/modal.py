@@ -132,7 +132,8 @@ def parse_options(argv, default_config):
     parser.add_argument('--seed', type=int, default=None, help='seed for initialisers, dropout and minibatch order '
                                                                '(the reference never seeds)')
     parser.add_argument('--precision', default=None, choices=['f32', 'bf16x3', 'mixed', 'bf16'],
-                        help='arithmetic of the model (default f32 = the reference); also ADN_PRECISION')
+                        help='arithmetic of the model (default bf16x3: fp32-grade products on the bf16 matrix pipe, the 1e-4 parity '
+                             'gate against the fp32 reference; f32 = exact fp32 MFMA products, diagnostic, ~5x slower); also ADN_PRECISION')
     args = parser.parse_args(argv)
     options = {'config': args.config or default_config, 'no_plot': bool(args.no_plot), 'seed': args.seed,
                'precision': args.precision}
@@ -806,7 +807,7 @@ def _main(dataset, script, argv=None):
         print(config.items(sec))
     print('preprocessing dataset...')
     from ..modelzoo import _factory
-    _factory.set_default_precision(options.get('precision') or os.environ.get('ADN_PRECISION', 'f32'))
+    _factory.set_default_precision(options.get('precision') or os.environ.get('ADN_PRECISION', _factory.PRODUCT_DEFAULT_PRECISION))
     plan = _PLANS[(dataset, script)](cfg, config, options)
     network, update, train = plan.network, plan.update, plan.train
     split, ys, lens = plan.split, plan.ys, plan.lens

@@ -108,9 +108,9 @@ def parse_options(argv=None):
     parser.add_argument('--seed', type=int, default=None, help='seed for initialisers and minibatch order '
                                                                '(the reference never seeds; required >1 GPU)')
     parser.add_argument('--precision', default=None, choices=['f32', 'bf16x3', 'mixed', 'bf16'],
-                        help='arithmetic of the model (default f32 = the reference; bf16x3 = fp32-grade products on the bf16 '
-                             'matrix pipe, meets the 1e-4 parity gate; mixed = bf16x3 forward pass, bf16 products in back-propagation; '
-                             'bf16 = fastest); also ADN_PRECISION')
+                        help='arithmetic of the model (default bf16x3 = fp32-grade products on the bf16 matrix pipe, meets the '
+                             '1e-4 parity gate against the fp32 reference; f32 = exact fp32 MFMA products, a diagnostic mode ~5x slower; '
+                             'mixed = bf16x3 forward pass, bf16 products in back-propagation; bf16 = fastest); also ADN_PRECISION')
     args = parser.parse_args(argv)
     options = {'config': args.config or 'config/bimodal_meanrm_raw_diff.ini', 'precision': args.precision}
     for key in ('write_results', 'save_best', 'save_plot'):
@@ -566,7 +566,7 @@ def _main(n_streams, argv=None, variant=None):
 
     say('constructing end to end model...')
     from ..modelzoo import _factory
-    _factory.set_default_precision(options.get('precision') or os.environ.get('ADN_PRECISION', 'f32'))
+    _factory.set_default_precision(options.get('precision') or os.environ.get('ADN_PRECISION', _factory.PRODUCT_DEFAULT_PRECISION))
     if avl:
         has_encoder = [config.getboolean(n, 'has_encoder') for n in names]
         network, l_fuse = build_network_avletters(

@@ -10,7 +10,11 @@ and nowhere else at this size -- bench.py itself only asserts a finite loss (VER
   (b) ping-pong GEMMs against the register-staged ones (ADN_GEMM_PP=0): the same;
   (c) against the fp64 ORACLE on a 26-utterance slice (the graph is independent per utterance, so rows 0..25 of the
       520-utterance result must be what the oracle computes for those 26 alone): probabilities and the measured
-      majority-vote agreement, which is reported and asserted."""
+      majority-vote agreement, which is reported and asserted;
+  (d) round 6 -- WHAT bench.py TIMES: the frame-compacted step (lengths announced, the library's own 8192-row threshold, the
+      selection rules as they fall at 13 730 rows) in bf16, bf16x3 and mixed against the padded run of the same parameters,
+      against the 26-utterance fp64-oracle slice, and on bench.py's own zero-bias parameters, where every padding row sits
+      exactly on the rectifier kink."""
 import os
 import subprocess
 import sys
@@ -30,24 +34,41 @@ import bench
 from ip_avsr_amd.model import AdeNetModel
 torch.cuda.set_device(0)
 m = AdeNetModel(bench.build_spec())
-m.set_precision("bf16")
+prec = os.environ.get("GEOM_PRECISION", "bf16")
+m.set_precision(prec)
 bench.synthetic_params(m)
 xs, y, m_d, mask = bench.synthetic_batch(torch, 0, int(os.environ.get("GEOM_BATCH", bench.B_PER_GPU)), torch.device("cuda", 0))
+x26 = [x[:26].cpu().numpy() for x in xs]
+lens = mask.sum(axis=1).astype(np.int32)
+compact = bool(os.environ.get("GEOM_COMPACT"))       # what bench.py does: the lengths announced ahead of every call
+announce = (lambda: m.set_batch_lengths(lens)) if compact else (lambda: None)
+if os.environ.get("GEOM_INPUTS") == "bench":         # ... and the resident form bench.py hands over in this arithmetic
+    if prec == "bf16":
+        xs = [x.to(torch.bfloat16) for x in xs]
+    elif prec in ("bf16x3", "mixed"):
+        from ip_avsr_amd.model import PlaneInput
+        xs = [PlaneInput.split(x) for x in xs]
 if len(sys.argv) > 2:                                # every variant evaluates the SAME parameters
     saved = np.load(sys.argv[2])
     for p in m.params:
         p.set_value(saved["p_" + p.name])
-else:
+elif not os.environ.get("GEOM_FRESH"):              # (GEOM_FRESH: bench.py's own start -- zero biases)
     for _ in range(3):                               # a few steps so that the outputs are not flat
+        announce()
         m.train_step(xs, y, m_d, bench.THETA, 2e-3, want_loss=False)
 params = {"p_" + p.name: p.get_value() for p in m.params}
+announce()
 probs = m.predict(xs, m_d, bench.THETA)
+rows = m.compact_rows()
+announce()
 loss = m.compute_grads(xs, y, m_d, bench.THETA)
+rows = min(rows, m.compact_rows())
 g = m.get_grads_dict()
 keep = ["fc1_s1.W", "fc2_s2.W", "bottleneck_s3.W", "lstm_s1.W_hid_to_cell", "lstm_s3.W_in_to_ingate", "lstm_s2.b_outgate",
         "f_lstm_agg.W_in_to_forgetgate", "b_lstm_agg.W_hid_to_outgate", "f_lstm_agg.hid_init", "softmax.W", "softmax.b"]
-np.savez(sys.argv[1], probs=probs, loss=loss, mask=mask, **{"g_" + k: g[k] for k in keep}, **params,
-         **{"x%%d" %% k: xs[k][:26].cpu().numpy() for k in range(3)})
+keep += [n for n in g if n.endswith(".b") and n.split("_")[0] in ("fc1", "fc2", "fc3", "bottleneck")]     # where the padding rows' sum lands
+np.savez(sys.argv[1], probs=probs, loss=loss, mask=mask, rows=rows, **{"g_" + k: g[k] for k in keep}, **params,
+         **{"x%%d" %% k: x26[k] for k in range(3)})
 ''' % ROOT
 
 
@@ -69,7 +90,24 @@ def runs(tmp_path_factory):
                 streammajor=_run(d, "streammajor", ref, ADN_NO_GROUPED_BACKWARD="1"),
                 norsgroups=_run(d, "norsgroups", ref, ADN_GEMM_NO_RS_GROUPS="1"),
                 b26=_run(d, "b26", ref, GEOM_BATCH="26"),
-                b26_norsgroups=_run(d, "b26_norsgroups", ref, GEOM_BATCH="26", ADN_GEMM_NO_RS_GROUPS="1"))
+                b26_norsgroups=_run(d, "b26_norsgroups", ref, GEOM_BATCH="26", ADN_GEMM_NO_RS_GROUPS="1"),
+                ref_path=ref, dir=d)
+
+
+@pytest.fixture(scope="module")
+def timed_path_runs(runs):
+    """The step bench.py times, per arithmetic: lengths announced (-> frame compaction at the library's own threshold), inputs in the
+    resident form bench.py hands over (bfloat16 / hi-lo planes), ADN_CHECK_PADDING=1 (mask and padding frames verified on the device);
+    each beside the padded run of the same arithmetic and the same parameters (those of runs['default'])."""
+    d, ref = runs["dir"], runs["ref_path"]
+    out = {}
+    for prec in ("bf16", "bf16x3", "mixed"):
+        out[prec + "_compact"] = _run(d, prec + "_compact", ref, GEOM_PRECISION=prec, GEOM_COMPACT="1", GEOM_INPUTS="bench", ADN_CHECK_PADDING="1")
+        out[prec + "_padded"] = runs["default"] if prec == "bf16" else _run(d, prec + "_padded", ref, GEOM_PRECISION=prec)
+    # bench.py's own start (no training step first): zero biases, every padding row exactly on the rectifier kink
+    out["fresh_compact"] = _run(d, "fresh_compact", None, GEOM_FRESH="1", GEOM_COMPACT="1", GEOM_INPUTS="bench")
+    out["fresh_padded"] = _run(d, "fresh_padded", None, GEOM_FRESH="1")
+    return out
 
 
 def _close(a, b, what, p_tol=1e-3, g_tol=3e-2, cos_tol=0.9995, bit_equal_forward=False):
@@ -168,10 +206,65 @@ def test_bf16_gradients_against_the_fp64_oracle_at_the_reference_minibatch(runs)
     assert abs(float(r["loss"]) - loss) <= 1e-3 * abs(loss)
     worst = {}
     for k in r:
-        if k.startswith("g_"):
+        # (the encoder bias gradients are kept for the compacted-vs-padded tests -- sums over 1 040 rows of bf16-rounded terms: 6 % at
+        #  this batch size, outside this test's 5 % band for weight tensors)
+        if k.startswith("g_") and not (k.endswith(".b") and k[2:].split("_")[0] in ("fc1", "fc2", "fc3", "bottleneck")):
             a, b = r[k].astype(np.float64).ravel(), g_ref[k[2:]].ravel()
             worst[k[2:]] = (round(float(np.linalg.norm(a - b) / np.linalg.norm(b)), 5), round(float(a @ b / np.sqrt((a @ a) * (b @ b))), 6))
     print("bf16 vs fp64 oracle gradients at B = 26 (relative L2, cosine):", worst)
     for k, (rel, cos) in worst.items():
         assert rel <= 0.05 and cos >= 0.9987, (k, rel, cos)       # (cosine >= 1 - 0.05^2 / 2; fc1 and the learnt initial states sit
                                                                   #  lowest: 0.99916 / 0.99949, every weight matrix above fc1 >= 0.9998)
+
+
+def _valid_rows(r):
+    return int(r["mask"].sum()) + 1
+
+
+@pytest.mark.parametrize("prec", ["bf16", "bf16x3", "mixed"])
+def test_the_compacted_step_bench_times_equals_the_padded_one(timed_path_runs, prec):
+    """VERDICT r5 next #1a: B = 520 x T = 40, real widths, default ADN_COMPACT_MIN_ROWS, lengths announced: the encoders ran over
+    sum(len) + 1 rows (asserted), and probabilities, loss and the kept gradient tensors (+ every encoder bias gradient: where
+    the padding rows' summed gradient lands) equal the padded run's at the arithmetic's grade."""
+    c, p = timed_path_runs[prec + "_compact"], timed_path_runs[prec + "_padded"]
+    declined = bool(os.environ.get("ADN_NO_COMPACT") or os.environ.get("ADN_STREAMS") or os.environ.get("ADN_BF16_NO_SHADOW") or
+                    (prec != "bf16" and os.environ.get("ADN_X3_NO_PLANES")))
+    assert int(c["rows"]) == (0 if declined else _valid_rows(c)) and int(p["rows"]) == 0
+    if prec == "bf16":       # another row count = other tiles / summation orders, and bf16-resident inputs: one bf16 rounding step
+        _close(c, p, "bf16: compacted (lengths announced, bfloat16-resident) vs padded", p_tol=1e-3, g_tol=2e-2, cos_tol=0.9998)
+    elif prec == "bf16x3":
+        _close(c, p, "bf16x3: compacted (planes resident) vs padded", p_tol=1e-5, g_tol=2e-4, cos_tol=0.999999)
+    else:                    # forward fp32-grade, back-propagation one bf16 product per GEMM
+        _close(c, p, "mixed: compacted (planes resident) vs padded", p_tol=1e-5, g_tol=2e-2, cos_tol=0.9998)
+
+
+def test_the_mixed_forward_pass_is_the_bf16x3_one_on_the_compacted_path(timed_path_runs):
+    a, b = timed_path_runs["mixed_compact"], timed_path_runs["bf16x3_compact"]
+    np.testing.assert_array_equal(a["probs"], b["probs"])
+    assert float(a["loss"]) == float(b["loss"])
+
+
+@pytest.mark.parametrize("prec,p_tol", [("bf16", 1e-3), ("bf16x3", 1e-4), ("mixed", 1e-4)])
+def test_the_compacted_step_against_the_fp64_oracle_slice(timed_path_runs, prec, p_tol):
+    """rows 0..25 of the compacted 520-utterance result against the oracle's forward pass of those 26 utterances alone: the parity
+    gate of north_star (1e-4 on probabilities, identical votes) for bf16x3 / mixed, bf16's own 1e-3 -- ON THE PATH THE BENCH TIMES."""
+    r = timed_path_runs[prec + "_compact"]
+    spec = O.spec_nstream([1200, 1200, 1200])
+    p64 = {k[2:]: v.astype(np.float64) for k, v in r.items() if k.startswith("p_")}
+    mask = r["mask"][:26]
+    xs = [r["x%d" % k].astype(np.float64) for k in range(3)]
+    ref = O.forward(spec, p64, xs, mask, 9)
+    got = r["probs"][:26]
+    err = np.abs(got - ref).max()
+    agree = float((O.majority_vote(ref, mask) == O.majority_vote(got, mask)).mean())
+    print("%s compacted vs fp64 oracle at the bench geometry: max |dp| = %.2e, majority-vote agreement %.3f" % (prec, err, agree))
+    assert err <= p_tol and agree == 1.0
+
+
+def test_zero_bias_start_compacted_equals_padded_at_the_bench_geometry(timed_path_runs):
+    """bench.py's own parameters (zero encoder biases: every padding row at pre-activation exactly 0 in all three rectifier layers):
+    probabilities / loss / gradients of the compacted and the padded computation of the SAME fresh parameters."""
+    c, p = timed_path_runs["fresh_compact"], timed_path_runs["fresh_padded"]
+    assert all(np.all(v == 0) for k, v in p.items() if k.startswith("p_") and k.endswith(".b") and not k.startswith("p_softmax"))
+    assert int(c["rows"]) in (0, _valid_rows(c)) and int(p["rows"]) == 0
+    _close(c, p, "zero-bias start: compacted vs padded", p_tol=1e-3, g_tol=2e-2, cos_tol=0.9998)

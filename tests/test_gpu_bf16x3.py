@@ -530,3 +530,40 @@ def test_skinny_and_fused_plane_kernels_against_the_oracle(torch_cuda, lib, widt
     for k in O.param_names(spec):
         assert np.abs(g[k] - g_ref[k]).max() <= 3e-2 * max(np.abs(g_ref[k]).max(), 1e-3 * gscale), k
     m.close()
+
+
+@pytest.mark.parametrize("steps", [0, 2])
+def test_a_model_created_in_mixed_keeps_the_lo_planes_its_forward_pass_reads(torch_cuda, lib, steps):
+    """the forward pass of the mixed arithmetic is a bf16x3 pass, and at >= 1024 rows its narrow products (the
+    50-unit bottleneck, the 26-way classifier) run on gemm_skinny.hip's kernels, which read the weights' k-contiguous TRANSPOSED
+    planes -- hi AND lo.  refresh_transposed() used to skip every transposed lo plane in this mode ("only back-propagation reads
+    them"): a model created directly in 'mixed' multiplied by zeros there, and after an Adam step by the previous weights' lo
+    parts.  Here: a model created in 'mixed' (never in bf16x3), `steps` train steps, then its predict / encoder activations must
+    equal, bit for bit, those of a bf16x3 model holding the same parameters (2 100 frames: the skinny kernels run)."""
+    from ip_avsr_amd.model import AdeNetModel
+    spec = O.spec_nstream([72, 56], enc_shapes=(160, 128, 50), enc_acts=("rectify", "rectify", "linear"), lstm_size=40, classes=26,
+                          fusion="concat")
+    B, T, theta = 70, 30, 3
+    rng = np.random.default_rng(77)
+    p = O.init_params(spec, rng, np.float32, enc_std=0.1, perturb=0.05)
+    mask = ragged_mask(rng, B, T)
+    inputs = [(rng.normal(size=(B, T, d)) * mask[..., None]).astype(np.float32) for d in (72, 56)]
+    y = np.repeat((np.arange(B) % 26)[:, None], T, axis=1).astype(np.int32)
+    m = AdeNetModel(dict(spec, precision="mixed"))
+    m.set_params_dict(p)
+    for _ in range(steps):
+        m.train_step(inputs, y, mask, theta, 1e-2)
+    now = m.get_params_dict()
+    probs = m.predict(inputs, mask, theta)
+    acts = [m.encoder_activation(s, l, B, T) for s in range(2) for l in range(3)]
+    m.close()
+    r = AdeNetModel(dict(spec, precision="bf16x3"))
+    r.set_params_dict(now)
+    probs_x3 = r.predict(inputs, mask, theta)
+    acts_x3 = [r.encoder_activation(s, l, B, T) for s in range(2) for l in range(3)]
+    r.close()
+    if steps:
+        assert max(np.abs(now[k] - p[k]).max() for k in p) > 1e-3        # (the weights did move: stale planes would show)
+    for a, b in zip(acts, acts_x3):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(probs, probs_x3)

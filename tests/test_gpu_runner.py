@@ -233,3 +233,35 @@ def test_two_stream_runner_variants(tmp_path, variant):
         assert net.get_param("lstm_s1.W_in_to_ingate").shape[0] == 5          # bottleneck features, no deltas
     assert np.isfinite(out["cost_val"]).all() and (min(out["cost_val"]) < out["cost_val"][0] or out["best_cr"] >= 0.5)
     net.close()
+
+
+def test_the_drivers_default_arithmetic_is_bf16x3_on_the_weight_stationary_kernels(tmp_path, monkeypatch):
+    """`python ip_avsr_amd/runners/3stream.py --config ...` WITHOUT --precision / ADN_PRECISION runs the fast
+    fp32-grade arithmetic (bf16x3: modelzoo/_factory.PRODUCT_DEFAULT_PRECISION), i.e. the weight-stationary LSTM kernels -- not the
+    exact-product diagnostic mode's one launch per time step (family counters of include/adenet.h adn_debug_lstm_family_counts:
+    [0] per-step launches, [3] weight-stationary bf16x3)."""
+    import ctypes as C
+    from ip_avsr_amd import _lib
+    from ip_avsr_amd.runners import nstream
+    monkeypatch.delenv("ADN_PRECISION", raising=False)            # (tests/conftest.py asks for f32 for the exact-product tests)
+    root = str(tmp_path)
+    make_dataset(root, 3)
+    ini = "".join(INI.format(k=k, root=root, reorder=(k == 1), diff=(k == 2)) for k in range(1, 4))
+    ini += TAIL.format(root=root, fusion="concat", dropout=False)
+    cfg = os.path.join(root, "cfg.ini")
+    open(cfg, "w").write(ini)
+    lib = _lib.load()
+
+    def families():
+        f, b = (C.c_int64 * 4)(), (C.c_int64 * 4)()
+        lib.adn_debug_lstm_family_counts(f); lib.adn_debug_lstm_backward_family_counts(b)
+        return np.array(list(f) + list(b))
+
+    before = families()
+    out = nstream.main(3, ["--config", cfg, "--seed", "7"])
+    ran = families() - before
+    assert out["network"].spec["precision"] == "bf16x3"
+    out["network"].close()
+    if not any(os.environ.get(k) for k in ("ADN_LSTM_NO_CLUSTER", "ADN_LSTM_NO_X3_CLUSTER", "ADN_LSTM_NO_X3_CLUSTER_BWD", "ADN_X3_NO_PLANES", "ADN_LSTM_CUS")):
+        assert ran[3] > 0 and ran[7] > 0 and ran[0] == 0 and ran[4] == 0, ran
+    assert np.isfinite(out["cost_val"]).all()
