@@ -292,6 +292,15 @@ int adn_get_deterministic(void);
 int adn_set_batch_lengths(adn_model* m, const int32_t* lengths, int B);
 /* rows of the encoder matrices in the last call: sum(len) + 1 when it ran compacted, 0 when it ran padded */
 int adn_get_compact_rows(const adn_model* m);
+/* The derivative the encoders' rectifiers take AT a pre-activation of exactly zero: 0 (default) or 0.5.  Lasagne's rectify is
+ * Theano's 0.5 (x + |x|), whose gradient at x == 0 is 0.5 (d|x|/dx = sgn(x), sgn(0) = 0).  That is not a measure-zero case for this
+ * model: the reference pads with ZERO frames (utils/datagen.py:129-142), so with zero encoder biases (SURVEY 8d's synthetic
+ * parameters; not DBN-pretrained ones) every padding row has pre-activation exactly 0 in every rectifier layer and the reference
+ * back-propagates half of the delta layer's leakage into b1..b3 there.  0.5 reproduces that: the forward pass marks an exactly-zero
+ * pre-activation (the activation leaves as -0.0f, equal to 0 in all arithmetic) and the masks read the mark.  The specialised
+ * kernels (persistent ping-pong, skinny) decline the marked rectifier: the encoders then run on the register-staged / fp32 kernels
+ * -- a parity switch, not a throughput mode. */
+int adn_set_relu_grad_at_zero(adn_model* m, float value);
 /* lengths read off a host mask (see above): on by default */
 int adn_set_auto_compaction(adn_model* m, int on);
 /* test hook: writes `value` into the current device's LSTM-exchange error word (what a weight-stationary LSTM kernel raises

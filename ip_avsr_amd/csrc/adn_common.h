@@ -158,6 +158,12 @@ void col_sum_batch_add(ColSumBatch& b, const float* in, int ld, int rows, int co
 int col_sum_batch(ColSumBatch& b, hipStream_t s);          // launches (if any item is pending) and clears the batch
 
 // the same for a table of matrices in ONE launch (items: device array; block_end[k] = running total of 32x32 tiles)
+// Internal activation code (never in an adn_config): the rectifier whose derivative AT a pre-activation of exactly zero is 0.5 --
+// Theano's rectify is 0.5 (x + |x|), d|x|/dx = sgn(x), sgn(0) = 0 -- instead of this build's default 0 (adn_set_relu_grad_at_zero).
+// Forward: a zero pre-activation leaves as -0.0f (a value equal to 0 in every product and sum downstream, and in the bf16 copy /
+// the hi plane: bf16(-0.0f) = 0x8000), anything negative as +0.0f; backward: the mask reads y > 0 ? 1 : (y is -0.0 ? 0.5 : 0).
+// Only the generic epilogues know the code (act_apply / act_grad_from_output): the specialised kernels decline it.
+constexpr int kActRectifyHalf = 64;
 struct TransposeItem { const float* W; void* out; int rows, cols, ld, ldT, block_end; };
 int transpose_to_bf16_batch(const TransposeItem* dev_items, int n, int total_blocks, hipStream_t s, int lo_part = 0);
 int split_hilo(const float* src, void* hi, void* lo, size_t n, hipStream_t s);   // fp32 -> the bf16x3 mode's two planes

@@ -740,6 +740,7 @@ __device__ __forceinline__ float act_grad_y(int act, float y) {
         case ADN_ACT_VERY_LEAKY_RECTIFY: return y > 0.f ? 1.f : (1.f / 3.f);
         case ADN_ACT_SCALED_TANH: { const float t = y * (1.f / 2.4f); return 1.2f * (1.f - t * t); }
         case ADN_ACT_SCALED_TANH_LECUN: { const float t = y * (1.f / 1.7159f); return (2.f / 3.f) * 1.7159f * (1.f - t * t); }
+        case kActRectifyHalf: return y > 0.f ? 1.f : (__float_as_uint(y) == 0x80000000u ? 0.5f : 0.f);      // (adn_common.h)
         default: return 1.f;
     }
 }

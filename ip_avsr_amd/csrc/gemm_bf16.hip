@@ -1840,8 +1840,12 @@ __global__ __launch_bounds__(256) void join_hilo_kernel(const __bf16* __restrict
         bf16x8 l;
         if (lo) l = reinterpret_cast<const bf16x8*>(lo)[i];
         else for (int j = 0; j < 8; ++j) l[j] = (__bf16)0.f;      // (a tensor that only ever had its hi plane written)
-        reinterpret_cast<float4*>(dst)[2 * i] = make_float4((float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]);
-        reinterpret_cast<float4*>(dst)[2 * i + 1] = make_float4((float)h[4] + (float)l[4], (float)h[5] + (float)l[5], (float)h[6] + (float)l[6], (float)h[7] + (float)l[7]);
+        // (hi + lo, except that hi = -0.0 stays -0.0 -- (-0) + (+0) is +0, and -0.0 is the rectifier's kink mark: adn_common.h)
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float lf = (float)l[j]; o[j] = lf == 0.f ? (float)h[j] : (float)h[j] + lf; }
+        reinterpret_cast<float4*>(dst)[2 * i] = make_float4(o[0], o[1], o[2], o[3]);
+        reinterpret_cast<float4*>(dst)[2 * i + 1] = make_float4(o[4], o[5], o[6], o[7]);
     }
 }
 int join_hilo(const void* hi, const void* lo, float* dst, size_t n, hipStream_t s) {

@@ -51,6 +51,7 @@ __device__ __forceinline__ float act_apply(int act, float v) {
         case ADN_ACT_VERY_LEAKY_RECTIFY: return v > 0.f ? v : (1.f / 3.f) * v;
         case ADN_ACT_SCALED_TANH: return 2.4f * tanhf(0.5f * v);
         case ADN_ACT_SCALED_TANH_LECUN: return 1.7159f * tanhf((2.f / 3.f) * v);
+        case kActRectifyHalf: return v > 0.f ? v : (v == 0.f ? -0.f : 0.f);       // (the kink leaves as -0.0: adn_common.h)
         default: return v;
     }
 }
@@ -64,6 +65,7 @@ __device__ __forceinline__ float act_grad_from_output(int act, float y) {
         case ADN_ACT_VERY_LEAKY_RECTIFY: return y > 0.f ? 1.f : (1.f / 3.f);
         case ADN_ACT_SCALED_TANH: { const float t = y * (1.f / 2.4f); return 1.2f * (1.f - t * t); }
         case ADN_ACT_SCALED_TANH_LECUN: { const float t = y * (1.f / 1.7159f); return (2.f / 3.f) * 1.7159f * (1.f - t * t); }
+        case kActRectifyHalf: return y > 0.f ? 1.f : (__float_as_uint(y) == 0x80000000u ? 0.5f : 0.f);
         default: return 1.f;
     }
 }

@@ -242,6 +242,9 @@ struct adn_model {
     std::vector<int32_t> call_lens;          // the lengths of the call in flight: the announcement, or read off a host mask
     bool call_lens_auto = false;             // ... read off the mask: nobody promised zero padding frames, the device looks first
     bool auto_compact = true;                // adn_set_auto_compaction
+    // adn_set_relu_grad_at_zero(0.5): the encoders' rectifiers run as kActRectifyHalf (adn_common.h) -- the generic epilogues
+    bool relu0_half = false;
+    int act_code(int act) const { return (relu0_half && act == ADN_ACT_RECTIFY) ? kActRectifyHalf : act; }
     struct PinSlot { int32_t* host = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; };
     PinSlot pin[4]; int pin_next = 0;        // pinned staging of lengths + prefix sums (a ring: the copies are asynchronous)
     int32_t *d_lens = nullptr, *d_prefix = nullptr, *comp_of_full = nullptr, *full_of_comp = nullptr;
@@ -1520,7 +1523,7 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
         g.layout = GEMM_NN; g.M = m->compact ? m->Nc : (int)N; g.N = st.cfg.enc_units[l]; g.K = st.enc_in[l];      // (compact.hip: valid frames + the zero row)
         g.A = l ? st.act[l - 1] : st.x; g.lda = l ? ld_of(st.enc_in[l]) : st.ldx;
         g.B = m->P(st.encW[l]); g.ldb = ld_of(g.N);
-        g.C = st.act[l]; g.ldc = ld_of(g.N); g.bias = m->P(st.encb[l]); g.act = st.cfg.enc_act[l];
+        g.C = st.act[l]; g.ldc = ld_of(g.N); g.bias = m->P(st.encb[l]); g.act = m->act_code(st.cfg.enc_act[l]);
         g.no_split = 1;                                          // forward pass: reproducible bits
         mgemm_prepare(m, g, /*lean=*/l + 1 < st.cfg.n_enc);      // the delta layer reads the last one in fp32
         // (bf16x3: a narrow next layer -- the 50-unit bottleneck -- reads the planes too since round 5 (gemm_skinny.hip); with those
@@ -2145,7 +2148,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
                                        m->training ? st.bn_save_inv_std : m->P(st.bn_inv_std), m->training ? 1 : 0,
                                        m->G(st.bn_gamma), m->G(st.bn_beta), st.bn_ws, m->stream, dE16));
         if (!last_linear)
-            ADN_TRY(act_backward(st.dE, ldE, st.act[L - 1], ldE, N, st.enc_out, st.cfg.enc_act[L - 1], m->stream));
+            ADN_TRY(act_backward(st.dE, ldE, st.act[L - 1], ldE, N, st.enc_out, m->act_code(st.cfg.enc_act[L - 1]), m->stream));
         if (!dE16) ADN_TRY(refresh(m, st.dE, (size_t)N * ldE));
         w.dZ = st.dE; w.lddz = ldE; w.bias_done = 0; w.active = true;
         // this stream's "top" bucket (BatchNorm, LSTMs) is final: its last writers are the launches above
@@ -2195,7 +2198,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             GemmArgs& gx = gxs[q];
             gx.layout = GEMM_NT; gx.M = Ne; gx.N = in_w; gx.K = out_w; gx.A = w.dZ; gx.lda = w.lddz;
             gx.B = m->P(st.encW[l]); gx.ldb = ld_of(out_w); gx.C = dst; gx.ldc = st.ping_ld;
-            gx.Y = st.act[l - 1]; gx.ldy = ld_of(in_w); gx.act_grad = st.cfg.enc_act[l - 1];
+            gx.Y = st.act[l - 1]; gx.ldy = ld_of(in_w); gx.act_grad = m->act_code(st.cfg.enc_act[l - 1]);
             gx.colsum = m->G(st.encb[l - 1]); gx.colsum_done = &w.bias_done;     // db_{l-1} rides on this GEMM
             gx.colsum_ws = st.colsum_ws + (size_t)l * st.colsum_ws_floats; gx.colsum_ws_floats = st.colsum_ws_floats;
             gx.colsum_batch = &bias_sums;
@@ -2496,6 +2499,13 @@ int adn_set_batch_lengths(adn_model* m, const int32_t* lengths, int B) {
 }
 
 int adn_get_compact_rows(const adn_model* m) { return (m && m->compact) ? m->Nc : 0; }
+
+int adn_set_relu_grad_at_zero(adn_model* m, float value) {
+    ADN_CHECK(m, ADN_ERR_INVALID, "null model");
+    ADN_CHECK(value == 0.f || value == 0.5f, ADN_ERR_INVALID, "adn_set_relu_grad_at_zero: 0 (this build's default) or 0.5 (Theano's 0.5 (x + |x|))");
+    m->relu0_half = value == 0.5f;
+    return ADN_OK;
+}
 
 int adn_set_auto_compaction(adn_model* m, int on) {
     ADN_CHECK(m, ADN_ERR_INVALID, "null model");

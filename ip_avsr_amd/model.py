@@ -159,6 +159,8 @@ class AdeNetModel(object):
         self._front = {}                      # stream index -> (conv encoder, frame width): frozen feature extractors
         if stream is not None:
             self.set_stream(stream)
+        if spec.get("relu_grad_at_zero"):     # (the same key the oracle reads: 0.5 = Theano's rectifier at exactly zero)
+            self.set_relu_grad_at_zero(spec["relu_grad_at_zero"])
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
@@ -199,6 +201,12 @@ class AdeNetModel(object):
         """Rows of the encoder matrices in the last call: sum(len) + 1 when it ran compacted (set_batch_lengths, or lengths read
         off a host mask), else 0."""
         return int(self._lib.adn_get_compact_rows(self._handle))
+
+    def set_relu_grad_at_zero(self, value):
+        """0 (default) or 0.5: the rectifier's derivative at a pre-activation of exactly zero (Theano's 0.5 (x + |x|) gives 0.5 --
+        every zero-padded frame of a zero-bias encoder sits there; include/adenet.h).  A parity switch: the encoders leave the
+        specialised kernels."""
+        _lib.check(self._lib.adn_set_relu_grad_at_zero(self._handle, float(value)))
 
     def set_auto_compaction(self, on):
         """Host arrays: whether the lengths are read off a (prefix) mask so that the call can run compacted without an announcement

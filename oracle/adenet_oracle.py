@@ -49,15 +49,24 @@ def act_fwd(name, z):
     raise ValueError("unsupported nonlinearity %r" % (name,))
 
 
-def act_bwd(name, y, dy):
+def act_bwd(name, y, dy, kink=None, at_zero=0.0):
     """dL/dz from the *output* y (every supported act is invertible enough).
 
-    relu'(0) is taken as 0 (Theano's 0.5*(x+|x|) form gives 0.5 at exactly 0; a
-    measure-zero divergence documented in DESIGN.md)."""
+    The rectifier at a pre-activation of EXACTLY zero.  Lasagne's ``rectify`` is Theano's ``0.5 * (x + abs(x))`` [upstream], and
+    Theano differentiates ``abs`` as ``sgn(x)`` with ``sgn(0) = 0``: the reference's relu'(0) is 0.5.  That is NOT a measure-zero
+    case for this model: the minibatch generators pad with zero frames (utils/datagen.py:129-142), so with zero encoder biases
+    (SURVEY.md 8d's synthetic parameters) every padding row has pre-activation exactly 0 in every rectifier layer, and the delta
+    layer leaks gradient into those rows (App. E-2) -- the reference sends half of it on into the biases below.  With DBN-pretrained
+    (non-zero) biases nothing sits on the kink.  ``at_zero`` selects the convention: 0.0 (this build's default: the mask is
+    ``y > 0``) or 0.5 (Theano's); ``kink`` is the boolean mask of the exactly-zero pre-activations kept by ``forward``
+    (spec["relu_grad_at_zero"]; the HIP path: adn_set_relu_grad_at_zero)."""
     if name in ("linear", "identity"):
         return dy
     if name == "rectify":
-        return dy * (y > 0)
+        g = (y > 0).astype(dy.dtype)
+        if at_zero and kink is not None:
+            g = g + dy.dtype.type(at_zero) * kink
+        return dy * g
     if name == "sigmoid":
         return dy * y * (1 - y)
     if name == "tanh":
@@ -439,11 +448,13 @@ def forward(spec, p, inputs, mask, theta, want_cache=False, dropout=None, traini
     S_ = len(spec["streams"])
     aux_inputs = list(inputs[S_:])
     for s, x in zip(spec["streams"], inputs[:S_]):
-        sc = dict(acts=[x.reshape(B * T, -1)])
+        sc = dict(acts=[x.reshape(B * T, -1)], kinks=[])
         a = sc["acts"][0]
         for n, act in zip(s["enc_names"], s["enc_acts"]):   # modelzoo/pretrained_encoder.py:4-9
-            a = act_fwd(act, a @ p[n + ".W"] + p[n + ".b"])
+            z = a @ p[n + ".W"] + p[n + ".b"]
+            a = act_fwd(act, z)
             sc["acts"].append(a)
+            sc["kinks"].append((z == 0) if act == "rectify" else None)       # (act_bwd: relu'(0))
         if s.get("batchnorm"):                               # BatchNormLayer on the (B*T, E) encoder output (adenet_v1.py:82)
             bn = s["batchnorm"]
             if training:
@@ -592,7 +603,7 @@ def loss_and_grads(spec, p, inputs, targets, mask, theta, total_frames=None, dro
                 da = gi * da
         for li in range(len(s["enc_names"]) - 1, -1, -1):
             n, act = s["enc_names"][li], s["enc_acts"][li]
-            dzl = act_bwd(act, sc["acts"][li + 1], da)
+            dzl = act_bwd(act, sc["acts"][li + 1], da, sc["kinks"][li], spec.get("relu_grad_at_zero", 0.0))
             g[n + ".W"] = sc["acts"][li].T @ dzl
             g[n + ".b"] = dzl.sum(0)
             da = dzl @ p[n + ".W"].T

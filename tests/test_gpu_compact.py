@@ -387,3 +387,57 @@ def test_a_device_mask_that_disagrees_is_reported_at_the_next_synchronising_call
     m.predict(dev, dmask, theta)                                          # the word was cleared with the report
     assert m.compact_rows() == int(lens.sum()) + 1
     m.close()
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "bf16"])
+def test_relu_grad_at_zero_one_half_matches_the_oracle_where_the_padding_rows_sit_on_the_kink(torch_cuda, prec):
+    """adn_set_relu_grad_at_zero(0.5) (include/adenet.h) against oracle spec['relu_grad_at_zero'] = 0.5 (Theano's rectifier is
+    0.5 (x + |x|): derivative 0.5 at exactly zero).  Zero encoder biases + zero padding frames put EVERY padding row on the kink in
+    all rectifier layers; the delta layer leaks gradient into those rows (window 9 reaches into the padding), so the two conventions
+    give different bias gradients -- asserted -- and the HIP path must follow the oracle under either: padded, and compacted (the one
+    zero row then carries the summed half-gradients)."""
+    from ip_avsr_amd.model import AdeNetModel
+    dims = (72, 56)
+    spec = O.spec_nstream(list(dims), enc_shapes=(160, 128, 50), enc_acts=("rectify", "rectify", "linear"), lstm_size=40, classes=26,
+                          fusion="concat")
+    B, T, theta = 70, 30, 9
+    p, lens, mask, xs, y = _data(spec, B, T, dims, 8, perturb=0.0)
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    x64 = [x.astype(np.float64) for x in xs]
+    ref = {}
+    for k0 in (0.0, 0.5):
+        ref[k0] = O.loss_and_grads(dict(spec, relu_grad_at_zero=k0), p64, x64, y, mask, theta)
+    assert ref[0.0][0] == ref[0.5][0]                              # the forward pass does not know the convention
+    bias_names = [k for k in O.param_names(spec) if k.endswith(".b") and k.split("_")[0] in ("fc1", "fc2")]
+    moved = max(np.abs(ref[0.5][1][k] - ref[0.0][1][k]).max() / np.abs(ref[0.5][1][k]).max() for k in bias_names)
+    print("relu'(0) = 0.5 against 0: the fc1 / fc2 bias gradients move by %.2f of their scale" % moved)
+    assert moved > 0.05, moved                                     # not measure zero: the conventions differ by a visible share
+    gscale = max(np.abs(v).max() for v in ref[0.5][1].values())
+    gtol = {"f32": 1e-4, "bf16x3": 2e-4, "bf16": 3e-2}[prec]
+    for k0 in (0.0, 0.5):
+        m = AdeNetModel(dict(spec, precision=prec, relu_grad_at_zero=k0))
+        m.set_auto_compaction(False)
+        m.set_params_dict(p)
+        for mode in ("padded", "compact"):
+            if mode == "compact":
+                if prec == "f32" or _declined(prec):
+                    continue
+                m.set_batch_lengths(lens)
+            loss = m.compute_grads(xs, y, mask, theta)
+            assert (m.compact_rows() > 0) == (mode == "compact")
+            g = m.get_grads_dict()
+            assert abs(loss - ref[k0][0]) <= (1e-5 if prec != "bf16" else 2e-3) * abs(ref[k0][0])
+            worst = 0.0
+            other = ref[0.5 if k0 == 0.0 else 0.0][1]
+            for k in O.param_names(spec):
+                e = np.abs(g[k] - ref[k0][1][k]).max() / max(np.abs(ref[k0][1][k]).max(), 1e-3 * gscale)
+                worst = max(worst, e)
+                # (bf16 against fp64 is a 20 %-of-scale comparison on the deepest tensors of this small graph -- tests/test_gpu_parity.py
+                #  holds that arithmetic to its own bands; here it only has to be on the right side of the kink, below)
+                assert e <= gtol or prec == "bf16", (prec, k0, mode, k, e)
+            # ... and it is THIS convention's gradient, not the other one's: the bias gradients under the rectifiers
+            for k in bias_names:
+                own = np.linalg.norm(g[k] - ref[k0][1][k]); far = np.linalg.norm(g[k] - other[k])
+                assert own < (1.0 if prec == "bf16" else 0.5) * far, (prec, k0, mode, k, own, far)
+            print("relu'(0) = %.1f, %s, %s: worst gradient %.2e of its scale against the fp64 oracle" % (k0, prec, mode, worst))
+        m.close()
