@@ -652,6 +652,13 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
             #  is repeated there)
             if prec == "mixed":
                 out["config"]["mixed_ms"] = acc["ms_per_step"]; out["config"]["mixed_seq_s"] = acc["value"]
+                # north_star's three gates -- encoder activations / probabilities within 1e-4 of the fp32 reference path, exact top-1,
+                # accuracy within +-0.5 % -- are met by this arithmetic too: its forward pass IS the bf16x3 one (bit-identical, asserted:
+                # tests/test_gpu_bf16x3.py, tests/test_gpu_bench_geometry.py on the compacted path), and over eight seeds its mean class
+                # rate sits with bf16x3's (+0.0010 +- 0.0014 of the f32 arm's, tests/test_gpu_accuracy.py).  What it does NOT have is
+                # parity-grade GRADIENTS (7.9e-3 of scale against the fp64 oracle): `parity_grade` stays the bf16x3 figure.
+                out["config"]["north_star_grade_mode"] = "mixed"
+                out["config"]["north_star_grade_ms"] = acc["ms_per_step"]; out["config"]["north_star_grade_seq_s"] = acc["value"]
                 if "roofline" in acc and "roofline" in out:
                     out["roofline"]["gemm_frac_mixed"] = acc["roofline"]["frac"]
             elif prec == "f32":
