@@ -121,6 +121,7 @@ struct GemmArgs {
     // B as a k-contiguous [N][K] bf16 matrix (hi / lo planes), leading dimension ldbkc: for an NN problem the transposed copy of the
     // weights the model keeps, for an NT problem B itself.  The skinny kernels (gemm_skinny.hip) read B in this form
     const void* Bkc16 = nullptr; const void* Bkc16lo = nullptr; int ldbkc = 0;
+    int no_planes = 0;                   // model.hip: nobody reads this result's hi / lo planes (the encoder's output): do not make them
     int hi_product = 0;                // ADN_PRECISION_MIXED, back-propagation: ONE bf16 product over the hi planes (A16 / B16 given,
                                        // no lo planes, precision = bf16) whose result is still offered as planes (C16 / C16lo, lean_ok)
     int hi_result = 0;                 // ... and whose readers take the hi plane alone: C16lo is NOT written, planes_done / lean_ok go by
@@ -174,10 +175,11 @@ int compact_build_maps(const int32_t* d_lens, const int32_t* d_prefix, int B, in
 int compact_gather_rows16(const void* src, int ld_src, void* dst, int ld_dst, const int32_t* full_of_comp, int Nc, int cols, hipStream_t s);
 // raises `bit` of *flag when a padding row (comp_of_full[r] == Z) of the 16-bit matrix holds anything but zeros
 int compact_check_padding16(const void* src, int ld_src, const int32_t* comp_of_full, int N, int cols, int Z, int* flag, int bit, hipStream_t s);
-int compact_expand_rows(const float* comp, int ld_comp, float* full, int ld_full, const int32_t* comp_of_full, int N, int cols, hipStream_t s);
-size_t compact_sum_ws_floats(int N, int cols);
-int compact_rows_sum(const float* full, int ld_full, float* comp, int ld_comp, const int32_t* comp_of_full, int N, int cols, int Z,
-                     float* ws, hipStream_t s);
+// the zero-input row's gradient from the per-utterance padding sums the delta layer's backward kernel left (DeltaJob::pad_partial):
+// comp[zrow][0 .. ld) (+ its 16-bit copies), up to kMaxPadFinishJobs rows per launch
+constexpr int kMaxPadFinishJobs = 4;
+struct PadFinishJob { const float* partial; int nparts; float* comp; int ld; int cols; int zrow; void* c16; void* c16lo; };
+int compact_pad_finish(const PadFinishJob* jobs, int n, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
 // element-wise / HBM-bound kernels (elementwise.hip)
@@ -216,7 +218,13 @@ int broadcast_rows(const float* vec, float* dst, int ld, int rows, int cols, hip
 int lstm_init_state_rows(const float* hid, const float* cell, float* h, float* c, void* h16, int ld, int rows, int cols, hipStream_t s);
 // housekeeping of several same-shape tensors in ONE launch (the S input streams' delta layers, the LSTMs' initial states)
 constexpr int kMaxDeltaJobs = 4, kMaxInitJobs = 8;
-struct DeltaJob { const float* src; int ld_src; float* dst; int ld_dst; int F; int append; void* dst16; };
+struct DeltaJob {
+    const float* src; int ld_src; float* dst; int ld_dst; int F; int append; void* dst16;
+    void* dst16lo = nullptr;              // bf16x3 / mixed: dst16 is the hi plane of the result, this its lo plane
+    // frame compaction (compact.hip): the batch-major side is the compact matrix -- frame (b, t) in row row_map[b T + t].  Backward:
+    // rows mapped to zrow (the padding frames) are summed per utterance into pad_partial[b][F] instead of stored
+    const int32_t* row_map = nullptr; int zrow = -1; float* pad_partial = nullptr;
+};
 struct LstmInitJob { const float* hid; const float* cell; float* h; float* c; void* h16; };
 int delta_forward_batch(const DeltaJob* jobs, int n, int B, int T, int theta, hipStream_t s);    // dst = [x | dx | ddx] (append) or a copy
 int delta_backward_batch(const DeltaJob* jobs, int n, int B, int T, int theta, hipStream_t s);   // src = d[x | dx | ddx], dst = dx

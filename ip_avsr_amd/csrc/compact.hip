@@ -5,7 +5,10 @@
 // (dZ_{l-1} = act'(a_{l-1}(0)) * (dZ_l W_l^T) is linear in dZ_l for a fixed mask).  So the encoder GEMMs run over
 //     Nc = sum(len) + 1 rows:  the valid frames, utterance after utterance, and ONE zero-input row Z = Nc - 1
 // instead of B T (65 % of them at lengths ~ U[12, 40]).  What stays padded: everything from the delta layer up (time-major, B rows per
-// step), which reads the encoder output through expand_rows() and hands its gradient back through compact_rows_sum().
+// step).  The delta layer is where the two layouts meet, and its kernels do the conversion on the way (elementwise.hip, round 6): the
+// forward kernel reads the compact encoder output through comp_of_full (every padding frame sees row Z), the backward kernel stores
+// a valid frame's gradient at its compact row and sums the padding frames' per utterance; compact_pad_finish() adds those sums up
+// into row Z.  (Round 5 ran separate expand / compact-and-sum passes over B T rows: 112 us of launches per step.)
 //   full row  r = b T + t  ->  compact row  comp_of_full[r] = prefix[b] + t (t < len[b]) | Z
 //   compact row c < Z      ->  full row     full_of_comp[c];   full_of_comp[Z] = -1
 #include "adn_common.h"
@@ -58,59 +61,34 @@ __global__ __launch_bounds__(256) void check_padding16_kernel(const u32x4* __res
     if (bad) atomicOr(flag, bit);
 }
 
-// full[r][0 .. cols) = comp[comp_of_full[r]][...]
-__global__ __launch_bounds__(256) void expand_rows_kernel(const float* __restrict__ comp, int ld_comp, float* __restrict__ full, int ld_full,
-                                                          const int32_t* __restrict__ comp_of_full, int N, int cols) {
-    const int64_t total = (int64_t)N * cols;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int r = (int)(e / cols), q = (int)(e - (int64_t)r * cols);
-        full[(size_t)r * ld_full + q] = comp[(size_t)comp_of_full[r] * ld_comp + q];
-    }
-}
-
-// comp[c] = full[full_of_comp[c]] for the valid rows; the padding rows of full are summed -- in row order, per block of kSumRows full
-// rows into partial[block], then by compact_sum_finish_kernel in block order: one fixed order, no atomics -- into comp[Z]
-constexpr int kSumRows = 256;
-__global__ __launch_bounds__(256) void compact_rows_sum_kernel(const float* __restrict__ full, int ld_full, float* __restrict__ comp, int ld_comp,
-                                                               const int32_t* __restrict__ comp_of_full, int N, int cols, int Z,
-                                                               float* __restrict__ partial) {
-    // blockIdx.x = block of kSumRows full rows, blockIdx.y = 32-column chunk; thread = (row lane ts of 8, column fl)
-    __shared__ float red[8][32];
-    const int fl = threadIdx.x & 31, ts = threadIdx.x >> 5;
-    const int q = blockIdx.y * 32 + fl;
-    const int r0 = blockIdx.x * kSumRows, r1 = min(N, r0 + kSumRows);
-    float acc = 0.f;
-    if (q < cols)
-        for (int r = r0 + ts; r < r1; r += 8) {
-            const float v = full[(size_t)r * ld_full + q];
-            const int c = comp_of_full[r];
-            if (c == Z) acc += v; else comp[(size_t)c * ld_comp + q] = v;
-        }
-    red[ts][fl] = acc;
-    __syncthreads();
-    if (ts == 0 && q < cols) {
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s += red[k][fl];
-        partial[(size_t)blockIdx.x * cols + q] = s;
-    }
-}
-// comp[Z][q] = sum over the blocks' partial sums, in one fixed order: lane ts adds blocks ts, ts + 8, ... and the eight lane sums are
-// added in lane order (blockIdx.x = 32-column chunk of the row, pad columns included: they become zero)
-__global__ __launch_bounds__(256) void compact_sum_finish_kernel(const float* __restrict__ partial, int nblocks, float* __restrict__ comp, int ld_comp,
-                                                                 int cols, int ld_cols, int Z) {
-    __shared__ float red[8][32];
-    const int fl = threadIdx.x & 31, ts = threadIdx.x >> 5;
+// comp[Z][q] = sum over the utterances' padding sums (pad[b][cols], written by the delta layer's backward kernel: elementwise.hip
+// delta_bwd_body), in one fixed order: lane ts adds utterances ts, ts + 32, ... and the 32 lane sums are added in lane order; the
+// row's pad columns become zero; the row's 16-bit copies (bf16 copy / hi + lo planes) are written with it.  blockIdx.y = job.
+struct PadFinishTable { PadFinishJob j[kMaxPadFinishJobs]; };
+__global__ __launch_bounds__(1024) void compact_pad_finish_kernel(const PadFinishTable tab) {
+    __shared__ float red[32][33];
+    PadFinishJob j = tab.j[0];
+    if (blockIdx.y == 1) j = tab.j[1];
+    if (blockIdx.y == 2) j = tab.j[2];
+    if (blockIdx.y == 3) j = tab.j[3];
+    const int fl = threadIdx.x & 31, ts = threadIdx.x >> 5;        // 32 column lanes x 32 utterance lanes
     const int q = blockIdx.x * 32 + fl;
+    if ((int)blockIdx.x * 32 >= j.ld) return;
     float s = 0.f;
-    if (q < cols) for (int k = ts; k < nblocks; k += 8) s += partial[(size_t)k * cols + q];
+    if (q < j.cols) for (int k = ts; k < j.nparts; k += 32) s += j.partial[(size_t)k * j.cols + q];
     red[ts][fl] = s;
     __syncthreads();
-    if (ts == 0 && q < ld_cols) {
+    if (ts == 0 && q < j.ld) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[k][fl];
-        comp[(size_t)Z * ld_comp + q] = t;
+        for (int k = 0; k < 32; ++k) t += red[k][fl];
+        const size_t o = (size_t)j.zrow * j.ld + q;
+        j.comp[o] = t;
+        if (j.c16) {
+            const __bf16 h = (__bf16)t;
+            reinterpret_cast<__bf16*>(j.c16)[o] = h;
+            if (j.c16lo) reinterpret_cast<__bf16*>(j.c16lo)[o] = (__bf16)(t - (float)h);
+        }
     }
 }
 
@@ -143,21 +121,14 @@ int compact_check_padding16(const void* src, int ld_src, const int32_t* comp_of_
     return ADN_OK;
 }
 
-int compact_expand_rows(const float* comp, int ld_comp, float* full, int ld_full, const int32_t* comp_of_full, int N, int cols, hipStream_t s) {
-    hipLaunchKernelGGL(expand_rows_kernel, dim3(grid_for_elems((int64_t)N * cols)), dim3(256), 0, s, comp, ld_comp, full, ld_full, comp_of_full,
-                       N, cols);
-    ADN_HIP_CHECK(hipGetLastError());
-    return ADN_OK;
-}
-
-size_t compact_sum_ws_floats(int N, int cols) { return (size_t)cdiv(N, kSumRows) * cols; }
-
-int compact_rows_sum(const float* full, int ld_full, float* comp, int ld_comp, const int32_t* comp_of_full, int N, int cols, int Z,
-                     float* ws, hipStream_t s) {
-    const int nblocks = cdiv(N, kSumRows);
-    hipLaunchKernelGGL(compact_rows_sum_kernel, dim3(nblocks, cdiv(cols, 32)), dim3(256), 0, s, full, ld_full, comp, ld_comp, comp_of_full, N,
-                       cols, Z, ws);
-    hipLaunchKernelGGL(compact_sum_finish_kernel, dim3(cdiv(ld_comp, 32)), dim3(256), 0, s, ws, nblocks, comp, ld_comp, cols, ld_comp, Z);
+int compact_pad_finish(const PadFinishJob* jobs, int n, hipStream_t s) {
+    for (int k0 = 0; k0 < n; k0 += kMaxPadFinishJobs) {
+        const int nn = std::min(kMaxPadFinishJobs, n - k0);
+        PadFinishTable tab;
+        int ldmax = 0;
+        for (int k = 0; k < kMaxPadFinishJobs; ++k) { tab.j[k] = jobs[k0 + std::min(k, nn - 1)]; if (k < nn) ldmax = std::max(ldmax, tab.j[k].ld); }
+        hipLaunchKernelGGL(compact_pad_finish_kernel, dim3(cdiv(ldmax, 32), nn), dim3(1024), 0, s, tab);
+    }
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }

@@ -158,7 +158,7 @@ struct StreamState {
     float* dE = nullptr;
     // frame compaction (compact.hip): the first layer's operand gathered to the valid frames + one zero row, the encoder output
     // expanded back to B T rows for the delta layer, the delta layer's gradient compacted (padding rows summed into the zero row)
-    float* xc = nullptr; float* enc_full = nullptr; float* dEc = nullptr; float* compact_ws = nullptr;
+    float* xc = nullptr; float* dEc = nullptr; float* compact_ws = nullptr;
     float* out_ptr = nullptr;
     size_t param_begin = 0;                    // this stream's parameters start here in the flat buffers
 };
@@ -222,6 +222,7 @@ struct adn_model {
     // shared workspace tensors
     uint8_t *mask_bt = nullptr, *mask_tb = nullptr;
     int32_t* y_bt = nullptr;
+    const int32_t* y_src = nullptr;          // the call's targets as the kernels read them: the caller's device array in place, or y_bt
     float *total = nullptr, *loss = nullptr, *row_loss = nullptr, *probs_bt = nullptr;
     float *z = nullptr, *dz = nullptr, *cls_in = nullptr, *dcls = nullptr, *fused = nullptr, *dfused = nullptr;
     // The S input streams are independent up to the fusion (and again below it in back-propagation): optionally each
@@ -539,12 +540,11 @@ size_t carve(adn_model* m, char* base, int B, int T, bool host_inputs) {
         st.feat = take_shadowed(m, cv, N * ld_of(st.feat_dim));
         st.dfeat = cv.take<float>(N * ld_of(st.feat_dim));
         st.dE = take_shadowed(m, cv, N * ld_of(st.enc_out));
-        st.xc = nullptr; st.enc_full = nullptr; st.dEc = nullptr; st.compact_ws = nullptr;
+        st.xc = nullptr; st.dEc = nullptr; st.compact_ws = nullptr;
         if (st.cfg.n_enc > 0 && compaction_possible(m, N)) {     // frame compaction (row counts <= N): only where a call of this shape can compact
             st.xc = take_shadowed(m, cv, N * ld_of(st.cfg.input_dim));
-            st.enc_full = cv.take<float>(N * ld_of(st.enc_out));
             st.dEc = take_shadowed(m, cv, N * ld_of(st.enc_out));
-            st.compact_ws = cv.take<float>(compact_sum_ws_floats((int)N, st.enc_out));
+            st.compact_ws = cv.take<float>((size_t)B * st.enc_out);      // the padding frames' gradient, summed per utterance (delta layer)
         }
         st.lw.resize(st.lstm.size());
         for (auto& w : st.lw) carve_lstm(m, cv, w, B, T, ldh, ldg);
@@ -743,13 +743,20 @@ int stage_inputs(adn_model* m, const void* const* inputs, const int32_t* targets
     }
     for (auto& st : m->st) if (!st.x16) ADN_TRY(refresh(m, st.x, N * st.ldx));
     ADN_TRY(refresh_params(m));
-    ADN_HIP_CHECK(hipMemcpyAsync(m->mask_bt, mask, N, kind, m->stream));
-    if (targets) ADN_HIP_CHECK(hipMemcpyAsync(m->y_bt, targets, N * sizeof(int32_t), kind, m->stream));
+    // (device arrays are read in place -- like the stream inputs: the caller keeps them alive until the stream has run the call --,
+    //  host arrays through the slab's copies)
+    const uint8_t* mask_src = mask;
+    m->y_src = targets;
+    if (!dev) {
+        ADN_HIP_CHECK(hipMemcpyAsync(m->mask_bt, mask, N, kind, m->stream));
+        mask_src = m->mask_bt;
+        if (targets) { ADN_HIP_CHECK(hipMemcpyAsync(m->y_bt, targets, N * sizeof(int32_t), kind, m->stream)); m->y_src = m->y_bt; }
+    }
     ADN_TRY(setup_compaction(m, B, T, dev));
     // (a device mask is compared with the announced lengths by the kernel that walks it anyway; the word is read at the call's next
     //  synchronisation point -- check_device_errors() -- or right here under ADN_CHECK_PADDING=1)
     const bool verify = m->compact && dev;
-    ADN_TRY(mask_prepare(m->mask_bt, m->mask_tb, B, T, m->total, m->stream, verify ? m->d_lens : nullptr, verify ? m->input_flags() : nullptr, kInputLens));
+    ADN_TRY(mask_prepare(mask_src, m->mask_tb, B, T, m->total, m->stream, verify ? m->d_lens : nullptr, verify ? m->input_flags() : nullptr, kInputLens));
     if (verify && getenv("ADN_CHECK_PADDING")) {
         int f = 0;
         ADN_TRY(read_input_flags(m, &f));
@@ -951,7 +958,7 @@ int refresh(adn_model* m, const float* p, size_t floats) {
 // bf16x3 through planes: the output of a GEMM that later GEMMs read gets its planes here (whole rows: the pad columns are
 // zero in fp32 and stay zero in both planes)
 int planes_of_output(adn_model* m, const GemmArgs& g) {
-    if (!m->planes() || !g.C || g.accumulate) return ADN_OK;
+    if (!m->planes() || !g.C || g.accumulate || g.no_planes) return ADN_OK;
     if (g.planes_done && *g.planes_done) return ADN_OK;             // the kernel wrote both planes in its epilogue
     if (!m->shadow_of(g.C)) return ADN_OK;
     return refresh(m, g.C, (size_t)g.M * g.ldc);
@@ -959,7 +966,7 @@ int planes_of_output(adn_model* m, const GemmArgs& g) {
 // (planes mode) offer the result's planes to the kernel: the ping-pong kernel writes them from its epilogue
 void offer_output_planes(adn_model* m, GemmArgs& g, int* done) {
     *done = 0;
-    if (!m->planes() || !g.C || g.accumulate || g.ldc % 8) return;
+    if (!m->planes() || !g.C || g.accumulate || g.ldc % 8 || g.no_planes) return;
     void* hi = m->shadow_of(g.C); void* lo = m->shadow_lo_of(g.C);
     if (!hi || !lo) return;
     g.C16 = hi; g.C16lo = lo; g.planes_done = done;
@@ -1525,6 +1532,8 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
         g.B = m->P(st.encW[l]); g.ldb = ld_of(g.N);
         g.C = st.act[l]; g.ldc = ld_of(g.N); g.bias = m->P(st.encb[l]); g.act = m->act_code(st.cfg.enc_act[l]);
         g.no_split = 1;                                          // forward pass: reproducible bits
+        // (the encoder's OUTPUT feeds no GEMM -- the delta layer / BatchNorm read it in fp32 --: no planes of it; round 5 split it anyway)
+        g.no_planes = (l + 1 == st.cfg.n_enc) ? 1 : 0;
         mgemm_prepare(m, g, /*lean=*/l + 1 < st.cfg.n_enc);      // the delta layer reads the last one in fp32
         // (bf16x3: a narrow next layer -- the 50-unit bottleneck -- reads the planes too since round 5 (gemm_skinny.hip); with those
         //  kernels switched off it multiplies over split images of the fp32 values, and writing them here is cheaper than writing
@@ -1580,20 +1589,27 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
                                                m->P(st.bn_mean), m->P(st.bn_inv_std), m->stream));
             a = st.bn_out; lda = ldE;
         }
-        if (m->compact && st.cfg.n_enc > 0) {                    // the delta layer reads B T rows: every padding frame sees enc(0)
-            ADN_TRY(compact_expand_rows(a, lda, st.enc_full, lda, m->comp_of_full, (int)N, st.enc_out, m->stream));
-            a = st.enc_full;
-        }
+        // (compact.hip) the delta layer spans B T frames and reads the compact encoder output through the row map: every padding
+        // frame sees row Z = enc(0) -- no expanded copy
+        const int32_t* enc_rows = (m->compact && st.cfg.n_enc > 0) ? m->comp_of_full : nullptr;
         const bool drop = m->stochastic && st.cfg.dropout_p > 0.f;
-        void* feat16 = (m->bf16() && !drop) ? m->shadow_of(st.feat) : nullptr;      // written by the delta kernel itself
+        // the 16-bit copies of the LSTM input are written by the delta kernel itself: the bf16 copy, or both planes
+        void* feat16 = (m->bf16() && !drop) ? m->shadow_of(st.feat) : nullptr;
+        void* feat16lo = nullptr;
+        if (m->planes() && !drop && m->shadow_of(st.feat) && m->shadow_lo_of(st.feat)) { feat16 = m->shadow_of(st.feat); feat16lo = m->shadow_lo_of(st.feat); }
         // (queued: the streams' delta layers go out as ONE launch ahead of their first reader -- the dropout / bf16-copy pass
         //  right below where a stream has one, else the grouped input projections behind this loop)
-        ADN_TRY(queue_delta(m, true, DeltaJob{a, lda, st.feat, ld_of(st.feat_dim), st.enc_out, st.cfg.use_delta, feat16}, B, T, theta, false));
-        if (st.cfg.aux_dim > 0)                                  // ConcatLayer([l_delta, l_dct], axis=2): columns behind the deltas
-            ADN_TRY(queue_delta(m, true, DeltaJob{st.aux_stage, ld_of(st.cfg.aux_dim), st.feat + st.delta_dim, ld_of(st.feat_dim),
-                                                  st.cfg.aux_dim, 0,
-                                                  feat16 ? static_cast<void*>(static_cast<char*>(feat16) + 2 * (size_t)st.delta_dim) : nullptr},
-                                B, T, theta, false));
+        {
+            DeltaJob dj{a, lda, st.feat, ld_of(st.feat_dim), st.enc_out, st.cfg.use_delta, feat16};
+            dj.dst16lo = feat16lo; dj.row_map = enc_rows;
+            ADN_TRY(queue_delta(m, true, dj, B, T, theta, false));
+        }
+        if (st.cfg.aux_dim > 0) {                                // ConcatLayer([l_delta, l_dct], axis=2): columns behind the deltas
+            DeltaJob dj{st.aux_stage, ld_of(st.cfg.aux_dim), st.feat + st.delta_dim, ld_of(st.feat_dim), st.cfg.aux_dim, 0,
+                        feat16 ? static_cast<void*>(static_cast<char*>(feat16) + 2 * (size_t)st.delta_dim) : nullptr};
+            dj.dst16lo = feat16lo ? static_cast<void*>(static_cast<char*>(feat16lo) + 2 * (size_t)st.delta_dim) : nullptr;
+            ADN_TRY(queue_delta(m, true, dj, B, T, theta, false));
+        }
         if (drop || !feat16 || !grouped) ADN_TRY(flush_deltas(m, B, T));
         if (drop)                                                // DropoutLayer ahead of the LSTM (adenet_v3.py:112,123,134)
             ADN_TRY(dropout_apply(st.feat, ld_of(st.feat_dim), st.feat, ld_of(st.feat_dim), B, T, st.feat_dim, st.feat_dim, 0,
@@ -1747,7 +1763,7 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
         g.layout = GEMM_NN; g.M = B; g.N = m->C; g.K = H; g.A = cls + (size_t)(T - 1) * B * ldh; g.lda = ldh;
         g.B = m->P(m->smW); g.ldb = m->ldc; g.C = m->z; g.ldc = m->ldc; g.bias = m->P(m->smb); g.no_split = 1;
         ADN_TRY(mgemm(m, g));
-        ADN_TRY(softmax_ce(m->z, m->ldc, B, T, m->C, want_loss ? m->y_bt : nullptr, m->total, m->probs_bt,
+        ADN_TRY(softmax_ce(m->z, m->ldc, B, T, m->C, want_loss ? m->y_src : nullptr, m->total, m->probs_bt,
                            want_loss ? m->row_loss : nullptr, want_dz ? m->dz : nullptr, m->ldc, s));
         if (want_dz) ADN_TRY(refresh(m, m->dz, (size_t)B * m->ldc));
         if (want_loss) ADN_TRY(reduce_loss(m->row_loss, B, m->total, m->loss, s));
@@ -1760,7 +1776,7 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
         g.B = m->P(m->smW); g.ldb = m->ldc; g.C = m->z; g.ldc = m->ldc; g.bias = m->P(m->smb); g.no_split = 1;
         ADN_TRY(mgemm(m, g));
     }
-    ADN_TRY(softmax_loss(m->z, m->ldc, B, T, m->C, m->mask_tb, want_loss ? m->y_bt : nullptr, m->total, m->probs_bt,
+    ADN_TRY(softmax_loss(m->z, m->ldc, B, T, m->C, m->mask_tb, want_loss ? m->y_src : nullptr, m->total, m->probs_bt,
                          want_loss ? m->row_loss : nullptr, want_dz ? m->dz : nullptr, m->ldc, s,
                          (want_dz && m->bf16()) ? m->shadow_of(m->dz) : nullptr));      // (pad columns of dz stay zero in both copies)
     if (want_dz && !m->bf16()) ADN_TRY(refresh(m, m->dz, (size_t)N * m->ldc));
@@ -2110,6 +2126,13 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
     const bool stream_major = dp_stream_major(m) != 0;
     // everything of stream si above its encoder: LSTM parameter / input gradients, dropout, delta layer, BatchNorm, act'
     std::vector<char> first_dx_done(m->st.size(), 0);          // layer-major: the first LSTM's input gradient went out grouped
+    std::vector<PadFinishJob> pad_rows;        // compact.hip: zero-input rows still to be summed from the delta kernels' partial sums
+    auto flush_pad_rows = [&]() -> int {
+        if (pad_rows.empty()) return ADN_OK;
+        const int rc = compact_pad_finish(pad_rows.data(), (int)pad_rows.size(), m->stream);
+        pad_rows.clear();
+        return rc;
+    };
     auto stream_head = [&](size_t si, bool lstm_grads_done) -> int {
         StreamState& st = m->st[si];
         Walk& w = walk[si];
@@ -2132,10 +2155,17 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         // (an auxiliary input sits in the columns behind the delta features: data, no gradient)
         // (queued: where nothing of this stream reads dE before the encoder's back-propagation starts -- no BatchNorm, a linear
         //  bottleneck, the bf16 copy written by the kernel -- the streams' delta layers go out as ONE launch behind this loop)
-        if (m->compact) {                         // compact.hip: the delta layer's gradient over B T rows -> valid rows + the padding rows' sum
-            ADN_TRY(queue_delta(m, false, DeltaJob{st.dfeat, ldf, st.dE, ldE, st.enc_out, st.cfg.use_delta, nullptr}, B, T, theta, true));
-            ADN_TRY(compact_rows_sum(st.dE, ldE, st.dEc, ldE, m->comp_of_full, N, st.enc_out, m->Nc - 1, st.compact_ws, m->stream));
-            ADN_TRY(refresh(m, st.dEc, (size_t)m->Nc * ldE));
+        if (m->compact) {
+            // compact.hip: the delta layer's backward kernel stores a valid frame's gradient at its compact row -- with its 16-bit
+            // copies -- and sums the padding frames' per utterance; the zero-input row is finished from those sums ahead of the
+            // first reader (flush_pad_rows)
+            DeltaJob dj{st.dfeat, ldf, st.dEc, ldE, st.enc_out, st.cfg.use_delta, nullptr};
+            dj.row_map = m->comp_of_full; dj.zrow = m->Nc - 1; dj.pad_partial = st.compact_ws;
+            if (m->bf16() || m->planes()) dj.dst16 = m->shadow_of(st.dEc);
+            if (m->planes() && dj.dst16) dj.dst16lo = m->shadow_lo_of(st.dEc);
+            ADN_TRY(queue_delta(m, false, dj, B, T, theta, true));
+            pad_rows.push_back(PadFinishJob{st.compact_ws, B, st.dEc, ldE, st.enc_out, m->Nc - 1, dj.dst16, dj.dst16lo});
+            if (!dj.dst16) { ADN_TRY(flush_pad_rows()); ADN_TRY(refresh(m, st.dEc, (size_t)m->Nc * ldE)); }
             w.dZ = st.dEc; w.lddz = ldE; w.bias_done = 0; w.active = true;
             return bucket_ready(bucket_of_top(m, si));
         }
@@ -2252,6 +2282,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         }
         for (size_t si = 0; si < m->st.size(); ++si) { ADN_TRY(stream_head(si, true)); max_depth = std::max(max_depth, walk[si].active ? walk[si].L : 0); }
         ADN_TRY(flush_deltas(m, B, T));
+        ADN_TRY(flush_pad_rows());
         for (int d = 0; d < max_depth; ++d)
             for (const auto& sis : depth_groups(m, d)) ADN_TRY(layer_step(sis, d));
         ADN_TRY(col_sum_batch(bias_sums, m->stream));
@@ -2259,6 +2290,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         for (size_t si = 0; si < m->st.size(); ++si) {
             OnSideStream on(m, (int)si);
             ADN_TRY(stream_head(si, false));
+            ADN_TRY(flush_pad_rows());
             if (!walk[si].active) continue;
             for (int d = 0; d < walk[si].L; ++d) ADN_TRY(layer_step(std::vector<size_t>{si}, d));
             ADN_TRY(col_sum_batch(bias_sums, m->stream));

@@ -24,6 +24,13 @@ def run():
     bench.synthetic_params(model)
     xs, y, m_d, mask = bench.synthetic_batch(torch, 0, int(os.environ.get("BD_BATCH", bench.B_PER_GPU)), device)   # BD_BATCH=26: the reference's minibatch
     lens = None if os.environ.get("BD_PADDED") else mask.sum(axis=1).astype("int32")     # frame compaction, as bench.py announces it (BD_PADDED=1: off)
+    if os.environ.get("BD_INPUTS") == "bench":         # the resident form bench.py hands over: bfloat16 (bf16) / hi-lo planes (bf16x3, mixed)
+        prec = os.environ.get("ADN_PRECISION", "bf16")
+        if prec == "bf16":
+            xs = [x.to(torch.bfloat16) for x in xs]
+        elif prec in ("bf16x3", "mixed"):
+            from ip_avsr_amd.model import PlaneInput
+            xs = [PlaneInput.split(x) for x in xs]
 
     def step():
         if lens is not None:
