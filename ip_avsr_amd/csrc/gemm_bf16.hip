@@ -1541,6 +1541,54 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
     }
 }
 
+// The tail band of a persistent NN launch (gemm_f32.hip gemm_pp_try_impl: the row tiles whose tiles would open a nearly empty last
+// round of the 256 workgroups run K-split over the whole device instead): sums the band's partial slabs ([group][split][Mt][ldc],
+// Mt = p.M band rows, slice order: one fixed order) and applies the epilogue the persistent kernel would have -- bias, rectifier,
+// rectify'(Y) mask from the bf16 copy of Y, fp32 store, bf16 copy or hi / lo planes, column sums (one partial row per kTailEpiRows
+// band rows, behind the main launch's partial rows) -- at rows m_off + r of the problem's matrices.  blockIdx.y = problem.
+__global__ __launch_bounds__(256) void splitk_tail_epilogue_kernel(const GemmParams p, int splits, int m_off, int cs_row0) {
+    const GemmGroup gp = pick_group(p, blockIdx.y);
+    const int r0 = blockIdx.x * kTailEpiRows, r1 = min(p.M, r0 + kTailEpiRows);
+    const size_t slab = (size_t)p.M * p.ldc;
+    const float* part = p.partial + (size_t)blockIdx.y * splits * slab;
+    const int n4 = p.N / 4;
+    for (int c4 = threadIdx.x; c4 < n4; c4 += 256) {
+        const int col = 4 * c4;
+        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gp.bias) b4 = *reinterpret_cast<const float4*>(gp.bias + col);
+        for (int r = r0; r < r1; ++r) {
+            float4 v = b4;
+            for (int s = 0; s < splits; ++s) {
+                const float4 w = *reinterpret_cast<const float4*>(part + (size_t)s * slab + (size_t)r * p.ldc + col);
+                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+            }
+            if (p.act == ADN_ACT_RECTIFY) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            const size_t row = (size_t)m_off + r;
+            if (gp.Y16) {
+                const bf16x4 y = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(gp.Y16) + row * p.ldy + col);
+                v.x = (float)y[0] > 0.f ? v.x : 0.f; v.y = (float)y[1] > 0.f ? v.y : 0.f;
+                v.z = (float)y[2] > 0.f ? v.z : 0.f; v.w = (float)y[3] > 0.f ? v.w : 0.f;
+            }
+            const size_t off = row * p.ldc + col;
+            if (gp.C) *reinterpret_cast<float4*>(gp.C + off) = v;
+            if (gp.C16) {
+                const bf16x4 h = cvt4(v);
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(gp.C16) + off) = h;
+                if (gp.C16lo)
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(gp.C16lo) + off) =
+                        cvt4(make_float4(v.x - (float)h[0], v.y - (float)h[1], v.z - (float)h[2], v.w - (float)h[3]));
+            }
+            cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+        }
+        if (gp.colsum) *reinterpret_cast<float4*>(gp.colsum + (size_t)(cs_row0 + blockIdx.x) * p.colsum_ld + col) = cs;
+    }
+}
+
+void launch_splitk_tail_epilogue(const GemmParams& p, int splits, int m_off, int cs_row0, hipStream_t s) {
+    hipLaunchKernelGGL(splitk_tail_epilogue_kernel, dim3((unsigned)cdiv(p.M, kTailEpiRows), (unsigned)p.ngroups), dim3(256), 0, s, p, splits, m_off, cs_row0);
+}
+
 void launch_splitk_reduce(const GemmParams& p, int splits, hipStream_t s) {
     const size_t n4 = (size_t)p.M * (p.N / 4);
     const int blocks = (int)std::min<size_t>(2048, (n4 + 255) / 256);
@@ -1559,7 +1607,7 @@ static void launch_pp_t(const GemmParams& p, int layout, bool split, dim3 grid, 
 }
 
 // tile_mode: 4 = 256 x 256, 5 = 256 x 128, 6 = 128 x 256 (eight waves); 7 = 256 x 256, four waves of 128 x 128
-void launch_gemm_bf16_pp(const GemmParams& p, int layout, int tile_mode, int splits, dim3 grid, hipStream_t s) {
+void launch_gemm_bf16_pp(const GemmParams& p, int layout, int tile_mode, int splits, dim3 grid, hipStream_t s, bool reduce) {
     const bool split = splits > 1;
     if (tile_mode == 7) {
         if (layout == GEMM_NN) {
@@ -1575,7 +1623,7 @@ void launch_gemm_bf16_pp(const GemmParams& p, int layout, int tile_mode, int spl
     else if (tile_mode == 5) launch_pp_t<256, 128, true>(p, layout, split, grid, s);      // (diagnostic tile shapes: the general form only)
     else launch_pp_t<128, 256, true>(p, layout, split, grid, s);
 #endif
-    if (split) launch_splitk_reduce(p, splits, s);
+    if (split && reduce) launch_splitk_reduce(p, splits, s);
 }
 
 template <int BM, int BN, int WM, typename T>

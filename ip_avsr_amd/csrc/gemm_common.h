@@ -126,6 +126,9 @@ void launch_gemm_bf16(const GemmParams& p, int layout, int tile_mode /*0: 64x64,
 int split3_cols(const float* src, int ld_src, int rows, int K, int Kp, void* dst, int lo_mask, hipStream_t s);
 int split3_transpose(const float* src, int ld_src, int R, int K, int Kp, void* dst, int ld_dst, int lo_mask, hipStream_t s);
 int split3_rows(const float* src, int ld_src, int K, int Kp, int cols, void* dst, int ld_dst, int lo_mask, hipStream_t s);
-void launch_gemm_bf16_pp(const GemmParams& p, int layout, int tile_mode, int splits, dim3 grid, hipStream_t s);
+void launch_gemm_bf16_pp(const GemmParams& p, int layout, int tile_mode, int splits, dim3 grid, hipStream_t s, bool reduce = true);
+// the tail band of a persistent launch (gemm_f32.hip gemm_pp_try_impl): sums the band's split-K slabs and applies the launch's epilogue
+void launch_splitk_tail_epilogue(const GemmParams& p, int splits, int m_off, int cs_row0, hipStream_t s);
+constexpr int kTailEpiRows = 8;      // rows per workgroup of that pass = rows per partial column-sum row it writes
 
 }  // namespace adn

@@ -216,7 +216,7 @@ static int planes_tile_mode(int layout, int mode_env, int default_mode) {
     if (mode_env >= 4) return (mode_env == 8 && !x3f_enabled()) ? default_mode : mode_env;
     return (x3f_enabled() && (!tn_only || layout == GEMM_TN)) ? 8 : default_mode;
 }
-void launch_gemm_x3f(const GemmParams& p, int layout, bool planes, int splits, dim3 grid, hipStream_t s);      // gemm_x3f.hip
+void launch_gemm_x3f(const GemmParams& p, int layout, bool planes, int splits, dim3 grid, hipStream_t s, bool reduce = true);      // gemm_x3f.hip
 static int gemm_pp_try(const GemmArgs* gs0, int n, hipStream_t stream, bool* used, bool dry = false) {
     *used = false;
     if (n < 1 || n > kMaxGemmGroups) return ADN_OK;
@@ -360,6 +360,38 @@ static int gemm_pp_try_impl(const GemmArgs* gs, int n, const GemmArgs& g, int ks
         p.partial = g.splitk_ws;
     }
     if (dry) { *used = true; return ADN_OK; }
+    // ---- tail band (round 6).  The tile list of an NN launch is walked by 256 persistent workgroups in rounds; a list that ends
+    // just behind a round boundary -- the compacted bench step: 54 row tiles x 8 x 3 streams = 1296 tiles = 5.06 rounds for the
+    // first layer and for its input gradient -- pays a whole round for a handful of tiles.  Then the last row tiles are taken off
+    // the list (the main launch ends on full rounds) and their rows run K-SPLIT over the whole device: S slices per tile into partial
+    // slabs, and splitk_tail_epilogue_kernel sums the slabs in slice order and applies this launch's epilogue (gemm_bf16.hip).  Same
+    // products; the band's rows are summed in another order than the main rows (fixed: reproducible).
+    // MEASURED, round 6, one box, alternating runs (profiles/r06/ab_tail_split.txt): bf16 3.162 / 3.163 ms per step with it against
+    // 3.170 / 3.077 without, bf16x3 6.040 / 6.035 against 6.007 / 5.998, mixed 4.390 / 4.395 against 4.323 / 4.333 -- it does NOT pay:
+    // the sixth "round" of 16 tiles costs less than a round (those workgroups run alone: full clocks, the whole L2 and HBM), and the
+    // band's slabs + two more launches cost about what it saves.  Kept as an experiment switch: ADN_GEMM_TAIL_SPLIT=1 turns it on.
+    int band_rt = 0, band_rows = 0, band_S = 1;
+    {
+        static const bool no_tail = getenv("ADN_GEMM_TAIL_SPLIT") == nullptr;
+        const int per_row = p.tiles_n * n;
+        const int64_t full = tiles / cus, rem = tiles - full * cus;
+        if (!no_tail && !dry && splits == 1 && g.layout == GEMM_NN && !g.accumulate && cd.bm == 256 && (cd.mode == 4 || cd.mode == 8) &&
+            (fused || !kseg) && full >= 2 && rem > 0 && rem * 4 <= cus && per_row > 0) {
+            const int rt = (int)((rem + per_row - 1) / per_row);           // row tiles that leave the main launch
+            const int64_t bt = (int64_t)rt * per_row;
+            int S = (int)(cus / std::max<int64_t>(1, bt));
+            S = S >= 8 ? 8 : (S >= 4 ? 4 : 1);
+            const int rows = g.M - (p.tiles_m - rt) * cd.bm;
+            const int cs_rows = (p.tiles_m - rt) * cd.wave_rows + cdiv(rows, kTailEpiRows);
+            bool ok = S > 1 && rt < p.tiles_m && rows > 0 && p.K / S >= 64 && g.splitk_ws && ((uintptr_t)g.splitk_ws % 16) == 0 &&
+                      (size_t)n * S * rows * g.ldc <= g.splitk_ws_floats;
+            if (ok && g.colsum)                                             // (fused sums: the band's partial rows must fit behind the main launch's)
+                for (int k = 0; k < n; ++k)
+                    ok = ok && (!gs[k].colsum_ws || (size_t)cs_rows * cs_ld <= gs[k].colsum_ws_floats);
+            if (ok) { band_rt = rt; band_rows = rows; band_S = S; }
+        }
+    }
+    const int main_tiles_m = p.tiles_m - band_rt;
     bool fused_colsum = false;
     if (g.colsum && splits == 1) {
         fused_colsum = true;
@@ -386,33 +418,75 @@ static int gemm_pp_try_impl(const GemmArgs* gs, int n, const GemmArgs& g, int ks
         q.colsum = fused_colsum ? gs[k].colsum_ws : nullptr;
         if (gs[k].colsum_done) *gs[k].colsum_done = fused_colsum ? 1 : 0;
     }
-    {   // square-ish per-XCD tile blocks (per group)
-        const int chunk = (int)std::max<int64_t>(1, (int64_t)p.tiles_m * p.tiles_n / 8);
-        p.panel_n = std::max(1, std::min((int)std::lround(std::sqrt((double)chunk)), p.tiles_n));
-    }
-    int gx = (int)std::min<int64_t>(tiles, cus / splits);
-    if (splits > 1) {
-        gx = (int)tiles;                      // one (tile, slice) per workgroup
-        static const bool no_xcd = getenv("ADN_GEMM_NO_XCD_SLICES") != nullptr;
-        p.xcd_slices = !no_xcd && (splits % 8 == 0 || 8 % splits == 0) && ((int64_t)gx * splits) % 8 == 0;
-    } else if (gx >= 8) gx = gx / 8 * 8;      // a workgroup's tiles then stay on its own XCD's chunk of the tile list
     static const bool trace = getenv("ADN_GEMM_TRACE") != nullptr;
-    if (trace)
-        fprintf(stderr, "ADN_GEMM %s M=%d N=%d K=%d tile=%d tiles=%lld split=%d shadows=1 lean=%d acc=%d groups=%d%s\n",
-                g.layout == GEMM_NN ? "NN" : "TN", g.M, g.N, g.K, cd.bm * 1000 + cd.bn, (long long)tiles, splits, (int)lean_c,
-                g.accumulate, n, kseg ? (fused ? " planes=1 fused=1" : " planes=1") : (fused ? " fused=1" : ""));
+    auto say = [&](int M_, long long tiles_, int split_) {
+        if (trace)
+            fprintf(stderr, "ADN_GEMM %s M=%d N=%d K=%d tile=%d tiles=%lld split=%d shadows=1 lean=%d acc=%d groups=%d%s\n",
+                    g.layout == GEMM_NN ? "NN" : "TN", M_, g.N, g.K, cd.bm * 1000 + cd.bn, tiles_, split_, (int)lean_c,
+                    g.accumulate, n, kseg ? (fused ? " planes=1 fused=1" : " planes=1") : (fused ? " fused=1" : ""));
+    };
+    auto launch = [&](const GemmParams& q, int sp, dim3 grid, bool reduce) {
+        if (fused) launch_gemm_x3f(q, g.layout, kseg != 0, sp, grid, stream, reduce);
+        else launch_gemm_bf16_pp(q, g.layout, cd.mode, sp, grid, stream, reduce);
+    };
+    auto set_panel = [](GemmParams& q) {   // square-ish per-XCD tile blocks (per group)
+        const int chunk = (int)std::max<int64_t>(1, (int64_t)q.tiles_m * q.tiles_n / 8);
+        q.panel_n = std::max(1, std::min((int)std::lround(std::sqrt((double)chunk)), q.tiles_n));
+    };
     {
         ProfScope prof(PROF_GEMM_NN + g.layout, 2.0 * g.M * g.N * g.K * n,
                        4.0 * n * ((double)g.M * g.K + (double)g.K * g.N + (double)g.M * g.N), stream, n);
-        if (fused) launch_gemm_x3f(p, g.layout, kseg != 0, splits, dim3((unsigned)gx, (unsigned)splits), stream);
-        else launch_gemm_bf16_pp(p, g.layout, cd.mode, splits, dim3((unsigned)gx, (unsigned)splits), stream);
+        if (band_rt > 0) {
+            // main launch: the row tiles that fill whole rounds
+            GemmParams pm = p;
+            pm.M = main_tiles_m * cd.bm; pm.tiles_m = main_tiles_m;
+            set_panel(pm);
+            const int64_t tiles_main = (int64_t)pm.tiles_m * pm.tiles_n * n;
+            int gxm = (int)std::min<int64_t>(tiles_main, cus);
+            if (gxm >= 8) gxm = gxm / 8 * 8;
+            say(pm.M, (long long)tiles_main, 1);
+            launch(pm, 1, dim3((unsigned)gxm, 1u), true);
+            // the band, K-split into slabs (no epilogue in the kernel) ...
+            GemmParams pt = p;
+            pt.M = band_rows; pt.tiles_m = band_rt;
+            set_panel(pt);
+            pt.partial = g.splitk_ws;
+            pt.k_chunk = (int)round_up(cdiv(pt.K, band_S), 32);
+            const int S = cdiv(pt.K, pt.k_chunk);
+            for (int k = 0; k < n; ++k) {
+                GemmGroup& q = pt.grp[k];
+                q.A16 = static_cast<const char*>(q.A16) + (size_t)pm.M * g.lda * 2;
+                if (q.A16lo) q.A16lo = static_cast<const char*>(q.A16lo) + (size_t)pm.M * g.lda * 2;
+                q.C16 = nullptr; q.C16lo = nullptr; q.Y16 = nullptr; q.bias = nullptr; q.colsum = nullptr;
+            }
+            const int gxt = band_rt * pt.tiles_n * n;
+            static const bool no_xcd = getenv("ADN_GEMM_NO_XCD_SLICES") != nullptr;
+            pt.xcd_slices = !no_xcd && (S % 8 == 0 || 8 % S == 0) && ((int64_t)gxt * S) % 8 == 0;
+            say(band_rows, (long long)gxt, S);
+            launch(pt, S, dim3((unsigned)gxt, (unsigned)S), false);
+            // ... and its epilogue over the summed slabs, at rows pm.M .. of the problems' matrices
+            GemmParams pe = p;
+            pe.M = band_rows; pe.partial = g.splitk_ws;
+            launch_splitk_tail_epilogue(pe, S, pm.M, main_tiles_m * cd.wave_rows, stream);
+        } else {
+            set_panel(p);
+            int gx = (int)std::min<int64_t>(tiles, cus / splits);
+            if (splits > 1) {
+                gx = (int)tiles;                      // one (tile, slice) per workgroup
+                static const bool no_xcd = getenv("ADN_GEMM_NO_XCD_SLICES") != nullptr;
+                p.xcd_slices = !no_xcd && (splits % 8 == 0 || 8 % splits == 0) && ((int64_t)gx * splits) % 8 == 0;
+            } else if (gx >= 8) gx = gx / 8 * 8;      // a workgroup's tiles then stay on its own XCD's chunk of the tile list
+            say(g.M, (long long)tiles, splits);
+            launch(p, splits, dim3((unsigned)gx, (unsigned)splits), true);
+        }
         ADN_HIP_CHECK(hipGetLastError());
     }
+    const int cs_part_rows = band_rt > 0 ? main_tiles_m * cd.wave_rows + cdiv(band_rows, kTailEpiRows) : p.tiles_m * cd.wave_rows;
     for (int k = 0; k < n; ++k) {
         if (fused_colsum) {
             if (gs[k].colsum_batch && gs[k].colsum_batch->n < 8)
-                col_sum_batch_add(*gs[k].colsum_batch, gs[k].colsum_ws, cs_ld, p.tiles_m * cd.wave_rows, g.N, gs[k].colsum);
-            else ADN_TRY(col_sum(gs[k].colsum_ws, cs_ld, p.tiles_m * cd.wave_rows, g.N, gs[k].colsum, 1, stream));
+                col_sum_batch_add(*gs[k].colsum_batch, gs[k].colsum_ws, cs_ld, cs_part_rows, g.N, gs[k].colsum);
+            else ADN_TRY(col_sum(gs[k].colsum_ws, cs_ld, cs_part_rows, g.N, gs[k].colsum, 1, stream));
         }
         if (gs[k].C16 && splits > 1) {            // split-K result: refresh the bf16 shadow of whole rows
             ADN_CHECK(g.ldc % 8 == 0, ADN_ERR_INVALID, "gemm: bf16 shadow of C needs ldc % 8 == 0");

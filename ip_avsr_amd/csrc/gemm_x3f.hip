@@ -519,7 +519,7 @@ __global__ __launch_bounds__(512) void gemm_x3f_kernel(const GemmParams p) {
 }
 
 // launch: grid = (workgroups, K-slices); splits > 1: partial slabs + the ping-pong kernel's reduce pass
-void launch_gemm_x3f(const GemmParams& p, int layout, bool planes, int splits, dim3 grid, hipStream_t s) {
+void launch_gemm_x3f(const GemmParams& p, int layout, bool planes, int splits, dim3 grid, hipStream_t s, bool reduce) {
     const bool split = splits > 1, kc = layout == GEMM_NN;
 #define ADN_X3F_LAUNCH(KC, SP, PL) hipLaunchKernelGGL((gemm_x3f_kernel<KC, SP, PL>), grid, dim3(512), 0, s, p)
     if (planes) {
@@ -530,7 +530,7 @@ void launch_gemm_x3f(const GemmParams& p, int layout, bool planes, int splits, d
         else { if (split) ADN_X3F_LAUNCH(false, true, false); else ADN_X3F_LAUNCH(false, false, false); }
     }
 #undef ADN_X3F_LAUNCH
-    if (split) launch_splitk_reduce(p, splits, s);
+    if (split && reduce) launch_splitk_reduce(p, splits, s);
 }
 
 }  // namespace adn

@@ -5,7 +5,9 @@
 #   conv AE counters.
 # Usage (from the repo root, on an MI355X):   bash profiles/collect.sh [rNN] [commit]
 set -u
-ROUND=${1:-r05}; COMMIT=${2:-unknown}
+ROUND=${1:-r06}; COMMIT=${2:-unknown}
+LABS=${LABS:-0}        # 1: also the GEMM labs / conv auto-encoder passes (kernels unchanged since round 5: profiles/r05/ holds them)
+export BD_INPUTS=bench   # breakdown passes: the batch resident as bench.py hands it over (bfloat16 / hi-lo planes)
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/collect
 mkdir -p $OUT
@@ -62,6 +64,7 @@ BD_BATCH=65 ADN_GEMM_TRACE=1 timeout 300 rocprofv3 --kernel-trace -d $OUT/bd65 -
 python3 $ROOT/profiles/gemm_breakdown.py join $OUT/gemm_trace_b65.txt $(find $OUT/bd65 -name "bd_kernel_trace.csv" | head -1) > $OUT/gemm_breakdown_bf16_B65.txt
 python3 $ROOT/profiles/step_breakdown.py $(find $OUT/bd65 -name "bd_kernel_trace.csv" | head -1) > $OUT/step_breakdown_bf16_B65.txt
 rm -rf $OUT/bdm $OUT/bdd $OUT/bd65 $OUT/gemm_trace_mixed.txt $OUT/gemm_trace_b65.txt
+if [ "$LABS" = 1 ]; then
 # conv auto-encoder: HBM bytes of its train step at batch 1024 (two PMC passes; 10 steps in the process)
 ( cd /tmp; CAE_BATCH=1024 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/caeA -o a --output-format csv -- python3 $ROOT/profiles/convae_profile.py bf16 > $OUT/caeA.log 2>&1
   CAE_BATCH=1024 timeout 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/caeB -o b --output-format csv -- python3 $ROOT/profiles/convae_profile.py bf16 > $OUT/caeB.log 2>&1
@@ -69,7 +72,9 @@ rm -rf $OUT/bdm $OUT/bdd $OUT/bd65 $OUT/gemm_trace_mixed.txt $OUT/gemm_trace_b65
 # conv auto-encoder: MFMA-busy share of its GEMM kernels
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmcC -o c --output-format csv -- python3 $ROOT/profiles/convae_profile.py > $OUT/pmcC.log 2>&1
 python3 $ROOT/profiles/pmc_summary.py $(find $OUT/pmcC -name "c_counter_collection.csv" | head -1) mfma > $OUT/pmc_mfma_convae.txt
+fi
 cd $ROOT
+if [ "$LABS" = 1 ]; then
 # GEMM lab: the ping-pong kernel (forced 256 x 256 tiles, auto selection, 3 grouped problems) against the register-staged kernels
 ( export LAB_PAD=64
   echo "=== register-staged kernels (ADN_GEMM_PP=0)"; ADN_GEMM_PP=0 timeout 200 profiles/gemm_lab
@@ -83,9 +88,12 @@ timeout 900 bash profiles/scripts/lab_x3f.sh > $OUT/lab_x3f.txt 2>&1
 timeout 300 bash profiles/scripts/x3f_stamps.sh > $OUT/x3f_stamps.txt 2>&1
 timeout 600 bash profiles/scripts/lab_skinny.sh > $OUT/lab_skinny.txt 2>&1
 timeout 600 bash profiles/scripts/lab_skinny2.sh > $OUT/lab_skinny2.txt 2>&1
+fi
 timeout 600 python3 profiles/scripts/strong_scaling_forecast.py bf16 > $OUT/strong_scaling_forecast.txt 2>&1
+if [ "$LABS" = 1 ]; then
 timeout 200 python3 profiles/hipblaslt_calibration.py > $OUT/hipblaslt_calibration.txt 2>/dev/null
 timeout 300 python3 profiles/convae_bench.py > $OUT/convae_bench.txt 2>/dev/null
+fi
 # the bench lines last, so that roofline.traffic comes from the PMC passes of THIS build
 mkdir -p profiles/$ROUND && cp $OUT/pmc_traffic_bf16.json profiles/$ROUND/pmc_traffic_bf16.json && cp $OUT/pmc_traffic_bf16x3.json profiles/$ROUND/pmc_traffic_bf16x3.json
 cp $OUT/pmc_traffic_f32.json $OUT/pmc_traffic_mixed.json profiles/$ROUND/ 2>/dev/null
@@ -104,9 +112,12 @@ timeout 600 python3 profiles/epoch_bench.py > $OUT/epoch_bench.txt 2>/dev/null
 # the gather kernel's own time inside the runner (B = 26 and B = 520 launches in one table), and the CLI driver end to end
 ( cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/eb -o eb --output-format csv -- python3 $ROOT/profiles/epoch_bench.py --precisions bf16 --epochs 4 > $OUT/eb.log 2>&1; grep -i "batch_gather\|\"Name\"" $(find $OUT/eb -name "eb_kernel_stats.csv" | head -1) > $OUT/batch_gather_kernel_stats.csv; rm -rf $OUT/eb )
 timeout 600 python3 profiles/scripts/runner_demo.py bf16 12 > $OUT/runner_demo.txt 2>&1
+if [ "$LABS" = 1 ]; then
 ADN_GEMM_TRACE=1 timeout 300 rocprofv3 --kernel-trace -d $OUT/cbd -o bd --output-format csv -- python3 $ROOT/profiles/scripts/convae_gemm_breakdown.py run 2> $OUT/cae_trace.txt > $OUT/cbd.log
 python3 $ROOT/profiles/scripts/convae_gemm_breakdown.py join $OUT/cae_trace.txt $(find $OUT/cbd -name "bd_kernel_trace.csv" | head -1) > $OUT/convae_gemm_breakdown.txt; rm -rf $OUT/cbd
 ( cd /tmp; CAE_BATCH=1024 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/cae -o cae --output-format csv -- python3 $ROOT/profiles/convae_profile.py bf16 > $OUT/cae.log 2>&1; cp $(find $OUT/cae -name "cae_kernel_stats.csv" | head -1) $OUT/convae_bf16_b1024_kernel_stats.csv; rm -rf $OUT/cae )
+fi
+for cfg in "bf16 520" "bf16x3 520" "mixed 520" "bf16 26"; do set -- $cfg; bash profiles/scripts/timeline.sh $1 $2 > /dev/null 2>&1; cp gpurun_out/tl/timeline_$1_b$2.txt $OUT/; done
 timeout 400 python3 bench.py --precision bf16 2>/dev/null | tail -1 > $OUT/final_bf16_bench.json
 rm -rf $OUT/ks_bf16 $OUT/ks_f32 $OUT/ks_bf16x3 $OUT/pmcA $OUT/pmcB $OUT/pmcA3 $OUT/pmcB3 $OUT/pmcM3 $OUT/pmcM $OUT/pmcC $OUT/bd $OUT/bd3 $OUT/gemm_trace_x3.txt
 ls -la $OUT
