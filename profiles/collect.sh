@@ -101,17 +101,16 @@ cp $OUT/pmc_traffic_f32.json $OUT/pmc_traffic_mixed.json profiles/$ROUND/ 2>/dev
 # of the reference minibatch
 timeout 300 python3 profiles/scripts/dp_order_bench.py > $OUT/dp_order_bench.txt 2>&1
 timeout 600 bash profiles/scripts/dp_forced.sh > $OUT/dp_forced.txt 2>&1
-timeout 300 python3 profiles/scripts/graph_b26.py > $OUT/graph_b26.txt 2>&1
 timeout 600 python3 profiles/configs_bench.py > $OUT/configs_bench.txt 2>/dev/null
 # round 4: the epoch through the product entry point (runners/nstream.fit, HBM-resident splits), the deterministic mode's cost,
 # the folded input projection A/B, the conv auto-encoder's kernel table at batch 1024
 timeout 600 python3 profiles/epoch_bench.py > $OUT/epoch_bench.txt 2>/dev/null
 ( for d in 0 1; do echo -n "ADN_DETERMINISTIC=$d: "; ADN_DETERMINISTIC=$d timeout 300 python3 bench.py --no-cpu-baseline --accurate-precision all --no-runner --no-profile 2>/dev/null | tail -1 | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print("bf16 %.3f ms/step, bf16x3 %.3f, mixed %.3f, f32 %.3f, B=26 %.3f" % (d["ms_per_step"], d["accurate"]["ms_per_step"], d["mixed"]["ms_per_step"], d["accurate_f32"]["ms_per_step"], d["reference_minibatch"]["ms_per_step"]))'; done
-  for v in "ADN_GEMM_NO_X3F=1" "ADN_GEMM_X3F=tn" "ADN_GEMM_NO_SKINNY=1" "ADN_GEMM_NO_SKINNY_WIDE=1" "ADN_MIXED_LSTM_X3=1" "ADN_MIXED_BOTH_PLANES=1" "ADN_NO_COMPACT=1"; do echo -n "$v: "; env $v timeout 300 python3 bench.py --no-cpu-baseline --accurate-precision all --no-runner --no-profile --no-reference-minibatch 2>/dev/null | tail -1 | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print("bf16 %.3f ms/step, bf16x3 %.3f, mixed %.3f" % (d["ms_per_step"], d["accurate"]["ms_per_step"], d["mixed"]["ms_per_step"]))'; done
-  for f in 0 1; do echo -n "ADN_LSTM_NO_FOLD=$f: "; if [ $f = 1 ]; then export ADN_LSTM_NO_FOLD=1; fi; timeout 300 python3 bench.py --no-cpu-baseline --accurate-precision none --no-runner 2>/dev/null | tail -1 | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); k=d["kernel_ms_per_step"]; print("bf16 %.3f ms/step, GEMM class %.3f ms = %.4f of peak, LSTM fwd %.3f ms, B=26 %.3f" % (d["ms_per_step"], k["gemm_nn"]+k.get("gemm_nt",0)+k["gemm_tn"], d["roofline"]["frac"], k["lstm_fwd_step"], d["reference_minibatch"]["ms_per_step"]))'; done ) > $OUT/mode_costs.txt 2>&1
+  for v in "ADN_NO_COMPACT=1" "ADN_GEMM_TAIL_SPLIT=1"; do echo -n "$v: "; env $v timeout 300 python3 bench.py --no-cpu-baseline --accurate-precision all --no-runner --no-profile --no-reference-minibatch 2>/dev/null | tail -1 | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print("bf16 %.3f ms/step, bf16x3 %.3f, mixed %.3f" % (d["ms_per_step"], d["accurate"]["ms_per_step"], d["mixed"]["ms_per_step"]))'; done
+) > $OUT/mode_costs.txt 2>&1
 # the gather kernel's own time inside the runner (B = 26 and B = 520 launches in one table), and the CLI driver end to end
 ( cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/eb -o eb --output-format csv -- python3 $ROOT/profiles/epoch_bench.py --precisions bf16 --epochs 4 > $OUT/eb.log 2>&1; grep -i "batch_gather\|\"Name\"" $(find $OUT/eb -name "eb_kernel_stats.csv" | head -1) > $OUT/batch_gather_kernel_stats.csv; rm -rf $OUT/eb )
-timeout 600 python3 profiles/scripts/runner_demo.py bf16 12 > $OUT/runner_demo.txt 2>&1
+timeout 600 python3 profiles/scripts/runner_demo.py bf16x3 12 > $OUT/runner_demo.txt 2>&1
 if [ "$LABS" = 1 ]; then
 ADN_GEMM_TRACE=1 timeout 300 rocprofv3 --kernel-trace -d $OUT/cbd -o bd --output-format csv -- python3 $ROOT/profiles/scripts/convae_gemm_breakdown.py run 2> $OUT/cae_trace.txt > $OUT/cbd.log
 python3 $ROOT/profiles/scripts/convae_gemm_breakdown.py join $OUT/cae_trace.txt $(find $OUT/cbd -name "bd_kernel_trace.csv" | head -1) > $OUT/convae_gemm_breakdown.txt; rm -rf $OUT/cbd
