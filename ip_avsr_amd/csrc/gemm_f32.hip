@@ -814,9 +814,9 @@ static int gemm_rs(const GemmArgs* gs, int n, hipStream_t stream) {
     const dim3 grid((unsigned)tiles_one, split, n);
     static const bool trace = getenv("ADN_GEMM_TRACE") != nullptr;       // one line per launch, pairs with a kernel trace
     if (trace)
-        fprintf(stderr, "ADN_GEMM %s M=%d N=%d K=%d tile=%d tiles=%lld split=%d shadows=%d lean=%d acc=%d\n",
+        fprintf(stderr, "ADN_GEMM %s M=%d N=%d K=%d tile=%d tiles=%lld split=%d shadows=%d lean=%d acc=%d groups=%d\n",
                 g.layout == GEMM_NN ? "NN" : (g.layout == GEMM_NT ? "NT" : "TN"), g.M, g.N, g.K, tall ? 25664 : tsz,
-                (long long)tiles, split, (int)(p.A16 && p.B16), (int)lean_c, g.accumulate);
+                (long long)tiles, split, (int)(p.A16 && p.B16), (int)lean_c, g.accumulate, n);      // (groups: problems of this launch, blockIdx.z)
     if (g.precision == ADN_PRECISION_BF16) launch_gemm_bf16(p, g.layout, tall ? 2 : (big ? 1 : 0), grid, stream);
     else if (big) launch<128, 128>(p, g.layout, grid, stream);
     else launch<64, 64>(p, g.layout, grid, stream);

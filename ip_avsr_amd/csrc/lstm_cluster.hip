@@ -594,8 +594,8 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClus
                 q_even = qb;
         }
         STAMP(1);
-        lds_barrier();                                // the own units' h_t is complete in both images
-        // ---- the step's outputs
+        // ---- the step's outputs: issued AHEAD of the barrier (round 6) -- they depend on nothing the barrier orders, and the
+        //      waves that reach it early spend the wait issuing stores instead of idling
         if (u < H) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -609,6 +609,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClus
                 }
             }
         }
+        lds_barrier();                                // the own units' h_t is complete in both images
         // ---- the own units' share of the NEXT step's product, while the partners' granules are in flight
         if (step + 1 < T) own_part();
         STAMP(2);
