@@ -1448,7 +1448,9 @@ int lstm_init_state(adn_model* m, const LstmParams& lp, const LstmWork& w, int B
     const size_t blk = lp.backwards ? (size_t)T * B * m->ldh : 0;
     char* h16 = m->bf16() ? static_cast<char*>(m->shadow_of(w.hbuf)) : nullptr;     // bf16 copy of the initial-state block
     m->init_q.push_back(LstmInitJob{m->P(lp.hid_init), m->P(lp.cell_init), w.hbuf + blk, w.cbuf + blk, h16 ? h16 + blk * 2 : nullptr});
-    if (!batched_housekeeping(m, B, T)) return flush_init_states(m, B);
+    // (queued at every batch size since round 6: the jobs are 5 us of launch latency each whatever B is, and their first reader is
+    //  the LSTM launch that run_lstm_group() puts behind the flush; forked streams keep one job per stream)
+    if (streams_concurrent(m)) return flush_init_states(m, B);
     return ADN_OK;
 }
 // the delta layers of the streams: queued while consecutive jobs share direction and window, flushed by the first reader
@@ -2207,7 +2209,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             const int l = w.L - 1 - depth;
             const int out_w = st.cfg.enc_units[l];
             if (!w.bias_done) {           // b_l did not ride on the input-gradient GEMM of the layer above: summed from dZ now
-                if (m->bf16() && (w.dZ == st.dE || w.dZ == st.dEc) && bias_sums.n < 8) col_sum_batch_add(bias_sums, w.dZ, w.lddz, Ne, out_w, m->G(st.encb[l]));   // (dE is not reused)
+                if ((m->bf16() || m->planes()) && (w.dZ == st.dE || w.dZ == st.dEc) && bias_sums.n < 8) col_sum_batch_add(bias_sums, w.dZ, w.lddz, Ne, out_w, m->G(st.encb[l]));   // (dE / dEc hold their fp32 values until the step ends: the delta layer wrote them, nothing reuses them)
                 else ADN_TRY(col_sum(w.dZ, w.lddz, Ne, out_w, m->G(st.encb[l]), 1, m->stream));
             }
             w.bias_done = 0;
