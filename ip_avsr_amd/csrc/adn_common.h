@@ -173,6 +173,10 @@ int join_hilo(const void* hi, const void* lo, float* dst, size_t n, hipStream_t 
 int compact_build_maps(const int32_t* d_lens, const int32_t* d_prefix, int B, int T, int Z, int32_t* comp_of_full, int32_t* full_of_comp,
                        hipStream_t s);
 int compact_gather_rows16(const void* src, int ld_src, void* dst, int ld_dst, const int32_t* full_of_comp, int Nc, int cols, hipStream_t s);
+// ... from float32 rows, converted on the way (dst_lo: the lo plane, or nullptr for the bf16 copy alone)
+int compact_gather_rows_f32(const float* src, int ld_src, void* dst_hi, void* dst_lo, int ld_dst, const int32_t* full_of_comp, int Nc, int cols,
+                            hipStream_t s);
+int compact_check_padding32(const float* src, int ld_src, const int32_t* comp_of_full, int N, int cols, int Z, int* flag, int bit, hipStream_t s);
 // raises `bit` of *flag when a padding row (comp_of_full[r] == Z) of the 16-bit matrix holds anything but zeros
 int compact_check_padding16(const void* src, int ld_src, const int32_t* comp_of_full, int N, int cols, int Z, int* flag, int bit, hipStream_t s);
 // the zero-input row's gradient from the per-utterance padding sums the delta layer's backward kernel left (DeltaJob::pad_partial):

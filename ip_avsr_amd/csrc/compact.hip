@@ -46,6 +46,41 @@ __global__ __launch_bounds__(256) void gather_rows16_kernel(const u32x4* __restr
     }
 }
 
+// the same gather from FLOAT32 rows, converting on the way: dst_hi[c] = bf16(src[full_of_comp[c]]) and -- planes -- dst_lo = bf16(x - hi);
+// 8 elements (two float4 in, 16 bytes per plane out) per thread
+typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void gather_rows_f32_kernel(const float4* __restrict__ src, int ld_src4, cbf16x8* __restrict__ dst_hi,
+                                                              cbf16x8* __restrict__ dst_lo, int ld_dst8, const int32_t* __restrict__ full_of_comp,
+                                                              int Nc, int cols8) {
+    const int64_t total = (int64_t)Nc * cols8;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e / cols8), q = (int)(e - (int64_t)c * cols8);
+        const int r = full_of_comp[c];
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (r >= 0) {
+            const float4 a = src[(size_t)r * ld_src4 + 2 * q], b = src[(size_t)r * ld_src4 + 2 * q + 1];
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        }
+        cbf16x8 h, l;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { h[k] = (__bf16)v[k]; l[k] = (__bf16)(v[k] - (float)h[k]); }
+        dst_hi[(size_t)c * ld_dst8 + q] = h;
+        if (dst_lo) dst_lo[(size_t)c * ld_dst8 + q] = l;
+    }
+}
+__global__ __launch_bounds__(256) void check_padding32_kernel(const float4* __restrict__ src, int ld_src4, const int32_t* __restrict__ comp_of_full,
+                                                              int N, int cols4, int Z, int* __restrict__ flag, int bit) {
+    const int64_t total = (int64_t)N * cols4;
+    bool bad = false;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int r = (int)(e / cols4), q = (int)(e - (int64_t)r * cols4);
+        if (comp_of_full[r] != Z) continue;
+        const float4 v = src[(size_t)r * ld_src4 + q];
+        bad = bad || v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f;
+    }
+    if (bad) atomicOr(flag, bit);
+}
+
 // the promise behind an announcement, checked: every 16-byte piece of a PADDING row (comp_of_full[r] == Z) of the 16-bit operand must be
 // zero (sign bits aside); a piece that is not raises bit `bit` of *flag
 __global__ __launch_bounds__(256) void check_padding16_kernel(const u32x4* __restrict__ src, int ld_src16, const int32_t* __restrict__ comp_of_full,
@@ -109,6 +144,24 @@ int compact_gather_rows16(const void* src, int ld_src, void* dst, int ld_dst, co
               "compact_gather_rows16: rows of whole 16-byte pieces");
     hipLaunchKernelGGL(gather_rows16_kernel, dim3(grid_for_elems((int64_t)Nc * (cols / 8))), dim3(256), 0, s, static_cast<const u32x4*>(src),
                        ld_src / 8, static_cast<u32x4*>(dst), ld_dst / 8, full_of_comp, Nc, cols / 8);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+int compact_gather_rows_f32(const float* src, int ld_src, void* dst_hi, void* dst_lo, int ld_dst, const int32_t* full_of_comp, int Nc, int cols,
+                            hipStream_t s) {
+    ADN_CHECK(cols % 8 == 0 && ld_src % 4 == 0 && ld_dst % 8 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst_hi % 16) == 0 &&
+              ((uintptr_t)dst_lo % 16) == 0 && dst_hi, ADN_ERR_INVALID, "compact_gather_rows_f32: rows of whole 16-byte pieces");
+    hipLaunchKernelGGL(gather_rows_f32_kernel, dim3(grid_for_elems((int64_t)Nc * (cols / 8))), dim3(256), 0, s, reinterpret_cast<const float4*>(src),
+                       ld_src / 4, static_cast<cbf16x8*>(dst_hi), static_cast<cbf16x8*>(dst_lo), ld_dst / 8, full_of_comp, Nc, cols / 8);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
+int compact_check_padding32(const float* src, int ld_src, const int32_t* comp_of_full, int N, int cols, int Z, int* flag, int bit, hipStream_t s) {
+    ADN_CHECK(cols % 4 == 0 && ld_src % 4 == 0 && ((uintptr_t)src % 16) == 0, ADN_ERR_INVALID, "compact_check_padding32: rows of whole 16-byte pieces");
+    hipLaunchKernelGGL(check_padding32_kernel, dim3(grid_for_elems((int64_t)N * (cols / 4))), dim3(256), 0, s, reinterpret_cast<const float4*>(src),
+                       ld_src / 4, comp_of_full, N, cols / 4, Z, flag, bit);
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }

@@ -1541,6 +1541,53 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
     }
 }
 
+// The same for MANY slabs over a small result (round 6): the weight gradients of the LSTMs -- 250 x 1000 and 150 x 1000 outputs cut
+// into 21 - 31 K-slices so that their 8 - 12 tiles fill the device -- are 62 500 float4 per problem: one element per thread with
+// `splits` loads one behind the other is a chain of round trips (27 us for 63 MB, 2.5 TB/s).  Here a workgroup takes 64 elements
+// and its four thread rows take the slabs s = q, q + 4, ... each, four loads in flight per thread; the four partial sums meet in
+// LDS and are added in row order on top of C: one fixed order (row q's slabs ascending, then rows 0..3), no atomics.
+// blockIdx.y = problem.
+__global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const GemmParams p, int splits) {
+    __shared__ float4 part4[3][64];
+    const size_t slab4 = (size_t)p.M * p.ldc / 4;
+    const int n4 = p.N / 4, ld4 = p.ldc / 4;
+    const size_t work = (size_t)p.M * n4;
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const float4* part = reinterpret_cast<const float4*>(p.partial) + (size_t)blockIdx.y * splits * slab4;
+    float4* C = reinterpret_cast<float4*>(pick_group(p, blockIdx.y).C);
+    for (size_t e0 = (size_t)blockIdx.x * 64; e0 < work; e0 += (size_t)gridDim.x * 64) {
+        const size_t e = e0 + lane;
+        const bool ok = e < work;
+        const size_t i = ok ? (e / n4) * ld4 + (e % n4) : 0;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+            int s = q;
+            for (; s + 12 < splits; s += 16) {                    // four slabs of this row in flight
+                const float4 a = part[(size_t)s * slab4 + i], b = part[(size_t)(s + 4) * slab4 + i];
+                const float4 c = part[(size_t)(s + 8) * slab4 + i], d = part[(size_t)(s + 12) * slab4 + i];
+                v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w;
+                v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
+            }
+            for (; s < splits; s += 4) {
+                const float4 a = part[(size_t)s * slab4 + i];
+                v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+            }
+        }
+        if (q > 0) part4[q - 1][lane] = v;
+        __syncthreads();
+        if (q == 0 && ok) {
+            float4 r = p.accumulate ? C[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { const float4 w = part4[k][lane]; r.x += w.x; r.y += w.y; r.z += w.z; r.w += w.w; }
+            C[i] = r;
+        }
+        __syncthreads();
+    }
+}
+
 // The tail band of a persistent NN launch (gemm_f32.hip gemm_pp_try_impl: the row tiles whose tiles would open a nearly empty last
 // round of the 256 workgroups run K-split over the whole device instead): sums the band's partial slabs ([group][split][Mt][ldc],
 // Mt = p.M band rows, slice order: one fixed order) and applies the epilogue the persistent kernel would have -- bias, rectifier,
@@ -1591,6 +1638,12 @@ void launch_splitk_tail_epilogue(const GemmParams& p, int splits, int m_off, int
 
 void launch_splitk_reduce(const GemmParams& p, int splits, hipStream_t s) {
     const size_t n4 = (size_t)p.M * (p.N / 4);
+    static const bool no_wide = getenv("ADN_GEMM_NO_WIDE_REDUCE") != nullptr;      // (A/B)
+    if (splits >= 8 && !no_wide) {                     // many slabs: the slabs of an element spread over four thread rows
+        const int blocks = (int)std::min<size_t>(4096, (n4 + 63) / 64);
+        hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3((unsigned)blocks, (unsigned)p.ngroups), dim3(256), 0, s, p, splits);
+        return;
+    }
     const int blocks = (int)std::min<size_t>(2048, (n4 + 255) / 256);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p, splits);
 }

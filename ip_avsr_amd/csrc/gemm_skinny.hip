@@ -461,15 +461,32 @@ __global__ __launch_bounds__(256) void skinny_tn_kernel(const SkinnyParams p) {
     }
 }
 
+// (round 6: the 36 - 65 slabs of an element are spread over the workgroup's four thread rows, four loads in flight each -- one
+//  thread walking them all was a chain of round trips; the four partial sums meet in LDS and are added in row order: one fixed order)
 __global__ __launch_bounds__(256) void skinny_tn_reduce_kernel(const SkinnyParams p) {
+    __shared__ float part4[3][64];
     const SkinnyGroup g = pick(p, blockIdx.y);
     const float* part = p.partial + (size_t)blockIdx.y * p.splits * p.M * p.ldc;
     const size_t slab = (size_t)p.M * p.ldc;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < p.M * p.N; e += gridDim.x * 256) {
-        const size_t i = (size_t)(e / p.N) * p.ldc + (size_t)(e % p.N);
-        float v = p.accumulate ? g.C[i] : 0.f;
-        for (int s = 0; s < p.splits; ++s) v += part[(size_t)s * slab + i];
-        g.C[i] = v;
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6, total = p.M * p.N;
+    for (int e0 = blockIdx.x * 64; e0 < total; e0 += gridDim.x * 64) {
+        const int e = e0 + lane;
+        const bool ok = e < total;
+        const size_t i = ok ? (size_t)(e / p.N) * p.ldc + (size_t)(e % p.N) : 0;
+        float v = 0.f;
+        if (ok) {
+            int s = q;
+            for (; s + 12 < p.splits; s += 16) {
+                const float a = part[(size_t)s * slab + i], b = part[(size_t)(s + 4) * slab + i];
+                const float c = part[(size_t)(s + 8) * slab + i], d = part[(size_t)(s + 12) * slab + i];
+                v += a; v += b; v += c; v += d;
+            }
+            for (; s < p.splits; s += 4) v += part[(size_t)s * slab + i];
+        }
+        if (q > 0) part4[q - 1][lane] = v;
+        __syncthreads();
+        if (q == 0 && ok) g.C[i] = (p.accumulate ? g.C[i] : 0.f) + v + part4[0][lane] + part4[1][lane] + part4[2][lane];
+        __syncthreads();
     }
 }
 
@@ -652,7 +669,7 @@ int gemm_skinny_try(const GemmArgs* gs, int n, hipStream_t stream, bool* used, b
         const dim3 grid = p.xcd_map ? dim3((unsigned)round_up(splits, 8), (unsigned)mblocks, (unsigned)n) : dim3((unsigned)mblocks, (unsigned)splits, (unsigned)n);
         if (planes) hipLaunchKernelGGL((skinny_tn_kernel<true>), grid, dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((skinny_tn_kernel<false>), grid, dim3(256), 0, stream, p);
-        hipLaunchKernelGGL(skinny_tn_reduce_kernel, dim3((unsigned)std::min(256, cdiv(g.M * g.N, 256)), (unsigned)n), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(skinny_tn_reduce_kernel, dim3((unsigned)std::min(1024, cdiv(g.M * g.N, 64)), (unsigned)n), dim3(256), 0, stream, p);
         ADN_HIP_CHECK(hipGetLastError());
         for (int k = 0; k < n; ++k)
             if (gs[k].C16 && g.ldc % 8 == 0) ADN_TRY(to_bf16(gs[k].C, gs[k].C16, (size_t)g.M * g.ldc, stream));

