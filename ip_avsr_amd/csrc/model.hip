@@ -242,6 +242,7 @@ struct adn_model {
     int lastB = 0, lastT = 0;
     // frame compaction: lengths announced by adn_set_batch_lengths (host), the row maps of the batch on the device, Nc = valid + 1
     std::vector<int32_t> batch_lens, maps_lens;
+    std::vector<const float*> ones_cols;      // matrices of the slab whose first pad column holds 1.0 (bias gradients on the dW GEMM)
     std::vector<int32_t> call_lens;          // the lengths of the call in flight: the announcement, or read off a host mask
     bool call_lens_auto = false;             // ... read off the mask: nobody promised zero padding frames, the device looks first
     bool auto_compact = true;                // adn_set_auto_compaction
@@ -504,6 +505,7 @@ size_t carve(adn_model* m, char* base, int B, int T, bool host_inputs) {
     Carver cv{base};
     m->shadows.clear();
     m->fp32_stale.clear();
+    m->ones_cols.clear();
     const size_t N = (size_t)B * T;
     const int ldh = m->ldh, ldg = m->ldg;
     m->mask_bt = cv.take<uint8_t>(N);
@@ -583,6 +585,42 @@ size_t carve(adn_model* m, char* base, int B, int T, bool host_inputs) {
     return cv.cursor;
 }
 
+// Bias gradients on the weight-gradient GEMM.  db_l = 1^T dZ_l is one more row of dW_l = A_l^T dZ_l when A_l (the layer's input: the
+// compacted stream input, or the activation below) carries a column of ones -- and it has a place for one: leading dimensions are
+// rounded up to 64, the first pad column of a width that is no multiple of 64 is free, and [W_l | b_l] are adjacent in the flat
+// buffers (build_params: b_l IS row in_w of W_l's matrix).  The MFMAs sum the column for nothing (1200 / 2000 / 1000 / 500 rows
+// + 1 fill the same 256-row tiles), where the input-gradient GEMM of the layer above paid ~60 us of epilogue VALU + shuffles for
+// its fused column sums at the bench size.  What keeps the column alive: every writer of these matrices stores columns < width
+// only (GEMM epilogues and the gather in whole 8-column groups: width % 8 == 0 is required), whole-buffer conversions
+// (refresh / restore_fp32) map 1.0 -> hi 1.0, lo 0 -> 1.0, and no reader depends on it being ZERO -- the kernels mask k >= K
+// in registers (gemm_bf16.hip header; "the columns of A behind K may hold anything").  The bf16 arithmetic only: there the sum runs
+// over the bf16 dZ the weight-gradient GEMM reads anyway; the parity-grade arithmetics (bf16x3, mixed) keep the sums of the fp32
+// accumulators (measured on both: 5.87 -> 5.89 ms and nothing -- and their bits, which the accuracy runs of tests/test_gpu_accuracy.py
+// are pinned on, stay what they were).  ADN_NO_BIAS_ON_DW=1 restores the fused / separate column sums everywhere.
+static bool bias_on_dw_enabled(const adn_model* m) {
+    static const bool off = getenv("ADN_NO_BIAS_ON_DW") != nullptr;
+    return !off && m->bf16();
+}
+static bool ones_col_fits(int width) { return width % 8 == 0 && ld_of(width) > width; }
+static bool has_ones_col(const adn_model* m, const float* A) {
+    for (const float* p : m->ones_cols) if (p == A) return true;
+    return false;
+}
+__global__ __launch_bounds__(256) void fill_ones_col_kernel(float* __restrict__ f32, uint16_t* __restrict__ hi, int ld, int64_t rows, int col) {
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
+        f32[r * ld + col] = 1.f;
+        if (hi) hi[r * ld + col] = 0x3F80u;          // bf16(1.0); the lo plane keeps its zero
+    }
+}
+static int fill_ones_col(adn_model* m, float* A, int width, int64_t rows) {
+    if (!A || !ones_col_fits(width)) return ADN_OK;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((rows + 255) / 256, 1024));
+    hipLaunchKernelGGL(fill_ones_col_kernel, dim3(grid), dim3(256), 0, m->stream, A, static_cast<uint16_t*>(m->shadow_of(A)), ld_of(width), rows, width);
+    ADN_HIP_CHECK(hipGetLastError());
+    m->ones_cols.push_back(A);
+    return ADN_OK;
+}
+
 int ensure_workspace(adn_model* m, int B, int T) {
     if (B == m->wsB && T == m->wsT && m->slab) return ADN_OK;
     const size_t need = carve(m, nullptr, B, T, true);
@@ -594,6 +632,11 @@ int ensure_workspace(adn_model* m, int B, int T) {
     }
     carve(m, m->slab, B, T, true);
     ADN_HIP_CHECK(hipMemsetAsync(m->slab, 0, need, m->stream));   // pad columns must read as zero
+    if (bias_on_dw_enabled(m))                                    // ... but for the ones behind the inputs of the encoder layers
+        for (auto& st : m->st) {
+            ADN_TRY(fill_ones_col(m, st.xc, st.cfg.input_dim, (int64_t)B * T));
+            for (int l = 0; l + 1 < st.cfg.n_enc; ++l) ADN_TRY(fill_ones_col(m, st.act[l], st.cfg.enc_units[l], (int64_t)B * T));
+        }
     m->wsB = B; m->wsT = T;
     return ADN_OK;
 }
@@ -2208,12 +2251,14 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
         const int n = (int)sis.size();
         const int Ne = m->compact ? m->Nc : N;       // rows of the encoder's matrices (compact.hip)
         GemmArgs gws[kMaxGemmGroups], gxs[kMaxGemmGroups];
+        // db_l as row in_w of dW_l where the layer's input carries its column of ones (ensure_workspace)
+        auto bias_rides = [&](const StreamState& st, int l) { return has_ones_col(m, l > 0 ? st.act[l - 1] : st.x); };
         for (int q = 0; q < n; ++q) {
             StreamState& st = m->st[sis[q]]; Walk& w = walk[sis[q]];
             const int l = w.L - 1 - depth;
             const int out_w = st.cfg.enc_units[l], in_w = st.enc_in[l];
             GemmArgs& gw = gws[q];
-            gw.layout = GEMM_TN; gw.M = in_w; gw.N = out_w; gw.K = Ne; gw.A = l > 0 ? st.act[l - 1] : st.x;
+            gw.layout = GEMM_TN; gw.M = in_w + (bias_rides(st, l) ? 1 : 0); gw.N = out_w; gw.K = Ne; gw.A = l > 0 ? st.act[l - 1] : st.x;
             gw.lda = l > 0 ? ld_of(in_w) : st.ldx;
             gw.B = w.dZ; gw.ldb = w.lddz; gw.C = m->G(st.encW[l]); gw.ldc = ld_of(out_w); gw.accumulate = 1;
             mgemm_prepare(m, gw, false);
@@ -2224,7 +2269,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             StreamState& st = m->st[sis[q]]; Walk& w = walk[sis[q]];
             const int l = w.L - 1 - depth;
             const int out_w = st.cfg.enc_units[l];
-            if (!w.bias_done) {           // b_l did not ride on the input-gradient GEMM of the layer above: summed from dZ now
+            if (!w.bias_done && !bias_rides(st, l)) {           // b_l rode neither on dW_l nor on the input-gradient GEMM of the layer above: summed from dZ now
                 if ((m->bf16() || m->planes()) && (w.dZ == st.dE || w.dZ == st.dEc) && bias_sums.n < 8) col_sum_batch_add(bias_sums, w.dZ, w.lddz, Ne, out_w, m->G(st.encb[l]));   // (dE / dEc hold their fp32 values until the step ends: the delta layer wrote them, nothing reuses them)
                 else ADN_TRY(col_sum(w.dZ, w.lddz, Ne, out_w, m->G(st.encb[l]), 1, m->stream));
             }
@@ -2247,9 +2292,11 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             gx.layout = GEMM_NT; gx.M = Ne; gx.N = in_w; gx.K = out_w; gx.A = w.dZ; gx.lda = w.lddz;
             gx.B = m->P(st.encW[l]); gx.ldb = ld_of(out_w); gx.C = dst; gx.ldc = st.ping_ld;
             gx.Y = st.act[l - 1]; gx.ldy = ld_of(in_w); gx.act_grad = m->act_code(st.cfg.enc_act[l - 1]);
-            gx.colsum = m->G(st.encb[l - 1]); gx.colsum_done = &w.bias_done;     // db_{l-1} rides on this GEMM
-            gx.colsum_ws = st.colsum_ws + (size_t)l * st.colsum_ws_floats; gx.colsum_ws_floats = st.colsum_ws_floats;
-            gx.colsum_batch = &bias_sums;
+            if (!bias_rides(st, l - 1)) {
+                gx.colsum = m->G(st.encb[l - 1]); gx.colsum_done = &w.bias_done;     // db_{l-1} rides on this GEMM
+                gx.colsum_ws = st.colsum_ws + (size_t)l * st.colsum_ws_floats; gx.colsum_ws_floats = st.colsum_ws_floats;
+                gx.colsum_batch = &bias_sums;
+            }
             mgemm_prepare(m, gx, /*lean=*/true);
         }
         if (!any_dx) return ADN_OK;                 // (streams of one group share l == 0)
@@ -2258,7 +2305,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             StreamState& st = m->st[sis[q]]; Walk& w = walk[sis[q]];
             const int l = w.L - 1 - depth, in_w = st.enc_in[l];
             float* dst = (w.dZ == st.pingA) ? st.pingB : st.pingA;
-            if (!w.bias_done && shadows_on(m) && !m->keep_fp32 && in_w % 4 == 0 && m->shadow_of(dst)) {
+            if (!w.bias_done && !bias_rides(st, l - 1) && shadows_on(m) && !m->keep_fp32 && in_w % 4 == 0 && m->shadow_of(dst)) {
                 // fp32 dZ was skipped but the fused column sum did not run: cannot happen for in_w % 4 == 0
                 set_error("internal: lean dZ without fused bias gradient"); return ADN_ERR_STATE;
             }
