@@ -344,10 +344,20 @@ def rooflines(prof, steps, prof_elapsed, precision, hbm_measured, traffic_file, 
                          "algorithmic_bytes_per_unit": unit,
                          "avg_launch_us": 1e3 * e["ms"] / e["launches"],
                          "share_of_step": e["ms"] / (1e3 * prof_elapsed)}
+            # length buckets: the launches run sum_k T_k steps of B / nb utterances per LSTM instead of T steps of B -- `achieved` /
+            # `frac` price the bytes of the steps that ran; the figure over the reference's B x T frames (SURVEY 8d's unit: 5 LSTMs
+            # x T steps of B utterances per train step) is reported beside it, like the encoders' algorithmic_*_BxT
+            bxt = 5.0 * T_MAX * unit * steps
+            if e["bytes"] < 0.99 * bxt:
+                out[name]["executed_share_of_BxT_bytes"] = e["bytes"] / bxt
+                out[name]["algorithmic_GBs_BxT"] = bxt / (e["ms"] * 1e-3) / 1e9
+                out[name]["algorithmic_frac_BxT"] = out[name]["algorithmic_GBs_BxT"] / PEAK_HBM_GBS
     for key, name in (("roofline_lstm_fwd", "lstm_fwd_frac"), ("roofline_lstm_bwd", "lstm_bwd_frac")):
         if key in out:                      # (inside `roofline`: the record the driver keeps holds this object whole)
             out["roofline"][name] = out[key]["frac"]
             out["roofline"][name + "_of_measured_copy"] = out[key]["frac_of_measured"]
+            if "algorithmic_frac_BxT" in out[key]:
+                out["roofline"][name + "_BxT"] = out[key]["algorithmic_frac_BxT"]
     out["kernel_ms_per_step"] = {k: v["ms"] / steps for k, v in prof.items()}
     return out
 
@@ -366,6 +376,26 @@ def compaction_check(model, xs, m_d, lens, precision):
     dp = float(np.abs(padded - compact).max())
     assert dp <= tol, "frame compaction changed the probabilities by %.3e (> %.1e) in %s" % (dp, tol, precision)
     return {"max_abs_dp_padded_vs_compacted": dp, "tolerance": tol, "encoder_rows_compacted": rows, "dtype": precision}
+
+
+def bucket_check(model, xs, y, m_d, lens, precision):
+    """Outside every timed region: the bench batch's gradients from ONE train step over length buckets and ONE over B x T rows
+    (include/adenet.h adn_set_length_buckets), largest difference relative to each tensor's scale asserted at the order-of-summation
+    grade -- the step that is timed computes the loss and the gradients of the unbucketed step."""
+    res = []
+    for on in (False, True):
+        model.set_length_buckets(on)
+        model.set_batch_lengths(lens)
+        loss = model.compute_grads(xs, y, m_d, THETA)
+        res.append((loss, model.get_grads_dict(), model.bucket_rows()))
+    (l0, g0, r0), (l1, g1, r1) = res
+    assert r0 == 0
+    scale = max(float(np.abs(v).max()) for v in g0.values())
+    worst = max(float(np.abs(g1[k] - g0[k]).max() / max(float(np.abs(g0[k]).max()), 1e-3 * scale)) for k in g0)
+    tol = 2e-4
+    assert abs(l1 - l0) <= 1e-5 * abs(l0) and worst <= tol, "length buckets changed the step: loss %.7f / %.7f, gradients %.2e" % (l1, l0, worst)
+    return {"time_major_rows": int(r1), "worst_gradient_difference_of_scale": float(worst), "tolerance": tol, "loss_bucketed": float(l1),
+            "loss_BxT": float(l0), "dtype": precision}
 
 
 def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
@@ -477,6 +507,7 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
         step()
     elapsed = timed(args.steps)
     encoder_rows = (model.compact_rows() or int(np.asarray(mask).size)) if on_gpu else None      # (of the step just run)
+    bucket_rows = model.bucket_rows() if on_gpu else 0                                           # (ditto: its time-major rows, 0 = B x T)
     # per-kernel-class timing: a SECOND pass of the same K steps with HIP events recorded on the model's stream
     # around every launch (sequence of T launches for the recurrent step kernels).  Kept out of the timed region
     # above because ~700 event records per step cost ~15 % of a step.
@@ -580,6 +611,11 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
                                                  "padded_rows": int(np.asarray(mask).size), "valid_frames": int(batch_lens.sum())}
             if compaction and world == 1:
                 out["config"]["frame_compaction"]["check"] = compaction_check(model, xs, m_d, batch_lens, args.precision)
+            # length buckets (the recurrent side of the compacted step): what the timed steps ran over, and -- once, untimed -- that it
+            # is the unbucketed step's loss and gradients
+            out["config"]["length_buckets"] = {"on": bucket_rows > 0, "time_major_rows": bucket_rows, "of_BxT_rows": int(np.asarray(mask).size)}
+            if compaction and world == 1 and bucket_rows > 0:
+                out["config"]["length_buckets"]["check"] = bucket_check(model, xs, y, m_d, batch_lens, args.precision)
         if on_gpu and world == 1 and compaction:
             # the same step with the encoders over all B x T rows (rounds 1-4, and this round before the compaction)
             announce["lens"] = None

@@ -303,6 +303,20 @@ int adn_get_compact_rows(const adn_model* m);
 int adn_set_relu_grad_at_zero(adn_model* m, float value);
 /* lengths read off a host mask (see above): on by default */
 int adn_set_auto_compaction(adn_model* m, int on);
+/* Length buckets (round 6; on by default).  A COMPACTED train step (adn_compute_grads on a batch whose lengths are known, above) also
+ * drops most padding frames behind the delta layer: the utterances, sorted by length inside the library, are cut into 2 - 4
+ * equal buckets, each as long as its longest utterance, laid one behind the other along the time axis of every time-major tensor
+ * -- the recurrent side's GEMMs, sums and loss walk ~Sum(len) / 0.85 rows instead of B T, the weight-stationary LSTM kernels run
+ * one launch entry per (LSTM, bucket).  Same loss and gradients as the padded step (a padding frame contributes zero to both;
+ * the sums run in another order: tests/test_gpu_buckets.py); taken when it saves >= 10 % of the rows and the model has nothing that
+ * walks the time-major tensors frame by frame outside the kernels that know the layout (no dropout, no last-timestep head, no
+ * adaptive fusion, no auxiliary inputs; H <= 256; not in deterministic mode).  Forward-only calls never bucket (the reference's
+ * val_fn returns probabilities at padding frames too); adn_read_probs after a bucketed train step is refused for the same reason.
+ * 0 keeps every train step on the B x T layout; ADN_NO_LENGTH_BUCKETS=1 does the same for the process. */
+int adn_set_length_buckets(adn_model* m, int on);
+/* rows of the time-major tensors in the last call when it ran over length buckets (Bb x Tt: the buckets' lengths + one spare block
+ * between two of them, times the utterances per bucket), else 0 */
+int adn_get_bucket_rows(const adn_model* m);
 /* test hook: writes `value` into the current device's LSTM-exchange error word (what a weight-stationary LSTM kernel raises
  * when a workgroup gave up waiting for its partners; 0 clears it).  Lets a test follow the word's way through the gradient
  * tail, the data-parallel all-reduce and the optimiser's skip without provoking a real time-out. */

@@ -113,6 +113,8 @@ _SIGNATURES = {
     "adn_set_batch_lengths": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int]),
     "adn_get_compact_rows": (C.c_int, [C.c_void_p]),
     "adn_set_auto_compaction": (C.c_int, [C.c_void_p, C.c_int]),
+    "adn_set_length_buckets": (C.c_int, [C.c_void_p, C.c_int]),
+    "adn_get_bucket_rows": (C.c_int, [C.c_void_p]),
     "adn_set_relu_grad_at_zero": (C.c_int, [C.c_void_p, C.c_float]),
     "adn_get_deterministic": (C.c_int, []),
     "adn_debug_raise_exchange_error": (C.c_int, [C.c_int]),

@@ -214,8 +214,9 @@ int dot_all(const float* a, int lda, const float* b, int ldb, int rows, int cols
 int act_backward(float* dy, int ld_dy, const float* y, int ld_y, int rows, int cols, int act, hipStream_t s);
 // mask (B,T) uint8 batch-major -> (T,B) time-major; total[0] = number of valid frames
 // lens / flag (optional): raises `bit` of *flag unless the mask is the prefix mask of lens (mask[b][t] != 0 <=> t < lens[b])
+// tm_row0 / tm_T / tm_stride (optional, length buckets -- DeltaJob): the time-major copy goes to row tm_row0[b] + t tm_stride, t < tm_T[b]
 int mask_prepare(const uint8_t* mask_bt, uint8_t* mask_tb, int B, int T, float* total, hipStream_t s, const int32_t* lens = nullptr,
-                 int* flag = nullptr, int bit = 0);
+                 int* flag = nullptr, int bit = 0, const int32_t* tm_row0 = nullptr, const int32_t* tm_T = nullptr, int tm_stride = 0);
 // rows [0,B) of dst = vec (broadcast of a (1,H) init vector)
 int broadcast_rows(const float* vec, float* dst, int ld, int rows, int cols, hipStream_t s);
 // h[r][:] = hid, c[r][:] = cell for r < rows (pad columns 0), h16 = optional bf16 copy of h
@@ -228,6 +229,9 @@ struct DeltaJob {
     // frame compaction (compact.hip): the batch-major side is the compact matrix -- frame (b, t) in row row_map[b T + t].  Backward:
     // rows mapped to zrow (the padding frames) are summed per utterance into pad_partial[b][F] instead of stored
     const int32_t* row_map = nullptr; int zrow = -1; float* pad_partial = nullptr;
+    // length buckets (model.hip, TmPlan): the time-major side keeps frame (b, t) in row tm_row0[b] + t * tm_stride for t < tm_T[b];
+    // later frames of the utterance have no row (forward: not stored; backward: their gradient is zero).  Null: row t B + b.
+    const int32_t* tm_row0 = nullptr; const int32_t* tm_T = nullptr; int tm_stride = 0;
 };
 struct LstmInitJob { const float* hid; const float* cell; float* h; float* c; void* h16; };
 int delta_forward_batch(const DeltaJob* jobs, int n, int B, int T, int theta, hipStream_t s);    // dst = [x | dx | ddx] (append) or a copy
@@ -237,7 +241,8 @@ int lstm_init_state_batch(const LstmInitJob* jobs, int n, int ld, int rows, int 
 //   z (T*B rows, time-major, ldz) -> probs_bt (B,T,C) batch-major dense (may be null),
 //   row_loss[r] = -mask*log softmax(softmax(z))[y]  (if y != null), dz (may be null)
 int softmax_loss(const float* z, int ldz, int B, int T, int C, const uint8_t* mask_tb, const int32_t* y_bt,
-                 const float* total, float* probs_bt, float* row_loss, float* dz, int lddz, hipStream_t s, void* dz16 = nullptr);
+                 const float* total, float* probs_bt, float* row_loss, float* dz, int lddz, hipStream_t s, void* dz16 = nullptr,
+                 const int32_t* bt_of_row = nullptr, int table_rows = 0);   // (bt_of_row: the frame b T + t of each of table_rows rows, -1 = none)
 // out[0] = (sum_i v[i]) / total[0], fixed summation order
 int reduce_loss(const float* v, int n, const float* total, float* out, hipStream_t s);
 // p16: optional bf16 shadow of the parameters, written with the update
@@ -331,8 +336,13 @@ struct LstmStep {          // one LSTM instance taking part in a (possibly multi
     float* dbias = nullptr;      // [ldg]  += sum_{t,b} dG
     float* dhid_init = nullptr;  // [ldh]  += sum_b dh_carry
     float* dcell_init = nullptr; // [ldh]  += sum_b dc_state
+    // optional (weight-stationary kernels at H <= 256 only -- lstm_cluster.hip): this entry is one LENGTH BUCKET of an LSTM (model.hip,
+    // TmPlan): its pointers name the bucket's first row, it runs T_own steps (0: the launch's T) over mask_own ([T_own][B] bytes;
+    // null: the launch's mask).  Every other kernel family rejects such entries (lstm_forward / lstm_backward check).
+    int T_own = 0;
+    const uint8_t* mask_own = nullptr;
 };
-constexpr int kMaxLstmPerLaunch = 8;
+constexpr int kMaxLstmPerLaunch = 12;      // (3 stream LSTMs x 4 length buckets; the launch descriptors stay below the 4 KB of kernel arguments)
 // runs all T steps of n (<= kMaxLstmPerLaunch) independent LSTMs of identical (B,T,H) concurrently
 int lstm_forward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, int precision, hipStream_t s);
 // W [H][ldg] fp32 -> out [ldg][ldk] bf16 (ldk = round_up(H,32)), zero padded
@@ -362,6 +372,10 @@ bool lstm_forward_folds_projection(const LstmStep* l, int n, int B, int T, int H
 size_t lstm_win_frag_elems(int Kx, int H);
 int lstm_pack_win_frags(int n, const float* const* W_in, void* const* out, int Kx, int H, hipStream_t s);
 size_t lstm_cluster_xchg_bytes(int B, int H);
+int lstm_cluster_cus();               // CUs the weight-stationary launches are sized for (ADN_LSTM_CUS)
+// whether lstm_forward / lstm_backward would run these entries on a kernel that takes LstmStep::T_own / mask_own (length buckets:
+// the weight-stationary kernels at H <= 256 in the bf16 and bf16x3 arithmetics, outside the deterministic mode)
+bool lstm_takes_length_buckets(const LstmStep* l, int n, int B, int T, int H, int precision, bool backward);
 int lstm_forward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);
 bool lstm_cluster_x3_supported(const LstmStep* l, int n, int B, int T, int H);
 int lstm_forward_cluster_x3(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, hipStream_t s);

@@ -50,6 +50,9 @@ __device__ __forceinline__ void delta_fwd_body(const DeltaJob& j, int B, int T, 
     const int fl = threadIdx.x & 31, ts = threadIdx.x >> 5;
     const int f = f0 + fl;
     const bool fv = f < F;
+    // time-major row of frame t: tm0 + t * tms for t < Tw (length buckets), the plain t B + b otherwise
+    const size_t tm0 = j.tm_row0 ? (size_t)j.tm_row0[b] : (size_t)b, tms = j.tm_row0 ? (size_t)j.tm_stride : (size_t)B;
+    const int Tw = j.tm_T ? j.tm_T[b] : T;
     for (int t = ts; t < T; t += 8) {
         const size_t row = j.row_map ? (size_t)j.row_map[(size_t)b * T + t] : (size_t)b * T + t;
         const float v = fv ? in[row * ld_in + f] : 0.f;
@@ -59,10 +62,10 @@ __device__ __forceinline__ void delta_fwd_body(const DeltaJob& j, int B, int T, 
     }
     __syncthreads();
     if (!j.append) {
-        for (int t = ts; t < T; t += 8)
+        for (int t = ts; t < Tw; t += 8)
             if (fv) {
                 const float v = xs[(theta + t) * kDeltaFC + fl];
-                const size_t o = ((size_t)t * B + b) * ld_out + f;
+                const size_t o = (tm0 + (size_t)t * tms) * ld_out + f;
                 out[o] = v;
                 if (out16) delta_put16(out16, out16lo, o, v);
             }
@@ -83,8 +86,8 @@ __device__ __forceinline__ void delta_fwd_body(const DeltaJob& j, int B, int T, 
         float acc = 0.f;
 #pragma unroll
         for (int k = 1; k <= (TH ? TH : theta); ++k) acc += (c[k * kDeltaFC] - c[-k * kDeltaFC]) * (0.5f / (float)k);
-        if (fv) {
-            const size_t o = ((size_t)t * B + b) * ld_out;
+        if (fv && t < Tw) {
+            const size_t o = (tm0 + (size_t)t * tms) * ld_out;
             const float x0 = xs[(theta + t) * kDeltaFC + fl], x1 = c[0];
             out[o + f] = x0;
             out[o + F + f] = x1;
@@ -129,6 +132,9 @@ __device__ __forceinline__ void delta_bwd_body(const DeltaJob& j, int B, int T, 
     const int fl = threadIdx.x & 31, ts = threadIdx.x >> 5;
     const int f = f0 + fl;
     const bool fv = f < F;
+    const size_t tm0 = j.tm_row0 ? (size_t)j.tm_row0[b] : (size_t)b, tms = j.tm_row0 ? (size_t)j.tm_stride : (size_t)B;
+    const int Tw = j.tm_T ? j.tm_T[b] : T;       // (frames t >= Tw have no time-major row: zero gradient)
+    auto tmrow = [&](int t) { return (tm0 + (size_t)t * tms) * ld_out; };
     float pad = 0.f;                  // this lane's share of the padding frames' gradient (row_map: rows mapped to zrow)
     auto put = [&](int t, float v) {
         size_t row = (size_t)b * T + t;
@@ -142,23 +148,23 @@ __device__ __forceinline__ void delta_bwd_body(const DeltaJob& j, int B, int T, 
     };
     if (!j.append) {
         for (int t = ts; t < T; t += 8)
-            if (fv) put(t, dout[((size_t)t * B + b) * ld_out + f]);
+            if (fv) put(t, t < Tw ? dout[tmrow(t) + f] : 0.f);
     } else {
         for (int k = ts; k < theta; k += 8) {
             g2[k * kDeltaFC + fl] = 0.f; g2[(theta + T + k) * kDeltaFC + fl] = 0.f;
             r1[k * kDeltaFC + fl] = 0.f; r1[(theta + T + k) * kDeltaFC + fl] = 0.f;
         }
         for (int t = ts; t < T; t += 8)
-            g2[(theta + t) * kDeltaFC + fl] = fv ? dout[((size_t)t * B + b) * ld_out + 2 * F + f] : 0.f;
+            g2[(theta + t) * kDeltaFC + fl] = (fv && t < Tw) ? dout[tmrow(t) + 2 * F + f] : 0.f;
         __syncthreads();
         for (int t = ts; t < T; t += 8) {
-            const float g1 = fv ? dout[((size_t)t * B + b) * ld_out + F + f] : 0.f;
+            const float g1 = (fv && t < Tw) ? dout[tmrow(t) + F + f] : 0.f;
             r1[(theta + t) * kDeltaFC + fl] = g1 + delta_adjoint_at<TH>(g2 + (theta + t) * kDeltaFC + fl, t, T, theta);
         }
         __syncthreads();
         for (int t = ts; t < T; t += 8) {
             if (fv) {
-                const float g0 = dout[((size_t)t * B + b) * ld_out + f];
+                const float g0 = t < Tw ? dout[tmrow(t) + f] : 0.f;
                 put(t, g0 + delta_adjoint_at<TH>(r1 + (theta + t) * kDeltaFC + fl, t, T, theta));
             }
         }
@@ -781,7 +787,8 @@ int act_backward(float* dy, int ld_dy, const float* y, int ld_y, int rows, int c
 // (lens: the lengths the caller announced for this batch -- frame compaction, compact.hip -- which the mask must agree with)
 __global__ __launch_bounds__(1024) void mask_prepare_kernel(const uint8_t* __restrict__ m_bt, uint8_t* __restrict__ m_tb,
                                                             int B, int T, float* __restrict__ total, const int32_t* __restrict__ lens,
-                                                            int* __restrict__ flag, int bit) {
+                                                            int* __restrict__ flag, int bit, const int32_t* __restrict__ tm_row0,
+                                                            const int32_t* __restrict__ tm_T, int tm_stride) {
     __shared__ int part[16];
     const int n = B * T;
     const bool vec = (reinterpret_cast<uintptr_t>(m_bt) & 15) == 0;
@@ -792,15 +799,23 @@ __global__ __launch_bounds__(1024) void mask_prepare_kernel(const uint8_t* __res
         else for (int k = 0; k < 16; ++k) v[k] = e0 + k < n ? m_bt[e0 + k] : 0;
         int b = e0 / T, t = e0 - b * T;
         int len = lens ? lens[min(b, B - 1)] : 0;
+        // (length buckets, model.hip TmPlan: frame (b, t) lives in row tm_row0[b] + t tm_stride while t < tm_T[b]; rows no frame
+        //  lives in are zeroed by whoever installs the tables)
+        int r0 = tm_row0 ? tm_row0[min(b, B - 1)] : 0, tw = tm_T ? tm_T[min(b, B - 1)] : T;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             if (e0 + k < n) {
                 const int u = v[k] ? 1 : 0;
-                m_tb[(size_t)t * B + b] = (uint8_t)u;
+                if (!tm_row0) m_tb[(size_t)t * B + b] = (uint8_t)u;
+                else if (t < tw) m_tb[(size_t)r0 + (size_t)t * tm_stride] = (uint8_t)u;
                 cnt += u;
                 if (lens) bad |= u ^ (t < len ? 1 : 0);
             }
-            if (++t == T) { t = 0; ++b; if (lens) len = lens[min(b, B - 1)]; }
+            if (++t == T) {
+                t = 0; ++b;
+                if (lens) len = lens[min(b, B - 1)];
+                if (tm_row0) { r0 = tm_row0[min(b, B - 1)]; tw = tm_T[min(b, B - 1)]; }
+            }
         }
     }
     if (bad) atomicOr(flag, bit);
@@ -815,8 +830,10 @@ __global__ __launch_bounds__(1024) void mask_prepare_kernel(const uint8_t* __res
     }
 }
 
-int mask_prepare(const uint8_t* mask_bt, uint8_t* mask_tb, int B, int T, float* total, hipStream_t s, const int32_t* lens, int* flag, int bit) {
-    hipLaunchKernelGGL(mask_prepare_kernel, dim3(1), dim3(1024), 0, s, mask_bt, mask_tb, B, T, total, flag ? lens : nullptr, flag, bit);
+int mask_prepare(const uint8_t* mask_bt, uint8_t* mask_tb, int B, int T, float* total, hipStream_t s, const int32_t* lens, int* flag, int bit,
+                 const int32_t* tm_row0, const int32_t* tm_T, int tm_stride) {
+    hipLaunchKernelGGL(mask_prepare_kernel, dim3(1), dim3(1024), 0, s, mask_bt, mask_tb, B, T, total, flag ? lens : nullptr, flag, bit,
+                       tm_row0, tm_T, tm_stride);
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }
@@ -910,24 +927,31 @@ __global__ __launch_bounds__(256) void softmax_loss_kernel(const float* __restri
                                                            const int32_t* __restrict__ y_bt,
                                                            const float* __restrict__ total,
                                                            float* __restrict__ probs_bt, float* __restrict__ row_loss,
-                                                           float* __restrict__ dz, int lddz, __bf16* __restrict__ dz16) {
-    const int rows = B * T;
+                                                           float* __restrict__ dz, int lddz, __bf16* __restrict__ dz16,
+                                                           const int32_t* __restrict__ bt_of_row, int rows) {
     const int r = (blockIdx.x * 256 + threadIdx.x) / G;
     const int c = threadIdx.x % G;
     if (r >= rows) return;                 // whole groups exit together (256 % G == 0)
-    const int t = r / B, b = r % B;
+    // the frame b T + t this row holds: t B + b -> (b, t), or what the table says (length buckets, model.hip TmPlan; -1 = a row no
+    // frame lives in: its gradient row must read as zero, it has no probabilities and no loss)
+    const int bt = bt_of_row ? bt_of_row[r] : (r % B) * T + r / B;
     const bool cv = c < C;
+    if (bt < 0) {
+        if (row_loss && c == 0) row_loss[r] = 0.f;
+        if (dz && cv) { dz[(size_t)r * lddz + c] = 0.f; if (dz16) dz16[(size_t)r * lddz + c] = (__bf16)0.f; }
+        return;
+    }
     const float zc = cv ? z[(size_t)r * ldz + c] : -INFINITY;
     const float m1 = group_max<G>(zc);
     const float e1 = cv ? expf(zc - m1) : 0.f;
     const float p = e1 / group_sum<G>(e1);
-    if (probs_bt && cv) probs_bt[((size_t)b * T + t) * C + c] = p;
+    if (probs_bt && cv) probs_bt[(size_t)bt * C + c] = p;
     if (!y_bt) return;
     const float m2 = group_max<G>(cv ? p : -INFINITY);
     const float e2 = cv ? expf(p - m2) : 0.f;
     const float s2 = group_sum<G>(e2);
     const float q = e2 / s2;
-    const int y = y_bt[(size_t)b * T + t];
+    const int y = y_bt[bt];
     const float msk = mask_tb[r] ? 1.f : 0.f;
     if (row_loss && c == y) row_loss[r] = msk * -(p - m2 - logf(s2));
     if (dz) {
@@ -939,16 +963,17 @@ __global__ __launch_bounds__(256) void softmax_loss_kernel(const float* __restri
 }
 
 int softmax_loss(const float* z, int ldz, int B, int T, int C, const uint8_t* mask_tb, const int32_t* y_bt,
-                 const float* total, float* probs_bt, float* row_loss, float* dz, int lddz, hipStream_t s, void* dz16) {
+                 const float* total, float* probs_bt, float* row_loss, float* dz, int lddz, hipStream_t s, void* dz16,
+                 const int32_t* bt_of_row, int table_rows) {
     ADN_CHECK(C >= 1 && C <= ADN_MAX_CLASSES, ADN_ERR_INVALID, "softmax: unsupported number of classes");
-    const int rows = B * T;
+    const int rows = bt_of_row ? table_rows : B * T;
     ProfScope prof(PROF_SOFTMAX_LOSS, 0.0, 4.0 * rows * (double)C * (dz ? 3.0 : 2.0), s);
     if (C <= 32) {
         hipLaunchKernelGGL(softmax_loss_kernel<32>, dim3(cdiv(rows, 8)), dim3(256), 0, s, z, ldz, B, T, C, mask_tb,
-                           y_bt, total, probs_bt, row_loss, dz, lddz, reinterpret_cast<__bf16*>(dz16));
+                           y_bt, total, probs_bt, row_loss, dz, lddz, reinterpret_cast<__bf16*>(dz16), bt_of_row, rows);
     } else {
         hipLaunchKernelGGL(softmax_loss_kernel<64>, dim3(cdiv(rows, 4)), dim3(256), 0, s, z, ldz, B, T, C, mask_tb,
-                           y_bt, total, probs_bt, row_loss, dz, lddz, reinterpret_cast<__bf16*>(dz16));
+                           y_bt, total, probs_bt, row_loss, dz, lddz, reinterpret_cast<__bf16*>(dz16), bt_of_row, rows);
     }
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;

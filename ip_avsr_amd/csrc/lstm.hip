@@ -319,8 +319,27 @@ int lstm_pack_whid_t(const float* W, void* out, int H, hipStream_t s) {
 long long g_lstm_family_forwards[4] = {0, 0, 0, 0};
 long long g_lstm_family_backwards[4] = {0, 0, 0, 0};
 
+// Length buckets (LstmStep::T_own / mask_own): only the four weight-stationary kernels of H <= 256 read them; the dispatchers
+// below refuse such entries on any other route rather than run them over the launch's T and mask.
+static bool has_bucket_entries(const LstmStep* l, int n) {
+    for (int k = 0; k < n; ++k) if (l[k].T_own || l[k].mask_own) return true;
+    return false;
+}
+bool lstm_takes_length_buckets(const LstmStep* l, int n, int B, int T, int H, int precision, bool backward) {
+    if (n < 1 || n > kMaxLstmPerLaunch || H > 256 || deterministic()) return false;
+    if (precision == ADN_PRECISION_BF16X3) return backward ? lstm_cluster_x3_bwd_supported(l, n, B, T, H) : lstm_cluster_x3_supported(l, n, B, T, H);
+    if (precision != ADN_PRECISION_BF16) return false;
+    for (int k = 0; k < n; ++k)
+        if (backward ? !(l[k].W_hid16 && l[k].dG16) : !(l[k].W_hid16T && l[k].h16)) return false;
+    if (!lstm_persistent_supported(H) || !(backward ? l[0].W_frag_bwd : l[0].W_frag_fwd)) return false;
+    if (backward && getenv("ADN_LSTM_NO_CLUSTER_BWD")) return false;
+    return lstm_cluster_supported(l, n, B, T, H);
+}
+
 int lstm_forward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, int precision, hipStream_t s) {
     ADN_CHECK(n >= 1 && n <= kMaxLstmPerLaunch, ADN_ERR_INVALID, "lstm_forward: bad LSTM count");
+    ADN_CHECK(!has_bucket_entries(l, n) || lstm_takes_length_buckets(l, n, B, T, H, precision, false), ADN_ERR_STATE,
+              "lstm_forward: length-bucket entries on a kernel family that does not take them");
     // bf16x3 mode: the weight-stationary forward kernel with fp32-grade products where it applies, the fp32 step kernels else
     if (precision == ADN_PRECISION_BF16X3) {
         if (lstm_cluster_x3_supported(l, n, B, T, H)) { g_lstm_family_forwards[3] += n; return lstm_forward_cluster_x3(l, n, mask_tb, B, T, H, s); }
@@ -517,6 +536,8 @@ int lstm_backward(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T
 static int lstm_backward_impl(const LstmStep* l, int n, const uint8_t* mask_tb, int B, int T, int H, int precision, hipStream_t s,
                               bool* sums_done) {
     ADN_CHECK(n >= 1 && n <= kMaxLstmPerLaunch, ADN_ERR_INVALID, "lstm_backward: bad LSTM count");
+    ADN_CHECK(!has_bucket_entries(l, n) || lstm_takes_length_buckets(l, n, B, T, H, precision, true), ADN_ERR_STATE,
+              "lstm_backward: length-bucket entries on a kernel family that does not take them");
     if (sums_done) *sums_done = false;
     if (precision == ADN_PRECISION_BF16X3) {          // fp32-grade products on the bf16 matrix pipe, or the fp32 step kernels
         if (lstm_cluster_x3_bwd_supported(l, n, B, T, H)) {

@@ -42,6 +42,7 @@ struct LstmClusterP {
     LstmStep l[kMaxLstmPerLaunch];
     int pair0, groups;
 };
+static_assert(sizeof(LstmClusterP) + 64 <= 4096, "kernel arguments: the launch descriptor + the scalars must fit 4 KB");
 
 __device__ __forceinline__ float c_sigmoid(float x) {
     return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
@@ -170,8 +171,8 @@ __device__ __forceinline__ bool granule_wait(const unsigned long long* const (&p
 // the GEMM: 250 MB for the three stream LSTMs of the bench model, 91 us; read back here, where the step waited ~0.7 us for it)
 // and a launch.  Same products: bf16 operands, fp32 accumulation over the k-steps in order, bias added last.
 template <int CWG, int KXS = 0>
-__global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const LstmClusterP L, const uint8_t* __restrict__ mask_tb,
-                                                               int B, int T, int H, int ldh, int ldg, unsigned tag0, int* err) {
+__global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const LstmClusterP L, const uint8_t* __restrict__ mask_arg,
+                                                               int B, int T_arg, int H, int ldh, int ldg, unsigned tag0, int* err) {
     using G = ClusterGeom<CWG, KXS>;
     constexpr int HP = G::HP, KS = G::KS, KSL = G::KSL, KSR = G::KSR, HS = G::HS, NF = G::NF;
     constexpr bool FOLD = KXS > 0;
@@ -184,6 +185,9 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const LstmCluster
     __bf16* xs = lds + G::WLdsFwd + kCRows * HS + 16 * KXS * 64 * 8;
     const int pair_ = L.pair0 + (int)blockIdx.x / CWG, lstm_ = pair_ / L.groups;
     const LstmStep& P = L.l[lstm_];
+    // (a launch entry may be one LENGTH BUCKET of an LSTM -- model.hip, TmPlan: its own step count and its own rows of the mask)
+    const int T = P.T_own ? P.T_own : T_arg;
+    const uint8_t* __restrict__ mask_tb = P.mask_own ? P.mask_own : mask_arg;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, kq = lane >> 4;
     const int group = pair_ - lstm_ * L.groups, j = blockIdx.x % CWG;
@@ -436,6 +440,7 @@ struct LstmClusterX3P {
     unsigned tag0[kMaxLstmPerLaunch];                                  // 1024 seq + 1, seq in [0, 64): tag0 + step < 65536
     int pair0, groups;
 };
+static_assert(sizeof(LstmClusterX3P) + 64 <= 4096, "kernel arguments: the launch descriptor + the scalars must fit 4 KB");
 __device__ __forceinline__ unsigned x3_quant(float h) { return (__builtin_bit_cast(unsigned, h) + 0x80u) & ~0xffu; }
 __device__ __forceinline__ void x3_split(unsigned qbits, __bf16& hi, __bf16& lo) {
     const float q = __builtin_bit_cast(float, qbits);
@@ -444,8 +449,8 @@ __device__ __forceinline__ void x3_split(unsigned qbits, __bf16& hi, __bf16& lo)
 }
 constexpr int kX3AccLds = 4 * 2 * 4 * 64 * 4;                          // fp32 words: [4 gates][2 row tiles][4 unit tiles][64 lanes] x 4 rows
 constexpr int kX3FwdLds = 3;                                           // lo k-steps of a wave's W fragments that live in LDS
-__global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClusterX3P L, const uint8_t* __restrict__ mask_tb,
-                                                                  int B, int T, int H, int ldh, int ldg, int* err) {
+__global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClusterX3P L, const uint8_t* __restrict__ mask_arg,
+                                                                  int B, int T_arg, int H, int ldh, int ldg, int* err) {
     using G = ClusterGeom<4>;
     constexpr int CWG = 4, HP = G::HP, KS = G::KS, HS = G::HS, NF = 8;
     const unsigned tag0 = L.tag0[(L.pair0 + (int)blockIdx.x / CWG) / L.groups];
@@ -456,6 +461,9 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_x3_kernel(const LstmClus
     bf16x8* wl = reinterpret_cast<bf16x8*>(lds + 2 * kCRows * HS + kX3AccLds * 2);   // [8 waves][2 gates][kX3FwdLds][64 lanes]
     const int pair_ = L.pair0 + (int)blockIdx.x / CWG, lstm_ = pair_ / L.groups;
     const LstmStep& P = L.l[lstm_];
+    // (a launch entry may be one LENGTH BUCKET of an LSTM -- model.hip, TmPlan: its own step count and its own rows of the mask)
+    const int T = P.T_own ? P.T_own : T_arg;
+    const uint8_t* __restrict__ mask_tb = P.mask_own ? P.mask_own : mask_arg;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, kq = lane >> 4;
     const int group = pair_ - lstm_ * L.groups, j = blockIdx.x % CWG;
@@ -888,8 +896,8 @@ __device__ __forceinline__ unsigned long long pack_partials(float a, float b, un
 }
 
 template <int CWG>
-__global__ __launch_bounds__(512) void lstm_bwd_cluster_kernel(const LstmClusterP L, const uint8_t* __restrict__ mask_tb,
-                                                               int B, int T, int H, int ldh, int ldg, int* err) {
+__global__ __launch_bounds__(512) void lstm_bwd_cluster_kernel(const LstmClusterP L, const uint8_t* __restrict__ mask_arg,
+                                                               int B, int T_arg, int H, int ldh, int ldg, int* err) {
     using G = ClusterGeom<CWG>;
     constexpr int HP = G::HP, KSLB = G::KSLB, KSRB = G::KSRB, NRT = G::NRT, NF = G::NB;
     extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
@@ -898,6 +906,9 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_kernel(const LstmCluster
     float (*part)[kCUnits + 1] = reinterpret_cast<float (*)[kCUnits + 1]>(lds + G::WLdsBwd + kCRows * kCDS);   // [32][65]
     const int pair_ = L.pair0 + (int)blockIdx.x / CWG, lstm_ = pair_ / L.groups;
     const LstmStep& P = L.l[lstm_];
+    // (a launch entry may be one LENGTH BUCKET of an LSTM -- model.hip, TmPlan: its own step count and its own rows of the mask)
+    const int T = P.T_own ? P.T_own : T_arg;
+    const uint8_t* __restrict__ mask_tb = P.mask_own ? P.mask_own : mask_arg;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, kq = lane >> 4;
     const int group = pair_ - lstm_ * L.groups, j = blockIdx.x % CWG;
@@ -1142,8 +1153,8 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_kernel(const LstmCluster
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kX3BwdLds = 3;                                           // lo k-steps of a wave's W fragments that live in LDS
 constexpr int kX3BwdWOff = (2 * kCRows * kCDS * 2 + kCRows * (kCUnits + 1) * 4 + 15) / 16 * 16 / 2;   // bf16 elements
-__global__ __launch_bounds__(512) void lstm_bwd_cluster_x3_kernel(const LstmClusterP L, const uint8_t* __restrict__ mask_tb,
-                                                                  int B, int T, int H, int ldh, int ldg, int* err) {
+__global__ __launch_bounds__(512) void lstm_bwd_cluster_x3_kernel(const LstmClusterP L, const uint8_t* __restrict__ mask_arg,
+                                                                  int B, int T_arg, int H, int ldh, int ldg, int* err) {
     using G = ClusterGeom<4>;
     constexpr int CWG = 4, HP = G::HP, NF = G::NB;
     extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
@@ -1153,6 +1164,9 @@ __global__ __launch_bounds__(512) void lstm_bwd_cluster_x3_kernel(const LstmClus
     bf16x8* wl = reinterpret_cast<bf16x8*>(lds + kX3BwdWOff);            // [8 waves][2 tiles][kX3BwdLds k-steps][64 lanes] lo fragments
     const int pair_ = L.pair0 + (int)blockIdx.x / CWG, lstm_ = pair_ / L.groups;
     const LstmStep& P = L.l[lstm_];
+    // (a launch entry may be one LENGTH BUCKET of an LSTM -- model.hip, TmPlan: its own step count and its own rows of the mask)
+    const int T = P.T_own ? P.T_own : T_arg;
+    const uint8_t* __restrict__ mask_tb = P.mask_own ? P.mask_own : mask_arg;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, kq = lane >> 4;
     const int group = pair_ - lstm_ * L.groups, j = blockIdx.x % CWG;
@@ -1733,6 +1747,8 @@ static int cluster_cus() {
     return g_cluster_cus[dev];
 }
 
+int lstm_cluster_cus() { return cluster_cus(); }
+
 // Residency guard.  The weight-stationary kernels are plain launches of one 512-thread workgroup per CU whose workgroups
 // wait for their group's partners.  What makes that safe is checked here instead of assumed: (1) the runtime's occupancy
 // answer for the kernel with its dynamic LDS is asked once per device and kernel -- a workgroup that cannot become resident
@@ -1850,6 +1866,12 @@ bool lstm_forward_folds_projection(const LstmStep* l, int n, int B, int T, int H
     return lstm_persistent_supported(H) && lstm_cluster_supported(l, n, B, T, H) && fold_offered(l, n, H, B);
 }
 
+// steps of a launch, summed over its entries (the profiler's bytes / flops: a length bucket runs its own count)
+static double entry_steps(const LstmStep* l, int n, int T) {
+    double s = 0.0;
+    for (int k = 0; k < n; ++k) s += l[k].T_own ? l[k].T_own : T;
+    return s;
+}
 // the (LSTM, group) pairs of a call over the fewest launches that keep every workgroup of a launch resident, in equal shares
 struct PairRange { int pair0, count; };
 static std::vector<PairRange> plan_pairs(int n, int groups, int cwg, int cus) {
@@ -1880,8 +1902,9 @@ static int forward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int
         attr = true;
     }
     // (KXS > 0: the step also multiplies x_t W_in -- its flops are booked with the recurrence's, its bytes replace the xproj read)
-    const double bytes = (double)n * T * (4.0 * (12.0 * B * H + 4.0 * H * H) + B),
-                 flops = (double)n * T * (8.0 * B * H * H + (KXS ? 8.0 * B * H * l[0].Kx : 0.0));
+    const double steps = entry_steps(l, n, T);        // (length buckets: every entry its own step count)
+    const double bytes = steps * (4.0 * (12.0 * B * H + 4.0 * H * H) + B),
+                 flops = steps * (8.0 * B * H * H + (KXS ? 8.0 * B * H * l[0].Kx : 0.0));
     ProfScope prof(PROF_LSTM_FWD, flops, bytes, s, T);
     LstmClusterP L;
     for (int k = 0; k < n; ++k) L.l[k] = l[k];
@@ -1939,7 +1962,8 @@ int lstm_forward_cluster_x3(const LstmStep* l, int n, const uint8_t* mask_tb, in
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
-    const double bytes = (double)n * T * (4.0 * (12.0 * B * H + 4.0 * H * H) + B), flops = (double)n * T * 8.0 * B * H * H;
+    const double steps = entry_steps(l, n, T);
+    const double bytes = steps * (4.0 * (12.0 * B * H + 4.0 * H * H) + B), flops = steps * 8.0 * B * H * H;
     ProfScope prof(PROF_LSTM_FWD, flops, bytes, s, T);
     LstmClusterX3P L;
     for (int k = 0; k < n; ++k) { L.l[k] = l[k]; L.tag0[k] = 0u; }
@@ -2023,7 +2047,8 @@ int lstm_backward_cluster_x3w(const LstmStep* l, int n, const uint8_t* mask_tb, 
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWBwdLdsBytes));
         attr = true;
     }
-    const double bytes = (double)n * T * 4.0 * (15.0 * B * H + 4.0 * H * H), flops = (double)n * T * 8.0 * B * H * H;
+    const double steps = entry_steps(l, n, T);
+    const double bytes = steps * 4.0 * (15.0 * B * H + 4.0 * H * H), flops = steps * 8.0 * B * H * H;
     ProfScope prof(PROF_LSTM_BWD, flops, bytes, s, T + 1);
     LstmClusterP L;
     for (int k = 0; k < n; ++k) L.l[k] = l[k];
@@ -2052,7 +2077,8 @@ static int backward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, in
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
-    const double bytes = (double)n * T * 4.0 * (15.0 * B * H + 4.0 * H * H), flops = (double)n * T * 8.0 * B * H * H;
+    const double steps = entry_steps(l, n, T);
+    const double bytes = steps * 4.0 * (15.0 * B * H + 4.0 * H * H), flops = steps * 8.0 * B * H * H;
     ProfScope prof(PROF_LSTM_BWD, flops, bytes, s, T + 1);
     LstmClusterP L;
     for (int k = 0; k < n; ++k) L.l[k] = l[k];
@@ -2093,7 +2119,8 @@ int lstm_backward_cluster_x3(const LstmStep* l, int n, const uint8_t* mask_tb, i
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
-    const double bytes = (double)n * T * 4.0 * (15.0 * B * H + 4.0 * H * H), flops = (double)n * T * 8.0 * B * H * H;
+    const double steps = entry_steps(l, n, T);
+    const double bytes = steps * 4.0 * (15.0 * B * H + 4.0 * H * H), flops = steps * 8.0 * B * H * H;
     ProfScope prof(PROF_LSTM_BWD, flops, bytes, s, T + 1);
     LstmClusterP L;
     for (int k = 0; k < n; ++k) L.l[k] = l[k];

@@ -118,6 +118,24 @@ struct LstmParams {      // physical tensors (float offsets into the flat buffer
     bool backwards = false;
 };
 
+// Length buckets: the time-major (recurrent) side of a train step without most of its padding frames.  The utterances of the call,
+// sorted by length, are cut into nb buckets of Bb = ceil(B / nb); bucket k keeps Tk[k] steps (its longest utterance) of Bb rows.  The
+// buckets follow one another along the TIME axis -- bucket k starts at block c[k] = sum_{k' < k} (Tk[k'] + 1), one spare block behind
+// each -- so every time-major tensor is an ordinary [Tt][Bb] one with Tt = c[nb] - 1: GEMMs, sums, concat and the loss only see a
+// row count (Bb Tt instead of B T: 15 860 instead of 20 800 at the bench lengths), the state histories keep their T + 1 block
+// convention PER BUCKET (block c[k] / c[k] + Tk[k] is the bucket's initial state), and the weight-stationary LSTM kernels run each
+// (LSTM, bucket) as an entry of its own -- the bucket's first row in every pointer, LstmStep::T_own steps, its own rows of the mask.
+// Rows no frame lives in (the spare blocks, the slots behind the last utterance of the last bucket): mask 0, zero rows in every
+// gradient matrix (softmax_loss writes them for dz, zero_spare_blocks() for the gate gradients the LSTM kernels never touch there),
+// finite anything elsewhere.  Frames (b, t >= Tk[bucket of b]) have no row at all: padding of every utterance of the bucket.
+constexpr int kMaxBuckets = 4;
+struct TmPlan {
+    bool on = false;
+    int nb = 1, Bb = 0, Tt = 0, Tmax = 0;
+    int c[kMaxBuckets + 1] = {0, 0, 0, 0, 0};
+    int Tk[kMaxBuckets] = {0, 0, 0, 0};
+};
+
 struct LstmWork {        // per-shape workspace pointers
     float *xproj = nullptr, *gates = nullptr, *dG = nullptr, *hbuf = nullptr, *cbuf = nullptr;
     float *dh_carry = nullptr, *dc_state = nullptr;
@@ -279,6 +297,11 @@ struct adn_model {
     // ADN_PRECISION_MIXED: cfg.precision is ADN_PRECISION_BF16X3 and back-propagation's GEMMs take the hi planes only (m_gemm)
     bool bwd_hi_only = false;
     bool in_backward = false;
+    // length buckets (TmPlan): asked for by the train-step entry points, decided per call by setup_buckets(); the tables live in the slab
+    TmPlan tm; bool want_buckets = false, buckets_allowed = true, probs_partial = false;
+    int32_t *tm_row0 = nullptr, *tm_T = nullptr, *tm_bt = nullptr;      // [B] first row / steps of an utterance; [rows] frame of a row (-1: none)
+    std::vector<int32_t> tm_lens; int tm_key_T = 0, tm_key_nb = 0;     // what the tables on the device were made for
+    PinSlot pin_tm[4]; int pin_tm_next = 0;
     bool bf16() const { return cfg.precision == ADN_PRECISION_BF16; }
     // bf16x3 mode keeps TWO bf16 planes (hi = bf16(x), lo = bf16(x - hi)) of every GEMM operand -- written once per tensor by a
     // split pass behind its producer -- and its large GEMMs run over the planes (three K-segments in the ping-pong kernel)
@@ -487,9 +510,10 @@ void carve_lstm(adn_model* m, Carver& cv, LstmWork& w, int B, int T, int ldh, in
     w.dG = take_shadowed(m, cv, N * ldg);
     w.hbuf = take_shadowed(m, cv, (size_t)(T + 1) * B * ldh);
     w.cbuf = cv.take<float>((size_t)(T + 1) * B * ldh);
-    w.dh_carry = cv.take<float>((size_t)B * ldh);
-    w.dc_state = cv.take<float>((size_t)B * ldh);
-    w.xchg = cv.take<char>(lstm_cluster_xchg_bytes(B, m->H));
+    // (length buckets: nb Bb <= B + nb - 1 utterance slots, and up to one more 32-utterance group per bucket in the exchange buffer)
+    w.dh_carry = cv.take<float>((size_t)(B + 2 * kMaxBuckets) * ldh);
+    w.dc_state = cv.take<float>((size_t)(B + 2 * kMaxBuckets) * ldh);
+    w.xchg = cv.take<char>(lstm_cluster_xchg_bytes(B + 32 * kMaxBuckets, m->H));
     w.xchg_seq = 0;          // ensure_workspace zeroes the whole slab behind every carve: all tag slots read 0
 }
 
@@ -513,6 +537,8 @@ size_t carve(adn_model* m, char* base, int B, int T, bool host_inputs) {
     m->d_lens = cv.take<int32_t>((size_t)B); m->d_prefix = cv.take<int32_t>((size_t)B + 1);
     m->comp_of_full = cv.take<int32_t>(N); m->full_of_comp = cv.take<int32_t>(N + 8);
     m->maps_lens.clear(); m->compact = false;          // (the maps live in the slab: re-made after every carve)
+    m->tm_row0 = cv.take<int32_t>((size_t)B); m->tm_T = cv.take<int32_t>((size_t)B); m->tm_bt = cv.take<int32_t>(N + 8);
+    m->tm_lens.clear(); m->tm = TmPlan{};
     m->y_bt = cv.take<int32_t>(N);
     m->total = cv.take<float>(8);
     m->loss = cv.take<float>(8);
@@ -668,6 +694,7 @@ int widen_bf16_rows(const void* src, int ld_src, float* dst, int ld_dst, int64_t
 }
 
 int setup_compaction(adn_model* m, int B, int T, bool dev);
+int setup_buckets(adn_model* m, int B, int T);
 int read_input_flags(adn_model* m, int* out);
 bool streams_concurrent(const adn_model* m);
 int stage_inputs(adn_model* m, const void* const* inputs, const int32_t* targets, const uint8_t* mask, int B, int T,
@@ -808,7 +835,9 @@ int stage_inputs(adn_model* m, const void* const* inputs, const int32_t* targets
     // (a device mask is compared with the announced lengths by the kernel that walks it anyway; the word is read at the call's next
     //  synchronisation point -- check_device_errors() -- or right here under ADN_CHECK_PADDING=1)
     const bool verify = m->compact && dev;
-    ADN_TRY(mask_prepare(mask_src, m->mask_tb, B, T, m->total, m->stream, verify ? m->d_lens : nullptr, verify ? m->input_flags() : nullptr, kInputLens));
+    ADN_TRY(setup_buckets(m, B, T));
+    ADN_TRY(mask_prepare(mask_src, m->mask_tb, B, T, m->total, m->stream, verify ? m->d_lens : nullptr, verify ? m->input_flags() : nullptr, kInputLens,
+                         m->tm.on ? m->tm_row0 : nullptr, m->tm.on ? m->tm_T : nullptr, m->tm.on ? m->tm.Bb : 0));
     if (verify && getenv("ADN_CHECK_PADDING")) {
         int f = 0;
         ADN_TRY(read_input_flags(m, &f));
@@ -916,6 +945,105 @@ int setup_compaction(adn_model* m, int B, int T, bool dev) {
             for (auto& e : m->fp32_stale) if (e.first == st.xc) { e.second = (size_t)m->Nc * ld; listed = true; }
             if (!listed) m->fp32_stale.push_back({st.xc, (size_t)m->Nc * ld});
         }
+    }
+    return ADN_OK;
+}
+
+// Length buckets (TmPlan), decided per call: a train step (the entry point asked) of a compacted batch -- the lengths are on the host
+// and the mask is checked against them --, the weight-stationary LSTM kernels of H <= 256 on every recurrence, nothing in the model
+// that walks the time-major tensors by (b, t) outside the kernels that take the tables (no dropout, no last-timestep head, no
+// adaptive fusion, no auxiliary inputs, one HIP stream), and >= 10 % fewer rows.  ADN_NO_LENGTH_BUCKETS=1 / adn_set_length_buckets(0): never.
+LstmStep make_step(const adn_model* m, const LstmParams& lp, const LstmWork& w, const float* dhs, bool grads);
+bool streams_concurrent(const adn_model* m);
+static std::vector<LstmStep> expand_entries(const adn_model* m, const TmPlan& p, const LstmStep* l, int n);
+int setup_buckets(adn_model* m, int B, int T) {
+    const bool was_on = m->tm.on;
+    m->tm.on = false;
+    static const bool off = getenv("ADN_NO_LENGTH_BUCKETS") != nullptr;
+    if (off || !m->buckets_allowed || !m->want_buckets || !m->compact || m->maps_lens.size() != (size_t)B) return ADN_OK;
+    if (m->head_last() || m->has_dropout() || m->cfg.fusion == ADN_FUSE_ADASUM || streams_concurrent(m) || deterministic() || m->H > 256 ||
+        m->keep_fp32) return ADN_OK;
+    size_t n_stream_lstm = 0;
+    for (auto& st : m->st) {
+        if (st.cfg.aux_dim > 0 || st.cfg.n_enc == 0 || st.lstm.empty()) return ADN_OK;
+        n_stream_lstm += st.lstm.size();
+    }
+    const int n_l = (int)std::max(n_stream_lstm, m->agg.size());       // LSTMs of the widest launch
+    const std::vector<int32_t>& lens = m->maps_lens;
+    std::vector<int32_t> order((size_t)B);
+    for (int b = 0; b < B; ++b) order[b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return lens[a] > lens[b]; });
+    // the bucket count: fewest rows among the counts whose launches still hold every LSTM of a group at once
+    TmPlan best; int64_t best_rows = (int64_t)B * T;
+    for (int nb = 2; nb <= kMaxBuckets; ++nb) {
+        const int Bb = cdiv(B, nb);
+        if (n_l * nb > kMaxLstmPerLaunch || (int64_t)n_l * nb * cdiv(Bb, 32) * 4 > lstm_cluster_cus()) continue;
+        TmPlan p; p.nb = nb; p.Bb = Bb;
+        for (int k = 0; k < nb; ++k) {
+            p.Tk[k] = (k * Bb < B) ? lens[order[(size_t)k * Bb]] : 1;      // (a bucket of phantom slots only: one masked step)
+            p.c[k + 1] = p.c[k] + p.Tk[k] + 1;
+            p.Tmax = std::max(p.Tmax, p.Tk[k]);
+        }
+        p.Tt = p.c[nb] - 1;
+        if ((int64_t)p.Bb * p.Tt < best_rows) { best_rows = (int64_t)p.Bb * p.Tt; best = p; }
+    }
+    if (best.nb < 2 || (double)best_rows > 0.9 * (double)B * T) return ADN_OK;
+    best.on = true;
+    // every recurrence of the model on a kernel that takes the entries? (asked of the dispatcher's own predicate, per launch)
+    {
+        const int per = kMaxLstmPerLaunch / best.nb;
+        const int prec = m->cfg.precision == ADN_PRECISION_BF16X3 ? ADN_PRECISION_BF16X3 : m->lstm_precision();
+        const int prec_bwd = (m->bwd_hi_only && m->planes()) ? ADN_PRECISION_BF16 : prec;      // (mixed: the bf16 kernel back-propagates)
+        std::vector<LstmStep> all[2];
+        for (auto& st : m->st) for (size_t k = 0; k < st.lstm.size(); ++k) all[0].push_back(make_step(m, st.lstm[k], st.lw[k], nullptr, true));
+        for (size_t k = 0; k < m->agg.size(); ++k) all[1].push_back(make_step(m, m->agg[k], m->aggw[k], nullptr, true));
+        for (auto& steps : all)
+            for (size_t i = 0; i < steps.size(); i += (size_t)per) {
+                const int n = (int)std::min<size_t>((size_t)per, steps.size() - i);
+                std::vector<LstmStep> ex = expand_entries(m, best, steps.data() + i, n);
+                if (!lstm_takes_length_buckets(ex.data(), (int)ex.size(), best.Bb, best.Tmax, m->H, prec, false)) return ADN_OK;
+                if (!lstm_takes_length_buckets(ex.data(), (int)ex.size(), best.Bb, best.Tmax, m->H, prec, true)) return ADN_OK;
+                if (prec_bwd != prec) {          // (run_lstm_group's mixed16 entries; where they cannot run the bf16x3 kernel does)
+                    for (auto& q : ex) { q.W_hid16 = m->shadow_of(q.W_hid); q.dG16 = q.dG ? m->shadow_of(q.dG) : nullptr; }
+                    (void)lstm_takes_length_buckets(ex.data(), (int)ex.size(), best.Bb, best.Tmax, m->H, prec_bwd, true);
+                }
+            }
+    }
+    m->tm = best;
+    // tables: only when the batch's lengths (or the cut) changed since they were made
+    if (!was_on || m->tm_lens != lens || m->tm_key_T != T || m->tm_key_nb != best.nb) {
+        m->tm_lens = lens; m->tm_key_T = T; m->tm_key_nb = best.nb;
+        const size_t rows = (size_t)best.Bb * best.Tt, want = 2 * (size_t)B + rows;
+        adn_model::PinSlot& slot = m->pin_tm[m->pin_tm_next++ & 3];
+        if (slot.ev) ADN_HIP_CHECK(hipEventSynchronize(slot.ev));
+        else ADN_HIP_CHECK(hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming));
+        if (slot.cap < want) {
+            if (slot.host) ADN_HIP_CHECK(hipHostFree(slot.host));
+            slot.host = nullptr; slot.cap = 0;
+            ADN_HIP_CHECK(hipHostMalloc((void**)&slot.host, (want + want / 2) * sizeof(int32_t), hipHostMallocDefault));
+            slot.cap = want + want / 2;
+        }
+        int32_t* row0 = slot.host; int32_t* tw = slot.host + B; int32_t* bt = slot.host + 2 * (size_t)B;
+        for (size_t r = 0; r < rows; ++r) bt[r] = -1;
+        for (int r = 0; r < B; ++r) {
+            const int b = order[r], k = r / best.Bb, j = r % best.Bb;
+            row0[b] = best.c[k] * best.Bb + j; tw[b] = best.Tk[k];
+            for (int t = 0; t < best.Tk[k]; ++t) bt[(size_t)row0[b] + (size_t)t * best.Bb] = b * T + t;
+        }
+        ADN_HIP_CHECK(hipMemcpyAsync(m->tm_row0, row0, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
+        ADN_HIP_CHECK(hipMemcpyAsync(m->tm_T, tw, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
+        ADN_HIP_CHECK(hipMemcpyAsync(m->tm_bt, bt, rows * 4, hipMemcpyHostToDevice, m->stream));
+        ADN_HIP_CHECK(hipEventRecord(slot.ev, m->stream));
+        // rows no frame lives in keep a zero mask (mask_prepare writes the frames' rows only); the exchange buffers' regions moved
+        // with Bb: no slot may keep a tag of an earlier cut (lstm_cluster.hip, x3_launch_seq -- the counters restart with them)
+        ADN_HIP_CHECK(hipMemsetAsync(m->mask_tb, 0, (size_t)B * T, m->stream));
+        auto reset_xchg = [&](LstmWork& w) -> int {
+            ADN_HIP_CHECK(hipMemsetAsync(w.xchg, 0, lstm_cluster_xchg_bytes(B + 32 * kMaxBuckets, m->H), m->stream));
+            w.xchg_seq = 0;
+            return ADN_OK;
+        };
+        for (auto& st : m->st) for (auto& w : st.lw) ADN_TRY(reset_xchg(w));
+        for (auto& w : m->aggw) ADN_TRY(reset_xchg(w));
     }
     return ADN_OK;
 }
@@ -1347,11 +1475,73 @@ LstmStep make_step(const adn_model* m, const LstmParams& lp, const LstmWork& w, 
     return s;
 }
 
+// Length buckets: the launch entries of n LSTMs -- one per (LSTM, bucket), the bucket's first row in every pointer (TmPlan)
+static std::vector<LstmStep> expand_entries(const adn_model* m, const TmPlan& p, const LstmStep* l, int n) {
+    std::vector<LstmStep> out;
+    if (!p.on || p.nb < 2) { out.assign(l, l + n); return out; }
+    const size_t ldh = (size_t)m->ldh, ldg = (size_t)m->ldg;
+    const size_t xchg_bytes = lstm_cluster_xchg_bytes(p.Bb, m->H);
+    auto rows_f = [](auto* q, size_t rows, size_t ld) { return q ? q + rows * ld : q; };
+    auto rows_16 = [](auto* q, size_t rows, size_t ld) -> decltype(q) {
+        typedef decltype(q) P;
+        return q ? reinterpret_cast<P>(reinterpret_cast<uintptr_t>(q) + rows * ld * 2) : q;
+    };
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < p.nb; ++k) {
+            LstmStep e = l[i];
+            const size_t r = (size_t)p.c[k] * p.Bb;
+            e.xproj = rows_f(e.xproj, r, ldg); e.gates = rows_f(e.gates, r, ldg); e.dG = rows_f(e.dG, r, ldg);
+            e.hbuf = rows_f(e.hbuf, r, ldh); e.cbuf = rows_f(e.cbuf, r, ldh);
+            e.dhs = rows_f(e.dhs, r, e.ld_dhs ? (size_t)e.ld_dhs : ldh);
+            e.dh_carry = rows_f(e.dh_carry, (size_t)k * p.Bb, ldh); e.dc_state = rows_f(e.dc_state, (size_t)k * p.Bb, ldh);
+            e.h16 = rows_16(e.h16, r, ldh); e.dG16 = rows_16(e.dG16, r, ldg); e.dG16lo = rows_16(e.dG16lo, r, ldg);
+            e.x16 = rows_16(e.x16, r, (size_t)e.ld_x);
+            if (e.xchg) e.xchg = static_cast<char*>(e.xchg) + (size_t)k * xchg_bytes;
+            e.T_own = p.Tk[k]; e.mask_own = m->mask_tb + r;
+            out.push_back(e);
+        }
+    return out;
+}
+// LSTMs per launch: all kMaxLstmPerLaunch entries, or as many whole LSTMs as their buckets leave room for
+static int lstms_per_launch(const adn_model* m) { return m->tm.on ? std::max(1, kMaxLstmPerLaunch / m->tm.nb) : kMaxLstmPerLaunch; }
+// the gate-gradient rows of the spare blocks: never written by the LSTM kernels, read by every GEMM over all rows -- zero, in the
+// copies the step's GEMMs read (one small launch per backward pass; rows of an earlier cut may lie there)
+struct ZeroBlocksArgs { void* p[3 * 8]; int row_bytes[3 * 8]; int n; int blk[kMaxBuckets]; int nblk; int Bb; };
+__global__ __launch_bounds__(256) void zero_spare_blocks_kernel(const ZeroBlocksArgs a) {
+    const int q = blockIdx.y;
+    if (q >= a.n) return;
+    const size_t per = (size_t)a.Bb * a.row_bytes[q] / 16;                  // uint4 per block
+    for (int k = 0; k < a.nblk; ++k) {
+        uint4* dst = reinterpret_cast<uint4*>(static_cast<char*>(a.p[q]) + (size_t)a.blk[k] * a.Bb * a.row_bytes[q]);
+        for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < per; e += (size_t)gridDim.x * 256) dst[e] = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+static int zero_spare_blocks(adn_model* m, const std::vector<LstmStep>& steps) {
+    if (!m->tm.on || m->tm.nb < 2) return ADN_OK;
+    for (size_t i = 0; i < steps.size(); i += 8) {
+        ZeroBlocksArgs a{};
+        for (size_t k = i; k < std::min(steps.size(), i + 8); ++k) {
+            const LstmStep& q = steps[k];
+            if (q.dG && !q.dG_fp32_off && !(q.dG16 && q.dG16lo)) { a.p[a.n] = q.dG; a.row_bytes[a.n++] = m->ldg * 4; }
+            if (q.dG16) { a.p[a.n] = q.dG16; a.row_bytes[a.n++] = m->ldg * 2; }
+            if (q.dG16lo) { a.p[a.n] = q.dG16lo; a.row_bytes[a.n++] = m->ldg * 2; }
+        }
+        a.Bb = m->tm.Bb;
+        for (int k = 0; k + 1 < m->tm.nb; ++k) a.blk[a.nblk++] = m->tm.c[k] + m->tm.Tk[k];
+        if (!a.n) continue;
+        hipLaunchKernelGGL(zero_spare_blocks_kernel, dim3(32, a.n), dim3(256), 0, m->stream, a);
+        ADN_HIP_CHECK(hipGetLastError());
+    }
+    return ADN_OK;
+}
+
 // sums_done: the backward kernels already added the bias / initial-state gradients of every LSTM of the group
 int flush_init_states(adn_model* m, int B);
 int run_lstm_group(adn_model* m, std::vector<LstmStep>& steps, int B, int T, bool backward, bool* sums_done = nullptr) {
     ADN_TRY(flush_init_states(m, B));
     bool all = true;
+    // (B, T: the time-major geometry -- with length buckets [Tt][Bb]; the launches then run Bb utterances over at most Tmax steps)
+    const int per = lstms_per_launch(m), Bk = m->tm.on ? m->tm.Bb : B, Tk = m->tm.on ? m->tm.Tmax : T;
     std::vector<char> planes_done(steps.size(), 0);
     // ADN_PRECISION_MIXED: back-propagation through the recurrences on the bf16 mode's weight-stationary kernel -- one bf16 product
     // dG W_hid^T per step over the hi image of W_hid (the image bf16 mode packs), like the mode's backward GEMMs; dG leaves as its hi
@@ -1368,20 +1558,27 @@ int run_lstm_group(adn_model* m, std::vector<LstmStep>& steps, int B, int T, boo
             q.dG_fp32_off = 1; q.W_frag_fwd_lo = q.W_frag_bwd_lo = nullptr;
             if (!q.W_hid16 || !q.dG16 || !q.W_frag_bwd) mixed16 = false;
         }
-        for (size_t i = 0; mixed16 && i < alt.size(); i += kMaxLstmPerLaunch)
-            mixed16 = lstm_cluster_supported(alt.data() + i, (int)std::min<size_t>(kMaxLstmPerLaunch, alt.size() - i), B, T, m->H);
+        for (size_t i = 0; mixed16 && i < alt.size(); i += (size_t)per) {
+            const std::vector<LstmStep> ex = expand_entries(m, m->tm, alt.data() + i, (int)std::min<size_t>((size_t)per, alt.size() - i));
+            mixed16 = lstm_cluster_supported(ex.data(), (int)ex.size(), Bk, Tk, m->H);
+        }
     }
-    for (size_t i = 0; i < steps.size(); i += kMaxLstmPerLaunch) {
-        const int n = (int)std::min<size_t>(kMaxLstmPerLaunch, steps.size() - i);
+    if (backward) ADN_TRY(zero_spare_blocks(m, mixed16 ? alt : steps));
+    for (size_t i = 0; i < steps.size(); i += (size_t)per) {
+        const int n = (int)std::min<size_t>((size_t)per, steps.size() - i);
         bool done = false;
+        // (length buckets: one entry per (LSTM, bucket), Bb utterances each, its own step count -- the launch's T is the longest)
+        const std::vector<LstmStep> ex = expand_entries(m, m->tm, (backward && mixed16 ? alt.data() : steps.data()) + i, n);
+        const int ne = (int)ex.size();
         if (backward && mixed16) {
-            ADN_TRY(lstm_backward(alt.data() + i, n, m->mask_tb, B, T, m->H, ADN_PRECISION_BF16, m->stream, &done));
+            ADN_TRY(lstm_backward(ex.data(), ne, m->mask_tb, Bk, Tk, m->H, ADN_PRECISION_BF16, m->stream, &done));
             ADN_CHECK(done, ADN_ERR_STATE, "mixed mode: the weight-stationary bf16 backward kernel was expected to run");
         } else if (backward)
-            ADN_TRY(lstm_backward(steps.data() + i, n, m->mask_tb, B, T, m->H,
+            ADN_TRY(lstm_backward(ex.data(), ne, m->mask_tb, Bk, Tk, m->H,
                                   m->cfg.precision == ADN_PRECISION_BF16X3 ? ADN_PRECISION_BF16X3 : m->lstm_precision(), m->stream, &done));
-        else ADN_TRY(lstm_forward(steps.data() + i, n, m->mask_tb, B, T, m->H,
+        else ADN_TRY(lstm_forward(ex.data(), ne, m->mask_tb, Bk, Tk, m->H,
                                   m->cfg.precision == ADN_PRECISION_BF16X3 ? ADN_PRECISION_BF16X3 : m->lstm_precision(), m->stream));
+        ADN_CHECK(!m->tm.on || !backward || done, ADN_ERR_STATE, "length buckets: the weight-stationary backward kernel was expected to run");
         all = all && done;
         // (bf16x3: `done` <=> the weight-stationary hi / lo kernel ran, which also writes the planes of dG when they are offered)
         for (int k = 0; k < n; ++k) planes_done[i + k] = backward && done && (mixed16 || (steps[i + k].dG16 && steps[i + k].dG16lo));
@@ -1504,9 +1701,13 @@ int flush_init_states(adn_model* m, int B) {
     return rc;
 }
 int lstm_init_state(adn_model* m, const LstmParams& lp, const LstmWork& w, int B, int T) {
-    const size_t blk = lp.backwards ? (size_t)T * B * m->ldh : 0;
     char* h16 = m->bf16() ? static_cast<char*>(m->shadow_of(w.hbuf)) : nullptr;     // bf16 copy of the initial-state block
-    m->init_q.push_back(LstmInitJob{m->P(lp.hid_init), m->P(lp.cell_init), w.hbuf + blk, w.cbuf + blk, h16 ? h16 + blk * 2 : nullptr});
+    // (length buckets: B = Bb, and every bucket has an initial-state block of its own -- its first, or its last for a backwards LSTM)
+    for (int k = 0; k < (m->tm.on ? m->tm.nb : 1); ++k) {
+        const int first = m->tm.on ? m->tm.c[k] : 0, steps_k = m->tm.on ? m->tm.Tk[k] : T;
+        const size_t blk = (size_t)(first + (lp.backwards ? steps_k : 0)) * B * m->ldh;
+        m->init_q.push_back(LstmInitJob{m->P(lp.hid_init), m->P(lp.cell_init), w.hbuf + blk, w.cbuf + blk, h16 ? h16 + blk * 2 : nullptr});
+    }
     // (queued at every batch size since round 6: the jobs are 5 us of launch latency each whatever B is, and their first reader is
     //  the LSTM launch that run_lstm_group() puts behind the flush; forked streams keep one job per stream)
     if (streams_concurrent(m)) return flush_init_states(m, B);
@@ -1580,8 +1781,14 @@ struct OnSideStream {
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool want_dz) {
+int forward_pass(adn_model* m, int B0, int T0, int theta, bool want_loss, bool want_dz) {
+    // (B0, T0): the call's batch.  (B, T): the geometry of the time-major tensors -- the same, or with length buckets (TmPlan) Bb rows
+    // per block over Tt chained blocks; everything behind the delta layer only ever sees that.  The encoders' own row count is Nc
+    // then (a bucketed call is a compacted call), the delta layer's kernels take (B0, T0) and the tables.
+    const int B = m->tm.on ? m->tm.Bb : B0, T = m->tm.on ? m->tm.Tt : T0;
     const int N = B * T, H = m->H, ldh = m->ldh;
+    m->probs_partial = m->tm.on;
+    auto tm_job = [&](DeltaJob& dj) { if (m->tm.on) { dj.tm_row0 = m->tm_row0; dj.tm_T = m->tm_T; dj.tm_stride = m->tm.Bb; } };
     hipStream_t s = m->stream;
     std::vector<LstmStep> steps;
     ADN_TRY(ensure_splitk_ws(m));                                // (bf16x3 mode: the weight gradients' partial slabs)
@@ -1662,16 +1869,16 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
         //  right below where a stream has one, else the grouped input projections behind this loop)
         {
             DeltaJob dj{a, lda, st.feat, ld_of(st.feat_dim), st.enc_out, st.cfg.use_delta, feat16};
-            dj.dst16lo = feat16lo; dj.row_map = enc_rows;
-            ADN_TRY(queue_delta(m, true, dj, B, T, theta, false));
+            dj.dst16lo = feat16lo; dj.row_map = enc_rows; tm_job(dj);
+            ADN_TRY(queue_delta(m, true, dj, B0, T0, theta, false));
         }
         if (st.cfg.aux_dim > 0) {                                // ConcatLayer([l_delta, l_dct], axis=2): columns behind the deltas
             DeltaJob dj{st.aux_stage, ld_of(st.cfg.aux_dim), st.feat + st.delta_dim, ld_of(st.feat_dim), st.cfg.aux_dim, 0,
                         feat16 ? static_cast<void*>(static_cast<char*>(feat16) + 2 * (size_t)st.delta_dim) : nullptr};
             dj.dst16lo = feat16lo ? static_cast<void*>(static_cast<char*>(feat16lo) + 2 * (size_t)st.delta_dim) : nullptr;
-            ADN_TRY(queue_delta(m, true, dj, B, T, theta, false));
+            ADN_TRY(queue_delta(m, true, dj, B0, T0, theta, false));
         }
-        if (drop || !feat16 || !grouped) ADN_TRY(flush_deltas(m, B, T));
+        if (drop || !feat16 || !grouped) ADN_TRY(flush_deltas(m, B0, T0));
         if (drop)                                                // DropoutLayer ahead of the LSTM (adenet_v3.py:112,123,134)
             ADN_TRY(dropout_apply(st.feat, ld_of(st.feat_dim), st.feat, ld_of(st.feat_dim), B, T, st.feat_dim, st.feat_dim, 0,
                                   st.cfg.dropout_p, m->drop_seed, m->drop_counter, (uint32_t)(&st - m->st.data()), m->stream));
@@ -1698,15 +1905,17 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
             }
         }
     }
-    ADN_TRY(flush_deltas(m, B, T));
+    ADN_TRY(flush_deltas(m, B0, T0));
     ADN_TRY(join_streams(m));
     if (grouped && stream_proj.size() == steps.size()) {
         // launch groups as run_lstm_group forms them: where the kernel folds the projection in, its GEMM is dropped; elsewhere
         // the offer is withdrawn, so that exactly one of the two computes it
         std::vector<GemmArgs> kept;
-        for (size_t i = 0; i < steps.size(); i += kMaxLstmPerLaunch) {
-            const int n = (int)std::min<size_t>(kMaxLstmPerLaunch, steps.size() - i);
-            const bool fold = lstm_forward_folds_projection(steps.data() + i, n, B, T, m->H, m->lstm_precision());
+        const size_t per = (size_t)lstms_per_launch(m);
+        for (size_t i = 0; i < steps.size(); i += per) {
+            const int n = (int)std::min<size_t>(per, steps.size() - i);
+            const std::vector<LstmStep> ex = expand_entries(m, m->tm, steps.data() + i, n);      // (the entries run_lstm_group will launch)
+            const bool fold = lstm_forward_folds_projection(ex.data(), (int)ex.size(), m->tm.on ? m->tm.Bb : B, m->tm.on ? m->tm.Tmax : T, m->H, m->lstm_precision());
             for (int k = 0; k < n; ++k) {
                 if (fold) continue;
                 steps[i + k].x16 = nullptr; steps[i + k].W_in_frag = nullptr;
@@ -1828,7 +2037,7 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
                            want_loss ? m->row_loss : nullptr, want_dz ? m->dz : nullptr, m->ldc, s));
         if (want_dz) ADN_TRY(refresh(m, m->dz, (size_t)B * m->ldc));
         if (want_loss) ADN_TRY(reduce_loss(m->row_loss, B, m->total, m->loss, s));
-        m->lastB = B; m->lastT = T;
+        m->lastB = B0; m->lastT = T0;
         return ADN_OK;
     }
     {   // Dense(C) + softmax per frame (modelzoo/adenet_v2.py:89-92)
@@ -1837,12 +2046,14 @@ int forward_pass(adn_model* m, int B, int T, int theta, bool want_loss, bool wan
         g.B = m->P(m->smW); g.ldb = m->ldc; g.C = m->z; g.ldc = m->ldc; g.bias = m->P(m->smb); g.no_split = 1;
         ADN_TRY(mgemm(m, g));
     }
-    ADN_TRY(softmax_loss(m->z, m->ldc, B, T, m->C, m->mask_tb, want_loss ? m->y_src : nullptr, m->total, m->probs_bt,
+    // (length buckets: which frame a row holds comes from the table; rows without one get a zero gradient and no loss)
+    ADN_TRY(softmax_loss(m->z, m->ldc, B0, T0, m->C, m->mask_tb, want_loss ? m->y_src : nullptr, m->total, m->probs_bt,
                          want_loss ? m->row_loss : nullptr, want_dz ? m->dz : nullptr, m->ldc, s,
-                         (want_dz && m->bf16()) ? m->shadow_of(m->dz) : nullptr));      // (pad columns of dz stay zero in both copies)
+                         (want_dz && m->bf16()) ? m->shadow_of(m->dz) : nullptr,      // (pad columns of dz stay zero in both copies)
+                         m->tm.on ? m->tm_bt : nullptr, N));
     if (want_dz && !m->bf16()) ADN_TRY(refresh(m, m->dz, (size_t)N * m->ldc));
     if (want_loss) ADN_TRY(reduce_loss(m->row_loss, N, m->total, m->loss, s));
-    m->lastB = B; m->lastT = T;
+    m->lastB = B0; m->lastT = T0;
     return ADN_OK;
 }
 
@@ -1985,9 +2196,13 @@ size_t bucket_count(const adn_model* m) {
     return n;
 }
 
-int backward_pass(adn_model* m, int B, int T, int theta) {
+int backward_pass(adn_model* m, int B0, int T0, int theta) {
     struct InBackward { adn_model* m; explicit InBackward(adn_model* m_) : m(m_) { m->in_backward = true; } ~InBackward() { m->in_backward = false; } } in_backward(m);
+    // (B, T): the time-major geometry, as in forward_pass -- with length buckets [Tt][Bb]; (B0, T0), the call's batch, is what the delta
+    // layer's kernels and the padding sums walk.  (Everything between them and the encoders' GEMMs -- Nc rows -- is time-major.)
+    const int B = m->tm.on ? m->tm.Bb : B0, T = m->tm.on ? m->tm.Tt : T0;
     const int N = B * T, H = m->H, ldh = m->ldh;
+    auto tm_job = [&](DeltaJob& dj) { if (m->tm.on) { dj.tm_row0 = m->tm_row0; dj.tm_T = m->tm_T; dj.tm_stride = m->tm.Bb; } };
     hipStream_t s = m->stream;
     ADN_HIP_CHECK(hipMemsetAsync(m->flat[ADN_BUF_GRAD], 0, (m->flat_floats + kAuxFloats) * sizeof(float), s));
     ADN_HIP_CHECK(hipMemcpyAsync(m->flat[ADN_BUF_GRAD] + m->flat_floats, m->loss, sizeof(float),
@@ -2221,11 +2436,11 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             // copies -- and sums the padding frames' per utterance; the zero-input row is finished from those sums ahead of the
             // first reader (flush_pad_rows)
             DeltaJob dj{st.dfeat, ldf, st.dEc, ldE, st.enc_out, st.cfg.use_delta, nullptr};
-            dj.row_map = m->comp_of_full; dj.zrow = m->Nc - 1; dj.pad_partial = st.compact_ws;
+            dj.row_map = m->comp_of_full; dj.zrow = m->Nc - 1; dj.pad_partial = st.compact_ws; tm_job(dj);
             if (m->bf16() || m->planes()) dj.dst16 = m->shadow_of(st.dEc);
             if (m->planes() && dj.dst16) dj.dst16lo = m->shadow_lo_of(st.dEc);
-            ADN_TRY(queue_delta(m, false, dj, B, T, theta, true));
-            pad_rows.push_back(PadFinishJob{st.compact_ws, B, st.dEc, ldE, st.enc_out, m->Nc - 1, dj.dst16, dj.dst16lo});
+            ADN_TRY(queue_delta(m, false, dj, B0, T0, theta, true));
+            pad_rows.push_back(PadFinishJob{st.compact_ws, B0, st.dEc, ldE, st.enc_out, m->Nc - 1, dj.dst16, dj.dst16lo});
             if (!dj.dst16) { ADN_TRY(flush_pad_rows()); ADN_TRY(refresh(m, st.dEc, (size_t)m->Nc * ldE)); }
             w.dZ = st.dEc; w.lddz = ldE; w.bias_done = 0; w.active = true;
             return bucket_ready(bucket_of_top(m, si));
@@ -2346,7 +2561,7 @@ int backward_pass(adn_model* m, int B, int T, int theta) {
             ADN_TRY(issue_grouped(m, dx));
         }
         for (size_t si = 0; si < m->st.size(); ++si) { ADN_TRY(stream_head(si, true)); max_depth = std::max(max_depth, walk[si].active ? walk[si].L : 0); }
-        ADN_TRY(flush_deltas(m, B, T));
+        ADN_TRY(flush_deltas(m, B0, T0));
         ADN_TRY(flush_pad_rows());
         for (int d = 0; d < max_depth; ++d)
             for (const auto& sis : depth_groups(m, d)) ADN_TRY(layer_step(sis, d));
@@ -2568,6 +2783,7 @@ void adn_destroy(adn_model* m) {
     if (m->splitk_ws) (void)hipFree(m->splitk_ws);
     if (m->poison_sticky) (void)hipFree(m->poison_sticky);
     for (auto& slot : m->pin) { if (slot.host) (void)hipHostFree(slot.host); if (slot.ev) (void)hipEventDestroy(slot.ev); }
+    for (auto& slot : m->pin_tm) { if (slot.host) (void)hipHostFree(slot.host); if (slot.ev) (void)hipEventDestroy(slot.ev); }
     delete m;
 }
 
@@ -2601,6 +2817,14 @@ int adn_set_relu_grad_at_zero(adn_model* m, float value) {
     ADN_CHECK(m, ADN_ERR_INVALID, "null model");
     ADN_CHECK(value == 0.f || value == 0.5f, ADN_ERR_INVALID, "adn_set_relu_grad_at_zero: 0 (this build's default) or 0.5 (Theano's 0.5 (x + |x|))");
     m->relu0_half = value == 0.5f;
+    return ADN_OK;
+}
+
+int adn_get_bucket_rows(const adn_model* m) { return (m && m->tm.on) ? m->tm.Bb * m->tm.Tt : 0; }
+
+int adn_set_length_buckets(adn_model* m, int on) {
+    ADN_CHECK(m, ADN_ERR_INVALID, "null model");
+    m->buckets_allowed = on != 0;
     return ADN_OK;
 }
 
@@ -2742,6 +2966,8 @@ int adn_loss(adn_model* m, const void* const* inputs, const int32_t* targets, co
 int adn_read_probs(adn_model* m, int B, int T, int flags, float* probs) {
     ADN_CHECK(m && probs, ADN_ERR_INVALID, "null argument");
     ADN_CHECK(m->lastB == B && m->lastT == T && B >= 1, ADN_ERR_STATE, "adn_read_probs: no forward pass of this (B, T) to read from");
+    ADN_CHECK(!m->probs_partial, ADN_ERR_STATE, "adn_read_probs: the last pass was a train step over length buckets -- its probabilities cover each "
+              "utterance's bucket only; run adn_forward / adn_loss for the batch's (adn_set_length_buckets(0) keeps train steps unbucketed)");
     const size_t rows = m->head_last() ? (size_t)B : (size_t)B * T;
     return fetch(m, probs, m->probs_bt, rows * m->C * sizeof(float), flags & ADN_FLAG_DEVICE_OUTPUTS);
 }
@@ -2751,7 +2977,10 @@ int adn_compute_grads(adn_model* m, const void* const* inputs, const int32_t* ta
     ADN_TRY(check_shape(m, B, T, theta));
     ADN_CHECK(targets, ADN_ERR_INVALID, "null targets");
     ADN_TRY(ensure_workspace(m, B, T));
-    ADN_TRY(stage_inputs(m, inputs, targets, mask, B, T, flags));
+    {   // a train step may keep its time-major side in length buckets (TmPlan): nobody reads per-frame outputs of this call
+        struct Ask { adn_model* m; explicit Ask(adn_model* m_) : m(m_) { m->want_buckets = true; } ~Ask() { m->want_buckets = false; } } ask(m);
+        ADN_TRY(stage_inputs(m, inputs, targets, mask, B, T, flags));
+    }
     ADN_TRY(set_loss_normaliser(m, B, total_frames));
     m->training = !(flags & ADN_FLAG_DETERMINISTIC);
     m->stochastic = m->training && m->has_dropout();

@@ -213,6 +213,15 @@ class AdeNetModel(object):
         (default on; the device checks the padding frames it was sent before relying on them -- include/adenet.h)."""
         _lib.check(self._lib.adn_set_auto_compaction(self._handle, 1 if on else 0))
 
+    def bucket_rows(self):
+        """Rows of the time-major tensors in the last call when it ran over length buckets, else 0 (include/adenet.h)."""
+        return int(self._lib.adn_get_bucket_rows(self._handle))
+
+    def set_length_buckets(self, on):
+        """Whether a compacted train step may keep its recurrent side in length buckets (default on; include/adenet.h): same loss and
+        gradients, ~24 % fewer time-major rows at AVLetters' lengths."""
+        _lib.check(self._lib.adn_set_length_buckets(self._handle, 1 if on else 0))
+
     def synchronize(self):
         _lib.check(self._lib.adn_synchronize(self._handle))
 

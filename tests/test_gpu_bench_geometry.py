@@ -28,11 +28,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 RUN = r'''
+import time as _t; _t0 = _t.time()
+def _tick(w):
+    if os.environ.get("GEOM_TICKS"): print("[tick] %%6.2f s %%s" %% (_t.time() - _t0, w), file=sys.stderr, flush=True)
 import os, sys, numpy as np, torch
 sys.path.insert(0, %r)
 import bench
 from ip_avsr_amd.model import AdeNetModel
 torch.cuda.set_device(0)
+_tick("imports")
 m = AdeNetModel(bench.build_spec())
 prec = os.environ.get("GEOM_PRECISION", "bf16")
 m.set_precision(prec)
@@ -56,18 +60,22 @@ elif not os.environ.get("GEOM_FRESH"):              # (GEOM_FRESH: bench.py's ow
     for _ in range(3):                               # a few steps so that the outputs are not flat
         announce()
         m.train_step(xs, y, m_d, bench.THETA, 2e-3, want_loss=False)
+_tick("params set / warm steps done")
 params = {"p_" + p.name: p.get_value() for p in m.params}
 announce()
 probs = m.predict(xs, m_d, bench.THETA)
+_tick("predict")
 rows = m.compact_rows()
 announce()
 loss = m.compute_grads(xs, y, m_d, bench.THETA)
 rows = min(rows, m.compact_rows())
+brows = m.bucket_rows()                              # (the train step's time-major rows when it ran over length buckets, else 0)
+_tick("compute_grads")
 g = m.get_grads_dict()
 keep = ["fc1_s1.W", "fc2_s2.W", "bottleneck_s3.W", "lstm_s1.W_hid_to_cell", "lstm_s3.W_in_to_ingate", "lstm_s2.b_outgate",
         "f_lstm_agg.W_in_to_forgetgate", "b_lstm_agg.W_hid_to_outgate", "f_lstm_agg.hid_init", "softmax.W", "softmax.b"]
 keep += [n for n in g if n.endswith(".b") and n.split("_")[0] in ("fc1", "fc2", "fc3", "bottleneck")]     # where the padding rows' sum lands
-np.savez(sys.argv[1], probs=probs, loss=loss, mask=mask, rows=rows, **{"g_" + k: g[k] for k in keep}, **params,
+np.savez(sys.argv[1], probs=probs, loss=loss, mask=mask, rows=rows, brows=brows, **{"g_" + k: g[k] for k in keep}, **params,
          **{"x%%d" %% k: x26[k] for k in range(3)})
 ''' % ROOT
 
@@ -104,6 +112,9 @@ def timed_path_runs(runs):
     for prec in ("bf16", "bf16x3", "mixed"):
         out[prec + "_compact"] = _run(d, prec + "_compact", ref, GEOM_PRECISION=prec, GEOM_COMPACT="1", GEOM_INPUTS="bench", ADN_CHECK_PADDING="1")
         out[prec + "_padded"] = runs["default"] if prec == "bf16" else _run(d, prec + "_padded", ref, GEOM_PRECISION=prec)
+        # ... and beside the same compacted step with its recurrent side over B x T rows (no length buckets)
+        out[prec + "_compact_bxt"] = _run(d, prec + "_compact_bxt", ref, GEOM_PRECISION=prec, GEOM_COMPACT="1", GEOM_INPUTS="bench",
+                                          ADN_NO_LENGTH_BUCKETS="1")
     # bench.py's own start (no training step first): zero biases, every padding row exactly on the rectifier kink
     out["fresh_compact"] = _run(d, "fresh_compact", None, GEOM_FRESH="1", GEOM_COMPACT="1", GEOM_INPUTS="bench")
     out["fresh_padded"] = _run(d, "fresh_padded", None, GEOM_FRESH="1")
@@ -237,6 +248,31 @@ def test_the_compacted_step_bench_times_equals_the_padded_one(timed_path_runs, p
         _close(c, p, "bf16x3: compacted (planes resident) vs padded", p_tol=1e-5, g_tol=5e-4, cos_tol=0.999999)
     else:                    # forward fp32-grade, back-propagation one bf16 product per GEMM
         _close(c, p, "mixed: compacted (planes resident) vs padded", p_tol=1e-5, g_tol=2e-2, cos_tol=0.9998)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "bf16x3", "mixed"])
+def test_the_bucketed_step_bench_times_equals_the_step_over_b_x_t_rows(timed_path_runs, prec):
+    """Round 6, length buckets (include/adenet.h adn_set_length_buckets) at B = 520 x T = 40: the timed train step keeps its
+    time-major tensors in 4 buckets of 130 utterances (asserted: fewer than 0.9 B T rows), and its loss and gradients are those of
+    the same compacted step over B x T rows up to the order of the sums -- every product is the same product in either layout."""
+    c, u = timed_path_runs[prec + "_compact"], timed_path_runs[prec + "_compact_bxt"]
+    declined = bool(os.environ.get("ADN_NO_COMPACT") or os.environ.get("ADN_STREAMS") or os.environ.get("ADN_BF16_NO_SHADOW") or
+                    os.environ.get("ADN_NO_LENGTH_BUCKETS") or os.environ.get("ADN_DETERMINISTIC") or os.environ.get("ADN_LSTM_NO_CLUSTER") or
+                    os.environ.get("ADN_LSTM_CUS") or (prec != "bf16x3" and os.environ.get("ADN_LSTM_NO_CLUSTER_BWD")) or
+                    (prec != "bf16" and (os.environ.get("ADN_X3_NO_PLANES") or os.environ.get("ADN_LSTM_NO_X3_CLUSTER") or
+                                         os.environ.get("ADN_LSTM_NO_X3_CLUSTER_BWD"))))
+    assert int(u["brows"]) == 0
+    if declined:
+        assert int(c["brows"]) == 0
+        return
+    n = int(c["mask"].size)
+    assert 0 < int(c["brows"]) <= 0.9 * n, int(c["brows"])
+    print("%s: %d time-major rows instead of %d" % (prec, int(c["brows"]), n))
+    np.testing.assert_array_equal(c["probs"], u["probs"])                 # (the forward-only pass never buckets: the same launches)
+    # bf16 / mixed re-round every gradient below an LSTM to bf16: a last-bit difference of a sum upstream flips roundings downstream
+    g_tol = {"bf16": 5e-3, "bf16x3": 1e-5, "mixed": 5e-3}[prec]
+    _close(c, u, "%s: length buckets vs B x T rows" % prec, p_tol=0.0, g_tol=g_tol, cos_tol=0.99999)
+    assert abs(float(c["loss"]) - float(u["loss"])) <= 2e-6 * abs(float(u["loss"]))
 
 
 def test_the_mixed_forward_pass_is_the_bf16x3_one_on_the_compacted_path(timed_path_runs):
