@@ -302,6 +302,7 @@ struct adn_model {
     int32_t *tm_row0 = nullptr, *tm_T = nullptr, *tm_bt = nullptr;      // [B] first row / steps of an utterance; [rows] frame of a row (-1: none)
     std::vector<int32_t> tm_lens; int tm_key_T = 0, tm_key_nb = 0;     // what the tables on the device were made for
     PinSlot pin_tm[4]; int pin_tm_next = 0;
+    int xchg_key = 0;                       // utterances per launch entry the LSTM exchange buffers were last used with (0: the whole batch)
     bool bf16() const { return cfg.precision == ADN_PRECISION_BF16; }
     // bf16x3 mode keeps TWO bf16 planes (hi = bf16(x), lo = bf16(x - hi)) of every GEMM operand -- written once per tensor by a
     // split pass behind its producer -- and its large GEMMs run over the planes (three K-segments in the ping-pong kernel)
@@ -538,7 +539,7 @@ size_t carve(adn_model* m, char* base, int B, int T, bool host_inputs) {
     m->comp_of_full = cv.take<int32_t>(N); m->full_of_comp = cv.take<int32_t>(N + 8);
     m->maps_lens.clear(); m->compact = false;          // (the maps live in the slab: re-made after every carve)
     m->tm_row0 = cv.take<int32_t>((size_t)B); m->tm_T = cv.take<int32_t>((size_t)B); m->tm_bt = cv.take<int32_t>(N + 8);
-    m->tm_lens.clear(); m->tm = TmPlan{};
+    m->tm_lens.clear(); m->tm = TmPlan{}; m->xchg_key = 0;
     m->y_bt = cv.take<int32_t>(N);
     m->total = cv.take<float>(8);
     m->loss = cv.take<float>(8);
@@ -956,7 +957,27 @@ int setup_compaction(adn_model* m, int B, int T, bool dev) {
 LstmStep make_step(const adn_model* m, const LstmParams& lp, const LstmWork& w, const float* dhs, bool grads);
 bool streams_concurrent(const adn_model* m);
 static std::vector<LstmStep> expand_entries(const adn_model* m, const TmPlan& p, const LstmStep* l, int n);
+static int decide_buckets(adn_model* m, int B, int T);
 int setup_buckets(adn_model* m, int B, int T) {
+    ADN_TRY(decide_buckets(m, B, T));
+    // The exchange buffers of the weight-stationary LSTM kernels are cut by the launch geometry: one region per entry, sized by the
+    // entry's utterances (forward granules, then the backward inboxes, which the kernels expect -- and leave -- EMPTY).  When the
+    // geometry changes (B x T rows <-> buckets, or another bucket size) what was somebody's forward region becomes somebody's inbox:
+    // no slot may keep a granule of the earlier cut (lstm_cluster.hip; the bf16x3 kernels' launch counters restart with the buffer).
+    const int key = m->tm.on ? m->tm.Bb : 0;
+    if (key != m->xchg_key) {
+        m->xchg_key = key;
+        auto reset_xchg = [&](LstmWork& w) -> int {
+            ADN_HIP_CHECK(hipMemsetAsync(w.xchg, 0, lstm_cluster_xchg_bytes(B + 32 * kMaxBuckets, m->H), m->stream));
+            w.xchg_seq = 0;
+            return ADN_OK;
+        };
+        for (auto& st : m->st) for (auto& w : st.lw) ADN_TRY(reset_xchg(w));
+        for (auto& w : m->aggw) ADN_TRY(reset_xchg(w));
+    }
+    return ADN_OK;
+}
+static int decide_buckets(adn_model* m, int B, int T) {
     const bool was_on = m->tm.on;
     m->tm.on = false;
     static const bool off = getenv("ADN_NO_LENGTH_BUCKETS") != nullptr;
@@ -1034,16 +1055,8 @@ int setup_buckets(adn_model* m, int B, int T) {
         ADN_HIP_CHECK(hipMemcpyAsync(m->tm_T, tw, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
         ADN_HIP_CHECK(hipMemcpyAsync(m->tm_bt, bt, rows * 4, hipMemcpyHostToDevice, m->stream));
         ADN_HIP_CHECK(hipEventRecord(slot.ev, m->stream));
-        // rows no frame lives in keep a zero mask (mask_prepare writes the frames' rows only); the exchange buffers' regions moved
-        // with Bb: no slot may keep a tag of an earlier cut (lstm_cluster.hip, x3_launch_seq -- the counters restart with them)
+        // rows no frame lives in keep a zero mask (mask_prepare writes the frames' rows only)
         ADN_HIP_CHECK(hipMemsetAsync(m->mask_tb, 0, (size_t)B * T, m->stream));
-        auto reset_xchg = [&](LstmWork& w) -> int {
-            ADN_HIP_CHECK(hipMemsetAsync(w.xchg, 0, lstm_cluster_xchg_bytes(B + 32 * kMaxBuckets, m->H), m->stream));
-            w.xchg_seq = 0;
-            return ADN_OK;
-        };
-        for (auto& st : m->st) for (auto& w : st.lw) ADN_TRY(reset_xchg(w));
-        for (auto& w : m->aggw) ADN_TRY(reset_xchg(w));
     }
     return ADN_OK;
 }
@@ -1725,11 +1738,17 @@ int flush_deltas(adn_model* m, int B, int T) {
     m->delta_q.clear();
     return rc;
 }
+// (the streams' delta layers as ONE launch at every batch size since round 6: at B = 520 three launches of 12 us each are latency-
+//  and tail-bound too -- 2.877 -> 2.856 ms per bf16 step, 5.694 -> 5.645 bf16x3, alternating runs on one box)
+static bool deltas_batched(const adn_model* m) {
+    static const bool off = getenv("ADN_NO_BATCHED_HOUSEKEEPING") != nullptr;
+    return !off && !streams_concurrent(m);
+}
 int queue_delta(adn_model* m, bool fwd, const DeltaJob& j, int B, int T, int theta, bool flush_now) {
     if (!m->delta_q.empty() && (m->delta_q_fwd != fwd || m->delta_q_theta != theta)) ADN_TRY(flush_deltas(m, B, T));
     m->delta_q_fwd = fwd; m->delta_q_theta = theta;
     m->delta_q.push_back(j);
-    if (flush_now || !batched_housekeeping(m, B, T)) return flush_deltas(m, B, T);
+    if (flush_now || !deltas_batched(m)) return flush_deltas(m, B, T);
     return ADN_OK;
 }
 
@@ -2439,7 +2458,9 @@ int backward_pass(adn_model* m, int B0, int T0, int theta) {
             dj.row_map = m->comp_of_full; dj.zrow = m->Nc - 1; dj.pad_partial = st.compact_ws; tm_job(dj);
             if (m->bf16() || m->planes()) dj.dst16 = m->shadow_of(st.dEc);
             if (m->planes() && dj.dst16) dj.dst16lo = m->shadow_lo_of(st.dEc);
-            ADN_TRY(queue_delta(m, false, dj, B0, T0, theta, true));
+            // (queued like the padded path's: flushed behind the streams' loop in the layer-major order; a stream that back-propagates
+            //  on its own right away, or reads the fp32 result here, takes it now)
+            ADN_TRY(queue_delta(m, false, dj, B0, T0, theta, stream_major || !dj.dst16));
             pad_rows.push_back(PadFinishJob{st.compact_ws, B0, st.dEc, ldE, st.enc_out, m->Nc - 1, dj.dst16, dj.dst16lo});
             if (!dj.dst16) { ADN_TRY(flush_pad_rows()); ADN_TRY(refresh(m, st.dEc, (size_t)m->Nc * ldE)); }
             w.dZ = st.dEc; w.lddz = ldE; w.bias_done = 0; w.active = true;

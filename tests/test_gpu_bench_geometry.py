@@ -258,7 +258,7 @@ def test_the_bucketed_step_bench_times_equals_the_step_over_b_x_t_rows(timed_pat
     c, u = timed_path_runs[prec + "_compact"], timed_path_runs[prec + "_compact_bxt"]
     declined = bool(os.environ.get("ADN_NO_COMPACT") or os.environ.get("ADN_STREAMS") or os.environ.get("ADN_BF16_NO_SHADOW") or
                     os.environ.get("ADN_NO_LENGTH_BUCKETS") or os.environ.get("ADN_DETERMINISTIC") or os.environ.get("ADN_LSTM_NO_CLUSTER") or
-                    os.environ.get("ADN_LSTM_CUS") or (prec != "bf16x3" and os.environ.get("ADN_LSTM_NO_CLUSTER_BWD")) or
+                    os.environ.get("ADN_LSTM_CUS") or (prec == "bf16" and os.environ.get("ADN_LSTM_NO_CLUSTER_BWD")) or
                     (prec != "bf16" and (os.environ.get("ADN_X3_NO_PLANES") or os.environ.get("ADN_LSTM_NO_X3_CLUSTER") or
                                          os.environ.get("ADN_LSTM_NO_X3_CLUSTER_BWD"))))
     assert int(u["brows"]) == 0

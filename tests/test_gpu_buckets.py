@@ -36,7 +36,7 @@ def _declined(prec):
                 (prec == "bf16" and os.environ.get("ADN_BF16_NO_SHADOW")) or
                 (prec in ("bf16x3", "mixed") and (os.environ.get("ADN_X3_NO_PLANES") or os.environ.get("ADN_LSTM_NO_X3_CLUSTER") or
                                                   os.environ.get("ADN_LSTM_NO_X3_CLUSTER_BWD"))) or
-                (prec != "bf16x3" and os.environ.get("ADN_LSTM_NO_CLUSTER_BWD")))
+                (prec == "bf16" and os.environ.get("ADN_LSTM_NO_CLUSTER_BWD")))       # (mixed: the bf16x3 backward kernel steps in)
 
 
 def _data(spec, B, T, dims, seed, perturb=0.05, lo=None):
@@ -127,10 +127,11 @@ def test_bucketed_bf16x3_gradients_against_the_oracle(torch_cuda):
         assert _rel(g[k], g_ref[k], gscale) <= 2e-4, k
 
 
-@pytest.mark.parametrize("prec", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("prec", ["bf16", "bf16x3", "mixed"])
 def test_a_sequence_of_batches_with_other_lengths_each(torch_cuda, prec):
-    """every step re-cuts the buckets: new tables, another bucket size (the exchange buffers' regions move), spare blocks where an
-    earlier step kept gradients -- against a second model that runs the same steps over B x T rows; the optimiser runs in between"""
+    """every call re-cuts the buckets or leaves them: new tables, another bucket size or none (the regions of the LSTM exchange
+    buffers move: what was a forward region becomes an inbox), spare blocks where an earlier call kept gradients, another (B, T) in
+    between -- each call against a second model of the same parameters that never buckets, at the order-of-summation grade"""
     from ip_avsr_amd.model import AdeNetModel
     dims = (72, 56)
     spec = O.spec_nstream(list(dims), enc_shapes=(96, 64, 24), enc_acts=("rectify", "rectify", "linear"), lstm_size=40, classes=26,
@@ -144,30 +145,33 @@ def test_a_sequence_of_batches_with_other_lengths_each(torch_cuda, prec):
         m.set_length_buckets(on)
         m.set_params_dict(p)
         models.append(m)
-    seen = set()
-    for step, (B, T, lo, seed) in enumerate([(70, 30, 4, 1), (70, 30, 20, 2), (70, 30, 4, 3), (96, 24, 3, 4), (70, 30, 29, 5), (70, 30, 4, 1)]):
+    seen = []
+    plan = [(70, 30, 4, 1), (70, 30, 20, 2), (70, 30, 4, 3), (70, 30, 29, 5), (150, 30, 4, 6), (150, 30, 28, 7), (96, 24, 3, 4), (70, 30, 4, 1),
+            (70, 30, 4, 1), (70, 30, 25, 8), (70, 30, 6, 9)]
+    for step, (B, T, lo, seed) in enumerate(plan):
         _, lens, mask, xs, y = _data(spec, B, T, dims, 100 + seed, lo=lo)
         res = []
         for m in models:
             m.set_batch_lengths(lens)
-            loss = m.train_step(xs, y, mask, theta, 1e-3)
+            loss = m.compute_grads(xs, y, mask, theta)
             res.append((loss, m.get_grads_dict(), m.bucket_rows()))
-        seen.add(res[1][2])
+        seen.append(res[1][2])
         assert res[0][2] == 0
-        best = min(_expected_rows(lens, B, nb) for nb in (2, 3, 4))
-        if best > 0.9 * B * T or _declined(prec):
-            assert res[1][2] == 0                      # (nearly full utterances: under 10 % to save -- the step stays on B x T rows)
+        cuts = [_expected_rows(lens, B, nb) for nb in (2, 3, 4)]
+        if min(cuts) > 0.9 * B * T or _declined(prec):
+            assert res[1][2] == 0                      # (nearly full utterances: under 10 % to save -- the call stays on B x T rows)
+        elif os.environ.get("ADN_LSTM_CUS"):           # (a smaller device may not hold the finest cut's launches resident)
+            assert res[1][2] == 0 or (res[1][2] in cuts and res[1][2] <= 0.9 * B * T)
         else:
-            assert res[1][2] == best
-        # (the two models' parameters drift apart by the gradients' rounding differences times Adam's normalisation: loose, growing)
-        tol = (2e-3 if prec == "bf16x3" else 3e-2) * (step + 1)
-        assert abs(res[1][0] - res[0][0]) <= tol * abs(res[0][0]), (step, res[1][0], res[0][0])
+            assert res[1][2] == min(cuts)
+        assert abs(res[1][0] - res[0][0]) <= 2e-6 * abs(res[0][0]), (step, res[1][0], res[0][0])
         gscale = max(np.abs(v).max() for v in res[0][1].values())
         for k in O.param_names(spec):
-            assert _rel(res[1][1][k], res[0][1][k], gscale) <= 10 * tol, (step, k)
+            assert _rel(res[1][1][k], res[0][1][k], gscale) <= 2e-4, (step, k)
     for m in models:
         m.close()
-    assert _declined(prec) or len(seen) >= 4          # several different cuts (and the uncut layout in between) were exercised
+    print("time-major rows of the calls:", seen)
+    assert _declined(prec) or os.environ.get("ADN_LSTM_CUS") or (len(set(seen)) >= 5 and 0 in seen)      # several cuts, and the uncut layout in between
 
 
 def test_forward_only_calls_and_the_probabilities_of_a_bucketed_step(torch_cuda):
