@@ -714,6 +714,8 @@ def run(args, make_model=None, batch_fn=None, device=None, dist_backend=None):
                 for k_src, k_dst in (("roofline_lstm_fwd", "lstm_fwd_frac_parity_grade"), ("roofline_lstm_bwd", "lstm_bwd_frac_parity_grade")):
                     if k_src in pg:
                         out["roofline"][k_dst] = pg[k_src]["frac"]
+                        if "algorithmic_frac_BxT" in pg[k_src]:      # (length buckets: the same launches priced over the B x T frames)
+                            out["roofline"][k_dst + "_BxT"] = pg[k_src]["algorithmic_frac_BxT"]
                 if "roofline" in pg:
                     out["roofline"]["gemm_frac_parity_grade"] = pg["roofline"]["frac"]
         if on_gpu and world == 1 and not getattr(args, "no_reference_minibatch", False):

@@ -1866,10 +1866,24 @@ bool lstm_forward_folds_projection(const LstmStep* l, int n, int B, int T, int H
     return lstm_persistent_supported(H) && lstm_cluster_supported(l, n, B, T, H) && fold_offered(l, n, H, B);
 }
 
-// steps of a launch, summed over its entries (the profiler's bytes / flops: a length bucket runs its own count)
-static double entry_steps(const LstmStep* l, int n, int T) {
-    double s = 0.0;
-    for (int k = 0; k < n; ++k) s += l[k].T_own ? l[k].T_own : T;
+// The profiler's units of a launch (SURVEY 8d prices one LSTM step as e(12 B H + 4 H^2) + B bytes and 8 B H^2 flops).  With length
+// buckets an entry is a BUCKET of an LSTM: the row terms are booked per entry and per step it runs (row_steps, B = the entry's
+// utterances), the W_hid term once per LSTM and step of its LONGEST bucket (weight_steps) -- the buckets of one LSTM are one
+// recurrence of the reference, which reads W_hid once per step; booking it per entry would count it nb times.
+struct EntrySteps { double rows, weights; };
+static EntrySteps entry_steps(const LstmStep* l, int n, int T) {
+    EntrySteps s{0.0, 0.0};
+    for (int k = 0; k < n; ++k) {
+        const int tk = l[k].T_own ? l[k].T_own : T;
+        s.rows += tk;
+        bool first = true; int tmax = tk;
+        for (int j = 0; j < n; ++j)
+            if (l[j].W_hid == l[k].W_hid) {
+                if (j < k) first = false;
+                tmax = std::max(tmax, l[j].T_own ? l[j].T_own : T);
+            }
+        if (first) s.weights += tmax;
+    }
     return s;
 }
 // the (LSTM, group) pairs of a call over the fewest launches that keep every workgroup of a launch resident, in equal shares
@@ -1902,9 +1916,9 @@ static int forward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, int
         attr = true;
     }
     // (KXS > 0: the step also multiplies x_t W_in -- its flops are booked with the recurrence's, its bytes replace the xproj read)
-    const double steps = entry_steps(l, n, T);        // (length buckets: every entry its own step count)
-    const double bytes = steps * (4.0 * (12.0 * B * H + 4.0 * H * H) + B),
-                 flops = steps * (8.0 * B * H * H + (KXS ? 8.0 * B * H * l[0].Kx : 0.0));
+    const EntrySteps es = entry_steps(l, n, T);       // (length buckets: every entry its own step count)
+    const double bytes = es.rows * (4.0 * 12.0 * B * H + B) + es.weights * 16.0 * H * H,
+                 flops = es.rows * (8.0 * B * H * H + (KXS ? 8.0 * B * H * l[0].Kx : 0.0));
     ProfScope prof(PROF_LSTM_FWD, flops, bytes, s, T);
     LstmClusterP L;
     for (int k = 0; k < n; ++k) L.l[k] = l[k];
@@ -1962,8 +1976,8 @@ int lstm_forward_cluster_x3(const LstmStep* l, int n, const uint8_t* mask_tb, in
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
-    const double steps = entry_steps(l, n, T);
-    const double bytes = steps * (4.0 * (12.0 * B * H + 4.0 * H * H) + B), flops = steps * 8.0 * B * H * H;
+    const EntrySteps es = entry_steps(l, n, T);
+    const double bytes = es.rows * (4.0 * 12.0 * B * H + B) + es.weights * 16.0 * H * H, flops = es.rows * 8.0 * B * H * H;
     ProfScope prof(PROF_LSTM_FWD, flops, bytes, s, T);
     LstmClusterX3P L;
     for (int k = 0; k < n; ++k) { L.l[k] = l[k]; L.tag0[k] = 0u; }
@@ -2047,8 +2061,8 @@ int lstm_backward_cluster_x3w(const LstmStep* l, int n, const uint8_t* mask_tb, 
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWBwdLdsBytes));
         attr = true;
     }
-    const double steps = entry_steps(l, n, T);
-    const double bytes = steps * 4.0 * (15.0 * B * H + 4.0 * H * H), flops = steps * 8.0 * B * H * H;
+    const EntrySteps es = entry_steps(l, n, T);
+    const double bytes = es.rows * 4.0 * 15.0 * B * H + es.weights * 16.0 * H * H, flops = es.rows * 8.0 * B * H * H;
     ProfScope prof(PROF_LSTM_BWD, flops, bytes, s, T + 1);
     LstmClusterP L;
     for (int k = 0; k < n; ++k) L.l[k] = l[k];
@@ -2077,8 +2091,8 @@ static int backward_cluster(const LstmStep* l, int n, const uint8_t* mask_tb, in
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
-    const double steps = entry_steps(l, n, T);
-    const double bytes = steps * 4.0 * (15.0 * B * H + 4.0 * H * H), flops = steps * 8.0 * B * H * H;
+    const EntrySteps es = entry_steps(l, n, T);
+    const double bytes = es.rows * 4.0 * 15.0 * B * H + es.weights * 16.0 * H * H, flops = es.rows * 8.0 * B * H * H;
     ProfScope prof(PROF_LSTM_BWD, flops, bytes, s, T + 1);
     LstmClusterP L;
     for (int k = 0; k < n; ++k) L.l[k] = l[k];
@@ -2119,8 +2133,8 @@ int lstm_backward_cluster_x3(const LstmStep* l, int n, const uint8_t* mask_tb, i
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
-    const double steps = entry_steps(l, n, T);
-    const double bytes = steps * 4.0 * (15.0 * B * H + 4.0 * H * H), flops = steps * 8.0 * B * H * H;
+    const EntrySteps es = entry_steps(l, n, T);
+    const double bytes = es.rows * 4.0 * 15.0 * B * H + es.weights * 16.0 * H * H, flops = es.rows * 8.0 * B * H * H;
     ProfScope prof(PROF_LSTM_BWD, flops, bytes, s, T + 1);
     LstmClusterP L;
     for (int k = 0; k < n; ++k) L.l[k] = l[k];
