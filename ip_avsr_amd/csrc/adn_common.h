@@ -168,6 +168,8 @@ constexpr int kActRectifyHalf = 64;
 struct TransposeItem { const float* W; void* out; int rows, cols, ld, ldT, block_end; };
 int transpose_to_bf16_batch(const TransposeItem* dev_items, int n, int total_blocks, hipStream_t s, int lo_part = 0);
 int split_hilo(const float* src, void* hi, void* lo, size_t n, hipStream_t s);   // fp32 -> the bf16x3 mode's two planes
+constexpr int kMaxSplitJobs = 8;
+int split_hilo_batch(const float* const* src, void* const* hi, void* const* lo, int n, size_t count, hipStream_t s);   // n tensors of `count` elements, one launch
 int join_hilo(const void* hi, const void* lo, float* dst, size_t n, hipStream_t s);   // ... and back (hi + lo)
 // frame compaction of the encoder path (compact.hip): row maps, gathers, the expand / compact-and-sum passes at the delta layer
 int compact_build_maps(const int32_t* d_lens, const int32_t* d_prefix, int B, int T, int Z, int32_t* comp_of_full, int32_t* full_of_comp,
@@ -197,12 +199,14 @@ int delta_backward(const float* dout, int ld_out, float* din, int ld_in, int B, 
                    int append, hipStream_t s, void* din16 = nullptr);
 // out[r][c] = sum_k alpha_k * in_k[r][c]  (alpha = device scalars or null for 1)
 int sum_k(int n_in, const float* const* in, const float* const* alpha, int ld_in, float* out, int ld_out,
-          int rows, int cols, hipStream_t s, void* out16 = nullptr);
+          int rows, int cols, hipStream_t s, void* out16 = nullptr, void* out16lo = nullptr);   // (out16lo: with out16 the hi / lo planes)
 // out[r][c] = alpha[0] * in[r][c]   (alpha device scalar)
 int scale_by(const float* in, int ld_in, const float* alpha, float* out, int ld_out, int rows, int cols,
              hipStream_t s);
 // bf16: out[r][j*cols + c] = in_j[r][c] (n <= 4 inputs with the same ld; cols % 8 == 0)
-int concat_cols_bf16(int n, const void* const* in, int ld_in, void* out, int ld_out, int rows, int cols, hipStream_t s);
+// (in_lo / out_lo: the lo planes of the same matrices, concatenated by the same launch)
+int concat_cols_bf16(int n, const void* const* in, int ld_in, void* out, int ld_out, int rows, int cols, hipStream_t s,
+                     const void* const* in_lo = nullptr, void* out_lo = nullptr);
 // dst[(j*rows_valid + k)*ld + c] += src[(j*rows_pad + k)*ld + c]
 int add_row_blocks(const float* src, float* dst, int ld, int nblk, int rows_valid, int rows_pad, int cols, hipStream_t s);
 // out[c] (+)= sum_r in[r][c]
@@ -242,7 +246,8 @@ int lstm_init_state_batch(const LstmInitJob* jobs, int n, int ld, int rows, int 
 //   row_loss[r] = -mask*log softmax(softmax(z))[y]  (if y != null), dz (may be null)
 int softmax_loss(const float* z, int ldz, int B, int T, int C, const uint8_t* mask_tb, const int32_t* y_bt,
                  const float* total, float* probs_bt, float* row_loss, float* dz, int lddz, hipStream_t s, void* dz16 = nullptr,
-                 const int32_t* bt_of_row = nullptr, int table_rows = 0);   // (bt_of_row: the frame b T + t of each of table_rows rows, -1 = none)
+                 const int32_t* bt_of_row = nullptr, int table_rows = 0,     // (bt_of_row: the frame b T + t of each of table_rows rows, -1 = none)
+                 void* dz16lo = nullptr);                                    // (dz16lo: with dz16 the hi / lo planes of dz)
 // out[0] = (sum_i v[i]) / total[0], fixed summation order
 int reduce_loss(const float* v, int n, const float* total, float* out, hipStream_t s);
 // p16: optional bf16 shadow of the parameters, written with the update

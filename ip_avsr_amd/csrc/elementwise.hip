@@ -292,7 +292,7 @@ struct SumKArgs {
 };
 
 __global__ __launch_bounds__(256) void sum_k_kernel(SumKArgs a, int ld_in, float* __restrict__ out, int ld_out,
-                                                    int rows, int cols4, __bf16* __restrict__ out16) {
+                                                    int rows, int cols4, __bf16* __restrict__ out16, __bf16* __restrict__ out16lo) {
     const int64_t total = (int64_t)rows * cols4;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int r = (int)(e / cols4), c = (int)(e % cols4) * 4;
@@ -307,6 +307,11 @@ __global__ __launch_bounds__(256) void sum_k_kernel(SumKArgs a, int ld_in, float
             typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
             bf16x4_t h; h[0] = (__bf16)acc.x; h[1] = (__bf16)acc.y; h[2] = (__bf16)acc.z; h[3] = (__bf16)acc.w;
             *reinterpret_cast<bf16x4_t*>(out16 + (size_t)r * ld_out + c) = h;
+            if (out16lo) {                  // bf16x3 / mixed: out16 is the hi plane, this the lo plane bf16(x - hi)
+                bf16x4_t l; l[0] = (__bf16)(acc.x - (float)h[0]); l[1] = (__bf16)(acc.y - (float)h[1]);
+                l[2] = (__bf16)(acc.z - (float)h[2]); l[3] = (__bf16)(acc.w - (float)h[3]);
+                *reinterpret_cast<bf16x4_t*>(out16lo + (size_t)r * ld_out + c) = l;
+            }
         }
     }
 }
@@ -319,14 +324,14 @@ static inline int grid_for(int64_t work_items) {
 // NOTE: operates on whole float4 groups up to round_up(cols,4) <= ld; pad columns of the inputs are
 // zero by construction, so the pad columns of the output stay zero.
 int sum_k(int n_in, const float* const* in, const float* const* alpha, int ld_in, float* out, int ld_out, int rows,
-          int cols, hipStream_t s, void* out16) {
-    ADN_CHECK(n_in >= 1 && n_in <= ADN_MAX_STREAMS, ADN_ERR_INVALID, "sum_k: bad operand count");
+          int cols, hipStream_t s, void* out16, void* out16lo) {
+    ADN_CHECK(n_in >= 1 && n_in <= ADN_MAX_STREAMS && (!out16lo || out16), ADN_ERR_INVALID, "sum_k: bad operand count");
     SumKArgs a;
     a.n = n_in;
     for (int k = 0; k < n_in; ++k) { a.in[k] = in[k]; a.alpha[k] = alpha ? alpha[k] : nullptr; }
     const int cols4 = cdiv(cols, 4);
     hipLaunchKernelGGL(sum_k_kernel, dim3(grid_for((int64_t)rows * cols4)), dim3(256), 0, s, a, ld_in, out, ld_out,
-                       rows, cols4, reinterpret_cast<__bf16*>(out16));
+                       rows, cols4, reinterpret_cast<__bf16*>(out16), reinterpret_cast<__bf16*>(out16lo));
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }
@@ -519,26 +524,34 @@ int repack_rows_bf16_lo(int n, const float* const* in, void* const* out, int nbl
 }
 
 // out[r][j * cols + c] = in_j[r][c]  (bf16; cols a multiple of 8): the materialised concat of up to 4 matrices
-struct ConcatArgs { const void* in[4]; };
+// (blockIdx.y = plane: the hi and the lo concat of the bf16x3 / mixed arithmetics leave in one launch -- in[4 + j] and out2)
+struct ConcatArgs { const void* in[8]; };
 __global__ __launch_bounds__(256) void concat_cols_bf16_kernel(ConcatArgs a, int n, int ld_in, uint4* __restrict__ out, int ld_out,
-                                                               int rows, int cols) {
+                                                               int rows, int cols, uint4* __restrict__ out2) {
     const int cpr = cols / 8, per_row = n * cpr;                       // 16-byte chunks
     const int64_t total = (int64_t)rows * per_row;
+    const int pl = (int)blockIdx.y;
+    uint4* __restrict__ dst = pl ? out2 : out;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int r = (int)(e / per_row), q = (int)(e % per_row), j = q / cpr, c = q % cpr;
-        out[(size_t)r * (ld_out / 8) + q] = reinterpret_cast<const uint4*>(a.in[j])[(size_t)r * (ld_in / 8) + c];
+        const void* src = a.in[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) if (4 * pl + j == k) src = a.in[k];        // (explicit selects: no scratch copy of the table)
+        dst[(size_t)r * (ld_out / 8) + q] = reinterpret_cast<const uint4*>(src)[(size_t)r * (ld_in / 8) + c];
     }
 }
 
-int concat_cols_bf16(int n, const void* const* in, int ld_in, void* out, int ld_out, int rows, int cols, hipStream_t s) {
-    ADN_CHECK(n >= 1 && n <= 4 && cols % 8 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0, ADN_ERR_INVALID, "concat_cols_bf16: bad shape");
+int concat_cols_bf16(int n, const void* const* in, int ld_in, void* out, int ld_out, int rows, int cols, hipStream_t s,
+                     const void* const* in_lo, void* out_lo) {
+    ADN_CHECK(n >= 1 && n <= 4 && cols % 8 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0 && (in_lo == nullptr) == (out_lo == nullptr), ADN_ERR_INVALID,
+              "concat_cols_bf16: bad shape");
     if (rows <= 0) return ADN_OK;
     ConcatArgs a{};
-    for (int j = 0; j < n; ++j) a.in[j] = in[j];
+    for (int j = 0; j < n; ++j) { a.in[j] = in[j]; a.in[4 + j] = in_lo ? in_lo[j] : in[j]; }
     const int64_t total = (int64_t)rows * n * (cols / 8);
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, 8192));
-    hipLaunchKernelGGL(concat_cols_bf16_kernel, dim3(grid), dim3(256), 0, s, a, n, ld_in, reinterpret_cast<uint4*>(out), ld_out,
-                       rows, cols);
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, in_lo ? 4096 : 8192));
+    hipLaunchKernelGGL(concat_cols_bf16_kernel, dim3(grid, in_lo ? 2 : 1), dim3(256), 0, s, a, n, ld_in, reinterpret_cast<uint4*>(out), ld_out,
+                       rows, cols, reinterpret_cast<uint4*>(out_lo));
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }
@@ -928,7 +941,7 @@ __global__ __launch_bounds__(256) void softmax_loss_kernel(const float* __restri
                                                            const float* __restrict__ total,
                                                            float* __restrict__ probs_bt, float* __restrict__ row_loss,
                                                            float* __restrict__ dz, int lddz, __bf16* __restrict__ dz16,
-                                                           const int32_t* __restrict__ bt_of_row, int rows) {
+                                                           const int32_t* __restrict__ bt_of_row, int rows, __bf16* __restrict__ dz16lo) {
     const int r = (blockIdx.x * 256 + threadIdx.x) / G;
     const int c = threadIdx.x % G;
     if (r >= rows) return;                 // whole groups exit together (256 % G == 0)
@@ -938,7 +951,11 @@ __global__ __launch_bounds__(256) void softmax_loss_kernel(const float* __restri
     const bool cv = c < C;
     if (bt < 0) {
         if (row_loss && c == 0) row_loss[r] = 0.f;
-        if (dz && cv) { dz[(size_t)r * lddz + c] = 0.f; if (dz16) dz16[(size_t)r * lddz + c] = (__bf16)0.f; }
+        if (dz && cv) {
+            dz[(size_t)r * lddz + c] = 0.f;
+            if (dz16) dz16[(size_t)r * lddz + c] = (__bf16)0.f;
+            if (dz16lo) dz16lo[(size_t)r * lddz + c] = (__bf16)0.f;
+        }
         return;
     }
     const float zc = cv ? z[(size_t)r * ldz + c] : -INFINITY;
@@ -957,23 +974,30 @@ __global__ __launch_bounds__(256) void softmax_loss_kernel(const float* __restri
     if (dz) {
         const float dp = cv ? (msk / total[0]) * (q - (c == y ? 1.f : 0.f)) : 0.f;
         const float dot = group_sum<G>(dp * p);
-        if (cv) dz[(size_t)r * lddz + c] = p * (dp - dot);
-        if (cv && dz16) dz16[(size_t)r * lddz + c] = (__bf16)(p * (dp - dot));
+        const float g = p * (dp - dot);
+        if (cv) dz[(size_t)r * lddz + c] = g;
+        if (cv && dz16) {
+            const __bf16 h = (__bf16)g;
+            dz16[(size_t)r * lddz + c] = h;
+            if (dz16lo) dz16lo[(size_t)r * lddz + c] = (__bf16)(g - (float)h);       // (planes: hi beside it)
+        }
     }
 }
 
 int softmax_loss(const float* z, int ldz, int B, int T, int C, const uint8_t* mask_tb, const int32_t* y_bt,
                  const float* total, float* probs_bt, float* row_loss, float* dz, int lddz, hipStream_t s, void* dz16,
-                 const int32_t* bt_of_row, int table_rows) {
+                 const int32_t* bt_of_row, int table_rows, void* dz16lo) {
     ADN_CHECK(C >= 1 && C <= ADN_MAX_CLASSES, ADN_ERR_INVALID, "softmax: unsupported number of classes");
     const int rows = bt_of_row ? table_rows : B * T;
     ProfScope prof(PROF_SOFTMAX_LOSS, 0.0, 4.0 * rows * (double)C * (dz ? 3.0 : 2.0), s);
     if (C <= 32) {
         hipLaunchKernelGGL(softmax_loss_kernel<32>, dim3(cdiv(rows, 8)), dim3(256), 0, s, z, ldz, B, T, C, mask_tb,
-                           y_bt, total, probs_bt, row_loss, dz, lddz, reinterpret_cast<__bf16*>(dz16), bt_of_row, rows);
+                           y_bt, total, probs_bt, row_loss, dz, lddz, reinterpret_cast<__bf16*>(dz16), bt_of_row, rows,
+                           reinterpret_cast<__bf16*>(dz16lo));
     } else {
         hipLaunchKernelGGL(softmax_loss_kernel<64>, dim3(cdiv(rows, 4)), dim3(256), 0, s, z, ldz, B, T, C, mask_tb,
-                           y_bt, total, probs_bt, row_loss, dz, lddz, reinterpret_cast<__bf16*>(dz16), bt_of_row, rows);
+                           y_bt, total, probs_bt, row_loss, dz, lddz, reinterpret_cast<__bf16*>(dz16), bt_of_row, rows,
+                           reinterpret_cast<__bf16*>(dz16lo));
     }
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;

@@ -1933,6 +1933,37 @@ int split_hilo(const float* src, void* hi, void* lo, size_t n, hipStream_t s) {
     return ADN_OK;
 }
 
+// the same for up to kMaxSplitJobs tensors of ONE size in one launch (blockIdx.y = tensor): the state histories of the LSTMs of a
+// launch, which become GEMM operands together -- three 7 us launches are latency, one is 9
+struct SplitJobTable { const float* src[kMaxSplitJobs]; __bf16* hi[kMaxSplitJobs]; __bf16* lo[kMaxSplitJobs]; };
+__global__ __launch_bounds__(256) void split_hilo_batch_kernel(const SplitJobTable t, size_t n8) {
+    const float* __restrict__ src = t.src[0]; __bf16* __restrict__ hi = t.hi[0]; __bf16* __restrict__ lo = t.lo[0];
+#pragma unroll
+    for (int k = 1; k < kMaxSplitJobs; ++k) if ((int)blockIdx.y == k) { src = t.src[k]; hi = t.hi[k]; lo = t.lo[k]; }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+        bf16x4 ha, la, hb, lb;
+        split4(a, ha, la); split4(b, hb, lb);
+        reinterpret_cast<bf16x8*>(hi)[i] = join(ha, hb);
+        reinterpret_cast<bf16x8*>(lo)[i] = join(la, lb);
+    }
+}
+int split_hilo_batch(const float* const* src, void* const* hi, void* const* lo, int n, size_t count, hipStream_t s) {
+    ADN_CHECK(n >= 1 && n <= kMaxSplitJobs && count % 8 == 0, ADN_ERR_INVALID, "split_hilo_batch: 1..8 tensors of a multiple of 8 elements");
+    if (!count) return ADN_OK;
+    if (n == 1) return split_hilo(src[0], hi[0], lo[0], count, s);
+    SplitJobTable t;
+    for (int k = 0; k < kMaxSplitJobs; ++k) {
+        const int q = k < n ? k : 0;
+        t.src[k] = src[q]; t.hi[k] = reinterpret_cast<__bf16*>(hi[q]); t.lo[k] = reinterpret_cast<__bf16*>(lo[q]);
+    }
+    const size_t n8 = count / 8;
+    const int grid = (int)std::max<size_t>(1, std::min<size_t>((n8 + 255) / 256, 2048));
+    hipLaunchKernelGGL(split_hilo_batch_kernel, dim3(grid, n), dim3(256), 0, s, t, n8);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
 // ... and back: x' = hi + lo (exact in fp32; splitting x' again gives the same two planes)
 __global__ __launch_bounds__(256) void join_hilo_kernel(const __bf16* __restrict__ hi, const __bf16* __restrict__ lo, float* __restrict__ dst,
                                                         size_t n8) {

@@ -1601,7 +1601,20 @@ int run_lstm_group(adn_model* m, std::vector<LstmStep>& steps, int B, int T, boo
         for (int k = 0; k < n; ++k) planes_done[i + k] = backward && done && (mixed16 || (steps[i + k].dG16 && steps[i + k].dG16lo));
     }
     if (sums_done) *sums_done = backward && all;
-    if (m->planes())                 // (bf16 mode: the kernels write the 16-bit copies themselves)
+    if (m->planes() && !backward && !streams_concurrent(m)) {
+        // the state histories of the group as planes (they are the next GEMMs' operands): one launch for all of them
+        const size_t count = (size_t)round_up((int64_t)(T + 1) * B * m->ldh, 8);
+        for (size_t q0 = 0; q0 < steps.size(); q0 += kMaxSplitJobs) {
+            const float* src[kMaxSplitJobs]; void* hi[kMaxSplitJobs]; void* lo[kMaxSplitJobs];
+            int n = 0;
+            for (size_t q = q0; q < std::min(steps.size(), q0 + kMaxSplitJobs); ++q) {
+                void* h = m->shadow_of(steps[q].hbuf); void* l = m->shadow_lo_of(steps[q].hbuf);
+                if (!h || !l) continue;
+                src[n] = steps[q].hbuf; hi[n] = h; lo[n] = l; ++n;
+            }
+            if (n) ADN_TRY(split_hilo_batch(src, hi, lo, n, count, m->stream));
+        }
+    } else if (m->planes())          // (bf16 mode: the kernels write the 16-bit copies themselves)
         for (size_t q = 0; q < steps.size(); ++q) {
             const LstmStep& st_ = steps[q];
             if (backward) {
@@ -1954,8 +1967,12 @@ int forward_pass(adn_model* m, int B0, int T0, int theta, bool want_loss, bool w
     for (auto& st : m->st) {
         if (st.lstm.size() == 2) {                               // summed BLSTM sub-stream
             const float* in[2] = {st.lw[0].out(B, ldh, false), st.lw[1].out(B, ldh, true)};
-            ADN_TRY(sum_k(2, in, nullptr, ldh, st.hsum, ldh, N, H, s));
-            ADN_TRY(refresh(m, st.hsum, (size_t)N * ldh));
+            // (the 16-bit copies the next GEMMs read leave with the sum: the bf16 copy, or both planes)
+            void* s16 = (m->bf16() || m->planes()) ? m->shadow_of(st.hsum) : nullptr;
+            void* s16lo = (m->planes() && s16) ? m->shadow_lo_of(st.hsum) : nullptr;
+            if (m->planes() && !s16lo) s16 = nullptr;
+            ADN_TRY(sum_k(2, in, nullptr, ldh, st.hsum, ldh, N, H, s, s16, s16lo));
+            if (!s16) ADN_TRY(refresh(m, st.hsum, (size_t)N * ldh));
             st.out_ptr = st.hsum;
         } else {
             st.out_ptr = st.lw[0].out(B, ldh, false);
@@ -2014,13 +2031,10 @@ int forward_pass(adn_model* m, int B0, int T0, int theta, bool want_loss, bool w
             m->cat_planes_ok = cat;
         }
         if (cat) {
-            const void* in16[4];
-            for (int j = 0; j < m->S; ++j) in16[j] = m->shadow_of(fin[j]);
-            ADN_TRY(concat_cols_bf16(m->S, in16, ldh, m->cat16, m->S * ldh, N, ldh, s));
-            if (m->planes()) {
-                for (int j = 0; j < m->S; ++j) in16[j] = m->shadow_lo_of(fin[j]);
-                ADN_TRY(concat_cols_bf16(m->S, in16, ldh, m->cat16lo, m->S * ldh, N, ldh, s));
-            }
+            const void* in16[4]; const void* in16lo[4];
+            for (int j = 0; j < m->S; ++j) { in16[j] = m->shadow_of(fin[j]); in16lo[j] = m->planes() ? m->shadow_lo_of(fin[j]) : nullptr; }
+            // (bf16x3 / mixed: the hi and the lo concat in one launch)
+            ADN_TRY(concat_cols_bf16(m->S, in16, ldh, m->cat16, m->S * ldh, N, ldh, s, m->planes() ? in16lo : nullptr, m->planes() ? m->cat16lo : nullptr));
         }
         if (cat) {                                               // the pair's projections share the concat: one grouped launch
             GemmArgs gs[kMaxGemmGroups];
@@ -2039,8 +2053,11 @@ int forward_pass(adn_model* m, int B0, int T0, int theta, bool want_loss, bool w
         ADN_TRY(run_lstm_group(m, steps, B, T, false));
         if (m->agg.size() == 2) {
             const float* in[2] = {m->aggw[0].out(B, ldh, false), m->aggw[1].out(B, ldh, true)};
-            ADN_TRY(sum_k(2, in, nullptr, ldh, m->cls_in, ldh, N, H, s, m->bf16() ? m->shadow_of(m->cls_in) : nullptr));
-            if (!m->bf16()) ADN_TRY(refresh(m, m->cls_in, (size_t)N * ldh));
+            void* c16 = (m->bf16() || m->planes()) ? m->shadow_of(m->cls_in) : nullptr;
+            void* c16lo = (m->planes() && c16) ? m->shadow_lo_of(m->cls_in) : nullptr;
+            if (m->planes() && !c16lo) c16 = nullptr;
+            ADN_TRY(sum_k(2, in, nullptr, ldh, m->cls_in, ldh, N, H, s, c16, c16lo));
+            if (!c16) ADN_TRY(refresh(m, m->cls_in, (size_t)N * ldh));
             cls = m->cls_in;
         } else {
             cls = m->aggw[0].out(B, ldh, false);
@@ -2070,11 +2087,12 @@ int forward_pass(adn_model* m, int B0, int T0, int theta, bool want_loss, bool w
         ADN_TRY(mgemm(m, g));
     }
     // (length buckets: which frame a row holds comes from the table; rows without one get a zero gradient and no loss)
+    const bool dz_planes = m->planes() && m->shadow_of(m->dz) && m->shadow_lo_of(m->dz);      // bf16x3 / mixed: dz leaves as fp32 + both planes
     ADN_TRY(softmax_loss(m->z, m->ldc, B0, T0, m->C, m->mask_tb, want_loss ? m->y_src : nullptr, m->total, m->probs_bt,
                          want_loss ? m->row_loss : nullptr, want_dz ? m->dz : nullptr, m->ldc, s,
-                         (want_dz && m->bf16()) ? m->shadow_of(m->dz) : nullptr,      // (pad columns of dz stay zero in both copies)
-                         m->tm.on ? m->tm_bt : nullptr, N));
-    if (want_dz && !m->bf16()) ADN_TRY(refresh(m, m->dz, (size_t)N * m->ldc));
+                         (want_dz && (m->bf16() || dz_planes)) ? m->shadow_of(m->dz) : nullptr,      // (pad columns of dz stay zero in every copy)
+                         m->tm.on ? m->tm_bt : nullptr, N, (want_dz && dz_planes) ? m->shadow_lo_of(m->dz) : nullptr));
+    if (want_dz && !m->bf16() && !dz_planes) ADN_TRY(refresh(m, m->dz, (size_t)N * m->ldc));
     if (want_loss) ADN_TRY(reduce_loss(m->row_loss, N, m->total, m->loss, s));
     m->lastB = B0; m->lastT = T0;
     return ADN_OK;
