@@ -226,7 +226,7 @@ int broadcast_rows(const float* vec, float* dst, int ld, int rows, int cols, hip
 // h[r][:] = hid, c[r][:] = cell for r < rows (pad columns 0), h16 = optional bf16 copy of h
 int lstm_init_state_rows(const float* hid, const float* cell, float* h, float* c, void* h16, int ld, int rows, int cols, hipStream_t s);
 // housekeeping of several same-shape tensors in ONE launch (the S input streams' delta layers, the LSTMs' initial states)
-constexpr int kMaxDeltaJobs = 4, kMaxInitJobs = 8;
+constexpr int kMaxDeltaJobs = 4, kMaxInitJobs = 12;      // (12: three stream LSTMs x four length buckets)
 struct DeltaJob {
     const float* src; int ld_src; float* dst; int ld_dst; int F; int append; void* dst16;
     void* dst16lo = nullptr;              // bf16x3 / mixed: dst16 is the hi plane of the result, this its lo plane
@@ -259,7 +259,7 @@ constexpr int kMaxAdamRanges = 16;
 struct AdamRanges { int64_t begin[kMaxAdamRanges], end[kMaxAdamRanges]; };    // float offsets into the flat buffers (multiples of 8)
 int adam_update_ranges(float* p, const float* g, float* m, float* v, const int64_t* begin, const int64_t* end, int n_ranges, float a_t,
                        float beta1, float beta2, float eps, hipStream_t s, void* p16, const float* poison, int* sticky, void* p16lo);
-int poison_tail(const int* err_word, float* tail1, hipStream_t s);
+int poison_tail(const int* err_word, float* tail1, hipStream_t s, const float* loss = nullptr, float* tail0 = nullptr);
 int copy_bench(const float* src, float* dst, int64_t n, int repeats, hipStream_t s, float* ms);
 // lasagne.updates.sgd (momentum == 0) / momentum / nesterov_momentum; adadelta
 int sgd_update(float* p, const float* g, float* vel, int64_t n, float lr, float momentum, int nesterov, hipStream_t s,

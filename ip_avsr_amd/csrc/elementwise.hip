@@ -1161,11 +1161,14 @@ int copy_bench(const float* src, float* dst, int64_t n, int repeats, hipStream_t
 
 // tail[1] of the gradient buffer = 1 when this device's LSTM-exchange error word is raised (it rides through the data-parallel
 // all-reduce, so that the optimiser kernels of EVERY rank see it and skip the update together)
-__global__ void poison_tail_kernel(const int* __restrict__ err_word, float* __restrict__ tail1) {
+// (loss / tail0, optional: the rank's cost share goes into tail[0] with the same launch -- it has the same deadline, bucket 0's release)
+__global__ void poison_tail_kernel(const int* __restrict__ err_word, float* __restrict__ tail1, const float* __restrict__ loss,
+                                   float* __restrict__ tail0) {
     *tail1 = (*err_word != 0) ? 1.f : 0.f;
+    if (loss) *tail0 = *loss;
 }
-int poison_tail(const int* err_word, float* tail1, hipStream_t s) {
-    hipLaunchKernelGGL(poison_tail_kernel, dim3(1), dim3(1), 0, s, err_word, tail1);
+int poison_tail(const int* err_word, float* tail1, hipStream_t s, const float* loss, float* tail0) {
+    hipLaunchKernelGGL(poison_tail_kernel, dim3(1), dim3(1), 0, s, err_word, tail1, loss, tail0);
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
 }

@@ -959,6 +959,7 @@ LstmStep make_step(const adn_model* m, const LstmParams& lp, const LstmWork& w, 
 bool streams_concurrent(const adn_model* m);
 static std::vector<LstmStep> expand_entries(const adn_model* m, const TmPlan& p, const LstmStep* l, int n);
 static int decide_buckets(adn_model* m, int B, int T);
+static int zero_spare_blocks(adn_model* m);
 int setup_buckets(adn_model* m, int B, int T) {
     ADN_TRY(decide_buckets(m, B, T));
     // The exchange buffers of the weight-stationary LSTM kernels are cut by the launch geometry: one region per entry, sized by the
@@ -996,7 +997,10 @@ static int decide_buckets(adn_model* m, int B, int T) {
     // its tables are still on the device; only the mask's empty rows need their zeros back when another layout was there since
     if (m->tm_cached.on && m->tm_lens == lens && m->tm_key_T == T && m->tm_key_prec == m->cfg.precision && m->tm_key_mixed == (int)m->bwd_hi_only) {
         m->tm = m->tm_cached;
-        if (!was_on) ADN_HIP_CHECK(hipMemsetAsync(m->mask_tb, 0, (size_t)B * T, m->stream));
+        if (!was_on) {                 // (a call over B x T rows wrote the mask's and the gate gradients' rows no frame lives in)
+            ADN_HIP_CHECK(hipMemsetAsync(m->mask_tb, 0, (size_t)B * T, m->stream));
+            ADN_TRY(zero_spare_blocks(m));
+        }
         return ADN_OK;
     }
     m->tm_cached.on = false;
@@ -1059,8 +1063,9 @@ static int decide_buckets(adn_model* m, int B, int T) {
         ADN_HIP_CHECK(hipMemcpyAsync(m->tm_T, tw, (size_t)B * 4, hipMemcpyHostToDevice, m->stream));
         ADN_HIP_CHECK(hipMemcpyAsync(m->tm_bt, bt, rows * 4, hipMemcpyHostToDevice, m->stream));
         ADN_HIP_CHECK(hipEventRecord(slot.ev, m->stream));
-        // rows no frame lives in keep a zero mask (mask_prepare writes the frames' rows only)
+        // rows no frame lives in keep a zero mask (mask_prepare writes the frames' rows only) and zero gate gradients
         ADN_HIP_CHECK(hipMemsetAsync(m->mask_tb, 0, (size_t)B * T, m->stream));
+        ADN_TRY(zero_spare_blocks(m));
     }
     return ADN_OK;
 }
@@ -1522,7 +1527,7 @@ static std::vector<LstmStep> expand_entries(const adn_model* m, const TmPlan& p,
 // LSTMs per launch: all kMaxLstmPerLaunch entries, or as many whole LSTMs as their buckets leave room for
 static int lstms_per_launch(const adn_model* m) { return m->tm.on ? std::max(1, kMaxLstmPerLaunch / m->tm.nb) : kMaxLstmPerLaunch; }
 // the gate-gradient rows of the spare blocks: never written by the LSTM kernels, read by every GEMM over all rows -- zero, in the
-// copies the step's GEMMs read (one small launch per backward pass; rows of an earlier cut may lie there)
+// copies the step's GEMMs read (rows of an earlier cut, or of a call over B x T rows, may lie there)
 struct ZeroBlocksArgs { void* p[3 * 8]; int row_bytes[3 * 8]; int n; int blk[kMaxBuckets]; int nblk; int Bb; };
 __global__ __launch_bounds__(256) void zero_spare_blocks_kernel(const ZeroBlocksArgs a) {
     const int q = blockIdx.y;
@@ -1533,23 +1538,31 @@ __global__ __launch_bounds__(256) void zero_spare_blocks_kernel(const ZeroBlocks
         for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < per; e += (size_t)gridDim.x * 256) dst[e] = make_uint4(0u, 0u, 0u, 0u);
     }
 }
-static int zero_spare_blocks(adn_model* m, const std::vector<LstmStep>& steps) {
+// ... of every LSTM of the model, in every copy a GEMM may read (fp32, bf16 copy / hi plane, lo plane).  Called where the layout
+// changes -- new tables, or a call over B x T rows in between, whose gate gradients fill those rows --, not per step: inside a run of
+// bucketed steps nothing writes there (the LSTM kernels store their own blocks; whole-buffer conversions map zeros to zeros).
+static int zero_spare_blocks(adn_model* m) {
     if (!m->tm.on || m->tm.nb < 2) return ADN_OK;
-    for (size_t i = 0; i < steps.size(); i += 8) {
-        ZeroBlocksArgs a{};
-        for (size_t k = i; k < std::min(steps.size(), i + 8); ++k) {
-            const LstmStep& q = steps[k];
-            if (q.dG && !q.dG_fp32_off && !(q.dG16 && q.dG16lo)) { a.p[a.n] = q.dG; a.row_bytes[a.n++] = m->ldg * 4; }
-            if (q.dG16) { a.p[a.n] = q.dG16; a.row_bytes[a.n++] = m->ldg * 2; }
-            if (q.dG16lo) { a.p[a.n] = q.dG16lo; a.row_bytes[a.n++] = m->ldg * 2; }
-        }
-        a.Bb = m->tm.Bb;
-        for (int k = 0; k + 1 < m->tm.nb; ++k) a.blk[a.nblk++] = m->tm.c[k] + m->tm.Tk[k];
-        if (!a.n) continue;
+    ZeroBlocksArgs a{};
+    a.Bb = m->tm.Bb;
+    for (int k = 0; k + 1 < m->tm.nb; ++k) a.blk[a.nblk++] = m->tm.c[k] + m->tm.Tk[k];
+    auto flush = [&]() -> int {
+        if (!a.n) return ADN_OK;
         hipLaunchKernelGGL(zero_spare_blocks_kernel, dim3(32, a.n), dim3(256), 0, m->stream, a);
         ADN_HIP_CHECK(hipGetLastError());
-    }
-    return ADN_OK;
+        a.n = 0;
+        return ADN_OK;
+    };
+    auto add = [&](LstmWork& w) -> int {
+        if (a.n + 3 > 3 * 8) ADN_TRY(flush());
+        a.p[a.n] = w.dG; a.row_bytes[a.n++] = m->ldg * 4;
+        if (void* h = m->shadow_of(w.dG)) { a.p[a.n] = h; a.row_bytes[a.n++] = m->ldg * 2; }
+        if (void* l = m->shadow_lo_of(w.dG)) { a.p[a.n] = l; a.row_bytes[a.n++] = m->ldg * 2; }
+        return ADN_OK;
+    };
+    for (auto& st : m->st) for (auto& w : st.lw) ADN_TRY(add(w));
+    for (auto& w : m->aggw) ADN_TRY(add(w));
+    return flush();
 }
 
 // sums_done: the backward kernels already added the bias / initial-state gradients of every LSTM of the group
@@ -1580,7 +1593,6 @@ int run_lstm_group(adn_model* m, std::vector<LstmStep>& steps, int B, int T, boo
             mixed16 = lstm_cluster_supported(ex.data(), (int)ex.size(), Bk, Tk, m->H);
         }
     }
-    if (backward) ADN_TRY(zero_spare_blocks(m, mixed16 ? alt : steps));
     for (size_t i = 0; i < steps.size(); i += (size_t)per) {
         const int n = (int)std::min<size_t>((size_t)per, steps.size() - i);
         bool done = false;
@@ -2246,8 +2258,9 @@ int backward_pass(adn_model* m, int B0, int T0, int theta) {
     auto tm_job = [&](DeltaJob& dj) { if (m->tm.on) { dj.tm_row0 = m->tm_row0; dj.tm_T = m->tm_T; dj.tm_stride = m->tm.Bb; } };
     hipStream_t s = m->stream;
     ADN_HIP_CHECK(hipMemsetAsync(m->flat[ADN_BUF_GRAD], 0, (m->flat_floats + kAuxFloats) * sizeof(float), s));
-    ADN_HIP_CHECK(hipMemcpyAsync(m->flat[ADN_BUF_GRAD] + m->flat_floats, m->loss, sizeof(float),
-                                 hipMemcpyDeviceToDevice, s));
+    // (the cost share, tail[0]: with the exchange status where a weight-stationary LSTM kernel may have run -- one launch for both)
+    if (m->cfg.precision == ADN_PRECISION_F32)
+        ADN_HIP_CHECK(hipMemcpyAsync(m->flat[ADN_BUF_GRAD] + m->flat_floats, m->loss, sizeof(float), hipMemcpyDeviceToDevice, s));
     const float* cls = classifier_input(m, B);
     if (m->head_last()) {   // classifier on the last time step only: every other row of d(cls) is zero
         const float* cl = cls + (size_t)(T - 1) * B * ldh;
@@ -2428,7 +2441,7 @@ int backward_pass(adn_model* m, int B0, int T0, int theta) {
         if (m->cfg.precision != ADN_PRECISION_F32) {   // (bf16 and bf16x3 run the weight-stationary LSTM kernels)
             int* word = nullptr;
             ADN_TRY(lstm_cluster_error_word(&word));
-            ADN_TRY(poison_tail(word, m->poison_word(), m->stream));
+            ADN_TRY(poison_tail(word, m->poison_word(), m->stream, m->loss, m->flat[ADN_BUF_GRAD] + m->flat_floats));
         }
         ADN_TRY(bucket_ready(0));
     }
