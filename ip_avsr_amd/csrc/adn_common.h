@@ -175,6 +175,9 @@ int join_hilo(const void* hi, const void* lo, float* dst, size_t n, hipStream_t 
 int compact_build_maps(const int32_t* d_lens, const int32_t* d_prefix, int B, int T, int Z, int32_t* comp_of_full, int32_t* full_of_comp,
                        hipStream_t s);
 int compact_gather_rows16(const void* src, int ld_src, void* dst, int ld_dst, const int32_t* full_of_comp, int Nc, int cols, hipStream_t s);
+constexpr int kMaxGatherJobs = 8;
+int compact_gather_rows16_batch(const void* const* src, void* const* dst, int n, int ld_src, int ld_dst, const int32_t* full_of_comp, int Nc, int cols,
+                                hipStream_t s);     // n matrices of one geometry, one launch
 // ... from float32 rows, converted on the way (dst_lo: the lo plane, or nullptr for the bf16 copy alone)
 int compact_gather_rows_f32(const float* src, int ld_src, void* dst_hi, void* dst_lo, int ld_dst, const int32_t* full_of_comp, int Nc, int cols,
                             hipStream_t s);
@@ -209,6 +212,7 @@ int concat_cols_bf16(int n, const void* const* in, int ld_in, void* out, int ld_
                      const void* const* in_lo = nullptr, void* out_lo = nullptr);
 // dst[(j*rows_valid + k)*ld + c] += src[(j*rows_pad + k)*ld + c]
 int add_row_blocks(const float* src, float* dst, int ld, int nblk, int rows_valid, int rows_pad, int cols, hipStream_t s);
+int add_row_blocks_batch(const float* const* src, float* const* dst, int n, int ld, int nblk, int rows_valid, int rows_pad, int cols, hipStream_t s);   // n <= 4 pairs, one launch
 // out[c] (+)= sum_r in[r][c]
 int col_sum(const float* in, int ld, int rows, int cols, float* out, int accumulate, hipStream_t s);
 // out[0] (+)= sum_{r,c} a[r][c]*b[r][c]

@@ -139,6 +139,40 @@ int compact_build_maps(const int32_t* d_lens, const int32_t* d_prefix, int B, in
     return ADN_OK;
 }
 
+// the same for up to kMaxGatherJobs matrices of ONE geometry in one launch (blockIdx.y = matrix): the S stream inputs of a call -- and
+// their lo planes -- are gathered together
+struct GatherJobTable { const u32x4* src[kMaxGatherJobs]; u32x4* dst[kMaxGatherJobs]; };
+__global__ __launch_bounds__(256) void gather_rows16_batch_kernel(const GatherJobTable t, int ld_src16, int ld_dst16, const int32_t* __restrict__ full_of_comp,
+                                                                  int Nc, int cols16) {
+    const u32x4* __restrict__ src = t.src[0]; u32x4* __restrict__ dst = t.dst[0];
+#pragma unroll
+    for (int k = 1; k < kMaxGatherJobs; ++k) if ((int)blockIdx.y == k) { src = t.src[k]; dst = t.dst[k]; }
+    const int64_t total = (int64_t)Nc * cols16;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e / cols16), q = (int)(e - (int64_t)c * cols16);
+        const int r = full_of_comp[c];
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (r >= 0) v = src[(size_t)r * ld_src16 + q];
+        dst[(size_t)c * ld_dst16 + q] = v;
+    }
+}
+int compact_gather_rows16_batch(const void* const* src, void* const* dst, int n, int ld_src, int ld_dst, const int32_t* full_of_comp, int Nc, int cols,
+                                hipStream_t s) {
+    ADN_CHECK(n >= 1 && n <= kMaxGatherJobs && cols % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0, ADN_ERR_INVALID,
+              "compact_gather_rows16_batch: 1..8 matrices, rows of whole 16-byte pieces");
+    if (n == 1) return compact_gather_rows16(src[0], ld_src, dst[0], ld_dst, full_of_comp, Nc, cols, s);
+    GatherJobTable t;
+    for (int k = 0; k < kMaxGatherJobs; ++k) {
+        const int q = k < n ? k : 0;
+        ADN_CHECK(((uintptr_t)src[q] % 16) == 0 && ((uintptr_t)dst[q] % 16) == 0, ADN_ERR_INVALID, "compact_gather_rows16_batch: 16-byte aligned matrices");
+        t.src[k] = static_cast<const u32x4*>(src[q]); t.dst[k] = static_cast<u32x4*>(dst[q]);
+    }
+    const int grid = std::max(1, grid_for_elems((int64_t)Nc * (cols / 8)) / 2);
+    hipLaunchKernelGGL(gather_rows16_batch_kernel, dim3(grid, n), dim3(256), 0, s, t, ld_src / 8, ld_dst / 8, full_of_comp, Nc, cols / 8);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
 int compact_gather_rows16(const void* src, int ld_src, void* dst, int ld_dst, const int32_t* full_of_comp, int Nc, int cols, hipStream_t s) {
     ADN_CHECK(cols % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, ADN_ERR_INVALID,
               "compact_gather_rows16: rows of whole 16-byte pieces");

@@ -569,6 +569,35 @@ __global__ __launch_bounds__(256) void add_row_blocks_kernel(const float4* __res
     }
 }
 
+// ... for up to 4 (src, dst) pairs of one geometry in one launch (blockIdx.y = pair): the aggregation LSTMs' scratch matrices
+struct RowBlocksPairs { const float4* src[4]; float4* dst[4]; };
+__global__ __launch_bounds__(256) void add_row_blocks_batch_kernel(const RowBlocksPairs t, int ld4, int nblk, int rows_valid, int rows_pad, int cols4) {
+    const float4* __restrict__ src = t.src[0]; float4* __restrict__ dst = t.dst[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) if ((int)blockIdx.y == k) { src = t.src[k]; dst = t.dst[k]; }
+    const int64_t total = (int64_t)nblk * rows_valid * cols4;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % cols4), rk = (int)(e / cols4), j = rk / rows_valid, k = rk % rows_valid;
+        const float4 a = src[(size_t)(j * rows_pad + k) * ld4 + c];
+        float4 d = dst[(size_t)(j * rows_valid + k) * ld4 + c];
+        d.x += a.x; d.y += a.y; d.z += a.z; d.w += a.w;
+        dst[(size_t)(j * rows_valid + k) * ld4 + c] = d;
+    }
+}
+int add_row_blocks_batch(const float* const* src, float* const* dst, int n, int ld, int nblk, int rows_valid, int rows_pad, int cols, hipStream_t s) {
+    ADN_CHECK(n >= 1 && n <= 4 && ld % 4 == 0, ADN_ERR_INVALID, "add_row_blocks_batch: 1..4 pairs, ld a multiple of 4");
+    if (n == 1) return add_row_blocks(src[0], dst[0], ld, nblk, rows_valid, rows_pad, cols, s);
+    const int cols4 = (cols + 3) / 4;
+    const int64_t total = (int64_t)nblk * rows_valid * cols4;
+    if (total <= 0) return ADN_OK;
+    RowBlocksPairs t;
+    for (int k = 0; k < 4; ++k) { const int q = k < n ? k : 0; t.src[k] = reinterpret_cast<const float4*>(src[q]); t.dst[k] = reinterpret_cast<float4*>(dst[q]); }
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, 2048));
+    hipLaunchKernelGGL(add_row_blocks_batch_kernel, dim3(grid, n), dim3(256), 0, s, t, ld / 4, nblk, rows_valid, rows_pad, cols4);
+    ADN_HIP_CHECK(hipGetLastError());
+    return ADN_OK;
+}
+
 int add_row_blocks(const float* src, float* dst, int ld, int nblk, int rows_valid, int rows_pad, int cols, hipStream_t s) {
     ADN_CHECK(ld % 4 == 0, ADN_ERR_INVALID, "add_row_blocks: ld must be a multiple of 4");
     const int cols4 = (cols + 3) / 4;

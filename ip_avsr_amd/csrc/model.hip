@@ -929,6 +929,21 @@ int setup_compaction(adn_model* m, int B, int T, bool dev) {
         }
     }
     m->Nc = Z + 1; m->compact = true;
+    // (the 16-bit gathers of streams of one geometry -- and their lo planes -- go out as ONE launch)
+    const void* gsrc[kMaxGatherJobs]; void* gdst[kMaxGatherJobs];
+    int gn = 0, g_ld_src = 0, g_ld = 0, g_D = 0;
+    auto flush_gathers = [&]() -> int {
+        if (!gn) return ADN_OK;
+        const int rc = compact_gather_rows16_batch(gsrc, gdst, gn, g_ld_src, g_ld, m->full_of_comp, m->Nc, g_D, m->stream);
+        gn = 0;
+        return rc;
+    };
+    auto queue_gather = [&](const void* src, int ld_src, void* dst, int ld, int D) -> int {
+        if (gn && (gn == kMaxGatherJobs || ld_src != g_ld_src || ld != g_ld || D != g_D)) ADN_TRY(flush_gathers());
+        g_ld_src = ld_src; g_ld = ld; g_D = D;
+        gsrc[gn] = src; gdst[gn] = dst; ++gn;
+        return ADN_OK;
+    };
     for (auto& st : m->st) {
         if (st.cfg.n_enc == 0) continue;
         const int D = st.cfg.input_dim, ld = ld_of(D);
@@ -939,8 +954,8 @@ int setup_compaction(adn_model* m, int B, int T, bool dev) {
         if (src_f32)
             ADN_TRY(compact_gather_rows_f32(src_f32, ld_src, m->shadow_of(st.xc), m->planes() ? m->shadow_lo_of(st.xc) : nullptr, ld, m->full_of_comp, m->Nc, D, m->stream));
         else {
-            ADN_TRY(compact_gather_rows16(src_hi, ld_src, m->shadow_of(st.xc), ld, m->full_of_comp, m->Nc, D, m->stream));
-            if (src_lo) ADN_TRY(compact_gather_rows16(src_lo, ld_src, m->shadow_lo_of(st.xc), ld, m->full_of_comp, m->Nc, D, m->stream));
+            ADN_TRY(queue_gather(src_hi, ld_src, m->shadow_of(st.xc), ld, D));
+            if (src_lo) ADN_TRY(queue_gather(src_lo, ld_src, m->shadow_lo_of(st.xc), ld, D));
         }
         if (m->planes()) {                    // the fp32 matrix behind the planes holds nothing: a reader that wants it gets hi + lo first
             bool listed = false;
@@ -948,6 +963,7 @@ int setup_compaction(adn_model* m, int B, int T, bool dev) {
             if (!listed) m->fp32_stale.push_back({st.xc, (size_t)m->Nc * ld});
         }
     }
+    ADN_TRY(flush_gathers());
     return ADN_OK;
 }
 
@@ -2320,8 +2336,12 @@ int backward_pass(adn_model* m, int B0, int T0, int theta) {
             }
             if (group_dw) {
                 ADN_TRY(gemm_grouped(dws, (int)m->agg.size(), s));
-                for (size_t k = 0; k < m->agg.size(); ++k)
-                    ADN_TRY(add_row_blocks(m->wcat_tmp + k * wcat_elems, m->G(m->agg[k].W_in), m->ldg, m->S, H, ldh, 4 * H, s));
+                for (size_t k0 = 0; k0 < m->agg.size(); k0 += 4) {        // (the LSTMs' scratch matrices into their gradients: one launch)
+                    const float* src[4]; float* dst[4];
+                    const int n = (int)std::min<size_t>(4, m->agg.size() - k0);
+                    for (int k = 0; k < n; ++k) { src[k] = m->wcat_tmp + (k0 + k) * wcat_elems; dst[k] = m->G(m->agg[k0 + k].W_in); }
+                    ADN_TRY(add_row_blocks_batch(src, dst, n, m->ldg, m->S, H, ldh, 4 * H, s));
+                }
             }
             for (size_t k = 0; k < m->agg.size(); ++k) {
                 GemmArgs d = cat_dx_args(m, k, N);
