@@ -176,6 +176,8 @@ int compact_build_maps(const int32_t* d_lens, const int32_t* d_prefix, int B, in
                        hipStream_t s);
 int compact_gather_rows16(const void* src, int ld_src, void* dst, int ld_dst, const int32_t* full_of_comp, int Nc, int cols, hipStream_t s);
 constexpr int kMaxGatherJobs = 8;
+int compact_gather_rows_f32_batch(const float* const* src, void* const* dst_hi, void* const* dst_lo, int n, int ld_src, int ld_dst,
+                                  const int32_t* full_of_comp, int Nc, int cols, hipStream_t s);     // n <= 4 float32 matrices, one launch
 int compact_gather_rows16_batch(const void* const* src, void* const* dst, int n, int ld_src, int ld_dst, const int32_t* full_of_comp, int Nc, int cols,
                                 hipStream_t s);     // n matrices of one geometry, one launch
 // ... from float32 rows, converted on the way (dst_lo: the lo plane, or nullptr for the bf16 copy alone)

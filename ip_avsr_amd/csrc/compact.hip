@@ -49,9 +49,13 @@ __global__ __launch_bounds__(256) void gather_rows16_kernel(const u32x4* __restr
 // the same gather from FLOAT32 rows, converting on the way: dst_hi[c] = bf16(src[full_of_comp[c]]) and -- planes -- dst_lo = bf16(x - hi);
 // 8 elements (two float4 in, 16 bytes per plane out) per thread
 typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
-__global__ __launch_bounds__(256) void gather_rows_f32_kernel(const float4* __restrict__ src, int ld_src4, cbf16x8* __restrict__ dst_hi,
-                                                              cbf16x8* __restrict__ dst_lo, int ld_dst8, const int32_t* __restrict__ full_of_comp,
+// (blockIdx.y = matrix: the S stream inputs of a call in one launch)
+struct GatherF32Table { const float4* src[4]; cbf16x8* hi[4]; cbf16x8* lo[4]; };
+__global__ __launch_bounds__(256) void gather_rows_f32_kernel(const GatherF32Table t, int ld_src4, int ld_dst8, const int32_t* __restrict__ full_of_comp,
                                                               int Nc, int cols8) {
+    const float4* __restrict__ src = t.src[0]; cbf16x8* __restrict__ dst_hi = t.hi[0]; cbf16x8* __restrict__ dst_lo = t.lo[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) if ((int)blockIdx.y == k) { src = t.src[k]; dst_hi = t.hi[k]; dst_lo = t.lo[k]; }
     const int64_t total = (int64_t)Nc * cols8;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int c = (int)(e / cols8), q = (int)(e - (int64_t)c * cols8);
@@ -182,14 +186,25 @@ int compact_gather_rows16(const void* src, int ld_src, void* dst, int ld_dst, co
     return ADN_OK;
 }
 
-int compact_gather_rows_f32(const float* src, int ld_src, void* dst_hi, void* dst_lo, int ld_dst, const int32_t* full_of_comp, int Nc, int cols,
-                            hipStream_t s) {
-    ADN_CHECK(cols % 8 == 0 && ld_src % 4 == 0 && ld_dst % 8 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst_hi % 16) == 0 &&
-              ((uintptr_t)dst_lo % 16) == 0 && dst_hi, ADN_ERR_INVALID, "compact_gather_rows_f32: rows of whole 16-byte pieces");
-    hipLaunchKernelGGL(gather_rows_f32_kernel, dim3(grid_for_elems((int64_t)Nc * (cols / 8))), dim3(256), 0, s, reinterpret_cast<const float4*>(src),
-                       ld_src / 4, static_cast<cbf16x8*>(dst_hi), static_cast<cbf16x8*>(dst_lo), ld_dst / 8, full_of_comp, Nc, cols / 8);
+int compact_gather_rows_f32_batch(const float* const* src, void* const* dst_hi, void* const* dst_lo, int n, int ld_src, int ld_dst,
+                                  const int32_t* full_of_comp, int Nc, int cols, hipStream_t s) {
+    ADN_CHECK(n >= 1 && n <= 4 && cols % 8 == 0 && ld_src % 4 == 0 && ld_dst % 8 == 0, ADN_ERR_INVALID,
+              "compact_gather_rows_f32: 1..4 matrices, rows of whole 16-byte pieces");
+    GatherF32Table t;
+    for (int k = 0; k < 4; ++k) {
+        const int q = k < n ? k : 0;
+        ADN_CHECK(((uintptr_t)src[q] % 16) == 0 && ((uintptr_t)dst_hi[q] % 16) == 0 && ((uintptr_t)dst_lo[q] % 16) == 0 && dst_hi[q] &&
+                  (dst_lo[q] == nullptr) == (dst_lo[0] == nullptr), ADN_ERR_INVALID, "compact_gather_rows_f32: 16-byte aligned matrices, planes for all or none");
+        t.src[k] = reinterpret_cast<const float4*>(src[q]); t.hi[k] = static_cast<cbf16x8*>(dst_hi[q]); t.lo[k] = static_cast<cbf16x8*>(dst_lo[q]);
+    }
+    const int grid = std::max(1, grid_for_elems((int64_t)Nc * (cols / 8)) / (n > 1 ? 2 : 1));
+    hipLaunchKernelGGL(gather_rows_f32_kernel, dim3(grid, n), dim3(256), 0, s, t, ld_src / 4, ld_dst / 8, full_of_comp, Nc, cols / 8);
     ADN_HIP_CHECK(hipGetLastError());
     return ADN_OK;
+}
+int compact_gather_rows_f32(const float* src, int ld_src, void* dst_hi, void* dst_lo, int ld_dst, const int32_t* full_of_comp, int Nc, int cols,
+                            hipStream_t s) {
+    return compact_gather_rows_f32_batch(&src, &dst_hi, &dst_lo, 1, ld_src, ld_dst, full_of_comp, Nc, cols, s);
 }
 
 int compact_check_padding32(const float* src, int ld_src, const int32_t* comp_of_full, int N, int cols, int Z, int* flag, int bit, hipStream_t s) {

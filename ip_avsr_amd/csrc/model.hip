@@ -944,6 +944,14 @@ int setup_compaction(adn_model* m, int B, int T, bool dev) {
         gsrc[gn] = src; gdst[gn] = dst; ++gn;
         return ADN_OK;
     };
+    const float* fsrc[4]; void* fhi[4]; void* flo[4];
+    int fn = 0, f_ld_src = 0, f_ld = 0, f_D = 0;
+    auto flush_f32 = [&]() -> int {
+        if (!fn) return ADN_OK;
+        const int rc = compact_gather_rows_f32_batch(fsrc, fhi, flo, fn, f_ld_src, f_ld, m->full_of_comp, m->Nc, f_D, m->stream);
+        fn = 0;
+        return rc;
+    };
     for (auto& st : m->st) {
         if (st.cfg.n_enc == 0) continue;
         const int D = st.cfg.input_dim, ld = ld_of(D);
@@ -951,9 +959,11 @@ int setup_compaction(adn_model* m, int B, int T, bool dev) {
         const float* src_f32 = st.x_convert_pending ? st.x : nullptr;         // float32 device rows: converted while they are gathered
         const int ld_src = st.ldx;
         st.x = st.xc; st.ldx = ld; st.x16 = nullptr; st.x16lo = nullptr; st.x_convert_pending = false;      // (the staged names go: shadow_of(xc) is the slab's)
-        if (src_f32)
-            ADN_TRY(compact_gather_rows_f32(src_f32, ld_src, m->shadow_of(st.xc), m->planes() ? m->shadow_lo_of(st.xc) : nullptr, ld, m->full_of_comp, m->Nc, D, m->stream));
-        else {
+        if (src_f32) {
+            if (fn && (fn == 4 || ld_src != f_ld_src || ld != f_ld || D != f_D)) ADN_TRY(flush_f32());
+            f_ld_src = ld_src; f_ld = ld; f_D = D;
+            fsrc[fn] = src_f32; fhi[fn] = m->shadow_of(st.xc); flo[fn] = m->planes() ? m->shadow_lo_of(st.xc) : nullptr; ++fn;
+        } else {
             ADN_TRY(queue_gather(src_hi, ld_src, m->shadow_of(st.xc), ld, D));
             if (src_lo) ADN_TRY(queue_gather(src_lo, ld_src, m->shadow_lo_of(st.xc), ld, D));
         }
@@ -964,6 +974,7 @@ int setup_compaction(adn_model* m, int B, int T, bool dev) {
         }
     }
     ADN_TRY(flush_gathers());
+    ADN_TRY(flush_f32());
     return ADN_OK;
 }
 
