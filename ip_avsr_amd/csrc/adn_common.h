@@ -118,6 +118,11 @@ struct GemmArgs {
     // ... and the result's own planes: C16 (hi) and C16lo, written by the kernel that multiplies over planes; *planes_done reports
     // whether they were (otherwise the caller splits C itself)
     void* C16lo = nullptr; int* planes_done = nullptr;
+    // rectifier bit images (gemm_common.h GemmGroup): a rectify launch may leave "C > 0" per (tile, thread) in Cbits -- *bits_done
+    // then holds the tile grid (tiles_m << 16 | tiles_n), else 0 --, and an act'(Y) launch reads Ybits instead of Y16 when its own
+    // tile grid is Ybits_tiles (and falls back to Y16 otherwise): same M x N, same kernel, same thread layout
+    void* Cbits = nullptr; int* bits_done = nullptr;
+    const void* Ybits = nullptr; int Ybits_tiles = 0;
     // B as a k-contiguous [N][K] bf16 matrix (hi / lo planes), leading dimension ldbkc: for an NN problem the transposed copy of the
     // weights the model keeps, for an NT problem B itself.  The skinny kernels (gemm_skinny.hip) read B in this form
     const void* Bkc16 = nullptr; const void* Bkc16lo = nullptr; int ldbkc = 0;

@@ -930,7 +930,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
             const unsigned rstep = 16u * (unsigned)p.ldc, ystep = 16u * (unsigned)p.ldy;       // one row block further (uniform)
             __bf16* C16m = (!SPLIT && gp.C16) ? reinterpret_cast<__bf16*>(gp.C16) : nullptr;
             __bf16* C16lm = (!SPLIT && gp.C16lo) ? reinterpret_cast<__bf16*>(gp.C16lo) : nullptr;
-            const __bf16* Ym = (!SPLIT && gp.Y16) ? reinterpret_cast<const __bf16*>(gp.Y16) : nullptr;
+            // rectifier bit images (GemmGroup::Cbits / Ybits): one uint4 per thread and tile, bit 4 q + j = column j of quad q = a TN + b
+            const uint4* Ybm = (!SPLIT && gp.Ybits) ? reinterpret_cast<const uint4*>(gp.Ybits) : nullptr;
+            uint4* Cbm = (!SPLIT && gp.Cbits) ? reinterpret_cast<uint4*>(gp.Cbits) : nullptr;
+            const size_t bits_at = ((size_t)tile_m * p.tiles_n + tile_n) * 512 + tid;
+            unsigned yb[4] = {0u, 0u, 0u, 0u}, cb[4] = {0u, 0u, 0u, 0u};
+            if (Ybm) { const uint4 t4 = Ybm[bits_at]; yb[0] = t4.x; yb[1] = t4.y; yb[2] = t4.z; yb[3] = t4.w; }
+            const __bf16* Ym = (!SPLIT && gp.Y16 && !Ybm) ? reinterpret_cast<const __bf16*>(gp.Y16) : nullptr;
             const float* biasm = (!SPLIT && gp.bias) ? gp.bias : nullptr;
             const float lower = (!SPLIT && p.act == ADN_ACT_RECTIFY) ? 0.f : -3.0e38f;
             const bool odd = hi & 1;
@@ -1000,6 +1006,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
                             vA.z = (float)yA[2] > 0.f ? vA.z : 0.f; vA.w = (float)yA[3] > 0.f ? vA.w : 0.f;
                             vB.x = (float)yB[0] > 0.f ? vB.x : 0.f; vB.y = (float)yB[1] > 0.f ? vB.y : 0.f;
                             vB.z = (float)yB[2] > 0.f ? vB.z : 0.f; vB.w = (float)yB[3] > 0.f ? vB.w : 0.f;
+                        } else if (Ybm) {
+                            const int qA = a * TN + b0, qB = qA + 1;              // (constants once the loops are unrolled: the yb / cb words stay in registers)
+                            const unsigned mA = yb[qA >> 3] >> ((qA & 7) * 4), mB = yb[qB >> 3] >> ((qB & 7) * 4);
+                            vA.x = (mA & 1u) ? vA.x : 0.f; vA.y = (mA & 2u) ? vA.y : 0.f; vA.z = (mA & 4u) ? vA.z : 0.f; vA.w = (mA & 8u) ? vA.w : 0.f;
+                            vB.x = (mB & 1u) ? vB.x : 0.f; vB.y = (mB & 2u) ? vB.y : 0.f; vB.z = (mB & 4u) ? vB.z : 0.f; vB.w = (mB & 8u) ? vB.w : 0.f;
+                        }
+                        if (Cbm) {
+                            const int qA = a * TN + b0, qB = qA + 1;
+                            const unsigned mA = (vA.x > 0.f ? 1u : 0u) | (vA.y > 0.f ? 2u : 0u) | (vA.z > 0.f ? 4u : 0u) | (vA.w > 0.f ? 8u : 0u);
+                            const unsigned mB = (vB.x > 0.f ? 1u : 0u) | (vB.y > 0.f ? 2u : 0u) | (vB.z > 0.f ? 4u : 0u) | (vB.w > 0.f ? 8u : 0u);
+                            cb[qA >> 3] |= mA << ((qA & 7) * 4); cb[qB >> 3] |= mB << ((qB & 7) * 4);
                         }
                         if (p.accumulate) {
                             if (okA) { const float4 c = *reinterpret_cast<const float4*>(Cg + oA); vA.x += c.x; vA.y += c.y; vA.z += c.z; vA.w += c.w; }
@@ -1038,6 +1055,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
                         }
                     }
                 }
+                if (Cbm && half == TN / TNH - 1) Cbm[bits_at] = make_uint4(cb[0], cb[1], cb[2], cb[3]);
                 if (!SPLIT && gp.colsum) {                     // column sums over this wave's WTM rows
 #pragma unroll
                     for (int o = 1; o < 16; o <<= 1) {

@@ -16,6 +16,10 @@ struct GemmGroup {
     const void* Y16; const float* Y;
     const float* bias;
     float* colsum;
+    // rectifier bit images (ping-pong kernel, 256 x 256 tiles, plain bf16): per tile and thread the 128 bits "C > 0" of the thread's
+    // accumulator quads, [tile_m * tiles_n + tile_n][512] uint4.  Cbits: written by a rectify epilogue; Ybits: read by an
+    // act'(Y) epilogue of the SAME tile grid instead of 32 eight-byte loads of Y16 per thread and tile
+    void* Cbits; const void* Ybits;
 };
 
 struct GemmParams {

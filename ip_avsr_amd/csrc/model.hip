@@ -164,6 +164,9 @@ struct StreamState {
     bool x_convert_pending = false;            // float32 device input: its 16-bit copies (x16 / x16lo) are not made yet -- a compacted call
                                                // converts while it gathers (one pass over the valid rows), any other call converts in full
     std::vector<float*> act;                   // encoder activations (batch-major)
+    // rectifier bit images (gemm_common.h GemmGroup::Cbits): per layer whose output is rectified and feeds another layer, what the
+    // forward epilogue left for the input-gradient epilogue of the same tile grid (bits_tiles: that grid, 0 = not written this pass)
+    std::vector<char*> relu_bits; std::vector<int> bits_tiles;
     float* feat = nullptr;                     // time-major LSTM input
     std::vector<LstmWork> lw;
     float* hsum = nullptr;                     // stream output when bidirectional (else alias of lw[0].out)
@@ -558,9 +561,12 @@ size_t carve(adn_model* m, char* base, int B, int T, bool host_inputs) {
         // multiple of 4 floats cannot feed the GEMM loader directly)
         st.xstage = take_shadowed(m, cv, N * ld_of(st.cfg.input_dim));
         st.act.resize(st.cfg.n_enc);
+        st.relu_bits.assign(st.cfg.n_enc, nullptr); st.bits_tiles.assign(st.cfg.n_enc, 0);
         for (int l = 0; l < st.cfg.n_enc; ++l) {
             st.act[l] = take_shadowed(m, cv, N * ld_of(st.cfg.enc_units[l]));
             maxw = std::max(maxw, ld_of(st.cfg.enc_units[l]));
+            if (l + 1 < st.cfg.n_enc && st.cfg.enc_act[l] == ADN_ACT_RECTIFY && m->cfg.precision == ADN_PRECISION_BF16)
+                st.relu_bits[l] = cv.take<char>((size_t)cdiv((int)N, 256) * cdiv(st.cfg.enc_units[l], 256) * 512 * 16);
         }
         if (st.cfg.batchnorm) {
             st.bn_out = cv.take<float>(N * ld_of(st.enc_out));
@@ -1877,6 +1883,10 @@ int forward_pass(adn_model* m, int B0, int T0, int theta, bool want_loss, bool w
         g.no_split = 1;                                          // forward pass: reproducible bits
         // (the encoder's OUTPUT feeds no GEMM -- the delta layer / BatchNorm read it in fp32 --: no planes of it; round 5 split it anyway)
         g.no_planes = (l + 1 == st.cfg.n_enc) ? 1 : 0;
+        // (bf16: the rectifier's mask for this layer's input gradient leaves with the activation, as one bit per element in the
+        //  kernel's own thread order -- read back by the input-gradient launch of the same tile grid instead of the bf16 activation)
+        st.bits_tiles[l] = 0;
+        if (st.relu_bits[l] && m->bf16() && g.act == ADN_ACT_RECTIFY) { g.Cbits = st.relu_bits[l]; g.bits_done = &st.bits_tiles[l]; }
         mgemm_prepare(m, g, /*lean=*/l + 1 < st.cfg.n_enc);      // the delta layer reads the last one in fp32
         // (bf16x3: a narrow next layer -- the 50-unit bottleneck -- reads the planes too since round 5 (gemm_skinny.hip); with those
         //  kernels switched off it multiplies over split images of the fp32 values, and writing them here is cheaper than writing
@@ -2594,6 +2604,7 @@ int backward_pass(adn_model* m, int B0, int T0, int theta) {
             gx.layout = GEMM_NT; gx.M = Ne; gx.N = in_w; gx.K = out_w; gx.A = w.dZ; gx.lda = w.lddz;
             gx.B = m->P(st.encW[l]); gx.ldb = ld_of(out_w); gx.C = dst; gx.ldc = st.ping_ld;
             gx.Y = st.act[l - 1]; gx.ldy = ld_of(in_w); gx.act_grad = m->act_code(st.cfg.enc_act[l - 1]);
+            if (st.relu_bits[l - 1] && st.bits_tiles[l - 1] && gx.act_grad == ADN_ACT_RECTIFY) { gx.Ybits = st.relu_bits[l - 1]; gx.Ybits_tiles = st.bits_tiles[l - 1]; }
             if (!bias_rides(st, l - 1)) {
                 gx.colsum = m->G(st.encb[l - 1]); gx.colsum_done = &w.bias_done;     // db_{l-1} rides on this GEMM
                 gx.colsum_ws = st.colsum_ws + (size_t)l * st.colsum_ws_floats; gx.colsum_ws_floats = st.colsum_ws_floats;

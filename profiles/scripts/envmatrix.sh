@@ -1,5 +1,5 @@
 # the core parity tests under every diagnostic switch that changes the kernel selection or the schedule
-for e in "X=1" "ADN_GEMM_PP=0" "ADN_GEMM_PP=7" "ADN_NO_GROUPED_BACKWARD=1" "ADN_DP_STREAM_MAJOR=1" "ADN_LSTM_DG_FP32=1" "ADN_NO_BATCHED_HOUSEKEEPING=1" "ADN_STREAMS=1" "ADN_GEMM_NO_XCD_SLICES=1" "ADN_LSTM_NO_CLUSTER=1" "ADN_NO_CAT=1" "ADN_GEMM_NO_RS_GROUPS=1" "ADN_LSTM_NO_FOLD=1" "ADN_LSTM_FOLD_MIN_B=1" "ADN_DETERMINISTIC=1" "ADN_LSTM_CUS=24" "ADN_HOST_BATCHES=1" "ADN_PREFETCH=1" "ADN_GEMM_NO_ASTAT=1" "ADN_GEMM_PP=8" "ADN_GEMM_SKINNY_ALL=1" "ADN_GEMM_NO_SKINNY=1" "ADN_FP32_RESIDENT=1" "ADN_GEMM_TAIL_SPLIT=1" "ADN_NO_COMPACT=1" "ADN_CHECK_PADDING=1" "ADN_NO_BIAS_ON_DW=1" "ADN_NO_LENGTH_BUCKETS=1"; do
+for e in "X=1" "ADN_GEMM_PP=0" "ADN_GEMM_PP=7" "ADN_NO_GROUPED_BACKWARD=1" "ADN_DP_STREAM_MAJOR=1" "ADN_LSTM_DG_FP32=1" "ADN_NO_BATCHED_HOUSEKEEPING=1" "ADN_STREAMS=1" "ADN_GEMM_NO_XCD_SLICES=1" "ADN_LSTM_NO_CLUSTER=1" "ADN_NO_CAT=1" "ADN_GEMM_NO_RS_GROUPS=1" "ADN_LSTM_NO_FOLD=1" "ADN_LSTM_FOLD_MIN_B=1" "ADN_DETERMINISTIC=1" "ADN_LSTM_CUS=24" "ADN_HOST_BATCHES=1" "ADN_PREFETCH=1" "ADN_GEMM_NO_ASTAT=1" "ADN_GEMM_PP=8" "ADN_GEMM_SKINNY_ALL=1" "ADN_GEMM_NO_SKINNY=1" "ADN_FP32_RESIDENT=1" "ADN_GEMM_TAIL_SPLIT=1" "ADN_NO_COMPACT=1" "ADN_CHECK_PADDING=1" "ADN_NO_BIAS_ON_DW=1" "ADN_NO_LENGTH_BUCKETS=1" "ADN_NO_RELU_BITS=1"; do
   echo "=== $e"
   env $e python -m pytest tests/test_gpu_parity.py tests/test_gpu_bench_geometry.py tests/test_gpu_last_head.py tests/test_gpu_adenet_v1.py tests/test_gpu_runner.py tests/test_gpu_batch.py tests/test_gpu_compact.py tests/test_gpu_buckets.py -q -x 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -2
 done

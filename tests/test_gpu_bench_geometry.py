@@ -115,6 +115,8 @@ def timed_path_runs(runs):
         # ... and beside the same compacted step with its recurrent side over B x T rows (no length buckets)
         out[prec + "_compact_bxt"] = _run(d, prec + "_compact_bxt", ref, GEOM_PRECISION=prec, GEOM_COMPACT="1", GEOM_INPUTS="bench",
                                           ADN_NO_LENGTH_BUCKETS="1")
+    # the bf16 step with the rectifier's mask read from the bf16 activations instead of the forward epilogue's bit images
+    out["bf16_compact_nobits"] = _run(d, "bf16_compact_nobits", ref, GEOM_PRECISION="bf16", GEOM_COMPACT="1", GEOM_INPUTS="bench", ADN_NO_RELU_BITS="1")
     # bench.py's own start (no training step first): zero biases, every padding row exactly on the rectifier kink
     out["fresh_compact"] = _run(d, "fresh_compact", None, GEOM_FRESH="1", GEOM_COMPACT="1", GEOM_INPUTS="bench")
     out["fresh_padded"] = _run(d, "fresh_padded", None, GEOM_FRESH="1")
@@ -275,6 +277,26 @@ def test_the_bucketed_step_bench_times_equals_the_step_over_b_x_t_rows(timed_pat
     g_tol = {"bf16": 5e-3, "bf16x3": 1e-5, "mixed": 5e-3}[prec]
     _close(c, u, "%s: length buckets vs B x T rows" % prec, p_tol=0.0, g_tol=g_tol, cos_tol=0.99999)
     assert abs(float(c["loss"]) - float(u["loss"])) <= 2e-6 * abs(float(u["loss"]))
+
+
+def test_rectifier_bit_images_give_the_masks_of_the_bf16_activations(timed_path_runs):
+    """Round 6: in the bf16 arithmetic the input-gradient epilogues of the two wide encoder layers read the rectifier's mask as the
+    bit image the forward epilogue of the same tile grid left (one 16-byte load per thread and tile instead of 32 eight-byte
+    loads of the bf16 activation; gemm_common.h GemmGroup::Cbits).  `y > 0` of the fp32 value and of its bf16 rounding are the
+    same bit (short of fp32 denormals), every product and every sum is the same: the step must equal the ADN_NO_RELU_BITS=1
+    step bit for bit in its forward pass and in every kept gradient tensor."""
+    a, b = timed_path_runs["bf16_compact"], timed_path_runs["bf16_compact_nobits"]
+    np.testing.assert_array_equal(a["probs"], b["probs"])
+    assert float(a["loss"]) == float(b["loss"])
+    if os.environ.get("ADN_GEMM_PP") == "0" or os.environ.get("ADN_DETERMINISTIC") is None and os.environ.get("ADN_NO_GROUPED_BACKWARD"):
+        return                       # (float atomics in arrival order somewhere in the step: equal to rounding only -- the tests above)
+    worst = 0.0
+    for k in a:
+        if k.startswith("g_"):
+            x, y = a[k].astype(np.float64), b[k].astype(np.float64)
+            worst = max(worst, float(np.abs(x - y).max() / max(np.abs(y).max(), 1e-30)))
+    print("bit images vs bf16 masks: worst kept-gradient difference %.2e of its scale" % worst)
+    assert worst <= 1e-5, worst       # (the split-K weight gradients of the LSTMs are summed by atomics: last bits may differ)
 
 
 def test_the_mixed_forward_pass_is_the_bf16x3_one_on_the_compacted_path(timed_path_runs):
