@@ -419,8 +419,11 @@ static int gemm_pp_try_impl(const GemmArgs* gs, int n, const GemmArgs& g, int ks
         if (gs[k].colsum_done) *gs[k].colsum_done = fused_colsum ? 1 : 0;
         // rectifier bit images: this kernel, whole 256 x 256 tile grid in one launch, one product per element
         static const bool no_bits = getenv("ADN_NO_RELU_BITS") != nullptr;
-        const bool bits_ok = !no_bits && !fused && !kseg && cd.mode == 4 && splits == 1 && band_rt == 0 && g.layout == GEMM_NN;
-        const int tiles_key = (p.tiles_m << 16) | p.tiles_n;
+        // (the key names kernel AND tile grid: the two kernels number their accumulator quads differently, and the mixed arithmetic
+        //  runs its forward pass on one and its back-propagation on the other -- there the mask stays the bf16 activation's)
+        const bool bits_ok = !no_bits && (cd.mode == 4 || (cd.mode == 8 && kseg)) && cd.bm == 256 && cd.bn == 256 && splits == 1 && band_rt == 0 &&
+                             g.layout == GEMM_NN;
+        const int tiles_key = (cd.mode << 26) | (p.tiles_m << 13) | p.tiles_n;
         q.Cbits = (bits_ok && g.act == ADN_ACT_RECTIFY && !g.accumulate && ((uintptr_t)gs[k].Cbits % 16) == 0) ? gs[k].Cbits : nullptr;
         if (gs[k].bits_done) *gs[k].bits_done = q.Cbits ? tiles_key : 0;
         q.Ybits = (bits_ok && q.Y16 && gs[k].Ybits && gs[k].Ybits_tiles == tiles_key && ((uintptr_t)gs[k].Ybits % 16) == 0) ? gs[k].Ybits : nullptr;

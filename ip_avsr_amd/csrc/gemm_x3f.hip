@@ -318,7 +318,16 @@ __global__ __launch_bounds__(512) void gemm_x3f_kernel(const GemmParams p) {
                 const unsigned rstep = 32u * (unsigned)p.ldc, ystep = 32u * (unsigned)p.ldy;
                 __bf16* C16m = (!SPLIT && gp.C16) ? reinterpret_cast<__bf16*>(gp.C16) : nullptr;
                 __bf16* C16lm = (!SPLIT && gp.C16lo) ? reinterpret_cast<__bf16*>(gp.C16lo) : nullptr;
-                const __bf16* Ym = (!SPLIT && gp.Y16) ? reinterpret_cast<const __bf16*>(gp.Y16) : nullptr;
+                // rectifier bit images (gemm_common.h GemmGroup::Cbits / Ybits): one uint4 per thread and tile, bit 4 q + e = column e of
+                // quad q = (a TN + b) 4 + j -- this kernel's own order: a launch only reads what a launch of this kernel wrote
+                // (over planes only: in the one-plane instantiations -- ADN_GEMM_PP=8 -- the four words cost a spill, and scratch traffic
+                //  sits in the vmcnt queue this kernel counts by hand; the host offers no images there)
+                const uint4* Ybm = (PLANES && !SPLIT && gp.Ybits) ? reinterpret_cast<const uint4*>(gp.Ybits) : nullptr;
+                uint4* Cbm = (PLANES && !SPLIT && gp.Cbits) ? reinterpret_cast<uint4*>(gp.Cbits) : nullptr;
+                const size_t bits_at = ((size_t)tile_m * p.tiles_n + tile_n) * 512 + tid;
+                unsigned yb[4] = {0u, 0u, 0u, 0u}, cb[4] = {0u, 0u, 0u, 0u};
+                if (Ybm) { const uint4 t4 = Ybm[bits_at]; yb[0] = t4.x; yb[1] = t4.y; yb[2] = t4.z; yb[3] = t4.w; }
+                const __bf16* Ym = (!SPLIT && gp.Y16 && !Ybm) ? reinterpret_cast<const __bf16*>(gp.Y16) : nullptr;
                 const float* biasm = (!SPLIT && gp.bias) ? gp.bias : nullptr;
                 const float lower = (!SPLIT && p.act == ADN_ACT_RECTIFY) ? 0.f : -3.0e38f;
                 const bool upper = h != 0;
@@ -386,6 +395,17 @@ __global__ __launch_bounds__(512) void gemm_x3f_kernel(const GemmParams p) {
                                         const float4 yA = unpack4(pre[(a * 2 + bb) * 4 + jA]), yB = unpack4(pre[(a * 2 + bb) * 4 + jB]);
                                         vA.x = yA.x > 0.f ? vA.x : 0.f; vA.y = yA.y > 0.f ? vA.y : 0.f; vA.z = yA.z > 0.f ? vA.z : 0.f; vA.w = yA.w > 0.f ? vA.w : 0.f;
                                         vB.x = yB.x > 0.f ? vB.x : 0.f; vB.y = yB.y > 0.f ? vB.y : 0.f; vB.z = yB.z > 0.f ? vB.z : 0.f; vB.w = yB.w > 0.f ? vB.w : 0.f;
+                                    } else if (Ybm) {
+                                        const int qA = (a * TN + b) * 4 + jA, qB = qA + 1;      // (constants once the loops are unrolled)
+                                        const unsigned mA = yb[qA >> 3] >> ((qA & 7) * 4), mB = yb[qB >> 3] >> ((qB & 7) * 4);
+                                        vA.x = (mA & 1u) ? vA.x : 0.f; vA.y = (mA & 2u) ? vA.y : 0.f; vA.z = (mA & 4u) ? vA.z : 0.f; vA.w = (mA & 8u) ? vA.w : 0.f;
+                                        vB.x = (mB & 1u) ? vB.x : 0.f; vB.y = (mB & 2u) ? vB.y : 0.f; vB.z = (mB & 4u) ? vB.z : 0.f; vB.w = (mB & 8u) ? vB.w : 0.f;
+                                    }
+                                    if (Cbm) {
+                                        const int qA = (a * TN + b) * 4 + jA, qB = qA + 1;
+                                        const unsigned mA = (vA.x > 0.f ? 1u : 0u) | (vA.y > 0.f ? 2u : 0u) | (vA.z > 0.f ? 4u : 0u) | (vA.w > 0.f ? 8u : 0u);
+                                        const unsigned mB = (vB.x > 0.f ? 1u : 0u) | (vB.y > 0.f ? 2u : 0u) | (vB.z > 0.f ? 4u : 0u) | (vB.w > 0.f ? 8u : 0u);
+                                        cb[qA >> 3] |= mA << ((qA & 7) * 4); cb[qB >> 3] |= mB << ((qB & 7) * 4);
                                     }
                                     if (p.accumulate) {
                                         if (okA) { const float4 c = *reinterpret_cast<const float4*>(Cg + oA); vA.x += c.x; vA.y += c.y; vA.z += c.z; vA.w += c.w; }
@@ -422,6 +442,7 @@ __global__ __launch_bounds__(512) void gemm_x3f_kernel(const GemmParams p) {
                                 }
                             }
                         }
+                        if (Cbm && half == 1 && bb == 1) Cbm[bits_at] = make_uint4(cb[0], cb[1], cb[2], cb[3]);
                         if (!SPLIT && gp.colsum) {
                             // column sums over this wave's 64 rows: a reduce-scatter butterfly over the 32 row lanes -- every step
                             // halves what a lane carries; lane bits 4..1 end up selecting (j, e), bit 0 pairs add

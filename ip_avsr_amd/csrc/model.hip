@@ -565,7 +565,7 @@ size_t carve(adn_model* m, char* base, int B, int T, bool host_inputs) {
         for (int l = 0; l < st.cfg.n_enc; ++l) {
             st.act[l] = take_shadowed(m, cv, N * ld_of(st.cfg.enc_units[l]));
             maxw = std::max(maxw, ld_of(st.cfg.enc_units[l]));
-            if (l + 1 < st.cfg.n_enc && st.cfg.enc_act[l] == ADN_ACT_RECTIFY && m->cfg.precision == ADN_PRECISION_BF16)
+            if (l + 1 < st.cfg.n_enc && st.cfg.enc_act[l] == ADN_ACT_RECTIFY && m->cfg.precision != ADN_PRECISION_F32)
                 st.relu_bits[l] = cv.take<char>((size_t)cdiv((int)N, 256) * cdiv(st.cfg.enc_units[l], 256) * 512 * 16);
         }
         if (st.cfg.batchnorm) {
@@ -1886,7 +1886,7 @@ int forward_pass(adn_model* m, int B0, int T0, int theta, bool want_loss, bool w
         // (bf16: the rectifier's mask for this layer's input gradient leaves with the activation, as one bit per element in the
         //  kernel's own thread order -- read back by the input-gradient launch of the same tile grid instead of the bf16 activation)
         st.bits_tiles[l] = 0;
-        if (st.relu_bits[l] && m->bf16() && g.act == ADN_ACT_RECTIFY) { g.Cbits = st.relu_bits[l]; g.bits_done = &st.bits_tiles[l]; }
+        if (st.relu_bits[l] && (m->bf16() || m->planes()) && g.act == ADN_ACT_RECTIFY) { g.Cbits = st.relu_bits[l]; g.bits_done = &st.bits_tiles[l]; }
         mgemm_prepare(m, g, /*lean=*/l + 1 < st.cfg.n_enc);      // the delta layer reads the last one in fp32
         // (bf16x3: a narrow next layer -- the 50-unit bottleneck -- reads the planes too since round 5 (gemm_skinny.hip); with those
         //  kernels switched off it multiplies over split images of the fp32 values, and writing them here is cheaper than writing
