@@ -272,7 +272,8 @@ int adn_get_deterministic(void);
  * encoders run over the sum(len) valid frames plus ONE zero-input row that stands for every padding frame -- forward its output
  * enc(0) is what the delta layer sees at the padding frames, backward it carries the sum of their gradients, which is all the
  * parameter gradients ever see of them (the encoder is row-wise).  Same results as the padded computation up to summation order;
- * everything from the delta layer up stays padded.  Applies in the 16-bit arithmetics (bf16 / bf16x3 / mixed) whose encoders end in
+ * behind the delta layer a train step runs over length buckets (adn_set_length_buckets, below), every other call over B T rows.
+ * Applies in the 16-bit arithmetics (bf16 / bf16x3 / mixed) whose encoders end in
  * a linear layer without BatchNorm, when the batch has at least 8192 rows (B T; smaller ones are latency-bound and gain nothing;
  * ADN_COMPACT_MIN_ROWS overrides) of which at least 10 % are padding; otherwise the call runs padded as before.  ADN_NO_COMPACT=1
  * in the environment switches it off.
